@@ -1,0 +1,278 @@
+"""CPU oracle for the TCAR training / evaluation step.  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (PyTorch-CPU, fp64 by default, autograd for the
+backward pass) of the TensorFlow-1.x graph the reference builds in
+``model_combine.py:52-163`` with the ops of ``modules.py:13-152`` and
+``util.py:59-100``.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it; the product path
+(``session-based-news-recommendation_amd``) never does.
+
+PARITY STATUS: **parity unpinned** for the graph arithmetic.  The reference
+model cannot run (TensorFlow 1.x absent; ``model_combine.py:113,115`` is a
+SyntaxError as shipped) and the reference has no tests / golden vectors for it.
+What IS pinned by the real reference: the sampler and ``cau_metrics``
+(see ``oracle/sampler_oracle.py``, ``oracle/metrics_oracle.py`` and
+``tests/golden/make_reference_fixtures.py``).
+
+TensorFlow-1.x semantics restated here (each is a documented choice):
+  S1  ``tf.nn.embedding_lookup(table, ids, max_norm=1)`` (modules.py:36,
+      model_combine.py:68,87-91,95-96) = gather, then ``tf.clip_by_norm`` of
+      every gathered row to L2 norm <= 1; the gradient flows THROUGH the clip;
+      an all-zero row is returned unchanged with identity gradient.
+  S2  ``interval=`` keyword conflict (model_combine.py:113,115) resolved as
+      ``interval=seq_active_time`` (the full model).
+  S3  ``normalizer`` (util.py:92-100): exp(x) / (sum exp(x) + 1e-9), NO max
+      subtraction.
+  S4  loss has shape [B,1]; ``compute_gradients`` differentiates the SUM over
+      sessions (model_combine.py:147,156).
+  S5  gradients of tables are IndexedSlices; ``tf.clip_by_norm`` of an
+      IndexedSlices uses the norm of the *concatenated slice values*, not of the
+      summed dense gradient (model_combine.py:157-160).  The dense
+      ``item_emb[1:]`` gradient (scoring + densified negative-gather part)
+      is one slice block, every gathered row is another.
+  S6  TF-1 Adam (model_combine.py:155,163): lr_t = lr*sqrt(1-b2^t)/(1-b1^t),
+      m,v dense (sparse apply is non-lazy and deduplicates => same as dense),
+      theta -= lr_t * m / (sqrt(v) + 1e-8).
+  S7  dwell bucket id 11 (sampler.py:18-21 returns 11 for >=1024 s, table has
+      11 rows model_combine.py:106): zero row, zero gradient (TF-GPU gather).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+# creation order of tf.trainable_variables() in model_combine.py:52-128
+TABLES = ["item_emb", "dec_pos", "month_embedding", "day_embedding", "week_embedding",
+          "hour_embedding", "minute_embedding", "duration_embedding"]
+TIME_TABLES = ["month_embedding", "day_embedding", "week_embedding", "hour_embedding", "minute_embedding"]
+TIME_VOCAB = [13, 32, 8, 25, 61]  # model_combine.py:73-81
+POS_VOCAB = 40                     # model_combine.py:57
+DUR_VOCAB = 11                     # model_combine.py:106
+
+
+def var_shapes(n_items: int, H: int, Ht: int) -> "OrderedDict[str, tuple]":
+    """Shapes of the 23 trainable variables, in TF creation order."""
+    s = OrderedDict()
+    s["item_emb"] = (n_items + 1, H)                                   # model_combine.py:54
+    s["dec_pos"] = (POS_VOCAB, H)                                      # :57
+    for name, v in zip(TIME_TABLES, TIME_VOCAB):                       # :73-81
+        s[name] = (v, Ht)
+    s["duration_embedding"] = (DUR_VOCAB, Ht)                          # :106
+    s["multi_attention/input_linear_trans/w_3d"] = (2 * H, H)          # modules.py:126
+    s["multi_attention/cont_linear_trans/w_3d"] = (H, H)               # :127
+    s["multi_attention/inter_linear_trans/w_3d"] = (Ht, H)             # :130
+    s["multi_attention/res_linear_trans/w_3d"] = (H, 1)                # :133
+    s["multi_attention/query_trans1/w1"] = (2 * Ht, H)                 # :138 (128 hard-coded = 2*Ht)
+    s["multi_attention/query_trans1/b1"] = (H,)
+    s["multi_attention/query_trans2/w1"] = (H, 2 * H)                  # :139
+    s["multi_attention/query_trans2/b1"] = (2 * H,)
+    s["attout_item_cont_trans/w1"] = (2 * H, 2 * H)                    # model_combine.py:119
+    s["attout_item_cont_trans/b1"] = (2 * H,)
+    s["cont_attention/input_linear_trans/w_3d"] = (5 * Ht, H)          # modules.py:94
+    s["cont_attention/cont_linear_trans/w_3d"] = (H, H)                # :95
+    s["cont_attention/res_linear_trans/w_3d"] = (H, 1)                 # :98
+    s["attout_pt_trans/w1"] = (5 * Ht, 5 * Ht)                         # model_combine.py:127
+    s["attout_pt_trans/b1"] = (5 * Ht,)
+    return s
+
+
+def init_params_numpy(n_items: int, H: int, Ht: int, emb_stddev: float, stddev: float,
+                      rng: np.random.RandomState) -> "OrderedDict[str, np.ndarray]":
+    """Reference-style initial values (fp32).
+
+    Tables follow modules.py:32-34 exactly (np.random.normal, row 0 zeroed when
+    zero_pad) in creation order; dec_pos uses the default stddev 0.02 and no
+    zero pad (model_combine.py:57-64), duration has no zero pad (:106).  Dense
+    weights are tf.random_normal(stddev) in the reference (modules.py:50-51,65);
+    TF's RNG stream cannot be reproduced, so they are drawn from `rng` too.
+    """
+    p = OrderedDict()
+    for name, shp in var_shapes(n_items, H, Ht).items():
+        if name == "dec_pos":
+            t = rng.normal(0, 0.02, shp)
+        elif name in TABLES:
+            t = rng.normal(0, emb_stddev, shp)
+            if name != "duration_embedding":
+                t[0] = 0.0
+        else:
+            t = rng.normal(0, stddev, shp)
+        p[name] = t.astype(np.float32)
+    return p
+
+
+def clip_rows(x: torch.Tensor) -> torch.Tensor:
+    """tf.clip_by_norm(x, 1.0, axes=[-1]) as used by embedding_lookup(max_norm=1) (S1)."""
+    ss = (x * x).sum(-1, keepdim=True)
+    pos = ss > 0
+    norm = torch.where(pos, torch.sqrt(torch.where(pos, ss, torch.ones_like(ss))), ss)
+    return x / torch.clamp(norm, min=1.0)
+
+
+def expnorm(x: torch.Tensor, dim: int = 1) -> torch.Tensor:
+    """util.py:92-100 normalizer (S3)."""
+    e = torch.exp(x)
+    return e / (e.sum(dim, keepdim=True) + 1e-9)
+
+
+class TcarOracle:
+    """CPU restatement of Seq2SeqAttNN's graph + optimizer (model_combine.py:16-163)."""
+
+    def __init__(self, params: Dict[str, np.ndarray], content_emb: np.ndarray, mwdhm: np.ndarray,
+                 lr: float = 1e-3, max_grad: Optional[float] = 150.0, dtype=torch.float64,
+                 neg_weight: float = 0.01, use_interval: bool = True):
+        self.dtype = dtype
+        self.p = OrderedDict((k, torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True))
+                             for k, v in params.items())
+        self.content = torch.tensor(np.asarray(content_emb), dtype=dtype)          # frozen, model_combine.py:67
+        self.mwdhm = torch.as_tensor(np.asarray(mwdhm), dtype=torch.long)          # [N,5], :37
+        self.N = self.content.shape[0] - 1
+        self.H = self.content.shape[1]
+        self.Ht = self.p["month_embedding"].shape[1]
+        self.lr, self.max_grad, self.neg_weight = lr, max_grad, neg_weight
+        self.use_interval = use_interval
+        self.b1, self.b2, self.eps = 0.9, 0.999, 1e-8                               # tf.train.AdamOptimizer defaults
+        self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in self.p.items())
+        self.v = OrderedDict((k, torch.zeros_like(v)) for k, v in self.p.items())
+        # TF keeps beta powers as fp32 variables initialised to beta and multiplied once per step
+        self.b1_pow = np.float32(self.b1)
+        self.b2_pow = np.float32(self.b2)
+        self.step = 0
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, batch: Dict[str, np.ndarray], with_neg: bool = True, keep: bool = False):
+        """model_combine.py:52-147.  batch keys: seq[B,T] (1-based), label[B] (0-based),
+        pm,pd,pw,ph,pmi [B,T], cw,ch [B], gap[B,T], neg[B,K] (0-based)."""
+        P, dt = self.p, self.dtype
+        L = lambda k: torch.as_tensor(np.asarray(batch[k]), dtype=torch.long)
+        seq = L("seq")
+        B, T = seq.shape
+        if T > POS_VOCAB:
+            raise IndexError("session longer than the 40-row position table (model_combine.py:57)")
+        vals = {}  # IndexedSlices value blocks (S5), filled only when keep=True
+
+        def gather(name, table, ids):
+            rows = table[ids]
+            if keep:
+                rows.retain_grad()
+                vals.setdefault(name, []).append(rows)
+            return clip_rows(rows)
+
+        # INPUT-CONTEXT  (model_combine.py:53-69)
+        seq_item = gather("item_emb", P["item_emb"], seq)
+        pos_ids = torch.arange(T).unsqueeze(0).expand(B, T)
+        seq_item = seq_item + gather("dec_pos", P["dec_pos"], pos_ids)
+        seq_content = clip_rows(self.content[seq])
+        # TEMPORAL-INFO (:72-97)
+        tkeys = ["pm", "pd", "pw", "ph", "pmi"]
+        seq_pt = torch.cat([gather(n, P[n], L(k)) for n, k in zip(TIME_TABLES, tkeys)], -1)
+        cand_pt = torch.cat([gather(n, P[n], self.mwdhm[:, i]) for i, n in enumerate(TIME_TABLES)], -1)
+        click_t = torch.cat([gather("week_embedding", P["week_embedding"], L("cw")),
+                             gather("hour_embedding", P["hour_embedding"], L("ch"))], -1)
+        # duration (:106-107); id >= 11 -> zero row, zero grad (S7)
+        gap = L("gap")
+        dur_ext = torch.cat([P["duration_embedding"], torch.zeros(1, self.Ht, dtype=dt)], 0)
+        seq_act = gather("duration_embedding", dur_ext, torch.clamp(gap, max=DUR_VOCAB))
+
+        seq_ic = torch.cat([seq_item, seq_content], -1)                                # :111
+        # multi_attention_layer / count_alpha_m  (modules.py:103-152)
+        pre1 = seq_ic @ P["multi_attention/input_linear_trans/w_3d"] \
+            + seq_content @ P["multi_attention/cont_linear_trans/w_3d"]
+        if self.use_interval:
+            pre1 = pre1 + seq_act @ P["multi_attention/inter_linear_trans/w_3d"]
+        e1 = (torch.sigmoid(pre1) @ P["multi_attention/res_linear_trans/w_3d"]).reshape(B, T)
+        alpha = expnorm(e1)
+        q = torch.relu(click_t @ P["multi_attention/query_trans1/w1"] + P["multi_attention/query_trans1/b1"])
+        q = torch.tanh(q @ P["multi_attention/query_trans2/w1"] + P["multi_attention/query_trans2/b1"])
+        e2 = torch.bmm(seq_ic, q.unsqueeze(-1))                                        # modules.py:140
+        alpha2 = expnorm(e2, 1).reshape(B, T)
+        alpha = alpha + alpha2                                                         # :142
+        pooled_ic = torch.bmm(alpha.unsqueeze(1), seq_ic).reshape(B, -1)               # :116-117
+        attout_ic = torch.tanh(pooled_ic @ P["attout_item_cont_trans/w1"] + P["attout_item_cont_trans/b1"])
+        # single_attention_layer / count_alpha_s (modules.py:72-101)
+        pre2 = seq_pt @ P["cont_attention/input_linear_trans/w_3d"] \
+            + seq_content @ P["cont_attention/cont_linear_trans/w_3d"]
+        e3 = (torch.sigmoid(pre2) @ P["cont_attention/res_linear_trans/w_3d"]).reshape(B, T)
+        alpha_t = expnorm(e3)
+        pooled_t = torch.bmm(alpha_t.unsqueeze(1), seq_pt).reshape(B, -1)
+        attout_t = torch.tanh(pooled_t @ P["attout_pt_trans/w1"] + P["attout_pt_trans/b1"])
+        # scoring (model_combine.py:132-147)
+        attout = torch.cat([attout_ic, attout_t], -1)
+        item_slice = P["item_emb"][1:]
+        if keep:
+            item_slice.retain_grad()
+            vals["item_emb"].append(item_slice)       # the densified [1:] gradient block (S5)
+        items_emb_cont = torch.cat([item_slice, self.content[1:]], -1)                 # :135
+        items_emb = torch.cat([items_emb_cont, cand_pt], -1)                           # :136
+        logits = attout @ items_emb.t()                                                # :138
+        label = L("label")
+        lse = torch.logsumexp(logits, 1)
+        ce = lse - logits.gather(1, label.unsqueeze(1)).squeeze(1)                     # :145
+        out = {"logits": logits, "ce": ce, "attout": attout, "pooled_ic": pooled_ic, "pooled_t": pooled_t,
+               "alpha1": alpha - alpha2, "alpha2": alpha2, "alpha_t": alpha_t, "q": q,
+               "seq_ic": seq_ic, "seq_pt": seq_pt, "seq_act": seq_act, "click_t": click_t,
+               "pre1": pre1, "pre2": pre2}
+        neg = batch.get("neg", None)
+        if with_neg and neg is not None and np.asarray(neg).size > 0:
+            negi = torch.as_tensor(np.asarray(neg), dtype=torch.long)
+            neg_rows = items_emb_cont[negi]                                            # [B,K,2H]  :142
+            neg_logits = torch.bmm(neg_rows, attout_ic.unsqueeze(-1)).sum(1).reshape(B)
+            neg_fb = -torch.log(1 - torch.sigmoid(neg_logits) + 1e-24)                 # :143
+            out["neg_logits"], out["neg_fb"] = neg_logits, neg_fb
+            out["loss"] = ce + self.neg_weight * neg_fb                                # :147
+        else:
+            out["loss"] = ce
+        out["_vals"] = vals
+        return out
+
+    # ----------------------------------------------------------------- backward
+    def loss_and_grads(self, batch):
+        """Returns (loss[B], grads: summed dense gradient per variable, sqn: squared norm
+        that tf.clip_by_norm sees per variable (S5))."""
+        for v in self.p.values():
+            v.grad = None
+        out = self.forward(batch, with_neg=True, keep=True)
+        out["loss"].sum().backward()                                                   # S4
+        grads, sqn = OrderedDict(), OrderedDict()
+        for k, v in self.p.items():
+            g = v.grad if v.grad is not None else torch.zeros_like(v)
+            grads[k] = g.detach().clone()
+            if k in TABLES:
+                sqn[k] = float(sum((r.grad * r.grad).sum() for r in out["_vals"][k] if r.grad is not None))
+            else:
+                sqn[k] = float((g * g).sum())
+        return out, grads, sqn
+
+    def apply_adam(self, grads, sqn):
+        """model_combine.py:155-163: per-variable clip_by_norm(max_grad) then TF-1 Adam (S6)."""
+        self.step += 1
+        lr_t = np.float32(self.lr) * np.sqrt(np.float32(1) - self.b2_pow) / (np.float32(1) - self.b1_pow)
+        lr_t = float(lr_t)
+        with torch.no_grad():
+            for k, w in self.p.items():
+                g = grads[k]
+                if self.max_grad is not None:
+                    nrm = math.sqrt(sqn[k])
+                    g = g * (self.max_grad / max(nrm, self.max_grad))
+                self.m[k].mul_(self.b1).add_(g, alpha=1 - self.b1)
+                self.v[k].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+                w.sub_(lr_t * self.m[k] / (self.v[k].sqrt() + self.eps))
+        self.b1_pow = np.float32(self.b1_pow * np.float32(self.b1))
+        self.b2_pow = np.float32(self.b2_pow * np.float32(self.b2))
+
+    def train_step(self, batch):
+        out, grads, sqn = self.loss_and_grads(batch)
+        self.apply_adam(grads, sqn)
+        return out["loss"].detach()
+
+    def eval_batch(self, batch):
+        """model_combine.py:283-286: returns (softmax_input [B,N], cross_loss [B])."""
+        with torch.no_grad():
+            out = self.forward(batch, with_neg=False)
+        return out["logits"], out["ce"]
+
+    def export(self) -> "OrderedDict[str, np.ndarray]":
+        return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.p.items())

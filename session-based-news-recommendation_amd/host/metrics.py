@@ -1,0 +1,56 @@
+"""Ranking / diversity metrics of the evaluation loop (util.py:8-18, model_combine.py:174-194,301-313).
+
+The GPU path returns, per session, the label's rank and the top-k indices (kernel `tcar_rank_topk`), so the
+host never sees the [B,N] score matrix; the functions here turn ranks / top-k lists into the numbers the
+reference prints.  `cau_metrics` keeps the reference signature for callers that do hold score rows.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def metrics_from_ranks(ranks: np.ndarray, cutoff: int = 20):
+    """ranks are 1-based.  Returns (hit, mrr, ndcg) arrays, element-wise as util.py:15-17."""
+    ranks = np.asarray(ranks, dtype=np.int64)
+    hit = ranks <= cutoff
+    mrr = np.where(hit, 1.0 / ranks, 0.0)
+    ndcg = np.where(hit, 1.0 / np.log2(ranks + 1.0), 0.0)
+    return hit, mrr, ndcg
+
+
+def cau_metrics(preds, labels, cutoff=20):
+    """Same contract as util.py:8-18: rank = 1 + #{j: preds[j] > preds[label]} (strict)."""
+    preds = np.asarray(preds)
+    labels = np.asarray(labels, dtype=np.int64)
+    if preds.ndim == 1:
+        preds = preds[None, :]
+    lab = preds[np.arange(len(labels)), labels]
+    ranks = (preds > lab[:, None]).sum(1) + 1
+    hit, mrr, ndcg = metrics_from_ranks(ranks, cutoff)
+    return hit.tolist(), mrr.tolist(), ndcg.tolist()
+
+
+def ild_batch(topk: np.ndarray, cat_of_item: np.ndarray) -> np.ndarray:
+    """model_combine.py:174-182 for a [B,k] array of 0-based item ids: share of ordered pairs (i != j) whose
+    categories differ."""
+    c = cat_of_item[topk]                                     # [B,k]
+    k = c.shape[1]
+    diff = (c[:, :, None] != c[:, None, :]).sum((1, 2))       # the diagonal never differs
+    return diff / float(k * (k - 1))
+
+
+def unexp_batch(seq: np.ndarray, topk: np.ndarray, cat_of_item: np.ndarray) -> np.ndarray:
+    """model_combine.py:184-194: share of (recommended, input) pairs with different category; `seq` holds
+    1-based ids."""
+    cr = cat_of_item[topk]                                    # [B,k]
+    ci = cat_of_item[np.asarray(seq) - 1]                     # [B,T]
+    diff = (cr[:, :, None] != ci[:, None, :]).sum((1, 2))
+    return diff / float(cr.shape[1] * ci.shape[1])
+
+
+def category_table(reverse_item: dict, category_id, n_items: int) -> np.ndarray:
+    """int table cat[item0] = category_id[reverse_item[item0]] (the double lookup of model_combine.py:180)."""
+    out = np.empty(n_items, dtype=np.int64)
+    for i in range(n_items):
+        out[i] = category_id[reverse_item[i]]
+    return out

@@ -1,0 +1,143 @@
+"""Host-side batch producer with the reference's ``Sampler`` interface (sampler.py:23-116).
+
+Same constructor arguments, ``has_next()`` / ``next_batch()`` and the same use of the global ``random`` /
+``numpy.random`` streams (so a seeded run forms the same batches as the reference), but the per-click Python
+loop of ``sampler.py:67-111`` is replaced by vectorised gathers over a `SessionStore` that is built once per
+dataset and cached.  ``next_batch_arrays()`` is what the HIP training loop consumes (int32 arrays, ready for
+one H2D copy); ``next_batch()`` re-nests them into the reference's 6-tuple of lists.
+
+The two call-site toggles the reference leaves as comments are explicit modes here:
+  gap_mode: "active_t" (sampler.py:87, shipped) | "click_delta" (sampler.py:91-94, Globo)
+  neg_mode: "uniform" (sampler.py:98-99, shipped) | "neighbor" (:97,:133-140) | "impression" (:96,:118-131)
+"""
+from __future__ import annotations
+
+import random
+from typing import Dict, Optional
+
+import numpy as np
+
+from .data import SessionStore
+
+_STORE_CACHE: Dict[int, SessionStore] = {}
+
+
+def store_for(session_dict, session_time_dict) -> SessionStore:
+    """Tensorise once per dataset object (the trainer builds a new Sampler every epoch, model_combine.py:204)."""
+    key = id(session_dict)
+    st = _STORE_CACHE.get(key)
+    if st is None or st.n != len(session_dict):
+        st = SessionStore.from_dicts(session_dict, session_time_dict)
+        _STORE_CACHE[key] = st
+    return st
+
+
+class Sampler(object):
+    def __init__(self, len_dict, session_dict, session_time_dict=None, neighbor_dict=None, item_dict=None,
+                 neg_num=None, batch_size=1024, gap_mode="active_t", neg_mode="uniform", store=None,
+                 verbose=True):
+        if verbose:
+            print('Sampler init begin...')
+        self.session_num = len(session_dict) if session_dict is not None else (store.n if store else 0)
+        self.batch_size = batch_size
+        self.batch_num = 0
+        self.batch_i = 0
+        self.neighbor_dict = neighbor_dict
+        self.item_dict = item_dict
+        if item_dict is not None:
+            self.item_num = len(item_dict)
+        self.neg_num = neg_num
+        self.len_dict = len_dict
+        self.session_dict = session_dict
+        self.session_time_dict = session_time_dict
+        self.gap_mode, self.neg_mode = gap_mode, neg_mode
+        if neg_mode not in ("uniform", "neighbor", "impression"):
+            raise ValueError("neg_mode must be uniform | neighbor | impression")
+        if gap_mode not in ("active_t", "click_delta"):
+            raise ValueError("gap_mode must be active_t | click_delta")
+        self.store = store if store is not None else store_for(session_dict, session_time_dict)
+        self.has_time = bool(session_time_dict) or store is not None
+        self.session_id_batches = []
+        for _slen, ids in len_dict.items():
+            random.shuffle(ids)                      # in place, like the reference (persists across epochs)
+            n = len(ids)
+            start = 0
+            while n - start > batch_size:            # strict: a bucket of exactly batch_size is one batch
+                self.session_id_batches.append(ids[start:start + batch_size])
+                start += batch_size
+            if n - start:
+                self.session_id_batches.append(ids[start:])
+        random.shuffle(self.session_id_batches)
+        self.batch_num = len(self.session_id_batches)
+        if verbose:
+            print('Sampler init finished, batch size : {}, # batch: {}.'.format(self.batch_size, self.batch_num))
+
+    def has_next(self):
+        return self.batch_i < self.batch_num
+
+    # ------------------------------------------------------------------ negatives
+    def _negatives(self, keys, labels0) -> Optional[np.ndarray]:
+        if not self.neighbor_dict or not self.has_time:        # sampler.py:72,95: only inside the time branch
+            return None
+        K, B = self.neg_num, len(keys)
+        if self.neg_mode == "uniform":
+            # K scalar draws per session in the reference == one vector draw from the same legacy stream
+            return np.random.randint(0, self.item_num, size=(B, K)).astype(np.int32)
+        out = np.empty((B, K), dtype=np.int32)
+        for b, key in enumerate(keys):
+            if self.neg_mode == "neighbor":
+                out[b] = self.neg_neighbor(int(labels0[b]))
+            else:
+                out[b] = self.neg_neighbor_from_impre(int(str(key).split('_')[0]))
+        return out
+
+    def neg_neighbor_from_impre(self, sessionid):
+        cand = self.neighbor_dict[sessionid]
+        neg, tries = [], 0
+        while len(neg) < self.neg_num:
+            tries += 1
+            pick = random.choice(cand)
+            if pick in self.item_dict:
+                neg.append(self.item_dict[pick] - 1)
+            if tries > 20:
+                break
+        if len(neg) < self.neg_num:
+            neg.extend(np.random.randint(0, self.item_num) for _ in range(self.neg_num - len(neg)))
+        return neg
+
+    def neg_neighbor(self, itemid):
+        cand = self.neighbor_dict[itemid]
+        neg = []
+        while len(neg) < self.neg_num:
+            pick = random.choice(cand)
+            if pick != itemid:
+                neg.append(pick)
+        return neg
+
+    # -------------------------------------------------------------------- batches
+    def next_batch_arrays(self) -> Dict[str, np.ndarray]:
+        keys = self.session_id_batches[self.batch_i]
+        st = self.store
+        if st.key_index is not None and not isinstance(keys[0], (int, np.integer)):
+            idx = np.fromiter((st.key_index[k] for k in keys), dtype=np.int64, count=len(keys))
+        elif st.key_index is not None and keys[0] in st.key_index:
+            idx = np.fromiter((st.key_index[k] for k in keys), dtype=np.int64, count=len(keys))
+        else:
+            idx = np.asarray(keys, dtype=np.int64)          # store-native integer example ids
+        arr = st.batch_arrays(idx, self.gap_mode)
+        arr["neg"] = self._negatives(keys, arr["label"])
+        arr["keys"] = keys
+        self.batch_i += 1
+        return arr
+
+    def next_batch(self):
+        a = self.next_batch_arrays()
+        B = len(a["label"])
+        if self.has_time:
+            pub = tuple(a[k].tolist() for k in ("pm", "pd", "pw", "ph", "pmi"))
+            clk = tuple(a[k].tolist() for k in ("cmo", "cd", "cw", "ch", "cmi"))
+            gap = a["gap"].tolist()
+        else:
+            pub, clk, gap = tuple([] for _ in range(5)), tuple([] for _ in range(5)), [[] for _ in range(B)]
+        neg = a["neg"].tolist() if a["neg"] is not None else [[] for _ in range(B)]
+        return a["seq"].tolist(), a["label"].tolist(), pub, clk, neg, gap
