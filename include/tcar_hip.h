@@ -1,0 +1,193 @@
+/*
+ * tcar_hip.h — C-ABI of the MI355X (gfx950) TCAR hot path.
+ *
+ * Drop-in boundary.  The reference has ONE device boundary per training step: the
+ * `sess.run([loss, global_step, train_op], feed_dict)` call at model_combine.py:231 (and
+ * `sess.run([softmax_input, cross_loss])` at model_combine.py:283 for evaluation); everything behind it is
+ * the TensorFlow op list built by model_combine.py:52-163 from modules.py:13-152 and util.py:59-100.
+ * Each entry point below replaces the TF ops named in its comment.  The reference is Python, so the
+ * binding a maintainer adds is a ctypes stub; the library itself has no Python or torch
+ * dependency.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked "host"; no entry point allocates;
+ *   - `stream` is a hipStream_t passed as void*; calls are stream-ordered, re-entrant, hold no global state;
+ *   - return value: 0 = ok, negative = TCAR_E_* (never throws across the boundary);
+ *   - device layout ("padded-concat space"): H is padded to ldh, Ht to ldt (multiples of 64, zero filled);
+ *       ic = 2*ldh   item | content           (model_combine.py:111  seq_item_cont)
+ *       pt = 5*ldt   month|day|week|hour|min  (model_combine.py:84   seq_publish_t)
+ *       ct = 2*ldt   week | hour              (model_combine.py:94-97 click_t)
+ *       ek = ic + pt                          (model_combine.py:132,136 attout / items_emb)
+ *     The candidate matrix E [N, ek] (row n = item id n+1) holds, in place, the trainable item table
+ *     (cols 0..H), the frozen content table (cols ldh..ldh+H) and the clipped candidate time vectors
+ *     (cols ic..ek) — items_emb of model_combine.py:135-136 without the per-step concat;
+ *   - item ids in `seq` are 1-based (sampler.py:68), labels and negatives 0-based (sampler.py:69,99).
+ */
+#ifndef TCAR_HIP_H
+#define TCAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCAR_OK 0
+#define TCAR_E_ARG (-1)     /* bad argument (alignment, range, unsupported size) */
+#define TCAR_E_LAUNCH (-2)  /* hip launch error */
+
+#define TCAR_POS_VOCAB 40   /* model_combine.py:57 */
+#define TCAR_DUR_VOCAB 11   /* model_combine.py:106 */
+#define TCAR_NSLOT 32       /* squared-norm slots (one per trainable variable, 23 used) */
+
+/* vocabularies of the five time tables: model_combine.py:73-81 */
+static const int32_t TCAR_TIME_VOCAB[5] = {13, 32, 8, 25, 61};
+
+typedef struct {
+  int32_t n_items;  /* N  = len(item_dict)                         main.py:25 */
+  int32_t H;        /* --hidden_size                               main.py:109 */
+  int32_t Ht;       /* --time_hidden_size                          main.py:110 */
+  int32_t ldh, ldt; /* padded H / Ht (multiples of 64)             */
+} tcar_dims_t;
+
+/* Parameter tables read by the lookups (model_combine.py:54-107).  Small tables are [vocab, ld*]. */
+typedef struct {
+  const float* E;        /* [N, ek]   item | content | cand-time (see header comment) */
+  const float* pos;      /* [40, ldh] dec_pos                       model_combine.py:57 */
+  const float* time[5];  /* month, day, week, hour, minute          model_combine.py:73-81 */
+  const float* dur;      /* [11, ldt] duration_embedding            model_combine.py:106 */
+} tcar_tables_t;
+
+/* Gradient accumulators that mirror tcar_tables_t (fp32, caller zeroes g_pos/g_time/g_dur/sqn per step;
+ * g_time[0..4] and g_dur MUST be one contiguous block in this order). */
+typedef struct {
+  float* g_item;         /* [N, ldh]  dense item-table gradient (row n = item id n+1) */
+  float* g_pos;          /* [40, ldh] */
+  float* g_time[5];
+  float* g_dur;
+  float* sqn;            /* [TCAR_NSLOT] IndexedSlices value-norm^2 pieces, slots below */
+  int32_t slot_item, slot_pos, slot_time[5], slot_dur;
+} tcar_grads_t;
+
+/* One mini-batch = the feed_dict of model_combine.py:214-227 (int32, row-major). */
+typedef struct {
+  int32_t B, T, K;
+  const int32_t* seq;     /* [B,T] 1-based item ids            input_seq */
+  const int32_t* pub[5];  /* [B,T] month, day, week, hour+1, minute+1   input_publish_* */
+  const int32_t* cw;      /* [B]   click isoweekday-1           input_click_week */
+  const int32_t* ch;      /* [B]   click hour                   input_click_hour */
+  const int32_t* gap;     /* [B,T] dwell bucket 0..11           active_interval */
+  const int32_t* label;   /* [B]   0-based                      label */
+  const int32_t* neg;     /* [B,K] 0-based or NULL              label_neg */
+} tcar_batch_t;
+
+/* ---- embedding lookups --------------------------------------------------------------------------------
+ * tcar_gather_clip_fwd: the 8 session-side + 2 click-side `embedding_lookup(..., max_norm=1)` calls of
+ * modules.py:36 / model_combine.py:54-82,94-97,106 fused with the concats of :65,84,94,111.
+ *   x_icp [B*T, ic] = clip(item)+clip(pos) | clip(content);  x_pt [B*T, pt];  x_act [B*T, ldt];
+ *   click_t [B, ct].  Dwell id >= 11 yields a zero row. */
+int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
+                         float* x_icp, float* x_pt, float* x_act, float* click_t, void* stream);
+
+/* tcar_gather_clip_bwd: gradient of the above w.r.t. the tables (through the norm clip), i.e. the
+ * IndexedSlices that tf.gradients builds for model_combine.py:156.  Adds into `g` (atomics) and adds
+ * sum ||row-gradient||^2 into g->sqn[slot] for every gathered row. */
+int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
+                         const float* dx_icp, const float* dx_pt, const float* dx_act, const float* dclick,
+                         const tcar_grads_t* g, void* stream);
+
+/* tcar_cand_time_fwd: candidate_publish_t of model_combine.py:86-92 written into E[:, ic:ek].
+ * mwdhm [N,5] int32 = publish_time_MWDHM (model_combine.py:37). */
+int tcar_cand_time_fwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
+                       float* E, void* stream);
+
+/* tcar_cand_time_bwd: gradient of the above; d_et [N, pt] (ld = pt) is the time-column block of dE. */
+int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
+                       const float* d_et, const tcar_grads_t* g, void* stream);
+
+/* ---- dense contractions --------------------------------------------------------------------------------
+ * tcar_gemm_f32: fp32-in / fp32-accumulate MFMA GEMM (v_mfma_f32_32x32x2_f32), C = act(A*B + bias) (+C).
+ * Replaces tf.matmul / BatchMatMul of modules.py:52,67 (linear_2d / linear_3d), model_combine.py:138
+ * (full-catalog logits) and their gradients.
+ *   layout 0 "NN": A[M,K] (lda), B[K,N] (ldb)      y = x W
+ *   layout 1 "NT": A[M,K] (lda), B[N,K] (ldb)      logits = attout E^T ;  dx = dy W^T
+ *   layout 2 "TN": A[K,M] (lda), B[K,N] (ldb)      dW = x^T dy ; dE = dlogits^T attout
+ * act: 0 none, 1 relu, 2 tanh (util.py:60-90).  beta: 0 overwrite, 1 accumulate into C.
+ * splitk > 1: C is [splitk, M, ldc] partial slabs (combine with tcar_splitk_reduce); bias/act/beta must be 0.
+ * Requirements: pointers 16-byte aligned, lda/ldb % 4 == 0; K % 4 == 0 for k-contiguous operands. */
+int tcar_gemm_f32(int layout, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                  float* C, int64_t ldc, const float* bias, int act, int beta, int splitk, void* stream);
+int tcar_splitk_reduce(const float* slabs, int splitk, int M, int N, int64_t ld, float* out, void* stream);
+/* number of slabs tcar_gemm_f32 actually writes for a requested split (K is cut in multiples of 32) */
+int tcar_gemm_splitk_effective(int K, int splitk);
+
+/* ---- attention pools (modules.py:72-152, util.py:92-100) --------------------------------------------------
+ * pre1 [B*T, ldh] = X_ic W_in + X_c W_c + X_act W_int (no activation), pre2 likewise for the time pool,
+ * q [B, ic] = tanh(relu(click_t Wq1 + b) Wq2 + b).  Computes alpha1 = expnorm(sigmoid(pre1) . w_res1),
+ * alpha2 = expnorm(X_ic . q), alpha_t = expnorm(sigmoid(pre2) . w_res2) and
+ * pooled [B, ek] = [ (alpha1+alpha2)^T X_ic | alpha_t^T X_pt ];  alpha [3, B*T] is saved for backward. */
+int tcar_attn_pool_fwd(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                       const float* pre1, const float* pre2, const float* q, const float* w_res1,
+                       const float* w_res2, float* pooled, float* alpha, void* stream);
+/* Backward: writes dx_icp, dx_pt (pool + query-dot parts), dq [B, ic], dpre1, dpre2 [B*T, ldh];
+ * adds into g_wres1, g_wres2 [ldh] (atomics). */
+int tcar_attn_pool_bwd(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                       const float* pre1, const float* pre2, const float* q, const float* w_res1,
+                       const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
+                       float* dx_pt, float* dq, float* dpre1, float* dpre2, float* g_wres1, float* g_wres2,
+                       void* stream);
+
+/* ---- scoring loss -----------------------------------------------------------------------------------------
+ * tcar_softmax_ce: tf.nn.sparse_softmax_cross_entropy_with_logits (model_combine.py:145) and its gradient.
+ * logits [B, ld] (first N columns valid) is overwritten by dlogits = softmax - onehot (pad columns 0). */
+int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* stream);
+
+/* tcar_neg_term: neg_logits / neg_feedback of model_combine.py:142-143 and their gradients.
+ * neg_fb[b] = -log(1 - sigmoid(x_b) + 1e-24), x_b = sum_k E[neg[b,k], 0:ic] . attout[b, 0:ic].
+ * Adds weight * d neg_fb into dattout[b, 0:ic] (plain adds: one wave owns a row) and into g_item (atomics);
+ * either may be NULL to skip (forward only). */
+int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg,
+                  const float* attout, float weight, float* neg_fb, float* dattout, float* g_item,
+                  void* stream);
+
+/* tcar_dact_colsum: dz = dy * act'(y) in place over dy ([M, ncol], ld) and bias_grad[c] = sum_m dz[m,c]
+ * (gradient of linear_2d's bias + activation, modules.py:52-54).  act: 1 relu, 2 tanh. */
+int tcar_dact_colsum(int M, int ncol, int64_t ld, const float* y, float* dy, float* bias_grad, int act,
+                     void* stream);
+
+/* ---- evaluation (util.py:8-18, model_combine.py:301) --------------------------------------------------------
+ * rank[b] = 1 + #{n : logits[b,n] > logits[b,label[b]]};  topk[b, 0:k] = indices of the k largest scores,
+ * descending, ties broken towards the higher index (np.argsort(...)[::-1]). */
+int tcar_rank_topk(int B, int N, const float* logits, int64_t ld, const int32_t* label, int k,
+                   int32_t* rank, int32_t* topk, void* stream);
+
+/* ---- optimizer (model_combine.py:155-163) ---------------------------------------------------------------------
+ * Segments of one flat fp32 arena (identical offsets in w, g, m, v). */
+typedef struct {
+  int32_t nseg;
+  int64_t off[TCAR_NSLOT];   /* start of segment (floats, multiple of 4) */
+  int64_t len[TCAR_NSLOT];   /* floats (multiple of 4) */
+  int32_t slot[TCAR_NSLOT];  /* squared-norm slot of the variable the segment belongs to */
+} tcar_segments_t;
+
+/* sqn_dense[slot] += sum g^2 over each segment. */
+int tcar_sqnorm(const float* g, const tcar_segments_t* segs /*host*/, float* sqn_dense, void* stream);
+/* Per-variable tf.clip_by_norm(g, clip) then TF-1 Adam.  norm^2 of a variable =
+ * use_dense[slot]*sqn_dense[slot] + sqn_pieces[slot]; scale = clip / max(norm, clip) (clip <= 0: no clipping).
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t m / (sqrt(v) + eps). */
+int tcar_clip_adam(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs /*host*/,
+                   const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense /*device [NSLOT]*/,
+                   float clip, float lr_t, float b1, float b2, float eps, void* stream);
+/* Same for a 2-D strided parameter block (the item table inside E): w [rows, cols] with leading dim ldw;
+ * g, m, v are compact [rows, cols]. */
+int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m, float* v, int64_t rows, int32_t cols,
+                      int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense,
+                      float clip, float lr_t, float b1, float b2, float eps, void* stream);
+
+/* Library self-description (for loaders). */
+int tcar_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCAR_HIP_H */

@@ -1,0 +1,133 @@
+"""Loader (and in-tree builder) of ``libtcar_hip.so`` — the C-ABI of include/tcar_hip.h.
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol is absent, importing the
+engine raises.  `build()` cross-compiles the HIP sources for gfx950 with hipcc (works without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libtcar_hip.so")
+SOURCES = ["gemm_f32.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip"]
+NSLOT = 32
+
+# every symbol include/tcar_hip.h declares
+SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_cand_time_fwd", "tcar_cand_time_bwd",
+           "tcar_gemm_f32", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_dact_colsum", "tcar_rank_topk",
+           "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_abi_version"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/*.hip -> libtcar_hip.so (in-tree)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "tcar_common.h"), os.path.join(PKG_DIR, "..", "include", "tcar_hip.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps if os.path.exists(d)):
+            return LIB_PATH
+    if not all(os.path.exists(s) for s in srcs):
+        raise FileNotFoundError("HIP sources missing under " + CSRC)
+    objs = []
+    procs = []
+    for s in srcs:
+        o = os.path.join(CSRC, os.path.basename(s).replace(".hip", ".o"))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o]
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(o)
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+        if verbose and out:
+            print(out.decode(errors="replace"))
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed: %s\n%s" % (" ".join(link), r.stdout.decode(errors="replace")))
+    return LIB_PATH
+
+
+# ------------------------------------------------------------------------------------------- ctypes mirrors
+class Dims(C.Structure):
+    _fields_ = [("n_items", C.c_int32), ("H", C.c_int32), ("Ht", C.c_int32), ("ldh", C.c_int32), ("ldt", C.c_int32)]
+
+
+class Tables(C.Structure):
+    _fields_ = [("E", C.c_void_p), ("pos", C.c_void_p), ("time", C.c_void_p * 5), ("dur", C.c_void_p)]
+
+
+class Grads(C.Structure):
+    _fields_ = [("g_item", C.c_void_p), ("g_pos", C.c_void_p), ("g_time", C.c_void_p * 5), ("g_dur", C.c_void_p),
+                ("sqn", C.c_void_p), ("slot_item", C.c_int32), ("slot_pos", C.c_int32),
+                ("slot_time", C.c_int32 * 5), ("slot_dur", C.c_int32)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("K", C.c_int32), ("seq", C.c_void_p),
+                ("pub", C.c_void_p * 5), ("cw", C.c_void_p), ("ch", C.c_void_p), ("gap", C.c_void_p),
+                ("label", C.c_void_p), ("neg", C.c_void_p)]
+
+
+class Segments(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("off", C.c_int64 * NSLOT), ("len", C.c_int64 * NSLOT),
+                ("slot", C.c_int32 * NSLOT)]
+
+
+class TcarError(RuntimeError):
+    pass
+
+
+_LIB = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library and check that every declared symbol is exported."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise TcarError("libtcar_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                        "there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    missing = [s for s in SYMBOLS if not hasattr(lib, s)]
+    if missing:
+        raise TcarError("libtcar_hip.so lacks symbols: %s" % missing)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    P = C.POINTER
+    lib.tcar_gather_clip_fwd.argtypes = [P(Dims), P(Tables), P(Batch), vp, vp, vp, vp, vp]
+    lib.tcar_gather_clip_bwd.argtypes = [P(Dims), P(Tables), P(Batch), vp, vp, vp, vp, P(Grads), vp]
+    lib.tcar_cand_time_fwd.argtypes = [P(Dims), P(vp * 5), vp, vp, vp]
+    lib.tcar_cand_time_bwd.argtypes = [P(Dims), P(vp * 5), vp, vp, P(Grads), vp]
+    lib.tcar_gemm_f32.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
+    lib.tcar_splitk_reduce.argtypes = [vp, i32, i32, i32, i64, vp, vp]
+    lib.tcar_gemm_splitk_effective.argtypes = [i32, i32]
+    lib.tcar_attn_pool_fwd.argtypes = [P(Dims), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.tcar_attn_pool_bwd.argtypes = [P(Dims), i32, i32] + [vp] * 17
+    lib.tcar_softmax_ce.argtypes = [i32, i32, vp, i64, vp, vp, vp]
+    lib.tcar_neg_term.argtypes = [P(Dims), i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]
+    lib.tcar_dact_colsum.argtypes = [i32, i32, i64, vp, vp, vp, i32, vp]
+    lib.tcar_rank_topk.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp, vp]
+    lib.tcar_sqnorm.argtypes = [vp, P(Segments), vp, vp]
+    lib.tcar_clip_adam.argtypes = [vp, vp, vp, vp, P(Segments), vp, vp, vp, f32, f32, f32, f32, f32, vp]
+    lib.tcar_clip_adam_2d.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp]
+    for s in SYMBOLS:
+        getattr(lib, s).restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise TcarError("%s failed with code %d (%s)" % (what, rc, {-1: "bad argument", -2: "launch error"}.get(rc, "?")))

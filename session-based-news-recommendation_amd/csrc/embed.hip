@@ -1,0 +1,422 @@
+// Embedding lookups with norm clipping (forward + backward) for gfx950.
+//
+// Reference ops: tf.nn.embedding_lookup(table, ids, max_norm=1) at modules.py:36 and
+// model_combine.py:68,87-91,95-96 (gather, then clip every gathered row to L2 norm <= 1, gradient through the
+// clip), plus the concats of model_combine.py:65,84,94,111.
+//
+// HBM-bound kernels.  One 64-lane wave owns one (session, position) row: an H-float row (<= 256 floats) is one
+// 16-byte load per lane = one fully coalesced 1-KiB wave instruction; the five 64-float time rows and the
+// dwell row share a wave instruction in 16-lane groups.  Row norms are wave / group shuffle reductions; nothing
+// goes through LDS in the forward pass.  The backward pass re-gathers the raw rows (needed by the clip
+// Jacobian), adds item-row gradients straight into the dense [N, ldh] gradient with 256-byte-contiguous float
+// atomics (the shape the memory-side atomic unit runs at full rate), and privatises the tiny, heavily
+// contended tables (position, 5 time tables, dwell: <= 190 rows) in LDS, flushing each workgroup's non-zero
+// rows once at the end.
+#include "tcar_common.h"
+
+namespace {
+
+struct EmbArgs {
+  tcar_dims_t d;
+  tcar_tables_t tab;
+  tcar_batch_t bt;
+  float* x_icp; float* x_pt; float* x_act; float* click_t;
+  const float* dx_icp; const float* dx_pt; const float* dx_act; const float* dclick;
+  tcar_grads_t g;
+};
+
+__device__ __forceinline__ int time_vocab(int k) {
+  return k == 0 ? 13 : k == 1 ? 32 : k == 2 ? 8 : k == 3 ? 25 : k == 4 ? 61 : TCAR_DUR_VOCAB;
+}
+// row offset of table k inside the contiguous [month|day|week|hour|minute|dur] block
+__device__ __forceinline__ int time_rowoff(int k) {
+  return k == 0 ? 0 : k == 1 ? 13 : k == 2 ? 45 : k == 3 ? 53 : k == 4 ? 78 : 139;
+}
+constexpr int SMALL_ROWS = 150;  // 13+32+8+25+61+11
+
+// select one of five kernel-argument pointers without a runtime-indexed (scratch) copy of the argument struct
+template <typename P>
+__device__ __forceinline__ P pick5(P const (&arr)[5], int k) {
+  return k == 0 ? arr[0] : k == 1 ? arr[1] : k == 2 ? arr[2] : k == 3 ? arr[3] : arr[4];
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NCH>  // NCH = ceil(ldh / 256): 16-byte chunks per lane for an H-row
+__global__ __launch_bounds__(256) void gather_clip_fwd_kernel(const EmbArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int B = a.bt.B, T = a.bt.T, BT = B * T;
+  const int ldh = a.d.ldh, ldt = a.d.ldt;
+  const int ic = 2 * ldh, pt = 5 * ldt, ek = ic + pt, ct = 2 * ldt;
+  const int sub = ldt >> 2;          // lanes per time row (16 for ldt = 64)
+  const int gpw = 64 / sub;          // time rows per wave instruction
+  const int grp = lane / sub, lin = lane - grp * sub;
+
+  for (int row = wave_g; row < BT + B; row += nwaves) {
+    if (row < BT) {
+      const int t = row % T;
+      const int n = clampi(a.bt.seq[row], 1, a.d.n_items) - 1;
+      const float* e = a.tab.E + (long)n * ek;
+      float4 xi[NCH], xc[NCH], xp[NCH];
+      float si = 0.f, sc = 0.f, sp = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = col < ldh;
+        xi[c] = ok ? ld4(e + col) : zero4();
+        xc[c] = ok ? ld4(e + ldh + col) : zero4();
+        xp[c] = ok ? ld4(a.tab.pos + (long)t * ldh + col) : zero4();
+        si += dot4(xi[c], xi[c]); sc += dot4(xc[c], xc[c]); sp += dot4(xp[c], xp[c]);
+      }
+      si = clip_scale(wave_sum(si)); sc = clip_scale(wave_sum(sc)); sp = clip_scale(wave_sum(sp));
+      float* o = a.x_icp + (long)row * ic;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) {
+          st4(o + col, fma4(xi[c], si, scale4(xp[c], sp)));
+          st4(o + ldh + col, scale4(xc[c], sc));
+        }
+      }
+      // five publish-time rows + the dwell row, `gpw` rows per pass
+      for (int k0 = 0; k0 < 6; k0 += gpw) {
+        const int k = k0 + grp;
+        const bool valid = k < 6;
+        const int kk = valid ? k : 0;
+        int id = (kk < 5) ? pick5(a.bt.pub, kk)[row] : a.bt.gap[row];
+        const bool oob = (kk == 5) && (id >= TCAR_DUR_VOCAB || id < 0);   // dwell bucket 11 -> zero row (S7)
+        id = clampi(id, 0, time_vocab(kk) - 1);
+        const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
+        float4 x = (valid && !oob) ? ld4(tp + (long)id * ldt + lin * 4) : zero4();
+        const float s = clip_scale(group_sum(dot4(x, x), sub));
+        if (valid) {
+          float* dst = (kk < 5) ? a.x_pt + (long)row * pt + kk * ldt : a.x_act + (long)row * ldt;
+          st4(dst + lin * 4, scale4(x, s));
+        }
+      }
+    } else {
+      // click-time query rows: week table by cw, hour table by ch (model_combine.py:94-97)
+      const int b = row - BT;
+      for (int k0 = 0; k0 < 2; k0 += gpw) {
+        const int j = k0 + grp;
+        const bool valid = j < 2;
+        const int jj = valid ? j : 0;
+        const int kk = jj == 0 ? 2 : 3;
+        const int id = clampi(jj == 0 ? a.bt.cw[b] : a.bt.ch[b], 0, time_vocab(kk) - 1);
+        float4 x = valid ? ld4(pick5(a.tab.time, kk) + (long)id * ldt + lin * 4) : zero4();
+        const float s = clip_scale(group_sum(dot4(x, x), sub));
+        if (valid) st4(a.click_t + (long)b * ct + jj * ldt + lin * 4, scale4(x, s));
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- backward
+template <int NCH>
+__global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_g = blockIdx.x * 4 + (tid >> 6);
+  const int nwaves = gridDim.x * 4;
+  const int B = a.bt.B, T = a.bt.T, BT = B * T;
+  const int ldh = a.d.ldh, ldt = a.d.ldt;
+  const int ic = 2 * ldh, pt = 5 * ldt, ek = ic + pt, ct = 2 * ldt;
+  const int sub = ldt >> 2, gpw = 64 / sub;
+  const int grp = lane / sub, lin = lane - grp * sub;
+  float* pos_acc = lds;                       // [T, ldh]
+  float* small_acc = lds + T * ldh;           // [150, ldt]
+  float* sq_acc = small_acc + SMALL_ROWS * ldt;  // [8]
+  const int lds_floats = T * ldh + SMALL_ROWS * ldt + 8;
+  for (int i = tid; i < lds_floats; i += 256) lds[i] = 0.f;
+  __syncthreads();
+
+  float sq[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sq[i] = 0.f;
+
+  for (int row = wave_g; row < BT + B; row += nwaves) {
+    if (row < BT) {
+      const int t = row % T;
+      const int n = clampi(a.bt.seq[row], 1, a.d.n_items) - 1;
+      const float* e = a.tab.E + (long)n * ek;
+      const float* gy = a.dx_icp + (long)row * ic;
+      float4 xi[NCH], xp[NCH], gi[NCH];
+      float ssi = 0.f, di = 0.f, ssp = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = col < ldh;
+        xi[c] = ok ? ld4(e + col) : zero4();
+        xp[c] = ok ? ld4(a.tab.pos + (long)t * ldh + col) : zero4();
+        gi[c] = ok ? ld4(gy + col) : zero4();
+        ssi += dot4(xi[c], xi[c]); di += dot4(xi[c], gi[c]);
+        ssp += dot4(xp[c], xp[c]); dp += dot4(xp[c], gi[c]);
+      }
+      ssi = wave_sum(ssi); di = wave_sum(di); ssp = wave_sum(ssp); dp = wave_sum(dp);
+      float ai, bi, ap, bp;
+      clip_bwd_coef(ssi, di, ai, bi);
+      clip_bwd_coef(ssp, dp, ap, bp);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) {
+          float4 gx = fma4(xi[c], -bi, scale4(gi[c], ai));
+          sq[0] += dot4(gx, gx);
+          atomic_add4(a.g.g_item + (long)n * ldh + col, gx);
+          float4 gp = fma4(xp[c], -bp, scale4(gi[c], ap));
+          sq[1] += dot4(gp, gp);
+          atomic_add4(pos_acc + t * ldh + col, gp);
+        }
+      }
+      for (int k0 = 0; k0 < 6; k0 += gpw) {
+        const int k = k0 + grp;
+        const bool valid = k < 6;
+        const int kk = valid ? k : 0;
+        int id = (kk < 5) ? pick5(a.bt.pub, kk)[row] : a.bt.gap[row];
+        const bool oob = (kk == 5) && (id >= TCAR_DUR_VOCAB || id < 0);
+        id = clampi(id, 0, time_vocab(kk) - 1);
+        const bool act = valid && !oob;
+        const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
+        const float* gp = (kk < 5) ? a.dx_pt + (long)row * pt + kk * ldt : a.dx_act + (long)row * ldt;
+        float4 x = act ? ld4(tp + (long)id * ldt + lin * 4) : zero4();
+        float4 gyv = act ? ld4(gp + lin * 4) : zero4();
+        const float ss = group_sum(dot4(x, x), sub), dd = group_sum(dot4(x, gyv), sub);
+        float ca, cb;
+        clip_bwd_coef(ss, dd, ca, cb);
+        if (act) {
+          float4 gx = fma4(x, -cb, scale4(gyv, ca));
+          const float q = dot4(gx, gx);
+          // per-lane partial of sum-of-squares, routed to the slot of table kk
+#pragma unroll
+          for (int s = 0; s < 6; ++s) sq[2 + s] += (s == kk) ? q : 0.f;
+          atomic_add4(small_acc + (time_rowoff(kk) + id) * ldt + lin * 4, gx);
+        }
+      }
+    } else {
+      const int b = row - BT;
+      for (int k0 = 0; k0 < 2; k0 += gpw) {
+        const int j = k0 + grp;
+        const bool valid = j < 2;
+        const int jj = valid ? j : 0;
+        const int kk = jj == 0 ? 2 : 3;
+        const int id = clampi(jj == 0 ? a.bt.cw[b] : a.bt.ch[b], 0, time_vocab(kk) - 1);
+        float4 x = valid ? ld4(pick5(a.tab.time, kk) + (long)id * ldt + lin * 4) : zero4();
+        float4 gyv = valid ? ld4(a.dclick + (long)b * ct + jj * ldt + lin * 4) : zero4();
+        const float ss = group_sum(dot4(x, x), sub), dd = group_sum(dot4(x, gyv), sub);
+        float ca, cb;
+        clip_bwd_coef(ss, dd, ca, cb);
+        if (valid) {
+          float4 gx = fma4(x, -cb, scale4(gyv, ca));
+          const float q = dot4(gx, gx);
+          sq[2 + 2] += (kk == 2) ? q : 0.f;
+          sq[2 + 3] += (kk == 3) ? q : 0.f;
+          atomic_add4(small_acc + (time_rowoff(kk) + id) * ldt + lin * 4, gx);
+        }
+      }
+    }
+  }
+  // squared-norm pieces: wave reduce -> LDS -> one global atomic per workgroup and slot
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float s = wave_sum(sq[i]);
+    if (lane == 0 && s != 0.f) atomicAdd(sq_acc + i, s);
+  }
+  __syncthreads();
+  for (int i = tid; i < T * ldh; i += 256) {
+    const float v = pos_acc[i];
+    if (v != 0.f) atomicAdd(a.g.g_pos + i, v);
+  }
+  for (int i = tid; i < SMALL_ROWS * ldt; i += 256) {
+    const float v = small_acc[i];
+    if (v != 0.f) atomicAdd(a.g.g_time[0] + i, v);   // g_time[0..4], g_dur are one contiguous block
+  }
+  if (tid < 8) {
+    const float v = sq_acc[tid];
+    if (v != 0.f) {
+      const int slot = tid == 0 ? a.g.slot_item : tid == 1 ? a.g.slot_pos : tid == 7 ? a.g.slot_dur : pick5(a.g.slot_time, tid - 2);
+      atomicAdd(a.g.sqn + slot, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- candidate-side time vectors
+struct CandArgs {
+  tcar_dims_t d;
+  const float* tab[5];
+  const int32_t* mwdhm;
+  float* E;
+  const float* d_et;
+  tcar_grads_t g;
+};
+
+// E[n, ic + k*ldt ...] = clip(table_k[mwdhm[n,k]])   (model_combine.py:86-92)
+__global__ __launch_bounds__(256) void cand_time_fwd_kernel(const CandArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // clipped copies of the 139 time rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ldt = a.d.ldt, ldh = a.d.ldh, ic = 2 * ldh, ek = ic + 5 * ldt;
+  const int sub = ldt >> 2, gpw = 64 / sub;
+  const int grp = lane / sub, lin = lane - grp * sub;
+  // stage: each 16-lane group clips one table row into LDS
+  for (int r0 = wave * gpw; r0 < 139; r0 += 4 * gpw) {
+    const int r = r0 + grp;
+    const bool valid = r < 139;
+    const int rr = valid ? r : 0;
+    const int k = rr < 13 ? 0 : rr < 45 ? 1 : rr < 53 ? 2 : rr < 78 ? 3 : 4;
+    const int id = rr - time_rowoff(k);
+    float4 x = valid ? ld4(pick5(a.tab, k) + (long)id * ldt + lin * 4) : zero4();
+    const float s = clip_scale(group_sum(dot4(x, x), sub));
+    if (valid) st4(lds + rr * ldt + lin * 4, scale4(x, s));
+  }
+  __syncthreads();
+  const long total = (long)a.d.n_items * 5 * sub;     // one float4 per (n, k, lin)
+  for (long i = (long)blockIdx.x * 256 + tid; i < total; i += (long)gridDim.x * 256) {
+    const int l = (int)(i % sub);
+    const long nk = i / sub;
+    const int k = (int)(nk % 5);
+    const long n = nk / 5;
+    const int id = clampi(a.mwdhm[n * 5 + k], 0, time_vocab(k) - 1);
+    st4(a.E + n * ek + ic + k * ldt + l * 4, ld4(lds + (time_rowoff(k) + id) * ldt + l * 4));
+  }
+}
+
+// gradient of the candidate-side lookups: for every (n, k) clip-backward of d_et[n, k*ldt ...]
+__global__ __launch_bounds__(256) void cand_time_bwd_kernel(const CandArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [139, ldt] accumulators + [5] norms
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ldt = a.d.ldt, pt = 5 * ldt;
+  const int sub = ldt >> 2, gpw = 64 / sub;
+  const int grp = lane / sub, lin = lane - grp * sub;
+  float* acc = lds;
+  float* sq_acc = lds + 139 * ldt;
+  for (int i = tid; i < 139 * ldt + 8; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  float sq[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  const long npairs = (long)a.d.n_items * 5;
+  const long wave_g = (long)blockIdx.x * 4 + (tid >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  for (long p0 = wave_g * gpw; p0 < npairs; p0 += nwaves * gpw) {
+    const long p = p0 + grp;
+    const bool valid = p < npairs;
+    const long pp = valid ? p : 0;
+    const int k = (int)(pp % 5);
+    const long n = pp / 5;
+    const int id = clampi(a.mwdhm[pp], 0, time_vocab(k) - 1);
+    float4 x = valid ? ld4(pick5(a.tab, k) + (long)id * ldt + lin * 4) : zero4();
+    float4 gy = valid ? ld4(a.d_et + n * pt + k * ldt + lin * 4) : zero4();
+    const float ss = group_sum(dot4(x, x), sub), dd = group_sum(dot4(x, gy), sub);
+    float ca, cb;
+    clip_bwd_coef(ss, dd, ca, cb);
+    if (valid) {
+      float4 gx = fma4(x, -cb, scale4(gy, ca));
+      const float q = dot4(gx, gx);
+#pragma unroll
+      for (int s = 0; s < 5; ++s) sq[s] += (s == k) ? q : 0.f;
+      atomic_add4(acc + (time_rowoff(k) + id) * ldt + lin * 4, gx);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float s = wave_sum(sq[i]);
+    if (lane == 0 && s != 0.f) atomicAdd(sq_acc + i, s);
+  }
+  __syncthreads();
+  for (int i = tid; i < 139 * ldt; i += 256) {
+    const float v = acc[i];
+    if (v != 0.f) atomicAdd(a.g.g_time[0] + i, v);
+  }
+  if (tid < 5) {
+    const float v = sq_acc[tid];
+    if (v != 0.f) atomicAdd(a.g.sqn + a.g.slot_time[tid], v);
+  }
+}
+
+int check_dims(const tcar_dims_t* d) {
+  if (!d || d->n_items <= 0 || d->H <= 0 || d->Ht <= 0) return TCAR_E_ARG;
+  if (d->ldh < d->H || d->ldt < d->Ht || (d->ldh & 63) || (d->ldh > 512)) return TCAR_E_ARG;
+  if (d->ldt != 64 && d->ldt != 128 && d->ldt != 256) return TCAR_E_ARG;
+  return TCAR_OK;
+}
+int grid_for_rows(long rows) {
+  long g = (rows + 3) / 4;
+  if (g < 1) g = 1;
+  if (g > 1024) g = 1024;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
+                                    float* x_icp, float* x_pt, float* x_act, float* click_t, void* stream) {
+  if (check_dims(d) || !tab || !bt || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
+  EmbArgs a{};
+  a.d = *d; a.tab = *tab; a.bt = *bt;
+  a.x_icp = x_icp; a.x_pt = x_pt; a.x_act = x_act; a.click_t = click_t;
+  const int grid = grid_for_rows((long)bt->B * bt->T + bt->B);
+  if (d->ldh <= 256) hipLaunchKernelGGL(gather_clip_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(gather_clip_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
+                                    const float* dx_icp, const float* dx_pt, const float* dx_act,
+                                    const float* dclick, const tcar_grads_t* g, void* stream) {
+  if (check_dims(d) || !tab || !bt || !g || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
+  EmbArgs a{};
+  a.d = *d; a.tab = *tab; a.bt = *bt; a.g = *g;
+  a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;
+  long rows = (long)bt->B * bt->T + bt->B;
+  int grid = (int)((rows + 15) / 16);          // >= 4 rows per wave: amortise the LDS zero / flush
+  if (grid < 1) grid = 1;
+  if (grid > 512) grid = 512;
+  const size_t lds = ((size_t)bt->T * d->ldh + (size_t)SMALL_ROWS * d->ldt + 8) * sizeof(float);
+  if (lds > 160 * 1024) return TCAR_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (d->ldh <= 256) {
+    (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(gather_clip_bwd_kernel<1>, dim3(grid), dim3(256), lds, st, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(gather_clip_bwd_kernel<2>, dim3(grid), dim3(256), lds, st, a);
+  }
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_cand_time_fwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
+                                  float* E, void* stream) {
+  if (check_dims(d) || !time_tab || !mwdhm || !E) return TCAR_E_ARG;
+  CandArgs a{};
+  a.d = *d;
+  for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
+  a.mwdhm = mwdhm; a.E = E;
+  const size_t lds = (size_t)139 * d->ldt * sizeof(float);
+  long total = (long)d->n_items * 5 * (d->ldt >> 2);
+  int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
+  if (grid < 1) grid = 1;
+  if (grid > 1024) grid = 1024;
+  (void)hipFuncSetAttribute((const void*)cand_time_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(cand_time_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
+                                  const float* d_et, const tcar_grads_t* g, void* stream) {
+  if (check_dims(d) || !time_tab || !mwdhm || !d_et || !g) return TCAR_E_ARG;
+  CandArgs a{};
+  a.d = *d;
+  for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
+  a.mwdhm = mwdhm; a.d_et = d_et; a.g = *g;
+  const size_t lds = ((size_t)139 * d->ldt + 8) * sizeof(float);
+  long npairs = (long)d->n_items * 5;
+  const int gpw = 64 / (d->ldt >> 2);
+  int grid = (int)((npairs / gpw + 4 * 16 - 1) / (4 * 16));   // >= 16 passes per wave
+  if (grid < 1) grid = 1;
+  if (grid > 512) grid = 512;
+  (void)hipFuncSetAttribute((const void*)cand_time_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  hipLaunchKernelGGL(cand_time_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}

@@ -1,0 +1,154 @@
+// Per-variable gradient clipping + TF-1 Adam for gfx950 (HBM-bound: 16 B read + 12 B written per parameter).
+//
+// Reference: model_combine.py:155-163 — tf.train.AdamOptimizer(lr) (beta1 .9, beta2 .999, eps 1e-8),
+// per-variable tf.clip_by_norm(grad, max_grad), apply_gradients.  TF-1 Adam:
+//   lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)            (computed by the caller)
+//   m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2 ;  w -= lr_t * m / (sqrt(v) + eps)
+// Its sparse apply de-duplicates indices and still decays / updates every row, so it equals this dense update
+// on the summed gradient.  The clip norm of a variable is sqrt(use_dense*sqn_dense + sqn_pieces)
+// where the pieces are the IndexedSlices value blocks accumulated by the embedding backward kernels (S5).
+#include "tcar_common.h"
+
+namespace {
+
+struct SegArgs {
+  tcar_segments_t s;
+};
+
+__device__ __forceinline__ float clip_factor(const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense,
+                                             int slot, float clip) {
+  if (clip <= 0.f) return 1.f;
+  const float n2 = (use_dense[slot] ? sqn_dense[slot] : 0.f) + sqn_pieces[slot];
+  const float n = sqrtf(n2);
+  return clip / fmaxf(n, clip);
+}
+
+// grid = (chunks, nseg); each workgroup reduces up to 4096 floats of one segment
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, const SegArgs a, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const int seg = blockIdx.y;
+  const long off = a.s.off[seg];
+  const long len = a.s.len[seg];
+  const long base = (long)blockIdx.x * 4096;
+  if (base >= len) return;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long e = base + (i * 256 + threadIdx.x) * 4;
+    if (e < len) { const float4 v = ld4(g + off + e); s += dot4(v, v); }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out + a.s.slot[seg], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+__device__ __forceinline__ void adam4(float4& w, const float4 g, float4& m, float4& v, float sc, float lr_t, float b1,
+                                      float b2, float eps) {
+  const float gx = g.x * sc, gy = g.y * sc, gz = g.z * sc, gw = g.w * sc;
+  m.x = b1 * m.x + (1.f - b1) * gx; m.y = b1 * m.y + (1.f - b1) * gy;
+  m.z = b1 * m.z + (1.f - b1) * gz; m.w = b1 * m.w + (1.f - b1) * gw;
+  v.x = b2 * v.x + (1.f - b2) * gx * gx; v.y = b2 * v.y + (1.f - b2) * gy * gy;
+  v.z = b2 * v.z + (1.f - b2) * gz * gz; v.w = b2 * v.w + (1.f - b2) * gw * gw;
+  w.x -= lr_t * m.x / (sqrtf(v.x) + eps); w.y -= lr_t * m.y / (sqrtf(v.y) + eps);
+  w.z -= lr_t * m.z / (sqrtf(v.z) + eps); w.w -= lr_t * m.w / (sqrtf(v.w) + eps);
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, const SegArgs a,
+                                                        const float* __restrict__ sqn_dense,
+                                                        const float* __restrict__ sqn_pieces,
+                                                        const int32_t* __restrict__ use_dense, float clip, float lr_t,
+                                                        float b1, float b2, float eps) {
+  const int seg = blockIdx.y;
+  const long off = a.s.off[seg];
+  const long len = a.s.len[seg];
+  const long base = (long)blockIdx.x * 4096;
+  if (base >= len) return;
+  const float sc = clip_factor(sqn_dense, sqn_pieces, use_dense, a.s.slot[seg], clip);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long e = base + (i * 256 + threadIdx.x) * 4;
+    if (e < len) {
+      const long p = off + e;
+      float4 ww = ld4(w + p), mm = ld4(m + p), vv = ld4(v + p);
+      adam4(ww, ld4(g + p), mm, vv, sc, lr_t, b1, b2, eps);
+      st4(w + p, ww); st4(m + p, mm); st4(v + p, vv);
+    }
+  }
+}
+
+// item table inside E: w [rows, cols] with leading dim ldw; g, m, v compact [rows, cols]
+__global__ __launch_bounds__(256) void clip_adam_2d_kernel(float* __restrict__ w, long ldw, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, long rows,
+                                                           int cols, int slot, const float* __restrict__ sqn_dense,
+                                                           const float* __restrict__ sqn_pieces,
+                                                           const int32_t* __restrict__ use_dense, float clip, float lr_t,
+                                                           float b1, float b2, float eps) {
+  const float sc = clip_factor(sqn_dense, sqn_pieces, use_dense, slot, clip);
+  const int c4 = cols >> 2;
+  const long total = rows * c4;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    const long p = r * cols + c;
+    float* wp = w + r * ldw + c;
+    float4 ww = ld4(wp), mm = ld4(m + p), vv = ld4(v + p);
+    adam4(ww, ld4(g + p), mm, vv, sc, lr_t, b1, b2, eps);
+    st4(wp, ww); st4(m + p, mm); st4(v + p, vv);
+  }
+}
+
+int seg_grid_x(const tcar_segments_t* s) {
+  int64_t mx = 0;
+  for (int i = 0; i < s->nseg; ++i) mx = s->len[i] > mx ? s->len[i] : mx;
+  return (int)((mx + 4095) / 4096);
+}
+int check_segs(const tcar_segments_t* s) {
+  if (!s || s->nseg < 0 || s->nseg > TCAR_NSLOT) return TCAR_E_ARG;
+  for (int i = 0; i < s->nseg; ++i)
+    if ((s->off[i] & 3) || (s->len[i] & 3) || s->slot[i] < 0 || s->slot[i] >= TCAR_NSLOT) return TCAR_E_ARG;
+  return TCAR_OK;
+}
+
+}  // namespace
+
+extern "C" int tcar_sqnorm(const float* g, const tcar_segments_t* segs, float* sqn_dense, void* stream) {
+  if (check_segs(segs) || !g || !sqn_dense || !tcar_aligned16(g)) return TCAR_E_ARG;
+  if (segs->nseg == 0) return TCAR_OK;
+  SegArgs a;
+  a.s = *segs;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_clip_adam(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs,
+                              const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip,
+                              float lr_t, float b1, float b2, float eps, void* stream) {
+  if (check_segs(segs) || !w || !g || !m || !v || !sqn_dense || !sqn_pieces || !use_dense) return TCAR_E_ARG;
+  if (segs->nseg == 0) return TCAR_OK;
+  SegArgs a;
+  a.s = *segs;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
+                     a, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m, float* v, int64_t rows, int32_t cols,
+                                 int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense,
+                                 float clip, float lr_t, float b1, float b2, float eps, void* stream) {
+  if (!w || !g || !m || !v || rows <= 0 || cols <= 0 || (cols & 3) || (ldw & 3) || slot < 0 || slot >= TCAR_NSLOT)
+    return TCAR_E_ARG;
+  long total = rows * (cols >> 2);
+  int grid = (int)((total + 256 * 4 - 1) / (256 * 4));
+  if (grid > 4096) grid = 4096;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(clip_adam_2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (long)ldw, g, m, v, (long)rows,
+                     (int)cols, (int)slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_abi_version(void) { return 1; }

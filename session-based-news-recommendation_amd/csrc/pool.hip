@@ -1,0 +1,266 @@
+// Session attention pools (forward + backward) for gfx950.
+//
+// Reference: count_alpha_m / multi_attention_layer (modules.py:103-152), count_alpha_s / single_attention_layer
+// (modules.py:72-101), normalizer (util.py:92-100: exp(x) / (sum exp(x) + 1e-9), NO max subtraction).
+//
+//   e1[t] = sum_j sigmoid(pre1[t,j]) * w_res1[j]         alpha1 = expnorm_t(e1)      modules.py:132-135
+//   e2[t] = X_ic[t] . q                                  alpha2 = expnorm_t(e2)      modules.py:140-141
+//   e3[t] = sum_j sigmoid(pre2[t,j]) * w_res2[j]         alpha_t = expnorm_t(e3)     modules.py:97-100
+//   pooled_ic = sum_t (alpha1+alpha2)[t] X_ic[t]         pooled_t = sum_t alpha_t[t] X_pt[t]   (:116-117, :82-83)
+//
+// A batch holds sessions of ONE length T <= 40 (sampler.py:40-49): no padding, no mask.  One 64-lane wave owns
+// one session; the T scores live one per lane, the exp-normalisation is a wave reduction, and the weighted sum
+// re-reads the T rows (L2 hits: they were just read for the scores).  Everything stays in registers — no LDS,
+// no cross-wave traffic.  This is the only softmax-attention on the executed graph (a single query per session),
+// far too small for MFMA: it is bound by the row reads.
+#include "tcar_common.h"
+
+namespace {
+
+struct PoolArgs {
+  int B, T, H, ldh, ldt;
+  const float* x_icp; const float* x_pt; const float* pre1; const float* pre2; const float* q;
+  const float* w1; const float* w2; const float* alpha_in; const float* dpooled;
+  float* pooled; float* alpha;
+  float* dx_icp; float* dx_pt; float* dq; float* dpre1; float* dpre2; float* g_w1; float* g_w2;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float4 sig4(float4 v) {
+  return make_float4(sigmoidf_(v.x), sigmoidf_(v.y), sigmoidf_(v.z), sigmoidf_(v.w));
+}
+// zero the lanes of a float4 whose column index is >= H (padding columns j in [H, ldh))
+__device__ __forceinline__ float4 mask4(float4 v, int col, int H) {
+  return make_float4(col + 0 < H ? v.x : 0.f, col + 1 < H ? v.y : 0.f, col + 2 < H ? v.z : 0.f, col + 3 < H ? v.w : 0.f);
+}
+
+template <int NCH>  // NCH = ceil(ldh/256)
+__global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= a.B) return;
+  const int T = a.T, H = a.H, ldh = a.ldh, ldt = a.ldt;
+  const int ic = 2 * ldh, pt = 5 * ldt, ek = ic + pt;
+  const int BT = a.B * T;
+  const int ptl = pt >> 2;   // float4 lanes of a publish-time row (80 for ldt = 64)
+
+  // per-lane constants
+  float4 w1[NCH], w2[NCH], qa[NCH], qb[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    const bool ok = col < ldh;
+    w1[c] = ok ? ld4(a.w1 + col) : zero4();
+    w2[c] = ok ? ld4(a.w2 + col) : zero4();
+    qa[c] = ok ? ld4(a.q + (long)b * ic + col) : zero4();
+    qb[c] = ok ? ld4(a.q + (long)b * ic + ldh + col) : zero4();
+  }
+  float e1 = 0.f, e2 = 0.f, e3 = 0.f;     // lane t keeps the scores of position t
+  for (int t = 0; t < T; ++t) {
+    const long row = (long)b * T + t;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) {
+        s1 += dot4(mask4(sig4(ld4(a.pre1 + row * ldh + col)), col, H), w1[c]);
+        s3 += dot4(mask4(sig4(ld4(a.pre2 + row * ldh + col)), col, H), w2[c]);
+        s2 += dot4(ld4(a.x_icp + row * ic + col), qa[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), qb[c]);
+      }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if (lane == t) { e1 = s1; e2 = s2; e3 = s3; }
+  }
+  const bool on = lane < T;
+  const float x1 = on ? expf(e1) : 0.f, x2 = on ? expf(e2) : 0.f, x3 = on ? expf(e3) : 0.f;
+  const float a1 = x1 / (wave_sum(x1) + 1e-9f);
+  const float a2 = x2 / (wave_sum(x2) + 1e-9f);
+  const float a3 = x3 / (wave_sum(x3) + 1e-9f);
+  if (on) {
+    a.alpha[(long)b * T + lane] = a1;
+    a.alpha[(long)BT + (long)b * T + lane] = a2;
+    a.alpha[2L * BT + (long)b * T + lane] = a3;
+  }
+  const float a12 = a1 + a2;
+  float4 pa[NCH], pb[NCH];
+  float4 pp[2];                // publish-time row: up to 2 float4 per lane (pt <= 512 floats)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) { pa[c] = zero4(); pb[c] = zero4(); }
+  pp[0] = zero4(); pp[1] = zero4();
+  for (int t = 0; t < T; ++t) {
+    const long row = (long)b * T + t;
+    const float wt = __shfl(a12, t), wt3 = __shfl(a3, t);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) {
+        pa[c] = fma4(ld4(a.x_icp + row * ic + col), wt, pa[c]);
+        pb[c] = fma4(ld4(a.x_icp + row * ic + ldh + col), wt, pb[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int l4 = c * 64 + lane;
+      if (l4 < ptl) pp[c] = fma4(ld4(a.x_pt + row * pt + l4 * 4), wt3, pp[c]);
+    }
+  }
+  float* o = a.pooled + (long)b * ek;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    if (col < ldh) { st4(o + col, pa[c]); st4(o + ldh + col, pb[c]); }
+  }
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int l4 = c * 64 + lane;
+    if (l4 < ptl) st4(o + ic + l4 * 4, pp[c]);
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
+  __shared__ float gw_lds[2 * 512];     // per-workgroup partial sums of d w_res1 | d w_res2
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int b = blockIdx.x * 4 + (tid >> 6);
+  const int T = a.T, H = a.H, ldh = a.ldh, ldt = a.ldt;
+  const int ic = 2 * ldh, pt = 5 * ldt, ek = ic + pt;
+  const int BT = a.B * T;
+  const int ptl = pt >> 2;
+  for (int i = tid; i < 2 * ldh; i += 256) gw_lds[i] = 0.f;
+  __syncthreads();
+  if (b < a.B) {
+    float4 w1[NCH], w2[NCH], qa[NCH], qb[NCH], da[NCH], db[NCH];
+    float4 dp[2];
+    const float* dpo = a.dpooled + (long)b * ek;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      const bool ok = col < ldh;
+      w1[c] = ok ? ld4(a.w1 + col) : zero4();
+      w2[c] = ok ? ld4(a.w2 + col) : zero4();
+      qa[c] = ok ? ld4(a.q + (long)b * ic + col) : zero4();
+      qb[c] = ok ? ld4(a.q + (long)b * ic + ldh + col) : zero4();
+      da[c] = ok ? ld4(dpo + col) : zero4();
+      db[c] = ok ? ld4(dpo + ldh + col) : zero4();
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int l4 = c * 64 + lane;
+      dp[c] = (l4 < ptl) ? ld4(dpo + ic + l4 * 4) : zero4();
+    }
+    const bool on = lane < T;
+    const float a1 = on ? a.alpha_in[(long)b * T + lane] : 0.f;
+    const float a2 = on ? a.alpha_in[(long)BT + (long)b * T + lane] : 0.f;
+    const float a3 = on ? a.alpha_in[2L * BT + (long)b * T + lane] : 0.f;
+    // pass A: d alpha[t] = dpooled . X[t]   (alpha1 and alpha2 share it: alpha = alpha1 + alpha2)
+    float dal = 0.f, dal3 = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const long row = (long)b * T + t;
+      float s = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh)
+          s += dot4(ld4(a.x_icp + row * ic + col), da[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), db[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int l4 = c * 64 + lane;
+        if (l4 < ptl) s3 += dot4(ld4(a.x_pt + row * pt + l4 * 4), dp[c]);
+      }
+      s = wave_sum(s); s3 = wave_sum(s3);
+      if (lane == t) { dal = s; dal3 = s3; }
+    }
+    // exp-normaliser backward: de = alpha * (dalpha - sum_s dalpha_s alpha_s)   (epsilon included exactly)
+    const float de1 = a1 * (dal - wave_sum(dal * a1));
+    const float de2 = a2 * (dal - wave_sum(dal * a2));
+    const float de3 = a3 * (dal3 - wave_sum(dal3 * a3));
+    const float a12 = a1 + a2;
+    // pass B
+    float4 dqa[NCH], dqb[NCH], gw1[NCH], gw2[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { dqa[c] = zero4(); dqb[c] = zero4(); gw1[c] = zero4(); gw2[c] = zero4(); }
+    for (int t = 0; t < T; ++t) {
+      const long row = (long)b * T + t;
+      const float wt = __shfl(a12, t), wt3 = __shfl(a3, t);
+      const float g1 = __shfl(de1, t), g2 = __shfl(de2, t), g3 = __shfl(de3, t);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) {
+          const float4 xa = ld4(a.x_icp + row * ic + col), xb = ld4(a.x_icp + row * ic + ldh + col);
+          st4(a.dx_icp + row * ic + col, fma4(qa[c], g2, scale4(da[c], wt)));
+          st4(a.dx_icp + row * ic + ldh + col, fma4(qb[c], g2, scale4(db[c], wt)));
+          dqa[c] = fma4(xa, g2, dqa[c]);
+          dqb[c] = fma4(xb, g2, dqb[c]);
+          const float4 s1 = mask4(sig4(ld4(a.pre1 + row * ldh + col)), col, H);
+          const float4 s2 = mask4(sig4(ld4(a.pre2 + row * ldh + col)), col, H);
+          gw1[c] = fma4(s1, g1, gw1[c]);
+          gw2[c] = fma4(s2, g3, gw2[c]);
+          // dpre = de * w * sig * (1 - sig)   (0 in padding columns: w = 0 there and sig is masked)
+          st4(a.dpre1 + row * ldh + col,
+              make_float4(g1 * w1[c].x * s1.x * (1.f - s1.x), g1 * w1[c].y * s1.y * (1.f - s1.y),
+                          g1 * w1[c].z * s1.z * (1.f - s1.z), g1 * w1[c].w * s1.w * (1.f - s1.w)));
+          st4(a.dpre2 + row * ldh + col,
+              make_float4(g3 * w2[c].x * s2.x * (1.f - s2.x), g3 * w2[c].y * s2.y * (1.f - s2.y),
+                          g3 * w2[c].z * s2.z * (1.f - s2.z), g3 * w2[c].w * s2.w * (1.f - s2.w)));
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int l4 = c * 64 + lane;
+        if (l4 < ptl) st4(a.dx_pt + row * pt + l4 * 4, scale4(dp[c], wt3));
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) {
+        st4(a.dq + (long)b * ic + col, dqa[c]);
+        st4(a.dq + (long)b * ic + ldh + col, dqb[c]);
+        atomic_add4(gw_lds + col, gw1[c]);
+        atomic_add4(gw_lds + ldh + col, gw2[c]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * ldh; i += 256) {
+    const float v = gw_lds[i];
+    if (v != 0.f) atomicAdd((i < ldh ? a.g_w1 + i : a.g_w2 + (i - ldh)), v);
+  }
+}
+
+}  // namespace
+
+extern "C" int tcar_attn_pool_fwd(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                                  const float* pre1, const float* pre2, const float* q, const float* w_res1,
+                                  const float* w_res2, float* pooled, float* alpha, void* stream) {
+  if (!d || B <= 0 || T <= 0 || T > TCAR_POS_VOCAB || (d->ldh & 63) || d->ldh > 512 || 5 * d->ldt > 512) return TCAR_E_ARG;
+  PoolArgs a{};
+  a.B = B; a.T = T; a.H = d->H; a.ldh = d->ldh; a.ldt = d->ldt;
+  a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1; a.pre2 = pre2; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
+  a.pooled = pooled; a.alpha = alpha;
+  const int grid = (B + 3) / 4;
+  if (d->ldh <= 256) hipLaunchKernelGGL(attn_pool_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_pool_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_attn_pool_bwd(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                                  const float* pre1, const float* pre2, const float* q, const float* w_res1,
+                                  const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
+                                  float* dx_pt, float* dq, float* dpre1, float* dpre2, float* g_wres1,
+                                  float* g_wres2, void* stream) {
+  if (!d || B <= 0 || T <= 0 || T > TCAR_POS_VOCAB || (d->ldh & 63) || d->ldh > 512 || 5 * d->ldt > 512) return TCAR_E_ARG;
+  PoolArgs a{};
+  a.B = B; a.T = T; a.H = d->H; a.ldh = d->ldh; a.ldt = d->ldt;
+  a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1; a.pre2 = pre2; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
+  a.alpha_in = alpha; a.dpooled = dpooled;
+  a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dq = dq; a.dpre1 = dpre1; a.dpre2 = dpre2; a.g_w1 = g_wres1; a.g_w2 = g_wres2;
+  const int grid = (B + 3) / 4;
+  if (d->ldh <= 256) hipLaunchKernelGGL(attn_pool_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(attn_pool_bwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}

@@ -1,0 +1,252 @@
+// Scoring-side kernels for gfx950: softmax cross-entropy over the full catalog, the sampled negative-feedback
+// term, activation/bias backward, and the evaluation rank / top-k.
+//
+// Reference: model_combine.py:138-147 (logits, sparse softmax CE, neg_logits / neg_feedback, loss),
+// modules.py:52-54 (bias + activation), util.py:8-18 and model_combine.py:301 (rank, top-20).
+// All four are HBM/L2-bandwidth bound passes over [B, N] or gathered rows; they use 16-byte accesses with one
+// workgroup (or wave) per session and wave-shuffle reductions.
+#include "tcar_common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  const float r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_max_256(float v, float* sh) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  const float r = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  return r;
+}
+
+// ---- sparse softmax cross entropy + gradient (model_combine.py:145) ------------------------------------
+// One workgroup per session.  Pass 1: online (max, sum-exp) over the row.  Pass 2: overwrite the row with
+// softmax - onehot (the gradient of the SUM of the per-session losses, model_combine.py:147,156).
+__global__ __launch_bounds__(256) void softmax_ce_kernel(int N, float* __restrict__ logits, long ld,
+                                                         const int32_t* __restrict__ label, float* __restrict__ ce) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float* row = logits + (long)b * ld;
+  const int n4 = (N + 3) >> 2;
+  float m = -INFINITY, s = 0.f;
+  for (int i = tid; i < n4; i += 256) {
+    float4 v = ld4(row + i * 4);
+    const int c = i * 4;
+    if (c + 1 >= N) v.y = -INFINITY;
+    if (c + 2 >= N) v.z = -INFINITY;
+    if (c + 3 >= N) v.w = -INFINITY;
+    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    const float mn = fmaxf(m, mx);
+    s = s * expf(m - mn) + expf(v.x - mn) + expf(v.y - mn) + expf(v.z - mn) + expf(v.w - mn);
+    m = mn;
+  }
+  const float gm = block_max_256(m, sh);
+  s = (m == -INFINITY) ? 0.f : s * expf(m - gm);
+  const float gs = block_sum_256(s, sh);
+  const float lse = gm + logf(gs);
+  const int lab = clampi(label[b], 0, N - 1);
+  if (tid == 0) ce[b] = lse - row[lab];
+  __syncthreads();                       // the label logit is read before the row is overwritten
+  const int l4 = (int)(ld >> 2);
+  for (int i = tid; i < l4; i += 256) {
+    const int c = i * 4;
+    float4 v = ld4(row + c);
+    float4 o;
+    o.x = (c + 0 < N) ? expf(v.x - lse) - (c + 0 == lab ? 1.f : 0.f) : 0.f;
+    o.y = (c + 1 < N) ? expf(v.y - lse) - (c + 1 == lab ? 1.f : 0.f) : 0.f;
+    o.z = (c + 2 < N) ? expf(v.z - lse) - (c + 2 == lab ? 1.f : 0.f) : 0.f;
+    o.w = (c + 3 < N) ? expf(v.w - lse) - (c + 3 == lab ? 1.f : 0.f) : 0.f;
+    st4(row + c, o);
+  }
+}
+
+// ---- negative-feedback term (model_combine.py:142-143) ---------------------------------------------------
+// One wave per session: gathers K item|content rows of E (2 x 16 B per lane per row), dots them with attout_ic.
+template <int NCH>
+__global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items, int ldh, int ek,
+                                                       const float* __restrict__ E, const int32_t* __restrict__ neg,
+                                                       const float* __restrict__ attout, float weight,
+                                                       float* __restrict__ neg_fb, float* __restrict__ dattout,
+                                                       float* __restrict__ g_item) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int ic = 2 * ldh;
+  float4 ua[NCH], ub[NCH], sa[NCH], sb[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    const bool ok = col < ldh;
+    ua[c] = ok ? ld4(attout + (long)b * ek + col) : zero4();
+    ub[c] = ok ? ld4(attout + (long)b * ek + ldh + col) : zero4();
+    sa[c] = zero4(); sb[c] = zero4();
+  }
+  float x = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int n = clampi(neg[(long)b * K + k], 0, n_items - 1);
+    const float* e = E + (long)n * ek;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) {
+        const float4 ra = ld4(e + col), rb = ld4(e + ldh + col);
+        x += dot4(ra, ua[c]) + dot4(rb, ub[c]);
+        sa[c] = add4(sa[c], ra); sb[c] = add4(sb[c], rb);
+      }
+    }
+  }
+  x = wave_sum(x);                                     // sum over K BEFORE the sigmoid (model_combine.py:142)
+  const float sg = 1.0f / (1.0f + expf(-x));
+  const float om = 1.0f - sg;
+  if (lane == 0) neg_fb[b] = -logf(om + 1e-24f);
+  const float coef = weight * sg * om / (om + 1e-24f);  // weight * d/dx[-log(1 - sigmoid(x) + 1e-24)]
+  if (dattout) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) {
+        float* p = dattout + (long)b * ek + col;
+        st4(p, fma4(sa[c], coef, ld4(p)));
+        st4(p + ldh, fma4(sb[c], coef, ld4(p + ldh)));
+      }
+    }
+  }
+  if (g_item) {
+    for (int k = 0; k < K; ++k) {
+      const int n = clampi(neg[(long)b * K + k], 0, n_items - 1);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) atomic_add4(g_item + (long)n * ldh + col, scale4(ua[c], coef));
+      }
+    }
+  }
+}
+
+// ---- dz = dy * act'(y), bias_grad = column sums (modules.py:52-54 backward) -------------------------------
+// grid.x = ncol/64 column blocks; 256 threads = 64 columns x 4 row phases.
+__global__ __launch_bounds__(256) void dact_colsum_kernel(int M, int ncol, long ld, const float* __restrict__ y,
+                                                          float* __restrict__ dy, float* __restrict__ bias_grad, int act) {
+  __shared__ float sh[256];
+  const int tid = threadIdx.x, cl = tid & 63, rp = tid >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  float s = 0.f;
+  if (col < ncol) {
+    for (int r = rp; r < M; r += 4) {
+      const long i = (long)r * ld + col;
+      const float yy = y[i];
+      float g = dy[i];
+      g = (act == 1) ? (yy > 0.f ? g : 0.f) : (act == 2 ? g * (1.f - yy * yy) : g);
+      dy[i] = g;
+      s += g;
+    }
+  }
+  sh[tid] = s;
+  __syncthreads();
+  if (rp == 0 && col < ncol && bias_grad) bias_grad[col] = sh[cl] + sh[64 + cl] + sh[128 + cl] + sh[192 + cl];
+}
+
+// ---- rank of the label and top-k (util.py:13-17, model_combine.py:301) -----------------------------------
+// One workgroup per session.  rank = 1 + #{n: x[n] > x[label]}.  top-k by k rounds of block-wide arg-max over
+// keys ordered by (score desc, index desc) — the order of np.argsort(x)[::-1]; the row stays in L2 between
+// rounds.
+__global__ __launch_bounds__(256) void rank_topk_kernel(int N, const float* __restrict__ logits, long ld,
+                                                        const int32_t* __restrict__ label, int k,
+                                                        int32_t* __restrict__ rank, int32_t* __restrict__ topk) {
+  __shared__ float shv[4];
+  __shared__ int shi[4];
+  __shared__ float sh[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* row = logits + (long)b * ld;
+  const int lab = clampi(label[b], 0, N - 1);
+  const float xl = row[lab];
+  float cnt = 0.f;
+  for (int i = tid; i < N; i += 256) cnt += (row[i] > xl) ? 1.f : 0.f;
+  const float tot = block_sum_256(cnt, sh);
+  if (tid == 0) rank[b] = (int)tot + 1;
+  float pv = INFINITY;
+  int pi = N;                       // previous pick; next key must be strictly "smaller" than (pv, pi)
+  const int kk = k < N ? k : N;
+  for (int r = 0; r < k; ++r) {
+    if (r >= kk) { if (tid == 0) topk[(long)b * k + r] = -1; continue; }
+    float bv = -INFINITY;
+    int bi = -1;
+    for (int i = tid; i < N; i += 256) {
+      const float v = row[i];
+      const bool eligible = (v < pv) || (v == pv && i < pi);
+      const bool better = (v > bv) || (v == bv && i > bi);
+      if (eligible && better) { bv = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi > bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { shv[w] = bv; shi[w] = bi; }
+    __syncthreads();
+    float fv = shv[0];
+    int fi = shi[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (shv[j] > fv || (shv[j] == fv && shi[j] > fi)) { fv = shv[j]; fi = shi[j]; }
+    __syncthreads();
+    if (tid == 0) topk[(long)b * k + r] = fi;
+    pv = fv; pi = fi;
+  }
+}
+
+}  // namespace
+
+extern "C" int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce) return TCAR_E_ARG;
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, ce);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg,
+                             const float* attout, float weight, float* neg_fb, float* dattout, float* g_item,
+                             void* stream) {
+  if (!d || B <= 0 || K <= 0) return TCAR_OK;
+  if (!E || !neg || !attout || !neg_fb || (d->ldh & 63) || d->ldh > 512) return TCAR_E_ARG;
+  const int ek = 2 * d->ldh + 5 * d->ldt;
+  const int grid = (B + 3) / 4;
+  if (d->ldh <= 256)
+    hipLaunchKernelGGL(neg_term_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
+                       neg, attout, weight, neg_fb, dattout, g_item);
+  else
+    hipLaunchKernelGGL(neg_term_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
+                       neg, attout, weight, neg_fb, dattout, g_item);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_dact_colsum(int M, int ncol, int64_t ld, const float* y, float* dy, float* bias_grad, int act,
+                                void* stream) {
+  if (M <= 0 || ncol <= 0) return TCAR_OK;
+  if (!y || !dy) return TCAR_E_ARG;
+  hipLaunchKernelGGL(dact_colsum_kernel, dim3((ncol + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, ncol, (long)ld, y,
+                     dy, bias_grad, act);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_rank_topk(int B, int N, const float* logits, int64_t ld, const int32_t* label, int k,
+                              int32_t* rank, int32_t* topk, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (N <= 0 || k < 0 || !logits || !label || !rank || (k > 0 && !topk)) return TCAR_E_ARG;
+  hipLaunchKernelGGL(rank_topk_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, k, rank, topk);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}

@@ -1,0 +1,63 @@
+// Shared device helpers for the TCAR gfx950 kernels (wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tcar_hip.h"
+
+#define TCAR_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return TCAR_E_LAUNCH;              \
+  } while (0)
+
+static inline bool tcar_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// sum over aligned groups of `width` consecutive lanes (width = 16, 32 or 64)
+__device__ __forceinline__ float group_sum(float v, int width) {
+  for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 fma4(float4 a, float s, float4 c) {
+  return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
+  atomicAdd(p + 0, v.x);
+  atomicAdd(p + 1, v.y);
+  atomicAdd(p + 2, v.z);
+  atomicAdd(p + 3, v.w);
+}
+
+// tf.clip_by_norm(row, 1.0): y = x / max(||x||, 1).  scale for a row with sum of squares ss.
+__device__ __forceinline__ float clip_scale(float ss) { return ss > 1.0f ? 1.0f / sqrtf(ss) : 1.0f; }
+// backward of the row clip: gx = gy/n - x (x.gy)/n^3 when n > 1, identity otherwise.
+// returns (a, b) with gx = a*gy - b*x
+__device__ __forceinline__ void clip_bwd_coef(float ss, float d, float& a, float& b) {
+  if (ss > 1.0f) {
+    float inv = 1.0f / sqrtf(ss);
+    a = inv;
+    b = d * inv * inv * inv;
+  } else {
+    a = 1.0f;
+    b = 0.0f;
+  }
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

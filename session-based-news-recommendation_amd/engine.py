@@ -1,0 +1,506 @@
+"""Device-resident TCAR model state and the per-batch step, driving the C-ABI of include/tcar_hip.h.
+
+PyTorch is used here for three things only: device memory (tensors as buffers), the current HIP stream, and
+(in `dp.py`) torch.distributed.  Every arithmetic operation of the step is a hand-written gfx950 kernel behind
+`libtcar_hip.so`; there is no eager/CPU fallback — constructing an engine without the library or a GPU raises.
+
+HBM layout (fp32, "padded-concat space", see include/tcar_hip.h):
+  E        [Npad, ek]   candidate matrix: item table | frozen content | clipped candidate time vectors.
+                        The trainable item table LIVES in E[:, 0:ldh] (no per-step concat / copy,
+                        model_combine.py:135-136); Npad = N rounded up to 64, padding rows are zero.
+  W/G/M/V  flat arenas  the other 22 trainable variables (padded), their gradients and Adam moments, at identical
+                        offsets; the tables that receive atomic adds come first so one memset clears them.
+  Gi/Mi/Vi [N, ldh]     item-table gradient and Adam moments.
+  work     per-batch activations sized for the largest (B, T) seen.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Batch, Dims, Grads, Segments, Tables, check
+
+TIME_NAMES = ["month_embedding", "day_embedding", "week_embedding", "hour_embedding", "minute_embedding"]
+TIME_VOCAB = [13, 32, 8, 25, 61]
+# TF creation order of the 23 trainable variables (model_combine.py:52-128) = squared-norm slot index
+VAR_ORDER = ["item_emb", "dec_pos"] + TIME_NAMES + ["duration_embedding",
+             "multi_attention/input_linear_trans/w_3d", "multi_attention/cont_linear_trans/w_3d",
+             "multi_attention/inter_linear_trans/w_3d", "multi_attention/res_linear_trans/w_3d",
+             "multi_attention/query_trans1/w1", "multi_attention/query_trans1/b1",
+             "multi_attention/query_trans2/w1", "multi_attention/query_trans2/b1",
+             "attout_item_cont_trans/w1", "attout_item_cont_trans/b1",
+             "cont_attention/input_linear_trans/w_3d", "cont_attention/cont_linear_trans/w_3d",
+             "cont_attention/res_linear_trans/w_3d", "attout_pt_trans/w1", "attout_pt_trans/b1"]
+SLOT = {n: i for i, n in enumerate(VAR_ORDER)}
+
+
+def _ru(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Geometry:
+    def __init__(self, n_items: int, H: int, Ht: int):
+        self.N, self.H, self.Ht = int(n_items), int(H), int(Ht)
+        self.ldh = _ru(H, 64)
+        self.ldt = 64 if Ht <= 64 else (128 if Ht <= 128 else 256)
+        if self.ldh > 512 or Ht > 256 or 5 * self.ldt > 512:
+            raise ValueError("unsupported hidden sizes for the gfx950 kernels: H<=512, Ht<=64 (5*ldt<=512)")
+        self.ic, self.pt, self.ct = 2 * self.ldh, 5 * self.ldt, 2 * self.ldt
+        self.ek = self.ic + self.pt
+        self.Npad = _ru(self.N, 64)
+
+    def idx(self, kind: str) -> np.ndarray:
+        """logical index -> padded index for a dimension of the given kind."""
+        H, Ht, ldh, ldt = self.H, self.Ht, self.ldh, self.ldt
+        if kind == "H":
+            return np.arange(H)
+        if kind == "2H":
+            return np.concatenate([np.arange(H), ldh + np.arange(H)])
+        if kind == "T":
+            return np.arange(Ht)
+        if kind == "2T":
+            return np.concatenate([np.arange(Ht) + k * ldt for k in range(2)])
+        if kind == "5T":
+            return np.concatenate([np.arange(Ht) + k * ldt for k in range(5)])
+        if kind.startswith("V"):
+            return np.arange(int(kind[1:]))
+        raise KeyError(kind)
+
+    def padded(self, kind: str) -> int:
+        return {"H": self.ldh, "2H": self.ic, "T": self.ldt, "2T": self.ct, "5T": self.pt}.get(kind) or int(kind[1:])
+
+
+# (short name, reference variable name, row kind, col kind or None for vectors); order = arena order.
+# First block = accumulated with atomics (zeroed every step); time tables + dur contiguous (tcar_grads_t).
+ARENA = [
+    ("pos", "dec_pos", "V40", "H"),
+    ("month", "month_embedding", "V13", "T"), ("day", "day_embedding", "V32", "T"),
+    ("week", "week_embedding", "V8", "T"), ("hour", "hour_embedding", "V25", "T"),
+    ("minute", "minute_embedding", "V61", "T"), ("dur", "duration_embedding", "V11", "T"),
+    ("m_wres", "multi_attention/res_linear_trans/w_3d", "H", None),
+    ("s_wres", "cont_attention/res_linear_trans/w_3d", "H", None),
+    # ---- written by GEMM / column-sum epilogues (no zeroing needed)
+    ("m_win", "multi_attention/input_linear_trans/w_3d", "2H", "H"),
+    ("m_wc", "multi_attention/cont_linear_trans/w_3d", "H", "H"),
+    ("m_wint", "multi_attention/inter_linear_trans/w_3d", "T", "H"),
+    ("q1_w", "multi_attention/query_trans1/w1", "2T", "H"), ("q1_b", "multi_attention/query_trans1/b1", "H", None),
+    ("q2_w", "multi_attention/query_trans2/w1", "H", "2H"), ("q2_b", "multi_attention/query_trans2/b1", "2H", None),
+    ("o_w", "attout_item_cont_trans/w1", "2H", "2H"), ("o_b", "attout_item_cont_trans/b1", "2H", None),
+    ("s_win", "cont_attention/input_linear_trans/w_3d", "5T", "H"),
+    ("s_wc", "cont_attention/cont_linear_trans/w_3d", "H", "H"),
+    ("ot_w", "attout_pt_trans/w1", "5T", "5T"), ("ot_b", "attout_pt_trans/b1", "5T", None),
+]
+N_ATOMIC = 9
+
+
+class TcarEngine:
+    def __init__(self, params: Dict[str, np.ndarray], content_emb: np.ndarray, mwdhm: np.ndarray, lr: float = 1e-3,
+                 max_grad: Optional[float] = 150.0, neg_weight: float = 0.01, device: str = "cuda:0",
+                 splitk: int = 16):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.TcarError("TcarEngine needs an MI355X (no CPU fallback)")
+        self.dev = torch.device(device)
+        N, H = content_emb.shape[0] - 1, content_emb.shape[1]
+        Ht = params["month_embedding"].shape[1]
+        self.geo = g = Geometry(N, H, Ht)
+        self.lr, self.max_grad, self.neg_weight = float(lr), max_grad, float(neg_weight)
+        self.b1, self.b2, self.eps = 0.9, 0.999, 1e-8
+        self.b1_pow, self.b2_pow = np.float32(self.b1), np.float32(self.b2)
+        self.step = 0
+        self.splitk = splitk
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        # arena layout ------------------------------------------------------------------------------------
+        self.seg = OrderedDict()
+        off = 0
+        for short, ref, rk, ck in ARENA:
+            rows = g.padded(rk)
+            cols = g.padded(ck) if ck else 1
+            n = rows * cols
+            self.seg[short] = dict(off=off, rows=rows, cols=cols, n=n, ref=ref, rk=rk, ck=ck, slot=SLOT[ref])
+            off += n
+        self.arena_n = off
+        self.atomic_n = sum(self.seg[a[0]]["n"] for a in ARENA[:N_ATOMIC])
+        self.W = torch.zeros(off, **f32)
+        self.G = torch.zeros(off, **f32)
+        self.M = torch.zeros(off, **f32)
+        self.V = torch.zeros(off, **f32)
+        self.E = torch.zeros(g.Npad, g.ek, **f32)
+        self.Gi = torch.zeros(g.N, g.ldh, **f32)
+        self.Mi = torch.zeros(g.N, g.ldh, **f32)
+        self.Vi = torch.zeros(g.N, g.ldh, **f32)
+        self.sqn_dense = torch.zeros(_lib.NSLOT, **f32)
+        self.sqn_pieces = torch.zeros(_lib.NSLOT, **f32)
+        use = np.ones(_lib.NSLOT, dtype=np.int32)
+        for n in ["dec_pos", "duration_embedding"] + TIME_NAMES:
+            use[SLOT[n]] = 0                      # tables: IndexedSlices pieces only
+        self.use_dense = torch.tensor(use, device=self.dev)
+        self.mwdhm = torch.tensor(np.ascontiguousarray(mwdhm, dtype=np.int32), device=self.dev)
+        self.dims = Dims(g.N, g.H, g.Ht, g.ldh, g.ldt)
+        # segment tables for the optimizer kernels
+        self.segs_all = self._segments([a[0] for a in ARENA])
+        self.segs_dense = self._segments([a[0] for a in ARENA if self.use_dense_np(a[1])])
+        self._use_np = use
+        self.load_params(params, content_emb)
+        self.work_rows = 0
+        self.work_B = 0
+        self._time_dirty = True
+        self.pin = None
+
+    def use_dense_np(self, ref: str) -> bool:
+        return ref not in (["dec_pos", "duration_embedding"] + TIME_NAMES)
+
+    def _segments(self, names) -> Segments:
+        s = Segments()
+        s.nseg = len(names)
+        for i, n in enumerate(names):
+            sg = self.seg[n]
+            s.off[i], s.len[i], s.slot[i] = sg["off"], sg["n"], sg["slot"]
+        return s
+
+    # --------------------------------------------------------------------------------- parameter (un)packing
+    def load_params(self, params: Dict[str, np.ndarray], content_emb: Optional[np.ndarray] = None):
+        g = self.geo
+        W = np.zeros(self.arena_n, dtype=np.float32)
+        for short, sg in self.seg.items():
+            src = np.asarray(params[sg["ref"]], dtype=np.float32)
+            dst = W[sg["off"]:sg["off"] + sg["n"]].reshape(sg["rows"], sg["cols"])
+            ri = g.idx(sg["rk"])
+            if sg["ck"] is None:
+                dst[ri, 0] = src.reshape(-1)
+            else:
+                dst[np.ix_(ri, g.idx(sg["ck"]))] = src
+        self.W.copy_(torch.from_numpy(W))
+        E = np.zeros((g.Npad, g.ek), dtype=np.float32)
+        E[:g.N, :g.H] = np.asarray(params["item_emb"], dtype=np.float32)[1:]
+        if content_emb is not None:
+            self._content = np.asarray(content_emb, dtype=np.float32)
+        E[:g.N, g.ldh:g.ldh + g.H] = self._content[1:]
+        self.E.copy_(torch.from_numpy(E))
+        self._item_row0 = np.asarray(params["item_emb"], dtype=np.float32)[0].copy()
+        self._time_dirty = True
+
+    def _unpack_arena(self, flat: np.ndarray) -> "OrderedDict[str, np.ndarray]":
+        g = self.geo
+        out = {}
+        for short, sg in self.seg.items():
+            src = flat[sg["off"]:sg["off"] + sg["n"]].reshape(sg["rows"], sg["cols"])
+            ri = g.idx(sg["rk"])
+            if sg["ck"] is None:
+                v = src[ri, 0]
+                out[sg["ref"]] = v.reshape(-1, 1).copy() if sg["ref"].endswith("w_3d") else v.copy()
+            else:
+                out[sg["ref"]] = src[np.ix_(ri, g.idx(sg["ck"]))].copy()
+        return out
+
+    def export_params(self) -> "OrderedDict[str, np.ndarray]":
+        """All 23 trainable variables in the reference's shapes."""
+        g = self.geo
+        out = self._unpack_arena(self.W.cpu().numpy())
+        item = np.zeros((g.N + 1, g.H), dtype=np.float32)
+        item[0] = self._item_row0
+        item[1:] = self.E[:g.N, :g.H].cpu().numpy()
+        out["item_emb"] = item
+        return OrderedDict((k, out[k]) for k in VAR_ORDER)
+
+    def export_grads(self) -> "OrderedDict[str, np.ndarray]":
+        """Summed dense gradients of the last backward, reference shapes (item row 0 has no gradient)."""
+        g = self.geo
+        out = self._unpack_arena(self.G.cpu().numpy())
+        item = np.zeros((g.N + 1, g.H), dtype=np.float32)
+        item[1:] = self.Gi[:, :g.H].cpu().numpy()
+        out["item_emb"] = item
+        return OrderedDict((k, out[k]) for k in VAR_ORDER)
+
+    def export_sqnorms(self) -> Dict[str, float]:
+        d = self.sqn_dense.cpu().numpy().astype(np.float64)
+        p = self.sqn_pieces.cpu().numpy().astype(np.float64)
+        return {n: float(self._use_np[i] * d[i] + p[i]) for i, n in enumerate(VAR_ORDER)}
+
+    # ------------------------------------------------------------------------------------------- workspace
+    def _ensure_work(self, B: int, T: int):
+        g = self.geo
+        rows = B * T
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        if rows > self.work_rows:
+            r = rows
+            self.x_icp = torch.empty(r, g.ic, **f32)
+            self.x_pt = torch.empty(r, g.pt, **f32)
+            self.x_act = torch.empty(r, g.ldt, **f32)
+            self.pre1 = torch.empty(r, g.ldh, **f32)
+            self.pre2 = torch.empty(r, g.ldh, **f32)
+            self.alpha = torch.empty(3 * r, **f32)
+            self.dx_icp = torch.empty(r, g.ic, **f32)
+            self.dx_pt = torch.empty(r, g.pt, **f32)
+            self.dx_act = torch.empty(r, g.ldt, **f32)
+            self.dpre1 = torch.empty(r, g.ldh, **f32)
+            self.dpre2 = torch.empty(r, g.ldh, **f32)
+            self.work_rows = r
+        if B > self.work_B:
+            self.click_t = torch.empty(B, g.ct, **f32)
+            self.q1 = torch.empty(B, g.ldh, **f32)
+            self.q = torch.empty(B, g.ic, **f32)
+            self.pooled = torch.empty(B, g.ek, **f32)
+            self.attout = torch.empty(B, g.ek, **f32)
+            self.logits = torch.empty(B, g.Npad, **f32)
+            self.ce = torch.empty(B, **f32)
+            self.neg_fb = torch.zeros(B, **f32)
+            self.dattout = torch.empty(B, g.ek, **f32)
+            self.dpooled = torch.empty(B, g.ek, **f32)
+            self.dq = torch.empty(B, g.ic, **f32)
+            self.dq1 = torch.empty(B, g.ldh, **f32)
+            self.dclick = torch.empty(B, g.ct, **f32)
+            self.slabs = torch.empty(self.splitk, B, g.ek, **f32)
+            self.rank = torch.empty(B, dtype=torch.int32, device=self.dev)
+            self.topk = torch.empty(B, 20, dtype=torch.int32, device=self.dev)
+            self.work_B = B
+        if not hasattr(self, "d_et"):
+            self.d_et = torch.empty(g.N, g.pt, **f32)
+
+    # --------------------------------------------------------------------------------------------- helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    @staticmethod
+    def _p(t: torch.Tensor, off: int = 0):
+        return C.c_void_p(t.data_ptr() + 4 * off)
+
+    def _w(self, name: str):
+        return C.c_void_p(self.W.data_ptr() + 4 * self.seg[name]["off"])
+
+    def _g(self, name: str):
+        return C.c_void_p(self.G.data_ptr() + 4 * self.seg[name]["off"])
+
+    def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, act=0, beta=0, splitk=1):
+        check(self.lib.tcar_gemm_f32(layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias, act, beta, splitk,
+                                     self._stream()), "tcar_gemm_f32")
+
+    def _tables(self) -> Tables:
+        t = Tables()
+        t.E = self.E.data_ptr()
+        t.pos = self._w("pos").value
+        for k, n in enumerate(["month", "day", "week", "hour", "minute"]):
+            t.time[k] = self._w(n).value
+        t.dur = self._w("dur").value
+        return t
+
+    def _grads(self) -> Grads:
+        gr = Grads()
+        gr.g_item = self.Gi.data_ptr()
+        gr.g_pos = self._g("pos").value
+        for k, n in enumerate(["month", "day", "week", "hour", "minute"]):
+            gr.g_time[k] = self._g(n).value
+            gr.slot_time[k] = SLOT[TIME_NAMES[k]]
+        gr.g_dur = self._g("dur").value
+        gr.sqn = self.sqn_pieces.data_ptr()
+        gr.slot_item, gr.slot_pos, gr.slot_dur = SLOT["item_emb"], SLOT["dec_pos"], SLOT["duration_embedding"]
+        return gr
+
+    def _time_ptrs(self):
+        arr = (C.c_void_p * 5)()
+        for k, n in enumerate(["month", "day", "week", "hour", "minute"]):
+            arr[k] = self._w(n).value
+        return arr
+
+    # ----------------------------------------------------------------------------------------------- batch
+    def upload(self, batch: Dict[str, np.ndarray]) -> Batch:
+        """Pack the feed arrays into ONE int32 buffer, one H2D copy; returns the C batch descriptor."""
+        seq = np.ascontiguousarray(batch["seq"], dtype=np.int32)
+        B, T = seq.shape
+        if T > 40:
+            raise IndexError("session longer than the 40-row position table (model_combine.py:57)")
+        if seq.min() < 1 or seq.max() > self.geo.N:
+            raise IndexError("item id outside [1, N]")
+        neg = batch.get("neg", None)
+        K = 0 if neg is None or np.asarray(neg).size == 0 else np.asarray(neg).shape[1]
+        parts = [seq.reshape(-1)] + [np.asarray(batch[k], dtype=np.int32).reshape(-1) for k in
+                                     ("pm", "pd", "pw", "ph", "pmi", "gap", "cw", "ch", "label")]
+        if K:
+            parts.append(np.asarray(neg, dtype=np.int32).reshape(-1))
+        flat = np.concatenate(parts)
+        if self.pin is None or self.pin[0].numel() < flat.size:
+            n = max(flat.size, 1 << 16)
+            self.pin = [torch.empty(n, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self.ibufs = [torch.empty(n, dtype=torch.int32, device=self.dev) for _ in range(2)]
+            self.pin_evt = [None, None]
+            self.pin_i = 0
+        i = self.pin_i = self.pin_i ^ 1          # two staging buffers: the host may run one step ahead
+        if self.pin_evt[i] is not None:
+            self.pin_evt[i].synchronize()        # the H2D copy that last used this pinned buffer has finished
+        self.pin[i][:flat.size].copy_(torch.from_numpy(flat))
+        self.ibufs[i][:flat.size].copy_(self.pin[i][:flat.size], non_blocking=True)
+        self.pin_evt[i] = torch.cuda.Event()
+        self.pin_evt[i].record(torch.cuda.current_stream(self.dev))
+        base = self.ibufs[i].data_ptr()
+        bt = Batch()
+        bt.B, bt.T, bt.K = B, T, K
+        o = 0
+        bt.seq = base
+        o += B * T
+        for k in range(5):
+            bt.pub[k] = base + 4 * o
+            o += B * T
+        bt.gap = base + 4 * o
+        o += B * T
+        bt.cw = base + 4 * o
+        o += B
+        bt.ch = base + 4 * o
+        o += B
+        bt.label = base + 4 * o
+        o += B
+        bt.neg = (base + 4 * o) if K else None
+        return bt
+
+    # --------------------------------------------------------------------------------------------- forward
+    def forward(self, bt: Batch):
+        """model_combine.py:52-138 up to the full-catalog logits."""
+        g, lib, st = self.geo, self.lib, self._stream()
+        B, T = bt.B, bt.T
+        BT = B * T
+        self._ensure_work(B, T)
+        p = self._p
+        if self._time_dirty:
+            check(lib.tcar_cand_time_fwd(C.byref(self.dims), C.byref(self._time_ptrs()), p(self.mwdhm), p(self.E), st),
+                  "tcar_cand_time_fwd")
+            self._time_dirty = False
+        tab = self._tables()
+        check(lib.tcar_gather_clip_fwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.x_icp), p(self.x_pt),
+                                       p(self.x_act), p(self.click_t), st), "tcar_gather_clip_fwd")
+        # pre1 = X_ic W_in + X_c W_c + X_act W_int      (modules.py:126-131)
+        self.gemm(0, BT, g.ldh, g.ic, p(self.x_icp), g.ic, self._w("m_win"), g.ldh, p(self.pre1), g.ldh)
+        self.gemm(0, BT, g.ldh, g.ldh, p(self.x_icp, g.ldh), g.ic, self._w("m_wc"), g.ldh, p(self.pre1), g.ldh, beta=1)
+        self.gemm(0, BT, g.ldh, g.ldt, p(self.x_act), g.ldt, self._w("m_wint"), g.ldh, p(self.pre1), g.ldh, beta=1)
+        # pre2 = X_pt W'_in + X_c W'_c                   (modules.py:94-96)
+        self.gemm(0, BT, g.ldh, g.pt, p(self.x_pt), g.pt, self._w("s_win"), g.ldh, p(self.pre2), g.ldh)
+        self.gemm(0, BT, g.ldh, g.ldh, p(self.x_icp, g.ldh), g.ic, self._w("s_wc"), g.ldh, p(self.pre2), g.ldh, beta=1)
+        # q = tanh(relu(click_t Wq1 + b) Wq2 + b)        (modules.py:138-139)
+        self.gemm(0, B, g.ldh, g.ct, p(self.click_t), g.ct, self._w("q1_w"), g.ldh, p(self.q1), g.ldh,
+                  bias=self._w("q1_b"), act=1)
+        self.gemm(0, B, g.ic, g.ldh, p(self.q1), g.ldh, self._w("q2_w"), g.ic, p(self.q), g.ic,
+                  bias=self._w("q2_b"), act=2)
+        check(lib.tcar_attn_pool_fwd(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2),
+                                     p(self.q), self._w("m_wres"), self._w("s_wres"), p(self.pooled), p(self.alpha),
+                                     st), "tcar_attn_pool_fwd")
+        # attout = [tanh(pooled_ic W_o + b) | tanh(pooled_t W'_o + b)]   (model_combine.py:119,127,132)
+        self.gemm(0, B, g.ic, g.ic, p(self.pooled), g.ek, self._w("o_w"), g.ic, p(self.attout), g.ek,
+                  bias=self._w("o_b"), act=2)
+        self.gemm(0, B, g.pt, g.pt, p(self.pooled, g.ic), g.ek, self._w("ot_w"), g.pt, p(self.attout, g.ic), g.ek,
+                  bias=self._w("ot_b"), act=2)
+        # logits = attout E^T                              (model_combine.py:138)
+        self.gemm(1, B, g.N, g.ek, p(self.attout), g.ek, p(self.E), g.ek, p(self.logits), g.Npad)
+
+    # -------------------------------------------------------------------------------------------- backward
+    def backward(self, bt: Batch):
+        """Loss (model_combine.py:142-147) and the gradient of its SUM w.r.t. all 23 variables."""
+        g, lib, st = self.geo, self.lib, self._stream()
+        B, T, K = bt.B, bt.T, bt.K
+        BT = B * T
+        p = self._p
+        self.G[:self.atomic_n].zero_()
+        self.sqn_dense.zero_()
+        self.sqn_pieces.zero_()
+        check(lib.tcar_softmax_ce(B, g.N, p(self.logits), g.Npad, C.c_void_p(bt.label), p(self.ce), st), "tcar_softmax_ce")
+        # d attout = dlogits E  (contraction over the catalog: split-K slabs + reduce)
+        S = lib.tcar_gemm_splitk_effective(g.Npad, self.splitk)
+        self.gemm(0, B, g.ek, g.Npad, p(self.logits), g.Npad, p(self.E), g.ek, p(self.slabs), g.ek, splitk=self.splitk)
+        check(lib.tcar_splitk_reduce(p(self.slabs), S, B, g.ek, g.ek, p(self.dattout), st), "tcar_splitk_reduce")
+        # dE = dlogits^T attout: item columns -> Gi, time columns -> d_et (content is frozen)
+        self.gemm(2, g.N, g.ldh, B, p(self.logits), g.Npad, p(self.attout), g.ek, p(self.Gi), g.ldh)
+        self.gemm(2, g.N, g.pt, B, p(self.logits), g.Npad, p(self.attout, g.ic), g.ek, p(self.d_et), g.pt)
+        if K:
+            check(lib.tcar_neg_term(C.byref(self.dims), B, K, p(self.E), C.c_void_p(bt.neg), p(self.attout),
+                                    self.neg_weight, p(self.neg_fb), p(self.dattout), p(self.Gi), st), "tcar_neg_term")
+        else:
+            self.neg_fb[:B].zero_()
+        # output transforms (linear_2d + tanh) backward
+        check(lib.tcar_dact_colsum(B, g.ic, g.ek, p(self.attout), p(self.dattout), self._g("o_b"), 2, st), "dact")
+        check(lib.tcar_dact_colsum(B, g.pt, g.ek, p(self.attout, g.ic), p(self.dattout, g.ic), self._g("ot_b"), 2, st), "dact")
+        self.gemm(1, B, g.ic, g.ic, p(self.dattout), g.ek, self._w("o_w"), g.ic, p(self.dpooled), g.ek)
+        self.gemm(1, B, g.pt, g.pt, p(self.dattout, g.ic), g.ek, self._w("ot_w"), g.pt, p(self.dpooled, g.ic), g.ek)
+        self.gemm(2, g.ic, g.ic, B, p(self.pooled), g.ek, p(self.dattout), g.ek, self._g("o_w"), g.ic)
+        self.gemm(2, g.pt, g.pt, B, p(self.pooled, g.ic), g.ek, p(self.dattout, g.ic), g.ek, self._g("ot_w"), g.pt)
+        check(lib.tcar_attn_pool_bwd(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2),
+                                     p(self.q), self._w("m_wres"), self._w("s_wres"), p(self.alpha), p(self.dpooled),
+                                     p(self.dx_icp), p(self.dx_pt), p(self.dq), p(self.dpre1), p(self.dpre2),
+                                     self._g("m_wres"), self._g("s_wres"), st), "tcar_attn_pool_bwd")
+        # query MLP backward (modules.py:138-139)
+        check(lib.tcar_dact_colsum(B, g.ic, g.ic, p(self.q), p(self.dq), self._g("q2_b"), 2, st), "dact")
+        self.gemm(1, B, g.ldh, g.ic, p(self.dq), g.ic, self._w("q2_w"), g.ic, p(self.dq1), g.ldh)
+        self.gemm(2, g.ldh, g.ic, B, p(self.q1), g.ldh, p(self.dq), g.ic, self._g("q2_w"), g.ic)
+        check(lib.tcar_dact_colsum(B, g.ldh, g.ldh, p(self.q1), p(self.dq1), self._g("q1_b"), 1, st), "dact")
+        self.gemm(1, B, g.ct, g.ldh, p(self.dq1), g.ldh, self._w("q1_w"), g.ldh, p(self.dclick), g.ct)
+        self.gemm(2, g.ct, g.ldh, B, p(self.click_t), g.ct, p(self.dq1), g.ldh, self._g("q1_w"), g.ldh)
+        # projection backward: only the ITEM half of dX_ic is needed (content is frozen)
+        self.gemm(1, BT, g.ldh, g.ldh, p(self.dpre1), g.ldh, self._w("m_win"), g.ldh, p(self.dx_icp), g.ic, beta=1)
+        self.gemm(1, BT, g.ldt, g.ldh, p(self.dpre1), g.ldh, self._w("m_wint"), g.ldh, p(self.dx_act), g.ldt)
+        self.gemm(1, BT, g.pt, g.ldh, p(self.dpre2), g.ldh, self._w("s_win"), g.ldh, p(self.dx_pt), g.pt, beta=1)
+        self.gemm(2, g.ic, g.ldh, BT, p(self.x_icp), g.ic, p(self.dpre1), g.ldh, self._g("m_win"), g.ldh)
+        self.gemm(2, g.ldh, g.ldh, BT, p(self.x_icp, g.ldh), g.ic, p(self.dpre1), g.ldh, self._g("m_wc"), g.ldh)
+        self.gemm(2, g.ldt, g.ldh, BT, p(self.x_act), g.ldt, p(self.dpre1), g.ldh, self._g("m_wint"), g.ldh)
+        self.gemm(2, g.pt, g.ldh, BT, p(self.x_pt), g.pt, p(self.dpre2), g.ldh, self._g("s_win"), g.ldh)
+        self.gemm(2, g.ldh, g.ldh, BT, p(self.x_icp, g.ldh), g.ic, p(self.dpre2), g.ldh, self._g("s_wc"), g.ldh)
+        # clip norms of the dense blocks BEFORE the sparse rows are scattered in
+        one = Segments()
+        one.nseg = 1
+        one.off[0], one.len[0], one.slot[0] = 0, g.N * g.ldh, SLOT["item_emb"]
+        check(lib.tcar_sqnorm(p(self.Gi), C.byref(one), p(self.sqn_dense), st), "tcar_sqnorm")
+        # embedding backward: sparse rows + IndexedSlices norm pieces
+        tab, gr = self._tables(), self._grads()
+        check(lib.tcar_gather_clip_bwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.dx_icp), p(self.dx_pt),
+                                       p(self.dx_act), p(self.dclick), C.byref(gr), st), "tcar_gather_clip_bwd")
+        check(lib.tcar_cand_time_bwd(C.byref(self.dims), C.byref(self._time_ptrs()), p(self.mwdhm), p(self.d_et),
+                                     C.byref(gr), st), "tcar_cand_time_bwd")
+        check(lib.tcar_sqnorm(p(self.G), C.byref(self.segs_dense), p(self.sqn_dense), st), "tcar_sqnorm")
+
+    # ---------------------------------------------------------------------------------------------- update
+    def update(self):
+        """model_combine.py:157-163: per-variable clip_by_norm(max_grad) + TF-1 Adam."""
+        g, lib, st, p = self.geo, self.lib, self._stream(), self._p
+        self.step += 1
+        lr_t = float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.b2_pow) / (np.float32(1) - self.b1_pow))
+        clip = float(self.max_grad) if self.max_grad else 0.0
+        check(lib.tcar_clip_adam(p(self.W), p(self.G), p(self.M), p(self.V), C.byref(self.segs_all), p(self.sqn_dense),
+                                 p(self.sqn_pieces), p(self.use_dense), clip, lr_t, self.b1, self.b2, self.eps, st),
+              "tcar_clip_adam")
+        check(lib.tcar_clip_adam_2d(p(self.E), g.ek, p(self.Gi), p(self.Mi), p(self.Vi), g.N, g.ldh, SLOT["item_emb"],
+                                    p(self.sqn_dense), p(self.sqn_pieces), p(self.use_dense), clip, lr_t, self.b1,
+                                    self.b2, self.eps, st), "tcar_clip_adam_2d")
+        self.b1_pow = np.float32(self.b1_pow * np.float32(self.b1))
+        self.b2_pow = np.float32(self.b2_pow * np.float32(self.b2))
+        self._time_dirty = True
+
+    # ------------------------------------------------------------------------------------------ public API
+    def train_step(self, batch: Dict[str, np.ndarray], bt: Optional[Batch] = None) -> torch.Tensor:
+        """One sess.run([loss, global_step, train_op]) (model_combine.py:231); returns loss[B] on device."""
+        bt = bt or self.upload(batch)
+        self.forward(bt)
+        self.backward(bt)
+        self.update()
+        return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
+
+    def loss_and_grads(self, batch, bt: Optional[Batch] = None) -> torch.Tensor:
+        bt = bt or self.upload(batch)
+        self.forward(bt)
+        self.backward(bt)
+        return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
+
+    def eval_step(self, batch, k: int = 20, bt: Optional[Batch] = None, keep_logits: bool = False):
+        """sess.run([softmax_input, cross_loss]) (model_combine.py:283) + rank / top-k on device.
+        Returns (rank[B] int32, topk[B,k] int32, ce[B] f32[, logits [B,N]])."""
+        bt = bt or self.upload(batch)
+        self.forward(bt)
+        g, lib, st, p = self.geo, self.lib, self._stream(), self._p
+        B = bt.B
+        if k != self.topk.shape[1] or self.topk.shape[0] < B:
+            self.topk = torch.empty(max(B, self.work_B), k, dtype=torch.int32, device=self.dev)
+        check(lib.tcar_rank_topk(B, g.N, p(self.logits), g.Npad, C.c_void_p(bt.label), k, p(self.rank), p(self.topk), st),
+              "tcar_rank_topk")
+        logits = self.logits[:B, :g.N].clone() if keep_logits else None
+        check(lib.tcar_softmax_ce(B, g.N, p(self.logits), g.Npad, C.c_void_p(bt.label), p(self.ce), st), "tcar_softmax_ce")
+        out = (self.rank[:B], self.topk[:B], self.ce[:B])
+        return out + (logits,) if keep_logits else out

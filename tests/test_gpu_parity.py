@@ -1,0 +1,255 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP kernel, through the C-ABI, against the fp64 CPU
+oracle on the same seeded inputs, the committed golden fixture, and size-independent properties at the full
+Globo-like size.  Tolerance: 1e-3 relative (BASELINE.json north_star) — the fp32 path is typically ~1e-5."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import tcar_amd  # noqa: F401
+from helpers import GOLD
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-3
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def close(got, want, rtol=RTOL, atol_scale=2e-5, name=""):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    scale = max(float(np.abs(want).max()), 1e-30)
+    err = np.abs(got - want)
+    tol = rtol * np.abs(want) + atol_scale * scale
+    bad = err > tol
+    assert not bad.any(), "%s: %d/%d off, max err %.3e (scale %.3e) at %s" % (
+        name, bad.sum(), bad.size, err.max(), scale, np.unravel_index(err.argmax(), err.shape))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _need_gpu()
+    from tcar_amd import _lib
+    return _lib.load()
+
+
+def ptr(t, off=0):
+    return C.c_void_p(t.data_ptr() + 4 * off)
+
+
+# ------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(1, 1, 4), (5, 7, 8), (130, 129, 36), (128, 128, 32), (512, 300, 832),
+                                   (257, 64, 1000), (64, 832, 2052)])
+def test_gemm_layouts(lib, layout, M, N, K):
+    rng = np.random.RandomState(M * 7 + N * 3 + K + layout)
+    ld = lambda x: (x + 3) // 4 * 4 + 4
+    a_shape = (M, ld(K)) if layout != 2 else (K, ld(M))
+    b_shape = (K, ld(N)) if layout != 1 else (N, ld(K))
+    A = rng.standard_normal(a_shape).astype(np.float32)
+    Bm = rng.standard_normal(b_shape).astype(np.float32)
+    Al = A[:, :K] if layout != 2 else A[:, :M].T
+    Bl = Bm[:, :N] if layout != 1 else Bm[:, :K].T
+    want = Al.astype(np.float64) @ Bl.astype(np.float64)
+    dA, dB = torch.tensor(A).cuda(), torch.tensor(Bm).cuda()
+    ldc = ld(N)
+    dC = torch.full((M, ldc), 7.0, device="cuda")
+    rc = lib.tcar_gemm_f32(layout, M, N, K, ptr(dA), A.shape[1], ptr(dB), Bm.shape[1], ptr(dC), ldc, None, 0, 0, 1, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = dC.cpu().numpy()
+    close(got[:, :N], want, name="gemm")
+    assert (got[:, N:] == 7.0).all()                      # nothing outside [M, N] is written
+
+
+def test_gemm_epilogues_and_splitk(lib):
+    rng = np.random.RandomState(5)
+    M, N, K = 200, 192, 4096
+    A = rng.standard_normal((M, K)).astype(np.float32) * 0.05
+    Bm = rng.standard_normal((K, N)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    dA, dB, db = torch.tensor(A).cuda(), torch.tensor(Bm).cuda(), torch.tensor(bias).cuda()
+    z = A.astype(np.float64) @ Bm.astype(np.float64) + bias
+    for act, f in ((1, lambda x: np.maximum(x, 0)), (2, np.tanh)):
+        dC = torch.tensor(C0).cuda()
+        assert lib.tcar_gemm_f32(0, M, N, K, ptr(dA), K, ptr(dB), N, ptr(dC), N, ptr(db), act, 0, 1, None) == 0
+        close(dC.cpu().numpy(), f(z), name="act%d" % act)
+    dC = torch.tensor(C0).cuda()
+    assert lib.tcar_gemm_f32(0, M, N, K, ptr(dA), K, ptr(dB), N, ptr(dC), N, None, 0, 1, 1, None) == 0
+    close(dC.cpu().numpy(), z - bias + C0, name="beta")
+    S = lib.tcar_gemm_splitk_effective(K, 7)
+    slabs = torch.empty(S, M, N, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    assert lib.tcar_gemm_f32(0, M, N, K, ptr(dA), K, ptr(dB), N, ptr(slabs), N, None, 0, 0, 7, None) == 0
+    assert lib.tcar_splitk_reduce(ptr(slabs), S, M, N, N, ptr(out), None) == 0
+    close(out.cpu().numpy(), z - bias, name="splitk")
+
+
+# -------------------------------------------------------------------------------------- standalone score ops
+def test_softmax_ce_and_rank_topk(lib):
+    rng = np.random.RandomState(2)
+    B, N = 9, 1003
+    ldn = 1024
+    x = (rng.standard_normal((B, ldn)) * 3).astype(np.float32)
+    x[3, :N] = 1.5                                   # all-tie row
+    x[4, 10:40] = x[4, 5]                            # partial ties
+    lab = rng.randint(0, N, B).astype(np.int32)
+    lab[4] = 5
+    d = torch.tensor(x).cuda()
+    dl = torch.tensor(lab).cuda()
+    rank = torch.empty(B, dtype=torch.int32, device="cuda")
+    topk = torch.empty(B, 20, dtype=torch.int32, device="cuda")
+    assert lib.tcar_rank_topk(B, N, ptr(d), ldn, ptr(dl), 20, ptr(rank), ptr(topk), None) == 0
+    xv = x[:, :N].astype(np.float64)
+    want_rank = (xv > xv[np.arange(B), lab][:, None]).sum(1) + 1
+    assert (rank.cpu().numpy() == want_rank).all()
+    from oracle.metrics_oracle import topk_list
+    for b in range(B):
+        assert topk[b].cpu().numpy().tolist() == topk_list(x[b, :N], 20), b
+    ce = torch.empty(B, device="cuda")
+    assert lib.tcar_softmax_ce(B, N, ptr(d), ldn, ptr(dl), ptr(ce), None) == 0
+    lse = np.log(np.exp(xv - xv.max(1, keepdims=True)).sum(1)) + xv.max(1)
+    close(ce.cpu().numpy(), lse - xv[np.arange(B), lab], name="ce")
+    p = np.exp(xv - lse[:, None])
+    p[np.arange(B), lab] -= 1
+    got = d.cpu().numpy()
+    close(got[:, :N], p, name="dlogits")
+    assert (got[:, N:] == 0).all()
+    assert np.abs(got[:, :N].sum(1)).max() < 1e-4    # rows of softmax - onehot sum to 0
+
+
+# --------------------------------------------------------------------------------------------- full model
+def _case(N, H, Ht, B, T, K, seed, emb_std=0.35, w_std=0.12):
+    from oracle.tcar_oracle import init_params_numpy
+    rng = np.random.RandomState(seed)
+    params = init_params_numpy(N, H, Ht, emb_std, w_std, rng)
+    content = (rng.standard_normal((N + 1, H)) * 0.5).astype(np.float32)
+    content[0] = 0
+    mw = np.stack([rng.randint(1, 13, N), rng.randint(1, 32, N), rng.randint(1, 8, N), rng.randint(1, 25, N),
+                   rng.randint(1, 61, N)], -1).astype(np.int32)
+    b = {"seq": rng.randint(1, N + 1, (B, T)), "label": rng.randint(0, N, B), "pm": rng.randint(1, 13, (B, T)),
+         "pd": rng.randint(1, 32, (B, T)), "pw": rng.randint(1, 8, (B, T)), "ph": rng.randint(1, 25, (B, T)),
+         "pmi": rng.randint(1, 61, (B, T)), "cw": rng.randint(0, 7, B), "ch": rng.randint(0, 24, B),
+         "gap": rng.randint(0, 12, (B, T)), "neg": rng.randint(0, N, (B, K))}
+    b = {k: v.astype(np.int32) for k, v in b.items()}
+    if T > 1:
+        b["seq"][0, 1] = b["seq"][0, 0]            # a repeated item inside one session
+    b["seq"][-1, 0] = b["seq"][0, 0]               # and across sessions (scatter collisions)
+    return params, content, mw, b
+
+
+CASES = [  # N, H, Ht, B, T, K
+    (50, 12, 8, 1, 1, 3),
+    (50, 12, 8, 3, 2, 4),
+    (1000, 250, 64, 64, 7, 20),
+    (1000, 40, 16, 3, 40, 5),
+    (1000, 256, 64, 5, 3, 2),
+]
+
+
+@pytest.mark.parametrize("N,H,Ht,B,T,K", CASES)
+def test_step_matches_oracle(N, H, Ht, B, T, K):
+    _need_gpu()
+    from oracle.tcar_oracle import TcarOracle
+    from tcar_amd.engine import TcarEngine
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=N + H + B + T)
+    eng = TcarEngine(params, content, mw, max_grad=2.0)
+    ora = TcarOracle(params, content, mw, max_grad=2.0)
+    # forward + eval
+    rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
+    o_logits, o_ce = ora.eval_batch(batch)
+    close(logits.cpu().numpy(), o_logits.numpy(), name="logits")
+    close(ce.cpu().numpy(), o_ce.numpy(), name="ce")
+    lab = torch.as_tensor(batch["label"], dtype=torch.long)
+    lg = logits.cpu().double()
+    assert (rank.cpu().numpy() == ((lg > lg.gather(1, lab[:, None])).sum(1).numpy() + 1)).all()
+    # gradients + clip norms
+    loss = eng.loss_and_grads(batch)
+    o, g_o, sq_o = ora.loss_and_grads(batch)
+    close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss")
+    g_e, sq_e = eng.export_grads(), eng.export_sqnorms()
+    for k in g_o:
+        close(g_e[k], g_o[k].numpy(), name="grad " + k, atol_scale=5e-5)
+        assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * max(sq_o[k], 1e-20), ("sqnorm", k, sq_e[k], sq_o[k])
+    # three optimizer steps
+    for _ in range(3):
+        le = eng.train_step(batch)
+        lo = ora.train_step(batch)
+        close(le.cpu().numpy(), lo.numpy(), name="train loss")
+    p_e, p_o = eng.export_params(), ora.export()
+    for k in p_o:
+        close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-4)
+
+
+def test_golden_fixture():
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    z = np.load(os.path.join(GOLD, "oracle_step_small.npz"))
+    params = {k[2:]: z[k] for k in z.files if k.startswith("p/")}
+    batch = {k[2:]: z[k] for k in z.files if k.startswith("b/")}
+    eng = TcarEngine(params, z["content"], z["mwdhm"], max_grad=1.5)
+    rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
+    close(logits.cpu().numpy(), z["logits"], name="logits")
+    assert (rank.cpu().numpy() == z["rank"]).all()
+    loss = eng.loss_and_grads(batch)
+    close(loss.cpu().numpy(), z["loss"], name="loss")
+    ge, sq = eng.export_grads(), eng.export_sqnorms()
+    for k in ge:
+        close(ge[k], z["g/" + k], name="grad " + k, atol_scale=5e-5)
+        assert abs(sq[k] - float(z["sqn/" + k])) <= 2e-3 * float(z["sqn/" + k])
+    eng.update()
+    p1 = eng.export_params()
+    for k in p1:
+        close(p1[k], z["p1/" + k], name="p1 " + k, atol_scale=1e-4)
+    eng.train_step(batch)
+    eng.train_step(batch)
+    p3 = eng.export_params()
+    for k in p3:
+        close(p3[k], z["p3/" + k], name="p3 " + k, atol_scale=1e-4)
+
+
+def test_full_size_properties():
+    """Globo-like size (N=46,033, H=250, B=512): properties that need no oracle run."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 46033, 250, 64, 512, 3, 20
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=99, emb_std=0.05, w_std=0.05)
+    eng = TcarEngine(params, content, mw)
+    rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
+    lg = logits.double()
+    lab = torch.as_tensor(batch["label"], dtype=torch.long, device="cuda")
+    # (1) rank / top-k consistency with the materialised scores
+    assert (rank.long() == (lg > lg.gather(1, lab[:, None])).sum(1) + 1).all()
+    tv = lg.gather(1, topk.long())
+    assert (tv[:, :-1] >= tv[:, 1:]).all()                               # sorted descending
+    assert (tv[:, -1:] >= lg.topk(21, dim=1).values[:, 20:21]).all()     # nothing larger was missed
+    # (2) CE equals logsumexp - label score
+    want = torch.logsumexp(lg, 1) - lg.gather(1, lab[:, None]).squeeze(1)
+    close(ce.cpu().numpy(), want.cpu().numpy(), name="ce full")
+    # (3) data-parallel additivity: gradients of two half batches add up to the full-batch gradient
+    eng.loss_and_grads(batch)
+    g_full = eng.export_grads()
+    acc = None
+    for sl in (slice(0, B // 2), slice(B // 2, B)):
+        sub = {k: v[sl] for k, v in batch.items()}
+        eng.loss_and_grads(sub)
+        g = eng.export_grads()
+        acc = g if acc is None else {k: acc[k] + g[k] for k in g}
+    for k in g_full:
+        close(acc[k], g_full[k], name="dp-sum " + k, atol_scale=1e-4)
+    # (4) a training step lowers the loss on the same batch
+    l0 = float(eng.train_step(batch).sum())
+    for _ in range(5):
+        l1 = float(eng.train_step(batch).sum())
+    assert l1 < l0
+    # (5) padding columns of the parameter arena stay exactly zero
+    E = eng.E
+    assert float(E[:, H:eng.geo.ldh].abs().max()) == 0.0 and float(E[N:].abs().max()) == 0.0

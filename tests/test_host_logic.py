@@ -1,0 +1,81 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, parameter packing
+round-trips, the tensorised store equals the dict path, synthetic folds follow the data contract."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import tcar_amd  # noqa: F401
+from tcar_amd import _lib
+from tcar_amd.engine import ARENA, Geometry, VAR_ORDER
+from tcar_amd.host.data import SessionStore
+from tcar_amd.host.synth import SynthFold
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "tcar_hip.h")).read()
+    declared = set(re.findall(r"^int (tcar_\w+)\(", header, flags=re.M))
+    assert declared == set(_lib.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.tcar_abi_version() == 1
+    assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
+    assert lib.tcar_gemm_splitk_effective(64, 16) == 2
+
+
+def test_c_abi_rejects_bad_arguments_without_touching_a_gpu():
+    lib = _lib.load()
+    # misaligned leading dimension / null pointers are refused before any launch
+    assert lib.tcar_gemm_f32(0, 4, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None) == -1
+    assert lib.tcar_gemm_f32(7, 4, 4, 4, 16, 4, 16, 4, 16, 4, None, 0, 0, 1, None) == -1
+    assert lib.tcar_gemm_f32(1, 4, 4, 6, 16, 8, 16, 8, 16, 8, None, 0, 0, 1, None) == -1     # K % 4 for k-contiguous
+    assert lib.tcar_softmax_ce(2, 10, 16, 10, 16, 16, None) == -1                              # ld % 4
+    assert lib.tcar_gemm_f32(0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None) == 0  # empty problem is a no-op
+
+
+def test_geometry_and_arena_cover_all_variables():
+    g = Geometry(46033, 250, 64)
+    assert (g.ldh, g.ldt, g.ic, g.pt, g.ct, g.ek, g.Npad) == (256, 64, 512, 320, 128, 832, 46080)
+    refs = [a[1] for a in ARENA]
+    assert sorted(refs + ["item_emb"]) == sorted(VAR_ORDER) and len(VAR_ORDER) == 23
+    # time tables + dwell table are contiguous and in the order tcar_grads_t requires
+    assert [a[0] for a in ARENA[1:7]] == ["month", "day", "week", "hour", "minute", "dur"]
+    idx = g.idx("2H")
+    assert idx[0] == 0 and idx[249] == 249 and idx[250] == 256 and idx[-1] == 505
+
+
+def test_store_from_dicts_equals_synth_store():
+    fold = SynthFold(n_items=80, dim=6, n_train=300, n_test=30, seed=4, active_t=True)
+    len_d, sess, times = fold.to_dicts(fold.train, with_active=True)
+    st = SessionStore.from_dicts(sess, times)
+    assert st.n == fold.train.n
+    np.testing.assert_array_equal(st.items, fold.train.items)
+    np.testing.assert_array_equal(st.pub, fold.train.pub)
+    np.testing.assert_array_equal(st.clk, fold.train.clk)
+    np.testing.assert_array_equal(st.gap_active, fold.train.gap_active)
+    # gap_delta is defined on input positions only
+    for e in range(st.n):
+        o, o2 = st.off[e], st.off[e + 1]
+        np.testing.assert_array_equal(st.gap_delta[o:o2 - 1], fold.train.gap_delta[o:o2 - 1])
+    assert sum(len(v) for v in len_d.values()) == st.n
+
+
+def test_synth_fold_contract():
+    fold = SynthFold(n_items=500, dim=10, n_train=2000, n_test=100, seed=1)
+    assert fold.content.shape == (501, 10) and not fold.content[0].any()
+    m = fold.mwdhm
+    assert m[:, 0].min() >= 1 and m[:, 0].max() <= 12 and m[:, 2].min() >= 1 and m[:, 2].max() <= 7
+    assert m[:, 3].min() >= 1 and m[:, 3].max() <= 24 and m[:, 4].min() >= 1 and m[:, 4].max() <= 60
+    st = fold.train
+    assert st.items.min() >= 1 and st.items.max() <= 500 and st.in_len.min() >= 1 and st.in_len.max() <= 40
+    b = st.batch_arrays(np.where(st.in_len == 2)[0][:5], "click_delta")
+    assert b["seq"].shape == (5, 2) and b["gap"].max() <= 11 and b["cw"].max() <= 6 and b["ch"].max() <= 23
+    with pytest.raises(ValueError):
+        st.batch_arrays(np.array([np.where(st.in_len == 1)[0][0], np.where(st.in_len == 2)[0][0]]))
+    nb = fold.neighbor_dict(k=3)
+    assert all(i not in v and 3 <= len(v) <= 6 for i, v in nb.items())

@@ -1,0 +1,137 @@
+"""CPU tests of the model oracle: golden fixture reproducibility, finite-difference gradient check, the
+IndexedSlices clip-norm semantics, TF-1 Adam, and data-parallel sum semantics."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import tcar_amd  # noqa: F401
+from oracle.tcar_oracle import TABLES, TcarOracle, init_params_numpy
+from helpers import GOLD
+
+
+def load_fixture():
+    z = np.load(os.path.join(GOLD, "oracle_step_small.npz"))
+    params = {k[2:]: z[k] for k in z.files if k.startswith("p/")}
+    batch = {k[2:]: z[k] for k in z.files if k.startswith("b/")}
+    return z, params, batch
+
+
+def test_oracle_reproduces_golden_fixture():
+    z, params, batch = load_fixture()
+    ora = TcarOracle(params, z["content"], z["mwdhm"], max_grad=1.5)
+    o, grads, sqn = ora.loss_and_grads(batch)
+    np.testing.assert_allclose(o["logits"].detach().numpy(), z["logits"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(o["loss"].detach().numpy(), z["loss"], rtol=1e-10)
+    for k in grads:
+        np.testing.assert_allclose(grads[k].numpy(), z["g/" + k], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(sqn[k], float(z["sqn/" + k]), rtol=1e-9)
+    ora.apply_adam(grads, sqn)
+    for k, v in ora.export().items():
+        np.testing.assert_allclose(v, z["p1/" + k], rtol=1e-10, atol=1e-14)
+
+
+def test_finite_difference_gradients():
+    z, params, batch = load_fixture()
+    ora = TcarOracle(params, z["content"], z["mwdhm"])
+    _, grads, _ = ora.loss_and_grads(batch)
+    rng = np.random.RandomState(0)
+
+    def total():
+        with torch.no_grad():
+            return float(ora.forward(batch)["loss"].sum())
+
+    for name, w in ora.p.items():
+        g = grads[name]
+        nz = torch.nonzero(g.abs() > 1e-8)
+        if len(nz) == 0:
+            continue
+        for _ in range(2):
+            ix = tuple(nz[rng.randint(len(nz))].tolist())
+            e = 1e-6
+            with torch.no_grad():
+                w[ix] += e
+                lp = total()
+                w[ix] -= 2 * e
+                lm = total()
+                w[ix] += e
+            fd = (lp - lm) / (2 * e)
+            assert abs(fd - float(g[ix])) <= 1e-5 * max(1.0, abs(fd)), (name, ix, fd, float(g[ix]))
+
+
+def test_indexed_slices_norm_differs_from_dense_norm():
+    """tf.clip_by_norm on an IndexedSlices uses the concatenated slice values (S5): for tables whose rows are
+    gathered more than once this is NOT the norm of the summed gradient."""
+    z, params, batch = load_fixture()
+    ora = TcarOracle(params, z["content"], z["mwdhm"])
+    _, grads, sqn = ora.loss_and_grads(batch)
+    differs = 0
+    for k in TABLES:
+        dense = float((grads[k] ** 2).sum())
+        if abs(dense - sqn[k]) > 1e-9 * max(dense, 1e-30):
+            differs += 1
+    assert differs >= 4
+    for k in grads:
+        if k not in TABLES:
+            np.testing.assert_allclose(float((grads[k] ** 2).sum()), sqn[k], rtol=1e-12)
+
+
+def test_adam_matches_closed_form_first_step():
+    z, params, batch = load_fixture()
+    ora = TcarOracle(params, z["content"], z["mwdhm"], max_grad=None)
+    _, grads, sqn = ora.loss_and_grads(batch)
+    before = ora.export()
+    ora.apply_adam(grads, sqn)
+    after = ora.export()
+    # t = 1: m = (1-b1) g, v = (1-b2) g^2, lr_t = lr*sqrt(1-b2)/(1-b1)  =>  step = lr * g / (|g| + eps*sqrt(1-b2)) ~ lr*sign(g)
+    k = "attout_item_cont_trans/w1"
+    g = grads[k].numpy()
+    step = before[k] - after[k]
+    want = 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9) * (0.1 * g) / (np.sqrt(0.001 * g * g) + 1e-8)
+    np.testing.assert_allclose(step, want, rtol=1e-5, atol=1e-12)
+
+
+def test_data_parallel_gradient_is_plain_sum():
+    """The loss is a SUM over sessions (model_combine.py:147,156): the global gradient (and every IndexedSlices
+    norm piece) is the plain sum of per-shard gradients — no 1/W rescale."""
+    z, params, batch = load_fixture()
+    ora = TcarOracle(params, z["content"], z["mwdhm"])
+    _, g_all, sqn_all = ora.loss_and_grads(batch)
+    B = len(batch["label"])
+    parts = [slice(0, B // 2), slice(B // 2, B)]
+    g_sum = {k: torch.zeros_like(v) for k, v in g_all.items()}
+    sq_sum = {k: 0.0 for k in g_all}
+    for sl in parts:
+        sub = {k: (v[sl] if v.shape[0] == B else v) for k, v in batch.items()}
+        _, g, sq = ora.loss_and_grads(sub)
+        for k in g:
+            g_sum[k] += g[k]
+            if k in TABLES and k != "item_emb":
+                sq_sum[k] += sq[k]
+    for k in g_all:
+        np.testing.assert_allclose(g_sum[k].numpy(), g_all[k].numpy(), rtol=1e-9, atol=1e-13)
+    # pure-gather tables: pieces add up, except the candidate-side rows which every shard would count once per
+    # shard; the DP engine therefore reduces dE BEFORE the candidate-side clip backward
+    for k in ("dec_pos", "duration_embedding"):
+        np.testing.assert_allclose(sq_sum[k], sqn_all[k], rtol=1e-9)
+
+
+def test_edge_shapes_run():
+    fold_n, H, Ht = 30, 6, 4
+    rng = np.random.RandomState(3)
+    params = init_params_numpy(fold_n, H, Ht, 0.3, 0.2, rng)
+    content = rng.standard_normal((fold_n + 1, H)).astype(np.float32)
+    content[0] = 0
+    mw = np.stack([rng.randint(1, 13, fold_n), rng.randint(1, 32, fold_n), rng.randint(1, 8, fold_n),
+                   rng.randint(1, 25, fold_n), rng.randint(1, 61, fold_n)], -1)
+    ora = TcarOracle(params, content, mw)
+    for B, T in [(1, 1), (3, 40), (2, 7)]:
+        b = {"seq": rng.randint(1, fold_n + 1, (B, T)), "label": rng.randint(0, fold_n, B),
+             "pm": rng.randint(1, 13, (B, T)), "pd": rng.randint(1, 32, (B, T)), "pw": rng.randint(1, 8, (B, T)),
+             "ph": rng.randint(1, 25, (B, T)), "pmi": rng.randint(1, 61, (B, T)), "cw": rng.randint(0, 7, B),
+             "ch": rng.randint(0, 24, B), "gap": rng.randint(0, 12, (B, T)), "neg": rng.randint(0, fold_n, (B, 3))}
+        loss = ora.train_step(b)
+        assert loss.shape == (B,) and torch.isfinite(loss).all()
+    with pytest.raises(IndexError):
+        ora.forward({**b, "seq": rng.randint(1, fold_n + 1, (1, 41)), "pm": np.ones((1, 41), int)})
