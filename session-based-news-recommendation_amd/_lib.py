@@ -97,6 +97,10 @@ def load() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    # The library must bind to the SAME HIP runtime instance that owns the caller's device pointers and streams.
+    # PyTorch-ROCm bundles its own libamdhip64; importing torch first makes the dynamic loader resolve our
+    # DT_NEEDED libamdhip64.so.N to that already-loaded copy (two runtimes in one process => hipErrorNoDevice).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise TcarError("libtcar_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
                         "there is no CPU fallback." % LIB_PATH)

@@ -180,17 +180,19 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
         const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
         const float* gp = (kk < 5) ? a.dx_pt + (long)row * pt + kk * ldt : a.dx_act + (long)row * ldt;
         float4 x = act ? ld4(tp + (long)id * ldt + lin * 4) : zero4();
-        float4 gyv = act ? ld4(gp + lin * 4) : zero4();
+        float4 gyv = valid ? ld4(gp + lin * 4) : zero4();
         const float ss = group_sum(dot4(x, x), sub), dd = group_sum(dot4(x, gyv), sub);
         float ca, cb;
         clip_bwd_coef(ss, dd, ca, cb);
-        if (act) {
+        if (valid) {
+          // an out-of-range dwell id gathers a zero row (S7): its gradient row still belongs to the
+          // IndexedSlices values (it counts in the clip norm) but is dropped by the scatter
           float4 gx = fma4(x, -cb, scale4(gyv, ca));
           const float q = dot4(gx, gx);
           // per-lane partial of sum-of-squares, routed to the slot of table kk
 #pragma unroll
           for (int s = 0; s < 6; ++s) sq[2 + s] += (s == kk) ? q : 0.f;
-          atomic_add4(small_acc + (time_rowoff(kk) + id) * ldt + lin * 4, gx);
+          if (act) atomic_add4(small_acc + (time_rowoff(kk) + id) * ldt + lin * 4, gx);
         }
       }
     } else {
@@ -353,8 +355,8 @@ extern "C" int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* t
   a.d = *d; a.tab = *tab; a.bt = *bt;
   a.x_icp = x_icp; a.x_pt = x_pt; a.x_act = x_act; a.click_t = click_t;
   const int grid = grid_for_rows((long)bt->B * bt->T + bt->B);
-  if (d->ldh <= 256) hipLaunchKernelGGL(gather_clip_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(gather_clip_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (d->ldh <= 256) TCAR_LAUNCH(gather_clip_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else TCAR_LAUNCH(gather_clip_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -375,10 +377,10 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
   hipStream_t st = (hipStream_t)stream;
   if (d->ldh <= 256) {
     (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(gather_clip_bwd_kernel<1>, dim3(grid), dim3(256), lds, st, a);
+    TCAR_LAUNCH(gather_clip_bwd_kernel<1>, dim3(grid), dim3(256), lds, st, a);
   } else {
     (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(gather_clip_bwd_kernel<2>, dim3(grid), dim3(256), lds, st, a);
+    TCAR_LAUNCH(gather_clip_bwd_kernel<2>, dim3(grid), dim3(256), lds, st, a);
   }
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -397,7 +399,7 @@ extern "C" int tcar_cand_time_fwd(const tcar_dims_t* d, const float* const time_
   if (grid < 1) grid = 1;
   if (grid > 1024) grid = 1024;
   (void)hipFuncSetAttribute((const void*)cand_time_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(cand_time_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  TCAR_LAUNCH(cand_time_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -416,7 +418,7 @@ extern "C" int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_
   if (grid < 1) grid = 1;
   if (grid > 512) grid = 512;
   (void)hipFuncSetAttribute((const void*)cand_time_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  hipLaunchKernelGGL(cand_time_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  TCAR_LAUNCH(cand_time_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -216,9 +216,9 @@ extern "C" int tcar_gemm_f32(int layout, int M, int N, int K, const float* A, in
     (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (layout == 0) hipLaunchKernelGGL((gemm_f32_kernel<0, 1>), grid, block, lds, st, g);
-  else if (layout == 1) hipLaunchKernelGGL((gemm_f32_kernel<0, 0>), grid, block, lds, st, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<1, 1>), grid, block, lds, st, g);
+  if (layout == 0) TCAR_LAUNCH((gemm_f32_kernel<0, 1>), grid, block, lds, st, g);
+  else if (layout == 1) TCAR_LAUNCH((gemm_f32_kernel<0, 0>), grid, block, lds, st, g);
+  else TCAR_LAUNCH((gemm_f32_kernel<1, 1>), grid, block, lds, st, g);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -238,7 +238,7 @@ extern "C" int tcar_splitk_reduce(const float* slabs, int splitk, int M, int N, 
   long total = (long)M * (N >> 2);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, N, (long)ld, out);
+  TCAR_LAUNCH(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, N, (long)ld, out);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -118,7 +118,7 @@ extern "C" int tcar_sqnorm(const float* g, const tcar_segments_t* segs, float* s
   if (segs->nseg == 0) return TCAR_OK;
   SegArgs a;
   a.s = *segs;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
+  TCAR_LAUNCH(sqnorm_kernel, dim3(seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -130,7 +130,7 @@ extern "C" int tcar_clip_adam(float* w, const float* g, float* m, float* v, cons
   if (segs->nseg == 0) return TCAR_OK;
   SegArgs a;
   a.s = *segs;
-  hipLaunchKernelGGL(clip_adam_kernel, dim3(seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
+  TCAR_LAUNCH(clip_adam_kernel, dim3(seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, w, g, m, v,
                      a, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -145,7 +145,7 @@ extern "C" int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m
   int grid = (int)((total + 256 * 4 - 1) / (256 * 4));
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(clip_adam_2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (long)ldw, g, m, v, (long)rows,
+  TCAR_LAUNCH(clip_adam_2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (long)ldw, g, m, v, (long)rows,
                      (int)cols, (int)slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;

@@ -241,8 +241,8 @@ extern "C" int tcar_attn_pool_fwd(const tcar_dims_t* d, int B, int T, const floa
   a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1; a.pre2 = pre2; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
   a.pooled = pooled; a.alpha = alpha;
   const int grid = (B + 3) / 4;
-  if (d->ldh <= 256) hipLaunchKernelGGL(attn_pool_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_pool_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (d->ldh <= 256) TCAR_LAUNCH(attn_pool_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else TCAR_LAUNCH(attn_pool_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -259,8 +259,8 @@ extern "C" int tcar_attn_pool_bwd(const tcar_dims_t* d, int B, int T, const floa
   a.alpha_in = alpha; a.dpooled = dpooled;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dq = dq; a.dpre1 = dpre1; a.dpre2 = dpre2; a.g_w1 = g_wres1; a.g_w2 = g_wres2;
   const int grid = (B + 3) / 4;
-  if (d->ldh <= 256) hipLaunchKernelGGL(attn_pool_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(attn_pool_bwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (d->ldh <= 256) TCAR_LAUNCH(attn_pool_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else TCAR_LAUNCH(attn_pool_bwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

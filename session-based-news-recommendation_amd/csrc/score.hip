@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void rank_topk_kernel(int N, const float* __re
 extern "C" int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* stream) {
   if (B <= 0) return TCAR_OK;
   if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce) return TCAR_E_ARG;
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, ce);
+  TCAR_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, ce);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -223,10 +223,10 @@ extern "C" int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E,
   const int ek = 2 * d->ldh + 5 * d->ldt;
   const int grid = (B + 3) / 4;
   if (d->ldh <= 256)
-    hipLaunchKernelGGL(neg_term_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
+    TCAR_LAUNCH(neg_term_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
                        neg, attout, weight, neg_fb, dattout, g_item);
   else
-    hipLaunchKernelGGL(neg_term_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
+    TCAR_LAUNCH(neg_term_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
                        neg, attout, weight, neg_fb, dattout, g_item);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -236,7 +236,7 @@ extern "C" int tcar_dact_colsum(int M, int ncol, int64_t ld, const float* y, flo
                                 void* stream) {
   if (M <= 0 || ncol <= 0) return TCAR_OK;
   if (!y || !dy) return TCAR_E_ARG;
-  hipLaunchKernelGGL(dact_colsum_kernel, dim3((ncol + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, ncol, (long)ld, y,
+  TCAR_LAUNCH(dact_colsum_kernel, dim3((ncol + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, ncol, (long)ld, y,
                      dy, bias_grad, act);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -246,7 +246,7 @@ extern "C" int tcar_rank_topk(int B, int N, const float* logits, int64_t ld, con
                               int32_t* rank, int32_t* topk, void* stream) {
   if (B <= 0) return TCAR_OK;
   if (N <= 0 || k < 0 || !logits || !label || !rank || (k > 0 && !topk)) return TCAR_E_ARG;
-  hipLaunchKernelGGL(rank_topk_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, k, rank, topk);
+  TCAR_LAUNCH(rank_topk_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, k, rank, topk);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -2,13 +2,25 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/tcar_hip.h"
 
 #define TCAR_CHECK_LAUNCH()                                   \
   do {                                                        \
     hipError_t e__ = hipGetLastError();                       \
-    if (e__ != hipSuccess) return TCAR_E_LAUNCH;              \
+    if (e__ != hipSuccess) {                                  \
+      fprintf(stderr, "tcar: HIP error %d (%s) at %s:%d\n", (int)e__, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return TCAR_E_LAUNCH;                                   \
+    }                                                         \
+  } while (0)
+
+// hipGetLastError() is sticky per thread: clear whatever an earlier (foreign) runtime call left behind, so the
+// check after the launch reports THIS launch only.
+#define TCAR_LAUNCH(...)                 \
+  do {                                   \
+    (void)hipGetLastError();             \
+    hipLaunchKernelGGL(__VA_ARGS__);     \
   } while (0)
 
 static inline bool tcar_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -27,7 +27,9 @@ def close(got, want, rtol=RTOL, atol_scale=2e-5, name=""):
     assert got.shape == want.shape, (name, got.shape, want.shape)
     scale = max(float(np.abs(want).max()), 1e-30)
     err = np.abs(got - want)
-    tol = rtol * np.abs(want) + atol_scale * scale
+    # absolute floor 1e-9: quantities below fp32 resolution of their inputs (e.g. the gradient through the
+    # exp-normaliser of a length-1 session, ~1e-9 relative) are legitimately 0 in fp32 and ~1e-11 in fp64
+    tol = rtol * np.abs(want) + atol_scale * scale + 1e-9
     bad = err > tol
     assert not bad.any(), "%s: %d/%d off, max err %.3e (scale %.3e) at %s" % (
         name, bad.sum(), bad.size, err.max(), scale, np.unravel_index(err.argmax(), err.shape))
@@ -178,7 +180,7 @@ def test_step_matches_oracle(N, H, Ht, B, T, K):
     g_e, sq_e = eng.export_grads(), eng.export_sqnorms()
     for k in g_o:
         close(g_e[k], g_o[k].numpy(), name="grad " + k, atol_scale=5e-5)
-        assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * max(sq_o[k], 1e-20), ("sqnorm", k, sq_e[k], sq_o[k])
+        assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12, ("sqnorm", k, sq_e[k], sq_o[k])
     # three optimizer steps
     for _ in range(3):
         le = eng.train_step(batch)
@@ -204,7 +206,7 @@ def test_golden_fixture():
     ge, sq = eng.export_grads(), eng.export_sqnorms()
     for k in ge:
         close(ge[k], z["g/" + k], name="grad " + k, atol_scale=5e-5)
-        assert abs(sq[k] - float(z["sqn/" + k])) <= 2e-3 * float(z["sqn/" + k])
+        assert abs(sq[k] - float(z["sqn/" + k])) <= 2e-3 * float(z["sqn/" + k]) + 1e-12
     eng.update()
     p1 = eng.export_params()
     for k in p1:
