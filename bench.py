@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — sessions/sec of TCAR training on the Globo-like configuration (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path (forward, loss, backward, per-variable clip, Adam) over one mini-batch of
+B = 512 sessions whose int32 feed arrays are already resident in HBM.  Prints ONE JSON line (rank 0) with the
+whole-job sessions/sec plus
+  "roofline"      dominant kernel (full-catalog scoring GEMM, gemm_f32_kernel<0,0>): algorithmic FLOPs per launch
+                  / mean HIP-event duration of that launch inside the timed region, against the gfx950 fp32
+                  matrix peak of /opt/skills/guides/MI355X_MICROARCH.md;
+  "cpu_baseline"  the CPU oracle (PyTorch-CPU fp32 restatement of the reference graph) on the host cores, on a
+                  bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0               # HBM3E spec peak
+
+
+def build_batches(fold, n_batches, B, K, rng):
+    """Full batches of exactly B sessions in the fold's own length mix (sampler.py:40-49 bucketing)."""
+    st = fold.train
+    out = []
+    by_len = {}
+    for T in np.unique(st.in_len):
+        idx = np.where(st.in_len == T)[0]
+        rng.shuffle(idx)
+        for i in range(0, len(idx) - B + 1, B):
+            by_len.setdefault(int(T), []).append(idx[i:i + B])
+    flat = [(T, ids) for T, lst in by_len.items() for ids in lst]
+    order = rng.permutation(len(flat))
+    for j in order[:n_batches]:
+        T, ids = flat[j]
+        b = st.batch_arrays(ids, "click_delta")
+        b["neg"] = rng.randint(0, fold.n_items, size=(B, K)).astype(np.int32)
+        out.append(b)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch_size", type=int, default=512)
+    ap.add_argument("--n_items", type=int, default=46033)
+    ap.add_argument("--hidden_size", type=int, default=250)
+    ap.add_argument("--time_hidden_size", type=int, default=64)
+    ap.add_argument("--neg_num", type=int, default=20)
+    ap.add_argument("--n_batches", type=int, default=48)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_steps", type=int, default=3)
+    ap.add_argument("--no_kernel_timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import tcar_amd  # noqa: F401
+    from tcar_amd.host.synth import SynthFold
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    B, K = args.batch_size, args.neg_num
+    # every rank builds the same catalog (seed 2020) and its own shard of sessions (weak scaling: B per GPU)
+    fold = SynthFold(n_items=args.n_items, dim=args.hidden_size, n_train=max(60000, 4 * B * args.n_batches),
+                     n_test=1000, seed=2020)
+    rng = np.random.RandomState(2020 + rank)
+    batches = build_batches(fold, args.n_batches, B, K, rng)
+    if world > 1:
+        # ranks step in lock-step over buckets of the same length T: share rank 0's T schedule
+        sched = torch.tensor([b["seq"].shape[1] for b in batches], device=dev)
+        dist.broadcast(sched, 0)
+        want = sched.cpu().tolist()
+        pool = {}
+        for b in build_batches(fold, 10 ** 9, B, K, rng):
+            pool.setdefault(b["seq"].shape[1], []).append(b)
+        batches = [pool[T][i % len(pool[T])] for i, T in enumerate(want)]
+
+    from oracle.tcar_oracle import init_params_numpy      # weight init only (np.random), not the oracle model
+    params = init_params_numpy(args.n_items, args.hidden_size, args.time_hidden_size, 0.002, 0.05,
+                               np.random.RandomState(2020))
+    if world > 1:
+        from tcar_amd.dp import DPEngine
+        eng = DPEngine(params, fold.content, fold.mwdhm, device=dev, group=dist.group.WORLD)
+    else:
+        from tcar_amd.engine import TcarEngine
+        eng = TcarEngine(params, fold.content, fold.mwdhm, device=dev)
+    resident = [eng.make_resident(b) for b in batches]
+    mean_T = float(np.mean([b["seq"].shape[1] for b in batches]))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        eng.train_step(None, bt=resident[i % len(resident)])
+    tags = ["score_fwd", "score_dx", "score_dE", "weight_grads", "gather_fwd", "softmax_ce", "adam_item"]
+    if not args.no_kernel_timing:
+        eng.enable_timing(tags)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        eng.train_step(None, bt=resident[(args.warmup + i) % len(resident)])
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last_loss = float((eng.ce[:B] + eng.neg_weight * eng.neg_fb[:B]).mean())
+    value = B * world * args.steps / dt
+
+    kern = eng.timing_summary() if not args.no_kernel_timing else {}
+    N, H = args.n_items, args.hidden_size
+    k_alg = 2 * H + 5 * args.time_hidden_size                      # 820 contraction length (model_combine.py:132-138)
+    flops = {"score_fwd": 2.0 * B * N * k_alg, "score_dx": 2.0 * B * N * k_alg,
+             "score_dE": 2.0 * B * N * (H + 5 * args.time_hidden_size)}
+    roof = None
+    kernels = {}
+    for t, (n, ms) in kern.items():
+        ent = {"launches": n, "avg_ms": round(ms, 5)}
+        if t in flops:
+            ent["tflops"] = round(flops[t] / (ms * 1e-3) / 1e12, 2)
+        elif t == "gather_fwd":
+            by = B * (3536.0 * mean_T + 512.0) * 2                 # read + write per session
+            ent["GBps"] = round(by / (ms * 1e-3) / 1e9, 1)
+        elif t == "adam_item":
+            ent["GBps"] = round(28.0 * N * H / (ms * 1e-3) / 1e9, 1)
+        elif t == "softmax_ce":
+            ent["GBps"] = round(12.0 * B * N / (ms * 1e-3) / 1e9, 1)  # read, read, write of the fp32 row
+        kernels[t] = ent
+    if "score_fwd" in kern:
+        ach = flops["score_fwd"] / (kern["score_fwd"][1] * 1e-3) / 1e12
+        roof = {"kernel": "gemm_f32_kernel<0,0> (full-catalog logits, model_combine.py:138)", "bound": "mfma",
+                "achieved": round(ach, 2), "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": flops["score_fwd"], "avg_ms": round(kern["score_fwd"][1], 5)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.tcar_oracle import TcarOracle
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        ora = TcarOracle(params, fold.content, fold.mwdhm, dtype=torch.float32)
+        ora.train_step(batches[0])                                  # warm-up
+        c0 = time.perf_counter()
+        for i in range(args.cpu_steps):
+            ora.train_step(batches[(i + 1) % len(batches)])
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(B * args.cpu_steps / cdt, 1), "unit": "sessions/s", "cores": cores, "kind": "port",
+               "sample": "%d training steps of B=%d (same synthetic Globo-like batches), PyTorch-CPU fp32 oracle, "
+                         "%d threads" % (args.cpu_steps, B, cores)}
+
+    if rank == 0:
+        out = {"metric": "sessions/sec TCAR train on Globo (synthetic Globo-like fold)", "value": round(value, 1),
+               "unit": "sessions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "TCAR Globo-like fold 0: N=%d items, %d-d content, B=%d/GPU, K=%d negatives, "
+                                      "mean input length %.2f, full-catalog scoring, clip %d + Adam" %
+                                      (N, H, B, K, mean_T, 150),
+                          "global_batch": B * world, "parallelism": "dp%d" % world},
+               "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "last_loss": round(last_loss, 4)}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

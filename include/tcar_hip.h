@@ -118,6 +118,25 @@ int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_tab[5], con
 int tcar_gemm_f32(int layout, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
                   float* C, int64_t ldc, const float* bias, int act, int beta, int splitk, void* stream);
 int tcar_splitk_reduce(const float* slabs, int splitk, int M, int N, int64_t ld, float* out, void* stream);
+
+/* Grouped form: up to 10 INDEPENDENT problems of one layout in a single launch (the step's ~25 small GEMMs are
+ * bound by launch latency and 16-workgroup grids, not FLOPs).  A problem may K-concatenate up to 3 operand pairs
+ * into one accumulator: C = act(sum_s A_s B_s + bias) (+C) — e.g. pre1 = X_ic W_in + X_c W_c + X_act W_int
+ * (modules.py:126-131).  splitk > 1 (single segment, no bias/act/beta): atomic = 0 writes slabs
+ * [splitk_eff, M, ldc]; atomic = 1 adds with fp32 atomics into a C the caller has zeroed (weight gradients,
+ * whose K is the batch). */
+typedef struct {
+  int32_t nseg;
+  const float* A[3];
+  const float* B[3];
+  int64_t lda[3], ldb[3];
+  int32_t K[3];
+  float* C;
+  int64_t ldc;
+  const float* bias;
+  int32_t M, N, act, beta, splitk, atomic;
+} tcar_gemm_desc_t;
+int tcar_gemm_f32_grouped(int layout, int nprob, const tcar_gemm_desc_t* descs /*host*/, void* stream);
 /* number of slabs tcar_gemm_f32 actually writes for a requested split (K is cut in multiples of 32) */
 int tcar_gemm_splitk_effective(int K, int splitk);
 
@@ -150,8 +169,9 @@ int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E, const int3
                   const float* attout, float weight, float* neg_fb, float* dattout, float* g_item,
                   void* stream);
 
-/* tcar_dact_colsum: dz = dy * act'(y) in place over dy ([M, ncol], ld) and bias_grad[c] = sum_m dz[m,c]
- * (gradient of linear_2d's bias + activation, modules.py:52-54).  act: 1 relu, 2 tanh. */
+/* tcar_dact_colsum: dz = dy * act'(y) in place over dy ([M, ncol], ld) and bias_grad[c] += sum_m dz[m,c]
+ * (gradient of linear_2d's bias + activation, modules.py:52-54; fp32 atomics into a caller-zeroed bias_grad).
+ * act: 1 relu, 2 tanh. */
 int tcar_dact_colsum(int M, int ncol, int64_t ld, const float* y, float* dy, float* bias_grad, int act,
                      void* stream);
 

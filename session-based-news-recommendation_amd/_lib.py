@@ -18,7 +18,7 @@ NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_cand_time_fwd", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_dact_colsum", "tcar_rank_topk",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_abi_version"]
 
@@ -85,6 +85,13 @@ class Segments(C.Structure):
                 ("slot", C.c_int32 * NSLOT)]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [("nseg", C.c_int32), ("A", C.c_void_p * 3), ("B", C.c_void_p * 3), ("lda", C.c_int64 * 3),
+                ("ldb", C.c_int64 * 3), ("K", C.c_int32 * 3), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("act", C.c_int32), ("beta", C.c_int32),
+                ("splitk", C.c_int32), ("atomic", C.c_int32)]
+
+
 class TcarError(RuntimeError):
     pass
 
@@ -115,6 +122,7 @@ def load() -> C.CDLL:
     lib.tcar_cand_time_fwd.argtypes = [P(Dims), P(vp * 5), vp, vp, vp]
     lib.tcar_cand_time_bwd.argtypes = [P(Dims), P(vp * 5), vp, vp, P(Grads), vp]
     lib.tcar_gemm_f32.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
+    lib.tcar_gemm_f32_grouped.argtypes = [i32, i32, P(GemmDesc), vp]
     lib.tcar_splitk_reduce.argtypes = [vp, i32, i32, i32, i64, vp, vp]
     lib.tcar_gemm_splitk_effective.argtypes = [i32, i32]
     lib.tcar_attn_pool_fwd.argtypes = [P(Dims), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -3,12 +3,20 @@
 // One kernel template covers the three operand layouts of the TCAR step (include/tcar_hip.h, tcar_gemm_f32):
 //   LA = 0: A is k-contiguous  A[m*lda + k]      LA = 1: A is m-contiguous  A[k*lda + m]
 //   LB = 0: B is k-contiguous  B[n*ldb + k]      LB = 1: B is n-contiguous  B[k*ldb + n]
-// Tile 128(M) x 128(N) x 32(K), 256 threads = 4 waves in a 2x2 grid, each wave owns 64x64 = 2x2 MFMA tiles
-// (64 accumulator VGPRs).  Operands are staged global -> registers -> LDS with the LDS image mirroring the
-// global layout (so every global access is a 16-byte, fully coalesced load):
-//   k-contiguous tiles  [128 rows][32 k + 4 pad]  read back with ds_read_b128 (row stride 36 dwords: 36/4 odd
+// and a GROUP of independent problems per launch (tcar_gemm_f32_grouped): the step has ~25 tiny GEMMs whose
+// cost is launch latency and a 16-workgroup grid, not FLOPs; grouping the independent ones (all weight
+// gradients; all input projections) fills the chip with one launch.  A problem may also K-concatenate up to
+// three (A, B) operand pairs into one accumulator ("segments": pre1 = X_ic W_in + X_c W_c + X_act W_int,
+// modules.py:126-131) and may split K over workgroups (slabs for a deterministic reduce, or fp32 atomics
+// into a pre-zeroed C for the weight gradients whose K is the batch).
+//
+// Tile TM x TN x 32 (128x128 for the full-catalog scoring GEMMs, 64x64 for the small ones), 256 threads =
+// 4 waves in a 2x2 grid, each wave owns (TM/2)x(TN/2) as 32x32 MFMA tiles.  Operands are staged
+// global -> registers -> LDS with the LDS image mirroring the global layout (every global access is a 16-byte,
+// fully coalesced load):
+//   k-contiguous tiles  [rows][32 k + 4 pad]  read back with ds_read_b128 (row stride 36 dwords: 36/4 odd
 //                       => the 16-lane b128 groups hit 16 distinct 4-bank slots, conflict free)
-//   m/n-contiguous tiles [32 k][128 + 4 pad]      read back with ds_read_b32 (lanes = consecutive columns)
+//   m/n-contiguous tiles [32 k][cols + 4 pad] read back with ds_read_b32 (lanes = consecutive columns)
 // MFMA operand pairing: the instruction contracts k in {0,1} = lane>>5.  For an 8-deep k chunk, lane half h
 // holds k = 8c + 4h + j (j = 0..3) of BOTH operands, so MFMA j sums k = 8c+j and 8c+4+j: any pairing is valid
 // as long as A and B agree, and it lets a k-contiguous operand be fetched with one b128 read per 4 MFMAs.
@@ -19,158 +27,194 @@
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-struct GemmArgs {
-  const float* A;
-  const float* B;
+constexpr int BK = 32;
+constexpr int MAXP = 10;      // problems per grouped launch
+constexpr int MAXSEG = 3;     // K-concatenated operand pairs per problem
+
+struct GemmProb {
+  const float* A[MAXSEG];
+  const float* B[MAXSEG];
+  long lda[MAXSEG], ldb[MAXSEG];
+  int K[MAXSEG];
+  int nseg;
   float* C;
+  long ldc;
   const float* bias;
-  int M, N, K;
-  long lda, ldb, ldc;
-  int act, beta, kchunk;
-  int mt, nt;  // tile counts
+  int M, N, act, beta;
+  int ksplit, kchunk, mode;   // mode 0: plain, 1: slabs C[split][M][ldc], 2: atomicAdd into C
+  int mt, nt, wg_begin;       // tiles and first workgroup id of this problem inside the launch
+};
+struct GroupArgs {
+  int nprob;
+  GemmProb p[MAXP];
 };
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int KC_LD = BK + 4;    // row stride (floats) of a k-contiguous tile
-constexpr int MC_LD = BM + 4;    // row stride (floats) of an m/n-contiguous tile
-constexpr int TILE_FLOATS = (BM * KC_LD > BK * MC_LD) ? BM * KC_LD : BK * MC_LD;  // 4608
+template <int LAY, int ROWS>   // ROWS = tile extent along the m/n dimension (64 or 128)
+struct TileGeo {
+  static constexpr int KC_LD = BK + 4;
+  static constexpr int MC_LD = ROWS + 4;
+  static constexpr int FLOATS = (LAY == 0) ? ROWS * KC_LD : BK * MC_LD;
+  static constexpr int NV = ROWS * BK / 4 / 256;   // float4 loads per thread (2 or 4)
+};
 
-template <int LAY>
+template <int LAY, int ROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kend,
-                                          int tid, float4 (&reg)[4]) {
-  // LAY 0: rows r (0..127) x k (32) ; LAY 1: k rows (32) x cols r (128)
+                                          int tid, float4 (&reg)[TileGeo<LAY, ROWS>::NV]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int f = tid + 256 * i;
+  for (int i = 0; i < TileGeo<LAY, ROWS>::NV; ++i) {
+    const int f = tid + 256 * i;
     if (LAY == 0) {
-      int row = f >> 3, c4 = f & 7;
-      int gr = r0 + row, gk = k0 + c4 * 4;
+      const int row = f >> 3, c4 = f & 7;
+      const int gr = r0 + row, gk = k0 + c4 * 4;
       reg[i] = (gr < rmax && gk < kend) ? ld4(P + (long)gr * ld + gk) : zero4();
     } else {
-      int krow = f >> 5, c4 = f & 31;
-      int gk = k0 + krow, gr = r0 + c4 * 4;
+      constexpr int C4 = ROWS / 4;
+      const int krow = f / C4, c4 = f - krow * C4;
+      const int gk = k0 + krow, gr = r0 + c4 * 4;
       reg[i] = (gk < kend && gr + 3 < rmax) ? ld4(P + (long)gk * ld + gr) : zero4();
     }
   }
 }
-template <int LAY>
-__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const float4 (&reg)[4]) {
+template <int LAY, int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const float4 (&reg)[TileGeo<LAY, ROWS>::NV]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int f = tid + 256 * i;
+  for (int i = 0; i < TileGeo<LAY, ROWS>::NV; ++i) {
+    const int f = tid + 256 * i;
     if (LAY == 0) {
-      int row = f >> 3, c4 = f & 7;
-      st4(S + row * KC_LD + c4 * 4, reg[i]);
+      const int row = f >> 3, c4 = f & 7;
+      st4(S + row * TileGeo<LAY, ROWS>::KC_LD + c4 * 4, reg[i]);
     } else {
-      int krow = f >> 5, c4 = f & 31;
-      st4(S + krow * MC_LD + c4 * 4, reg[i]);
+      constexpr int C4 = ROWS / 4;
+      const int krow = f / C4, c4 = f - krow * C4;
+      st4(S + krow * TileGeo<LAY, ROWS>::MC_LD + c4 * 4, reg[i]);
     }
   }
 }
 // fragment for k chunk c (8 deep): out[j] = element k = 8c + 4h + j of tile row/col `idx`
-template <int LAY>
+template <int LAY, int ROWS>
 __device__ __forceinline__ void read_frag(const float* __restrict__ S, int idx, int c, int h, float (&out)[4]) {
   if (LAY == 0) {
-    float4 v = ld4(S + idx * KC_LD + c * 8 + 4 * h);
+    const float4 v = ld4(S + idx * TileGeo<LAY, ROWS>::KC_LD + c * 8 + 4 * h);
     out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] = S[(c * 8 + 4 * h + j) * MC_LD + idx];
+    for (int j = 0; j < 4; ++j) out[j] = S[(c * 8 + 4 * h + j) * TileGeo<LAY, ROWS>::MC_LD + idx];
   }
 }
 
-template <int LA, int LB>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs g) {
+template <int LA, int LB, int TM, int TN>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int FM = TM / 64, FN = TN / 64;              // 32x32 MFMA tiles per wave along m / n
+  constexpr int A_FL = TileGeo<LA, TM>::FLOATS, B_FL = TileGeo<LB, TN>::FLOATS;
+  constexpr int STAGE = A_FL + B_FL;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  // XCD-aware, bijective tile id remap (blocks b and b+8 share an XCD)
+  // XCD-aware, bijective workgroup id remap (blocks b and b+8 share an XCD)
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int pi = 0;
+#pragma unroll 1
+  for (int i = 1; i < ga.nprob; ++i)
+    if (id >= ga.p[i].wg_begin) pi = i;
+  const GemmProb& g = ga.p[pi];
+  id -= g.wg_begin;
+  const int tiles = g.mt * g.nt;
+  const int split = id / tiles;
+  id -= split * tiles;
   int tm, tn;
   if (g.mt <= g.nt) { tn = id / g.mt; tm = id - tn * g.mt; } else { tm = id / g.nt; tn = id - tm * g.nt; }
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * TM, n0 = tn * TN;
 
-  const int ks = blockIdx.z * g.kchunk;
-  const int ke = min(g.K, ks + g.kchunk);
-  const int nit = (ke - ks + BK - 1) / BK;
-  float* Cs = g.C + (long)blockIdx.z * g.M * g.ldc;
-
-  // rmax for loads: k-contiguous operands guard rows by M/N; m/n-contiguous guard columns by the leading dim
-  // (values beyond M / N never reach a stored element; the bound only keeps 16-byte loads inside the rows)
-  const int a_rmax = (LA == 0) ? g.M : min((int)g.lda, (g.M + 3) & ~3);
-  const int b_rmax = (LB == 0) ? g.N : min((int)g.ldb, (g.N + 3) & ~3);
-
-  f32x16 acc[2][2];
+  f32x16 acc[FM][FN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < FM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < FN; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  float4 ra[4], rb[4];
-  if (nit > 0) {
-    load_tile<LA>(g.A, g.lda, m0, a_rmax, ks, ke, tid, ra);
-    load_tile<LB>(g.B, g.ldb, n0, b_rmax, ks, ke, tid, rb);
-    store_tile<LA>(smem, tid, ra);
-    store_tile<LB>(smem + TILE_FLOATS, tid, rb);
-  }
-  __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const float* As = smem + (it & 1) * 2 * TILE_FLOATS;
-    const float* Bs = As + TILE_FLOATS;
-    const bool more = (it + 1 < nit);
-    if (more) {
-      load_tile<LA>(g.A, g.lda, m0, a_rmax, ks + (it + 1) * BK, ke, tid, ra);
-      load_tile<LB>(g.B, g.ldb, n0, b_rmax, ks + (it + 1) * BK, ke, tid, rb);
-    }
-#pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
-      float a[2][4], b[2][4];
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        read_frag<LA>(As, wm * 64 + s * 32 + li, c, lh, a[s]);
-        read_frag<LB>(Bs, wn * 64 + s * 32 + li, c, lh, b[s]);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][j], b[t][j], acc[s][t], 0, 0, 0);
-    }
-    if (more) {
-      float* An = smem + ((it + 1) & 1) * 2 * TILE_FLOATS;
-      store_tile<LA>(An, tid, ra);
-      store_tile<LB>(An + TILE_FLOATS, tid, rb);
+  float4 ra[TileGeo<LA, TM>::NV], rb[TileGeo<LB, TN>::NV];
+#pragma unroll 1
+  for (int sg = 0; sg < g.nseg; ++sg) {
+    const float* __restrict__ Ap = g.A[sg];
+    const float* __restrict__ Bp = g.B[sg];
+    const long lda = g.lda[sg], ldb = g.ldb[sg];
+    const int Kseg = g.K[sg];
+    const int ks = split * g.kchunk;
+    const int ke = min(Kseg, ks + g.kchunk);
+    const int nit = (ke - ks + BK - 1) / BK;
+    // load bounds: k-contiguous operands guard rows by M/N; m/n-contiguous guard columns (values beyond M / N
+    // never reach a stored element; the bound only keeps 16-byte loads inside the rows)
+    const int a_rmax = (LA == 0) ? g.M : min((int)lda, (g.M + 3) & ~3);
+    const int b_rmax = (LB == 0) ? g.N : min((int)ldb, (g.N + 3) & ~3);
+    if (nit > 0) {
+      load_tile<LA, TM>(Ap, lda, m0, a_rmax, ks, ke, tid, ra);
+      load_tile<LB, TN>(Bp, ldb, n0, b_rmax, ks, ke, tid, rb);
+      __syncthreads();                                   // previous segment finished reading stage 0
+      store_tile<LA, TM>(smem, tid, ra);
+      store_tile<LB, TN>(smem + A_FL, tid, rb);
     }
     __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const float* As = smem + (it & 1) * STAGE;
+      const float* Bs = As + A_FL;
+      const bool more = (it + 1 < nit);
+      if (more) {
+        load_tile<LA, TM>(Ap, lda, m0, a_rmax, ks + (it + 1) * BK, ke, tid, ra);
+        load_tile<LB, TN>(Bp, ldb, n0, b_rmax, ks + (it + 1) * BK, ke, tid, rb);
+      }
+#pragma unroll
+      for (int c = 0; c < BK / 8; ++c) {
+        float a[FM][4], b[FN][4];
+#pragma unroll
+        for (int s = 0; s < FM; ++s) read_frag<LA, TM>(As, wm * (TM / 2) + s * 32 + li, c, lh, a[s]);
+#pragma unroll
+        for (int s = 0; s < FN; ++s) read_frag<LB, TN>(Bs, wn * (TN / 2) + s * 32 + li, c, lh, b[s]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int s = 0; s < FM; ++s)
+#pragma unroll
+            for (int t = 0; t < FN; ++t)
+              acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s][j], b[t][j], acc[s][t], 0, 0, 0);
+      }
+      if (more) {
+        float* An = smem + ((it + 1) & 1) * STAGE;
+        store_tile<LA, TM>(An, tid, ra);
+        store_tile<LB, TN>(An + A_FL, tid, rb);
+      }
+      __syncthreads();
+    }
   }
 
   // epilogue: D row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31
+  float* Cs = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
 #pragma unroll
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < FM; ++s)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int col = n0 + wn * 64 + t * 32 + li;
+    for (int t = 0; t < FN; ++t) {
+      const int col = n0 + wn * (TN / 2) + t * 32 + li;
       if (col >= g.N) continue;
       const float bv = g.bias ? g.bias[col] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + s * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int row = m0 + wm * (TM / 2) + s * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (row < g.M) {
-          float v = acc[s][t][e] + bv;
-          if (g.act == 1) v = fmaxf(v, 0.f);
-          else if (g.act == 2) v = tanhf(v);
           float* p = Cs + (long)row * g.ldc + col;
-          if (g.beta) v += *p;
-          *p = v;
+          if (g.mode == 2) {
+            atomicAdd(p, acc[s][t][e]);
+          } else {
+            float v = acc[s][t][e] + bv;
+            if (g.act == 1) v = fmaxf(v, 0.f);
+            else if (g.act == 2) v = tanhf(v);
+            if (g.beta) v += *p;
+            *p = v;
+          }
         }
       }
     }
@@ -188,43 +232,98 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-extern "C" int tcar_gemm_f32(int layout, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
-                             float* C, int64_t ldc, const float* bias, int act, int beta, int splitk, void* stream) {
-  if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
-  if (layout < 0 || layout > 2 || !A || !B || !C) return TCAR_E_ARG;
-  if (!tcar_aligned16(A) || !tcar_aligned16(B) || (lda & 3) || (ldb & 3)) return TCAR_E_ARG;
-  if (splitk < 1) splitk = 1;
-  if (splitk > 1 && (bias || act || beta)) return TCAR_E_ARG;
-  const bool a_kc = (layout != 2), b_kc = (layout == 1);
-  if ((a_kc || b_kc) && (K & 3)) return TCAR_E_ARG;
-  GemmArgs g;
-  g.A = A; g.B = B; g.C = C; g.bias = bias;
-  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-  g.act = act; g.beta = beta;
-  int kchunk = (K + splitk - 1) / splitk;
-  kchunk = ((kchunk + BK - 1) / BK) * BK;
-  g.kchunk = kchunk;
-  splitk = (K + kchunk - 1) / kchunk;
-  g.mt = (M + BM - 1) / BM; g.nt = (N + BN - 1) / BN;
-  dim3 grid(g.mt * g.nt, 1, splitk), block(256);
-  const size_t lds = 4 * TILE_FLOATS * sizeof(float);  // 73,728 B
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+
+template <int LA, int LB, int TM, int TN>
+int launch_variant(const GroupArgs& ga, int nwg, hipStream_t st) {
+  constexpr size_t lds = 2 * (TileGeo<LA, TM>::FLOATS + TileGeo<LB, TN>::FLOATS) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<LA, LB, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_done = true;
   }
-  if (layout == 0) TCAR_LAUNCH((gemm_f32_kernel<0, 1>), grid, block, lds, st, g);
-  else if (layout == 1) TCAR_LAUNCH((gemm_f32_kernel<0, 0>), grid, block, lds, st, g);
-  else TCAR_LAUNCH((gemm_f32_kernel<1, 1>), grid, block, lds, st, g);
+  TCAR_LAUNCH((gemm_f32_kernel<LA, LB, TM, TN>), dim3(nwg), dim3(256), lds, st, ga);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
 
-// NOTE: with splitk > 1 the caller must size C as [splitk_eff, M, ldc] where splitk_eff <= splitk; slabs of
-// unused splits are simply never written, so tcar_splitk_reduce must be given the effective count:
+template <int LA, int LB>
+int launch_layout(GroupArgs& ga, hipStream_t st) {
+  // tile choice: 128x128 when that alone fills the chip, 64x64 otherwise
+  long big = 0;
+  for (int i = 0; i < ga.nprob; ++i)
+    big += (long)((ga.p[i].M + 127) / 128) * ((ga.p[i].N + 127) / 128) * ga.p[i].ksplit;
+  const int T = big >= 192 ? 128 : 64;
+  int wg = 0;
+  for (int i = 0; i < ga.nprob; ++i) {
+    GemmProb& p = ga.p[i];
+    p.mt = (p.M + T - 1) / T;
+    p.nt = (p.N + T - 1) / T;
+    p.wg_begin = wg;
+    wg += p.mt * p.nt * p.ksplit;
+  }
+  if (T == 128) return launch_variant<LA, LB, 128, 128>(ga, wg, st);
+  return launch_variant<LA, LB, 64, 64>(ga, wg, st);
+}
+
+int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {
+  if (d.M <= 0 || d.N <= 0 || d.nseg < 1 || d.nseg > MAXSEG || !d.C) return TCAR_E_ARG;
+  const bool a_kc = (layout != 2), b_kc = (layout == 1);
+  p.nseg = d.nseg;
+  for (int s = 0; s < d.nseg; ++s) {
+    if (!d.A[s] || !d.B[s] || d.K[s] <= 0 || !tcar_aligned16(d.A[s]) || !tcar_aligned16(d.B[s]) || (d.lda[s] & 3) ||
+        (d.ldb[s] & 3))
+      return TCAR_E_ARG;
+    if ((a_kc || b_kc) && (d.K[s] & 3)) return TCAR_E_ARG;
+    p.A[s] = d.A[s]; p.B[s] = d.B[s]; p.lda[s] = d.lda[s]; p.ldb[s] = d.ldb[s]; p.K[s] = d.K[s];
+  }
+  p.C = d.C; p.ldc = d.ldc; p.bias = d.bias; p.M = d.M; p.N = d.N; p.act = d.act; p.beta = d.beta;
+  int splitk = d.splitk < 1 ? 1 : d.splitk;
+  p.mode = splitk > 1 ? (d.atomic ? 2 : 1) : 0;
+  if (splitk > 1 && (d.nseg != 1 || d.bias || d.act || d.beta)) return TCAR_E_ARG;
+  int kmax = 0;
+  for (int s = 0; s < d.nseg; ++s) kmax = d.K[s] > kmax ? d.K[s] : kmax;
+  int kchunk = (kmax + splitk - 1) / splitk;
+  kchunk = ((kchunk + BK - 1) / BK) * BK;
+  p.kchunk = kchunk;
+  p.ksplit = (kmax + kchunk - 1) / kchunk;
+  if (p.ksplit == 1) p.mode = (splitk > 1 && d.atomic) ? 2 : 0;
+  return TCAR_OK;
+}
+
+}  // namespace
+
+extern "C" int tcar_gemm_f32_grouped(int layout, int nprob, const tcar_gemm_desc_t* descs, void* stream) {
+  if (nprob <= 0) return TCAR_OK;
+  if (layout < 0 || layout > 2 || nprob > MAXP || !descs) return TCAR_E_ARG;
+  GroupArgs ga;
+  ga.nprob = 0;
+  for (int i = 0; i < nprob; ++i) {
+    if (descs[i].M <= 0 || descs[i].N <= 0) continue;        // empty problems are no-ops
+    const int rc = fill_prob(ga.p[ga.nprob], layout, descs[i]);
+    if (rc) return rc;
+    ga.nprob++;
+  }
+  if (ga.nprob == 0) return TCAR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == 0) return launch_layout<0, 1>(ga, st);
+  if (layout == 1) return launch_layout<0, 0>(ga, st);
+  return launch_layout<1, 1>(ga, st);
+}
+
+extern "C" int tcar_gemm_f32(int layout, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,
+                             float* C, int64_t ldc, const float* bias, int act, int beta, int splitk, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
+  tcar_gemm_desc_t d = {};
+  d.nseg = 1;
+  d.A[0] = A; d.B[0] = B; d.lda[0] = lda; d.ldb[0] = ldb; d.K[0] = K;
+  d.C = C; d.ldc = ldc; d.bias = bias; d.M = M; d.N = N; d.act = act; d.beta = beta; d.splitk = splitk; d.atomic = 0;
+  return tcar_gemm_f32_grouped(layout, 1, &d, stream);
+}
+
+// with splitk > 1 (slab mode) C is [splitk_eff, M, ldc]; K is cut in multiples of 32, so fewer slabs than
+// requested may be written — tcar_splitk_reduce must be given this effective count:
 extern "C" int tcar_gemm_splitk_effective(int K, int splitk) {
   if (splitk < 1) splitk = 1;
   int kchunk = (K + splitk - 1) / splitk;

@@ -132,16 +132,19 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
   }
 }
 
-// ---- dz = dy * act'(y), bias_grad = column sums (modules.py:52-54 backward) -------------------------------
-// grid.x = ncol/64 column blocks; 256 threads = 64 columns x 4 row phases.
+// ---- dz = dy * act'(y), bias_grad += column sums (modules.py:52-54 backward) ------------------------------
+// grid = (ncol/64 column blocks, row chunks); 256 threads = 64 columns x 4 row phases; one atomic per column
+// and workgroup into the (zeroed) bias gradient.
 __global__ __launch_bounds__(256) void dact_colsum_kernel(int M, int ncol, long ld, const float* __restrict__ y,
                                                           float* __restrict__ dy, float* __restrict__ bias_grad, int act) {
   __shared__ float sh[256];
   const int tid = threadIdx.x, cl = tid & 63, rp = tid >> 6;
   const int col = blockIdx.x * 64 + cl;
+  const int rows_per = (M + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
   float s = 0.f;
   if (col < ncol) {
-    for (int r = rp; r < M; r += 4) {
+    for (int r = r0 + rp; r < r1; r += 4) {
       const long i = (long)r * ld + col;
       const float yy = y[i];
       float g = dy[i];
@@ -152,7 +155,10 @@ __global__ __launch_bounds__(256) void dact_colsum_kernel(int M, int ncol, long 
   }
   sh[tid] = s;
   __syncthreads();
-  if (rp == 0 && col < ncol && bias_grad) bias_grad[col] = sh[cl] + sh[64 + cl] + sh[128 + cl] + sh[192 + cl];
+  if (rp == 0 && col < ncol && bias_grad) {
+    const float v = sh[cl] + sh[64 + cl] + sh[128 + cl] + sh[192 + cl];
+    if (v != 0.f) atomicAdd(bias_grad + col, v);
+  }
 }
 
 // ---- rank of the label and top-k (util.py:13-17, model_combine.py:301) -----------------------------------
@@ -236,8 +242,10 @@ extern "C" int tcar_dact_colsum(int M, int ncol, int64_t ld, const float* y, flo
                                 void* stream) {
   if (M <= 0 || ncol <= 0) return TCAR_OK;
   if (!y || !dy) return TCAR_E_ARG;
-  TCAR_LAUNCH(dact_colsum_kernel, dim3((ncol + 63) / 64), dim3(256), 0, (hipStream_t)stream, M, ncol, (long)ld, y,
-                     dy, bias_grad, act);
+  int chunks = (M + 31) / 32;
+  if (chunks > 16) chunks = 16;
+  TCAR_LAUNCH(dact_colsum_kernel, dim3((ncol + 63) / 64, chunks), dim3(256), 0, (hipStream_t)stream, M, ncol, (long)ld, y,
+              dy, bias_grad, act);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

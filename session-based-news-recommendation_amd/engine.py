@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Batch, Dims, Grads, Segments, Tables, check
+from ._lib import Batch, Dims, GemmDesc, Grads, Segments, Tables, check
 
 TIME_NAMES = ["month_embedding", "day_embedding", "week_embedding", "hour_embedding", "minute_embedding"]
 TIME_VOCAB = [13, 32, 8, 25, 61]
@@ -276,9 +276,65 @@ class TcarEngine:
     def _g(self, name: str):
         return C.c_void_p(self.G.data_ptr() + 4 * self.seg[name]["off"])
 
-    def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, act=0, beta=0, splitk=1):
+    def gemm(self, layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias=None, act=0, beta=0, splitk=1, tag=None):
+        ev = self._tick(tag)
         check(self.lib.tcar_gemm_f32(layout, M, N, K, A, lda, Bm, ldb, Cm, ldc, bias, act, beta, splitk,
                                      self._stream()), "tcar_gemm_f32")
+        self._tock(ev)
+
+    @staticmethod
+    def desc(M, N, segs, Cm, ldc, bias=None, act=0, beta=0, splitk=1, atomic=0) -> GemmDesc:
+        """One problem of a grouped GEMM; segs = [(A, lda, B, ldb, K), ...] accumulate into one C."""
+        d = GemmDesc()
+        d.nseg = len(segs)
+        for i, (A, lda, Bm, ldb, K) in enumerate(segs):
+            d.A[i], d.lda[i], d.B[i], d.ldb[i], d.K[i] = A.value, lda, Bm.value, ldb, K
+        d.C, d.ldc, d.bias = Cm.value, ldc, (bias.value if bias is not None else None)
+        d.M, d.N, d.act, d.beta, d.splitk, d.atomic = M, N, act, beta, splitk, atomic
+        return d
+
+    def ggemm(self, layout, descs, tag=None):
+        arr = (GemmDesc * len(descs))(*descs)
+        ev = self._tick(tag)
+        check(self.lib.tcar_gemm_f32_grouped(layout, len(descs), arr, self._stream()), "tcar_gemm_f32_grouped")
+        self._tock(ev)
+
+    # per-kernel device timing (bench.py): HIP events on the stream the kernels are launched on
+    timing = None
+
+    def enable_timing(self, tags):
+        self.timing = {t: [] for t in tags}
+
+    def _tick(self, tag):
+        if self.timing is None or tag not in self.timing:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.dev))
+        self.timing[tag].append((e0, e1))
+        return e1
+
+    def _tock(self, ev):
+        if ev is not None:
+            ev.record(torch.cuda.current_stream(self.dev))
+
+    def timing_summary(self):
+        """tag -> (launches, mean ms); call after a device synchronize."""
+        out = {}
+        for t, evs in (self.timing or {}).items():
+            if evs:
+                ms = [a.elapsed_time(b) for a, b in evs]
+                out[t] = (len(ms), float(np.mean(ms)))
+        return out
+
+    def make_resident(self, batch: Dict[str, np.ndarray]) -> Batch:
+        """Upload a batch into its OWN device buffer (kept alive by the engine) and return its descriptor."""
+        save = (self.pin, getattr(self, "ibufs", None), getattr(self, "pin_evt", None), getattr(self, "pin_i", 0))
+        self.pin = None
+        bt = self.upload(batch)
+        torch.cuda.current_stream(self.dev).synchronize()
+        self._resident = getattr(self, "_resident", []) + [self.ibufs]
+        self.pin, self.ibufs, self.pin_evt, self.pin_i = save
+        return bt
 
     def _tables(self) -> Tables:
         t = Tables()
@@ -369,30 +425,35 @@ class TcarEngine:
                   "tcar_cand_time_fwd")
             self._time_dirty = False
         tab = self._tables()
+        ev = self._tick("gather_fwd")
         check(lib.tcar_gather_clip_fwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.x_icp), p(self.x_pt),
                                        p(self.x_act), p(self.click_t), st), "tcar_gather_clip_fwd")
-        # pre1 = X_ic W_in + X_c W_c + X_act W_int      (modules.py:126-131)
-        self.gemm(0, BT, g.ldh, g.ic, p(self.x_icp), g.ic, self._w("m_win"), g.ldh, p(self.pre1), g.ldh)
-        self.gemm(0, BT, g.ldh, g.ldh, p(self.x_icp, g.ldh), g.ic, self._w("m_wc"), g.ldh, p(self.pre1), g.ldh, beta=1)
-        self.gemm(0, BT, g.ldh, g.ldt, p(self.x_act), g.ldt, self._w("m_wint"), g.ldh, p(self.pre1), g.ldh, beta=1)
-        # pre2 = X_pt W'_in + X_c W'_c                   (modules.py:94-96)
-        self.gemm(0, BT, g.ldh, g.pt, p(self.x_pt), g.pt, self._w("s_win"), g.ldh, p(self.pre2), g.ldh)
-        self.gemm(0, BT, g.ldh, g.ldh, p(self.x_icp, g.ldh), g.ic, self._w("s_wc"), g.ldh, p(self.pre2), g.ldh, beta=1)
-        # q = tanh(relu(click_t Wq1 + b) Wq2 + b)        (modules.py:138-139)
-        self.gemm(0, B, g.ldh, g.ct, p(self.click_t), g.ct, self._w("q1_w"), g.ldh, p(self.q1), g.ldh,
-                  bias=self._w("q1_b"), act=1)
-        self.gemm(0, B, g.ic, g.ldh, p(self.q1), g.ldh, self._w("q2_w"), g.ic, p(self.q), g.ic,
-                  bias=self._w("q2_b"), act=2)
+        self._tock(ev)
+        # one grouped launch:  pre1 = X_ic W_in + X_c W_c + X_act W_int (modules.py:126-131),
+        # pre2 = X_pt W'_in + X_c W'_c (modules.py:94-96), q1 = relu(click_t Wq1 + b) (modules.py:138)
+        D = self.desc
+        x_c = p(self.x_icp, g.ldh)
+        self.ggemm(0, [
+            D(BT, g.ldh, [(p(self.x_icp), g.ic, self._w("m_win"), g.ldh, g.ic), (x_c, g.ic, self._w("m_wc"), g.ldh, g.ldh),
+                          (p(self.x_act), g.ldt, self._w("m_wint"), g.ldh, g.ldt)], p(self.pre1), g.ldh),
+            D(BT, g.ldh, [(p(self.x_pt), g.pt, self._w("s_win"), g.ldh, g.pt), (x_c, g.ic, self._w("s_wc"), g.ldh, g.ldh)],
+              p(self.pre2), g.ldh),
+            D(B, g.ldh, [(p(self.click_t), g.ct, self._w("q1_w"), g.ldh, g.ct)], p(self.q1), g.ldh,
+              bias=self._w("q1_b"), act=1)])
+        # q = tanh(q1 Wq2 + b)                           (modules.py:139)
+        self.ggemm(0, [D(B, g.ic, [(p(self.q1), g.ldh, self._w("q2_w"), g.ic, g.ldh)], p(self.q), g.ic,
+                         bias=self._w("q2_b"), act=2)])
         check(lib.tcar_attn_pool_fwd(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2),
                                      p(self.q), self._w("m_wres"), self._w("s_wres"), p(self.pooled), p(self.alpha),
                                      st), "tcar_attn_pool_fwd")
         # attout = [tanh(pooled_ic W_o + b) | tanh(pooled_t W'_o + b)]   (model_combine.py:119,127,132)
-        self.gemm(0, B, g.ic, g.ic, p(self.pooled), g.ek, self._w("o_w"), g.ic, p(self.attout), g.ek,
-                  bias=self._w("o_b"), act=2)
-        self.gemm(0, B, g.pt, g.pt, p(self.pooled, g.ic), g.ek, self._w("ot_w"), g.pt, p(self.attout, g.ic), g.ek,
-                  bias=self._w("ot_b"), act=2)
+        self.ggemm(0, [
+            D(B, g.ic, [(p(self.pooled), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.attout), g.ek,
+              bias=self._w("o_b"), act=2),
+            D(B, g.pt, [(p(self.pooled, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.attout, g.ic), g.ek,
+              bias=self._w("ot_b"), act=2)])
         # logits = attout E^T                              (model_combine.py:138)
-        self.gemm(1, B, g.N, g.ek, p(self.attout), g.ek, p(self.E), g.ek, p(self.logits), g.Npad)
+        self.gemm(1, B, g.N, g.ek, p(self.attout), g.ek, p(self.E), g.ek, p(self.logits), g.Npad, tag="score_fwd")
 
     # -------------------------------------------------------------------------------------------- backward
     def backward(self, bt: Batch):
@@ -401,17 +462,23 @@ class TcarEngine:
         B, T, K = bt.B, bt.T, bt.K
         BT = B * T
         p = self._p
-        self.G[:self.atomic_n].zero_()
+        self.G.zero_()                # tables, bias and weight gradients are accumulated with atomics
         self.sqn_dense.zero_()
         self.sqn_pieces.zero_()
+        ev = self._tick("softmax_ce")
         check(lib.tcar_softmax_ce(B, g.N, p(self.logits), g.Npad, C.c_void_p(bt.label), p(self.ce), st), "tcar_softmax_ce")
+        self._tock(ev)
         # d attout = dlogits E  (contraction over the catalog: split-K slabs + reduce)
         S = lib.tcar_gemm_splitk_effective(g.Npad, self.splitk)
-        self.gemm(0, B, g.ek, g.Npad, p(self.logits), g.Npad, p(self.E), g.ek, p(self.slabs), g.ek, splitk=self.splitk)
+        self.gemm(0, B, g.ek, g.Npad, p(self.logits), g.Npad, p(self.E), g.ek, p(self.slabs), g.ek, splitk=self.splitk,
+                  tag="score_dx")
         check(lib.tcar_splitk_reduce(p(self.slabs), S, B, g.ek, g.ek, p(self.dattout), st), "tcar_splitk_reduce")
-        # dE = dlogits^T attout: item columns -> Gi, time columns -> d_et (content is frozen)
-        self.gemm(2, g.N, g.ldh, B, p(self.logits), g.Npad, p(self.attout), g.ek, p(self.Gi), g.ldh)
-        self.gemm(2, g.N, g.pt, B, p(self.logits), g.Npad, p(self.attout, g.ic), g.ek, p(self.d_et), g.pt)
+        # dE = dlogits^T attout: item columns -> Gi, time columns -> d_et (content is frozen); one launch, both
+        # problems stream the same dlogits tiles
+        D = self.desc
+        self.ggemm(2, [
+            D(g.N, g.ldh, [(p(self.logits), g.Npad, p(self.attout), g.ek, B)], p(self.Gi), g.ldh),
+            D(g.N, g.pt, [(p(self.logits), g.Npad, p(self.attout, g.ic), g.ek, B)], p(self.d_et), g.pt)], tag="score_dE")
         if K:
             check(lib.tcar_neg_term(C.byref(self.dims), B, K, p(self.E), C.c_void_p(bt.neg), p(self.attout),
                                     self.neg_weight, p(self.neg_fb), p(self.dattout), p(self.Gi), st), "tcar_neg_term")
@@ -420,30 +487,41 @@ class TcarEngine:
         # output transforms (linear_2d + tanh) backward
         check(lib.tcar_dact_colsum(B, g.ic, g.ek, p(self.attout), p(self.dattout), self._g("o_b"), 2, st), "dact")
         check(lib.tcar_dact_colsum(B, g.pt, g.ek, p(self.attout, g.ic), p(self.dattout, g.ic), self._g("ot_b"), 2, st), "dact")
-        self.gemm(1, B, g.ic, g.ic, p(self.dattout), g.ek, self._w("o_w"), g.ic, p(self.dpooled), g.ek)
-        self.gemm(1, B, g.pt, g.pt, p(self.dattout, g.ic), g.ek, self._w("ot_w"), g.pt, p(self.dpooled, g.ic), g.ek)
-        self.gemm(2, g.ic, g.ic, B, p(self.pooled), g.ek, p(self.dattout), g.ek, self._g("o_w"), g.ic)
-        self.gemm(2, g.pt, g.pt, B, p(self.pooled, g.ic), g.ek, p(self.dattout, g.ic), g.ek, self._g("ot_w"), g.pt)
+        self.ggemm(1, [
+            D(B, g.ic, [(p(self.dattout), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.dpooled), g.ek),
+            D(B, g.pt, [(p(self.dattout, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.dpooled, g.ic), g.ek)])
         check(lib.tcar_attn_pool_bwd(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2),
                                      p(self.q), self._w("m_wres"), self._w("s_wres"), p(self.alpha), p(self.dpooled),
                                      p(self.dx_icp), p(self.dx_pt), p(self.dq), p(self.dpre1), p(self.dpre2),
                                      self._g("m_wres"), self._g("s_wres"), st), "tcar_attn_pool_bwd")
         # query MLP backward (modules.py:138-139)
         check(lib.tcar_dact_colsum(B, g.ic, g.ic, p(self.q), p(self.dq), self._g("q2_b"), 2, st), "dact")
-        self.gemm(1, B, g.ldh, g.ic, p(self.dq), g.ic, self._w("q2_w"), g.ic, p(self.dq1), g.ldh)
-        self.gemm(2, g.ldh, g.ic, B, p(self.q1), g.ldh, p(self.dq), g.ic, self._g("q2_w"), g.ic)
+        self.ggemm(1, [D(B, g.ldh, [(p(self.dq), g.ic, self._w("q2_w"), g.ic, g.ic)], p(self.dq1), g.ldh)])
         check(lib.tcar_dact_colsum(B, g.ldh, g.ldh, p(self.q1), p(self.dq1), self._g("q1_b"), 1, st), "dact")
-        self.gemm(1, B, g.ct, g.ldh, p(self.dq1), g.ldh, self._w("q1_w"), g.ldh, p(self.dclick), g.ct)
-        self.gemm(2, g.ct, g.ldh, B, p(self.click_t), g.ct, p(self.dq1), g.ldh, self._g("q1_w"), g.ldh)
-        # projection backward: only the ITEM half of dX_ic is needed (content is frozen)
-        self.gemm(1, BT, g.ldh, g.ldh, p(self.dpre1), g.ldh, self._w("m_win"), g.ldh, p(self.dx_icp), g.ic, beta=1)
-        self.gemm(1, BT, g.ldt, g.ldh, p(self.dpre1), g.ldh, self._w("m_wint"), g.ldh, p(self.dx_act), g.ldt)
-        self.gemm(1, BT, g.pt, g.ldh, p(self.dpre2), g.ldh, self._w("s_win"), g.ldh, p(self.dx_pt), g.pt, beta=1)
-        self.gemm(2, g.ic, g.ldh, BT, p(self.x_icp), g.ic, p(self.dpre1), g.ldh, self._g("m_win"), g.ldh)
-        self.gemm(2, g.ldh, g.ldh, BT, p(self.x_icp, g.ldh), g.ic, p(self.dpre1), g.ldh, self._g("m_wc"), g.ldh)
-        self.gemm(2, g.ldt, g.ldh, BT, p(self.x_act), g.ldt, p(self.dpre1), g.ldh, self._g("m_wint"), g.ldh)
-        self.gemm(2, g.pt, g.ldh, BT, p(self.x_pt), g.pt, p(self.dpre2), g.ldh, self._g("s_win"), g.ldh)
-        self.gemm(2, g.ldh, g.ldh, BT, p(self.x_icp, g.ldh), g.ic, p(self.dpre2), g.ldh, self._g("s_wc"), g.ldh)
+        # input gradients: click query rows and the projections (only the ITEM half of dX_ic is needed: content
+        # is frozen)
+        self.ggemm(1, [
+            D(B, g.ct, [(p(self.dq1), g.ldh, self._w("q1_w"), g.ldh, g.ldh)], p(self.dclick), g.ct),
+            D(BT, g.ldh, [(p(self.dpre1), g.ldh, self._w("m_win"), g.ldh, g.ldh)], p(self.dx_icp), g.ic, beta=1),
+            D(BT, g.ldt, [(p(self.dpre1), g.ldh, self._w("m_wint"), g.ldh, g.ldh)], p(self.dx_act), g.ldt),
+            D(BT, g.pt, [(p(self.dpre2), g.ldh, self._w("s_win"), g.ldh, g.ldh)], p(self.dx_pt), g.pt, beta=1)])
+        # all nine weight gradients (x^T dy, K = batch rows) in one launch, split-K with fp32 atomics into the
+        # zeroed gradient arena
+        kb = max(1, min(16, (B + 1023) // 1024))
+        kr = max(1, min(16, (BT + 1023) // 1024))
+        x_c = p(self.x_icp, g.ldh)
+        W = lambda M, N, A, lda, Bm, ldb, K, name, ks: D(M, N, [(A, lda, Bm, ldb, K)], self._g(name), N, splitk=max(ks, 2),
+                                                          atomic=1)
+        self.ggemm(2, [
+            W(g.ic, g.ic, p(self.pooled), g.ek, p(self.dattout), g.ek, B, "o_w", kb),
+            W(g.pt, g.pt, p(self.pooled, g.ic), g.ek, p(self.dattout, g.ic), g.ek, B, "ot_w", kb),
+            W(g.ldh, g.ic, p(self.q1), g.ldh, p(self.dq), g.ic, B, "q2_w", kb),
+            W(g.ct, g.ldh, p(self.click_t), g.ct, p(self.dq1), g.ldh, B, "q1_w", kb),
+            W(g.ic, g.ldh, p(self.x_icp), g.ic, p(self.dpre1), g.ldh, BT, "m_win", kr),
+            W(g.ldh, g.ldh, x_c, g.ic, p(self.dpre1), g.ldh, BT, "m_wc", kr),
+            W(g.ldt, g.ldh, p(self.x_act), g.ldt, p(self.dpre1), g.ldh, BT, "m_wint", kr),
+            W(g.pt, g.ldh, p(self.x_pt), g.pt, p(self.dpre2), g.ldh, BT, "s_win", kr),
+            W(g.ldh, g.ldh, x_c, g.ic, p(self.dpre2), g.ldh, BT, "s_wc", kr)], tag="weight_grads")
         # clip norms of the dense blocks BEFORE the sparse rows are scattered in
         one = Segments()
         one.nseg = 1
@@ -467,9 +545,11 @@ class TcarEngine:
         check(lib.tcar_clip_adam(p(self.W), p(self.G), p(self.M), p(self.V), C.byref(self.segs_all), p(self.sqn_dense),
                                  p(self.sqn_pieces), p(self.use_dense), clip, lr_t, self.b1, self.b2, self.eps, st),
               "tcar_clip_adam")
+        ev = self._tick("adam_item")
         check(lib.tcar_clip_adam_2d(p(self.E), g.ek, p(self.Gi), p(self.Mi), p(self.Vi), g.N, g.ldh, SLOT["item_emb"],
                                     p(self.sqn_dense), p(self.sqn_pieces), p(self.use_dense), clip, lr_t, self.b1,
                                     self.b2, self.eps, st), "tcar_clip_adam_2d")
+        self._tock(ev)
         self.b1_pow = np.float32(self.b1_pow * np.float32(self.b1))
         self.b2_pow = np.float32(self.b2_pow * np.float32(self.b2))
         self._time_dirty = True

@@ -95,6 +95,44 @@ def test_gemm_epilogues_and_splitk(lib):
     close(out.cpu().numpy(), z - bias, name="splitk")
 
 
+def test_gemm_grouped_segments_and_atomic_splitk(lib):
+    """Grouped launch: a 3-segment K-concatenated problem + a biased/activated one (NN), and atomic split-K
+    weight-gradient problems (TN) into a zeroed C."""
+    from tcar_amd._lib import GemmDesc
+    from tcar_amd.engine import TcarEngine
+    rng = np.random.RandomState(9)
+    D = TcarEngine.desc
+    M = 300
+    xs = [rng.standard_normal((M, k)).astype(np.float32) for k in (512, 256, 64)]
+    ws = [rng.standard_normal((k, 192)).astype(np.float32) * 0.1 for k in (512, 256, 64)]
+    x2, w2 = rng.standard_normal((70, 128)).astype(np.float32), rng.standard_normal((128, 64)).astype(np.float32) * 0.1
+    b2 = rng.standard_normal(64).astype(np.float32)
+    dx = [torch.tensor(a).cuda() for a in xs]
+    dw = [torch.tensor(a).cuda() for a in ws]
+    dx2, dw2, db2 = torch.tensor(x2).cuda(), torch.tensor(w2).cuda(), torch.tensor(b2).cuda()
+    c1 = torch.empty(M, 192, device="cuda")
+    c2 = torch.empty(70, 64, device="cuda")
+    descs = [D(M, 192, [(ptr(dx[i]), xs[i].shape[1], ptr(dw[i]), 192, xs[i].shape[1]) for i in range(3)], ptr(c1), 192),
+             D(70, 64, [(ptr(dx2), 128, ptr(dw2), 64, 128)], ptr(c2), 64, bias=ptr(db2), act=2)]
+    arr = (GemmDesc * 2)(*descs)
+    assert lib.tcar_gemm_f32_grouped(0, 2, arr, None) == 0
+    close(c1.cpu().numpy(), sum(x.astype(np.float64) @ w.astype(np.float64) for x, w in zip(xs, ws)), name="3seg")
+    close(c2.cpu().numpy(), np.tanh(x2.astype(np.float64) @ w2 + b2), name="bias-tanh")
+    # TN, atomic split-K: dW = x^T dy with K = 5000 rows
+    Kr = 5000
+    x = rng.standard_normal((Kr, 320)).astype(np.float32)
+    dy = rng.standard_normal((Kr, 256)).astype(np.float32)
+    xd, dyd = torch.tensor(x).cuda(), torch.tensor(dy).cuda()
+    g1 = torch.zeros(320, 256, device="cuda")
+    g2 = torch.zeros(64, 256, device="cuda")
+    descs = [D(320, 256, [(ptr(xd), 320, ptr(dyd), 256, Kr)], ptr(g1), 256, splitk=5, atomic=1),
+             D(64, 256, [(ptr(xd, 128), 320, ptr(dyd), 256, Kr)], ptr(g2), 256, splitk=2, atomic=1)]
+    arr = (GemmDesc * 2)(*descs)
+    assert lib.tcar_gemm_f32_grouped(2, 2, arr, None) == 0
+    close(g1.cpu().numpy(), x.astype(np.float64).T @ dy, name="atomic dW", atol_scale=5e-5)
+    close(g2.cpu().numpy(), x[:, 128:192].astype(np.float64).T @ dy, name="atomic dW view", atol_scale=5e-5)
+
+
 # -------------------------------------------------------------------------------------- standalone score ops
 def test_softmax_ce_and_rank_topk(lib):
     rng = np.random.RandomState(2)
