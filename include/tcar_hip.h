@@ -67,6 +67,9 @@ typedef struct {
   float* g_dur;
   float* sqn;            /* [TCAR_NSLOT] IndexedSlices value-norm^2 pieces, slots below */
   int32_t slot_item, slot_pos, slot_time[5], slot_dur;
+  float* rows_out;       /* NULL, or [B*T, ldh]: tcar_gather_clip_bwd WRITES each item-row gradient here instead
+                            of adding it into g_item (data-parallel path: rows are all-gathered, then applied on
+                            every rank with tcar_scatter_add_rows) */
 } tcar_grads_t;
 
 /* One mini-batch = the feed_dict of model_combine.py:214-227 (int32, row-major). */
@@ -95,6 +98,11 @@ int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* tab, const t
 int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
                          const float* dx_icp, const float* dx_pt, const float* dx_act, const float* dclick,
                          const tcar_grads_t* g, void* stream);
+
+/* tcar_scatter_add_rows: g_item[ids[r]-1, :] += rows[r, :] for r < R (ids 1-based like `seq`; id 0 = padding
+ * row, skipped).  The "bucketed sparse-embedding exchange" applies the all-gathered (id, row) pairs with it. */
+int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float* rows, int64_t R, float* g_item,
+                          void* stream);
 
 /* tcar_cand_time_fwd: candidate_publish_t of model_combine.py:86-92 written into E[:, ic:ek].
  * mwdhm [N,5] int32 = publish_time_MWDHM (model_combine.py:37). */

@@ -205,6 +205,8 @@ class TcarOracle:
         if keep:
             item_slice.retain_grad()
             vals["item_emb"].append(item_slice)       # the densified [1:] gradient block (S5)
+        if keep:
+            cand_pt.retain_grad()                     # d(loss)/d(candidate_publish_t): the time block of dE
         items_emb_cont = torch.cat([item_slice, self.content[1:]], -1)                 # :135
         items_emb = torch.cat([items_emb_cont, cand_pt], -1)                           # :136
         logits = attout @ items_emb.t()                                                # :138
@@ -214,7 +216,7 @@ class TcarOracle:
         out = {"logits": logits, "ce": ce, "attout": attout, "pooled_ic": pooled_ic, "pooled_t": pooled_t,
                "alpha1": alpha - alpha2, "alpha2": alpha2, "alpha_t": alpha_t, "q": q,
                "seq_ic": seq_ic, "seq_pt": seq_pt, "seq_act": seq_act, "click_t": click_t,
-               "pre1": pre1, "pre2": pre2}
+               "pre1": pre1, "pre2": pre2, "cand_pt": cand_pt}
         neg = batch.get("neg", None)
         if with_neg and neg is not None and np.asarray(neg).size > 0:
             negi = torch.as_tensor(np.asarray(neg), dtype=torch.long)

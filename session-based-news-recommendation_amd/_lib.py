@@ -17,7 +17,7 @@ SOURCES = ["gemm_f32.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip"]
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_cand_time_fwd", "tcar_cand_time_bwd",
+SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_dact_colsum", "tcar_rank_topk",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_abi_version"]
@@ -71,7 +71,7 @@ class Tables(C.Structure):
 class Grads(C.Structure):
     _fields_ = [("g_item", C.c_void_p), ("g_pos", C.c_void_p), ("g_time", C.c_void_p * 5), ("g_dur", C.c_void_p),
                 ("sqn", C.c_void_p), ("slot_item", C.c_int32), ("slot_pos", C.c_int32),
-                ("slot_time", C.c_int32 * 5), ("slot_dur", C.c_int32)]
+                ("slot_time", C.c_int32 * 5), ("slot_dur", C.c_int32), ("rows_out", C.c_void_p)]
 
 
 class Batch(C.Structure):
@@ -119,6 +119,7 @@ def load() -> C.CDLL:
     P = C.POINTER
     lib.tcar_gather_clip_fwd.argtypes = [P(Dims), P(Tables), P(Batch), vp, vp, vp, vp, vp]
     lib.tcar_gather_clip_bwd.argtypes = [P(Dims), P(Tables), P(Batch), vp, vp, vp, vp, P(Grads), vp]
+    lib.tcar_scatter_add_rows.argtypes = [P(Dims), vp, vp, i64, vp, vp]
     lib.tcar_cand_time_fwd.argtypes = [P(Dims), P(vp * 5), vp, vp, vp]
     lib.tcar_cand_time_bwd.argtypes = [P(Dims), P(vp * 5), vp, vp, P(Grads), vp]
     lib.tcar_gemm_f32.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
         if (col < ldh) {
           float4 gx = fma4(xi[c], -bi, scale4(gi[c], ai));
           sq[0] += dot4(gx, gx);
-          atomic_add4(a.g.g_item + (long)n * ldh + col, gx);
+          if (a.g.rows_out) st4(a.g.rows_out + (long)row * ldh + col, gx);
+          else atomic_add4(a.g.g_item + (long)n * ldh + col, gx);
           float4 gp = fma4(xp[c], -bp, scale4(gi[c], ap));
           sq[1] += dot4(gp, gp);
           atomic_add4(pos_acc + t * ldh + col, gp);
@@ -333,6 +334,21 @@ __global__ __launch_bounds__(256) void cand_time_bwd_kernel(const CandArgs a) {
   }
 }
 
+// g_item[ids[r]-1] += rows[r]: one wave per row, 256-byte-contiguous float atomics
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(int ldh, int n_items, const int32_t* __restrict__ ids,
+                                                               const float* __restrict__ rows, long R,
+                                                               float* __restrict__ g_item) {
+  const int lane = threadIdx.x & 63;
+  const long wave_g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  for (long r = wave_g; r < R; r += nwaves) {
+    const int id = ids[r];
+    if (id < 1 || id > n_items) continue;
+    for (int col = lane * 4; col < ldh; col += 256)
+      atomic_add4(g_item + (long)(id - 1) * ldh + col, ld4(rows + r * ldh + col));
+  }
+}
+
 int check_dims(const tcar_dims_t* d) {
   if (!d || d->n_items <= 0 || d->H <= 0 || d->Ht <= 0) return TCAR_E_ARG;
   if (d->ldh < d->H || d->ldt < d->Ht || (d->ldh & 63) || (d->ldh > 512)) return TCAR_E_ARG;
@@ -382,6 +398,18 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
     (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     TCAR_LAUNCH(gather_clip_bwd_kernel<2>, dim3(grid), dim3(256), lds, st, a);
   }
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float* rows, int64_t R,
+                                     float* g_item, void* stream) {
+  if (R <= 0) return TCAR_OK;
+  if (check_dims(d) || !ids || !rows || !g_item) return TCAR_E_ARG;
+  int grid = (int)((R + 3) / 4);
+  if (grid > 2048) grid = 2048;
+  TCAR_LAUNCH(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d->ldh, d->n_items, ids, rows,
+              (long)R, g_item);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -1,0 +1,136 @@
+"""Data-parallel TCAR step: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm).
+
+The reference is single-process (no collectives anywhere); this layer is new design.  Examples are
+independent given the weights and the loss is a SUM over sessions (model_combine.py:147,156), so the global
+gradient is the plain sum of the ranks' gradients — no 1/W rescale — and every rank applies the same clip + Adam
+to its replica.  What makes it more than one all-reduce is the clip: tf.clip_by_norm of an IndexedSlices uses the
+norm of the concatenated slice VALUES, which is not additive for blocks that are sums over the
+whole (global) batch.  The exchange therefore runs in this order (all on the compute stream; `GradExchange`):
+
+  1. all-reduce  [ dE_item | dE_time ]      [N, ldh + pt] fp32 — the dense item-table block (scoring + densified
+                                            negative part) and the candidate-side time block, BEFORE any per-row work
+  2. local       ||dE_item||^2              -> dense norm piece of item_emb (now global)
+  3. all-reduce  [ arena grads | pieces ]   dense weights, small tables (session-side rows only), per-row norm
+                                            pieces (these ARE additive: each gathered row belongs to one rank)
+  4. local       candidate-side clip backward of the reduced dE_time -> time-table grads + their norm pieces,
+                                            added ONCE after step 3 (adding before would count them W times)
+  5. all-gather  (item id, gradient row)    the "bucketed sparse-embedding exchange": B_local*T rows per rank,
+                                            padded to a common row count with id 0 (skipped by the scatter)
+  6. local       scatter-add all rows into dE_item, then the norms of the dense weights.
+
+xGMI is point-to-point (7 links/GPU): step 1 moves ~106 MB per rank at the Globo size and dominates; it only
+depends on the scoring backward, so a later round can overlap it with the attention / embedding backward.
+`GradExchange` is device-agnostic (tests run it over gloo on CPU tensors with the oracle's gradients).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import check
+from .engine import SLOT, TcarEngine
+
+
+class GradExchange:
+    """The collective schedule above, independent of where the local pieces come from."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def run(self, big: torch.Tensor, arena_pieces: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor,
+            sqnorm_item: Callable[[], None], cand_time_bwd: Callable[[], None],
+            scatter_rows: Callable[[torch.Tensor, torch.Tensor], None], sqnorm_dense: Callable[[], None]):
+        g = self.group
+        if self.world > 1:
+            dist.all_reduce(big, group=g)                                   # 1
+        sqnorm_item()                                                       # 2
+        if self.world > 1:
+            dist.all_reduce(arena_pieces, group=g)                          # 3
+        cand_time_bwd()                                                     # 4
+        if self.world > 1:                                                  # 5
+            all_ids = torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+            all_rows = torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
+            dist.all_gather_into_tensor(all_ids.view(-1), ids.reshape(-1).contiguous(), group=g)
+            dist.all_gather_into_tensor(all_rows.view(-1), rows.reshape(-1).contiguous(), group=g)
+            scatter_rows(all_ids.view(-1), all_rows.view(-1, rows.shape[-1]))
+        else:
+            scatter_rows(ids.reshape(-1), rows.reshape(-1, rows.shape[-1]))
+        sqnorm_dense()                                                      # 6
+
+
+def shard_bounds(b: int, world: int, rank: int):
+    """Contiguous split of a length-bucketed batch of b sessions (sampler.py:40-49) into `world` shards of
+    ceil(b/world); trailing ranks may get fewer (or zero) rows.  Returns (lo, hi, cap)."""
+    cap = (b + world - 1) // world
+    lo = min(b, rank * cap)
+    hi = min(b, lo + cap)
+    return lo, hi, cap
+
+
+class DPEngine(TcarEngine):
+    """TcarEngine whose backward ends with the `GradExchange` schedule.  All ranks must call train_step with
+    batches of the SAME input length T (they walk the same bucket schedule)."""
+
+    def __init__(self, *a, group=None, **kw):
+        super().__init__(*a, **kw)
+        self.group = group
+        self.xch = GradExchange(group)
+        self.rows_cap = 0
+
+    def _ensure_rows(self, rows: int):
+        if rows > self.rows_cap:
+            self.rows_buf = torch.zeros(rows, self.geo.ldh, dtype=torch.float32, device=self.dev)
+            self.ids_buf = torch.zeros(rows, dtype=torch.int32, device=self.dev)
+            self.rows_cap = rows
+
+    def finish_backward(self, bt, cap_rows: Optional[int] = None):
+        g, lib, st, p = self.geo, self.lib, self._stream(), self._p
+        B, T = (bt.B, bt.T) if bt is not None else (0, 0)
+        n_rows = B * T
+        cap = max(cap_rows or 0, n_rows)
+        self._ensure_rows(max(cap, 1))
+        rows, ids = self.rows_buf[:max(cap, 1)], self.ids_buf[:max(cap, 1)]
+        if cap > n_rows:
+            rows[n_rows:].zero_()
+            ids[n_rows:].zero_()
+        if bt is not None:
+            ids[:n_rows].copy_(bt._seq_t[:n_rows])
+            tab, gr = self._tables(), self._grads()
+            gr.rows_out = rows.data_ptr()
+            check(lib.tcar_gather_clip_bwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.dx_icp), p(self.dx_pt),
+                                           p(self.dx_act), p(self.dclick), C.byref(gr), st), "tcar_gather_clip_bwd")
+
+        def scatter(all_ids, all_rows):
+            check(lib.tcar_scatter_add_rows(C.byref(self.dims), p(all_ids), p(all_rows), all_ids.numel(), p(self.Gi),
+                                            self._stream()), "tcar_scatter_add_rows")
+
+        self.xch.run(self.big, self.Gx, ids, rows, self._sqnorm_item, self._cand_time_bwd, scatter, self._sqnorm_dense)
+
+    def train_step(self, batch, bt=None, cap_rows: Optional[int] = None):
+        """`batch` may be None for a rank whose shard of the global batch is empty (it still joins the collectives)."""
+        if batch is None and bt is None:
+            self.Gx.zero_()
+            self.big.zero_()
+            self.sqn_dense.zero_()
+            self.finish_backward(None, cap_rows)
+            self.update()
+            return torch.zeros(0, device=self.dev)
+        bt = bt or self.upload(batch)
+        self.forward(bt)
+        self.backward_local(bt)
+        self.finish_backward(bt, cap_rows)
+        self.update()
+        return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
+
+    def loss_and_grads(self, batch, bt=None, cap_rows: Optional[int] = None):
+        bt = bt or self.upload(batch)
+        self.forward(bt)
+        self.backward_local(bt)
+        self.finish_backward(bt, cap_rows)
+        return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]

@@ -127,15 +127,20 @@ class TcarEngine:
         self.arena_n = off
         self.atomic_n = sum(self.seg[a[0]]["n"] for a in ARENA[:N_ATOMIC])
         self.W = torch.zeros(off, **f32)
-        self.G = torch.zeros(off, **f32)
+        # gradients + the per-row norm pieces live in ONE buffer (a single all-reduce in the data-parallel path)
+        self.Gx = torch.zeros(off + _lib.NSLOT, **f32)
+        self.G = self.Gx[:off]
         self.M = torch.zeros(off, **f32)
         self.V = torch.zeros(off, **f32)
         self.E = torch.zeros(g.Npad, g.ek, **f32)
-        self.Gi = torch.zeros(g.N, g.ldh, **f32)
+        # dense item-table gradient and the candidate-side time block of dE, contiguous for the same reason
+        self.big = torch.zeros(g.N * (g.ldh + g.pt), **f32)
+        self.Gi = self.big[:g.N * g.ldh].view(g.N, g.ldh)
+        self.d_et = self.big[g.N * g.ldh:].view(g.N, g.pt)
         self.Mi = torch.zeros(g.N, g.ldh, **f32)
         self.Vi = torch.zeros(g.N, g.ldh, **f32)
         self.sqn_dense = torch.zeros(_lib.NSLOT, **f32)
-        self.sqn_pieces = torch.zeros(_lib.NSLOT, **f32)
+        self.sqn_pieces = self.Gx[off:]
         use = np.ones(_lib.NSLOT, dtype=np.int32)
         for n in ["dec_pos", "duration_embedding"] + TIME_NAMES:
             use[SLOT[n]] = 0                      # tables: IndexedSlices pieces only
@@ -259,8 +264,6 @@ class TcarEngine:
             self.rank = torch.empty(B, dtype=torch.int32, device=self.dev)
             self.topk = torch.empty(B, 20, dtype=torch.int32, device=self.dev)
             self.work_B = B
-        if not hasattr(self, "d_et"):
-            self.d_et = torch.empty(g.N, g.pt, **f32)
 
     # --------------------------------------------------------------------------------------------- helpers
     def _stream(self):
@@ -410,6 +413,8 @@ class TcarEngine:
         bt.label = base + 4 * o
         o += B
         bt.neg = (base + 4 * o) if K else None
+        bt._seq_t = self.ibufs[i][:B * T]           # tensor view of `seq` (ids of the sparse-row exchange)
+        bt._keep = self.ibufs[i]
         return bt
 
     # --------------------------------------------------------------------------------------------- forward
@@ -458,13 +463,40 @@ class TcarEngine:
     # -------------------------------------------------------------------------------------------- backward
     def backward(self, bt: Batch):
         """Loss (model_combine.py:142-147) and the gradient of its SUM w.r.t. all 23 variables."""
+        self.backward_local(bt)
+        lib, st, p = self.lib, self._stream(), self._p
+        # clip norm of the dense item block BEFORE the sparse rows are scattered in (DESIGN.md S5)
+        self._sqnorm_item()
+        tab, gr = self._tables(), self._grads()
+        check(lib.tcar_gather_clip_bwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.dx_icp), p(self.dx_pt),
+                                       p(self.dx_act), p(self.dclick), C.byref(gr), st), "tcar_gather_clip_bwd")
+        self._cand_time_bwd()
+        self._sqnorm_dense()
+
+    def _sqnorm_item(self):
+        g = self.geo
+        one = Segments()
+        one.nseg = 1
+        one.off[0], one.len[0], one.slot[0] = 0, g.N * g.ldh, SLOT["item_emb"]
+        check(self.lib.tcar_sqnorm(self._p(self.Gi), C.byref(one), self._p(self.sqn_dense), self._stream()), "tcar_sqnorm")
+
+    def _cand_time_bwd(self):
+        gr = self._grads()
+        check(self.lib.tcar_cand_time_bwd(C.byref(self.dims), C.byref(self._time_ptrs()), self._p(self.mwdhm),
+                                          self._p(self.d_et), C.byref(gr), self._stream()), "tcar_cand_time_bwd")
+
+    def _sqnorm_dense(self):
+        check(self.lib.tcar_sqnorm(self._p(self.G), C.byref(self.segs_dense), self._p(self.sqn_dense), self._stream()),
+              "tcar_sqnorm")
+
+    def backward_local(self, bt: Batch):
+        """Everything of the backward pass that needs no other rank: loss, dlogits, dE, input / weight gradients."""
         g, lib, st = self.geo, self.lib, self._stream()
         B, T, K = bt.B, bt.T, bt.K
         BT = B * T
         p = self._p
-        self.G.zero_()                # tables, bias and weight gradients are accumulated with atomics
+        self.Gx.zero_()               # tables, bias, weight gradients and norm pieces are accumulated with atomics
         self.sqn_dense.zero_()
-        self.sqn_pieces.zero_()
         ev = self._tick("softmax_ce")
         check(lib.tcar_softmax_ce(B, g.N, p(self.logits), g.Npad, C.c_void_p(bt.label), p(self.ce), st), "tcar_softmax_ce")
         self._tock(ev)
@@ -522,18 +554,6 @@ class TcarEngine:
             W(g.ldt, g.ldh, p(self.x_act), g.ldt, p(self.dpre1), g.ldh, BT, "m_wint", kr),
             W(g.pt, g.ldh, p(self.x_pt), g.pt, p(self.dpre2), g.ldh, BT, "s_win", kr),
             W(g.ldh, g.ldh, x_c, g.ic, p(self.dpre2), g.ldh, BT, "s_wc", kr)], tag="weight_grads")
-        # clip norms of the dense blocks BEFORE the sparse rows are scattered in
-        one = Segments()
-        one.nseg = 1
-        one.off[0], one.len[0], one.slot[0] = 0, g.N * g.ldh, SLOT["item_emb"]
-        check(lib.tcar_sqnorm(p(self.Gi), C.byref(one), p(self.sqn_dense), st), "tcar_sqnorm")
-        # embedding backward: sparse rows + IndexedSlices norm pieces
-        tab, gr = self._tables(), self._grads()
-        check(lib.tcar_gather_clip_bwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.dx_icp), p(self.dx_pt),
-                                       p(self.dx_act), p(self.dclick), C.byref(gr), st), "tcar_gather_clip_bwd")
-        check(lib.tcar_cand_time_bwd(C.byref(self.dims), C.byref(self._time_ptrs()), p(self.mwdhm), p(self.d_et),
-                                     C.byref(gr), st), "tcar_cand_time_bwd")
-        check(lib.tcar_sqnorm(p(self.G), C.byref(self.segs_dense), p(self.sqn_dense), st), "tcar_sqnorm")
 
     # ---------------------------------------------------------------------------------------------- update
     def update(self):

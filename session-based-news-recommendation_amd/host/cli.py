@@ -1,0 +1,148 @@
+"""Command line of the trainer: the reference's flags (main.py:94-123, same names and defaults) plus the inputs
+the reference hard-codes as author paths (main.py:36, util.py:47) and the MI355X-specific switches.
+
+    python main.py --foldnum=0 --epoch=1                      # a fold on disk (data_partition layout)
+    python main.py --synthetic 46033 --epoch 1                # synthetic Globo-like fold (no dataset needed)
+    python -m torch.distributed.run --nproc-per-node 8 main.py --gpus 8 ...   # data parallel over RCCL
+
+`--save / --is_print / --train` keep argparse `type=bool` (any non-empty string is True), as in the reference.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import pickle
+import random
+import sys
+
+import numpy as np
+
+# (flag, default, type, help) — main.py:94-123
+REFERENCE_FLAGS = [
+    ("datapath", "./data/", str, "Location of pre-processed dataset"),
+    ("dataset", "mind/TCAR-mid/", str, "Dataset"),
+    ("foldnum", 1, int, "The fold number of pre-processed dataset"),
+    ("batch_size", 512, int, "Batch size"),
+    ("lr", 0.001, float, "Learning rate"),
+    ("epoch", 10, int, "Number of epochs"),
+    ("maxlen", 20, int, "Number of max window size"),
+    ("neg_num", 20, int, "Number of neg samples"),
+    ("model", "model_combine", str, "Model to use"),
+    ("hidden_size", 250, int, None),
+    ("time_hidden_size", 64, int, None),
+    ("max_grad", 150, int, None),
+    ("stddev", 0.05, float, None),
+    ("emb_stddev", 0.002, float, None),
+    ("dropout_rate", 0.5, float, None),
+    ("l2_emb", 0.0, float, None),
+    ("save", False, bool, "Save model and test results"),
+    ("is_print", False, bool, "Save model and test results"),
+    ("train", True, bool, "Train or just test the specified model"),
+    ("modelpath", "./ckpt/", str, "File to save model checkpoints"),
+    ("inputdata", "test", str, "Use train or test data to test model"),
+    ("threshold_acc", 0.27, float, "Accuracy threshold to save"),
+]
+
+
+def build_parser() -> argparse.ArgumentParser:
+    ap = argparse.ArgumentParser(description="TCAR trainer (MI355X-native hot path)")
+    for name, default, typ, hlp in REFERENCE_FLAGS:
+        ap.add_argument("--" + name, default=default, type=typ, help=hlp)
+    ap.add_argument("--split_way", default="Normal/", type=str, choices=["Normal/", "TrainLen/", "TestLen/"],
+                    help="Choose different split ways")
+    # inputs the reference hard-codes
+    ap.add_argument("--category_path", default=None, type=str, help="pickle of article categories (main.py:36)")
+    ap.add_argument("--neighbor_path", default=None, type=str, help="pickle of the negative source (util.py:47-48)")
+    # call-site toggles the reference leaves as comments (sampler.py:87-99)
+    ap.add_argument("--gap_mode", default="active_t", choices=["active_t", "click_delta"])
+    ap.add_argument("--neg_mode", default="uniform", choices=["uniform", "neighbor", "impression"])
+    # MI355X
+    ap.add_argument("--gpus", default=1, type=int, help="data-parallel ranks (launch with torch.distributed.run)")
+    ap.add_argument("--synthetic", default=0, type=int, help="N items of a synthetic Globo-like fold (no files)")
+    ap.add_argument("--synthetic_train", default=100000, type=int)
+    ap.add_argument("--synthetic_test", default=10000, type=int)
+    ap.add_argument("--seed", default=2020, type=int)
+    return ap
+
+
+def load_datas(args):
+    """main.py:14-47: returns train_data, test_data, neighbor, args(dict), item_dict."""
+    print("load the datasets.")
+    a = vars(args).copy()
+    if args.synthetic:
+        from .synth import SynthFold
+        fold = SynthFold(n_items=args.synthetic, dim=args.hidden_size, n_train=args.synthetic_train,
+                         n_test=args.synthetic_test, seed=args.seed, active_t=(args.gap_mode == "active_t"))
+
+        def as_data(store):
+            len_dict = {}
+            for T in np.unique(store.in_len):
+                len_dict[int(T)] = np.where(store.in_len == T)[0].tolist()
+            return (len_dict, None, None, store)
+
+        train_data, test_data = as_data(fold.train), as_data(fold.test)
+        item_dict = fold.item_dict
+        neighbor = fold.neighbor_dict() if args.neg_mode == "neighbor" else {0: [0]}     # truthy => negatives on
+        a.update(fold.model_args())
+        for k, v in vars(args).items():
+            a[k] = v
+    else:
+        from .data import load_fold
+        base = args.datapath + args.dataset + args.split_way
+        train_data, test_data, item_dict, neighbor, content_emb, publish_time, _ = load_fold(
+            base, args.foldnum, args.neighbor_path)
+        freq = base + 'item_freq_dict_norm_' + str(args.foldnum) + '.txt'
+        a['item_freq_dict_norm'] = pickle.load(open(freq, 'rb')) if os.path.exists(freq) else None
+        a['reverse_item'] = {cnt - 1: idx for idx, cnt in item_dict.items()}
+        if args.category_path:
+            a['category_id'] = pickle.load(open(args.category_path, 'rb'))
+        else:
+            a['category_id'] = {idx: 0 for idx in item_dict}     # no category file: ILD / unexp degenerate to 0
+        a['publish_time'] = publish_time[0]
+        a['publish_time_MWDHM'] = publish_time[1]
+        a['content_emb'] = content_emb
+    a["itemnum"] = len(item_dict)
+    print('------', len(item_dict), len(a['publish_time_MWDHM']))
+    return train_data, test_data, neighbor, a, item_dict
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    random.seed(args.seed)                       # main.py:10-12
+    np.random.seed(args.seed)
+    is_train, model_path, input_data = args.train, args.modelpath, args.inputdata
+    dp_group = None
+    if args.gpus > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local))
+        dp_group = dist.group.WORLD
+    train_data, test_data, neighbor, a, item_dict = load_datas(args)
+    if dp_group is not None:
+        import torch
+        a['dp_group'] = dp_group
+        a['device'] = "cuda:%d" % torch.cuda.current_device()
+    modname = args.model
+    mod = __import__(modname, fromlist=True)     # main.py:65-66 plug-in protocol
+    model = getattr(mod, "Seq2SeqAttNN")(a)
+    if is_train:
+        print('Begin Training')
+        model.train(None, item_dict, train_data, neighbor, a, test_data, None)
+    else:
+        import torch
+        sent = train_data if input_data == "train" else test_data
+        print('Begin Testing. Test data is %s data' % ("train" if input_data == "train" else "test"))
+        ck = torch.load(model_path, weights_only=False)
+        model.engine.load_params(ck["variables"])
+        model.test(None, sent, a)
+    if dp_group is not None:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    return model
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

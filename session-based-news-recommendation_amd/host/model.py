@@ -1,0 +1,229 @@
+"""`Seq2SeqAttNN` — host-side mirror of the reference's model plug-in (model_combine.py:10-315).
+
+main.py:65-66 loads the model as ``getattr(__import__(args.model), "Seq2SeqAttNN")(args_dict)`` and calls
+``train(sess, item_dict, train_data, neighbor_dict, args, test_data, saver)`` / ``test(sess, test_data, args)``.
+This class keeps those signatures (``sess`` / ``saver`` are accepted and ignored: there is no TensorFlow session),
+the stdout lines of model_combine.py:201,229-230,244,247,255,288-293,310-314 and the NaN guard (:243-246), and
+runs every step on the HIP engine (`tcar_amd.engine.TcarEngine`).  Differences that are deliberate:
+
+  * the per-batch feed is int32 arrays from the tensorised sampler (host/sampler.py), not nested lists;
+  * evaluation ranks / top-20 come from the `tcar_rank_topk` kernel, so the [B, N] score matrix never travels to
+    the host (model_combine.py:293,296,301 argsort it twice per session on the CPU);
+  * ILD / unexp are vectorised over an int category table (model_combine.py:174-194 are O(20^2) dict lookups);
+  * dense weights are drawn from RandomState(2020) (TF's RNG stream of tf.set_random_seed(2020) cannot be
+    reproduced); the embedding tables consume the GLOBAL numpy stream in creation order exactly like
+    modules.py:32, so a seeded run draws the same negatives as the reference afterwards.
+"""
+from __future__ import annotations
+
+import os
+import time
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from ..engine import TIME_NAMES, TIME_VOCAB, TcarEngine, VAR_ORDER
+from . import metrics as M
+from .sampler import Sampler
+
+
+def _shapes(N, H, Ht):
+    s = OrderedDict()
+    s["item_emb"] = (N + 1, H)
+    s["dec_pos"] = (40, H)
+    for n, v in zip(TIME_NAMES, TIME_VOCAB):
+        s[n] = (v, Ht)
+    s["duration_embedding"] = (11, Ht)
+    dense = {"multi_attention/input_linear_trans/w_3d": (2 * H, H), "multi_attention/cont_linear_trans/w_3d": (H, H),
+             "multi_attention/inter_linear_trans/w_3d": (Ht, H), "multi_attention/res_linear_trans/w_3d": (H, 1),
+             "multi_attention/query_trans1/w1": (2 * Ht, H), "multi_attention/query_trans1/b1": (H,),
+             "multi_attention/query_trans2/w1": (H, 2 * H), "multi_attention/query_trans2/b1": (2 * H,),
+             "attout_item_cont_trans/w1": (2 * H, 2 * H), "attout_item_cont_trans/b1": (2 * H,),
+             "cont_attention/input_linear_trans/w_3d": (5 * Ht, H), "cont_attention/cont_linear_trans/w_3d": (H, H),
+             "cont_attention/res_linear_trans/w_3d": (H, 1), "attout_pt_trans/w1": (5 * Ht, 5 * Ht),
+             "attout_pt_trans/b1": (5 * Ht,)}
+    for n in VAR_ORDER:
+        if n in dense:
+            s[n] = dense[n]
+    return s
+
+
+def initial_variables(N, H, Ht, emb_stddev, stddev, weight_seed=2020):
+    """Tables: np.random.normal on the global stream, creation order, row 0 zeroed when zero_pad
+    (modules.py:32-34; dec_pos default stddev 0.02 and no pad, model_combine.py:57-64; duration no pad, :106).
+    Dense weights ~ N(0, stddev) (modules.py:50-51,65) from a private stream."""
+    wr = np.random.RandomState(weight_seed)
+    out = OrderedDict()
+    for name, shp in _shapes(N, H, Ht).items():
+        if name == "dec_pos":
+            t = np.random.normal(0, 0.02, shp)
+        elif name in ("item_emb", "duration_embedding") or name in TIME_NAMES:
+            t = np.random.normal(0, emb_stddev, shp)
+            if name != "duration_embedding":
+                t[0] = 0.0
+        else:
+            t = wr.normal(0, stddev, shp)
+        out[name] = t.astype(np.float32)
+    return out
+
+
+class Seq2SeqAttNN():
+    """The memory network with context/temporal attention, MI355X edition."""
+
+    def __init__(self, args):
+        self.publish_time_MWDHM = np.asarray(args['publish_time_MWDHM'], dtype=np.int32)
+        self.itemnum = args['itemnum']
+        self.category_id = args['category_id']
+        self.item_freq_dict_norm = args.get('item_freq_dict_norm')
+        self.reverse_item = args['reverse_item']
+        content = np.asarray(args['content_emb'], dtype=np.float32)
+        self.candidate_n = content.shape[0]
+        self.emb_stddev = args['emb_stddev']
+        self.stddev = args['stddev']
+        self.hidden_size = args['hidden_size']
+        self.time_hidden_size = args['time_hidden_size']
+        self.l2_emb = args.get('l2_emb', 0.0)
+        self.batch_size = args['batch_size']
+        self.epoch = args['epoch']
+        self.neg_num = args['neg_num']
+        self.gap_mode = args.get('gap_mode', 'active_t')
+        self.neg_mode = args.get('neg_mode', 'uniform')
+        self.curEpoch = 0
+        self.error_during_train = False
+        if content.shape[1] != self.hidden_size:
+            raise ValueError("content_emb width %d != --hidden_size %d (model_combine.py:111 concatenates them)"
+                             % (content.shape[1], self.hidden_size))
+        N = self.candidate_n - 1
+        print('size of seq_content', (None, None, self.hidden_size))
+        print('size of seq_publish_t', (None, None, 5 * self.time_hidden_size))
+        print('size of click_t', (None, 2 * self.time_hidden_size))
+        params = args.get('initial_variables') or initial_variables(N, self.hidden_size, self.time_hidden_size,
+                                                                    self.emb_stddev, self.stddev)
+        self.variables_names = [n + ':0' for n in VAR_ORDER]
+        print(self.variables_names)
+        engine_cls = TcarEngine
+        kw = {}
+        if args.get('dp_group') is not None:
+            from ..dp import DPEngine
+            engine_cls, kw = DPEngine, {"group": args['dp_group']}
+        self.engine = engine_cls(params, content, self.publish_time_MWDHM, lr=args['lr'], max_grad=args.get('max_grad'),
+                                 device=args.get('device', 'cuda:0'), **kw)
+        self._cat = None
+        self._store_cache = {}
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _category_table(self):
+        if self._cat is None:
+            self._cat = M.category_table(self.reverse_item, self.category_id, self.candidate_n - 1)
+        return self._cat
+
+    def printData(self, filename, batch_in, batch_out, batch_pred):
+        os.makedirs('saved', exist_ok=True)
+        with open('saved/CAR+P_Normal_predict_exa_' + filename + '.txt', 'a+') as f:
+            for index in range(len(batch_in)):
+                f.write('# batch in: {} # batch out: {} # batch pred: {} \n'.format(
+                    str(batch_in[index]), str(batch_out[index]), str(batch_pred[index])))
+
+    def getILD(self, recList):
+        return float(M.ild_batch(np.asarray([recList]), self._category_table())[0])
+
+    def getUnexp(self, inSeq, recList):
+        if len(recList) == 0:
+            return 0
+        return float(M.unexp_batch(np.asarray([inSeq]), np.asarray([recList]), self._category_table())[0])
+
+    def _sampler(self, data, neighbor_dict=None, item_dict=None, neg_num=None):
+        # (len_dict, session_dict, session_time_dict) as util.py:56 returns it, or with a 4th element: a prebuilt
+        # SessionStore whose integer example ids populate len_dict (large synthetic folds skip the dict form)
+        len_d, sess_d, time_d = data[:3]
+        store = data[3] if len(data) > 3 else None
+        return Sampler(len_d, sess_d, time_d, neighbor_dict, item_dict, neg_num, batch_size=self.batch_size,
+                       gap_mode=self.gap_mode, neg_mode=self.neg_mode, store=store)
+
+    # -------------------------------------------------------------------------------------------- train
+    def train(self, sess, item_dict, train_data, neighbor_dict, args, test_data=None, saver=None, threshold_acc=0.99):
+        eng = self.engine
+        for epoch in range(self.epoch):
+            self.curEpoch = epoch
+            print('Epoch {}'.format(epoch))
+            batch = 0
+            sampler = self._sampler(train_data, neighbor_dict, item_dict, args['neg_num'])
+            total = torch.zeros((), dtype=torch.float64, device=eng.dev)
+            count = 0
+            t0 = time.time()
+            while sampler.has_next():
+                batch += 1
+                feed = sampler.next_batch_arrays()
+                if batch < 3 and feed["neg"] is not None:
+                    print(feed["neg"][0][:10].tolist())
+                crt_loss = eng.train_step(feed)                 # [b] on device; no host sync inside the loop
+                total += crt_loss.double().sum()
+                count += crt_loss.numel()
+            avgc = float(total.item()) / max(count, 1)
+            self.train_seconds = time.time() - t0
+            self.train_sessions = count
+            if np.isnan(avgc):
+                print('Epoch {}: NaN error!'.format(str(epoch)))
+                self.error_during_train = True
+                return
+            print('\tloss: {:.6f}'.format(avgc))
+            if test_data is not None:
+                recall = self.test(sess, test_data, args)
+                if recall > threshold_acc:
+                    modelname = self.save(args)
+                    print('Model saved - {}'.format(modelname))
+
+    def save(self, args):
+        suf = time.strftime("%Y%m%d%H%M", time.localtime()) + '-' + str(args.get('dataset', '')).replace('/', '_') \
+            + '-' + str(args.get('split_way', '')).replace('/', '_') + '-' + str(args.get('foldnum', 0))
+        path = os.path.join(args.get('modelpath', './ckpt/'), "model.ckpt-" + suf + ".pt")
+        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+        torch.save({"variables": self.engine.export_params(), "step": self.engine.step}, path)
+        return path
+
+    # --------------------------------------------------------------------------------------------- test
+    def test(self, sess, test_data, args):
+        print('Measuring...')
+        eng = self.engine
+        cat = self._category_table()
+        hits, mrrs, ndcgs, ilds, unexps, losses = [], [], [], [], [], []
+        sampler = self._sampler(test_data)
+        batch = 0
+        result_items = set()
+        pending = []
+        while sampler.has_next():
+            batch += 1
+            feed = sampler.next_batch_arrays()
+            rank, topk, ce = eng.eval_step(feed, k=20)
+            pending.append((feed, rank.clone(), topk.clone(), ce.clone()))     # device results; drained below
+            if batch < 3:
+                tk = topk[0].cpu().numpy().tolist()
+                print('batch_in:', feed["seq"][0].tolist())
+                print('active_interval:', feed["gap"][0].tolist())
+                print('input_click_week:', int(feed["cw"][0]))
+                print('batch_out:', int(feed["label"][0]), args['publish_time'][int(feed["label"][0])])
+                print('batch pred:', tk[:10])
+        for feed, rank, topk, ce in pending:
+            r = rank.cpu().numpy()
+            tk = topk.cpu().numpy().astype(np.int64)
+            h, m, n = M.metrics_from_ranks(r, 20)
+            hits += h.tolist()
+            mrrs += m.tolist()
+            ndcgs += n.tolist()
+            losses += ce.cpu().numpy().tolist()
+            ilds += M.ild_batch(tk, cat).tolist()
+            unexps += M.unexp_batch(feed["seq"], tk, cat).tolist()
+            result_items.update(np.unique(tk).tolist())
+            if args.get('is_print'):
+                self.printData(str(args['foldnum']) + '_' + str(self.curEpoch), feed["seq"].tolist(),
+                               feed["label"].tolist(), tk.tolist())
+        print('avg loss...', np.mean(losses))
+        print('avg ILD...', np.mean(ilds))
+        print('avg unexp...', np.mean(unexps))
+        print('len of result dict: ', len(result_items))
+        print('MRR@20: {}, Recall@20: {}, nDCG@20: {}'.format(np.mean(mrrs), np.mean(hits), np.mean(ndcgs)))
+        self.last_metrics = {"mrr": float(np.mean(mrrs)), "recall": float(np.mean(hits)), "ndcg": float(np.mean(ndcgs)),
+                             "loss": float(np.mean(losses)), "ild": float(np.mean(ilds)),
+                             "unexp": float(np.mean(unexps)), "coverage": len(result_items)}
+        return np.mean(hits)

@@ -293,3 +293,27 @@ def test_full_size_properties():
     # (5) padding columns of the parameter arena stay exactly zero
     E = eng.E
     assert float(E[:, H:eng.geo.ldh].abs().max()) == 0.0 and float(E[N:].abs().max()) == 0.0
+
+
+def test_dp_engine_single_rank_path_matches_oracle():
+    """The data-parallel code path (gather backward emitting rows -> exchange schedule -> scatter kernel) with a
+    world of one must reproduce the oracle exactly like the fused single-GPU path."""
+    _need_gpu()
+    from oracle.tcar_oracle import TcarOracle
+    from tcar_amd.dp import DPEngine
+    N, H, Ht, B, T, K = 1000, 250, 64, 33, 5, 7
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=321)
+    eng = DPEngine(params, content, mw, max_grad=2.0)
+    ora = TcarOracle(params, content, mw, max_grad=2.0)
+    loss = eng.loss_and_grads(batch, cap_rows=(B + 3) * T)          # padded row capacity, as an uneven shard has
+    o, g_o, sq_o = ora.loss_and_grads(batch)
+    close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss")
+    g_e, sq_e = eng.export_grads(), eng.export_sqnorms()
+    for k in g_o:
+        close(g_e[k], g_o[k].numpy(), name="grad " + k, atol_scale=5e-5)
+        assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12, ("sqnorm", k, sq_e[k], sq_o[k])
+    for _ in range(2):
+        close(eng.train_step(batch).cpu().numpy(), ora.train_step(batch).numpy(), name="train loss")
+    p_e, p_o = eng.export_params(), ora.export()
+    for k in p_o:
+        close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-4)
