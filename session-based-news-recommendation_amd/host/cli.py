@@ -131,6 +131,10 @@ def main(argv=None):
     if is_train:
         print('Begin Training')
         model.train(None, item_dict, train_data, neighbor, a, test_data, None)
+        if getattr(model, "train_seconds", None):
+            print("[tcar] last epoch: %d sessions in %.2f s = %.0f sessions/s (host sampler + H2D + device step)"
+                  % (model.train_sessions, model.train_seconds, model.train_sessions / model.train_seconds),
+                  file=sys.stderr)
     else:
         import torch
         sent = train_data if input_data == "train" else test_data
