@@ -215,6 +215,57 @@ int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m, float* v,
 /* Library self-description (for loaders). */
 int tcar_abi_version(void);
 
+/* ---- step-level entry points ------------------------------------------------------------------------------------
+ * tcar_train_step IS `sess.run([self.loss, self.global_step, self.train_op], feed_dict)` (model_combine.py:231) and
+ * tcar_eval_step IS `sess.run([self.softmax_input, self.cross_loss], feed_dict)` + cau_metrics / top-k
+ * (model_combine.py:283,296,301): they sequence the op-level entry points above on `stream` with no host
+ * synchronisation and no allocation.  All buffers are caller-owned and described by tcar_ctx_t.
+ * Arena segment order (identical offsets in W, G, M, V), index into ctx->off[]: */
+enum {
+  TCAR_V_POS = 0, TCAR_V_MONTH, TCAR_V_DAY, TCAR_V_WEEK, TCAR_V_HOUR, TCAR_V_MINUTE, TCAR_V_DUR,
+  TCAR_V_M_WRES, TCAR_V_S_WRES,                      /* [0..8] accumulate with atomics */
+  TCAR_V_M_WIN, TCAR_V_M_WC, TCAR_V_M_WINT, TCAR_V_Q1_W, TCAR_V_Q1_B, TCAR_V_Q2_W, TCAR_V_Q2_B,
+  TCAR_V_O_W, TCAR_V_O_B, TCAR_V_S_WIN, TCAR_V_S_WC, TCAR_V_OT_W, TCAR_V_OT_B, TCAR_NVAR
+};
+
+typedef struct {
+  tcar_dims_t d;
+  int32_t splitk;                 /* slabs of the catalog-contraction GEMM (d attout) */
+  int32_t slot_of[TCAR_NVAR];     /* norm slot of each arena segment */
+  int32_t slot_item;
+  float b1, b2, eps, clip, neg_weight;
+  /* parameters / optimizer state */
+  float* E;                       /* [Npad, ek] */
+  float* W; float* Gx; float* M; float* V;   /* arenas; Gx = gradients followed by TCAR_NSLOT norm pieces */
+  int64_t arena_n;
+  int64_t off[TCAR_NVAR];
+  float* big;                     /* [N*ldh | N*pt]: dense item gradient, then the time block of dE */
+  float* Mi; float* Vi;           /* [N, ldh] */
+  float* sqn_dense;               /* [TCAR_NSLOT] */
+  const int32_t* use_dense;       /* [TCAR_NSLOT] */
+  const int32_t* mwdhm;           /* [N,5] publish_time_MWDHM */
+  tcar_segments_t segs_all, segs_dense;
+  /* workspace (sized by the caller for the largest B and B*T it will submit) */
+  float *x_icp, *x_pt, *x_act, *click_t, *pre1, *pre2, *q1, *q, *alpha, *pooled, *attout, *logits, *ce, *neg_fb;
+  float *dattout, *dpooled, *dq, *dq1, *dclick, *slabs, *dx_icp, *dx_pt, *dx_act, *dpre1, *dpre2;
+  int32_t* rank; int32_t* topk;
+  /* optional device timing of the dominant kernel (full-catalog logits GEMM): ev_n pairs of hipEvent_t, used
+   * round-robin through the host counter *ev_cursor; ev_n = 0 disables it */
+  void* const* ev_start; void* const* ev_stop; int32_t ev_n; int32_t* ev_cursor;
+} tcar_ctx_t;
+
+/* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */
+int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream);
+/* loss + every gradient that needs no other rank (everything except the row scatter / candidate-side clip backward) */
+int tcar_step_backward_local(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream);
+/* single-GPU completion: dense item norm, embedding backward (scatter), candidate-side backward, dense norms */
+int tcar_step_finish(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream);
+/* per-variable clip + Adam with the bias-corrected rate lr_t */
+int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream);
+int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream);
+/* rank [B], topk [B,k], ce [B] (the logits buffer is consumed) */
+int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,14 +13,16 @@ from typing import List
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libtcar_hip.so")
-SOURCES = ["gemm_f32.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip"]
+SOURCES = ["gemm_f32.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip", "step.hip"]
+NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_dact_colsum", "tcar_rank_topk",
-           "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_abi_version"]
+           "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_abi_version", "tcar_step_forward",
+           "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_eval_step"]
 
 
 def _hipcc() -> str:
@@ -92,6 +94,24 @@ class GemmDesc(C.Structure):
                 ("splitk", C.c_int32), ("atomic", C.c_int32)]
 
 
+_WS = ["x_icp", "x_pt", "x_act", "click_t", "pre1", "pre2", "q1", "q", "alpha", "pooled", "attout", "logits", "ce",
+       "neg_fb", "dattout", "dpooled", "dq", "dq1", "dclick", "slabs", "dx_icp", "dx_pt", "dx_act", "dpre1", "dpre2"]
+
+
+class Ctx(C.Structure):
+    """mirror of tcar_ctx_t (include/tcar_hip.h)"""
+    _fields_ = ([("d", Dims), ("splitk", C.c_int32), ("slot_of", C.c_int32 * NVAR), ("slot_item", C.c_int32),
+                 ("b1", C.c_float), ("b2", C.c_float), ("eps", C.c_float), ("clip", C.c_float),
+                 ("neg_weight", C.c_float),
+                 ("E", C.c_void_p), ("W", C.c_void_p), ("Gx", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p),
+                 ("arena_n", C.c_int64), ("off", C.c_int64 * NVAR),
+                 ("big", C.c_void_p), ("Mi", C.c_void_p), ("Vi", C.c_void_p), ("sqn_dense", C.c_void_p),
+                 ("use_dense", C.c_void_p), ("mwdhm", C.c_void_p), ("segs_all", Segments), ("segs_dense", Segments)]
+                + [(n, C.c_void_p) for n in _WS]
+                + [("rank", C.c_void_p), ("topk", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+                   ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p)])
+
+
 class TcarError(RuntimeError):
     pass
 
@@ -135,6 +155,12 @@ def load() -> C.CDLL:
     lib.tcar_sqnorm.argtypes = [vp, P(Segments), vp, vp]
     lib.tcar_clip_adam.argtypes = [vp, vp, vp, vp, P(Segments), vp, vp, vp, f32, f32, f32, f32, f32, vp]
     lib.tcar_clip_adam_2d.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp]
+    lib.tcar_step_forward.argtypes = [P(Ctx), P(Batch), i32, vp]
+    lib.tcar_step_backward_local.argtypes = [P(Ctx), P(Batch), vp]
+    lib.tcar_step_finish.argtypes = [P(Ctx), P(Batch), vp]
+    lib.tcar_step_update.argtypes = [P(Ctx), f32, vp]
+    lib.tcar_train_step.argtypes = [P(Ctx), P(Batch), i32, f32, vp]
+    lib.tcar_eval_step.argtypes = [P(Ctx), P(Batch), i32, i32, vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = C.c_int
     _LIB = lib

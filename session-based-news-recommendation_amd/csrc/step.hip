@@ -1,0 +1,225 @@
+// Step-level driver: sequences the op-level launchers for one training / evaluation step on one stream, from C++
+// (a few microseconds of host time per launch instead of a Python round trip), with no host synchronisation and no
+// allocation.  tcar_train_step == sess.run([loss, global_step, train_op]) (model_combine.py:231);
+// tcar_eval_step == sess.run([softmax_input, cross_loss]) + util.cau_metrics + top-k (model_combine.py:283,296,301).
+#include "tcar_common.h"
+
+namespace {
+
+#define RET(x)            \
+  do {                    \
+    int rc__ = (x);       \
+    if (rc__) return rc__; \
+  } while (0)
+
+struct Geo {
+  int N, Npad, H, ldh, ldt, ic, pt, ct, ek;
+  explicit Geo(const tcar_dims_t& d)
+      : N(d.n_items), Npad((d.n_items + 63) / 64 * 64), H(d.H), ldh(d.ldh), ldt(d.ldt), ic(2 * d.ldh), pt(5 * d.ldt),
+        ct(2 * d.ldt), ek(2 * d.ldh + 5 * d.ldt) {}
+};
+
+inline float* W(const tcar_ctx_t* c, int v) { return c->W + c->off[v]; }
+inline float* G(const tcar_ctx_t* c, int v) { return c->Gx + c->off[v]; }
+
+tcar_gemm_desc_t prob(int M, int N, float* C, int64_t ldc, const float* bias = nullptr, int act = 0, int beta = 0,
+                      int splitk = 1, int atomic = 0) {
+  tcar_gemm_desc_t d = {};
+  d.nseg = 0; d.C = C; d.ldc = ldc; d.bias = bias; d.M = M; d.N = N; d.act = act; d.beta = beta; d.splitk = splitk;
+  d.atomic = atomic;
+  return d;
+}
+void seg(tcar_gemm_desc_t& d, const float* A, int64_t lda, const float* B, int64_t ldb, int K) {
+  const int i = d.nseg++;
+  d.A[i] = A; d.lda[i] = lda; d.B[i] = B; d.ldb[i] = ldb; d.K[i] = K;
+}
+tcar_gemm_desc_t prob1(int M, int N, const float* A, int64_t lda, const float* B, int64_t ldb, int K, float* C,
+                       int64_t ldc, const float* bias = nullptr, int act = 0, int beta = 0, int splitk = 1,
+                       int atomic = 0) {
+  tcar_gemm_desc_t d = prob(M, N, C, ldc, bias, act, beta, splitk, atomic);
+  seg(d, A, lda, B, ldb, K);
+  return d;
+}
+
+void tables_of(const tcar_ctx_t* c, tcar_tables_t& t) {
+  t.E = c->E; t.pos = W(c, TCAR_V_POS);
+  for (int k = 0; k < 5; ++k) t.time[k] = W(c, TCAR_V_MONTH + k);
+  t.dur = W(c, TCAR_V_DUR);
+}
+void grads_of(const tcar_ctx_t* c, tcar_grads_t& g) {
+  g.g_item = c->big; g.g_pos = G(c, TCAR_V_POS);
+  for (int k = 0; k < 5; ++k) { g.g_time[k] = G(c, TCAR_V_MONTH + k); g.slot_time[k] = c->slot_of[TCAR_V_MONTH + k]; }
+  g.g_dur = G(c, TCAR_V_DUR);
+  g.sqn = c->Gx + c->arena_n;
+  g.slot_item = c->slot_item; g.slot_pos = c->slot_of[TCAR_V_POS]; g.slot_dur = c->slot_of[TCAR_V_DUR];
+  g.rows_out = nullptr;
+}
+
+int check_ctx(const tcar_ctx_t* c, const tcar_batch_t* bt) {
+  if (!c || !bt || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
+  if (!c->E || !c->W || !c->Gx || !c->M || !c->V || !c->big || !c->Mi || !c->Vi) return TCAR_E_ARG;
+  return TCAR_OK;
+}
+
+}  // namespace
+
+extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream) {
+  RET(check_ctx(c, bt));
+  const Geo g(c->d);
+  const int B = bt->B, BT = bt->B * bt->T;
+  if (refresh_time) {
+    const float* tt[5];
+    for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+    RET(tcar_cand_time_fwd(&c->d, tt, c->mwdhm, c->E, stream));
+  }
+  tcar_tables_t tab;
+  tables_of(c, tab);
+  RET(tcar_gather_clip_fwd(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream));
+  const float* x_c = c->x_icp + g.ldh;
+  {  // pre1, pre2, q1 (modules.py:126-131, 94-96, 138)
+    tcar_gemm_desc_t p[3];
+    p[0] = prob(BT, g.ldh, c->pre1, g.ldh);
+    seg(p[0], c->x_icp, g.ic, W(c, TCAR_V_M_WIN), g.ldh, g.ic);
+    seg(p[0], x_c, g.ic, W(c, TCAR_V_M_WC), g.ldh, g.ldh);
+    seg(p[0], c->x_act, g.ldt, W(c, TCAR_V_M_WINT), g.ldh, g.ldt);
+    p[1] = prob(BT, g.ldh, c->pre2, g.ldh);
+    seg(p[1], c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt);
+    seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
+    p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
+    RET(tcar_gemm_f32_grouped(0, 3, p, stream));
+  }
+  {  // q = tanh(q1 Wq2 + b) (modules.py:139)
+    tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
+    RET(tcar_gemm_f32_grouped(0, 1, &p, stream));
+  }
+  RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
+                         W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
+  {  // attout (model_combine.py:119,127,132)
+    tcar_gemm_desc_t p[2];
+    p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->attout, g.ek, W(c, TCAR_V_O_B), 2);
+    p[1] = prob1(B, g.pt, c->pooled + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->attout + g.ic, g.ek,
+                 W(c, TCAR_V_OT_B), 2);
+    RET(tcar_gemm_f32_grouped(0, 2, p, stream));
+  }
+  // logits = attout E^T (model_combine.py:138)
+  int ei = -1;
+  if (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) {
+    ei = (*c->ev_cursor)++ % c->ev_n;
+    (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
+  }
+  const int rc = tcar_gemm_f32(1, B, g.N, g.ek, c->attout, g.ek, c->E, g.ek, c->logits, g.Npad, nullptr, 0, 0, 1, stream);
+  if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[ei], (hipStream_t)stream);
+  return rc;
+}
+
+extern "C" int tcar_step_backward_local(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream) {
+  RET(check_ctx(c, bt));
+  const Geo g(c->d);
+  const int B = bt->B, T = bt->T, BT = B * T, K = bt->K;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
+  if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
+  RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
+  // d attout = dlogits E: contraction over the catalog, split-K slabs + deterministic reduce
+  const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
+  RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
+  RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
+  float* Gi = c->big;
+  float* d_et = c->big + (size_t)g.N * g.ldh;
+  {  // dE = dlogits^T attout: item block and time block (content is frozen)
+    tcar_gemm_desc_t p[2];
+    p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
+    p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
+    RET(tcar_gemm_f32_grouped(2, 2, p, stream));
+  }
+  if (K > 0 && bt->neg) {
+    RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->dattout, Gi, stream));
+  } else if (hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) {
+    return TCAR_E_LAUNCH;
+  }
+  RET(tcar_dact_colsum(B, g.ic, g.ek, c->attout, c->dattout, G(c, TCAR_V_O_B), 2, stream));
+  RET(tcar_dact_colsum(B, g.pt, g.ek, c->attout + g.ic, c->dattout + g.ic, G(c, TCAR_V_OT_B), 2, stream));
+  {
+    tcar_gemm_desc_t p[2];
+    p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->dpooled, g.ek);
+    p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->dpooled + g.ic, g.ek);
+    RET(tcar_gemm_f32_grouped(1, 2, p, stream));
+  }
+  RET(tcar_attn_pool_bwd(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
+                         W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
+                         G(c, TCAR_V_M_WRES), G(c, TCAR_V_S_WRES), stream));
+  // query MLP backward (modules.py:138-139)
+  RET(tcar_dact_colsum(B, g.ic, g.ic, c->q, c->dq, G(c, TCAR_V_Q2_B), 2, stream));
+  {
+    tcar_gemm_desc_t p = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
+    RET(tcar_gemm_f32_grouped(1, 1, &p, stream));
+  }
+  RET(tcar_dact_colsum(B, g.ldh, g.ldh, c->q1, c->dq1, G(c, TCAR_V_Q1_B), 1, stream));
+  {  // input gradients (only the ITEM half of dX_ic: content is frozen)
+    tcar_gemm_desc_t p[4];
+    p[0] = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+    p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
+    p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
+    p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
+    RET(tcar_gemm_f32_grouped(1, 4, p, stream));
+  }
+  {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
+    auto ks = [](int K) { int s = (K + 1023) / 1024; return s < 2 ? 2 : (s > 16 ? 16 : s); };
+    const int kb = ks(B), kr = ks(BT);
+    const float* x_c = c->x_icp + g.ldh;
+    tcar_gemm_desc_t p[9];
+    p[0] = prob1(g.ic, g.ic, c->pooled, g.ek, c->dattout, g.ek, B, G(c, TCAR_V_O_W), g.ic, nullptr, 0, 0, kb, 1);
+    p[1] = prob1(g.pt, g.pt, c->pooled + g.ic, g.ek, c->dattout + g.ic, g.ek, B, G(c, TCAR_V_OT_W), g.pt, nullptr, 0, 0, kb, 1);
+    p[2] = prob1(g.ldh, g.ic, c->q1, g.ldh, c->dq, g.ic, B, G(c, TCAR_V_Q2_W), g.ic, nullptr, 0, 0, kb, 1);
+    p[3] = prob1(g.ct, g.ldh, c->click_t, g.ct, c->dq1, g.ldh, B, G(c, TCAR_V_Q1_W), g.ldh, nullptr, 0, 0, kb, 1);
+    p[4] = prob1(g.ic, g.ldh, c->x_icp, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WIN), g.ldh, nullptr, 0, 0, kr, 1);
+    p[5] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WC), g.ldh, nullptr, 0, 0, kr, 1);
+    p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
+    p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
+    p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
+    RET(tcar_gemm_f32_grouped(2, 9, p, stream));
+  }
+  return TCAR_OK;
+}
+
+extern "C" int tcar_step_finish(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream) {
+  RET(check_ctx(c, bt));
+  const Geo g(c->d);
+  // clip norm of the dense item block BEFORE the sparse rows are scattered in
+  tcar_segments_t one = {};
+  one.nseg = 1; one.off[0] = 0; one.len[0] = (int64_t)g.N * g.ldh; one.slot[0] = c->slot_item;
+  RET(tcar_sqnorm(c->big, &one, c->sqn_dense, stream));
+  tcar_tables_t tab;
+  tcar_grads_t gr;
+  tables_of(c, tab);
+  grads_of(c, gr);
+  RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
+  const float* tt[5];
+  for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+  RET(tcar_cand_time_bwd(&c->d, tt, c->mwdhm, c->big + (size_t)g.N * g.ldh, &gr, stream));
+  return tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream);
+}
+
+extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
+  if (!c) return TCAR_E_ARG;
+  const Geo g(c->d);
+  const float* pieces = c->Gx + c->arena_n;
+  RET(tcar_clip_adam(c->W, c->Gx, c->M, c->V, &c->segs_all, c->sqn_dense, pieces, c->use_dense, c->clip, lr_t, c->b1,
+                     c->b2, c->eps, stream));
+  return tcar_clip_adam_2d(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
+                           c->clip, lr_t, c->b1, c->b2, c->eps, stream);
+}
+
+extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {
+  RET(tcar_step_forward(c, bt, refresh_time, stream));
+  RET(tcar_step_backward_local(c, bt, stream));
+  RET(tcar_step_finish(c, bt, stream));
+  return tcar_step_update(c, lr_t, stream);
+}
+
+extern "C" int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream) {
+  RET(tcar_step_forward(c, bt, refresh_time, stream));
+  const Geo g(c->d);
+  RET(tcar_rank_topk(bt->B, g.N, c->logits, g.Npad, bt->label, k, c->rank, c->topk, stream));
+  return tcar_softmax_ce(bt->B, g.N, c->logits, g.Npad, bt->label, c->ce, stream);
+}

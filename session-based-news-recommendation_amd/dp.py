@@ -122,15 +122,25 @@ class DPEngine(TcarEngine):
             self.update()
             return torch.zeros(0, device=self.dev)
         bt = bt or self.upload(batch)
-        self.forward(bt)
-        self.backward_local(bt)
+        self._local(bt)
         self.finish_backward(bt, cap_rows)
         self.update()
         return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
 
+    def _local(self, bt):
+        """forward + rank-local backward, driven from C++ (tcar_step_forward / tcar_step_backward_local)."""
+        if self.native and self.timing is None:
+            self._ensure_work(bt.B, bt.T)
+            ctx, st = self._ctx(), self._stream()
+            check(self.lib.tcar_step_forward(C.byref(ctx), C.byref(bt), int(self._time_dirty), st), "tcar_step_forward")
+            self._time_dirty = False
+            check(self.lib.tcar_step_backward_local(C.byref(ctx), C.byref(bt), st), "tcar_step_backward_local")
+        else:
+            self.forward(bt)
+            self.backward_local(bt)
+
     def loss_and_grads(self, batch, bt=None, cap_rows: Optional[int] = None):
         bt = bt or self.upload(batch)
-        self.forward(bt)
-        self.backward_local(bt)
+        self._local(bt)
         self.finish_backward(bt, cap_rows)
         return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]

@@ -559,8 +559,7 @@ class TcarEngine:
     def update(self):
         """model_combine.py:157-163: per-variable clip_by_norm(max_grad) + TF-1 Adam."""
         g, lib, st, p = self.geo, self.lib, self._stream(), self._p
-        self.step += 1
-        lr_t = float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.b2_pow) / (np.float32(1) - self.b1_pow))
+        lr_t = self._lr_t()
         clip = float(self.max_grad) if self.max_grad else 0.0
         check(lib.tcar_clip_adam(p(self.W), p(self.G), p(self.M), p(self.V), C.byref(self.segs_all), p(self.sqn_dense),
                                  p(self.sqn_pieces), p(self.use_dense), clip, lr_t, self.b1, self.b2, self.eps, st),
@@ -570,6 +569,63 @@ class TcarEngine:
                                     p(self.sqn_dense), p(self.sqn_pieces), p(self.use_dense), clip, lr_t, self.b1,
                                     self.b2, self.eps, st), "tcar_clip_adam_2d")
         self._tock(ev)
+        self._after_update()
+
+    # ------------------------------------------------------------------------------ native (C++) step driver
+    native = True        # drive the step from libtcar_hip.so (tcar_train_step / tcar_eval_step); False = Python
+
+    def _ctx(self) -> "_lib.Ctx":
+        """tcar_ctx_t for the current workspace (rebuilt when a buffer is re-allocated)."""
+        key = (self.work_rows, self.work_B, self.topk.data_ptr() if hasattr(self, "topk") else 0, id(self._ev))
+        if getattr(self, "_ctx_key", None) == key:
+            return self._ctx_obj
+        g, c = self.geo, _lib.Ctx()
+        c.d = self.dims
+        c.splitk = self.splitk
+        for i, (short, sg) in enumerate(self.seg.items()):
+            c.slot_of[i], c.off[i] = sg["slot"], sg["off"]
+        c.slot_item = SLOT["item_emb"]
+        c.b1, c.b2, c.eps = self.b1, self.b2, self.eps
+        c.clip = float(self.max_grad) if self.max_grad else 0.0
+        c.neg_weight = self.neg_weight
+        for n, t in (("E", self.E), ("W", self.W), ("Gx", self.Gx), ("M", self.M), ("V", self.V), ("big", self.big),
+                     ("Mi", self.Mi), ("Vi", self.Vi), ("sqn_dense", self.sqn_dense), ("use_dense", self.use_dense),
+                     ("mwdhm", self.mwdhm), ("rank", self.rank), ("topk", self.topk)):
+            setattr(c, n, t.data_ptr())
+        c.arena_n = self.arena_n
+        c.segs_all, c.segs_dense = self.segs_all, self.segs_dense
+        for n in _lib._WS:
+            setattr(c, n, getattr(self, n).data_ptr())
+        if self._ev is not None:
+            c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
+            c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)
+            c.ev_n = self._ev["n"]
+            c.ev_cursor = C.cast(C.pointer(self._ev["cursor"]), C.c_void_p)
+        self._ctx_key, self._ctx_obj = key, c
+        return c
+
+    _ev = None
+
+    def enable_native_timing(self, n: int):
+        """HIP events around the full-catalog logits GEMM inside tcar_train_step (bench.py roofline)."""
+        st = torch.cuda.current_stream(self.dev)
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        stops = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for e in starts + stops:
+            e.record(st)                      # materialise the underlying hipEvent_t
+        self._ev = {"n": n, "starts": starts, "stops": stops, "cursor": C.c_int32(0),
+                    "start_arr": (C.c_void_p * n)(*[e.cuda_event for e in starts]),
+                    "stop_arr": (C.c_void_p * n)(*[e.cuda_event for e in stops])}
+
+    def native_timing_ms(self):
+        used = min(self._ev["cursor"].value, self._ev["n"])
+        return [self._ev["starts"][i].elapsed_time(self._ev["stops"][i]) for i in range(used)]
+
+    def _lr_t(self) -> float:
+        return float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.b2_pow) / (np.float32(1) - self.b1_pow))
+
+    def _after_update(self):
+        self.step += 1
         self.b1_pow = np.float32(self.b1_pow * np.float32(self.b1))
         self.b2_pow = np.float32(self.b2_pow * np.float32(self.b2))
         self._time_dirty = True
@@ -578,26 +634,46 @@ class TcarEngine:
     def train_step(self, batch: Dict[str, np.ndarray], bt: Optional[Batch] = None) -> torch.Tensor:
         """One sess.run([loss, global_step, train_op]) (model_combine.py:231); returns loss[B] on device."""
         bt = bt or self.upload(batch)
-        self.forward(bt)
-        self.backward(bt)
-        self.update()
+        if self.native and self.timing is None:
+            self._ensure_work(bt.B, bt.T)
+            check(self.lib.tcar_train_step(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), self._lr_t(),
+                                           self._stream()), "tcar_train_step")
+            self._after_update()
+        else:
+            self.forward(bt)
+            self.backward(bt)
+            self.update()
         return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
 
     def loss_and_grads(self, batch, bt: Optional[Batch] = None) -> torch.Tensor:
         bt = bt or self.upload(batch)
-        self.forward(bt)
-        self.backward(bt)
+        if self.native and self.timing is None:
+            self._ensure_work(bt.B, bt.T)
+            ctx, st = self._ctx(), self._stream()
+            check(self.lib.tcar_step_forward(C.byref(ctx), C.byref(bt), int(self._time_dirty), st), "tcar_step_forward")
+            self._time_dirty = False
+            check(self.lib.tcar_step_backward_local(C.byref(ctx), C.byref(bt), st), "tcar_step_backward_local")
+            check(self.lib.tcar_step_finish(C.byref(ctx), C.byref(bt), st), "tcar_step_finish")
+        else:
+            self.forward(bt)
+            self.backward(bt)
         return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
 
     def eval_step(self, batch, k: int = 20, bt: Optional[Batch] = None, keep_logits: bool = False):
         """sess.run([softmax_input, cross_loss]) (model_combine.py:283) + rank / top-k on device.
         Returns (rank[B] int32, topk[B,k] int32, ce[B] f32[, logits [B,N]])."""
         bt = bt or self.upload(batch)
-        self.forward(bt)
-        g, lib, st, p = self.geo, self.lib, self._stream(), self._p
         B = bt.B
+        self._ensure_work(B, bt.T)
         if k != self.topk.shape[1] or self.topk.shape[0] < B:
             self.topk = torch.empty(max(B, self.work_B), k, dtype=torch.int32, device=self.dev)
+        if self.native and not keep_logits:
+            check(self.lib.tcar_eval_step(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), k, self._stream()),
+                  "tcar_eval_step")
+            self._time_dirty = False
+            return (self.rank[:B], self.topk[:B], self.ce[:B])
+        self.forward(bt)
+        g, lib, st, p = self.geo, self.lib, self._stream(), self._p
         check(lib.tcar_rank_topk(B, g.N, p(self.logits), g.Npad, C.c_void_p(bt.label), k, p(self.rank), p(self.topk), st),
               "tcar_rank_topk")
         logits = self.logits[:B, :g.N].clone() if keep_logits else None
