@@ -113,6 +113,14 @@ int tcar_cand_time_fwd(const tcar_dims_t* d, const float* const time_tab[5], con
 int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
                        const float* d_et, const tcar_grads_t* g, void* stream);
 
+/* Same result through a static inverted index (deterministic, no atomics): inv_n [5N] lists, per table row
+ * r = rowoff(k)+v (month 0..12, day 13..44, week 45..52, hour 53..77, minute 78..138), the candidates n with
+ * mwdhm[n,k] == v; inv_off [140] are the list offsets; ws holds tcar_cand_time_ws_floats(d) floats. */
+int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* inv_n,
+                               const int32_t* inv_off, const float* d_et, float* ws, const tcar_grads_t* g,
+                               void* stream);
+int tcar_cand_time_ws_floats(const tcar_dims_t* d);
+
 /* ---- dense contractions --------------------------------------------------------------------------------
  * tcar_gemm_f32: fp32-in / fp32-accumulate MFMA GEMM (v_mfma_f32_32x32x2_f32), C = act(A*B + bias) (+C).
  * Replaces tf.matmul / BatchMatMul of modules.py:52,67 (linear_2d / linear_3d), model_combine.py:138
@@ -244,6 +252,7 @@ typedef struct {
   float* sqn_dense;               /* [TCAR_NSLOT] */
   const int32_t* use_dense;       /* [TCAR_NSLOT] */
   const int32_t* mwdhm;           /* [N,5] publish_time_MWDHM */
+  const int32_t* inv_n; const int32_t* inv_off; float* ct_ws;   /* inverted index of mwdhm + its workspace */
   tcar_segments_t segs_all, segs_dense;
   /* workspace (sized by the caller for the largest B and B*T it will submit) */
   float *x_icp, *x_pt, *x_act, *click_t, *pre1, *pre2, *q1, *q, *alpha, *pooled, *attout, *logits, *ce, *neg_fb;

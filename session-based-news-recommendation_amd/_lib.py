@@ -18,7 +18,7 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd",
+SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_dact_colsum", "tcar_rank_topk",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_abi_version", "tcar_step_forward",
@@ -106,7 +106,8 @@ class Ctx(C.Structure):
                  ("E", C.c_void_p), ("W", C.c_void_p), ("Gx", C.c_void_p), ("M", C.c_void_p), ("V", C.c_void_p),
                  ("arena_n", C.c_int64), ("off", C.c_int64 * NVAR),
                  ("big", C.c_void_p), ("Mi", C.c_void_p), ("Vi", C.c_void_p), ("sqn_dense", C.c_void_p),
-                 ("use_dense", C.c_void_p), ("mwdhm", C.c_void_p), ("segs_all", Segments), ("segs_dense", Segments)]
+                 ("use_dense", C.c_void_p), ("mwdhm", C.c_void_p), ("inv_n", C.c_void_p),
+                 ("inv_off", C.c_void_p), ("ct_ws", C.c_void_p), ("segs_all", Segments), ("segs_dense", Segments)]
                 + [(n, C.c_void_p) for n in _WS]
                 + [("rank", C.c_void_p), ("topk", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
                    ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p)])
@@ -142,6 +143,8 @@ def load() -> C.CDLL:
     lib.tcar_scatter_add_rows.argtypes = [P(Dims), vp, vp, i64, vp, vp]
     lib.tcar_cand_time_fwd.argtypes = [P(Dims), P(vp * 5), vp, vp, vp]
     lib.tcar_cand_time_bwd.argtypes = [P(Dims), P(vp * 5), vp, vp, P(Grads), vp]
+    lib.tcar_cand_time_bwd_indexed.argtypes = [P(Dims), P(vp * 5), vp, vp, vp, vp, P(Grads), vp]
+    lib.tcar_cand_time_ws_floats.argtypes = [P(Dims)]
     lib.tcar_gemm_f32.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
     lib.tcar_gemm_f32_grouped.argtypes = [i32, i32, P(GemmDesc), vp]
     lib.tcar_splitk_reduce.argtypes = [vp, i32, i32, i32, i64, vp, vp]

@@ -334,6 +334,101 @@ __global__ __launch_bounds__(256) void cand_time_bwd_kernel(const CandArgs a) {
   }
 }
 
+// ---- candidate-side time gradient through a STATIC inverted index (deterministic, no atomics) ---------------
+// publish_time_MWDHM never changes, so the candidates that share table row (k, v) are listed once on the host:
+// inv_n[inv_off[r] .. inv_off[r+1]) for r = rowoff(k) + v.  The clip Jacobian depends only on the table row x, so
+//   sum_n gx_n          = a*S - x*inv^3*(x.S),   S = sum_n gy_n         (linear in the list sum)
+//   sum_n ||gx_n||^2    = inv^2*Q - inv^4*D2,    Q = sum ||gy_n||^2, D2 = sum (x.gy_n)^2     (n over the list, ||x||>1)
+// Pass 1: grid (139 rows, CH chunks); each 16-lane group streams its candidates' 256-byte d_et segments and keeps
+// S, Q, D2; fixed-order reductions; partials to a workspace.  Pass 2: one workgroup folds the chunks in order,
+// applies the Jacobian, adds into the time-table gradients and the norm pieces.
+constexpr int CT_CHUNKS = 8;
+
+__global__ __launch_bounds__(256) void cand_time_bwd_idx_kernel(const CandArgs a, const int32_t* __restrict__ inv_n,
+                                                                const int32_t* __restrict__ inv_off,
+                                                                float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float shS[16 * 256];   // [groups][ldt]  (groups*ldt = 1024 floats)
+  __shared__ float shQ[16], shD[16];
+  const int tid = threadIdx.x;
+  const int ldt = a.d.ldt, pt = 5 * ldt, sub = ldt >> 2, groups = 256 / sub;
+  const int grp = tid / sub, lin = tid - grp * sub;
+  const int r = blockIdx.x, c = blockIdx.y;
+  const int k = r < 13 ? 0 : r < 45 ? 1 : r < 53 ? 2 : r < 78 ? 3 : 4;
+  const int v = r - time_rowoff(k);
+  const int lo = inv_off[r], hi = inv_off[r + 1];
+  const int per = (hi - lo + CT_CHUNKS - 1) / CT_CHUNKS;
+  const int s0 = lo + c * per, s1 = min(hi, s0 + per);
+  const float4 x = ld4(pick5(a.tab, k) + (long)v * ldt + lin * 4);
+  float4 S = zero4();
+  float Q = 0.f, D2 = 0.f;
+  for (int i = s0 + grp; i < s1; i += groups) {
+    const long n = inv_n[i];
+    const float4 gy = ld4(a.d_et + n * pt + k * ldt + lin * 4);
+    S = add4(S, gy);
+    Q += dot4(gy, gy);
+    const float d = group_sum(dot4(x, gy), sub);
+    D2 += (lin == 0) ? d * d : 0.f;
+  }
+  Q = group_sum(Q, sub);
+  st4(shS + grp * ldt + lin * 4, S);
+  if (lin == 0) { shQ[grp] = Q; shD[grp] = D2; }
+  __syncthreads();
+  float* out = ws + ((long)r * CT_CHUNKS + c) * (ldt + 4);
+  if (tid < sub) {
+    float4 t = zero4();
+    for (int g2 = 0; g2 < groups; ++g2) t = add4(t, ld4(shS + g2 * ldt + tid * 4));
+    st4(out + tid * 4, t);
+  }
+  if (tid == 0) {
+    float q = 0.f, d2 = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) { q += shQ[g2]; d2 += shD[g2]; }
+    out[ldt] = q;
+    out[ldt + 1] = d2;
+  }
+}
+
+__global__ __launch_bounds__(256) void cand_time_bwd_fin_kernel(const CandArgs a, const float* __restrict__ ws) {
+  __shared__ float piece[139];
+  const int tid = threadIdx.x;
+  const int ldt = a.d.ldt, sub = ldt >> 2, groups = 256 / sub;
+  const int grp = tid / sub, lin = tid - grp * sub;
+  for (int r0 = 0; r0 < 139; r0 += groups) {
+    const int r = r0 + grp;
+    const bool valid = r < 139;
+    const int rr = valid ? r : 0;
+    const int k = rr < 13 ? 0 : rr < 45 ? 1 : rr < 53 ? 2 : rr < 78 ? 3 : 4;
+    const int v = rr - time_rowoff(k);
+    float4 S = zero4();
+    float Q = 0.f, D2 = 0.f;
+    for (int c = 0; c < CT_CHUNKS; ++c) {
+      const float* p = ws + ((long)rr * CT_CHUNKS + c) * (ldt + 4);
+      S = add4(S, ld4(p + lin * 4));
+      Q += p[ldt];
+      D2 += p[ldt + 1];
+    }
+    const float4 x = ld4(pick5(a.tab, k) + (long)v * ldt + lin * 4);
+    const float ss = group_sum(dot4(x, x), sub), xs = group_sum(dot4(x, S), sub);
+    float4 gx = S;
+    float pc = Q;
+    if (ss > 1.0f) {
+      const float inv = 1.0f / sqrtf(ss), inv2 = inv * inv;
+      gx = fma4(x, -(xs * inv2 * inv), scale4(S, inv));
+      pc = inv2 * Q - inv2 * inv2 * D2;
+    }
+    if (valid) {
+      float* gp = a.g.g_time[0] + (long)rr * ldt + lin * 4;       // month..minute gradients are contiguous
+      st4(gp, add4(ld4(gp), gx));
+      if (lin == 0) piece[rr] = pc;
+    }
+  }
+  __syncthreads();
+  if (tid < 5) {
+    float s = 0.f;
+    for (int r = time_rowoff(tid); r < time_rowoff(tid) + time_vocab(tid); ++r) s += piece[r];
+    atomicAdd(a.g.sqn + pick5(a.g.slot_time, tid), s);
+  }
+}
+
 // g_item[ids[r]-1] += rows[r]: one wave per row, 256-byte-contiguous float atomics
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int ldh, int n_items, const int32_t* __restrict__ ids,
                                                                const float* __restrict__ rows, long R,
@@ -401,6 +496,23 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
+
+extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* inv_n,
+                                         const int32_t* inv_off, const float* d_et, float* ws,
+                                         const tcar_grads_t* g, void* stream) {
+  if (check_dims(d) || !time_tab || !inv_n || !inv_off || !d_et || !ws || !g) return TCAR_E_ARG;
+  CandArgs a{};
+  a.d = *d;
+  for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
+  a.d_et = d_et; a.g = *g;
+  TCAR_LAUNCH(cand_time_bwd_idx_kernel, dim3(139, CT_CHUNKS), dim3(256), 0, (hipStream_t)stream, a, inv_n, inv_off, ws);
+  TCAR_CHECK_LAUNCH();
+  TCAR_LAUNCH(cand_time_bwd_fin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, (const float*)ws);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_cand_time_ws_floats(const tcar_dims_t* d) { return d ? 139 * CT_CHUNKS * (d->ldt + 4) : 0; }
 
 extern "C" int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float* rows, int64_t R,
                                      float* g_item, void* stream) {

@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
                                                        const float* __restrict__ attout, float weight,
                                                        float* __restrict__ neg_fb, float* __restrict__ dattout,
                                                        float* __restrict__ g_item) {
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
+  // one WORKGROUP per session: the 4 waves split the K negatives (independent row gathers in flight), partial
+  // dot / row sums meet in LDS, every wave then scatters its own negatives' gradient rows
+  __shared__ __attribute__((aligned(16))) float part[4 * 2 * 512];   // [wave][item|content sums]
+  __shared__ float px[4];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.x;
   const int ic = 2 * ldh;
   float4 ua[NCH], ub[NCH], sa[NCH], sb[NCH];
 #pragma unroll
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
     sa[c] = zero4(); sb[c] = zero4();
   }
   float x = 0.f;
-  for (int k = 0; k < K; ++k) {
+  for (int k = w; k < K; k += 4) {
     const int n = clampi(neg[(long)b * K + k], 0, n_items - 1);
     const float* e = E + (long)n * ek;
 #pragma unroll
@@ -104,24 +107,28 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
       }
     }
   }
-  x = wave_sum(x);                                     // sum over K BEFORE the sigmoid (model_combine.py:142)
+  x = wave_sum(x);
+  if (lane == 0) px[w] = x;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    if (col < ldh) { st4(part + w * ic + col, sa[c]); st4(part + w * ic + ldh + col, sb[c]); }
+  }
+  __syncthreads();
+  x = px[0] + px[1] + px[2] + px[3];                   // sum over K BEFORE the sigmoid (model_combine.py:142)
   const float sg = 1.0f / (1.0f + expf(-x));
   const float om = 1.0f - sg;
-  if (lane == 0) neg_fb[b] = -logf(om + 1e-24f);
+  if (tid == 0) neg_fb[b] = -logf(om + 1e-24f);
   const float coef = weight * sg * om / (om + 1e-24f);  // weight * d/dx[-log(1 - sigmoid(x) + 1e-24)]
   if (dattout) {
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (col < ldh) {
-        float* p = dattout + (long)b * ek + col;
-        st4(p, fma4(sa[c], coef, ld4(p)));
-        st4(p + ldh, fma4(sb[c], coef, ld4(p + ldh)));
-      }
+    for (int col = tid * 4; col < ic; col += 1024) {
+      const float4 s = add4(add4(ld4(part + col), ld4(part + ic + col)), add4(ld4(part + 2 * ic + col), ld4(part + 3 * ic + col)));
+      float* p = dattout + (long)b * ek + col;
+      st4(p, fma4(s, coef, ld4(p)));
     }
   }
   if (g_item) {
-    for (int k = 0; k < K; ++k) {
+    for (int k = w; k < K; k += 4) {
       const int n = clampi(neg[(long)b * K + k], 0, n_items - 1);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -227,7 +234,7 @@ extern "C" int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E,
   if (!d || B <= 0 || K <= 0) return TCAR_OK;
   if (!E || !neg || !attout || !neg_fb || (d->ldh & 63) || d->ldh > 512) return TCAR_E_ARG;
   const int ek = 2 * d->ldh + 5 * d->ldt;
-  const int grid = (B + 3) / 4;
+  const int grid = B;          // one workgroup per session
   if (d->ldh <= 256)
     TCAR_LAUNCH(neg_term_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
                        neg, attout, weight, neg_fb, dattout, g_item);

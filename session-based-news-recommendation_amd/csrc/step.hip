@@ -196,7 +196,7 @@ extern "C" int tcar_step_finish(const tcar_ctx_t* c, const tcar_batch_t* bt, voi
   RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
   const float* tt[5];
   for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-  RET(tcar_cand_time_bwd(&c->d, tt, c->mwdhm, c->big + (size_t)g.N * g.ldh, &gr, stream));
+  RET(tcar_cand_time_bwd_indexed(&c->d, tt, c->inv_n, c->inv_off, c->big + (size_t)g.N * g.ldh, c->ct_ws, &gr, stream));
   return tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream);
 }
 

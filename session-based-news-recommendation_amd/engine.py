@@ -147,6 +147,16 @@ class TcarEngine:
         self.use_dense = torch.tensor(use, device=self.dev)
         self.mwdhm = torch.tensor(np.ascontiguousarray(mwdhm, dtype=np.int32), device=self.dev)
         self.dims = Dims(g.N, g.H, g.Ht, g.ldh, g.ldt)
+        # static inverted index of publish_time_MWDHM: candidates listed per time-table row (cand_time_bwd_indexed)
+        mw = np.ascontiguousarray(mwdhm, dtype=np.int64)
+        rowoff = np.array([0, 13, 45, 53, 78])
+        key = (np.clip(mw, 0, np.array(TIME_VOCAB) - 1) + rowoff[None, :]).T.reshape(-1)          # [5N], k-major
+        order = np.argsort(key, kind="stable")
+        inv_off = np.zeros(140, dtype=np.int32)
+        inv_off[1:] = np.cumsum(np.bincount(key, minlength=139))
+        self.inv_n = torch.tensor((order % g.N).astype(np.int32), device=self.dev)
+        self.inv_off = torch.tensor(inv_off, device=self.dev)
+        self.ct_ws = torch.zeros(self.lib.tcar_cand_time_ws_floats(C.byref(self.dims)), **f32)
         # segment tables for the optimizer kernels
         self.segs_all = self._segments([a[0] for a in ARENA])
         self.segs_dense = self._segments([a[0] for a in ARENA if self.use_dense_np(a[1])])
@@ -482,8 +492,9 @@ class TcarEngine:
 
     def _cand_time_bwd(self):
         gr = self._grads()
-        check(self.lib.tcar_cand_time_bwd(C.byref(self.dims), C.byref(self._time_ptrs()), self._p(self.mwdhm),
-                                          self._p(self.d_et), C.byref(gr), self._stream()), "tcar_cand_time_bwd")
+        check(self.lib.tcar_cand_time_bwd_indexed(C.byref(self.dims), C.byref(self._time_ptrs()), self._p(self.inv_n),
+                                                  self._p(self.inv_off), self._p(self.d_et), self._p(self.ct_ws),
+                                                  C.byref(gr), self._stream()), "tcar_cand_time_bwd_indexed")
 
     def _sqnorm_dense(self):
         check(self.lib.tcar_sqnorm(self._p(self.G), C.byref(self.segs_dense), self._p(self.sqn_dense), self._stream()),
@@ -590,7 +601,8 @@ class TcarEngine:
         c.neg_weight = self.neg_weight
         for n, t in (("E", self.E), ("W", self.W), ("Gx", self.Gx), ("M", self.M), ("V", self.V), ("big", self.big),
                      ("Mi", self.Mi), ("Vi", self.Vi), ("sqn_dense", self.sqn_dense), ("use_dense", self.use_dense),
-                     ("mwdhm", self.mwdhm), ("rank", self.rank), ("topk", self.topk)):
+                     ("mwdhm", self.mwdhm), ("inv_n", self.inv_n), ("inv_off", self.inv_off), ("ct_ws", self.ct_ws),
+                     ("rank", self.rank), ("topk", self.topk)):
             setattr(c, n, t.data_ptr())
         c.arena_n = self.arena_n
         c.segs_all, c.segs_dense = self.segs_all, self.segs_dense
