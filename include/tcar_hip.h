@@ -109,6 +109,10 @@ int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float*
 int tcar_cand_time_fwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
                        float* E, void* stream);
 
+/* ..._bf16: additionally refreshes the same columns of the bf16 hi / lo planes of E (operands of tcar_gemm_bf16). */
+int tcar_cand_time_fwd_bf16(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm, float* E,
+                            void* e16_hi, void* e16_lo, void* stream);
+
 /* tcar_cand_time_bwd: gradient of the above; d_et [N, pt] (ld = pt) is the time-column block of dE. */
 int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
                        const float* d_et, const tcar_grads_t* g, void* stream);
@@ -156,6 +160,20 @@ int tcar_gemm_f32_grouped(int layout, int nprob, const tcar_gemm_desc_t* descs /
 /* number of slabs tcar_gemm_f32 actually writes for a requested split (K is cut in multiples of 32) */
 int tcar_gemm_splitk_effective(int K, int splitk);
 
+/* tcar_gemm_bf16: the same three layouts on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for
+ * the full-catalog scoring GEMMs.  Operands are bf16 PLANES of fp32 data: x = hi + lo (tcar_split_bf16);
+ * nsplit = 3 computes a_hi b_hi + a_hi b_lo + a_lo b_hi (fp32-class accuracy, ~1e-5), nsplit = 1 uses the hi
+ * planes only (plain bf16).  lda/ldb in elements, multiples of 8; K % 8 == 0 for k-contiguous operands.
+ * C2 != NULL: output columns >= csplit are written to C2[:, col - csplit] (dE: item block | time block).
+ * splitk > 1: C is [splitk_eff, M, ldc] slabs (tcar_gemm_splitk_effective / tcar_splitk_reduce). */
+int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t lda, const void* B_hi,
+                   const void* B_lo, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2, int csplit, int nsplit,
+                   int splitk, void* stream);
+/* fp32 [rows, cols] (ld) -> bf16 hi / lo planes [rows, ld16] (columns >= cols zero filled; lo may be NULL).
+ * packed_* != NULL additionally writes columns [0,c0) U [c1,cols) contiguously into [rows, packed_ld]. */
+int tcar_split_bf16(const float* x, int64_t ld, int rows, int cols, void* hi, void* lo, int64_t ld16, void* packed_hi,
+                    void* packed_lo, int64_t packed_ld, int c0, int c1, void* stream);
+
 /* ---- attention pools (modules.py:72-152, util.py:92-100) --------------------------------------------------
  * pre1 [B*T, ldh] = X_ic W_in + X_c W_c + X_act W_int (no activation), pre2 likewise for the time pool,
  * q [B, ic] = tanh(relu(click_t Wq1 + b) Wq2 + b).  Computes alpha1 = expnorm(sigmoid(pre1) . w_res1),
@@ -176,6 +194,10 @@ int tcar_attn_pool_bwd(const tcar_dims_t* d, int B, int T, const float* x_icp, c
  * tcar_softmax_ce: tf.nn.sparse_softmax_cross_entropy_with_logits (model_combine.py:145) and its gradient.
  * logits [B, ld] (first N columns valid) is overwritten by dlogits = softmax - onehot (pad columns 0). */
 int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* stream);
+
+/* ..._bf16: the gradient goes to bf16 hi / lo planes [B, ld] (operands of tcar_gemm_bf16); logits stay intact. */
+int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* dl_hi,
+                         void* dl_lo, void* stream);
 
 /* tcar_neg_term: neg_logits / neg_feedback of model_combine.py:142-143 and their gradients.
  * neg_fb[b] = -log(1 - sigmoid(x_b) + 1e-24), x_b = sum_k E[neg[b,k], 0:ic] . attout[b, 0:ic].
@@ -220,6 +242,12 @@ int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m, float* v,
                       int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense,
                       float clip, float lr_t, float b1, float b2, float eps, void* stream);
 
+/* ..._bf16: also rewrites the updated block into the bf16 hi / lo planes [rows, ld16] of the candidate matrix. */
+int tcar_clip_adam_2d_bf16(float* w, int64_t ldw, const float* g, float* m, float* v, int64_t rows, int32_t cols,
+                           int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense,
+                           float clip, float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo,
+                           int64_t ld16, void* stream);
+
 /* Library self-description (for loaders). */
 int tcar_abi_version(void);
 
@@ -258,6 +286,11 @@ typedef struct {
   float *x_icp, *x_pt, *x_act, *click_t, *pre1, *pre2, *q1, *q, *alpha, *pooled, *attout, *logits, *ce, *neg_fb;
   float *dattout, *dpooled, *dq, *dq1, *dclick, *slabs, *dx_icp, *dx_pt, *dx_act, *dpre1, *dpre2;
   int32_t* rank; int32_t* topk;
+  /* scoring precision: 0 = fp32 MFMA, 3 = split-bf16 (hi/lo planes, 3 MFMAs per product, fp32-class accuracy),
+   * 1 = plain bf16.  The bf16 modes need the planes below: e16* [Npad, ek] (kept in step with E by
+   * tcar_clip_adam_2d_bf16 / tcar_cand_time_fwd_bf16), a16* [B, ek], ap16* [B, ldh+pt], dl16* [B, Npad]. */
+  int32_t scoring;
+  void *e16h, *e16l, *a16h, *a16l, *ap16h, *ap16l, *dl16h, *dl16l;
   /* optional device timing of the dominant kernel (full-catalog logits GEMM): ev_n pairs of hipEvent_t, used
    * round-robin through the host counter *ev_cursor; ev_n = 0 disables it */
   void* const* ev_start; void* const* ev_stop; int32_t ev_n; int32_t* ev_cursor;

@@ -13,15 +13,16 @@ from typing import List
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libtcar_hip.so")
-SOURCES = ["gemm_f32.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip", "step.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip", "step.hip"]
 NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_bf16", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_dact_colsum", "tcar_rank_topk",
-           "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_abi_version", "tcar_step_forward",
+           "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
+           "tcar_abi_version", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_eval_step"]
 
 
@@ -109,7 +110,9 @@ class Ctx(C.Structure):
                  ("use_dense", C.c_void_p), ("mwdhm", C.c_void_p), ("inv_n", C.c_void_p),
                  ("inv_off", C.c_void_p), ("ct_ws", C.c_void_p), ("segs_all", Segments), ("segs_dense", Segments)]
                 + [(n, C.c_void_p) for n in _WS]
-                + [("rank", C.c_void_p), ("topk", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+                + [("rank", C.c_void_p), ("topk", C.c_void_p), ("scoring", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l")]
+                + [("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
                    ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p)])
 
 
@@ -147,6 +150,8 @@ def load() -> C.CDLL:
     lib.tcar_cand_time_ws_floats.argtypes = [P(Dims)]
     lib.tcar_gemm_f32.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
     lib.tcar_gemm_f32_grouped.argtypes = [i32, i32, P(GemmDesc), vp]
+    lib.tcar_gemm_bf16.argtypes = [i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp]
+    lib.tcar_split_bf16.argtypes = [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp]
     lib.tcar_splitk_reduce.argtypes = [vp, i32, i32, i32, i64, vp, vp]
     lib.tcar_gemm_splitk_effective.argtypes = [i32, i32]
     lib.tcar_attn_pool_fwd.argtypes = [P(Dims), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -158,6 +163,10 @@ def load() -> C.CDLL:
     lib.tcar_sqnorm.argtypes = [vp, P(Segments), vp, vp]
     lib.tcar_clip_adam.argtypes = [vp, vp, vp, vp, P(Segments), vp, vp, vp, f32, f32, f32, f32, f32, vp]
     lib.tcar_clip_adam_2d.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp]
+    lib.tcar_clip_adam_2d_bf16.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp,
+                                           i64, vp]
+    lib.tcar_cand_time_fwd_bf16.argtypes = [P(Dims), P(vp * 5), vp, vp, vp, vp, vp]
+    lib.tcar_softmax_ce_bf16.argtypes = [i32, i32, vp, i64, vp, vp, vp, vp, vp]
     lib.tcar_step_forward.argtypes = [P(Ctx), P(Batch), i32, vp]
     lib.tcar_step_backward_local.argtypes = [P(Ctx), P(Batch), vp]
     lib.tcar_step_finish.argtypes = [P(Ctx), P(Batch), vp]

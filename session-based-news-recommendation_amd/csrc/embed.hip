@@ -14,6 +14,8 @@
 // rows once at the end.
 #include "tcar_common.h"
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
+
 namespace {
 
 struct EmbArgs {
@@ -251,6 +253,7 @@ struct CandArgs {
   float* E;
   const float* d_et;
   tcar_grads_t g;
+  __bf16* eh; __bf16* el;     // optional bf16 hi / lo planes of E (same [Npad, ek] layout)
 };
 
 // E[n, ic + k*ldt ...] = clip(table_k[mwdhm[n,k]])   (model_combine.py:86-92)
@@ -279,7 +282,16 @@ __global__ __launch_bounds__(256) void cand_time_fwd_kernel(const CandArgs a) {
     const int k = (int)(nk % 5);
     const long n = nk / 5;
     const int id = clampi(a.mwdhm[n * 5 + k], 0, time_vocab(k) - 1);
-    st4(a.E + n * ek + ic + k * ldt + l * 4, ld4(lds + (time_rowoff(k) + id) * ldt + l * 4));
+    const float4 v = ld4(lds + (time_rowoff(k) + id) * ldt + l * 4);
+    st4(a.E + n * ek + ic + k * ldt + l * 4, v);
+    if (a.eh) {
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      bf16x4_e h, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { h[j] = (__bf16)vv[j]; lo[j] = (__bf16)(vv[j] - (float)h[j]); }
+      *reinterpret_cast<bf16x4_e*>(a.eh + n * ek + ic + k * ldt + l * 4) = h;
+      *reinterpret_cast<bf16x4_e*>(a.el + n * ek + ic + k * ldt + l * 4) = lo;
+    }
   }
 }
 
@@ -342,7 +354,7 @@ __global__ __launch_bounds__(256) void cand_time_bwd_kernel(const CandArgs a) {
 // Pass 1: grid (139 rows, CH chunks); each 16-lane group streams its candidates' 256-byte d_et segments and keeps
 // S, Q, D2; fixed-order reductions; partials to a workspace.  Pass 2: one workgroup folds the chunks in order,
 // applies the Jacobian, adds into the time-table gradients and the norm pieces.
-constexpr int CT_CHUNKS = 8;
+constexpr int CT_CHUNKS = 32;
 
 __global__ __launch_bounds__(256) void cand_time_bwd_idx_kernel(const CandArgs a, const int32_t* __restrict__ inv_n,
                                                                 const int32_t* __restrict__ inv_off,
@@ -361,13 +373,24 @@ __global__ __launch_bounds__(256) void cand_time_bwd_idx_kernel(const CandArgs a
   const float4 x = ld4(pick5(a.tab, k) + (long)v * ldt + lin * 4);
   float4 S = zero4();
   float Q = 0.f, D2 = 0.f;
-  for (int i = s0 + grp; i < s1; i += groups) {
-    const long n = inv_n[i];
-    const float4 gy = ld4(a.d_et + n * pt + k * ldt + lin * 4);
-    S = add4(S, gy);
-    Q += dot4(gy, gy);
-    const float d = group_sum(dot4(x, gy), sub);
-    D2 += (lin == 0) ? d * d : 0.f;
+  // 4 candidates per group and trip: index loads, then row loads, all independent (memory-level parallelism)
+  for (int i0 = s0 + grp; i0 < s1; i0 += 4 * groups) {
+    long n[4];
+    float4 gy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * groups;
+      n[u] = (i < s1) ? (long)inv_n[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) gy[u] = (n[u] >= 0) ? ld4(a.d_et + n[u] * pt + k * ldt + lin * 4) : zero4();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      S = add4(S, gy[u]);
+      Q += dot4(gy[u], gy[u]);
+      const float d = group_sum(dot4(x, gy[u]), sub);
+      D2 += (lin == 0) ? d * d : 0.f;
+    }
   }
   Q = group_sum(Q, sub);
   st4(shS + grp * ldt + lin * 4, S);
@@ -387,26 +410,31 @@ __global__ __launch_bounds__(256) void cand_time_bwd_idx_kernel(const CandArgs a
   }
 }
 
-__global__ __launch_bounds__(256) void cand_time_bwd_fin_kernel(const CandArgs a, const float* __restrict__ ws) {
-  __shared__ float piece[139];
+// pass 2a: one workgroup per table row folds its CT_CHUNKS partials (each 16-lane group takes chunks g, g+16, ...;
+// the groups' sums meet in LDS and are added in fixed order) and applies the clip Jacobian
+__global__ __launch_bounds__(256) void cand_time_bwd_fin_kernel(const CandArgs a, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float shS[16 * 256];
+  __shared__ float shQ[16], shD[16];
   const int tid = threadIdx.x;
   const int ldt = a.d.ldt, sub = ldt >> 2, groups = 256 / sub;
   const int grp = tid / sub, lin = tid - grp * sub;
-  for (int r0 = 0; r0 < 139; r0 += groups) {
-    const int r = r0 + grp;
-    const bool valid = r < 139;
-    const int rr = valid ? r : 0;
-    const int k = rr < 13 ? 0 : rr < 45 ? 1 : rr < 53 ? 2 : rr < 78 ? 3 : 4;
-    const int v = rr - time_rowoff(k);
-    float4 S = zero4();
-    float Q = 0.f, D2 = 0.f;
-    for (int c = 0; c < CT_CHUNKS; ++c) {
-      const float* p = ws + ((long)rr * CT_CHUNKS + c) * (ldt + 4);
-      S = add4(S, ld4(p + lin * 4));
-      Q += p[ldt];
-      D2 += p[ldt + 1];
-    }
-    const float4 x = ld4(pick5(a.tab, k) + (long)v * ldt + lin * 4);
+  const int r = blockIdx.x;
+  const int k = r < 13 ? 0 : r < 45 ? 1 : r < 53 ? 2 : r < 78 ? 3 : 4;
+  float4 S = zero4();
+  float Q = 0.f, D2 = 0.f;
+  for (int c = grp; c < CT_CHUNKS; c += groups) {
+    const float* p = ws + ((long)r * CT_CHUNKS + c) * (ldt + 4);
+    S = add4(S, ld4(p + lin * 4));
+    Q += p[ldt];
+    D2 += p[ldt + 1];
+  }
+  st4(shS + grp * ldt + lin * 4, S);
+  if (lin == 0) { shQ[grp] = Q; shD[grp] = D2; }
+  __syncthreads();
+  if (tid < sub) {                                            // the first 16-lane group finishes the row
+    S = zero4(); Q = 0.f; D2 = 0.f;
+    for (int g2 = 0; g2 < groups; ++g2) { S = add4(S, ld4(shS + g2 * ldt + lin * 4)); Q += shQ[g2]; D2 += shD[g2]; }
+    const float4 x = ld4(pick5(a.tab, k) + (long)(r - time_rowoff(k)) * ldt + lin * 4);
     const float ss = group_sum(dot4(x, x), sub), xs = group_sum(dot4(x, S), sub);
     float4 gx = S;
     float pc = Q;
@@ -415,18 +443,19 @@ __global__ __launch_bounds__(256) void cand_time_bwd_fin_kernel(const CandArgs a
       gx = fma4(x, -(xs * inv2 * inv), scale4(S, inv));
       pc = inv2 * Q - inv2 * inv2 * D2;
     }
-    if (valid) {
-      float* gp = a.g.g_time[0] + (long)rr * ldt + lin * 4;       // month..minute gradients are contiguous
-      st4(gp, add4(ld4(gp), gx));
-      if (lin == 0) piece[rr] = pc;
-    }
+    float* gp = a.g.g_time[0] + (long)r * ldt + lin * 4;       // month..minute gradients are contiguous
+    st4(gp, add4(ld4(gp), gx));
+    if (lin == 0) ws[(long)139 * CT_CHUNKS * (ldt + 4) + r] = pc;
   }
-  __syncthreads();
-  if (tid < 5) {
-    float s = 0.f;
-    for (int r = time_rowoff(tid); r < time_rowoff(tid) + time_vocab(tid); ++r) s += piece[r];
-    atomicAdd(a.g.sqn + pick5(a.g.slot_time, tid), s);
-  }
+}
+// pass 2b: per-table norm pieces, summed in row order by one thread each
+__global__ __launch_bounds__(64) void cand_time_bwd_piece_kernel(const CandArgs a, const float* __restrict__ ws) {
+  const int k = threadIdx.x;
+  if (k >= 5) return;
+  const float* pc = ws + (long)139 * CT_CHUNKS * (a.d.ldt + 4);
+  float s = 0.f;
+  for (int r = time_rowoff(k); r < time_rowoff(k) + time_vocab(k); ++r) s += pc[r];
+  atomicAdd(a.g.sqn + pick5(a.g.slot_time, k), s);
 }
 
 // g_item[ids[r]-1] += rows[r]: one wave per row, 256-byte-contiguous float atomics
@@ -507,12 +536,14 @@ extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* con
   a.d_et = d_et; a.g = *g;
   TCAR_LAUNCH(cand_time_bwd_idx_kernel, dim3(139, CT_CHUNKS), dim3(256), 0, (hipStream_t)stream, a, inv_n, inv_off, ws);
   TCAR_CHECK_LAUNCH();
-  TCAR_LAUNCH(cand_time_bwd_fin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, (const float*)ws);
+  TCAR_LAUNCH(cand_time_bwd_fin_kernel, dim3(139), dim3(256), 0, (hipStream_t)stream, a, ws);
+  TCAR_CHECK_LAUNCH();
+  TCAR_LAUNCH(cand_time_bwd_piece_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, (const float*)ws);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
 
-extern "C" int tcar_cand_time_ws_floats(const tcar_dims_t* d) { return d ? 139 * CT_CHUNKS * (d->ldt + 4) : 0; }
+extern "C" int tcar_cand_time_ws_floats(const tcar_dims_t* d) { return d ? 139 * CT_CHUNKS * (d->ldt + 4) + 144 : 0; }
 
 extern "C" int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float* rows, int64_t R,
                                      float* g_item, void* stream) {
@@ -528,11 +559,16 @@ extern "C" int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, c
 
 extern "C" int tcar_cand_time_fwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
                                   float* E, void* stream) {
-  if (check_dims(d) || !time_tab || !mwdhm || !E) return TCAR_E_ARG;
+  return tcar_cand_time_fwd_bf16(d, time_tab, mwdhm, E, nullptr, nullptr, stream);
+}
+
+extern "C" int tcar_cand_time_fwd_bf16(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
+                                       float* E, void* e16_hi, void* e16_lo, void* stream) {
+  if (check_dims(d) || !time_tab || !mwdhm || !E || (e16_hi && !e16_lo)) return TCAR_E_ARG;
   CandArgs a{};
   a.d = *d;
   for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
-  a.mwdhm = mwdhm; a.E = E;
+  a.mwdhm = mwdhm; a.E = E; a.eh = (__bf16*)e16_hi; a.el = (__bf16*)e16_lo;
   const size_t lds = (size_t)139 * d->ldt * sizeof(float);
   long total = (long)d->n_items * 5 * (d->ldt >> 2);
   int grid = (int)((total + 256 * 8 - 1) / (256 * 8));

@@ -9,6 +9,8 @@
 // where the pieces are the IndexedSlices value blocks accumulated by the embedding backward kernels (S5).
 #include "tcar_common.h"
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
 namespace {
 
 struct SegArgs {
@@ -23,19 +25,21 @@ __device__ __forceinline__ float clip_factor(const float* sqn_dense, const float
   return clip / fmaxf(n, clip);
 }
 
-// grid = (chunks, nseg); each workgroup reduces up to 4096 floats of one segment
+// grid = (chunks <= 256, nseg); each workgroup strides over 4096-float pieces of one segment and issues ONE
+// atomic (same-address float atomics serialise at ~12 ns each: thousands of them cost more than the read)
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, const SegArgs a, float* __restrict__ out) {
   __shared__ float sh[4];
   const int seg = blockIdx.y;
   const long off = a.s.off[seg];
   const long len = a.s.len[seg];
-  const long base = (long)blockIdx.x * 4096;
-  if (base >= len) return;
+  if ((long)blockIdx.x * 4096 >= len) return;
   float s = 0.f;
+  for (long base = (long)blockIdx.x * 4096; base < len; base += (long)gridDim.x * 4096) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const long e = base + (i * 256 + threadIdx.x) * 4;
-    if (e < len) { const float4 v = ld4(g + off + e); s += dot4(v, v); }
+    for (int i = 0; i < 4; ++i) {
+      const long e = base + (i * 256 + threadIdx.x) * 4;
+      if (e < len) { const float4 v = ld4(g + off + e); s += dot4(v, v); }
+    }
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -84,7 +88,8 @@ __global__ __launch_bounds__(256) void clip_adam_2d_kernel(float* __restrict__ w
                                                            int cols, int slot, const float* __restrict__ sqn_dense,
                                                            const float* __restrict__ sqn_pieces,
                                                            const int32_t* __restrict__ use_dense, float clip, float lr_t,
-                                                           float b1, float b2, float eps) {
+                                                           float b1, float b2, float eps, __bf16* __restrict__ eh,
+                                                           __bf16* __restrict__ el, long ld16) {
   const float sc = clip_factor(sqn_dense, sqn_pieces, use_dense, slot, clip);
   const int c4 = cols >> 2;
   const long total = rows * c4;
@@ -96,6 +101,14 @@ __global__ __launch_bounds__(256) void clip_adam_2d_kernel(float* __restrict__ w
     float4 ww = ld4(wp), mm = ld4(m + p), vv = ld4(v + p);
     adam4(ww, ld4(g + p), mm, vv, sc, lr_t, b1, b2, eps);
     st4(wp, ww); st4(m + p, mm); st4(v + p, vv);
+    if (eh) {   // keep the bf16 hi / lo planes of the candidate matrix in step with the fp32 master (gemm_bf16.hip)
+      const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+      bf16x4_t h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { h[j] = (__bf16)wv[j]; l[j] = (__bf16)(wv[j] - (float)h[j]); }
+      *reinterpret_cast<bf16x4_t*>(eh + r * ld16 + c) = h;
+      *reinterpret_cast<bf16x4_t*>(el + r * ld16 + c) = l;
+    }
   }
 }
 
@@ -118,7 +131,7 @@ extern "C" int tcar_sqnorm(const float* g, const tcar_segments_t* segs, float* s
   if (segs->nseg == 0) return TCAR_OK;
   SegArgs a;
   a.s = *segs;
-  TCAR_LAUNCH(sqnorm_kernel, dim3(seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
+  TCAR_LAUNCH(sqnorm_kernel, dim3(seg_grid_x(segs) > 256 ? 256 : seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -136,9 +149,11 @@ extern "C" int tcar_clip_adam(float* w, const float* g, float* m, float* v, cons
   return TCAR_OK;
 }
 
-extern "C" int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m, float* v, int64_t rows, int32_t cols,
-                                 int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense,
-                                 float clip, float lr_t, float b1, float b2, float eps, void* stream) {
+extern "C" int tcar_clip_adam_2d_bf16(float* w, int64_t ldw, const float* g, float* m, float* v, int64_t rows,
+                                      int32_t cols, int32_t slot, const float* sqn_dense, const float* sqn_pieces,
+                                      const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
+                                      void* e16_hi, void* e16_lo, int64_t ld16, void* stream) {
+  if (e16_hi && (!e16_lo || (ld16 & 3))) return TCAR_E_ARG;
   if (!w || !g || !m || !v || rows <= 0 || cols <= 0 || (cols & 3) || (ldw & 3) || slot < 0 || slot >= TCAR_NSLOT)
     return TCAR_E_ARG;
   long total = rows * (cols >> 2);
@@ -146,9 +161,17 @@ extern "C" int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m
   if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   TCAR_LAUNCH(clip_adam_2d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (long)ldw, g, m, v, (long)rows,
-                     (int)cols, (int)slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps);
+                     (int)cols, (int)slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps, (__bf16*)e16_hi,
+              (__bf16*)e16_lo, (long)ld16);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
+}
+
+extern "C" int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m, float* v, int64_t rows, int32_t cols,
+                                 int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense,
+                                 float clip, float lr_t, float b1, float b2, float eps, void* stream) {
+  return tcar_clip_adam_2d_bf16(w, ldw, g, m, v, rows, cols, slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2,
+                                eps, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int tcar_abi_version(void) { return 1; }

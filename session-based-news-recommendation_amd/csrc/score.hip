@@ -7,6 +7,8 @@
 // workgroup (or wave) per session and wave-shuffle reductions.
 #include "tcar_common.h"
 
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_s;
+
 namespace {
 
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
@@ -31,8 +33,11 @@ __device__ __forceinline__ float block_max_256(float v, float* sh) {
 // ---- sparse softmax cross entropy + gradient (model_combine.py:145) ------------------------------------
 // One workgroup per session.  Pass 1: online (max, sum-exp) over the row.  Pass 2: overwrite the row with
 // softmax - onehot (the gradient of the SUM of the per-session losses, model_combine.py:147,156).
+// dh != NULL: the gradient is written as bf16 hi / lo planes [B, ld] (operands of gemm_bf16.hip) and the logits are
+// left untouched; otherwise it overwrites the logits in fp32.
 __global__ __launch_bounds__(256) void softmax_ce_kernel(int N, float* __restrict__ logits, long ld,
-                                                         const int32_t* __restrict__ label, float* __restrict__ ce) {
+                                                         const int32_t* __restrict__ label, float* __restrict__ ce,
+                                                         __bf16* __restrict__ dh, __bf16* __restrict__ dl) {
   __shared__ float sh[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   float* row = logits + (long)b * ld;
@@ -65,7 +70,16 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int N, float* __restric
     o.y = (c + 1 < N) ? expf(v.y - lse) - (c + 1 == lab ? 1.f : 0.f) : 0.f;
     o.z = (c + 2 < N) ? expf(v.z - lse) - (c + 2 == lab ? 1.f : 0.f) : 0.f;
     o.w = (c + 3 < N) ? expf(v.w - lse) - (c + 3 == lab ? 1.f : 0.f) : 0.f;
-    st4(row + c, o);
+    if (dh) {
+      const float ov[4] = {o.x, o.y, o.z, o.w};
+      bf16x4_s h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { h[j] = (__bf16)ov[j]; l[j] = (__bf16)(ov[j] - (float)h[j]); }
+      *reinterpret_cast<bf16x4_s*>(dh + (long)b * ld + c) = h;
+      *reinterpret_cast<bf16x4_s*>(dl + (long)b * ld + c) = l;
+    } else {
+      st4(row + c, o);
+    }
   }
 }
 
@@ -221,9 +235,15 @@ __global__ __launch_bounds__(256) void rank_topk_kernel(int N, const float* __re
 }  // namespace
 
 extern "C" int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* stream) {
+  return tcar_softmax_ce_bf16(B, N, logits, ld, label, ce, nullptr, nullptr, stream);
+}
+
+extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce,
+                                    void* dl_hi, void* dl_lo, void* stream) {
   if (B <= 0) return TCAR_OK;
-  if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce) return TCAR_E_ARG;
-  TCAR_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, ce);
+  if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && !dl_lo)) return TCAR_E_ARG;
+  TCAR_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, ce,
+              (__bf16*)dl_hi, (__bf16*)dl_lo);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -70,7 +70,8 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
   if (refresh_time) {
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-    RET(tcar_cand_time_fwd(&c->d, tt, c->mwdhm, c->E, stream));
+    RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
+                                stream));
   }
   tcar_tables_t tab;
   tables_of(c, tab);
@@ -107,7 +108,17 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
     ei = (*c->ev_cursor)++ % c->ev_n;
     (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
   }
-  const int rc = tcar_gemm_f32(1, B, g.N, g.ek, c->attout, g.ek, c->E, g.ek, c->logits, g.Npad, nullptr, 0, 0, 1, stream);
+  int rc;
+  if (c->scoring) {
+    // split-bf16 path: attout -> hi/lo planes (+ the packed item|time operand of dE), then the bf16 MFMA GEMM
+    rc = tcar_split_bf16(c->attout, g.ek, B, g.ek, c->a16h, c->a16l, g.ek, c->ap16h, c->ap16l, g.ldh + g.pt, g.ldh, g.ic,
+                         stream);
+    if (!rc)
+      rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, c->e16h, c->e16l, g.ek, c->logits, g.Npad, nullptr, 0,
+                          0, c->scoring, 1, stream);
+  } else {
+    rc = tcar_gemm_f32(1, B, g.N, g.ek, c->attout, g.ek, c->E, g.ek, c->logits, g.Npad, nullptr, 0, 0, 1, stream);
+  }
   if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[ei], (hipStream_t)stream);
   return rc;
 }
@@ -119,18 +130,28 @@ extern "C" int tcar_step_backward_local(const tcar_ctx_t* c, const tcar_batch_t*
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
   if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
-  RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
-  // d attout = dlogits E: contraction over the catalog, split-K slabs + deterministic reduce
-  const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
-  RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
-  RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
+  const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
+  if (c->scoring) {
+    // split-bf16 scoring backward: dlogits as bf16 planes; dX (split-K slabs) and dE (item | time destinations)
+    RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, c->dl16l, stream));
+    RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, c->e16h, c->e16l, g.ek, c->slabs, g.ek, nullptr, 0,
+                       0, c->scoring, c->splitk, stream));
+    RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
+    RET(tcar_gemm_bf16(2, g.N, g.ldh + g.pt, B, c->dl16h, c->dl16l, g.Npad, c->ap16h, c->ap16l, g.ldh + g.pt, Gi, g.ldh,
+                       d_et, g.pt, g.ldh, c->scoring, 1, stream));
+  } else {
+  RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
+  // d attout = dlogits E: contraction over the catalog, split-K slabs + deterministic reduce
+  RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
+  RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
   {  // dE = dlogits^T attout: item block and time block (content is frozen)
     tcar_gemm_desc_t p[2];
     p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
     p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
     RET(tcar_gemm_f32_grouped(2, 2, p, stream));
+  }
   }
   if (K > 0 && bt->neg) {
     RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->dattout, Gi, stream));
@@ -206,8 +227,9 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
   const float* pieces = c->Gx + c->arena_n;
   RET(tcar_clip_adam(c->W, c->Gx, c->M, c->V, &c->segs_all, c->sqn_dense, pieces, c->use_dense, c->clip, lr_t, c->b1,
                      c->b2, c->eps, stream));
-  return tcar_clip_adam_2d(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
-                           c->clip, lr_t, c->b1, c->b2, c->eps, stream);
+  return tcar_clip_adam_2d_bf16(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces,
+                                c->use_dense, c->clip, lr_t, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
+                                c->scoring ? c->e16l : nullptr, g.ek, stream);
 }
 
 extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {

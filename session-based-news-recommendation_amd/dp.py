@@ -127,6 +127,13 @@ class DPEngine(TcarEngine):
         self.update()
         return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
 
+    def update(self):
+        if self.native and self.timing is None and hasattr(self, "_ctx_obj"):
+            check(self.lib.tcar_step_update(C.byref(self._ctx()), self._lr_t(), self._stream()), "tcar_step_update")
+            self._after_update()
+        else:
+            super().update()
+
     def _local(self, bt):
         """forward + rank-local backward, driven from C++ (tcar_step_forward / tcar_step_backward_local)."""
         if self.native and self.timing is None:

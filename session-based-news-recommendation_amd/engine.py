@@ -101,7 +101,7 @@ N_ATOMIC = 9
 class TcarEngine:
     def __init__(self, params: Dict[str, np.ndarray], content_emb: np.ndarray, mwdhm: np.ndarray, lr: float = 1e-3,
                  max_grad: Optional[float] = 150.0, neg_weight: float = 0.01, device: str = "cuda:0",
-                 splitk: int = 16):
+                 splitk: int = 16, scoring: str = "f32"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.TcarError("TcarEngine needs an MI355X (no CPU fallback)")
@@ -114,6 +114,12 @@ class TcarEngine:
         self.b1_pow, self.b2_pow = np.float32(self.b1), np.float32(self.b2)
         self.step = 0
         self.splitk = splitk
+        # precision of the three full-catalog scoring GEMMs: "f32" (fp32 MFMA), "bf16x3" (split-bf16 planes, three
+        # bf16 MFMAs per product, fp32-class accuracy), "bf16" (hi plane only)
+        if scoring not in ("f32", "bf16x3", "bf16"):
+            raise ValueError("scoring must be f32 | bf16x3 | bf16")
+        self.scoring = scoring
+        self.scoring_code = {"f32": 0, "bf16": 1, "bf16x3": 3}[scoring]
         f32 = dict(dtype=torch.float32, device=self.dev)
         # arena layout ------------------------------------------------------------------------------------
         self.seg = OrderedDict()
@@ -133,6 +139,9 @@ class TcarEngine:
         self.M = torch.zeros(off, **f32)
         self.V = torch.zeros(off, **f32)
         self.E = torch.zeros(g.Npad, g.ek, **f32)
+        if self.scoring_code:
+            self.e16h = torch.zeros(g.Npad, g.ek, dtype=torch.bfloat16, device=self.dev)
+            self.e16l = torch.zeros(g.Npad, g.ek, dtype=torch.bfloat16, device=self.dev)
         # dense item-table gradient and the candidate-side time block of dE, contiguous for the same reason
         self.big = torch.zeros(g.N * (g.ldh + g.pt), **f32)
         self.Gi = self.big[:g.N * g.ldh].view(g.N, g.ldh)
@@ -197,6 +206,9 @@ class TcarEngine:
             self._content = np.asarray(content_emb, dtype=np.float32)
         E[:g.N, g.ldh:g.ldh + g.H] = self._content[1:]
         self.E.copy_(torch.from_numpy(E))
+        if self.scoring_code:
+            check(self.lib.tcar_split_bf16(self._p(self.E), g.ek, g.Npad, g.ek, self._p(self.e16h), self._p(self.e16l), g.ek,
+                                           None, None, 0, 0, 0, self._stream()), "tcar_split_bf16")
         self._item_row0 = np.asarray(params["item_emb"], dtype=np.float32)[0].copy()
         self._time_dirty = True
 
@@ -271,6 +283,11 @@ class TcarEngine:
             self.dq1 = torch.empty(B, g.ldh, **f32)
             self.dclick = torch.empty(B, g.ct, **f32)
             self.slabs = torch.empty(self.splitk, B, g.ek, **f32)
+            if self.scoring_code:
+                bf = dict(dtype=torch.bfloat16, device=self.dev)
+                self.a16h, self.a16l = torch.zeros(B, g.ek, **bf), torch.zeros(B, g.ek, **bf)
+                self.ap16h, self.ap16l = torch.zeros(B, g.ldh + g.pt, **bf), torch.zeros(B, g.ldh + g.pt, **bf)
+                self.dl16h, self.dl16l = torch.zeros(B, g.Npad, **bf), torch.zeros(B, g.Npad, **bf)
             self.rank = torch.empty(B, dtype=torch.int32, device=self.dev)
             self.topk = torch.empty(B, 20, dtype=torch.int32, device=self.dev)
             self.work_B = B
@@ -429,7 +446,10 @@ class TcarEngine:
 
     # --------------------------------------------------------------------------------------------- forward
     def forward(self, bt: Batch):
-        """model_combine.py:52-138 up to the full-catalog logits."""
+        """model_combine.py:52-138 up to the full-catalog logits (Python-sequenced op-level path, fp32 scoring only;
+        the bf16 scoring modes are sequenced by the C++ step driver)."""
+        if self.scoring_code:
+            raise _lib.TcarError("the Python-sequenced op-level path supports scoring='f32' only")
         g, lib, st = self.geo, self.lib, self._stream()
         B, T = bt.B, bt.T
         BT = B * T
@@ -608,6 +628,10 @@ class TcarEngine:
         c.segs_all, c.segs_dense = self.segs_all, self.segs_dense
         for n in _lib._WS:
             setattr(c, n, getattr(self, n).data_ptr())
+        c.scoring = self.scoring_code
+        if self.scoring_code:
+            for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l"):
+                setattr(c, n, getattr(self, n).data_ptr())
         if self._ev is not None:
             c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
             c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)
@@ -684,7 +708,12 @@ class TcarEngine:
                   "tcar_eval_step")
             self._time_dirty = False
             return (self.rank[:B], self.topk[:B], self.ce[:B])
-        self.forward(bt)
+        if self.native:
+            check(self.lib.tcar_step_forward(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), self._stream()),
+                  "tcar_step_forward")
+            self._time_dirty = False
+        else:
+            self.forward(bt)
         g, lib, st, p = self.geo, self.lib, self._stream(), self._p
         check(lib.tcar_rank_topk(B, g.N, p(self.logits), g.Npad, C.c_void_p(bt.label), k, p(self.rank), p(self.topk), st),
               "tcar_rank_topk")

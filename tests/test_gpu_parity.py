@@ -195,13 +195,15 @@ CASES = [  # N, H, Ht, B, T, K
 ]
 
 
+@pytest.mark.parametrize("scoring", ["f32", "bf16x3"])
 @pytest.mark.parametrize("N,H,Ht,B,T,K", CASES)
-def test_step_matches_oracle(N, H, Ht, B, T, K):
+def test_step_matches_oracle(N, H, Ht, B, T, K, scoring):
+    """Both scoring precisions hold the SAME 1e-3 gate: bf16x3 carries fp32 operands as hi/lo bf16 planes."""
     _need_gpu()
     from oracle.tcar_oracle import TcarOracle
     from tcar_amd.engine import TcarEngine
     params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=N + H + B + T)
-    eng = TcarEngine(params, content, mw, max_grad=2.0)
+    eng = TcarEngine(params, content, mw, max_grad=2.0, scoring=scoring)
     ora = TcarOracle(params, content, mw, max_grad=2.0)
     # forward + eval
     rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
@@ -256,13 +258,14 @@ def test_golden_fixture():
         close(p3[k], z["p3/" + k], name="p3 " + k, atol_scale=1e-4)
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("scoring", ["f32", "bf16x3"])
+def test_full_size_properties(scoring):
     """Globo-like size (N=46,033, H=250, B=512): properties that need no oracle run."""
     _need_gpu()
     from tcar_amd.engine import TcarEngine
     N, H, Ht, B, T, K = 46033, 250, 64, 512, 3, 20
     params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=99, emb_std=0.05, w_std=0.05)
-    eng = TcarEngine(params, content, mw)
+    eng = TcarEngine(params, content, mw, scoring=scoring)
     rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
     lg = logits.double()
     lab = torch.as_tensor(batch["label"], dtype=torch.long, device="cuda")
@@ -317,3 +320,114 @@ def test_dp_engine_single_rank_path_matches_oracle():
     p_e, p_o = eng.export_params(), ora.export()
     for k in p_o:
         close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-4)
+
+
+# ----------------------------------------------------------------------------------------- split-bf16 GEMM
+def _planes(x):
+    t = torch.tensor(x).cuda()
+    hi = t.bfloat16()
+    lo = (t - hi.float()).bfloat16()
+    return hi.contiguous(), lo.contiguous()
+
+
+@pytest.mark.parametrize("nsplit", [3, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(512, 300, 832), (130, 129, 40), (64, 832, 2056), (257, 576, 512), (5, 7, 8)])
+def test_gemm_bf16_layouts(lib, layout, nsplit, M, N, K):
+    """All three operand layouts (k-contiguous b128 fragments and ds_read_b64_tr_b16 transposed fragments) against
+    fp64; asymmetric random operands (a swapped row/col map cannot pass)."""
+    rng = np.random.RandomState(M + 3 * N + 7 * K + layout)
+    ld8 = lambda x: (x + 7) // 8 * 8 + 8
+    a_shape = (M, ld8(K)) if layout != 2 else (K, ld8(M))
+    b_shape = (K, ld8(N)) if layout != 1 else (N, ld8(K))
+    A = rng.standard_normal(a_shape).astype(np.float32)
+    Bm = rng.standard_normal(b_shape).astype(np.float32) * 0.5 + 0.25
+    Al = A[:, :K] if layout != 2 else A[:, :M].T
+    Bl = Bm[:, :N] if layout != 1 else Bm[:, :K].T
+    want = Al.astype(np.float64) @ Bl.astype(np.float64)
+    ah, al = _planes(A)
+    bh, bl = _planes(Bm)
+    ldc = N + 4
+    dC = torch.full((M, ldc), 7.0, device="cuda")
+    rc = lib.tcar_gemm_bf16(layout, M, N, K, ptr2(ah), ptr2(al), A.shape[1], ptr2(bh), ptr2(bl), Bm.shape[1], ptr(dC), ldc,
+                            None, 0, 0, nsplit, 1, None)
+    assert rc == 0
+    got = dC.cpu().numpy()
+    close(got[:, :N], want, rtol=1e-3 if nsplit == 3 else 2e-2, atol_scale=2e-5 if nsplit == 3 else 6e-3, name="bf16 gemm")
+    assert (got[:, N:] == 7.0).all()
+
+
+def ptr2(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def test_gemm_bf16_dual_output_and_splitk(lib):
+    rng = np.random.RandomState(4)
+    # TN with two destinations (dE: item block | time block)
+    Kb, M, N = 96, 700, 576
+    dl = rng.standard_normal((Kb, 704)).astype(np.float32) * 0.1
+    at = rng.standard_normal((Kb, 576)).astype(np.float32)
+    want = dl[:, :M].astype(np.float64).T @ at.astype(np.float64)
+    ah, al = _planes(dl)
+    bh, bl = _planes(at)
+    c1 = torch.zeros(M, 256, device="cuda")
+    c2 = torch.zeros(M, 320, device="cuda")
+    assert lib.tcar_gemm_bf16(2, M, N, Kb, ptr2(ah), ptr2(al), 704, ptr2(bh), ptr2(bl), 576, ptr(c1), 256, ptr(c2), 320,
+                              256, 3, 1, None) == 0
+    close(c1.cpu().numpy(), want[:, :256], atol_scale=2e-5, name="dual C1")
+    close(c2.cpu().numpy(), want[:, 256:], atol_scale=2e-5, name="dual C2")
+    # NN with split-K slabs (dX: contraction over the catalog)
+    M, N, K = 100, 832, 6400
+    a = rng.standard_normal((M, K)).astype(np.float32) * 0.05
+    b = rng.standard_normal((K, N)).astype(np.float32)
+    ah, al = _planes(a)
+    bh, bl = _planes(b)
+    S = lib.tcar_gemm_splitk_effective(K, 9)
+    slabs = torch.empty(S, M, N, device="cuda")
+    out = torch.empty(M, N, device="cuda")
+    assert lib.tcar_gemm_bf16(0, M, N, K, ptr2(ah), ptr2(al), K, ptr2(bh), ptr2(bl), N, ptr(slabs), N, None, 0, 0, 3, 9,
+                              None) == 0
+    assert lib.tcar_splitk_reduce(ptr(slabs), S, M, N, N, ptr(out), None) == 0
+    close(out.cpu().numpy(), a.astype(np.float64) @ b.astype(np.float64), atol_scale=2e-5, name="splitk bf16")
+
+
+def test_split_bf16_planes(lib):
+    rng = np.random.RandomState(1)
+    x = (rng.standard_normal((37, 820)) * np.exp(rng.uniform(-8, 8, (37, 820)))).astype(np.float32)
+    xd = torch.zeros(37, 832, device="cuda")
+    xd[:, :820] = torch.tensor(x).cuda()
+    hi = torch.empty(37, 832, dtype=torch.bfloat16, device="cuda")
+    lo = torch.empty_like(hi)
+    phi = torch.empty(37, 576, dtype=torch.bfloat16, device="cuda")
+    plo = torch.empty_like(phi)
+    assert lib.tcar_split_bf16(ptr(xd), 832, 37, 832, ptr2(hi), ptr2(lo), 832, ptr2(phi), ptr2(plo), 576, 256, 512,
+                               None) == 0
+    t = xd
+    want_hi = t.bfloat16()
+    want_lo = (t - want_hi.float()).bfloat16()
+    assert torch.equal(hi, want_hi) and torch.equal(lo, want_lo)
+    assert torch.equal(phi[:, :256], want_hi[:, :256]) and torch.equal(phi[:, 256:], want_hi[:, 512:])
+    assert torch.equal(plo[:, 256:], want_lo[:, 512:])
+    rec = hi.double() + lo.double()
+    assert ((rec - t.double()).abs() <= 2.0 ** -16 * t.double().abs() + 1e-40).all()
+
+
+def test_plain_bf16_scoring_is_close_and_trains():
+    """scoring='bf16' (hi planes only) is the speed mode: logits within ~1e-2 of the oracle norm-wise, same top ranks
+    up to near-ties, loss decreases."""
+    _need_gpu()
+    from oracle.tcar_oracle import TcarOracle
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 1000, 250, 64, 64, 4, 20
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=77)
+    eng = TcarEngine(params, content, mw, scoring="bf16")
+    ora = TcarOracle(params, content, mw)
+    rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
+    o_logits, o_ce = ora.eval_batch(batch)
+    rel = float((logits.cpu().double() - o_logits).norm() / o_logits.norm())
+    assert rel < 1e-2, rel
+    close(ce.cpu().numpy(), o_ce.numpy(), rtol=2e-2, atol_scale=1e-2, name="ce bf16")
+    l0 = float(eng.train_step(batch).sum())
+    for _ in range(5):
+        l1 = float(eng.train_step(batch).sum())
+    assert l1 < l0
