@@ -201,8 +201,8 @@ int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t*
 
 /* tcar_neg_term: neg_logits / neg_feedback of model_combine.py:142-143 and their gradients.
  * neg_fb[b] = -log(1 - sigmoid(x_b) + 1e-24), x_b = sum_k E[neg[b,k], 0:ic] . attout[b, 0:ic].
- * Adds weight * d neg_fb into dattout[b, 0:ic] (plain adds: one wave owns a row) and into g_item (atomics);
- * either may be NULL to skip (forward only). */
+ * Adds weight * d neg_fb into dattout[b, 0:ic] (plain adds: one workgroup owns a row) and into g_item (atomics);
+ * neg_fb, dattout and g_item may each be NULL to skip that output. */
 int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg,
                   const float* attout, float weight, float* neg_fb, float* dattout, float* g_item,
                   void* stream);
@@ -291,6 +291,9 @@ typedef struct {
    * tcar_clip_adam_2d_bf16 / tcar_cand_time_fwd_bf16), a16* [B, ek], ap16* [B, ldh+pt], dl16* [B, Npad]. */
   int32_t scoring;
   void *e16h, *e16l, *a16h, *a16l, *ap16h, *ap16l, *dl16h, *dl16l;
+  /* optional auxiliary stream + 4 events (hipStream_t / hipEvent_t, caller-created): the candidate-side time refresh
+   * (forward) and the dE chain (backward) run on it concurrently with the session-side chain; NULL = one stream */
+  void* stream2; void* ev[4];
   /* optional device timing of the dominant kernel (full-catalog logits GEMM): ev_n pairs of hipEvent_t, used
    * round-robin through the host counter *ev_cursor; ev_n = 0 disables it */
   void* const* ev_start; void* const* ev_stop; int32_t ev_n; int32_t* ev_cursor;

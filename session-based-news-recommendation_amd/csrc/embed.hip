@@ -448,14 +448,12 @@ __global__ __launch_bounds__(256) void cand_time_bwd_fin_kernel(const CandArgs a
     if (lin == 0) ws[(long)139 * CT_CHUNKS * (ldt + 4) + r] = pc;
   }
 }
-// pass 2b: per-table norm pieces, summed in row order by one thread each
+// pass 2b: per-table norm pieces: one wave per table, fixed lane assignment + shuffle tree (deterministic)
 __global__ __launch_bounds__(64) void cand_time_bwd_piece_kernel(const CandArgs a, const float* __restrict__ ws) {
-  const int k = threadIdx.x;
-  if (k >= 5) return;
-  const float* pc = ws + (long)139 * CT_CHUNKS * (a.d.ldt + 4);
-  float s = 0.f;
-  for (int r = time_rowoff(k); r < time_rowoff(k) + time_vocab(k); ++r) s += pc[r];
-  atomicAdd(a.g.sqn + pick5(a.g.slot_time, k), s);
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const float* pc = ws + (long)139 * CT_CHUNKS * (a.d.ldt + 4) + time_rowoff(k);
+  const float s = wave_sum(lane < time_vocab(k) ? pc[lane] : 0.f);
+  if (lane == 0) atomicAdd(a.g.sqn + pick5(a.g.slot_time, k), s);
 }
 
 // g_item[ids[r]-1] += rows[r]: one wave per row, 256-byte-contiguous float atomics
@@ -538,7 +536,7 @@ extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* con
   TCAR_CHECK_LAUNCH();
   TCAR_LAUNCH(cand_time_bwd_fin_kernel, dim3(139), dim3(256), 0, (hipStream_t)stream, a, ws);
   TCAR_CHECK_LAUNCH();
-  TCAR_LAUNCH(cand_time_bwd_piece_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, (const float*)ws);
+  TCAR_LAUNCH(cand_time_bwd_piece_kernel, dim3(5), dim3(64), 0, (hipStream_t)stream, a, (const float*)ws);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

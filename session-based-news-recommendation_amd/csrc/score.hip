@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
   x = px[0] + px[1] + px[2] + px[3];                   // sum over K BEFORE the sigmoid (model_combine.py:142)
   const float sg = 1.0f / (1.0f + expf(-x));
   const float om = 1.0f - sg;
-  if (tid == 0) neg_fb[b] = -logf(om + 1e-24f);
+  if (tid == 0 && neg_fb) neg_fb[b] = -logf(om + 1e-24f);
   const float coef = weight * sg * om / (om + 1e-24f);  // weight * d/dx[-log(1 - sigmoid(x) + 1e-24)]
   if (dattout) {
     for (int col = tid * 4; col < ic; col += 1024) {
@@ -252,7 +252,7 @@ extern "C" int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E,
                              const float* attout, float weight, float* neg_fb, float* dattout, float* g_item,
                              void* stream) {
   if (!d || B <= 0 || K <= 0) return TCAR_OK;
-  if (!E || !neg || !attout || !neg_fb || (d->ldh & 63) || d->ldh > 512) return TCAR_E_ARG;
+  if (!E || !neg || !attout || (d->ldh & 63) || d->ldh > 512) return TCAR_E_ARG;
   const int ek = 2 * d->ldh + 5 * d->ldt;
   const int grid = B;          // one workgroup per session
   if (d->ldh <= 256)

@@ -55,6 +55,10 @@ void grads_of(const tcar_ctx_t* c, tcar_grads_t& g) {
   g.rows_out = nullptr;
 }
 
+inline hipStream_t aux_stream(const tcar_ctx_t* c) {
+  return (c->stream2 && c->ev[0] && c->ev[1] && c->ev[2] && c->ev[3]) ? (hipStream_t)c->stream2 : nullptr;
+}
+
 int check_ctx(const tcar_ctx_t* c, const tcar_batch_t* bt) {
   if (!c || !bt || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   if (!c->E || !c->W || !c->Gx || !c->M || !c->V || !c->big || !c->Mi || !c->Vi) return TCAR_E_ARG;
@@ -67,11 +71,23 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
   RET(check_ctx(c, bt));
   const Geo g(c->d);
   const int B = bt->B, BT = bt->B * bt->T;
+  // The candidate-side time block of E depends only on the time tables: it is rebuilt on the auxiliary stream while
+  // the session side (gather, projections, pools) runs on the main one; the logits GEMM joins them.
+  hipStream_t s1 = (hipStream_t)stream, s2 = aux_stream(c);
+  bool joined = true;
   if (refresh_time) {
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+    if (s2) {
+      if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
+        return TCAR_E_LAUNCH;
+    }
     RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
-                                stream));
+                                s2 ? (void*)s2 : stream));
+    if (s2) {
+      if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+      joined = false;
+    }
   }
   tcar_tables_t tab;
   tables_of(c, tab);
@@ -102,6 +118,7 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
                  W(c, TCAR_V_OT_B), 2);
     RET(tcar_gemm_f32_grouped(0, 2, p, stream));
   }
+  if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138)
   int ei = -1;
   if (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) {
@@ -123,38 +140,54 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
   return rc;
 }
 
-extern "C" int tcar_step_backward_local(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream) {
+namespace {
+int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream);
+
+// Backward pass.  Two independent chains follow the softmax gradient:
+//   A (main stream):  dX = dlogits E -> attention / projection backward -> weight gradients           (many small kernels)
+//   B (aux stream):   dE = dlogits^T attout -> negative rows into dE_item [-> dense norm, candidate-side time backward]
+// They are forked / joined with events so the small kernels of A fill the gaps of B's large GEMM.
+int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
   const int B = bt->B, T = bt->T, BT = B * T, K = bt->K;
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
+  void* sB = s2 ? (void*)s2 : stream;
+  const bool has_neg = K > 0 && bt->neg;
   if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
   if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
   const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
+  if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, c->dl16l, stream));
+  else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
+  if (s2) {
+    if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
+      return TCAR_E_LAUNCH;
+  }
+  // ---- chain B
   if (c->scoring) {
-    // split-bf16 scoring backward: dlogits as bf16 planes; dX (split-K slabs) and dE (item | time destinations)
-    RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, c->dl16l, stream));
-    RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, c->e16h, c->e16l, g.ek, c->slabs, g.ek, nullptr, 0,
-                       0, c->scoring, c->splitk, stream));
-    RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
     RET(tcar_gemm_bf16(2, g.N, g.ldh + g.pt, B, c->dl16h, c->dl16l, g.Npad, c->ap16h, c->ap16l, g.ldh + g.pt, Gi, g.ldh,
-                       d_et, g.pt, g.ldh, c->scoring, 1, stream));
-  } else {
-  RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
-  // d attout = dlogits E: contraction over the catalog, split-K slabs + deterministic reduce
-  RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
-  RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
-  {  // dE = dlogits^T attout: item block and time block (content is frozen)
+                       d_et, g.pt, g.ldh, c->scoring, 1, sB));
+  } else {  // dE = dlogits^T attout: item block and time block (content is frozen)
     tcar_gemm_desc_t p[2];
     p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
     p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
-    RET(tcar_gemm_f32_grouped(2, 2, p, stream));
+    RET(tcar_gemm_f32_grouped(2, 2, p, sB));
   }
+  if (has_neg) RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, nullptr, nullptr, Gi, sB));
+  if (fuse_finish) RET(finish_dense_side(c, g, sB));
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  // ---- chain A
+  if (c->scoring) {
+    RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, c->e16h, c->e16l, g.ek, c->slabs, g.ek, nullptr, 0,
+                       0, c->scoring, c->splitk, stream));
+  } else {
+    RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
   }
-  if (K > 0 && bt->neg) {
-    RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->dattout, Gi, stream));
+  RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
+  if (has_neg) {
+    RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->dattout, nullptr, stream));
   } else if (hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) {
     return TCAR_E_LAUNCH;
   }
@@ -200,24 +233,46 @@ extern "C" int tcar_step_backward_local(const tcar_ctx_t* c, const tcar_batch_t*
     p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
     RET(tcar_gemm_f32_grouped(2, 9, p, stream));
   }
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[3], 0) != hipSuccess) return TCAR_E_LAUNCH;    // join
+  if (fuse_finish) {
+    // sparse rows and per-row norm pieces (after the dense item norm of chain B), then the dense-weight norms
+    tcar_tables_t tab;
+    tcar_grads_t gr;
+    tables_of(c, tab);
+    grads_of(c, gr);
+    RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
+    RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
+  }
   return TCAR_OK;
+}
+
+// clip norm of the dense item block BEFORE the sparse rows are scattered in, then the candidate-side
+// time backward (static inverted index)
+int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream) {
+  tcar_segments_t one = {};
+  one.nseg = 1; one.off[0] = 0; one.len[0] = (int64_t)g.N * g.ldh; one.slot[0] = c->slot_item;
+  RET(tcar_sqnorm(c->big, &one, c->sqn_dense, stream));
+  tcar_grads_t gr;
+  grads_of(c, gr);
+  const float* tt[5];
+  for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+  return tcar_cand_time_bwd_indexed(&c->d, tt, c->inv_n, c->inv_off, c->big + (size_t)g.N * g.ldh, c->ct_ws, &gr, stream);
+}
+}  // namespace
+
+extern "C" int tcar_step_backward_local(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream) {
+  return backward_impl(c, bt, stream, false);
 }
 
 extern "C" int tcar_step_finish(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
-  // clip norm of the dense item block BEFORE the sparse rows are scattered in
-  tcar_segments_t one = {};
-  one.nseg = 1; one.off[0] = 0; one.len[0] = (int64_t)g.N * g.ldh; one.slot[0] = c->slot_item;
-  RET(tcar_sqnorm(c->big, &one, c->sqn_dense, stream));
+  RET(finish_dense_side(c, g, stream));
   tcar_tables_t tab;
   tcar_grads_t gr;
   tables_of(c, tab);
   grads_of(c, gr);
   RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
-  const float* tt[5];
-  for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-  RET(tcar_cand_time_bwd_indexed(&c->d, tt, c->inv_n, c->inv_off, c->big + (size_t)g.N * g.ldh, c->ct_ws, &gr, stream));
   return tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream);
 }
 
@@ -234,8 +289,7 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
 
 extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {
   RET(tcar_step_forward(c, bt, refresh_time, stream));
-  RET(tcar_step_backward_local(c, bt, stream));
-  RET(tcar_step_finish(c, bt, stream));
+  RET(backward_impl(c, bt, stream, true));
   return tcar_step_update(c, lr_t, stream);
 }
 

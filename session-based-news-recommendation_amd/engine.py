@@ -603,6 +603,7 @@ class TcarEngine:
         self._after_update()
 
     # ------------------------------------------------------------------------------ native (C++) step driver
+    overlap = True       # second HIP stream for the independent dE / candidate-time chains (C++ driver only)
     native = True        # drive the step from libtcar_hip.so (tcar_train_step / tcar_eval_step); False = Python
 
     def _ctx(self) -> "_lib.Ctx":
@@ -632,6 +633,15 @@ class TcarEngine:
         if self.scoring_code:
             for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l"):
                 setattr(c, n, getattr(self, n).data_ptr())
+        if self.overlap:
+            if not hasattr(self, "_aux"):
+                self._aux = torch.cuda.Stream(self.dev)
+                self._aux_ev = [torch.cuda.Event() for _ in range(4)]
+                for e in self._aux_ev:
+                    e.record(torch.cuda.current_stream(self.dev))      # materialise the hipEvent_t handles
+            c.stream2 = self._aux.cuda_stream
+            for i, e in enumerate(self._aux_ev):
+                c.ev[i] = e.cuda_event
         if self._ev is not None:
             c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
             c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)
