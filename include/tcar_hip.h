@@ -157,22 +157,32 @@ typedef struct {
   int32_t M, N, act, beta, splitk, atomic;
 } tcar_gemm_desc_t;
 int tcar_gemm_f32_grouped(int layout, int nprob, const tcar_gemm_desc_t* descs /*host*/, void* stream);
+/* Same contract on the bf16 matrix cores: each staged fp32 tile is split on the fly into bf16 hi / lo planes and every
+ * product is three bf16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate, ~1e-5 relative).  For the latency-bound small
+ * contractions of the step when the scoring precision is a bf16 mode. */
+int tcar_gemm_x3_grouped(int layout, int nprob, const tcar_gemm_desc_t* descs /*host*/, void* stream);
 /* number of slabs tcar_gemm_f32 actually writes for a requested split (K is cut in multiples of 32) */
 int tcar_gemm_splitk_effective(int K, int splitk);
 
 /* tcar_gemm_bf16: the same three layouts on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for
- * the full-catalog scoring GEMMs.  Operands are bf16 PLANES of fp32 data: x = hi + lo (tcar_split_bf16);
- * nsplit = 3 computes a_hi b_hi + a_hi b_lo + a_lo b_hi (fp32-class accuracy, ~1e-5), nsplit = 1 uses the hi
- * planes only (plain bf16).  lda/ldb in elements, multiples of 8; K % 8 == 0 for k-contiguous operands.
+ * the full-catalog scoring GEMMs.  Operands are bf16 PLANES of fp32 data, x = hi + lo, in the KB32 blocked layout
+ * (csrc/tcar_bf16_layout.h: 128-row x 32-inner blocks of 8 KB, rows padded to 128 with zeros) produced by
+ * tcar_split_bf16 / tcar_clip_adam_2d_bf16 / tcar_cand_time_fwd_bf16 / tcar_softmax_ce_bf16.
+ * nsplit = 3 computes a_hi b_hi + a_hi b_lo + a_lo b_hi (fp32-class accuracy, ~1e-5), nsplit = 1 uses hi only.
+ * *_inner = inner (contiguous) dimension of the plane, % 32 == 0; *_rows = its row count.  K % 32 == 0 (zero padded).
+ *   layout 0: A plane [M rows, inner >= K],  B plane [K rows, inner >= N]
+ *   layout 1: A plane [M rows, inner >= K],  B plane [N rows, inner >= K]
+ *   layout 2: A plane [K rows, inner >= M],  B plane [K rows, inner >= N]
  * C2 != NULL: output columns >= csplit are written to C2[:, col - csplit] (dE: item block | time block).
  * splitk > 1: C is [splitk_eff, M, ldc] slabs (tcar_gemm_splitk_effective / tcar_splitk_reduce). */
-int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t lda, const void* B_hi,
-                   const void* B_lo, int64_t ldb, float* C, int64_t ldc, float* C2, int64_t ldc2, int csplit, int nsplit,
-                   int splitk, void* stream);
-/* fp32 [rows, cols] (ld) -> bf16 hi / lo planes [rows, ld16] (columns >= cols zero filled; lo may be NULL).
- * packed_* != NULL additionally writes columns [0,c0) U [c1,cols) contiguously into [rows, packed_ld]. */
-int tcar_split_bf16(const float* x, int64_t ld, int rows, int cols, void* hi, void* lo, int64_t ld16, void* packed_hi,
-                    void* packed_lo, int64_t packed_ld, int c0, int c1, void* stream);
+int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
+                   const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
+                   int64_t ldc2, int csplit, int nsplit, int splitk, void* stream);
+/* fp32 [rows, cols] (ld) -> bf16 hi / lo KB32 planes with inner dimension `inner` (>= cols, % 32 == 0); padding rows
+ * up to ceil128(rows) and columns >= cols are zero filled (lo may be NULL).  packed_* != NULL additionally writes
+ * columns [0,c0) U [c1,cols) as a second plane pair with inner dimension packed_inner. */
+int tcar_split_bf16(const float* x, int64_t ld, int rows, int cols, void* hi, void* lo, int64_t inner, void* packed_hi,
+                    void* packed_lo, int64_t packed_inner, int c0, int c1, void* stream);
 
 /* ---- attention pools (modules.py:72-152, util.py:92-100) --------------------------------------------------
  * pre1 [B*T, ldh] = X_ic W_in + X_c W_c + X_act W_int (no activation), pre2 likewise for the time pool,
@@ -195,7 +205,8 @@ int tcar_attn_pool_bwd(const tcar_dims_t* d, int B, int T, const float* x_icp, c
  * logits [B, ld] (first N columns valid) is overwritten by dlogits = softmax - onehot (pad columns 0). */
 int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* stream);
 
-/* ..._bf16: the gradient goes to bf16 hi / lo planes [B, ld] (operands of tcar_gemm_bf16); logits stay intact. */
+/* ..._bf16: the gradient goes to bf16 hi / lo KB32 planes [ceil128(B), ld] (ld % 32 == 0; padding rows zeroed);
+ * the logits stay intact. */
 int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* dl_hi,
                          void* dl_lo, void* stream);
 

@@ -19,7 +19,7 @@ NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_bf16", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_dact_colsum", "tcar_rank_topk",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
            "tcar_abi_version", "tcar_step_forward",
@@ -150,7 +150,9 @@ def load() -> C.CDLL:
     lib.tcar_cand_time_ws_floats.argtypes = [P(Dims)]
     lib.tcar_gemm_f32.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
     lib.tcar_gemm_f32_grouped.argtypes = [i32, i32, P(GemmDesc), vp]
-    lib.tcar_gemm_bf16.argtypes = [i32, i32, i32, i32, vp, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp]
+    lib.tcar_gemm_x3_grouped.argtypes = [i32, i32, P(GemmDesc), vp]
+    lib.tcar_gemm_bf16.argtypes = [i32, i32, i32, i32, vp, vp, i64, i64, vp, vp, i64, i64, vp, i64, vp, i64, i32, i32, i32,
+                                   vp]
     lib.tcar_split_bf16.argtypes = [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp]
     lib.tcar_splitk_reduce.argtypes = [vp, i32, i32, i32, i64, vp, vp]
     lib.tcar_gemm_splitk_effective.argtypes = [i32, i32]

@@ -13,6 +13,7 @@
 // contended tables (position, 5 time tables, dwell: <= 190 rows) in LDS, flushing each workgroup's non-zero
 // rows once at the end.
 #include "tcar_common.h"
+#include "tcar_bf16_layout.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_e;
 
@@ -289,8 +290,9 @@ __global__ __launch_bounds__(256) void cand_time_fwd_kernel(const CandArgs a) {
       bf16x4_e h, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { h[j] = (__bf16)vv[j]; lo[j] = (__bf16)(vv[j] - (float)h[j]); }
-      *reinterpret_cast<bf16x4_e*>(a.eh + n * ek + ic + k * ldt + l * 4) = h;
-      *reinterpret_cast<bf16x4_e*>(a.el + n * ek + ic + k * ldt + l * 4) = lo;
+      const long o = kb32_off(n, ic + k * ldt + l * 4, ek >> 5);   // KB32 blocked plane [Npad, ek]
+      *reinterpret_cast<bf16x4_e*>(a.eh + o) = h;
+      *reinterpret_cast<bf16x4_e*>(a.el + o) = lo;
     }
   }
 }

@@ -7,19 +7,21 @@
 // accumulated in fp32: logits and gradients stay within ~1e-5 of the fp32 path (tests keep the 1e-3 gate) at
 // 3/16 of its MFMA time.  NSPLIT = 1 uses the hi planes only (plain bf16, ~4e-3 relative).
 //
-// Operand layouts (both planes share one layout), tile 128 x 128 x 32, 256 threads = 4 waves (2 x 2), each wave
-// 64 x 64 = 2 x 2 MFMA tiles of 32 x 32:
-//   LAY 0  k-contiguous   X[row*ld + k]   LDS image [128 rows][32 k] (64 B + 16 B pad; stride 80 B = 20 dwords,
-//          20/4 odd => conflict-free ds_read_b128); a lane's fragment (row = lane&31, k = 8*(lane>>5)+0..7) is one
-//          16-byte read.
-//   LAY 1  m/n-contiguous X[k*ld + col]   LDS image [32 k][128 cols] exactly as in memory (256 B + 64 B pad;
-//          stride 320 B makes the 4 k-rows x 2 column groups x 4 pieces of one 32-lane half hit 32 distinct
-//          8-byte bank pairs); fragments come from ds_read_b64_tr_b16, the gfx950 transposing LDS read: per 16-lane
-//          group it returns, to lane i, column i of a 4 (k) x 16 (col) block => 4 consecutive k of the lane's own
-//          row/column; two reads give the 8 k of the fragment.  No transposed copy of E or dlogits ever exists.
-// Staging is global -> registers -> LDS, double buffered (next tile's loads in flight during the MFMAs); the
-// XCD-aware tile remap is the one of gemm_f32.hip.  Split-K (slabs) serves the catalog-long contraction of dX.
+// Planes live in the KB32 blocked layout (tcar_bf16_layout.h): every stage of every operand tile is a handful of
+// contiguous 8-KB / 2-KB chunks.  Staging is DIRECT global -> LDS DMA (global_load_lds_dwordx4: 1 KB per wave
+// instruction, no VGPR round trip, no ds_write; measured on the register-staged predecessor: the data path alone
+// took 118 us of a 165 us launch and its fragment-shaped 64-byte reads ran at ~1/3 of the L2 rate), double
+// buffered: the next stage's DMA is in flight while the current one is multiplied; __syncthreads() drains it
+// (s_waitcnt vmcnt(0) + s_barrier), which is exactly the visibility rule for LDS-DMA data.
+// Workgroup tile (64*WMW) x (64*WNW) x 32 with WMW x WNW waves, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32;
+// 256 x 128 (8 waves) for the large shapes, 128 x 128 (4 waves) otherwise.  Operand modes:
+//   MODE 0  k-contiguous: fragment (row = lane&31, k = 8*(lane>>5)+0..7) is one swizzled ds_read_b128;
+//   MODE 1  m/n-contiguous: fragments come from ds_read_b64_tr_b16, the gfx950 transposing LDS read (per 16-lane group
+//           it returns, to lane i, column i of a 4 (k) x 16 (col) block): no transposed copy of E or dlogits exists.
+// XCD-aware tile remap as in gemm_f32.hip; split-K (slabs) serves the catalog-long contraction of dX.
 #include "tcar_common.h"
+#include "tcar_bf16_layout.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
@@ -27,87 +29,65 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 
-constexpr int TB = 128, KB = 32;
-constexpr int KC_STRIDE = 80;    // bytes per row of a k-contiguous tile
-constexpr int MC_STRIDE = 320;   // bytes per k-row of an m/n-contiguous tile
-constexpr int PLANE = 10240;     // bytes of one plane of one operand tile (128*80 == 32*320)
+constexpr int KB = 32;
 
 struct BArgs {
   const __bf16* A[2];
   const __bf16* B[2];
-  long lda, ldb;
+  int a_in32, b_in32;          // inner dimension / 32 of the A / B planes
+  int a_rb, b_rb;              // allocated 128-row blocks of the A / B planes
   float* C; long ldc;
   float* C2; long ldc2; int csplit;     // columns >= csplit go to C2 (column index rebased); csplit >= N: unused
   int M, N, K, kchunk, mode, mt, nt;
 };
 
-// global -> registers: two 16-byte pieces per thread and plane
-template <int LAY>
-__device__ __forceinline__ void gload(const __bf16* __restrict__ P, long ld, int r0, int rmax, int k0, int kend, int tid,
-                                      uint4 (&reg)[2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int f = tid + 256 * i;
-    if (LAY == 0) {
-      const int row = f >> 2, c = f & 3;
-      const int gr = r0 + row, gk = k0 + c * 8;
-      reg[i] = (gr < rmax && gk < kend) ? *reinterpret_cast<const uint4*>(P + (long)gr * ld + gk) : make_uint4(0, 0, 0, 0);
-    } else {
-      const int krow = f >> 4, c = f & 15;
-      const int gk = k0 + krow, gr = r0 + c * 8;
-      reg[i] = (gk < kend && gr + 7 < rmax) ? *reinterpret_cast<const uint4*>(P + (long)gk * ld + gr) : make_uint4(0, 0, 0, 0);
-    }
-  }
-}
-template <int LAY>
-__device__ __forceinline__ void lstore(char* __restrict__ S, int tid, const uint4 (&reg)[2]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int f = tid + 256 * i;
-    if (LAY == 0) {
-      const int row = f >> 2, c = f & 3;
-      *reinterpret_cast<uint4*>(S + row * KC_STRIDE + c * 16) = reg[i];
-    } else {
-      const int krow = f >> 4, c = f & 15;
-      *reinterpret_cast<uint4*>(S + krow * MC_STRIDE + c * 16) = reg[i];
-    }
-  }
-}
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef __attribute__((address_space(1))) const void* glb_vp;
+
 // fragment of the 32-row block starting at tile row/col `base`, k16 sub-step s (0/1) of the 32-deep stage
-template <int LAY>
+template <int MODE>
 __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int s, int lane) {
-  if (LAY == 0) {
-    return *reinterpret_cast<const bf16x8*>(S + (base + (lane & 31)) * KC_STRIDE + s * 32 + (lane >> 5) * 16);
+  if (MODE == 0) {
+    const int rr = base + (lane & 31), r = rr & 127;
+    const int piece = (s * 2 + (lane >> 5)) ^ ((r >> 2) & 3);
+    return *reinterpret_cast<const bf16x8*>(S + (rr >> 7) * 8192 + r * 64 + piece * 16);
   } else {
     const int g = lane >> 4, i = lane & 15;
-    const int mbase = 16 * (g & 1), kbase = 8 * (g >> 1), q = i >> 2, p = i & 3;
-    const char* a0 = S + (s * 16 + kbase + q) * MC_STRIDE + (base + mbase + 4 * p) * 2;
+    const int q = i >> 2, p = i & 3;
+    const int col = base + 16 * (g & 1) + 4 * p, row = s * 16 + 8 * (g >> 1) + q;
+    const int cc = col & 31, pc = cc >> 3;
+    const char* a0 = S + (col >> 5) * 2048 + row * 64 + (cc & 7) * 2;
     typedef __attribute__((address_space(3))) bf16x4* lds_p;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 4 * MC_STRIDE));
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + ((pc ^ ((row >> 2) & 3)) << 4)));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 256 + ((pc ^ (((row + 4) >> 2) & 3)) << 4)));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   }
 }
 
-template <int LA, int LB, int NSPLIT>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const BArgs g) {
+template <int MA, int MB, int NSPLIT, int WMW, int WNW>
+__global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NP = (NSPLIT == 1) ? 1 : 2;        // planes per operand
-  constexpr int STAGE = 2 * NP * PLANE;            // A planes then B planes
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1;
+  constexpr int NW = WMW * WNW, TM = 64 * WMW, TN = 64 * WNW;
+  constexpr int NP = (NSPLIT == 1) ? 1 : 2;                 // planes per operand
+  constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64;       // one plane of one operand, one stage
+  constexpr int PL = A_BYTES + B_BYTES;                     // LDS stage = [plane][A | B]
+  constexpr int STAGE = NP * PL;
+  constexpr int A_CP = A_BYTES / 1024, B_CP = B_BYTES / 1024;   // 1-KB wave copies per plane
+  constexpr int CPW = NP * (A_CP + B_CP) / NW;              // copies per wave and stage
+  static_assert(NP * (A_CP + B_CP) % NW == 0, "copies must divide evenly over the waves");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WNW, wn = wave - wm * WNW;
 
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   int tm, tn;
   if (g.mt <= g.nt) { tn = id / g.mt; tm = id - tn * g.mt; } else { tm = id / g.nt; tn = id - tm * g.nt; }
-  const int m0 = tm * TB, n0 = tn * TB;
+  const int m0 = tm * TM, n0 = tn * TN;
   const int ks = blockIdx.z * g.kchunk;
   const int ke = min(g.K, ks + g.kchunk);
-  const int nit = (ke - ks + KB - 1) / KB;
-  const int a_rmax = (LA == 0) ? g.M : min((int)g.lda, (g.M + 7) & ~7);
-  const int b_rmax = (LB == 0) ? g.N : min((int)g.ldb, (g.N + 7) & ~7);
+  const int nit = (ke - ks) / KB;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -117,59 +97,64 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const BArgs g) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  uint4 ra[NP][2], rb[NP][2];
-  if (nit > 0) {
+  // issue this wave's share of the DMA copies of k-stage `t` into LDS stage buffer t & 1
+  auto issue = [&](int t) {
+    const int k0 = ks + t * KB;
+    char* St = smem + (t & 1) * STAGE;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      gload<LA>(g.A[p], g.lda, m0, a_rmax, ks, ke, tid, ra[p]);
-      gload<LB>(g.B[p], g.ldb, n0, b_rmax, ks, ke, tid, rb[p]);
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      lstore<LA>(smem + p * PLANE, tid, ra[p]);
-      lstore<LB>(smem + (NP + p) * PLANE, tid, rb[p]);
-    }
-  }
-  __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const char* St = smem + (it & 1) * STAGE;
-    const bool more = (it + 1 < nit);
-    if (more) {
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        gload<LA>(g.A[p], g.lda, m0, a_rmax, ks + (it + 1) * KB, ke, tid, ra[p]);
-        gload<LB>(g.B[p], g.ldb, n0, b_rmax, ks + (it + 1) * KB, ke, tid, rb[p]);
+    for (int i = 0; i < CPW; ++i) {
+      const int c = wave + NW * i;                     // copy index in [0, NP*(A_CP+B_CP))   (wave-uniform)
+      const int p = c / (A_CP + B_CP), rem = c - p * (A_CP + B_CP);
+      const bool isA = rem < A_CP;
+      const int ci = isA ? rem : rem - A_CP;
+      const __bf16* P = isA ? g.A[p] : g.B[p];
+      const int in32 = isA ? g.a_in32 : g.b_in32, nrb = isA ? g.a_rb : g.b_rb;
+      const int mode = isA ? MA : MB, t0 = isA ? m0 : n0;
+      long src;
+      bool ok;
+      if (mode == 0) {          // k-contiguous: 8 copies per 8-KB block (rows t0.., inner block k0/32)
+        const int rb = (t0 >> 7) + (ci >> 3);
+        ok = rb < nrb;
+        src = ((long)rb * in32 + (k0 >> 5)) * 4096 + (ci & 7) * 512;
+      } else {                  // transposed-read: 2 copies per 2-KB chunk (32 rows k0.. of inner block t0/32 + j)
+        const int cb = (t0 >> 5) + (ci >> 1);
+        ok = cb < in32;
+        src = ((long)(k0 >> 7) * in32 + cb) * 4096 + (k0 & 127) * 32 + (ci & 1) * 512;
       }
+      char* dst = St + p * PL + (isA ? 0 : A_BYTES) + ci * 1024;
+      if (ok) __builtin_amdgcn_global_load_lds((glb_vp)(P + src + lane * 8), (lds_vp)dst, 16, 0, 0);
     }
+  };
+  auto compute = [&](int t) {
+    const char* St = smem + (t & 1) * STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 a[NP][2], b[NP][2];
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          a[p][t] = frag<LA>(St + p * PLANE, wm * 64 + t * 32, s, lane);
-          b[p][t] = frag<LB>(St + (NP + p) * PLANE, wn * 64 + t * 32, s, lane);
+        for (int u = 0; u < 2; ++u) {
+          a[p][u] = frag<MA>(St + p * PL, wm * 64 + u * 32, s, lane);
+          b[p][u] = frag<MB>(St + p * PL + A_BYTES, wn * 64 + u * 32, s, lane);
         }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t2 = 0; t2 < 2; ++t2) {
           if constexpr (NSPLIT == 3) {
-            acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0][t], acc[u][t], 0, 0, 0);
-            acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1][t], acc[u][t], 0, 0, 0);
+            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0][t2], acc[u][t2], 0, 0, 0);
+            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1][t2], acc[u][t2], 0, 0, 0);
           }
-          acc[u][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0][t], acc[u][t], 0, 0, 0);
+          acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0][t2], acc[u][t2], 0, 0, 0);
         }
     }
-    if (more) {
-      char* Sn = smem + ((it + 1) & 1) * STAGE;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        lstore<LA>(Sn + p * PLANE, tid, ra[p]);
-        lstore<LB>(Sn + (NP + p) * PLANE, tid, rb[p]);
-      }
-    }
+  };
+
+  if (nit > 0) issue(0);
+  __syncthreads();                       // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
+  for (int it = 0; it < nit; ++it) {
+    if (it + 1 < nit) issue(it + 1);     // buffer (it+1)&1 was last read in iteration it-1, which ended with a barrier
+    compute(it);
     __syncthreads();
   }
 
@@ -183,76 +168,98 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const BArgs g) {
       if (col >= g.N) continue;
       float* base = (col < g.csplit) ? C1 + col : g.C2 + (col - g.csplit);
       const long ld = (col < g.csplit) ? g.ldc : g.ldc2;
+      const int row0 = m0 + wm * 64 + u * 32 + 4 * lh;
+      if (m0 + TM <= g.M) {            // interior tile (workgroup-uniform): 16 unguarded stores, no per-element branch
+        float* pr = base + (long)row0 * ld;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + u * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (row < g.M) base[(long)row * ld] = acc[u][t][e];
+        for (int e = 0; e < 16; ++e) pr[(long)((e & 3) + 8 * (e >> 2)) * ld] = acc[u][t][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + (e & 3) + 8 * (e >> 2);
+          if (row < g.M) base[(long)row * ld] = acc[u][t][e];
+        }
       }
     }
 }
 
-// fp32 [rows, cols] (ld) -> bf16 hi / lo planes [rows, ld16]; columns [cols, ld16) are zero filled.
-// Optional second, PACKED output pair taking columns [0, c0) U [c1, cols) (the dE operand: item | time blocks).
+// fp32 [rows, cols] (ld) -> bf16 hi / lo planes in the KB32 layout with inner dimension in16 (>= cols, % 32 == 0);
+// rows [rows, ceil128(rows)) and columns [cols, in16) are zero filled.  Optional second, PACKED output pair taking
+// columns [0, c0) U [c1, cols) (inner dimension pin16) — the dE operand: item | time blocks of attout.
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, long ld, int rows, int cols,
-                                                         __bf16* __restrict__ hi, __bf16* __restrict__ lo, long ld16,
-                                                         __bf16* __restrict__ phi, __bf16* __restrict__ plo, long pld,
+                                                         __bf16* __restrict__ hi, __bf16* __restrict__ lo, int in16,
+                                                         __bf16* __restrict__ phi, __bf16* __restrict__ plo, int pin16,
                                                          int c0, int c1) {
-  const long c4n = ld16 >> 2;
-  const long total = (long)rows * c4n;
+  const long c4n = in16 >> 2;
+  const long rpad = ((long)rows + 127) & ~127L;
+  const long total = rpad * c4n;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const long r = i / c4n;
     const int c = (int)(i - r * c4n) * 4;
     float v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (c + j < cols) ? x[r * ld + c + j] : 0.f;
+    for (int j = 0; j < 4; ++j) v[j] = (r < rows && c + j < cols) ? x[r * ld + c + j] : 0.f;
     bf16x4 h, l;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       h[j] = (__bf16)v[j];
       l[j] = (__bf16)(v[j] - (float)h[j]);
     }
-    *reinterpret_cast<bf16x4*>(hi + r * ld16 + c) = h;
-    if (lo) *reinterpret_cast<bf16x4*>(lo + r * ld16 + c) = l;
-    if (phi && (c < c0 || c >= c1)) {
-      const int pc = c < c0 ? c : c - (c1 - c0);
-      *reinterpret_cast<bf16x4*>(phi + r * pld + pc) = h;
-      if (plo) *reinterpret_cast<bf16x4*>(plo + r * pld + pc) = l;
+    const long o = kb32_off(r, c, in16 >> 5);
+    *reinterpret_cast<bf16x4*>(hi + o) = h;
+    if (lo) *reinterpret_cast<bf16x4*>(lo + o) = l;
+    if (phi && (c < c0 || c >= c1) && c < cols) {
+      const long po = kb32_off(r, c < c0 ? c : c - (c1 - c0), pin16 >> 5);
+      *reinterpret_cast<bf16x4*>(phi + po) = h;
+      if (plo) *reinterpret_cast<bf16x4*>(plo + po) = l;
     }
   }
 }
 
-template <int LA, int LB>
-int launch_b(const BArgs& g, int nsplit, int splitk, hipStream_t st) {
-  const size_t lds1 = 2 * 2 * 1 * PLANE, lds3 = 2 * 2 * 2 * PLANE;
-  dim3 grid(g.mt * g.nt, 1, splitk), block(256);
-  if (nsplit == 3) {
-    static bool done = false;
-    if (!done) {
-      (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<LA, LB, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-      done = true;
-    }
-    TCAR_LAUNCH((gemm_bf16_kernel<LA, LB, 3>), grid, block, lds3, st, g);
-  } else {
-    TCAR_LAUNCH((gemm_bf16_kernel<LA, LB, 1>), grid, block, lds1, st, g);
+template <int MA, int MB, int NSPLIT, int WMW, int WNW>
+int launch_v(BArgs& g, int splitk, hipStream_t st) {
+  constexpr int NT = 64 * WMW * WNW, TM = 64 * WMW, TN = 64 * WNW, NP = (NSPLIT == 1) ? 1 : 2;
+  constexpr size_t lds = 2 * NP * (TM + TN) * 64;
+  g.mt = (g.M + TM - 1) / TM;
+  g.nt = (g.N + TN - 1) / TN;
+  static bool done = false;
+  if (!done) {
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done = true;
   }
+  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW>), dim3(g.mt * g.nt, 1, splitk), dim3(NT), lds, st, g);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
 
+template <int MA, int MB>
+int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
+  // 256 x 128 tiles (8 waves) once they give the chip at least ~3/4 of a full wave of workgroups; else 128 x 128
+  const long big = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
+  if (big >= 192) return nsplit == 3 ? launch_v<MA, MB, 3, 4, 2>(g, splitk, st) : launch_v<MA, MB, 1, 4, 2>(g, splitk, st);
+  return nsplit == 3 ? launch_v<MA, MB, 3, 2, 2>(g, splitk, st) : launch_v<MA, MB, 1, 2, 2>(g, splitk, st);
+}
+
 }  // namespace
 
-extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t lda,
-                              const void* B_hi, const void* B_lo, int64_t ldb, float* C, int64_t ldc, float* C2,
-                              int64_t ldc2, int csplit, int nsplit, int splitk, void* stream) {
+extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner,
+                              int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C,
+                              int64_t ldc, float* C2, int64_t ldc2, int csplit, int nsplit, int splitk, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
   if (layout < 0 || layout > 2 || !A_hi || !B_hi || !C || (nsplit != 1 && nsplit != 3)) return TCAR_E_ARG;
   if (nsplit == 3 && (!A_lo || !B_lo)) return TCAR_E_ARG;
-  if ((lda & 7) || (ldb & 7) || !tcar_aligned16(A_hi) || !tcar_aligned16(B_hi)) return TCAR_E_ARG;
+  if ((a_inner & 31) || (b_inner & 31) || (K & 31) || !tcar_aligned16(A_hi) || !tcar_aligned16(B_hi)) return TCAR_E_ARG;
+  // the planes must cover what the tiles touch: a k-contiguous operand has inner >= K and rows >= its M/N extent,
+  // a transposed-read operand has inner >= its M/N extent and rows >= K
   const bool a_kc = (layout != 2), b_kc = (layout == 1);
-  if ((a_kc || b_kc) && (K & 7)) return TCAR_E_ARG;
+  if (a_kc ? (a_inner < K || a_rows < M) : (a_inner < M || a_rows < K)) return TCAR_E_ARG;
+  if (b_kc ? (b_inner < K || b_rows < N) : (b_inner < N || b_rows < K)) return TCAR_E_ARG;
   BArgs g;
   g.A[0] = (const __bf16*)A_hi; g.A[1] = (const __bf16*)A_lo; g.B[0] = (const __bf16*)B_hi; g.B[1] = (const __bf16*)B_lo;
-  g.lda = lda; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.a_in32 = (int)(a_inner >> 5); g.b_in32 = (int)(b_inner >> 5);
+  g.a_rb = (int)((a_rows + 127) >> 7); g.b_rb = (int)((b_rows + 127) >> 7);
+  g.C = C; g.ldc = ldc;
   g.C2 = C2 ? C2 : C; g.ldc2 = C2 ? ldc2 : ldc; g.csplit = C2 ? csplit : N;
   g.M = M; g.N = N; g.K = K;
   if (splitk < 1) splitk = 1;
@@ -262,22 +269,21 @@ extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi,
   g.kchunk = kchunk;
   splitk = (K + kchunk - 1) / kchunk;
   g.mode = splitk > 1 ? 1 : 0;
-  g.mt = (M + TB - 1) / TB; g.nt = (N + TB - 1) / TB;
   hipStream_t st = (hipStream_t)stream;
   if (layout == 0) return launch_b<0, 1>(g, nsplit, splitk, st);
   if (layout == 1) return launch_b<0, 0>(g, nsplit, splitk, st);
   return launch_b<1, 1>(g, nsplit, splitk, st);
 }
 
-extern "C" int tcar_split_bf16(const float* x, int64_t ld, int rows, int cols, void* hi, void* lo, int64_t ld16,
-                               void* packed_hi, void* packed_lo, int64_t packed_ld, int c0, int c1, void* stream) {
+extern "C" int tcar_split_bf16(const float* x, int64_t ld, int rows, int cols, void* hi, void* lo, int64_t inner,
+                               void* packed_hi, void* packed_lo, int64_t packed_inner, int c0, int c1, void* stream) {
   if (rows <= 0 || cols <= 0) return TCAR_OK;
-  if (!x || !hi || (ld16 & 3) || ld16 < cols || (c0 & 3) || (c1 & 3) || (packed_ld & 3)) return TCAR_E_ARG;
-  long total = (long)rows * (ld16 >> 2);
+  if (!x || !hi || (inner & 31) || inner < cols || (c0 & 3) || (c1 & 3) || (packed_hi && (packed_inner & 31))) return TCAR_E_ARG;
+  long total = (((long)rows + 127) & ~127L) * (inner >> 2);
   int blocks = (int)((total + 255) / 256);
   if (blocks > 4096) blocks = 4096;
   TCAR_LAUNCH(split_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)ld, rows, cols, (__bf16*)hi,
-              (__bf16*)lo, (long)ld16, (__bf16*)packed_hi, (__bf16*)packed_lo, (long)packed_ld, c0, c1);
+              (__bf16*)lo, (int)inner, (__bf16*)packed_hi, (__bf16*)packed_lo, (int)packed_inner, c0, c1);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

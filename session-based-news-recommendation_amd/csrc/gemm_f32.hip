@@ -232,6 +232,141 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// ----------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant of the grouped kernel for the SMALL contractions (projections, output transforms, their
+// gradients): same problems / segments / epilogues, fp32 operands in memory, but each staged tile is split on the fly
+// into bf16 hi / lo planes (x = hi + lo) and multiplied with three v_mfma_f32_32x32x16_bf16 per product
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate: ~1e-5 relative, see gemm_bf16.hip).  These GEMMs are latency bound: a
+// 64x64x832 tile takes 26 stages x 16 fp32 MFMAs x 64 cycles on one CU no matter how idle the chip is; the bf16 form
+// needs 6 MFMAs x 32 cycles per stage.  Tile 64 x 64 x 32, 4 waves, one 32x32 MFMA tile per wave.
+typedef __attribute__((ext_vector_type(8))) __bf16 xbf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 xbf16x4;
+constexpr int X3_KC = 80;      // bytes per row of a k-contiguous bf16 tile (64 + 16 pad: conflict-free b128)
+constexpr int X3_MC = 192;     // bytes per k-row of an m/n-contiguous bf16 tile (128 + 64 pad: conflict-free tr reads)
+constexpr int X3_PLANE = 6144; // >= 64*80 and 32*192
+
+template <int LAY>
+__device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict__ lo, int tid, const float4 (&reg)[2]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int f = tid + 256 * i;
+    const float v[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    xbf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
+    int off;
+    if (LAY == 0) { const int row = f >> 3, c4 = f & 7; off = row * X3_KC + c4 * 8; }
+    else { const int krow = f >> 4, c4 = f & 15; off = krow * X3_MC + c4 * 8; }
+    *reinterpret_cast<xbf16x4*>(hi + off) = h;
+    *reinterpret_cast<xbf16x4*>(lo + off) = l;
+  }
+}
+template <int LAY>
+__device__ __forceinline__ xbf16x8 x3_frag(const char* __restrict__ S, int base, int s, int lane) {
+  if (LAY == 0) {
+    return *reinterpret_cast<const xbf16x8*>(S + (base + (lane & 31)) * X3_KC + s * 32 + (lane >> 5) * 16);
+  } else {
+    const int g = lane >> 4, i = lane & 15;
+    const int mbase = 16 * (g & 1), kbase = 8 * (g >> 1), q = i >> 2, p = i & 3;
+    const char* a0 = S + (s * 16 + kbase + q) * X3_MC + (base + mbase + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) xbf16x4* lds_p;
+    const xbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0));
+    const xbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(a0 + 4 * X3_MC));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GroupArgs ga) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * X3_PLANE];     // 2 stages x (A hi, A lo, B hi, B lo)
+  constexpr int T = 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int pi = 0;
+#pragma unroll 1
+  for (int i = 1; i < ga.nprob; ++i)
+    if (id >= ga.p[i].wg_begin) pi = i;
+  const GemmProb& g = ga.p[pi];
+  id -= g.wg_begin;
+  const int tiles = g.mt * g.nt;
+  const int split = id / tiles;
+  id -= split * tiles;
+  int tm, tn;
+  if (g.mt <= g.nt) { tn = id / g.mt; tm = id - tn * g.mt; } else { tm = id / g.nt; tn = id - tm * g.nt; }
+  const int m0 = tm * T, n0 = tn * T;
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  float4 ra[2], rb[2];
+#pragma unroll 1
+  for (int sg = 0; sg < g.nseg; ++sg) {
+    const float* __restrict__ Ap = g.A[sg];
+    const float* __restrict__ Bp = g.B[sg];
+    const long lda = g.lda[sg], ldb = g.ldb[sg];
+    const int ks = split * g.kchunk;
+    const int ke = min(g.K[sg], ks + g.kchunk);
+    const int nit = (ke - ks + BK - 1) / BK;
+    const int a_rmax = (LA == 0) ? g.M : min((int)lda, (g.M + 3) & ~3);
+    const int b_rmax = (LB == 0) ? g.N : min((int)ldb, (g.N + 3) & ~3);
+    if (nit > 0) {
+      load_tile<LA, T>(Ap, lda, m0, a_rmax, ks, ke, tid, ra);
+      load_tile<LB, T>(Bp, ldb, n0, b_rmax, ks, ke, tid, rb);
+      __syncthreads();
+      x3_store<LA>(smem, smem + X3_PLANE, tid, ra);
+      x3_store<LB>(smem + 2 * X3_PLANE, smem + 3 * X3_PLANE, tid, rb);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+      const char* St = smem + (it & 1) * 4 * X3_PLANE;
+      const bool more = (it + 1 < nit);
+      if (more) {
+        load_tile<LA, T>(Ap, lda, m0, a_rmax, ks + (it + 1) * BK, ke, tid, ra);
+        load_tile<LB, T>(Bp, ldb, n0, b_rmax, ks + (it + 1) * BK, ke, tid, rb);
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const xbf16x8 ah = x3_frag<LA>(St, wm * 32, s, lane), al = x3_frag<LA>(St + X3_PLANE, wm * 32, s, lane);
+        const xbf16x8 bh = x3_frag<LB>(St + 2 * X3_PLANE, wn * 32, s, lane), bl = x3_frag<LB>(St + 3 * X3_PLANE, wn * 32, s, lane);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      }
+      if (more) {
+        char* Sn = smem + ((it + 1) & 1) * 4 * X3_PLANE;
+        x3_store<LA>(Sn, Sn + X3_PLANE, tid, ra);
+        x3_store<LB>(Sn + 2 * X3_PLANE, Sn + 3 * X3_PLANE, tid, rb);
+      }
+      __syncthreads();
+    }
+  }
+  float* Cs = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
+  const int col = n0 + wn * 32 + (lane & 31);
+  if (col < g.N) {
+    const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+      if (row < g.M) {
+        float* p = Cs + (long)row * g.ldc + col;
+        if (g.mode == 2) {
+          atomicAdd(p, acc[e]);
+        } else {
+          float v = acc[e] + bv;
+          if (g.act == 1) v = fmaxf(v, 0.f);
+          else if (g.act == 2) v = tanhf(v);
+          if (g.beta) v += *p;
+          *p = v;
+        }
+      }
+    }
+  }
+}
+
+
 namespace {
 
 template <int LA, int LB, int TM, int TN>
@@ -265,6 +400,21 @@ int launch_layout(GroupArgs& ga, hipStream_t st) {
   }
   if (T == 128) return launch_variant<LA, LB, 128, 128>(ga, wg, st);
   return launch_variant<LA, LB, 64, 64>(ga, wg, st);
+}
+
+template <int LA, int LB>
+int launch_x3(GroupArgs& ga, hipStream_t st) {
+  int wg = 0;
+  for (int i = 0; i < ga.nprob; ++i) {
+    GemmProb& p = ga.p[i];
+    p.mt = (p.M + 63) / 64;
+    p.nt = (p.N + 63) / 64;
+    p.wg_begin = wg;
+    wg += p.mt * p.nt * p.ksplit;
+  }
+  TCAR_LAUNCH((gemm_x3_kernel<LA, LB>), dim3(wg), dim3(256), 0, st, ga);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
 }
 
 int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {
@@ -310,6 +460,24 @@ extern "C" int tcar_gemm_f32_grouped(int layout, int nprob, const tcar_gemm_desc
   if (layout == 0) return launch_layout<0, 1>(ga, st);
   if (layout == 1) return launch_layout<0, 0>(ga, st);
   return launch_layout<1, 1>(ga, st);
+}
+
+extern "C" int tcar_gemm_x3_grouped(int layout, int nprob, const tcar_gemm_desc_t* descs, void* stream) {
+  if (nprob <= 0) return TCAR_OK;
+  if (layout < 0 || layout > 2 || nprob > MAXP || !descs) return TCAR_E_ARG;
+  GroupArgs ga;
+  ga.nprob = 0;
+  for (int i = 0; i < nprob; ++i) {
+    if (descs[i].M <= 0 || descs[i].N <= 0) continue;
+    const int rc = fill_prob(ga.p[ga.nprob], layout, descs[i]);
+    if (rc) return rc;
+    ga.nprob++;
+  }
+  if (ga.nprob == 0) return TCAR_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (layout == 0) return launch_x3<0, 1>(ga, st);
+  if (layout == 1) return launch_x3<0, 0>(ga, st);
+  return launch_x3<1, 1>(ga, st);
 }
 
 extern "C" int tcar_gemm_f32(int layout, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,

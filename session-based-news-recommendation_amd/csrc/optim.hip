@@ -8,6 +8,7 @@
 // on the summed gradient.  The clip norm of a variable is sqrt(use_dense*sqn_dense + sqn_pieces)
 // where the pieces are the IndexedSlices value blocks accumulated by the embedding backward kernels (S5).
 #include "tcar_common.h"
+#include "tcar_bf16_layout.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
@@ -106,8 +107,9 @@ __global__ __launch_bounds__(256) void clip_adam_2d_kernel(float* __restrict__ w
       bf16x4_t h, l;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { h[j] = (__bf16)wv[j]; l[j] = (__bf16)(wv[j] - (float)h[j]); }
-      *reinterpret_cast<bf16x4_t*>(eh + r * ld16 + c) = h;
-      *reinterpret_cast<bf16x4_t*>(el + r * ld16 + c) = l;
+      const long o = kb32_off(r, c, (int)(ld16 >> 5));          // KB32 blocked plane, inner dimension ld16
+      *reinterpret_cast<bf16x4_t*>(eh + o) = h;
+      *reinterpret_cast<bf16x4_t*>(el + o) = l;
     }
   }
 }
@@ -153,7 +155,7 @@ extern "C" int tcar_clip_adam_2d_bf16(float* w, int64_t ldw, const float* g, flo
                                       int32_t cols, int32_t slot, const float* sqn_dense, const float* sqn_pieces,
                                       const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
                                       void* e16_hi, void* e16_lo, int64_t ld16, void* stream) {
-  if (e16_hi && (!e16_lo || (ld16 & 3))) return TCAR_E_ARG;
+  if (e16_hi && (!e16_lo || (ld16 & 31))) return TCAR_E_ARG;
   if (!w || !g || !m || !v || rows <= 0 || cols <= 0 || (cols & 3) || (ldw & 3) || slot < 0 || slot >= TCAR_NSLOT)
     return TCAR_E_ARG;
   long total = rows * (cols >> 2);

@@ -6,6 +6,7 @@
 // All four are HBM/L2-bandwidth bound passes over [B, N] or gathered rows; they use 16-byte accesses with one
 // workgroup (or wave) per session and wave-shuffle reductions.
 #include "tcar_common.h"
+#include "tcar_bf16_layout.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_s;
 
@@ -35,11 +36,20 @@ __device__ __forceinline__ float block_max_256(float v, float* sh) {
 // softmax - onehot (the gradient of the SUM of the per-session losses, model_combine.py:147,156).
 // dh != NULL: the gradient is written as bf16 hi / lo planes [B, ld] (operands of gemm_bf16.hip) and the logits are
 // left untouched; otherwise it overwrites the logits in fp32.
-__global__ __launch_bounds__(256) void softmax_ce_kernel(int N, float* __restrict__ logits, long ld,
+__global__ __launch_bounds__(256) void softmax_ce_kernel(int B, int N, float* __restrict__ logits, long ld,
                                                          const int32_t* __restrict__ label, float* __restrict__ ce,
                                                          __bf16* __restrict__ dh, __bf16* __restrict__ dl) {
   __shared__ float sh[4];
   const int b = blockIdx.x, tid = threadIdx.x;
+  if (b >= B) {   // padding rows of the KB32 planes (grid covers ceil128(B) rows): zero, they are k-rows of dE
+    for (int i = tid; i < (int)(ld >> 2); i += 256) {
+      const long o = kb32_off(b, i * 4, (int)(ld >> 5));
+      bf16x4_s z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      *reinterpret_cast<bf16x4_s*>(dh + o) = z;
+      *reinterpret_cast<bf16x4_s*>(dl + o) = z;
+    }
+    return;
+  }
   float* row = logits + (long)b * ld;
   const int n4 = (N + 3) >> 2;
   float m = -INFINITY, s = 0.f;
@@ -75,8 +85,9 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int N, float* __restric
       bf16x4_s h, l;
 #pragma unroll
       for (int j = 0; j < 4; ++j) { h[j] = (__bf16)ov[j]; l[j] = (__bf16)(ov[j] - (float)h[j]); }
-      *reinterpret_cast<bf16x4_s*>(dh + (long)b * ld + c) = h;
-      *reinterpret_cast<bf16x4_s*>(dl + (long)b * ld + c) = l;
+      const long o = kb32_off(b, c, (int)(ld >> 5));            // KB32 blocked planes [ceil128(B), ld]
+      *reinterpret_cast<bf16x4_s*>(dh + o) = h;
+      *reinterpret_cast<bf16x4_s*>(dl + o) = l;
     } else {
       st4(row + c, o);
     }
@@ -241,8 +252,10 @@ extern "C" int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const in
 extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce,
                                     void* dl_hi, void* dl_lo, void* stream) {
   if (B <= 0) return TCAR_OK;
-  if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && !dl_lo)) return TCAR_E_ARG;
-  TCAR_LAUNCH(softmax_ce_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, ce,
+  if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && (!dl_lo || (ld & 31))))
+    return TCAR_E_ARG;
+  const int grid = dl_hi ? ((B + 127) & ~127) : B;
+  TCAR_LAUNCH(softmax_ce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, N, logits, (long)ld, label, ce,
               (__bf16*)dl_hi, (__bf16*)dl_lo);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;

@@ -15,7 +15,7 @@ namespace {
 struct Geo {
   int N, Npad, H, ldh, ldt, ic, pt, ct, ek;
   explicit Geo(const tcar_dims_t& d)
-      : N(d.n_items), Npad((d.n_items + 63) / 64 * 64), H(d.H), ldh(d.ldh), ldt(d.ldt), ic(2 * d.ldh), pt(5 * d.ldt),
+      : N(d.n_items), Npad((d.n_items + 127) / 128 * 128), H(d.H), ldh(d.ldh), ldt(d.ldt), ic(2 * d.ldh), pt(5 * d.ldt),
         ct(2 * d.ldt), ek(2 * d.ldh + 5 * d.ldt) {}
 };
 
@@ -53,6 +53,11 @@ void grads_of(const tcar_ctx_t* c, tcar_grads_t& g) {
   g.sqn = c->Gx + c->arena_n;
   g.slot_item = c->slot_item; g.slot_pos = c->slot_of[TCAR_V_POS]; g.slot_dur = c->slot_of[TCAR_V_DUR];
   g.rows_out = nullptr;
+}
+
+// the small contractions follow the scoring precision: exact fp32 MFMA in "f32" mode, split-bf16 otherwise
+inline int small_gemm(const tcar_ctx_t* c, int layout, int n, const tcar_gemm_desc_t* p, void* stream) {
+  return c->scoring ? tcar_gemm_x3_grouped(layout, n, p, stream) : tcar_gemm_f32_grouped(layout, n, p, stream);
 }
 
 inline hipStream_t aux_stream(const tcar_ctx_t* c) {
@@ -103,11 +108,11 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
     seg(p[1], c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt);
     seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
     p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
-    RET(tcar_gemm_f32_grouped(0, 3, p, stream));
+    RET(small_gemm(c, 0, 3, p, stream));
   }
   {  // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
-    RET(tcar_gemm_f32_grouped(0, 1, &p, stream));
+    RET(small_gemm(c, 0, 1, &p, stream));
   }
   RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
                          W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
@@ -116,7 +121,7 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
     p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->attout, g.ek, W(c, TCAR_V_O_B), 2);
     p[1] = prob1(B, g.pt, c->pooled + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->attout + g.ic, g.ek,
                  W(c, TCAR_V_OT_B), 2);
-    RET(tcar_gemm_f32_grouped(0, 2, p, stream));
+    RET(small_gemm(c, 0, 2, p, stream));
   }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138)
@@ -131,8 +136,8 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
     rc = tcar_split_bf16(c->attout, g.ek, B, g.ek, c->a16h, c->a16l, g.ek, c->ap16h, c->ap16l, g.ldh + g.pt, g.ldh, g.ic,
                          stream);
     if (!rc)
-      rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, c->e16h, c->e16l, g.ek, c->logits, g.Npad, nullptr, 0,
-                          0, c->scoring, 1, stream);
+      rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
+                          nullptr, 0, 0, c->scoring, 1, stream);
   } else {
     rc = tcar_gemm_f32(1, B, g.N, g.ek, c->attout, g.ek, c->E, g.ek, c->logits, g.Npad, nullptr, 0, 0, 1, stream);
   }
@@ -167,21 +172,21 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   }
   // ---- chain B
   if (c->scoring) {
-    RET(tcar_gemm_bf16(2, g.N, g.ldh + g.pt, B, c->dl16h, c->dl16l, g.Npad, c->ap16h, c->ap16l, g.ldh + g.pt, Gi, g.ldh,
-                       d_et, g.pt, g.ldh, c->scoring, 1, sB));
+    RET(tcar_gemm_bf16(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h, c->ap16l,
+                       g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, c->scoring, 1, sB));
   } else {  // dE = dlogits^T attout: item block and time block (content is frozen)
     tcar_gemm_desc_t p[2];
     p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
     p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
-    RET(tcar_gemm_f32_grouped(2, 2, p, sB));
+    RET(small_gemm(c, 2, 2, p, sB));
   }
   if (has_neg) RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, nullptr, nullptr, Gi, sB));
   if (fuse_finish) RET(finish_dense_side(c, g, sB));
   if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
   // ---- chain A
   if (c->scoring) {
-    RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, c->e16h, c->e16l, g.ek, c->slabs, g.ek, nullptr, 0,
-                       0, c->scoring, c->splitk, stream));
+    RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
+                       nullptr, 0, 0, c->scoring, c->splitk, stream));
   } else {
     RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
   }
@@ -197,7 +202,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     tcar_gemm_desc_t p[2];
     p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->dpooled, g.ek);
     p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->dpooled + g.ic, g.ek);
-    RET(tcar_gemm_f32_grouped(1, 2, p, stream));
+    RET(small_gemm(c, 1, 2, p, stream));
   }
   RET(tcar_attn_pool_bwd(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
                          W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
@@ -206,7 +211,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   RET(tcar_dact_colsum(B, g.ic, g.ic, c->q, c->dq, G(c, TCAR_V_Q2_B), 2, stream));
   {
     tcar_gemm_desc_t p = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
-    RET(tcar_gemm_f32_grouped(1, 1, &p, stream));
+    RET(small_gemm(c, 1, 1, &p, stream));
   }
   RET(tcar_dact_colsum(B, g.ldh, g.ldh, c->q1, c->dq1, G(c, TCAR_V_Q1_B), 1, stream));
   {  // input gradients (only the ITEM half of dX_ic: content is frozen)
@@ -215,7 +220,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
     p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
-    RET(tcar_gemm_f32_grouped(1, 4, p, stream));
+    RET(small_gemm(c, 1, 4, p, stream));
   }
   {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
     auto ks = [](int K) { int s = (K + 1023) / 1024; return s < 2 ? 2 : (s > 16 ? 16 : s); };
@@ -231,7 +236,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
     p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
     p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
-    RET(tcar_gemm_f32_grouped(2, 9, p, stream));
+    RET(small_gemm(c, 2, 9, p, stream));
   }
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[3], 0) != hipSuccess) return TCAR_E_LAUNCH;    // join
   if (fuse_finish) {

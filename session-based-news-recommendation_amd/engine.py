@@ -52,7 +52,7 @@ class Geometry:
             raise ValueError("unsupported hidden sizes for the gfx950 kernels: H<=512, Ht<=64 (5*ldt<=512)")
         self.ic, self.pt, self.ct = 2 * self.ldh, 5 * self.ldt, 2 * self.ldt
         self.ek = self.ic + self.pt
-        self.Npad = _ru(self.N, 64)
+        self.Npad = _ru(self.N, 128)        # KB32 planes are blocked in 128-row units
 
     def idx(self, kind: str) -> np.ndarray:
         """logical index -> padded index for a dimension of the given kind."""
@@ -285,9 +285,10 @@ class TcarEngine:
             self.slabs = torch.empty(self.splitk, B, g.ek, **f32)
             if self.scoring_code:
                 bf = dict(dtype=torch.bfloat16, device=self.dev)
-                self.a16h, self.a16l = torch.zeros(B, g.ek, **bf), torch.zeros(B, g.ek, **bf)
-                self.ap16h, self.ap16l = torch.zeros(B, g.ldh + g.pt, **bf), torch.zeros(B, g.ldh + g.pt, **bf)
-                self.dl16h, self.dl16l = torch.zeros(B, g.Npad, **bf), torch.zeros(B, g.Npad, **bf)
+                Bp = _ru(B, 128)
+                self.a16h, self.a16l = torch.zeros(Bp, g.ek, **bf), torch.zeros(Bp, g.ek, **bf)
+                self.ap16h, self.ap16l = torch.zeros(Bp, g.ldh + g.pt, **bf), torch.zeros(Bp, g.ldh + g.pt, **bf)
+                self.dl16h, self.dl16l = torch.zeros(Bp, g.Npad, **bf), torch.zeros(Bp, g.Npad, **bf)
             self.rank = torch.empty(B, dtype=torch.int32, device=self.dev)
             self.topk = torch.empty(B, 20, dtype=torch.int32, device=self.dev)
             self.work_B = B

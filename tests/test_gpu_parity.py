@@ -95,9 +95,11 @@ def test_gemm_epilogues_and_splitk(lib):
     close(out.cpu().numpy(), z - bias, name="splitk")
 
 
-def test_gemm_grouped_segments_and_atomic_splitk(lib):
+@pytest.mark.parametrize("entry", ["tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped"])
+def test_gemm_grouped_segments_and_atomic_splitk(lib, entry):
     """Grouped launch: a 3-segment K-concatenated problem + a biased/activated one (NN), and atomic split-K
-    weight-gradient problems (TN) into a zeroed C."""
+    weight-gradient problems (TN) into a zeroed C — for the fp32-MFMA kernel and its split-bf16 twin."""
+    grouped = getattr(lib, entry)
     from tcar_amd._lib import GemmDesc
     from tcar_amd.engine import TcarEngine
     rng = np.random.RandomState(9)
@@ -115,7 +117,7 @@ def test_gemm_grouped_segments_and_atomic_splitk(lib):
     descs = [D(M, 192, [(ptr(dx[i]), xs[i].shape[1], ptr(dw[i]), 192, xs[i].shape[1]) for i in range(3)], ptr(c1), 192),
              D(70, 64, [(ptr(dx2), 128, ptr(dw2), 64, 128)], ptr(c2), 64, bias=ptr(db2), act=2)]
     arr = (GemmDesc * 2)(*descs)
-    assert lib.tcar_gemm_f32_grouped(0, 2, arr, None) == 0
+    assert grouped(0, 2, arr, None) == 0
     close(c1.cpu().numpy(), sum(x.astype(np.float64) @ w.astype(np.float64) for x, w in zip(xs, ws)), name="3seg")
     close(c2.cpu().numpy(), np.tanh(x2.astype(np.float64) @ w2 + b2), name="bias-tanh")
     # TN, atomic split-K: dW = x^T dy with K = 5000 rows
@@ -128,9 +130,19 @@ def test_gemm_grouped_segments_and_atomic_splitk(lib):
     descs = [D(320, 256, [(ptr(xd), 320, ptr(dyd), 256, Kr)], ptr(g1), 256, splitk=5, atomic=1),
              D(64, 256, [(ptr(xd, 128), 320, ptr(dyd), 256, Kr)], ptr(g2), 256, splitk=2, atomic=1)]
     arr = (GemmDesc * 2)(*descs)
-    assert lib.tcar_gemm_f32_grouped(2, 2, arr, None) == 0
+    assert grouped(2, 2, arr, None) == 0
     close(g1.cpu().numpy(), x.astype(np.float64).T @ dy, name="atomic dW", atol_scale=5e-5)
     close(g2.cpu().numpy(), x[:, 128:192].astype(np.float64).T @ dy, name="atomic dW view", atol_scale=5e-5)
+    # NT (dx = dy W^T) with odd sizes
+    dyn = rng.standard_normal((77, 256)).astype(np.float32)
+    wn = rng.standard_normal((130, 256)).astype(np.float32)
+    dd, wd = torch.tensor(dyn).cuda(), torch.tensor(wn).cuda()
+    o = torch.full((77, 132), 3.0, device="cuda")
+    arr = (GemmDesc * 1)(D(77, 130, [(ptr(dd), 256, ptr(wd), 256, 256)], ptr(o), 132))
+    assert grouped(1, 1, arr, None) == 0
+    got = o.cpu().numpy()
+    close(got[:, :130], dyn.astype(np.float64) @ wn.astype(np.float64).T, name="NT")
+    assert (got[:, 130:] == 3.0).all()
 
 
 # -------------------------------------------------------------------------------------- standalone score ops
@@ -226,9 +238,15 @@ def test_step_matches_oracle(N, H, Ht, B, T, K, scoring):
         le = eng.train_step(batch)
         lo = ora.train_step(batch)
         close(le.cpu().numpy(), lo.numpy(), name="train loss")
+    # after Adam steps a coordinate whose gradient is at rounding level moves by ~lr with a rounding-determined sign
+    # (Adam normalises by sqrt(v)); the split-bf16 mode has ~1e-5 relative gradient noise instead of ~1e-7
     p_e, p_o = eng.export_params(), ora.export()
     for k in p_o:
-        close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-4)
+        if scoring == "f32":
+            close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-4)
+        else:   # gradients were compared at 1e-3 above; here allow a quarter of the distance Adam can travel (lr * steps)
+            d = np.abs(p_e[k] - p_o[k]).max()
+            assert d <= 1e-3 * np.abs(p_o[k]).max() + 0.25 * 1e-3 * 3, ("param " + k, d)
 
 
 def test_golden_fixture():
@@ -323,33 +341,75 @@ def test_dp_engine_single_rank_path_matches_oracle():
 
 
 # ----------------------------------------------------------------------------------------- split-bf16 GEMM
-def _planes(x):
-    t = torch.tensor(x).cuda()
-    hi = t.bfloat16()
-    lo = (t - hi.float()).bfloat16()
-    return hi.contiguous(), lo.contiguous()
+def ptr2(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _kb32_index(rows, inner):
+    """numpy restatement of csrc/tcar_bf16_layout.h: flat element offset of every (row, k)."""
+    r = np.arange(rows)[:, None]
+    k = np.arange(inner)[None, :]
+    blk = (r >> 7) * (inner // 32) + (k >> 5)
+    rr, kk = r & 127, k & 31
+    return blk * 4096 + rr * 32 + ((((kk >> 3) ^ ((rr >> 2) & 3)) << 3) | (kk & 7))
+
+
+def _planes(lib, x):
+    """fp32 [rows, cols] -> KB32 hi / lo planes through the product's own tcar_split_bf16; returns (hi, lo, inner, rows)."""
+    rows, cols = x.shape
+    inner = (cols + 31) // 32 * 32
+    rp = (rows + 127) // 128 * 128
+    xd = torch.tensor(np.ascontiguousarray(x)).cuda()
+    hi = torch.full((rp * inner,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lo = torch.full((rp * inner,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    assert lib.tcar_split_bf16(ptr(xd), cols, rows, cols, ptr2(hi), ptr2(lo), inner, None, None, 0, 0, 0, None) == 0
+    return hi, lo, inner, rows
+
+
+def test_split_bf16_planes_kb32_layout(lib):
+    rng = np.random.RandomState(1)
+    rows, cols = 137, 820
+    x = (rng.standard_normal((rows, cols)) * np.exp(rng.uniform(-8, 8, (rows, cols)))).astype(np.float32)
+    xd = torch.tensor(x).cuda()
+    inner, rp = 832, 256
+    hi = torch.full((rp * inner,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    lo = torch.full((rp * inner,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    phi = torch.full((rp * 576,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    plo = torch.full((rp * 576,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    assert lib.tcar_split_bf16(ptr(xd), cols, rows, cols, ptr2(hi), ptr2(lo), inner, ptr2(phi), ptr2(plo), 576, 256, 512,
+                               None) == 0
+    full = torch.zeros(rp, inner, device="cuda")
+    full[:rows, :cols] = xd
+    want_hi = full.bfloat16()
+    want_lo = (full - want_hi.float()).bfloat16()
+    idx = torch.tensor(_kb32_index(rp, inner), device="cuda")
+    assert torch.equal(hi[idx], want_hi) and torch.equal(lo[idx], want_lo)          # incl. zero-filled padding
+    pidx = torch.tensor(_kb32_index(rp, 576), device="cuda")
+    packed = torch.cat([want_hi[:, :256], want_hi[:, 512:832]], 1)
+    got = phi[pidx]
+    assert torch.equal(got[:rows, :256 + 308], packed[:rows, :256 + 308])
+    rec = hi[idx].double() + lo[idx].double()
+    assert ((rec - full.double()).abs() <= 2.0 ** -16 * full.double().abs() + 1e-40).all()
 
 
 @pytest.mark.parametrize("nsplit", [3, 1])
 @pytest.mark.parametrize("layout", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(512, 300, 832), (130, 129, 40), (64, 832, 2056), (257, 576, 512), (5, 7, 8)])
+@pytest.mark.parametrize("M,N,K", [(512, 300, 832), (130, 129, 64), (64, 832, 2080), (257, 576, 512), (5, 7, 32),
+                                   (600, 260, 96)])
 def test_gemm_bf16_layouts(lib, layout, nsplit, M, N, K):
-    """All three operand layouts (k-contiguous b128 fragments and ds_read_b64_tr_b16 transposed fragments) against
-    fp64; asymmetric random operands (a swapped row/col map cannot pass)."""
+    """All three operand layouts (swizzled b128 fragments and ds_read_b64_tr_b16 transposed fragments, staged by
+    direct-to-LDS DMA) against fp64; asymmetric random operands (a swapped row/col map cannot pass)."""
     rng = np.random.RandomState(M + 3 * N + 7 * K + layout)
-    ld8 = lambda x: (x + 7) // 8 * 8 + 8
-    a_shape = (M, ld8(K)) if layout != 2 else (K, ld8(M))
-    b_shape = (K, ld8(N)) if layout != 1 else (N, ld8(K))
-    A = rng.standard_normal(a_shape).astype(np.float32)
-    Bm = rng.standard_normal(b_shape).astype(np.float32) * 0.5 + 0.25
-    Al = A[:, :K] if layout != 2 else A[:, :M].T
-    Bl = Bm[:, :N] if layout != 1 else Bm[:, :K].T
+    A = rng.standard_normal((M, K) if layout != 2 else (K, M)).astype(np.float32)
+    Bm = (rng.standard_normal((K, N) if layout != 1 else (N, K)) * 0.5 + 0.25).astype(np.float32)
+    Al = A if layout != 2 else A.T
+    Bl = Bm if layout != 1 else Bm.T
     want = Al.astype(np.float64) @ Bl.astype(np.float64)
-    ah, al = _planes(A)
-    bh, bl = _planes(Bm)
+    ah, al, ai, ar = _planes(lib, A)
+    bh, bl, bi, br = _planes(lib, Bm)
     ldc = N + 4
     dC = torch.full((M, ldc), 7.0, device="cuda")
-    rc = lib.tcar_gemm_bf16(layout, M, N, K, ptr2(ah), ptr2(al), A.shape[1], ptr2(bh), ptr2(bl), Bm.shape[1], ptr(dC), ldc,
+    rc = lib.tcar_gemm_bf16(layout, M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(dC), ldc,
                             None, 0, 0, nsplit, 1, None)
     assert rc == 0
     got = dC.cpu().numpy()
@@ -357,59 +417,34 @@ def test_gemm_bf16_layouts(lib, layout, nsplit, M, N, K):
     assert (got[:, N:] == 7.0).all()
 
 
-def ptr2(t):
-    return C.c_void_p(t.data_ptr())
-
-
 def test_gemm_bf16_dual_output_and_splitk(lib):
     rng = np.random.RandomState(4)
     # TN with two destinations (dE: item block | time block)
     Kb, M, N = 96, 700, 576
-    dl = rng.standard_normal((Kb, 704)).astype(np.float32) * 0.1
-    at = rng.standard_normal((Kb, 576)).astype(np.float32)
-    want = dl[:, :M].astype(np.float64).T @ at.astype(np.float64)
-    ah, al = _planes(dl)
-    bh, bl = _planes(at)
+    dl = (rng.standard_normal((Kb, M)) * 0.1).astype(np.float32)
+    at = rng.standard_normal((Kb, N)).astype(np.float32)
+    want = dl.astype(np.float64).T @ at.astype(np.float64)
+    ah, al, ai, ar = _planes(lib, dl)
+    bh, bl, bi, br = _planes(lib, at)
     c1 = torch.zeros(M, 256, device="cuda")
     c2 = torch.zeros(M, 320, device="cuda")
-    assert lib.tcar_gemm_bf16(2, M, N, Kb, ptr2(ah), ptr2(al), 704, ptr2(bh), ptr2(bl), 576, ptr(c1), 256, ptr(c2), 320,
+    assert lib.tcar_gemm_bf16(2, M, N, Kb, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(c1), 256, ptr(c2), 320,
                               256, 3, 1, None) == 0
     close(c1.cpu().numpy(), want[:, :256], atol_scale=2e-5, name="dual C1")
     close(c2.cpu().numpy(), want[:, 256:], atol_scale=2e-5, name="dual C2")
     # NN with split-K slabs (dX: contraction over the catalog)
     M, N, K = 100, 832, 6400
-    a = rng.standard_normal((M, K)).astype(np.float32) * 0.05
+    a = (rng.standard_normal((M, K)) * 0.05).astype(np.float32)
     b = rng.standard_normal((K, N)).astype(np.float32)
-    ah, al = _planes(a)
-    bh, bl = _planes(b)
+    ah, al, ai, ar = _planes(lib, a)
+    bh, bl, bi, br = _planes(lib, b)
     S = lib.tcar_gemm_splitk_effective(K, 9)
     slabs = torch.empty(S, M, N, device="cuda")
     out = torch.empty(M, N, device="cuda")
-    assert lib.tcar_gemm_bf16(0, M, N, K, ptr2(ah), ptr2(al), K, ptr2(bh), ptr2(bl), N, ptr(slabs), N, None, 0, 0, 3, 9,
-                              None) == 0
+    assert lib.tcar_gemm_bf16(0, M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(slabs), N, None, 0, 0,
+                              3, 9, None) == 0
     assert lib.tcar_splitk_reduce(ptr(slabs), S, M, N, N, ptr(out), None) == 0
     close(out.cpu().numpy(), a.astype(np.float64) @ b.astype(np.float64), atol_scale=2e-5, name="splitk bf16")
-
-
-def test_split_bf16_planes(lib):
-    rng = np.random.RandomState(1)
-    x = (rng.standard_normal((37, 820)) * np.exp(rng.uniform(-8, 8, (37, 820)))).astype(np.float32)
-    xd = torch.zeros(37, 832, device="cuda")
-    xd[:, :820] = torch.tensor(x).cuda()
-    hi = torch.empty(37, 832, dtype=torch.bfloat16, device="cuda")
-    lo = torch.empty_like(hi)
-    phi = torch.empty(37, 576, dtype=torch.bfloat16, device="cuda")
-    plo = torch.empty_like(phi)
-    assert lib.tcar_split_bf16(ptr(xd), 832, 37, 832, ptr2(hi), ptr2(lo), 832, ptr2(phi), ptr2(plo), 576, 256, 512,
-                               None) == 0
-    t = xd
-    want_hi = t.bfloat16()
-    want_lo = (t - want_hi.float()).bfloat16()
-    assert torch.equal(hi, want_hi) and torch.equal(lo, want_lo)
-    assert torch.equal(phi[:, :256], want_hi[:, :256]) and torch.equal(phi[:, 256:], want_hi[:, 512:])
-    assert torch.equal(plo[:, 256:], want_lo[:, 512:])
-    rec = hi.double() + lo.double()
-    assert ((rec - t.double()).abs() <= 2.0 ** -16 * t.double().abs() + 1e-40).all()
 
 
 def test_plain_bf16_scoring_is_close_and_trains():
