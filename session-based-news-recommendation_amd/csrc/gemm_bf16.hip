@@ -38,7 +38,8 @@ struct BArgs {
   int a_rb, b_rb;              // allocated 128-row blocks of the A / B planes
   float* C; long ldc;
   float* C2; long ldc2; int csplit;     // columns >= csplit go to C2 (column index rebased); csplit >= N: unused
-  int M, N, K, kchunk, mode, mt, nt;
+  int M, N, K, kchunk, mode, mt, nt, nsk;
+  int n_fastest;               // tile order inside the XCD-contiguous id run: 1 = consecutive ids walk the N tiles
 };
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -79,13 +80,20 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNW, wn = wave - wm * WNW;
 
+  // 1-D grid over (split, tile): the bijective XCD remap hands each XCD a contiguous run of logical ids, and the
+  // tile order inside the run is chosen by the caller so that the workgroups which re-read the SAME large operand
+  // tile are neighbours on one XCD (one HBM/MALL fetch, the rest L2 hits): logits -> M fastest (share the E tile),
+  // dX (split-K) and dE -> N fastest (share the dlogits tile)
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tiles = g.mt * g.nt;
+  const int split = id / tiles;
+  id -= split * tiles;
   int tm, tn;
-  if (g.mt <= g.nt) { tn = id / g.mt; tm = id - tn * g.mt; } else { tm = id / g.nt; tn = id - tm * g.nt; }
+  if (g.n_fastest) { tm = id / g.nt; tn = id - tm * g.nt; } else { tn = id / g.mt; tm = id - tn * g.mt; }
   const int m0 = tm * TM, n0 = tn * TN;
-  const int ks = blockIdx.z * g.kchunk;
+  const int ks = split * g.kchunk;
   const int ke = min(g.K, ks + g.kchunk);
   const int nit = (ke - ks) / KB;
 
@@ -158,7 +166,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
     __syncthreads();
   }
 
-  float* C1 = g.C + (g.mode == 1 ? (long)blockIdx.z * g.M * g.ldc : 0L);
+  float* C1 = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -228,16 +236,24 @@ int launch_v(BArgs& g, int splitk, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW>), dim3(g.mt * g.nt, 1, splitk), dim3(NT), lds, st, g);
+  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
 
 template <int MA, int MB>
 int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
-  // 256 x 128 tiles (8 waves) once they give the chip at least ~3/4 of a full wave of workgroups; else 128 x 128
-  const long big = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
-  if (big >= 192) return nsplit == 3 ? launch_v<MA, MB, 3, 4, 2>(g, splitk, st) : launch_v<MA, MB, 1, 4, 2>(g, splitk, st);
+  // Tile choice.  The kernel is bound by the per-CU load path (~70 GB/s from L2): bytes per flop fall with the tile
+  // area/perimeter ratio, so take the largest tile that still gives the chip about a full wave of workgroups:
+  // 256 x 256 (16 waves, 64 KB per stage), then 256 x 128 (8 waves), else 128 x 128 (4 waves).
+  const char* force = getenv("TCAR_BF16_TILE");
+  const int f = force ? atoi(force) : 0;
+  const long w256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splitk;
+  const long w128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
+  if (f == 256 || (f == 0 && w256 >= 224))
+    return nsplit == 3 ? launch_v<MA, MB, 3, 4, 4>(g, splitk, st) : launch_v<MA, MB, 1, 4, 4>(g, splitk, st);
+  if (f == 128 || (f == 0 && w128 >= 192))
+    return nsplit == 3 ? launch_v<MA, MB, 3, 4, 2>(g, splitk, st) : launch_v<MA, MB, 1, 4, 2>(g, splitk, st);
   return nsplit == 3 ? launch_v<MA, MB, 3, 2, 2>(g, splitk, st) : launch_v<MA, MB, 1, 2, 2>(g, splitk, st);
 }
 
@@ -269,6 +285,8 @@ extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi,
   g.kchunk = kchunk;
   splitk = (K + kchunk - 1) / kchunk;
   g.mode = splitk > 1 ? 1 : 0;
+  g.nsk = splitk;
+  g.n_fastest = (layout != 1);        // layouts 0 / 2 stream dlogits tiles that several N tiles re-read
   hipStream_t st = (hipStream_t)stream;
   if (layout == 0) return launch_b<0, 1>(g, nsplit, splitk, st);
   if (layout == 1) return launch_b<0, 0>(g, nsplit, splitk, st);

@@ -241,26 +241,49 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // needs 6 MFMAs x 32 cycles per stage.  Tile 64 x 64 x 32, 4 waves, one 32x32 MFMA tile per wave.
 typedef __attribute__((ext_vector_type(8))) __bf16 xbf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 xbf16x4;
-constexpr int X3_KC = 80;      // bytes per row of a k-contiguous bf16 tile (64 + 16 pad: conflict-free b128)
-constexpr int X3_MC = 192;     // bytes per k-row of an m/n-contiguous bf16 tile (128 + 64 pad: conflict-free tr reads)
-constexpr int X3_PLANE = 6144; // >= 64*80 and 32*192
+// The K loop of these launches is a latency chain (one workgroup per tile, <= 1 workgroup per CU): with 32-deep stages
+// a K = 832 tile paid 26 dependent global-load round trips (~0.75 us each).  Stages are therefore 128 deep: a thread
+// prefetches the whole next 64 x 128 (+ 128 x 64) fp32 slab into registers while the current one is multiplied.
+constexpr int XK = 128;
+constexpr int X3_KC = 2 * XK + 16;   // bytes per row of a k-contiguous bf16 tile (272 = 68 dwords, 68/4 odd: conflict-free b128)
+constexpr int X3_MC = 192;           // bytes per k-row of an m/n-contiguous bf16 tile (128 + 64 pad: conflict-free tr reads)
+constexpr int X3_PLANE = XK * X3_MC; // 24576 >= 64 * X3_KC
+constexpr int X3_NV = 64 * XK / 4 / 256;   // float4 per thread, operand and stage (8)
 
 template <int LAY>
-__device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict__ lo, int tid, const float4 (&reg)[2]) {
+__device__ __forceinline__ void x3_load(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kend, int tid,
+                                        float4 (&reg)[X3_NV]) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < X3_NV; ++i) {
+    const int f = tid + 256 * i;
+    if (LAY == 0) {
+      const int row = f >> 5, c4 = f & 31;
+      const int gr = r0 + row, gk = k0 + c4 * 4;
+      reg[i] = (gr < rmax && gk < kend) ? ld4(P + (long)gr * ld + gk) : zero4();
+    } else {
+      const int krow = f >> 4, c4 = f & 15;
+      const int gk = k0 + krow, gr = r0 + c4 * 4;
+      reg[i] = (gk < kend && gr + 3 < rmax) ? ld4(P + (long)gk * ld + gr) : zero4();
+    }
+  }
+}
+template <int LAY>
+__device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict__ lo, int tid, const float4 (&reg)[X3_NV]) {
+#pragma unroll
+  for (int i = 0; i < X3_NV; ++i) {
     const int f = tid + 256 * i;
     const float v[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
     xbf16x4 h, l;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
     int off;
-    if (LAY == 0) { const int row = f >> 3, c4 = f & 7; off = row * X3_KC + c4 * 8; }
+    if (LAY == 0) { const int row = f >> 5, c4 = f & 31; off = row * X3_KC + c4 * 8; }
     else { const int krow = f >> 4, c4 = f & 15; off = krow * X3_MC + c4 * 8; }
     *reinterpret_cast<xbf16x4*>(hi + off) = h;
     *reinterpret_cast<xbf16x4*>(lo + off) = l;
   }
 }
+// fragment of the 32-row block at `base`, k16 sub-step s (0..7) of the 128-deep stage
 template <int LAY>
 __device__ __forceinline__ xbf16x8 x3_frag(const char* __restrict__ S, int base, int s, int lane) {
   if (LAY == 0) {
@@ -277,8 +300,9 @@ __device__ __forceinline__ xbf16x8 x3_frag(const char* __restrict__ S, int base,
 }
 
 template <int LA, int LB>
-__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GroupArgs ga) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 4 * X3_PLANE];     // 2 stages x (A hi, A lo, B hi, B lo)
+__global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) float smem_f[];
+  char* smem = reinterpret_cast<char*>(smem_f);     // A hi, A lo, B hi, B lo (one stage)
   constexpr int T = 64;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
@@ -301,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GroupArgs ga) {
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  float4 ra[2], rb[2];
+  float4 ra[X3_NV], rb[X3_NV];
 #pragma unroll 1
   for (int sg = 0; sg < g.nseg; ++sg) {
     const float* __restrict__ Ap = g.A[sg];
@@ -309,38 +333,31 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GroupArgs ga) {
     const long lda = g.lda[sg], ldb = g.ldb[sg];
     const int ks = split * g.kchunk;
     const int ke = min(g.K[sg], ks + g.kchunk);
-    const int nit = (ke - ks + BK - 1) / BK;
+    const int nit = (ke - ks + XK - 1) / XK;
     const int a_rmax = (LA == 0) ? g.M : min((int)lda, (g.M + 3) & ~3);
     const int b_rmax = (LB == 0) ? g.N : min((int)ldb, (g.N + 3) & ~3);
     if (nit > 0) {
-      load_tile<LA, T>(Ap, lda, m0, a_rmax, ks, ke, tid, ra);
-      load_tile<LB, T>(Bp, ldb, n0, b_rmax, ks, ke, tid, rb);
-      __syncthreads();
+      x3_load<LA>(Ap, lda, m0, a_rmax, ks, ke, tid, ra);
+      x3_load<LB>(Bp, ldb, n0, b_rmax, ks, ke, tid, rb);
+    }
+    for (int it = 0; it < nit; ++it) {
+      __syncthreads();                                        // everyone is done reading the previous stage
       x3_store<LA>(smem, smem + X3_PLANE, tid, ra);
       x3_store<LB>(smem + 2 * X3_PLANE, smem + 3 * X3_PLANE, tid, rb);
-    }
-    __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-      const char* St = smem + (it & 1) * 4 * X3_PLANE;
-      const bool more = (it + 1 < nit);
-      if (more) {
-        load_tile<LA, T>(Ap, lda, m0, a_rmax, ks + (it + 1) * BK, ke, tid, ra);
-        load_tile<LB, T>(Bp, ldb, n0, b_rmax, ks + (it + 1) * BK, ke, tid, rb);
+      __syncthreads();
+      if (it + 1 < nit) {                                     // next slab in flight during the MFMAs
+        x3_load<LA>(Ap, lda, m0, a_rmax, ks + (it + 1) * XK, ke, tid, ra);
+        x3_load<LB>(Bp, ldb, n0, b_rmax, ks + (it + 1) * XK, ke, tid, rb);
       }
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const xbf16x8 ah = x3_frag<LA>(St, wm * 32, s, lane), al = x3_frag<LA>(St + X3_PLANE, wm * 32, s, lane);
-        const xbf16x8 bh = x3_frag<LB>(St + 2 * X3_PLANE, wn * 32, s, lane), bl = x3_frag<LB>(St + 3 * X3_PLANE, wn * 32, s, lane);
+      const int nsub = min(XK, ke - (ks + it * XK) + 15) >> 4;      // k16 sub-steps that hold data
+#pragma unroll 2
+      for (int s = 0; s < nsub; ++s) {
+        const xbf16x8 ah = x3_frag<LA>(smem, wm * 32, s, lane), al = x3_frag<LA>(smem + X3_PLANE, wm * 32, s, lane);
+        const xbf16x8 bh = x3_frag<LB>(smem + 2 * X3_PLANE, wn * 32, s, lane), bl = x3_frag<LB>(smem + 3 * X3_PLANE, wn * 32, s, lane);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
       }
-      if (more) {
-        char* Sn = smem + ((it + 1) & 1) * 4 * X3_PLANE;
-        x3_store<LA>(Sn, Sn + X3_PLANE, tid, ra);
-        x3_store<LB>(Sn + 2 * X3_PLANE, Sn + 3 * X3_PLANE, tid, rb);
-      }
-      __syncthreads();
     }
   }
   float* Cs = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
@@ -365,7 +382,6 @@ __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(const GroupArgs ga) {
     }
   }
 }
-
 
 namespace {
 
@@ -412,7 +428,13 @@ int launch_x3(GroupArgs& ga, hipStream_t st) {
     p.wg_begin = wg;
     wg += p.mt * p.nt * p.ksplit;
   }
-  TCAR_LAUNCH((gemm_x3_kernel<LA, LB>), dim3(wg), dim3(256), 0, st, ga);
+  constexpr size_t lds = 4 * X3_PLANE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  TCAR_LAUNCH((gemm_x3_kernel<LA, LB>), dim3(wg), dim3(256), lds, st, ga);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

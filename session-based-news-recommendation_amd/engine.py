@@ -16,6 +16,7 @@ HBM layout (fp32, "padded-concat space", see include/tcar_hip.h):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -604,7 +605,7 @@ class TcarEngine:
         self._after_update()
 
     # ------------------------------------------------------------------------------ native (C++) step driver
-    overlap = True       # second HIP stream for the independent dE / candidate-time chains (C++ driver only)
+    overlap = os.environ.get("TCAR_NO_OVERLAP", "") == ""      # second HIP stream for the independent dE / candidate-time chains (C++ driver only)
     native = True        # drive the step from libtcar_hip.so (tcar_train_step / tcar_eval_step); False = Python
 
     def _ctx(self) -> "_lib.Ctx":
