@@ -178,8 +178,14 @@ def main():
             # also contains the [B,832] operand split kernel (~3 us)
             kname, peak, mult = "gemm_bf16_kernel<0,0,%s>" % ("3" if args.scoring == "bf16x3" else "1"), PEAK_BF16_DENSE_TFLOPS, \
                 (3 if args.scoring == "bf16x3" else 1)
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_logits_gemm.json")
+        if args.scoring == "bf16x3" and os.path.exists(pmc):
+            # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same kernel and
+            # shape (tools/gemm_bench.py fwd), gfx950 FETCH_SIZE x2 correction applied; see the file for the raw counters
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         roof = {"kernel": kname + " (full-catalog logits, model_combine.py:138)", "bound": "mfma",
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "flops_per_launch": flops["score_fwd"], "avg_ms": round(kern["score_fwd"][1], 5),
                 "mfma_executed_tflops": round(ach * mult, 2), "frac_executed": round(ach * mult / peak, 4)}
 
