@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--cpu_steps", type=int, default=20)
     ap.add_argument("--cpu_threads", type=int, default=16)
     ap.add_argument("--no_kernel_timing", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
+    ap.add_argument("--same_device", action="store_true", help="dry run: put every rank on cuda:0")
     ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
                     help="precision of the full-catalog scoring GEMMs (bf16x3 = split-bf16 planes, fp32-class accuracy)")
     args = ap.parse_args()
@@ -78,13 +80,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B, K = args.batch_size, args.neg_num
     # every rank builds the same catalog (seed 2020) and its own shard of sessions (weak scaling: B per GPU)
