@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--no_kernel_timing", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same_device", action="store_true", help="dry run: put every rank on cuda:0")
-    ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16"],
+    ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
                     help="precision of the full-catalog scoring GEMMs (bf16x3 = split-bf16 planes, fp32-class accuracy)")
     args = ap.parse_args()
 
@@ -183,11 +183,11 @@ def main():
         else:
             # bf16 matrix cores; bf16x3 issues 3 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi); the timed span
             # also contains the [B,832] operand split kernel (~3 us)
-            kname, peak, mult = "gemm_bf16_kernel<0,0,%s>" % ("3" if args.scoring == "bf16x3" else "1"), PEAK_BF16_DENSE_TFLOPS, \
-                (3 if args.scoring == "bf16x3" else 1)
+            x3 = args.scoring.startswith("bf16x3")
+            kname, peak, mult = "gemm_bf16_kernel<0,0,%s>" % ("3" if x3 else "1"), PEAK_BF16_DENSE_TFLOPS, (3 if x3 else 1)
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_pmc_logits_gemm.json")
-        if args.scoring == "bf16x3" and os.path.exists(pmc):
+        if args.scoring.startswith("bf16x3") and os.path.exists(pmc) and (N, B) == (46033, 512):
             # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same kernel and
             # shape (tools/gemm_bench.py fwd), gfx950 FETCH_SIZE x2 correction applied; see the file for the raw counters
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")

@@ -301,6 +301,7 @@ typedef struct {
    * 1 = plain bf16.  The bf16 modes need the planes below: e16* [Npad, ek] (kept in step with E by
    * tcar_clip_adam_2d_bf16 / tcar_cand_time_fwd_bf16), a16* [B, ek], ap16* [B, ldh+pt], dl16* [B, Npad]. */
   int32_t scoring;
+  int32_t scoring_bwd;   /* 0 = same as `scoring`; 1 = the two scoring GRADIENT GEMMs use the hi planes only (plain bf16) */
   void *e16h, *e16l, *a16h, *a16l, *ap16h, *ap16l, *dl16h, *dl16l;
   /* optional auxiliary stream + 4 events (hipStream_t / hipEvent_t, caller-created): the candidate-side time refresh
    * (forward) and the dE chain (backward) run on it concurrently with the session-side chain; NULL = one stream */

@@ -35,6 +35,11 @@ TensorFlow-1.x semantics restated here (each is a documented choice, DESIGN.md Â
       theta -= lr_t * m / (sqrt(v) + 1e-8).
   S7  dwell bucket id 11 (sampler.py:18-21 returns 11 for >=1024 s, table has
       11 rows model_combine.py:106): zero row, zero gradient (TF-GPU gather).
+  S8  the negative term -log(1 - sigmoid(x) + 1e-24) (model_combine.py:143) is
+      evaluated in the graph's fp32: for x >~ 16.6 sigmoid rounds to 1, the
+      term saturates at -log(1e-24) = 55.26 and its gradient is 0.  The rest
+      of this oracle is fp64; this one expression is rounded through fp32
+      because the saturation is observable (fp64 would give ~x instead).
 """
 from __future__ import annotations
 
@@ -123,7 +128,7 @@ class TcarOracle:
 
     def __init__(self, params: Dict[str, np.ndarray], content_emb: np.ndarray, mwdhm: np.ndarray,
                  lr: float = 1e-3, max_grad: Optional[float] = 150.0, dtype=torch.float64,
-                 neg_weight: float = 0.01, use_interval: bool = True):
+                 neg_weight: float = 0.01, use_interval: bool = True, neg_fp32: bool = True):
         self.dtype = dtype
         self.p = OrderedDict((k, torch.tensor(np.asarray(v), dtype=dtype, requires_grad=True))
                              for k, v in params.items())
@@ -133,6 +138,7 @@ class TcarOracle:
         self.H = self.content.shape[1]
         self.Ht = self.p["month_embedding"].shape[1]
         self.lr, self.max_grad, self.neg_weight = lr, max_grad, neg_weight
+        self.neg_fp32 = neg_fp32      # S8; False only for finite-difference checks of the analytic gradient
         self.use_interval = use_interval
         self.b1, self.b2, self.eps = 0.9, 0.999, 1e-8                               # tf.train.AdamOptimizer defaults
         self.m = OrderedDict((k, torch.zeros_like(v)) for k, v in self.p.items())
@@ -222,7 +228,8 @@ class TcarOracle:
             negi = torch.as_tensor(np.asarray(neg), dtype=torch.long)
             neg_rows = items_emb_cont[negi]                                            # [B,K,2H]  :142
             neg_logits = torch.bmm(neg_rows, attout_ic.unsqueeze(-1)).sum(1).reshape(B)
-            neg_fb = -torch.log(1 - torch.sigmoid(neg_logits) + 1e-24)                 # :143
+            xs = neg_logits.float() if self.neg_fp32 else neg_logits                   # S8
+            neg_fb = (-torch.log(1 - torch.sigmoid(xs) + 1e-24)).to(neg_logits.dtype)  # :143
             out["neg_logits"], out["neg_fb"] = neg_logits, neg_fb
             out["loss"] = ce + self.neg_weight * neg_fb                                # :147
         else:

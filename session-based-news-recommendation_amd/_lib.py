@@ -110,7 +110,7 @@ class Ctx(C.Structure):
                  ("use_dense", C.c_void_p), ("mwdhm", C.c_void_p), ("inv_n", C.c_void_p),
                  ("inv_off", C.c_void_p), ("ct_ws", C.c_void_p), ("segs_all", Segments), ("segs_dense", Segments)]
                 + [(n, C.c_void_p) for n in _WS]
-                + [("rank", C.c_void_p), ("topk", C.c_void_p), ("scoring", C.c_int32)]
+                + [("rank", C.c_void_p), ("topk", C.c_void_p), ("scoring", C.c_int32), ("scoring_bwd", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l")]
                 + [("stream2", C.c_void_p), ("ev", C.c_void_p * 4), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
                    ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p)])

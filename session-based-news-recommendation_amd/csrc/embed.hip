@@ -56,61 +56,87 @@ __global__ __launch_bounds__(256) void gather_clip_fwd_kernel(const EmbArgs a) {
   const int gpw = 64 / sub;          // time rows per wave instruction
   const int grp = lane / sub, lin = lane - grp * sub;
 
-  for (int row = wave_g; row < BT + B; row += nwaves) {
-    if (row < BT) {
-      const int t = row % T;
-      const int n = clampi(a.bt.seq[row], 1, a.d.n_items) - 1;
+  // Two session rows per wave and trip: all row loads of both rows (item, content, position; then the six small
+  // rows) are issued before the first reduction, doubling the bytes a wave keeps in flight (a row is ~3.5 KB).
+  constexpr int R = 2;
+  for (int row0 = wave_g; row0 < BT; row0 += R * nwaves) {
+    float4 xi[R][NCH], xc[R][NCH], xp[R][NCH];
+    bool live[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int row = row0 + u * nwaves;
+      live[u] = row < BT;
+      const int rw = live[u] ? row : row0;
+      const int t = rw % T;
+      const int n = clampi(a.bt.seq[rw], 1, a.d.n_items) - 1;
       const float* e = a.tab.E + (long)n * ek;
-      float4 xi[NCH], xc[NCH], xp[NCH];
-      float si = 0.f, sc = 0.f, sp = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int col = c * 256 + lane * 4;
         const bool ok = col < ldh;
-        xi[c] = ok ? ld4(e + col) : zero4();
-        xc[c] = ok ? ld4(e + ldh + col) : zero4();
-        xp[c] = ok ? ld4(a.tab.pos + (long)t * ldh + col) : zero4();
-        si += dot4(xi[c], xi[c]); sc += dot4(xc[c], xc[c]); sp += dot4(xp[c], xp[c]);
+        xi[u][c] = ok ? ld4(e + col) : zero4();
+        xc[u][c] = ok ? ld4(e + ldh + col) : zero4();
+        xp[u][c] = ok ? ld4(a.tab.pos + (long)t * ldh + col) : zero4();
       }
-      si = clip_scale(wave_sum(si)); sc = clip_scale(wave_sum(sc)); sp = clip_scale(wave_sum(sp));
-      float* o = a.x_icp + (long)row * ic;
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int row = row0 + u * nwaves;
+      float si = 0.f, sc = 0.f, sp = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        const int col = c * 256 + lane * 4;
-        if (col < ldh) {
-          st4(o + col, fma4(xi[c], si, scale4(xp[c], sp)));
-          st4(o + ldh + col, scale4(xc[c], sc));
+        si += dot4(xi[u][c], xi[u][c]); sc += dot4(xc[u][c], xc[u][c]); sp += dot4(xp[u][c], xp[u][c]);
+      }
+      si = clip_scale(wave_sum(si)); sc = clip_scale(wave_sum(sc)); sp = clip_scale(wave_sum(sp));
+      if (live[u]) {
+        float* o = a.x_icp + (long)row * ic;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          if (col < ldh) {
+            st4(o + col, fma4(xi[u][c], si, scale4(xp[u][c], sp)));
+            st4(o + ldh + col, scale4(xc[u][c], sc));
+          }
         }
       }
-      // five publish-time rows + the dwell row, `gpw` rows per pass
-      for (int k0 = 0; k0 < 6; k0 += gpw) {
-        const int k = k0 + grp;
-        const bool valid = k < 6;
-        const int kk = valid ? k : 0;
-        int id = (kk < 5) ? pick5(a.bt.pub, kk)[row] : a.bt.gap[row];
+    }
+    // five publish-time rows + the dwell row of both session rows, `gpw` small rows per pass
+    for (int k0 = 0; k0 < 6; k0 += gpw) {
+      const int k = k0 + grp;
+      const bool valid = k < 6;
+      const int kk = valid ? k : 0;
+      const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
+      float4 x[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int rw = live[u] ? row0 + u * nwaves : row0;
+        int id = (kk < 5) ? pick5(a.bt.pub, kk)[rw] : a.bt.gap[rw];
         const bool oob = (kk == 5) && (id >= TCAR_DUR_VOCAB || id < 0);   // dwell bucket 11 -> zero row (S7)
         id = clampi(id, 0, time_vocab(kk) - 1);
-        const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
-        float4 x = (valid && !oob) ? ld4(tp + (long)id * ldt + lin * 4) : zero4();
-        const float s = clip_scale(group_sum(dot4(x, x), sub));
-        if (valid) {
+        x[u] = (valid && !oob) ? ld4(tp + (long)id * ldt + lin * 4) : zero4();
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int row = row0 + u * nwaves;
+        const float sx = clip_scale(group_sum(dot4(x[u], x[u]), sub));
+        if (valid && live[u]) {
           float* dst = (kk < 5) ? a.x_pt + (long)row * pt + kk * ldt : a.x_act + (long)row * ldt;
-          st4(dst + lin * 4, scale4(x, s));
+          st4(dst + lin * 4, scale4(x[u], sx));
         }
       }
-    } else {
-      // click-time query rows: week table by cw, hour table by ch (model_combine.py:94-97)
-      const int b = row - BT;
-      for (int k0 = 0; k0 < 2; k0 += gpw) {
-        const int j = k0 + grp;
-        const bool valid = j < 2;
-        const int jj = valid ? j : 0;
-        const int kk = jj == 0 ? 2 : 3;
-        const int id = clampi(jj == 0 ? a.bt.cw[b] : a.bt.ch[b], 0, time_vocab(kk) - 1);
-        float4 x = valid ? ld4(pick5(a.tab.time, kk) + (long)id * ldt + lin * 4) : zero4();
-        const float s = clip_scale(group_sum(dot4(x, x), sub));
-        if (valid) st4(a.click_t + (long)b * ct + jj * ldt + lin * 4, scale4(x, s));
-      }
+    }
+  }
+  // click-time query rows: week table by cw, hour table by ch (model_combine.py:94-97)
+  for (int b = wave_g; b < B; b += nwaves) {
+    for (int k0 = 0; k0 < 2; k0 += gpw) {
+      const int j = k0 + grp;
+      const bool valid = j < 2;
+      const int jj = valid ? j : 0;
+      const int kk = jj == 0 ? 2 : 3;
+      const int id = clampi(jj == 0 ? a.bt.cw[b] : a.bt.ch[b], 0, time_vocab(kk) - 1);
+      float4 x = valid ? ld4(pick5(a.tab.time, kk) + (long)id * ldt + lin * 4) : zero4();
+      const float sx = clip_scale(group_sum(dot4(x, x), sub));
+      if (valid) st4(a.click_t + (long)b * ct + jj * ldt + lin * 4, scale4(x, sx));
     }
   }
 }
@@ -482,7 +508,7 @@ int check_dims(const tcar_dims_t* d) {
 int grid_for_rows(long rows) {
   long g = (rows + 3) / 4;
   if (g < 1) g = 1;
-  if (g > 1024) g = 1024;
+  if (g > 2048) g = 2048;          // 8 workgroups x 4 waves per CU: 32 waves/CU, each with a ~3.5 KB row in flight
   return (int)g;
 }
 

@@ -164,6 +164,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
   const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
+  // backward precision: scoring_bwd (1 = hi planes only) or the forward precision
+  const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   if (s2) {
@@ -173,7 +175,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // ---- chain B
   if (c->scoring) {
     RET(tcar_gemm_bf16(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h, c->ap16l,
-                       g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, c->scoring, 1, sB));
+                       g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, nsb, 1, sB));
   } else {  // dE = dlogits^T attout: item block and time block (content is frozen)
     tcar_gemm_desc_t p[2];
     p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
@@ -186,7 +188,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // ---- chain A
   if (c->scoring) {
     RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
-                       nullptr, 0, 0, c->scoring, c->splitk, stream));
+                       nullptr, 0, 0, nsb, c->splitk, stream));
   } else {
     RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
   }

@@ -117,10 +117,12 @@ class TcarEngine:
         self.splitk = splitk
         # precision of the three full-catalog scoring GEMMs: "f32" (fp32 MFMA), "bf16x3" (split-bf16 planes, three
         # bf16 MFMAs per product, fp32-class accuracy), "bf16" (hi plane only)
-        if scoring not in ("f32", "bf16x3", "bf16"):
-            raise ValueError("scoring must be f32 | bf16x3 | bf16")
+        # "bf16x3-mixed": logits in bf16x3 (fp32-class), the two gradient GEMMs in plain bf16 (mixed-precision backward)
+        if scoring not in ("f32", "bf16x3", "bf16x3-mixed", "bf16"):
+            raise ValueError("scoring must be f32 | bf16x3 | bf16x3-mixed | bf16")
         self.scoring = scoring
-        self.scoring_code = {"f32": 0, "bf16": 1, "bf16x3": 3}[scoring]
+        self.scoring_code = {"f32": 0, "bf16": 1, "bf16x3": 3, "bf16x3-mixed": 3}[scoring]
+        self.scoring_bwd = 1 if scoring == "bf16x3-mixed" else 0
         f32 = dict(dtype=torch.float32, device=self.dev)
         # arena layout ------------------------------------------------------------------------------------
         self.seg = OrderedDict()
@@ -632,6 +634,7 @@ class TcarEngine:
         for n in _lib._WS:
             setattr(c, n, getattr(self, n).data_ptr())
         c.scoring = self.scoring_code
+        c.scoring_bwd = self.scoring_bwd
         if self.scoring_code:
             for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l"):
                 setattr(c, n, getattr(self, n).data_ptr())

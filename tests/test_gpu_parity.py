@@ -466,3 +466,29 @@ def test_plain_bf16_scoring_is_close_and_trains():
     for _ in range(5):
         l1 = float(eng.train_step(batch).sum())
     assert l1 < l0
+
+
+def test_mixed_precision_backward_mode():
+    """scoring='bf16x3-mixed': logits / loss hold the fp32-class gate (forward is bf16x3); the scoring gradients are
+    plain bf16 (norm-wise 1e-2), the loss still decreases."""
+    _need_gpu()
+    from oracle.tcar_oracle import TcarOracle
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 1000, 250, 64, 64, 4, 20
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=78)
+    eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+    ora = TcarOracle(params, content, mw)
+    rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
+    o_logits, o_ce = ora.eval_batch(batch)
+    close(logits.cpu().numpy(), o_logits.numpy(), name="logits mixed")
+    loss = eng.loss_and_grads(batch)
+    o, g_o, _ = ora.loss_and_grads(batch)
+    close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss mixed")
+    g_e = eng.export_grads()
+    for k in ("item_emb", "attout_item_cont_trans/w1", "hour_embedding"):
+        rel = np.linalg.norm(g_e[k] - g_o[k].numpy()) / max(np.linalg.norm(g_o[k].numpy()), 1e-30)
+        assert rel < 1e-2, (k, rel)
+    l0 = float(eng.train_step(batch).sum())
+    for _ in range(5):
+        l1 = float(eng.train_step(batch).sum())
+    assert l1 < l0

@@ -34,7 +34,7 @@ def test_oracle_reproduces_golden_fixture():
 
 def test_finite_difference_gradients():
     z, params, batch = load_fixture()
-    ora = TcarOracle(params, z["content"], z["mwdhm"])
+    ora = TcarOracle(params, z["content"], z["mwdhm"], neg_fp32=False)   # FD needs the smooth fp64 term
     _, grads, _ = ora.loss_and_grads(batch)
     rng = np.random.RandomState(0)
 
@@ -135,3 +135,13 @@ def test_edge_shapes_run():
         assert loss.shape == (B,) and torch.isfinite(loss).all()
     with pytest.raises(IndexError):
         ora.forward({**b, "seq": rng.randint(1, fold_n + 1, (1, 41)), "pm": np.ones((1, 41), int)})
+
+
+def test_negative_term_saturates_like_fp32_graph():
+    """S8: model_combine.py:143 in fp32 — a large summed negative logit gives -log(1e-24) and zero gradient."""
+    import torch
+    x = torch.tensor([30.0, 0.0], dtype=torch.float64, requires_grad=True)
+    y = (-torch.log(1 - torch.sigmoid(x.float()) + 1e-24)).to(x.dtype)
+    y.sum().backward()
+    assert abs(float(y[0]) - 55.262) < 1e-2 and float(x.grad[0]) == 0.0
+    assert abs(float(y[1]) - np.log(2)) < 1e-6 and abs(float(x.grad[1]) - 0.5) < 1e-6
