@@ -141,7 +141,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    last_loss = float((eng.ce[:B] + eng.neg_weight * eng.neg_fb[:B]).mean())
+    last_loss = float(eng.loss[:B].mean())
     value = B * world * args.steps / dt
 
     kern = {}

@@ -213,10 +213,11 @@ int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t*
 /* tcar_neg_term: neg_logits / neg_feedback of model_combine.py:142-143 and their gradients.
  * neg_fb[b] = -log(1 - sigmoid(x_b) + 1e-24), x_b = sum_k E[neg[b,k], 0:ic] . attout[b, 0:ic].
  * Adds weight * d neg_fb into dattout[b, 0:ic] (plain adds: one workgroup owns a row) and into g_item (atomics);
- * neg_fb, dattout and g_item may each be NULL to skip that output. */
+ * neg_fb, dattout and g_item may each be NULL to skip that output.  With loss != NULL it also writes the per-session
+ * training loss of model_combine.py:147, loss[b] = ce[b] + weight * neg_fb[b] (ce: the softmax cross entropy). */
 int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg,
                   const float* attout, float weight, float* neg_fb, float* dattout, float* g_item,
-                  void* stream);
+                  const float* ce, float* loss, void* stream);
 
 /* tcar_dact_colsum: dz = dy * act'(y) in place over dy ([M, ncol], ld) and bias_grad[c] += sum_m dz[m,c]
  * (gradient of linear_2d's bias + activation, modules.py:52-54; fp32 atomics into a caller-zeroed bias_grad).
@@ -294,7 +295,7 @@ typedef struct {
   const int32_t* inv_n; const int32_t* inv_off; float* ct_ws;   /* inverted index of mwdhm + its workspace */
   tcar_segments_t segs_all, segs_dense;
   /* workspace (sized by the caller for the largest B and B*T it will submit) */
-  float *x_icp, *x_pt, *x_act, *click_t, *pre1, *pre2, *q1, *q, *alpha, *pooled, *attout, *logits, *ce, *neg_fb;
+  float *x_icp, *x_pt, *x_act, *click_t, *pre1, *pre2, *q1, *q, *alpha, *pooled, *attout, *logits, *ce, *neg_fb, *loss;
   float *dattout, *dpooled, *dq, *dq1, *dclick, *slabs, *dx_icp, *dx_pt, *dx_act, *dpre1, *dpre2;
   int32_t* rank; int32_t* topk;
   /* scoring precision: 0 = fp32 MFMA, 3 = split-bf16 (hi/lo planes, 3 MFMAs per product, fp32-class accuracy),

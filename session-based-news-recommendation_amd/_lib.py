@@ -96,7 +96,7 @@ class GemmDesc(C.Structure):
 
 
 _WS = ["x_icp", "x_pt", "x_act", "click_t", "pre1", "pre2", "q1", "q", "alpha", "pooled", "attout", "logits", "ce",
-       "neg_fb", "dattout", "dpooled", "dq", "dq1", "dclick", "slabs", "dx_icp", "dx_pt", "dx_act", "dpre1", "dpre2"]
+       "neg_fb", "loss", "dattout", "dpooled", "dq", "dq1", "dclick", "slabs", "dx_icp", "dx_pt", "dx_act", "dpre1", "dpre2"]
 
 
 class Ctx(C.Structure):
@@ -159,7 +159,7 @@ def load() -> C.CDLL:
     lib.tcar_attn_pool_fwd.argtypes = [P(Dims), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tcar_attn_pool_bwd.argtypes = [P(Dims), i32, i32] + [vp] * 17
     lib.tcar_softmax_ce.argtypes = [i32, i32, vp, i64, vp, vp, vp]
-    lib.tcar_neg_term.argtypes = [P(Dims), i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]
+    lib.tcar_neg_term.argtypes = [P(Dims), i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.tcar_dact_colsum.argtypes = [i32, i32, i64, vp, vp, vp, i32, vp]
     lib.tcar_rank_topk.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp, vp]
     lib.tcar_sqnorm.argtypes = [vp, P(Segments), vp, vp]

@@ -74,8 +74,9 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
   constexpr int PL = A_BYTES + B_BYTES;                     // LDS stage = [plane][A | B]
   constexpr int STAGE = NP * PL;
   constexpr int A_CP = A_BYTES / 1024, B_CP = B_BYTES / 1024;   // 1-KB wave copies per plane
-  constexpr int CPW = NP * (A_CP + B_CP) / NW;              // copies per wave and stage
-  static_assert(NP * (A_CP + B_CP) % NW == 0, "copies must divide evenly over the waves");
+  constexpr int NCOPY = NP * (A_CP + B_CP);
+  constexpr int CPW = (NCOPY + NW - 1) / NW;                // copies per wave and stage (the last round may be partial)
+  static_assert((MA == 1 || TM % 128 == 0) && (MB == 1 || TN % 128 == 0), "k-contiguous operand tiles are whole 128-row blocks");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNW, wn = wave - wm * WNW;
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
     char* St = smem + (t & 1) * STAGE;
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
-      const int c = wave + NW * i;                     // copy index in [0, NP*(A_CP+B_CP))   (wave-uniform)
+      const int c = wave + NW * i;                     // copy index in [0, NCOPY)   (wave-uniform)
+      if (NCOPY % NW != 0 && c >= NCOPY) break;
       const int p = c / (A_CP + B_CP), rem = c - p * (A_CP + B_CP);
       const bool isA = rem < A_CP;
       const int ci = isA ? rem : rem - A_CP;
@@ -250,6 +252,13 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
   const int f = force ? atoi(force) : 0;
   const long w256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splitk;
   const long w128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
+  if constexpr (MB == 1) {
+    // 256 x 192 (12 waves): an N extent such as 576 = 3 x 192 wastes no MFMA work on padding columns (256-wide tiles
+    // would run a third, three-quarters-empty tile column)
+    const int n192 = (g.N + 191) / 192 * 192, n256 = (g.N + 255) / 256 * 256;
+    if (f == 192 || (f == 0 && w256 >= 224 && n192 < n256))
+      return nsplit == 3 ? launch_v<MA, MB, 3, 4, 3>(g, splitk, st) : launch_v<MA, MB, 1, 4, 3>(g, splitk, st);
+  }
   if (f == 256 || (f == 0 && w256 >= 224))
     return nsplit == 3 ? launch_v<MA, MB, 3, 4, 4>(g, splitk, st) : launch_v<MA, MB, 1, 4, 4>(g, splitk, st);
   if (f == 128 || (f == 0 && w128 >= 192))

@@ -176,4 +176,4 @@ extern "C" int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m
                                 eps, nullptr, nullptr, 0, stream);
 }
 
-extern "C" int tcar_abi_version(void) { return 1; }
+extern "C" int tcar_abi_version(void) { return 2; }

@@ -7,6 +7,7 @@
 // workgroup (or wave) per session and wave-shuffle reductions.
 #include "tcar_common.h"
 #include "tcar_bf16_layout.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_s;
 
@@ -94,6 +95,85 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int B, int N, float* __
   }
 }
 
+// Row-resident variant: the whole logits row lives in registers between the two passes (NT threads x R float4, all
+// loads issued up front), so the row is read from memory ONCE: 1 read + 1 write of [B, N] instead of 2 reads + 1 write,
+// and one exp per element (the pass-1 exponentials are kept and rescaled by 1 / sum).
+template <int NT, int R>
+__global__ __launch_bounds__(NT) void softmax_ce_rows_kernel(int B, int N, float* __restrict__ logits, long ld,
+                                                              const int32_t* __restrict__ label, float* __restrict__ ce,
+                                                              __bf16* __restrict__ dh, __bf16* __restrict__ dl) {
+  __shared__ float sh[NT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (b >= B) {   // padding rows of the KB32 planes
+    for (int i = tid; i < (int)(ld >> 2); i += NT) {
+      const long o = kb32_off(b, i * 4, (int)(ld >> 5));
+      bf16x4_s z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      *reinterpret_cast<bf16x4_s*>(dh + o) = z;
+      *reinterpret_cast<bf16x4_s*>(dl + o) = z;
+    }
+    return;
+  }
+  float* row = logits + (long)b * ld;
+  float4 v[R];
+  const float ninf = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int c = (tid + r * NT) * 4;
+    v[r] = (c < (int)ld) ? ld4(row + c) : make_float4(ninf, ninf, ninf, ninf);
+  }
+  float m = ninf;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int c = (tid + r * NT) * 4;
+    if (c + 0 >= N) v[r].x = ninf;
+    if (c + 1 >= N) v[r].y = ninf;
+    if (c + 2 >= N) v[r].z = ninf;
+    if (c + 3 >= N) v[r].w = ninf;
+    m = fmaxf(m, fmaxf(fmaxf(v[r].x, v[r].y), fmaxf(v[r].z, v[r].w)));
+  }
+  m = wave_max(m);
+  if (lane == 0) sh[w] = m;
+  __syncthreads();
+  float gm = sh[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) gm = fmaxf(gm, sh[i]);
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    v[r].x = expf(v[r].x - gm); v[r].y = expf(v[r].y - gm); v[r].z = expf(v[r].z - gm); v[r].w = expf(v[r].w - gm);
+    s += (v[r].x + v[r].y) + (v[r].z + v[r].w);
+  }
+  s = wave_sum(s);
+  if (lane == 0) sh[w] = s;
+  __syncthreads();
+  float gs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NT / 64; ++i) gs += sh[i];
+  const float lse = gm + logf(gs), inv = 1.0f / gs;
+  const int lab = clampi(label[b], 0, N - 1);
+  if (tid == 0) ce[b] = lse - row[lab];
+  __syncthreads();                       // the label logit is read before the row is overwritten (fp32 mode)
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int c = (tid + r * NT) * 4;
+    if (c >= (int)ld) continue;
+    float ov[4] = {v[r].x * inv, v[r].y * inv, v[r].z * inv, v[r].w * inv};     // masked columns hold exp(-inf) = 0
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ov[j] -= (c + j == lab) ? 1.f : 0.f;
+    if (dh) {
+      bf16x4_s h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { h[j] = (__bf16)ov[j]; l[j] = (__bf16)(ov[j] - (float)h[j]); }
+      const long o = kb32_off(b, c, (int)(ld >> 5));
+      *reinterpret_cast<bf16x4_s*>(dh + o) = h;
+      *reinterpret_cast<bf16x4_s*>(dl + o) = l;
+    } else {
+      st4(row + c, make_float4(ov[0], ov[1], ov[2], ov[3]));
+    }
+  }
+}
+
 // ---- negative-feedback term (model_combine.py:142-143) ---------------------------------------------------
 // One wave per session: gathers K item|content rows of E (2 x 16 B per lane per row), dots them with attout_ic.
 template <int NCH>
@@ -101,7 +181,8 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
                                                        const float* __restrict__ E, const int32_t* __restrict__ neg,
                                                        const float* __restrict__ attout, float weight,
                                                        float* __restrict__ neg_fb, float* __restrict__ dattout,
-                                                       float* __restrict__ g_item) {
+                                                       float* __restrict__ g_item, const float* __restrict__ ce,
+                                                       float* __restrict__ loss) {
   // one WORKGROUP per session: the 4 waves split the K negatives (independent row gathers in flight), partial
   // dot / row sums meet in LDS, every wave then scatters its own negatives' gradient rows
   __shared__ __attribute__((aligned(16))) float part[4 * 2 * 512];   // [wave][item|content sums]
@@ -119,18 +200,30 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
     sa[c] = zero4(); sb[c] = zero4();
   }
   float x = 0.f;
-  for (int k = w; k < K; k += 4) {
-    const int n = clampi(neg[(long)b * K + k], 0, n_items - 1);
-    const float* e = E + (long)n * ek;
+  constexpr int U = 4;                  // rows in flight per wave: all loads of a group are issued before the first use
+  for (int kb = w; kb < K; kb += 4 * U) {
+    float4 ra[U][NCH], rb[U][NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (col < ldh) {
-        const float4 ra = ld4(e + col), rb = ld4(e + ldh + col);
-        x += dot4(ra, ua[c]) + dot4(rb, ub[c]);
-        sa[c] = add4(sa[c], ra); sb[c] = add4(sb[c], rb);
+    for (int u = 0; u < U; ++u) {
+      const int k = kb + 4 * u;
+      const bool live = k < K;
+      const int n = live ? clampi(neg[(long)b * K + k], 0, n_items - 1) : 0;
+      const float* e = E + (long)n * ek;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = live && col < ldh;
+        ra[u][c] = ok ? ld4(e + col) : zero4();
+        rb[u][c] = ok ? ld4(e + ldh + col) : zero4();
       }
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        x += dot4(ra[u][c], ua[c]) + dot4(rb[u][c], ub[c]);
+        sa[c] = add4(sa[c], ra[u][c]); sb[c] = add4(sb[c], rb[u][c]);
+      }
   }
   x = wave_sum(x);
   if (lane == 0) px[w] = x;
@@ -143,7 +236,9 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
   x = px[0] + px[1] + px[2] + px[3];                   // sum over K BEFORE the sigmoid (model_combine.py:142)
   const float sg = 1.0f / (1.0f + expf(-x));
   const float om = 1.0f - sg;
-  if (tid == 0 && neg_fb) neg_fb[b] = -logf(om + 1e-24f);
+  const float fb = -logf(om + 1e-24f);
+  if (tid == 0 && neg_fb) neg_fb[b] = fb;
+  if (tid == 0 && loss) loss[b] = ce[b] + weight * fb;          // model_combine.py:147
   const float coef = weight * sg * om / (om + 1e-24f);  // weight * d/dx[-log(1 - sigmoid(x) + 1e-24)]
   if (dattout) {
     for (int col = tid * 4; col < ic; col += 1024) {
@@ -255,6 +350,23 @@ extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, con
   if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && (!dl_lo || (ld & 31))))
     return TCAR_E_ARG;
   const int grid = dl_hi ? ((B + 127) & ~127) : B;
+  static const int variant = getenv("TCAR_SOFTMAX_VARIANT") ? atoi(getenv("TCAR_SOFTMAX_VARIANT")) : 1;
+  if (variant == 2 && ld <= 1024L * 4 * 12) {
+    TCAR_LAUNCH((softmax_ce_rows_kernel<1024, 12>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, B, N, logits, (long)ld,
+                label, ce, (__bf16*)dl_hi, (__bf16*)dl_lo);
+    TCAR_CHECK_LAUNCH();
+    return TCAR_OK;
+  }
+  if (variant && ld <= 512L * 4 * 24) {      // the row fits the register-resident variant (catalogs up to 49,152 items)
+    if (ld <= 512L * 4 * 8)
+      TCAR_LAUNCH((softmax_ce_rows_kernel<512, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, B, N, logits, (long)ld,
+                  label, ce, (__bf16*)dl_hi, (__bf16*)dl_lo);
+    else
+      TCAR_LAUNCH((softmax_ce_rows_kernel<512, 24>), dim3(grid), dim3(512), 0, (hipStream_t)stream, B, N, logits, (long)ld,
+                  label, ce, (__bf16*)dl_hi, (__bf16*)dl_lo);
+    TCAR_CHECK_LAUNCH();
+    return TCAR_OK;
+  }
   TCAR_LAUNCH(softmax_ce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, N, logits, (long)ld, label, ce,
               (__bf16*)dl_hi, (__bf16*)dl_lo);
   TCAR_CHECK_LAUNCH();
@@ -263,17 +375,17 @@ extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, con
 
 extern "C" int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg,
                              const float* attout, float weight, float* neg_fb, float* dattout, float* g_item,
-                             void* stream) {
+                             const float* ce, float* loss, void* stream) {
   if (!d || B <= 0 || K <= 0) return TCAR_OK;
-  if (!E || !neg || !attout || (d->ldh & 63) || d->ldh > 512) return TCAR_E_ARG;
+  if (!E || !neg || !attout || (d->ldh & 63) || d->ldh > 512 || (loss && !ce)) return TCAR_E_ARG;
   const int ek = 2 * d->ldh + 5 * d->ldt;
   const int grid = B;          // one workgroup per session
   if (d->ldh <= 256)
     TCAR_LAUNCH(neg_term_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
-                       neg, attout, weight, neg_fb, dattout, g_item);
+                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss);
   else
     TCAR_LAUNCH(neg_term_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
-                       neg, attout, weight, neg_fb, dattout, g_item);
+                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

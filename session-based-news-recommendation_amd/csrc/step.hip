@@ -159,8 +159,14 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
   void* sB = s2 ? (void*)s2 : stream;
   const bool has_neg = K > 0 && bt->neg;
-  if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
-  if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
+  // zero the gradient arena and the norm slots; with an aux stream this happens beside the softmax, not before it
+  // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
+  hipStream_t sz = s2 ? s2 : st;
+  if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+    return TCAR_E_LAUNCH;
+  if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
+  if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
   const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
@@ -169,7 +175,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   if (s2) {
-    if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
+    if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess ||
+        hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess)
       return TCAR_E_LAUNCH;
   }
   // ---- chain B
@@ -182,7 +189,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
     RET(small_gemm(c, 2, 2, p, sB));
   }
-  if (has_neg) RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, nullptr, nullptr, Gi, sB));
+  if (has_neg) RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, nullptr, nullptr, Gi, nullptr, nullptr, sB));
   if (fuse_finish) RET(finish_dense_side(c, g, sB));
   if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
   // ---- chain A
@@ -194,7 +201,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   }
   RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
   if (has_neg) {
-    RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->dattout, nullptr, stream));
+    RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->dattout, nullptr, c->ce, c->loss,
+                      stream));
   } else if (hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) {
     return TCAR_E_LAUNCH;
   }

@@ -125,7 +125,7 @@ class DPEngine(TcarEngine):
         self._local(bt)
         self.finish_backward(bt, cap_rows)
         self.update()
-        return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
+        return self._loss_view(bt)
 
     def update(self):
         if self.native and self.timing is None and hasattr(self, "_ctx_obj"):
@@ -150,4 +150,4 @@ class DPEngine(TcarEngine):
         bt = bt or self.upload(batch)
         self._local(bt)
         self.finish_backward(bt, cap_rows)
-        return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
+        return self._loss_view(bt)

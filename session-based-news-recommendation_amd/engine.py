@@ -280,6 +280,7 @@ class TcarEngine:
             self.logits = torch.empty(B, g.Npad, **f32)
             self.ce = torch.empty(B, **f32)
             self.neg_fb = torch.zeros(B, **f32)
+            self.loss = torch.zeros(B, **f32)
             self.dattout = torch.empty(B, g.ek, **f32)
             self.dpooled = torch.empty(B, g.ek, **f32)
             self.dq = torch.empty(B, g.ic, **f32)
@@ -548,7 +549,8 @@ class TcarEngine:
             D(g.N, g.pt, [(p(self.logits), g.Npad, p(self.attout, g.ic), g.ek, B)], p(self.d_et), g.pt)], tag="score_dE")
         if K:
             check(lib.tcar_neg_term(C.byref(self.dims), B, K, p(self.E), C.c_void_p(bt.neg), p(self.attout),
-                                    self.neg_weight, p(self.neg_fb), p(self.dattout), p(self.Gi), st), "tcar_neg_term")
+                                    self.neg_weight, p(self.neg_fb), p(self.dattout), p(self.Gi), p(self.ce), p(self.loss),
+                                    st), "tcar_neg_term")
         else:
             self.neg_fb[:B].zero_()
         # output transforms (linear_2d + tanh) backward
@@ -682,6 +684,10 @@ class TcarEngine:
         self._time_dirty = True
 
     # ------------------------------------------------------------------------------------------ public API
+    def _loss_view(self, bt: Batch) -> torch.Tensor:
+        """per-session loss of model_combine.py:147 — written by the negative-term kernel; ce alone without negatives"""
+        return self.loss[:bt.B] if (bt.K > 0 and bt.neg) else self.ce[:bt.B]
+
     def train_step(self, batch: Dict[str, np.ndarray], bt: Optional[Batch] = None) -> torch.Tensor:
         """One sess.run([loss, global_step, train_op]) (model_combine.py:231); returns loss[B] on device."""
         bt = bt or self.upload(batch)
@@ -694,7 +700,7 @@ class TcarEngine:
             self.forward(bt)
             self.backward(bt)
             self.update()
-        return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
+        return self._loss_view(bt)
 
     def loss_and_grads(self, batch, bt: Optional[Batch] = None) -> torch.Tensor:
         bt = bt or self.upload(batch)
@@ -708,7 +714,7 @@ class TcarEngine:
         else:
             self.forward(bt)
             self.backward(bt)
-        return self.ce[:bt.B] + self.neg_weight * self.neg_fb[:bt.B]
+        return self._loss_view(bt)
 
     def eval_step(self, batch, k: int = 20, bt: Optional[Batch] = None, keep_logits: bool = False):
         """sess.run([softmax_input, cross_loss]) (model_combine.py:283) + rank / top-k on device.

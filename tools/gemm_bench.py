@@ -13,7 +13,9 @@ lib = _lib.load()
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 nsplit = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-B, N, Npad, EK = 512, 46033, 46080, 832
+N = int(os.environ.get("GB_N", 46033))
+SK = int(os.environ.get("GB_SPLITK", 16))
+B, Npad, EK = 512, (N + 127) // 128 * 128, 832
 bf = dict(dtype=torch.bfloat16, device="cuda")
 p = lambda t: C.c_void_p(t.data_ptr())
 e_h, e_l = torch.randn(Npad, EK, **bf), torch.randn(Npad, EK, **bf) * 0.004
@@ -21,7 +23,7 @@ a_h, a_l = torch.randn(B, EK, **bf), torch.randn(B, EK, **bf) * 0.004
 d_h, d_l = torch.randn(B, Npad, **bf) * 0.01, torch.randn(B, Npad, **bf) * 1e-4
 ap_h, ap_l = torch.randn(B, 576, **bf), torch.randn(B, 576, **bf) * 0.004
 logits = torch.empty(B, Npad, device="cuda")
-slabs = torch.empty(16, B, EK, device="cuda")
+slabs = torch.empty(SK, B, EK, device="cuda")
 gi, det = torch.empty(N, 256, device="cuda"), torch.empty(N, 320, device="cuda")
 
 
@@ -29,7 +31,7 @@ def run():
     if which == "fwd":
         return lib.tcar_gemm_bf16(1, B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, p(logits), Npad, None, 0, 0, nsplit, 1, None), 2.0 * B * N * 820
     if which == "dx":
-        return lib.tcar_gemm_bf16(0, B, EK, Npad, p(d_h), p(d_l), Npad, B, p(e_h), p(e_l), EK, Npad, p(slabs), EK, None, 0, 0, nsplit, 16, None), 2.0 * B * N * 820
+        return lib.tcar_gemm_bf16(0, B, EK, Npad, p(d_h), p(d_l), Npad, B, p(e_h), p(e_l), EK, Npad, p(slabs), EK, None, 0, 0, nsplit, SK, None), 2.0 * B * N * 820
     return lib.tcar_gemm_bf16(2, N, 576, B, p(d_h), p(d_l), Npad, B, p(ap_h), p(ap_l), 576, B, p(gi), 256, p(det), 320, 256, nsplit, 1, None), 2.0 * B * N * 570
 
 
@@ -44,4 +46,5 @@ for _ in range(iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
+print("N=%d sk=%d " % (N, SK), end="")
 print("%s nsplit=%d: %.1f us  alg %.0f TF  executed %.0f TF" % (which, nsplit, ms * 1e3, fl / ms / 1e9, fl * (3 if nsplit == 3 else 1) / ms / 1e9))
