@@ -219,6 +219,24 @@ int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E, const int3
                   const float* attout, float weight, float* neg_fb, float* dattout, float* g_item,
                   const float* ce, float* loss, void* stream);
 
+/* The same term split along the step's dependency graph (model_combine.py:142-143,147): tcar_neg_fwd needs only
+ * forward quantities and runs beside the logits GEMM — neg_fb[b], coef[b] = weight * d neg_fb / d x_b and
+ * negpart[b, 0:ic] = coef[b] * sum_k E[neg[b,k], 0:ic] (the term's gradient w.r.t. attout[b, 0:ic]);
+ * tcar_neg_scatter adds coef[b] * attout[b, 0:ldh] into g_item[neg[b,k]] (atomics) once dE is in place and, with
+ * loss != NULL, writes loss[b] = ce[b] + weight * neg_fb[b]. */
+int tcar_neg_fwd(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg, const float* attout,
+                 float weight, float* neg_fb, float* coef, float* negpart, void* stream);
+int tcar_neg_scatter(const tcar_dims_t* d, int B, int K, const int32_t* neg, const float* attout, const float* coef,
+                     float* g_item, const float* neg_fb, const float* ce, float weight, float* loss, void* stream);
+
+/* tcar_splitk_reduce_dact: out[m,n] = (sum_s slabs[s,m,n] + (n < n_add ? addend[m,n] : 0)) * act'(y[m,n]) and the bias
+ * gradients bias_grad0[n] (n < split_col) / bias_grad1[n - split_col] += sum_m out[m,n] (atomics into zeroed buffers).
+ * Fuses tcar_splitk_reduce, the dattout part of tcar_neg_term and tcar_dact_colsum for the output transforms
+ * (model_combine.py:119,127,132 backward).  addend / bias_grad* may be NULL; act as in tcar_gemm_f32. */
+int tcar_splitk_reduce_dact(const float* slabs, int splitk, int M, int N, int64_t ld, const float* addend, int64_t ld_add,
+                            int n_add, const float* y, int64_t ldy, int act, float* out, float* bias_grad0, int split_col,
+                            float* bias_grad1, void* stream);
+
 /* tcar_dact_colsum: dz = dy * act'(y) in place over dy ([M, ncol], ld) and bias_grad[c] += sum_m dz[m,c]
  * (gradient of linear_2d's bias + activation, modules.py:52-54; fp32 atomics into a caller-zeroed bias_grad).
  * act: 1 relu, 2 tanh. */
@@ -295,7 +313,7 @@ typedef struct {
   const int32_t* inv_n; const int32_t* inv_off; float* ct_ws;   /* inverted index of mwdhm + its workspace */
   tcar_segments_t segs_all, segs_dense;
   /* workspace (sized by the caller for the largest B and B*T it will submit) */
-  float *x_icp, *x_pt, *x_act, *click_t, *pre1, *pre2, *q1, *q, *alpha, *pooled, *attout, *logits, *ce, *neg_fb, *loss;
+  float *x_icp, *x_pt, *x_act, *click_t, *pre1, *pre2, *q1, *q, *alpha, *pooled, *attout, *logits, *ce, *neg_fb, *loss, *neg_coef, *negpart;
   float *dattout, *dpooled, *dq, *dq1, *dclick, *slabs, *dx_icp, *dx_pt, *dx_act, *dpre1, *dpre2;
   int32_t* rank; int32_t* topk;
   /* scoring precision: 0 = fp32 MFMA, 3 = split-bf16 (hi/lo planes, 3 MFMAs per product, fp32-class accuracy),

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
                                                        const float* __restrict__ attout, float weight,
                                                        float* __restrict__ neg_fb, float* __restrict__ dattout,
                                                        float* __restrict__ g_item, const float* __restrict__ ce,
-                                                       float* __restrict__ loss) {
+                                                       float* __restrict__ loss, float* __restrict__ coef_out,
+                                                       long datt_ld, int datt_overwrite) {
   // one WORKGROUP per session: the 4 waves split the K negatives (independent row gathers in flight), partial
   // dot / row sums meet in LDS, every wave then scatters its own negatives' gradient rows
   __shared__ __attribute__((aligned(16))) float part[4 * 2 * 512];   // [wave][item|content sums]
@@ -240,11 +241,12 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
   if (tid == 0 && neg_fb) neg_fb[b] = fb;
   if (tid == 0 && loss) loss[b] = ce[b] + weight * fb;          // model_combine.py:147
   const float coef = weight * sg * om / (om + 1e-24f);  // weight * d/dx[-log(1 - sigmoid(x) + 1e-24)]
+  if (tid == 0 && coef_out) coef_out[b] = coef;
   if (dattout) {
     for (int col = tid * 4; col < ic; col += 1024) {
       const float4 s = add4(add4(ld4(part + col), ld4(part + ic + col)), add4(ld4(part + 2 * ic + col), ld4(part + 3 * ic + col)));
-      float* p = dattout + (long)b * ek + col;
-      st4(p, fma4(s, coef, ld4(p)));
+      float* p = dattout + (long)b * datt_ld + col;
+      st4(p, datt_overwrite ? scale4(s, coef) : fma4(s, coef, ld4(p)));
     }
   }
   if (g_item) {
@@ -255,6 +257,87 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
         const int col = c * 256 + lane * 4;
         if (col < ldh) atomic_add4(g_item + (long)n * ldh + col, scale4(ua[c], coef));
       }
+    }
+  }
+}
+
+// ---- negative rows of the item-table gradient: g_item[neg[b,k], :] += coef[b] * attout[b, 0:ldh] --------------
+// One wave per (session, negative); lanes walk consecutive columns so each atomic instruction covers 256 contiguous
+// bytes.  The first wave of a session also writes the training loss (model_combine.py:147).
+__global__ __launch_bounds__(256) void neg_scatter_kernel(int B, int K, int n_items, int ldh, int ek,
+                                                          const int32_t* __restrict__ neg, const float* __restrict__ attout,
+                                                          const float* __restrict__ coef, float* __restrict__ g_item,
+                                                          const float* __restrict__ neg_fb, const float* __restrict__ ce,
+                                                          float weight, float* __restrict__ loss) {
+  const int lane = threadIdx.x & 63;
+  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wv >= (long)B * K) return;
+  const int b = (int)(wv / K), k = (int)(wv - (long)b * K);
+  if (k == 0 && lane == 0 && loss) loss[b] = ce[b] + weight * neg_fb[b];
+  const int n = clampi(neg[wv], 0, n_items - 1);
+  const float cf = coef[b];
+  if (cf == 0.f) return;                        // saturated sigmoid (S8): no gradient
+  const float* a = attout + (long)b * ek;
+  float* gdst = g_item + (long)n * ldh;
+  for (int col = lane; col < ldh; col += 64) atomicAdd(gdst + col, cf * a[col]);
+}
+
+// ---- dattout = sum of the split-K slabs [+ negative part], times act'(attout), plus the bias gradients -----------
+// One pass instead of four launches (slab reduce, negative term, two activation backward passes): tile = 32 rows x 64
+// columns, thread = (float4 column group, row phase); the slab loads of a row are all issued before the first add.
+__global__ __launch_bounds__(256) void reduce_dact_kernel(const float* __restrict__ slabs, int S, int M, int N, long ld,
+                                                          const float* __restrict__ addend, long ld_add, int n_add,
+                                                          const float* __restrict__ y, long ldy, int act,
+                                                          float* __restrict__ out, float* __restrict__ bg0, int split_col,
+                                                          float* __restrict__ bg1) {
+  __shared__ float4 sh[256];
+  const int tid = threadIdx.x, cg = tid & 15, rp = tid >> 4;
+  const int col = blockIdx.x * 64 + cg * 4;
+  const int r0 = blockIdx.y * 32;
+  float4 cs = zero4();
+  if (col < N) {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = r0 + rp + 16 * rr;
+      if (row >= M) continue;
+      float4 acc = (addend && col < n_add) ? ld4(addend + (long)row * ld_add + col) : zero4();
+      const float* sp = slabs + (long)row * ld + col;
+      int k = 0;
+      for (; k + 6 <= S; k += 6) {
+        float4 t[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t[j] = ld4(sp + (long)(k + j) * M * ld);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc = add4(acc, t[j]);
+      }
+      for (; k < S; ++k) acc = add4(acc, ld4(sp + (long)k * M * ld));
+      if (act) {
+        const float4 yy = ld4(y + (long)row * ldy + col);
+        if (act == 1) {
+          acc.x = yy.x > 0.f ? acc.x : 0.f; acc.y = yy.y > 0.f ? acc.y : 0.f;
+          acc.z = yy.z > 0.f ? acc.z : 0.f; acc.w = yy.w > 0.f ? acc.w : 0.f;
+        } else {
+          acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+        }
+      }
+      st4(out + (long)row * ld + col, acc);
+      cs = add4(cs, acc);
+    }
+  }
+  sh[tid] = cs;
+  __syncthreads();
+  if (tid < 64) {                                // thread = one column of the tile: sum its 16 row phases
+    const int g4 = tid >> 2, j = tid & 3;
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float4 t = sh[q * 16 + g4];
+      v += (j == 0) ? t.x : (j == 1) ? t.y : (j == 2) ? t.z : t.w;
+    }
+    const int c = blockIdx.x * 64 + tid;
+    if (c < N && v != 0.f) {
+      if (c < split_col) { if (bg0) atomicAdd(bg0 + c, v); }
+      else if (bg1) atomicAdd(bg1 + (c - split_col), v);
     }
   }
 }
@@ -382,10 +465,51 @@ extern "C" int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E,
   const int grid = B;          // one workgroup per session
   if (d->ldh <= 256)
     TCAR_LAUNCH(neg_term_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
-                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss);
+                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss, (float*)nullptr, (long)ek, 0);
   else
     TCAR_LAUNCH(neg_term_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
-                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss);
+                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss, (float*)nullptr, (long)ek, 0);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_neg_fwd(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg, const float* attout,
+                            float weight, float* neg_fb, float* coef, float* negpart, void* stream) {
+  if (!d || B <= 0 || K <= 0) return TCAR_OK;
+  if (!E || !neg || !attout || !coef || !negpart || (d->ldh & 63) || d->ldh > 512) return TCAR_E_ARG;
+  const int ek = 2 * d->ldh + 5 * d->ldt;
+  if (d->ldh <= 256)
+    TCAR_LAUNCH(neg_term_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E, neg, attout,
+                weight, neg_fb, negpart, (float*)nullptr, (const float*)nullptr, (float*)nullptr, coef, (long)(2 * d->ldh), 1);
+  else
+    TCAR_LAUNCH(neg_term_kernel<2>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E, neg, attout,
+                weight, neg_fb, negpart, (float*)nullptr, (const float*)nullptr, (float*)nullptr, coef, (long)(2 * d->ldh), 1);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_neg_scatter(const tcar_dims_t* d, int B, int K, const int32_t* neg, const float* attout,
+                                const float* coef, float* g_item, const float* neg_fb, const float* ce, float weight,
+                                float* loss, void* stream) {
+  if (!d || B <= 0 || K <= 0) return TCAR_OK;
+  if (!neg || !attout || !coef || !g_item || (loss && (!ce || !neg_fb))) return TCAR_E_ARG;
+  const int ek = 2 * d->ldh + 5 * d->ldt;
+  const long waves = (long)B * K;
+  TCAR_LAUNCH(neg_scatter_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items,
+              d->ldh, ek, neg, attout, coef, g_item, neg_fb, ce, weight, loss);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_splitk_reduce_dact(const float* slabs, int splitk, int M, int N, int64_t ld, const float* addend,
+                                       int64_t ld_add, int n_add, const float* y, int64_t ldy, int act, float* out,
+                                       float* bias_grad0, int split_col, float* bias_grad1, void* stream) {
+  if (M <= 0 || N <= 0) return TCAR_OK;
+  if ((N & 3) || (ld & 3) || !tcar_aligned16(slabs) || !tcar_aligned16(out) || splitk < 1 || (act && (!y || (ldy & 3))) ||
+      (addend && ((ld_add & 3) || (n_add & 3) || !tcar_aligned16(addend))))
+    return TCAR_E_ARG;
+  TCAR_LAUNCH(reduce_dact_kernel, dim3((N + 63) / 64, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, N,
+              (long)ld, addend, (long)ld_add, n_add, y, (long)ldy, act, out, bias_grad0, split_col, bias_grad1);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

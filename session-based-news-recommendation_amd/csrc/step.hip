@@ -123,6 +123,14 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
                  W(c, TCAR_V_OT_B), 2);
     RET(small_gemm(c, 0, 2, p, stream));
   }
+  if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart) {
+    // the sampled negative term needs only attout and E: it runs on the aux stream beside the logits GEMM; the
+    // backward pass picks its outputs up after its own fork (which orders the aux stream's earlier work)
+    if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
+      return TCAR_E_LAUNCH;
+    RET(tcar_neg_fwd(&c->d, B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart,
+                     s2 ? (void*)s2 : stream));
+  }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138)
   int ei = -1;
@@ -158,7 +166,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const int B = bt->B, T = bt->T, BT = B * T, K = bt->K;
   hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
   void* sB = s2 ? (void*)s2 : stream;
-  const bool has_neg = K > 0 && bt->neg;
+  const bool has_neg = K > 0 && bt->neg && c->neg_coef && c->negpart;      // tcar_step_forward ran tcar_neg_fwd
   // zero the gradient arena and the norm slots; with an aux stream this happens beside the softmax, not before it
   // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
   hipStream_t sz = s2 ? s2 : st;
@@ -189,7 +197,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
     RET(small_gemm(c, 2, 2, p, sB));
   }
-  if (has_neg) RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, nullptr, nullptr, Gi, nullptr, nullptr, sB));
+  if (has_neg)
+    RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, sB));
   if (fuse_finish) RET(finish_dense_side(c, g, sB));
   if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
   // ---- chain A
@@ -199,15 +208,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   } else {
     RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
   }
-  RET(tcar_splitk_reduce(c->slabs, S, B, g.ek, g.ek, c->dattout, stream));
-  if (has_neg) {
-    RET(tcar_neg_term(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->dattout, nullptr, c->ce, c->loss,
-                      stream));
-  } else if (hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) {
-    return TCAR_E_LAUNCH;
-  }
-  RET(tcar_dact_colsum(B, g.ic, g.ek, c->attout, c->dattout, G(c, TCAR_V_O_B), 2, stream));
-  RET(tcar_dact_colsum(B, g.pt, g.ek, c->attout + g.ic, c->dattout + g.ic, G(c, TCAR_V_OT_B), 2, stream));
+  // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
+  RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
+                              c->dattout, G(c, TCAR_V_O_B), g.ic, G(c, TCAR_V_OT_B), stream));
+  if (!has_neg && hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
   {
     tcar_gemm_desc_t p[2];
     p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->dpooled, g.ek);

@@ -281,6 +281,8 @@ class TcarEngine:
             self.ce = torch.empty(B, **f32)
             self.neg_fb = torch.zeros(B, **f32)
             self.loss = torch.zeros(B, **f32)
+            self.neg_coef = torch.zeros(B, **f32)
+            self.negpart = torch.zeros(B, g.ic, **f32)
             self.dattout = torch.empty(B, g.ek, **f32)
             self.dpooled = torch.empty(B, g.ek, **f32)
             self.dq = torch.empty(B, g.ic, **f32)

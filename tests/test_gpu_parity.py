@@ -492,3 +492,85 @@ def test_mixed_precision_backward_mode():
     for _ in range(5):
         l1 = float(eng.train_step(batch).sum())
     assert l1 < l0
+
+
+@pytest.mark.parametrize("N", [8200, 20001, 49200])
+def test_softmax_ce_kernel_variants(lib, N):
+    """row-resident kernels (<= 16,384 / <= 49,152 columns) and the streaming kernel beyond: fp32 and bf16-plane outputs"""
+    rng = np.random.RandomState(N)
+    B, ldn = 3, (N + 127) // 128 * 128
+    x = (rng.standard_normal((B, ldn)) * 4).astype(np.float32)
+    lab = np.array([0, N - 1, N // 2], np.int32)
+    xv = x[:, :N].astype(np.float64)
+    lse = np.log(np.exp(xv - xv.max(1, keepdims=True)).sum(1)) + xv.max(1)
+    p = np.exp(xv - lse[:, None])
+    p[np.arange(B), lab] -= 1
+    d, dl = torch.tensor(x).cuda(), torch.tensor(lab).cuda()
+    ce = torch.empty(B, device="cuda")
+    hi = torch.full((128 * ldn,), 7.0, dtype=torch.bfloat16, device="cuda")
+    lo = torch.full((128 * ldn,), 7.0, dtype=torch.bfloat16, device="cuda")
+    assert lib.tcar_softmax_ce_bf16(B, N, ptr(d), ldn, ptr(dl), ptr(ce), ptr(hi), ptr(lo), None) == 0
+    close(ce.cpu().numpy(), lse - xv[np.arange(B), lab], name="ce planes")
+    assert (d.cpu().numpy() == x).all()                       # logits untouched in plane mode
+    idx = _kb32_index(128, ldn)
+    g = (hi.float() + lo.float()).cpu().numpy()[idx]
+    close(g[:B, :N], p, name="dlogits planes", rtol=2e-5)
+    assert (g[B:] == 0).all() and (g[:B, N:] == 0).all()      # padding rows / columns are zero
+    assert lib.tcar_softmax_ce(B, N, ptr(d), ldn, ptr(dl), ptr(ce), None) == 0
+    got = d.cpu().numpy()
+    close(got[:, :N], p, name="dlogits fp32")
+    assert (got[:, N:] == 0).all()
+
+
+def test_negative_term_split_and_fused_reduce(lib):
+    """tcar_neg_fwd + tcar_neg_scatter + tcar_splitk_reduce_dact reproduce tcar_neg_term + tcar_splitk_reduce +
+    tcar_dact_colsum (the unfused sequence), including a saturated session (S8) whose gradient is exactly 0."""
+    from tcar_amd._lib import Dims
+    rng = np.random.RandomState(5)
+    N, H, Ht, B, K, S = 300, 250, 64, 37, 7, 5
+    ldh, ldt = 256, 64
+    ic, pt = 2 * ldh, 5 * ldt
+    ek = ic + pt
+    dims = Dims(n_items=N, H=H, Ht=Ht, ldh=ldh, ldt=ldt)
+    E = (rng.standard_normal((N, ek)) * 0.3).astype(np.float32)
+    att = np.tanh(rng.standard_normal((B, ek))).astype(np.float32)
+    att[3, :ic] = np.sign(E[5, :ic]) * 0.99                  # session 3: huge positive logit -> saturation
+    neg = rng.randint(0, N, (B, K)).astype(np.int32)
+    neg[3] = 5
+    slabs = rng.standard_normal((S, B, ek)).astype(np.float32)
+    ce = rng.rand(B).astype(np.float32)
+    w = 0.01
+    t = lambda a: torch.tensor(a).cuda()
+    dE, datt, dneg, dslab, dce = t(E), t(att), t(neg), t(slabs), t(ce)
+    # unfused sequence
+    ref_datt = torch.empty(B, ek, device="cuda")
+    assert lib.tcar_splitk_reduce(ptr(dslab), S, B, ek, ek, ptr(ref_datt), None) == 0
+    ref_fb, ref_loss = torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    ref_gi = torch.zeros(N, ldh, device="cuda")
+    assert lib.tcar_neg_term(C.byref(dims), B, K, ptr(dE), ptr(dneg), ptr(datt), w, ptr(ref_fb), ptr(ref_datt), ptr(ref_gi),
+                             ptr(dce), ptr(ref_loss), None) == 0
+    ref_b0, ref_b1 = torch.zeros(ic, device="cuda"), torch.zeros(pt, device="cuda")
+    assert lib.tcar_dact_colsum(B, ic, ek, ptr(datt), ptr(ref_datt), ptr(ref_b0), 2, None) == 0
+    assert lib.tcar_dact_colsum(B, pt, ek, ptr(datt, ic), ptr(ref_datt, ic), ptr(ref_b1), 2, None) == 0
+    # split + fused
+    fb, coef, part = torch.empty(B, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, ic, device="cuda")
+    assert lib.tcar_neg_fwd(C.byref(dims), B, K, ptr(dE), ptr(dneg), ptr(datt), w, ptr(fb), ptr(coef), ptr(part), None) == 0
+    gi, loss = torch.zeros(N, ldh, device="cuda"), torch.empty(B, device="cuda")
+    assert lib.tcar_neg_scatter(C.byref(dims), B, K, ptr(dneg), ptr(datt), ptr(coef), ptr(gi), ptr(fb), ptr(dce), w,
+                                ptr(loss), None) == 0
+    out = torch.empty(B, ek, device="cuda")
+    b0, b1 = torch.zeros(ic, device="cuda"), torch.zeros(pt, device="cuda")
+    assert lib.tcar_splitk_reduce_dact(ptr(dslab), S, B, ek, ek, ptr(part), ic, ic, ptr(datt), ek, 2, ptr(out), ptr(b0), ic,
+                                       ptr(b1), None) == 0
+    close(fb.cpu().numpy(), ref_fb.cpu().numpy(), name="neg_fb")
+    close(loss.cpu().numpy(), ref_loss.cpu().numpy(), name="loss")
+    close(out.cpu().numpy(), ref_datt.cpu().numpy(), name="dattout", rtol=1e-5)
+    close(gi.cpu().numpy(), ref_gi.cpu().numpy(), name="g_item", rtol=1e-5)
+    close(b0.cpu().numpy(), ref_b0.cpu().numpy(), name="bias O", rtol=1e-4)
+    close(b1.cpu().numpy(), ref_b1.cpu().numpy(), name="bias OT", rtol=1e-4)
+    assert float(coef[3]) == 0.0 and abs(float(fb[3]) - 55.262) < 1e-2          # S8
+    # against numpy for the fused reduce itself
+    want = (slabs.astype(np.float64).sum(0))
+    want[:, :ic] += part.cpu().numpy()
+    want *= 1 - att.astype(np.float64) ** 2
+    close(out.cpu().numpy(), want, name="dattout numpy", rtol=1e-5)
