@@ -109,7 +109,8 @@ int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float*
 int tcar_cand_time_fwd(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
                        float* E, void* stream);
 
-/* ..._bf16: additionally refreshes the same columns of the bf16 hi / lo planes of E (operands of tcar_gemm_bf16). */
+/* ..._bf16: additionally refreshes the same columns of the bf16 hi / lo planes of E (operands of tcar_gemm_bf16);
+ * E may then be NULL (planes only: the split-bf16 scoring modes never read the fp32 time block). */
 int tcar_cand_time_fwd_bf16(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm, float* E,
                             void* e16_hi, void* e16_lo, void* stream);
 

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void cand_time_fwd_kernel(const CandArgs a) {
     const long n = nk / 5;
     const int id = clampi(a.mwdhm[n * 5 + k], 0, time_vocab(k) - 1);
     const float4 v = ld4(lds + (time_rowoff(k) + id) * ldt + l * 4);
-    st4(a.E + n * ek + ic + k * ldt + l * 4, v);
+    if (a.E) st4(a.E + n * ek + ic + k * ldt + l * 4, v);
     if (a.eh) {
       const float vv[4] = {v.x, v.y, v.z, v.w};
       bf16x4_e h, lo;
@@ -590,7 +590,7 @@ extern "C" int tcar_cand_time_fwd(const tcar_dims_t* d, const float* const time_
 
 extern "C" int tcar_cand_time_fwd_bf16(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* mwdhm,
                                        float* E, void* e16_hi, void* e16_lo, void* stream) {
-  if (check_dims(d) || !time_tab || !mwdhm || !E || (e16_hi && !e16_lo)) return TCAR_E_ARG;
+  if (check_dims(d) || !time_tab || !mwdhm || (!E && !e16_hi) || (e16_hi && !e16_lo)) return TCAR_E_ARG;
   CandArgs a{};
   a.d = *d;
   for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
@@ -599,7 +599,7 @@ extern "C" int tcar_cand_time_fwd_bf16(const tcar_dims_t* d, const float* const 
   long total = (long)d->n_items * 5 * (d->ldt >> 2);
   int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
   if (grid < 1) grid = 1;
-  if (grid > 1024) grid = 1024;
+  if (grid > 512) grid = 512;     // it runs beside the session-side kernels: leave them room on every CU
   (void)hipFuncSetAttribute((const void*)cand_time_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   TCAR_LAUNCH(cand_time_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();

@@ -87,7 +87,7 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
       if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
         return TCAR_E_LAUNCH;
     }
-    RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
+    RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
                                 s2 ? (void*)s2 : stream));
     if (s2) {
       if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
@@ -228,14 +228,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     RET(small_gemm(c, 1, 1, &p, stream));
   }
   RET(tcar_dact_colsum(B, g.ldh, g.ldh, c->q1, c->dq1, G(c, TCAR_V_Q1_B), 1, stream));
-  {  // input gradients (only the ITEM half of dX_ic: content is frozen)
-    tcar_gemm_desc_t p[4];
-    p[0] = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
-    p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
-    p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
-    p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
-    RET(small_gemm(c, 1, 4, p, stream));
-  }
+  // Everything the weight gradients need exists now; they run on the aux stream (behind chain B) while the main stream
+  // continues with the input gradients and the row scatter.
+  if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+    return TCAR_E_LAUNCH;
   {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
     auto ks = [](int K) { int s = (K + 1023) / 1024; return s < 2 ? 2 : (s > 16 ? 16 : s); };
     const int kb = ks(B), kr = ks(BT);
@@ -250,9 +246,18 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
     p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
     p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
-    RET(small_gemm(c, 2, 9, p, stream));
+    RET(small_gemm(c, 2, 9, p, sB));
   }
-  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[3], 0) != hipSuccess) return TCAR_E_LAUNCH;    // join
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  {  // input gradients (only the ITEM half of dX_ic: content is frozen)
+    tcar_gemm_desc_t p[4];
+    p[0] = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+    p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
+    p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
+    p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
+    RET(small_gemm(c, 1, 4, p, stream));
+  }
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[3], 0) != hipSuccess) return TCAR_E_LAUNCH;    // chain B is done
   if (fuse_finish) {
     // sparse rows and per-row norm pieces (after the dense item norm of chain B), then the dense-weight norms
     tcar_tables_t tab;
@@ -260,8 +265,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     tables_of(c, tab);
     grads_of(c, gr);
     RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
-    RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
   }
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // weight gradients are in
+  if (fuse_finish) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
   return TCAR_OK;
 }
 
