@@ -109,9 +109,9 @@ def main():
             pool.setdefault(b["seq"].shape[1], []).append(b)
         batches = [pool[T][i % len(pool[T])] for i, T in enumerate(want)]
 
-    from oracle.tcar_oracle import init_params_numpy      # weight init only (np.random), not the oracle model
-    params = init_params_numpy(args.n_items, args.hidden_size, args.time_hidden_size, 0.002, 0.05,
-                               np.random.RandomState(2020))
+    from tcar_amd.host.model import initial_variables     # the product's own initialiser (modules.py:32-34,50-51)
+    np.random.seed(2020)
+    params = initial_variables(args.n_items, args.hidden_size, args.time_hidden_size, 0.002, 0.05, weight_seed=2020)
     if world > 1:
         from tcar_amd.dp import DPEngine
         eng = DPEngine(params, fold.content, fold.mwdhm, device=dev, group=dist.group.WORLD, scoring=args.scoring)

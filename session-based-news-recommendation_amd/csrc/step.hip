@@ -165,7 +165,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const Geo g(c->d);
   const int B = bt->B, T = bt->T, BT = B * T, K = bt->K;
   hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
-  void* sB = s2 ? (void*)s2 : stream;
+  // chain B runs on the aux stream in the fused single-rank step; in the rank-local backward of the data-parallel step
+  // it runs FIRST on the main stream, so that dE is complete early and its all-reduce overlaps chain A (dp.py)
+  void* sB = (s2 && fuse_finish) ? (void*)s2 : stream;
+  void* sW = s2 ? (void*)s2 : stream;          // the weight-gradient GEMM
   const bool has_neg = K > 0 && bt->neg && c->neg_coef && c->negpart;      // tcar_step_forward ran tcar_neg_fwd
   // zero the gradient arena and the norm slots; with an aux stream this happens beside the softmax, not before it
   // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
@@ -200,7 +203,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (has_neg)
     RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, sB));
   if (fuse_finish) RET(finish_dense_side(c, g, sB));
-  if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // dE (+ its finish) done
   // ---- chain A
   if (c->scoring) {
     RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
@@ -246,7 +249,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
     p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
     p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
-    RET(small_gemm(c, 2, 9, p, sB));
+    RET(small_gemm(c, 2, 9, p, sW));
   }
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   {  // input gradients (only the ITEM half of dX_ic: content is frozen)

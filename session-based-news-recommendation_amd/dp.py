@@ -19,7 +19,9 @@ whole (global) batch.  The exchange therefore runs in this order (all on the com
   6. local       scatter-add all rows into dE_item, then the norms of the dense weights.
 
 xGMI is point-to-point (7 links/GPU): step 1 moves ~106 MB per rank at the Globo size and dominates; it only
-depends on the scoring backward, so a later round can overlap it with the attention / embedding backward.
+depends on dE, so the rank-local backward runs dE FIRST and `DPEngine` starts step 1 on a communication stream the
+moment dE is complete (an event recorded by the C++ driver): the all-reduce runs beside dX, the attention / projection
+backward and the weight gradients, and is joined just before step 2.
 `GradExchange` is device-agnostic (tests run it over gloo on CPU tensors with the oracle's gradients).
 """
 from __future__ import annotations
@@ -45,9 +47,13 @@ class GradExchange:
 
     def run(self, big: torch.Tensor, arena_pieces: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor,
             sqnorm_item: Callable[[], None], cand_time_bwd: Callable[[], None],
-            scatter_rows: Callable[[torch.Tensor, torch.Tensor], None], sqnorm_dense: Callable[[], None]):
+            scatter_rows: Callable[[torch.Tensor, torch.Tensor], None], sqnorm_dense: Callable[[], None],
+            big_wait: Optional[Callable[[], None]] = None):
+        """`big_wait`: step 1 was already started asynchronously (DPEngine.start_big_reduce); call it to join."""
         g = self.group
-        if self.world > 1:
+        if big_wait is not None:
+            big_wait()                                                      # 1 (started early, overlapped)
+        elif self.world > 1:
             dist.all_reduce(big, group=g)                                   # 1
         sqnorm_item()                                                       # 2
         if self.world > 1:
@@ -110,7 +116,27 @@ class DPEngine(TcarEngine):
             check(lib.tcar_scatter_add_rows(C.byref(self.dims), p(all_ids), p(all_rows), all_ids.numel(), p(self.Gi),
                                             self._stream()), "tcar_scatter_add_rows")
 
-        self.xch.run(self.big, self.Gx, ids, rows, self._sqnorm_item, self._cand_time_bwd, scatter, self._sqnorm_dense)
+        self.xch.run(self.big, self.Gx, ids, rows, self._sqnorm_item, self._cand_time_bwd, scatter, self._sqnorm_dense,
+                     big_wait=self._big_wait)
+        self._big_wait = None
+
+    _big_wait = None
+
+    def start_big_reduce(self):
+        """Step 1 of the exchange, started on a communication stream as soon as dE is complete (event 3 of the C++
+        driver, recorded after the dE GEMM + negative rows) so that it overlaps chain A.  Falls back to the in-line
+        all-reduce when there is no aux stream / single rank."""
+        self._big_wait = None
+        if self.xch.world <= 1 or not self.big.is_cuda or not getattr(self, "_aux_ev", None):
+            return
+        if not hasattr(self, "_comm"):
+            self._comm = torch.cuda.Stream(self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        self._comm.wait_event(self._aux_ev[3])
+        with torch.cuda.stream(self._comm):
+            dist.all_reduce(self.big, group=self.group)
+        comm = self._comm
+        self._big_wait = lambda: main.wait_stream(comm)
 
     def train_step(self, batch, bt=None, cap_rows: Optional[int] = None):
         """`batch` may be None for a rank whose shard of the global batch is empty (it still joins the collectives)."""
@@ -142,6 +168,7 @@ class DPEngine(TcarEngine):
             check(self.lib.tcar_step_forward(C.byref(ctx), C.byref(bt), int(self._time_dirty), st), "tcar_step_forward")
             self._time_dirty = False
             check(self.lib.tcar_step_backward_local(C.byref(ctx), C.byref(bt), st), "tcar_step_backward_local")
+            self.start_big_reduce()
         else:
             self.forward(bt)
             self.backward_local(bt)
