@@ -302,23 +302,43 @@ __global__ __launch_bounds__(256) void cand_time_fwd_kernel(const CandArgs a) {
     if (valid) st4(lds + rr * ldt + lin * 4, scale4(x, s));
   }
   __syncthreads();
-  const long total = (long)a.d.n_items * 5 * sub;     // one float4 per (n, k, lin)
-  for (long i = (long)blockIdx.x * 256 + tid; i < total; i += (long)gridDim.x * 256) {
-    const int l = (int)(i % sub);
-    const long nk = i / sub;
-    const int k = (int)(nk % 5);
-    const long n = nk / 5;
-    const int id = clampi(a.mwdhm[n * 5 + k], 0, time_vocab(k) - 1);
-    const float4 v = ld4(lds + (time_rowoff(k) + id) * ldt + l * 4);
-    if (a.E) st4(a.E + n * ek + ic + k * ldt + l * 4, v);
-    if (a.eh) {
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      bf16x4_e h, lo;
+  // One 128-row block of E per workgroup pass; thread = (row, 16-column half of a 32-wide k-block).  In the KB32 planes
+  // a wave then writes 32 rows x 64 B = 2 KB contiguous per store pair; all index arithmetic is 32-bit.
+  typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_e;
+  const int kpt = ldt >> 5, in32 = ek >> 5;
+  const int r = tid >> 1, half = tid & 1;
+  const int nrb = (a.d.n_items + 127) >> 7;
+  for (int rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    const int n = rb * 128 + r;
+    if (n >= a.d.n_items) continue;                   // padding rows of E / the planes stay zero
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { h[j] = (__bf16)vv[j]; lo[j] = (__bf16)(vv[j] - (float)h[j]); }
-      const long o = kb32_off(n, ic + k * ldt + l * 4, ek >> 5);   // KB32 blocked plane [Npad, ek]
-      *reinterpret_cast<bf16x4_e*>(a.eh + o) = h;
-      *reinterpret_cast<bf16x4_e*>(a.el + o) = lo;
+    for (int k = 0; k < 5; ++k) {
+      const int id = clampi(a.mwdhm[n * 5 + k], 0, time_vocab(k) - 1);
+      const float* src = lds + (time_rowoff(k) + id) * ldt + half * 16;
+      for (int q = 0; q < kpt; ++q) {
+        const int col = ic + k * ldt + q * 32 + half * 16;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 t = ld4(src + q * 32 + j * 4);
+          v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+          if (a.E) st4(a.E + (long)n * ek + col + j * 4, t);
+        }
+        if (a.eh) {
+#pragma unroll
+          for (int pc = 0; pc < 2; ++pc) {
+            bf16x8_e h, lo;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              h[j] = (__bf16)v[pc * 8 + j];
+              lo[j] = (__bf16)(v[pc * 8 + j] - (float)h[j]);
+            }
+            const long o = kb32_off(n, col + pc * 8, in32);
+            *reinterpret_cast<bf16x8_e*>(a.eh + o) = h;
+            *reinterpret_cast<bf16x8_e*>(a.el + o) = lo;
+          }
+        }
+      }
     }
   }
 }
@@ -596,10 +616,8 @@ extern "C" int tcar_cand_time_fwd_bf16(const tcar_dims_t* d, const float* const 
   for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
   a.mwdhm = mwdhm; a.E = E; a.eh = (__bf16*)e16_hi; a.el = (__bf16*)e16_lo;
   const size_t lds = (size_t)139 * d->ldt * sizeof(float);
-  long total = (long)d->n_items * 5 * (d->ldt >> 2);
-  int grid = (int)((total + 256 * 8 - 1) / (256 * 8));
-  if (grid < 1) grid = 1;
-  if (grid > 512) grid = 512;     // it runs beside the session-side kernels: leave them room on every CU
+  int grid = (d->n_items + 127) / 128;      // one 128-row block per workgroup (grid-stride beyond 1024 blocks)
+  if (grid > 1024) grid = 1024;
   (void)hipFuncSetAttribute((const void*)cand_time_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   TCAR_LAUNCH(cand_time_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();

@@ -26,21 +26,24 @@ __device__ __forceinline__ float clip_factor(const float* sqn_dense, const float
   return clip / fmaxf(n, clip);
 }
 
-// grid = (chunks <= 256, nseg); each workgroup strides over 4096-float pieces of one segment and issues ONE
+// grid = (chunks <= 512, nseg); each workgroup strides over 8192-float pieces of one segment and issues ONE
 // atomic (same-address float atomics serialise at ~12 ns each: thousands of them cost more than the read)
 __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, const SegArgs a, float* __restrict__ out) {
   __shared__ float sh[4];
   const int seg = blockIdx.y;
   const long off = a.s.off[seg];
   const long len = a.s.len[seg];
-  if ((long)blockIdx.x * 4096 >= len) return;
+  if ((long)blockIdx.x * 8192 >= len) return;
   float s = 0.f;
-  for (long base = (long)blockIdx.x * 4096; base < len; base += (long)gridDim.x * 4096) {
+  for (long base = (long)blockIdx.x * 8192; base < len; base += (long)gridDim.x * 8192) {
+    float4 v[8];                      // 8 loads in flight per thread: the pass is latency bound otherwise
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const long e = base + (i * 256 + threadIdx.x) * 4;
-      if (e < len) { const float4 v = ld4(g + off + e); s += dot4(v, v); }
+      v[i] = (e < len) ? ld4(g + off + e) : zero4();
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += dot4(v[i], v[i]);
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -128,12 +131,19 @@ int check_segs(const tcar_segments_t* s) {
 
 }  // namespace
 
+static int sqnorm_grid_x(const tcar_segments_t* segs) {
+  long mx = 1;
+  for (int i = 0; i < segs->nseg; ++i) mx = segs->len[i] > mx ? segs->len[i] : mx;
+  long gx = (mx + 8191) / 8192;
+  return (int)(gx > 512 ? 512 : gx);
+}
+
 extern "C" int tcar_sqnorm(const float* g, const tcar_segments_t* segs, float* sqn_dense, void* stream) {
   if (check_segs(segs) || !g || !sqn_dense || !tcar_aligned16(g)) return TCAR_E_ARG;
   if (segs->nseg == 0) return TCAR_OK;
   SegArgs a;
   a.s = *segs;
-  TCAR_LAUNCH(sqnorm_kernel, dim3(seg_grid_x(segs) > 256 ? 256 : seg_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
+  TCAR_LAUNCH(sqnorm_kernel, dim3(sqnorm_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
