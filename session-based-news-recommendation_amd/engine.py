@@ -107,6 +107,7 @@ class TcarEngine:
         if not torch.cuda.is_available():
             raise _lib.TcarError("TcarEngine needs an MI355X (no CPU fallback)")
         self.dev = torch.device(device)
+        self.is_cuda = self.dev.type == "cuda"
         N, H = content_emb.shape[0] - 1, content_emb.shape[1]
         Ht = params["month_embedding"].shape[1]
         self.geo = g = Geometry(N, H, Ht)
@@ -415,20 +416,23 @@ class TcarEngine:
                                      ("pm", "pd", "pw", "ph", "pmi", "gap", "cw", "ch", "label")]
         if K:
             parts.append(np.asarray(neg, dtype=np.int32).reshape(-1))
-        flat = np.concatenate(parts)
-        if self.pin is None or self.pin[0].numel() < flat.size:
-            n = max(flat.size, 1 << 16)
+        total = sum(x.size for x in parts)
+        if self.pin is None or self.pin[0].numel() < total:
+            n = max(total, 1 << 16)
             self.pin = [torch.empty(n, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self.pin_np = [t.numpy() for t in self.pin]          # numpy views of the pinned staging buffers
             self.ibufs = [torch.empty(n, dtype=torch.int32, device=self.dev) for _ in range(2)]
-            self.pin_evt = [None, None]
+            self.pin_evt = [torch.cuda.Event(), torch.cuda.Event()] if self.is_cuda else [None, None]
+            self.pin_used = [False, False]
             self.pin_i = 0
         i = self.pin_i = self.pin_i ^ 1          # two staging buffers: the host may run one step ahead
-        if self.pin_evt[i] is not None:
+        if self.pin_used[i]:
             self.pin_evt[i].synchronize()        # the H2D copy that last used this pinned buffer has finished
-        self.pin[i][:flat.size].copy_(torch.from_numpy(flat))
-        self.ibufs[i][:flat.size].copy_(self.pin[i][:flat.size], non_blocking=True)
-        self.pin_evt[i] = torch.cuda.Event()
-        self.pin_evt[i].record(torch.cuda.current_stream(self.dev))
+        np.concatenate(parts, out=self.pin_np[i][:total])        # packed straight into pinned memory
+        self.ibufs[i][:total].copy_(self.pin[i][:total], non_blocking=True)
+        if self.is_cuda:
+            self.pin_evt[i].record(torch.cuda.current_stream(self.dev))
+            self.pin_used[i] = True
         base = self.ibufs[i].data_ptr()
         bt = Batch()
         bt.B, bt.T, bt.K = B, T, K

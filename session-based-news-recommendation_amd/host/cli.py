@@ -57,6 +57,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--gap_mode", default="active_t", choices=["active_t", "click_delta"])
     ap.add_argument("--neg_mode", default="uniform", choices=["uniform", "neighbor", "impression"])
     # MI355X
+    ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
+                    help="precision of the full-catalog scoring GEMMs (bf16x3: split-bf16 planes, fp32-class accuracy)")
     ap.add_argument("--gpus", default=1, type=int, help="data-parallel ranks (launch with torch.distributed.run)")
     ap.add_argument("--synthetic", default=0, type=int, help="N items of a synthetic Globo-like fold (no files)")
     ap.add_argument("--synthetic_train", default=100000, type=int)

@@ -68,6 +68,35 @@ def initial_variables(N, H, Ht, emb_stddev, stddev, weight_seed=2020):
     return out
 
 
+def prefetch_batches(sampler, depth: int = 4):
+    """Iterate sampler.next_batch_arrays() from a producer thread (same order, same RNG stream: only this thread draws
+    from numpy's global generator while it runs) so batch assembly overlaps the upload / step enqueue of the consumer;
+    the ctypes step call and the H2D copy release the GIL."""
+    import queue
+    import threading
+    q = queue.Queue(maxsize=depth)
+    END = object()
+
+    def produce():
+        try:
+            while sampler.has_next():
+                q.put(sampler.next_batch_arrays())
+            q.put(END)
+        except BaseException as e:          # surfaced in the consumer
+            q.put(e)
+
+    th = threading.Thread(target=produce, daemon=True)
+    th.start()
+    while True:
+        item = q.get()
+        if item is END:
+            break
+        if isinstance(item, BaseException):
+            raise item
+        yield item
+    th.join()
+
+
 class Seq2SeqAttNN():
     """The memory network with context/temporal attention, MI355X edition."""
 
@@ -108,7 +137,7 @@ class Seq2SeqAttNN():
             from ..dp import DPEngine
             engine_cls, kw = DPEngine, {"group": args['dp_group']}
         self.engine = engine_cls(params, content, self.publish_time_MWDHM, lr=args['lr'], max_grad=args.get('max_grad'),
-                                 device=args.get('device', 'cuda:0'), **kw)
+                                 device=args.get('device', 'cuda:0'), scoring=args.get('scoring', 'bf16x3'), **kw)
         self._cat = None
         self._store_cache = {}
 
@@ -152,9 +181,8 @@ class Seq2SeqAttNN():
             total = torch.zeros((), dtype=torch.float64, device=eng.dev)
             count = 0
             t0 = time.time()
-            while sampler.has_next():
+            for feed in prefetch_batches(sampler):
                 batch += 1
-                feed = sampler.next_batch_arrays()
                 if batch < 3 and feed["neg"] is not None:
                     print(feed["neg"][0][:10].tolist())
                 crt_loss = eng.train_step(feed)                 # [b] on device; no host sync inside the loop
@@ -192,9 +220,8 @@ class Seq2SeqAttNN():
         batch = 0
         result_items = set()
         pending = []
-        while sampler.has_next():
+        for feed in prefetch_batches(sampler):
             batch += 1
-            feed = sampler.next_batch_arrays()
             rank, topk, ce = eng.eval_step(feed, k=20)
             pending.append((feed, rank.clone(), topk.clone(), ce.clone()))     # device results; drained below
             if batch < 3:
