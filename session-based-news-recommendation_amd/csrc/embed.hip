@@ -555,7 +555,9 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
   a.d = *d; a.tab = *tab; a.bt = *bt; a.g = *g;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;
   long rows = (long)bt->B * bt->T + bt->B;
-  int grid = (int)((rows + 15) / 16);          // >= 4 rows per wave: amortise the LDS zero / flush
+  // rows are a latency chain per wave (ids -> rows -> reductions -> atomics): one row per wave until the chip is
+  // full (512 workgroups), more beyond; the LDS zero / flush per workgroup costs ~2 us
+  int grid = (int)((rows + 3) / 4);
   if (grid < 1) grid = 1;
   if (grid > 512) grid = 512;
   const size_t lds = ((size_t)bt->T * d->ldh + (size_t)SMALL_ROWS * d->ldt + 8) * sizeof(float);

@@ -244,20 +244,23 @@ typedef __attribute__((ext_vector_type(4))) __bf16 xbf16x4;
 // The K loop of these launches is a latency chain (one workgroup per tile, <= 1 workgroup per CU): with 32-deep stages
 // a K = 832 tile paid 26 dependent global-load round trips (~0.75 us each).  Stages are therefore 128 deep: a thread
 // prefetches the whole next 64 x 128 (+ 128 x 64) fp32 slab into registers while the current one is multiplied.
-constexpr int XK = 128;
-constexpr int X3_KC = 2 * XK + 16;   // bytes per row of a k-contiguous bf16 tile (272 = 68 dwords, 68/4 odd: conflict-free b128)
+// Launches with more workgroups than CUs use 64-deep stages instead: 48 KB of LDS per workgroup lets three of them share
+// a CU and hide each other's load latency (a 128-deep stage set is 96 KB: one workgroup per CU).
 constexpr int X3_MC = 192;           // bytes per k-row of an m/n-contiguous bf16 tile (128 + 64 pad: conflict-free tr reads)
-constexpr int X3_PLANE = XK * X3_MC; // 24576 >= 64 * X3_KC
-constexpr int X3_NV = 64 * XK / 4 / 256;   // float4 per thread, operand and stage (8)
+template <int XK> struct X3 {
+  static constexpr int KC = 2 * XK + 16;      // bytes per row of a k-contiguous bf16 tile (KC/16 odd: conflict-free b128)
+  static constexpr int PLANE = XK * X3_MC;    // >= 64 * KC
+  static constexpr int NV = 64 * XK / 4 / 256;   // float4 per thread, operand and stage
+};
 
-template <int LAY>
+template <int LAY, int XK>
 __device__ __forceinline__ void x3_load(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kend, int tid,
-                                        float4 (&reg)[X3_NV]) {
+                                        float4 (&reg)[X3<XK>::NV]) {
 #pragma unroll
-  for (int i = 0; i < X3_NV; ++i) {
+  for (int i = 0; i < X3<XK>::NV; ++i) {
     const int f = tid + 256 * i;
     if (LAY == 0) {
-      const int row = f >> 5, c4 = f & 31;
+      const int row = f / (XK / 4), c4 = f % (XK / 4);
       const int gr = r0 + row, gk = k0 + c4 * 4;
       reg[i] = (gr < rmax && gk < kend) ? ld4(P + (long)gr * ld + gk) : zero4();
     } else {
@@ -267,27 +270,27 @@ __device__ __forceinline__ void x3_load(const float* __restrict__ P, long ld, in
     }
   }
 }
-template <int LAY>
-__device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict__ lo, int tid, const float4 (&reg)[X3_NV]) {
+template <int LAY, int XK>
+__device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict__ lo, int tid, const float4 (&reg)[X3<XK>::NV]) {
 #pragma unroll
-  for (int i = 0; i < X3_NV; ++i) {
+  for (int i = 0; i < X3<XK>::NV; ++i) {
     const int f = tid + 256 * i;
     const float v[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
     xbf16x4 h, l;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
     int off;
-    if (LAY == 0) { const int row = f >> 5, c4 = f & 31; off = row * X3_KC + c4 * 8; }
+    if (LAY == 0) { const int row = f / (XK / 4), c4 = f % (XK / 4); off = row * X3<XK>::KC + c4 * 8; }
     else { const int krow = f >> 4, c4 = f & 15; off = krow * X3_MC + c4 * 8; }
     *reinterpret_cast<xbf16x4*>(hi + off) = h;
     *reinterpret_cast<xbf16x4*>(lo + off) = l;
   }
 }
-// fragment of the 32-row block at `base`, k16 sub-step s (0..7) of the 128-deep stage
-template <int LAY>
+// fragment of the 32-row block at `base`, k16 sub-step s of the XK-deep stage
+template <int LAY, int XK>
 __device__ __forceinline__ xbf16x8 x3_frag(const char* __restrict__ S, int base, int s, int lane) {
   if (LAY == 0) {
-    return *reinterpret_cast<const xbf16x8*>(S + (base + (lane & 31)) * X3_KC + s * 32 + (lane >> 5) * 16);
+    return *reinterpret_cast<const xbf16x8*>(S + (base + (lane & 31)) * X3<XK>::KC + s * 32 + (lane >> 5) * 16);
   } else {
     const int g = lane >> 4, i = lane & 15;
     const int mbase = 16 * (g & 1), kbase = 8 * (g >> 1), q = i >> 2, p = i & 3;
@@ -299,8 +302,9 @@ __device__ __forceinline__ xbf16x8 x3_frag(const char* __restrict__ S, int base,
   }
 }
 
-template <int LA, int LB>
+template <int LA, int LB, int XK>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
+  constexpr int X3_PLANE = X3<XK>::PLANE, X3_NV = X3<XK>::NV;
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
   char* smem = reinterpret_cast<char*>(smem_f);     // A hi, A lo, B hi, B lo (one stage)
   constexpr int T = 64;
@@ -337,23 +341,23 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
     const int a_rmax = (LA == 0) ? g.M : min((int)lda, (g.M + 3) & ~3);
     const int b_rmax = (LB == 0) ? g.N : min((int)ldb, (g.N + 3) & ~3);
     if (nit > 0) {
-      x3_load<LA>(Ap, lda, m0, a_rmax, ks, ke, tid, ra);
-      x3_load<LB>(Bp, ldb, n0, b_rmax, ks, ke, tid, rb);
+      x3_load<LA, XK>(Ap, lda, m0, a_rmax, ks, ke, tid, ra);
+      x3_load<LB, XK>(Bp, ldb, n0, b_rmax, ks, ke, tid, rb);
     }
     for (int it = 0; it < nit; ++it) {
       __syncthreads();                                        // everyone is done reading the previous stage
-      x3_store<LA>(smem, smem + X3_PLANE, tid, ra);
-      x3_store<LB>(smem + 2 * X3_PLANE, smem + 3 * X3_PLANE, tid, rb);
+      x3_store<LA, XK>(smem, smem + X3_PLANE, tid, ra);
+      x3_store<LB, XK>(smem + 2 * X3_PLANE, smem + 3 * X3_PLANE, tid, rb);
       __syncthreads();
       if (it + 1 < nit) {                                     // next slab in flight during the MFMAs
-        x3_load<LA>(Ap, lda, m0, a_rmax, ks + (it + 1) * XK, ke, tid, ra);
-        x3_load<LB>(Bp, ldb, n0, b_rmax, ks + (it + 1) * XK, ke, tid, rb);
+        x3_load<LA, XK>(Ap, lda, m0, a_rmax, ks + (it + 1) * XK, ke, tid, ra);
+        x3_load<LB, XK>(Bp, ldb, n0, b_rmax, ks + (it + 1) * XK, ke, tid, rb);
       }
       const int nsub = min(XK, ke - (ks + it * XK) + 15) >> 4;      // k16 sub-steps that hold data
 #pragma unroll 2
       for (int s = 0; s < nsub; ++s) {
-        const xbf16x8 ah = x3_frag<LA>(smem, wm * 32, s, lane), al = x3_frag<LA>(smem + X3_PLANE, wm * 32, s, lane);
-        const xbf16x8 bh = x3_frag<LB>(smem + 2 * X3_PLANE, wn * 32, s, lane), bl = x3_frag<LB>(smem + 3 * X3_PLANE, wn * 32, s, lane);
+        const xbf16x8 ah = x3_frag<LA, XK>(smem, wm * 32, s, lane), al = x3_frag<LA, XK>(smem + X3_PLANE, wm * 32, s, lane);
+        const xbf16x8 bh = x3_frag<LB, XK>(smem + 2 * X3_PLANE, wn * 32, s, lane), bl = x3_frag<LB, XK>(smem + 3 * X3_PLANE, wn * 32, s, lane);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
@@ -418,6 +422,19 @@ int launch_layout(GroupArgs& ga, hipStream_t st) {
   return launch_variant<LA, LB, 64, 64>(ga, wg, st);
 }
 
+template <int LA, int LB, int XK>
+int launch_x3_v(const GroupArgs& ga, int wg, hipStream_t st) {
+  constexpr size_t lds = 4 * X3<XK>::PLANE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<LA, LB, XK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  TCAR_LAUNCH((gemm_x3_kernel<LA, LB, XK>), dim3(wg), dim3(256), lds, st, ga);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
 template <int LA, int LB>
 int launch_x3(GroupArgs& ga, hipStream_t st) {
   int wg = 0;
@@ -428,15 +445,8 @@ int launch_x3(GroupArgs& ga, hipStream_t st) {
     p.wg_begin = wg;
     wg += p.mt * p.nt * p.ksplit;
   }
-  constexpr size_t lds = 4 * X3_PLANE;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
-  TCAR_LAUNCH((gemm_x3_kernel<LA, LB>), dim3(wg), dim3(256), lds, st, ga);
-  TCAR_CHECK_LAUNCH();
-  return TCAR_OK;
+  // <= one workgroup per CU: a pure latency chain, deep stages; more: shallow stages, three workgroups per CU
+  return wg > 256 ? launch_x3_v<LA, LB, 64>(ga, wg, st) : launch_x3_v<LA, LB, 128>(ga, wg, st);
 }
 
 int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {
