@@ -142,16 +142,17 @@ __global__ __launch_bounds__(256) void gather_clip_fwd_kernel(const EmbArgs a) {
 }
 
 // ----------------------------------------------------------------------------------------------- backward
-template <int NCH>
+template <int NCH, int LDT>   // LDT = ldt (64 / 128 / 256): the 16-lane-group geometry of the small tables is compile time
 __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave_g = blockIdx.x * 4 + (tid >> 6);
   const int nwaves = gridDim.x * 4;
   const int B = a.bt.B, T = a.bt.T, BT = B * T;
-  const int ldh = a.d.ldh, ldt = a.d.ldt;
+  const int ldh = a.d.ldh;
+  constexpr int ldt = LDT;
   const int ic = 2 * ldh, pt = 5 * ldt, ek = ic + pt, ct = 2 * ldt;
-  const int sub = ldt >> 2, gpw = 64 / sub;
+  constexpr int sub = LDT >> 2, gpw = 64 / sub, NIT = (6 + gpw - 1) / gpw;
   const int grp = lane / sub, lin = lane - grp * sub;
   float* pos_acc = lds;                       // [T, ldh]
   float* small_acc = lds + T * ldh;           // [150, ldt]
@@ -170,7 +171,21 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
       const int n = clampi(a.bt.seq[row], 1, a.d.n_items) - 1;
       const float* e = a.tab.E + (long)n * ek;
       const float* gy = a.dx_icp + (long)row * ic;
-      float4 xi[NCH], xp[NCH], gi[NCH];
+      // every load of the row is issued before its first use: the ids of the six small tables first, then all rows
+      // (a row is otherwise a chain of 5-6 dependent global round trips, ~9 us per row and wave)
+      int kid[NIT];
+      bool kval[NIT], kact[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int k = it * gpw + grp;
+        kval[it] = k < 6;
+        const int kk = kval[it] ? k : 0;
+        int id = (kk < 5) ? pick5(a.bt.pub, kk)[row] : a.bt.gap[row];
+        const bool oob = (kk == 5) && (id >= TCAR_DUR_VOCAB || id < 0);   // dwell bucket 11 (S7)
+        kid[it] = clampi(id, 0, time_vocab(kk) - 1);
+        kact[it] = kval[it] && !oob;
+      }
+      float4 xi[NCH], xp[NCH], gi[NCH], kx[NIT], kgy[NIT];
       float ssi = 0.f, di = 0.f, ssp = 0.f, dp = 0.f;
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -179,6 +194,17 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
         xi[c] = ok ? ld4(e + col) : zero4();
         xp[c] = ok ? ld4(a.tab.pos + (long)t * ldh + col) : zero4();
         gi[c] = ok ? ld4(gy + col) : zero4();
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int kk = kval[it] ? it * gpw + grp : 0;
+        const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
+        const float* gp = (kk < 5) ? a.dx_pt + (long)row * pt + kk * ldt : a.dx_act + (long)row * ldt;
+        kx[it] = kact[it] ? ld4(tp + (long)kid[it] * ldt + lin * 4) : zero4();
+        kgy[it] = kval[it] ? ld4(gp + lin * 4) : zero4();
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
         ssi += dot4(xi[c], xi[c]); di += dot4(xi[c], gi[c]);
         ssp += dot4(xp[c], xp[c]); dp += dot4(xp[c], gi[c]);
       }
@@ -199,30 +225,21 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
           atomic_add4(pos_acc + t * ldh + col, gp);
         }
       }
-      for (int k0 = 0; k0 < 6; k0 += gpw) {
-        const int k = k0 + grp;
-        const bool valid = k < 6;
-        const int kk = valid ? k : 0;
-        int id = (kk < 5) ? pick5(a.bt.pub, kk)[row] : a.bt.gap[row];
-        const bool oob = (kk == 5) && (id >= TCAR_DUR_VOCAB || id < 0);
-        id = clampi(id, 0, time_vocab(kk) - 1);
-        const bool act = valid && !oob;
-        const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
-        const float* gp = (kk < 5) ? a.dx_pt + (long)row * pt + kk * ldt : a.dx_act + (long)row * ldt;
-        float4 x = act ? ld4(tp + (long)id * ldt + lin * 4) : zero4();
-        float4 gyv = valid ? ld4(gp + lin * 4) : zero4();
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int kk = kval[it] ? it * gpw + grp : 0;
+        const float4 x = kx[it], gyv = kgy[it];
         const float ss = group_sum(dot4(x, x), sub), dd = group_sum(dot4(x, gyv), sub);
         float ca, cb;
         clip_bwd_coef(ss, dd, ca, cb);
-        if (valid) {
+        if (kval[it]) {
           // an out-of-range dwell id gathers a zero row (S7): its gradient row still belongs to the
           // IndexedSlices values (it counts in the clip norm) but is dropped by the scatter
           float4 gx = fma4(x, -cb, scale4(gyv, ca));
           const float q = dot4(gx, gx);
-          // per-lane partial of sum-of-squares, routed to the slot of table kk
 #pragma unroll
-          for (int s = 0; s < 6; ++s) sq[2 + s] += (s == kk) ? q : 0.f;
-          if (act) atomic_add4(small_acc + (time_rowoff(kk) + id) * ldt + lin * 4, gx);
+          for (int s2 = 0; s2 < 6; ++s2) sq[2 + s2] += (s2 == kk) ? q : 0.f;
+          if (kact[it]) atomic_add4(small_acc + (time_rowoff(kk) + kid[it]) * ldt + lin * 4, gx);
         }
       }
     } else {
@@ -563,13 +580,18 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
   const size_t lds = ((size_t)bt->T * d->ldh + (size_t)SMALL_ROWS * d->ldt + 8) * sizeof(float);
   if (lds > 160 * 1024) return TCAR_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+#define TCAR_GBWD(NCH_, LDT_)                                                                                         \
+  do {                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<NCH_, LDT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              160 * 1024);                                                                            \
+    TCAR_LAUNCH((gather_clip_bwd_kernel<NCH_, LDT_>), dim3(grid), dim3(256), lds, st, a);                             \
+  } while (0)
   if (d->ldh <= 256) {
-    (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    TCAR_LAUNCH(gather_clip_bwd_kernel<1>, dim3(grid), dim3(256), lds, st, a);
+    if (d->ldt == 64) TCAR_GBWD(1, 64); else if (d->ldt == 128) TCAR_GBWD(1, 128); else TCAR_GBWD(1, 256);
   } else {
-    (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    TCAR_LAUNCH(gather_clip_bwd_kernel<2>, dim3(grid), dim3(256), lds, st, a);
+    if (d->ldt == 64) TCAR_GBWD(2, 64); else if (d->ldt == 128) TCAR_GBWD(2, 128); else TCAR_GBWD(2, 256);
   }
+#undef TCAR_GBWD
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

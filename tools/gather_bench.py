@@ -60,3 +60,32 @@ rd = B * (3536.0 * T + 512)                 # bytes read per ses
 wr = rd
 print("gather_clip_fwd: rows=%d  %.3f ms  read %.1f GB/s  read+write %.1f GB/s  (%.0f %% / %.0f %% of 8 TB/s)" %
       (B * T, ms, rd / ms / 1e6, (rd + wr) / ms / 1e6, rd / ms / 1e6 / 80, (rd + wr) / ms / 1e6 / 80))
+
+# ---- backward: atomics into the item gradient vs plain row output (the data-parallel mode), uniform vs skewed item ids
+dx_icp, dx_pt = torch.randn(B * T, ic, device=dev) * 1e-3, torch.randn(B * T, pt, device=dev) * 1e-3
+dx_act, dclick = torch.randn(B * T, ldt, device=dev) * 1e-3, torch.randn(B, ct, device=dev) * 1e-3
+Gi = torch.zeros(N, ldh, device=dev)
+arena = torch.zeros(40 * ldh + 150 * ldt, device=dev)
+sqn = torch.zeros(64, device=dev)
+rows_out = torch.empty(B * T, ldh, device=dev)
+
+
+def grads(with_rows):
+    gr = Grads()
+    gr.g_item, gr.g_pos, gr.sqn = Gi.data_ptr(), arena.data_ptr(), sqn.data_ptr()
+    off = 40 * ldh
+    for k, v in enumerate((13, 32, 8, 25, 61)):
+        gr.g_time[k] = arena.data_ptr() + 4 * off
+        gr.slot_time[k] = 2 + k
+        off += v * ldt
+    gr.g_dur = arena.data_ptr() + 4 * off
+    gr.slot_item, gr.slot_pos, gr.slot_dur = 0, 1, 7
+    gr.rows_out = rows_out.data_ptr() if with_rows else None
+    return gr
+
+
+for label_, wr_ in (("atomics", False), ("rows_out", True)):
+    gr = grads(wr_)
+    ms = timeit(lambda: lib.tcar_gather_clip_bwd(C.byref(d), C.byref(tab), C.byref(bt), p(dx_icp), p(dx_pt), p(dx_act), p(dclick),
+                                                 C.byref(gr), None))
+    print("gather_clip_bwd (%s, uniform ids): rows=%d  %.1f us  %.1f ns/row" % (label_, B * T + B, ms * 1e3, ms * 1e6 / (B * T + B)))
