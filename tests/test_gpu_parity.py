@@ -574,3 +574,28 @@ def test_negative_term_split_and_fused_reduce(lib):
     want[:, :ic] += part.cpu().numpy()
     want *= 1 - att.astype(np.float64) ** 2
     close(out.cpu().numpy(), want, name="dattout numpy", rtol=1e-5)
+
+
+@pytest.mark.parametrize("scoring", ["f32", "bf16x3"])
+def test_step_without_negatives(scoring):
+    """a feed without the sampled negatives (model_combine.py:142-143 contribute nothing): loss = CE, the item gradient
+    has no negative rows, and a step following a step WITH negatives does not reuse their stale forward outputs"""
+    _need_gpu()
+    from oracle.tcar_oracle import TcarOracle
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 400, 250, 64, 33, 3, 6
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=91)
+    eng = TcarEngine(params, content, mw, scoring=scoring)
+    ora = TcarOracle(params, content, mw)
+    eng.loss_and_grads(batch)                              # with negatives first (fills the negative-term buffers)
+    plain = {k: v for k, v in batch.items() if k != "neg"}
+    loss = eng.loss_and_grads(plain)
+    o, g_o, sq_o = ora.loss_and_grads(plain)
+    close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss")
+    close(loss.cpu().numpy(), o["ce"].detach().numpy(), name="loss == ce")
+    g_e, sq_e = eng.export_grads(), eng.export_sqnorms()
+    for k in g_o:
+        close(g_e[k], g_o[k].numpy(), name="grad " + k, atol_scale=5e-5)
+        assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12, ("sqnorm", k, sq_e[k], sq_o[k])
+    le, lo = eng.train_step(plain), ora.train_step(plain)
+    close(le.cpu().numpy(), lo.numpy(), name="train loss")
