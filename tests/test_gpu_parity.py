@@ -599,3 +599,57 @@ def test_step_without_negatives(scoring):
         assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12, ("sqnorm", k, sq_e[k], sq_o[k])
     le, lo = eng.train_step(plain), ora.train_step(plain)
     close(le.cpu().numpy(), lo.numpy(), name="train loss")
+
+
+def test_catalog_beyond_int32_flat_indices():
+    """N = 4.3 M items at B = 512: B * Npad > 2^31, so any 32-bit flat index into the [B, N] score matrix, the bf16
+    planes or E would wrap.  Size-independent properties on the highest rows / columns (no oracle run at this size)."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 4_300_000, 250, 64, 512, 2, 4
+    if torch.cuda.get_device_properties(0).total_memory < 150e9:
+        pytest.skip("needs ~70 GB of device memory")
+    rng = np.random.RandomState(7)
+    from tcar_amd.host.model import initial_variables
+    np.random.seed(7)
+    params = initial_variables(N, H, Ht, 0.05, 0.05, weight_seed=7)
+    content = (rng.standard_normal((N + 1, H)).astype(np.float32) * 0.5)
+    content[0] = 0
+    mw = np.stack([rng.randint(1, 13, N), rng.randint(1, 32, N), rng.randint(1, 8, N), rng.randint(1, 25, N),
+                   rng.randint(1, 61, N)], -1).astype(np.int32)
+    b = {"seq": rng.randint(1, N + 1, (B, T)), "label": rng.randint(0, N, B), "pm": rng.randint(1, 13, (B, T)),
+         "pd": rng.randint(1, 32, (B, T)), "pw": rng.randint(1, 8, (B, T)), "ph": rng.randint(1, 25, (B, T)),
+         "pmi": rng.randint(1, 61, (B, T)), "cw": rng.randint(0, 7, B), "ch": rng.randint(0, 24, B),
+         "gap": rng.randint(0, 11, (B, T)), "neg": rng.randint(0, N, (B, K))}
+    b = {k: v.astype(np.int32) for k, v in b.items()}
+    b["label"][-1] = N - 1                    # the very last score of the last row: flat index B * Npad - pad
+    b["seq"][-1, :] = N                       # highest item row on the session side
+    b["neg"][-1, :] = N - 1
+    eng = TcarEngine(params, content, mw, scoring="bf16x3")
+    rank, topk, ce, logits = eng.eval_step(b, keep_logits=True)
+    lab = torch.as_tensor(b["label"], dtype=torch.long, device="cuda")
+    for r in (0, B // 2, B - 1):                                       # row-wise, to keep the fp64 copies small
+        lg = logits[r].double()
+        assert int(rank[r]) == int((lg > lg[lab[r]]).sum()) + 1, r
+        assert abs(float(ce[r]) - float(torch.logsumexp(lg, 0) - lg[lab[r]])) < 1e-3, r
+        tv = lg[topk[r].long()]
+        assert (tv[:-1] >= tv[1:]).all() and float(tv[-1]) >= float(lg.topk(21).values[20])
+    # last row against a direct fp64 dot product of its operands (attout . E^T): catches a wrapped row offset
+    att = eng.attout[B - 1].double()
+    ek = eng.geo.ek
+    hi, lo = eng.e16h.view(-1), eng.e16l.view(-1)
+    assert hi.numel() > 2 ** 31                                          # the planes themselves exceed 2^31 elements
+    k = np.arange(ek)
+    for n in (0, N // 2, N - 1):
+        r = n & 127                                                      # csrc/tcar_bf16_layout.h, one row
+        off = ((n >> 7) * (ek // 32) + (k >> 5)).astype(np.int64) * 4096 + r * 32 + ((((k & 31) >> 3) ^ ((r >> 2) & 3)) << 3 | (k & 7))
+        o = torch.as_tensor(off, device="cuda")
+        row = hi[o].double() + lo[o].double()                            # E row n as the GEMM sees it (item|content|time)
+        assert float((row[:512] - eng.E[n, :512].double()).abs().max()) < 1e-4
+        want = float((row * att).sum())
+        assert abs(float(logits[B - 1, n]) - want) <= 1e-3 * abs(want) + 1e-4, (n, float(logits[B - 1, n]), want)
+    l0 = float(eng.train_step(b).sum())
+    for _ in range(3):
+        l1 = float(eng.train_step(b).sum())
+    assert np.isfinite(l1) and l1 < l0
+    assert float(eng.E[N:].abs().max()) == 0.0                           # padding rows untouched
