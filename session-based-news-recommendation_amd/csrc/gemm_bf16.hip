@@ -65,10 +65,12 @@ __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int
   }
 }
 
-template <int MA, int MB, int NSPLIT, int WMW, int WNW>
+// TMW x TNW = MFMA tiles (32 x 32) per wave along M / N: 2 x 2 for the 4-waves-per-SIMD shapes, 4 x 3 (12 accumulator
+// tiles = 192 registers, 2 waves per SIMD) for the 256 x 384 workgroup tile of the logits GEMM
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2>
 __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = WMW * WNW, TM = 64 * WMW, TN = 64 * WNW;
+  constexpr int NW = WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW;
   constexpr int NP = (NSPLIT == 1) ? 1 : 2;                 // planes per operand
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64;       // one plane of one operand, one stage
   constexpr int PL = A_BYTES + B_BYTES;                     // LDS stage = [plane][A | B]
@@ -98,11 +100,11 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
   const int ke = min(g.K, ks + g.kchunk);
   const int nit = (ke - ks) / KB;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TMW][TNW];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TMW; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TNW; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
@@ -139,24 +141,25 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
     const char* St = smem + (t & 1) * STAGE;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 a[NP][2], b[NP][2];
+      bf16x8 a[NP][TMW];
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          a[p][u] = frag<MA>(St + p * PL, wm * 64 + u * 32, s, lane);
-          b[p][u] = frag<MB>(St + p * PL + A_BYTES, wn * 64 + u * 32, s, lane);
-        }
+        for (int u = 0; u < TMW; ++u) a[p][u] = frag<MA>(St + p * PL, wm * (32 * TMW) + u * 32, s, lane);
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int t2 = 0; t2 < TNW; ++t2) {          // one B tile at a time: its fragments die after TMW * NSPLIT MFMAs
+        bf16x8 b[NP];
 #pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
+        for (int p = 0; p < NP; ++p) b[p] = frag<MB>(St + p * PL + A_BYTES, wn * (32 * TNW) + t2 * 32, s, lane);
+#pragma unroll
+        for (int u = 0; u < TMW; ++u) {
           if constexpr (NSPLIT == 3) {
-            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0][t2], acc[u][t2], 0, 0, 0);
-            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1][t2], acc[u][t2], 0, 0, 0);
+            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0], acc[u][t2], 0, 0, 0);
+            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1], acc[u][t2], 0, 0, 0);
           }
-          acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0][t2], acc[u][t2], 0, 0, 0);
+          acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0], acc[u][t2], 0, 0, 0);
         }
+      }
     }
   };
 
@@ -171,14 +174,14 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
   float* C1 = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
   const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < TMW; ++u)
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int col = n0 + wn * 64 + t * 32 + li;
+    for (int t = 0; t < TNW; ++t) {
+      const int col = n0 + wn * (32 * TNW) + t * 32 + li;
       if (col >= g.N) continue;
       float* base = (col < g.csplit) ? C1 + col : g.C2 + (col - g.csplit);
       const long ld = (col < g.csplit) ? g.ldc : g.ldc2;
-      const int row0 = m0 + wm * 64 + u * 32 + 4 * lh;
+      const int row0 = m0 + wm * (32 * TMW) + u * 32 + 4 * lh;
       if (m0 + TM <= g.M) {            // interior tile (workgroup-uniform): 16 unguarded stores, no per-element branch
         float* pr = base + (long)row0 * ld;
 #pragma unroll
@@ -226,19 +229,19 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
-template <int MA, int MB, int NSPLIT, int WMW, int WNW>
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2>
 int launch_v(BArgs& g, int splitk, hipStream_t st) {
-  constexpr int NT = 64 * WMW * WNW, TM = 64 * WMW, TN = 64 * WNW, NP = (NSPLIT == 1) ? 1 : 2;
+  constexpr int NT = 64 * WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW, NP = (NSPLIT == 1) ? 1 : 2;
   constexpr size_t lds = 2 * NP * (TM + TN) * 64;
   g.mt = (g.M + TM - 1) / TM;
   g.nt = (g.N + TN - 1) / TN;
   static bool done = false;
   if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW>,
+    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     done = true;
   }
-  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
+  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -252,6 +255,13 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
   const int f = force ? atoi(force) : 0;
   const long w256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splitk;
   const long w128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
+  if constexpr (MA == 0 && MB == 0) {
+    // 256 x 384 (8 waves, 4 x 3 MFMA tiles each; 160 KB of LDS): the kernel is bound by the L2 -> LDS fill rate, and this
+    // shape moves 17 % fewer bytes per flop than 256 x 256; at the Globo catalog it is also ONE round of 240 workgroups
+    // instead of 360 workgroups in 1.4 rounds
+    const long w384 = (long)((g.M + 255) / 256) * ((g.N + 383) / 384) * splitk;
+    if (nsplit == 3 && (f == 384 || (f == 0 && w384 >= 200))) return launch_v<0, 0, 3, 2, 4, 4, 3>(g, splitk, st);
+  }
   if constexpr (MB == 1) {
     // 256 x 192 (12 waves): an N extent such as 576 = 3 x 192 wastes no MFMA work on padding columns (256-wide tiles
     // would run a third, three-quarters-empty tile column)

@@ -653,3 +653,28 @@ def test_catalog_beyond_int32_flat_indices():
         l1 = float(eng.train_step(b).sum())
     assert np.isfinite(l1) and l1 < l0
     assert float(eng.E[N:].abs().max()) == 0.0                           # padding rows untouched
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 40000, 96), (512, 38417, 64)])
+def test_gemm_bf16_large_n_tiles(lib, M, N, K):
+    """shapes whose workgroup count selects the 256 x 384 (8 waves, 4 x 3 MFMA tiles per wave) and 256 x 256 tiles of the
+    logits GEMM, ragged in both M and N"""
+    rng = np.random.RandomState(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = (rng.standard_normal((N, K)) * 0.5 + 0.25).astype(np.float32)
+    want = A.astype(np.float64) @ Bm.astype(np.float64).T
+    ah, al, ai, ar = _planes(lib, A)
+    bh, bl, bi, br = _planes(lib, Bm)
+    ldc = (N + 127) // 128 * 128
+    dC = torch.full((M, ldc), 7.0, device="cuda")
+    for env in ("384", "256"):
+        os.environ["TCAR_BF16_TILE"] = env
+        try:
+            dC.fill_(7.0)
+            assert lib.tcar_gemm_bf16(1, M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(dC), ldc, None, 0,
+                                      0, 3, 1, None) == 0
+            got = dC.cpu().numpy()
+        finally:
+            del os.environ["TCAR_BF16_TILE"]
+        close(got[:, :N], want, rtol=1e-3, atol_scale=2e-5, name="bf16 gemm tile " + env)
+        assert (got[:, N:] == 7.0).all()
