@@ -262,6 +262,14 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
     const long w384 = (long)((g.M + 255) / 256) * ((g.N + 383) / 384) * splitk;
     if (nsplit == 3 && (f == 384 || (f == 0 && w384 >= 200))) return launch_v<0, 0, 3, 2, 4, 4, 3>(g, splitk, st);
   }
+  if constexpr (MA == 0 && MB == 1) {
+    // 512 x 128 (16 waves): the whole session batch is ONE M tile, so every dlogits stage is fetched once per N tile and
+    // the fill bytes per flop drop 16 % against two 256 x 128 tiles (dX: 170 -> 147 us at split-K 36)
+    const long w512 = (long)((g.M + 511) / 512) * ((g.N + 127) / 128) * splitk;
+    static const bool dx512 = !(getenv("TCAR_DX512") && atoi(getenv("TCAR_DX512")) == 0);
+    if (f == 512 || (f == 0 && dx512 && g.M > 256 && w512 >= 192))
+      return nsplit == 3 ? launch_v<0, 1, 3, 8, 2>(g, splitk, st) : launch_v<0, 1, 1, 8, 2>(g, splitk, st);
+  }
   if constexpr (MB == 1) {
     // 256 x 192 (12 waves): an N extent such as 576 = 3 x 192 wastes no MFMA work on padding columns (256-wide tiles
     // would run a third, three-quarters-empty tile column)

@@ -102,7 +102,7 @@ N_ATOMIC = 9
 class TcarEngine:
     def __init__(self, params: Dict[str, np.ndarray], content_emb: np.ndarray, mwdhm: np.ndarray, lr: float = 1e-3,
                  max_grad: Optional[float] = 150.0, neg_weight: float = 0.01, device: str = "cuda:0",
-                 splitk: int = 16, scoring: str = "f32"):
+                 splitk: Optional[int] = None, scoring: str = "f32"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.TcarError("TcarEngine needs an MI355X (no CPU fallback)")
@@ -115,7 +115,10 @@ class TcarEngine:
         self.b1, self.b2, self.eps = 0.9, 0.999, 1e-8
         self.b1_pow, self.b2_pow = np.float32(self.b1), np.float32(self.b2)
         self.step = 0
-        self.splitk = splitk
+        # split-K of dX = dlogits E: 36 slabs with the 512 x 128 bf16 tile (7 N tiles x 36 = 252 workgroups), 16 in fp32
+        self.splitk = splitk if splitk else (16 if scoring == "f32" else 36)
+        if os.environ.get("TCAR_SPLITK"):
+            self.splitk = int(os.environ["TCAR_SPLITK"])
         # precision of the three full-catalog scoring GEMMs: "f32" (fp32 MFMA), "bf16x3" (split-bf16 planes, three
         # bf16 MFMAs per product, fp32-class accuracy), "bf16" (hi plane only)
         # "bf16x3-mixed": logits in bf16x3 (fp32-class), the two gradient GEMMs in plain bf16 (mixed-precision backward)
