@@ -274,6 +274,15 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
     // 256 x 192 (12 waves): an N extent such as 576 = 3 x 192 wastes no MFMA work on padding columns (256-wide tiles
     // would run a third, three-quarters-empty tile column)
     const int n192 = (g.N + 191) / 192 * 192, n256 = (g.N + 255) / 256 * 256;
+    if constexpr (MA == 1) {
+      // 192 x 192 (12 waves of 1 x 3 MFMA tiles): when 256-row tiles leave a ragged last round (dE at the Globo catalog:
+      // 540 workgroups = 2.1 rounds of 256 CUs) three-quarter-size tiles in 2.8 rounds do 25 % less work per round
+      const long w192 = (long)((g.M + 191) / 192) * (n192 / 192) * splitk;
+      const long r256 = (w256 > 0 ? ((long)((g.M + 255) / 256) * (n192 / 192) * splitk + 255) / 256 : 0) * 4;   // rounds x size
+      const long r192 = ((w192 + 255) / 256) * 3;
+      if (f == 193 || (f == 0 && w256 >= 224 && n192 < n256 && r192 < r256))
+        return nsplit == 3 ? launch_v<1, 1, 3, 6, 2, 1, 3>(g, splitk, st) : launch_v<1, 1, 1, 6, 2, 1, 3>(g, splitk, st);
+    }
     if (f == 192 || (f == 0 && w256 >= 224 && n192 < n256))
       return nsplit == 3 ? launch_v<MA, MB, 3, 4, 3>(g, splitk, st) : launch_v<MA, MB, 1, 4, 3>(g, splitk, st);
   }

@@ -678,3 +678,28 @@ def test_gemm_bf16_large_n_tiles(lib, M, N, K):
             del os.environ["TCAR_BF16_TILE"]
         close(got[:, :N], want, rtol=1e-3, atol_scale=2e-5, name="bf16 gemm tile " + env)
         assert (got[:, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize("tile", ["193", "192", "256"])
+def test_gemm_bf16_de_tiles(lib, tile):
+    """the dE layout (both operands read transposed) on its three workgroup tiles: 192 x 192 (12 waves of 1 x 3 MFMA
+    tiles), 256 x 192 and 256 x 256, with the dual (item | time) destination and ragged M"""
+    rng = np.random.RandomState(11)
+    M, N, K = 1000, 576, 96
+    A = rng.standard_normal((K, M)).astype(np.float32)
+    Bm = (rng.standard_normal((K, N)) * 0.5 + 0.25).astype(np.float32)
+    want = A.astype(np.float64).T @ Bm.astype(np.float64)
+    ah, al, ai, ar = _planes(lib, A)
+    bh, bl, bi, br = _planes(lib, Bm)
+    c1 = torch.full((M, 260), 7.0, device="cuda")
+    c2 = torch.full((M, 324), 7.0, device="cuda")
+    os.environ["TCAR_BF16_TILE"] = tile
+    try:
+        assert lib.tcar_gemm_bf16(2, M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(c1), 260, ptr(c2), 324,
+                                  256, 3, 1, None) == 0
+        g1, g2 = c1.cpu().numpy(), c2.cpu().numpy()
+    finally:
+        del os.environ["TCAR_BF16_TILE"]
+    close(g1[:, :256], want[:, :256], rtol=1e-3, atol_scale=2e-5, name="dE item block")
+    close(g2[:, :320], want[:, 256:], rtol=1e-3, atol_scale=2e-5, name="dE time block")
+    assert (g1[:, 256:] == 7.0).all() and (g2[:, 320:] == 7.0).all()
