@@ -16,6 +16,7 @@ HBM layout (fp32, "padded-concat space", see include/tcar_hip.h):
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from collections import OrderedDict
 from typing import Dict, Optional
@@ -99,6 +100,27 @@ ARENA = [
 N_ATOMIC = 9
 
 
+_HP_STREAMS: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def use_priority_stream(dev: torch.device) -> None:
+    """Make ONE process-wide high-priority stream the current stream of `dev`.  The main chain of a step (logits ->
+    softmax -> dX -> the long tail of small kernels -> Adam) is the critical path, the aux stream's dE GEMM and
+    candidate-time work have slack: with the main chain on a priority -1 stream its workgroups are dispatched first
+    whenever both streams have work queued (measured 0.752 -> 0.731 ms per step).  Setting the current stream once
+    (instead of entering / leaving a stream per step) costs no per-step events.
+    SIDE EFFECT: torch.cuda.current_stream(dev) changes for the whole process; code that mixes the engine with launches
+    on the NULL stream must pass torch.cuda.current_stream().cuda_stream instead.  TCAR_NO_PRIO=1 disables it."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    hp = _HP_STREAMS.get(idx)
+    if hp is None:
+        hp = _HP_STREAMS[idx] = torch.cuda.Stream(dev, priority=-1)
+    cur = torch.cuda.current_stream(dev)
+    if cur != hp:
+        hp.wait_stream(cur)
+        torch.cuda.set_stream(hp)
+
+
 class TcarEngine:
     def __init__(self, params: Dict[str, np.ndarray], content_emb: np.ndarray, mwdhm: np.ndarray, lr: float = 1e-3,
                  max_grad: Optional[float] = 150.0, neg_weight: float = 0.01, device: str = "cuda:0",
@@ -108,6 +130,8 @@ class TcarEngine:
             raise _lib.TcarError("TcarEngine needs an MI355X (no CPU fallback)")
         self.dev = torch.device(device)
         self.is_cuda = self.dev.type == "cuda"
+        if self.is_cuda and self.overlap and self.native and not os.environ.get("TCAR_NO_PRIO"):
+            use_priority_stream(self.dev)
         N, H = content_emb.shape[0] - 1, content_emb.shape[1]
         Ht = params["month_embedding"].shape[1]
         self.geo = g = Geometry(N, H, Ht)

@@ -15,3 +15,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _default_stream_per_test():
+    """TcarEngine makes a process-wide high-priority stream the CURRENT stream (engine.use_priority_stream).  The op-level
+    tests pass stream = NULL to the C-ABI, so every test starts (synchronised) on the default stream again."""
+    yield
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.set_stream(torch.cuda.default_stream())
+    except ImportError:
+        pass
