@@ -280,6 +280,13 @@ int tcar_clip_adam_2d_bf16(float* w, int64_t ldw, const float* g, float* m, floa
                            int64_t ld16, void* stream);
 
 /* Library self-description (for loaders). */
+/* tcar_clip_adam_all: tcar_clip_adam over the arena segments AND tcar_clip_adam_2d_bf16 over the item table in ONE launch
+ * (the arena update is a 14-us latency-bound launch on its own; here its blocks ride behind the item table's). */
+int tcar_clip_adam_all(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,
+                       const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot,
+                       const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t,
+                       float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, void* stream);
+
 int tcar_abi_version(void);
 
 /* ---- step-level entry points ------------------------------------------------------------------------------------

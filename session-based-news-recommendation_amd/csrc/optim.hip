@@ -62,16 +62,14 @@ __device__ __forceinline__ void adam4(float4& w, const float4 g, float4& m, floa
   w.z -= lr_t * m.z / (sqrtf(v.z) + eps); w.w -= lr_t * m.w / (sqrtf(v.w) + eps);
 }
 
-__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ w, const float* __restrict__ g,
-                                                        float* __restrict__ m, float* __restrict__ v, const SegArgs a,
-                                                        const float* __restrict__ sqn_dense,
-                                                        const float* __restrict__ sqn_pieces,
-                                                        const int32_t* __restrict__ use_dense, float clip, float lr_t,
-                                                        float b1, float b2, float eps) {
-  const int seg = blockIdx.y;
+__device__ __forceinline__ void arena_adam_block(int seg, int chunk, float* __restrict__ w, const float* __restrict__ g,
+                                                 float* __restrict__ m, float* __restrict__ v, const SegArgs& a,
+                                                 const float* __restrict__ sqn_dense, const float* __restrict__ sqn_pieces,
+                                                 const int32_t* __restrict__ use_dense, float clip, float lr_t, float b1,
+                                                 float b2, float eps) {
   const long off = a.s.off[seg];
   const long len = a.s.len[seg];
-  const long base = (long)blockIdx.x * 4096;
+  const long base = (long)chunk * 4096;
   if (base >= len) return;
   const float sc = clip_factor(sqn_dense, sqn_pieces, use_dense, a.s.slot[seg], clip);
 #pragma unroll
@@ -86,18 +84,26 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ w, c
   }
 }
 
-// item table inside E: w [rows, cols] with leading dim ldw; g, m, v compact [rows, cols]
-__global__ __launch_bounds__(256) void clip_adam_2d_kernel(float* __restrict__ w, long ldw, const float* __restrict__ g,
-                                                           float* __restrict__ m, float* __restrict__ v, long rows,
-                                                           int cols, int slot, const float* __restrict__ sqn_dense,
-                                                           const float* __restrict__ sqn_pieces,
-                                                           const int32_t* __restrict__ use_dense, float clip, float lr_t,
-                                                           float b1, float b2, float eps, __bf16* __restrict__ eh,
-                                                           __bf16* __restrict__ el, long ld16) {
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ w, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, const SegArgs a,
+                                                        const float* __restrict__ sqn_dense,
+                                                        const float* __restrict__ sqn_pieces,
+                                                        const int32_t* __restrict__ use_dense, float clip, float lr_t,
+                                                        float b1, float b2, float eps) {
+  arena_adam_block(blockIdx.y, blockIdx.x, w, g, m, v, a, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps);
+}
+
+// item table inside E: w [rows, cols] with leading dim ldw; g, m, v compact [rows, cols]; blocks [0, nblk) stride over it
+__device__ __forceinline__ void item_adam_blocks(int blk, int nblk, float* __restrict__ w, long ldw,
+                                                 const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                 long rows, int cols, int slot, const float* __restrict__ sqn_dense,
+                                                 const float* __restrict__ sqn_pieces, const int32_t* __restrict__ use_dense,
+                                                 float clip, float lr_t, float b1, float b2, float eps,
+                                                 __bf16* __restrict__ eh, __bf16* __restrict__ el, long ld16) {
   const float sc = clip_factor(sqn_dense, sqn_pieces, use_dense, slot, clip);
   const int c4 = cols >> 2;
   const long total = rows * c4;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
     const long r = i / c4;
     const int c = (int)(i - r * c4) * 4;
     const long p = r * cols + c;
@@ -114,6 +120,36 @@ __global__ __launch_bounds__(256) void clip_adam_2d_kernel(float* __restrict__ w
       *reinterpret_cast<bf16x4_t*>(eh + o) = h;
       *reinterpret_cast<bf16x4_t*>(el + o) = l;
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void clip_adam_2d_kernel(float* __restrict__ w, long ldw, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, long rows,
+                                                           int cols, int slot, const float* __restrict__ sqn_dense,
+                                                           const float* __restrict__ sqn_pieces,
+                                                           const int32_t* __restrict__ use_dense, float clip, float lr_t,
+                                                           float b1, float b2, float eps, __bf16* __restrict__ eh,
+                                                           __bf16* __restrict__ el, long ld16) {
+  item_adam_blocks(blockIdx.x, gridDim.x, w, ldw, g, m, v, rows, cols, slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1,
+                   b2, eps, eh, el, ld16);
+}
+
+// every variable in ONE launch: blocks [0, n2d) take the item table, the rest the (segment, chunk) pairs of the arena
+struct AdamAll {
+  float* w2; long ldw; const float* g2; float* m2; float* v2; long rows; int cols, slot; __bf16* eh; __bf16* el; long ld16;
+  int n2d, gx;
+  float* w; const float* g; float* m; float* v;
+  const float* sqn_dense; const float* sqn_pieces; const int32_t* use_dense;
+  float clip, lr_t, b1, b2, eps;
+};
+__global__ __launch_bounds__(256) void clip_adam_all_kernel(const AdamAll p, const SegArgs a) {
+  if ((int)blockIdx.x < p.n2d) {
+    item_adam_blocks(blockIdx.x, p.n2d, p.w2, p.ldw, p.g2, p.m2, p.v2, p.rows, p.cols, p.slot, p.sqn_dense, p.sqn_pieces,
+                     p.use_dense, p.clip, p.lr_t, p.b1, p.b2, p.eps, p.eh, p.el, p.ld16);
+  } else {
+    const int idx = blockIdx.x - p.n2d;
+    arena_adam_block(idx / p.gx, idx % p.gx, p.w, p.g, p.m, p.v, a, p.sqn_dense, p.sqn_pieces, p.use_dense, p.clip, p.lr_t,
+                     p.b1, p.b2, p.eps);
   }
 }
 
@@ -184,6 +220,34 @@ extern "C" int tcar_clip_adam_2d(float* w, int64_t ldw, const float* g, float* m
                                  float clip, float lr_t, float b1, float b2, float eps, void* stream) {
   return tcar_clip_adam_2d_bf16(w, ldw, g, m, v, rows, cols, slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2,
                                 eps, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int tcar_clip_adam_all(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d,
+                                  int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols,
+                                  int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense,
+                                  float clip, float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo,
+                                  int64_t ld16, void* stream) {
+  if (check_segs(segs) || !w || !g || !m || !v || !sqn_dense || !sqn_pieces || !use_dense) return TCAR_E_ARG;
+  if (e16_hi && (!e16_lo || (ld16 & 31))) return TCAR_E_ARG;
+  if (!w2d || !g2d || !m2d || !v2d || rows <= 0 || cols <= 0 || (cols & 3) || (ldw & 3) || slot < 0 || slot >= TCAR_NSLOT)
+    return TCAR_E_ARG;
+  AdamAll p;
+  p.w2 = w2d; p.ldw = ldw; p.g2 = g2d; p.m2 = m2d; p.v2 = v2d; p.rows = rows; p.cols = cols; p.slot = slot;
+  p.eh = (__bf16*)e16_hi; p.el = (__bf16*)e16_lo; p.ld16 = ld16;
+  long total = rows * (cols >> 2);
+  long n2d = (total + 256 * 4 - 1) / (256 * 4);
+  p.n2d = (int)(n2d > 4096 ? 4096 : (n2d < 1 ? 1 : n2d));
+  p.gx = segs->nseg ? seg_grid_x(segs) : 1;
+  if (p.gx < 1) p.gx = 1;
+  p.w = w; p.g = g; p.m = m; p.v = v;
+  p.sqn_dense = sqn_dense; p.sqn_pieces = sqn_pieces; p.use_dense = use_dense;
+  p.clip = clip; p.lr_t = lr_t; p.b1 = b1; p.b2 = b2; p.eps = eps;
+  SegArgs a;
+  a.s = *segs;
+  const int grid = p.n2d + p.gx * segs->nseg;
+  TCAR_LAUNCH(clip_adam_all_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
 }
 
 extern "C" int tcar_abi_version(void) { return 2; }

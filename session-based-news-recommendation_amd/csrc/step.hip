@@ -123,14 +123,6 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
                  W(c, TCAR_V_OT_B), 2);
     RET(small_gemm(c, 0, 2, p, stream));
   }
-  if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart) {
-    // the sampled negative term needs only attout and E: it runs on the aux stream beside the logits GEMM; the
-    // backward pass picks its outputs up after its own fork (which orders the aux stream's earlier work)
-    if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
-      return TCAR_E_LAUNCH;
-    RET(tcar_neg_fwd(&c->d, B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart,
-                     s2 ? (void*)s2 : stream));
-  }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138)
   int ei = -1;
@@ -169,7 +161,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // it runs FIRST on the main stream, so that dE is complete early and its all-reduce overlaps chain A (dp.py)
   void* sB = (s2 && fuse_finish) ? (void*)s2 : stream;
   void* sW = s2 ? (void*)s2 : stream;          // the weight-gradient GEMM
-  const bool has_neg = K > 0 && bt->neg && c->neg_coef && c->negpart;      // tcar_step_forward ran tcar_neg_fwd
+  const bool has_neg = K > 0 && bt->neg && c->neg_coef && c->negpart;
   // zero the gradient arena and the norm slots; with an aux stream this happens beside the softmax, not before it
   // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
   hipStream_t sz = s2 ? s2 : st;
@@ -177,6 +169,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     return TCAR_E_LAUNCH;
   if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
   if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
+  // the forward part of the sampled negative term needs only attout and E: it runs here, beside the softmax
+  if (has_neg)
+    RET(tcar_neg_fwd(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
   if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
@@ -186,11 +181,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   if (s2) {
-    if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess ||
-        hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess)
+    if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
       return TCAR_E_LAUNCH;
   }
-  // ---- chain B
+  // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
+  if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   if (c->scoring) {
     RET(tcar_gemm_bf16(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h, c->ap16l,
                        g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, nsb, 1, sB));
@@ -211,6 +206,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   } else {
     RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
   }
+  // first use of the zeroed arena and of the negative term's forward outputs on the main stream
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
   RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
                               c->dattout, G(c, TCAR_V_O_B), g.ic, G(c, TCAR_V_OT_B), stream));
@@ -308,11 +305,9 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
   if (!c) return TCAR_E_ARG;
   const Geo g(c->d);
   const float* pieces = c->Gx + c->arena_n;
-  RET(tcar_clip_adam(c->W, c->Gx, c->M, c->V, &c->segs_all, c->sqn_dense, pieces, c->use_dense, c->clip, lr_t, c->b1,
-                     c->b2, c->eps, stream));
-  return tcar_clip_adam_2d_bf16(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces,
-                                c->use_dense, c->clip, lr_t, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
-                                c->scoring ? c->e16l : nullptr, g.ek, stream);
+  return tcar_clip_adam_all(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item,
+                            c->sqn_dense, pieces, c->use_dense, c->clip, lr_t, c->b1, c->b2, c->eps,
+                            c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, stream);
 }
 
 extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {
