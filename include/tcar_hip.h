@@ -332,7 +332,7 @@ typedef struct {
   void *e16h, *e16l, *a16h, *a16l, *ap16h, *ap16l, *dl16h, *dl16l;
   /* optional auxiliary stream + 4 events (hipStream_t / hipEvent_t, caller-created): the candidate-side time refresh
    * (forward) and the dE chain (backward) run on it concurrently with the session-side chain; NULL = one stream */
-  void* stream2; void* ev[4];
+  void* stream2; void* ev[6];
   /* optional device timing of the dominant kernel (full-catalog logits GEMM): ev_n pairs of hipEvent_t, used
    * round-robin through the host counter *ev_cursor; ev_n = 0 disables it */
   void* const* ev_start; void* const* ev_stop; int32_t ev_n; int32_t* ev_cursor;

@@ -113,7 +113,7 @@ class Ctx(C.Structure):
                 + [(n, C.c_void_p) for n in _WS]
                 + [("rank", C.c_void_p), ("topk", C.c_void_p), ("scoring", C.c_int32), ("scoring_bwd", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l")]
-                + [("stream2", C.c_void_p), ("ev", C.c_void_p * 4), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+                + [("stream2", C.c_void_p), ("ev", C.c_void_p * 6), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
                    ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p)])
 
 

@@ -61,7 +61,7 @@ inline int small_gemm(const tcar_ctx_t* c, int layout, int n, const tcar_gemm_de
 }
 
 inline hipStream_t aux_stream(const tcar_ctx_t* c) {
-  return (c->stream2 && c->ev[0] && c->ev[1] && c->ev[2] && c->ev[3]) ? (hipStream_t)c->stream2 : nullptr;
+  return (c->stream2 && c->ev[0] && c->ev[1] && c->ev[2] && c->ev[3] && c->ev[4]) ? (hipStream_t)c->stream2 : nullptr;
 }
 
 int check_ctx(const tcar_ctx_t* c, const tcar_batch_t* bt) {
@@ -147,6 +147,8 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
 
 namespace {
 int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream);
+int item_norm(const tcar_ctx_t* c, const Geo& g, void* stream);
+int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream);
 
 // Backward pass.  Two independent chains follow the softmax gradient:
 //   A (main stream):  dX = dlogits E -> attention / projection backward -> weight gradients           (many small kernels)
@@ -195,10 +197,15 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
     RET(small_gemm(c, 2, 2, p, sB));
   }
-  if (has_neg)
+  // Fused single-rank step: the aux stream goes straight on to the candidate-side time backward (it needs only d_et),
+  // while the negative rows and the dense item norm (they need Gi) are appended to the MAIN chain, which has slack
+  // once dX has been given priority.  Rank-local backward: negative rows here, the rest in tcar_step_finish.
+  const bool split_finish = fuse_finish && s2;
+  if (split_finish && hipEventRecord((hipEvent_t)c->ev[4], s2) != hipSuccess) return TCAR_E_LAUNCH;         // dE done
+  if (has_neg && !split_finish)
     RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, sB));
-  if (fuse_finish) RET(finish_dense_side(c, g, sB));
-  if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // dE (+ its finish) done
+  if (fuse_finish) RET(split_finish ? cand_time_backward(c, g, sB) : finish_dense_side(c, g, sB));
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // chain B done
   // ---- chain A
   if (c->scoring) {
     RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
@@ -257,6 +264,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
     RET(small_gemm(c, 1, 4, p, stream));
   }
+  if (split_finish) {   // Gi is complete once dE has landed: negative rows (+ loss), then its norm BEFORE any row scatter (S5)
+    if (hipStreamWaitEvent(st, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
+    if (has_neg)
+      RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, stream));
+    RET(item_norm(c, g, stream));
+  }
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[3], 0) != hipSuccess) return TCAR_E_LAUNCH;    // chain B is done
   if (fuse_finish) {
     // sparse rows and per-row norm pieces (after the dense item norm of chain B), then the dense-weight norms
@@ -273,10 +286,20 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
 
 // clip norm of the dense item block BEFORE the sparse rows are scattered in, then the candidate-side
 // time backward (static inverted index)
-int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream) {
+int item_norm(const tcar_ctx_t* c, const Geo& g, void* stream) {
   tcar_segments_t one = {};
   one.nseg = 1; one.off[0] = 0; one.len[0] = (int64_t)g.N * g.ldh; one.slot[0] = c->slot_item;
-  RET(tcar_sqnorm(c->big, &one, c->sqn_dense, stream));
+  return tcar_sqnorm(c->big, &one, c->sqn_dense, stream);
+}
+int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream) {
+  tcar_grads_t gr;
+  grads_of(c, gr);
+  const float* tt[5];
+  for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+  return tcar_cand_time_bwd_indexed(&c->d, tt, c->inv_n, c->inv_off, c->big + (size_t)g.N * g.ldh, c->ct_ws, &gr, stream);
+}
+int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream) {
+  RET(item_norm(c, g, stream));
   tcar_grads_t gr;
   grads_of(c, gr);
   const float* tt[5];

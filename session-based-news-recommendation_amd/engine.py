@@ -676,7 +676,7 @@ class TcarEngine:
         if self.overlap:
             if not hasattr(self, "_aux"):
                 self._aux = torch.cuda.Stream(self.dev)
-                self._aux_ev = [torch.cuda.Event() for _ in range(4)]
+                self._aux_ev = [torch.cuda.Event() for _ in range(6)]
                 for e in self._aux_ev:
                     e.record(torch.cuda.current_stream(self.dev))      # materialise the hipEvent_t handles
             c.stream2 = self._aux.cuda_stream
