@@ -120,9 +120,11 @@ int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_tab[5], con
 
 /* Same result through a static inverted index (deterministic, no atomics): inv_n [5N] lists, per table row
  * r = rowoff(k)+v (month 0..12, day 13..44, week 45..52, hour 53..77, minute 78..138), the candidates n with
- * mwdhm[n,k] == v; inv_off [140] are the list offsets; ws holds tcar_cand_time_ws_floats(d) floats. */
+ * mwdhm[n,k] == v; inv_off [140] are the list offsets; ws holds tcar_cand_time_ws_floats(d) floats.
+ * permuted != 0: d_et is stored IN LIST ORDER (segment i of ldt floats belongs to list entry i — the layout
+ * tcar_gemm_bf16_perm writes with c2_perm = the inverse of the index), so every list is one contiguous stream. */
 int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* inv_n,
-                               const int32_t* inv_off, const float* d_et, float* ws, const tcar_grads_t* g,
+                               const int32_t* inv_off, const float* d_et, int permuted, float* ws, const tcar_grads_t* g,
                                void* stream);
 int tcar_cand_time_ws_floats(const tcar_dims_t* d);
 
@@ -179,6 +181,15 @@ int tcar_gemm_splitk_effective(int K, int splitk);
 int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
                    const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
                    int64_t ldc2, int csplit, int nsplit, int splitk, void* stream);
+
+/* ..._perm: as tcar_gemm_bf16, with a grouped row permutation of the SECOND destination: element (m, cc) of the C2 block
+ * (cc = column - csplit) is stored at C2[c2_perm[(cc / c2_group) * M + m] * c2_group + cc % c2_group] (ldc2 unused).
+ * The dE GEMM writes the candidate-time block this way, in the order of the static inverted index of
+ * publish_time_MWDHM, so that tcar_cand_time_bwd_indexed streams it (permuted = 1).  c2_perm == NULL: plain layout. */
+int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner,
+                        int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C,
+                        int64_t ldc, float* C2, int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit,
+                        int splitk, void* stream);
 /* fp32 [rows, cols] (ld) -> bf16 hi / lo KB32 planes with inner dimension `inner` (>= cols, % 32 == 0); padding rows
  * up to ceil128(rows) and columns >= cols are zero filled (lo may be NULL).  packed_* != NULL additionally writes
  * columns [0,c0) U [c1,cols) as a second plane pair with inner dimension packed_inner. */
@@ -333,6 +344,7 @@ typedef struct {
   /* optional auxiliary stream + 4 events (hipStream_t / hipEvent_t, caller-created): the candidate-side time refresh
    * (forward) and the dE chain (backward) run on it concurrently with the session-side chain; NULL = one stream */
   void* stream2; void* ev[6];
+  const int32_t* et_perm;   /* [5, N] position of (k, n) in the inverted index (bf16 scoring modes: dE writes d_et in that order) */
   /* optional device timing of the dominant kernel (full-catalog logits GEMM): ev_n pairs of hipEvent_t, used
    * round-robin through the host counter *ev_cursor; ev_n = 0 disables it */
   void* const* ev_start; void* const* ev_stop; int32_t ev_n; int32_t* ev_cursor;

@@ -19,7 +19,7 @@ NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
@@ -113,7 +113,7 @@ class Ctx(C.Structure):
                 + [(n, C.c_void_p) for n in _WS]
                 + [("rank", C.c_void_p), ("topk", C.c_void_p), ("scoring", C.c_int32), ("scoring_bwd", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l")]
-                + [("stream2", C.c_void_p), ("ev", C.c_void_p * 6), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+                + [("stream2", C.c_void_p), ("ev", C.c_void_p * 6), ("et_perm", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
                    ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p)])
 
 
@@ -147,13 +147,15 @@ def load() -> C.CDLL:
     lib.tcar_scatter_add_rows.argtypes = [P(Dims), vp, vp, i64, vp, vp]
     lib.tcar_cand_time_fwd.argtypes = [P(Dims), P(vp * 5), vp, vp, vp]
     lib.tcar_cand_time_bwd.argtypes = [P(Dims), P(vp * 5), vp, vp, P(Grads), vp]
-    lib.tcar_cand_time_bwd_indexed.argtypes = [P(Dims), P(vp * 5), vp, vp, vp, vp, P(Grads), vp]
+    lib.tcar_cand_time_bwd_indexed.argtypes = [P(Dims), P(vp * 5), vp, vp, vp, i32, vp, P(Grads), vp]
     lib.tcar_cand_time_ws_floats.argtypes = [P(Dims)]
     lib.tcar_gemm_f32.argtypes = [i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
     lib.tcar_gemm_f32_grouped.argtypes = [i32, i32, P(GemmDesc), vp]
     lib.tcar_gemm_x3_grouped.argtypes = [i32, i32, P(GemmDesc), vp]
     lib.tcar_gemm_bf16.argtypes = [i32, i32, i32, i32, vp, vp, i64, i64, vp, vp, i64, i64, vp, i64, vp, i64, i32, i32, i32,
                                    vp]
+    lib.tcar_gemm_bf16_perm.argtypes = [i32, i32, i32, i32, vp, vp, i64, i64, vp, vp, i64, i64, vp, i64, vp, i64, i32, vp, i32,
+                                        i32, i32, vp]
     lib.tcar_split_bf16.argtypes = [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp]
     lib.tcar_splitk_reduce.argtypes = [vp, i32, i32, i32, i64, vp, vp]
     lib.tcar_gemm_splitk_effective.argtypes = [i32, i32]

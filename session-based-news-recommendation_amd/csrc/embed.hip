@@ -423,7 +423,7 @@ constexpr int CT_CHUNKS = 32;
 
 __global__ __launch_bounds__(256) void cand_time_bwd_idx_kernel(const CandArgs a, const int32_t* __restrict__ inv_n,
                                                                 const int32_t* __restrict__ inv_off,
-                                                                float* __restrict__ ws) {
+                                                                float* __restrict__ ws, int permuted) {
   __shared__ __attribute__((aligned(16))) float shS[16 * 256];   // [groups][ldt]  (groups*ldt = 1024 floats)
   __shared__ float shQ[16], shD[16];
   const int tid = threadIdx.x;
@@ -442,13 +442,21 @@ __global__ __launch_bounds__(256) void cand_time_bwd_idx_kernel(const CandArgs a
   for (int i0 = s0 + grp; i0 < s1; i0 += 4 * groups) {
     long n[4];
     float4 gy[4];
+    if (permuted) {         // d_et is in list order: entry i is the contiguous segment i (no index load, pure streaming)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int i = i0 + u * groups;
-      n[u] = (i < s1) ? (long)inv_n[i] : -1;
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * groups;
+        gy[u] = (i < s1) ? ld4(a.d_et + (long)i * ldt + lin * 4) : zero4();
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * groups;
+        n[u] = (i < s1) ? (long)inv_n[i] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gy[u] = (n[u] >= 0) ? ld4(a.d_et + n[u] * pt + k * ldt + lin * 4) : zero4();
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) gy[u] = (n[u] >= 0) ? ld4(a.d_et + n[u] * pt + k * ldt + lin * 4) : zero4();
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       S = add4(S, gy[u]);
@@ -597,14 +605,14 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
 }
 
 extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* inv_n,
-                                         const int32_t* inv_off, const float* d_et, float* ws,
+                                         const int32_t* inv_off, const float* d_et, int permuted, float* ws,
                                          const tcar_grads_t* g, void* stream) {
   if (check_dims(d) || !time_tab || !inv_n || !inv_off || !d_et || !ws || !g) return TCAR_E_ARG;
   CandArgs a{};
   a.d = *d;
   for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
   a.d_et = d_et; a.g = *g;
-  TCAR_LAUNCH(cand_time_bwd_idx_kernel, dim3(139, CT_CHUNKS), dim3(256), 0, (hipStream_t)stream, a, inv_n, inv_off, ws);
+  TCAR_LAUNCH(cand_time_bwd_idx_kernel, dim3(139, CT_CHUNKS), dim3(256), 0, (hipStream_t)stream, a, inv_n, inv_off, ws, permuted);
   TCAR_CHECK_LAUNCH();
   TCAR_LAUNCH(cand_time_bwd_fin_kernel, dim3(139), dim3(256), 0, (hipStream_t)stream, a, ws);
   TCAR_CHECK_LAUNCH();

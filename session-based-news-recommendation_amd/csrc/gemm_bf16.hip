@@ -40,6 +40,8 @@ struct BArgs {
   float* C2; long ldc2; int csplit;     // columns >= csplit go to C2 (column index rebased); csplit >= N: unused
   int M, N, K, kchunk, mode, mt, nt, nsk;
   int n_fastest;               // tile order inside the XCD-contiguous id run: 1 = consecutive ids walk the N tiles
+  const int32_t* perm;         // optional grouped row permutation of the C2 destination (see tcar_gemm_bf16), else NULL
+  int pgroup;                  // columns per permutation group
 };
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -179,9 +181,22 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
     for (int t = 0; t < TNW; ++t) {
       const int col = n0 + wn * (32 * TNW) + t * 32 + li;
       if (col >= g.N) continue;
+      const int row0 = m0 + wm * (32 * TMW) + u * 32 + 4 * lh;
+      if (g.perm && col >= g.csplit) {
+        // C2 element (m, cc) lives at C2[perm[(cc / pgroup) * M + m] * pgroup + cc % pgroup]: the 32 lanes of a half wave
+        // share m, so the permutation load is a broadcast
+        const int cc = col - g.csplit;
+        const int32_t* pp = g.perm + (long)(cc / g.pgroup) * g.M;
+        float* pb = g.C2 + cc % g.pgroup;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = row0 + (e & 3) + 8 * (e >> 2);
+          if (row < g.M) pb[(long)pp[row] * g.pgroup] = acc[u][t][e];
+        }
+        continue;
+      }
       float* base = (col < g.csplit) ? C1 + col : g.C2 + (col - g.csplit);
       const long ld = (col < g.csplit) ? g.ldc : g.ldc2;
-      const int row0 = m0 + wm * (32 * TMW) + u * 32 + 4 * lh;
       if (m0 + TM <= g.M) {            // interior tile (workgroup-uniform): 16 unguarded stores, no per-element branch
         float* pr = base + (long)row0 * ld;
 #pragma unroll
@@ -298,6 +313,15 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
 extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner,
                               int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C,
                               int64_t ldc, float* C2, int64_t ldc2, int csplit, int nsplit, int splitk, void* stream) {
+  return tcar_gemm_bf16_perm(layout, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, C, ldc, C2, ldc2,
+                             csplit, nullptr, 0, nsplit, splitk, stream);
+}
+
+extern "C" int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner,
+                                   int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows,
+                                   float* C, int64_t ldc, float* C2, int64_t ldc2, int csplit, const int32_t* c2_perm,
+                                   int c2_group, int nsplit, int splitk, void* stream) {
+  if (c2_perm && (!C2 || c2_group <= 0 || splitk > 1)) return TCAR_E_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
   if (layout < 0 || layout > 2 || !A_hi || !B_hi || !C || (nsplit != 1 && nsplit != 3)) return TCAR_E_ARG;
   if (nsplit == 3 && (!A_lo || !B_lo)) return TCAR_E_ARG;
@@ -313,6 +337,7 @@ extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi,
   g.a_rb = (int)((a_rows + 127) >> 7); g.b_rb = (int)((b_rows + 127) >> 7);
   g.C = C; g.ldc = ldc;
   g.C2 = C2 ? C2 : C; g.ldc2 = C2 ? ldc2 : ldc; g.csplit = C2 ? csplit : N;
+  g.perm = c2_perm; g.pgroup = c2_group;
   g.M = M; g.N = N; g.K = K;
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && C2) return TCAR_E_ARG;

@@ -189,8 +189,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   if (c->scoring) {
-    RET(tcar_gemm_bf16(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h, c->ap16l,
-                       g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, nsb, 1, sB));
+    // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
+    RET(tcar_gemm_bf16_perm(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h,
+                            c->ap16l, g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, c->et_perm, g.ldt, nsb, 1,
+                            sB));
   } else {  // dE = dlogits^T attout: item block and time block (content is frozen)
     tcar_gemm_desc_t p[2];
     p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
@@ -296,7 +298,8 @@ int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream) {
   grads_of(c, gr);
   const float* tt[5];
   for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-  return tcar_cand_time_bwd_indexed(&c->d, tt, c->inv_n, c->inv_off, c->big + (size_t)g.N * g.ldh, c->ct_ws, &gr, stream);
+  return tcar_cand_time_bwd_indexed(&c->d, tt, c->inv_n, c->inv_off, c->big + (size_t)g.N * g.ldh,
+                                    (c->scoring && c->et_perm) ? 1 : 0, c->ct_ws, &gr, stream);
 }
 int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream) {
   RET(item_norm(c, g, stream));
@@ -304,7 +307,8 @@ int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream) {
   grads_of(c, gr);
   const float* tt[5];
   for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-  return tcar_cand_time_bwd_indexed(&c->d, tt, c->inv_n, c->inv_off, c->big + (size_t)g.N * g.ldh, c->ct_ws, &gr, stream);
+  return tcar_cand_time_bwd_indexed(&c->d, tt, c->inv_n, c->inv_off, c->big + (size_t)g.N * g.ldh,
+                                    (c->scoring && c->et_perm) ? 1 : 0, c->ct_ws, &gr, stream);
 }
 }  // namespace
 

@@ -196,6 +196,11 @@ class TcarEngine:
         inv_off[1:] = np.cumsum(np.bincount(key, minlength=139))
         self.inv_n = torch.tensor((order % g.N).astype(np.int32), device=self.dev)
         self.inv_off = torch.tensor(inv_off, device=self.dev)
+        # inverse of the index: position of (k, n) in list order.  In the bf16 scoring modes the dE GEMM writes the time
+        # block of dE in THAT order (tcar_gemm_bf16_perm), so the candidate-time backward streams contiguous lists
+        et_perm = np.empty(5 * g.N, dtype=np.int32)
+        et_perm[order] = np.arange(5 * g.N, dtype=np.int32)
+        self.et_perm = torch.tensor(et_perm, device=self.dev)
         self.ct_ws = torch.zeros(self.lib.tcar_cand_time_ws_floats(C.byref(self.dims)), **f32)
         # segment tables for the optimizer kernels
         self.segs_all = self._segments([a[0] for a in ARENA])
@@ -551,8 +556,9 @@ class TcarEngine:
     def _cand_time_bwd(self):
         gr = self._grads()
         check(self.lib.tcar_cand_time_bwd_indexed(C.byref(self.dims), C.byref(self._time_ptrs()), self._p(self.inv_n),
-                                                  self._p(self.inv_off), self._p(self.d_et), self._p(self.ct_ws),
-                                                  C.byref(gr), self._stream()), "tcar_cand_time_bwd_indexed")
+                                                  self._p(self.inv_off), self._p(self.d_et), int(self.scoring_code != 0),
+                                                  self._p(self.ct_ws), C.byref(gr), self._stream()),
+              "tcar_cand_time_bwd_indexed")
 
     def _sqnorm_dense(self):
         check(self.lib.tcar_sqnorm(self._p(self.G), C.byref(self.segs_dense), self._p(self.sqn_dense), self._stream()),
@@ -669,6 +675,7 @@ class TcarEngine:
         for n in _lib._WS:
             setattr(c, n, getattr(self, n).data_ptr())
         c.scoring = self.scoring_code
+        c.et_perm = self.et_perm.data_ptr()
         c.scoring_bwd = self.scoring_bwd
         if self.scoring_code:
             for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l"):

@@ -703,3 +703,32 @@ def test_gemm_bf16_de_tiles(lib, tile):
     close(g1[:, :256], want[:, :256], rtol=1e-3, atol_scale=2e-5, name="dE item block")
     close(g2[:, :320], want[:, 256:], rtol=1e-3, atol_scale=2e-5, name="dE time block")
     assert (g1[:, 256:] == 7.0).all() and (g2[:, 320:] == 7.0).all()
+
+
+def test_cand_time_bwd_permuted_layout_equals_plain():
+    """The candidate-time backward reads d_et either as [N, pt] through the inverted index or in list order (the layout
+    the dE GEMM writes through tcar_gemm_bf16_perm): same table gradients and norm pieces, bit for bit."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 3000, 250, 64, 8, 2, 2
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=5)
+    eng = TcarEngine(params, content, mw, scoring="bf16x3")
+    g = eng.geo
+    rng = np.random.RandomState(3)
+    d_et = rng.standard_normal((N, g.pt)).astype(np.float32)
+    perm = eng.et_perm.cpu().numpy().reshape(5, N)
+    listed = np.zeros((5 * N, g.ldt), np.float32)
+    for k in range(5):
+        listed[perm[k]] = d_et[:, k * g.ldt:(k + 1) * g.ldt]
+    outs = []
+    for permuted, src in ((0, d_et), (1, listed)):
+        eng.Gx.zero_()
+        eng.sqn_pieces.zero_() if hasattr(eng, "sqn_pieces") else None
+        eng.d_et.view(-1).copy_(torch.tensor(src.reshape(-1)).cuda())
+        gr = eng._grads()
+        assert eng.lib.tcar_cand_time_bwd_indexed(C.byref(eng.dims), C.byref(eng._time_ptrs()), eng._p(eng.inv_n),
+                                                  eng._p(eng.inv_off), eng._p(eng.d_et), permuted, eng._p(eng.ct_ws),
+                                                  C.byref(gr), eng._stream()) == 0
+        outs.append(eng.Gx.clone().cpu().numpy())
+    assert np.abs(outs[0]).max() > 0
+    assert (outs[0] == outs[1]).all()
