@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void cand_time_bwd_fin_kernel(const CandArgs a
       pc = inv2 * Q - inv2 * inv2 * D2;
     }
     float* gp = a.g.g_time[0] + (long)r * ldt + lin * 4;       // month..minute gradients are contiguous
-    st4(gp, add4(ld4(gp), gx));
+    atomic_add4(gp, gx);       // atomics: the session-side gather backward may be adding into the same rows concurrently
     if (lin == 0) ws[(long)139 * CT_CHUNKS * (ldt + 4) + r] = pc;
   }
 }

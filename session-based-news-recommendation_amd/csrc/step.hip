@@ -272,7 +272,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, stream));
     RET(item_norm(c, g, stream));
   }
-  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[3], 0) != hipSuccess) return TCAR_E_LAUNCH;    // chain B is done
+  // The row scatter needs the item norm (same stream) but NOT the candidate-time backward: both only add (atomically) into
+  // the time-table gradients, and the final join below covers the whole aux stream.  Without the split, wait for chain B.
+  if (s2 && !split_finish && hipStreamWaitEvent(st, (hipEvent_t)c->ev[3], 0) != hipSuccess) return TCAR_E_LAUNCH;
   if (fuse_finish) {
     // sparse rows and per-row norm pieces (after the dense item norm of chain B), then the dense-weight norms
     tcar_tables_t tab;
