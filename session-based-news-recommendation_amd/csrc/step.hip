@@ -257,6 +257,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
     RET(small_gemm(c, 2, 9, p, sW));
   }
+  // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
+  // aux stream they follow the weight gradients there, beside the scatter
+  if (fuse_finish && s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, sW));
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   {  // input gradients (only the ITEM half of dX_ic: content is frozen)
     tcar_gemm_desc_t p[4];
@@ -284,7 +287,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
   }
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // weight gradients are in
-  if (fuse_finish) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
+  if (fuse_finish && !s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
   return TCAR_OK;
 }
 
