@@ -98,3 +98,28 @@ def test_cli_synthetic_runs():
     out = buf.getvalue()
     assert "Begin Training" in out and "Recall@20" in out
     assert 0.0 <= model.last_metrics["recall"] <= 1.0 and np.isfinite(model.last_metrics["loss"])
+
+
+def test_cli_runs_on_a_fold_in_the_reference_pickle_layout(tmp_path):
+    """main.py --datapath/--dataset/--split_way/--foldnum on files written the way the reference's preprocessing writes
+    them (util.py:20-56): load, tensorise, train one epoch, evaluate — the stdout contract of model_combine.py holds."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from helpers import write_reference_fold
+    from tcar_amd.host.cli import main
+    from tcar_amd.host.synth import SynthFold
+    fold = SynthFold(n_items=500, dim=48, n_train=2500, n_test=300, seed=11, active_t=True)
+    base = tmp_path / "data" / "globo" / "Normal"
+    base.mkdir(parents=True)
+    write_reference_fold(str(base) + "/", fold, foldnum=1)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        model = main(["--datapath", str(tmp_path / "data") + "/", "--dataset", "globo/", "--split_way", "Normal/",
+                      "--foldnum", "1", "--epoch", "1", "--hidden_size", "48", "--time_hidden_size", "16",
+                      "--batch_size", "128", "--category_path", str(base / "articles_category.pkl")])
+    out = buf.getvalue()
+    for line in ("Epoch 0", "\tloss:", "Measuring...", "avg loss...", "avg ILD...", "avg unexp...", "len of result dict:",
+                 "MRR@20:"):
+        assert line in out, line
+    assert 0.0 <= model.last_metrics["recall"] <= 1.0 and np.isfinite(model.last_metrics["loss"])
+    assert model.last_metrics["ild"] > 0          # the category file was used

@@ -79,3 +79,40 @@ def test_synth_fold_contract():
         st.batch_arrays(np.array([np.where(st.in_len == 1)[0][0], np.where(st.in_len == 2)[0][0]]))
     nb = fold.neighbor_dict(k=3)
     assert all(i not in v and 3 <= len(v) <= 6 for i, v in nb.items())
+
+
+def test_load_fold_reads_the_reference_pickle_layout(tmp_path):
+    """host/data.load_fold is data_partition (util.py:20-56) minus the hard-coded path: a fold written in that layout
+    comes back as the same dicts, and its tensorised store yields the same batches as the synthetic store it was
+    written from."""
+    import random
+    from helpers import write_reference_fold
+    from tcar_amd.host.data import SessionStore, load_fold
+    from tcar_amd.host.sampler import Sampler
+    from tcar_amd.host.synth import SynthFold
+    fold = SynthFold(n_items=120, dim=16, n_train=300, n_test=60, seed=3, active_t=True)
+    base = str(tmp_path) + "/"
+    item_dict = write_reference_fold(base, fold, foldnum=2)
+    train, test, items, neighbor, content, publish_time, _ = load_fold(base, 2)
+    assert items == item_dict and len(publish_time) == 2 and np.array_equal(publish_time[1], fold.mwdhm)
+    assert np.array_equal(content, fold.content) and neighbor == fold.neighbor_dict()
+    want = fold.to_dicts(fold.train, with_active=True)
+    assert train[0] == want[0] and train[1] == want[1] and train[2] == want[2]
+    assert set(test[0]) == set(fold.to_dicts(fold.test, with_active=True)[0])
+
+    def batches(data, store):
+        random.seed(5)
+        np.random.seed(5)
+        len_d = {k: list(v) for k, v in data[0].items()}
+        s = Sampler(len_d, data[1], data[2], neighbor, items, 4, batch_size=32, store=store)
+        out = []
+        while s.has_next():
+            out.append(s.next_batch_arrays())
+        return out
+
+    a = batches(train, None)                                   # store built from the loaded dicts
+    b = batches(want, None)                                    # store built from the in-memory dicts
+    assert len(a) == len(b) > 0
+    for x, y in zip(a, b):
+        for k in x:
+            assert (x[k] is None and y[k] is None) or np.array_equal(x[k], y[k]), k
