@@ -261,6 +261,13 @@ int tcar_dact_colsum(int M, int ncol, int64_t ld, const float* y, float* dy, flo
 int tcar_rank_topk(int B, int N, const float* logits, int64_t ld, const int32_t* label, int k,
                    int32_t* rank, int32_t* topk, void* stream);
 
+/* tcar_eval_rows: tcar_rank_topk plus (ce != NULL) the sparse softmax cross entropy of the same rows, from ONE read of the
+ * score matrix (row-resident kernel, ld <= 49,152 and 16-byte aligned rows; otherwise ce must be NULL and the streaming
+ * kernel runs).  The logits are left untouched.  This is the whole of `sess.run([softmax_input, cross_loss])` +
+ * cau_metrics + argsort (model_combine.py:283,293-301) after the logits GEMM. */
+int tcar_eval_rows(int B, int N, const float* logits, int64_t ld, const int32_t* label, int k, int32_t* rank, int32_t* topk,
+                   float* ce, void* stream);
+
 /* ---- optimizer (model_combine.py:155-163) ---------------------------------------------------------------------
  * Segments of one flat fp32 arena (identical offsets in w, g, m, v). */
 typedef struct {

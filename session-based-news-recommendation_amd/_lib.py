@@ -21,7 +21,7 @@ NSLOT = 32
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
-           "tcar_dact_colsum", "tcar_rank_topk",
+           "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
            "tcar_clip_adam_all", "tcar_abi_version", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_eval_step"]
@@ -168,6 +168,7 @@ def load() -> C.CDLL:
     lib.tcar_splitk_reduce_dact.argtypes = [vp, i32, i32, i32, i64, vp, i64, i32, vp, i64, i32, vp, vp, i32, vp, vp]
     lib.tcar_dact_colsum.argtypes = [i32, i32, i64, vp, vp, vp, i32, vp]
     lib.tcar_rank_topk.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp, vp]
+    lib.tcar_eval_rows.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp, vp, vp]
     lib.tcar_sqnorm.argtypes = [vp, P(Segments), vp, vp]
     lib.tcar_clip_adam.argtypes = [vp, vp, vp, vp, P(Segments), vp, vp, vp, f32, f32, f32, f32, f32, vp]
     lib.tcar_clip_adam_all.argtypes = [vp, vp, vp, vp, P(Segments), vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32,

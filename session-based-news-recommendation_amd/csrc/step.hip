@@ -351,6 +351,8 @@ extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int 
 extern "C" int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream) {
   RET(tcar_step_forward(c, bt, refresh_time, stream));
   const Geo g(c->d);
+  if (g.Npad <= 512L * 4 * 24)      // one read of the score matrix: rank, top-k and CE from the row-resident kernel
+    return tcar_eval_rows(bt->B, g.N, c->logits, g.Npad, bt->label, k, c->rank, c->topk, c->ce, stream);
   RET(tcar_rank_topk(bt->B, g.N, c->logits, g.Npad, bt->label, k, c->rank, c->topk, stream));
   return tcar_softmax_ce(bt->B, g.N, c->logits, g.Npad, bt->label, c->ce, stream);
 }

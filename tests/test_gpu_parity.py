@@ -732,3 +732,39 @@ def test_cand_time_bwd_permuted_layout_equals_plain():
         outs.append(eng.Gx.clone().cpu().numpy())
     assert np.abs(outs[0]).max() > 0
     assert (outs[0] == outs[1]).all()
+
+
+@pytest.mark.parametrize("N", [7, 1003, 20001, 49200])
+def test_eval_rows_rank_topk_ce(lib, N):
+    """row-resident rank / top-20 / CE kernel (N <= 49,152) and the streaming fallback: strict-greater rank
+    (util.py:13-17), top-k in the order of np.argsort(x)[::-1] incl. ties (model_combine.py:301), CE (:145)"""
+    from oracle.metrics_oracle import topk_list
+    rng = np.random.RandomState(N)
+    B, k = 5, 20
+    ldn = (N + 127) // 128 * 128
+    x = (rng.standard_normal((B, ldn)) * 2).astype(np.float32)
+    x[1, :N] = -0.75                                      # all-tie row: top-k is the highest indices
+    x[2, : N // 2] = x[2, 0]                              # half the row tied at one value
+    x[3, N - 1] = 50.0                                    # the winner sits in the last column
+    x[:, N:] = 1e9                                        # padding columns must never be picked
+    lab = np.array([0, N - 1, N // 3, N - 1, min(5, N - 1)], np.int32)
+    d, dl = torch.tensor(x).cuda(), torch.tensor(lab).cuda()
+    rank = torch.empty(B, dtype=torch.int32, device="cuda")
+    topk = torch.full((B, k), -7, dtype=torch.int32, device="cuda")
+    ce = torch.empty(B, device="cuda")
+    fused = ldn <= 49152
+    rc = lib.tcar_eval_rows(B, N, ptr(d), ldn, ptr(dl), k, ptr(rank), ptr(topk), ptr(ce) if fused else None, None)
+    assert rc == 0
+    xv = x[:, :N].astype(np.float64)
+    assert (rank.cpu().numpy() == (xv > xv[np.arange(B), lab][:, None]).sum(1) + 1).all()
+    tk = topk.cpu().numpy()
+    for b in range(B):
+        want = topk_list(x[b, :N], k)
+        want = want + [-1] * (k - len(want))
+        assert tk[b].tolist() == want, (b, tk[b].tolist(), want)
+    assert (d.cpu().numpy() == x).all()                   # the scores are left untouched
+    if fused:
+        lse = np.log(np.exp(xv - xv.max(1, keepdims=True)).sum(1)) + xv.max(1)
+        close(ce.cpu().numpy(), lse - xv[np.arange(B), lab], name="ce")
+    else:
+        assert lib.tcar_eval_rows(B, N, ptr(d), ldn, ptr(dl), k, ptr(rank), ptr(topk), ptr(ce), None) != 0
