@@ -498,10 +498,8 @@ __global__ __launch_bounds__(NT) void rank_topk_rows_kernel(int N, const float* 
   int cbi;
   scan(INFINITY, N, cbv, cbi);
   const int kk = k < N ? k : N;
-  for (int r = 0; r < k; ++r) {
-    if (r >= kk) { if (tid == 0) topk[(long)b * k + r] = -1; continue; }
-    float bv = cbv;
-    int bi = cbi;
+  // block-wide arg-max of one (value, index) key per thread under (score desc, index desc); result to every thread
+  auto block_best = [&](float bv, int bi, float& fv, int& fi) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(bv, o);
@@ -510,14 +508,71 @@ __global__ __launch_bounds__(NT) void rank_topk_rows_kernel(int N, const float* 
     }
     if (lane == 0) { shv[w] = bv; shi[w] = bi; }
     __syncthreads();
-    float fv = shv[0];
-    int fi = shi[0];
+    fv = shv[0]; fi = shi[0];
 #pragma unroll
     for (int j = 1; j < NWV; ++j)
       if (shv[j] > fv || (shv[j] == fv && shi[j] > fi)) { fv = shv[j]; fi = shi[j]; }
     __syncthreads();
+  };
+  // Phase A: the kk-th largest of the per-thread bests, L.  At least kk elements are >= L, so the whole top-kk is.
+  float lv = INFINITY;
+  int li = N;
+  {
+    float av = cbv;
+    int ai = cbi;
+    for (int r = 0; r < kk; ++r) {
+      float fv; int fi;
+      block_best(av, ai, fv, fi);
+      if (fi < 0) { lv = ninf; li = -1; break; }        // fewer than kk threads hold anything: every element qualifies
+      lv = fv; li = fi;
+      if (ai == fi) { av = ninf; ai = -1; }
+    }
+  }
+  // Phase B: compact the elements >= L into LDS
+  constexpr int CAP = 2 * NT;
+  __shared__ float candv[CAP];
+  __shared__ int candi[CAP];
+  __shared__ int ncand;
+  if (tid == 0) ncand = 0;
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int c = (tid + r * NT) * 4;
+    const float e[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = c + j;
+      if (i < N && (e[j] > lv || (e[j] == lv && i >= li))) {
+        const int pos = atomicAdd(&ncand, 1);
+        if (pos < CAP) { candv[pos] = e[j]; candi[pos] = i; }
+      }
+    }
+  }
+  __syncthreads();
+  const int nc = ncand;
+  if (nc <= CAP) {
+    // Phase C: kk rounds over <= 2 candidates per thread
+    float c0v = tid < nc ? candv[tid] : ninf, c1v = tid + NT < nc ? candv[tid + NT] : ninf;
+    int c0i = tid < nc ? candi[tid] : -1, c1i = tid + NT < nc ? candi[tid + NT] : -1;
+    for (int r = 0; r < k; ++r) {
+      if (r >= kk) { if (tid == 0) topk[(long)b * k + r] = -1; continue; }
+      const bool first = (c0v > c1v) || (c0v == c1v && c0i > c1i);
+      float fv; int fi;
+      block_best(first ? c0v : c1v, first ? c0i : c1i, fv, fi);
+      if (tid == 0) topk[(long)b * k + r] = fi;
+      if (c0i == fi) { c0v = ninf; c0i = -1; }
+      if (c1i == fi) { c1v = ninf; c1i = -1; }
+    }
+    return;
+  }
+  // Fallback (more than CAP elements tie with or exceed L, e.g. a constant row): extract one element per round; only the
+  // owner of the extracted element rescans its registers
+  for (int r = 0; r < k; ++r) {
+    if (r >= kk) { if (tid == 0) topk[(long)b * k + r] = -1; continue; }
+    float fv; int fi;
+    block_best(cbv, cbi, fv, fi);
     if (tid == 0) topk[(long)b * k + r] = fi;
-    if (fi >= 0 && ((fi >> 2) % NT) == tid) scan(fv, fi, cbv, cbi);      // only the owner of the extracted element rescans
+    if (fi >= 0 && ((fi >> 2) % NT) == tid) scan(fv, fi, cbv, cbi);
   }
 }
 
