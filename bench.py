@@ -112,9 +112,9 @@ def main():
     from tcar_amd.host.model import initial_variables     # the product's own initialiser (modules.py:32-34,50-51)
     np.random.seed(2020)
     params = initial_variables(args.n_items, args.hidden_size, args.time_hidden_size, 0.002, 0.05, weight_seed=2020)
-    if world > 1:
+    if world > 1 or os.environ.get("TCAR_FORCE_DP"):       # TCAR_FORCE_DP=1: time the data-parallel code path on one rank
         from tcar_amd.dp import DPEngine
-        eng = DPEngine(params, fold.content, fold.mwdhm, device=dev, group=dist.group.WORLD, scoring=args.scoring)
+        eng = DPEngine(params, fold.content, fold.mwdhm, device=dev, group=(dist.group.WORLD if dist is not None else None), scoring=args.scoring)
     else:
         from tcar_amd.engine import TcarEngine
         eng = TcarEngine(params, fold.content, fold.mwdhm, device=dev, scoring=args.scoring)
