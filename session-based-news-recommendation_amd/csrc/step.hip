@@ -3,6 +3,7 @@
 // allocation.  tcar_train_step == sess.run([loss, global_step, train_op]) (model_combine.py:231);
 // tcar_eval_step == sess.run([softmax_input, cross_loss]) + util.cau_metrics + top-k (model_combine.py:283,296,301).
 #include "tcar_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -242,7 +243,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
-    auto ks = [](int K) { int s = (K + 1023) / 1024; return s < 2 ? 2 : (s > 16 ? 16 : s); };
+    static const int ksdiv = getenv("TCAR_WGRAD_KS") ? atoi(getenv("TCAR_WGRAD_KS")) : 512;
+    auto ks = [](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 2 ? 2 : (s > 16 ? 16 : s); };
     const int kb = ks(B), kr = ks(BT);
     const float* x_c = c->x_icp + g.ldh;
     tcar_gemm_desc_t p[9];
