@@ -135,6 +135,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         eng.train_step(None, bt=resident[(args.warmup + i) % len(resident)])
+    t_enq = time.perf_counter() - t0          # host time to enqueue every step (the loop never synchronises)
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -222,7 +223,7 @@ def main():
                                       "mean input length %.2f, full-catalog scoring, clip %d + Adam" %
                                       (N, H, B, K, mean_T, 150),
                           "global_batch": B * world, "parallelism": "dp%d" % world},
-               "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "last_loss": round(last_loss, 4)}
+               "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "last_loss": round(last_loss, 4)}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
