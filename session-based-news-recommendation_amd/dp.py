@@ -5,7 +5,8 @@ independent given the weights and the loss is a SUM over sessions (model_combine
 gradient is the plain sum of the ranks' gradients — no 1/W rescale — and every rank applies the same clip + Adam
 to its replica.  What makes it more than one all-reduce is the clip: tf.clip_by_norm of an IndexedSlices uses the
 norm of the concatenated slice VALUES, which is not additive for blocks that are sums over the
-whole (global) batch.  The exchange therefore runs in this order (all on the compute stream; `GradExchange`):
+whole (global) batch.  The exchange has these steps (`GradExchange`; the collectives 1, 5, 3 are issued in that one
+canonical order on every rank and do not depend on each other, the local steps 2, 4, 6 follow once they have landed):
 
   1. all-reduce  [ dE_item | dE_time ]      [N, ldh + pt] fp32 — the dense item-table block (scoring + densified
                                             negative part) and the candidate-side time block, BEFORE any per-row work
@@ -21,7 +22,8 @@ whole (global) batch.  The exchange therefore runs in this order (all on the com
 xGMI is point-to-point (7 links/GPU): step 1 moves ~106 MB per rank at the Globo size and dominates; it only
 depends on dE, so the rank-local backward runs dE FIRST and `DPEngine` starts step 1 on a communication stream the
 moment dE is complete (an event recorded by the C++ driver): the all-reduce runs beside dX, the attention / projection
-backward and the weight gradients, and is joined just before step 2.
+backward and the weight gradients; the sparse-row all-gather and the arena all-reduce are queued behind it on the same
+stream as soon as the rank-local backward has produced them, and the main stream joins once, before step 2.
 `GradExchange` is device-agnostic (tests run it over gloo on CPU tensors with the oracle's gradients).
 """
 from __future__ import annotations
@@ -45,29 +47,38 @@ class GradExchange:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
+    def communicate(self, big: torch.Tensor, arena_pieces: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor,
+                    big_done: bool = False):
+        """Every collective of the step, in ONE canonical order on every rank (also the ranks whose shard is empty):
+        all-reduce big (1) -> all-gather ids, rows (5) -> all-reduce arena (3).  None of them depends on another one's
+        result, so a caller may issue them back to back on a communication stream.  `big_done`: (1) was already issued."""
+        g = self.group
+        if self.world <= 1:
+            return ids.reshape(-1), rows.reshape(-1, rows.shape[-1])
+        if not big_done:
+            dist.all_reduce(big, group=g)                                   # 1
+        all_ids = torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
+        all_rows = torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(all_ids.view(-1), ids.reshape(-1).contiguous(), group=g)      # 5
+        dist.all_gather_into_tensor(all_rows.view(-1), rows.reshape(-1).contiguous(), group=g)
+        dist.all_reduce(arena_pieces, group=g)                              # 3
+        return all_ids.view(-1), all_rows.view(-1, rows.shape[-1])
+
+    @staticmethod
+    def finish(all_ids: torch.Tensor, all_rows: torch.Tensor, sqnorm_item: Callable[[], None],
+               cand_time_bwd: Callable[[], None], scatter_rows: Callable[[torch.Tensor, torch.Tensor], None],
+               sqnorm_dense: Callable[[], None]):
+        """The local steps, once every collective has landed."""
+        sqnorm_item()                                                       # 2  (before any row is scattered in: S5)
+        cand_time_bwd()                                                     # 4  (once, on top of the reduced arena)
+        scatter_rows(all_ids, all_rows)                                     # 6
+        sqnorm_dense()
+
     def run(self, big: torch.Tensor, arena_pieces: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor,
             sqnorm_item: Callable[[], None], cand_time_bwd: Callable[[], None],
-            scatter_rows: Callable[[torch.Tensor, torch.Tensor], None], sqnorm_dense: Callable[[], None],
-            big_wait: Optional[Callable[[], None]] = None):
-        """`big_wait`: step 1 was already started asynchronously (DPEngine.start_big_reduce); call it to join."""
-        g = self.group
-        if big_wait is not None:
-            big_wait()                                                      # 1 (started early, overlapped)
-        elif self.world > 1:
-            dist.all_reduce(big, group=g)                                   # 1
-        sqnorm_item()                                                       # 2
-        if self.world > 1:
-            dist.all_reduce(arena_pieces, group=g)                          # 3
-        cand_time_bwd()                                                     # 4
-        if self.world > 1:                                                  # 5
-            all_ids = torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
-            all_rows = torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
-            dist.all_gather_into_tensor(all_ids.view(-1), ids.reshape(-1).contiguous(), group=g)
-            dist.all_gather_into_tensor(all_rows.view(-1), rows.reshape(-1).contiguous(), group=g)
-            scatter_rows(all_ids.view(-1), all_rows.view(-1, rows.shape[-1]))
-        else:
-            scatter_rows(ids.reshape(-1), rows.reshape(-1, rows.shape[-1]))
-        sqnorm_dense()                                                      # 6
+            scatter_rows: Callable[[torch.Tensor, torch.Tensor], None], sqnorm_dense: Callable[[], None]):
+        all_ids, all_rows = self.communicate(big, arena_pieces, ids, rows)
+        self.finish(all_ids, all_rows, sqnorm_item, cand_time_bwd, scatter_rows, sqnorm_dense)
 
 
 def shard_bounds(b: int, world: int, rank: int):
@@ -116,27 +127,36 @@ class DPEngine(TcarEngine):
             check(lib.tcar_scatter_add_rows(C.byref(self.dims), p(all_ids), p(all_rows), all_ids.numel(), p(self.Gi),
                                             self._stream()), "tcar_scatter_add_rows")
 
-        self.xch.run(self.big, self.Gx, ids, rows, self._sqnorm_item, self._cand_time_bwd, scatter, self._sqnorm_dense,
-                     big_wait=self._big_wait)
-        self._big_wait = None
+        if self._comm_busy:
+            # the big all-reduce is already running on the communication stream (start_big_reduce); queue the other
+            # collectives behind it there — they need only the arena / rows this stream has just produced — and join once
+            main = torch.cuda.current_stream(self.dev)
+            self._comm.wait_stream(main)
+            with torch.cuda.stream(self._comm):
+                all_ids, all_rows = self.xch.communicate(self.big, self.Gx, ids, rows, big_done=True)
+            main.wait_stream(self._comm)
+            all_ids.record_stream(main)
+            all_rows.record_stream(main)
+            self._comm_busy = False
+        else:
+            all_ids, all_rows = self.xch.communicate(self.big, self.Gx, ids, rows)
+        self.xch.finish(all_ids, all_rows, self._sqnorm_item, self._cand_time_bwd, scatter, self._sqnorm_dense)
 
-    _big_wait = None
+    _comm_busy = False
 
     def start_big_reduce(self):
         """Step 1 of the exchange, started on a communication stream as soon as dE is complete (event 3 of the C++
         driver, recorded after the dE GEMM + negative rows) so that it overlaps chain A.  Falls back to the in-line
         all-reduce when there is no aux stream / single rank."""
-        self._big_wait = None
+        self._comm_busy = False
         if self.xch.world <= 1 or not self.big.is_cuda or not getattr(self, "_aux_ev", None):
             return
         if not hasattr(self, "_comm"):
             self._comm = torch.cuda.Stream(self.dev)
-        main = torch.cuda.current_stream(self.dev)
         self._comm.wait_event(self._aux_ev[3])
         with torch.cuda.stream(self._comm):
             dist.all_reduce(self.big, group=self.group)
-        comm = self._comm
-        self._big_wait = lambda: main.wait_stream(comm)
+        self._comm_busy = True
 
     def train_step(self, batch, bt=None, cap_rows: Optional[int] = None):
         """`batch` may be None for a rank whose shard of the global batch is empty (it still joins the collectives)."""
