@@ -140,7 +140,18 @@ class DPEngine(TcarEngine):
             self._comm_busy = False
         else:
             all_ids, all_rows = self.xch.communicate(self.big, self.Gx, ids, rows)
-        self.xch.finish(all_ids, all_rows, self._sqnorm_item, self._cand_time_bwd, scatter, self._sqnorm_dense)
+        aux = getattr(self, "_aux", None)
+        if aux is not None and self.big.is_cuda:
+            # the candidate-time backward (needs only the reduced d_et; adds atomically into the reduced arena) runs on the
+            # aux stream beside the item norm, the row scatter and the dense-weight norms
+            main = torch.cuda.current_stream(self.dev)
+            aux.wait_stream(main)
+            with torch.cuda.stream(aux):
+                self._cand_time_bwd()
+            self.xch.finish(all_ids, all_rows, self._sqnorm_item, lambda: None, scatter, self._sqnorm_dense)
+            main.wait_stream(aux)
+        else:
+            self.xch.finish(all_ids, all_rows, self._sqnorm_item, self._cand_time_bwd, scatter, self._sqnorm_dense)
 
     _comm_busy = False
 
