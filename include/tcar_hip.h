@@ -305,6 +305,8 @@ int tcar_clip_adam_all(float* w, const float* g, float* m, float* v, const tcar_
                        const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t,
                        float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, void* stream);
 
+/* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
+#define TCAR_ABI_VERSION 3
 int tcar_abi_version(void);
 
 /* ---- step-level entry points ------------------------------------------------------------------------------------

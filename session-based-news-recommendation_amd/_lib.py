@@ -18,6 +18,8 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
+ABI_VERSION = 3          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
@@ -140,6 +142,9 @@ def load() -> C.CDLL:
     missing = [s for s in SYMBOLS if not hasattr(lib, s)]
     if missing:
         raise TcarError("libtcar_hip.so lacks symbols: %s" % missing)
+    if lib.tcar_abi_version() != ABI_VERSION:
+        raise TcarError("libtcar_hip.so has ABI %d, these bindings expect %d: rebuild (python -c 'import __graft_entry__ "
+                        "as g; g.build()')" % (lib.tcar_abi_version(), ABI_VERSION))
     vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     P = C.POINTER
     lib.tcar_gather_clip_fwd.argtypes = [P(Dims), P(Tables), P(Batch), vp, vp, vp, vp, vp]

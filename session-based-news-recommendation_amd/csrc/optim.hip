@@ -250,4 +250,4 @@ extern "C" int tcar_clip_adam_all(float* w, const float* g, float* m, float* v, 
   return TCAR_OK;
 }
 
-extern "C" int tcar_abi_version(void) { return 2; }
+extern "C" int tcar_abi_version(void) { return TCAR_ABI_VERSION; }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tcar_abi_version() == 2
+    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 3
     assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
     assert lib.tcar_gemm_splitk_effective(64, 16) == 2
 
@@ -116,3 +116,9 @@ def test_load_fold_reads_the_reference_pickle_layout(tmp_path):
     for x, y in zip(a, b):
         for k in x:
             assert (x[k] is None and y[k] is None) or np.array_equal(x[k], y[k]), k
+
+
+def test_graft_entry_build_runs():
+    """the driver's per-round build check: compiles (or reuses) libtcar_hip.so, loads it, checks the ABI, imports the oracle"""
+    import __graft_entry__ as g
+    g.build()
