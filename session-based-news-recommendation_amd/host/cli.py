@@ -56,6 +56,8 @@ def build_parser() -> argparse.ArgumentParser:
     # call-site toggles the reference leaves as comments (sampler.py:87-99)
     ap.add_argument("--gap_mode", default="active_t", choices=["active_t", "click_delta"])
     ap.add_argument("--neg_mode", default="uniform", choices=["uniform", "neighbor", "impression"])
+    ap.add_argument("--neg_fast", default=0, type=int,
+                    help="1: vectorised neighbour / impression negatives (same rules, not the reference's random.choice order)")
     # MI355X
     ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
                     help="precision of the full-catalog scoring GEMMs (bf16x3: split-bf16 planes, fp32-class accuracy)")

@@ -118,6 +118,7 @@ class Seq2SeqAttNN():
         self.neg_num = args['neg_num']
         self.gap_mode = args.get('gap_mode', 'active_t')
         self.neg_mode = args.get('neg_mode', 'uniform')
+        self.neg_fast = bool(args.get('neg_fast', 0))
         self.curEpoch = 0
         self.error_during_train = False
         if content.shape[1] != self.hidden_size:
@@ -168,7 +169,7 @@ class Seq2SeqAttNN():
         len_d, sess_d, time_d = data[:3]
         store = data[3] if len(data) > 3 else None
         return Sampler(len_d, sess_d, time_d, neighbor_dict, item_dict, neg_num, batch_size=self.batch_size,
-                       gap_mode=self.gap_mode, neg_mode=self.neg_mode, store=store)
+                       gap_mode=self.gap_mode, neg_mode=self.neg_mode, store=store, neg_fast=self.neg_fast)
 
     # -------------------------------------------------------------------------------------------- train
     def train(self, sess, item_dict, train_data, neighbor_dict, args, test_data=None, saver=None, threshold_acc=0.99):

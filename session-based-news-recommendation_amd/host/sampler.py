@@ -9,6 +9,11 @@ one H2D copy); ``next_batch()`` re-nests them into the reference's 6-tuple of li
 The two call-site toggles the reference leaves as comments are explicit modes here:
   gap_mode: "active_t" (sampler.py:87, shipped) | "click_delta" (sampler.py:91-94, Globo)
   neg_mode: "uniform" (sampler.py:98-99, shipped) | "neighbor" (:97,:133-140) | "impression" (:96,:118-131)
+
+``neg_fast=True`` draws the neighbour / impression negatives with vectorised numpy from a CSR of the source lists (same
+distribution and rules — neighbour picks differ from the label; impression mode makes at most 21 tries, keeps the
+candidates present in ``item_dict`` and pads with uniform draws — but NOT the reference's ``random.choice`` call
+order, which costs ~5 ms of Python per batch of 512 x 20 and would starve a 0.7-ms device step).
 """
 from __future__ import annotations
 
@@ -20,6 +25,7 @@ import numpy as np
 from .data import SessionStore
 
 _STORE_CACHE: Dict[int, SessionStore] = {}
+_CSR_CACHE: Dict[tuple, tuple] = {}          # (id(neighbor_dict), mode) -> CSR of the negative source (built once per dataset)
 
 
 def store_for(session_dict, session_time_dict) -> SessionStore:
@@ -35,7 +41,7 @@ def store_for(session_dict, session_time_dict) -> SessionStore:
 class Sampler(object):
     def __init__(self, len_dict, session_dict, session_time_dict=None, neighbor_dict=None, item_dict=None,
                  neg_num=None, batch_size=1024, gap_mode="active_t", neg_mode="uniform", store=None,
-                 verbose=True):
+                 verbose=True, neg_fast=False):
         if verbose:
             print('Sampler init begin...')
         self.session_num = len(session_dict) if session_dict is not None else (store.n if store else 0)
@@ -51,6 +57,8 @@ class Sampler(object):
         self.session_dict = session_dict
         self.session_time_dict = session_time_dict
         self.gap_mode, self.neg_mode = gap_mode, neg_mode
+        self.neg_fast = bool(neg_fast)
+        self._csr = None
         if neg_mode not in ("uniform", "neighbor", "impression"):
             raise ValueError("neg_mode must be uniform | neighbor | impression")
         if gap_mode not in ("active_t", "click_delta"):
@@ -83,6 +91,8 @@ class Sampler(object):
         if self.neg_mode == "uniform":
             # K scalar draws per session in the reference == one vector draw from the same legacy stream
             return np.random.randint(0, self.item_num, size=(B, K)).astype(np.int32)
+        if self.neg_fast:
+            return self._negatives_fast(keys, np.asarray(labels0, dtype=np.int64))
         out = np.empty((B, K), dtype=np.int32)
         for b, key in enumerate(keys):
             if self.neg_mode == "neighbor":
@@ -90,6 +100,71 @@ class Sampler(object):
             else:
                 out[b] = self.neg_neighbor_from_impre(int(str(key).split('_')[0]))
         return out
+
+    # vectorised variants ---------------------------------------------------------------------------------------
+    def _source_csr(self):
+        """neighbor_dict as CSR over its keys: (key -> slot, offsets, flat candidate ids).  Impression candidates are
+        mapped through item_dict once (original article id -> 0-based item id, -1 when absent)."""
+        ck = (id(self.neighbor_dict), self.neg_mode, len(self.neighbor_dict))
+        if self._csr is None:
+            self._csr = _CSR_CACHE.get(ck)
+        if self._csr is None:
+            keys = list(self.neighbor_dict.keys())
+            slot = {k: i for i, k in enumerate(keys)}
+            lens = np.fromiter((len(self.neighbor_dict[k]) for k in keys), dtype=np.int64, count=len(keys))
+            off = np.zeros(len(keys) + 1, dtype=np.int64)
+            np.cumsum(lens, out=off[1:])
+            flat = np.empty(int(off[-1]), dtype=np.int64)
+            for i, k in enumerate(keys):
+                c = self.neighbor_dict[k]
+                if self.neg_mode == "impression":
+                    flat[off[i]:off[i + 1]] = [self.item_dict.get(x, 0) - 1 for x in c]
+                else:
+                    flat[off[i]:off[i + 1]] = c
+            arr = None
+            if keys and all(isinstance(k, (int, np.integer)) and 0 <= k < (1 << 26) for k in keys):
+                arr = np.full(int(max(keys)) + 1, -1, dtype=np.int64)          # dense key -> slot map (vectorised lookup)
+                arr[np.asarray(keys, dtype=np.int64)] = np.arange(len(keys))
+            self._csr = _CSR_CACHE[ck] = (slot, off, flat, arr, {})
+        return self._csr
+
+    def _negatives_fast(self, keys, labels0) -> np.ndarray:
+        slot, off, flat, arr, kcache = self._source_csr()
+        K, B = self.neg_num, len(keys)
+        if self.neg_mode == "neighbor":
+            if arr is not None and labels0.max() < len(arr):
+                sl = arr[labels0]
+                if (sl < 0).any():
+                    raise KeyError("label without a neighbour list")
+            else:
+                sl = np.fromiter((slot[int(x)] for x in labels0), dtype=np.int64, count=B)
+        else:
+            sl = np.empty(B, dtype=np.int64)
+            for b, k in enumerate(keys):               # session key "sid_len" -> slot, parsed once per key
+                v = kcache.get(k)
+                if v is None:
+                    v = kcache[k] = slot[int(str(k).split('_')[0])]
+                sl[b] = v
+        lo, cnt = off[sl], off[sl + 1] - off[sl]
+        if (cnt <= 0).any():
+            raise KeyError("empty negative source list")
+        if self.neg_mode == "neighbor":                   # K picks from the label's list, each != label (sampler.py:133-140)
+            pick = flat[lo[:, None] + (np.random.random_sample((B, K)) * cnt[:, None]).astype(np.int64)]
+            bad = pick == labels0[:, None]
+            while bad.any():
+                r, c = np.nonzero(bad)
+                pick[r, c] = flat[lo[r] + (np.random.random_sample(len(r)) * cnt[r]).astype(np.int64)]
+                bad = pick == labels0[:, None]
+            return pick.astype(np.int32)
+        # impression (sampler.py:118-131): at most 21 tries, keep candidates that are catalog items, pad with uniform draws
+        tries = flat[lo[:, None] + (np.random.random_sample((B, 21)) * cnt[:, None]).astype(np.int64)]
+        valid = tries >= 0
+        order = np.argsort(~valid, axis=1, kind="stable")                 # valid tries first, in try order
+        tries = np.take_along_axis(tries, order, 1)[:, :K]
+        nvalid = np.minimum(valid.sum(1), K)
+        fill = np.arange(K)[None, :] >= nvalid[:, None]
+        tries[fill] = np.random.randint(0, self.item_num, size=int(fill.sum()))
+        return tries.astype(np.int32)
 
     def neg_neighbor_from_impre(self, sessionid):
         cand = self.neighbor_dict[sessionid]

@@ -140,3 +140,34 @@ def test_ild_unexp_host_vs_oracle():
     want_un = [metrics_oracle.unexp(s.tolist(), t.tolist(), reverse_item, category_id) for s, t in zip(seq, topk)]
     np.testing.assert_allclose(host_metrics.ild_batch(topk, table), want_ild, rtol=1e-12)
     np.testing.assert_allclose(host_metrics.unexp_batch(seq, topk, table), want_un, rtol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["neighbor", "impression"])
+def test_fast_negative_modes_follow_the_reference_rules(fx, mode):
+    """neg_fast=True does not replay the reference's random.choice order; it must still obey its rules: neighbour picks
+    come from the label's list and differ from the label (sampler.py:133-140); impression picks come from the session's
+    impression list mapped through item_dict, uniform padding only when fewer than K of 21 tries were catalog items
+    (sampler.py:118-131)."""
+    len_d, sess, times = fx["train"]
+    src = fx["neighbor"] if mode == "neighbor" else fx["impressions"]
+    random.seed(3)
+    np.random.seed(3)
+    s = host_sampler.Sampler(copy.deepcopy(len_d), sess, times, neighbor_dict=src, item_dict=fx["item_dict"],
+                             neg_num=fx["neg_num"], batch_size=16, neg_mode=mode, neg_fast=True, verbose=False)
+    seen = 0
+    while s.has_next():
+        keys = s.session_id_batches[s.batch_i]
+        f = s.next_batch_arrays()
+        neg, lab = f["neg"], f["label"]
+        assert neg.shape == (len(keys), fx["neg_num"]) and neg.dtype == np.int32
+        assert (neg >= 0).all() and (neg < len(fx["item_dict"])).all()
+        for b, key in enumerate(keys):
+            if mode == "neighbor":
+                assert set(neg[b].tolist()) <= set(src[int(lab[b])]) and int(lab[b]) not in neg[b].tolist()
+            else:
+                mapped = {fx["item_dict"][x] - 1 for x in src[int(str(key).split('_')[0])] if x in fx["item_dict"]}
+                frac_valid = len(mapped) / max(len(set(src[int(str(key).split('_')[0])])), 1)
+                if frac_valid == 1.0:                      # every try is a catalog item: no uniform padding can occur
+                    assert set(neg[b].tolist()) <= mapped
+        seen += len(keys)
+    assert seen > 0
