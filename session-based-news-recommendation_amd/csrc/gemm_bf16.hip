@@ -13,8 +13,11 @@
 // took 118 us of a 165 us launch and its fragment-shaped 64-byte reads ran at ~1/3 of the L2 rate), double
 // buffered: the next stage's DMA is in flight while the current one is multiplied; __syncthreads() drains it
 // (s_waitcnt vmcnt(0) + s_barrier), which is exactly the visibility rule for LDS-DMA data.
-// Workgroup tile (64*WMW) x (64*WNW) x 32 with WMW x WNW waves, each wave 64 x 64 = 2 x 2 MFMA tiles of 32 x 32;
-// 256 x 128 (8 waves) for the large shapes, 128 x 128 (4 waves) otherwise.  Operand modes:
+// Workgroup tile (32*TMW*WMW) x (32*TNW*WNW) x 32 with WMW x WNW waves of TMW x TNW MFMA tiles (32 x 32).  The kernel is
+// bound by the L2 -> LDS fill rate (PMC: MFMA busy 41-44 % of the SIMD cycles), so each GEMM takes the tile with the
+// fewest fill bytes per flop that LDS (160 KB, two stages) and the register file allow and that fills the chip evenly:
+// logits 256 x 384 (8 waves of 4 x 3 tiles), dX 512 x 128 (16 waves), dE 192 x 192 (12 waves of 1 x 3 tiles);
+// 256 x 256 / 256 x 192 / 256 x 128 / 128 x 128 for other shapes (launch_b).  Operand modes:
 //   MODE 0  k-contiguous: fragment (row = lane&31, k = 8*(lane>>5)+0..7) is one swizzled ds_read_b128;
 //   MODE 1  m/n-contiguous: fragments come from ds_read_b64_tr_b16, the gfx950 transposing LDS read (per 16-lane group
 //           it returns, to lane i, column i of a 4 (k) x 16 (col) block): no transposed copy of E or dlogits exists.

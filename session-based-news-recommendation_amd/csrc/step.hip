@@ -1,6 +1,6 @@
-// Step-level driver: sequences the op-level launchers for one training / evaluation step on one stream, from C++
-// (a few microseconds of host time per launch instead of a Python round trip), with no host synchronisation and no
-// allocation.  tcar_train_step == sess.run([loss, global_step, train_op]) (model_combine.py:231);
+// Step-level driver: sequences the op-level launchers for one training / evaluation step from C++ (a few microseconds of
+// host time per launch instead of a Python round trip) on the caller's stream plus, when the context carries one, an
+// aux stream joined by events — no host synchronisation, no allocation.  tcar_train_step == sess.run([loss, global_step, train_op]) (model_combine.py:231);
 // tcar_eval_step == sess.run([softmax_input, cross_loss]) + util.cau_metrics + top-k (model_combine.py:283,296,301).
 #include "tcar_common.h"
 #include <stdlib.h>
@@ -151,10 +151,15 @@ int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream);
 int item_norm(const tcar_ctx_t* c, const Geo& g, void* stream);
 int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream);
 
-// Backward pass.  Two independent chains follow the softmax gradient:
-//   A (main stream):  dX = dlogits E -> attention / projection backward -> weight gradients           (many small kernels)
-//   B (aux stream):   dE = dlogits^T attout -> negative rows into dE_item [-> dense norm, candidate-side time backward]
-// They are forked / joined with events so the small kernels of A fill the gaps of B's large GEMM.
+// Backward pass.  Two chains follow the softmax gradient (fused single-rank step; `main` is the caller's stream, which the
+// engine makes a high-priority one so that its workgroups are dispatched first):
+//   main:  softmax -> dX = dlogits E -> slab reduce + tanh' + bias -> attention / projection / query backward -> input
+//          gradients -> negative rows + loss -> item norm -> row scatter -> [join] -> (update)
+//   aux:   zero arena, negative-term forward (beside the softmax) -> dE = dlogits^T attout (time block in inverted-index
+//          order) -> candidate-side time backward -> weight-gradient GEMM -> dense-weight norms
+// Every cross-stream join costs ~10 us of launch latency behind an event, so there are as few as the data flow allows.
+// Rank-local backward of the data-parallel step (fuse_finish = false): dE and the negative rows run FIRST on the main
+// stream (their all-reduce then overlaps everything else, dp.py); the finish is tcar_step_finish after the exchange.
 int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
