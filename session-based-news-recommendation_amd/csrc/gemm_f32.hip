@@ -24,6 +24,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) receives a contiguous run of tile ids, with the
 // shorter tile dimension fastest: the workgroups that share the large operand's tile run on one XCD.
 #include "tcar_common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -445,8 +446,13 @@ int launch_x3(GroupArgs& ga, hipStream_t st) {
     p.wg_begin = wg;
     wg += p.mt * p.nt * p.ksplit;
   }
-  // <= one workgroup per CU: a pure latency chain, deep stages; more: shallow stages, three workgroups per CU
-  return wg > 256 ? launch_x3_v<LA, LB, 64>(ga, wg, st) : launch_x3_v<LA, LB, 128>(ga, wg, st);
+    static const int force = getenv("TCAR_X3_XK") ? atoi(getenv("TCAR_X3_XK")) : 0;
+  if (force == 32) return launch_x3_v<LA, LB, 32>(ga, wg, st);
+  if (force == 128) return launch_x3_v<LA, LB, 128>(ga, wg, st);
+  // 64-deep stages (48 KB of LDS) by default: these launches run beside the dE GEMM, whose workgroups hold 96 KB of a CU's
+  // 160 KB — a 96-KB (128-deep) workgroup would have to wait for one of them to retire (measured: 0.704 / 0.690 / 0.680 ms
+  // per step with 128-deep / mixed / 64-deep stages)
+  return launch_x3_v<LA, LB, 64>(ga, wg, st);
 }
 
 int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {
