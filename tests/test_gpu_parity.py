@@ -204,6 +204,8 @@ CASES = [  # N, H, Ht, B, T, K
     (1000, 250, 64, 64, 7, 20),
     (1000, 40, 16, 3, 40, 5),
     (1000, 256, 64, 5, 3, 2),
+    (129, 250, 64, 130, 3, 1),          # N just past one 128-row block, B past one 128-row plane block, a single negative
+    (1000, 250, 64, 513, 2, 33),        # B = 512 + 1: a second (one-row) M tile in every scoring GEMM; K > 32 negatives
 ]
 
 
