@@ -56,7 +56,8 @@ class GradExchange:
         if self.world <= 1:
             return ids.reshape(-1), rows.reshape(-1, rows.shape[-1])
         if not big_done:
-            dist.all_reduce(big, group=g)                                   # 1
+            for part in (big if isinstance(big, (list, tuple)) else (big,)):
+                dist.all_reduce(part, group=g)                              # 1  (parts in the caller's canonical order)
         all_ids = torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
         all_rows = torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
         dist.all_gather_into_tensor(all_ids.view(-1), ids.reshape(-1).contiguous(), group=g)      # 5
@@ -98,6 +99,12 @@ class DPEngine(TcarEngine):
         super().__init__(*a, **kw)
         self.group = group
         self.xch = GradExchange(group)
+        g = self.geo
+        # step 1 in two parts, the candidate-time block FIRST: its clip backward can then run (into a scratch copy of the
+        # time-table gradients) while the item block is still being reduced
+        self.big_parts = [self.big[g.N * g.ldh:], self.big[:g.N * g.ldh]]
+        self._ct_rows = 139 * g.ldt
+        self._ct_scratch = torch.zeros(self._ct_rows + _lib.NSLOT, dtype=torch.float32, device=self.dev)
         self.rows_cap = 0
 
     def _ensure_rows(self, rows: int):
@@ -133,13 +140,19 @@ class DPEngine(TcarEngine):
             main = torch.cuda.current_stream(self.dev)
             self._comm.wait_stream(main)
             with torch.cuda.stream(self._comm):
-                all_ids, all_rows = self.xch.communicate(self.big, self.Gx, ids, rows, big_done=True)
+                all_ids, all_rows = self.xch.communicate(self.big_parts, self.Gx, ids, rows, big_done=True)
             main.wait_stream(self._comm)
+            main.wait_stream(self._aux)                  # the candidate-time backward into the scratch block
             all_ids.record_stream(main)
             all_rows.record_stream(main)
             self._comm_busy = False
-        else:
-            all_ids, all_rows = self.xch.communicate(self.big, self.Gx, ids, rows)
+            # its table gradients and norm pieces go on top of the REDUCED arena (once, like step 4 of the in-line order)
+            o = self.seg["month"]["off"]
+            self.Gx[o:o + self._ct_rows] += self._ct_scratch[:self._ct_rows]
+            self.sqn_pieces += self._ct_scratch[self._ct_rows:]
+            self.xch.finish(all_ids, all_rows, self._sqnorm_item, lambda: None, scatter, self._sqnorm_dense)
+            return
+        all_ids, all_rows = self.xch.communicate(self.big_parts, self.Gx, ids, rows)
         aux = getattr(self, "_aux", None)
         if aux is not None and self.big.is_cuda:
             # the candidate-time backward (needs only the reduced d_et; adds atomically into the reduced arena) runs on the
@@ -154,6 +167,7 @@ class DPEngine(TcarEngine):
             self.xch.finish(all_ids, all_rows, self._sqnorm_item, self._cand_time_bwd, scatter, self._sqnorm_dense)
 
     _comm_busy = False
+    async_exchanges = 0      # steps whose collectives ran on the communication stream (tests assert the path is live)
 
     def start_big_reduce(self):
         """Step 1 of the exchange, started on a communication stream as soon as dE is complete (event 3 of the C++
@@ -166,8 +180,27 @@ class DPEngine(TcarEngine):
             self._comm = torch.cuda.Stream(self.dev)
         self._comm.wait_event(self._aux_ev[3])
         with torch.cuda.stream(self._comm):
-            dist.all_reduce(self.big, group=self.group)
+            dist.all_reduce(self.big_parts[0], group=self.group)        # candidate-time block
+            det_done = torch.cuda.Event()
+            det_done.record(self._comm)
+            dist.all_reduce(self.big_parts[1], group=self.group)        # item block
+        # candidate-side clip backward of the reduced time block, on the aux stream beside the item block's all-reduce,
+        # into a scratch copy of the time-table gradients / norm pieces (added to the arena after ITS all-reduce)
+        self._aux.wait_event(det_done)
+        with torch.cuda.stream(self._aux):
+            self._ct_scratch.zero_()
+            gr = self._grads()
+            base = self._ct_scratch.data_ptr()
+            o0 = self.seg["month"]["off"]
+            for k, n in enumerate(["month", "day", "week", "hour", "minute"]):
+                gr.g_time[k] = base + 4 * (self.seg[n]["off"] - o0)
+            gr.sqn = base + 4 * self._ct_rows
+            check(self.lib.tcar_cand_time_bwd_indexed(C.byref(self.dims), C.byref(self._time_ptrs()), self._p(self.inv_n),
+                                                      self._p(self.inv_off), self._p(self.d_et), int(self.scoring_code != 0),
+                                                      self._p(self.ct_ws), C.byref(gr), self._stream()),
+                  "tcar_cand_time_bwd_indexed")
         self._comm_busy = True
+        self.async_exchanges += 1
 
     def train_step(self, batch, bt=None, cap_rows: Optional[int] = None):
         """`batch` may be None for a rank whose shard of the global batch is empty (it still joins the collectives)."""

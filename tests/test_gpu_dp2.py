@@ -42,6 +42,7 @@ def _worker(rank, world, port, scoring, ret):
         for _ in range(3):
             eng.train_step(sub, cap_rows=cap * T)
         torch.cuda.synchronize()
+        assert eng.async_exchanges == 3          # the collectives really ran on the communication stream (overlapped path)
         got = eng.export_params()
         if rank == 0:
             ref = TcarEngine(params, content, mw, max_grad=2.0, scoring=scoring)
