@@ -23,7 +23,9 @@ xGMI is point-to-point (7 links/GPU): step 1 moves ~106 MB per rank at the Globo
 depends on dE, so the rank-local backward runs dE FIRST and `DPEngine` starts step 1 on a communication stream the
 moment dE is complete (an event recorded by the C++ driver): the all-reduce runs beside dX, the attention / projection
 backward and the weight gradients; the sparse-row all-gather and the arena all-reduce are queued behind it on the same
-stream as soon as the rank-local backward has produced them, and the main stream joins once, before step 2.
+stream as soon as the rank-local backward has produced them, and the main stream joins once, before step 2.  Step 1 is
+sent as two all-reduces, the candidate-time block first, so that step 4 can run (into a scratch block, added to the arena
+after step 3) while the item block is still on the wire.
 `GradExchange` is device-agnostic (tests run it over gloo on CPU tensors with the oracle's gradients).
 """
 from __future__ import annotations
