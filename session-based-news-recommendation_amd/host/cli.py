@@ -121,8 +121,14 @@ def main(argv=None):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        backend = os.environ.get("TCAR_DIST_BACKEND", "nccl")       # "gloo" + TCAR_SAME_DEVICE=1: dry runs on one GPU
+        if os.environ.get("TCAR_SAME_DEVICE"):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local))
+        else:
+            dist.init_process_group(backend)
         dp_group = dist.group.WORLD
     train_data, test_data, neighbor, a, item_dict = load_datas(args)
     if dp_group is not None:

@@ -141,6 +141,13 @@ class Seq2SeqAttNN():
                                  device=args.get('device', 'cuda:0'), scoring=args.get('scoring', 'bf16x3'), **kw)
         self._cat = None
         self._store_cache = {}
+        # data parallel (main.py --gpus N): every rank builds the SAME batches (same seeds) and keeps its contiguous shard
+        self.dp_group = args.get('dp_group')
+        if self.dp_group is not None:
+            import torch.distributed as dist
+            self.dp_rank, self.dp_world = dist.get_rank(self.dp_group), dist.get_world_size(self.dp_group)
+        else:
+            self.dp_rank, self.dp_world = 0, 1
 
     # ------------------------------------------------------------------------------------------ helpers
     def _category_table(self):
@@ -171,6 +178,26 @@ class Seq2SeqAttNN():
         return Sampler(len_d, sess_d, time_d, neighbor_dict, item_dict, neg_num, batch_size=self.batch_size,
                        gap_mode=self.gap_mode, neg_mode=self.neg_mode, store=store, neg_fast=self.neg_fast)
 
+    def _shard(self, feed):
+        """this rank's contiguous shard of a batch (dp.shard_bounds) -> (sub-feed or None when empty, rows capacity / T)"""
+        if self.dp_world == 1:
+            return feed, None
+        from ..dp import shard_bounds
+        b = feed["seq"].shape[0]
+        lo, hi, cap = shard_bounds(b, self.dp_world, self.dp_rank)
+        if hi <= lo:
+            return None, cap
+        return {k: (v[lo:hi] if v is not None else None) for k, v in feed.items()}, cap
+
+    def _allsum(self, values):
+        """sum a list of python floats over the ranks"""
+        if self.dp_world == 1:
+            return values
+        import torch.distributed as dist
+        t = torch.tensor(values, dtype=torch.float64, device=self.engine.dev)
+        dist.all_reduce(t, group=self.dp_group)
+        return t.cpu().tolist()
+
     # -------------------------------------------------------------------------------------------- train
     def train(self, sess, item_dict, train_data, neighbor_dict, args, test_data=None, saver=None, threshold_acc=0.99):
         eng = self.engine
@@ -186,12 +213,18 @@ class Seq2SeqAttNN():
                 batch += 1
                 if batch < 3 and feed["neg"] is not None:
                     print(feed["neg"][0][:10].tolist())
-                crt_loss = eng.train_step(feed)                 # [b] on device; no host sync inside the loop
+                if self.dp_world > 1:
+                    T = feed["seq"].shape[1]
+                    sub, cap = self._shard(feed)
+                    crt_loss = eng.train_step(sub, cap_rows=cap * T)
+                else:
+                    crt_loss = eng.train_step(feed)             # [b] on device; no host sync inside the loop
                 total += crt_loss.double().sum()
                 count += crt_loss.numel()
-            avgc = float(total.item()) / max(count, 1)
+            tot, cnt = self._allsum([float(total.item()), float(count)])
+            avgc = tot / max(cnt, 1)
             self.train_seconds = time.time() - t0
-            self.train_sessions = count
+            self.train_sessions = int(cnt)
             if np.isnan(avgc):
                 print('Epoch {}: NaN error!'.format(str(epoch)))
                 self.error_during_train = True
@@ -223,6 +256,9 @@ class Seq2SeqAttNN():
         pending = []
         for feed in prefetch_batches(sampler):
             batch += 1
+            feed, _cap = self._shard(feed)           # data parallel: every rank scores its shard of the batch
+            if feed is None:
+                continue
             rank, topk, ce = eng.eval_step(feed, k=20)
             pending.append((feed, rank.clone(), topk.clone(), ce.clone()))     # device results; drained below
             if batch < 3:
@@ -246,12 +282,20 @@ class Seq2SeqAttNN():
             if args.get('is_print'):
                 self.printData(str(args['foldnum']) + '_' + str(self.curEpoch), feed["seq"].tolist(),
                                feed["label"].tolist(), tk.tolist())
-        print('avg loss...', np.mean(losses))
-        print('avg ILD...', np.mean(ilds))
-        print('avg unexp...', np.mean(unexps))
+        # sums over this rank's sessions, then over the ranks; coverage = union of the recommended items
+        sums = self._allsum([float(np.sum(x)) for x in (losses, ilds, unexps, mrrs, hits, ndcgs)] + [float(len(hits))])
+        n = max(sums[6], 1.0)
+        if self.dp_world > 1:
+            import torch.distributed as dist
+            parts = [None] * self.dp_world
+            dist.all_gather_object(parts, sorted(result_items), group=self.dp_group)
+            result_items = set().union(*[set(p) for p in parts])
+        m_loss, m_ild, m_unexp, m_mrr, m_hit, m_ndcg = [v / n for v in sums[:6]]
+        print('avg loss...', m_loss)
+        print('avg ILD...', m_ild)
+        print('avg unexp...', m_unexp)
         print('len of result dict: ', len(result_items))
-        print('MRR@20: {}, Recall@20: {}, nDCG@20: {}'.format(np.mean(mrrs), np.mean(hits), np.mean(ndcgs)))
-        self.last_metrics = {"mrr": float(np.mean(mrrs)), "recall": float(np.mean(hits)), "ndcg": float(np.mean(ndcgs)),
-                             "loss": float(np.mean(losses)), "ild": float(np.mean(ilds)),
-                             "unexp": float(np.mean(unexps)), "coverage": len(result_items)}
-        return np.mean(hits)
+        print('MRR@20: {}, Recall@20: {}, nDCG@20: {}'.format(m_mrr, m_hit, m_ndcg))
+        self.last_metrics = {"mrr": m_mrr, "recall": m_hit, "ndcg": m_ndcg, "loss": m_loss, "ild": m_ild,
+                             "unexp": m_unexp, "coverage": len(result_items)}
+        return m_hit

@@ -77,3 +77,46 @@ def test_two_ranks_match_single_engine(scoring):
     mp.spawn(_worker, args=(world, _free_port(), scoring, ret), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", ret.get(r)
+
+
+def _cli_worker(rank, world, port, argv, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), TCAR_DIST_BACKEND="gloo", TCAR_SAME_DEVICE="1")
+    try:
+        import io
+        from contextlib import redirect_stdout
+        import tcar_amd  # noqa: F401
+        from tcar_amd.host.cli import main
+        with redirect_stdout(io.StringIO()):
+            model = main(argv + ["--gpus", str(world)])
+        ret[rank] = dict(model.last_metrics, sessions=model.train_sessions)
+    except Exception as e:
+        import traceback
+        ret[rank] = "FAIL: " + repr(e) + "\n" + traceback.format_exc()
+
+
+def test_cli_two_ranks_shard_batches_and_agree_with_one_rank():
+    """main.py --gpus 2: both ranks form the same batches, train on their contiguous shards (DPEngine) and evaluate their
+    shards; the all-reduced metrics equal the single-process run's up to float-atomic noise."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import io
+    from contextlib import redirect_stdout
+    import torch.multiprocessing as mp
+    argv = ["--synthetic", "700", "--synthetic_train", "3000", "--synthetic_test", "600", "--epoch", "2",
+            "--hidden_size", "48", "--time_hidden_size", "16", "--batch_size", "128", "--gap_mode", "click_delta"]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cli_worker, args=(2, _free_port(), argv, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert isinstance(ret.get(r), dict), ret.get(r)
+    assert ret[0] == ret[1]                                   # every rank reports the same all-reduced numbers
+    import tcar_amd  # noqa: F401
+    from tcar_amd.host.cli import main
+    with redirect_stdout(io.StringIO()):
+        one = main(argv)
+    m1, m2 = one.last_metrics, ret[0]
+    assert m2["sessions"] == one.train_sessions               # every session was trained on exactly once
+    assert abs(m1["loss"] - m2["loss"]) <= 2e-3 * abs(m1["loss"])
+    for k in ("recall", "mrr", "ndcg"):
+        assert abs(m1[k] - m2[k]) <= 0.01, (k, m1[k], m2[k])
