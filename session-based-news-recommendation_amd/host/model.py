@@ -232,7 +232,7 @@ class Seq2SeqAttNN():
             print('\tloss: {:.6f}'.format(avgc))
             if test_data is not None:
                 recall = self.test(sess, test_data, args)
-                if recall > threshold_acc:
+                if recall > threshold_acc and self.dp_rank == 0:       # replicas are identical: one writer
                     modelname = self.save(args)
                     print('Model saved - {}'.format(modelname))
 
