@@ -140,7 +140,12 @@ def main(argv=None):
     model = getattr(mod, "Seq2SeqAttNN")(a)
     if is_train:
         print('Begin Training')
-        model.train(None, item_dict, train_data, neighbor, a, test_data, None)
+        # The reference never forwards --threshold_acc (main.py:76: train() keeps its default 0.99, so nothing is ever
+        # saved).  Here `--save 1` makes the flag live; without it the reference's behaviour is kept.
+        if args.save:
+            model.train(None, item_dict, train_data, neighbor, a, test_data, None, threshold_acc=args.threshold_acc)
+        else:
+            model.train(None, item_dict, train_data, neighbor, a, test_data, None)
         if getattr(model, "train_seconds", None):
             print("[tcar] last epoch: %d sessions in %.2f s = %.0f sessions/s (host sampler + H2D + device step)"
                   % (model.train_sessions, model.train_seconds, model.train_sessions / model.train_seconds),

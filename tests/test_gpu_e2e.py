@@ -123,3 +123,27 @@ def test_cli_runs_on_a_fold_in_the_reference_pickle_layout(tmp_path):
         assert line in out, line
     assert 0.0 <= model.last_metrics["recall"] <= 1.0 and np.isfinite(model.last_metrics["loss"])
     assert model.last_metrics["ild"] > 0          # the category file was used
+
+
+def test_cli_checkpoint_save_then_test_only(tmp_path):
+    """--save 1 --threshold_acc / --modelpath save (model_combine.py:249-252) and the test-only run (main.py:85-91, --train ''):
+    the restored variables reproduce the evaluation of the training run."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import glob
+    from tcar_amd.host.cli import main
+    common = ["--synthetic", "600", "--synthetic_train", "3000", "--synthetic_test", "400", "--hidden_size", "48",
+              "--time_hidden_size", "16", "--batch_size", "128", "--gap_mode", "click_delta"]
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        trained = main(common + ["--epoch", "1", "--save", "1", "--threshold_acc", "-1", "--modelpath", str(tmp_path) + "/"])
+    assert "Model saved" in buf.getvalue()
+    files = glob.glob(str(tmp_path / "model.ckpt-*.pt"))
+    assert len(files) == 1
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        restored = main(common + ["--train", "", "--modelpath", files[0]])
+    assert "Begin Testing" in buf.getvalue()
+    for k in ("recall", "mrr", "ndcg", "coverage"):
+        assert restored.last_metrics[k] == trained.last_metrics[k], k
+    assert abs(restored.last_metrics["loss"] - trained.last_metrics["loss"]) <= 1e-6 * abs(trained.last_metrics["loss"])
