@@ -1,3 +1,5 @@
+"""Thread sweep of the CPU baseline (the oracle, i.e. test infrastructure: this helper lives under tests/ for that reason).
+Usage (repo root): python tests/cpu_baseline_threads.py"""
 import sys, time, os
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
