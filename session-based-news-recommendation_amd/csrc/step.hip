@@ -125,21 +125,25 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
     RET(small_gemm(c, 0, 2, p, stream));
   }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
-  // logits = attout E^T (model_combine.py:138)
+  // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   int ei = -1;
-  if (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) {
-    ei = (*c->ev_cursor)++ % c->ev_n;
-    (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
-  }
+  auto start_timer = [&]() {
+    if (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) {
+      ei = (*c->ev_cursor)++ % c->ev_n;
+      (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
+    }
+  };
   int rc;
   if (c->scoring) {
     // split-bf16 path: attout -> hi/lo planes (+ the packed item|time operand of dE), then the bf16 MFMA GEMM
     rc = tcar_split_bf16(c->attout, g.ek, B, g.ek, c->a16h, c->a16l, g.ek, c->ap16h, c->ap16l, g.ldh + g.pt, g.ldh, g.ic,
                          stream);
+    start_timer();
     if (!rc)
       rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
                           nullptr, 0, 0, c->scoring, 1, stream);
   } else {
+    start_timer();
     rc = tcar_gemm_f32(1, B, g.N, g.ek, c->attout, g.ek, c->E, g.ek, c->logits, g.Npad, nullptr, 0, 0, 1, stream);
   }
   if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[ei], (hipStream_t)stream);
