@@ -770,3 +770,25 @@ def test_eval_rows_rank_topk_ce(lib, N):
         close(ce.cpu().numpy(), lse - xv[np.arange(B), lab], name="ce")
     else:
         assert lib.tcar_eval_rows(B, N, ptr(d), ldn, ptr(dl), k, ptr(rank), ptr(topk), ptr(ce), None) != 0
+
+
+def test_python_sequenced_op_level_path_matches_the_cpp_driver():
+    """engine.forward / backward / update call the op-level C-ABI entry points one by one from Python (fp32 scoring; the
+    order INTEGRATION.md documents); the C++ step driver must produce the same losses, gradients and updated variables."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 700, 250, 64, 41, 3, 5
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=17)
+    a = TcarEngine(params, content, mw, max_grad=2.0, scoring="f32")
+    b = TcarEngine(params, content, mw, max_grad=2.0, scoring="f32")
+    b.native = False
+    la, lb = a.loss_and_grads(batch), b.loss_and_grads(batch)
+    close(la.cpu().numpy(), lb.cpu().numpy(), name="loss", rtol=1e-5)
+    ga, gb = a.export_grads(), b.export_grads()
+    for k in ga:
+        close(ga[k], gb[k], name="grad " + k, rtol=1e-4, atol_scale=1e-5)
+    for _ in range(2):
+        close(a.train_step(batch).cpu().numpy(), b.train_step(batch).cpu().numpy(), name="train loss", rtol=1e-4)
+    pa, pb = a.export_params(), b.export_params()
+    for k in pa:
+        assert np.abs(pa[k] - pb[k]).max() <= 1e-4 * np.abs(pa[k]).max() + 0.25 * 1e-3 * 2, k
