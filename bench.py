@@ -126,15 +126,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # training loops defer each step's Adam into the next step's forward pass (engine.train_step docstring); the last
+    # update is flushed INSIDE the timed region, so K timed steps contain exactly K updates
+    defer = {} if world > 1 or os.environ.get("TCAR_FORCE_DP") or os.environ.get("TCAR_NO_DEFER") else {"defer_update": True}
     for i in range(args.warmup):
-        eng.train_step(None, bt=resident[i % len(resident)])
+        eng.train_step(None, bt=resident[i % len(resident)], **defer)
     tags = ["score_fwd", "score_dx", "score_dE", "weight_grads", "gather_fwd", "softmax_ce", "adam_item"]
     if not args.no_kernel_timing:
         eng.enable_native_timing(args.steps)     # HIP events around the logits GEMM inside tcar_train_step
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        eng.train_step(None, bt=resident[(args.warmup + i) % len(resident)])
+        eng.train_step(None, bt=resident[(args.warmup + i) % len(resident)], **defer)
+    eng.flush()
     t_enq = time.perf_counter() - t0          # host time to enqueue every step (the loop never synchronises)
     sync()
     dt = time.perf_counter() - t0

@@ -305,8 +305,22 @@ int tcar_clip_adam_all(float* w, const float* g, float* m, float* v, const tcar_
                        const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t,
                        float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, void* stream);
 
+/* Split update.  tcar_clip_adam_early: tcar_clip_adam over the arena segments plus the item rows listed in `ids` (1-based
+ * item ids, repeats allowed: a bit per row in `bitmap` — zero on entry — makes every row update exactly once);
+ * tcar_clip_adam_rest: every item row whose bit is clear, then clears the bitmap.  Together they equal
+ * tcar_clip_adam_all; the step driver runs the second on the aux stream beside the next forward pass. */
+int tcar_clip_adam_early(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,
+                         const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot,
+                         const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t,
+                         float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, const int32_t* ids,
+                         int64_t n_ids, uint32_t* bitmap, void* stream);
+int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols,
+                        int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip,
+                        float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap,
+                        void* stream);
+
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 3
+#define TCAR_ABI_VERSION 4
 int tcar_abi_version(void);
 
 /* ---- step-level entry points ------------------------------------------------------------------------------------
@@ -353,6 +367,7 @@ typedef struct {
   /* optional auxiliary stream + 4 events (hipStream_t / hipEvent_t, caller-created): the candidate-side time refresh
    * (forward) and the dE chain (backward) run on it concurrently with the session-side chain; NULL = one stream */
   void* stream2; void* ev[6];
+  uint32_t* adam_bitmap;    /* [ceil(N/32)] zeroed words: rows already updated by the early pass of a split update */
   const int32_t* et_perm;   /* [5, N] position of (k, n) in the inverted index (bf16 scoring modes: dE writes d_et in that order) */
   /* optional device timing of the dominant kernel (full-catalog logits GEMM): ev_n pairs of hipEvent_t, used
    * round-robin through the host counter *ev_cursor; ev_n = 0 disables it */
@@ -368,6 +383,13 @@ int tcar_step_finish(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream);
 /* per-variable clip + Adam with the bias-corrected rate lr_t */
 int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream);
 int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream);
+
+/* tcar_train_step_deferred: forward + backward of `bt` WITHOUT its optimizer update; if `pending` != 0 the update of the
+ * PREVIOUS step (bias-corrected rate lr_pending) is applied first, split: arena + the item rows of bt's sessions on the
+ * main stream, all other item rows on the aux stream beside this forward pass (they are only needed by the logits GEMM).
+ * The caller owes one tcar_step_update (or a further deferred step) for `bt`.  Same results as tcar_train_step. */
+int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int pending, float lr_pending,
+                             void* stream);
 /* rank [B], topk [B,k], ce [B] (the logits buffer is consumed) */
 int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream);
 

@@ -18,15 +18,15 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 3          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 4          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_clip_adam_all", "tcar_abi_version", "tcar_step_forward",
-           "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_eval_step"]
+           "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_step_forward",
+           "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
 
 
 def _hipcc() -> str:
@@ -115,7 +115,7 @@ class Ctx(C.Structure):
                 + [(n, C.c_void_p) for n in _WS]
                 + [("rank", C.c_void_p), ("topk", C.c_void_p), ("scoring", C.c_int32), ("scoring_bwd", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l")]
-                + [("stream2", C.c_void_p), ("ev", C.c_void_p * 6), ("et_perm", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
+                + [("stream2", C.c_void_p), ("ev", C.c_void_p * 6), ("adam_bitmap", C.c_void_p), ("et_perm", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
                    ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p)])
 
 
@@ -178,6 +178,10 @@ def load() -> C.CDLL:
     lib.tcar_clip_adam.argtypes = [vp, vp, vp, vp, P(Segments), vp, vp, vp, f32, f32, f32, f32, f32, vp]
     lib.tcar_clip_adam_all.argtypes = [vp, vp, vp, vp, P(Segments), vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32,
                                        f32, f32, f32, vp, vp, i64, vp]
+    lib.tcar_clip_adam_early.argtypes = [vp, vp, vp, vp, P(Segments), vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32,
+                                         f32, f32, f32, vp, vp, i64, vp, i64, vp, vp]
+    lib.tcar_clip_adam_rest.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64,
+                                        vp, vp]
     lib.tcar_clip_adam_2d.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp]
     lib.tcar_clip_adam_2d_bf16.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp,
                                            i64, vp]
@@ -188,6 +192,7 @@ def load() -> C.CDLL:
     lib.tcar_step_finish.argtypes = [P(Ctx), P(Batch), vp]
     lib.tcar_step_update.argtypes = [P(Ctx), f32, vp]
     lib.tcar_train_step.argtypes = [P(Ctx), P(Batch), i32, f32, vp]
+    lib.tcar_train_step_deferred.argtypes = [P(Ctx), P(Batch), i32, i32, f32, vp]
     lib.tcar_eval_step.argtypes = [P(Ctx), P(Batch), i32, i32, vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = C.c_int

@@ -99,12 +99,14 @@ __device__ __forceinline__ void item_adam_blocks(int blk, int nblk, float* __res
                                                  long rows, int cols, int slot, const float* __restrict__ sqn_dense,
                                                  const float* __restrict__ sqn_pieces, const int32_t* __restrict__ use_dense,
                                                  float clip, float lr_t, float b1, float b2, float eps,
-                                                 __bf16* __restrict__ eh, __bf16* __restrict__ el, long ld16) {
+                                                 __bf16* __restrict__ eh, __bf16* __restrict__ el, long ld16,
+                                                 const uint32_t* __restrict__ skip = nullptr) {
   const float sc = clip_factor(sqn_dense, sqn_pieces, use_dense, slot, clip);
   const int c4 = cols >> 2;
   const long total = rows * c4;
   for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
     const long r = i / c4;
+    if (skip && ((skip[r >> 5] >> (r & 31)) & 1u)) continue;      // row already updated by the early pass
     const int c = (int)(i - r * c4) * 4;
     const long p = r * cols + c;
     float* wp = w + r * ldw + c;
@@ -151,6 +153,55 @@ __global__ __launch_bounds__(256) void clip_adam_all_kernel(const AdamAll p, con
     arena_adam_block(idx / p.gx, idx % p.gx, p.w, p.g, p.m, p.v, a, p.sqn_dense, p.sqn_pieces, p.use_dense, p.clip, p.lr_t,
                      p.b1, p.b2, p.eps);
   }
+}
+
+// ---- split update (deferred item-table Adam) ---------------------------------------------------------------------
+// The NEXT step's gather needs only the item rows of its own sessions and its small kernels leave the chip idle; the
+// item table's Adam is an HBM-bound pass over all rows.  So the update is issued in two parts: EARLY = the arena + the
+// item rows listed in `ids` (the next batch's session items; a bitmap makes every row update exactly once although ids
+// repeat), REST = every other row, which the step driver runs on the aux stream beside the next forward pass.
+struct AdamEarly {
+  AdamAll p;
+  const int32_t* ids; long n_ids; uint32_t* bitmap; int n_rowblk;
+};
+__global__ __launch_bounds__(256) void clip_adam_early_kernel(const AdamEarly e, const SegArgs a) {
+  const AdamAll& p = e.p;
+  if ((int)blockIdx.x >= e.n_rowblk) {
+    const int idx = blockIdx.x - e.n_rowblk;
+    arena_adam_block(idx / p.gx, idx % p.gx, p.w, p.g, p.m, p.v, a, p.sqn_dense, p.sqn_pieces, p.use_dense, p.clip, p.lr_t,
+                     p.b1, p.b2, p.eps);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per listed id
+  if (i >= e.n_ids) return;
+  long r = (long)e.ids[i] - 1;                                        // ids are 1-based item ids (sampler.py:67)
+  r = r < 0 ? 0 : (r >= p.rows ? p.rows - 1 : r);
+  unsigned old = 0;
+  if (lane == 0) old = atomicOr(e.bitmap + (r >> 5), 1u << (r & 31));
+  old = __shfl(old, 0);
+  if ((old >> (r & 31)) & 1u) return;                                 // another wave owns this row
+  const float sc = clip_factor(p.sqn_dense, p.sqn_pieces, p.use_dense, p.slot, p.clip);
+  for (int c = lane * 4; c < p.cols; c += 256) {
+    const long q = r * p.cols + c;
+    float* wp = p.w2 + r * p.ldw + c;
+    float4 ww = ld4(wp), mm = ld4(p.m2 + q), vv = ld4(p.v2 + q);
+    adam4(ww, ld4(p.g2 + q), mm, vv, sc, p.lr_t, p.b1, p.b2, p.eps);
+    st4(wp, ww); st4(p.m2 + q, mm); st4(p.v2 + q, vv);
+    if (p.eh) {
+      const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
+      bf16x4_t h, l;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { h[j] = (__bf16)wv[j]; l[j] = (__bf16)(wv[j] - (float)h[j]); }
+      const long o = kb32_off(r, c, (int)(p.ld16 >> 5));
+      *reinterpret_cast<bf16x4_t*>(p.eh + o) = h;
+      *reinterpret_cast<bf16x4_t*>(p.el + o) = l;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void clip_adam_rest_kernel(const AdamAll p, const uint32_t* __restrict__ skip) {
+  item_adam_blocks(blockIdx.x, gridDim.x, p.w2, p.ldw, p.g2, p.m2, p.v2, p.rows, p.cols, p.slot, p.sqn_dense, p.sqn_pieces,
+                   p.use_dense, p.clip, p.lr_t, p.b1, p.b2, p.eps, p.eh, p.el, p.ld16, skip);
 }
 
 int seg_grid_x(const tcar_segments_t* s) {
@@ -247,6 +298,66 @@ extern "C" int tcar_clip_adam_all(float* w, const float* g, float* m, float* v, 
   const int grid = p.n2d + p.gx * segs->nseg;
   TCAR_LAUNCH(clip_adam_all_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a);
   TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+static int fill_adam_all(AdamAll& p, float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d,
+                         int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot,
+                         const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t,
+                         float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16) {
+  if (!sqn_dense || !sqn_pieces || !use_dense) return TCAR_E_ARG;
+  if (e16_hi && (!e16_lo || (ld16 & 31))) return TCAR_E_ARG;
+  if (!w2d || !g2d || !m2d || !v2d || rows <= 0 || cols <= 0 || (cols & 3) || (ldw & 3) || slot < 0 || slot >= TCAR_NSLOT)
+    return TCAR_E_ARG;
+  p.w2 = w2d; p.ldw = ldw; p.g2 = g2d; p.m2 = m2d; p.v2 = v2d; p.rows = rows; p.cols = cols; p.slot = slot;
+  p.eh = (__bf16*)e16_hi; p.el = (__bf16*)e16_lo; p.ld16 = ld16;
+  long total = rows * (cols >> 2);
+  long n2d = (total + 256 * 4 - 1) / (256 * 4);
+  p.n2d = (int)(n2d > 4096 ? 4096 : (n2d < 1 ? 1 : n2d));
+  p.gx = (segs && segs->nseg) ? seg_grid_x(segs) : 1;
+  if (p.gx < 1) p.gx = 1;
+  p.w = w; p.g = g; p.m = m; p.v = v;
+  p.sqn_dense = sqn_dense; p.sqn_pieces = sqn_pieces; p.use_dense = use_dense;
+  p.clip = clip; p.lr_t = lr_t; p.b1 = b1; p.b2 = b2; p.eps = eps;
+  return TCAR_OK;
+}
+
+extern "C" int tcar_clip_adam_early(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d,
+                                    int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols,
+                                    int32_t slot, const float* sqn_dense, const float* sqn_pieces,
+                                    const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
+                                    void* e16_hi, void* e16_lo, int64_t ld16, const int32_t* ids, int64_t n_ids,
+                                    uint32_t* bitmap, void* stream) {
+  if (check_segs(segs) || !w || !g || !m || !v || !bitmap || n_ids < 0 || (n_ids > 0 && !ids)) return TCAR_E_ARG;
+  AdamEarly e;
+  const int rc = fill_adam_all(e.p, w, g, m, v, segs, w2d, ldw, g2d, m2d, v2d, rows, cols, slot, sqn_dense, sqn_pieces,
+                               use_dense, clip, lr_t, b1, b2, eps, e16_hi, e16_lo, ld16);
+  if (rc) return rc;
+  e.ids = ids; e.n_ids = n_ids; e.bitmap = bitmap;
+  e.n_rowblk = (int)((n_ids + 3) / 4);
+  SegArgs a;
+  a.s = *segs;
+  const int grid = e.n_rowblk + e.p.gx * segs->nseg;
+  if (grid <= 0) return TCAR_OK;
+  TCAR_LAUNCH(clip_adam_early_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, e, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows,
+                                   int32_t cols, int32_t slot, const float* sqn_dense, const float* sqn_pieces,
+                                   const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
+                                   void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap, void* stream) {
+  if (!bitmap) return TCAR_E_ARG;
+  AdamAll p;
+  const int rc = fill_adam_all(p, nullptr, nullptr, nullptr, nullptr, nullptr, w2d, ldw, g2d, m2d, v2d, rows, cols, slot,
+                               sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps, e16_hi, e16_lo, ld16);
+  if (rc) return rc;
+  TCAR_LAUNCH(clip_adam_rest_kernel, dim3(p.n2d), dim3(256), 0, (hipStream_t)stream, p, (const uint32_t*)bitmap);
+  TCAR_CHECK_LAUNCH();
+  // every row is up to date now: clear the marks for the next step (stream ordered behind the kernel)
+  if (hipMemsetAsync(bitmap, 0, (size_t)((rows + 31) / 32) * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+    return TCAR_E_LAUNCH;
   return TCAR_OK;
 }
 

@@ -73,7 +73,18 @@ int check_ctx(const tcar_ctx_t* c, const tcar_batch_t* bt) {
 
 }  // namespace
 
+namespace {
+// `rest_lr` >= 0: the item rows the early pass of a split update left out are updated on the aux stream, behind the
+// candidate-time refresh and in front of the join that the logits GEMM waits for
+int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream, float rest_lr);
+}  // namespace
+
 extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream) {
+  return forward_impl(c, bt, refresh_time, stream, -1.f);
+}
+
+namespace {
+int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream, float rest_lr) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
   const int B = bt->B, BT = bt->B * bt->T;
@@ -90,6 +101,12 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
     }
     RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
                                 s2 ? (void*)s2 : stream));
+    if (s2 && rest_lr >= 0.f) {
+      const float* pieces = c->Gx + c->arena_n;
+      RET(tcar_clip_adam_rest(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
+                              c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
+                              c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2));
+    }
     if (s2) {
       if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
       joined = false;
@@ -149,6 +166,7 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
   if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[ei], (hipStream_t)stream);
   return rc;
 }
+}  // namespace
 
 namespace {
 int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream);
@@ -357,6 +375,29 @@ extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int 
   RET(tcar_step_forward(c, bt, refresh_time, stream));
   RET(backward_impl(c, bt, stream, true));
   return tcar_step_update(c, lr_t, stream);
+}
+
+extern "C" int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int pending,
+                                        float lr_pending, void* stream) {
+  RET(check_ctx(c, bt));
+  float rest_lr = -1.f;
+  if (pending) {
+    hipStream_t s2 = aux_stream(c);
+    if (s2 && refresh_time && c->adam_bitmap) {
+      // EARLY part on the main stream: arena + the item rows this batch gathers; the REST runs inside the forward pass
+      const Geo g(c->d);
+      const float* pieces = c->Gx + c->arena_n;
+      RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
+                               c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, lr_pending, c->b1, c->b2, c->eps,
+                               c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq,
+                               (int64_t)bt->B * bt->T, c->adam_bitmap, stream));
+      rest_lr = lr_pending;
+    } else {
+      RET(tcar_step_update(c, lr_pending, stream));
+    }
+  }
+  RET(forward_impl(c, bt, refresh_time, stream, rest_lr));
+  return backward_impl(c, bt, stream, true);
 }
 
 extern "C" int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream) {

@@ -228,6 +228,7 @@ class DPEngine(TcarEngine):
 
     def _local(self, bt):
         """forward + rank-local backward, driven from C++ (tcar_step_forward / tcar_step_backward_local)."""
+        self.flush()
         if self.native and self.timing is None:
             self._ensure_work(bt.B, bt.T)
             ctx, st = self._ctx(), self._stream()

@@ -201,6 +201,7 @@ class TcarEngine:
         et_perm = np.empty(5 * g.N, dtype=np.int32)
         et_perm[order] = np.arange(5 * g.N, dtype=np.int32)
         self.et_perm = torch.tensor(et_perm, device=self.dev)
+        self.adam_bitmap = torch.zeros((g.N + 31) // 32 + 1, dtype=torch.int32, device=self.dev)   # split update marks
         self.ct_ws = torch.zeros(self.lib.tcar_cand_time_ws_floats(C.byref(self.dims)), **f32)
         # segment tables for the optimizer kernels
         self.segs_all = self._segments([a[0] for a in ARENA])
@@ -225,6 +226,8 @@ class TcarEngine:
 
     # --------------------------------------------------------------------------------- parameter (un)packing
     def load_params(self, params: Dict[str, np.ndarray], content_emb: Optional[np.ndarray] = None):
+        if getattr(self, "_pending_lr", None) is not None:
+            self.flush()
         g = self.geo
         W = np.zeros(self.arena_n, dtype=np.float32)
         for short, sg in self.seg.items():
@@ -263,6 +266,7 @@ class TcarEngine:
 
     def export_params(self) -> "OrderedDict[str, np.ndarray]":
         """All 23 trainable variables in the reference's shapes."""
+        self.flush()
         g = self.geo
         out = self._unpack_arena(self.W.cpu().numpy())
         item = np.zeros((g.N + 1, g.H), dtype=np.float32)
@@ -676,6 +680,7 @@ class TcarEngine:
             setattr(c, n, getattr(self, n).data_ptr())
         c.scoring = self.scoring_code
         c.et_perm = self.et_perm.data_ptr()
+        c.adam_bitmap = self.adam_bitmap.data_ptr()
         c.scoring_bwd = self.scoring_bwd
         if self.scoring_code:
             for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l"):
@@ -728,21 +733,46 @@ class TcarEngine:
         """per-session loss of model_combine.py:147 — written by the negative-term kernel; ce alone without negatives"""
         return self.loss[:bt.B] if (bt.K > 0 and bt.neg) else self.ce[:bt.B]
 
-    def train_step(self, batch: Dict[str, np.ndarray], bt: Optional[Batch] = None) -> torch.Tensor:
-        """One sess.run([loss, global_step, train_op]) (model_combine.py:231); returns loss[B] on device."""
+    _pending_lr = None        # bias-corrected rate of an optimizer update that has been deferred (train_step(defer_update=True))
+
+    def flush(self):
+        """Apply a deferred optimizer update now (no-op otherwise).  Every entry point except train_step(defer_update=True)
+        calls it first, so a deferred update is never observable."""
+        if self._pending_lr is not None:
+            lr, self._pending_lr = self._pending_lr, None
+            check(self.lib.tcar_step_update(C.byref(self._ctx()), lr, self._stream()), "tcar_step_update")
+
+    def train_step(self, batch: Dict[str, np.ndarray], bt: Optional[Batch] = None, defer_update: bool = False) -> torch.Tensor:
+        """One sess.run([loss, global_step, train_op]) (model_combine.py:231); returns loss[B] on device.
+        defer_update=True (training loops): the Adam update of THIS step is applied at the start of the next train_step —
+        arena + the item rows that step gathers first, the other item rows on the aux stream beside its forward pass
+        (tcar_train_step_deferred) — or by flush(); results are identical, the HBM-bound pass over the item table leaves
+        the critical path."""
         bt = bt or self.upload(batch)
         if self.native and self.timing is None:
             self._ensure_work(bt.B, bt.T)
-            check(self.lib.tcar_train_step(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), self._lr_t(),
-                                           self._stream()), "tcar_train_step")
-            self._after_update()
+            if defer_update or self._pending_lr is not None:
+                pend, lr_p = (1, self._pending_lr) if self._pending_lr is not None else (0, 0.0)
+                self._pending_lr = None
+                check(self.lib.tcar_train_step_deferred(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), pend, lr_p,
+                                                        self._stream()), "tcar_train_step_deferred")
+                self._pending_lr = self._lr_t()
+                self._after_update()              # step count / beta powers advance now; the device work is owed
+                if not defer_update:
+                    self.flush()
+            else:
+                check(self.lib.tcar_train_step(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), self._lr_t(),
+                                               self._stream()), "tcar_train_step")
+                self._after_update()
         else:
+            self.flush()
             self.forward(bt)
             self.backward(bt)
             self.update()
         return self._loss_view(bt)
 
     def loss_and_grads(self, batch, bt: Optional[Batch] = None) -> torch.Tensor:
+        self.flush()
         bt = bt or self.upload(batch)
         if self.native and self.timing is None:
             self._ensure_work(bt.B, bt.T)
@@ -759,6 +789,7 @@ class TcarEngine:
     def eval_step(self, batch, k: int = 20, bt: Optional[Batch] = None, keep_logits: bool = False):
         """sess.run([softmax_input, cross_loss]) (model_combine.py:283) + rank / top-k on device.
         Returns (rank[B] int32, topk[B,k] int32, ce[B] f32[, logits [B,N]])."""
+        self.flush()
         bt = bt or self.upload(batch)
         B = bt.B
         self._ensure_work(B, bt.T)

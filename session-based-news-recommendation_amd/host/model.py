@@ -218,9 +218,10 @@ class Seq2SeqAttNN():
                     sub, cap = self._shard(feed)
                     crt_loss = eng.train_step(sub, cap_rows=cap * T)
                 else:
-                    crt_loss = eng.train_step(feed)             # [b] on device; no host sync inside the loop
+                    crt_loss = eng.train_step(feed, defer_update=True)   # [b] on device; no host sync inside the loop
                 total += crt_loss.double().sum()
                 count += crt_loss.numel()
+            eng.flush()                                         # the last step's deferred update
             tot, cnt = self._allsum([float(total.item()), float(count)])
             avgc = tot / max(cnt, 1)
             self.train_seconds = time.time() - t0

@@ -792,3 +792,79 @@ def test_python_sequenced_op_level_path_matches_the_cpp_driver():
     pa, pb = a.export_params(), b.export_params()
     for k in pa:
         assert np.abs(pa[k] - pb[k]).max() <= 1e-4 * np.abs(pa[k]).max() + 0.25 * 1e-3 * 2, k
+
+
+@pytest.mark.parametrize("scoring", ["f32", "bf16x3"])
+def test_deferred_update_matches_the_immediate_one(scoring):
+    """train_step(defer_update=True): the Adam update of a step is applied at the start of the next one — arena + the item
+    rows that step gathers first, the rest on the aux stream — or by flush() / any other entry point.  Same arithmetic
+    per element as tcar_train_step (the kernel-level test below is bitwise); two engine runs differ only by the float
+    atomics inside a step.  Repeated item ids (the bitmap) and an interleaved evaluation (auto-flush) are in the sequence."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 900, 250, 64, 48, 3, 4
+    params, content, mw, b0 = _case(N, H, Ht, B, T, K, seed=21)
+    _, _, _, b1 = _case(N, H, Ht, B, 2, K, seed=22)
+    _, _, _, b2 = _case(N, H, Ht, 7, 5, K, seed=23)
+    b1["seq"][:, :] = b1["seq"][0, 0]                     # one item repeated in every session: one row, many ids
+    a = TcarEngine(params, content, mw, max_grad=2.0, scoring=scoring)
+    d = TcarEngine(params, content, mw, max_grad=2.0, scoring=scoring)
+    seq = [b0, b1, b2, b0, b2]
+    for i, bt in enumerate(seq):
+        la = a.train_step(bt)
+        ld = d.train_step(bt, defer_update=True)
+        close(ld.cpu().numpy(), la.cpu().numpy(), name="loss step %d" % i, rtol=2e-4)
+        if i == 2:
+            ra, rd = a.eval_step(b0), d.eval_step(b0)                     # flushes the pending update first
+            close(rd[2].cpu().numpy(), ra[2].cpu().numpy(), name="eval ce", rtol=2e-4)
+    assert d._pending_lr is not None
+    pa, pd = a.export_params(), d.export_params()                         # export flushes
+    assert d._pending_lr is None and int(d.adam_bitmap.abs().sum()) == 0
+    for k in pa:
+        assert np.abs(pa[k] - pd[k]).max() <= 1e-3 * np.abs(pa[k]).max() + 0.25 * 1e-3 * len(seq), k
+
+
+def test_split_adam_kernels_equal_the_single_launch_bitwise(lib):
+    """tcar_clip_adam_early (arena + listed item rows, each exactly once although ids repeat) followed by
+    tcar_clip_adam_rest (every other row; clears the bitmap) == tcar_clip_adam_all, bit for bit, incl. the bf16 planes."""
+    from tcar_amd._lib import Segments
+    rng = np.random.RandomState(9)
+    N, ldh, ek, arena_n = 777, 256, 832, 4096
+    Npad = (N + 127) // 128 * 128
+    t = lambda a: torch.tensor(a).cuda()
+    E0 = rng.standard_normal((Npad, ek)).astype(np.float32)
+    W0, G = rng.standard_normal(arena_n).astype(np.float32), rng.standard_normal(arena_n + 32).astype(np.float32) * 0.1
+    Gi = (rng.standard_normal((N, ldh)) * 0.1).astype(np.float32)
+    M0, V0 = rng.standard_normal(arena_n).astype(np.float32) * 0.01, rng.rand(arena_n).astype(np.float32) * 1e-3
+    Mi0, Vi0 = (rng.standard_normal((N, ldh)) * 0.01).astype(np.float32), (rng.rand(N, ldh) * 1e-3).astype(np.float32)
+    segs = Segments()
+    segs.nseg = 2
+    segs.off[0], segs.len[0], segs.slot[0] = 0, 1000, 1
+    segs.off[1], segs.len[1], segs.slot[1] = 1024, 3072, 2
+    sqn = t(np.array([2.0, 3.0, 50.0] + [0.0] * 29, np.float32))
+    use = t(np.ones(32, np.int32))
+    ids = t(np.array([5, 5, 5, 1, N, 300, 300, 64, 65], np.int32))      # 1-based, with repeats and both ends
+    args = (2.0, 1e-3, 0.9, 0.999, 1e-8)
+    out = []
+    for split in (False, True):
+        W, M, V, E, Mi, Vi = t(W0), t(M0), t(V0), t(E0), t(Mi0), t(Vi0)
+        dG, dGi = t(G), t(Gi)
+        eh = torch.zeros(Npad * ek, dtype=torch.bfloat16, device="cuda")
+        el = torch.zeros_like(eh)
+        bm = torch.zeros((N + 31) // 32 + 1, dtype=torch.int32, device="cuda")
+        pieces = C.c_void_p(dG.data_ptr() + 4 * arena_n)
+        if split:
+            assert lib.tcar_clip_adam_early(ptr(W), ptr(dG), ptr(M), ptr(V), C.byref(segs), ptr(E), ek, ptr(dGi), ptr(Mi), ptr(Vi),
+                                            N, ldh, 0, ptr(sqn), pieces, ptr(use), *args, ptr2(eh), ptr2(el), ek, ptr(ids),
+                                            ids.numel(), ptr(bm), None) == 0
+            assert int((bm != 0).sum()) > 0
+            assert lib.tcar_clip_adam_rest(ptr(E), ek, ptr(dGi), ptr(Mi), ptr(Vi), N, ldh, 0, ptr(sqn), pieces, ptr(use), *args,
+                                           ptr2(eh), ptr2(el), ek, ptr(bm), None) == 0
+            assert int(bm.abs().sum()) == 0
+        else:
+            assert lib.tcar_clip_adam_all(ptr(W), ptr(dG), ptr(M), ptr(V), C.byref(segs), ptr(E), ek, ptr(dGi), ptr(Mi), ptr(Vi), N,
+                                          ldh, 0, ptr(sqn), pieces, ptr(use), *args, ptr2(eh), ptr2(el), ek, None) == 0
+        out.append([x.cpu() for x in (W, M, V, E, Mi, Vi, eh.view(torch.int16), el.view(torch.int16))])
+    assert not torch.equal(out[0][3], torch.tensor(E0))                   # something was updated
+    for x, y in zip(*out):
+        assert torch.equal(x, y)

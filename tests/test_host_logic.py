@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 4
     assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
     assert lib.tcar_gemm_splitk_effective(64, 16) == 2
 
