@@ -8,6 +8,7 @@
 // on the summed gradient.  The clip norm of a variable is sqrt(use_dense*sqn_dense + sqn_pieces)
 // where the pieces are the IndexedSlices value blocks accumulated by the embedding backward kernels (S5).
 #include "tcar_common.h"
+#include <stdlib.h>
 #include "tcar_bf16_layout.h"
 
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
@@ -353,6 +354,9 @@ extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, fl
   const int rc = fill_adam_all(p, nullptr, nullptr, nullptr, nullptr, nullptr, w2d, ldw, g2d, m2d, v2d, rows, cols, slot,
                                sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps, e16_hi, e16_lo, ld16);
   if (rc) return rc;
+  // a modest grid: the pass shares the chip with the latency-bound kernels of the forward head and has ~100 us to finish
+  static const int cap = getenv("TCAR_REST_GRID") ? atoi(getenv("TCAR_REST_GRID")) : 512;
+  if (cap > 0 && p.n2d > cap) p.n2d = cap;
   TCAR_LAUNCH(clip_adam_rest_kernel, dim3(p.n2d), dim3(256), 0, (hipStream_t)stream, p, (const uint32_t*)bitmap);
   TCAR_CHECK_LAUNCH();
   // every row is up to date now: clear the marks for the next step (stream ordered behind the kernel)
