@@ -126,9 +126,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # training loops defer each step's Adam into the next step's forward pass (engine.train_step docstring); the last
-    # update is flushed INSIDE the timed region, so K timed steps contain exactly K updates
-    defer = {} if world > 1 or os.environ.get("TCAR_FORCE_DP") or os.environ.get("TCAR_NO_DEFER") else {"defer_update": True}
+    # TCAR_DEFER=1 (experiment): defer each step's Adam into the next step's forward pass (engine.train_step docstring);
+    # the last update is flushed INSIDE the timed region, so K timed steps contain exactly K updates.  Measured neutral.
+    defer = {"defer_update": True} if (os.environ.get("TCAR_DEFER") and world == 1 and not os.environ.get("TCAR_FORCE_DP")) else {}
     for i in range(args.warmup):
         eng.train_step(None, bt=resident[i % len(resident)], **defer)
     tags = ["score_fwd", "score_dx", "score_dE", "weight_grads", "gather_fwd", "softmax_ce", "adam_item"]

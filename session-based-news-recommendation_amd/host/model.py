@@ -218,7 +218,7 @@ class Seq2SeqAttNN():
                     sub, cap = self._shard(feed)
                     crt_loss = eng.train_step(sub, cap_rows=cap * T)
                 else:
-                    crt_loss = eng.train_step(feed, defer_update=True)   # [b] on device; no host sync inside the loop
+                    crt_loss = eng.train_step(feed)             # [b] on device; no host sync inside the loop
                 total += crt_loss.double().sum()
                 count += crt_loss.numel()
             eng.flush()                                         # the last step's deferred update
