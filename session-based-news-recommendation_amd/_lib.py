@@ -39,7 +39,8 @@ def _hipcc() -> str:
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/*.hip -> libtcar_hip.so (in-tree)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "tcar_common.h"), os.path.join(PKG_DIR, "..", "include", "tcar_hip.h")]
+    deps = srcs + [os.path.join(CSRC, "tcar_common.h"), os.path.join(CSRC, "tcar_bf16_layout.h"),
+                   os.path.join(PKG_DIR, "..", "include", "tcar_hip.h")]
     if not force and os.path.exists(LIB_PATH):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps if os.path.exists(d)):
             return LIB_PATH
