@@ -147,3 +147,26 @@ def test_cli_checkpoint_save_then_test_only(tmp_path):
     for k in ("recall", "mrr", "ndcg", "coverage"):
         assert restored.last_metrics[k] == trained.last_metrics[k], k
     assert abs(restored.last_metrics["loss"] - trained.last_metrics["loss"]) <= 1e-6 * abs(trained.last_metrics["loss"])
+
+
+def test_cli_is_print_dump_format(tmp_path, monkeypatch):
+    """--is_print writes the prediction dump of model_combine.py:165-169 (consumed by data_process/evaluation_predict*.py):
+    one line per test session, 1-based input ids, 0-based label and top-20."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import glob
+    import re
+    from tcar_amd.host.cli import main
+    monkeypatch.chdir(tmp_path)
+    with redirect_stdout(io.StringIO()):
+        main(["--synthetic", "400", "--synthetic_train", "1500", "--synthetic_test", "200", "--epoch", "1", "--hidden_size", "48",
+              "--time_hidden_size", "16", "--batch_size", "64", "--gap_mode", "click_delta", "--is_print", "1"])
+    files = glob.glob(str(tmp_path / "saved" / "CAR+P_Normal_predict_exa_*.txt"))
+    assert len(files) == 1
+    lines = open(files[0]).read().splitlines()
+    assert len(lines) == 200
+    pat = re.compile(r"^# batch in: \[(\d+(, \d+)*)\] # batch out: (\d+) # batch pred: \[(\d+(, \d+){19})\] $")
+    for ln in lines:
+        m = pat.match(ln)
+        assert m, ln
+        assert all(1 <= int(x) <= 400 for x in m.group(1).split(", ")) and 0 <= int(m.group(3)) < 400
