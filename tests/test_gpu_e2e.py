@@ -170,3 +170,27 @@ def test_cli_is_print_dump_format(tmp_path, monkeypatch):
         m = pat.match(ln)
         assert m, ln
         assert all(1 <= int(x) <= 400 for x in m.group(1).split(", ")) and 0 <= int(m.group(3)) < 400
+
+
+def test_nan_guard_stops_training():
+    """model_combine.py:243-246: a NaN epoch loss prints 'Epoch {e}: NaN error!', sets error_during_train and returns
+    before any evaluation."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tcar_amd.host.model import Seq2SeqAttNN, initial_variables
+    fold = _fold()
+    tr = fold.to_dicts(fold.train, with_active=True)
+    te = fold.to_dicts(fold.test, with_active=True)
+    np.random.seed(3)
+    init = initial_variables(400, 32, 16, 0.3, 0.1)
+    init["attout_item_cont_trans/b1"][0] = np.nan                      # poisons every logit
+    args = fold.model_args(batch_size=64, epoch=3, neg_num=8, hidden_size=32, time_hidden_size=16, initial_variables=init,
+                           emb_stddev=0.3, stddev=0.1)
+    model = Seq2SeqAttNN(args)
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        model.train(None, fold.item_dict, (copy.deepcopy(tr[0]), tr[1], tr[2]), {0: [0]}, args,
+                    (copy.deepcopy(te[0]), te[1], te[2]), None)
+    out = buf.getvalue()
+    assert "Epoch 0: NaN error!" in out and "Epoch 1" not in out and "Measuring..." not in out
+    assert model.error_during_train is True
