@@ -36,6 +36,24 @@ def test_c_abi_rejects_bad_arguments_without_touching_a_gpu():
     assert lib.tcar_gemm_f32(1, 4, 4, 6, 16, 8, 16, 8, 16, 8, None, 0, 0, 1, None) == -1     # K % 4 for k-contiguous
     assert lib.tcar_softmax_ce(2, 10, 16, 10, 16, 16, None) == -1                              # ld % 4
     assert lib.tcar_gemm_f32(0, 0, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, 1, None) == 0  # empty problem is a no-op
+    # the entry points added with the fused step: same contract (error code, never a launch or an exception)
+    import ctypes as C
+    from tcar_amd._lib import Dims, Segments
+    d = Dims(100, 250, 64, 256, 64)
+    assert lib.tcar_eval_rows(2, 10, None, 12, None, 20, None, None, None, None) == -1
+    assert lib.tcar_eval_rows(0, 10, None, 12, None, 20, None, None, None, None) == 0          # B = 0: no-op
+    assert lib.tcar_gemm_bf16(1, 4, 4, 30, 16, 16, 32, 4, 16, 16, 32, 4, 16, 4, None, 0, 0, 3, 1, None) == -1   # K % 32
+    assert lib.tcar_gemm_bf16_perm(2, 4, 4, 32, 16, 16, 32, 32, 16, 16, 32, 32, 16, 4, None, 0, 0, 16, 64, 3, 1, None) == -1
+    assert lib.tcar_neg_fwd(C.byref(d), 2, 3, None, None, None, 0.01, None, None, None, None) == -1
+    assert lib.tcar_neg_scatter(C.byref(d), 2, 3, None, None, None, None, None, None, 0.01, None, None) == -1
+    assert lib.tcar_neg_fwd(C.byref(d), 2, 0, None, None, None, 0.01, None, None, None, None) == 0           # K = 0: no-op
+    assert lib.tcar_splitk_reduce_dact(None, 2, 4, 6, 8, None, 0, 0, None, 0, 0, None, None, 0, None, None) == -1  # N % 4
+    segs = Segments()
+    assert lib.tcar_clip_adam_early(16, 16, 16, 16, C.byref(segs), 16, 832, 16, 16, 16, 10, 256, 0, 16, 16, 16, 1.0, 1e-3, 0.9,
+                                    0.999, 1e-8, None, None, 0, None, 0, None, None) == -1              # no bitmap
+    assert lib.tcar_clip_adam_rest(16, 832, 16, 16, 16, 10, 256, 0, 16, 16, 16, 1.0, 1e-3, 0.9, 0.999, 1e-8, None, None, 0,
+                                   None, None) == -1
+    assert lib.tcar_cand_time_bwd_indexed(C.byref(d), None, None, None, None, 0, None, None, None) == -1
 
 
 def test_geometry_and_arena_cover_all_variables():
