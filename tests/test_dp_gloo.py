@@ -69,7 +69,7 @@ def _local_pieces(ora, sub):
     return out, big, arena, pieces, ids, item_rows.reshape(-1, H).clone()
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, split_big=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -114,7 +114,9 @@ def _worker(rank, world, port, ret):
             ok = all_ids > 0
             big[:N * H].view(N, H).index_add_(0, (all_ids[ok] - 1).long(), all_rows[ok])
 
-        GradExchange(None).run(big, flat, ids, rows, sqnorm_item, cand_time_bwd, scatter_rows, lambda: None)
+        # split_big: step 1 as two all-reduces, the candidate-time block first (the order DPEngine uses on the GPU)
+        bigs = [big[N * H:], big[:N * H]] if split_big else big
+        GradExchange(None).run(bigs, flat, ids, rows, sqnorm_item, cand_time_bwd, scatter_rows, lambda: None)
         # unpack the exchanged result into per-variable gradients and clip norms
         grads, sqn, off = {}, {}, 0
         for k in names:
@@ -150,11 +152,12 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_gradient_exchange_world2_matches_single_process():
+@pytest.mark.parametrize("split_big", [False, True])
+def test_gradient_exchange_world2_matches_single_process(split_big):
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, split_big), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", ret.get(r)
 
