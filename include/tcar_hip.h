@@ -305,6 +305,17 @@ int tcar_clip_adam_all(float* w, const float* g, float* m, float* v, const tcar_
                        const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t,
                        float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, void* stream);
 
+/* ---- optional op, NOT on TCAR's executed graph: the attention core of multihead_attention (modules.py:220-304) ------
+ * Q [N,Tq,C], K, V [N,Tk,C] are the dense projections (tcar_gemm_f32), key_mask [N,Tk] = sign(|sum_c keys|),
+ * query_mask [N,Tq] = sign(|sum_c queries|) (modules.py:263,283).  Per head h (C % heads == 0, Tq, Tk <= 64):
+ * S = Q_h K_h^T / sqrt(C/heads), S = -2^32+1 where key_mask == 0 or (causal and tk > tq), P = softmax(S) * query_mask,
+ * O_h = P V_h.  P [N*heads, Tq, Tk] is saved for the backward pass, which returns dQ, dK, dV. */
+int tcar_mha_core_fwd(int N, int Tq, int Tk, int C, int heads, int causal, const float* Q, const float* K, const float* V,
+                      const float* key_mask, const float* query_mask, float* O, float* P, void* stream);
+int tcar_mha_core_bwd(int N, int Tq, int Tk, int C, int heads, int causal, const float* Q, const float* K, const float* V,
+                      const float* P, const float* key_mask, const float* query_mask, const float* dO, float* dQ, float* dK,
+                      float* dV, void* stream);
+
 /* Split update.  tcar_clip_adam_early: tcar_clip_adam over the arena segments plus the item rows listed in `ids` (1-based
  * item ids, repeats allowed: a bit per row in `bitmap` — zero on entry — makes every row update exactly once);
  * tcar_clip_adam_rest: every item row whose bit is clear, then clears the bitmap.  Together they equal

@@ -143,3 +143,45 @@ def rank_topk(logits, label, n_valid=None, k: int = 20):
     topk = torch.empty(B, k, dtype=torch.int32, device=x.device)
     check(lib.tcar_rank_topk(B, n, _p(x), ld, _p(lab), k, _p(rank), _p(topk), _st(x)), "tcar_rank_topk")
     return rank, topk
+
+
+# ---- optional: multihead_attention (modules.py:220-304) — not on TCAR's executed graph ---------------------------------
+class _MhaCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Q, K, V, key_mask, query_mask, heads: int, causal: bool):
+        lib = _lib.load()
+        Q, K, V, km, qm = map(_f32c, (Q, K, V, key_mask, query_mask))
+        N, Tq, Cc = Q.shape
+        Tk = K.shape[1]
+        O = torch.empty_like(Q)
+        P = torch.empty(N * heads, Tq, Tk, device=Q.device)
+        check(lib.tcar_mha_core_fwd(N, Tq, Tk, Cc, heads, int(causal), _p(Q), _p(K), _p(V), _p(km), _p(qm), _p(O), _p(P),
+                                    _st(Q)), "tcar_mha_core_fwd")
+        ctx.save_for_backward(Q, K, V, P, km, qm)
+        ctx.heads, ctx.causal = heads, int(causal)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        lib = _lib.load()
+        Q, K, V, P, km, qm = ctx.saved_tensors
+        N, Tq, Cc = Q.shape
+        dO = _f32c(dO)
+        dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        check(lib.tcar_mha_core_bwd(N, Tq, K.shape[1], Cc, ctx.heads, ctx.causal, _p(Q), _p(K), _p(V), _p(P), _p(km), _p(qm),
+                                    _p(dO), _p(dQ), _p(dK), _p(dV), _st(Q)), "tcar_mha_core_bwd")
+        return dQ, dK, dV, None, None, None, None
+
+
+def multihead_attention(queries, keys, wq, bq, wk, bk, wv, bv, num_heads=8, causality=False):
+    """modules.py:220-304 with dropout off: dense Q/K/V projections without activation (:247-249), head split, scaled
+    dot-product scores with the key mask (:263-268) and the optional causal mask (:271-277), softmax, query mask
+    (:283-286), weighted sum, head merge, residual (:298).  queries [N,Tq,C], keys [N,Tk,C], w* [C,C], b* [C]."""
+    N, Tq, Cc = queries.shape
+    Tk = keys.shape[1]
+    Q = linear(queries.reshape(N * Tq, Cc), wq, bq).reshape(N, Tq, Cc)
+    K = linear(keys.reshape(N * Tk, Cc), wk, bk).reshape(N, Tk, Cc)
+    V = linear(keys.reshape(N * Tk, Cc), wv, bv).reshape(N, Tk, Cc)
+    key_mask = torch.sign(keys.detach().sum(-1).abs())
+    query_mask = torch.sign(queries.detach().sum(-1).abs())
+    return _MhaCore.apply(Q, K, V, key_mask, query_mask, num_heads, bool(causality)) + queries

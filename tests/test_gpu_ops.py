@@ -106,3 +106,47 @@ def test_rank_topk_op():
     want_rank = (xs > xs.gather(1, lab[:, None])).sum(1) + 1
     assert (rank.long() == want_rank).all()
     assert (topk.long() == xs.topk(20, dim=1).indices).all()          # no ties in random data
+
+
+def _mha_ref(queries, keys, wq, bq, wk, bk, wv, bv, h, causal):
+    """PyTorch fp64 restatement of modules.py:220-304 (dropout off)."""
+    N, Tq, C = queries.shape
+    Tk = keys.shape[1]
+    Q, K, V = queries @ wq + bq, keys @ wk + bk, keys @ wv + bv
+    split = lambda x: torch.cat(torch.split(x, C // h, dim=2), dim=0)                 # (h*N, T, C/h)
+    Q_, K_, V_ = split(Q), split(K), split(V)
+    out = Q_ @ K_.transpose(1, 2) / (C // h) ** 0.5
+    km = torch.sign(keys.sum(-1).abs()).repeat(h, 1)[:, None, :].expand(-1, Tq, -1)
+    pad = torch.full_like(out, -2.0 ** 32 + 1)
+    out = torch.where(km == 0, pad, out)
+    if causal:
+        tril = torch.tril(torch.ones(Tq, Tk, dtype=out.dtype, device=out.device))[None].expand_as(out)
+        out = torch.where(tril == 0, pad, out)
+    out = torch.softmax(out, -1)
+    qm = torch.sign(queries.sum(-1).abs()).repeat(h, 1)[:, :, None]
+    out = (out * qm) @ V_
+    out = torch.cat(torch.split(out, N, dim=0), dim=2)
+    return out + queries
+
+
+@pytest.mark.parametrize("N,T,C,h,causal", [(3, 5, 32, 4, False), (2, 40, 256, 8, True), (4, 7, 48, 1, True)])
+def test_multihead_attention_optional_op(N, T, C, h, causal):
+    _need_gpu()
+    from tcar_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(N * 1000 + T)
+    r = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    q, k = r(N, T, C) * 0.5, r(N, T, C) * 0.5
+    k[0, T - 1] = 0                                            # a padded key position (key mask = 0)
+    q[N - 1, 0] = 0                                            # a padded query position (query mask = 0)
+    ws = [r(C, C) * 0.1, r(C) * 0.1, r(C, C) * 0.1, r(C) * 0.1, r(C, C) * 0.1, r(C) * 0.1]
+    a = [t.clone().requires_grad_(True) for t in [q, k] + ws]
+    b = [t.double().clone().requires_grad_(True) for t in [q, k] + ws]
+    out = ops.multihead_attention(*a, num_heads=h, causality=causal)
+    ref = _mha_ref(*b, h, causal)
+    assert torch.allclose(out.double(), ref, rtol=1e-4, atol=1e-5)
+    go = torch.randn(out.shape, device="cuda", generator=g)
+    out.backward(go)
+    ref.backward(go.double())
+    gmax = max(float(y.grad.abs().max()) for y in b)          # the K bias has an exactly-zero gradient (softmax shift invariance)
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert torch.allclose(x.grad.double(), y.grad, rtol=2e-3, atol=2e-5 * gmax), (i, float((x.grad.double() - y.grad).abs().max()))
