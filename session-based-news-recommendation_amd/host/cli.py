@@ -86,7 +86,12 @@ def load_datas(args):
 
         train_data, test_data = as_data(fold.train), as_data(fold.test)
         item_dict = fold.item_dict
-        neighbor = fold.neighbor_dict() if args.neg_mode == "neighbor" else {0: [0]}     # truthy => negatives on
+        if args.neg_mode == "neighbor":
+            neighbor = fold.neighbor_dict()
+        elif args.neg_mode == "impression":
+            neighbor = fold.impression_dict(fold.train)
+        else:
+            neighbor = {0: [0]}                                                          # truthy => negatives on
         a.update(fold.model_args())
         for k, v in vars(args).items():
             a[k] = v

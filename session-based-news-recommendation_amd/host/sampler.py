@@ -84,21 +84,26 @@ class Sampler(object):
         return self.batch_i < self.batch_num
 
     # ------------------------------------------------------------------ negatives
-    def _negatives(self, keys, labels0) -> Optional[np.ndarray]:
+    def _negatives(self, keys, labels0, idx=None) -> Optional[np.ndarray]:
         if not self.neighbor_dict or not self.has_time:        # sampler.py:72,95: only inside the time branch
             return None
         K, B = self.neg_num, len(keys)
         if self.neg_mode == "uniform":
             # K scalar draws per session in the reference == one vector draw from the same legacy stream
             return np.random.randint(0, self.item_num, size=(B, K)).astype(np.int32)
+        # impression mode: the session id of an example — parsed from its "sid_len" key (sampler.py:96) or, for stores
+        # with integer example ids, taken from the store's impression_key column
+        ik = self.store.impression_key if (idx is not None and self.store is not None) else None
         if self.neg_fast:
-            return self._negatives_fast(keys, np.asarray(labels0, dtype=np.int64))
+            sids = ik[idx] if (ik is not None and self.neg_mode == "impression") else None
+            return self._negatives_fast(keys, np.asarray(labels0, dtype=np.int64), sids)
         out = np.empty((B, K), dtype=np.int32)
         for b, key in enumerate(keys):
             if self.neg_mode == "neighbor":
                 out[b] = self.neg_neighbor(int(labels0[b]))
             else:
-                out[b] = self.neg_neighbor_from_impre(int(str(key).split('_')[0]))
+                sid = int(ik[idx[b]]) if ik is not None else int(str(key).split('_')[0])
+                out[b] = self.neg_neighbor_from_impre(sid)
         return out
 
     # vectorised variants ---------------------------------------------------------------------------------------
@@ -128,7 +133,7 @@ class Sampler(object):
             self._csr = _CSR_CACHE[ck] = (slot, off, flat, arr, {})
         return self._csr
 
-    def _negatives_fast(self, keys, labels0) -> np.ndarray:
+    def _negatives_fast(self, keys, labels0, sids=None) -> np.ndarray:
         slot, off, flat, arr, kcache = self._source_csr()
         K, B = self.neg_num, len(keys)
         if self.neg_mode == "neighbor":
@@ -138,6 +143,10 @@ class Sampler(object):
                     raise KeyError("label without a neighbour list")
             else:
                 sl = np.fromiter((slot[int(x)] for x in labels0), dtype=np.int64, count=B)
+        elif sids is not None and arr is not None and int(np.max(sids)) < len(arr):
+            sl = arr[np.asarray(sids, dtype=np.int64)]
+            if (sl < 0).any():
+                raise KeyError("session without an impression list")
         else:
             sl = np.empty(B, dtype=np.int64)
             for b, k in enumerate(keys):               # session key "sid_len" -> slot, parsed once per key
@@ -200,7 +209,7 @@ class Sampler(object):
         else:
             idx = np.asarray(keys, dtype=np.int64)          # store-native integer example ids
         arr = st.batch_arrays(idx, self.gap_mode)
-        arr["neg"] = self._negatives(keys, arr["label"])
+        arr["neg"] = self._negatives(keys, arr["label"], idx)
         arr["keys"] = keys
         self.batch_i += 1
         return arr

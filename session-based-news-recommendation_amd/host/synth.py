@@ -123,6 +123,18 @@ class SynthFold:
             out[it] = [int(x) for x in order[lo:hi] if x != it]
         return out
 
+    def impression_dict(self, store: SessionStore, lo=20, hi=60, unknown=0.1, seed=7) -> Dict[int, list]:
+        """MIND-style impression lists (mind_preprocess.py:62-69,85): per raw session id 20-60 ORIGINAL article ids, about
+        10 % of them outside the catalog (never-clicked candidates: sampler.py:124 skips those)."""
+        rng = np.random.RandomState(seed)
+        out = {}
+        for sid in np.unique(store.impression_key).tolist():
+            n = int(rng.randint(lo, hi + 1))
+            ids = 10_000 + rng.randint(0, self.n_items, n)
+            ids[rng.random_sample(n) < unknown] += 50_000_000
+            out[int(sid)] = ids.tolist()
+        return out
+
     def to_dicts(self, store: SessionStore, with_active=False) -> Tuple[dict, dict, dict]:
         """Materialise (len_dict, session_dict, session_time_dict) in the reference's pickle form."""
         len_dict, sess, times = {}, {}, {}

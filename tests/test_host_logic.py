@@ -140,3 +140,29 @@ def test_graft_entry_build_runs():
     """the driver's per-round build check: compiles (or reuses) libtcar_hip.so, loads it, checks the ABI, imports the oracle"""
     import __graft_entry__ as g
     g.build()
+
+
+def test_impression_mode_on_a_store_with_integer_example_ids():
+    """Large synthetic folds key examples by integer id; impression mode then takes the session id from the store's
+    impression_key column (the value sampler.py:96 parses out of "sid_len" keys).  Exact and vectorised paths obey the
+    same rules: picks are catalog items of the session's impression list, padded with uniform draws."""
+    import random
+    from tcar_amd.host.sampler import Sampler
+    from tcar_amd.host.synth import SynthFold
+    fold = SynthFold(n_items=300, dim=16, n_train=2000, n_test=100, seed=3)
+    st = fold.train
+    imp = fold.impression_dict(st, unknown=0.0)             # every impression is a catalog item: no padding can occur
+    len_d = {int(T): np.where(st.in_len == T)[0].tolist() for T in np.unique(st.in_len)}
+    for fast in (False, True):
+        random.seed(1)
+        np.random.seed(1)
+        s = Sampler({k: list(v) for k, v in len_d.items()}, None, None, imp, fold.item_dict, 10, batch_size=64,
+                    neg_mode="impression", store=st, neg_fast=fast, verbose=False)
+        n = 0
+        while s.has_next() and n < 5:
+            keys = s.session_id_batches[s.batch_i]
+            f = s.next_batch_arrays()
+            for b, e in enumerate(keys):
+                allowed = {fold.item_dict[x] - 1 for x in imp[int(st.impression_key[e])]}
+                assert set(f["neg"][b].tolist()) <= allowed, (fast, b)
+            n += 1
