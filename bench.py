@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — sessions/sec of TCAR training on the Globo-like configuration (BASELINE.json configs[1]).
+"""bench.py — sessions/sec of TCAR training (BASELINE.json metric), one JSON line per run.
 
-  python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config globo|adressa|mind|stress10m]
 
-One "step" = one pass of the hot path (forward, loss, backward, per-variable clip, Adam) over one mini-batch of
-B = 512 sessions whose int32 feed arrays are already resident in HBM.  Prints ONE JSON line (rank 0) with the
+N > 1: when the process is not already a rank of a torch.distributed.run job (WORLD_SIZE unset) it STARTS one as a child
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same flags>`)
+before anything touches the GPU, relays the ranks' JSON line and exits with the child's return code; under
+torch.distributed.run (the driver's own launch form) it simply is one of the ranks.
+
+One "step" = one pass of the hot path (forward, loss, backward, per-variable clip, Adam: model_combine.py:231) over one
+mini-batch of B = 512 sessions per GPU whose int32 feed arrays are already resident in HBM.  Rank 0 prints ONE JSON line:
 whole-job sessions/sec plus
-  "roofline"      dominant kernel (full-catalog scoring GEMM, gemm_f32_kernel<0,0>): algorithmic FLOPs per launch
-                  / mean HIP-event duration of that launch inside the timed region, against the gfx950 fp32
-                  matrix peak of /opt/skills/guides/MI355X_MICROARCH.md;
-  "cpu_baseline"  the CPU oracle (PyTorch-CPU fp32 restatement of the reference graph) on the host cores, on a
-                  bounded sample of the same workload (rank 0, N = 1 only).
+  "roofline"      the kernel with the largest total time among the three full-catalog GEMMs (logits = attout E^T,
+                  dX = dlogits E, dE = dlogits^T attout): algorithmic FLOPs per launch / mean HIP-event duration of that
+                  launch measured IN the timed steps, on the stream the kernel is launched on (the C++ step driver records the
+                  events), against the dense bf16 MFMA peak (fp32 matrix peak for --scoring f32) of
+                  /opt/skills/guides/MI355X_MICROARCH.md; "others" lists the other two the same way; "traffic" = HBM bytes
+                  per launch from the committed rocprofv3 --pmc passes under profiles/ (null when the shape differs);
+  "cpu_baseline"  the CPU oracle (PyTorch-CPU fp32 restatement of the reference graph) on the host cores, on a bounded
+                  sample of the same workload (rank 0, N = 1 only);
+  "end_to_end_sessions_per_s"  one epoch through the trainer loop of main.py (host sampler + H2D + device step), N = 1.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,11 +39,52 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), v
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 PEAK_HBM_GBS = 8000.0               # HBM3E spec peak
 
+# BASELINE.json configs[1..4] as synthetic folds of the same shape (no dataset files exist in this environment)
+CONFIGS = {
+    # configs[1]: Globo, ~46k items, 250-d content, uniform negatives (sampler.py:98-99), click-delta dwell (sampler.py:91-94)
+    "globo": dict(n_items=46033, hidden=250, neg_mode="uniform", gap_mode="click_delta", fold={}),
+    # configs[2]: Adressa, active_t dwell seconds (adre_preprocess.py:14-20), negative-impression sampling on (sampler.py:96,118-131)
+    "adressa": dict(n_items=15000, hidden=250, neg_mode="impression", gap_mode="active_t", fold=dict(active_t=True)),
+    # configs[3]: MIND, one click time per session, active_t = 1 (mind_preprocess.py:22), generate_neighbor.py negatives
+    # (sampler.py:97,133-140)
+    "mind": dict(n_items=30000, hidden=250, neg_mode="neighbor", gap_mode="active_t",
+                 fold=dict(active_t=True, same_click_time=True)),
+    # configs[4]: synthetic 10M-item catalog, d = 256 (needs ~150 GB of HBM per GPU)
+    "stress10m": dict(n_items=10_000_000, hidden=256, neg_mode="uniform", gap_mode="click_delta",
+                      fold=dict(zipf_s=1.05, lean=True)),
+}
 
-def build_batches(fold, n_batches, B, K, rng):
-    """Full batches of exactly B sessions in the fold's own length mix (sampler.py:40-49 bucketing)."""
+
+def launch_ranks(n: int) -> int:
+    """Parent of a multi-GPU run: never imports torch / touches the GPU; the ranks are child processes."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    last = None
+    for line in p.stdout:
+        line = line.rstrip("\n")
+        if line.startswith("{") and '"metric"' in line:
+            last = line
+        elif line:
+            print(line, file=sys.stderr)
+    rc = p.wait()
+    if last is not None:
+        print(last)
+        sys.stdout.flush()
+    return rc if rc else (0 if last is not None else 1)
+
+
+def build_batches(fold, n_batches, B, K, rng, cfg):
+    """Full batches of exactly B sessions in the fold's own length mix (sampler.py:40-49 bucketing); negatives in the
+    configuration's mode, drawn with the vectorised host rules of host/sampler.py (outside the timed region)."""
+    from tcar_amd.host.sampler import Sampler
     st = fold.train
-    out = []
     by_len = {}
     for T in np.unique(st.in_len):
         idx = np.where(st.in_len == T)[0]
@@ -42,12 +93,36 @@ def build_batches(fold, n_batches, B, K, rng):
             by_len.setdefault(int(T), []).append(idx[i:i + B])
     flat = [(T, ids) for T, lst in by_len.items() for ids in lst]
     order = rng.permutation(len(flat))
+    neg_sampler = None
+    if cfg["neg_mode"] != "uniform":
+        src = fold.neighbor_dict() if cfg["neg_mode"] == "neighbor" else fold.impression_dict(st)
+        neg_sampler = Sampler({}, None, None, src, fold.item_dict, K, batch_size=B, gap_mode=cfg["gap_mode"],
+                              neg_mode=cfg["neg_mode"], store=st, verbose=False, neg_fast=True)
+    out = []
+    state = np.random.get_state()
+    np.random.seed(int(rng.randint(1 << 30)))
     for j in order[:n_batches]:
         T, ids = flat[j]
-        b = st.batch_arrays(ids, "click_delta")
-        b["neg"] = rng.randint(0, fold.n_items, size=(B, K)).astype(np.int32)
+        b = st.batch_arrays(ids, cfg["gap_mode"])
+        if neg_sampler is None:
+            b["neg"] = rng.randint(0, fold.n_items, size=(B, K)).astype(np.int32)
+        else:
+            b["neg"] = neg_sampler._negatives(ids.tolist(), b["label"], ids)
         out.append(b)
+    np.random.set_state(state)
     return out
+
+
+def pmc_traffic(tag, N, B):
+    """HBM bytes per launch of one scoring GEMM from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
+    MI355X_MICROARCH.md §HBM); only valid for the shape it was collected on."""
+    for rnd in ("r02", "r01"):
+        p = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, tag))
+        if os.path.exists(p):
+            d = json.load(open(p))
+            if tuple(d.get("shape_N_B", (46033, 512))) == (N, B):
+                return d.get("hbm_bytes_per_launch"), os.path.relpath(p, ROOT)
+    return None, None
 
 
 def main():
@@ -55,31 +130,59 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="globo", choices=sorted(CONFIGS),
+                    help="BASELINE.json configuration (synthetic fold of that shape)")
     ap.add_argument("--batch_size", type=int, default=512)
-    ap.add_argument("--n_items", type=int, default=46033)
-    ap.add_argument("--hidden_size", type=int, default=250)
+    ap.add_argument("--n_items", type=int, default=0, help="override the configuration's catalog size")
+    ap.add_argument("--hidden_size", type=int, default=0, help="override the configuration's hidden size")
     ap.add_argument("--time_hidden_size", type=int, default=64)
     ap.add_argument("--neg_num", type=int, default=20)
     ap.add_argument("--n_batches", type=int, default=48)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_e2e", action="store_true", help="skip the end-to-end epoch through the trainer loop")
     ap.add_argument("--cpu_steps", type=int, default=20)
     ap.add_argument("--cpu_threads", type=int, default=16)
     ap.add_argument("--no_kernel_timing", action="store_true")
+    ap.add_argument("--dp_mode", default="auto", choices=["auto", "replica", "sharded"],
+                    help="multi-GPU exchange: replica = all-reduce of the dense item gradient; sharded = catalog-sharded scoring")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same_device", action="store_true", help="dry run: put every rank on cuda:0")
     ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
                     help="precision of the full-catalog scoring GEMMs (bf16x3 = split-bf16 planes, fp32-class accuracy)")
+    ap.add_argument("--launch_check", action="store_true",
+                    help="CPU-only check of the rank launch: rendezvous over gloo, one all-reduce, print n_gpus (tests/)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))           # before any import of torch: this process never initialises a GPU
+    if args.launch_check:
+        import torch
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            assert int(t.item()) == world
+            if dist.get_rank() == 0:
+                print(json.dumps({"metric": "launch_check", "n_gpus": world}))
+            dist.destroy_process_group()
+        else:
+            print(json.dumps({"metric": "launch_check", "n_gpus": 1}))
+        return
 
     import torch
     import tcar_amd  # noqa: F401
     from tcar_amd.host.synth import SynthFold
 
+    cfg = dict(CONFIGS[args.config])
+    N = args.n_items or cfg["n_items"]
+    H = args.hidden_size or cfg["hidden"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -94,27 +197,30 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     B, K = args.batch_size, args.neg_num
+    lean = bool(cfg["fold"].get("lean"))
     # every rank builds the same catalog (seed 2020) and its own shard of sessions (weak scaling: B per GPU)
-    fold = SynthFold(n_items=args.n_items, dim=args.hidden_size, n_train=max(60000, 4 * B * args.n_batches),
-                     n_test=1000, seed=2020)
+    fold = SynthFold(n_items=N, dim=H, n_train=max(60000, 4 * B * args.n_batches), n_test=1000, seed=2020, **cfg["fold"])
     rng = np.random.RandomState(2020 + rank)
-    batches = build_batches(fold, args.n_batches, B, K, rng)
+    batches = build_batches(fold, args.n_batches, B, K, rng, cfg)
     if world > 1:
         # ranks step in lock-step over buckets of the same length T: share rank 0's T schedule
         sched = torch.tensor([b["seq"].shape[1] for b in batches], device=dev)
         dist.broadcast(sched, 0)
         want = sched.cpu().tolist()
         pool = {}
-        for b in build_batches(fold, 10 ** 9, B, K, rng):
+        for b in build_batches(fold, 10 ** 9, B, K, rng, cfg):
             pool.setdefault(b["seq"].shape[1], []).append(b)
         batches = [pool[T][i % len(pool[T])] for i, T in enumerate(want)]
 
     from tcar_amd.host.model import initial_variables     # the product's own initialiser (modules.py:32-34,50-51)
     np.random.seed(2020)
-    params = initial_variables(args.n_items, args.hidden_size, args.time_hidden_size, 0.002, 0.05, weight_seed=2020)
+    params = initial_variables(N, H, args.time_hidden_size, 0.002, 0.05, weight_seed=2020, lean=lean)
+    exchange = None
     if world > 1 or os.environ.get("TCAR_FORCE_DP"):       # TCAR_FORCE_DP=1: time the data-parallel code path on one rank
-        from tcar_amd.dp import DPEngine
-        eng = DPEngine(params, fold.content, fold.mwdhm, device=dev, group=(dist.group.WORLD if dist is not None else None), scoring=args.scoring)
+        from tcar_amd.dp import make_dp_engine
+        eng = make_dp_engine(params, fold.content, fold.mwdhm, device=dev, group=(dist.group.WORLD if dist is not None else None),
+                             scoring=args.scoring, mode=args.dp_mode)
+        exchange = eng.exchange_info()
     else:
         from tcar_amd.engine import TcarEngine
         eng = TcarEngine(params, fold.content, fold.mwdhm, device=dev, scoring=args.scoring)
@@ -131,9 +237,8 @@ def main():
     defer = {"defer_update": True} if (os.environ.get("TCAR_DEFER") and world == 1 and not os.environ.get("TCAR_FORCE_DP")) else {}
     for i in range(args.warmup):
         eng.train_step(None, bt=resident[i % len(resident)], **defer)
-    tags = ["score_fwd", "score_dx", "score_dE", "weight_grads", "gather_fwd", "softmax_ce", "adam_item"]
     if not args.no_kernel_timing:
-        eng.enable_native_timing(args.steps)     # HIP events around the logits GEMM inside tcar_train_step
+        eng.enable_native_timing(args.steps)     # HIP events around the three scoring GEMMs inside the step driver
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -149,64 +254,61 @@ def main():
     last_loss = float(eng.loss[:B].mean())
     value = B * world * args.steps / dt
 
-    kern = {}
-    if not args.no_kernel_timing:
-        # dominant kernel: timed live inside the timed region (events recorded by the C++ step driver);
-        # the other kernels: a short extra pass through the Python-sequenced path with per-launch events
-        ms = eng.native_timing_ms()
+    # ---- roofline of the three full-catalog GEMMs, timed live inside the timed steps -------------------------------
+    Ht = args.time_hidden_size
+    k_alg = 2 * H + 5 * Ht                                          # 820 contraction length (model_combine.py:132-138)
+    n_local = getattr(eng, "n_local_items", N)                      # catalog-sharded scoring: this rank's share of N
+    b_glob = getattr(eng, "score_batch", B)                         # ... scored against the all-gathered session batch
+    flops = {"score_fwd": 2.0 * b_glob * n_local * k_alg, "score_dx": 2.0 * b_glob * n_local * k_alg,
+             "score_dE": 2.0 * b_glob * n_local * (H + 5 * Ht)}     # content columns are frozen: no dE for them
+    ref = {"score_fwd": "full-catalog logits = attout E^T, model_combine.py:138",
+           "score_dx": "dX = dlogits E (gradient of :138 w.r.t. attout)",
+           "score_dE": "dE = dlogits^T attout (gradient of :138 w.r.t. the item table and candidate time vectors)"}
+    roof, kernels = None, {}
+    if not args.no_kernel_timing and hasattr(eng, "native_timing_ms"):
+        import ctypes as C
+        g = eng.geo
+        x3 = args.scoring.startswith("bf16x3")
+        nsb = 1 if args.scoring in ("bf16", "bf16x3-mixed") else 3
+        peak, mult_f = (PEAK_F32_MATRIX_TFLOPS, 1) if args.scoring == "f32" else (PEAK_BF16_DENSE_TFLOPS, 3 if x3 else 1)
+        shapes = {"score_fwd": (1, b_glob, n_local, g.ek, mult_f, 1),
+                  "score_dx": (0, b_glob, g.ek, g.Npad if n_local == N else ((n_local + 127) // 128) * 128, nsb, eng.splitk),
+                  "score_dE": (2, n_local, g.ldh + g.pt, (b_glob + 31) & ~31, nsb, 1)}
+        ents = []
+        for kind, tag in enumerate(eng.TIMED_KERNELS):
+            ms = [m for m in eng.native_timing_ms(kind) if m > 0]
+            if not ms:
+                continue
+            avg = float(np.mean(ms))
+            ach = flops[tag] / (avg * 1e-3) / 1e12
+            lay, M_, N_, K_, mult, sk = shapes[tag]
+            name = "gemm_f32_kernel (fp32 MFMA)"
+            if args.scoring != "f32":
+                buf = C.create_string_buffer(160)
+                eng.lib.tcar_gemm_bf16_variant(lay, M_, N_, K_, 3 if mult == 3 else 1, sk, buf, 160)
+                name = buf.value.decode()
+            traffic, src = pmc_traffic(tag, N, B) if (x3 and world == 1) else (None, None)
+            ents.append({"kernel": "%s (%s)" % (name, ref[tag]), "tag": tag, "bound": "mfma", "achieved": round(ach, 2),
+                         "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                         "traffic_source": src, "flops_per_launch": flops[tag], "launches": len(ms), "avg_ms": round(avg, 5),
+                         "total_ms": round(avg * len(ms), 3), "mfma_executed_tflops": round(ach * mult, 2),
+                         "frac_executed": round(ach * mult / peak, 4),
+                         "timing": "HIP events on the launch stream inside the timed steps (other streams' kernels co-run)"})
+            kernels[tag] = {"launches": len(ms), "avg_ms": round(avg, 5), "tflops": round(ach, 2)}
+        if ents:
+            ents.sort(key=lambda e: -e["total_ms"])
+            roof = dict(ents[0])
+            roof["others"] = ents[1:]
         eng._ev = None
-        if args.scoring == "f32" and world == 1:
-            eng.enable_timing(tags)
-            for i in range(min(20, args.steps)):
-                eng.train_step(None, bt=resident[i % len(resident)])
-            sync()
-            kern = eng.timing_summary()
-            eng.timing = None
-        kern["score_fwd"] = (len(ms), float(np.mean(ms)))
-    N, H = args.n_items, args.hidden_size
-    k_alg = 2 * H + 5 * args.time_hidden_size                      # 820 contraction length (model_combine.py:132-138)
-    flops = {"score_fwd": 2.0 * B * N * k_alg, "score_dx": 2.0 * B * N * k_alg,
-             "score_dE": 2.0 * B * N * (H + 5 * args.time_hidden_size)}
-    roof = None
-    kernels = {}
-    for t, (n, ms) in kern.items():
-        ent = {"launches": n, "avg_ms": round(ms, 5)}
-        if t in flops:
-            ent["tflops"] = round(flops[t] / (ms * 1e-3) / 1e12, 2)
-        elif t == "gather_fwd":
-            by = B * (3536.0 * mean_T + 512.0) * 2                 # read + write per session
-            ent["GBps"] = round(by / (ms * 1e-3) / 1e9, 1)
-        elif t == "adam_item":
-            ent["GBps"] = round(28.0 * N * H / (ms * 1e-3) / 1e9, 1)
-        elif t == "softmax_ce":
-            ent["GBps"] = round(12.0 * B * N / (ms * 1e-3) / 1e9, 1)  # read, read, write of the fp32 row
-        kernels[t] = ent
-    if "score_fwd" in kern:
-        ach = flops["score_fwd"] / (kern["score_fwd"][1] * 1e-3) / 1e12
-        if args.scoring == "f32":
-            kname, peak, mult = "gemm_f32_kernel<0,0,128,128>", PEAK_F32_MATRIX_TFLOPS, 1
-        else:
-            # bf16 matrix cores; bf16x3 issues 3 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi); the timed span
-            # also contains the [B,832] operand split kernel (~3 us)
-            x3 = args.scoring.startswith("bf16x3")
-            kname, peak, mult = "gemm_bf16_kernel<0,0,%s>" % ("3" if x3 else "1"), PEAK_BF16_DENSE_TFLOPS, (3 if x3 else 1)
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_logits_gemm.json")
-        if args.scoring.startswith("bf16x3") and os.path.exists(pmc) and (N, B) == (46033, 512):
-            # HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same kernel and
-            # shape (tools/gemm_bench.py fwd), gfx950 FETCH_SIZE x2 correction applied; see the file for the raw counters
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        roof = {"kernel": kname + " (full-catalog logits, model_combine.py:138)", "bound": "mfma",
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                "flops_per_launch": flops["score_fwd"], "avg_ms": round(kern["score_fwd"][1], 5),
-                "mfma_executed_tflops": round(ach * mult, 2), "frac_executed": round(ach * mult / peak, 4)}
+        eng._ctx_key = None
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and N <= 200000:
         from oracle.tcar_oracle import TcarOracle
         # thread sweep on the GPU box host (256 hw threads): 8/16/32/64/128 threads -> 945/1066/991/592/208
         # sessions/s; more threads oversubscribe the many small ops, so the baseline runs at its best setting
-        cores = min(os.cpu_count() or 1, args.cpu_threads)
+        hw = os.cpu_count() or 1
+        cores = min(hw, args.cpu_threads)
         torch.set_num_threads(cores)
         ora = TcarOracle(params, fold.content, fold.mwdhm, dtype=torch.float32)
         ora.train_step(batches[0])                                  # warm-up
@@ -214,21 +316,49 @@ def main():
         for i in range(args.cpu_steps):
             ora.train_step(batches[(i + 1) % len(batches)])
         cdt = time.perf_counter() - c0
-        cpu = {"value": round(B * args.cpu_steps / cdt, 1), "unit": "sessions/s", "cores": cores, "kind": "port",
-               "sample": "%d training steps of B=%d (same synthetic Globo-like batches), PyTorch-CPU fp32 oracle, "
-                         "%d threads" % (args.cpu_steps, B, cores)}
+        cpu = {"value": round(B * args.cpu_steps / cdt, 1), "unit": "sessions/s", "cores": cores, "host_threads": hw,
+               "kind": "port",
+               "sample": "%d training steps of B=%d (the same synthetic batches), PyTorch-CPU fp32 oracle on %d of the "
+                         "host's %d hardware threads (its fastest setting in a thread sweep)" % (args.cpu_steps, B, cores, hw)}
+
+    e2e = None
+    if rank == 0 and world == 1 and not args.no_e2e and N <= 200000 and not os.environ.get("TCAR_FORCE_DP"):
+        # one epoch through the trainer loop of main.py (Seq2SeqAttNN.train): host sampler on a prefetch thread, batches
+        # packed into pinned memory, H2D, device step; the second epoch is the figure (the first builds caches)
+        import contextlib
+        import io
+        from tcar_amd.host.model import Seq2SeqAttNN
+        a = fold.model_args(batch_size=B, neg_num=K, epoch=2, hidden_size=H, time_hidden_size=Ht, scoring=args.scoring,
+                            gap_mode=cfg["gap_mode"], neg_mode=cfg["neg_mode"], neg_fast=1, initial_variables=params)
+        st = fold.train
+        len_dict = {int(T): np.where(st.in_len == T)[0].tolist() for T in np.unique(st.in_len)}
+        src = {0: [0]} if cfg["neg_mode"] == "uniform" else (fold.neighbor_dict() if cfg["neg_mode"] == "neighbor"
+                                                              else fold.impression_dict(st))
+        del eng, resident
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = Seq2SeqAttNN(a)
+            model.train(None, fold.item_dict, (len_dict, None, None, st), src, a, None, None)
+        e2e = {"value": round(model.train_sessions / model.train_seconds, 1), "unit": "sessions/s",
+               "sessions": model.train_sessions,
+               "what": "2nd epoch of Seq2SeqAttNN.train on the same fold: host sampler + pinned H2D + device step"}
 
     if rank == 0:
-        out = {"metric": "sessions/sec TCAR train on Globo (synthetic Globo-like fold)", "value": round(value, 1),
+        labels = {"globo": "TCAR Globo-like fold 0", "adressa": "TCAR Adressa-like fold (active_t dwell, impression negatives)",
+                  "mind": "TCAR MIND-like fold (one click time per session, neighbour negatives)",
+                  "stress10m": "synthetic 10M-item catalog"}
+        out = {"metric": "sessions/sec TCAR train on Globo (synthetic %s fold)" % args.config, "value": round(value, 1),
                "unit": "sessions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.scoring, "data": "synthetic",
-               "config": {"workload": "TCAR Globo-like fold 0: N=%d items, %d-d content, B=%d/GPU, K=%d negatives, "
-                                      "mean input length %.2f, full-catalog scoring, clip %d + Adam" %
-                                      (N, H, B, K, mean_T, 150),
-                          "global_batch": B * world, "parallelism": "dp%d" % world},
-               "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4), "last_loss": round(last_loss, 4)}
+               "config": {"workload": "%s: N=%d items, %d-d content, B=%d/GPU, K=%d %s negatives, mean input length %.2f, "
+                                      "full-catalog scoring, clip %d + Adam" %
+                                      (labels[args.config], N, H, B, K, cfg["neg_mode"], mean_T, 150),
+                          "name": args.config, "global_batch": B * world, "parallelism": "dp%d" % world},
+               "roofline": roof, "cpu_baseline": cpu, "end_to_end_sessions_per_s": e2e, "exchange": exchange,
+               "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+               "last_loss": round(last_loss, 4)}
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -11,7 +11,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller unless marked "host"; no entry point allocates;
- *   - `stream` is a hipStream_t passed as void*; calls are stream-ordered, re-entrant, hold no global state;
+ *   - `stream` is a hipStream_t passed as void*; calls are stream-ordered and re-entrant; the library keeps no mutable
+ *     state except idempotent per-device kernel attributes (set once per device, thread-safe) and the diagnostic
+ *     TCAR_* environment switches, which are read once per process (README.md);
  *   - return value: 0 = ok, negative = TCAR_E_* (never throws across the boundary);
  *   - device layout ("padded-concat space"): H is padded to ldh, Ht to ldt (multiples of 64, zero filled);
  *       ic = 2*ldh   item | content           (model_combine.py:111  seq_item_cont)
@@ -190,6 +192,9 @@ int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* A_hi, const
                         int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C,
                         int64_t ldc, float* C2, int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit,
                         int splitk, void* stream);
+/* Names the kernel instantiation (template arguments, workgroup tile, grid) that tcar_gemm_bf16 would launch for this
+ * problem, without launching it (profiling tools match rocprofv3 kernel names with it).  buf: host, buflen >= 96. */
+int tcar_gemm_bf16_variant(int layout, int M, int N, int K, int nsplit, int splitk, char* buf /*host*/, int buflen);
 /* fp32 [rows, cols] (ld) -> bf16 hi / lo KB32 planes with inner dimension `inner` (>= cols, % 32 == 0); padding rows
  * up to ceil128(rows) and columns >= cols are zero filled (lo may be NULL).  packed_* != NULL additionally writes
  * columns [0,c0) U [c1,cols) as a second plane pair with inner dimension packed_inner. */
@@ -331,8 +336,11 @@ int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, f
                         void* stream);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 4
+#define TCAR_ABI_VERSION 5
 int tcar_abi_version(void);
+/* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
+ * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
+const char* tcar_build_id(void);
 
 /* ---- step-level entry points ------------------------------------------------------------------------------------
  * tcar_train_step IS `sess.run([self.loss, self.global_step, self.train_op], feed_dict)` (model_combine.py:231) and
@@ -380,8 +388,10 @@ typedef struct {
   void* stream2; void* ev[6];
   uint32_t* adam_bitmap;    /* [ceil(N/32)] zeroed words: rows already updated by the early pass of a split update */
   const int32_t* et_perm;   /* [5, N] position of (k, n) in the inverted index (bf16 scoring modes: dE writes d_et in that order) */
-  /* optional device timing of the dominant kernel (full-catalog logits GEMM): ev_n pairs of hipEvent_t, used
-   * round-robin through the host counter *ev_cursor; ev_n = 0 disables it */
+  /* optional device timing of the three full-catalog GEMMs: ev_start / ev_stop hold 3 * ev_n hipEvent_t each
+   * ([kind][slot]: kind 0 = logits, 1 = dX = dlogits E, 2 = dE = dlogits^T attout), recorded on the stream the GEMM is
+   * launched on; slots are used round-robin through the host counter ev_cursor[0] (ev_cursor[1] = slot of the step in
+   * flight, written by the forward pass); ev_n = 0 disables it */
   void* const* ev_start; void* const* ev_stop; int32_t ev_n; int32_t* ev_cursor;
 } tcar_ctx_t;
 

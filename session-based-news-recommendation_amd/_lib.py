@@ -13,19 +13,21 @@ from typing import List
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libtcar_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip", "step.hip", "mha.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip", "step.hip", "mha.hip",
+           "buildid.hip"]
+BUILD_ID_TU = "buildid.hip"        # the one translation unit that carries the digest of all sources
 NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 4          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 5          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_step_forward",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
 
 
@@ -36,27 +38,73 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+HEADERS = [os.path.join(CSRC, "tcar_common.h"), os.path.join(CSRC, "tcar_bf16_layout.h"),
+           os.path.join(PKG_DIR, "..", "include", "tcar_hip.h")]
+_ID_MARK = b"TCAR_BUILD_ID="
+
+
+def _digest(paths) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    for p in paths:
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:32]
+
+
+def source_build_id() -> str:
+    """Digest of every source the library is compiled from (csrc/*.hip, the two csrc headers, include/tcar_hip.h)."""
+    return _digest([os.path.join(CSRC, s) for s in SOURCES] + HEADERS)
+
+
+def binary_build_id(path: str = LIB_PATH):
+    """The digest baked into a built libtcar_hip.so (tcar_build_id()), read from the file without loading it."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(_ID_MARK)
+    if i < 0:
+        return None
+    j = blob.find(b"\0", i)
+    return blob[i + len(_ID_MARK):j].decode(errors="replace")
+
+
+def have_sources() -> bool:
+    return all(os.path.exists(os.path.join(CSRC, s)) for s in SOURCES) and all(os.path.exists(h) for h in HEADERS)
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/*.hip -> libtcar_hip.so (in-tree)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "tcar_common.h"), os.path.join(CSRC, "tcar_bf16_layout.h"),
-                   os.path.join(PKG_DIR, "..", "include", "tcar_hip.h")]
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps if os.path.exists(d)):
-            return LIB_PATH
-    if not all(os.path.exists(s) for s in srcs):
+    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/*.hip -> libtcar_hip.so (in-tree).  The digest of the sources
+    is compiled in (tcar_build_id); a library whose digest differs from the sources next to it is rebuilt.  Objects are
+    cached per source file (digest of the file + headers), so an edit recompiles one translation unit."""
+    if not have_sources():
         raise FileNotFoundError("HIP sources missing under " + CSRC)
+    want = source_build_id()
+    if not force and os.path.exists(LIB_PATH) and binary_build_id() == want:
+        return LIB_PATH
     objs = []
     procs = []
-    for s in srcs:
-        o = os.path.join(CSRC, os.path.basename(s).replace(".hip", ".o"))
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", s, "-o", o]
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        o = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
-    for cmd, p in procs:
+        dig = _digest([src] + HEADERS) + (":" + want if s == BUILD_ID_TU else "")
+        stamp = o + ".digest"
+        if not force and os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == dig:
+            continue
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", src, "-o", o]
+        if s == BUILD_ID_TU:
+            cmd.insert(1, '-DTCAR_BUILD_ID="%s"' % want)
+        procs.append((cmd, stamp, dig, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, stamp, dig, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), out.decode(errors="replace")))
+        with open(stamp, "w") as f:
+            f.write(dig)
         if verbose and out:
             print(out.decode(errors="replace"))
     link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
@@ -162,6 +210,7 @@ def load() -> C.CDLL:
                                    vp]
     lib.tcar_gemm_bf16_perm.argtypes = [i32, i32, i32, i32, vp, vp, i64, i64, vp, vp, i64, i64, vp, i64, vp, i64, i32, vp, i32,
                                         i32, i32, vp]
+    lib.tcar_gemm_bf16_variant.argtypes = [i32, i32, i32, i32, i32, i32, C.c_char_p, i32]
     lib.tcar_split_bf16.argtypes = [vp, i64, i32, i32, vp, vp, i64, vp, vp, i64, i32, i32, vp]
     lib.tcar_splitk_reduce.argtypes = [vp, i32, i32, i32, i64, vp, vp]
     lib.tcar_gemm_splitk_effective.argtypes = [i32, i32]
@@ -199,6 +248,14 @@ def load() -> C.CDLL:
     lib.tcar_eval_step.argtypes = [P(Ctx), P(Batch), i32, i32, vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = C.c_int
+    lib.tcar_build_id.restype = C.c_char_p
+    lib.tcar_build_id.argtypes = []
+    # a binary built from other sources than the ones next to it is stale (the build is digest-gated, not mtime-gated)
+    if have_sources():
+        got, want = lib.tcar_build_id().decode(), source_build_id()
+        if got != want:
+            raise TcarError("libtcar_hip.so was built from other sources (build id %s, sources %s): rebuild with "
+                            "python -c 'import __graft_entry__ as g; g.build()'" % (got, want))
     _LIB = lib
     return lib
 

@@ -590,8 +590,7 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
   hipStream_t st = (hipStream_t)stream;
 #define TCAR_GBWD(NCH_, LDT_)                                                                                         \
   do {                                                                                                                \
-    (void)hipFuncSetAttribute((const void*)gather_clip_bwd_kernel<NCH_, LDT_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              160 * 1024);                                                                            \
+    TCAR_SET_LDS_ONCE((gather_clip_bwd_kernel<NCH_, LDT_>), 160 * 1024);                                              \
     TCAR_LAUNCH((gather_clip_bwd_kernel<NCH_, LDT_>), dim3(grid), dim3(256), lds, st, a);                             \
   } while (0)
   if (d->ldh <= 256) {
@@ -650,7 +649,7 @@ extern "C" int tcar_cand_time_fwd_bf16(const tcar_dims_t* d, const float* const 
   const size_t lds = (size_t)139 * d->ldt * sizeof(float);
   int grid = (d->n_items + 127) / 128;      // one 128-row block per workgroup (grid-stride beyond 1024 blocks)
   if (grid > 1024) grid = 1024;
-  (void)hipFuncSetAttribute((const void*)cand_time_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  TCAR_SET_LDS_ONCE(cand_time_fwd_kernel, 160 * 1024);
   TCAR_LAUNCH(cand_time_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -669,7 +668,7 @@ extern "C" int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_
   int grid = (int)((npairs / gpw + 4 * 16 - 1) / (4 * 16));   // >= 16 passes per wave
   if (grid < 1) grid = 1;
   if (grid > 512) grid = 512;
-  (void)hipFuncSetAttribute((const void*)cand_time_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  TCAR_SET_LDS_ONCE(cand_time_bwd_kernel, 160 * 1024);
   TCAR_LAUNCH(cand_time_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;

@@ -247,18 +247,23 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
+// dry-run sink of tcar_gemm_bf16_variant: when set (host, per call, thread local) the chosen instantiation is named
+// instead of launched
+thread_local char* t_variant_out = nullptr;
+thread_local int t_variant_len = 0;
+
 template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2>
 int launch_v(BArgs& g, int splitk, hipStream_t st) {
   constexpr int NT = 64 * WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW, NP = (NSPLIT == 1) ? 1 : 2;
   constexpr size_t lds = 2 * NP * (TM + TN) * 64;
   g.mt = (g.M + TM - 1) / TM;
   g.nt = (g.N + TN - 1) / TN;
-  static bool done = false;
-  if (!done) {
-    (void)hipFuncSetAttribute((const void*)gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done = true;
+  if (t_variant_out) {
+    snprintf(t_variant_out, t_variant_len, "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d, %d> tile %dx%dx32 grid %d", MA, MB, NSPLIT,
+             WMW, WNW, TMW, TNW, TM, TN, g.mt * g.nt * splitk);
+    return TCAR_OK;
   }
+  TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW>), lds);
   TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -269,8 +274,7 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
   // Tile choice.  The kernel is bound by the per-CU load path (~70 GB/s from L2): bytes per flop fall with the tile
   // area/perimeter ratio, so take the largest tile that still gives the chip about a full wave of workgroups:
   // 256 x 256 (16 waves, 64 KB per stage), then 256 x 128 (8 waves), else 128 x 128 (4 waves).
-  const char* force = getenv("TCAR_BF16_TILE");
-  const int f = force ? atoi(force) : 0;
+  const int f = tcar_tuning().bf16_tile;
   const long w256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splitk;
   const long w128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
   if constexpr (MA == 0 && MB == 0) {
@@ -284,7 +288,7 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
     // 512 x 128 (16 waves): the whole session batch is ONE M tile, so every dlogits stage is fetched once per N tile and
     // the fill bytes per flop drop 16 % against two 256 x 128 tiles (dX: 170 -> 147 us at split-K 36)
     const long w512 = (long)((g.M + 511) / 512) * ((g.N + 127) / 128) * splitk;
-    static const bool dx512 = !(getenv("TCAR_DX512") && atoi(getenv("TCAR_DX512")) == 0);
+    const bool dx512 = tcar_tuning().dx512 != 0;
     if (f == 512 || (f == 0 && dx512 && g.M > 256 && w512 >= 192))
       return nsplit == 3 ? launch_v<0, 1, 3, 8, 2>(g, splitk, st) : launch_v<0, 1, 1, 8, 2>(g, splitk, st);
   }
@@ -355,6 +359,24 @@ extern "C" int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* 
   if (layout == 0) return launch_b<0, 1>(g, nsplit, splitk, st);
   if (layout == 1) return launch_b<0, 0>(g, nsplit, splitk, st);
   return launch_b<1, 1>(g, nsplit, splitk, st);
+}
+
+extern "C" int tcar_gemm_bf16_variant(int layout, int M, int N, int K, int nsplit, int splitk, char* buf, int buflen) {
+  if (!buf || buflen < 8 || layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || (K & 31)) return TCAR_E_ARG;
+  t_variant_out = buf;
+  t_variant_len = buflen;
+  buf[0] = 0;
+  // plane geometry as tcar_gemm_bf16 requires it; the pointers are never dereferenced on the dry path
+  const bool a_kc = (layout != 2), b_kc = (layout == 1);
+  const int64_t r32 = 31;
+  const int64_t a_inner = ((a_kc ? K : M) + r32) & ~r32, a_rows = a_kc ? M : K;
+  const int64_t b_inner = ((b_kc ? K : N) + r32) & ~r32, b_rows = b_kc ? N : K;
+  static const char dummy[16] __attribute__((aligned(16))) = {0};
+  float c = 0.f;
+  const int rc = tcar_gemm_bf16(layout, M, N, K, dummy, dummy, a_inner, a_rows, dummy, dummy, b_inner, b_rows, &c, N, nullptr, 0,
+                                0, nsplit, splitk, nullptr);
+  t_variant_out = nullptr;
+  return rc;
 }
 
 extern "C" int tcar_split_bf16(const float* x, int64_t ld, int rows, int cols, void* hi, void* lo, int64_t inner,

@@ -393,12 +393,7 @@ namespace {
 template <int LA, int LB, int TM, int TN>
 int launch_variant(const GroupArgs& ga, int nwg, hipStream_t st) {
   constexpr size_t lds = 2 * (TileGeo<LA, TM>::FLOATS + TileGeo<LB, TN>::FLOATS) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_f32_kernel<LA, LB, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_done = true;
-  }
+  TCAR_SET_LDS_ONCE((gemm_f32_kernel<LA, LB, TM, TN>), lds);
   TCAR_LAUNCH((gemm_f32_kernel<LA, LB, TM, TN>), dim3(nwg), dim3(256), lds, st, ga);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -426,11 +421,7 @@ int launch_layout(GroupArgs& ga, hipStream_t st) {
 template <int LA, int LB, int XK>
 int launch_x3_v(const GroupArgs& ga, int wg, hipStream_t st) {
   constexpr size_t lds = 4 * X3<XK>::PLANE;
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<LA, LB, XK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  TCAR_SET_LDS_ONCE((gemm_x3_kernel<LA, LB, XK>), lds);
   TCAR_LAUNCH((gemm_x3_kernel<LA, LB, XK>), dim3(wg), dim3(256), lds, st, ga);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -446,7 +437,7 @@ int launch_x3(GroupArgs& ga, hipStream_t st) {
     p.wg_begin = wg;
     wg += p.mt * p.nt * p.ksplit;
   }
-    static const int force = getenv("TCAR_X3_XK") ? atoi(getenv("TCAR_X3_XK")) : 0;
+  const int force = tcar_tuning().x3_xk;
   if (force == 32) return launch_x3_v<LA, LB, 32>(ga, wg, st);
   if (force == 128) return launch_x3_v<LA, LB, 128>(ga, wg, st);
   // 64-deep stages (48 KB of LDS) by default: these launches run beside the dE GEMM, whose workgroups hold 96 KB of a CU's

@@ -355,7 +355,7 @@ extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, fl
                                sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps, e16_hi, e16_lo, ld16);
   if (rc) return rc;
   // a modest grid: the pass shares the chip with the latency-bound kernels of the forward head and has ~100 us to finish
-  static const int cap = getenv("TCAR_REST_GRID") ? atoi(getenv("TCAR_REST_GRID")) : 512;
+  const int cap = tcar_tuning().rest_grid;
   if (cap > 0 && p.n2d > cap) p.n2d = cap;
   TCAR_LAUNCH(clip_adam_rest_kernel, dim3(p.n2d), dim3(256), 0, (hipStream_t)stream, p, (const uint32_t*)bitmap);
   TCAR_CHECK_LAUNCH();
@@ -365,4 +365,3 @@ extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, fl
   return TCAR_OK;
 }
 
-extern "C" int tcar_abi_version(void) { return TCAR_ABI_VERSION; }

@@ -588,7 +588,7 @@ extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, con
   if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && (!dl_lo || (ld & 31))))
     return TCAR_E_ARG;
   const int grid = dl_hi ? ((B + 127) & ~127) : B;
-  static const int variant = getenv("TCAR_SOFTMAX_VARIANT") ? atoi(getenv("TCAR_SOFTMAX_VARIANT")) : 1;
+  const int variant = tcar_tuning().softmax_variant;
   if (variant == 2 && ld <= 1024L * 4 * 12) {
     TCAR_LAUNCH((softmax_ce_rows_kernel<1024, 12>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, B, N, logits, (long)ld,
                 label, ce, (__bf16*)dl_hi, (__bf16*)dl_lo);

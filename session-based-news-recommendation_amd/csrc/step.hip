@@ -5,6 +5,17 @@
 #include "tcar_common.h"
 #include <stdlib.h>
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+const TcarTuning& tcar_tuning() {
+  static const TcarTuning t = {env_int("TCAR_BF16_TILE", 0), env_int("TCAR_DX512", 1), env_int("TCAR_X3_XK", 0),
+                               env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
+                               env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_SORT_SCATTER", 1)};
+  return t;
+}
+
 namespace {
 
 #define RET(x)            \
@@ -146,7 +157,8 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   int ei = -1;
   auto start_timer = [&]() {
     if (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) {
-      ei = (*c->ev_cursor)++ % c->ev_n;
+      ei = c->ev_cursor[0]++ % c->ev_n;
+      c->ev_cursor[1] = ei;              // the backward pass of this step times dX / dE into the same slot
       (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
     }
   };
@@ -216,6 +228,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   }
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
+  // optional HIP events around exactly the dE and dX launches (slot chosen by the forward pass; kind 1 = dX, 2 = dE)
+  const int ei = (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) ? c->ev_cursor[1] : -1;
+  auto tick = [&](int kind, bool stop, void* s) {
+    if (ei >= 0) (void)hipEventRecord((hipEvent_t)(stop ? c->ev_stop : c->ev_start)[kind * c->ev_n + ei], (hipStream_t)s);
+  };
+  tick(2, false, sB);
   if (c->scoring) {
     // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
     RET(tcar_gemm_bf16_perm(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h,
@@ -227,6 +245,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
     RET(small_gemm(c, 2, 2, p, sB));
   }
+  tick(2, true, sB);
   // Fused single-rank step: the aux stream goes straight on to the candidate-side time backward (it needs only d_et),
   // while the negative rows and the dense item norm (they need Gi) are appended to the MAIN chain, which has slack
   // once dX has been given priority.  Rank-local backward: negative rows here, the rest in tcar_step_finish.
@@ -237,12 +256,14 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (fuse_finish) RET(split_finish ? cand_time_backward(c, g, sB) : finish_dense_side(c, g, sB));
   if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // chain B done
   // ---- chain A
+  tick(1, false, stream);
   if (c->scoring) {
     RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
                        nullptr, 0, 0, nsb, c->splitk, stream));
   } else {
     RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
   }
+  tick(1, true, stream);
   // first use of the zeroed arena and of the negative term's forward outputs on the main stream
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
@@ -270,8 +291,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
-    static const int ksdiv = getenv("TCAR_WGRAD_KS") ? atoi(getenv("TCAR_WGRAD_KS")) : 512;
-    auto ks = [](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 2 ? 2 : (s > 16 ? 16 : s); };
+    const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 512;
+    auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 2 ? 2 : (s > 16 ? 16 : s); };
     const int kb = ks(B), kr = ks(BT);
     const float* x_c = c->x_icp + g.ldh;
     tcar_gemm_desc_t p[9];

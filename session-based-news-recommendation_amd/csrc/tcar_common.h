@@ -25,6 +25,41 @@
 
 static inline bool tcar_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// One-time, per-DEVICE kernel attributes (hipFuncSetAttribute for > 64 KB of dynamic LDS).  One bit per device ordinal:
+// correct with several devices in one process and safe from several host threads (two threads may both set the
+// attribute once: the call is idempotent).  This is the only mutable state the library keeps.
+#include <atomic>
+struct TcarOnce {
+  std::atomic<unsigned long long> mask{0};
+};
+static inline bool tcar_first_on_device(TcarOnce& o) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (o.mask.load(std::memory_order_acquire) & bit) return false;
+  o.mask.fetch_or(bit, std::memory_order_acq_rel);
+  return true;
+}
+#define TCAR_SET_LDS_ONCE(kernel, bytes)                                                                     \
+  do {                                                                                                        \
+    static TcarOnce once__;                                                                                   \
+    if (tcar_first_on_device(once__))                                                                         \
+      (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+  } while (0)
+
+// Diagnostic tuning switches (environment, read ONCE per process at first use — C++11 thread-safe static — never per
+// launch).  Defaults are the shipped configuration; README.md lists them.  Defined in step.hip.
+struct TcarTuning {
+  int bf16_tile;        // TCAR_BF16_TILE      force a workgroup tile of the bf16 GEMM (0 = heuristic)
+  int dx512;            // TCAR_DX512          0 disables the 512 x 128 dX tile
+  int x3_xk;            // TCAR_X3_XK          stage depth of the small split-bf16 GEMM (0 = default)
+  int rest_grid;        // TCAR_REST_GRID      grid cap of the deferred Adam rest pass
+  int softmax_variant;  // TCAR_SOFTMAX_VARIANT
+  int wgrad_ks;         // TCAR_WGRAD_KS       K chunk of the weight-gradient split
+  int sort_scatter;     // TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum
+};
+const TcarTuning& tcar_tuning();
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

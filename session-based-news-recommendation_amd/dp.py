@@ -245,3 +245,30 @@ class DPEngine(TcarEngine):
         self._local(bt)
         self.finish_backward(bt, cap_rows)
         return self._loss_view(bt)
+
+
+    def exchange_info(self) -> Dict[str, object]:
+        """Bytes this rank hands to the collectives per step (bench.py prints it)."""
+        g = self.geo
+        big = 4 * g.N * (g.ldh + g.pt)
+        arena = 4 * (self.arena_n + _lib.NSLOT)
+        return {"mode": "replica", "world": self.xch.world, "allreduce_bytes": big + arena,
+                "allgather_bytes_per_session_row": 4 * (g.ldh + 1),
+                "note": "all-reduce of the dense item-table block + candidate-time block of dE, all-reduce of the arena, "
+                        "all-gather of the (id, row) sparse item rows"}
+
+
+def make_dp_engine(params, content_emb, mwdhm, device="cuda:0", group=None, scoring="bf16x3", mode="auto", **kw):
+    """Data-parallel engine factory.  mode "replica": every rank holds the whole catalog and the dense item gradient is
+    all-reduced (`DPEngine`); "sharded": catalog-sharded scoring (`sharded.ShardedEngine`, ~1/8 of the bytes); "auto"
+    picks the sharded exchange when there is more than one rank."""
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if mode == "auto":
+        mode = "sharded" if (world > 1 and _HAVE_SHARDED) else "replica"
+    if mode == "sharded":
+        from .sharded import ShardedEngine
+        return ShardedEngine(params, content_emb, mwdhm, device=device, group=group, scoring=scoring, **kw)
+    return DPEngine(params, content_emb, mwdhm, device=device, group=group, scoring=scoring, **kw)
+
+
+_HAVE_SHARDED = False        # flipped by sharded.py once the catalog-sharded engine is in place

@@ -239,12 +239,15 @@ class TcarEngine:
             else:
                 dst[np.ix_(ri, g.idx(sg["ck"]))] = src
         self.W.copy_(torch.from_numpy(W))
-        E = np.zeros((g.Npad, g.ek), dtype=np.float32)
-        E[:g.N, :g.H] = np.asarray(params["item_emb"], dtype=np.float32)[1:]
         if content_emb is not None:
             self._content = np.asarray(content_emb, dtype=np.float32)
-        E[:g.N, g.ldh:g.ldh + g.H] = self._content[1:]
-        self.E.copy_(torch.from_numpy(E))
+        item = np.asarray(params["item_emb"], dtype=np.float32)
+        # the candidate matrix is assembled on the device in row chunks: no [Npad, ek] host image (33 GB at 10 M items)
+        self.E.zero_()
+        for lo in range(0, g.N, 1 << 20):
+            hi = min(g.N, lo + (1 << 20))
+            self.E[lo:hi, :g.H].copy_(torch.from_numpy(np.ascontiguousarray(item[1 + lo:1 + hi])))
+            self.E[lo:hi, g.ldh:g.ldh + g.H].copy_(torch.from_numpy(np.ascontiguousarray(self._content[1 + lo:1 + hi])))
         if self.scoring_code:
             check(self.lib.tcar_split_bf16(self._p(self.E), g.ek, g.Npad, g.ek, self._p(self.e16h), self._p(self.e16l), g.ek,
                                            None, None, 0, 0, 0, self._stream()), "tcar_split_bf16")
@@ -698,26 +701,32 @@ class TcarEngine:
             c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
             c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)
             c.ev_n = self._ev["n"]
-            c.ev_cursor = C.cast(C.pointer(self._ev["cursor"]), C.c_void_p)
+            c.ev_cursor = C.cast(self._ev["cursor"], C.c_void_p)
         self._ctx_key, self._ctx_obj = key, c
         return c
 
     _ev = None
 
+    TIMED_KERNELS = ("score_fwd", "score_dx", "score_dE")      # kinds 0, 1, 2 of tcar_ctx_t.ev_start / ev_stop
+
     def enable_native_timing(self, n: int):
-        """HIP events around the full-catalog logits GEMM inside tcar_train_step (bench.py roofline)."""
+        """HIP events around the three full-catalog GEMMs inside tcar_train_step (logits, dX, dE), each pair recorded on the
+        stream its GEMM is launched on (bench.py roofline): n slots per kernel, used round-robin."""
         st = torch.cuda.current_stream(self.dev)
-        starts = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
-        stops = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        k = len(self.TIMED_KERNELS)
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(k * n)]
+        stops = [torch.cuda.Event(enable_timing=True) for _ in range(k * n)]
         for e in starts + stops:
             e.record(st)                      # materialise the underlying hipEvent_t
-        self._ev = {"n": n, "starts": starts, "stops": stops, "cursor": C.c_int32(0),
-                    "start_arr": (C.c_void_p * n)(*[e.cuda_event for e in starts]),
-                    "stop_arr": (C.c_void_p * n)(*[e.cuda_event for e in stops])}
+        self._ev = {"n": n, "starts": starts, "stops": stops, "cursor": (C.c_int32 * 2)(0, 0),
+                    "start_arr": (C.c_void_p * (k * n))(*[e.cuda_event for e in starts]),
+                    "stop_arr": (C.c_void_p * (k * n))(*[e.cuda_event for e in stops])}
 
-    def native_timing_ms(self):
-        used = min(self._ev["cursor"].value, self._ev["n"])
-        return [self._ev["starts"][i].elapsed_time(self._ev["stops"][i]) for i in range(used)]
+    def native_timing_ms(self, kind: int = 0):
+        """per-launch milliseconds of kernel `kind` (index into TIMED_KERNELS); call after a device synchronize"""
+        n = self._ev["n"]
+        used = min(self._ev["cursor"][0], n)
+        return [self._ev["starts"][kind * n + i].elapsed_time(self._ev["stops"][kind * n + i]) for i in range(used)]
 
     def _lr_t(self) -> float:
         return float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.b2_pow) / (np.float32(1) - self.b1_pow))

@@ -49,13 +49,24 @@ def _shapes(N, H, Ht):
     return s
 
 
-def initial_variables(N, H, Ht, emb_stddev, stddev, weight_seed=2020):
+def initial_variables(N, H, Ht, emb_stddev, stddev, weight_seed=2020, lean=False):
     """Tables: np.random.normal on the global stream, creation order, row 0 zeroed when zero_pad
     (modules.py:32-34; dec_pos default stddev 0.02 and no pad, model_combine.py:57-64; duration no pad, :106).
-    Dense weights ~ N(0, stddev) (modules.py:50-51,65) from a private stream."""
+    Dense weights ~ N(0, stddev) (modules.py:50-51,65) from a private stream.
+    lean=True (multi-million-item catalogs): the item table is drawn in fp32 row chunks from a private generator (the
+    fp64 draw of a 10M x 256 table alone is 20 GB)."""
     wr = np.random.RandomState(weight_seed)
     out = OrderedDict()
     for name, shp in _shapes(N, H, Ht).items():
+        if name == "item_emb" and lean:
+            g32 = np.random.default_rng(weight_seed + 1)
+            t = np.empty(shp, dtype=np.float32)
+            for lo in range(0, shp[0], 1 << 20):
+                hi = min(shp[0], lo + (1 << 20))
+                t[lo:hi] = g32.standard_normal((hi - lo, shp[1]), dtype=np.float32) * np.float32(emb_stddev)
+            t[0] = 0.0
+            out[name] = t
+            continue
         if name == "dec_pos":
             t = np.random.normal(0, 0.02, shp)
         elif name in ("item_emb", "duration_embedding") or name in TIME_NAMES:

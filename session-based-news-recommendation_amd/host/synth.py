@@ -34,11 +34,20 @@ class SynthFold:
 
     def __init__(self, n_items=46033, dim=250, n_train=100000, n_test=10000, seed=2020, p_len=0.45,
                  zipf_s=1.1, max_clicks=41, active_t=False, same_click_time=False, n_categories=300,
-                 content_scale=0.5):
+                 content_scale=0.5, lean=False):
+        """lean=True (multi-million-item catalogs): the content table is drawn in fp32 row chunks (no fp64 copy of the
+        whole table) and the orig-id dictionary is not materialised (`item_dict` is None)."""
         rng = np.random.RandomState(seed)
         self.n_items, self.dim = n_items, dim
         # catalog ------------------------------------------------------------------------------------------
-        content = (rng.standard_normal((n_items + 1, dim)) * content_scale).astype(np.float32)
+        if lean:
+            g32 = np.random.default_rng(seed)
+            content = np.empty((n_items + 1, dim), dtype=np.float32)
+            for lo in range(0, n_items + 1, 1 << 20):
+                hi = min(n_items + 1, lo + (1 << 20))
+                content[lo:hi] = g32.standard_normal((hi - lo, dim), dtype=np.float32) * np.float32(content_scale)
+        else:
+            content = (rng.standard_normal((n_items + 1, dim)) * content_scale).astype(np.float32)
         content[0] = 0.0                                   # globo_preprocess.py:315
         self.content = content
         pub_ts = _EPOCH0 + rng.randint(-30 * 86400, 16 * 86400, size=n_items).astype("timedelta64[s]")
@@ -49,7 +58,7 @@ class SynthFold:
         w = 1.0 / np.arange(1, n_items + 1, dtype=np.float64) ** zipf_s
         self._cdf = np.cumsum(w / w.sum())
         self._perm = rng.permutation(n_items).astype(np.int64)   # popularity rank -> item id (0-based)
-        self.item_dict = {int(10_000 + i): int(i + 1) for i in range(n_items)}        # orig id -> 1-based id
+        self.item_dict = None if lean else {int(10_000 + i): int(i + 1) for i in range(n_items)}   # orig id -> 1-based id
         self.train = self._sessions(rng, n_train, p_len, max_clicks, active_t, same_click_time, 0)
         self.test = self._sessions(rng, n_test, p_len, max_clicks, active_t, same_click_time, 50_000_000)
 

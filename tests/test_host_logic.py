@@ -19,11 +19,13 @@ def test_library_exports_every_declared_symbol():
     _lib.build()
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "tcar_hip.h")).read()
-    declared = set(re.findall(r"^int (tcar_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|const char\*) (tcar_\w+)\(", header, flags=re.M))
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 5
+    # the binary carries the digest of the sources it was built from; the loader refuses a stale one
+    assert lib.tcar_build_id().decode() == _lib.source_build_id() == _lib.binary_build_id()
     assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
     assert lib.tcar_gemm_splitk_effective(64, 16) == 2
 
