@@ -232,6 +232,10 @@ class TcarOracle:
             neg_fb = (-torch.log(1 - torch.sigmoid(xs) + 1e-24)).to(neg_logits.dtype)  # :143
             out["neg_logits"], out["neg_fb"] = neg_logits, neg_fb
             out["loss"] = ce + self.neg_weight * neg_fb                                # :147
+        elif with_neg:
+            # label_neg fed as [B, 0] (sampler.py:95 without a neighbor_dict): neg_logits = 0 and the term is the
+            # constant -log(1 - sigmoid(0) + 1e-24) = ln 2 per session (model_combine.py:142-143,147); no gradient
+            out["loss"] = ce + self.neg_weight * math.log(2.0)
         else:
             out["loss"] = ce
         out["_vals"] = vals

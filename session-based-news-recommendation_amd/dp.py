@@ -220,7 +220,11 @@ class DPEngine(TcarEngine):
         return self._loss_view(bt)
 
     def update(self):
-        if self.native and self.timing is None and hasattr(self, "_ctx_obj"):
+        if self.native and self.timing is None:
+            if self.work_B == 0:
+                # a rank whose very first shard is empty has no workspace yet: give it a minimal one, so that the update
+                # always goes through tcar_step_update (which also refreshes the bf16 planes of the item table)
+                self._ensure_work(1, 1)
             check(self.lib.tcar_step_update(C.byref(self._ctx()), self._lr_t(), self._stream()), "tcar_step_update")
             self._after_update()
         else:

@@ -229,16 +229,7 @@ class TcarEngine:
         if getattr(self, "_pending_lr", None) is not None:
             self.flush()
         g = self.geo
-        W = np.zeros(self.arena_n, dtype=np.float32)
-        for short, sg in self.seg.items():
-            src = np.asarray(params[sg["ref"]], dtype=np.float32)
-            dst = W[sg["off"]:sg["off"] + sg["n"]].reshape(sg["rows"], sg["cols"])
-            ri = g.idx(sg["rk"])
-            if sg["ck"] is None:
-                dst[ri, 0] = src.reshape(-1)
-            else:
-                dst[np.ix_(ri, g.idx(sg["ck"]))] = src
-        self.W.copy_(torch.from_numpy(W))
+        self.W.copy_(torch.from_numpy(self._pack_arena(params)))
         if content_emb is not None:
             self._content = np.asarray(content_emb, dtype=np.float32)
         item = np.asarray(params["item_emb"], dtype=np.float32)
@@ -253,6 +244,55 @@ class TcarEngine:
                                            None, None, 0, 0, 0, self._stream()), "tcar_split_bf16")
         self._item_row0 = np.asarray(params["item_emb"], dtype=np.float32)[0].copy()
         self._time_dirty = True
+
+    def _pack_arena(self, values: Dict[str, np.ndarray]) -> np.ndarray:
+        """reference-shaped arrays of the 22 arena variables -> one padded flat fp32 arena (pads zero)"""
+        g = self.geo
+        W = np.zeros(self.arena_n, dtype=np.float32)
+        for short, sg in self.seg.items():
+            src = np.asarray(values[sg["ref"]], dtype=np.float32)
+            dst = W[sg["off"]:sg["off"] + sg["n"]].reshape(sg["rows"], sg["cols"])
+            ri = g.idx(sg["rk"])
+            if sg["ck"] is None:
+                dst[ri, 0] = src.reshape(-1)
+            else:
+                dst[np.ix_(ri, g.idx(sg["ck"]))] = src
+        return W
+
+    # ------------------------------------------------------------------------------------- checkpoint state
+    def export_state(self) -> Dict[str, np.ndarray]:
+        """Everything a resumed run needs, as plain arrays (np.savez, loadable with allow_pickle=False): the 23 variables
+        `var/<name>`, the Adam moments `m/<name>`, `v/<name>` in the reference's shapes, the beta powers and the step
+        count (tf.train.AdamOptimizer's beta1_power / beta2_power non-slot variables, model_combine.py:155)."""
+        self.flush()
+        g = self.geo
+        out = {"var/" + k: v for k, v in self.export_params().items()}
+        for tag, arena, item in (("m/", self.M, self.Mi), ("v/", self.V, self.Vi)):
+            d = self._unpack_arena(arena.cpu().numpy())
+            it = np.zeros((g.N + 1, g.H), dtype=np.float32)
+            it[1:] = item[:, :g.H].cpu().numpy()
+            d["item_emb"] = it
+            out.update({tag + k: d[k] for k in VAR_ORDER})
+        out["meta/step"] = np.asarray(self.step, dtype=np.int64)
+        out["meta/beta_pow"] = np.asarray([self.b1_pow, self.b2_pow], dtype=np.float32)
+        return out
+
+    def load_state(self, st) -> None:
+        """Inverse of export_state (moments / powers / step are optional: a variables-only file restores the weights)."""
+        self.load_params({k[4:]: np.asarray(st[k]) for k in st if k.startswith("var/")})
+        g = self.geo
+        if all(("m/" + k) in st and ("v/" + k) in st for k in VAR_ORDER):
+            for tag, arena, item in (("m/", self.M, self.Mi), ("v/", self.V, self.Vi)):
+                vals = {k: np.asarray(st[tag + k]) for k in VAR_ORDER}
+                arena.copy_(torch.from_numpy(self._pack_arena(vals)))
+                it = np.zeros((g.N, g.ldh), dtype=np.float32)
+                it[:, :g.H] = vals["item_emb"][1:]
+                item.copy_(torch.from_numpy(it))
+        if "meta/step" in st:
+            self.step = int(np.asarray(st["meta/step"]))
+        if "meta/beta_pow" in st:
+            bp = np.asarray(st["meta/beta_pow"], dtype=np.float32)
+            self.b1_pow, self.b2_pow = np.float32(bp[0]), np.float32(bp[1])
 
     def _unpack_arena(self, flat: np.ndarray) -> "OrderedDict[str, np.ndarray]":
         g = self.geo
@@ -404,13 +444,19 @@ class TcarEngine:
         return out
 
     def make_resident(self, batch: Dict[str, np.ndarray]) -> Batch:
-        """Upload a batch into its OWN device buffer (kept alive by the engine) and return its descriptor."""
-        save = (self.pin, getattr(self, "ibufs", None), getattr(self, "pin_evt", None), getattr(self, "pin_i", 0))
+        """Upload a batch into its OWN device buffer (kept alive by the engine) and return its descriptor.  The staging
+        state of upload() (pinned double buffer, events, cursor) is saved and restored as a whole, so uploads before and
+        after are unaffected."""
+        names = ("pin", "pin_np", "ibufs", "pin_evt", "pin_used", "pin_i")
+        save = {n: getattr(self, n, None) for n in names}
         self.pin = None
-        bt = self.upload(batch)
-        torch.cuda.current_stream(self.dev).synchronize()
-        self._resident = getattr(self, "_resident", []) + [self.ibufs]
-        self.pin, self.ibufs, self.pin_evt, self.pin_i = save
+        try:
+            bt = self.upload(batch)
+            torch.cuda.current_stream(self.dev).synchronize()
+            self._resident = getattr(self, "_resident", []) + [self.ibufs]
+        finally:
+            for n in names:
+                setattr(self, n, save[n])
         return bt
 
     def _tables(self) -> Tables:
@@ -739,8 +785,12 @@ class TcarEngine:
 
     # ------------------------------------------------------------------------------------------ public API
     def _loss_view(self, bt: Batch) -> torch.Tensor:
-        """per-session loss of model_combine.py:147 — written by the negative-term kernel; ce alone without negatives"""
-        return self.loss[:bt.B] if (bt.K > 0 and bt.neg) else self.ce[:bt.B]
+        """per-session loss of model_combine.py:147 — written by the negative-term kernel.  Without negatives the reference
+        still feeds label_neg as [B, 0]: neg_logits = 0 and every session's loss carries the constant
+        neg_weight * -log(1 - sigmoid(0)) = neg_weight * ln 2 (no gradient)."""
+        if bt.K > 0 and bt.neg:
+            return self.loss[:bt.B]
+        return self.ce[:bt.B] + float(np.float32(self.neg_weight) * np.float32(np.log(2.0)))
 
     _pending_lr = None        # bias-corrected rate of an optimizer update that has been deferred (train_step(defer_update=True))
 

@@ -159,8 +159,8 @@ def main(argv=None):
         import torch
         sent = train_data if input_data == "train" else test_data
         print('Begin Testing. Test data is %s data' % ("train" if input_data == "train" else "test"))
-        ck = torch.load(model_path, weights_only=False)
-        model.engine.load_params(ck["variables"])
+        with np.load(model_path, allow_pickle=False) as ck:          # plain arrays only: nothing is unpickled
+            model.engine.load_state(ck)
         model.test(None, sent, a)
     if dp_group is not None:
         import torch.distributed as dist

@@ -49,8 +49,29 @@ def unexp_batch(seq: np.ndarray, topk: np.ndarray, cat_of_item: np.ndarray) -> n
 
 
 def category_table(reverse_item: dict, category_id, n_items: int) -> np.ndarray:
-    """int table cat[item0] = category_id[reverse_item[item0]] (the double lookup of model_combine.py:180)."""
-    out = np.empty(n_items, dtype=np.int64)
+    """int table cat[item0] = code of category_id[reverse_item[item0]] (the double lookup of model_combine.py:180).
+    The reference only ever compares categories with `!=`, so any label type works (MIND's categories are strings): the
+    labels are factorised to integer codes.  Items without a category (the reference raises KeyError lazily, when such an
+    item is first recommended) get one code of their own each, i.e. they differ from everything else."""
+    labels, missing = [], []
     for i in range(n_items):
-        out[i] = category_id[reverse_item[i]]
+        orig = reverse_item.get(i) if hasattr(reverse_item, "get") else reverse_item[i]
+        if orig is not None and orig in category_id:
+            labels.append(category_id[orig])
+        else:
+            labels.append(None)
+            missing.append(i)
+    out = np.empty(n_items, dtype=np.int64)
+    known = [l for l in labels if l is not None]
+    codes = {}
+    for l in known:
+        if l not in codes:
+            codes[l] = len(codes)
+    nxt = len(codes)
+    for i, l in enumerate(labels):
+        if l is None:
+            out[i] = nxt
+            nxt += 1
+        else:
+            out[i] = codes[l]
     return out

@@ -251,9 +251,11 @@ class Seq2SeqAttNN():
     def save(self, args):
         suf = time.strftime("%Y%m%d%H%M", time.localtime()) + '-' + str(args.get('dataset', '')).replace('/', '_') \
             + '-' + str(args.get('split_way', '')).replace('/', '_') + '-' + str(args.get('foldnum', 0))
-        path = os.path.join(args.get('modelpath', './ckpt/'), "model.ckpt-" + suf + ".pt")
+        path = os.path.join(args.get('modelpath', './ckpt/'), "model.ckpt-" + suf + ".npz")
         os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
-        torch.save({"variables": self.engine.export_params(), "step": self.engine.step}, path)
+        # plain arrays only (variables, Adam moments, beta powers, step): loadable without unpickling anything.  NOT
+        # interchangeable with the reference's tf.train.Saver checkpoints (README.md).
+        np.savez(path, **self.engine.export_state())
         return path
 
     # --------------------------------------------------------------------------------------------- test

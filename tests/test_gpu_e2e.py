@@ -138,8 +138,11 @@ def test_cli_checkpoint_save_then_test_only(tmp_path):
     with redirect_stdout(buf):
         trained = main(common + ["--epoch", "1", "--save", "1", "--threshold_acc", "-1", "--modelpath", str(tmp_path) + "/"])
     assert "Model saved" in buf.getvalue()
-    files = glob.glob(str(tmp_path / "model.ckpt-*.pt"))
+    files = glob.glob(str(tmp_path / "model.ckpt-*.npz"))
     assert len(files) == 1
+    with np.load(files[0], allow_pickle=False) as ck:                  # plain arrays: variables, Adam moments, powers, step
+        assert int(ck["meta/step"]) == trained.engine.step > 0
+        assert {"var/item_emb", "m/item_emb", "v/item_emb", "meta/beta_pow"} <= set(ck.files)
     buf = io.StringIO()
     with redirect_stdout(buf):
         restored = main(common + ["--train", "", "--modelpath", files[0]])
@@ -147,6 +150,20 @@ def test_cli_checkpoint_save_then_test_only(tmp_path):
     for k in ("recall", "mrr", "ndcg", "coverage"):
         assert restored.last_metrics[k] == trained.last_metrics[k], k
     assert abs(restored.last_metrics["loss"] - trained.last_metrics["loss"]) <= 1e-6 * abs(trained.last_metrics["loss"])
+    # resume: the restored engine continues exactly like the one that kept running (moments, beta powers and step restored)
+    fold_batch = None
+    from tcar_amd.host.synth import SynthFold
+    fold = SynthFold(n_items=600, dim=48, n_train=300, n_test=10, seed=11)
+    idx = np.where(fold.train.in_len == 2)[0][:32]
+    fold_batch = fold.train.batch_arrays(idx, "click_delta")
+    fold_batch["neg"] = np.random.RandomState(3).randint(0, 600, size=(len(idx), 5)).astype(np.int32)
+    assert restored.engine.step == trained.engine.step
+    la = trained.engine.train_step(fold_batch).cpu().numpy()
+    lb = restored.engine.train_step(fold_batch).cpu().numpy()
+    la2 = trained.engine.train_step(fold_batch).cpu().numpy()
+    lb2 = restored.engine.train_step(fold_batch).cpu().numpy()
+    np.testing.assert_allclose(lb, la, rtol=1e-5)
+    np.testing.assert_allclose(lb2, la2, rtol=1e-4)                    # second step: depends on the restored moments
 
 
 def test_cli_is_print_dump_format(tmp_path, monkeypatch):

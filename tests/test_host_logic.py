@@ -168,3 +168,17 @@ def test_impression_mode_on_a_store_with_integer_example_ids():
                 allowed = {fold.item_dict[x] - 1 for x in imp[int(st.impression_key[e])]}
                 assert set(f["neg"][b].tolist()) <= allowed, (fast, b)
             n += 1
+
+
+def test_category_table_accepts_any_label_type_and_missing_items():
+    """The reference only compares categories with != (model_combine.py:180,190): string labels (MIND) must work, and an
+    item without a category differs from everything (the reference raises KeyError lazily)."""
+    from tcar_amd.host import metrics as M
+    rev = {0: "a", 1: "b", 2: "c", 3: "d"}
+    cat = M.category_table(rev, {"a": "news", "b": "sport", "c": "news"}, 4)
+    assert cat[0] == cat[2] != cat[1]
+    assert cat[3] not in (cat[0], cat[1])
+    ints = M.category_table({0: 10, 1: 11}, {10: 7, 11: 7}, 2)
+    assert ints[0] == ints[1]
+    ild = M.ild_batch(np.array([[0, 1, 2]]), cat)
+    assert abs(float(ild[0]) - 4.0 / 6.0) < 1e-12          # pairs (0,1),(1,0),(1,2),(2,1) differ
