@@ -39,6 +39,9 @@ VAR_ORDER = ["item_emb", "dec_pos"] + TIME_NAMES + ["duration_embedding",
              "cont_attention/input_linear_trans/w_3d", "cont_attention/cont_linear_trans/w_3d",
              "cont_attention/res_linear_trans/w_3d", "attout_pt_trans/w1", "attout_pt_trans/b1"]
 SLOT = {n: i for i, n in enumerate(VAR_ORDER)}
+# variables whose gradient is accumulated in a fixed order (bitwise repeatable from step to step and across replicas);
+# tests/test_gpu_configs.py::test_same_step_twice_bitwise_report keeps this list honest
+DETERMINISTIC_GRADS: tuple = ()
 
 
 def _ru(x: int, m: int) -> int:

@@ -1,5 +1,6 @@
 """Micro-benchmark of the split-bf16 scoring GEMMs at the Globo shape (B=512, N=46033, K=832).
-Usage: python tools/gemm_bench.py [fwd|dx|de] [nsplit] [iters]"""
+Usage: python tools/gemm_bench.py [fwd|dx|de|both] [nsplit] [iters]
+`both`: dX on a high-priority stream and dE on a second stream, concurrently, as the step driver runs them."""
 import ctypes as C
 import os
 import sys
@@ -14,7 +15,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 nsplit = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 N = int(os.environ.get("GB_N", 46033))
-SK = int(os.environ.get("GB_SPLITK", 16))
+SK = int(os.environ.get("GB_SPLITK", 36))
 B, Npad, EK = 512, (N + 127) // 128 * 128, 832
 bf = dict(dtype=torch.bfloat16, device="cuda")
 p = lambda t: C.c_void_p(t.data_ptr())
@@ -27,7 +28,26 @@ slabs = torch.empty(SK, B, EK, device="cuda")
 gi, det = torch.empty(N, 256, device="cuda"), torch.empty(N, 320, device="cuda")
 
 
+hp, s2 = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+
+
+def run_both():
+    """dX on the priority stream, dE on the other, joined before the next iteration (like backward_impl)"""
+    cur = torch.cuda.current_stream()
+    hp.wait_stream(cur)
+    s2.wait_stream(cur)
+    rc1 = lib.tcar_gemm_bf16(2, N, 576, B, p(d_h), p(d_l), Npad, B, p(ap_h), p(ap_l), 576, B, p(gi), 256, p(det), 320, 256, nsplit, 1,
+                             C.c_void_p(s2.cuda_stream))
+    rc0 = lib.tcar_gemm_bf16(0, B, EK, Npad, p(d_h), p(d_l), Npad, B, p(e_h), p(e_l), EK, Npad, p(slabs), EK, None, 0, 0, nsplit, SK,
+                             C.c_void_p(hp.cuda_stream))
+    cur.wait_stream(hp)
+    cur.wait_stream(s2)
+    return rc0 or rc1, 2.0 * B * N * (820 + 570)
+
+
 def run():
+    if which == "both":
+        return run_both()
     if which == "fwd":
         return lib.tcar_gemm_bf16(1, B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, p(logits), Npad, None, 0, 0, nsplit, 1, None), 2.0 * B * N * 820
     if which == "dx":
