@@ -335,6 +335,10 @@ int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, f
                         float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap,
                         void* stream);
 
+/* Diagnostic hook (tests, profiling tools): override one of the TCAR_* tuning switches at run time (they are otherwise read
+ * from the environment once per process).  Returns the previous value, INT_MIN for an unknown name.  Not for product code. */
+int tcar_set_tuning(const char* name /*host*/, int value);
+
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
 #define TCAR_ABI_VERSION 5
 int tcar_abi_version(void);

@@ -27,7 +27,7 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_step_forward",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
 
 
@@ -248,6 +248,7 @@ def load() -> C.CDLL:
     lib.tcar_eval_step.argtypes = [P(Ctx), P(Batch), i32, i32, vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = C.c_int
+    lib.tcar_set_tuning.argtypes = [C.c_char_p, i32]
     lib.tcar_build_id.restype = C.c_char_p
     lib.tcar_build_id.argtypes = []
     # a binary built from other sources than the ones next to it is stale (the build is digest-gated, not mtime-gated)

@@ -254,29 +254,67 @@ template <int XK> struct X3 {
   static constexpr int NV = 64 * XK / 4 / 256;   // float4 per thread, operand and stage
 };
 
+// The ring's loads are hidden from hipcc (inline asm, guide §5.7 form (ii)): with compiler-visible loads the wait in front
+// of each stage's LDS store came out as s_waitcnt vmcnt(0) — the loop back-edge makes hipcc's counter bookkeeping
+// conservative — which drains the whole ring once per round.  Every lane ALWAYS issues its loads (out-of-range lanes read
+// the operand's first 16 bytes; the zero mask is applied at x3_store), so the per-stage count is exact and the waits are
+// hand-counted: x3_wait<N>() = s_waitcnt vmcnt(N) naming every register of the slot as "+v", so that no consumer is
+// scheduled above it.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f gload16_hidden(const float* p) {
+  v4f v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+template <int N, int NV>
+__device__ __forceinline__ void x3_wait(v4f (&a)[NV], v4f (&b)[NV]) {
+  static_assert(NV == 2 || NV == 4 || NV == 8, "stage depth 32 / 64 / 128");
+  if constexpr (NV == 2)
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+  else if constexpr (NV == 4)
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(N) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(%16)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(b[0]),
+                   "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7])
+                 : "n"(N) : "memory");
+}
+
 template <int LAY, int XK>
-__device__ __forceinline__ void x3_load(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kend, int tid,
-                                        float4 (&reg)[X3<XK>::NV]) {
+__device__ __forceinline__ unsigned x3_load(const float* __restrict__ P, long ld, int r0, int rmax, int k0, int kend, int tid,
+                                            v4f (&reg)[X3<XK>::NV]) {
+  unsigned mask = 0;
 #pragma unroll
   for (int i = 0; i < X3<XK>::NV; ++i) {
     const int f = tid + 256 * i;
+    bool ok;
+    long off;
     if (LAY == 0) {
       const int row = f / (XK / 4), c4 = f % (XK / 4);
       const int gr = r0 + row, gk = k0 + c4 * 4;
-      reg[i] = (gr < rmax && gk < kend) ? ld4(P + (long)gr * ld + gk) : zero4();
+      ok = gr < rmax && gk < kend;
+      off = (long)gr * ld + gk;
     } else {
       const int krow = f >> 4, c4 = f & 15;
       const int gk = k0 + krow, gr = r0 + c4 * 4;
-      reg[i] = (gk < kend && gr + 3 < rmax) ? ld4(P + (long)gk * ld + gr) : zero4();
+      ok = gk < kend && gr + 3 < rmax;
+      off = (long)gk * ld + gr;
     }
+    reg[i] = gload16_hidden(P + (ok ? off : 0L));
+    mask |= ok ? (1u << i) : 0u;
   }
+  return mask;
 }
 template <int LAY, int XK>
-__device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict__ lo, int tid, const float4 (&reg)[X3<XK>::NV]) {
+__device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict__ lo, int tid, const v4f (&reg)[X3<XK>::NV],
+                                         unsigned mask) {
 #pragma unroll
   for (int i = 0; i < X3<XK>::NV; ++i) {
     const int f = tid + 256 * i;
-    const float v[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
+    const bool ok = (mask >> i) & 1u;
+    const float v[4] = {ok ? reg[i].x : 0.f, ok ? reg[i].y : 0.f, ok ? reg[i].z : 0.f, ok ? reg[i].w : 0.f};
     xbf16x4 h, l;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
@@ -303,6 +341,11 @@ __device__ __forceinline__ xbf16x8 x3_frag(const char* __restrict__ S, int base,
   }
 }
 
+// Register prefetch ring: the K loop of these launches is a latency chain (<= 1 workgroup per CU, a global-load round
+// trip of ~1-2 us per stage under load), so each thread keeps XD stages of both operands in flight in registers and the
+// (segment, k) stages of a K-concatenated problem form ONE flattened sequence — the ring runs across segment boundaries.
+constexpr int XD = 3;
+
 template <int LA, int LB, int XK>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
   constexpr int X3_PLANE = X3<XK>::PLANE, X3_NV = X3<XK>::NV;
@@ -327,44 +370,72 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
   if (g.mt <= g.nt) { tn = id / g.mt; tm = id - tn * g.mt; } else { tm = id / g.nt; tn = id - tm * g.nt; }
   const int m0 = tm * T, n0 = tn * T;
 
+  // flattened stage sequence: stage s of segment sg covers k in [ks + (s - c[sg]) * XK, ...) clipped to ke[sg]
+  const int ks = split * g.kchunk;
+  int cst[MAXSEG + 1];
+  cst[0] = 0;
+#pragma unroll
+  for (int sg = 0; sg < MAXSEG; ++sg) {
+    int n = 0;
+    if (sg < g.nseg) {
+      const int ke = min(g.K[sg], ks + g.kchunk);
+      n = ke > ks ? (ke - ks + XK - 1) / XK : 0;
+    }
+    cst[sg + 1] = cst[sg] + n;
+  }
+  const int total = cst[MAXSEG];
+  const int a_rmax0 = (LA == 0) ? g.M : (g.M + 3) & ~3;
+  const int b_rmax0 = (LB == 0) ? g.N : (g.N + 3) & ~3;
+
+  // segment of stage s; stages >= total map to the last segment with k0 >= its end (every lane masked)
+  auto stage_seg = [&](int s) { return min((s >= cst[1] ? 1 : 0) + (s >= cst[2] ? 1 : 0), g.nseg - 1); };
+  auto load_stage = [&](int s, v4f (&ra)[X3_NV], v4f (&rb)[X3_NV], unsigned& ma, unsigned& mb) {
+    const int sg = stage_seg(s);
+    const int k0 = ks + (s - cst[sg]) * XK;
+    const int ke = min(g.K[sg], ks + g.kchunk);
+    const long lda = g.lda[sg], ldb = g.ldb[sg];
+    const int a_rmax = (LA == 0) ? a_rmax0 : min((int)lda, a_rmax0);
+    const int b_rmax = (LB == 0) ? b_rmax0 : min((int)ldb, b_rmax0);
+    ma = x3_load<LA, XK>(g.A[sg], lda, m0, a_rmax, k0, ke, tid, ra);
+    mb = x3_load<LB, XK>(g.B[sg], ldb, n0, b_rmax, k0, ke, tid, rb);
+  };
+
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  float4 ra[X3_NV], rb[X3_NV];
+  // The ring body is STRAIGHT-LINE code: every slot is refilled unconditionally, in the same order, every round (stages
+  // past the end load the operand's first bytes with an all-zero mask and are never multiplied).  Any branch around a load
+  // makes hipcc fall back to s_waitcnt vmcnt(0), which would drain the ring once per round.
+  v4f ra[XD][X3_NV], rb[XD][X3_NV];
+  unsigned ma[XD], mb[XD];
+#pragma unroll
+  for (int d = 0; d < XD; ++d) load_stage(d, ra[d], rb[d], ma[d], mb[d]);
 #pragma unroll 1
-  for (int sg = 0; sg < g.nseg; ++sg) {
-    const float* __restrict__ Ap = g.A[sg];
-    const float* __restrict__ Bp = g.B[sg];
-    const long lda = g.lda[sg], ldb = g.ldb[sg];
-    const int ks = split * g.kchunk;
-    const int ke = min(g.K[sg], ks + g.kchunk);
-    const int nit = (ke - ks + XK - 1) / XK;
-    const int a_rmax = (LA == 0) ? g.M : min((int)lda, (g.M + 3) & ~3);
-    const int b_rmax = (LB == 0) ? g.N : min((int)ldb, (g.N + 3) & ~3);
-    if (nit > 0) {
-      x3_load<LA, XK>(Ap, lda, m0, a_rmax, ks, ke, tid, ra);
-      x3_load<LB, XK>(Bp, ldb, n0, b_rmax, ks, ke, tid, rb);
-    }
-    for (int it = 0; it < nit; ++it) {
+  for (int base = 0; base < total; base += XD) {
+#pragma unroll
+    for (int d = 0; d < XD; ++d) {
+      const int s = base + d;
       __syncthreads();                                        // everyone is done reading the previous stage
-      x3_store<LA, XK>(smem, smem + X3_PLANE, tid, ra);
-      x3_store<LB, XK>(smem + 2 * X3_PLANE, smem + 3 * X3_PLANE, tid, rb);
+      x3_wait<(XD - 1) * 2 * X3_NV, X3_NV>(ra[d], rb[d]);      // this slot has landed; XD - 1 younger stages stay in flight
+      x3_store<LA, XK>(smem, smem + X3_PLANE, tid, ra[d], ma[d]);
+      x3_store<LB, XK>(smem + 2 * X3_PLANE, smem + 3 * X3_PLANE, tid, rb[d], mb[d]);
       __syncthreads();
-      if (it + 1 < nit) {                                     // next slab in flight during the MFMAs
-        x3_load<LA, XK>(Ap, lda, m0, a_rmax, ks + (it + 1) * XK, ke, tid, ra);
-        x3_load<LB, XK>(Bp, ldb, n0, b_rmax, ks + (it + 1) * XK, ke, tid, rb);
-      }
-      const int nsub = min(XK, ke - (ks + it * XK) + 15) >> 4;      // k16 sub-steps that hold data
+      load_stage(s + XD, ra[d], rb[d], ma[d], mb[d]);         // refill this ring slot: XD - 1 stages stay in flight
+      const int sg = stage_seg(s);
+      const int k0 = ks + (s - cst[sg]) * XK;
+      const int left = min(g.K[sg], ks + g.kchunk) - k0;
+      const int nsub = s < total ? (min(XK, left + 15) >> 4) : 0;     // k16 sub-steps that hold data
 #pragma unroll 2
-      for (int s = 0; s < nsub; ++s) {
-        const xbf16x8 ah = x3_frag<LA, XK>(smem, wm * 32, s, lane), al = x3_frag<LA, XK>(smem + X3_PLANE, wm * 32, s, lane);
-        const xbf16x8 bh = x3_frag<LB, XK>(smem + 2 * X3_PLANE, wn * 32, s, lane), bl = x3_frag<LB, XK>(smem + 3 * X3_PLANE, wn * 32, s, lane);
+      for (int u = 0; u < nsub; ++u) {
+        const xbf16x8 ah = x3_frag<LA, XK>(smem, wm * 32, u, lane), al = x3_frag<LA, XK>(smem + X3_PLANE, wm * 32, u, lane);
+        const xbf16x8 bh = x3_frag<LB, XK>(smem + 2 * X3_PLANE, wn * 32, u, lane), bl = x3_frag<LB, XK>(smem + 3 * X3_PLANE, wn * 32, u, lane);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's trailing (masked) loads, before compiler-counted accesses
   float* Cs = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
   const int col = n0 + wn * 32 + (lane & 31);
   if (col < g.N) {

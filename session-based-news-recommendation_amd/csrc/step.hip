@@ -9,11 +9,32 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
-const TcarTuning& tcar_tuning() {
-  static const TcarTuning t = {env_int("TCAR_BF16_TILE", 0), env_int("TCAR_DX512", 1), env_int("TCAR_X3_XK", 0),
-                               env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
-                               env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_SORT_SCATTER", 1)};
+static TcarTuning& tuning_storage() {
+  static TcarTuning t = {env_int("TCAR_BF16_TILE", 0), env_int("TCAR_DX512", 1), env_int("TCAR_X3_XK", 0),
+                         env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
+                         env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_TILE288", 1), env_int("TCAR_SORT_SCATTER", 1)};
   return t;
+}
+const TcarTuning& tcar_tuning() { return tuning_storage(); }
+
+// Diagnostic hook (tests, tools): override one switch at run time; returns the previous value, or INT_MIN for an unknown
+// name.  Not thread safe against concurrent launches — product code never calls it.
+extern "C" int tcar_set_tuning(const char* name, int value) {
+  if (!name) return -2147483647 - 1;
+  TcarTuning& t = tuning_storage();
+  struct { const char* n; int* p; } tab[] = {{"TCAR_BF16_TILE", &t.bf16_tile}, {"TCAR_DX512", &t.dx512}, {"TCAR_X3_XK", &t.x3_xk},
+                                              {"TCAR_REST_GRID", &t.rest_grid}, {"TCAR_SOFTMAX_VARIANT", &t.softmax_variant},
+                                              {"TCAR_WGRAD_KS", &t.wgrad_ks}, {"TCAR_TILE288", &t.tile288},
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}};
+  for (auto& e : tab) {
+    bool same = true;
+    for (int i = 0; same; ++i) {
+      if (e.n[i] != name[i]) same = false;
+      else if (!e.n[i]) break;
+    }
+    if (same) { const int old = *e.p; *e.p = value; return old; }
+  }
+  return -2147483647 - 1;
 }
 
 namespace {

@@ -56,6 +56,7 @@ struct TcarTuning {
   int rest_grid;        // TCAR_REST_GRID      grid cap of the deferred Adam rest pass
   int softmax_variant;  // TCAR_SOFTMAX_VARIANT
   int wgrad_ks;         // TCAR_WGRAD_KS       K chunk of the weight-gradient split
+  int tile288;          // TCAR_TILE288        0 disables the 256 x 288 tile of the dX / dE GEMMs
   int sort_scatter;     // TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum
 };
 const TcarTuning& tcar_tuning();
