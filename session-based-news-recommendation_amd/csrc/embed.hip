@@ -141,6 +141,142 @@ __global__ __launch_bounds__(256) void gather_clip_fwd_kernel(const EmbArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------- forward, throughput form
+// Large launches (>= 16 k session rows: evaluation sweeps, the 100 M-session stress configuration, tools/gather_bench.py).
+// The latency form above keeps ~2 rows per wave in flight and re-reads the seven small rows of every session row from L2
+// (2.5 KB of L1/L2 traffic beside 2 KB of HBM reads) with a shuffle reduction each.  Here:
+//   * the <= 190 small rows (position, 5 time tables, dwell) are clipped ONCE per workgroup into LDS (78 KB for H = 250,
+//     Ht = 64): a session row then costs two HBM row reads, two wave reductions and seven LDS reads;
+//   * one 1024-thread workgroup per CU (16 waves), every wave owns R = 4 CONSECUTIVE session rows per trip: 8 KB of HBM
+//     reads in flight per wave, 128 KB per CU, and 14 KB of contiguous output per trip;
+//   * the ids of the next trip are fetched (scalar loads: the row index is wave uniform) before the current one is reduced;
+//   * outputs leave with non-temporal stores (3.5 KB written per 2 KB read: they would only evict the table rows).
+typedef float v4f_e __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float* p, float4 v) {
+  v4f_e x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<v4f_e*>(p));
+}
+
+template <int NCH>
+__global__ __launch_bounds__(1024) void gather_clip_fwd_big_kernel(const EmbArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int B = a.bt.B, T = a.bt.T, BT = B * T;
+  const int ldh = a.d.ldh, ldt = a.d.ldt;
+  const int ic = 2 * ldh, pt = 5 * ldt, ek = ic + pt, ct = 2 * ldt;
+  const int sub = ldt >> 2, gpw = 64 / sub;
+  const int grp = lane / sub, lin = lane - grp * sub;
+  float* lpos = lds;                                  // [40][ldh]   clipped position rows
+  float* lsm = lds + TCAR_POS_VOCAB * ldh;            // [150][ldt]  clipped month|day|week|hour|minute|dwell rows
+  for (int r = wave; r < TCAR_POS_VOCAB; r += 16) {
+    float4 x[NCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      x[c] = col < ldh ? ld4(a.tab.pos + (long)r * ldh + col) : zero4();
+      ss += dot4(x[c], x[c]);
+    }
+    ss = clip_scale(wave_sum(ss));
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) st4(lpos + r * ldh + col, scale4(x[c], ss));
+    }
+  }
+  for (int r0 = wave * gpw; r0 < SMALL_ROWS; r0 += 16 * gpw) {
+    const int r = r0 + grp;
+    const bool ok = r < SMALL_ROWS;
+    const int rr = ok ? r : 0;
+    const int k = rr < 13 ? 0 : rr < 45 ? 1 : rr < 53 ? 2 : rr < 78 ? 3 : rr < 139 ? 4 : 5;
+    const float* tp = (k < 5) ? pick5(a.tab.time, k) : a.tab.dur;
+    const float4 x = ok ? ld4(tp + (long)(rr - time_rowoff(k)) * ldt + lin * 4) : zero4();
+    const float sx = clip_scale(group_sum(dot4(x, x), sub));
+    if (ok) st4(lsm + rr * ldt + lin * 4, scale4(x, sx));
+  }
+  __syncthreads();
+
+  constexpr int R = 4;
+  const long wave_g = (long)blockIdx.x * 16 + wave;
+  const long stride = (long)gridDim.x * 16 * R;
+  int ids[R], ids_n[R];
+#pragma unroll
+  for (int u = 0; u < R; ++u) {
+    const long rw = wave_g * R + u;
+    ids[u] = a.bt.seq[rw < BT ? rw : 0];
+  }
+  for (long row0 = wave_g * R; row0 < BT; row0 += stride) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {                     // next trip's item ids (consumed one trip later)
+      const long rn = row0 + stride + u;
+      ids_n[u] = a.bt.seq[rn < BT ? rn : 0];
+    }
+    float4 xi[R][NCH], xc[R][NCH];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const int n = clampi(ids[u], 1, a.d.n_items) - 1;
+      const float* e = a.tab.E + (long)n * ek;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = col < ldh;
+        xi[u][c] = ok ? ld4(e + col) : zero4();
+        xc[u][c] = ok ? ld4(e + ldh + col) : zero4();
+      }
+    }
+    // the small rows of the R session rows: `gpw` (row, table) pairs per pass out of 6 * R, straight from LDS
+    for (int q0 = 0; q0 < 6 * R; q0 += gpw) {
+      const int q = q0 + grp;
+      const int u = q / 6, k = q - u * 6;
+      const long row = row0 + u;
+      const bool valid = q < 6 * R && row < BT;
+      const long rw = valid ? row : row0;
+      const int kk = valid ? k : 0;
+      int id = (kk < 5) ? pick5(a.bt.pub, kk)[rw] : a.bt.gap[rw];
+      const bool oob = (kk == 5) && (id >= TCAR_DUR_VOCAB || id < 0);   // dwell bucket 11 -> zero row (S7)
+      id = clampi(id, 0, time_vocab(kk) - 1);
+      const float4 x = oob ? zero4() : ld4(lsm + (time_rowoff(kk) + id) * ldt + lin * 4);
+      if (valid) {
+        float* dst = (kk < 5) ? a.x_pt + row * pt + kk * ldt : a.x_act + row * ldt;
+        st4_nt(dst + lin * 4, x);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const long row = row0 + u;
+      float si = 0.f, sc = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) { si += dot4(xi[u][c], xi[u][c]); sc += dot4(xc[u][c], xc[u][c]); }
+      si = clip_scale(wave_sum(si)); sc = clip_scale(wave_sum(sc));
+      if (row < BT) {
+        const int t = (int)(row % T);
+        float* o = a.x_icp + row * ic;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          if (col < ldh) {
+            st4_nt(o + col, fma4(xi[u][c], si, ld4(lpos + t * ldh + col)));
+            st4_nt(o + ldh + col, scale4(xc[u][c], sc));
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < R; ++u) ids[u] = ids_n[u];
+  }
+  // click-time query rows: week table by cw, hour table by ch (model_combine.py:94-97)
+  for (long b0 = wave_g * gpw; b0 < 2L * B; b0 += (long)gridDim.x * 16 * gpw) {
+    const long q = b0 + grp;
+    const bool valid = q < 2L * B;
+    const long b = valid ? (q >> 1) : 0;
+    const int jj = (int)(q & 1), kk = jj == 0 ? 2 : 3;
+    const int id = clampi(jj == 0 ? a.bt.cw[b] : a.bt.ch[b], 0, time_vocab(kk) - 1);
+    const float4 x = ld4(lsm + (time_rowoff(kk) + id) * ldt + lin * 4);
+    if (valid) st4(a.click_t + b * ct + jj * ldt + lin * 4, x);
+  }
+}
+
 // ----------------------------------------------------------------------------------------------- backward
 template <int NCH, int LDT>   // LDT = ldt (64 / 128 / 256): the 16-lane-group geometry of the small tables is compile time
 __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
@@ -565,6 +701,25 @@ extern "C" int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* t
   EmbArgs a{};
   a.d = *d; a.tab = *tab; a.bt = *bt;
   a.x_icp = x_icp; a.x_pt = x_pt; a.x_act = x_act; a.click_t = click_t;
+  const long rows = (long)bt->B * bt->T;
+  const size_t big_lds = ((size_t)TCAR_POS_VOCAB * d->ldh + (size_t)SMALL_ROWS * d->ldt) * sizeof(float);
+  if (rows >= tcar_tuning().gather_big_rows && big_lds <= 160 * 1024) {
+    // throughput form: one 16-wave workgroup per CU (the clipped small tables live in its LDS)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    long g = (rows + 16 * 4 - 1) / (16 * 4);
+    const long cap = (long)cus * (tcar_tuning().gather_wg_per_cu > 0 ? tcar_tuning().gather_wg_per_cu : 1);
+    if (g > cap) g = cap;
+    if (d->ldh <= 256) {
+      TCAR_SET_LDS_ONCE(gather_clip_fwd_big_kernel<1>, 160 * 1024);
+      TCAR_LAUNCH(gather_clip_fwd_big_kernel<1>, dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a);
+    } else {
+      TCAR_SET_LDS_ONCE(gather_clip_fwd_big_kernel<2>, 160 * 1024);
+      TCAR_LAUNCH(gather_clip_fwd_big_kernel<2>, dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a);
+    }
+    TCAR_CHECK_LAUNCH();
+    return TCAR_OK;
+  }
   const int grid = grid_for_rows((long)bt->B * bt->T + bt->B);
   if (d->ldh <= 256) TCAR_LAUNCH(gather_clip_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else TCAR_LAUNCH(gather_clip_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -344,9 +344,7 @@ __device__ __forceinline__ xbf16x8 x3_frag(const char* __restrict__ S, int base,
 // Register prefetch ring: the K loop of these launches is a latency chain (<= 1 workgroup per CU, a global-load round
 // trip of ~1-2 us per stage under load), so each thread keeps XD stages of both operands in flight in registers and the
 // (segment, k) stages of a K-concatenated problem form ONE flattened sequence — the ring runs across segment boundaries.
-constexpr int XD = 3;
-
-template <int LA, int LB, int XK>
+template <int LA, int LB, int XK, int XD>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
   constexpr int X3_PLANE = X3<XK>::PLANE, X3_NV = X3<XK>::NV;
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -489,11 +487,11 @@ int launch_layout(GroupArgs& ga, hipStream_t st) {
   return launch_variant<LA, LB, 64, 64>(ga, wg, st);
 }
 
-template <int LA, int LB, int XK>
+template <int LA, int LB, int XK, int XD>
 int launch_x3_v(const GroupArgs& ga, int wg, hipStream_t st) {
   constexpr size_t lds = 4 * X3<XK>::PLANE;
-  TCAR_SET_LDS_ONCE((gemm_x3_kernel<LA, LB, XK>), lds);
-  TCAR_LAUNCH((gemm_x3_kernel<LA, LB, XK>), dim3(wg), dim3(256), lds, st, ga);
+  TCAR_SET_LDS_ONCE((gemm_x3_kernel<LA, LB, XK, XD>), lds);
+  TCAR_LAUNCH((gemm_x3_kernel<LA, LB, XK, XD>), dim3(wg), dim3(256), lds, st, ga);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -508,13 +506,15 @@ int launch_x3(GroupArgs& ga, hipStream_t st) {
     p.wg_begin = wg;
     wg += p.mt * p.nt * p.ksplit;
   }
-  const int force = tcar_tuning().x3_xk;
-  if (force == 32) return launch_x3_v<LA, LB, 32>(ga, wg, st);
-  if (force == 128) return launch_x3_v<LA, LB, 128>(ga, wg, st);
+  const int force = tcar_tuning().x3_xk, ring = tcar_tuning().x3_ring;
+  if (force == 32) return launch_x3_v<LA, LB, 32, 3>(ga, wg, st);
+  if (force == 128) return launch_x3_v<LA, LB, 128, 2>(ga, wg, st);
   // 64-deep stages (48 KB of LDS) by default: these launches run beside the dE GEMM, whose workgroups hold 96 KB of a CU's
   // 160 KB — a 96-KB (128-deep) workgroup would have to wait for one of them to retire (measured: 0.704 / 0.690 / 0.680 ms
   // per step with 128-deep / mixed / 64-deep stages)
-  return launch_x3_v<LA, LB, 64>(ga, wg, st);
+  if (ring == 1) return launch_x3_v<LA, LB, 64, 1>(ga, wg, st);
+  if (ring == 2) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st);
+  return launch_x3_v<LA, LB, 64, 3>(ga, wg, st);
 }
 
 int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {

@@ -11,8 +11,9 @@ static int env_int(const char* name, int dflt) {
 }
 static TcarTuning& tuning_storage() {
   static TcarTuning t = {env_int("TCAR_BF16_TILE", 0), env_int("TCAR_DX512", 1), env_int("TCAR_X3_XK", 0),
-                         env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
-                         env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_TILE288", 1), env_int("TCAR_SORT_SCATTER", 1)};
+                         env_int("TCAR_X3_RING", 3), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
+                         env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
+                         env_int("TCAR_GATHER_WG", 2), env_int("TCAR_SORT_SCATTER", 1)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -23,8 +24,10 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
   if (!name) return -2147483647 - 1;
   TcarTuning& t = tuning_storage();
   struct { const char* n; int* p; } tab[] = {{"TCAR_BF16_TILE", &t.bf16_tile}, {"TCAR_DX512", &t.dx512}, {"TCAR_X3_XK", &t.x3_xk},
+                                              {"TCAR_X3_RING", &t.x3_ring},
                                               {"TCAR_REST_GRID", &t.rest_grid}, {"TCAR_SOFTMAX_VARIANT", &t.softmax_variant},
                                               {"TCAR_WGRAD_KS", &t.wgrad_ks}, {"TCAR_TILE288", &t.tile288},
+                                              {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_SORT_SCATTER", &t.sort_scatter}};
   for (auto& e : tab) {
     bool same = true;

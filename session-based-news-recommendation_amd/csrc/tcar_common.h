@@ -53,10 +53,13 @@ struct TcarTuning {
   int bf16_tile;        // TCAR_BF16_TILE      force a workgroup tile of the bf16 GEMM (0 = heuristic)
   int dx512;            // TCAR_DX512          0 disables the 512 x 128 dX tile
   int x3_xk;            // TCAR_X3_XK          stage depth of the small split-bf16 GEMM (0 = default)
+  int x3_ring;          // TCAR_X3_RING        stages the small GEMM keeps in flight in registers (1, 2 or 3)
   int rest_grid;        // TCAR_REST_GRID      grid cap of the deferred Adam rest pass
   int softmax_variant;  // TCAR_SOFTMAX_VARIANT
   int wgrad_ks;         // TCAR_WGRAD_KS       K chunk of the weight-gradient split
   int tile288;          // TCAR_TILE288        0 disables the 256 x 288 tile of the dX / dE GEMMs
+  int gather_big_rows;  // TCAR_GATHER_BIG_ROWS  session rows from which the forward gather runs its throughput form
+  int gather_wg_per_cu; // TCAR_GATHER_WG      1024-thread workgroups per CU of that form (2 x 78 KB of LDS fit)
   int sort_scatter;     // TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum
 };
 const TcarTuning& tcar_tuning();
@@ -76,8 +79,10 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
   return v;
 }
+// explicit fma chain: hipcc contracts a plain a*b + c*d + ... differently from one inlining context to the next, and two
+// kernels that must agree bit for bit (the two forms of the forward gather) would round their row norms differently
 __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
-  return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

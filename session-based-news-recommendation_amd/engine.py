@@ -142,9 +142,9 @@ class TcarEngine:
         self.b1, self.b2, self.eps = 0.9, 0.999, 1e-8
         self.b1_pow, self.b2_pow = np.float32(self.b1), np.float32(self.b2)
         self.step = 0
-        # split-K of dX = dlogits E: 42 slabs with the 256 x 288 bf16 tile (2 M tiles x 3 N tiles x 42 = 252 workgroups;
-        # 36 x 7 with the 512 x 128 tile it replaces, TCAR_TILE288=0), 16 in fp32
-        self.splitk = splitk if splitk else (16 if scoring == "f32" else (42 if os.environ.get("TCAR_TILE288", "1") != "0" else 36))
+        # split-K of dX = dlogits E: 36 slabs with the 512 x 128 bf16 tile (7 N tiles x 36 = 252 workgroups), 16 in fp32;
+        # 42 with the optional 256 x 288 tile (TCAR_TILE288=1: 2 x 3 x 42 = 252)
+        self.splitk = splitk if splitk else (16 if scoring == "f32" else (42 if os.environ.get("TCAR_TILE288", "0") == "1" else 36))
         if os.environ.get("TCAR_SPLITK"):
             self.splitk = int(os.environ["TCAR_SPLITK"])
         # precision of the three full-catalog scoring GEMMs: "f32" (fp32 MFMA), "bf16x3" (split-bf16 planes, three

@@ -902,3 +902,52 @@ def test_gemm_bf16_tile_256x288(lib, layout, nsplit, M, N, K, splitk):
     tol = dict(rtol=1e-3, atol_scale=2e-5) if nsplit == 3 else dict(rtol=2e-2, atol_scale=2e-2)
     close(got[:, :, :N].sum(0), want, name="256x288 tile", **tol)
     assert (got[:, :, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize("B,T,H,Ht", [(37, 3, 250, 64), (5, 1, 250, 64), (300, 40, 250, 64), (64, 7, 300, 64), (33, 2, 48, 16)])
+def test_gather_forward_throughput_form_equals_latency_form(lib, B, T, H, Ht):
+    """tcar_gather_clip_fwd has a latency form (in-step launches) and a throughput form (>= 16 k rows: small tables clipped
+    once into LDS, 4 consecutive rows per wave, non-temporal stores).  Same arithmetic, so the outputs are bit-identical —
+    incl. dwell bucket 11 (zero row), row counts that are no multiple of 4 and T = 1."""
+    from tcar_amd._lib import Batch, Dims, Tables
+    rng = np.random.RandomState(B * 100 + T)
+    N = 5000
+    ldh = (H + 63) // 64 * 64
+    ldt = 64 if Ht <= 64 else 128
+    ic, pt, ct, ek = 2 * ldh, 5 * ldt, 2 * ldt, 2 * ldh + 5 * ldt
+    dev = "cuda"
+    E = torch.tensor((rng.standard_normal((N, ek)) * 0.08).astype(np.float32), device=dev)
+    small = [torch.tensor((rng.standard_normal((v, ldt)) * 0.3).astype(np.float32), device=dev) for v in (13, 32, 8, 25, 61, 11)]
+    pos = torch.tensor((rng.standard_normal((40, ldh)) * 0.1).astype(np.float32), device=dev)
+    ti = lambda a: torch.tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev)
+    seq = ti(rng.randint(1, N + 1, (B, T)))
+    pub = [ti(rng.randint(1, v, (B, T))) for v in (13, 32, 8, 25, 61)]
+    gap_np = rng.randint(0, 12, (B, T))
+    gap_np.flat[0] = 11                                  # out of range for the 11-row table (DESIGN S7)
+    gap, cw, ch, label = ti(gap_np), ti(rng.randint(0, 7, B)), ti(rng.randint(0, 24, B)), ti(rng.randint(0, N, B))
+    d = Dims(N, H, Ht, ldh, ldt)
+    tab = Tables()
+    tab.E, tab.pos, tab.dur = E.data_ptr(), pos.data_ptr(), small[5].data_ptr()
+    for k in range(5):
+        tab.time[k] = small[k].data_ptr()
+    bt = Batch()
+    bt.B, bt.T, bt.K = B, T, 0
+    bt.seq, bt.cw, bt.ch, bt.gap, bt.label = seq.data_ptr(), cw.data_ptr(), ch.data_ptr(), gap.data_ptr(), label.data_ptr()
+    for k in range(5):
+        bt.pub[k] = pub[k].data_ptr()
+    outs = []
+    for big in (1 << 30, 1):
+        x_icp, x_pt = torch.full((B * T, ic), 7.0, device=dev), torch.full((B * T, pt), 7.0, device=dev)
+        x_act, click = torch.full((B * T, ldt), 7.0, device=dev), torch.full((B, ct), 7.0, device=dev)
+        prev = lib.tcar_set_tuning(b"TCAR_GATHER_BIG_ROWS", big)
+        try:
+            assert lib.tcar_gather_clip_fwd(C.byref(d), C.byref(tab), C.byref(bt), ptr(x_icp), ptr(x_pt), ptr(x_act), ptr(click),
+                                            None) == 0
+            torch.cuda.synchronize()
+        finally:
+            lib.tcar_set_tuning(b"TCAR_GATHER_BIG_ROWS", prev)
+        outs.append([t.cpu().numpy() for t in (x_icp, x_pt, x_act, click)])
+    for name, a, b in zip(("x_icp", "x_pt", "x_act", "click_t"), outs[0], outs[1]):
+        bad = np.argwhere(a != b)
+        assert bad.size == 0, (name, len(bad), bad[:8].tolist(), [(float(a[tuple(i)]), float(b[tuple(i)])) for i in bad[:4]])
+    assert not (outs[1][0] == 7.0).all() and float(np.abs(outs[1][2][0]).max()) == 0.0      # the bucket-11 row is zero
