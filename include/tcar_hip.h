@@ -160,6 +160,20 @@ typedef struct {
   int64_t ldc;
   const float* bias;
   int32_t M, N, act, beta, splitk, atomic;
+  /* Optional fused epilogues of tcar_gemm_x3_grouped (ignored by tcar_gemm_f32_grouped; all NULL / 0 = plain):
+   *  - activation BACKWARD: dact = 1 (relu) / 2 (tanh): C = acc * act'(dact_y[m, n]) and, with colsum != NULL,
+   *    colsum[n] += sum_m C[m, n] (fp32 atomics into a caller-zeroed vector): the bias + activation backward of linear_2d
+   *    (modules.py:52-54) in the epilogue of the GEMM that produces the incoming gradient;
+   *  - bf16 planes: the result (after bias / act) additionally goes to hi / lo KB32 planes with inner dimension
+   *    plane_inner (>= N, % 32 == 0) at column offset plane_col0, and columns outside [pack_c0, pack_c1) to a second,
+   *    PACKED plane pair (column index rebased past the gap, inner dimension pack_inner) — the operands the scoring GEMMs
+   *    read (tcar_split_bf16 without its own launch). */
+  int32_t dact;
+  const float* dact_y;
+  int64_t ld_dact_y;
+  float* colsum;
+  void* plane_hi; void* plane_lo; int32_t plane_inner, plane_col0;
+  void* pack_hi; void* pack_lo; int32_t pack_inner, pack_c0, pack_c1;
 } tcar_gemm_desc_t;
 int tcar_gemm_f32_grouped(int layout, int nprob, const tcar_gemm_desc_t* descs /*host*/, void* stream);
 /* Same contract on the bf16 matrix cores: each staged fp32 tile is split on the fly into bf16 hi / lo planes and every
@@ -216,6 +230,14 @@ int tcar_attn_pool_bwd(const tcar_dims_t* d, int B, int T, const float* x_icp, c
                        const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
                        float* dx_pt, float* dq, float* dpre1, float* dpre2, float* g_wres1, float* g_wres2,
                        void* stream);
+
+/* ..._q: with g_qbias != NULL (a caller-zeroed [ic] vector) dq leaves already multiplied by tanh'(q) = 1 - q^2 and its column
+ * sums are added into g_qbias — the activation + bias backward of query_trans2 (modules.py:139) without its own launch. */
+int tcar_attn_pool_bwd_q(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                         const float* pre1, const float* pre2, const float* q, const float* w_res1,
+                         const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
+                         float* dx_pt, float* dq, float* dpre1, float* dpre2, float* g_wres1, float* g_wres2,
+                         float* g_qbias, void* stream);
 
 /* ---- scoring loss -----------------------------------------------------------------------------------------
  * tcar_softmax_ce: tf.nn.sparse_softmax_cross_entropy_with_logits (model_combine.py:145) and its gradient.
@@ -340,7 +362,7 @@ int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, f
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 5
+#define TCAR_ABI_VERSION 6
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -397,6 +419,10 @@ typedef struct {
    * launched on; slots are used round-robin through the host counter ev_cursor[0] (ev_cursor[1] = slot of the step in
    * flight, written by the forward pass); ev_n = 0 disables it */
   void* const* ev_start; void* const* ev_stop; int32_t ev_n; int32_t* ev_cursor;
+  /* optional third stream + one event (fused single-rank step only): the weight-gradient GEMM and the dense-weight norms
+   * run on it, so that they start the moment their inputs exist instead of queueing behind the aux stream's
+   * candidate-time backward; NULL = they follow on the aux stream */
+  void* stream3; void* ev3;
 } tcar_ctx_t;
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */

@@ -20,11 +20,11 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 5          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 6          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
-           "tcar_attn_pool_bwd", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
+           "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
            "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_step_forward",
@@ -144,7 +144,11 @@ class GemmDesc(C.Structure):
     _fields_ = [("nseg", C.c_int32), ("A", C.c_void_p * 3), ("B", C.c_void_p * 3), ("lda", C.c_int64 * 3),
                 ("ldb", C.c_int64 * 3), ("K", C.c_int32 * 3), ("C", C.c_void_p), ("ldc", C.c_int64),
                 ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("act", C.c_int32), ("beta", C.c_int32),
-                ("splitk", C.c_int32), ("atomic", C.c_int32)]
+                ("splitk", C.c_int32), ("atomic", C.c_int32),
+                ("dact", C.c_int32), ("dact_y", C.c_void_p), ("ld_dact_y", C.c_int64), ("colsum", C.c_void_p),
+                ("plane_hi", C.c_void_p), ("plane_lo", C.c_void_p), ("plane_inner", C.c_int32), ("plane_col0", C.c_int32),
+                ("pack_hi", C.c_void_p), ("pack_lo", C.c_void_p), ("pack_inner", C.c_int32), ("pack_c0", C.c_int32),
+                ("pack_c1", C.c_int32)]
 
 
 _WS = ["x_icp", "x_pt", "x_act", "click_t", "pre1", "pre2", "q1", "q", "alpha", "pooled", "attout", "logits", "ce",
@@ -165,7 +169,7 @@ class Ctx(C.Structure):
                 + [("rank", C.c_void_p), ("topk", C.c_void_p), ("scoring", C.c_int32), ("scoring_bwd", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l")]
                 + [("stream2", C.c_void_p), ("ev", C.c_void_p * 6), ("adam_bitmap", C.c_void_p), ("et_perm", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
-                   ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p)])
+                   ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p), ("stream3", C.c_void_p), ("ev3", C.c_void_p)])
 
 
 class TcarError(RuntimeError):
@@ -216,6 +220,7 @@ def load() -> C.CDLL:
     lib.tcar_gemm_splitk_effective.argtypes = [i32, i32]
     lib.tcar_attn_pool_fwd.argtypes = [P(Dims), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tcar_attn_pool_bwd.argtypes = [P(Dims), i32, i32] + [vp] * 17
+    lib.tcar_attn_pool_bwd_q.argtypes = [P(Dims), i32, i32] + [vp] * 18
     lib.tcar_softmax_ce.argtypes = [i32, i32, vp, i64, vp, vp, vp]
     lib.tcar_neg_term.argtypes = [P(Dims), i32, i32, vp, vp, vp, f32, vp, vp, vp, vp, vp, vp]
     lib.tcar_neg_fwd.argtypes = [P(Dims), i32, i32, vp, vp, vp, f32, vp, vp, vp, vp]

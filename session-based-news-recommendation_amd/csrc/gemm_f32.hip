@@ -24,6 +24,7 @@
 // Workgroup ids are remapped so that each XCD (private L2) receives a contiguous run of tile ids, with the
 // shorter tile dimension fastest: the workgroups that share the large operand's tile run on one XCD.
 #include "tcar_common.h"
+#include "tcar_bf16_layout.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -44,6 +45,10 @@ struct GemmProb {
   int M, N, act, beta;
   int ksplit, kchunk, mode;   // mode 0: plain, 1: slabs C[split][M][ldc], 2: atomicAdd into C
   int mt, nt, wg_begin;       // tiles and first workgroup id of this problem inside the launch
+  // fused epilogues of the split-bf16 kernel (tcar_gemm_desc_t): activation backward + column sums; bf16 plane outputs
+  int dact; const float* dact_y; long ld_dact_y; float* colsum;
+  __bf16* plane_hi; __bf16* plane_lo; int plane_in32, plane_col0;
+  __bf16* pack_hi; __bf16* pack_lo; int pack_in32, pack_c0, pack_c1;
 };
 struct GroupArgs {
   int nprob;
@@ -436,8 +441,13 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's trailing (masked) loads, before compiler-counted accesses
   float* Cs = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
   const int col = n0 + wn * 32 + (lane & 31);
+  float csum = 0.f;
   if (col < g.N) {
     const float bv = g.bias ? g.bias[col] : 0.f;
+    // packed-plane column of this lane: columns [pack_c0, pack_c1) are left out, later columns move down
+    const int gcol = g.plane_col0 + col;               // column in plane space
+    const bool packed = g.pack_hi && (gcol < g.pack_c0 || gcol >= g.pack_c1);
+    const int pcol = gcol < g.pack_c0 ? gcol : gcol - (g.pack_c1 - g.pack_c0);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
@@ -449,11 +459,31 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
           float v = acc[e] + bv;
           if (g.act == 1) v = fmaxf(v, 0.f);
           else if (g.act == 2) v = tanhf(v);
+          if (g.dact) {                                   // activation backward: times act'(y)
+            const float y = g.dact_y[(long)row * g.ld_dact_y + col];
+            v = g.dact == 1 ? (y > 0.f ? v : 0.f) : v * (1.f - y * y);
+            csum += v;
+          }
           if (g.beta) v += *p;
           *p = v;
+          if (g.plane_hi) {
+            const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
+            const long o = kb32_off(row, gcol, g.plane_in32);
+            g.plane_hi[o] = h;
+            g.plane_lo[o] = l;
+            if (packed) {
+              const long po = kb32_off(row, pcol, g.pack_in32);
+              g.pack_hi[po] = h;
+              g.pack_lo[po] = l;
+            }
+          }
         }
       }
     }
+  }
+  if (g.dact && g.colsum) {      // column sums (bias gradient): the two lane halves hold the same column
+    csum += __shfl_xor(csum, 32);
+    if (lane < 32 && col < g.N && csum != 0.f) atomicAdd(g.colsum + col, csum);
   }
 }
 
@@ -529,6 +559,14 @@ int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {
     p.A[s] = d.A[s]; p.B[s] = d.B[s]; p.lda[s] = d.lda[s]; p.ldb[s] = d.ldb[s]; p.K[s] = d.K[s];
   }
   p.C = d.C; p.ldc = d.ldc; p.bias = d.bias; p.M = d.M; p.N = d.N; p.act = d.act; p.beta = d.beta;
+  p.dact = d.dact; p.dact_y = d.dact_y; p.ld_dact_y = d.ld_dact_y; p.colsum = d.colsum;
+  if (d.dact && (d.dact < 1 || d.dact > 2 || !d.dact_y)) return TCAR_E_ARG;
+  p.plane_hi = (__bf16*)d.plane_hi; p.plane_lo = (__bf16*)d.plane_lo; p.plane_in32 = d.plane_inner >> 5; p.plane_col0 = d.plane_col0;
+  p.pack_hi = (__bf16*)d.pack_hi; p.pack_lo = (__bf16*)d.pack_lo; p.pack_in32 = d.pack_inner >> 5;
+  p.pack_c0 = d.pack_c0; p.pack_c1 = d.pack_c1;
+  if (d.plane_hi && (!d.plane_lo || (d.plane_inner & 31) || d.plane_col0 < 0 || d.plane_col0 + d.N > d.plane_inner)) return TCAR_E_ARG;
+  if (d.pack_hi && (!d.plane_hi || !d.pack_lo || (d.pack_inner & 31) || d.pack_c0 > d.pack_c1)) return TCAR_E_ARG;
+  if ((d.dact || d.plane_hi) && d.splitk > 1) return TCAR_E_ARG;
   int splitk = d.splitk < 1 ? 1 : d.splitk;
   p.mode = splitk > 1 ? (d.atomic ? 2 : 1) : 0;
   if (splitk > 1 && (d.nseg != 1 || d.bias || d.act || d.beta)) return TCAR_E_ARG;

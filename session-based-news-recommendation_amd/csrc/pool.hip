@@ -23,6 +23,7 @@ struct PoolArgs {
   const float* w1; const float* w2; const float* alpha_in; const float* dpooled;
   float* pooled; float* alpha;
   float* dx_icp; float* dx_pt; float* dq; float* dpre1; float* dpre2; float* g_w1; float* g_w2;
+  float* g_qb;     // optional: bias gradient of query_trans2; dq then leaves multiplied by tanh'(q) (modules.py:139 backward)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -119,14 +120,15 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
 
 template <int NCH>
 __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
-  __shared__ float gw_lds[2 * 512];     // per-workgroup partial sums of d w_res1 | d w_res2
+  __shared__ float gw_lds[4 * 512];     // per-workgroup partial sums of d w_res1 | d w_res2 | d q-bias (2 * ldh)
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = blockIdx.x * 4 + (tid >> 6);
   const int T = a.T, H = a.H, ldh = a.ldh, ldt = a.ldt;
   const int ic = 2 * ldh, pt = 5 * ldt, ek = ic + pt;
   const int BT = a.B * T;
   const int ptl = pt >> 2;
-  for (int i = tid; i < 2 * ldh; i += 256) gw_lds[i] = 0.f;
+  const int nlds = a.g_qb ? 4 * ldh : 2 * ldh;
+  for (int i = tid; i < nlds; i += 256) gw_lds[i] = 0.f;
   __syncthreads();
   if (b < a.B) {
     float4 w1[NCH], w2[NCH], qa[NCH], qb[NCH], da[NCH], db[NCH];
@@ -216,6 +218,14 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       if (col < ldh) {
+        if (a.g_qb) {        // q = tanh(.): the gradient leaves through tanh' = 1 - q^2, and its column sums are the bias gradient
+          dqa[c] = make_float4(dqa[c].x * (1.f - qa[c].x * qa[c].x), dqa[c].y * (1.f - qa[c].y * qa[c].y),
+                               dqa[c].z * (1.f - qa[c].z * qa[c].z), dqa[c].w * (1.f - qa[c].w * qa[c].w));
+          dqb[c] = make_float4(dqb[c].x * (1.f - qb[c].x * qb[c].x), dqb[c].y * (1.f - qb[c].y * qb[c].y),
+                               dqb[c].z * (1.f - qb[c].z * qb[c].z), dqb[c].w * (1.f - qb[c].w * qb[c].w));
+          atomic_add4(gw_lds + 2 * ldh + col, dqa[c]);
+          atomic_add4(gw_lds + 3 * ldh + col, dqb[c]);
+        }
         st4(a.dq + (long)b * ic + col, dqa[c]);
         st4(a.dq + (long)b * ic + ldh + col, dqb[c]);
         atomic_add4(gw_lds + col, gw1[c]);
@@ -224,9 +234,9 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * ldh; i += 256) {
+  for (int i = tid; i < nlds; i += 256) {
     const float v = gw_lds[i];
-    if (v != 0.f) atomicAdd((i < ldh ? a.g_w1 + i : a.g_w2 + (i - ldh)), v);
+    if (v != 0.f) atomicAdd((i < ldh ? a.g_w1 + i : i < 2 * ldh ? a.g_w2 + (i - ldh) : a.g_qb + (i - 2 * ldh)), v);
   }
 }
 
@@ -252,12 +262,22 @@ extern "C" int tcar_attn_pool_bwd(const tcar_dims_t* d, int B, int T, const floa
                                   const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
                                   float* dx_pt, float* dq, float* dpre1, float* dpre2, float* g_wres1,
                                   float* g_wres2, void* stream) {
+  return tcar_attn_pool_bwd_q(d, B, T, x_icp, x_pt, pre1, pre2, q, w_res1, w_res2, alpha, dpooled, dx_icp, dx_pt, dq, dpre1,
+                              dpre2, g_wres1, g_wres2, nullptr, stream);
+}
+
+extern "C" int tcar_attn_pool_bwd_q(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                                    const float* pre1, const float* pre2, const float* q, const float* w_res1,
+                                    const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
+                                    float* dx_pt, float* dq, float* dpre1, float* dpre2, float* g_wres1,
+                                    float* g_wres2, float* g_qbias, void* stream) {
   if (!d || B <= 0 || T <= 0 || T > TCAR_POS_VOCAB || (d->ldh & 63) || d->ldh > 512 || 5 * d->ldt > 512) return TCAR_E_ARG;
   PoolArgs a{};
   a.B = B; a.T = T; a.H = d->H; a.ldh = d->ldh; a.ldt = d->ldt;
   a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1; a.pre2 = pre2; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
   a.alpha_in = alpha; a.dpooled = dpooled;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dq = dq; a.dpre1 = dpre1; a.dpre2 = dpre2; a.g_w1 = g_wres1; a.g_w2 = g_wres2;
+  a.g_qb = g_qbias;
   const int grid = (B + 3) / 4;
   if (d->ldh <= 256) TCAR_LAUNCH(attn_pool_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else TCAR_LAUNCH(attn_pool_bwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);

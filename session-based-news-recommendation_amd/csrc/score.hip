@@ -283,8 +283,9 @@ __global__ __launch_bounds__(256) void neg_scatter_kernel(int B, int K, int n_it
 }
 
 // ---- dattout = sum of the split-K slabs [+ negative part], times act'(attout), plus the bias gradients -----------
-// One pass instead of four launches (slab reduce, negative term, two activation backward passes): tile = 32 rows x 64
-// columns, thread = (float4 column group, row phase); the slab loads of a row are all issued before the first add.
+// One pass instead of four launches (slab reduce, negative term, two activation backward passes): tile = 16 rows x 64
+// columns (416 workgroups at B = 512, ek = 832), thread = (float4 column group, row); twelve slab loads are in flight per
+// thread before the first add (the pass is a 61-MB read at the Globo shape: 36 slabs of [512, 832]).
 __global__ __launch_bounds__(256) void reduce_dact_kernel(const float* __restrict__ slabs, int S, int M, int N, long ld,
                                                           const float* __restrict__ addend, long ld_add, int n_add,
                                                           const float* __restrict__ y, long ldy, int act,
@@ -293,22 +294,21 @@ __global__ __launch_bounds__(256) void reduce_dact_kernel(const float* __restric
   __shared__ float4 sh[256];
   const int tid = threadIdx.x, cg = tid & 15, rp = tid >> 4;
   const int col = blockIdx.x * 64 + cg * 4;
-  const int r0 = blockIdx.y * 32;
+  const int r0 = blockIdx.y * 16;
   float4 cs = zero4();
   if (col < N) {
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int row = r0 + rp + 16 * rr;
-      if (row >= M) continue;
+    {
+      const int row = r0 + rp;
+      if (row < M) {
       float4 acc = (addend && col < n_add) ? ld4(addend + (long)row * ld_add + col) : zero4();
       const float* sp = slabs + (long)row * ld + col;
       int k = 0;
-      for (; k + 6 <= S; k += 6) {
-        float4 t[6];
+      for (; k + 12 <= S; k += 12) {
+        float4 t[12];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) t[j] = ld4(sp + (long)(k + j) * M * ld);
+        for (int j = 0; j < 12; ++j) t[j] = ld4(sp + (long)(k + j) * M * ld);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) acc = add4(acc, t[j]);
+        for (int j = 0; j < 12; ++j) acc = add4(acc, t[j]);
       }
       for (; k < S; ++k) acc = add4(acc, ld4(sp + (long)k * M * ld));
       if (act) {
@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void reduce_dact_kernel(const float* __restric
       }
       st4(out + (long)row * ld + col, acc);
       cs = add4(cs, acc);
+      }
     }
   }
   sh[tid] = cs;
@@ -663,7 +664,7 @@ extern "C" int tcar_splitk_reduce_dact(const float* slabs, int splitk, int M, in
   if ((N & 3) || (ld & 3) || !tcar_aligned16(slabs) || !tcar_aligned16(out) || splitk < 1 || (act && (!y || (ldy & 3))) ||
       (addend && ((ld_add & 3) || (n_add & 3) || !tcar_aligned16(addend))))
     return TCAR_E_ARG;
-  TCAR_LAUNCH(reduce_dact_kernel, dim3((N + 63) / 64, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, N,
+  TCAR_LAUNCH(reduce_dact_kernel, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, N,
               (long)ld, addend, (long)ld_add, n_add, y, (long)ldy, act, out, bias_grad0, split_col, bias_grad1);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;

@@ -11,9 +11,10 @@ static int env_int(const char* name, int dflt) {
 }
 static TcarTuning& tuning_storage() {
   static TcarTuning t = {env_int("TCAR_BF16_TILE", 0), env_int("TCAR_DX512", 1), env_int("TCAR_X3_XK", 0),
-                         env_int("TCAR_X3_RING", 3), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
+                         env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
-                         env_int("TCAR_GATHER_WG", 2), env_int("TCAR_SORT_SCATTER", 1)};
+                         env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
+                         env_int("TCAR_SORT_SCATTER", 1)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -28,6 +29,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_REST_GRID", &t.rest_grid}, {"TCAR_SOFTMAX_VARIANT", &t.softmax_variant},
                                               {"TCAR_WGRAD_KS", &t.wgrad_ks}, {"TCAR_TILE288", &t.tile288},
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
+                                              {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_SORT_SCATTER", &t.sort_scatter}};
   for (auto& e : tab) {
     bool same = true;
@@ -174,6 +176,14 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->attout, g.ek, W(c, TCAR_V_O_B), 2);
     p[1] = prob1(B, g.pt, c->pooled + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->attout + g.ic, g.ek,
                  W(c, TCAR_V_OT_B), 2);
+    if (c->scoring && tcar_tuning().planes_epi) {
+      // split-bf16 scoring: the epilogue also writes attout's hi / lo planes (operand of the logits GEMM) and the packed
+      // item | time planes (operand of dE) — tcar_split_bf16 without its own launch
+      for (int i = 0; i < 2; ++i) {
+        p[i].plane_hi = c->a16h; p[i].plane_lo = c->a16l; p[i].plane_inner = g.ek; p[i].plane_col0 = i ? g.ic : 0;
+        p[i].pack_hi = c->ap16h; p[i].pack_lo = c->ap16l; p[i].pack_inner = g.ldh + g.pt; p[i].pack_c0 = g.ldh; p[i].pack_c1 = g.ic;
+      }
+    }
     RET(small_gemm(c, 0, 2, p, stream));
   }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
@@ -188,9 +198,11 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   };
   int rc;
   if (c->scoring) {
-    // split-bf16 path: attout -> hi/lo planes (+ the packed item|time operand of dE), then the bf16 MFMA GEMM
-    rc = tcar_split_bf16(c->attout, g.ek, B, g.ek, c->a16h, c->a16l, g.ek, c->ap16h, c->ap16l, g.ldh + g.pt, g.ldh, g.ic,
-                         stream);
+    // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue (TCAR_PLANES_EPI=0: by
+    // their own launch)
+    rc = tcar_tuning().planes_epi ? TCAR_OK
+                                  : tcar_split_bf16(c->attout, g.ek, B, g.ek, c->a16h, c->a16l, g.ek, c->ap16h, c->ap16l,
+                                                    g.ldh + g.pt, g.ldh, g.ic, stream);
     start_timer();
     if (!rc)
       rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
@@ -226,7 +238,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // chain B runs on the aux stream in the fused single-rank step; in the rank-local backward of the data-parallel step
   // it runs FIRST on the main stream, so that dE is complete early and its all-reduce overlaps chain A (dp.py)
   void* sB = (s2 && fuse_finish) ? (void*)s2 : stream;
-  void* sW = s2 ? (void*)s2 : stream;          // the weight-gradient GEMM
+  void* sW = s2 ? (void*)s2 : stream;          // the weight-gradient GEMM (third stream below, when there is one)
   const bool has_neg = K > 0 && bt->neg && c->neg_coef && c->negpart;
   // zero the gradient arena and the norm slots; with an aux stream this happens beside the softmax, not before it
   // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
@@ -300,19 +312,41 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->dpooled + g.ic, g.ek);
     RET(small_gemm(c, 1, 2, p, stream));
   }
-  RET(tcar_attn_pool_bwd(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
-                         W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
-                         G(c, TCAR_V_M_WRES), G(c, TCAR_V_S_WRES), stream));
-  // query MLP backward (modules.py:138-139)
-  RET(tcar_dact_colsum(B, g.ic, g.ic, c->q, c->dq, G(c, TCAR_V_Q2_B), 2, stream));
-  {
-    tcar_gemm_desc_t p = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
-    RET(small_gemm(c, 1, 1, &p, stream));
+  // query MLP backward (modules.py:138-139).  Split-bf16 modes: tanh' + bias gradient of query_trans2 ride in the pool
+  // backward, relu' + bias gradient of query_trans1 in the epilogue of the GEMM that produces dq1, and that GEMM shares ONE
+  // launch with the three input-gradient GEMMs of the projections (all four need only the pool backward's outputs); the
+  // click-query input gradient (needs dq1) follows.  fp32 mode: the op-level sequence.
+  const bool fusedq = c->scoring != 0 && tcar_tuning().fused_q;
+  RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
+                           W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
+                           G(c, TCAR_V_M_WRES), G(c, TCAR_V_S_WRES), fusedq ? G(c, TCAR_V_Q2_B) : nullptr, stream));
+  if (fusedq) {
+    tcar_gemm_desc_t p[4];
+    p[0] = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
+    p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = G(c, TCAR_V_Q1_B);
+    // input gradients (only the ITEM half of dX_ic: content is frozen)
+    p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
+    p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
+    p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
+    RET(small_gemm(c, 1, 4, p, stream));
+  } else {
+    RET(tcar_dact_colsum(B, g.ic, g.ic, c->q, c->dq, G(c, TCAR_V_Q2_B), 2, stream));
+    {
+      tcar_gemm_desc_t p = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
+      RET(small_gemm(c, 1, 1, &p, stream));
+    }
+    RET(tcar_dact_colsum(B, g.ldh, g.ldh, c->q1, c->dq1, G(c, TCAR_V_Q1_B), 1, stream));
   }
-  RET(tcar_dact_colsum(B, g.ldh, g.ldh, c->q1, c->dq1, G(c, TCAR_V_Q1_B), 1, stream));
-  // Everything the weight gradients need exists now; they run on the aux stream (behind chain B) while the main stream
-  // continues with the input gradients and the row scatter.
-  if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+  // Everything the weight gradients need exists now; they run beside the main stream's input gradients and row scatter:
+  // on the third stream when the context has one (fused step: the aux stream is still busy with the candidate-time
+  // backward, which only became ready when dE finished), else on the aux stream behind chain B.
+  hipStream_t s3 = (s2 && fuse_finish && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
+  if (s3) {
+    sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
+    if (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s3, (hipEvent_t)c->ev[0], 0) != hipSuccess ||
+        hipStreamWaitEvent(s3, (hipEvent_t)c->ev[1], 0) != hipSuccess)
+      return TCAR_E_LAUNCH;
+  } else if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
     const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 512;
@@ -334,8 +368,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
   if (fuse_finish && s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, sW));
+  if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
-  {  // input gradients (only the ITEM half of dX_ic: content is frozen)
+  if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
+    tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+    RET(small_gemm(c, 1, 1, &p, stream));
+  } else {  // input gradients (only the ITEM half of dX_ic: content is frozen)
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
@@ -360,7 +398,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     grads_of(c, gr);
     RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
   }
-  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // weight gradients are in
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
+  if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
   if (fuse_finish && !s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
   return TCAR_OK;
 }

@@ -60,6 +60,8 @@ struct TcarTuning {
   int tile288;          // TCAR_TILE288        0 disables the 256 x 288 tile of the dX / dE GEMMs
   int gather_big_rows;  // TCAR_GATHER_BIG_ROWS  session rows from which the forward gather runs its throughput form
   int gather_wg_per_cu; // TCAR_GATHER_WG      1024-thread workgroups per CU of that form (2 x 78 KB of LDS fit)
+  int fused_q;          // TCAR_FUSED_Q        0: query-MLP backward as separate activation-backward launches
+  int planes_epi;       // TCAR_PLANES_EPI     0: attout's bf16 planes by tcar_split_bf16 instead of the GEMM epilogue
   int sort_scatter;     // TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum
 };
 const TcarTuning& tcar_tuning();

@@ -747,6 +747,13 @@ class TcarEngine:
             c.stream2 = self._aux.cuda_stream
             for i, e in enumerate(self._aux_ev):
                 c.ev[i] = e.cuda_event
+            if not os.environ.get("TCAR_NO_STREAM3"):
+                if not hasattr(self, "_aux3"):
+                    self._aux3 = torch.cuda.Stream(self.dev)
+                    self._aux3_ev = torch.cuda.Event()
+                    self._aux3_ev.record(torch.cuda.current_stream(self.dev))
+                c.stream3 = self._aux3.cuda_stream
+                c.ev3 = self._aux3_ev.cuda_event
         if self._ev is not None:
             c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
             c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)

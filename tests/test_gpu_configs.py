@@ -78,6 +78,39 @@ def test_step_parity_with_reference_negative_modes(name, scoring):
     params = initial_variables(n_items, H, Ht, 0.25, 0.1, weight_seed=5)      # norms > 1 on many rows: the clip is active
     eng = TcarEngine(params, fold.content, fold.mwdhm, lr=2e-3, scoring=scoring)
     ora = TcarOracle(params, fold.content, fold.mwdhm, lr=2e-3)
+    # evaluation of a test batch at the initial variables: per-session logits, CE and ranks (north star: 1e-3 relative)
+    te = fold.test
+    idx = np.where(te.in_len == 2)[0][:64]
+    tb = te.batch_arrays(idx, "active_t")
+
+    def check_eval(tight):
+        rank, topk, ce, logits = eng.eval_step(tb, keep_logits=True)
+        lo, ce_o = ora.eval_batch(tb)
+        if tight:
+            close(logits.cpu().numpy(), lo.numpy(), name="logits", atol_scale=1e-4)
+            close(ce.cpu().numpy(), ce_o.numpy(), name="ce")
+        else:
+            # after Adam steps a few ill-conditioned coordinates have moved by +-lr per step on either side (see below):
+            # the scores agree norm-wise and the batch loss at the gate
+            d = logits.cpu().numpy().astype(np.float64) - lo.numpy()
+            assert np.sqrt((d * d).mean()) <= 2e-3 * np.sqrt((lo.numpy() ** 2).mean()), "logits after training"
+            assert abs(float(ce.mean()) - float(ce_o.mean())) <= 1e-3 * float(ce_o.mean())
+        lab = torch.as_tensor(tb["label"], dtype=torch.long)
+        want_rank = ((lo > lo.gather(1, lab[:, None])).sum(1) + 1).numpy()
+        r = rank.cpu().numpy()
+        # ranks can differ where two scores are within rounding of each other: allow near ties, nothing else
+        off = np.nonzero(r != want_rank)[0]
+        tol = 1e-3 if tight else 5e-3
+        for i in off:
+            row = lo[i].numpy()
+            gap = np.abs(row - row[tb["label"][i]])
+            assert abs(int(r[i]) - int(want_rank[i])) <= int((gap < tol * max(1e-6, np.abs(row).max())).sum()), (i, r[i], want_rank[i])
+        if tight:
+            assert len(off) <= max(3, len(r) // 8)
+        hr_e, hr_o = float((r <= 20).mean()), float((want_rank <= 20).mean())
+        assert abs(hr_e - hr_o) <= 0.002 + 1.0 / len(r)
+
+    check_eval(tight=True)
     # first batch: loss, every gradient, clip norms
     loss = eng.loss_and_grads(batches[0])
     o, g_o, sq_o = ora.loss_and_grads(batches[0])
@@ -92,7 +125,7 @@ def test_step_parity_with_reference_negative_modes(name, scoring):
         scale = max(5e-5, 1e-7 * gmax / max(1e-30, float(np.abs(want).max())))
         close(g_e[k], want, name="grad " + k, atol_scale=scale)
         assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12 * gmax * gmax * want.size, ("sqnorm", k, sq_e[k], sq_o[k])
-    # training steps over all four batches, then evaluation of a test batch
+    # training steps over all four batches
     for b in batches:
         close(eng.train_step(b).cpu().numpy(), ora.train_step(b).numpy(), name="train loss")
     # Variables after the four Adam steps.  Adam normalises by sqrt(v): a coordinate whose gradient sits at rounding level
@@ -107,23 +140,7 @@ def test_step_parity_with_reference_negative_modes(name, scoring):
         if k == "item_emb" or k.startswith("attout_"):      # well-conditioned gradients (the scoring side)
             assert bad.sum() <= max(8, 2e-3 * bad.size), ("param", k, int(bad.sum()), bad.size)
         assert err.max() <= 2.2 * lr * steps, ("param", k, float(err.max()))
-    te = fold.test
-    idx = np.where(te.in_len == 2)[0][:64]
-    tb = te.batch_arrays(idx, "active_t")
-    rank, topk, ce, logits = eng.eval_step(tb, keep_logits=True)
-    lo, ce_o = ora.eval_batch(tb)
-    close(logits.cpu().numpy(), lo.numpy(), name="logits", atol_scale=1e-4)
-    close(ce.cpu().numpy(), ce_o.numpy(), name="ce")
-    lab = torch.as_tensor(tb["label"], dtype=torch.long)
-    want_rank = ((lo > lo.gather(1, lab[:, None])).sum(1) + 1).numpy()
-    r = rank.cpu().numpy()
-    # ranks can differ where two scores are within rounding of each other: allow a few near ties, nothing else
-    off = np.nonzero(r != want_rank)[0]
-    for i in off:
-        row = lo[i].numpy()
-        gap = np.abs(row - row[tb["label"][i]])
-        assert abs(int(r[i]) - int(want_rank[i])) <= int((gap < 1e-3 * max(1e-6, np.abs(row).max())).sum()), (i, r[i], want_rank[i])
-    assert len(off) <= max(3, len(r) // 8)
+    check_eval(tight=False)
 
 
 def _host_mem_available_gb():
