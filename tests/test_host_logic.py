@@ -182,3 +182,14 @@ def test_category_table_accepts_any_label_type_and_missing_items():
     assert ints[0] == ints[1]
     ild = M.ild_batch(np.array([[0, 1, 2]]), cat)
     assert abs(float(ild[0]) - 4.0 / 6.0) < 1e-12          # pairs (0,1),(1,0),(1,2),(2,1) differ
+
+
+def test_torch_ops_are_registered_without_a_gpu():
+    """torch.ops.tcar.* (SURVEY.md 8(b) op-level boundary) register at import, with schemas; only a CUDA kernel exists."""
+    import torch
+    from tcar_amd import torch_ops
+    for name in torch_ops.OPS:
+        op = getattr(torch.ops.tcar, name)
+        assert "Tensor" in str(op.default._schema)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.tcar.rank_topk(torch.zeros(2, 8), torch.zeros(2, dtype=torch.int32), 8, 3)     # CPU tensors: no fallback
