@@ -357,6 +357,33 @@ int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, f
                         float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap,
                         void* stream);
 
+/* ---- device-side batch formation and negative sampling (sampler.py:52-113,118-140) ---------------------------------
+ * The tensorised session store (CSR over clicks, per-click uint8 features; host/data.py SessionStore) and the negative
+ * source (CSR of neighbor_dict / the impression lists) stay resident in HBM; one call writes the packed int32 feed
+ *   seq[B,T] | month | day | week | hour+1 | minute+1 [B,T] | dwell bucket [B,T] | click week [B] | click hour [B] |
+ *   label [B] | negatives [B,K]
+ * of the batch whose example indices are idx[B] (all of input length T).  Negatives follow the reference's rules with a
+ * counter-based generator keyed by (seed, counter, example index): same key, same negatives. */
+typedef struct {
+  const int64_t* off;          /* [n_examples + 1] CSR offsets into the per-click arrays */
+  const int32_t* items;        /* [clicks] 1-based item ids; the last click of an example is its label */
+  const uint8_t* pub;          /* [clicks, 5] publish month, day, isoweekday, hour+1, minute+1        sampler.py:81-85 */
+  const uint8_t* clk;          /* [clicks, 5] click month-1, day-1, isoweekday-1, hour, minute          sampler.py:105-109 */
+  const uint8_t* gap_active;   /* [clicks] bucketized(active_t)                                         sampler.py:87 */
+  const uint8_t* gap_delta;    /* [clicks] bucketized(seconds to the next click)                        sampler.py:91-94 */
+  int64_t n_examples;
+} tcar_store_t;
+typedef struct {
+  int32_t mode;                /* 0 uniform (sampler.py:98-99), 1 neighbour (:133-140), 2 impression (:118-131) */
+  const int64_t* off;          /* [n_lists + 1]: neighbour mode: list of 0-based item i; impression mode: list of slot s */
+  const int32_t* flat;         /* candidates: 0-based item ids; impression mode: -1 = article outside the catalog */
+  const int32_t* slot_of_example;   /* impression mode: [n_examples] example -> list slot */
+  int64_t n_lists;
+} tcar_negsrc_t;
+/* gap_mode: 0 = active_t buckets (sampler.py:87), 1 = click-delta buckets (sampler.py:91-94).  src == NULL: uniform. */
+int tcar_form_batch(const tcar_dims_t* d, const tcar_store_t* st, const tcar_negsrc_t* src, const int32_t* idx, int B, int T,
+                    int K, int gap_mode, uint64_t seed, uint64_t counter, int32_t* feed, void* stream);
+
 /* Diagnostic hook (tests, profiling tools): override one of the TCAR_* tuning switches at run time (they are otherwise read
  * from the environment once per process).  Returns the previous value, INT_MIN for an unknown name.  Not for product code. */
 int tcar_set_tuning(const char* name /*host*/, int value);

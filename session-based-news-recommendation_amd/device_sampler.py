@@ -1,0 +1,163 @@
+"""HBM-resident session store + negative sources, and batch formation on the device (csrc/sampler.hip, tcar_form_batch).
+
+The host keeps what `Sampler.__init__` does (sampler.py:40-49: shuffle every length bucket, cut it into batches, shuffle the
+batches — the reference's use of the `random` stream, so batch composition is unchanged); the per-click loop of
+`next_batch` (sampler.py:67-111) and the negative draws (sampler.py:95-99,118-140) run in one kernel launch per batch from
+arrays that were uploaded once:
+
+  store      CSR over clicks + per-click uint8 features (host/data.py SessionStore)
+  negatives  "uniform":    nothing to upload
+             "neighbor":   CSR over the 0-based item id of `neighbor_dict` (generate_neighbor.py:7-21: the +-100 items
+                           adjacent in publish-time order)
+             "impression": CSR over the session ids of `neighbor_dict` (mind_preprocess.py:62-69,85), candidates mapped
+                           through item_dict to 0-based ids (-1 = not a catalog item, sampler.py:124), plus example -> list
+
+Only the example indices of a batch (4 B per session) cross PCIe.  The negatives follow the reference's rules with a
+counter-based generator (rule equivalence is tested in tests/test_gpu_sampler.py; draw-for-draw replay of Python's
+generators is what the host sampler is for).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Batch, NegSrc, Store, check
+from .host.data import SessionStore
+
+NEG_MODES = {"uniform": 0, "neighbor": 1, "impression": 2}
+
+
+def neighbor_csr(neighbor_dict: Dict[int, list], n_items: int):
+    """CSR over 0-based item ids; an item without a list gets an empty one (the kernel then falls back to uniform draws)."""
+    lens = np.zeros(n_items, dtype=np.int64)
+    for k, v in neighbor_dict.items():
+        if 0 <= int(k) < n_items:
+            lens[int(k)] = len(v)
+    off = np.zeros(n_items + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    flat = np.empty(int(off[-1]), dtype=np.int32)
+    for k, v in neighbor_dict.items():
+        k = int(k)
+        if 0 <= k < n_items:
+            flat[off[k]:off[k + 1]] = v
+    return off, flat
+
+
+def impression_csr(neighbor_dict: Dict[int, list], item_dict: Dict[int, int], store: SessionStore):
+    """CSR over the session ids that own an impression list; candidates as 0-based item ids, -1 when the article is not in
+    item_dict (sampler.py:124); slot_of_example maps an example to its session's list."""
+    if store.impression_key is None:
+        raise ValueError("impression negatives need the session id of every example (SessionStore.impression_key)")
+    keys = list(neighbor_dict.keys())
+    slot = {int(k): i for i, k in enumerate(keys)}
+    lens = np.fromiter((len(neighbor_dict[k]) for k in keys), dtype=np.int64, count=len(keys))
+    off = np.zeros(len(keys) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    flat = np.empty(int(off[-1]), dtype=np.int32)
+    for i, k in enumerate(keys):
+        flat[off[i]:off[i + 1]] = [item_dict.get(x, 0) - 1 for x in neighbor_dict[k]]
+    try:
+        soe = np.fromiter((slot[int(s)] for s in store.impression_key), dtype=np.int32, count=store.n)
+    except KeyError as e:
+        raise KeyError("session %s has no impression list" % e)
+    return off, flat, soe
+
+
+class DeviceSampler:
+    def __init__(self, engine, store: SessionStore, neg_mode: str = "uniform", neighbor_dict: Optional[dict] = None,
+                 item_dict: Optional[dict] = None, seed: int = 2020):
+        if neg_mode not in NEG_MODES:
+            raise ValueError("neg_mode must be uniform | neighbor | impression")
+        self.eng, self.store, self.neg_mode = engine, store, neg_mode
+        self.lib, self.dev = engine.lib, engine.dev
+        self.seed, self.counter = int(seed) & ((1 << 64) - 1), 0
+        up = lambda a, dt: torch.tensor(np.ascontiguousarray(a, dtype=dt), device=self.dev)
+        self.t_off, self.t_items = up(store.off, np.int64), up(store.items, np.int32)
+        self.t_pub, self.t_clk = up(store.pub, np.uint8), up(store.clk, np.uint8)
+        self.t_ga, self.t_gd = up(store.gap_active, np.uint8), up(store.gap_delta, np.uint8)
+        self.in_len = store.in_len
+        st = Store()
+        st.off, st.items, st.pub, st.clk = (t.data_ptr() for t in (self.t_off, self.t_items, self.t_pub, self.t_clk))
+        st.gap_active, st.gap_delta, st.n_examples = self.t_ga.data_ptr(), self.t_gd.data_ptr(), store.n
+        self.c_store = st
+        src = NegSrc()
+        src.mode = NEG_MODES[neg_mode]
+        if neg_mode == "neighbor":
+            off, flat = neighbor_csr(neighbor_dict, engine.geo.N)
+            self.t_noff, self.t_nflat = up(off, np.int64), up(flat, np.int32)
+            src.off, src.flat, src.n_lists = self.t_noff.data_ptr(), self.t_nflat.data_ptr(), engine.geo.N
+        elif neg_mode == "impression":
+            off, flat, soe = impression_csr(neighbor_dict, item_dict, store)
+            self.t_noff, self.t_nflat, self.t_soe = up(off, np.int64), up(flat, np.int32), up(soe, np.int32)
+            src.off, src.flat, src.slot_of_example = self.t_noff.data_ptr(), self.t_nflat.data_ptr(), self.t_soe.data_ptr()
+            src.n_lists = len(off) - 1
+        self.c_src = src
+        self.feed = None
+        self.pin = None
+
+    def bytes_resident(self) -> int:
+        return sum(t.numel() * t.element_size() for t in vars(self).values() if torch.is_tensor(t))
+
+    def form(self, idx: np.ndarray, K: int, gap_mode: str = "active_t", counter: Optional[int] = None) -> Batch:
+        """Feed of the batch whose examples are `idx` (all of one input length), formed on the device; returns the C batch
+        descriptor for TcarEngine.train_step / eval_step (bt=...).  K = 0: no negatives (evaluation)."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        B = int(idx.shape[0])
+        T = int(self.in_len[idx[0]])
+        if T > 40:
+            raise IndexError("session longer than the 40-row position table (model_combine.py:57)")
+        need = 7 * B * T + 3 * B + B * K
+        if self.feed is None or self.feed.numel() < need or self.idx_dev.numel() < B:
+            n = max(need, 1 << 16)
+            self.feed = torch.empty(n, dtype=torch.int32, device=self.dev)
+            nb = max(B, 4096)
+            self.idx_dev = torch.empty(nb, dtype=torch.int32, device=self.dev)
+            self.pin = [torch.empty(nb, dtype=torch.int32).pin_memory() for _ in range(2)]
+            self.pin_evt = [torch.cuda.Event(), torch.cuda.Event()]
+            self.pin_used, self.pin_i = [False, False], 0
+        i = self.pin_i = self.pin_i ^ 1
+        if self.pin_used[i]:
+            self.pin_evt[i].synchronize()
+        self.pin[i][:B].copy_(torch.from_numpy(idx))
+        st = torch.cuda.current_stream(self.dev)
+        self.idx_dev[:B].copy_(self.pin[i][:B], non_blocking=True)
+        self.pin_evt[i].record(st)
+        self.pin_used[i] = True
+        if counter is None:
+            counter = self.counter
+            self.counter += 1
+        check(self.lib.tcar_form_batch(C.byref(self.eng.dims), C.byref(self.c_store), C.byref(self.c_src),
+                                       C.c_void_p(self.idx_dev.data_ptr()), B, T, K, 1 if gap_mode == "click_delta" else 0,
+                                       C.c_uint64(self.seed), C.c_uint64(int(counter)), C.c_void_p(self.feed.data_ptr()),
+                                       C.c_void_p(st.cuda_stream)), "tcar_form_batch")
+        base = self.feed.data_ptr()
+        bt = Batch()
+        bt.B, bt.T, bt.K = B, T, K
+        n = B * T
+        bt.seq = base
+        for k in range(5):
+            bt.pub[k] = base + 4 * (k + 1) * n
+        bt.gap = base + 4 * 6 * n
+        bt.cw = base + 4 * 7 * n
+        bt.ch = base + 4 * (7 * n + B)
+        bt.label = base + 4 * (7 * n + 2 * B)
+        bt.neg = (base + 4 * (7 * n + 3 * B)) if K else None
+        bt._seq_t = self.feed[:n]
+        bt._keep = self.feed
+        return bt
+
+    def read_back(self, bt: Batch) -> Dict[str, np.ndarray]:
+        """The feed of `bt` as the host arrays of SessionStore.batch_arrays (+ "neg"): tests / debugging."""
+        B, T, K = bt.B, bt.T, bt.K
+        n = B * T
+        f = self.feed[:7 * n + 3 * B + B * K].cpu().numpy()
+        out = {"seq": f[:n].reshape(B, T)}
+        for j, name in enumerate(("pm", "pd", "pw", "ph", "pmi", "gap")):
+            out[name] = f[(j + 1) * n:(j + 2) * n].reshape(B, T)
+        out["cw"], out["ch"], out["label"] = f[7 * n:7 * n + B], f[7 * n + B:7 * n + 2 * B], f[7 * n + 2 * B:7 * n + 3 * B]
+        out["neg"] = f[7 * n + 3 * B:].reshape(B, K) if K else None
+        return out

@@ -56,6 +56,8 @@ def build_parser() -> argparse.ArgumentParser:
     # call-site toggles the reference leaves as comments (sampler.py:87-99)
     ap.add_argument("--gap_mode", default="active_t", choices=["active_t", "click_delta"])
     ap.add_argument("--neg_mode", default="uniform", choices=["uniform", "neighbor", "impression"])
+    ap.add_argument("--device_sampler", default=0, type=int,
+                    help="1: training batches are formed and their negatives drawn ON THE GPU from the HBM-resident session store")
     ap.add_argument("--neg_fast", default=0, type=int,
                     help="1: vectorised neighbour / impression negatives (same rules, not the reference's random.choice order)")
     # MI355X

@@ -130,6 +130,9 @@ class Seq2SeqAttNN():
         self.gap_mode = args.get('gap_mode', 'active_t')
         self.neg_mode = args.get('neg_mode', 'uniform')
         self.neg_fast = bool(args.get('neg_fast', 0))
+        self.device_sampler = bool(args.get('device_sampler', 0))   # form batches + draw negatives on the GPU
+        self.seed = int(args.get('seed', 2020))
+        self._ds_cache = {}
         self.curEpoch = 0
         self.error_during_train = False
         if content.shape[1] != self.hidden_size:
@@ -189,6 +192,28 @@ class Seq2SeqAttNN():
         return Sampler(len_d, sess_d, time_d, neighbor_dict, item_dict, neg_num, batch_size=self.batch_size,
                        gap_mode=self.gap_mode, neg_mode=self.neg_mode, store=store, neg_fast=self.neg_fast)
 
+    def _device_batches(self, data, sampler, neighbor_dict, item_dict, K):
+        """Iterate C batch descriptors formed ON THE DEVICE (device_sampler.DeviceSampler): the host sampler has only done
+        the bucketed shuffle (sampler.py:40-49); each batch costs one H2D copy of its example indices."""
+        from ..device_sampler import DeviceSampler
+        store = sampler.store
+        mode = self.neg_mode if (neighbor_dict and K) else "uniform"
+        key = (id(store), mode)
+        ds = self._ds_cache.get(key)
+        if ds is None:
+            ds = self._ds_cache[key] = DeviceSampler(self.engine, store, mode, neighbor_dict if mode != "uniform" else None,
+                                                     item_dict, seed=self.seed)
+        k = K if (neighbor_dict and K) else 0
+        for i in range(sampler.batch_num):
+            idx = sampler.batch_indices(i)
+            if self.dp_world > 1:
+                from ..dp import shard_bounds
+                lo, hi, cap = shard_bounds(len(idx), self.dp_world, self.dp_rank)
+                T = int(store.in_len[idx[0]])
+                yield (ds.form(idx[lo:hi], k, self.gap_mode) if hi > lo else None), cap * T, idx[lo:hi]
+            else:
+                yield ds.form(idx, k, self.gap_mode), None, idx
+
     def _shard(self, feed):
         """this rank's contiguous shard of a batch (dp.shard_bounds) -> (sub-feed or None when empty, rows capacity / T)"""
         if self.dp_world == 1:
@@ -220,7 +245,16 @@ class Seq2SeqAttNN():
             total = torch.zeros((), dtype=torch.float64, device=eng.dev)
             count = 0
             t0 = time.time()
-            for feed in prefetch_batches(sampler):
+            if self.device_sampler:
+                for bt, cap_rows, _idx in self._device_batches(train_data, sampler, neighbor_dict, item_dict, args['neg_num']):
+                    batch += 1
+                    if self.dp_world > 1:
+                        crt_loss = eng.train_step(None, bt=bt, cap_rows=cap_rows)
+                    else:
+                        crt_loss = eng.train_step(None, bt=bt)
+                    total += crt_loss.double().sum()
+                    count += crt_loss.numel()
+            for feed in (() if self.device_sampler else prefetch_batches(sampler)):
                 batch += 1
                 if batch < 3 and feed["neg"] is not None:
                     print(feed["neg"][0][:10].tolist())

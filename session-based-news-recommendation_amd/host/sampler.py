@@ -199,15 +199,20 @@ class Sampler(object):
         return neg
 
     # -------------------------------------------------------------------- batches
+    def batch_indices(self, i: int) -> np.ndarray:
+        """store row indices of the examples of batch i (the device sampler forms the batch from these alone)"""
+        keys = self.session_id_batches[i]
+        st = self.store
+        if st.key_index is not None and not isinstance(keys[0], (int, np.integer)):
+            return np.fromiter((st.key_index[k] for k in keys), dtype=np.int64, count=len(keys))
+        if st.key_index is not None and keys[0] in st.key_index:
+            return np.fromiter((st.key_index[k] for k in keys), dtype=np.int64, count=len(keys))
+        return np.asarray(keys, dtype=np.int64)              # store-native integer example ids
+
     def next_batch_arrays(self) -> Dict[str, np.ndarray]:
         keys = self.session_id_batches[self.batch_i]
         st = self.store
-        if st.key_index is not None and not isinstance(keys[0], (int, np.integer)):
-            idx = np.fromiter((st.key_index[k] for k in keys), dtype=np.int64, count=len(keys))
-        elif st.key_index is not None and keys[0] in st.key_index:
-            idx = np.fromiter((st.key_index[k] for k in keys), dtype=np.int64, count=len(keys))
-        else:
-            idx = np.asarray(keys, dtype=np.int64)          # store-native integer example ids
+        idx = self.batch_indices(self.batch_i)
         arr = st.batch_arrays(idx, self.gap_mode)
         arr["neg"] = self._negatives(keys, arr["label"], idx)
         arr["keys"] = keys

@@ -253,7 +253,10 @@ def score_ce_bwd(dlogits: Tensor, attout: Tensor, E: Tensor) -> Tuple[Tensor, Te
     N, npad = E.shape[0], dlogits.shape[1]
     dattout, dE = torch.empty_like(attout), torch.empty_like(E)
     st = _st(attout)
-    check(_lib_().tcar_gemm_f32(0, B, ek, N, _p(dlogits), npad, _p(E), ek, _p(dattout), ek, None, 0, 0, 1, st), "tcar_gemm_f32")
+    # the catalog-long contraction runs over ceil4(N) (the k-contiguous operand needs K % 4 == 0): the pad columns of dlogits
+    # are zero (tcar_softmax_ce) and E is given zero rows to match
+    Ek = E if npad == N else torch.cat([E, E.new_zeros(npad - N, ek)])
+    check(_lib_().tcar_gemm_f32(0, B, ek, npad, _p(dlogits), npad, _p(Ek), ek, _p(dattout), ek, None, 0, 0, 1, st), "tcar_gemm_f32")
     check(_lib_().tcar_gemm_f32(2, N, ek, B, _p(dlogits), npad, _p(attout), ek, _p(dE), ek, None, 0, 0, 1, st), "tcar_gemm_f32")
     return dattout, dE
 

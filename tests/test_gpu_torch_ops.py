@@ -125,8 +125,11 @@ def test_attn_pool_op(B, T):
     wgt = torch.tensor(rng.standard_normal(tuple(want.shape)), dtype=torch.float64)
     (pooled.double() * wgt.to(DEV)).sum().backward()
     (want * wgt).sum().backward()
+    gmax = max(float(b.grad.abs().max()) for b in d64)
     for name, a, b in zip(("x_icp", "x_pt", "pre1", "pre2", "q", "w1", "w2"), dev, d64):
-        close(a.grad, b.grad, name="d " + name, atol_scale=1e-4)
+        # T = 1: alpha = e / (e + 1e-9) ~ 1 whatever the scores, so the score-side gradients are zero up to fp32 rounding
+        floor = 1e-7 * gmax / max(1e-30, float(b.grad.abs().max()))
+        close(a.grad, b.grad, name="d " + name, atol_scale=max(1e-4, floor))
 
 
 def test_score_ce_and_score_rank_ops():
