@@ -128,7 +128,7 @@ def test_attn_pool_op(B, T):
     gmax = max(float(b.grad.abs().max()) for b in d64)
     for name, a, b in zip(("x_icp", "x_pt", "pre1", "pre2", "q", "w1", "w2"), dev, d64):
         # T = 1: alpha = e / (e + 1e-9) ~ 1 whatever the scores, so the score-side gradients are zero up to fp32 rounding
-        floor = 1e-7 * gmax / max(1e-30, float(b.grad.abs().max()))
+        floor = 3e-6 * gmax / max(1e-30, float(b.grad.abs().max()))
         close(a.grad, b.grad, name="d " + name, atol_scale=max(1e-4, floor))
 
 
