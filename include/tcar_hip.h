@@ -343,6 +343,14 @@ int tcar_mha_core_bwd(int N, int Tq, int Tk, int C, int heads, int causal, const
                       const float* P, const float* key_mask, const float* query_mask, const float* dO, float* dQ, float* dK,
                       float* dV, void* stream);
 
+/* ---- optional op, NOT on TCAR's executed graph: `normalize` of modules.py:194-218 (layer normalisation over the last axis):
+ * y = gamma * (x - mean) / sqrt(var + eps) + beta with the biased variance of tf.nn.moments; stats [M, 2] = (mean, 1/std) is
+ * saved for the backward pass, which returns dx and ADDS the column sums into caller-zeroed dgamma / dbeta (atomics). */
+int tcar_layernorm_fwd(int64_t M, int C, const float* x, const float* gamma, const float* beta, float eps, float* y,
+                       float* stats, void* stream);
+int tcar_layernorm_bwd(int64_t M, int C, const float* x, const float* gamma, const float* stats, const float* dy, float* dx,
+                       float* dgamma, float* dbeta, void* stream);
+
 /* Split update.  tcar_clip_adam_early: tcar_clip_adam over the arena segments plus the item rows listed in `ids` (1-based
  * item ids, repeats allowed: a bit per row in `bitmap` — zero on entry — makes every row update exactly once);
  * tcar_clip_adam_rest: every item row whose bit is clear, then clears the bitmap.  Together they equal

@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_SORT_SCATTER", 1)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -30,6 +30,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_WGRAD_KS", &t.wgrad_ks}, {"TCAR_TILE288", &t.tile288},
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
+                                              {"TCAR_MHA_MFMA", &t.mha_mfma},
                                               {"TCAR_SORT_SCATTER", &t.sort_scatter}};
   for (auto& e : tab) {
     bool same = true;

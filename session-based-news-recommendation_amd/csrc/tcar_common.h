@@ -62,6 +62,7 @@ struct TcarTuning {
   int gather_wg_per_cu; // TCAR_GATHER_WG      1024-thread workgroups per CU of that form (2 x 78 KB of LDS fit)
   int fused_q;          // TCAR_FUSED_Q        0: query-MLP backward as separate activation-backward launches
   int planes_epi;       // TCAR_PLANES_EPI     0: attout's bf16 planes by tcar_split_bf16 instead of the GEMM epilogue
+  int mha_mfma;         // TCAR_MHA_MFMA       0: multihead_attention core always in its scalar form
   int sort_scatter;     // TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum
 };
 const TcarTuning& tcar_tuning();

@@ -460,4 +460,157 @@ def _lin_backward(ctx, dy):
 
 linear.register_autograd(_lin_backward, setup_context=_lin_setup)
 
-OPS = ("gather_clip", "attn_pool", "score_ce", "score_rank", "neg_term", "clip_adam_", "rank_topk", "linear")
+# --------------------------------------------------------- optional blocks of modules.py:194-336 (not on TCAR's graph)
+@torch.library.custom_op("tcar::linear_residual", mutates_args=(), device_types="cuda")
+def linear_residual(x: Tensor, w: Tensor, bias: Tensor, res: Tensor) -> Tensor:
+    """x @ w + bias + res: the readout layer + residual of `feedforward` (modules.py:327-333) in one GEMM epilogue"""
+    _chk(x, w, bias, res)
+    M, K = x.shape
+    N = w.shape[1]
+    y = res.clone()                                   # the epilogue accumulates into it (beta = 1)
+    check(_lib_().tcar_gemm_f32(0, M, N, K, _p(x), K, _p(w), N, _p(y), N, _p(bias), 0, 1, 1, _st(x)), "tcar_gemm_f32")
+    return y
+
+
+@linear_residual.register_fake
+def _(x, w, bias, res):
+    return torch.empty_like(res)
+
+
+def _linres_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1])
+
+
+def _linres_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    dy = dy.contiguous()
+    dx, dw, db = torch.ops.tcar.linear_bwd(dy, x, w, dy, 0)
+    return dx, dw, db, dy
+
+
+linear_residual.register_autograd(_linres_backward, setup_context=_linres_setup)
+
+
+def feedforward(inputs: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    """modules.py:306-336 with dropout off: two kernel-size-1 convolutions = per-position linear layers, relu inside,
+    residual outside: relu(x w1 + b1) w2 + b2 + x.  inputs [N, T, C], w1 [C, F], w2 [F, C]."""
+    N, T, Cc = inputs.shape
+    x = inputs.reshape(N * T, Cc).contiguous()
+    h = torch.ops.tcar.linear(x, w1, b1, 1)
+    return torch.ops.tcar.linear_residual(h, w2, b2, x).reshape(N, T, Cc)
+
+
+@torch.library.custom_op("tcar::normalize", mutates_args=(), device_types="cuda")
+def normalize(x: Tensor, gamma: Tensor, beta: Tensor, epsilon: float) -> Tuple[Tensor, Tensor]:
+    """modules.py:194-218: layer normalisation over the last axis -> (y, stats [M, 2] = (mean, 1/std) for the backward pass)"""
+    _chk(x, gamma, beta)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    y = torch.empty_like(x)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+    check(_lib_().tcar_layernorm_fwd(M, Cc, _p(x), _p(gamma), _p(beta), epsilon, _p(y), _p(stats), _st(x)), "tcar_layernorm_fwd")
+    return y, stats
+
+
+@normalize.register_fake
+def _(x, gamma, beta, epsilon):
+    return torch.empty_like(x), x.new_empty(x.numel() // x.shape[-1], 2)
+
+
+@torch.library.custom_op("tcar::normalize_bwd", mutates_args=(), device_types="cuda")
+def normalize_bwd(x: Tensor, gamma: Tensor, stats: Tensor, dy: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    _chk(x, gamma, stats, dy)
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    dx, dg, db = torch.empty_like(x), torch.zeros_like(gamma), torch.zeros_like(gamma)
+    check(_lib_().tcar_layernorm_bwd(M, Cc, _p(x), _p(gamma), _p(stats), _p(dy), _p(dx), _p(dg), _p(db), _st(x)),
+          "tcar_layernorm_bwd")
+    return dx, dg, db
+
+
+@normalize_bwd.register_fake
+def _(x, gamma, stats, dy):
+    return torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+
+
+def _ln_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], output[1])
+
+
+def _ln_backward(ctx, dy, _ds):
+    x, gamma, stats = ctx.saved_tensors
+    dx, dg, db = torch.ops.tcar.normalize_bwd(x, gamma, stats, dy.contiguous())
+    return dx, dg, db, None
+
+
+normalize.register_autograd(_ln_backward, setup_context=_ln_setup)
+
+
+@torch.library.custom_op("tcar::mha_core", mutates_args=(), device_types="cuda")
+def mha_core(Q: Tensor, K: Tensor, V: Tensor, key_mask: Tensor, query_mask: Tensor, heads: int, causal: bool) -> Tuple[Tensor, Tensor]:
+    """the attention core of modules.py:256-292 (scores, key / causal masks, softmax, query mask, weighted sum) on the
+    matrix cores for head sizes 32 / 64 -> (O [N,Tq,C], P [N*heads,Tq,Tk])"""
+    _chk(Q, K, V, key_mask, query_mask)
+    N, Tq, Cc = Q.shape
+    Tk = K.shape[1]
+    O = torch.empty_like(Q)
+    P = torch.empty(N * heads, Tq, Tk, dtype=torch.float32, device=Q.device)
+    check(_lib_().tcar_mha_core_fwd(N, Tq, Tk, Cc, heads, int(causal), _p(Q), _p(K), _p(V), _p(key_mask), _p(query_mask), _p(O),
+                                    _p(P), _st(Q)), "tcar_mha_core_fwd")
+    return O, P
+
+
+@mha_core.register_fake
+def _(Q, K, V, key_mask, query_mask, heads, causal):
+    return torch.empty_like(Q), Q.new_empty(Q.shape[0] * heads, Q.shape[1], K.shape[1])
+
+
+@torch.library.custom_op("tcar::mha_core_bwd", mutates_args=(), device_types="cuda")
+def mha_core_bwd(Q: Tensor, K: Tensor, V: Tensor, P: Tensor, key_mask: Tensor, query_mask: Tensor, dO: Tensor, heads: int,
+                 causal: bool) -> Tuple[Tensor, Tensor, Tensor]:
+    _chk(Q, K, V, P, key_mask, query_mask, dO)
+    N, Tq, Cc = Q.shape
+    dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+    check(_lib_().tcar_mha_core_bwd(N, Tq, K.shape[1], Cc, heads, int(causal), _p(Q), _p(K), _p(V), _p(P), _p(key_mask),
+                                    _p(query_mask), _p(dO), _p(dQ), _p(dK), _p(dV), _st(Q)), "tcar_mha_core_bwd")
+    return dQ, dK, dV
+
+
+@mha_core_bwd.register_fake
+def _(Q, K, V, P, key_mask, query_mask, dO, heads, causal):
+    return torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+
+
+def _mha_setup(ctx, inputs, output):
+    Q, K, V, km, qm, heads, causal = inputs
+    ctx.save_for_backward(Q, K, V, output[1], km, qm)
+    ctx.hc = (heads, causal)
+
+
+def _mha_backward(ctx, dO, _dP):
+    Q, K, V, P, km, qm = ctx.saved_tensors
+    dQ, dK, dV = torch.ops.tcar.mha_core_bwd(Q, K, V, P, km, qm, dO.contiguous(), ctx.hc[0], ctx.hc[1])
+    return dQ, dK, dV, None, None, None, None
+
+
+mha_core.register_autograd(_mha_backward, setup_context=_mha_setup)
+
+
+def multihead_attention(queries: Tensor, keys: Tensor, wq: Tensor, bq: Tensor, wk: Tensor, bk: Tensor, wv: Tensor, bv: Tensor,
+                        num_heads: int = 8, causality: bool = False) -> Tensor:
+    """modules.py:220-304 with dropout off: dense Q / K / V projections without activation (:247-249), head split, the
+    attention core (`mha_core`), head merge, residual (:298).  queries [N,Tq,C], keys [N,Tk,C], w* [C,C], b* [C]."""
+    N, Tq, Cc = queries.shape
+    Tk = keys.shape[1]
+    q2, k2 = queries.reshape(N * Tq, Cc).contiguous(), keys.reshape(N * Tk, Cc).contiguous()
+    Q = torch.ops.tcar.linear(q2, wq, bq, 0).reshape(N, Tq, Cc)
+    K = torch.ops.tcar.linear(k2, wk, bk, 0).reshape(N, Tk, Cc)
+    V = torch.ops.tcar.linear(k2, wv, bv, 0).reshape(N, Tk, Cc)
+    key_mask = torch.sign(keys.detach().sum(-1).abs()).contiguous()          # modules.py:263
+    query_mask = torch.sign(queries.detach().sum(-1).abs()).contiguous()     # modules.py:283
+    O, _ = torch.ops.tcar.mha_core(Q, K, V, key_mask, query_mask, num_heads, bool(causality))
+    return O + queries
+
+
+OPS = ("gather_clip", "attn_pool", "score_ce", "score_rank", "neg_term", "clip_adam_", "rank_topk", "linear", "linear_residual",
+       "normalize", "mha_core")

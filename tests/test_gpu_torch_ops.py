@@ -237,3 +237,107 @@ def test_rank_topk_and_linear_ops():
         close(xs.grad, x64.grad, name="dx", atol_scale=5e-5)
         close(w.grad, w64.grad, name="dw", atol_scale=5e-5)
         close(bias.grad, b64.grad, name="db", atol_scale=5e-5)
+
+
+# ------------------------------------------------------------- optional blocks of modules.py:194-336
+@pytest.mark.parametrize("shape", [(7, 5, 250), (300, 64), (3, 2, 2048), (5, 33)])
+def test_normalize_op(shape):
+    _need_gpu()
+    from tcar_amd import torch_ops  # noqa: F401
+    rng = np.random.RandomState(sum(shape))
+    C_ = shape[-1]
+    x = torch.tensor((rng.standard_normal(shape) * 2 + 0.5).astype(np.float32), device=DEV, requires_grad=True)
+    gamma = torch.tensor((1 + 0.3 * rng.standard_normal(C_)).astype(np.float32), device=DEV, requires_grad=True)
+    beta = torch.tensor((0.2 * rng.standard_normal(C_)).astype(np.float32), device=DEV, requires_grad=True)
+    y, _ = torch.ops.tcar.normalize(x, gamma, beta, 1e-8)
+    x64, g64, b64 = (t.detach().double().cpu().requires_grad_(True) for t in (x, gamma, beta))
+    mean, var = x64.mean(-1, keepdim=True), x64.var(-1, unbiased=False, keepdim=True)       # tf.nn.moments (modules.py:213)
+    want = g64 * (x64 - mean) / (var + 1e-8) ** 0.5 + b64                                   # modules.py:216-217
+    close(y, want, name="normalize")
+    wgt = torch.tensor(rng.standard_normal(shape))
+    (y.double() * wgt.to(DEV)).sum().backward()
+    (want * wgt).sum().backward()
+    close(x.grad, x64.grad, name="dx", atol_scale=1e-4)
+    close(gamma.grad, g64.grad, name="dgamma", atol_scale=1e-4)
+    close(beta.grad, b64.grad, name="dbeta", atol_scale=1e-4)
+
+
+def test_feedforward_block():
+    _need_gpu()
+    from tcar_amd import torch_ops
+    rng = np.random.RandomState(21)
+    N, T, C_, F = 6, 9, 64, 256
+    mk = lambda *s, sc=0.2: torch.tensor((rng.standard_normal(s) * sc).astype(np.float32), device=DEV, requires_grad=True)
+    x, w1, b1, w2, b2 = mk(N, T, C_, sc=1.0), mk(C_, F), mk(F), mk(F, C_), mk(C_)
+    y = torch_ops.feedforward(x, w1, b1, w2, b2)
+    d = [t.detach().double().cpu().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    want = torch.relu(d[0] @ d[1] + d[2]) @ d[3] + d[4] + d[0]                               # modules.py:319-333
+    close(y, want, name="feedforward")
+    wgt = torch.tensor(rng.standard_normal((N, T, C_)))
+    (y.double() * wgt.to(DEV)).sum().backward()
+    (want * wgt).sum().backward()
+    for name, a, b in zip(("x", "w1", "b1", "w2", "b2"), (x, w1, b1, w2, b2), d):
+        close(a.grad, b.grad, name="d " + name, atol_scale=1e-4)
+
+
+def _mha_ref(queries, keys, wq, bq, wk, bk, wv, bv, h, causal):
+    N, Tq, C_ = queries.shape
+    Tk = keys.shape[1]
+    Q, K, V = queries @ wq + bq, keys @ wk + bk, keys @ wv + bv                              # modules.py:247-249
+    split = lambda t: torch.cat(torch.split(t, C_ // h, dim=2), dim=0)                       # :252-254
+    Q_, K_, V_ = split(Q), split(K), split(V)
+    out = Q_ @ K_.transpose(1, 2) / (C_ // h) ** 0.5                                         # :257-261
+    km = torch.sign(keys.sum(-1).abs()).repeat(h, 1)[:, None, :].expand(-1, Tq, -1)          # :263-265
+    out = torch.where(km == 0, torch.full_like(out, -2.0 ** 32 + 1), out)                    # :267-268
+    if causal:
+        tril = torch.tril(torch.ones(Tq, Tk, dtype=out.dtype))
+        out = torch.where(tril[None] == 0, torch.full_like(out, -2.0 ** 32 + 1), out)        # :271-277
+    out = torch.softmax(out, -1)                                                             # :280
+    qm = torch.sign(queries.sum(-1).abs()).repeat(h, 1)[:, :, None]                          # :283-285
+    out = (out * qm) @ V_                                                                    # :286,292
+    return torch.cat(torch.split(out, N, dim=0), dim=2) + queries                            # :295-298
+
+
+@pytest.mark.parametrize("N,T,C_,h,causal", [(5, 40, 256, 8, True), (3, 17, 128, 2, False), (4, 64, 64, 2, True),
+                                               (2, 9, 48, 3, False)])
+def test_multihead_attention_block_on_the_matrix_cores(N, T, C_, h, causal):
+    """head sizes 32 and 64 run the MFMA form, 16 the scalar one; padded keys / queries (all-zero rows) exercise the key and
+    query masks, and one sample has EVERY key masked (the reference's softmax is then uniform over the masked keys)"""
+    _need_gpu()
+    from tcar_amd import torch_ops
+    rng = np.random.RandomState(N * 1000 + T)
+    mk = lambda *s, sc=0.3: (rng.standard_normal(s) * sc).astype(np.float32)
+    q_np, k_np = mk(N, T, C_, sc=1.0), mk(N, T, C_, sc=1.0)
+    k_np[0, T // 2:] = 0          # padded keys
+    q_np[1, -2:] = 0              # padded queries
+    k_np[N - 1] = 0               # every key masked
+    ws = [mk(C_, C_, sc=C_ ** -0.5), mk(C_, sc=0.1), mk(C_, C_, sc=C_ ** -0.5), mk(C_, sc=0.1), mk(C_, C_, sc=C_ ** -0.5), mk(C_, sc=0.1)]
+    dev = [torch.tensor(a, device=DEV, requires_grad=True) for a in [q_np, k_np] + ws]
+    y = torch_ops.multihead_attention(*dev, num_heads=h, causality=causal)
+    d = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in [q_np, k_np] + ws]
+    want = _mha_ref(*d, h, causal)
+    close(y, want, name="multihead_attention", atol_scale=1e-4)
+    wgt = torch.tensor(rng.standard_normal((N, T, C_)))
+    (y.double() * wgt.to(DEV)).sum().backward()
+    (want * wgt).sum().backward()
+    for name, a, b in zip(("queries", "keys", "wq", "bq", "wk", "bk", "wv", "bv"), dev, d):
+        close(a.grad, b.grad, name="d " + name, atol_scale=2e-4)
+    if C_ // h in (32, 64):
+        # the MFMA form against the scalar form of the same entry point
+        lib = torch_ops._lib_()
+        Q = torch.tensor(mk(N, T, C_), device=DEV)
+        Kt, V = torch.tensor(mk(N, T, C_), device=DEV), torch.tensor(mk(N, T, C_), device=DEV)
+        km = torch.sign(torch.tensor(k_np, device=DEV).sum(-1).abs()).contiguous()
+        qm = torch.sign(torch.tensor(q_np, device=DEV).sum(-1).abs()).contiguous()
+        outs = []
+        for flag in (1, 0):
+            prev = lib.tcar_set_tuning(b"TCAR_MHA_MFMA", flag)
+            try:
+                O, P = torch.ops.tcar.mha_core(Q, Kt, V, km, qm, h, causal)
+                g = torch.ops.tcar.mha_core_bwd(Q, Kt, V, P, km, qm, torch.ones_like(O), h, causal)
+                torch.cuda.synchronize()
+            finally:
+                lib.tcar_set_tuning(b"TCAR_MHA_MFMA", prev)
+            outs.append([O, P] + list(g))
+        for name, a, b in zip(("O", "P", "dQ", "dK", "dV"), outs[0], outs[1]):
+            close(a, b, name="mfma vs scalar " + name, atol_scale=1e-5)
