@@ -320,8 +320,11 @@ def test_multihead_attention_block_on_the_matrix_cores(N, T, C_, h, causal):
     wgt = torch.tensor(rng.standard_normal((N, T, C_)))
     (y.double() * wgt.to(DEV)).sum().backward()
     (want * wgt).sum().backward()
+    gmax = max(float(b.grad.abs().max()) for b in d)
     for name, a, b in zip(("queries", "keys", "wq", "bq", "wk", "bk", "wv", "bv"), dev, d):
-        close(a.grad, b.grad, name="d " + name, atol_scale=2e-4)
+        # d bk is zero in exact arithmetic (a bias on the keys shifts every score of a query alike: softmax is invariant)
+        floor = 3e-6 * gmax / max(1e-30, float(b.grad.abs().max()))
+        close(a.grad, b.grad, name="d " + name, atol_scale=max(2e-4, floor))
     if C_ // h in (32, 64):
         # the MFMA form against the scalar form of the same entry point
         lib = torch_ops._lib_()
