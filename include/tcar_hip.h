@@ -392,6 +392,20 @@ typedef struct {
 int tcar_form_batch(const tcar_dims_t* d, const tcar_store_t* st, const tcar_negsrc_t* src, const int32_t* idx, int B, int T,
                     int K, int gap_mode, uint64_t seed, uint64_t counter, int32_t* feed, void* stream);
 
+/* ---- catalog-sharded data-parallel step (no reference equivalent: SURVEY.md 8(e)) ------------------------------------
+ * Rank r scores the catalog rows [n0, n0 + N) against the sessions of every rank; the softmax over the whole catalog
+ * (model_combine.py:145) is split into per-shard statistics, an exchange, and the gradient:
+ *   tcar_softmax_stats    stats[b] = (max, sum exp(x - max), logits[b, label[b] - n0] if the label lives here else 0)
+ *   tcar_softmax_combine  stats_all [W, B, 3] (all-gathered) -> lse [B], ce [B] = lse - label logit (ce may be NULL)
+ *   tcar_softmax_grad     dlogits = exp(x - lse) - onehot as bf16 hi / lo KB32 planes [ceil128(B), ld] (ld % 32 == 0)
+ *   tcar_neg_scatter_range  g_item[neg[b,k] - n0, 0:ldh] += coef[b] * attout[b, 0:ldh] for the negatives inside the shard */
+int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld, const int32_t* label, int n0, float* stats, void* stream);
+int tcar_softmax_combine(int W, int B, const float* stats_all, float* lse, float* ce, void* stream);
+int tcar_softmax_grad(int B, int N, const float* logits, int64_t ld, const float* lse, const int32_t* label, int n0, void* dl_hi,
+                      void* dl_lo, void* stream);
+int tcar_neg_scatter_range(const tcar_dims_t* d, int64_t B, int K, int n0, int n_loc, const int32_t* neg, const float* attout,
+                           int64_t ld_att, const float* coef, float* g_item, void* stream);
+
 /* Diagnostic hook (tests, profiling tools): override one of the TCAR_* tuning switches at run time (they are otherwise read
  * from the environment once per process).  Returns the previous value, INT_MIN for an unknown name.  Not for product code. */
 int tcar_set_tuning(const char* name /*host*/, int value);

@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libtcar_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip", "step.hip", "mha.hip",
-           "sampler.hip", "norm.hip", "buildid.hip"]
+           "sampler.hip", "norm.hip", "shard.hip", "buildid.hip"]
 BUILD_ID_TU = "buildid.hip"        # the one translation unit that carries the digest of all sources
 NVAR = 22
 NSLOT = 32
@@ -27,7 +27,7 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_step_forward",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
 
 
@@ -268,6 +268,10 @@ def load() -> C.CDLL:
     for s in SYMBOLS:
         getattr(lib, s).restype = C.c_int
     lib.tcar_set_tuning.argtypes = [C.c_char_p, i32]
+    lib.tcar_softmax_stats.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp]
+    lib.tcar_softmax_combine.argtypes = [i32, i32, vp, vp, vp, vp]
+    lib.tcar_softmax_grad.argtypes = [i32, i32, vp, i64, vp, vp, i32, vp, vp, vp]
+    lib.tcar_neg_scatter_range.argtypes = [P(Dims), i64, i32, i32, i32, vp, vp, i64, vp, vp, vp]
     lib.tcar_form_batch.argtypes = [P(Dims), P(Store), P(NegSrc), vp, i32, i32, i32, i32, C.c_uint64, C.c_uint64, vp, vp]
     lib.tcar_build_id.restype = C.c_char_p
     lib.tcar_build_id.argtypes = []

@@ -1,0 +1,158 @@
+// Kernels of the catalog-sharded data-parallel step (sharded.py).  With W ranks, rank r owns the catalog rows
+// [n0, n0 + Nloc) of the candidate matrix, scores them against the sessions of ALL ranks (attout is all-gathered), and keeps
+// their gradient, Adam moments and bf16 planes to itself: the dense item gradient never crosses a link.  What the split of
+// the softmax over the catalog (model_combine.py:145) needs beyond the single-GPU kernels:
+//   tcar_softmax_stats     per (session, shard): max, sum exp(x - max) and the label's logit when the label lives here
+//   tcar_softmax_combine   folds the W all-gathered stat triples of every session into lse and the cross entropy
+//   tcar_softmax_grad      dlogits = exp(x - lse) - onehot as bf16 hi / lo KB32 planes of the shard's columns
+//   tcar_neg_scatter_range the negative-term rows of ALL sessions that fall into this shard (model_combine.py:142, backward)
+#include "tcar_common.h"
+#include "tcar_bf16_layout.h"
+
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_h;
+
+namespace {
+
+__global__ __launch_bounds__(256) void softmax_stats_kernel(int B, int N, const float* __restrict__ logits, long ld,
+                                                            const int32_t* __restrict__ label, int n0, float* __restrict__ stats) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* row = logits + (long)b * ld;
+  float m = -INFINITY;
+  for (int c = tid * 4; c < N; c += 1024) {
+    const float4 v = ld4(row + c);
+    m = fmaxf(m, v.x);
+    if (c + 1 < N) m = fmaxf(m, v.y);
+    if (c + 2 < N) m = fmaxf(m, v.z);
+    if (c + 3 < N) m = fmaxf(m, v.w);
+  }
+  m = wave_max(m);
+  if (lane == 0) sh[w] = m;
+  __syncthreads();
+  const float gm = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid * 4; c < N; c += 1024) {
+    const float4 v = ld4(row + c);
+    s += expf(v.x - gm);
+    if (c + 1 < N) s += expf(v.y - gm);
+    if (c + 2 < N) s += expf(v.z - gm);
+    if (c + 3 < N) s += expf(v.w - gm);
+  }
+  s = wave_sum(s);
+  if (lane == 0) sh[w] = s;
+  __syncthreads();
+  if (tid == 0) {
+    const int lab = label[b] - n0;
+    stats[3L * b + 0] = gm;
+    stats[3L * b + 1] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    stats[3L * b + 2] = (lab >= 0 && lab < N) ? row[lab] : 0.f;
+  }
+}
+
+// stats_all [W, B, 3] -> lse [B], ce [B] = lse - label logit (the label lives in exactly one shard; the others sent 0)
+__global__ __launch_bounds__(256) void softmax_combine_kernel(int W, int B, const float* __restrict__ stats_all,
+                                                              float* __restrict__ lse, float* __restrict__ ce) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  float m = -INFINITY;
+  for (int w = 0; w < W; ++w) m = fmaxf(m, stats_all[((long)w * B + b) * 3]);
+  float s = 0.f, lab = 0.f;
+  for (int w = 0; w < W; ++w) {                      // fixed order: every rank folds the same numbers the same way
+    const float* t = stats_all + ((long)w * B + b) * 3;
+    s += t[1] * expf(t[0] - m);
+    lab += t[2];
+  }
+  const float l = m + logf(s);
+  lse[b] = l;
+  if (ce) ce[b] = l - lab;
+}
+
+__global__ __launch_bounds__(256) void softmax_grad_kernel(int B, int N, const float* __restrict__ logits, long ld,
+                                                           const float* __restrict__ lse, const int32_t* __restrict__ label,
+                                                           int n0, __bf16* __restrict__ dh, __bf16* __restrict__ dl) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int in32 = (int)(ld >> 5);
+  if (b >= B) {   // padding rows of the planes
+    for (int c = tid * 4; c < (int)ld; c += 1024) {
+      const long o = kb32_off(b, c, in32);
+      const bf16x4_h z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      *reinterpret_cast<bf16x4_h*>(dh + o) = z;
+      *reinterpret_cast<bf16x4_h*>(dl + o) = z;
+    }
+    return;
+  }
+  const float* row = logits + (long)b * ld;
+  const float l = lse[b];
+  const int lab = label[b] - n0;
+  for (int c = tid * 4; c < (int)ld; c += 1024) {
+    const float4 v = ld4(row + c);
+    float ov[4] = {v.x, v.y, v.z, v.w};
+    bf16x4_h h, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float p = (c + j < N) ? expf(ov[j] - l) - ((c + j == lab) ? 1.f : 0.f) : 0.f;
+      h[j] = (__bf16)p;
+      lo[j] = (__bf16)(p - (float)h[j]);
+    }
+    const long o = kb32_off(b, c, in32);
+    *reinterpret_cast<bf16x4_h*>(dh + o) = h;
+    *reinterpret_cast<bf16x4_h*>(dl + o) = lo;
+  }
+}
+
+// one wave per (session, negative) of the GLOBAL batch; rows outside [n0, n0 + n_loc) belong to another rank
+__global__ __launch_bounds__(256) void neg_scatter_range_kernel(long BK, int K, int n0, int n_loc, int ldh, long ld_att,
+                                                                const int32_t* __restrict__ neg, const float* __restrict__ attout,
+                                                                const float* __restrict__ coef, float* __restrict__ g_item) {
+  const int lane = threadIdx.x & 63;
+  const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wv >= BK) return;
+  const long b = wv / K;
+  const int n = neg[wv] - n0;
+  const float cf = coef[b];
+  if (n < 0 || n >= n_loc || cf == 0.f) return;
+  const float* a = attout + b * ld_att;
+  float* gdst = g_item + (long)n * ldh;
+  for (int col = lane; col < ldh; col += 64) atomicAdd(gdst + col, cf * a[col]);
+}
+
+}  // namespace
+
+extern "C" int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld, const int32_t* label, int n0, float* stats,
+                                  void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !stats) return TCAR_E_ARG;
+  TCAR_LAUNCH(softmax_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, N, logits, (long)ld, label, n0, stats);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_softmax_combine(int W, int B, const float* stats_all, float* lse, float* ce, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (W <= 0 || !stats_all || !lse) return TCAR_E_ARG;
+  TCAR_LAUNCH(softmax_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, B, stats_all, lse, ce);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_softmax_grad(int B, int N, const float* logits, int64_t ld, const float* lse, const int32_t* label, int n0,
+                                 void* dl_hi, void* dl_lo, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (N <= 0 || ld < N || (ld & 31) || !tcar_aligned16(logits) || !lse || !label || !dl_hi || !dl_lo) return TCAR_E_ARG;
+  TCAR_LAUNCH(softmax_grad_kernel, dim3((B + 127) & ~127), dim3(256), 0, (hipStream_t)stream, B, N, logits, (long)ld, lse, label, n0,
+              (__bf16*)dl_hi, (__bf16*)dl_lo);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_neg_scatter_range(const tcar_dims_t* d, int64_t B, int K, int n0, int n_loc, const int32_t* neg,
+                                      const float* attout, int64_t ld_att, const float* coef, float* g_item, void* stream) {
+  if (!d || B <= 0 || K <= 0) return TCAR_OK;
+  if (!neg || !attout || !coef || !g_item || n_loc <= 0) return TCAR_E_ARG;
+  const long waves = (long)B * K;
+  TCAR_LAUNCH(neg_scatter_range_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, waves, K, n0, n_loc,
+              d->ldh, (long)ld_att, neg, attout, coef, g_item);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}

@@ -204,8 +204,9 @@ class DPEngine(TcarEngine):
         self._comm_busy = True
         self.async_exchanges += 1
 
-    def train_step(self, batch, bt=None, cap_rows: Optional[int] = None):
-        """`batch` may be None for a rank whose shard of the global batch is empty (it still joins the collectives)."""
+    def train_step(self, batch, bt=None, cap_rows: Optional[int] = None, T: Optional[int] = None, K: Optional[int] = None):
+        """`batch` may be None for a rank whose shard of the global batch is empty (it still joins the collectives).
+        T / K: accepted for interface parity with sharded.ShardedEngine (an empty rank needs them there)."""
         if batch is None and bt is None:
             self.Gx.zero_()
             self.big.zero_()

@@ -127,7 +127,10 @@ def use_priority_stream(dev: torch.device) -> None:
 class TcarEngine:
     def __init__(self, params: Dict[str, np.ndarray], content_emb: np.ndarray, mwdhm: np.ndarray, lr: float = 1e-3,
                  max_grad: Optional[float] = 150.0, neg_weight: float = 0.01, device: str = "cuda:0",
-                 splitk: Optional[int] = None, scoring: str = "f32"):
+                 splitk: Optional[int] = None, scoring: str = "f32", shard: Optional[tuple] = None):
+        """shard = (n0, n_loc): catalog-sharded data parallelism (sharded.py) — the candidate-side state (bf16 planes of E,
+        dense item gradient, candidate-time block, Adam moments, inverted index) covers the catalog rows [n0, n0 + n_loc)
+        only; E itself stays whole (the session-side gathers read any row)."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.TcarError("TcarEngine needs an MI355X (no CPU fallback)")
@@ -174,39 +177,43 @@ class TcarEngine:
         self.M = torch.zeros(off, **f32)
         self.V = torch.zeros(off, **f32)
         self.E = torch.zeros(g.Npad, g.ek, **f32)
+        self.shard = (0, g.N) if shard is None else (int(shard[0]), int(shard[1]))
+        n0, nl = self.shard                       # candidate-side state covers rows [n0, n0 + nl)
+        nlpad = _ru(nl, 128)
         if self.scoring_code:
-            self.e16h = torch.zeros(g.Npad, g.ek, dtype=torch.bfloat16, device=self.dev)
-            self.e16l = torch.zeros(g.Npad, g.ek, dtype=torch.bfloat16, device=self.dev)
+            self.e16h = torch.zeros(nlpad, g.ek, dtype=torch.bfloat16, device=self.dev)
+            self.e16l = torch.zeros(nlpad, g.ek, dtype=torch.bfloat16, device=self.dev)
         # dense item-table gradient and the candidate-side time block of dE, contiguous for the same reason
-        self.big = torch.zeros(g.N * (g.ldh + g.pt), **f32)
-        self.Gi = self.big[:g.N * g.ldh].view(g.N, g.ldh)
-        self.d_et = self.big[g.N * g.ldh:].view(g.N, g.pt)
-        self.Mi = torch.zeros(g.N, g.ldh, **f32)
-        self.Vi = torch.zeros(g.N, g.ldh, **f32)
+        self.big = torch.zeros(nl * (g.ldh + g.pt), **f32)
+        self.Gi = self.big[:nl * g.ldh].view(nl, g.ldh)
+        self.d_et = self.big[nl * g.ldh:].view(nl, g.pt)
+        self.Mi = torch.zeros(nl, g.ldh, **f32)
+        self.Vi = torch.zeros(nl, g.ldh, **f32)
         self.sqn_dense = torch.zeros(_lib.NSLOT, **f32)
         self.sqn_pieces = self.Gx[off:]
         use = np.ones(_lib.NSLOT, dtype=np.int32)
         for n in ["dec_pos", "duration_embedding"] + TIME_NAMES:
             use[SLOT[n]] = 0                      # tables: IndexedSlices pieces only
         self.use_dense = torch.tensor(use, device=self.dev)
-        self.mwdhm = torch.tensor(np.ascontiguousarray(mwdhm, dtype=np.int32), device=self.dev)
+        self.mwdhm = torch.tensor(np.ascontiguousarray(np.asarray(mwdhm)[n0:n0 + nl], dtype=np.int32), device=self.dev)
         self.dims = Dims(g.N, g.H, g.Ht, g.ldh, g.ldt)
+        self.dims_cand = Dims(nl, g.H, g.Ht, g.ldh, g.ldt)        # the candidate-side kernels see the shard as a catalog
         # static inverted index of publish_time_MWDHM: candidates listed per time-table row (cand_time_bwd_indexed)
-        mw = np.ascontiguousarray(mwdhm, dtype=np.int64)
+        mw = np.ascontiguousarray(np.asarray(mwdhm)[n0:n0 + nl], dtype=np.int64)
         rowoff = np.array([0, 13, 45, 53, 78])
         key = (np.clip(mw, 0, np.array(TIME_VOCAB) - 1) + rowoff[None, :]).T.reshape(-1)          # [5N], k-major
         order = np.argsort(key, kind="stable")
         inv_off = np.zeros(140, dtype=np.int32)
         inv_off[1:] = np.cumsum(np.bincount(key, minlength=139))
-        self.inv_n = torch.tensor((order % g.N).astype(np.int32), device=self.dev)
+        self.inv_n = torch.tensor((order % nl).astype(np.int32), device=self.dev)
         self.inv_off = torch.tensor(inv_off, device=self.dev)
         # inverse of the index: position of (k, n) in list order.  In the bf16 scoring modes the dE GEMM writes the time
         # block of dE in THAT order (tcar_gemm_bf16_perm), so the candidate-time backward streams contiguous lists
-        et_perm = np.empty(5 * g.N, dtype=np.int32)
-        et_perm[order] = np.arange(5 * g.N, dtype=np.int32)
+        et_perm = np.empty(5 * nl, dtype=np.int32)
+        et_perm[order] = np.arange(5 * nl, dtype=np.int32)
         self.et_perm = torch.tensor(et_perm, device=self.dev)
-        self.adam_bitmap = torch.zeros((g.N + 31) // 32 + 1, dtype=torch.int32, device=self.dev)   # split update marks
-        self.ct_ws = torch.zeros(self.lib.tcar_cand_time_ws_floats(C.byref(self.dims)), **f32)
+        self.adam_bitmap = torch.zeros((nl + 31) // 32 + 1, dtype=torch.int32, device=self.dev)   # split update marks
+        self.ct_ws = torch.zeros(self.lib.tcar_cand_time_ws_floats(C.byref(self.dims_cand)), **f32)
         # segment tables for the optimizer kernels
         self.segs_all = self._segments([a[0] for a in ARENA])
         self.segs_dense = self._segments([a[0] for a in ARENA if self.use_dense_np(a[1])])
@@ -244,8 +251,9 @@ class TcarEngine:
             self.E[lo:hi, :g.H].copy_(torch.from_numpy(np.ascontiguousarray(item[1 + lo:1 + hi])))
             self.E[lo:hi, g.ldh:g.ldh + g.H].copy_(torch.from_numpy(np.ascontiguousarray(self._content[1 + lo:1 + hi])))
         if self.scoring_code:
-            check(self.lib.tcar_split_bf16(self._p(self.E), g.ek, g.Npad, g.ek, self._p(self.e16h), self._p(self.e16l), g.ek,
-                                           None, None, 0, 0, 0, self._stream()), "tcar_split_bf16")
+            n0, nl = self.shard
+            check(self.lib.tcar_split_bf16(self._p(self.E, n0 * g.ek), g.ek, nl, g.ek, self._p(self.e16h), self._p(self.e16l),
+                                           g.ek, None, None, 0, 0, 0, self._stream()), "tcar_split_bf16")
         self._item_row0 = np.asarray(params["item_emb"], dtype=np.float32)[0].copy()
         self._time_dirty = True
 

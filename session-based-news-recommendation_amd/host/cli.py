@@ -64,6 +64,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
                     help="precision of the full-catalog scoring GEMMs (bf16x3: split-bf16 planes, fp32-class accuracy)")
     ap.add_argument("--gpus", default=1, type=int, help="data-parallel ranks (launch with torch.distributed.run)")
+    ap.add_argument("--dp_mode", default="replica", choices=["replica", "sharded"],
+                    help="multi-GPU exchange: replica = all-reduce of the dense item gradient (dp.py); sharded = catalog-sharded "
+                         "scoring (sharded.py: the item gradient stays on the rank that owns the rows)")
     ap.add_argument("--synthetic", default=0, type=int, help="N items of a synthetic Globo-like fold (no files)")
     ap.add_argument("--synthetic_train", default=100000, type=int)
     ap.add_argument("--synthetic_test", default=10000, type=int)

@@ -79,6 +79,11 @@ def initial_variables(N, H, Ht, emb_stddev, stddev, weight_seed=2020, lean=False
     return out
 
 
+def _idx0(sampler, i: int) -> int:
+    """store row of the first example of batch i (its input length is the batch's T)"""
+    return int(sampler.batch_indices(i)[0])
+
+
 def prefetch_batches(sampler, depth: int = 4):
     """Iterate sampler.next_batch_arrays() from a producer thread (same order, same RNG stream: only this thread draws
     from numpy's global generator while it runs) so batch assembly overlaps the upload / step enqueue of the consumer;
@@ -151,6 +156,9 @@ class Seq2SeqAttNN():
         if args.get('dp_group') is not None:
             from ..dp import DPEngine
             engine_cls, kw = DPEngine, {"group": args['dp_group']}
+            if args.get('dp_mode', 'replica') == 'sharded':
+                from ..sharded import ShardedEngine
+                engine_cls = ShardedEngine
         self.engine = engine_cls(params, content, self.publish_time_MWDHM, lr=args['lr'], max_grad=args.get('max_grad'),
                                  device=args.get('device', 'cuda:0'), scoring=args.get('scoring', 'bf16x3'), **kw)
         self._cat = None
@@ -249,7 +257,8 @@ class Seq2SeqAttNN():
                 for bt, cap_rows, _idx in self._device_batches(train_data, sampler, neighbor_dict, item_dict, args['neg_num']):
                     batch += 1
                     if self.dp_world > 1:
-                        crt_loss = eng.train_step(None, bt=bt, cap_rows=cap_rows)
+                        crt_loss = eng.train_step(None, bt=bt, cap_rows=cap_rows, T=int(sampler.store.in_len[_idx0(sampler, batch - 1)]),
+                                                  K=args['neg_num'] if neighbor_dict else 0)
                     else:
                         crt_loss = eng.train_step(None, bt=bt)
                     total += crt_loss.double().sum()
@@ -261,7 +270,7 @@ class Seq2SeqAttNN():
                 if self.dp_world > 1:
                     T = feed["seq"].shape[1]
                     sub, cap = self._shard(feed)
-                    crt_loss = eng.train_step(sub, cap_rows=cap * T)
+                    crt_loss = eng.train_step(sub, cap_rows=cap * T, T=T, K=(feed["neg"].shape[1] if feed["neg"] is not None else 0))
                 else:
                     crt_loss = eng.train_step(feed)             # [b] on device; no host sync inside the loop
                 total += crt_loss.double().sum()

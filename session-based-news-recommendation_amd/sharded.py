@@ -1,0 +1,407 @@
+"""Catalog-sharded data-parallel TCAR step ("catalog-sharded scoring"): one process per GPU,
+torch.distributed ("nccl" = RCCL over xGMI).  No reference equivalent — the reference is single process.
+
+The replica exchange of dp.py moves the dense item-table gradient and the candidate-time block of dE through an all-reduce
+(106 MB per step and rank at the Globo size).  Here rank r OWNS the catalog rows [n0_r, n0_r + S) of the candidate side —
+their bf16 planes, their gradient, their Adam moments — and scores them against the sessions of EVERY rank:
+
+  session forward (local B sessions)   gather, projections, pools, output transforms           -> attout [B, ek]
+  all-gather   attout, labels, negatives, (later) negative-term coefficients                   -> [W*B, ...]
+  scoring      logits = attout_all . E_shard^T  [W*B, S];  per-shard softmax statistics
+  all-gather   (max, sum exp, label logit) per session and shard -> lse, cross entropy          (3 floats per session)
+  gradients    dlogits planes;  dE_shard = dlogits^T attout_all (item block | time block) STAYS LOCAL;
+               dX_partial = dlogits . E_shard [W*B, ek]
+  reduce-scatter dX_partial over the ranks                                                     -> dattout of the local sessions
+  session backward (local)            ... -> (id, row) item-row gradients of the local sessions
+  all-gather   (id, row) pairs (as in dp.py); every owner keeps the rows of its shard
+  all-reduce   arena gradients + IndexedSlices norm pieces (+ the shards' dense item norms)     (5 MB)
+  update       clip + Adam: arena on every rank (identical inputs), item rows by their owner
+  all-gather   the updated item rows [S, ldh] -> every rank's E (the session-side gathers of the next step read any row)
+
+Per step and rank at W = 8, B = 512, N = 46,033: ~14 MB attout + ~14 MB dX + ~9 MB rows + 5 MB arena + 47 MB item rows
+received, against 2 x 106 MB through the replica all-reduce; the candidate-side memory (planes, gradient, moments: 0.5 GB
+at this size, 130 GB at 10 M items) divides by W.  The clip semantics of DESIGN.md S5 hold exactly: the dense item norm is
+the sum of the shards' norms of (scoring + densified negative part), taken BEFORE the gathered rows are scattered in.
+
+Python-sequenced over the op-level C-ABI (the fused single-rank driver, csrc/step.hip, cannot be cut at the exchange points);
+split-bf16 scoring modes only.  Evaluation scores the local sessions against the whole catalog on the fp32 GEMM.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, dp
+from ._lib import Batch, Dims, GemmDesc, Segments, check
+from .engine import SLOT, TcarEngine, _ru
+
+
+def shard_rows(n_items: int, world: int):
+    """rows per shard (a multiple of 128: the bf16 planes are blocked in 128-row units); the last shard may be short"""
+    return _ru((n_items + world - 1) // world, 128)
+
+
+class ShardedEngine(TcarEngine):
+    def __init__(self, params, content_emb, mwdhm, lr=1e-3, max_grad=150.0, neg_weight=0.01, device="cuda:0", group=None,
+                 scoring="bf16x3", world: Optional[int] = None, rank: Optional[int] = None, **kw):
+        if scoring == "f32":
+            raise ValueError("the catalog-sharded step runs the split-bf16 scoring modes (use mode='replica' for f32)")
+        self.group = group
+        live = dist.is_available() and dist.is_initialized()
+        self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
+        self.dp_rank = rank if rank is not None else (dist.get_rank(group) if live else 0)
+        self._mwdhm_full = np.asarray(mwdhm)
+        N = content_emb.shape[0] - 1
+        self.S = shard_rows(N, self.world)
+        n0 = min(N, self.dp_rank * self.S)
+        nl = max(0, min(N, n0 + self.S) - n0)
+        if nl <= 0:
+            raise ValueError("more ranks than 128-row catalog blocks")
+        super().__init__(params, content_emb, mwdhm, lr=lr, max_grad=max_grad, neg_weight=neg_weight, device=device,
+                         scoring=scoring, shard=(n0, nl), **kw)
+        self.n0, self.nl = n0, nl
+        self.nlpad = _ru(nl, 128)
+        self.n_local_items = nl
+        self.backend = dist.get_backend(group) if live and self.world > 1 else "none"
+        self.cap = 0
+        self._stage = torch.zeros(self.world, self.S, self.geo.ldh, dtype=torch.float32, device=self.dev)
+        self.bytes_moved = {}
+
+    # ------------------------------------------------------------------------------------------ collectives
+    def _allgather(self, t: torch.Tensor, key: str) -> torch.Tensor:
+        """[..] -> [W, ..] (rank-major); world 1: a view"""
+        if self.world == 1:
+            return t.unsqueeze(0)
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group)
+        self.bytes_moved[key] = out.numel() * out.element_size()
+        return out
+
+    def _reduce_scatter_rows(self, full: torch.Tensor, cap: int, key: str) -> torch.Tensor:
+        """sum over the ranks of full [W*cap, C]; returns this rank's rows [cap, C]"""
+        if self.world == 1:
+            return full[:cap]
+        self.bytes_moved[key] = full.numel() * full.element_size()
+        if self.backend == "nccl":
+            out = torch.empty(cap, full.shape[1], dtype=full.dtype, device=full.device)
+            dist.reduce_scatter_tensor(out, full, group=self.group)
+            return out
+        dist.all_reduce(full, group=self.group)              # gloo (single-GPU dry runs) has no reduce-scatter
+        return full[self.dp_rank * cap:(self.dp_rank + 1) * cap]
+
+    def exchange_info(self) -> Dict[str, object]:
+        g = self.geo
+        return {"mode": "sharded", "world": self.world, "shard_rows": self.S,
+                "bytes_per_step": dict(self.bytes_moved),
+                "item_rows_allgather_bytes": 4 * self.world * self.S * g.ldh,
+                "replica_mode_allreduce_bytes": 4 * (g.N * (g.ldh + g.pt) + self.arena_n + _lib.NSLOT),
+                "note": "all-gather attout / labels / negatives / softmax stats / (id,row) pairs / updated item rows, "
+                        "reduce-scatter dX, all-reduce arena; the dense item gradient and the candidate-time block stay local"}
+
+    # -------------------------------------------------------------------------------------------- workspace
+    def _ensure_score(self, cap: int, K: int):
+        g = self.geo
+        Bq = self.world * cap
+        if cap > self.cap or K > getattr(self, "_kcap", 0):
+            f32 = dict(dtype=torch.float32, device=self.dev)
+            bf = dict(dtype=torch.bfloat16, device=self.dev)
+            Bp = _ru(Bq, 128)
+            self.att_loc = torch.zeros(cap, g.ek, **f32)
+            self.lab_loc = torch.full((cap,), -1, dtype=torch.int32, device=self.dev)
+            self.neg_loc = torch.full((cap, max(K, 1)), -1, dtype=torch.int32, device=self.dev)
+            self.coef_loc = torch.zeros(cap, **f32)
+            self.s_logits = torch.empty(Bq, self.nlpad, **f32)
+            self.s_stats = torch.empty(Bq, 3, **f32)
+            self.s_lse, self.s_ce = torch.empty(Bq, **f32), torch.empty(Bq, **f32)
+            self.s_a16h, self.s_a16l = torch.zeros(Bp, g.ek, **bf), torch.zeros(Bp, g.ek, **bf)
+            self.s_ap16h, self.s_ap16l = torch.zeros(Bp, g.ldh + g.pt, **bf), torch.zeros(Bp, g.ldh + g.pt, **bf)
+            self.s_dl16h, self.s_dl16l = torch.zeros(Bp, self.nlpad, **bf), torch.zeros(Bp, self.nlpad, **bf)
+            self.s_slabs = torch.empty(self.splitk, Bq, g.ek, **f32)
+            self.s_dx = torch.empty(Bq, g.ek, **f32)
+            self.cap, self._kcap = cap, max(K, 1)
+
+    # ------------------------------------------------------------------------------------------- primitives
+    def _xg(self, layout, descs):
+        arr = (GemmDesc * len(descs))(*descs)
+        check(self.lib.tcar_gemm_x3_grouped(layout, len(descs), arr, self._stream()), "tcar_gemm_x3_grouped")
+
+    def _session_forward(self, bt: Batch):
+        """model_combine.py:52-132 for the local sessions: attout [B, ek]"""
+        g, lib, st, p, D = self.geo, self.lib, self._stream(), self._p, self.desc
+        B, T = bt.B, bt.T
+        BT = B * T
+        tab = self._tables()
+        check(lib.tcar_gather_clip_fwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.x_icp), p(self.x_pt), p(self.x_act),
+                                       p(self.click_t), st), "tcar_gather_clip_fwd")
+        x_c = p(self.x_icp, g.ldh)
+        self._xg(0, [
+            D(BT, g.ldh, [(p(self.x_icp), g.ic, self._w("m_win"), g.ldh, g.ic), (x_c, g.ic, self._w("m_wc"), g.ldh, g.ldh),
+                          (p(self.x_act), g.ldt, self._w("m_wint"), g.ldh, g.ldt)], p(self.pre1), g.ldh),
+            D(BT, g.ldh, [(p(self.x_pt), g.pt, self._w("s_win"), g.ldh, g.pt), (x_c, g.ic, self._w("s_wc"), g.ldh, g.ldh)],
+              p(self.pre2), g.ldh),
+            D(B, g.ldh, [(p(self.click_t), g.ct, self._w("q1_w"), g.ldh, g.ct)], p(self.q1), g.ldh, bias=self._w("q1_b"), act=1)])
+        self._xg(0, [D(B, g.ic, [(p(self.q1), g.ldh, self._w("q2_w"), g.ic, g.ldh)], p(self.q), g.ic, bias=self._w("q2_b"), act=2)])
+        check(lib.tcar_attn_pool_fwd(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2), p(self.q),
+                                     self._w("m_wres"), self._w("s_wres"), p(self.pooled), p(self.alpha), st), "tcar_attn_pool_fwd")
+        self._xg(0, [
+            D(B, g.ic, [(p(self.pooled), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.attout), g.ek, bias=self._w("o_b"), act=2),
+            D(B, g.pt, [(p(self.pooled, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.attout, g.ic), g.ek,
+              bias=self._w("ot_b"), act=2)])
+
+    def _session_backward(self, bt: Batch, dx_rows: torch.Tensor, has_neg: bool, rows_out: torch.Tensor):
+        """from the summed dX rows of the local sessions to every rank-local gradient (the sequence of csrc/step.hip's
+        backward, split-bf16 branch); the item-row gradients of the gathers go to rows_out [B*T, ldh]"""
+        g, lib, st, p, D = self.geo, self.lib, self._stream(), self._p, self.desc
+        B, T = bt.B, bt.T
+        BT = B * T
+        # dattout = (dX + the negative term's part) * tanh'(attout), plus the bias gradients of both output transforms
+        check(lib.tcar_splitk_reduce_dact(p(dx_rows), 1, B, g.ek, g.ek, p(self.negpart) if has_neg else None, g.ic, g.ic,
+                                          p(self.attout), g.ek, 2, p(self.dattout), self._g("o_b"), g.ic, self._g("ot_b"), st),
+              "tcar_splitk_reduce_dact")
+        self._xg(1, [D(B, g.ic, [(p(self.dattout), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.dpooled), g.ek),
+                     D(B, g.pt, [(p(self.dattout, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.dpooled, g.ic), g.ek)])
+        check(lib.tcar_attn_pool_bwd_q(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2), p(self.q),
+                                       self._w("m_wres"), self._w("s_wres"), p(self.alpha), p(self.dpooled), p(self.dx_icp),
+                                       p(self.dx_pt), p(self.dq), p(self.dpre1), p(self.dpre2), self._g("m_wres"),
+                                       self._g("s_wres"), self._g("q2_b"), st), "tcar_attn_pool_bwd_q")
+        d0 = D(B, g.ldh, [(p(self.dq), g.ic, self._w("q2_w"), g.ic, g.ic)], p(self.dq1), g.ldh)
+        d0.dact, d0.dact_y, d0.ld_dact_y, d0.colsum = 1, self.q1.data_ptr(), g.ldh, self._g("q1_b").value
+        self._xg(1, [d0,
+                     D(BT, g.ldh, [(p(self.dpre1), g.ldh, self._w("m_win"), g.ldh, g.ldh)], p(self.dx_icp), g.ic, beta=1),
+                     D(BT, g.ldt, [(p(self.dpre1), g.ldh, self._w("m_wint"), g.ldh, g.ldh)], p(self.dx_act), g.ldt),
+                     D(BT, g.pt, [(p(self.dpre2), g.ldh, self._w("s_win"), g.ldh, g.ldh)], p(self.dx_pt), g.pt, beta=1)])
+        self._xg(1, [D(B, g.ct, [(p(self.dq1), g.ldh, self._w("q1_w"), g.ldh, g.ldh)], p(self.dclick), g.ct)])
+        ks = lambda K: max(2, min(16, (K + 511) // 512))
+        kb, kr = ks(B), ks(BT)
+        x_c = p(self.x_icp, g.ldh)
+        Wd = lambda M, N, A, lda, Bm, ldb, K, name, k: D(M, N, [(A, lda, Bm, ldb, K)], self._g(name), N, splitk=k, atomic=1)
+        self._xg(2, [
+            Wd(g.ic, g.ic, p(self.pooled), g.ek, p(self.dattout), g.ek, B, "o_w", kb),
+            Wd(g.pt, g.pt, p(self.pooled, g.ic), g.ek, p(self.dattout, g.ic), g.ek, B, "ot_w", kb),
+            Wd(g.ldh, g.ic, p(self.q1), g.ldh, p(self.dq), g.ic, B, "q2_w", kb),
+            Wd(g.ct, g.ldh, p(self.click_t), g.ct, p(self.dq1), g.ldh, B, "q1_w", kb),
+            Wd(g.ic, g.ldh, p(self.x_icp), g.ic, p(self.dpre1), g.ldh, BT, "m_win", kr),
+            Wd(g.ldh, g.ldh, x_c, g.ic, p(self.dpre1), g.ldh, BT, "m_wc", kr),
+            Wd(g.ldt, g.ldh, p(self.x_act), g.ldt, p(self.dpre1), g.ldh, BT, "m_wint", kr),
+            Wd(g.pt, g.ldh, p(self.x_pt), g.pt, p(self.dpre2), g.ldh, BT, "s_win", kr),
+            Wd(g.ldh, g.ldh, x_c, g.ic, p(self.dpre2), g.ldh, BT, "s_wc", kr)])
+        tab, gr = self._tables(), self._grads()
+        gr.rows_out = rows_out.data_ptr()
+        check(lib.tcar_gather_clip_bwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.dx_icp), p(self.dx_pt), p(self.dx_act),
+                                       p(self.dclick), C.byref(gr), st), "tcar_gather_clip_bwd")
+
+    # ----------------------------------------------------------------------------------------------- step
+    def _step(self, bt: Optional[Batch], cap: int, K: int, update: bool, T: int):
+        """one training step; bt = None: a rank whose shard of the global batch is empty still joins every collective (T is
+        the step's input length: the row buffers of the exchanges have the same shape on every rank)"""
+        g, lib, p = self.geo, self.lib, self._p
+        W, n0, nl, nlpad = self.world, self.n0, self.nl, self.nlpad
+        B = bt.B if bt is not None else 0
+        cap = max(cap, B, 1)
+        Bq = W * cap
+        self._ensure_work(max(B, 1), T)
+        self._ensure_score(cap, K)
+        has_neg = K > 0
+        st = self._stream()
+        self.Gx.zero_()
+        self.sqn_dense.zero_()
+        # ---- session forward + the feed pieces the other ranks need
+        self.att_loc[:cap].zero_()
+        self.lab_loc[:cap].fill_(-1)
+        self.neg_loc[:cap].fill_(-1)
+        self.coef_loc[:cap].zero_()
+        if bt is not None:
+            self._session_forward(bt)
+            self.att_loc[:B].copy_(self.attout[:B])
+            lab = torch.as_strided(bt._keep, (B,), (1,), (bt.label - bt._keep.data_ptr()) // 4)
+            self.lab_loc[:B].copy_(lab)
+            if has_neg:
+                neg = torch.as_strided(bt._keep, (B, K), (K, 1), (bt.neg - bt._keep.data_ptr()) // 4)
+                self.neg_loc[:B, :K].copy_(neg)
+                check(lib.tcar_neg_fwd(C.byref(self.dims), B, K, p(self.E), C.c_void_p(bt.neg), p(self.attout), self.neg_weight,
+                                       p(self.neg_fb), p(self.neg_coef), p(self.negpart), st), "tcar_neg_fwd")
+                self.coef_loc[:B].copy_(self.neg_coef[:B])
+        att_all = self._allgather(self.att_loc[:cap], "attout").view(Bq, g.ek)
+        lab_all = self._allgather(self.lab_loc[:cap], "labels").view(Bq)
+        # ---- scoring of the shard against every session
+        if self._time_dirty:
+            check(lib.tcar_cand_time_fwd_bf16(C.byref(self.dims_cand), C.byref(self._time_ptrs()), p(self.mwdhm), None,
+                                              p(self.e16h), p(self.e16l), st), "tcar_cand_time_fwd_bf16")
+            self._time_dirty = False
+        check(lib.tcar_split_bf16(p(att_all), g.ek, Bq, g.ek, p(self.s_a16h), p(self.s_a16l), g.ek, p(self.s_ap16h),
+                                  p(self.s_ap16l), g.ldh + g.pt, g.ldh, g.ic, st), "tcar_split_bf16")
+        nsf = self.scoring_code
+        nsb = 1 if self.scoring_bwd else nsf
+        Bp = _ru(Bq, 128)
+        check(lib.tcar_gemm_bf16(1, Bq, nl, g.ek, p(self.s_a16h), p(self.s_a16l), g.ek, Bq, p(self.e16h), p(self.e16l), g.ek,
+                                 nlpad, p(self.s_logits), nlpad, None, 0, 0, nsf, 1, st), "tcar_gemm_bf16 logits")
+        check(lib.tcar_softmax_stats(Bq, nl, p(self.s_logits), nlpad, p(lab_all), n0, p(self.s_stats), st), "tcar_softmax_stats")
+        stats_all = self._allgather(self.s_stats[:Bq], "softmax_stats")
+        check(lib.tcar_softmax_combine(W, Bq, p(stats_all), p(self.s_lse), p(self.s_ce), st), "tcar_softmax_combine")
+        # padding sessions (label -1) get a zero gradient row: their lse is forced to +inf
+        self.s_lse[:Bq].masked_fill_(lab_all < 0, float("inf"))
+        check(lib.tcar_softmax_grad(Bq, nl, p(self.s_logits), nlpad, p(self.s_lse), p(lab_all), n0, p(self.s_dl16h),
+                                    p(self.s_dl16l), st), "tcar_softmax_grad")
+        # dE of the shard: item block | candidate-time block (in inverted-index order), local for good
+        check(lib.tcar_gemm_bf16_perm(2, nl, g.ldh + g.pt, (Bq + 31) & ~31, p(self.s_dl16h), p(self.s_dl16l), nlpad, Bp,
+                                      p(self.s_ap16h), p(self.s_ap16l), g.ldh + g.pt, Bp, p(self.Gi), g.ldh, p(self.d_et), g.pt,
+                                      g.ldh, p(self.et_perm), g.ldt, nsb, 1, st), "tcar_gemm_bf16 dE")
+        # dX partial of every session against this shard, summed over the ranks
+        S = lib.tcar_gemm_splitk_effective(nlpad, self.splitk)
+        check(lib.tcar_gemm_bf16(0, Bq, g.ek, nlpad, p(self.s_dl16h), p(self.s_dl16l), nlpad, Bp, p(self.e16h), p(self.e16l),
+                                 g.ek, nlpad, p(self.s_slabs), g.ek, None, 0, 0, nsb, self.splitk, st), "tcar_gemm_bf16 dX")
+        check(lib.tcar_splitk_reduce(p(self.s_slabs), S, Bq, g.ek, g.ek, p(self.s_dx), st), "tcar_splitk_reduce")
+        dx_rows = self._reduce_scatter_rows(self.s_dx[:Bq], cap, "dX")
+        # negative-term rows of ALL sessions that fall into this shard (densified part of the item gradient, S5)
+        if has_neg:
+            neg_all = self._allgather(self.neg_loc[:cap, :K].contiguous(), "negatives").view(Bq, K)
+            coef_all = self._allgather(self.coef_loc[:cap], "neg_coef").view(Bq)
+            check(lib.tcar_neg_scatter_range(C.byref(self.dims), Bq, K, n0, nl, p(neg_all), p(att_all), g.ek, p(coef_all),
+                                             p(self.Gi), st), "tcar_neg_scatter_range")
+        # dense item norm of the shard BEFORE any gathered row is scattered in (S5); summed over the shards by the arena
+        # all-reduce (it rides in the item slot of the norm pieces)
+        one = Segments()
+        one.nseg = 1
+        one.off[0], one.len[0], one.slot[0] = 0, nl * g.ldh, SLOT["item_emb"]
+        check(lib.tcar_sqnorm(p(self.Gi), C.byref(one), p(self.sqn_dense), st), "tcar_sqnorm")
+        # candidate-side time backward of the shard -> time-table gradients + their norm pieces (partial sums over shards)
+        gr = self._grads()
+        check(lib.tcar_cand_time_bwd_indexed(C.byref(self.dims_cand), C.byref(self._time_ptrs()), p(self.inv_n), p(self.inv_off),
+                                             p(self.d_et), 1, p(self.ct_ws), C.byref(gr), st), "tcar_cand_time_bwd_indexed")
+        # ---- session backward (local) and the sparse-row exchange
+        rows = torch.zeros(cap * T, g.ldh, dtype=torch.float32, device=self.dev)
+        ids = torch.zeros(cap * T, dtype=torch.int32, device=self.dev)
+        if bt is not None:
+            self._session_backward(bt, dx_rows, has_neg, rows)
+            ids[:B * T].copy_(bt._seq_t[:B * T])
+            if has_neg:
+                self.loss[:B] = self.s_ce[self.dp_rank * cap:self.dp_rank * cap + B] + self.neg_weight * self.neg_fb[:B]
+        all_ids = self._allgather(ids, "row_ids").view(-1)
+        all_rows = self._allgather(rows, "rows").view(-1, g.ldh)
+        shifted = all_ids - n0                      # ids are 1-based: rows of this shard become 1 .. nl, the rest fall out
+        check(lib.tcar_scatter_add_rows(C.byref(self.dims_cand), p(shifted), p(all_rows), shifted.numel(), p(self.Gi), st),
+              "tcar_scatter_add_rows")
+        # ---- arena exchange, norms, update
+        slot = SLOT["item_emb"]
+        self.sqn_pieces[slot] += self.sqn_dense[slot]
+        self.sqn_dense[slot] = 0.0
+        if W > 1:
+            dist.all_reduce(self.Gx, group=self.group)
+            self.bytes_moved["arena"] = self.Gx.numel() * 4
+        check(lib.tcar_sqnorm(p(self.G), C.byref(self.segs_dense), p(self.sqn_dense), st), "tcar_sqnorm")
+        if W > 1:
+            dist.broadcast(self.sqn_dense, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)        # atomically summed norms: one rank's bits for everyone (identical replicas)
+        if update:
+            self._update_and_share()
+
+    def _shard_ctx(self):
+        """tcar_ctx_t whose candidate side is this rank's shard (tcar_step_update: arena + the owned item rows + planes)"""
+        c = self._ctx()
+        if getattr(self, "_sctx_src", None) is not c:
+            s = _lib.Ctx()
+            C.memmove(C.byref(s), C.byref(c), C.sizeof(_lib.Ctx))
+            s.d = self.dims_cand
+            s.E = self.E.data_ptr() + 4 * self.n0 * self.geo.ek
+            self._sctx, self._sctx_src = s, c
+        return self._sctx
+
+    def _update_and_share(self):
+        g = self.geo
+        check(self.lib.tcar_step_update(C.byref(self._shard_ctx()), self._lr_t(), self._stream()), "tcar_step_update")
+        self._after_update()
+        if self.world > 1:
+            self._stage[self.dp_rank, :self.nl].copy_(self.E[self.n0:self.n0 + self.nl, :g.ldh])
+            dist.all_gather_into_tensor(self._stage.view(-1), self._stage[self.dp_rank].reshape(-1).clone(), group=self.group)
+            self.bytes_moved["item_rows"] = self._stage.numel() * 4
+            self.E[:g.N, :g.ldh].copy_(self._stage.view(-1, g.ldh)[:g.N])
+
+    # ------------------------------------------------------------------------------------------- public API
+    score_batch = property(lambda self: self.world * max(self.cap, 1))
+
+    def train_step(self, batch, bt: Optional[Batch] = None, cap_rows: Optional[int] = None, cap: Optional[int] = None,
+                   T: Optional[int] = None, K: Optional[int] = None, defer_update: bool = False):
+        """`batch` / `bt` = this rank's sessions (None: its shard of the global batch is empty — it still joins every
+        collective and must be told the step's input length T and negative count K, which every rank knows from the bucket
+        schedule).  cap = rows every rank contributes to the all-gathers (>= the largest local batch of the step; default: the
+        local batch size — weak-scaling runs with equal batches); cap_rows (dp.DPEngine's argument: cap * T) is accepted
+        for drop-in use.  No metadata collective, no host synchronisation."""
+        if bt is None and batch is not None:
+            bt = self.upload(batch)
+        if bt is not None:
+            T = bt.T
+            K = bt.K if bt.neg else 0
+        elif T is None or K is None:
+            raise ValueError("an empty rank needs the step's T and K")
+        if cap is None:
+            cap = (cap_rows // max(T, 1)) if cap_rows else (bt.B if bt is not None else 1)
+        self.flush()
+        self._step(bt, cap, K, True, T)
+        if bt is None:
+            return torch.zeros(0, device=self.dev)
+        return self._loss_rows(bt, cap, K)
+
+    def _loss_rows(self, bt, cap, K):
+        if K:
+            return self.loss[:bt.B]
+        # label_neg fed as [B, 0]: the negative term is the constant neg_weight * ln 2 (model_combine.py:142-147)
+        return self.s_ce[self.dp_rank * cap:self.dp_rank * cap + bt.B] + float(np.float32(self.neg_weight) * np.float32(np.log(2.0)))
+
+    def loss_and_grads(self, batch, bt: Optional[Batch] = None, cap_rows: Optional[int] = None, cap: Optional[int] = None):
+        bt = bt or self.upload(batch)
+        if cap is None:
+            cap = (cap_rows // max(bt.T, 1)) if cap_rows else bt.B
+        K = bt.K if bt.neg else 0
+        self.flush()
+        self._step(bt, cap, K, False, bt.T)
+        return self._loss_rows(bt, cap, K)
+
+    def update(self):
+        self._update_and_share()
+
+    def eval_step(self, batch, k: int = 20, bt: Optional[Batch] = None, keep_logits: bool = False):
+        """local sessions against the WHOLE catalog on the fp32 GEMM (evaluation runs once per epoch)"""
+        self.flush()
+        bt = bt or self.upload(batch)
+        g, lib, st, p = self.geo, self.lib, self._stream(), self._p
+        B = bt.B
+        self._ensure_work(B, bt.T)
+        if not hasattr(self, "ev_logits") or self.ev_logits.shape[0] < B:
+            self.ev_logits = torch.empty(max(B, self.work_B), g.Npad, dtype=torch.float32, device=self.dev)
+        if k != self.topk.shape[1] or self.topk.shape[0] < B:
+            self.topk = torch.empty(max(B, self.work_B), k, dtype=torch.int32, device=self.dev)
+        full = Dims(g.N, g.H, g.Ht, g.ldh, g.ldt)
+        if getattr(self, "_ev_mw", None) is None:
+            self._ev_mw = torch.tensor(np.ascontiguousarray(self._mwdhm_full, dtype=np.int32), device=self.dev)
+        check(lib.tcar_cand_time_fwd(C.byref(full), C.byref(self._time_ptrs()), p(self._ev_mw), p(self.E), st), "tcar_cand_time_fwd")
+        self._session_forward(bt)
+        check(lib.tcar_gemm_f32(1, B, g.N, g.ek, p(self.attout), g.ek, p(self.E), g.ek, p(self.ev_logits), g.Npad, None, 0, 0, 1,
+                                st), "tcar_gemm_f32")
+        check(lib.tcar_eval_rows(B, g.N, p(self.ev_logits), g.Npad, C.c_void_p(bt.label), k, p(self.rank), p(self.topk),
+                                 p(self.ce), st), "tcar_eval_rows")
+        out = (self.rank[:B], self.topk[:B], self.ce[:B])
+        return out + (self.ev_logits[:B, :g.N].clone(),) if keep_logits else out
+
+    # ------------------------------------------------------------------------------ inspection (tests, export)
+    def export_grads(self):
+        """summed dense gradients of the last backward, reference shapes (the item rows of every shard are all-gathered)"""
+        g = self.geo
+        out = self._unpack_arena(self.G.cpu().numpy())
+        gi = torch.zeros(self.world, self.S, g.ldh, dtype=torch.float32, device=self.dev)
+        gi[self.dp_rank, :self.nl] = self.Gi
+        if self.world > 1:
+            dist.all_gather_into_tensor(gi.view(-1), gi[self.dp_rank].reshape(-1).clone(), group=self.group)
+        item = np.zeros((g.N + 1, g.H), dtype=np.float32)
+        item[1:] = gi.view(-1, g.ldh)[:g.N, :g.H].cpu().numpy()
+        out["item_emb"] = item
+        from collections import OrderedDict
+        from .engine import VAR_ORDER
+        return OrderedDict((k, out[k]) for k in VAR_ORDER)
+
+
+dp._HAVE_SHARDED = True
