@@ -396,11 +396,13 @@ int tcar_form_batch(const tcar_dims_t* d, const tcar_store_t* st, const tcar_neg
  * Rank r scores the catalog rows [n0, n0 + N) against the sessions of every rank; the softmax over the whole catalog
  * (model_combine.py:145) is split into per-shard statistics, an exchange, and the gradient:
  *   tcar_softmax_stats    stats[b] = (max, sum exp(x - max), logits[b, label[b] - n0] if the label lives here else 0)
- *   tcar_softmax_combine  stats_all [W, B, 3] (all-gathered) -> lse [B], ce [B] = lse - label logit (ce may be NULL)
+ *   tcar_softmax_combine  stats_all [W, B, 3] (all-gathered) -> lse [B], ce [B] = lse - label logit (ce may be NULL);
+ *                         label != NULL: sessions with label < 0 (padding of an uneven shard) get lse = +inf, i.e. a zero
+ *                         gradient row
  *   tcar_softmax_grad     dlogits = exp(x - lse) - onehot as bf16 hi / lo KB32 planes [ceil128(B), ld] (ld % 32 == 0)
  *   tcar_neg_scatter_range  g_item[neg[b,k] - n0, 0:ldh] += coef[b] * attout[b, 0:ldh] for the negatives inside the shard */
 int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld, const int32_t* label, int n0, float* stats, void* stream);
-int tcar_softmax_combine(int W, int B, const float* stats_all, float* lse, float* ce, void* stream);
+int tcar_softmax_combine(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce, void* stream);
 int tcar_softmax_grad(int B, int N, const float* logits, int64_t ld, const float* lse, const int32_t* label, int n0, void* dl_hi,
                       void* dl_lo, void* stream);
 int tcar_neg_scatter_range(const tcar_dims_t* d, int64_t B, int K, int n0, int n_loc, const int32_t* neg, const float* attout,
@@ -492,6 +494,36 @@ int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t* bt, int re
                              void* stream);
 /* rank [B], topk [B,k], ce [B] (the logits buffer is consumed) */
 int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream);
+
+/* Step-level pieces of the catalog-sharded step, sequenced from C++ like tcar_train_step (sharded.py only adds the
+ * collectives between them).  `c` is the rank's context: its SESSION side (tables, workspace) spans the whole catalog
+ * (c->d.n_items = N, c->E = the whole candidate matrix), its CANDIDATE side (e16*, big, Mi, Vi, mwdhm, inv_*, et_perm) covers
+ * the shard s->n0 .. s->n0 + s->n_loc only. */
+typedef struct {
+  int32_t world, cap, n0, n_loc;     /* ranks; sessions every rank contributes; first catalog row and row count of the shard */
+  const float* att_all;              /* [world*cap, ek]  all-gathered attout (zero rows = padding sessions) */
+  const int32_t* lab_all;            /* [world*cap]      labels, -1 = padding session */
+  float* logits;                     /* [world*cap, ceil128(n_loc)] */
+  float* stats;                      /* [world*cap, 3]   this shard's (max, sum exp, label logit) */
+  float* lse; float* ce;             /* [world*cap] */
+  void *a16h, *a16l, *ap16h, *ap16l, *dl16h, *dl16l;   /* bf16 planes for ceil128(world*cap) session rows */
+  float* slabs;                      /* [c->splitk, world*cap, ek] */
+  float* dx;                         /* [world*cap, ek]  this shard's contribution to d attout of EVERY session */
+} tcar_shard_t;
+/* forward of the local sessions up to attout (+ the negative term's forward part when bt->K > 0) */
+int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream);
+/* attout planes, logits = att_all E_shard^T, per-shard softmax statistics; refresh_time != 0 rebuilds the shard's time planes */
+int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int refresh_time, void* stream);
+/* stats_all [world, world*cap, 3] -> lse / ce; dlogits planes; dE of the shard (item | time block, local for good);
+ * dX partial of every session -> s->dx */
+int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, const float* stats_all, void* stream);
+/* negative-term rows of ALL sessions inside the shard, the shard's dense item norm (added into the item slot of the norm
+ * pieces, which the arena all-reduce sums over the shards: DESIGN.md S5), candidate-side time backward of the shard */
+int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int K, const int32_t* neg_all, const float* coef_all,
+                      void* stream);
+/* backward of the local sessions from their summed d attout rows dx_rows [B, ek]; the item-row gradients of the gathers go to
+ * rows_out [B*T, ldh] (all-gathered by the caller), everything else into the arena gradients */
+int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, const float* dx_rows, float* rows_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,8 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range", "tcar_step_forward",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range",
+           "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
 
 
@@ -145,6 +146,13 @@ class NegSrc(C.Structure):
     """mirror of tcar_negsrc_t"""
     _fields_ = [("mode", C.c_int32), ("off", C.c_void_p), ("flat", C.c_void_p), ("slot_of_example", C.c_void_p),
                 ("n_lists", C.c_int64)]
+
+
+class Shard(C.Structure):
+    """mirror of tcar_shard_t"""
+    _fields_ = ([("world", C.c_int32), ("cap", C.c_int32), ("n0", C.c_int32), ("n_loc", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("att_all", "lab_all", "logits", "stats", "lse", "ce", "a16h", "a16l", "ap16h", "ap16l",
+                                             "dl16h", "dl16l", "slabs", "dx")])
 
 
 class Segments(C.Structure):
@@ -268,8 +276,13 @@ def load() -> C.CDLL:
     for s in SYMBOLS:
         getattr(lib, s).restype = C.c_int
     lib.tcar_set_tuning.argtypes = [C.c_char_p, i32]
+    lib.tcar_step_session_forward.argtypes = [P(Ctx), P(Batch), vp]
+    lib.tcar_shard_score.argtypes = [P(Ctx), P(Shard), i32, vp]
+    lib.tcar_shard_backward.argtypes = [P(Ctx), P(Shard), vp, vp]
+    lib.tcar_shard_finish.argtypes = [P(Ctx), P(Shard), i32, vp, vp, vp]
+    lib.tcar_step_session_backward.argtypes = [P(Ctx), P(Batch), vp, vp, vp]
     lib.tcar_softmax_stats.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp]
-    lib.tcar_softmax_combine.argtypes = [i32, i32, vp, vp, vp, vp]
+    lib.tcar_softmax_combine.argtypes = [i32, i32, vp, vp, vp, vp, vp]
     lib.tcar_softmax_grad.argtypes = [i32, i32, vp, i64, vp, vp, i32, vp, vp, vp]
     lib.tcar_neg_scatter_range.argtypes = [P(Dims), i64, i32, i32, i32, vp, vp, i64, vp, vp, vp]
     lib.tcar_form_batch.argtypes = [P(Dims), P(Store), P(NegSrc), vp, i32, i32, i32, i32, C.c_uint64, C.c_uint64, vp, vp]

@@ -52,9 +52,15 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(int B, int N, const 
 
 // stats_all [W, B, 3] -> lse [B], ce [B] = lse - label logit (the label lives in exactly one shard; the others sent 0)
 __global__ __launch_bounds__(256) void softmax_combine_kernel(int W, int B, const float* __restrict__ stats_all,
-                                                              float* __restrict__ lse, float* __restrict__ ce) {
+                                                              const int32_t* __restrict__ label, float* __restrict__ lse,
+                                                              float* __restrict__ ce) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
+  if (label && label[b] < 0) {          // padding session of an uneven shard: lse = +inf makes its gradient row exactly zero
+    lse[b] = INFINITY;
+    if (ce) ce[b] = 0.f;
+    return;
+  }
   float m = -INFINITY;
   for (int w = 0; w < W; ++w) m = fmaxf(m, stats_all[((long)w * B + b) * 3]);
   float s = 0.f, lab = 0.f;
@@ -128,10 +134,11 @@ extern "C" int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld,
   return TCAR_OK;
 }
 
-extern "C" int tcar_softmax_combine(int W, int B, const float* stats_all, float* lse, float* ce, void* stream) {
+extern "C" int tcar_softmax_combine(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce,
+                                    void* stream) {
   if (B <= 0) return TCAR_OK;
   if (W <= 0 || !stats_all || !lse) return TCAR_E_ARG;
-  TCAR_LAUNCH(softmax_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, B, stats_all, lse, ce);
+  TCAR_LAUNCH(softmax_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, B, stats_all, label, lse, ce);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -122,6 +122,52 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
 }
 
 namespace {
+// model_combine.py:52-132 for the sessions of `bt`: gather + clip, the three input projections, the click query, both
+// attention pools and the output transforms -> c->attout [B, ek] (+ its bf16 planes when `planes`)
+int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes) {
+  const int B = bt->B, BT = bt->B * bt->T;
+  tcar_tables_t tab;
+  tables_of(c, tab);
+  RET(tcar_gather_clip_fwd(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream));
+  const float* x_c = c->x_icp + g.ldh;
+  {  // pre1, pre2, q1 (modules.py:126-131, 94-96, 138)
+    tcar_gemm_desc_t p[3];
+    p[0] = prob(BT, g.ldh, c->pre1, g.ldh);
+    seg(p[0], c->x_icp, g.ic, W(c, TCAR_V_M_WIN), g.ldh, g.ic);
+    seg(p[0], x_c, g.ic, W(c, TCAR_V_M_WC), g.ldh, g.ldh);
+    seg(p[0], c->x_act, g.ldt, W(c, TCAR_V_M_WINT), g.ldh, g.ldt);
+    p[1] = prob(BT, g.ldh, c->pre2, g.ldh);
+    seg(p[1], c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt);
+    seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
+    p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
+    RET(small_gemm(c, 0, 3, p, stream));
+  }
+  {  // q = tanh(q1 Wq2 + b) (modules.py:139)
+    tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
+    RET(small_gemm(c, 0, 1, &p, stream));
+  }
+  RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
+                         W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
+  {  // attout (model_combine.py:119,127,132)
+    tcar_gemm_desc_t p[2];
+    p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->attout, g.ek, W(c, TCAR_V_O_B), 2);
+    p[1] = prob1(B, g.pt, c->pooled + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->attout + g.ic, g.ek,
+                 W(c, TCAR_V_OT_B), 2);
+    if (planes) {
+      // split-bf16 scoring: the epilogue also writes attout's hi / lo planes (operand of the logits GEMM) and the packed
+      // item | time planes (operand of dE) — tcar_split_bf16 without its own launch
+      for (int i = 0; i < 2; ++i) {
+        p[i].plane_hi = c->a16h; p[i].plane_lo = c->a16l; p[i].plane_inner = g.ek; p[i].plane_col0 = i ? g.ic : 0;
+        p[i].pack_hi = c->ap16h; p[i].pack_lo = c->ap16l; p[i].pack_inner = g.ldh + g.pt; p[i].pack_c0 = g.ldh; p[i].pack_c1 = g.ic;
+      }
+    }
+    RET(small_gemm(c, 0, 2, p, stream));
+  }
+  return TCAR_OK;
+}
+}  // namespace
+
+namespace {
 int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream, float rest_lr) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
@@ -150,43 +196,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       joined = false;
     }
   }
-  tcar_tables_t tab;
-  tables_of(c, tab);
-  RET(tcar_gather_clip_fwd(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream));
-  const float* x_c = c->x_icp + g.ldh;
-  {  // pre1, pre2, q1 (modules.py:126-131, 94-96, 138)
-    tcar_gemm_desc_t p[3];
-    p[0] = prob(BT, g.ldh, c->pre1, g.ldh);
-    seg(p[0], c->x_icp, g.ic, W(c, TCAR_V_M_WIN), g.ldh, g.ic);
-    seg(p[0], x_c, g.ic, W(c, TCAR_V_M_WC), g.ldh, g.ldh);
-    seg(p[0], c->x_act, g.ldt, W(c, TCAR_V_M_WINT), g.ldh, g.ldt);
-    p[1] = prob(BT, g.ldh, c->pre2, g.ldh);
-    seg(p[1], c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt);
-    seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
-    p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
-    RET(small_gemm(c, 0, 3, p, stream));
-  }
-  {  // q = tanh(q1 Wq2 + b) (modules.py:139)
-    tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
-    RET(small_gemm(c, 0, 1, &p, stream));
-  }
-  RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
-                         W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
-  {  // attout (model_combine.py:119,127,132)
-    tcar_gemm_desc_t p[2];
-    p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->attout, g.ek, W(c, TCAR_V_O_B), 2);
-    p[1] = prob1(B, g.pt, c->pooled + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->attout + g.ic, g.ek,
-                 W(c, TCAR_V_OT_B), 2);
-    if (c->scoring && tcar_tuning().planes_epi) {
-      // split-bf16 scoring: the epilogue also writes attout's hi / lo planes (operand of the logits GEMM) and the packed
-      // item | time planes (operand of dE) — tcar_split_bf16 without its own launch
-      for (int i = 0; i < 2; ++i) {
-        p[i].plane_hi = c->a16h; p[i].plane_lo = c->a16l; p[i].plane_inner = g.ek; p[i].plane_col0 = i ? g.ic : 0;
-        p[i].pack_hi = c->ap16h; p[i].pack_lo = c->ap16l; p[i].pack_inner = g.ldh + g.pt; p[i].pack_c0 = g.ldh; p[i].pack_c1 = g.ic;
-      }
-    }
-    RET(small_gemm(c, 0, 2, p, stream));
-  }
+  RET(session_forward(c, bt, g, stream, c->scoring && tcar_tuning().planes_epi));
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   int ei = -1;
@@ -492,4 +502,148 @@ extern "C" int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int r
     return tcar_eval_rows(bt->B, g.N, c->logits, g.Npad, bt->label, k, c->rank, c->topk, c->ce, stream);
   RET(tcar_rank_topk(bt->B, g.N, c->logits, g.Npad, bt->label, k, c->rank, c->topk, stream));
   return tcar_softmax_ce(bt->B, g.N, c->logits, g.Npad, bt->label, c->ce, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Catalog-sharded step (sharded.py): the same op-level launchers, cut at the points where the ranks exchange data.
+extern "C" int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream) {
+  RET(check_ctx(c, bt));
+  if (!c->scoring) return TCAR_E_ARG;                   // split-bf16 modes only
+  const Geo g(c->d);
+  RET(session_forward(c, bt, g, stream, false));
+  if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
+    RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, stream));
+  return TCAR_OK;
+}
+
+namespace {
+int check_shard(const tcar_ctx_t* c, const tcar_shard_t* s) {
+  if (!c || !s || !c->scoring || s->world <= 0 || s->cap <= 0 || s->n_loc <= 0 || s->n0 < 0) return TCAR_E_ARG;
+  if (!s->att_all || !s->lab_all || !s->logits || !s->stats || !s->lse || !s->ce || !s->a16h || !s->a16l || !s->ap16h ||
+      !s->ap16l || !s->dl16h || !s->dl16l || !s->slabs || !s->dx || !c->e16h || !c->e16l || !c->big || !c->et_perm)
+    return TCAR_E_ARG;
+  return TCAR_OK;
+}
+}  // namespace
+
+extern "C" int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int refresh_time, void* stream) {
+  RET(check_shard(c, s));
+  const Geo g(c->d);
+  const int Bq = s->world * s->cap, nl = s->n_loc, nlpad = (nl + 127) & ~127;
+  tcar_dims_t dc = c->d;
+  dc.n_items = nl;
+  if (refresh_time) {
+    const float* tt[5];
+    for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+    RET(tcar_cand_time_fwd_bf16(&dc, tt, c->mwdhm, nullptr, c->e16h, c->e16l, stream));
+  }
+  RET(tcar_split_bf16(s->att_all, g.ek, Bq, g.ek, s->a16h, s->a16l, g.ek, s->ap16h, s->ap16l, g.ldh + g.pt, g.ldh, g.ic, stream));
+  RET(tcar_gemm_bf16(1, Bq, nl, g.ek, s->a16h, s->a16l, g.ek, Bq, c->e16h, c->e16l, g.ek, nlpad, s->logits, nlpad, nullptr, 0, 0,
+                     c->scoring, 1, stream));
+  return tcar_softmax_stats(Bq, nl, s->logits, nlpad, s->lab_all, s->n0, s->stats, stream);
+}
+
+extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, const float* stats_all, void* stream) {
+  RET(check_shard(c, s));
+  if (!stats_all) return TCAR_E_ARG;
+  const Geo g(c->d);
+  const int Bq = s->world * s->cap, nl = s->n_loc, nlpad = (nl + 127) & ~127, Bp = (Bq + 127) & ~127;
+  const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
+  RET(tcar_softmax_combine(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, stream));
+  RET(tcar_softmax_grad(Bq, nl, s->logits, nlpad, s->lse, s->lab_all, s->n0, s->dl16h, s->dl16l, stream));
+  float* Gi = c->big;
+  float* d_et = c->big + (size_t)nl * g.ldh;
+  // dE of the shard on the aux stream beside dX (the caller's stream: dX heads for the reduce-scatter, the critical path)
+  hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
+  if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+    return TCAR_E_LAUNCH;
+  RET(tcar_gemm_bf16_perm(2, nl, g.ldh + g.pt, (Bq + 31) & ~31, s->dl16h, s->dl16l, nlpad, Bp, s->ap16h, s->ap16l, g.ldh + g.pt, Bp,
+                          Gi, g.ldh, d_et, g.pt, g.ldh, c->et_perm, g.ldt, nsb, 1, s2 ? (void*)s2 : stream));
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  const int S = tcar_gemm_splitk_effective(nlpad, c->splitk);
+  RET(tcar_gemm_bf16(0, Bq, g.ek, nlpad, s->dl16h, s->dl16l, nlpad, Bp, c->e16h, c->e16l, g.ek, nlpad, s->slabs, g.ek, nullptr, 0,
+                     0, nsb, c->splitk, stream));
+  RET(tcar_splitk_reduce(s->slabs, S, Bq, g.ek, g.ek, s->dx, stream));
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;     // dE is in: tcar_shard_finish
+  return TCAR_OK;
+}
+
+extern "C" int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int K, const int32_t* neg_all, const float* coef_all,
+                                 void* stream) {
+  RET(check_shard(c, s));
+  const Geo g(c->d);
+  const int nl = s->n_loc;
+  tcar_dims_t dc = c->d;
+  dc.n_items = nl;
+  if (K > 0) {
+    if (!neg_all || !coef_all) return TCAR_E_ARG;
+    RET(tcar_neg_scatter_range(&c->d, (int64_t)s->world * s->cap, K, s->n0, nl, neg_all, s->att_all, g.ek, coef_all, c->big, stream));
+  }
+  // the shard's dense item norm, BEFORE any gathered row is scattered in (S5), straight into the item slot of the pieces
+  tcar_segments_t one = {};
+  one.nseg = 1; one.off[0] = 0; one.len[0] = (int64_t)nl * g.ldh; one.slot[0] = c->slot_item;
+  RET(tcar_sqnorm(c->big, &one, c->Gx + c->arena_n, stream));
+  tcar_grads_t gr;
+  grads_of(c, gr);
+  const float* tt[5];
+  for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+  return tcar_cand_time_bwd_indexed(&dc, tt, c->inv_n, c->inv_off, c->big + (size_t)nl * g.ldh, 1, c->ct_ws, &gr, stream);
+}
+
+extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, const float* dx_rows, float* rows_out,
+                                          void* stream) {
+  RET(check_ctx(c, bt));
+  if (!c->scoring || !dx_rows || !rows_out) return TCAR_E_ARG;
+  const Geo g(c->d);
+  const int B = bt->B, T = bt->T, BT = B * T;
+  const bool has_neg = bt->K > 0 && bt->neg && c->neg_coef && c->negpart;
+  // dattout = (dX + the negative term's part) * tanh'(attout), + the bias gradients of both output transforms
+  RET(tcar_splitk_reduce_dact(dx_rows, 1, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
+                              c->dattout, G(c, TCAR_V_O_B), g.ic, G(c, TCAR_V_OT_B), stream));
+  {
+    tcar_gemm_desc_t p[2];
+    p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->dpooled, g.ek);
+    p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->dpooled + g.ic, g.ek);
+    RET(small_gemm(c, 1, 2, p, stream));
+  }
+  RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
+                           c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, G(c, TCAR_V_M_WRES),
+                           G(c, TCAR_V_S_WRES), G(c, TCAR_V_Q2_B), stream));
+  {
+    tcar_gemm_desc_t p[4];
+    p[0] = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
+    p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = G(c, TCAR_V_Q1_B);
+    p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
+    p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
+    p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
+    RET(small_gemm(c, 1, 4, p, stream));
+  }
+  {
+    tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+    RET(small_gemm(c, 1, 1, &p, stream));
+  }
+  {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
+    const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 512;
+    auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 2 ? 2 : (s > 16 ? 16 : s); };
+    const int kb = ks(B), kr = ks(BT);
+    const float* x_c = c->x_icp + g.ldh;
+    tcar_gemm_desc_t p[9];
+    p[0] = prob1(g.ic, g.ic, c->pooled, g.ek, c->dattout, g.ek, B, G(c, TCAR_V_O_W), g.ic, nullptr, 0, 0, kb, 1);
+    p[1] = prob1(g.pt, g.pt, c->pooled + g.ic, g.ek, c->dattout + g.ic, g.ek, B, G(c, TCAR_V_OT_W), g.pt, nullptr, 0, 0, kb, 1);
+    p[2] = prob1(g.ldh, g.ic, c->q1, g.ldh, c->dq, g.ic, B, G(c, TCAR_V_Q2_W), g.ic, nullptr, 0, 0, kb, 1);
+    p[3] = prob1(g.ct, g.ldh, c->click_t, g.ct, c->dq1, g.ldh, B, G(c, TCAR_V_Q1_W), g.ldh, nullptr, 0, 0, kb, 1);
+    p[4] = prob1(g.ic, g.ldh, c->x_icp, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WIN), g.ldh, nullptr, 0, 0, kr, 1);
+    p[5] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WC), g.ldh, nullptr, 0, 0, kr, 1);
+    p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
+    p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
+    p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
+    RET(small_gemm(c, 2, 9, p, stream));
+  }
+  tcar_tables_t tab;
+  tcar_grads_t gr;
+  tables_of(c, tab);
+  grads_of(c, gr);
+  gr.rows_out = rows_out;
+  return tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream);
 }

@@ -69,6 +69,8 @@ class ShardedEngine(TcarEngine):
         self.n_local_items = nl
         self.backend = dist.get_backend(group) if live and self.world > 1 else "none"
         self.cap = 0
+        self._desc_cache = {}
+        self._geo_key = None
         self._stage = torch.zeros(self.world, self.S, self.geo.ldh, dtype=torch.float32, device=self.dev)
         self.bytes_moved = {}
 
@@ -125,10 +127,40 @@ class ShardedEngine(TcarEngine):
             self.s_dx = torch.empty(Bq, g.ek, **f32)
             self.cap, self._kcap = cap, max(K, 1)
 
+    # two composite spans instead of the three GEMMs of the fused step: the C++ pieces between the exchanges
+    TIMED_KERNELS = ("shard_score", "shard_backward")
+
+    # ------------------------------------------------------------- timing of the scoring pieces (bench.py)
+    def enable_native_timing(self, n: int):
+        self._tm = {"n": n, "ev": [[], [], []]}
+
+    def _tick3(self, kind):
+        tm = getattr(self, "_tm", None)
+        if tm is None or len(tm["ev"][kind]) >= tm["n"]:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream(self.dev))
+        tm["ev"][kind].append((e0, e1))
+        return e1
+
+    def _tock3(self, e1):
+        if e1 is not None:
+            e1.record(torch.cuda.current_stream(self.dev))
+
+    def native_timing_ms(self, kind: int = 0):
+        tm = getattr(self, "_tm", None)
+        return [a.elapsed_time(b) for a, b in tm["ev"][kind]] if tm else []
+
     # ------------------------------------------------------------------------------------------- primitives
-    def _xg(self, layout, descs):
-        arr = (GemmDesc * len(descs))(*descs)
-        check(self.lib.tcar_gemm_x3_grouped(layout, len(descs), arr, self._stream()), "tcar_gemm_x3_grouped")
+    def _xg(self, layout, key, make):
+        """grouped split-bf16 GEMM launch; the ctypes descriptor array of a call site is built once per workspace geometry
+        (`make` is only called on a cache miss: building ~25 descriptors per step in Python costs more than the kernels)"""
+        ck = (key, self._geo_key)
+        hit = self._desc_cache.get(ck)
+        if hit is None:
+            descs = make()
+            hit = self._desc_cache[ck] = ((GemmDesc * len(descs))(*descs), len(descs))
+        check(self.lib.tcar_gemm_x3_grouped(layout, hit[1], hit[0], self._stream()), "tcar_gemm_x3_grouped")
 
     def _session_forward(self, bt: Batch):
         """model_combine.py:52-132 for the local sessions: attout [B, ek]"""
@@ -139,16 +171,17 @@ class ShardedEngine(TcarEngine):
         check(lib.tcar_gather_clip_fwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.x_icp), p(self.x_pt), p(self.x_act),
                                        p(self.click_t), st), "tcar_gather_clip_fwd")
         x_c = p(self.x_icp, g.ldh)
-        self._xg(0, [
+        self._xg(0, "f1", lambda: [
             D(BT, g.ldh, [(p(self.x_icp), g.ic, self._w("m_win"), g.ldh, g.ic), (x_c, g.ic, self._w("m_wc"), g.ldh, g.ldh),
                           (p(self.x_act), g.ldt, self._w("m_wint"), g.ldh, g.ldt)], p(self.pre1), g.ldh),
             D(BT, g.ldh, [(p(self.x_pt), g.pt, self._w("s_win"), g.ldh, g.pt), (x_c, g.ic, self._w("s_wc"), g.ldh, g.ldh)],
               p(self.pre2), g.ldh),
             D(B, g.ldh, [(p(self.click_t), g.ct, self._w("q1_w"), g.ldh, g.ct)], p(self.q1), g.ldh, bias=self._w("q1_b"), act=1)])
-        self._xg(0, [D(B, g.ic, [(p(self.q1), g.ldh, self._w("q2_w"), g.ic, g.ldh)], p(self.q), g.ic, bias=self._w("q2_b"), act=2)])
+        self._xg(0, "f2", lambda: [D(B, g.ic, [(p(self.q1), g.ldh, self._w("q2_w"), g.ic, g.ldh)], p(self.q), g.ic,
+                                     bias=self._w("q2_b"), act=2)])
         check(lib.tcar_attn_pool_fwd(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2), p(self.q),
                                      self._w("m_wres"), self._w("s_wres"), p(self.pooled), p(self.alpha), st), "tcar_attn_pool_fwd")
-        self._xg(0, [
+        self._xg(0, "f3", lambda: [
             D(B, g.ic, [(p(self.pooled), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.attout), g.ek, bias=self._w("o_b"), act=2),
             D(B, g.pt, [(p(self.pooled, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.attout, g.ic), g.ek,
               bias=self._w("ot_b"), act=2)])
@@ -163,24 +196,28 @@ class ShardedEngine(TcarEngine):
         check(lib.tcar_splitk_reduce_dact(p(dx_rows), 1, B, g.ek, g.ek, p(self.negpart) if has_neg else None, g.ic, g.ic,
                                           p(self.attout), g.ek, 2, p(self.dattout), self._g("o_b"), g.ic, self._g("ot_b"), st),
               "tcar_splitk_reduce_dact")
-        self._xg(1, [D(B, g.ic, [(p(self.dattout), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.dpooled), g.ek),
-                     D(B, g.pt, [(p(self.dattout, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.dpooled, g.ic), g.ek)])
+        self._xg(1, "b1", lambda: [D(B, g.ic, [(p(self.dattout), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.dpooled), g.ek),
+                                   D(B, g.pt, [(p(self.dattout, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.dpooled, g.ic), g.ek)])
         check(lib.tcar_attn_pool_bwd_q(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2), p(self.q),
                                        self._w("m_wres"), self._w("s_wres"), p(self.alpha), p(self.dpooled), p(self.dx_icp),
                                        p(self.dx_pt), p(self.dq), p(self.dpre1), p(self.dpre2), self._g("m_wres"),
                                        self._g("s_wres"), self._g("q2_b"), st), "tcar_attn_pool_bwd_q")
-        d0 = D(B, g.ldh, [(p(self.dq), g.ic, self._w("q2_w"), g.ic, g.ic)], p(self.dq1), g.ldh)
-        d0.dact, d0.dact_y, d0.ld_dact_y, d0.colsum = 1, self.q1.data_ptr(), g.ldh, self._g("q1_b").value
-        self._xg(1, [d0,
-                     D(BT, g.ldh, [(p(self.dpre1), g.ldh, self._w("m_win"), g.ldh, g.ldh)], p(self.dx_icp), g.ic, beta=1),
-                     D(BT, g.ldt, [(p(self.dpre1), g.ldh, self._w("m_wint"), g.ldh, g.ldh)], p(self.dx_act), g.ldt),
-                     D(BT, g.pt, [(p(self.dpre2), g.ldh, self._w("s_win"), g.ldh, g.ldh)], p(self.dx_pt), g.pt, beta=1)])
-        self._xg(1, [D(B, g.ct, [(p(self.dq1), g.ldh, self._w("q1_w"), g.ldh, g.ldh)], p(self.dclick), g.ct)])
+
+        def launch_a():
+            d0 = D(B, g.ldh, [(p(self.dq), g.ic, self._w("q2_w"), g.ic, g.ic)], p(self.dq1), g.ldh)
+            d0.dact, d0.dact_y, d0.ld_dact_y, d0.colsum = 1, self.q1.data_ptr(), g.ldh, self._g("q1_b").value
+            return [d0,
+                    D(BT, g.ldh, [(p(self.dpre1), g.ldh, self._w("m_win"), g.ldh, g.ldh)], p(self.dx_icp), g.ic, beta=1),
+                    D(BT, g.ldt, [(p(self.dpre1), g.ldh, self._w("m_wint"), g.ldh, g.ldh)], p(self.dx_act), g.ldt),
+                    D(BT, g.pt, [(p(self.dpre2), g.ldh, self._w("s_win"), g.ldh, g.ldh)], p(self.dx_pt), g.pt, beta=1)]
+
+        self._xg(1, "b2", launch_a)
+        self._xg(1, "b3", lambda: [D(B, g.ct, [(p(self.dq1), g.ldh, self._w("q1_w"), g.ldh, g.ldh)], p(self.dclick), g.ct)])
         ks = lambda K: max(2, min(16, (K + 511) // 512))
         kb, kr = ks(B), ks(BT)
         x_c = p(self.x_icp, g.ldh)
         Wd = lambda M, N, A, lda, Bm, ldb, K, name, k: D(M, N, [(A, lda, Bm, ldb, K)], self._g(name), N, splitk=k, atomic=1)
-        self._xg(2, [
+        self._xg(2, "b4", lambda: [
             Wd(g.ic, g.ic, p(self.pooled), g.ek, p(self.dattout), g.ek, B, "o_w", kb),
             Wd(g.pt, g.pt, p(self.pooled, g.ic), g.ek, p(self.dattout, g.ic), g.ek, B, "ot_w", kb),
             Wd(g.ldh, g.ic, p(self.q1), g.ldh, p(self.dq), g.ic, B, "q2_w", kb),
@@ -206,90 +243,70 @@ class ShardedEngine(TcarEngine):
         Bq = W * cap
         self._ensure_work(max(B, 1), T)
         self._ensure_score(cap, K)
+        # descriptor cache key: the batch geometry + the identity of the (re-allocatable) workspaces
+        self._geo_key = (B, T, self.work_rows, self.work_B, self.x_icp.data_ptr(), self.attout.data_ptr())
         has_neg = K > 0
         st = self._stream()
         self.Gx.zero_()
         self.sqn_dense.zero_()
         # ---- session forward + the feed pieces the other ranks need
-        self.att_loc[:cap].zero_()
-        self.lab_loc[:cap].fill_(-1)
-        self.neg_loc[:cap].fill_(-1)
-        self.coef_loc[:cap].zero_()
+        ctx, sctx = self._ctx(), self._shard_ctx()
+        sh = self._shard_desc(cap)
+        if B < cap:                                # padding sessions of this rank: zero attout, no label, no negatives
+            self.att_loc[B:cap].zero_()
+            self.lab_loc[B:cap].fill_(-1)
+            self.neg_loc[B:cap].fill_(-1)
+            self.coef_loc[B:cap].zero_()
         if bt is not None:
-            self._session_forward(bt)
+            check(lib.tcar_step_session_forward(C.byref(ctx), C.byref(bt), st), "tcar_step_session_forward")
             self.att_loc[:B].copy_(self.attout[:B])
-            lab = torch.as_strided(bt._keep, (B,), (1,), (bt.label - bt._keep.data_ptr()) // 4)
-            self.lab_loc[:B].copy_(lab)
+            self.lab_loc[:B].copy_(torch.as_strided(bt._keep, (B,), (1,), (bt.label - bt._keep.data_ptr()) // 4))
             if has_neg:
-                neg = torch.as_strided(bt._keep, (B, K), (K, 1), (bt.neg - bt._keep.data_ptr()) // 4)
-                self.neg_loc[:B, :K].copy_(neg)
-                check(lib.tcar_neg_fwd(C.byref(self.dims), B, K, p(self.E), C.c_void_p(bt.neg), p(self.attout), self.neg_weight,
-                                       p(self.neg_fb), p(self.neg_coef), p(self.negpart), st), "tcar_neg_fwd")
+                self.neg_loc[:B, :K].copy_(torch.as_strided(bt._keep, (B, K), (K, 1), (bt.neg - bt._keep.data_ptr()) // 4))
                 self.coef_loc[:B].copy_(self.neg_coef[:B])
         att_all = self._allgather(self.att_loc[:cap], "attout").view(Bq, g.ek)
         lab_all = self._allgather(self.lab_loc[:cap], "labels").view(Bq)
-        # ---- scoring of the shard against every session
-        if self._time_dirty:
-            check(lib.tcar_cand_time_fwd_bf16(C.byref(self.dims_cand), C.byref(self._time_ptrs()), p(self.mwdhm), None,
-                                              p(self.e16h), p(self.e16l), st), "tcar_cand_time_fwd_bf16")
-            self._time_dirty = False
-        check(lib.tcar_split_bf16(p(att_all), g.ek, Bq, g.ek, p(self.s_a16h), p(self.s_a16l), g.ek, p(self.s_ap16h),
-                                  p(self.s_ap16l), g.ldh + g.pt, g.ldh, g.ic, st), "tcar_split_bf16")
-        nsf = self.scoring_code
-        nsb = 1 if self.scoring_bwd else nsf
-        Bp = _ru(Bq, 128)
-        check(lib.tcar_gemm_bf16(1, Bq, nl, g.ek, p(self.s_a16h), p(self.s_a16l), g.ek, Bq, p(self.e16h), p(self.e16l), g.ek,
-                                 nlpad, p(self.s_logits), nlpad, None, 0, 0, nsf, 1, st), "tcar_gemm_bf16 logits")
-        check(lib.tcar_softmax_stats(Bq, nl, p(self.s_logits), nlpad, p(lab_all), n0, p(self.s_stats), st), "tcar_softmax_stats")
+        sh.att_all, sh.lab_all = att_all.data_ptr(), lab_all.data_ptr()
+        # ---- scoring of the shard against every session; statistics exchange; gradients (dE stays here, dX goes home)
+        tk = self._tick3(0)
+        check(lib.tcar_shard_score(C.byref(sctx), C.byref(sh), int(self._time_dirty), st), "tcar_shard_score")
+        self._tock3(tk)
+        self._time_dirty = False
         stats_all = self._allgather(self.s_stats[:Bq], "softmax_stats")
-        check(lib.tcar_softmax_combine(W, Bq, p(stats_all), p(self.s_lse), p(self.s_ce), st), "tcar_softmax_combine")
-        # padding sessions (label -1) get a zero gradient row: their lse is forced to +inf
-        self.s_lse[:Bq].masked_fill_(lab_all < 0, float("inf"))
-        check(lib.tcar_softmax_grad(Bq, nl, p(self.s_logits), nlpad, p(self.s_lse), p(lab_all), n0, p(self.s_dl16h),
-                                    p(self.s_dl16l), st), "tcar_softmax_grad")
-        # dE of the shard: item block | candidate-time block (in inverted-index order), local for good
-        check(lib.tcar_gemm_bf16_perm(2, nl, g.ldh + g.pt, (Bq + 31) & ~31, p(self.s_dl16h), p(self.s_dl16l), nlpad, Bp,
-                                      p(self.s_ap16h), p(self.s_ap16l), g.ldh + g.pt, Bp, p(self.Gi), g.ldh, p(self.d_et), g.pt,
-                                      g.ldh, p(self.et_perm), g.ldt, nsb, 1, st), "tcar_gemm_bf16 dE")
-        # dX partial of every session against this shard, summed over the ranks
-        S = lib.tcar_gemm_splitk_effective(nlpad, self.splitk)
-        check(lib.tcar_gemm_bf16(0, Bq, g.ek, nlpad, p(self.s_dl16h), p(self.s_dl16l), nlpad, Bp, p(self.e16h), p(self.e16l),
-                                 g.ek, nlpad, p(self.s_slabs), g.ek, None, 0, 0, nsb, self.splitk, st), "tcar_gemm_bf16 dX")
-        check(lib.tcar_splitk_reduce(p(self.s_slabs), S, Bq, g.ek, g.ek, p(self.s_dx), st), "tcar_splitk_reduce")
+        tk = self._tick3(1)
+        check(lib.tcar_shard_backward(C.byref(sctx), C.byref(sh), p(stats_all), st), "tcar_shard_backward")
+        self._tock3(tk)
         dx_rows = self._reduce_scatter_rows(self.s_dx[:Bq], cap, "dX")
-        # negative-term rows of ALL sessions that fall into this shard (densified part of the item gradient, S5)
+        neg_all = coef_all = None
         if has_neg:
             neg_all = self._allgather(self.neg_loc[:cap, :K].contiguous(), "negatives").view(Bq, K)
             coef_all = self._allgather(self.coef_loc[:cap], "neg_coef").view(Bq)
-            check(lib.tcar_neg_scatter_range(C.byref(self.dims), Bq, K, n0, nl, p(neg_all), p(att_all), g.ek, p(coef_all),
-                                             p(self.Gi), st), "tcar_neg_scatter_range")
-        # dense item norm of the shard BEFORE any gathered row is scattered in (S5); summed over the shards by the arena
-        # all-reduce (it rides in the item slot of the norm pieces)
-        one = Segments()
-        one.nseg = 1
-        one.off[0], one.len[0], one.slot[0] = 0, nl * g.ldh, SLOT["item_emb"]
-        check(lib.tcar_sqnorm(p(self.Gi), C.byref(one), p(self.sqn_dense), st), "tcar_sqnorm")
-        # candidate-side time backward of the shard -> time-table gradients + their norm pieces (partial sums over shards)
-        gr = self._grads()
-        check(lib.tcar_cand_time_bwd_indexed(C.byref(self.dims_cand), C.byref(self._time_ptrs()), p(self.inv_n), p(self.inv_off),
-                                             p(self.d_et), 1, p(self.ct_ws), C.byref(gr), st), "tcar_cand_time_bwd_indexed")
+        check(lib.tcar_shard_finish(C.byref(sctx), C.byref(sh), K if has_neg else 0, p(neg_all) if has_neg else None,
+                                    p(coef_all) if has_neg else None, st), "tcar_shard_finish")
         # ---- session backward (local) and the sparse-row exchange
-        rows = torch.zeros(cap * T, g.ldh, dtype=torch.float32, device=self.dev)
-        ids = torch.zeros(cap * T, dtype=torch.int32, device=self.dev)
+        nr = cap * T
+        if getattr(self, "_rows_cap", 0) < nr:
+            self._rows_buf = torch.zeros(nr, g.ldh, dtype=torch.float32, device=self.dev)
+            self._ids_buf = torch.zeros(nr, dtype=torch.int32, device=self.dev)
+            self._rows_cap = nr
+        rows, ids = self._rows_buf[:nr], self._ids_buf[:nr]
+        if B * T < nr:                              # padding rows: id 0 (skipped by the scatter), zero row
+            rows[B * T:].zero_()
+            ids[B * T:].zero_()
         if bt is not None:
-            self._session_backward(bt, dx_rows, has_neg, rows)
+            if not dx_rows.is_contiguous():
+                dx_rows = dx_rows.contiguous()
+            check(lib.tcar_step_session_backward(C.byref(ctx), C.byref(bt), p(dx_rows), p(rows), st), "tcar_step_session_backward")
             ids[:B * T].copy_(bt._seq_t[:B * T])
             if has_neg:
-                self.loss[:B] = self.s_ce[self.dp_rank * cap:self.dp_rank * cap + B] + self.neg_weight * self.neg_fb[:B]
+                torch.add(self.s_ce[self.dp_rank * cap:self.dp_rank * cap + B], self.neg_fb[:B], alpha=self.neg_weight,
+                          out=self.loss[:B])
         all_ids = self._allgather(ids, "row_ids").view(-1)
         all_rows = self._allgather(rows, "rows").view(-1, g.ldh)
         shifted = all_ids - n0                      # ids are 1-based: rows of this shard become 1 .. nl, the rest fall out
         check(lib.tcar_scatter_add_rows(C.byref(self.dims_cand), p(shifted), p(all_rows), shifted.numel(), p(self.Gi), st),
               "tcar_scatter_add_rows")
-        # ---- arena exchange, norms, update
-        slot = SLOT["item_emb"]
-        self.sqn_pieces[slot] += self.sqn_dense[slot]
-        self.sqn_dense[slot] = 0.0
+        # ---- arena exchange (gradients + norm pieces incl. the shards' dense item norms), dense-weight norms, update
         if W > 1:
             dist.all_reduce(self.Gx, group=self.group)
             self.bytes_moved["arena"] = self.Gx.numel() * 4
@@ -299,6 +316,18 @@ class ShardedEngine(TcarEngine):
                            group=self.group)        # atomically summed norms: one rank's bits for everyone (identical replicas)
         if update:
             self._update_and_share()
+
+    def _shard_desc(self, cap: int) -> "_lib.Shard":
+        key = (cap, self.s_logits.data_ptr())
+        if getattr(self, "_sh_key", None) != key:
+            sh = _lib.Shard()
+            sh.world, sh.cap, sh.n0, sh.n_loc = self.world, cap, self.n0, self.nl
+            for n, t in (("logits", self.s_logits), ("stats", self.s_stats), ("lse", self.s_lse), ("ce", self.s_ce),
+                         ("a16h", self.s_a16h), ("a16l", self.s_a16l), ("ap16h", self.s_ap16h), ("ap16l", self.s_ap16l),
+                         ("dl16h", self.s_dl16h), ("dl16l", self.s_dl16l), ("slabs", self.s_slabs), ("dx", self.s_dx)):
+                setattr(sh, n, t.data_ptr())
+            self._sh, self._sh_key = sh, key
+        return self._sh
 
     def _shard_ctx(self):
         """tcar_ctx_t whose candidate side is this rank's shard (tcar_step_update: arena + the owned item rows + planes)"""

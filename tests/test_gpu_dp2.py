@@ -95,9 +95,11 @@ def _cli_worker(rank, world, port, argv, ret):
         ret[rank] = "FAIL: " + repr(e) + "\n" + traceback.format_exc()
 
 
-def test_cli_two_ranks_shard_batches_and_agree_with_one_rank():
-    """main.py --gpus 2: both ranks form the same batches, train on their contiguous shards (DPEngine) and evaluate their
-    shards; the all-reduced metrics equal the single-process run's up to float-atomic noise."""
+@pytest.mark.parametrize("extra", [[], ["--dp_mode", "sharded"], ["--dp_mode", "sharded", "--device_sampler", "1"]])
+def test_cli_two_ranks_shard_batches_and_agree_with_one_rank(extra):
+    """main.py --gpus 2: both ranks form the same batches, train on their contiguous shards (DPEngine, or the catalog-sharded
+    ShardedEngine with --dp_mode sharded) and evaluate their shards; the all-reduced metrics equal the single-process run's
+    up to float-atomic noise."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import io
@@ -107,7 +109,7 @@ def test_cli_two_ranks_shard_batches_and_agree_with_one_rank():
             "--hidden_size", "48", "--time_hidden_size", "16", "--batch_size", "128", "--gap_mode", "click_delta"]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_cli_worker, args=(2, _free_port(), argv, ret), nprocs=2, join=True)
+    mp.spawn(_cli_worker, args=(2, _free_port(), argv + extra, ret), nprocs=2, join=True)
     for r in range(2):
         assert isinstance(ret.get(r), dict), ret.get(r)
     assert ret[0] == ret[1]                                   # every rank reports the same all-reduced numbers
@@ -117,6 +119,7 @@ def test_cli_two_ranks_shard_batches_and_agree_with_one_rank():
         one = main(argv)
     m1, m2 = one.last_metrics, ret[0]
     assert m2["sessions"] == one.train_sessions               # every session was trained on exactly once
-    assert abs(m1["loss"] - m2["loss"]) <= 2e-3 * abs(m1["loss"])
+    dev_neg = "--device_sampler" in extra                     # other negative stream than the host-sampled reference run
+    assert abs(m1["loss"] - m2["loss"]) <= (2e-2 if dev_neg else 2e-3) * abs(m1["loss"])
     for k in ("recall", "mrr", "ndcg"):
-        assert abs(m1[k] - m2[k]) <= 0.01, (k, m1[k], m2[k])
+        assert abs(m1[k] - m2[k]) <= (0.03 if dev_neg else 0.01), (k, m1[k], m2[k])

@@ -52,8 +52,8 @@ def test_single_rank_sharded_path_matches_oracle(K):
     for _ in range(2):
         close(eng.train_step(batch).cpu().numpy(), ora.train_step(batch).numpy(), name="train loss")
     p_e, p_o = eng.export_params(), ora.export()
-    for k in p_o:
-        close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-4)
+    for k in p_o:      # two Adam steps at lr 1e-3: a rounding-level gradient coordinate may move by up to ~2e-3 * |w| scale
+        close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-3)
     rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
     lo, ce_o = ora.eval_batch(batch)
     close(logits.cpu().numpy(), lo.numpy(), name="eval logits", atol_scale=1e-4)
