@@ -23,8 +23,8 @@ received, against 2 x 106 MB through the replica all-reduce; the candidate-side 
 at this size, 130 GB at 10 M items) divides by W.  The clip semantics of DESIGN.md S5 hold exactly: the dense item norm is
 the sum of the shards' norms of (scoring + densified negative part), taken BEFORE the gathered rows are scattered in.
 
-Python-sequenced over the op-level C-ABI (the fused single-rank driver, csrc/step.hip, cannot be cut at the exchange points);
-split-bf16 scoring modes only.  Evaluation scores the local sessions against the whole catalog on the fp32 GEMM.
+Sequenced from C++ between the exchanges (csrc/step.hip: tcar_step_session_forward / tcar_shard_score / tcar_shard_backward /
+tcar_shard_finish / tcar_step_session_backward), the collectives in between from here; split-bf16 scoring modes only.  Evaluation scores the local sessions against the whole catalog on the fp32 GEMM.
 """
 from __future__ import annotations
 
@@ -69,8 +69,6 @@ class ShardedEngine(TcarEngine):
         self.n_local_items = nl
         self.backend = dist.get_backend(group) if live and self.world > 1 else "none"
         self.cap = 0
-        self._desc_cache = {}
-        self._geo_key = None
         self._stage = torch.zeros(self.world, self.S, self.geo.ldh, dtype=torch.float32, device=self.dev)
         self.bytes_moved = {}
 
@@ -151,87 +149,6 @@ class ShardedEngine(TcarEngine):
         tm = getattr(self, "_tm", None)
         return [a.elapsed_time(b) for a, b in tm["ev"][kind]] if tm else []
 
-    # ------------------------------------------------------------------------------------------- primitives
-    def _xg(self, layout, key, make):
-        """grouped split-bf16 GEMM launch; the ctypes descriptor array of a call site is built once per workspace geometry
-        (`make` is only called on a cache miss: building ~25 descriptors per step in Python costs more than the kernels)"""
-        ck = (key, self._geo_key)
-        hit = self._desc_cache.get(ck)
-        if hit is None:
-            descs = make()
-            hit = self._desc_cache[ck] = ((GemmDesc * len(descs))(*descs), len(descs))
-        check(self.lib.tcar_gemm_x3_grouped(layout, hit[1], hit[0], self._stream()), "tcar_gemm_x3_grouped")
-
-    def _session_forward(self, bt: Batch):
-        """model_combine.py:52-132 for the local sessions: attout [B, ek]"""
-        g, lib, st, p, D = self.geo, self.lib, self._stream(), self._p, self.desc
-        B, T = bt.B, bt.T
-        BT = B * T
-        tab = self._tables()
-        check(lib.tcar_gather_clip_fwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.x_icp), p(self.x_pt), p(self.x_act),
-                                       p(self.click_t), st), "tcar_gather_clip_fwd")
-        x_c = p(self.x_icp, g.ldh)
-        self._xg(0, "f1", lambda: [
-            D(BT, g.ldh, [(p(self.x_icp), g.ic, self._w("m_win"), g.ldh, g.ic), (x_c, g.ic, self._w("m_wc"), g.ldh, g.ldh),
-                          (p(self.x_act), g.ldt, self._w("m_wint"), g.ldh, g.ldt)], p(self.pre1), g.ldh),
-            D(BT, g.ldh, [(p(self.x_pt), g.pt, self._w("s_win"), g.ldh, g.pt), (x_c, g.ic, self._w("s_wc"), g.ldh, g.ldh)],
-              p(self.pre2), g.ldh),
-            D(B, g.ldh, [(p(self.click_t), g.ct, self._w("q1_w"), g.ldh, g.ct)], p(self.q1), g.ldh, bias=self._w("q1_b"), act=1)])
-        self._xg(0, "f2", lambda: [D(B, g.ic, [(p(self.q1), g.ldh, self._w("q2_w"), g.ic, g.ldh)], p(self.q), g.ic,
-                                     bias=self._w("q2_b"), act=2)])
-        check(lib.tcar_attn_pool_fwd(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2), p(self.q),
-                                     self._w("m_wres"), self._w("s_wres"), p(self.pooled), p(self.alpha), st), "tcar_attn_pool_fwd")
-        self._xg(0, "f3", lambda: [
-            D(B, g.ic, [(p(self.pooled), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.attout), g.ek, bias=self._w("o_b"), act=2),
-            D(B, g.pt, [(p(self.pooled, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.attout, g.ic), g.ek,
-              bias=self._w("ot_b"), act=2)])
-
-    def _session_backward(self, bt: Batch, dx_rows: torch.Tensor, has_neg: bool, rows_out: torch.Tensor):
-        """from the summed dX rows of the local sessions to every rank-local gradient (the sequence of csrc/step.hip's
-        backward, split-bf16 branch); the item-row gradients of the gathers go to rows_out [B*T, ldh]"""
-        g, lib, st, p, D = self.geo, self.lib, self._stream(), self._p, self.desc
-        B, T = bt.B, bt.T
-        BT = B * T
-        # dattout = (dX + the negative term's part) * tanh'(attout), plus the bias gradients of both output transforms
-        check(lib.tcar_splitk_reduce_dact(p(dx_rows), 1, B, g.ek, g.ek, p(self.negpart) if has_neg else None, g.ic, g.ic,
-                                          p(self.attout), g.ek, 2, p(self.dattout), self._g("o_b"), g.ic, self._g("ot_b"), st),
-              "tcar_splitk_reduce_dact")
-        self._xg(1, "b1", lambda: [D(B, g.ic, [(p(self.dattout), g.ek, self._w("o_w"), g.ic, g.ic)], p(self.dpooled), g.ek),
-                                   D(B, g.pt, [(p(self.dattout, g.ic), g.ek, self._w("ot_w"), g.pt, g.pt)], p(self.dpooled, g.ic), g.ek)])
-        check(lib.tcar_attn_pool_bwd_q(C.byref(self.dims), B, T, p(self.x_icp), p(self.x_pt), p(self.pre1), p(self.pre2), p(self.q),
-                                       self._w("m_wres"), self._w("s_wres"), p(self.alpha), p(self.dpooled), p(self.dx_icp),
-                                       p(self.dx_pt), p(self.dq), p(self.dpre1), p(self.dpre2), self._g("m_wres"),
-                                       self._g("s_wres"), self._g("q2_b"), st), "tcar_attn_pool_bwd_q")
-
-        def launch_a():
-            d0 = D(B, g.ldh, [(p(self.dq), g.ic, self._w("q2_w"), g.ic, g.ic)], p(self.dq1), g.ldh)
-            d0.dact, d0.dact_y, d0.ld_dact_y, d0.colsum = 1, self.q1.data_ptr(), g.ldh, self._g("q1_b").value
-            return [d0,
-                    D(BT, g.ldh, [(p(self.dpre1), g.ldh, self._w("m_win"), g.ldh, g.ldh)], p(self.dx_icp), g.ic, beta=1),
-                    D(BT, g.ldt, [(p(self.dpre1), g.ldh, self._w("m_wint"), g.ldh, g.ldh)], p(self.dx_act), g.ldt),
-                    D(BT, g.pt, [(p(self.dpre2), g.ldh, self._w("s_win"), g.ldh, g.ldh)], p(self.dx_pt), g.pt, beta=1)]
-
-        self._xg(1, "b2", launch_a)
-        self._xg(1, "b3", lambda: [D(B, g.ct, [(p(self.dq1), g.ldh, self._w("q1_w"), g.ldh, g.ldh)], p(self.dclick), g.ct)])
-        ks = lambda K: max(2, min(16, (K + 511) // 512))
-        kb, kr = ks(B), ks(BT)
-        x_c = p(self.x_icp, g.ldh)
-        Wd = lambda M, N, A, lda, Bm, ldb, K, name, k: D(M, N, [(A, lda, Bm, ldb, K)], self._g(name), N, splitk=k, atomic=1)
-        self._xg(2, "b4", lambda: [
-            Wd(g.ic, g.ic, p(self.pooled), g.ek, p(self.dattout), g.ek, B, "o_w", kb),
-            Wd(g.pt, g.pt, p(self.pooled, g.ic), g.ek, p(self.dattout, g.ic), g.ek, B, "ot_w", kb),
-            Wd(g.ldh, g.ic, p(self.q1), g.ldh, p(self.dq), g.ic, B, "q2_w", kb),
-            Wd(g.ct, g.ldh, p(self.click_t), g.ct, p(self.dq1), g.ldh, B, "q1_w", kb),
-            Wd(g.ic, g.ldh, p(self.x_icp), g.ic, p(self.dpre1), g.ldh, BT, "m_win", kr),
-            Wd(g.ldh, g.ldh, x_c, g.ic, p(self.dpre1), g.ldh, BT, "m_wc", kr),
-            Wd(g.ldt, g.ldh, p(self.x_act), g.ldt, p(self.dpre1), g.ldh, BT, "m_wint", kr),
-            Wd(g.pt, g.ldh, p(self.x_pt), g.pt, p(self.dpre2), g.ldh, BT, "s_win", kr),
-            Wd(g.ldh, g.ldh, x_c, g.ic, p(self.dpre2), g.ldh, BT, "s_wc", kr)])
-        tab, gr = self._tables(), self._grads()
-        gr.rows_out = rows_out.data_ptr()
-        check(lib.tcar_gather_clip_bwd(C.byref(self.dims), C.byref(tab), C.byref(bt), p(self.dx_icp), p(self.dx_pt), p(self.dx_act),
-                                       p(self.dclick), C.byref(gr), st), "tcar_gather_clip_bwd")
-
     # ----------------------------------------------------------------------------------------------- step
     def _step(self, bt: Optional[Batch], cap: int, K: int, update: bool, T: int):
         """one training step; bt = None: a rank whose shard of the global batch is empty still joins every collective (T is
@@ -243,8 +160,6 @@ class ShardedEngine(TcarEngine):
         Bq = W * cap
         self._ensure_work(max(B, 1), T)
         self._ensure_score(cap, K)
-        # descriptor cache key: the batch geometry + the identity of the (re-allocatable) workspaces
-        self._geo_key = (B, T, self.work_rows, self.work_B, self.x_icp.data_ptr(), self.attout.data_ptr())
         has_neg = K > 0
         st = self._stream()
         self.Gx.zero_()
@@ -408,7 +323,7 @@ class ShardedEngine(TcarEngine):
         if getattr(self, "_ev_mw", None) is None:
             self._ev_mw = torch.tensor(np.ascontiguousarray(self._mwdhm_full, dtype=np.int32), device=self.dev)
         check(lib.tcar_cand_time_fwd(C.byref(full), C.byref(self._time_ptrs()), p(self._ev_mw), p(self.E), st), "tcar_cand_time_fwd")
-        self._session_forward(bt)
+        check(lib.tcar_step_session_forward(C.byref(self._ctx()), C.byref(bt), st), "tcar_step_session_forward")
         check(lib.tcar_gemm_f32(1, B, g.N, g.ek, p(self.attout), g.ek, p(self.E), g.ek, p(self.ev_logits), g.Npad, None, 0, 0, 1,
                                 st), "tcar_gemm_f32")
         check(lib.tcar_eval_rows(B, g.N, p(self.ev_logits), g.Npad, C.c_void_p(bt.label), k, p(self.rank), p(self.topk),
