@@ -365,6 +365,25 @@ int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, f
                         float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap,
                         void* stream);
 
+/* ---- deterministic sparse backward of the item table: sort by row + segmented wavefront reduction -----------------------
+ * The IndexedSlices gradient of the item lookups (model_combine.py:54,142,156): B*T session rows + B*K negative rows.
+ *   tcar_segsum_ws_bytes    workspace for up to max_sources = B*(T+K) sources
+ *   tcar_segsum_index       sorts the sources of `bt` by destination row (stable radix sort) and cuts the runs into work
+ *                           items of <= 16 sources; depends on the feed only
+ *   tcar_segsum_rows_buffer [B*T, ldh] buffer inside ws for the session sources' gradient rows (tcar_grads_t.rows_out)
+ *   tcar_segsum_apply       mode 0: g_item[row] += sum of those rows per destination, *sqn_slot += sum ||row||^2 (S5);
+ *                           mode 1: g_item[row] += sum over the negatives (b,k) of the row of coef[b] * attout[b, 0:ldh]
+ *                           ONE writer per destination row, fixed summation order: bit-for-bit repeatable
+ *   tcar_sqnorm_det         *out += sum g^2 in a fixed order (ws: 512 floats)
+ *   tcar_loss_combine       loss[b] = ce[b] + weight * neg_fb[b]                                     model_combine.py:147 */
+int64_t tcar_segsum_ws_bytes(const tcar_dims_t* d, int64_t max_sources);
+int tcar_segsum_index(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws, int64_t ws_bytes, void* stream);
+float* tcar_segsum_rows_buffer(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws);
+int tcar_segsum_apply(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws, int mode, const float* rows, const float* coef,
+                      const float* attout, int64_t ld_att, float* g_item, float* sqn_slot, void* stream);
+int tcar_sqnorm_det(const float* g, int64_t len, float* out, float* ws, void* stream);
+int tcar_loss_combine(int B, const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
+
 /* ---- device-side batch formation and negative sampling (sampler.py:52-113,118-140) ---------------------------------
  * The tensorised session store (CSR over clicks, per-click uint8 features; host/data.py SessionStore) and the negative
  * source (CSR of neighbor_dict / the impression lists) stay resident in HBM; one call writes the packed int32 feed
@@ -474,6 +493,9 @@ typedef struct {
    * run on it, so that they start the moment their inputs exist instead of queueing behind the aux stream's
    * candidate-time backward; NULL = they follow on the aux stream */
   void* stream3; void* ev3;
+  /* optional workspace of the sorted segmented sum (tcar_segsum_*): with it the fused step adds the item-row gradients of
+   * the gathers and of the negatives in a fixed order (bit-for-bit repeatable) instead of with float atomics */
+  void* segsum_ws; int64_t segsum_bytes;
 } tcar_ctx_t;
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */

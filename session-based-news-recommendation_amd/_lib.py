@@ -14,7 +14,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libtcar_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip", "step.hip", "mha.hip",
-           "sampler.hip", "norm.hip", "shard.hip", "buildid.hip"]
+           "sampler.hip", "norm.hip", "shard.hip", "segsum.hip", "buildid.hip"]
 BUILD_ID_TU = "buildid.hip"        # the one translation unit that carries the digest of all sources
 NVAR = 22
 NSLOT = 32
@@ -27,7 +27,8 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer",
+           "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_loss_combine", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range",
            "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
 
@@ -189,7 +190,8 @@ class Ctx(C.Structure):
                 + [("rank", C.c_void_p), ("topk", C.c_void_p), ("scoring", C.c_int32), ("scoring_bwd", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l")]
                 + [("stream2", C.c_void_p), ("ev", C.c_void_p * 6), ("adam_bitmap", C.c_void_p), ("et_perm", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
-                   ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p), ("stream3", C.c_void_p), ("ev3", C.c_void_p)])
+                   ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p), ("stream3", C.c_void_p), ("ev3", C.c_void_p),
+                   ("segsum_ws", C.c_void_p), ("segsum_bytes", C.c_int64)])
 
 
 class TcarError(RuntimeError):
@@ -275,6 +277,14 @@ def load() -> C.CDLL:
     lib.tcar_eval_step.argtypes = [P(Ctx), P(Batch), i32, i32, vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = C.c_int
+    lib.tcar_segsum_ws_bytes.restype = C.c_int64
+    lib.tcar_segsum_ws_bytes.argtypes = [P(Dims), i64]
+    lib.tcar_segsum_rows_buffer.restype = C.c_void_p
+    lib.tcar_segsum_rows_buffer.argtypes = [P(Dims), P(Batch), vp]
+    lib.tcar_segsum_index.argtypes = [P(Dims), P(Batch), vp, i64, vp]
+    lib.tcar_segsum_apply.argtypes = [P(Dims), P(Batch), vp, i32, vp, vp, vp, i64, vp, vp, vp]
+    lib.tcar_sqnorm_det.argtypes = [vp, i64, vp, vp, vp]
+    lib.tcar_loss_combine.argtypes = [i32, vp, vp, f32, vp, vp]
     lib.tcar_set_tuning.argtypes = [C.c_char_p, i32]
     lib.tcar_step_session_forward.argtypes = [P(Ctx), P(Batch), vp]
     lib.tcar_shard_score.argtypes = [P(Ctx), P(Shard), i32, vp]

@@ -261,6 +261,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // the forward part of the sampled negative term needs only attout and E: it runs here, beside the softmax
   if (has_neg)
     RET(tcar_neg_fwd(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
+  // sorted segmented sum of the item-row gradients (deterministic): its index depends on the feed only and is built here, on
+  // the aux stream, long before the rows exist
+  const bool sorted = fuse_finish && s2 && c->segsum_ws && tcar_tuning().sort_scatter &&
+                      c->segsum_bytes >= tcar_segsum_ws_bytes(&c->d, (int64_t)B * (T + (has_neg ? K : 0)));
+  if (sorted) RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)sz));
   if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
@@ -394,9 +399,17 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   }
   if (split_finish) {   // Gi is complete once dE has landed: negative rows (+ loss), then its norm BEFORE any row scatter (S5)
     if (hipStreamWaitEvent(st, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
-    if (has_neg)
+    if (has_neg && sorted) {
+      RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, 1, nullptr, c->neg_coef, c->attout, g.ek, Gi, nullptr, stream));
+      RET(tcar_loss_combine(B, c->ce, c->neg_fb, c->neg_weight, c->loss, stream));
+    } else if (has_neg) {
       RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, stream));
-    RET(item_norm(c, g, stream));
+    }
+    if (sorted)
+      RET(tcar_sqnorm_det(Gi, (int64_t)g.N * g.ldh, c->sqn_dense + c->slot_item,
+                          (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048), stream));
+    else
+      RET(item_norm(c, g, stream));
   }
   // The row scatter needs the item norm (same stream) but NOT the candidate-time backward: both only add (atomically) into
   // the time-table gradients, and the final join below covers the whole aux stream.  Without the split, wait for chain B.
@@ -407,7 +420,17 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     tcar_grads_t gr;
     tables_of(c, tab);
     grads_of(c, gr);
-    RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
+    if (sorted) {
+      // the gather backward WRITES the session sources' item rows (plain stores) and diverts their norm piece to a spare slot;
+      // the segmented sum adds them into Gi in sorted order and folds the pieces in a fixed order
+      gr.rows_out = tcar_segsum_rows_buffer(&c->d, bt, c->segsum_ws);
+      gr.slot_item = TCAR_NSLOT - 1;
+      RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
+      RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, 0, gr.rows_out, nullptr, nullptr, 0, Gi, c->Gx + c->arena_n + c->slot_item,
+                            stream));
+    } else {
+      RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
+    }
   }
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
   if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in

@@ -41,7 +41,7 @@ VAR_ORDER = ["item_emb", "dec_pos"] + TIME_NAMES + ["duration_embedding",
 SLOT = {n: i for i, n in enumerate(VAR_ORDER)}
 # variables whose gradient is accumulated in a fixed order (bitwise repeatable from step to step and across replicas);
 # tests/test_gpu_configs.py::test_same_step_twice_bitwise_report keeps this list honest
-DETERMINISTIC_GRADS: tuple = ()
+DETERMINISTIC_GRADS: tuple = ("item_emb",)
 
 
 def _ru(x: int, m: int) -> int:
@@ -755,6 +755,11 @@ class TcarEngine:
             c.stream2 = self._aux.cuda_stream
             for i, e in enumerate(self._aux_ev):
                 c.ev[i] = e.cuda_event
+            # workspace of the deterministic item-row scatter (sort + segmented sum), sized for the workspace's largest batch
+            need = int(self.lib.tcar_segsum_ws_bytes(C.byref(self.dims), max(1, self.work_rows + self.work_B * 64)))
+            if getattr(self, "_segsum_ws", None) is None or self._segsum_ws.numel() < need:
+                self._segsum_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            c.segsum_ws, c.segsum_bytes = self._segsum_ws.data_ptr(), self._segsum_ws.numel()
             if not os.environ.get("TCAR_NO_STREAM3"):
                 if not hasattr(self, "_aux3"):
                     self._aux3 = torch.cuda.Stream(self.dev)

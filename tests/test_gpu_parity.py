@@ -951,3 +951,53 @@ def test_gather_forward_throughput_form_equals_latency_form(lib, B, T, H, Ht):
         bad = np.argwhere(a != b)
         assert bad.size == 0, (name, len(bad), bad[:8].tolist(), [(float(a[tuple(i)]), float(b[tuple(i)])) for i in bad[:4]])
     assert not (outs[1][0] == 7.0).all() and float(np.abs(outs[1][2][0]).max()) == 0.0      # the bucket-11 row is zero
+
+
+@pytest.mark.parametrize("B,T,K,N", [(512, 2, 20, 3000), (64, 40, 7, 50), (300, 5, 0, 100000), (1, 1, 3, 10)])
+def test_sorted_segmented_item_scatter(lib, B, T, K, N):
+    """tcar_segsum_*: the item-row gradients of the gathers (mode 0) and of the negatives (mode 1) added into the dense
+    gradient by sort + segmented sum — head-heavy ids (runs of hundreds: multi-chunk runs), against np.add.at in fp64, the
+    norm pieces, and bit-for-bit repeatability."""
+    from tcar_amd._lib import Batch, Dims
+    rng = np.random.RandomState(B + T + K)
+    ldh, ek = 256, 832
+    d = Dims(N, 250, 64, ldh, 64)
+    zipf = np.minimum(rng.zipf(1.3, size=(B, T)), N).astype(np.int32)                 # ids 1..N, head heavy
+    seq = torch.tensor(zipf, device="cuda")
+    neg_np = (np.minimum(rng.zipf(1.5, size=(B, max(K, 1))), N) - 1).astype(np.int32)
+    neg = torch.tensor(neg_np, device="cuda")
+    rows_np = rng.standard_normal((B * T, ldh)).astype(np.float32)
+    coef_np = rng.standard_normal(B).astype(np.float32)
+    coef_np[::7] = 0.0
+    att_np = np.tanh(rng.standard_normal((B, ek))).astype(np.float32)
+    g0 = rng.standard_normal((N, ldh)).astype(np.float32)
+    bt = Batch()
+    bt.B, bt.T, bt.K = B, T, K
+    bt.seq, bt.neg = seq.data_ptr(), (neg.data_ptr() if K else None)
+    nbytes = lib.tcar_segsum_ws_bytes(C.byref(d), B * (T + K))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    coef, att = torch.tensor(coef_np, device="cuda"), torch.tensor(att_np, device="cuda")
+    want = g0.astype(np.float64)
+    if K:
+        for k in range(K):
+            np.add.at(want, neg_np[:, k], coef_np[:, None].astype(np.float64) * att_np[:, :ldh])
+    np.add.at(want, zipf.reshape(-1) - 1, rows_np.astype(np.float64))
+    outs = []
+    for _ in range(3):
+        g = torch.tensor(g0, device="cuda")
+        sq = torch.zeros(4, device="cuda")
+        assert lib.tcar_segsum_index(C.byref(d), C.byref(bt), ptr(ws), nbytes, None) == 0
+        rows = torch.tensor(rows_np, device="cuda")
+        assert lib.tcar_segsum_rows_buffer(C.byref(d), C.byref(bt), ptr(ws))           # the in-workspace buffer the step driver uses
+        if K:
+            assert lib.tcar_segsum_apply(C.byref(d), C.byref(bt), ptr(ws), 1, None, ptr(coef), ptr(att), ek, ptr(g), None, None) == 0
+        assert lib.tcar_segsum_apply(C.byref(d), C.byref(bt), ptr(ws), 0, ptr(rows), None, None, 0, ptr(g), ptr(sq, 1), None) == 0
+        assert lib.tcar_sqnorm_det(ptr(g), N * ldh, ptr(sq, 2), ptr(ws, (nbytes - 2048) // 4), None) == 0
+        torch.cuda.synchronize()
+        outs.append((g.cpu().numpy(), sq.cpu().numpy()))
+    close(outs[0][0], want, rtol=1e-4, atol_scale=1e-6, name="segmented scatter")
+    assert abs(outs[0][1][1] - (rows_np.astype(np.float64) ** 2).sum()) <= 1e-4 * (rows_np.astype(np.float64) ** 2).sum()
+    assert abs(outs[0][1][2] - (outs[0][0].astype(np.float64) ** 2).sum()) <= 1e-4 * (outs[0][0].astype(np.float64) ** 2).sum()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])        # bit for bit
+

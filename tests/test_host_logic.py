@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     _lib.build()
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "tcar_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*) (tcar_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|float\*|const char\*) (tcar_\w+)\(", header, flags=re.M))
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
