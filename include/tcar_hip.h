@@ -72,6 +72,8 @@ typedef struct {
   float* rows_out;       /* NULL, or [B*T, ldh]: tcar_gather_clip_bwd WRITES each item-row gradient here instead
                             of adding it into g_item (data-parallel path: rows are all-gathered, then applied on
                             every rank with tcar_scatter_add_rows) */
+  float* norms_out;      /* NULL, or [B*T]: with it the squared norm of each item-row gradient is WRITTEN here instead of
+                            being added (atomically) into sqn[slot_item] — summed later in a fixed order (segsum) */
 } tcar_grads_t;
 
 /* One mini-batch = the feed_dict of model_combine.py:214-227 (int32, row-major). */
@@ -368,21 +370,25 @@ int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, f
 /* ---- deterministic sparse backward of the item table: sort by row + segmented wavefront reduction -----------------------
  * The IndexedSlices gradient of the item lookups (model_combine.py:54,142,156): B*T session rows + B*K negative rows.
  *   tcar_segsum_ws_bytes    workspace for up to max_sources = B*(T+K) sources
- *   tcar_segsum_index       sorts the sources of `bt` by destination row (stable radix sort) and cuts the runs into work
- *                           items of <= 16 sources; depends on the feed only
+ *   tcar_segsum_index       sorts the sources of each list of `bt` (session clicks, negatives) by destination row, stably:
+ *                           lists of up to 16384 sources by one workgroup each in LDS, longer ones through rocPRIM; depends
+ *                           on the feed only
  *   tcar_segsum_rows_buffer [B*T, ldh] buffer inside ws for the session sources' gradient rows (tcar_grads_t.rows_out)
- *   tcar_segsum_apply       mode 0: g_item[row] += sum of those rows per destination, *sqn_slot += sum ||row||^2 (S5);
- *                           mode 1: g_item[row] += sum over the negatives (b,k) of the row of coef[b] * attout[b, 0:ldh]
+ *   tcar_segsum_norms_buffer [B*T] buffer inside ws for their squared norms (tcar_grads_t.norms_out)
+ *   tcar_segsum_apply       mode 0: g_item[row] += sum of those rows per destination; *sqn_slot += sum of the norms buffer
+ *                           (S5); *dense_slot += sum of tcar_sqnorm_det's partials;
+ *                           mode 1: g_item[row] += sum over the negatives (b,k) of the row of coef[b] * attout[b, 0:ldh],
+ *                           and with `loss`: loss[b] = ce[b] + weight * neg_fb[b]                    model_combine.py:147
  *                           ONE writer per destination row, fixed summation order: bit-for-bit repeatable
- *   tcar_sqnorm_det         *out += sum g^2 in a fixed order (ws: 512 floats)
- *   tcar_loss_combine       loss[b] = ce[b] + weight * neg_fb[b]                                     model_combine.py:147 */
+ *   tcar_sqnorm_det         block partials of sum g^2 into the last 4096 bytes of ws (folded by mode 0 above) */
 int64_t tcar_segsum_ws_bytes(const tcar_dims_t* d, int64_t max_sources);
 int tcar_segsum_index(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws, int64_t ws_bytes, void* stream);
 float* tcar_segsum_rows_buffer(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws);
-int tcar_segsum_apply(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws, int mode, const float* rows, const float* coef,
-                      const float* attout, int64_t ld_att, float* g_item, float* sqn_slot, void* stream);
-int tcar_sqnorm_det(const float* g, int64_t len, float* out, float* ws, void* stream);
-int tcar_loss_combine(int B, const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
+float* tcar_segsum_norms_buffer(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws);
+int tcar_segsum_apply(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws, int64_t ws_bytes, int mode, const float* rows,
+                      const float* coef, const float* attout, int64_t ld_att, float* g_item, float* sqn_slot, float* dense_slot,
+                      const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
+int tcar_sqnorm_det(const float* g, int64_t len, void* ws, int64_t ws_bytes, void* stream);
 
 /* ---- device-side batch formation and negative sampling (sampler.py:52-113,118-140) ---------------------------------
  * The tensorised session store (CSR over clicks, per-click uint8 features; host/data.py SessionStore) and the negative
@@ -432,7 +438,7 @@ int tcar_neg_scatter_range(const tcar_dims_t* d, int64_t B, int K, int n0, int n
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 6
+#define TCAR_ABI_VERSION 7
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */

@@ -348,18 +348,24 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
       float ai, bi, ap, bp;
       clip_bwd_coef(ssi, di, ai, bi);
       clip_bwd_coef(ssp, dp, ap, bp);
+      float rown = 0.f;                       // this source row's squared norm (norms_out: summed later in a fixed order)
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < ldh) {
           float4 gx = fma4(xi[c], -bi, scale4(gi[c], ai));
-          sq[0] += dot4(gx, gx);
+          if (a.g.norms_out) rown += dot4(gx, gx);
+          else sq[0] += dot4(gx, gx);
           if (a.g.rows_out) st4(a.g.rows_out + (long)row * ldh + col, gx);
           else atomic_add4(a.g.g_item + (long)n * ldh + col, gx);
           float4 gp = fma4(xp[c], -bp, scale4(gi[c], ap));
           sq[1] += dot4(gp, gp);
           atomic_add4(pos_acc + t * ldh + col, gp);
         }
+      }
+      if (a.g.norms_out) {
+        rown = wave_sum(rown);
+        if (lane == 0) a.g.norms_out[row] = rown;
       }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {

@@ -5,31 +5,35 @@
 // the dense gradient of the candidate block.  News batches are head heavy — one article can own 10 % of the rows of a
 // batch — and the plain form (float atomics, embed.hip / score.hip) makes the sum depend on arrival order: replicas and
 // repeated runs differ in the last bit.  Here the order is fixed:
-//   1. keys: (tag << 25 | item row) for every source — tag 0 = session row, 1 = negative row — sorted ONCE per batch with a
-//      radix sort (rocPRIM; it only depends on the feed, so it runs on the aux stream under the forward pass);
-//   2. work items: every run of equal keys is cut into chunks of <= 16 sources (a news batch has runs of hundreds);
-//   3. one wave per work item sums its rows in sorted order (the sort is stable: equal rows keep their source order);
-//      single-chunk runs add straight into the dense gradient — ONE writer per destination row, no atomics — multi-chunk
-//      runs leave partial rows that a second pass folds in chunk order;
-//   4. the per-row norm pieces of tf.clip_by_norm are summed per work item and folded in item order.
-// Bit-for-bit repeatable whatever the dispatch order, and one read-modify-write per touched row instead of one atomic
-// per (row, source).
+//   1. index (depends on the feed only; the step driver runs it on the aux stream under the forward pass): the sources of
+//      each list — session clicks, negatives — sorted by destination row with a STABLE radix sort: lists of up to 16384
+//      sources in ONE workgroup each, keys and counters resident in LDS (no host-side library call on the step's path);
+//      longer lists through rocPRIM;
+//   2. rows: every wave owns 4 sorted positions (a workgroup: 64) and sums the runs that START there, in sorted order =
+//      source order, then adds the sum into the dense gradient — ONE writer per destination row, no atomics, no partial
+//      rows in memory.  A run of more than 64 sources (a popular article) is summed by the 16 waves of its workgroup
+//      together: fixed 1/16 slices, folded through LDS in wave order;
+//   3. the norm pieces of tf.clip_by_norm — one per source row, written by the gather backward — and the
+//      block partials of the dense norm are folded in index order by workgroup 0 of the session-list pass.
+// Bit-for-bit repeatable whatever the dispatch order.
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 #include "tcar_common.h"
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
-constexpr int CH = 16;                 // sources per work item
-constexpr int IDX_THREADS = 1024;
+constexpr int SORT_T = 1024, SORT_E = 16, SORT_MAX = SORT_T * SORT_E;     // LDS sort: elements per thread, list limit
+constexpr int SORT_LDS = SORT_MAX * 4 + SORT_MAX * 2 + 16 * SORT_T * 2 + 64;
+constexpr int DENSE_PARTS = 512;       // block partials of tcar_sqnorm_det
+constexpr int TAIL_BYTES = 4096;       // scratch at the end of the workspace: DENSE_PARTS floats
 
 struct SegWs {                         // carved out of the caller's workspace (all device pointers)
-  unsigned* k_in; unsigned* v_in; unsigned* k_out; unsigned* v_out;
-  int* item_start; int* item_len; int* item_flag;      // per work item: first sorted position, sources, bit0 first / bit1 last of its run
-  int* counts;                                          // [0] items of the session list, [1] items of the negative list (after it)
-  float* norm_part;                                     // per work item: sum of ||row||^2 of its sources (session list)
-  float* partial;                                       // [items, ldh] partial rows of multi-chunk runs
-  float* rows;                                          // [B*T, ldh] the session sources' gradient rows (written by the gather backward)
+  unsigned* ks; unsigned* vs;          // sorted destination rows / source indices: session list [0, BT), negatives [BT, BT + BK)
+  unsigned* k_in; unsigned* v_in;      // unsorted (rocPRIM path only)
+  float* src_norm;                     // [B*T] squared norm of every session source row (written by the gather backward)
+  float* rows;                         // [B*T, ldh] the session sources' gradient rows (written by the gather backward)
   void* sort_tmp; size_t sort_bytes;
 };
 
@@ -38,193 +42,270 @@ size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t carve(SegWs& w, char* base, long n, int ldh, size_t sort_bytes) {
   size_t o = 0;
   auto take = [&](size_t bytes) { char* p = base ? base + o : nullptr; o += align_up(bytes); return p; };
-  w.k_in = (unsigned*)take(4 * n); w.v_in = (unsigned*)take(4 * n); w.k_out = (unsigned*)take(4 * n); w.v_out = (unsigned*)take(4 * n);
-  w.item_start = (int*)take(4 * n); w.item_len = (int*)take(4 * n); w.item_flag = (int*)take(4 * n);
-  w.counts = (int*)take(16);
-  w.norm_part = (float*)take(4 * n);
-  w.partial = (float*)take((size_t)4 * n * ldh);
+  w.ks = (unsigned*)take(4 * n); w.vs = (unsigned*)take(4 * n); w.k_in = (unsigned*)take(4 * n); w.v_in = (unsigned*)take(4 * n);
+  w.src_norm = (float*)take(4 * n);
   w.rows = (float*)take((size_t)4 * n * ldh);
   w.sort_tmp = take(sort_bytes); w.sort_bytes = sort_bytes;
   return o;
 }
 
+// rocPRIM's size query walks its device configuration on the host: asked once per length
 size_t sort_tmp_bytes(long n) {
+  if (n <= SORT_MAX) return 0;
+  static std::mutex mu;
+  static std::unordered_map<long, size_t> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(n);
+  if (it != cache.end()) return it->second;
   size_t bytes = 0;
   (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr,
-                                  (unsigned*)nullptr, (size_t)n, 0, 26, (hipStream_t)0);
+                                  (unsigned*)nullptr, (size_t)n, 0, 25, (hipStream_t)0);
+  cache[n] = bytes;
   return bytes;
 }
 
-__global__ __launch_bounds__(256) void make_keys_kernel(long BT, long BK, int n_items, const int32_t* __restrict__ seq,
-                                                        const int32_t* __restrict__ neg, unsigned* __restrict__ k,
-                                                        unsigned* __restrict__ v) {
-  const long n = BT + BK;
+__device__ __forceinline__ unsigned key_of(int list, int id, int n_items) {
+  return list == 0 ? (unsigned)(clampi(id, 1, n_items) - 1) : (unsigned)clampi(id, 0, n_items - 1);
+}
+
+struct SortArgs {
+  const int32_t* ids[2]; long n[2]; long lo[2];          // the two lists: ids, length, first sorted position
+  int n_items, npass;
+  unsigned* ks; unsigned* vs;
+};
+
+// One workgroup per list: LSD radix sort, 4 bits per pass, everything in LDS.  Thread t owns the 16 consecutive slots
+// [16t, 16t+16) of the current order (so equal digits keep their order: stable); the counters are digit-major, so one
+// exclusive scan over all 16 * 1024 of them yields every thread's write position for every digit.  Unused slots hold key
+// 0xffffffff: digit 15 in every pass, they stay behind the sources.
+__global__ __launch_bounds__(SORT_T) void lds_sort_kernel(const SortArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* keys = (unsigned*)smem;
+  unsigned short* vals = (unsigned short*)(smem + SORT_MAX * 4);
+  unsigned short* cnt = (unsigned short*)(smem + SORT_MAX * 6);
+  unsigned* wsum = (unsigned*)(smem + SORT_MAX * 6 + 16 * SORT_T * 2);
+  const int list = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long n = a.n[list];
+  if (n <= 0 || n > SORT_MAX) return;
+  const int32_t* ids = a.ids[list];
+  unsigned k[SORT_E];
+  unsigned short v[SORT_E];
+#pragma unroll
+  for (int i = 0; i < SORT_E; ++i) {
+    const int e = tid * SORT_E + i;
+    k[i] = e < n ? key_of(list, ids[e], a.n_items) : 0xffffffffu;
+    v[i] = (unsigned short)e;
+  }
+  for (int pass = 0; pass < a.npass; ++pass) {
+    const int sh = pass * 4;
+#pragma unroll
+    for (int d = 0; d < 16; ++d) cnt[d * SORT_T + tid] = 0;
+#pragma unroll
+    for (int i = 0; i < SORT_E; ++i) cnt[((k[i] >> sh) & 15) * SORT_T + tid] += 1;
+    __syncthreads();
+    {  // exclusive scan of the 16384 counters in place
+      unsigned short c[16];
+      unsigned tot = 0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { c[j] = cnt[tid * 16 + j]; tot += c[j]; }
+      unsigned inc = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+      }
+      if (lane == 63) wsum[wv] = inc;
+      __syncthreads();
+      unsigned base = inc - tot;
+      for (int w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) { cnt[tid * 16 + j] = (unsigned short)base; base += c[j]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SORT_E; ++i) {
+      const int ci = ((k[i] >> sh) & 15) * SORT_T + tid;
+      const unsigned pos = cnt[ci];
+      cnt[ci] = (unsigned short)(pos + 1);
+      keys[pos] = k[i];
+      vals[pos] = v[i];
+    }
+    __syncthreads();
+    if (pass + 1 < a.npass) {
+#pragma unroll
+      for (int i = 0; i < SORT_E; ++i) { k[i] = keys[tid * SORT_E + i]; v[i] = vals[tid * SORT_E + i]; }
+      __syncthreads();
+    }
+  }
+  for (long e = tid; e < n; e += SORT_T) {
+    a.ks[a.lo[list] + e] = keys[e];
+    a.vs[a.lo[list] + e] = vals[e];
+  }
+}
+
+__global__ __launch_bounds__(256) void make_keys_kernel(long n, int list, int n_items, const int32_t* __restrict__ ids,
+                                                        unsigned* __restrict__ k, unsigned* __restrict__ v) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    unsigned key;
-    if (i < BT) key = (unsigned)(clampi(seq[i], 1, n_items) - 1);
-    else key = (1u << 25) | (unsigned)clampi(neg[i - BT], 0, n_items - 1);
-    k[i] = key;
+    k[i] = key_of(list, ids[i], n_items);
     v[i] = (unsigned)i;
   }
 }
 
-// One workgroup walks the sorted keys and emits the work items of both lists (session sources first, then negatives).
-// item boundary at position i: the key changes, or the run has reached a multiple of CH sources.
-__global__ __launch_bounds__(IDX_THREADS) void build_items_kernel(long n, long BT, const unsigned* __restrict__ ks,
-                                                                  int* __restrict__ item_start, int* __restrict__ item_len,
-                                                                  int* __restrict__ item_flag, int* __restrict__ counts) {
-  __shared__ int sh_cnt[IDX_THREADS];
-  __shared__ int sh_run[IDX_THREADS];      // sorted position where the run reaching INTO this thread's span starts
-  const int tid = threadIdx.x;
-  const long per = (n + IDX_THREADS - 1) / IDX_THREADS;
-  const long lo = (long)tid * per, hi = lo + per < n ? lo + per : n;
-  // pass 1: the start of the run that is open at the end of my span (or -1: my span holds no run head and is empty)
-  long last_head = -1;
-  for (long i = lo; i < hi; ++i)
-    if (i == 0 || ks[i] != ks[i - 1]) last_head = i;
-  sh_run[tid] = (int)last_head;
-  __syncthreads();
-  // run start of the element just before my span
-  long open = 0;
-  for (int t = tid - 1; t >= 0; --t)
-    if (sh_run[t] >= 0) { open = sh_run[t]; break; }
-  // pass 2: count my item heads
-  int cnt = 0;
-  {
-    long rs = open;
-    for (long i = lo; i < hi; ++i) {
-      if (i == 0 || ks[i] != ks[i - 1]) rs = i;
-      if (((i - rs) % CH) == 0) ++cnt;
-    }
-  }
-  sh_cnt[tid] = cnt;
-  __syncthreads();
-  // exclusive scan of the counts (1024 entries: a serial scan by thread 0 is ~1 us)
-  if (tid == 0) {
-    int acc = 0;
-    for (int t = 0; t < IDX_THREADS; ++t) { const int c = sh_cnt[t]; sh_cnt[t] = acc; acc += c; }
-    counts[2] = acc;                         // all items
-  }
-  __syncthreads();
-  int it = sh_cnt[tid];
-  {
-    long rs = open;
-    for (long i = lo; i < hi; ++i) {
-      const bool head = (i == 0 || ks[i] != ks[i - 1]);
-      if (head) rs = i;
-      if (((i - rs) % CH) == 0) {
-        // length: up to CH sources, cut at the end of the run
-        long e = i + 1;
-        while (e < n && e - i < CH && ks[e] == ks[i]) ++e;
-        const bool last = (e >= n) || ks[e] != ks[i];
-        item_start[it] = (int)i;
-        item_len[it] = (int)(e - i);
-        item_flag[it] = (head ? 1 : 0) | (last ? 2 : 0);
-        if (i == BT && BT > 0) counts[0] = it;           // first item of the negative list = number of session items
-        ++it;
-      }
-    }
-  }
-  if (tid == 0 && (BT == 0 || BT >= n)) counts[0] = (BT == 0) ? 0 : counts[2];
-}
-
 struct RowArgs {
   const unsigned* ks; const unsigned* vs;
-  const int* item_start; const int* item_len; const int* item_flag; const int* counts;
-  int mode;                 // 0: session rows from `rows` [BT, ldh]; 1: negative rows coef[b] * attout[b, 0:ldh]
-  long BT; int K, ldh; long ld_att;
+  long lo, hi;              // sorted positions of this list
+  int mode;                 // 0: session rows from `rows` [BT, ldh]; 1: negative rows coef[b] * attout[b, 0:ldh], b = source / K
+  int K, ldh; long ld_att;
   const float* rows; const float* coef; const float* attout;
-  float* g_item; float* partial; float* norm_part;
+  float* g_item;
+  const float* src_norm; long n_norm; float* sqn_slot;        // mode 0: *sqn_slot += sum src_norm[0:n_norm] in index order
+  const float* dense_part; int n_dense; float* dense_slot;     // mode 0: *dense_slot += sum dense_part[0:n_dense] in index order
+  int B; const float* ce; const float* fb; float weight; float* loss;      // mode 1 (optional): loss[b] = ce[b] + weight * fb[b]
 };
 
-// one wave per work item
 template <int NCH>
-__global__ __launch_bounds__(256) void segsum_rows_kernel(const RowArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int n_sess = a.counts[0], n_all = a.counts[2];
-  const int first = a.mode ? n_sess : 0, count = a.mode ? n_all - n_sess : n_sess;
-  for (int w = blockIdx.x * 4 + (threadIdx.x >> 6); w < count; w += gridDim.x * 4) {
-    const int it = first + w;
-    const int s0 = a.item_start[it], len = a.item_len[it], fl = a.item_flag[it];
-    const unsigned row = a.ks[s0] & ((1u << 25) - 1);
-    float4 acc[NCH];
+__device__ __forceinline__ void load_source(const RowArgs& a, unsigned src, int lane, float4 (&v)[NCH]) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) acc[c] = zero4();
-    float nrm = 0.f;
-    for (int j = 0; j < len; ++j) {                      // sorted order = source order inside a run (stable sort)
-      const long src = a.vs[s0 + j];
+  for (int c = 0; c < NCH; ++c) {
+    const int col = c * 256 + lane * 4;
+    v[c] = zero4();
+    if (col < a.ldh) {
+      if (a.mode == 0) v[c] = ld4(a.rows + (long)src * a.ldh + col);
+      else { const long b = src / (unsigned)a.K; v[c] = scale4(ld4(a.attout + b * a.ld_att + col), a.coef[b]); }
+    }
+  }
+}
+
+// acc += sources [s0, s1) of the sorted list, in order, 4 row loads in flight
+template <int NCH>
+__device__ __forceinline__ void sum_sources(const RowArgs& a, long s0, long s1, int lane, float4 (&acc)[NCH]) {
+  for (long c0 = s0; c0 < s1; c0 += 64) {
+    const int m = (int)(s1 - c0 < 64 ? s1 - c0 : 64);
+    const unsigned my = lane < m ? a.vs[c0 + lane] : 0u;
+    int t = 0;
+    for (; t + 4 <= m; t += 4) {
+      float4 v[4][NCH];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int col = c * 256 + lane * 4;
-        if (col < a.ldh) {
-          float4 v;
-          if (a.mode == 0) v = ld4(a.rows + src * a.ldh + col);
-          else { const long b = (src - a.BT) / a.K; v = scale4(ld4(a.attout + b * a.ld_att + col), a.coef[b]); }
-          acc[c] = add4(acc[c], v);
-          nrm += dot4(v, v);
+      for (int u = 0; u < 4; ++u) load_source<NCH>(a, (unsigned)__builtin_amdgcn_readlane((int)my, t + u), lane, v[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = add4(acc[c], v[u][c]);
+    }
+    for (; t < m; ++t) {
+      float4 v[NCH];
+      load_source<NCH>(a, (unsigned)__builtin_amdgcn_readlane((int)my, t), lane, v);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = add4(acc[c], v[c]);
+    }
+  }
+}
+
+// sum of v[0:n] in a fixed order by one workgroup of 1024 threads: strided per-thread sums, xor tree, waves in order
+__device__ __forceinline__ float block_fold(const float* __restrict__ v, long n, float* sh16) {
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += 1024) s += v[i];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh16[threadIdx.x >> 6] = s;
+  __syncthreads();
+  float tot = 0.f;
+  for (int w = 0; w < 16; ++w) tot += sh16[w];
+  return tot;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(1024) void segsum_rows_kernel(const RowArgs a) {
+  __shared__ __attribute__((aligned(16))) float part[16][NCH * 256];
+  __shared__ float sh16[16];
+  __shared__ long long_p;
+  __shared__ int long_len;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (long base = a.lo + (long)blockIdx.x * 64; base < a.hi; base += (long)gridDim.x * 64) {
+    if (tid == 0) long_len = 0;
+    __syncthreads();
+    const long p0 = base + wv * 4;
+    if (p0 < a.hi) {
+      // lane j looks at sorted position p0 - 1 + j: the predecessor, my 4 positions, 59 of look-ahead
+      const long q = p0 - 1 + lane;
+      const unsigned kq = q < a.lo ? 0xfffffffeu : (q < a.hi ? a.ks[q] : 0xffffffffu);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long p = p0 + i;
+        if (p >= a.hi) break;
+        const unsigned kp = (unsigned)__builtin_amdgcn_readlane((int)kq, i + 1);
+        if (kp == (unsigned)__builtin_amdgcn_readlane((int)kq, i)) continue;      // the run started earlier: its owner sums it
+        // length of the run: equal keys from p on
+        const unsigned long long same = __ballot(kq == kp) >> (i + 1);
+        const int len = __builtin_ctzll(~same);                                      // <= 63 - i (zeros were shifted in)
+        long e = p + len;
+        if (len == 63 - i) {                                                         // reaches the end of the window: look on
+          for (;;) {
+            const long qq = e + lane;
+            const unsigned k2 = qq < a.hi ? a.ks[qq] : 0xffffffffu;
+            const unsigned long long ne = ~__ballot(k2 == kp);
+            if (ne == 0ull) { e += 64; continue; }
+            e += __builtin_ctzll(ne);
+            break;
+          }
+        }
+        if (e - p > 64) {                      // at most one per workgroup: it covers the rest of the slab
+          if (lane == 0) { long_p = p; long_len = (int)(e - p); }
+          continue;
+        }
+        float4 gi[NCH], acc[NCH];
+        float* dst = a.g_item + (long)kp * a.ldh;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          gi[c] = col < a.ldh ? ld4(dst + col) : zero4();
+          acc[c] = zero4();
+        }
+        sum_sources<NCH>(a, p, e, lane, acc);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          if (col < a.ldh) st4(dst + col, add4(gi[c], acc[c]));
         }
       }
     }
-    if (a.mode == 0) {
-      nrm = wave_sum(nrm);
-      if (lane == 0) a.norm_part[it] = nrm;
-    }
-    float* dst = (fl == 3) ? a.g_item + (long)row * a.ldh : a.partial + (long)it * a.ldh;
+    __syncthreads();
+    if (long_len > 0) {                        // the 16 waves take fixed sixteenths of the run; folded in wave order
+      const long P = long_p;
+      const int L = long_len, per = (L + 15) / 16;
+      const long s0 = P + (long)wv * per, s1 = (P + L < s0 + per) ? P + L : s0 + per;
+      float4 acc[NCH];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (col < a.ldh) st4(dst + col, (fl == 3) ? add4(ld4(dst + col), acc[c]) : acc[c]);
-    }
-  }
-}
-
-// multi-chunk runs: the wave of the run's FIRST item folds the partial rows in item order; one more wave (the last of the
-// grid) folds the norm pieces of the session list in item order into sqn[slot]
-template <int NCH>
-__global__ __launch_bounds__(256) void segsum_fold_kernel(const RowArgs a, float* __restrict__ sqn_slot) {
-  const int lane = threadIdx.x & 63;
-  const int n_sess = a.counts[0], n_all = a.counts[2];
-  const int first = a.mode ? n_sess : 0, count = a.mode ? n_all - n_sess : n_sess;
-  const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
-  if (a.mode == 0 && sqn_slot && wave_g == nw - 1) {
-    float s = 0.f;
-    for (int i = 0; i < count; i += 64) {               // 64 items per trip, folded in item order
-      const float v = (i + lane < count) ? a.norm_part[first + i + lane] : 0.f;
-      float t = v;                                      // fixed-shape tree inside the trip, trips in order
+      for (int c = 0; c < NCH; ++c) acc[c] = zero4();
+      if (s0 < s1) sum_sources<NCH>(a, s0, s1, lane, acc);
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) t += __shfl_xor(t, o);
-      s += t;
-    }
-    if (lane == 0) *sqn_slot += s;
-  }
-  for (int w = wave_g; w < count; w += nw) {
-    const int it = first + w;
-    const int fl = a.item_flag[it];
-    if ((fl & 1) == 0 || fl == 3) continue;              // not the first chunk of a run, or a single-chunk run (already added)
-    const unsigned row = a.ks[a.item_start[it]] & ((1u << 25) - 1);
-    float4 acc[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      acc[c] = col < a.ldh ? ld4(a.g_item + (long)row * a.ldh + col) : zero4();
-    }
-    for (int j = it;; ++j) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int col = c * 256 + lane * 4;
-        if (col < a.ldh) acc[c] = add4(acc[c], ld4(a.partial + (long)j * a.ldh + col));
+      for (int c = 0; c < NCH; ++c) st4(&part[wv][c * 256 + lane * 4], acc[c]);
+      __syncthreads();
+      const unsigned row = a.ks[P];
+      for (int col = tid; col < a.ldh; col += 1024) {
+        float s = 0.f;
+        for (int w = 0; w < 16; ++w) s += part[w][col];
+        a.g_item[(long)row * a.ldh + col] += s;
       }
-      if (a.item_flag[j] & 2) break;
     }
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (col < a.ldh) st4(a.g_item + (long)row * a.ldh + col, acc[c]);
+    __syncthreads();
+  }
+  if (a.mode == 1 && a.loss)
+    for (int b = blockIdx.x * 1024 + tid; b < a.B; b += gridDim.x * 1024) a.loss[b] = a.ce[b] + a.weight * a.fb[b];
+  if (a.mode == 0 && blockIdx.x == 0) {
+    if (a.sqn_slot && a.src_norm) {
+      const float s = block_fold(a.src_norm, a.n_norm, sh16);
+      if (tid == 0) *a.sqn_slot += s;
+    }
+    if (a.dense_slot && a.dense_part) {
+      const float s = block_fold(a.dense_part, a.n_dense, sh16);
+      if (tid == 0) *a.dense_slot += s;
     }
   }
 }
 
-// deterministic sum of squares: per-block partials in block order
+// deterministic sum of squares: block partials (folded in block order by the session-list pass of tcar_segsum_apply)
 __global__ __launch_bounds__(256) void sqnorm_part_kernel(const float* __restrict__ g, long len, float* __restrict__ part) {
   __shared__ float sh[4];
   float s = 0.f;
@@ -243,16 +324,12 @@ __global__ __launch_bounds__(256) void sqnorm_part_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ __launch_bounds__(64) void sqnorm_fold_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
-  const int lane = threadIdx.x;
-  float s = 0.f;
-  for (int i = 0; i < n; i += 64) {
-    float t = (i + lane < n) ? part[i + lane] : 0.f;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) t += __shfl_xor(t, o);
-    s += t;
-  }
-  if (lane == 0) *out += s;
+
+int list_lengths(const tcar_batch_t* bt, long& BT, long& BK) {
+  if (!bt || bt->B <= 0 || bt->T <= 0) return TCAR_E_ARG;
+  BT = (long)bt->B * bt->T;
+  BK = (bt->K > 0 && bt->neg) ? (long)bt->B * bt->K : 0;
+  return TCAR_OK;
 }
 
 }  // namespace
@@ -260,94 +337,106 @@ __global__ __launch_bounds__(64) void sqnorm_fold_kernel(const float* __restrict
 extern "C" int64_t tcar_segsum_ws_bytes(const tcar_dims_t* d, int64_t max_sources) {
   if (!d || max_sources <= 0) return 0;
   SegWs w;
-  return (int64_t)carve(w, nullptr, max_sources, d->ldh, sort_tmp_bytes(max_sources)) + 4 * 512;
+  return (int64_t)carve(w, nullptr, max_sources, d->ldh, sort_tmp_bytes(max_sources)) + TAIL_BYTES;
 }
 
-// sort the item-row sources of a batch and cut them into work items (depends on the feed only)
+// sort the item-row sources of a batch by destination row (depends on the feed only)
 extern "C" int tcar_segsum_index(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws, int64_t ws_bytes, void* stream) {
-  if (!d || !bt || !ws || bt->B <= 0 || bt->T <= 0) return TCAR_E_ARG;
-  const long BT = (long)bt->B * bt->T, BK = (bt->K > 0 && bt->neg) ? (long)bt->B * bt->K : 0, n = BT + BK;
-  if (n >= (1L << 25) || d->n_items > (1 << 25)) return TCAR_E_ARG;
+  long BT, BK;
+  if (!d || !ws || list_lengths(bt, BT, BK) != TCAR_OK) return TCAR_E_ARG;
+  const long n = BT + BK;
+  if (n >= (1L << 25) || d->n_items > (1 << 25) || d->n_items < 1) return TCAR_E_ARG;
   SegWs w;
-  const size_t sb = sort_tmp_bytes(n);
-  if ((int64_t)carve(w, (char*)ws, n, d->ldh, sb) + 4 * 512 > ws_bytes) return TCAR_E_ARG;
+  if ((int64_t)carve(w, (char*)ws, n, d->ldh, sort_tmp_bytes(n)) + TAIL_BYTES > ws_bytes) return TCAR_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  TCAR_LAUNCH(make_keys_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, BT, BK, d->n_items, bt->seq, bt->neg, w.k_in, w.v_in);
-  TCAR_CHECK_LAUNCH();
-  size_t bytes = w.sort_bytes;
-  if (rocprim::radix_sort_pairs(w.sort_tmp, bytes, (const unsigned*)w.k_in, w.k_out, (const unsigned*)w.v_in, w.v_out, (size_t)n, 0,
-                                26, st) != hipSuccess)
-    return TCAR_E_LAUNCH;
-  TCAR_LAUNCH(build_items_kernel, dim3(1), dim3(IDX_THREADS), 0, st, n, BT, (const unsigned*)w.k_out, w.item_start, w.item_len,
-              w.item_flag, w.counts);
-  TCAR_CHECK_LAUNCH();
+  int bits = 1;
+  while ((1L << bits) < d->n_items) ++bits;
+  SortArgs a{};
+  a.ids[0] = bt->seq; a.n[0] = BT; a.lo[0] = 0;
+  a.ids[1] = bt->neg; a.n[1] = BK; a.lo[1] = BT;
+  a.n_items = d->n_items; a.npass = (bits + 3) / 4; a.ks = w.ks; a.vs = w.vs;
+  if (BT <= SORT_MAX || (BK > 0 && BK <= SORT_MAX)) {
+    TCAR_SET_LDS_ONCE(lds_sort_kernel, SORT_LDS);
+    TCAR_LAUNCH(lds_sort_kernel, dim3(BK > 0 ? 2 : 1), dim3(SORT_T), SORT_LDS, st, a);
+    TCAR_CHECK_LAUNCH();
+  }
+  for (int list = 0; list < 2; ++list) {
+    const long nl = a.n[list];
+    if (nl <= SORT_MAX) continue;
+    if (!w.sort_tmp || sort_tmp_bytes(nl) > w.sort_bytes) return TCAR_E_ARG;    // carved for a sort of n >= nl elements
+    TCAR_LAUNCH(make_keys_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, nl, list, d->n_items, a.ids[list],
+                w.k_in + a.lo[list], w.v_in + a.lo[list]);
+    TCAR_CHECK_LAUNCH();
+    size_t bytes = w.sort_bytes;
+    if (rocprim::radix_sort_pairs(w.sort_tmp, bytes, (const unsigned*)(w.k_in + a.lo[list]), w.ks + a.lo[list],
+                                  (const unsigned*)(w.v_in + a.lo[list]), w.vs + a.lo[list], (size_t)nl, 0, 25, st) != hipSuccess)
+      return TCAR_E_LAUNCH;
+  }
   return TCAR_OK;
 }
 
-// mode 0: g_item[row] += sum of rows [B*T, ldh] over the session sources of `row`, and *sqn_slot += sum ||rows[r]||^2;
-// mode 1: g_item[row] += sum over the negative sources (b, k) of `row` of coef[b] * attout[b, 0:ldh]
-extern "C" int tcar_segsum_apply(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws, int mode, const float* rows,
-                                 const float* coef, const float* attout, int64_t ld_att, float* g_item, float* sqn_slot,
-                                 void* stream) {
-  if (!d || !bt || !ws || !g_item || (mode == 0 && !rows) || (mode == 1 && (!coef || !attout))) return TCAR_E_ARG;
-  const long BT = (long)bt->B * bt->T, BK = (bt->K > 0 && bt->neg) ? (long)bt->B * bt->K : 0, n = BT + BK;
-  if (mode == 1 && BK == 0) return TCAR_OK;
+// mode 0: g_item[row] += sum of rows [B*T, ldh] over the session sources of `row`; with sqn_slot: *sqn_slot += the sum of the
+//         per-source norms the gather backward left in tcar_segsum_norms_buffer; with dense_slot: *dense_slot += the fold of
+//         tcar_sqnorm_det's partials (both in index order)
+// mode 1: g_item[row] += sum over the negative sources (b, k) of `row` of coef[b] * attout[b, 0:ldh]; with `loss` also
+//         loss[b] = ce[b] + weight * neg_fb[b] (model_combine.py:147)
+extern "C" int tcar_segsum_apply(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws, int64_t ws_bytes, int mode,
+                                 const float* rows, const float* coef, const float* attout, int64_t ld_att, float* g_item,
+                                 float* sqn_slot, float* dense_slot, const float* ce, const float* neg_fb, float weight,
+                                 float* loss, void* stream) {
+  long BT, BK;
+  if (!d || !ws || !g_item || list_lengths(bt, BT, BK) != TCAR_OK) return TCAR_E_ARG;
+  if ((mode == 0 && !rows) || (mode == 1 && (!coef || !attout || BK == 0)) || (loss && (!ce || !neg_fb))) return TCAR_E_ARG;
+  if (d->ldh > 512 || (d->ldh & 3)) return TCAR_E_ARG;  // two 256-column chunks per wave
+  const long n = BT + BK;
   SegWs w;
-  carve(w, (char*)ws, n, d->ldh, sort_tmp_bytes(n));
+  if ((int64_t)carve(w, (char*)ws, n, d->ldh, sort_tmp_bytes(n)) + TAIL_BYTES > ws_bytes) return TCAR_E_ARG;
   RowArgs a{};
-  a.ks = w.k_out; a.vs = w.v_out; a.item_start = w.item_start; a.item_len = w.item_len; a.item_flag = w.item_flag; a.counts = w.counts;
-  a.mode = mode; a.BT = BT; a.K = bt->K > 0 ? bt->K : 1; a.ldh = d->ldh; a.ld_att = ld_att;
-  a.rows = rows; a.coef = coef; a.attout = attout; a.g_item = g_item; a.partial = w.partial; a.norm_part = w.norm_part;
-  const long src = mode ? BK : BT;
-  int grid = (int)((src + 3) / 4);                      // items <= sources
-  if (grid > 1024) grid = 1024;
+  a.ks = w.ks; a.vs = w.vs;
+  a.lo = mode ? BT : 0; a.hi = mode ? n : BT;
+  a.mode = mode; a.K = bt->K > 0 ? bt->K : 1; a.ldh = d->ldh; a.ld_att = ld_att;
+  a.rows = rows; a.coef = coef; a.attout = attout; a.g_item = g_item;
+  a.src_norm = w.src_norm; a.n_norm = BT; a.sqn_slot = mode == 0 ? sqn_slot : nullptr;
+  a.dense_part = (const float*)((char*)ws + ws_bytes - TAIL_BYTES); a.n_dense = DENSE_PARTS; a.dense_slot = mode == 0 ? dense_slot : nullptr;
+  a.B = bt->B; a.ce = ce; a.fb = neg_fb; a.weight = weight; a.loss = loss;
+  long grid = (a.hi - a.lo + 63) / 64;
+  if (grid > 4096) grid = 4096;
   if (grid < 1) grid = 1;
   hipStream_t st = (hipStream_t)stream;
-  if (d->ldh <= 256) {
-    TCAR_LAUNCH(segsum_rows_kernel<1>, dim3(grid), dim3(256), 0, st, a);
-    TCAR_CHECK_LAUNCH();
-    TCAR_LAUNCH(segsum_fold_kernel<1>, dim3(grid), dim3(256), 0, st, a, sqn_slot);
-  } else {
-    TCAR_LAUNCH(segsum_rows_kernel<2>, dim3(grid), dim3(256), 0, st, a);
-    TCAR_CHECK_LAUNCH();
-    TCAR_LAUNCH(segsum_fold_kernel<2>, dim3(grid), dim3(256), 0, st, a, sqn_slot);
-  }
+  if (d->ldh <= 256) TCAR_LAUNCH(segsum_rows_kernel<1>, dim3((unsigned)grid), dim3(1024), 0, st, a);
+  else TCAR_LAUNCH(segsum_rows_kernel<2>, dim3((unsigned)grid), dim3(1024), 0, st, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
 
-// where the gather backward writes the session sources' item-row gradients ([B*T, ldh], tcar_grads_t.rows_out) for mode 0
+// where the gather backward writes the session sources' item-row gradients ([B*T, ldh], tcar_grads_t.rows_out) and their
+// squared norms ([B*T], tcar_grads_t.norms_out) for mode 0
 extern "C" float* tcar_segsum_rows_buffer(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws) {
-  if (!d || !bt || !ws) return nullptr;
-  const long BT = (long)bt->B * bt->T, BK = (bt->K > 0 && bt->neg) ? (long)bt->B * bt->K : 0, n = BT + BK;
+  long BT, BK;
+  if (!d || !ws || list_lengths(bt, BT, BK) != TCAR_OK) return nullptr;
   SegWs w;
-  carve(w, (char*)ws, n, d->ldh, sort_tmp_bytes(n));
+  carve(w, (char*)ws, BT + BK, d->ldh, sort_tmp_bytes(BT + BK));
   return w.rows;
 }
-
-__global__ __launch_bounds__(256) void loss_combine_kernel(int B, const float* __restrict__ ce, const float* __restrict__ fb,
-                                                           float weight, float* __restrict__ loss) {
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  if (b < B) loss[b] = ce[b] + weight * fb[b];
-}
-// loss[b] = ce[b] + weight * neg_fb[b] (model_combine.py:147)
-extern "C" int tcar_loss_combine(int B, const float* ce, const float* neg_fb, float weight, float* loss, void* stream) {
-  if (B <= 0) return TCAR_OK;
-  if (!ce || !neg_fb || !loss) return TCAR_E_ARG;
-  TCAR_LAUNCH(loss_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, ce, neg_fb, weight, loss);
-  TCAR_CHECK_LAUNCH();
-  return TCAR_OK;
+extern "C" float* tcar_segsum_norms_buffer(const tcar_dims_t* d, const tcar_batch_t* bt, void* ws) {
+  long BT, BK;
+  if (!d || !ws || list_lengths(bt, BT, BK) != TCAR_OK) return nullptr;
+  SegWs w;
+  carve(w, (char*)ws, BT + BK, d->ldh, sort_tmp_bytes(BT + BK));
+  return w.src_norm;
 }
 
-// *out += sum g[0:len]^2 in a fixed order (512 block partials folded by one wave); ws: >= 512 floats
-extern "C" int tcar_sqnorm_det(const float* g, int64_t len, float* out, float* ws, void* stream) {
-  if (len <= 0) return TCAR_OK;
-  if (!g || !out || !ws || (len & 3) || !tcar_aligned16(g)) return TCAR_E_ARG;
+// block partials of sum g[0:len]^2 into the LAST 4096 bytes of the segsum workspace (512 floats, unused ones zero); the
+// session-list pass of tcar_segsum_apply folds them in block order into its dense_slot
+extern "C" int tcar_sqnorm_det(const float* g, int64_t len, void* ws, int64_t ws_bytes, void* stream) {
+  if (!g || !ws || ws_bytes < TAIL_BYTES || len < 0 || (len & 3) || !tcar_aligned16(g)) return TCAR_E_ARG;
+  float* part = (float*)((char*)ws + ws_bytes - TAIL_BYTES);
   long blocks = (len + 8191) / 8192;
-  if (blocks > 512) blocks = 512;
-  TCAR_LAUNCH(sqnorm_part_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (long)len, ws);
-  TCAR_CHECK_LAUNCH();
-  TCAR_LAUNCH(sqnorm_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)ws, (int)blocks, out);
-  TCAR_CHECK_LAUNCH();
+  if (blocks > DENSE_PARTS) blocks = DENSE_PARTS;
+  if (blocks < DENSE_PARTS && hipMemsetAsync(part, 0, DENSE_PARTS * sizeof(float), (hipStream_t)stream) != hipSuccess) return TCAR_E_LAUNCH;
+  if (blocks > 0) {
+    TCAR_LAUNCH(sqnorm_part_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, (long)len, part);
+    TCAR_CHECK_LAUNCH();
+  }
   return TCAR_OK;
 }

@@ -91,7 +91,7 @@ void grads_of(const tcar_ctx_t* c, tcar_grads_t& g) {
   g.g_dur = G(c, TCAR_V_DUR);
   g.sqn = c->Gx + c->arena_n;
   g.slot_item = c->slot_item; g.slot_pos = c->slot_of[TCAR_V_POS]; g.slot_dur = c->slot_of[TCAR_V_DUR];
-  g.rows_out = nullptr;
+  g.rows_out = nullptr; g.norms_out = nullptr;
 }
 
 // the small contractions follow the scoring precision: exact fp32 MFMA in "f32" mode, split-bf16 otherwise
@@ -114,11 +114,20 @@ int check_ctx(const tcar_ctx_t* c, const tcar_batch_t* bt) {
 namespace {
 // `rest_lr` >= 0: the item rows the early pass of a split update left out are updated on the aux stream, behind the
 // candidate-time refresh and in front of the join that the logits GEMM waits for
-int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream, float rest_lr);
+// `train_index`: the fused training step follows — the sort index of its deterministic item-row sum (segsum.hip) depends on
+// the feed only and is built on the aux stream under the forward pass
+int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream, float rest_lr, bool train_index);
+
+// does the fused step add the item-row gradients through the sorted segmented sum?
+bool sorted_rows(const tcar_ctx_t* c, const tcar_batch_t* bt) {
+  if (!aux_stream(c) || !c->segsum_ws || !tcar_tuning().sort_scatter || c->d.ldh > 512) return false;
+  const bool has_neg = bt->K > 0 && bt->neg && c->neg_coef && c->negpart;
+  return c->segsum_bytes >= tcar_segsum_ws_bytes(&c->d, (int64_t)bt->B * (bt->T + (has_neg ? bt->K : 0)));
+}
 }  // namespace
 
 extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream) {
-  return forward_impl(c, bt, refresh_time, stream, -1.f);
+  return forward_impl(c, bt, refresh_time, stream, -1.f, false);
 }
 
 namespace {
@@ -168,7 +177,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
 }  // namespace
 
 namespace {
-int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream, float rest_lr) {
+int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream, float rest_lr, bool train_index) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
   const int B = bt->B, BT = bt->B * bt->T;
@@ -195,6 +204,12 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
       joined = false;
     }
+  }
+  if (train_index && sorted_rows(c, bt)) {   // behind the join point: the logits GEMM does not wait for it, the backward does
+    if (!refresh_time &&
+        (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+      return TCAR_E_LAUNCH;
+    RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)s2));
   }
   RET(session_forward(c, bt, g, stream, c->scoring && tcar_tuning().planes_epi));
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
@@ -261,11 +276,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // the forward part of the sampled negative term needs only attout and E: it runs here, beside the softmax
   if (has_neg)
     RET(tcar_neg_fwd(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
-  // sorted segmented sum of the item-row gradients (deterministic): its index depends on the feed only and is built here, on
-  // the aux stream, long before the rows exist
-  const bool sorted = fuse_finish && s2 && c->segsum_ws && tcar_tuning().sort_scatter &&
-                      c->segsum_bytes >= tcar_segsum_ws_bytes(&c->d, (int64_t)B * (T + (has_neg ? K : 0)));
-  if (sorted) RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)sz));
+  // sorted segmented sum of the item-row gradients (deterministic); its index was built under the forward pass, on the aux
+  // stream — ev[1] below orders the main stream behind it
+  const bool sorted = fuse_finish && sorted_rows(c, bt);
   if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
@@ -400,14 +413,13 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (split_finish) {   // Gi is complete once dE has landed: negative rows (+ loss), then its norm BEFORE any row scatter (S5)
     if (hipStreamWaitEvent(st, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
     if (has_neg && sorted) {
-      RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, 1, nullptr, c->neg_coef, c->attout, g.ek, Gi, nullptr, stream));
-      RET(tcar_loss_combine(B, c->ce, c->neg_fb, c->neg_weight, c->loss, stream));
+      RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, c->segsum_bytes, 1, nullptr, c->neg_coef, c->attout, g.ek, Gi, nullptr, nullptr,
+                            c->ce, c->neg_fb, c->neg_weight, c->loss, stream));
     } else if (has_neg) {
       RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, stream));
     }
-    if (sorted)
-      RET(tcar_sqnorm_det(Gi, (int64_t)g.N * g.ldh, c->sqn_dense + c->slot_item,
-                          (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048), stream));
+    if (sorted)    // block partials of ||Gi||^2; the session-list pass below folds them (S5: BEFORE any session row lands)
+      RET(tcar_sqnorm_det(Gi, (int64_t)g.N * g.ldh, c->segsum_ws, c->segsum_bytes, stream));
     else
       RET(item_norm(c, g, stream));
   }
@@ -421,13 +433,13 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     tables_of(c, tab);
     grads_of(c, gr);
     if (sorted) {
-      // the gather backward WRITES the session sources' item rows (plain stores) and diverts their norm piece to a spare slot;
-      // the segmented sum adds them into Gi in sorted order and folds the pieces in a fixed order
+      // the gather backward WRITES the session sources' item rows and their squared norms (plain stores); the segmented sum
+      // adds the rows into Gi in sorted order and folds the norms — and the dense norm's partials — in a fixed order
       gr.rows_out = tcar_segsum_rows_buffer(&c->d, bt, c->segsum_ws);
-      gr.slot_item = TCAR_NSLOT - 1;
+      gr.norms_out = tcar_segsum_norms_buffer(&c->d, bt, c->segsum_ws);
       RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
-      RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, 0, gr.rows_out, nullptr, nullptr, 0, Gi, c->Gx + c->arena_n + c->slot_item,
-                            stream));
+      RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, c->segsum_bytes, 0, gr.rows_out, nullptr, nullptr, 0, Gi,
+                            c->Gx + c->arena_n + c->slot_item, c->sqn_dense + c->slot_item, nullptr, nullptr, 0.f, nullptr, stream));
     } else {
       RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
     }
@@ -490,7 +502,7 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
 }
 
 extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {
-  RET(tcar_step_forward(c, bt, refresh_time, stream));
+  RET(forward_impl(c, bt, refresh_time, stream, -1.f, true));
   RET(backward_impl(c, bt, stream, true));
   return tcar_step_update(c, lr_t, stream);
 }
@@ -514,7 +526,7 @@ extern "C" int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t*
       RET(tcar_step_update(c, lr_pending, stream));
     }
   }
-  RET(forward_impl(c, bt, refresh_time, stream, rest_lr));
+  RET(forward_impl(c, bt, refresh_time, stream, rest_lr, true));
   return backward_impl(c, bt, stream, true);
 }
 

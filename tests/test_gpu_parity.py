@@ -953,11 +953,12 @@ def test_gather_forward_throughput_form_equals_latency_form(lib, B, T, H, Ht):
     assert not (outs[1][0] == 7.0).all() and float(np.abs(outs[1][2][0]).max()) == 0.0      # the bucket-11 row is zero
 
 
-@pytest.mark.parametrize("B,T,K,N", [(512, 2, 20, 3000), (64, 40, 7, 50), (300, 5, 0, 100000), (1, 1, 3, 10)])
+@pytest.mark.parametrize("B,T,K,N", [(512, 2, 20, 3000), (64, 40, 7, 50), (300, 5, 0, 100000), (1, 1, 3, 10), (2048, 40, 2, 500)])
 def test_sorted_segmented_item_scatter(lib, B, T, K, N):
     """tcar_segsum_*: the item-row gradients of the gathers (mode 0) and of the negatives (mode 1) added into the dense
     gradient by sort + segmented sum — head-heavy ids (runs of hundreds: multi-chunk runs), against np.add.at in fp64, the
-    norm pieces, and bit-for-bit repeatability."""
+    folds of the norms, and bit-for-bit repeatability.  Lists of up to 16384 sources are sorted in LDS, the last case takes
+    the rocPRIM path for its session list; its head article has a run of thousands (summed by a whole workgroup)."""
     from tcar_amd._lib import Batch, Dims
     rng = np.random.RandomState(B + T + K)
     ldh, ek = 256, 832
@@ -977,27 +978,41 @@ def test_sorted_segmented_item_scatter(lib, B, T, K, N):
     nbytes = lib.tcar_segsum_ws_bytes(C.byref(d), B * (T + K))
     ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     coef, att = torch.tensor(coef_np, device="cuda"), torch.tensor(att_np, device="cuda")
+    ce, fb = torch.rand(B, device="cuda"), torch.rand(B, device="cuda")
     want = g0.astype(np.float64)
     if K:
         for k in range(K):
             np.add.at(want, neg_np[:, k], coef_np[:, None].astype(np.float64) * att_np[:, :ldh])
     np.add.at(want, zipf.reshape(-1) - 1, rows_np.astype(np.float64))
     outs = []
+    norms_np = (rows_np.astype(np.float64) ** 2).sum(1).astype(np.float32)
     for _ in range(3):
         g = torch.tensor(g0, device="cuda")
         sq = torch.zeros(4, device="cuda")
+        ws.fill_(0xEE)                                                                 # nothing may depend on old contents
         assert lib.tcar_segsum_index(C.byref(d), C.byref(bt), ptr(ws), nbytes, None) == 0
         rows = torch.tensor(rows_np, device="cuda")
-        assert lib.tcar_segsum_rows_buffer(C.byref(d), C.byref(bt), ptr(ws))           # the in-workspace buffer the step driver uses
+        assert lib.tcar_segsum_rows_buffer(C.byref(d), C.byref(bt), ptr(ws))           # the in-workspace buffers the step driver uses
+        nb = lib.tcar_segsum_norms_buffer(C.byref(d), C.byref(bt), ptr(ws))
+        assert ws.data_ptr() <= nb < ws.data_ptr() + nbytes
+        off = nb - ws.data_ptr()
+        ws[off:off + 4 * B * T].view(torch.float32).copy_(torch.tensor(norms_np, device="cuda"))   # what the gather backward leaves
+        loss = torch.zeros(B, device="cuda")
         if K:
-            assert lib.tcar_segsum_apply(C.byref(d), C.byref(bt), ptr(ws), 1, None, ptr(coef), ptr(att), ek, ptr(g), None, None) == 0
-        assert lib.tcar_segsum_apply(C.byref(d), C.byref(bt), ptr(ws), 0, ptr(rows), None, None, 0, ptr(g), ptr(sq, 1), None) == 0
-        assert lib.tcar_sqnorm_det(ptr(g), N * ldh, ptr(sq, 2), ptr(ws, (nbytes - 2048) // 4), None) == 0
+            assert lib.tcar_segsum_apply(C.byref(d), C.byref(bt), ptr(ws), nbytes, 1, None, ptr(coef), ptr(att), ek, ptr(g), None,
+                                         None, ptr(ce), ptr(fb), 0.25, ptr(loss), None) == 0
+        assert lib.tcar_sqnorm_det(ptr(g), N * ldh, ptr(ws), nbytes, None) == 0        # ||g||^2 BEFORE the session rows (S5)
         torch.cuda.synchronize()
+        g_mid = g.cpu().numpy().astype(np.float64)
+        assert lib.tcar_segsum_apply(C.byref(d), C.byref(bt), ptr(ws), nbytes, 0, ptr(rows), None, None, 0, ptr(g), ptr(sq, 1),
+                                     ptr(sq, 2), None, None, 0.0, None, None) == 0
+        torch.cuda.synchronize()
+        if K:
+            np.testing.assert_allclose(loss.cpu().numpy(), (ce + 0.25 * fb).cpu().numpy(), rtol=1e-6)
         outs.append((g.cpu().numpy(), sq.cpu().numpy()))
+    assert abs(outs[0][1][1] - norms_np.astype(np.float64).sum()) <= 1e-5 * norms_np.astype(np.float64).sum()
+    assert abs(outs[0][1][2] - (g_mid ** 2).sum()) <= 1e-5 * (g_mid ** 2).sum()
     close(outs[0][0], want, rtol=1e-4, atol_scale=1e-6, name="segmented scatter")
-    assert abs(outs[0][1][1] - (rows_np.astype(np.float64) ** 2).sum()) <= 1e-4 * (rows_np.astype(np.float64) ** 2).sum()
-    assert abs(outs[0][1][2] - (outs[0][0].astype(np.float64) ** 2).sum()) <= 1e-4 * (outs[0][0].astype(np.float64) ** 2).sum()
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])        # bit for bit
 
