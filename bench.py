@@ -38,6 +38,10 @@ if ROOT not in sys.path:
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix), v_mfma_f32_32x32x2_f32
 PEAK_BF16_DENSE_TFLOPS = 2500.0     # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 PEAK_HBM_GBS = 8000.0               # HBM3E spec peak
+DTYPE_NOTE = {"f32": "f32", "bf16": "bf16",
+              "bf16x3": "bf16x3 (split-bf16 planes, 3 MFMAs per product: fp32-class; fp32 accumulate, fp32 master state)",
+              "bf16x3-mixed": "bf16 (logits GEMM on split-bf16 planes = 3 MFMAs per product, gradient GEMMs plain bf16; fp32 "
+                              "accumulate, fp32 master state)"}
 
 # BASELINE.json configs[1..4] as synthetic folds of the same shape (no dataset files exist in this environment)
 CONFIGS = {
@@ -113,15 +117,14 @@ def build_batches(fold, n_batches, B, K, rng, cfg):
     return out
 
 
-def pmc_traffic(tag, N, B):
+def pmc_traffic(tag, nsplit, N, B):
     """HBM bytes per launch of one scoring GEMM from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
-    MI355X_MICROARCH.md §HBM); only valid for the shape it was collected on."""
-    for rnd in ("r02", "r01"):
-        p = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, tag))
-        if os.path.exists(p):
-            d = json.load(open(p))
-            if tuple(d.get("shape_N_B", (46033, 512))) == (N, B):
-                return d.get("hbm_bytes_per_launch"), os.path.relpath(p, ROOT)
+    MI355X_MICROARCH.md §HBM; tools/pmc_gemm.sh); only valid for the shape and plane count it was collected on."""
+    p = os.path.join(ROOT, "profiles", "r02_pmc_%s_n%d.json" % (tag, nsplit))
+    if os.path.exists(p):
+        d = json.load(open(p))
+        if tuple(d.get("shape_N_B", ())) == (N, B):
+            return d.get("hbm_bytes_per_launch"), os.path.relpath(p, ROOT)
     return None, None
 
 
@@ -147,8 +150,11 @@ def main():
                     help="multi-GPU exchange: replica = all-reduce of the dense item gradient; sharded = catalog-sharded scoring")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same_device", action="store_true", help="dry run: put every rank on cuda:0")
-    ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
-                    help="precision of the full-catalog scoring GEMMs (bf16x3 = split-bf16 planes, fp32-class accuracy)")
+    ap.add_argument("--scoring", default="bf16x3-mixed", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
+                    help="precision of the full-catalog scoring GEMMs.  bf16x3-mixed (default; BASELINE.json configs[1] is "
+                         "quoted in bf16): logits from split-bf16 planes (three MFMAs per product, fp32-class: the 1e-3 "
+                         "logits / HR@20 / MRR@20 gate of the north star), the two gradient GEMMs in plain bf16, fp32 "
+                         "accumulation and fp32 master state throughout; bf16x3: all three GEMMs fp32-class")
     ap.add_argument("--launch_check", action="store_true",
                     help="CPU-only check of the rank launch: rendezvous over gloo, one all-reduce, print n_gpus (tests/)")
     args = ap.parse_args()
@@ -302,13 +308,27 @@ def main():
                 buf = C.create_string_buffer(160)
                 eng.lib.tcar_gemm_bf16_variant(lay, M_, N_, K_, 3 if mult == 3 else 1, sk, buf, 160)
                 name = buf.value.decode()
-            traffic, src = pmc_traffic(tag, N, B) if (x3 and world == 1) else (None, None)
-            ents.append({"kernel": "%s (%s)" % (name, ref[tag]), "tag": tag, "bound": "mfma", "achieved": round(ach, 2),
-                         "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                         "traffic_source": src, "flops_per_launch": flops[tag], "launches": len(ms), "avg_ms": round(avg, 5),
-                         "total_ms": round(avg * len(ms), 3), "mfma_executed_tflops": round(ach * mult, 2),
-                         "frac_executed": round(ach * mult / peak, 4),
-                         "timing": "HIP events on the launch stream inside the timed steps (other streams' kernels co-run)"})
+            traffic, src = pmc_traffic(tag, 3 if mult == 3 else 1, N, B) if (world == 1 and args.scoring != "f32") else (None, None)
+            # algorithmic HBM bytes of the launch: every operand once (bf16 planes: 2 B per plane and element; fp32: 4 B), the
+            # result once
+            opb = 4 if args.scoring == "f32" else 2 * (2 if mult == 3 else 1)
+            n_rows = g.Npad if n_local == N else ((n_local + 127) // 128) * 128
+            alg_bytes = {"score_fwd": opb * (n_rows * g.ek + b_glob * g.ek) + 4 * b_glob * n_rows,
+                         "score_dx": opb * (b_glob * n_rows + n_rows * g.ek) + 4 * sk * b_glob * g.ek,
+                         "score_dE": opb * (b_glob * n_rows + b_glob * (g.ldh + g.pt)) + 4 * n_local * (g.ldh + g.pt)}[tag]
+            gbs = alg_bytes / (avg * 1e-3) / 1e9
+            f_mfma, f_hbm = ach * mult / peak, gbs / PEAK_HBM_GBS
+            ent = {"kernel": "%s (%s)" % (name, ref[tag]), "tag": tag}
+            if f_hbm > f_mfma:       # the hi-only gradient GEMMs: a third of the MFMA work, the same fp32 result to write
+                ent.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)})
+            else:
+                ent.update({"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4)})
+            ent.update({"traffic": traffic, "traffic_source": src, "flops_per_launch": flops[tag], "bytes_per_launch": alg_bytes,
+                        "launches": len(ms), "avg_ms": round(avg, 5), "total_ms": round(avg * len(ms), 3),
+                        "tflops": round(ach, 2), "mfma_executed_tflops": round(ach * mult, 2), "frac_mfma_executed": round(f_mfma, 4),
+                        "hbm_GBps_algorithmic": round(gbs, 1), "frac_hbm": round(f_hbm, 4),
+                        "timing": "HIP events on the launch stream inside the timed steps (other streams' kernels co-run)"})
+            ents.append(ent)
             kernels[tag] = {"launches": len(ms), "avg_ms": round(avg, 5), "tflops": round(ach, 2)}
         if ents:
             ents.sort(key=lambda e: -e["total_ms"])
@@ -371,7 +391,7 @@ def main():
         out = {"metric": "sessions/sec TCAR train on Globo (synthetic %s fold)" % args.config, "value": round(value, 1),
                "unit": "sessions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": args.scoring, "data": "synthetic",
+               "vs_baseline": None, "dtype": DTYPE_NOTE[args.scoring], "scoring": args.scoring, "data": "synthetic",
                "config": {"workload": "%s: N=%d items, %d-d content, B=%d/GPU, K=%d %s negatives, mean input length %.2f, "
                                       "full-catalog scoring, clip %d + Adam" %
                                       (labels[args.config], N, H, B, K, cfg["neg_mode"], mean_T, 150),

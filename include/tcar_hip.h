@@ -247,7 +247,7 @@ int tcar_attn_pool_bwd_q(const tcar_dims_t* d, int B, int T, const float* x_icp,
 int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* stream);
 
 /* ..._bf16: the gradient goes to bf16 hi / lo KB32 planes [ceil128(B), ld] (ld % 32 == 0; padding rows zeroed);
- * the logits stay intact. */
+ * the logits stay intact.  dl_lo may be NULL (hi-only backward: the lo plane is neither read nor written). */
 int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* dl_hi,
                          void* dl_lo, void* stream);
 

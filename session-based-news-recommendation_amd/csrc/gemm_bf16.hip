@@ -72,14 +72,17 @@ __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int
 
 // TMW x TNW = MFMA tiles (32 x 32) per wave along M / N: 2 x 2 for the 4-waves-per-SIMD shapes, 4 x 3 (12 accumulator
 // tiles = 192 registers, 2 waves per SIMD) for the 256 x 384 workgroup tile of the logits GEMM
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2>
+// KS = 32-deep k blocks per LDS stage: the hi-only (NSPLIT = 1) form has a third of the MFMA work between two barriers
+// and half the bytes per stage, so it takes 64-deep stages (same LDS as the two-plane form, half the barriers).
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1>
 __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW;
   constexpr int NP = (NSPLIT == 1) ? 1 : 2;                 // planes per operand
   constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64;       // one plane of one operand, one stage
   constexpr int PL = A_BYTES + B_BYTES;                     // LDS stage = [plane][A | B]
-  constexpr int STAGE = NP * PL;
+  constexpr int SUB = NP * PL;                              // one 32-deep k block of both operands
+  constexpr int STAGE = KS * SUB;
   constexpr int A_CP = A_BYTES / 1024, B_CP = B_BYTES / 1024;   // 1-KB wave copies per plane
   constexpr int NCOPY = NP * (A_CP + B_CP);
   constexpr int CPW = (NCOPY + NW - 1) / NW;                // copies per wave and stage (the last round may be partial)
@@ -103,7 +106,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
   const int m0 = tm * TM, n0 = tn * TN;
   const int ks = split * g.kchunk;
   const int ke = min(g.K, ks + g.kchunk);
-  const int nit = (ke - ks) / KB;
+  const int nkb = (ke - ks) / KB;
+  const int nit = (nkb + KS - 1) / KS;
 
   f32x16 acc[TMW][TNW];
 #pragma unroll
@@ -115,54 +119,62 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
 
   // issue this wave's share of the DMA copies of k-stage `t` into LDS stage buffer t & 1
   auto issue = [&](int t) {
-    const int k0 = ks + t * KB;
-    char* St = smem + (t & 1) * STAGE;
 #pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-      const int c = wave + NW * i;                     // copy index in [0, NCOPY)   (wave-uniform)
-      if (NCOPY % NW != 0 && c >= NCOPY) break;
-      const int p = c / (A_CP + B_CP), rem = c - p * (A_CP + B_CP);
-      const bool isA = rem < A_CP;
-      const int ci = isA ? rem : rem - A_CP;
-      const __bf16* P = isA ? g.A[p] : g.B[p];
-      const int in32 = isA ? g.a_in32 : g.b_in32, nrb = isA ? g.a_rb : g.b_rb;
-      const int mode = isA ? MA : MB, t0 = isA ? m0 : n0;
-      long src;
-      bool ok;
-      if (mode == 0) {          // k-contiguous: 8 copies per 8-KB block (rows t0.., inner block k0/32)
-        const int rb = (t0 >> 7) + (ci >> 3);
-        ok = rb < nrb;
-        src = ((long)rb * in32 + (k0 >> 5)) * 4096 + (ci & 7) * 512;
-      } else {                  // transposed-read: 2 copies per 2-KB chunk (32 rows k0.. of inner block t0/32 + j)
-        const int cb = (t0 >> 5) + (ci >> 1);
-        ok = cb < in32;
-        src = ((long)(k0 >> 7) * in32 + cb) * 4096 + (k0 & 127) * 32 + (ci & 1) * 512;
+    for (int j = 0; j < KS; ++j) {
+      if (KS > 1 && t * KS + j >= nkb) break;
+      const int k0 = ks + (t * KS + j) * KB;
+      char* St = smem + (t & 1) * STAGE + j * SUB;
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+        const int c = wave + NW * i;                     // copy index in [0, NCOPY)   (wave-uniform)
+        if (NCOPY % NW != 0 && c >= NCOPY) break;
+        const int p = c / (A_CP + B_CP), rem = c - p * (A_CP + B_CP);
+        const bool isA = rem < A_CP;
+        const int ci = isA ? rem : rem - A_CP;
+        const __bf16* P = isA ? g.A[p] : g.B[p];
+        const int in32 = isA ? g.a_in32 : g.b_in32, nrb = isA ? g.a_rb : g.b_rb;
+        const int mode = isA ? MA : MB, t0 = isA ? m0 : n0;
+        long src;
+        bool ok;
+        if (mode == 0) {          // k-contiguous: 8 copies per 8-KB block (rows t0.., inner block k0/32)
+          const int rb = (t0 >> 7) + (ci >> 3);
+          ok = rb < nrb;
+          src = ((long)rb * in32 + (k0 >> 5)) * 4096 + (ci & 7) * 512;
+        } else {                  // transposed-read: 2 copies per 2-KB chunk (32 rows k0.. of inner block t0/32 + j)
+          const int cb = (t0 >> 5) + (ci >> 1);
+          ok = cb < in32;
+          src = ((long)(k0 >> 7) * in32 + cb) * 4096 + (k0 & 127) * 32 + (ci & 1) * 512;
+        }
+        char* dst = St + p * PL + (isA ? 0 : A_BYTES) + ci * 1024;
+        if (ok) __builtin_amdgcn_global_load_lds((glb_vp)(P + src + lane * 8), (lds_vp)dst, 16, 0, 0);
       }
-      char* dst = St + p * PL + (isA ? 0 : A_BYTES) + ci * 1024;
-      if (ok) __builtin_amdgcn_global_load_lds((glb_vp)(P + src + lane * 8), (lds_vp)dst, 16, 0, 0);
     }
   };
   auto compute = [&](int t) {
-    const char* St = smem + (t & 1) * STAGE;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 a[NP][TMW];
+    for (int j = 0; j < KS; ++j) {
+      if (KS > 1 && t * KS + j >= nkb) break;
+      const char* St = smem + (t & 1) * STAGE + j * SUB;
 #pragma unroll
-      for (int p = 0; p < NP; ++p)
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 a[NP][TMW];
 #pragma unroll
-        for (int u = 0; u < TMW; ++u) a[p][u] = frag<MA>(St + p * PL, wm * (32 * TMW) + u * 32, s, lane);
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
-      for (int t2 = 0; t2 < TNW; ++t2) {          // one B tile at a time: its fragments die after TMW * NSPLIT MFMAs
-        bf16x8 b[NP];
+          for (int u = 0; u < TMW; ++u) a[p][u] = frag<MA>(St + p * PL, wm * (32 * TMW) + u * 32, s, lane);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) b[p] = frag<MB>(St + p * PL + A_BYTES, wn * (32 * TNW) + t2 * 32, s, lane);
+        for (int t2 = 0; t2 < TNW; ++t2) {          // one B tile at a time: its fragments die after TMW * NSPLIT MFMAs
+          bf16x8 b[NP];
 #pragma unroll
-        for (int u = 0; u < TMW; ++u) {
-          if constexpr (NSPLIT == 3) {
-            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0], acc[u][t2], 0, 0, 0);
-            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1], acc[u][t2], 0, 0, 0);
+          for (int p = 0; p < NP; ++p) b[p] = frag<MB>(St + p * PL + A_BYTES, wn * (32 * TNW) + t2 * 32, s, lane);
+#pragma unroll
+          for (int u = 0; u < TMW; ++u) {
+            if constexpr (NSPLIT == 3) {
+              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0], acc[u][t2], 0, 0, 0);
+              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1], acc[u][t2], 0, 0, 0);
+            }
+            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0], acc[u][t2], 0, 0, 0);
           }
-          acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0], acc[u][t2], 0, 0, 0);
         }
       }
     }
@@ -252,21 +264,33 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 thread_local char* t_variant_out = nullptr;
 thread_local int t_variant_len = 0;
 
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2>
-int launch_v(BArgs& g, int splitk, hipStream_t st) {
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW, int TNW, int KS>
+int launch_k(BArgs& g, int splitk, hipStream_t st) {
   constexpr int NT = 64 * WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW, NP = (NSPLIT == 1) ? 1 : 2;
-  constexpr size_t lds = 2 * NP * (TM + TN) * 64;
+  constexpr size_t lds = 2 * KS * NP * (TM + TN) * 64;
   g.mt = (g.M + TM - 1) / TM;
   g.nt = (g.N + TN - 1) / TN;
   if (t_variant_out) {
-    snprintf(t_variant_out, t_variant_len, "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d, %d> tile %dx%dx32 grid %d", MA, MB, NSPLIT,
-             WMW, WNW, TMW, TNW, TM, TN, g.mt * g.nt * splitk);
+    snprintf(t_variant_out, t_variant_len, "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d, %d> tile %dx%dx%d grid %d", MA, MB, NSPLIT,
+             WMW, WNW, TMW, TNW, TM, TN, 32 * KS, g.mt * g.nt * splitk);
     return TCAR_OK;
   }
-  TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW>), lds);
-  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
+  TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS>), lds);
+  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
+}
+
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2>
+int launch_v(BArgs& g, int splitk, hipStream_t st) {
+  // measured at the Globo shape (hi-only backward): dX 68 -> 59 us with 64-deep stages; dE (192 x 192 tiles, three
+  // workgroups per CU at 48 KB) loses its occupancy with 96 KB and slows down 129 -> 136 us, so it keeps 32-deep stages
+  // (TCAR_BF16_KS: 1 = never, 2 = k-contiguous A operand only, 3 = always)
+  if constexpr (NSPLIT == 1) {
+    const int ks = tcar_tuning().bf16_ks;
+    if (ks == 3 || (ks == 2 && MA == 0)) return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 2>(g, splitk, st);
+  }
+  return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 1>(g, splitk, st);
 }
 
 template <int MA, int MB>

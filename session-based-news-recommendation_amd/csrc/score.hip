@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int B, int N, float* __
       const long o = kb32_off(b, i * 4, (int)(ld >> 5));
       bf16x4_s z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
       *reinterpret_cast<bf16x4_s*>(dh + o) = z;
-      *reinterpret_cast<bf16x4_s*>(dl + o) = z;
+      if (dl) *reinterpret_cast<bf16x4_s*>(dl + o) = z;
     }
     return;
   }
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(int B, int N, float* __
       for (int j = 0; j < 4; ++j) { h[j] = (__bf16)ov[j]; l[j] = (__bf16)(ov[j] - (float)h[j]); }
       const long o = kb32_off(b, c, (int)(ld >> 5));            // KB32 blocked planes [ceil128(B), ld]
       *reinterpret_cast<bf16x4_s*>(dh + o) = h;
-      *reinterpret_cast<bf16x4_s*>(dl + o) = l;
+      if (dl) *reinterpret_cast<bf16x4_s*>(dl + o) = l;
     } else {
       st4(row + c, o);
     }
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NT) void softmax_ce_rows_kernel(int B, int N, float
       const long o = kb32_off(b, i * 4, (int)(ld >> 5));
       bf16x4_s z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
       *reinterpret_cast<bf16x4_s*>(dh + o) = z;
-      *reinterpret_cast<bf16x4_s*>(dl + o) = z;
+      if (dl) *reinterpret_cast<bf16x4_s*>(dl + o) = z;
     }
     return;
   }
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NT) void softmax_ce_rows_kernel(int B, int N, float
       for (int j = 0; j < 4; ++j) { h[j] = (__bf16)ov[j]; l[j] = (__bf16)(ov[j] - (float)h[j]); }
       const long o = kb32_off(b, c, (int)(ld >> 5));
       *reinterpret_cast<bf16x4_s*>(dh + o) = h;
-      *reinterpret_cast<bf16x4_s*>(dl + o) = l;
+      if (dl) *reinterpret_cast<bf16x4_s*>(dl + o) = l;
     } else {
       st4(row + c, make_float4(ov[0], ov[1], ov[2], ov[3]));
     }
@@ -586,7 +586,7 @@ extern "C" int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const in
 extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce,
                                     void* dl_hi, void* dl_lo, void* stream) {
   if (B <= 0) return TCAR_OK;
-  if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && (!dl_lo || (ld & 31))))
+  if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && (ld & 31)) || (dl_lo && !dl_hi))
     return TCAR_E_ARG;
   const int grid = dl_hi ? ((B + 127) & ~127) : B;
   const int variant = tcar_tuning().softmax_variant;

@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -31,7 +31,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}};
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}};
   for (auto& e : tab) {
     bool same = true;
     for (int i = 0; same; ++i) {
@@ -285,7 +285,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
   // backward precision: scoring_bwd (1 = hi planes only) or the forward precision
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
-  if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, c->dl16l, stream));
+  // hi-only backward (bf16x3-mixed, bf16): the lo plane of dlogits is never read — and not written
+  if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   if (s2) {
     if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)

@@ -269,7 +269,9 @@ def make_dp_engine(params, content_emb, mwdhm, device="cuda:0", group=None, scor
     picks the sharded exchange when there is more than one rank."""
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     if mode == "auto":
-        mode = "sharded" if (world > 1 and _HAVE_SHARDED) else "replica"
+        if world > 1 and scoring != "f32":
+            from . import sharded  # noqa: F401  (sets _HAVE_SHARDED)
+        mode = "sharded" if (world > 1 and _HAVE_SHARDED and scoring != "f32") else "replica"
     if mode == "sharded":
         from .sharded import ShardedEngine
         return ShardedEngine(params, content_emb, mwdhm, device=device, group=group, scoring=scoring, **kw)

@@ -100,6 +100,30 @@ def test_cli_synthetic_runs():
     assert 0.0 <= model.last_metrics["recall"] <= 1.0 and np.isfinite(model.last_metrics["loss"])
 
 
+def test_bf16_gradient_gemms_keep_hr_and_mrr():
+    """north star: HR@20 within +-0.002 of the reference, logits / HR@20 / MRR@20 within 1e-3 relative.  The same run
+    (same fold, seeds, batches) in the four scoring modes: f32 is the reference precision; bf16x3 (all three GEMMs on
+    split-bf16 planes) and bf16x3-mixed (bench.py's default: gradient GEMMs in plain bf16) must land on its metrics.
+    20,000 test sessions: one session is 5e-5 of HR@20.  Atomic-order noise alone moves HR@20 by ~2e-4 between two runs."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tcar_amd.host.cli import main
+    res = {}
+    for mode in ("f32", "bf16x3", "bf16x3-mixed"):
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            m = main(["--synthetic", "8000", "--synthetic_train", "60000", "--synthetic_test", "20000", "--epoch", "3",
+                      "--batch_size", "512", "--gap_mode", "click_delta", "--scoring", mode])
+        res[mode] = dict(m.last_metrics)
+    ref = res["f32"]
+    assert ref["recall"] > 0.1                                    # the run learns something: the comparison is not vacuous
+    for mode in ("bf16x3", "bf16x3-mixed"):
+        r = res[mode]
+        assert abs(r["recall"] - ref["recall"]) <= 0.002, (mode, r["recall"], ref["recall"])
+        assert abs(r["mrr"] - ref["mrr"]) <= 0.002, (mode, r["mrr"], ref["mrr"])
+        assert abs(r["loss"] - ref["loss"]) <= 1e-3 * abs(ref["loss"]), (mode, r["loss"], ref["loss"])
+
+
 def test_cli_runs_on_a_fold_in_the_reference_pickle_layout(tmp_path):
     """main.py --datapath/--dataset/--split_way/--foldnum on files written the way the reference's preprocessing writes
     them (util.py:20-56): load, tensorise, train one epoch, evaluate — the stdout contract of model_combine.py holds."""

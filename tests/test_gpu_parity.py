@@ -417,6 +417,9 @@ def test_gemm_bf16_layouts(lib, layout, nsplit, M, N, K):
     got = dC.cpu().numpy()
     close(got[:, :N], want, rtol=1e-3 if nsplit == 3 else 2e-2, atol_scale=2e-5 if nsplit == 3 else 6e-3, name="bf16 gemm")
     assert (got[:, N:] == 7.0).all()
+    if nsplit == 1:     # hi planes only (64-deep LDS stages): exactly the product of the bf16-rounded operands, fp32 accumulation
+        rb = lambda x: torch.tensor(x).bfloat16().double().numpy()
+        close(got[:, :N], rb(Al) @ rb(Bl), rtol=1e-4, atol_scale=2e-6, name="bf16 gemm, hi planes")
 
 
 def test_gemm_bf16_dual_output_and_splitk(lib):
