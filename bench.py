@@ -231,6 +231,10 @@ def main():
         eng = TcarEngine(params, fold.content, fold.mwdhm, device=dev, scoring=args.scoring)
     resident = [eng.make_resident(b) for b in batches]
     mean_T = float(np.mean([b["seq"].shape[1] for b in batches]))
+    if not os.environ.get("TCAR_NO_RESERVE"):
+        # setup, not steps: size the activation workspace for the longest bucket once (a trainer does the same from its bucket
+        # table), so that no step of a short run re-allocates when a longer bucket first appears
+        eng._ensure_work(B, max(b["seq"].shape[1] for b in batches))
 
     def sync():
         if dist is not None:

@@ -74,6 +74,7 @@ typedef struct {
                             every rank with tcar_scatter_add_rows) */
   float* norms_out;      /* NULL, or [B*T]: with it the squared norm of each item-row gradient is WRITTEN here instead of
                             being added (atomically) into sqn[slot_item] — summed later in a fixed order (segsum) */
+  int64_t rows_ld;       /* row stride of rows_out in floats (0 = ldh): a packed exchange buffer keeps the row's id beside it */
 } tcar_grads_t;
 
 /* One mini-batch = the feed_dict of model_combine.py:214-227 (int32, row-major). */
@@ -107,6 +108,11 @@ int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const t
  * row, skipped).  The "bucketed sparse-embedding exchange" applies the all-gathered (id, row) pairs with it. */
 int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float* rows, int64_t R, float* g_item,
                           void* stream);
+/* ..._packed: the exchange buffer keeps each row's id behind it — packed[r, 0:ldh] = row, packed[r, ldh] = the 1-based id as
+ * int32 bits, row stride ld floats (ld >= ldh + 1, ld % 4 == 0).  g_item[id - id0 - 1] += row for id0 < id <= id0 + n_items
+ * (a catalog shard keeps the rows it owns; everything else, incl. id 0 padding, falls out). */
+int tcar_scatter_add_rows_packed(const tcar_dims_t* d, const float* packed, int64_t ld, int64_t R, int32_t id0, float* g_item,
+                                 void* stream);
 
 /* tcar_cand_time_fwd: candidate_publish_t of model_combine.py:86-92 written into E[:, ic:ek].
  * mwdhm [N,5] int32 = publish_time_MWDHM (model_combine.py:37). */
@@ -307,6 +313,8 @@ typedef struct {
 } tcar_segments_t;
 
 /* sqn_dense[slot] += sum g^2 over each segment. */
+/* (segments of <= 262,144 floats: one workgroup each, fixed summation order — identical inputs give identical bits;
+ *  longer segments: chunked with one float atomic per chunk) */
 int tcar_sqnorm(const float* g, const tcar_segments_t* segs /*host*/, float* sqn_dense, void* stream);
 /* Per-variable tf.clip_by_norm(g, clip) then TF-1 Adam.  norm^2 of a variable =
  * use_dense[slot]*sqn_dense[slot] + sqn_pieces[slot]; scale = clip / max(norm, clip) (clip <= 0: no clipping).
@@ -432,13 +440,25 @@ int tcar_softmax_grad(int B, int N, const float* logits, int64_t ld, const float
                       void* dl_lo, void* stream);
 int tcar_neg_scatter_range(const tcar_dims_t* d, int64_t B, int K, int n0, int n_loc, const int32_t* neg, const float* attout,
                            int64_t ld_att, const float* coef, float* g_item, void* stream);
+/* Packed exchange rows of the catalog-sharded step (one all-gather instead of four; ints travel as bits):
+ *   tcar_shard_pack_head    head[b] = [attout[b, 0:ek] | label | negative-term coefficient | Kc negatives | pad], row stride ld
+ *                           (ld >= ek + 2 + Kc, ld % 4 == 0); rows B <= b < cap are padding sessions (zero, label -1, negatives -1)
+ *   tcar_shard_unpack_head  the all-gathered rows [Bq, ld] back into contiguous label [Bq], coef [Bq], neg [Bq, K]
+ *   tcar_shard_pack_ids     rows[r, ldh] = seq[r] (r < n_live) or 0 (padding) behind the packed item-row gradients
+ *                           [n_total, ld]; with `loss`: loss[b] = ce[b] + weight * neg_fb[b]          model_combine.py:147 */
+int tcar_shard_pack_head(int B, int cap, int ek, int K, int Kc, const float* attout, const int32_t* label, const float* coef,
+                         const int32_t* neg, float* head, int64_t ld, void* stream);
+int tcar_shard_unpack_head(int Bq, int ek, int K, const float* head, int64_t ld, int32_t* label, float* coef, int32_t* neg,
+                           void* stream);
+int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t* seq, float* rows, int64_t ld, int B,
+                        const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
 /* Diagnostic hook (tests, profiling tools): override one of the TCAR_* tuning switches at run time (they are otherwise read
  * from the environment once per process).  Returns the previous value, INT_MIN for an unknown name.  Not for product code. */
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 7
+#define TCAR_ABI_VERSION 9
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -529,7 +549,9 @@ int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time
  * the shard s->n0 .. s->n0 + s->n_loc only. */
 typedef struct {
   int32_t world, cap, n0, n_loc;     /* ranks; sessions every rank contributes; first catalog row and row count of the shard */
-  const float* att_all;              /* [world*cap, ek]  all-gathered attout (zero rows = padding sessions) */
+  const float* att_all;              /* [world*cap, ek]  all-gathered attout (zero rows = padding sessions), row stride ld_att */
+  int64_t ld_att;                    /* floats between session rows of att_all (0 = ek): the packed exchange buffer carries label,
+                                        negatives and coefficient behind each row */
   const int32_t* lab_all;            /* [world*cap]      labels, -1 = padding session */
   float* logits;                     /* [world*cap, ceil128(n_loc)] */
   float* stats;                      /* [world*cap, 3]   this shard's (max, sum exp, label logit) */
@@ -537,6 +559,11 @@ typedef struct {
   void *a16h, *a16l, *ap16h, *ap16l, *dl16h, *dl16l;   /* bf16 planes for ceil128(world*cap) session rows */
   float* slabs;                      /* [c->splitk, world*cap, ek] */
   float* dx;                         /* [world*cap, ek]  this shard's contribution to d attout of EVERY session */
+  /* packed exchange (ld_att > ek): tcar_shard_score first unpacks label / negatives / coefficient from the rows of att_all into
+   * lab_all (written here), neg_all [world*cap, head_K] and coef_all [world*cap] */
+  int32_t head_K;
+  int32_t* neg_all;
+  float* coef_all;
 } tcar_shard_t;
 /* forward of the local sessions up to attout (+ the negative term's forward part when bt->K > 0) */
 int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream);
@@ -551,7 +578,14 @@ int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int K, const i
                       void* stream);
 /* backward of the local sessions from their summed d attout rows dx_rows [B, ek]; the item-row gradients of the gathers go to
  * rows_out [B*T, ldh] (all-gathered by the caller), everything else into the arena gradients */
-int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, const float* dx_rows, float* rows_out, void* stream);
+int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, const float* dx_rows, float* rows_out,
+                               int64_t rows_ld /* floats between rows of rows_out; 0 = ldh */,
+                               int64_t rows_total /* packed form (rows_ld > ldh): ids are written behind the rows, 0 for the
+                                                     padding rows B*T <= r < rows_total */,
+                               const float* ce_rows /* NULL, or [B]: also loss = ce_rows + neg_weight * neg_fb */, void* stream);
+/* first piece of the catalog-sharded step: zero the gradient arena, session forward (+ negative-term forward) of the local
+ * sessions — bt may be NULL on a rank whose shard of the batch is empty — and the packed exchange rows (tcar_shard_pack_head) */
+int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int Kc, float* head, int64_t ld_head, void* stream);
 
 #ifdef __cplusplus
 }

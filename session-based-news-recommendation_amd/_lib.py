@@ -20,7 +20,7 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 7          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 9          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
@@ -29,7 +29,7 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
            "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
            "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range",
-           "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_step_forward",
+           "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
 
 
@@ -128,7 +128,7 @@ class Tables(C.Structure):
 class Grads(C.Structure):
     _fields_ = [("g_item", C.c_void_p), ("g_pos", C.c_void_p), ("g_time", C.c_void_p * 5), ("g_dur", C.c_void_p),
                 ("sqn", C.c_void_p), ("slot_item", C.c_int32), ("slot_pos", C.c_int32),
-                ("slot_time", C.c_int32 * 5), ("slot_dur", C.c_int32), ("rows_out", C.c_void_p), ("norms_out", C.c_void_p)]
+                ("slot_time", C.c_int32 * 5), ("slot_dur", C.c_int32), ("rows_out", C.c_void_p), ("norms_out", C.c_void_p), ("rows_ld", C.c_int64)]
 
 
 class Batch(C.Structure):
@@ -151,9 +151,11 @@ class NegSrc(C.Structure):
 
 class Shard(C.Structure):
     """mirror of tcar_shard_t"""
-    _fields_ = ([("world", C.c_int32), ("cap", C.c_int32), ("n0", C.c_int32), ("n_loc", C.c_int32)]
-                + [(n, C.c_void_p) for n in ("att_all", "lab_all", "logits", "stats", "lse", "ce", "a16h", "a16l", "ap16h", "ap16l",
-                                             "dl16h", "dl16l", "slabs", "dx")])
+    _fields_ = ([("world", C.c_int32), ("cap", C.c_int32), ("n0", C.c_int32), ("n_loc", C.c_int32),
+                 ("att_all", C.c_void_p), ("ld_att", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("lab_all", "logits", "stats", "lse", "ce", "a16h", "a16l", "ap16h", "ap16l",
+                                             "dl16h", "dl16l", "slabs", "dx")]
+                + [("head_K", C.c_int32), ("neg_all", C.c_void_p), ("coef_all", C.c_void_p)])
 
 
 class Segments(C.Structure):
@@ -291,7 +293,12 @@ def load() -> C.CDLL:
     lib.tcar_shard_score.argtypes = [P(Ctx), P(Shard), i32, vp]
     lib.tcar_shard_backward.argtypes = [P(Ctx), P(Shard), vp, vp]
     lib.tcar_shard_finish.argtypes = [P(Ctx), P(Shard), i32, vp, vp, vp]
-    lib.tcar_step_session_backward.argtypes = [P(Ctx), P(Batch), vp, vp, vp]
+    lib.tcar_step_session_backward.argtypes = [P(Ctx), P(Batch), vp, vp, i64, i64, vp, vp]
+    lib.tcar_shard_begin.argtypes = [P(Ctx), P(Batch), i32, i32, vp, i64, vp]
+    lib.tcar_shard_pack_head.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp]
+    lib.tcar_shard_unpack_head.argtypes = [i32, i32, i32, vp, i64, vp, vp, vp, vp]
+    lib.tcar_shard_pack_ids.argtypes = [i64, i64, i32, vp, vp, i64, i32, vp, vp, f32, vp, vp]
+    lib.tcar_scatter_add_rows_packed.argtypes = [P(Dims), vp, i64, i64, i32, vp, vp]
     lib.tcar_softmax_stats.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp]
     lib.tcar_softmax_combine.argtypes = [i32, i32, vp, vp, vp, vp, vp]
     lib.tcar_softmax_grad.argtypes = [i32, i32, vp, i64, vp, vp, i32, vp, vp, vp]

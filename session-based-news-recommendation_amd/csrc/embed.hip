@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
           float4 gx = fma4(xi[c], -bi, scale4(gi[c], ai));
           if (a.g.norms_out) rown += dot4(gx, gx);
           else sq[0] += dot4(gx, gx);
-          if (a.g.rows_out) st4(a.g.rows_out + (long)row * ldh + col, gx);
+          if (a.g.rows_out) st4(a.g.rows_out + (long)row * (a.g.rows_ld ? a.g.rows_ld : (long)ldh) + col, gx);
           else atomic_add4(a.g.g_item + (long)n * ldh + col, gx);
           float4 gp = fma4(xp[c], -bp, scale4(gi[c], ap));
           sq[1] += dot4(gp, gp);
@@ -686,6 +686,20 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int ldh, int n_it
   }
 }
 
+// packed form: the id rides behind its row (row stride ld), ids shifted by id0 (catalog shards)
+__global__ __launch_bounds__(256) void scatter_add_rows_packed_kernel(int ldh, int n_items, int id0, const float* __restrict__ packed,
+                                                                      long ld, long R, float* __restrict__ g_item) {
+  const int lane = threadIdx.x & 63;
+  const long wave_g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long nwaves = (long)gridDim.x * 4;
+  for (long r = wave_g; r < R; r += nwaves) {
+    const float* row = packed + r * ld;
+    const int id = __float_as_int(row[ldh]) - id0;
+    if (id < 1 || id > n_items) continue;
+    for (int col = lane * 4; col < ldh; col += 256) atomic_add4(g_item + (long)(id - 1) * ldh + col, ld4(row + col));
+  }
+}
+
 int check_dims(const tcar_dims_t* d) {
   if (!d || d->n_items <= 0 || d->H <= 0 || d->Ht <= 0) return TCAR_E_ARG;
   if (d->ldh < d->H || d->ldt < d->Ht || (d->ldh & 63) || (d->ldh > 512)) return TCAR_E_ARG;
@@ -791,6 +805,18 @@ extern "C" int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, c
   if (grid > 2048) grid = 2048;
   TCAR_LAUNCH(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d->ldh, d->n_items, ids, rows,
               (long)R, g_item);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_scatter_add_rows_packed(const tcar_dims_t* d, const float* packed, int64_t ld, int64_t R, int32_t id0,
+                                            float* g_item, void* stream) {
+  if (R <= 0) return TCAR_OK;
+  if (check_dims(d) || !packed || !g_item || ld < d->ldh + 1 || (ld & 3) || !tcar_aligned16(packed)) return TCAR_E_ARG;
+  int grid = (int)((R + 3) / 4);
+  if (grid > 2048) grid = 2048;
+  TCAR_LAUNCH(scatter_add_rows_packed_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d->ldh, d->n_items, (int)id0, packed,
+              (long)ld, (long)R, g_item);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -52,6 +52,35 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
   if (threadIdx.x == 0) atomicAdd(out + a.s.slot[seg], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// Small segments (the dense weights: <= 262,144 floats each): ONE workgroup of 1024 threads per segment, fixed summation
+// order (thread-strided partial sums, xor tree inside the wave, the 16 waves in order).  The result depends on the data
+// only, so ranks that hold identical gradients compute identical norms — no broadcast needed to keep them in step.
+__global__ __launch_bounds__(1024) void sqnorm_seg_kernel(const float* __restrict__ g, const SegArgs a, float* __restrict__ out) {
+  __shared__ float sh[16];
+  const int seg = blockIdx.x;
+  const long off = a.s.off[seg];
+  const long len = a.s.len[seg];
+  float s = 0.f;
+  for (long base = 0; base < len; base += 1024 * 4 * 4) {
+    float4 v[4];                      // 4 loads in flight per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long e = base + (i * 1024 + threadIdx.x) * 4;
+      v[i] = (e < len) ? ld4(g + off + e) : zero4();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += dot4(v[i], v[i]);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    atomicAdd(out + a.s.slot[seg], t);                  // one add per segment
+  }
+}
+
 __device__ __forceinline__ void adam4(float4& w, const float4 g, float4& m, float4& v, float sc, float lr_t, float b1,
                                       float b2, float eps) {
   const float gx = g.x * sc, gy = g.y * sc, gz = g.z * sc, gw = g.w * sc;
@@ -231,7 +260,12 @@ extern "C" int tcar_sqnorm(const float* g, const tcar_segments_t* segs, float* s
   if (segs->nseg == 0) return TCAR_OK;
   SegArgs a;
   a.s = *segs;
-  TCAR_LAUNCH(sqnorm_kernel, dim3(sqnorm_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
+  long longest = 0;
+  for (int i = 0; i < segs->nseg; ++i) longest = segs->len[i] > longest ? segs->len[i] : longest;
+  if (longest <= 262144)
+    TCAR_LAUNCH(sqnorm_seg_kernel, dim3(segs->nseg), dim3(1024), 0, (hipStream_t)stream, g, a, sqn_dense);
+  else
+    TCAR_LAUNCH(sqnorm_kernel, dim3(sqnorm_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

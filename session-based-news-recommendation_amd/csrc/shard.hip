@@ -123,6 +123,52 @@ __global__ __launch_bounds__(256) void neg_scatter_range_kernel(long BK, int K, 
   for (int col = lane; col < ldh; col += 64) atomicAdd(gdst + col, cf * a[col]);
 }
 
+
+// ---- packed exchange rows (one all-gather instead of four) --------------------------------------------------------
+// head[b] = [attout[b, 0:ek] | label | coefficient of the negative term | Kc negatives | pad], ints as bits, row stride ld;
+// rows b >= B are padding sessions: zero attout / coefficient, label -1, negatives -1
+__global__ __launch_bounds__(256) void pack_head_kernel(int B, int cap, int ek, int K, int Kc, const float* __restrict__ attout,
+                                                        const int32_t* __restrict__ label, const float* __restrict__ coef,
+                                                        const int32_t* __restrict__ neg, float* __restrict__ head, long ld) {
+  const int b = blockIdx.x;
+  float* row = head + (long)b * ld;
+  const bool live = b < B;
+  for (int c = threadIdx.x * 4; c < ek; c += 1024) st4(row + c, live ? ld4(attout + (long)b * ek + c) : zero4());
+  for (int j = threadIdx.x; j < (int)ld - ek; j += 256) {
+    int bits;
+    if (j == 0) bits = live ? label[b] : -1;
+    else if (j == 1) bits = (live && coef) ? __float_as_int(coef[b]) : 0;
+    else if (j - 2 < Kc) bits = (live && neg && j - 2 < K) ? neg[(long)b * K + (j - 2)] : -1;
+    else bits = 0;
+    row[ek + j] = __int_as_float(bits);
+  }
+}
+
+// the all-gathered rows back into the contiguous arrays the scoring kernels read
+__global__ __launch_bounds__(256) void unpack_head_kernel(int Bq, int ek, int K, const float* __restrict__ head, long ld,
+                                                          int32_t* __restrict__ label, float* __restrict__ coef,
+                                                          int32_t* __restrict__ neg) {
+  const long n = (long)Bq * (2 + K);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / (2 + K);
+    const int j = (int)(i - b * (2 + K));
+    const float v = head[b * ld + ek + j];
+    if (j == 0) label[b] = __float_as_int(v);
+    else if (j == 1) { if (coef) coef[b] = v; }
+    else if (neg) neg[b * K + (j - 2)] = __float_as_int(v);
+  }
+}
+
+// ids behind the packed item-row gradients (rows r >= n_live: id 0 = padding, skipped by the scatter), and the loss rows
+__global__ __launch_bounds__(256) void pack_ids_kernel(long n_live, long n_total, int ldh, const int32_t* __restrict__ seq,
+                                                       float* __restrict__ rows, long ld, int B, const float* __restrict__ ce,
+                                                       const float* __restrict__ fb, float weight, float* __restrict__ loss) {
+  for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < n_total; r += (long)gridDim.x * 256)
+    rows[r * ld + ldh] = __int_as_float(r < n_live ? seq[r] : 0);
+  if (loss)
+    for (int b = blockIdx.x * 256 + threadIdx.x; b < B; b += gridDim.x * 256) loss[b] = ce[b] + weight * fb[b];
+}
+
 }  // namespace
 
 extern "C" int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld, const int32_t* label, int n0, float* stats,
@@ -160,6 +206,41 @@ extern "C" int tcar_neg_scatter_range(const tcar_dims_t* d, int64_t B, int K, in
   const long waves = (long)B * K;
   TCAR_LAUNCH(neg_scatter_range_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, waves, K, n0, n_loc,
               d->ldh, (long)ld_att, neg, attout, coef, g_item);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_shard_pack_head(int B, int cap, int ek, int K, int Kc, const float* attout, const int32_t* label,
+                                    const float* coef, const int32_t* neg, float* head, int64_t ld, void* stream) {
+  if (cap <= 0) return TCAR_OK;
+  if (B < 0 || B > cap || !head || (ek & 3) || (ld & 3) || ld < ek + 2 + Kc || K > Kc || (B > 0 && (!attout || !label)) ||
+      !tcar_aligned16(head) || (B > 0 && !tcar_aligned16(attout)))
+    return TCAR_E_ARG;
+  TCAR_LAUNCH(pack_head_kernel, dim3(cap), dim3(256), 0, (hipStream_t)stream, B, cap, ek, K, Kc, attout, label, coef, neg, head, (long)ld);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_shard_unpack_head(int Bq, int ek, int K, const float* head, int64_t ld, int32_t* label, float* coef, int32_t* neg,
+                                      void* stream) {
+  if (Bq <= 0) return TCAR_OK;
+  if (!head || !label || ld < ek + 2 + K || (K > 0 && (!coef || !neg))) return TCAR_E_ARG;
+  long n = (long)Bq * (2 + K);
+  int grid = (int)((n + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  TCAR_LAUNCH(unpack_head_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, Bq, ek, K, head, (long)ld, label, coef, neg);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t* seq, float* rows, int64_t ld, int B,
+                                   const float* ce, const float* neg_fb, float weight, float* loss, void* stream) {
+  if (n_total <= 0) return TCAR_OK;
+  if (!rows || ld < ldh + 1 || n_live < 0 || n_live > n_total || (n_live > 0 && !seq) || (loss && (!ce || !neg_fb))) return TCAR_E_ARG;
+  int grid = (int)((n_total + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  TCAR_LAUNCH(pack_ids_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)n_live, (long)n_total, ldh, seq, rows, (long)ld, B,
+              ce, neg_fb, weight, loss);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

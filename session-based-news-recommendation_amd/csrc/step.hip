@@ -91,7 +91,7 @@ void grads_of(const tcar_ctx_t* c, tcar_grads_t& g) {
   g.g_dur = G(c, TCAR_V_DUR);
   g.sqn = c->Gx + c->arena_n;
   g.slot_item = c->slot_item; g.slot_pos = c->slot_of[TCAR_V_POS]; g.slot_dur = c->slot_of[TCAR_V_DUR];
-  g.rows_out = nullptr; g.norms_out = nullptr;
+  g.rows_out = nullptr; g.norms_out = nullptr; g.rows_ld = 0;
 }
 
 // the small contractions follow the scoring precision: exact fp32 MFMA in "f32" mode, split-bf16 otherwise
@@ -553,6 +553,20 @@ extern "C" int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t
   return TCAR_OK;
 }
 
+extern "C" int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int Kc, float* head, int64_t ld_head,
+                                void* stream) {
+  if (!c || !c->scoring || !c->Gx || !c->sqn_dense || !head || cap <= 0) return TCAR_E_ARG;
+  const Geo g(c->d);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
+  if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
+  if (!bt) return tcar_shard_pack_head(0, cap, g.ek, 0, Kc, nullptr, nullptr, nullptr, nullptr, head, ld_head, stream);
+  RET(tcar_step_session_forward(c, bt, stream));
+  const bool has_neg = bt->K > 0 && bt->neg && c->neg_coef && c->negpart;
+  return tcar_shard_pack_head(bt->B, cap, g.ek, has_neg ? bt->K : 0, Kc, c->attout, bt->label, has_neg ? c->neg_coef : nullptr,
+                              has_neg ? bt->neg : nullptr, head, ld_head, stream);
+}
+
 namespace {
 int check_shard(const tcar_ctx_t* c, const tcar_shard_t* s) {
   if (!c || !s || !c->scoring || s->world <= 0 || s->cap <= 0 || s->n_loc <= 0 || s->n0 < 0) return TCAR_E_ARG;
@@ -574,7 +588,10 @@ extern "C" int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int 
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
     RET(tcar_cand_time_fwd_bf16(&dc, tt, c->mwdhm, nullptr, c->e16h, c->e16l, stream));
   }
-  RET(tcar_split_bf16(s->att_all, g.ek, Bq, g.ek, s->a16h, s->a16l, g.ek, s->ap16h, s->ap16l, g.ldh + g.pt, g.ldh, g.ic, stream));
+  if (s->ld_att > g.ek)     // packed exchange rows: label / negatives / coefficient ride behind attout
+    RET(tcar_shard_unpack_head(Bq, g.ek, s->head_K, s->att_all, s->ld_att, const_cast<int32_t*>(s->lab_all), s->coef_all, s->neg_all,
+                               stream));
+  RET(tcar_split_bf16(s->att_all, s->ld_att ? s->ld_att : g.ek, Bq, g.ek, s->a16h, s->a16l, g.ek, s->ap16h, s->ap16l, g.ldh + g.pt, g.ldh, g.ic, stream));
   RET(tcar_gemm_bf16(1, Bq, nl, g.ek, s->a16h, s->a16l, g.ek, Bq, c->e16h, c->e16l, g.ek, nlpad, s->logits, nlpad, nullptr, 0, 0,
                      c->scoring, 1, stream));
   return tcar_softmax_stats(Bq, nl, s->logits, nlpad, s->lab_all, s->n0, s->stats, stream);
@@ -614,7 +631,7 @@ extern "C" int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int
   dc.n_items = nl;
   if (K > 0) {
     if (!neg_all || !coef_all) return TCAR_E_ARG;
-    RET(tcar_neg_scatter_range(&c->d, (int64_t)s->world * s->cap, K, s->n0, nl, neg_all, s->att_all, g.ek, coef_all, c->big, stream));
+    RET(tcar_neg_scatter_range(&c->d, (int64_t)s->world * s->cap, K, s->n0, nl, neg_all, s->att_all, s->ld_att ? s->ld_att : g.ek, coef_all, c->big, stream));
   }
   // the shard's dense item norm, BEFORE any gathered row is scattered in (S5), straight into the item slot of the pieces
   tcar_segments_t one = {};
@@ -628,9 +645,9 @@ extern "C" int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int
 }
 
 extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, const float* dx_rows, float* rows_out,
-                                          void* stream) {
+                                          int64_t rows_ld, int64_t rows_total, const float* ce_rows, void* stream) {
   RET(check_ctx(c, bt));
-  if (!c->scoring || !dx_rows || !rows_out) return TCAR_E_ARG;
+  if (!c->scoring || !dx_rows || !rows_out || (rows_ld && (rows_ld < c->d.ldh || (rows_ld & 3)))) return TCAR_E_ARG;
   const Geo g(c->d);
   const int B = bt->B, T = bt->T, BT = B * T;
   const bool has_neg = bt->K > 0 && bt->neg && c->neg_coef && c->negpart;
@@ -681,5 +698,10 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
   tables_of(c, tab);
   grads_of(c, gr);
   gr.rows_out = rows_out;
-  return tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream);
+  gr.rows_ld = rows_ld;
+  RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
+  if (rows_ld > g.ldh && rows_total >= BT)       // packed exchange rows: the ids behind the rows, loss beside them
+    RET(tcar_shard_pack_ids(BT, rows_total, g.ldh, bt->seq, rows_out, rows_ld, B, ce_rows, c->neg_fb, c->neg_weight,
+                            (ce_rows && has_neg) ? c->loss : nullptr, stream));
+  return TCAR_OK;
 }

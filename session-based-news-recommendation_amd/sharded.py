@@ -6,22 +6,25 @@ The replica exchange of dp.py moves the dense item-table gradient and the candid
 their bf16 planes, their gradient, their Adam moments — and scores them against the sessions of EVERY rank:
 
   session forward (local B sessions)   gather, projections, pools, output transforms           -> attout [B, ek]
-  all-gather   attout, labels, negatives, (later) negative-term coefficients                   -> [W*B, ...]
+  all-gather   ONE packed row per session: [attout | label | negative-term coefficient | negatives]    -> [W*B, ld]
   scoring      logits = attout_all . E_shard^T  [W*B, S];  per-shard softmax statistics
   all-gather   (max, sum exp, label logit) per session and shard -> lse, cross entropy          (3 floats per session)
   gradients    dlogits planes;  dE_shard = dlogits^T attout_all (item block | time block) STAYS LOCAL;
                dX_partial = dlogits . E_shard [W*B, ek]
   reduce-scatter dX_partial over the ranks                                                     -> dattout of the local sessions
   session backward (local)            ... -> (id, row) item-row gradients of the local sessions
-  all-gather   (id, row) pairs (as in dp.py); every owner keeps the rows of its shard
+  all-gather   packed [row | id] item-row gradients; every owner keeps the rows of its shard
   all-reduce   arena gradients + IndexedSlices norm pieces (+ the shards' dense item norms)     (5 MB)
-  update       clip + Adam: arena on every rank (identical inputs), item rows by their owner
+  update       clip + Adam: arena on every rank (identical inputs, dense norms summed in a fixed order: identical bits,
+               no broadcast), item rows by their owner
   all-gather   the updated item rows [S, ldh] -> every rank's E (the session-side gathers of the next step read any row)
 
 Per step and rank at W = 8, B = 512, N = 46,033: ~14 MB attout + ~14 MB dX + ~9 MB rows + 5 MB arena + 47 MB item rows
 received, against 2 x 106 MB through the replica all-reduce; the candidate-side memory (planes, gradient, moments: 0.5 GB
 at this size, 130 GB at 10 M items) divides by W.  The clip semantics of DESIGN.md S5 hold exactly: the dense item norm is
 the sum of the shards' norms of (scoring + densified negative part), taken BEFORE the gathered rows are scattered in.
+Six collectives per step (eleven before the exchange buffers were packed): at ~20-40 us of latency each over RCCL they,
+not the bytes, are what a step waits for at this catalog size.
 
 Sequenced from C++ between the exchanges (csrc/step.hip: tcar_step_session_forward / tcar_shard_score / tcar_shard_backward /
 tcar_shard_finish / tcar_step_session_backward), the collectives in between from here; split-bf16 scoring modes only.  Evaluation scores the local sessions against the whole catalog on the fp32 GEMM.
@@ -100,21 +103,26 @@ class ShardedEngine(TcarEngine):
                 "bytes_per_step": dict(self.bytes_moved),
                 "item_rows_allgather_bytes": 4 * self.world * self.S * g.ldh,
                 "replica_mode_allreduce_bytes": 4 * (g.N * (g.ldh + g.pt) + self.arena_n + _lib.NSLOT),
-                "note": "all-gather attout / labels / negatives / softmax stats / (id,row) pairs / updated item rows, "
-                        "reduce-scatter dX, all-reduce arena; the dense item gradient and the candidate-time block stay local"}
+                "collectives_per_step": 6,
+                "note": "all-gather [attout | label | negatives | coefficient] rows, all-gather softmax stats, reduce-scatter dX, "
+                        "all-gather [row | id] item-row gradients, all-reduce arena, all-gather updated item rows; the dense item "
+                        "gradient and the candidate-time block stay local"}
 
     # -------------------------------------------------------------------------------------------- workspace
     def _ensure_score(self, cap: int, K: int):
         g = self.geo
-        Bq = self.world * cap
         if cap > self.cap or K > getattr(self, "_kcap", 0):
+            cap = max(cap, self.cap)
+            Bq = self.world * cap
             f32 = dict(dtype=torch.float32, device=self.dev)
             bf = dict(dtype=torch.bfloat16, device=self.dev)
             Bp = _ru(Bq, 128)
-            self.att_loc = torch.zeros(cap, g.ek, **f32)
-            self.lab_loc = torch.full((cap,), -1, dtype=torch.int32, device=self.dev)
-            self.neg_loc = torch.full((cap, max(K, 1)), -1, dtype=torch.int32, device=self.dev)
-            self.coef_loc = torch.zeros(cap, **f32)
+            kc = max(K, getattr(self, "_kcap", 0), 1)
+            self.ld_head = _ru(g.ek + 2 + kc, 4)
+            self.head_loc = torch.zeros(cap, self.ld_head, **f32)          # [attout | label | neg coefficient | negatives | pad]
+            self.s_lab = torch.full((Bq,), -1, dtype=torch.int32, device=self.dev)      # unpacked by tcar_shard_score
+            self.s_neg = torch.full((Bq, kc), -1, dtype=torch.int32, device=self.dev)
+            self.s_coef = torch.zeros(Bq, **f32)
             self.s_logits = torch.empty(Bq, self.nlpad, **f32)
             self.s_stats = torch.empty(Bq, 3, **f32)
             self.s_lse, self.s_ce = torch.empty(Bq, **f32), torch.empty(Bq, **f32)
@@ -123,7 +131,7 @@ class ShardedEngine(TcarEngine):
             self.s_dl16h, self.s_dl16l = torch.zeros(Bp, self.nlpad, **bf), torch.zeros(Bp, self.nlpad, **bf)
             self.s_slabs = torch.empty(self.splitk, Bq, g.ek, **f32)
             self.s_dx = torch.empty(Bq, g.ek, **f32)
-            self.cap, self._kcap = cap, max(K, 1)
+            self.cap, self._kcap = cap, kc
 
     # two composite spans instead of the three GEMMs of the fused step: the C++ pieces between the exchanges
     TIMED_KERNELS = ("shard_score", "shard_backward")
@@ -162,26 +170,17 @@ class ShardedEngine(TcarEngine):
         self._ensure_score(cap, K)
         has_neg = K > 0
         st = self._stream()
-        self.Gx.zero_()
-        self.sqn_dense.zero_()
-        # ---- session forward + the feed pieces the other ranks need
+        # ---- zero the arena, session forward, and ONE packed row per session for the exchange:
+        # [attout (ek) | label | coefficient of the negative term | K negatives | pad], ints as bits, row stride ld_head —
+        # one all-gather instead of four, packed / unpacked by one kernel each (tcar_shard_begin / tcar_shard_score)
         ctx, sctx = self._ctx(), self._shard_ctx()
         sh = self._shard_desc(cap)
-        if B < cap:                                # padding sessions of this rank: zero attout, no label, no negatives
-            self.att_loc[B:cap].zero_()
-            self.lab_loc[B:cap].fill_(-1)
-            self.neg_loc[B:cap].fill_(-1)
-            self.coef_loc[B:cap].zero_()
-        if bt is not None:
-            check(lib.tcar_step_session_forward(C.byref(ctx), C.byref(bt), st), "tcar_step_session_forward")
-            self.att_loc[:B].copy_(self.attout[:B])
-            self.lab_loc[:B].copy_(torch.as_strided(bt._keep, (B,), (1,), (bt.label - bt._keep.data_ptr()) // 4))
-            if has_neg:
-                self.neg_loc[:B, :K].copy_(torch.as_strided(bt._keep, (B, K), (K, 1), (bt.neg - bt._keep.data_ptr()) // 4))
-                self.coef_loc[:B].copy_(self.neg_coef[:B])
-        att_all = self._allgather(self.att_loc[:cap], "attout").view(Bq, g.ek)
-        lab_all = self._allgather(self.lab_loc[:cap], "labels").view(Bq)
-        sh.att_all, sh.lab_all = att_all.data_ptr(), lab_all.data_ptr()
+        ldh_ = self.ld_head
+        head = self.head_loc[:cap]
+        check(lib.tcar_shard_begin(C.byref(ctx), C.byref(bt) if bt is not None else None, cap, self._kcap, p(head), ldh_, st),
+              "tcar_shard_begin")
+        head_all = self._allgather(head, "attout+labels+negatives").view(Bq, ldh_)
+        sh.att_all, sh.ld_att, sh.head_K = head_all.data_ptr(), ldh_, (K if has_neg else 0)
         # ---- scoring of the shard against every session; statistics exchange; gradients (dE stays here, dX goes home)
         tk = self._tick3(0)
         check(lib.tcar_shard_score(C.byref(sctx), C.byref(sh), int(self._time_dirty), st), "tcar_shard_score")
@@ -192,43 +191,34 @@ class ShardedEngine(TcarEngine):
         check(lib.tcar_shard_backward(C.byref(sctx), C.byref(sh), p(stats_all), st), "tcar_shard_backward")
         self._tock3(tk)
         dx_rows = self._reduce_scatter_rows(self.s_dx[:Bq], cap, "dX")
-        neg_all = coef_all = None
-        if has_neg:
-            neg_all = self._allgather(self.neg_loc[:cap, :K].contiguous(), "negatives").view(Bq, K)
-            coef_all = self._allgather(self.coef_loc[:cap], "neg_coef").view(Bq)
-        check(lib.tcar_shard_finish(C.byref(sctx), C.byref(sh), K if has_neg else 0, p(neg_all) if has_neg else None,
-                                    p(coef_all) if has_neg else None, st), "tcar_shard_finish")
-        # ---- session backward (local) and the sparse-row exchange
+        check(lib.tcar_shard_finish(C.byref(sctx), C.byref(sh), K if has_neg else 0, p(self.s_neg) if has_neg else None,
+                                    p(self.s_coef) if has_neg else None, st), "tcar_shard_finish")
+        # ---- session backward (local) and the sparse-row exchange: packed rows [row (ldh) | id | pad], one all-gather
         nr = cap * T
+        ldr = g.ldh + 4
         if getattr(self, "_rows_cap", 0) < nr:
-            self._rows_buf = torch.zeros(nr, g.ldh, dtype=torch.float32, device=self.dev)
-            self._ids_buf = torch.zeros(nr, dtype=torch.int32, device=self.dev)
+            self._rows_buf = torch.zeros(nr, ldr, dtype=torch.float32, device=self.dev)
             self._rows_cap = nr
-        rows, ids = self._rows_buf[:nr], self._ids_buf[:nr]
-        if B * T < nr:                              # padding rows: id 0 (skipped by the scatter), zero row
-            rows[B * T:].zero_()
-            ids[B * T:].zero_()
+        rows = self._rows_buf[:nr]
         if bt is not None:
             if not dx_rows.is_contiguous():
                 dx_rows = dx_rows.contiguous()
-            check(lib.tcar_step_session_backward(C.byref(ctx), C.byref(bt), p(dx_rows), p(rows), st), "tcar_step_session_backward")
-            ids[:B * T].copy_(bt._seq_t[:B * T])
-            if has_neg:
-                torch.add(self.s_ce[self.dp_rank * cap:self.dp_rank * cap + B], self.neg_fb[:B], alpha=self.neg_weight,
-                          out=self.loss[:B])
-        all_ids = self._allgather(ids, "row_ids").view(-1)
-        all_rows = self._allgather(rows, "rows").view(-1, g.ldh)
-        shifted = all_ids - n0                      # ids are 1-based: rows of this shard become 1 .. nl, the rest fall out
-        check(lib.tcar_scatter_add_rows(C.byref(self.dims_cand), p(shifted), p(all_rows), shifted.numel(), p(self.Gi), st),
-              "tcar_scatter_add_rows")
-        # ---- arena exchange (gradients + norm pieces incl. the shards' dense item norms), dense-weight norms, update
+            ce_rows = self.s_ce[self.dp_rank * cap:self.dp_rank * cap + B]
+            check(lib.tcar_step_session_backward(C.byref(ctx), C.byref(bt), p(dx_rows), p(rows), ldr, nr, p(ce_rows), st),
+                  "tcar_step_session_backward")
+        else:
+            rows.view(torch.int32)[:, g.ldh] = 0    # an empty rank contributes padding rows only (id 0)
+        all_rows = self._allgather(rows, "rows+ids").view(-1, ldr)
+        # ids are 1-based: the rows of this shard become 1 .. nl, the rest (and the id-0 padding) fall out
+        check(lib.tcar_scatter_add_rows_packed(C.byref(self.dims_cand), p(all_rows), ldr, all_rows.shape[0], n0, p(self.Gi), st),
+              "tcar_scatter_add_rows_packed")
+        # ---- arena exchange (gradients + norm pieces incl. the shards' dense item norms), dense-weight norms, update.  The
+        # dense-weight norms are summed in a fixed order (tcar_sqnorm, one workgroup per variable): identical gradients give
+        # identical norms on every rank, the replicas stay bit-identical without a broadcast.
         if W > 1:
             dist.all_reduce(self.Gx, group=self.group)
             self.bytes_moved["arena"] = self.Gx.numel() * 4
         check(lib.tcar_sqnorm(p(self.G), C.byref(self.segs_dense), p(self.sqn_dense), st), "tcar_sqnorm")
-        if W > 1:
-            dist.broadcast(self.sqn_dense, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                           group=self.group)        # atomically summed norms: one rank's bits for everyone (identical replicas)
         if update:
             self._update_and_share()
 
@@ -239,7 +229,8 @@ class ShardedEngine(TcarEngine):
             sh.world, sh.cap, sh.n0, sh.n_loc = self.world, cap, self.n0, self.nl
             for n, t in (("logits", self.s_logits), ("stats", self.s_stats), ("lse", self.s_lse), ("ce", self.s_ce),
                          ("a16h", self.s_a16h), ("a16l", self.s_a16l), ("ap16h", self.s_ap16h), ("ap16l", self.s_ap16l),
-                         ("dl16h", self.s_dl16h), ("dl16l", self.s_dl16l), ("slabs", self.s_slabs), ("dx", self.s_dx)):
+                         ("dl16h", self.s_dl16h), ("dl16l", self.s_dl16l), ("slabs", self.s_slabs), ("dx", self.s_dx),
+                         ("lab_all", self.s_lab), ("neg_all", self.s_neg), ("coef_all", self.s_coef)):
                 setattr(sh, n, t.data_ptr())
             self._sh, self._sh_key = sh, key
         return self._sh
