@@ -432,7 +432,8 @@ int tcar_form_batch(const tcar_dims_t* d, const tcar_store_t* st, const tcar_neg
  *   tcar_softmax_combine  stats_all [W, B, 3] (all-gathered) -> lse [B], ce [B] = lse - label logit (ce may be NULL);
  *                         label != NULL: sessions with label < 0 (padding of an uneven shard) get lse = +inf, i.e. a zero
  *                         gradient row
- *   tcar_softmax_grad     dlogits = exp(x - lse) - onehot as bf16 hi / lo KB32 planes [ceil128(B), ld] (ld % 32 == 0)
+ *   tcar_softmax_grad     dlogits = exp(x - lse) - onehot as bf16 hi / lo KB32 planes [ceil128(B), ld] (ld % 32 == 0;
+ *                         dl_lo may be NULL: hi-only backward)
  *   tcar_neg_scatter_range  g_item[neg[b,k] - n0, 0:ldh] += coef[b] * attout[b, 0:ldh] for the negatives inside the shard */
 int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld, const int32_t* label, int n0, float* stats, void* stream);
 int tcar_softmax_combine(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce, void* stream);
@@ -458,7 +459,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 9
+#define TCAR_ABI_VERSION 10
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -585,7 +586,12 @@ int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, cons
                                const float* ce_rows /* NULL, or [B]: also loss = ce_rows + neg_weight * neg_fb */, void* stream);
 /* first piece of the catalog-sharded step: zero the gradient arena, session forward (+ negative-term forward) of the local
  * sessions — bt may be NULL on a rank whose shard of the batch is empty — and the packed exchange rows (tcar_shard_pack_head) */
-int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int Kc, float* head, int64_t ld_head, void* stream);
+int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int Kc, float* head, int64_t ld_head,
+                     int refresh_time /* as for tcar_shard_score: with an aux stream the shard's time planes are rebuilt there */,
+                     int n_loc, void* stream);
+/* orders `stream` behind the aux-stream work of the step (tcar_shard_finish, weight gradients): call before
+ * tcar_scatter_add_rows_packed and the arena exchange */
+int tcar_shard_join(const tcar_ctx_t* c, void* stream);
 
 #ifdef __cplusplus
 }

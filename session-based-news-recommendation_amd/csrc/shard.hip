@@ -50,6 +50,53 @@ __global__ __launch_bounds__(256) void softmax_stats_kernel(int B, int N, const 
   }
 }
 
+// the same from ONE read of the row: it is held in registers between the max and the sum (rows of up to NT * 4 * R columns)
+template <int NT, int R>
+__global__ __launch_bounds__(NT) void softmax_stats_rows_kernel(int B, int N, const float* __restrict__ logits, long ld,
+                                                                const int32_t* __restrict__ label, int n0, float* __restrict__ stats) {
+  __shared__ float sh[NT / 64];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const float* row = logits + (long)b * ld;
+  const float ninf = -INFINITY;
+  float4 v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int c = (tid + r * NT) * 4;
+    v[r] = (c < N) ? ld4(row + c) : make_float4(ninf, ninf, ninf, ninf);        // ld >= ceil4(N): the load stays inside the row
+  }
+  float m = ninf;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int c = (tid + r * NT) * 4;
+    if (c + 1 >= N) v[r].y = ninf;
+    if (c + 2 >= N) v[r].z = ninf;
+    if (c + 3 >= N) v[r].w = ninf;
+    m = fmaxf(m, fmaxf(fmaxf(v[r].x, v[r].y), fmaxf(v[r].z, v[r].w)));
+  }
+  m = wave_max(m);
+  if (lane == 0) sh[w] = m;
+  __syncthreads();
+  float gm = sh[0];
+#pragma unroll
+  for (int i = 1; i < NT / 64; ++i) gm = fmaxf(gm, sh[i]);
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) s += (expf(v[r].x - gm) + expf(v[r].y - gm)) + (expf(v[r].z - gm) + expf(v[r].w - gm));
+  s = wave_sum(s);
+  if (lane == 0) sh[w] = s;
+  __syncthreads();
+  if (tid == 0) {
+    float gs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) gs += sh[i];
+    const int lab = label[b] - n0;
+    stats[3L * b + 0] = gm;
+    stats[3L * b + 1] = gs;
+    stats[3L * b + 2] = (lab >= 0 && lab < N) ? row[lab] : 0.f;
+  }
+}
+
 // stats_all [W, B, 3] -> lse [B], ce [B] = lse - label logit (the label lives in exactly one shard; the others sent 0)
 __global__ __launch_bounds__(256) void softmax_combine_kernel(int W, int B, const float* __restrict__ stats_all,
                                                               const int32_t* __restrict__ label, float* __restrict__ lse,
@@ -84,7 +131,7 @@ __global__ __launch_bounds__(256) void softmax_grad_kernel(int B, int N, const f
       const long o = kb32_off(b, c, in32);
       const bf16x4_h z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
       *reinterpret_cast<bf16x4_h*>(dh + o) = z;
-      *reinterpret_cast<bf16x4_h*>(dl + o) = z;
+      if (dl) *reinterpret_cast<bf16x4_h*>(dl + o) = z;
     }
     return;
   }
@@ -103,7 +150,7 @@ __global__ __launch_bounds__(256) void softmax_grad_kernel(int B, int N, const f
     }
     const long o = kb32_off(b, c, in32);
     *reinterpret_cast<bf16x4_h*>(dh + o) = h;
-    *reinterpret_cast<bf16x4_h*>(dl + o) = lo;
+    if (dl) *reinterpret_cast<bf16x4_h*>(dl + o) = lo;
   }
 }
 
@@ -175,7 +222,12 @@ extern "C" int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld,
                                   void* stream) {
   if (B <= 0) return TCAR_OK;
   if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !stats) return TCAR_E_ARG;
-  TCAR_LAUNCH(softmax_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, N, logits, (long)ld, label, n0, stats);
+  if (N <= 512 * 4 * 8)
+    TCAR_LAUNCH((softmax_stats_rows_kernel<512, 8>), dim3(B), dim3(512), 0, (hipStream_t)stream, B, N, logits, (long)ld, label, n0, stats);
+  else if (N <= 512 * 4 * 24)
+    TCAR_LAUNCH((softmax_stats_rows_kernel<512, 24>), dim3(B), dim3(512), 0, (hipStream_t)stream, B, N, logits, (long)ld, label, n0, stats);
+  else
+    TCAR_LAUNCH(softmax_stats_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, B, N, logits, (long)ld, label, n0, stats);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -192,7 +244,7 @@ extern "C" int tcar_softmax_combine(int W, int B, const float* stats_all, const 
 extern "C" int tcar_softmax_grad(int B, int N, const float* logits, int64_t ld, const float* lse, const int32_t* label, int n0,
                                  void* dl_hi, void* dl_lo, void* stream) {
   if (B <= 0) return TCAR_OK;
-  if (N <= 0 || ld < N || (ld & 31) || !tcar_aligned16(logits) || !lse || !label || !dl_hi || !dl_lo) return TCAR_E_ARG;
+  if (N <= 0 || ld < N || (ld & 31) || !tcar_aligned16(logits) || !lse || !label || !dl_hi) return TCAR_E_ARG;
   TCAR_LAUNCH(softmax_grad_kernel, dim3((B + 127) & ~127), dim3(256), 0, (hipStream_t)stream, B, N, logits, (long)ld, lse, label, n0,
               (__bf16*)dl_hi, (__bf16*)dl_lo);
   TCAR_CHECK_LAUNCH();

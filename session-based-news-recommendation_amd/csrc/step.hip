@@ -554,10 +554,22 @@ extern "C" int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t
 }
 
 extern "C" int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int Kc, float* head, int64_t ld_head,
-                                void* stream) {
-  if (!c || !c->scoring || !c->Gx || !c->sqn_dense || !head || cap <= 0) return TCAR_E_ARG;
+                                int refresh_time, int n_loc, void* stream) {
+  if (!c || !c->scoring || !c->Gx || !c->sqn_dense || !head || cap <= 0 || n_loc <= 0) return TCAR_E_ARG;
   const Geo g(c->d);
-  hipStream_t st = (hipStream_t)stream;
+  hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
+  if (refresh_time && s2) {
+    // the candidate-side time planes of the shard depend on the time tables only: rebuilt on the aux stream beside the session
+    // forward pass and the first all-gather (tcar_shard_score joins)
+    tcar_dims_t dc = c->d;
+    dc.n_items = n_loc;
+    const float* tt[5];
+    for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+    if (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
+      return TCAR_E_LAUNCH;
+    RET(tcar_cand_time_fwd_bf16(&dc, tt, c->mwdhm, nullptr, c->e16h, c->e16l, (void*)s2));
+    if (hipEventRecord((hipEvent_t)c->ev[5], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  }
   if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
   if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
   if (!bt) return tcar_shard_pack_head(0, cap, g.ek, 0, Kc, nullptr, nullptr, nullptr, nullptr, head, ld_head, stream);
@@ -584,9 +596,14 @@ extern "C" int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int 
   tcar_dims_t dc = c->d;
   dc.n_items = nl;
   if (refresh_time) {
-    const float* tt[5];
-    for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-    RET(tcar_cand_time_fwd_bf16(&dc, tt, c->mwdhm, nullptr, c->e16h, c->e16l, stream));
+    if (hipStream_t s2 = aux_stream(c)) {      // tcar_shard_begin issued the refresh on the aux stream
+      (void)s2;
+      if (hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)c->ev[5], 0) != hipSuccess) return TCAR_E_LAUNCH;
+    } else {
+      const float* tt[5];
+      for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+      RET(tcar_cand_time_fwd_bf16(&dc, tt, c->mwdhm, nullptr, c->e16h, c->e16l, stream));
+    }
   }
   if (s->ld_att > g.ek)     // packed exchange rows: label / negatives / coefficient ride behind attout
     RET(tcar_shard_unpack_head(Bq, g.ek, s->head_K, s->att_all, s->ld_att, const_cast<int32_t*>(s->lab_all), s->coef_all, s->neg_all,
@@ -604,7 +621,7 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
   const int Bq = s->world * s->cap, nl = s->n_loc, nlpad = (nl + 127) & ~127, Bp = (Bq + 127) & ~127;
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   RET(tcar_softmax_combine(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, stream));
-  RET(tcar_softmax_grad(Bq, nl, s->logits, nlpad, s->lse, s->lab_all, s->n0, s->dl16h, s->dl16l, stream));
+  RET(tcar_softmax_grad(Bq, nl, s->logits, nlpad, s->lse, s->lab_all, s->n0, s->dl16h, nsb == 1 ? nullptr : s->dl16l, stream));
   float* Gi = c->big;
   float* d_et = c->big + (size_t)nl * g.ldh;
   // dE of the shard on the aux stream beside dX (the caller's stream: dX heads for the reduce-scatter, the critical path)
@@ -618,8 +635,7 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
   RET(tcar_gemm_bf16(0, Bq, g.ek, nlpad, s->dl16h, s->dl16l, nlpad, Bp, c->e16h, c->e16l, g.ek, nlpad, s->slabs, g.ek, nullptr, 0,
                      0, nsb, c->splitk, stream));
   RET(tcar_splitk_reduce(s->slabs, S, Bq, g.ek, g.ek, s->dx, stream));
-  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;     // dE is in: tcar_shard_finish
-  return TCAR_OK;
+  return TCAR_OK;      // dE is still running on the aux stream: tcar_shard_finish queues behind it there, tcar_shard_join joins
 }
 
 extern "C" int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int K, const int32_t* neg_all, const float* coef_all,
@@ -629,19 +645,33 @@ extern "C" int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int
   const int nl = s->n_loc;
   tcar_dims_t dc = c->d;
   dc.n_items = nl;
+  // Everything here needs dE (aux stream, tcar_shard_backward) and nothing of the dX exchange: it queues behind dE on the aux
+  // stream and runs beside the reduce-scatter and the session backward; tcar_shard_join orders the main stream behind it.
+  hipStream_t s2 = aux_stream(c);
+  void* sf = s2 ? (void*)s2 : stream;
   if (K > 0) {
     if (!neg_all || !coef_all) return TCAR_E_ARG;
-    RET(tcar_neg_scatter_range(&c->d, (int64_t)s->world * s->cap, K, s->n0, nl, neg_all, s->att_all, s->ld_att ? s->ld_att : g.ek, coef_all, c->big, stream));
+    RET(tcar_neg_scatter_range(&c->d, (int64_t)s->world * s->cap, K, s->n0, nl, neg_all, s->att_all, s->ld_att ? s->ld_att : g.ek, coef_all, c->big, sf));
   }
   // the shard's dense item norm, BEFORE any gathered row is scattered in (S5), straight into the item slot of the pieces
   tcar_segments_t one = {};
   one.nseg = 1; one.off[0] = 0; one.len[0] = (int64_t)nl * g.ldh; one.slot[0] = c->slot_item;
-  RET(tcar_sqnorm(c->big, &one, c->Gx + c->arena_n, stream));
+  RET(tcar_sqnorm(c->big, &one, c->Gx + c->arena_n, sf));
   tcar_grads_t gr;
   grads_of(c, gr);
   const float* tt[5];
   for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-  return tcar_cand_time_bwd_indexed(&dc, tt, c->inv_n, c->inv_off, c->big + (size_t)nl * g.ldh, 1, c->ct_ws, &gr, stream);
+  RET(tcar_cand_time_bwd_indexed(&dc, tt, c->inv_n, c->inv_off, c->big + (size_t)nl * g.ldh, 1, c->ct_ws, &gr, sf));
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  return TCAR_OK;
+}
+
+// the main stream behind everything the aux stream still holds of this step (dE, negative rows, shard norm, candidate-time
+// backward, weight gradients): before the gathered rows are scattered into the shard's gradient and the arena is exchanged
+extern "C" int tcar_shard_join(const tcar_ctx_t* c, void* stream) {
+  if (!c) return TCAR_E_ARG;
+  if (aux_stream(c) && hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)c->ev[3], 0) != hipSuccess) return TCAR_E_LAUNCH;
+  return TCAR_OK;
 }
 
 extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, const float* dx_rows, float* rows_out,
@@ -691,7 +721,12 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
     p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
     p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
     p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
-    RET(small_gemm(c, 2, 9, p, stream));
+    // beside the row gradients on the aux stream (behind tcar_shard_finish there); tcar_shard_join covers it
+    hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
+    if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+      return TCAR_E_LAUNCH;
+    RET(small_gemm(c, 2, 9, p, s2 ? (void*)s2 : stream));
+    if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
   tcar_tables_t tab;
   tcar_grads_t gr;

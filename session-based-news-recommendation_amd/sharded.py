@@ -177,22 +177,25 @@ class ShardedEngine(TcarEngine):
         sh = self._shard_desc(cap)
         ldh_ = self.ld_head
         head = self.head_loc[:cap]
-        check(lib.tcar_shard_begin(C.byref(ctx), C.byref(bt) if bt is not None else None, cap, self._kcap, p(head), ldh_, st),
-              "tcar_shard_begin")
+        refresh = int(self._time_dirty)
+        check(lib.tcar_shard_begin(C.byref(ctx), C.byref(bt) if bt is not None else None, cap, self._kcap, p(head), ldh_, refresh,
+                                   nl, st), "tcar_shard_begin")
         head_all = self._allgather(head, "attout+labels+negatives").view(Bq, ldh_)
         sh.att_all, sh.ld_att, sh.head_K = head_all.data_ptr(), ldh_, (K if has_neg else 0)
         # ---- scoring of the shard against every session; statistics exchange; gradients (dE stays here, dX goes home)
         tk = self._tick3(0)
-        check(lib.tcar_shard_score(C.byref(sctx), C.byref(sh), int(self._time_dirty), st), "tcar_shard_score")
+        check(lib.tcar_shard_score(C.byref(sctx), C.byref(sh), refresh, st), "tcar_shard_score")
         self._tock3(tk)
         self._time_dirty = False
         stats_all = self._allgather(self.s_stats[:Bq], "softmax_stats")
         tk = self._tick3(1)
         check(lib.tcar_shard_backward(C.byref(sctx), C.byref(sh), p(stats_all), st), "tcar_shard_backward")
         self._tock3(tk)
-        dx_rows = self._reduce_scatter_rows(self.s_dx[:Bq], cap, "dX")
+        # negative rows, shard norm, candidate-time backward: on the aux stream behind dE, beside the dX exchange and the
+        # session backward (tcar_shard_join orders the main stream behind them)
         check(lib.tcar_shard_finish(C.byref(sctx), C.byref(sh), K if has_neg else 0, p(self.s_neg) if has_neg else None,
                                     p(self.s_coef) if has_neg else None, st), "tcar_shard_finish")
+        dx_rows = self._reduce_scatter_rows(self.s_dx[:Bq], cap, "dX")
         # ---- session backward (local) and the sparse-row exchange: packed rows [row (ldh) | id | pad], one all-gather
         nr = cap * T
         ldr = g.ldh + 4
@@ -209,6 +212,7 @@ class ShardedEngine(TcarEngine):
         else:
             rows.view(torch.int32)[:, g.ldh] = 0    # an empty rank contributes padding rows only (id 0)
         all_rows = self._allgather(rows, "rows+ids").view(-1, ldr)
+        check(lib.tcar_shard_join(C.byref(ctx), st), "tcar_shard_join")
         # ids are 1-based: the rows of this shard become 1 .. nl, the rest (and the id-0 padding) fall out
         check(lib.tcar_scatter_add_rows_packed(C.byref(self.dims_cand), p(all_rows), ldr, all_rows.shape[0], n0, p(self.Gi), st),
               "tcar_scatter_add_rows_packed")
