@@ -4,7 +4,9 @@
   the fp64 oracle — loss, every gradient, the clip norms, the variables after Adam steps;
 * world 2 on ONE GPU (gloo moving CUDA tensors through the host; RCCL needs > 1 GPU): uneven session shards and a rank whose
   shard of a batch is empty, against a single engine that sees the whole batch; the replicas must agree BIT FOR BIT (every item
-  row has one owner, the dense-weight norms are broadcast)."""
+  row has one owner, the dense-weight norms are summed in a fixed order);
+* the packed exchange rows (tcar_shard_pack_head / _unpack_head / _pack_ids, tcar_scatter_add_rows_packed) and the
+  fixed-order dense norm at op level."""
 import os
 import socket
 import sys
@@ -116,3 +118,75 @@ def test_two_ranks_sharded_match_single_engine():
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", ret.get(r)
+
+
+def test_packed_exchange_rows_and_fixed_order_norm():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import ctypes as C
+    import tcar_amd  # noqa: F401
+    from tcar_amd import _lib
+    from tcar_amd._lib import Dims, Segments
+    lib = _lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rng = np.random.RandomState(5)
+    B, cap, ek, K, Kc = 37, 48, 832, 7, 9
+    ld = (ek + 2 + Kc + 3) // 4 * 4
+    att = torch.tensor(rng.standard_normal((B, ek)).astype(np.float32), device="cuda")
+    lab = torch.tensor(rng.randint(0, 1000, B).astype(np.int32), device="cuda")
+    coef = torch.tensor(rng.standard_normal(B).astype(np.float32), device="cuda")
+    neg = torch.tensor(rng.randint(0, 1000, (B, K)).astype(np.int32), device="cuda")
+    head = torch.full((cap, ld), 7.0, device="cuda")
+    assert lib.tcar_shard_pack_head(B, cap, ek, K, Kc, p(att), p(lab), p(coef), p(neg), p(head), ld, None) == 0
+    hi = head.view(torch.int32)
+    assert torch.equal(head[:B, :ek], att) and (head[B:, :ek] == 0).all()
+    assert torch.equal(hi[:B, ek], lab) and (hi[B:, ek] == -1).all()
+    assert torch.equal(head[:B, ek + 1], coef) and (head[B:, ek + 1] == 0).all()
+    assert torch.equal(hi[:B, ek + 2:ek + 2 + K], neg) and (hi[:, ek + 2 + K:ek + 2 + Kc] == -1).all() and (hi[B:, ek + 2:ek + 2 + Kc] == -1).all()
+    # two "ranks" worth of rows back into contiguous arrays
+    both = torch.cat([head, head])
+    Bq = 2 * cap
+    lab_o = torch.zeros(Bq, dtype=torch.int32, device="cuda")
+    coef_o = torch.zeros(Bq, device="cuda")
+    neg_o = torch.zeros(Bq, K, dtype=torch.int32, device="cuda")
+    assert lib.tcar_shard_unpack_head(Bq, ek, K, p(both), ld, p(lab_o), p(coef_o), p(neg_o), None) == 0
+    assert torch.equal(lab_o[:B], lab) and torch.equal(lab_o[cap:cap + B], lab) and (lab_o[B:cap] == -1).all()
+    assert torch.equal(coef_o[:B], coef) and torch.equal(neg_o[cap:cap + B], neg) and (neg_o[B:cap] == -1).all()
+    # packed item rows: [row | id | pad], shifted owner range, padding ids 0
+    ldh, T, N = 256, 3, 500
+    d = Dims(200, 250, 64, ldh, 64)                                       # a shard of 200 rows starting at id0 = 150
+    nlive, ntot, ldr = B * T, cap * T, ldh + 4
+    seq = torch.tensor(rng.randint(1, N + 1, nlive).astype(np.int32), device="cuda")
+    rows = torch.zeros(ntot, ldr, device="cuda")
+    rows[:, :ldh] = torch.tensor(rng.standard_normal((ntot, ldh)).astype(np.float32), device="cuda")
+    ce, fb, loss = torch.rand(B, device="cuda"), torch.rand(B, device="cuda"), torch.zeros(B, device="cuda")
+    assert lib.tcar_shard_pack_ids(nlive, ntot, ldh, p(seq), p(rows), ldr, B, p(ce), p(fb), 0.5, p(loss), None) == 0
+    ri = rows.view(torch.int32)
+    assert torch.equal(ri[:nlive, ldh], seq) and (ri[nlive:, ldh] == 0).all()
+    np.testing.assert_allclose(loss.cpu().numpy(), (ce + 0.5 * fb).cpu().numpy(), rtol=1e-6)
+    g = torch.zeros(200, ldh, device="cuda")
+    assert lib.tcar_scatter_add_rows_packed(C.byref(d), p(rows), ldr, ntot, 150, p(g), None) == 0
+    want = np.zeros((200, ldh), dtype=np.float64)
+    sq, rw = seq.cpu().numpy(), rows[:nlive, :ldh].cpu().numpy().astype(np.float64)
+    for r in range(nlive):
+        if 150 < sq[r] <= 350:
+            want[sq[r] - 151] += rw[r]
+    np.testing.assert_allclose(g.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # dense-weight norms: one workgroup per segment, fixed order -> bit-for-bit repeatable, equal to the fp64 sums
+    segs = Segments()
+    lens = [64, 250 * 256, 512 * 256, 4]
+    arena = torch.tensor(rng.standard_normal(sum(lens)).astype(np.float32), device="cuda")
+    segs.nseg, off = len(lens), 0
+    for i, n in enumerate(lens):
+        segs.off[i], segs.len[i], segs.slot[i] = off, n, i
+        off += n
+    outs = []
+    for _ in range(3):
+        sqn = torch.zeros(_lib.NSLOT, device="cuda")
+        assert lib.tcar_sqnorm(p(arena), C.byref(segs), p(sqn), None) == 0
+        outs.append(sqn.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    a64, off = arena.cpu().numpy().astype(np.float64), 0
+    for i, n in enumerate(lens):
+        np.testing.assert_allclose(outs[0][i], (a64[off:off + n] ** 2).sum(), rtol=1e-5)
+        off += n
