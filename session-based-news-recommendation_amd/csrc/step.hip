@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -31,7 +31,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}};
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}};
   for (auto& e : tab) {
     bool same = true;
     for (int i = 0; same; ++i) {
@@ -299,28 +299,34 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   auto tick = [&](int kind, bool stop, void* s) {
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)(stop ? c->ev_stop : c->ev_start)[kind * c->ev_n + ei], (hipStream_t)s);
   };
-  tick(2, false, sB);
-  if (c->scoring) {
-    // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
-    RET(tcar_gemm_bf16_perm(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h,
-                            c->ap16l, g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, c->et_perm, g.ldt, nsb, 1,
-                            sB));
-  } else {  // dE = dlogits^T attout: item block and time block (content is frozen)
-    tcar_gemm_desc_t p[2];
-    p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
-    p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
-    RET(small_gemm(c, 2, 2, p, sB));
-  }
-  tick(2, true, sB);
-  // Fused single-rank step: the aux stream goes straight on to the candidate-side time backward (it needs only d_et),
-  // while the negative rows and the dense item norm (they need Gi) are appended to the MAIN chain, which has slack
-  // once dX has been given priority.  Rank-local backward: negative rows here, the rest in tcar_step_finish.
   const bool split_finish = fuse_finish && s2;
-  if (split_finish && hipEventRecord((hipEvent_t)c->ev[4], s2) != hipSuccess) return TCAR_E_LAUNCH;         // dE done
-  if (has_neg && !split_finish)
-    RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, sB));
-  if (fuse_finish) RET(split_finish ? cand_time_backward(c, g, sB) : finish_dense_side(c, g, sB));
-  if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // chain B done
+  auto chain_b = [&]() -> int {
+    tick(2, false, sB);
+    if (c->scoring) {
+      // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
+      RET(tcar_gemm_bf16_perm(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h,
+                              c->ap16l, g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, c->et_perm, g.ldt, nsb, 1,
+                              sB));
+    } else {  // dE = dlogits^T attout: item block and time block (content is frozen)
+      tcar_gemm_desc_t p[2];
+      p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
+      p[1] = prob1(g.N, g.pt, c->logits, g.Npad, c->attout + g.ic, g.ek, B, d_et, g.pt);
+      RET(small_gemm(c, 2, 2, p, sB));
+    }
+    tick(2, true, sB);
+    // Fused single-rank step: the aux stream goes straight on to the candidate-side time backward (it needs only d_et),
+    // while the negative rows and the dense item norm (they need Gi) are appended to the MAIN chain, which has slack
+    // once dX has been given priority.  Rank-local backward: negative rows here, the rest in tcar_step_finish.
+    if (split_finish && hipEventRecord((hipEvent_t)c->ev[4], s2) != hipSuccess) return TCAR_E_LAUNCH;         // dE done
+    if (has_neg && !split_finish)
+      RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, sB));
+    if (fuse_finish) RET(split_finish ? cand_time_backward(c, g, sB) : finish_dense_side(c, g, sB));
+    if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // chain B done
+    return TCAR_OK;
+  };
+  // TCAR_DE_LATE=1 (fused step): dE starts only after dX and its slab reduce, instead of beside them
+  const bool de_late = split_finish && tcar_tuning().de_late != 0;
+  if (!de_late) RET(chain_b());
   // ---- chain A
   tick(1, false, stream);
   if (c->scoring) {
@@ -336,6 +342,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
                               c->dattout, G(c, TCAR_V_O_B), g.ic, G(c, TCAR_V_OT_B), stream));
   if (!has_neg && hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
+  if (de_late) {
+    if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
+      return TCAR_E_LAUNCH;
+    RET(chain_b());
+  }
   {
     tcar_gemm_desc_t p[2];
     p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->dpooled, g.ek);
