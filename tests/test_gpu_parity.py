@@ -956,19 +956,28 @@ def test_gather_forward_throughput_form_equals_latency_form(lib, B, T, H, Ht):
     assert not (outs[1][0] == 7.0).all() and float(np.abs(outs[1][2][0]).max()) == 0.0      # the bucket-11 row is zero
 
 
-@pytest.mark.parametrize("B,T,K,N", [(512, 2, 20, 3000), (64, 40, 7, 50), (300, 5, 0, 100000), (1, 1, 3, 10), (2048, 40, 2, 500)])
-def test_sorted_segmented_item_scatter(lib, B, T, K, N):
+@pytest.mark.parametrize("B,T,K,N,ldh", [(512, 2, 20, 3000, 256), (64, 40, 7, 50, 256), (300, 5, 0, 100000, 256), (1, 1, 3, 10, 256),
+                                         (2048, 40, 2, 500, 256), (512, 32, 33, 2, 256), (128, 3, 4, 1_000_000, 512),
+                                         (4096, 4, 1, 70000, 320)])
+def test_sorted_segmented_item_scatter(lib, B, T, K, N, ldh):
     """tcar_segsum_*: the item-row gradients of the gathers (mode 0) and of the negatives (mode 1) added into the dense
     gradient by sort + segmented sum — head-heavy ids (runs of hundreds: multi-chunk runs), against np.add.at in fp64, the
     folds of the norms, and bit-for-bit repeatability.  Lists of up to 16384 sources are sorted in LDS, the last case takes
-    the rocPRIM path for its session list; its head article has a run of thousands (summed by a whole workgroup)."""
+    the rocPRIM path for its session list; its head article has a run of thousands (summed by a whole workgroup).  The last
+    three: a 2-item catalog with both lists at / over the LDS-sort limit (16,384 session sources exactly, 16,896 negatives:
+    one 1-bit pass, runs of thousands), a 1 M-item catalog (20 key bits: five passes) with 512-column rows (two column
+    chunks per wave), and a row width that is not a multiple of 256."""
     from tcar_amd._lib import Batch, Dims
     rng = np.random.RandomState(B + T + K)
-    ldh, ek = 256, 832
-    d = Dims(N, 250, 64, ldh, 64)
-    zipf = np.minimum(rng.zipf(1.3, size=(B, T)), N).astype(np.int32)                 # ids 1..N, head heavy
+    ek = 2 * ldh + 320
+    d = Dims(N, ldh - 6, 64, ldh, 64)
+    zipf = np.minimum(rng.zipf(1.3, size=(B, T)), N).astype(np.int32)                 # ids 1..N, head heavy ...
+    far = rng.rand(B, T) < 0.4                                                         # ... and a tail that uses every key bit
+    zipf[far] = rng.randint(1, N + 1, size=int(far.sum()))
     seq = torch.tensor(zipf, device="cuda")
     neg_np = (np.minimum(rng.zipf(1.5, size=(B, max(K, 1))), N) - 1).astype(np.int32)
+    farn = rng.rand(B, max(K, 1)) < 0.4
+    neg_np[farn] = rng.randint(0, N, size=int(farn.sum()))
     neg = torch.tensor(neg_np, device="cuda")
     rows_np = rng.standard_normal((B * T, ldh)).astype(np.float32)
     coef_np = rng.standard_normal(B).astype(np.float32)
