@@ -246,6 +246,12 @@ int tcar_attn_pool_bwd_q(const tcar_dims_t* d, int B, int T, const float* x_icp,
                          const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
                          float* dx_pt, float* dq, float* dpre1, float* dpre2, float* g_wres1, float* g_wres2,
                          float* g_qbias, void* stream);
+/* order-fixed form of the same: dq leaves through tanh'(q), the per-session rows d w_res1 | d w_res2 are written to gw_rows
+ * [B, 2*ldh] and nothing is summed atomically (tcar_colsum_det folds gw_rows and dq into the three gradients) */
+int tcar_attn_pool_bwd_det(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1,
+                           const float* pre2, const float* q, const float* w_res1, const float* w_res2, const float* alpha,
+                           const float* dpooled, float* dx_icp, float* dx_pt, float* dq, float* dpre1, float* dpre2,
+                           float* gw_rows, void* stream);
 
 /* ---- scoring loss -----------------------------------------------------------------------------------------
  * tcar_softmax_ce: tf.nn.sparse_softmax_cross_entropy_with_logits (model_combine.py:145) and its gradient.
@@ -313,6 +319,14 @@ typedef struct {
 } tcar_segments_t;
 
 /* sqn_dense[slot] += sum g^2 over each segment. */
+/* dst[c] += sum over rows of x[r, c] in a FIXED order (64 columns per workgroup, 16 row phases folded in order): the bias
+ * gradients of linear_2d (column sums of dy * act', modules.py:52-54 backward) and the residual-weight gradients of the
+ * attention layers without float atomics.  Up to 8 matrices per launch. */
+typedef struct {
+  const float* x; int64_t ld; int32_t rows, cols;
+  float* dst;
+} tcar_colsum_t;
+int tcar_colsum_det(int nseg, const tcar_colsum_t* segs /*host*/, void* stream);
 /* (segments of <= 262,144 floats: one workgroup each, fixed summation order — identical inputs give identical bits;
  *  longer segments: chunked with one float atomic per chunk) */
 int tcar_sqnorm(const float* g, const tcar_segments_t* segs /*host*/, float* sqn_dense, void* stream);
@@ -459,7 +473,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 10
+#define TCAR_ABI_VERSION 11
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -523,6 +537,9 @@ typedef struct {
   /* optional workspace of the sorted segmented sum (tcar_segsum_*): with it the fused step adds the item-row gradients of
    * the gathers and of the negatives in a fixed order (bit-for-bit repeatable) instead of with float atomics */
   void* segsum_ws; int64_t segsum_bytes;
+  /* optional [B, 2*ldh] workspace: with it (split-bf16 modes) the bias gradients and the residual-weight gradients are column
+   * sums in a fixed order (tcar_attn_pool_bwd_det + tcar_colsum_det) instead of float atomics */
+  float* gw_rows;
 } tcar_ctx_t;
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */

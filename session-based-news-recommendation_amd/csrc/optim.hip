@@ -81,6 +81,44 @@ __global__ __launch_bounds__(1024) void sqnorm_seg_kernel(const float* __restric
   }
 }
 
+// ---- column sums in a fixed order (bias gradients, residual-weight gradients) ---------------------------------------
+// dst[c] += sum_r x[r, c]: a workgroup owns 64 columns; its 16 waves take the rows r = phase (mod 16) in order, eight loads
+// in flight, and the 16 partial sums are folded in phase order — the result depends on the data only.
+struct ColsumArgs {
+  int nseg;
+  const float* x[8]; long ld[8]; int rows[8]; int cols[8]; float* dst[8]; int first_block[9];
+};
+__global__ __launch_bounds__(1024) void colsum_det_kernel(const ColsumArgs a) {
+  __shared__ float sh[16][64];
+  int seg = 0;
+  while (seg + 1 < a.nseg && (int)blockIdx.x >= a.first_block[seg + 1]) ++seg;
+  const int col = ((int)blockIdx.x - a.first_block[seg]) * 64 + (threadIdx.x & 63);
+  const int phase = threadIdx.x >> 6;
+  const float* x = a.x[seg];
+  const long ld = a.ld[seg];
+  const int rows = a.rows[seg];
+  const bool ok = col < a.cols[seg];
+  float s = 0.f;
+  for (int r0 = phase; r0 < rows; r0 += 16 * 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = r0 + 16 * j;
+      v[j] = (ok && r < rows) ? x[(long)r * ld + col] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+  }
+  sh[phase][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (phase == 0 && ok) {
+    float t = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) t += sh[p][threadIdx.x];
+    a.dst[seg][col] += t;
+  }
+}
+
 __device__ __forceinline__ void adam4(float4& w, const float4 g, float4& m, float4& v, float sc, float lr_t, float b1,
                                       float b2, float eps) {
   const float gx = g.x * sc, gy = g.y * sc, gz = g.z * sc, gw = g.w * sc;
@@ -399,3 +437,21 @@ extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, fl
   return TCAR_OK;
 }
 
+
+extern "C" int tcar_colsum_det(int nseg, const tcar_colsum_t* segs, void* stream) {
+  if (nseg <= 0) return TCAR_OK;
+  if (nseg > 8 || !segs) return TCAR_E_ARG;
+  ColsumArgs a{};
+  int blocks = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!segs[i].x || !segs[i].dst || segs[i].rows < 0 || segs[i].cols <= 0 || segs[i].ld < segs[i].cols) return TCAR_E_ARG;
+    a.x[i] = segs[i].x; a.ld[i] = (long)segs[i].ld; a.rows[i] = segs[i].rows; a.cols[i] = segs[i].cols; a.dst[i] = segs[i].dst;
+    a.first_block[i] = blocks;
+    blocks += (segs[i].cols + 63) / 64;
+  }
+  a.first_block[nseg] = blocks;
+  a.nseg = nseg;
+  TCAR_LAUNCH(colsum_det_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}

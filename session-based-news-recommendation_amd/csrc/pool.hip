@@ -24,6 +24,8 @@ struct PoolArgs {
   float* pooled; float* alpha;
   float* dx_icp; float* dx_pt; float* dq; float* dpre1; float* dpre2; float* g_w1; float* g_w2;
   float* g_qb;     // optional: bias gradient of query_trans2; dq then leaves multiplied by tanh'(q) (modules.py:139 backward)
+  float* gw_rows;  // optional [B, 2 * ldh]: the per-session d w_res1 | d w_res2 rows are WRITTEN here (and dq leaves through
+                   // tanh') instead of any atomic sum: tcar_colsum_det adds the columns up in a fixed order
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
   const int ic = 2 * ldh, pt = 5 * ldt, ek = ic + pt;
   const int BT = a.B * T;
   const int ptl = pt >> 2;
-  const int nlds = a.g_qb ? 4 * ldh : 2 * ldh;
+  const int nlds = a.gw_rows ? 0 : (a.g_qb ? 4 * ldh : 2 * ldh);
   for (int i = tid; i < nlds; i += 256) gw_lds[i] = 0.f;
   __syncthreads();
   if (b < a.B) {
@@ -218,18 +220,25 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       if (col < ldh) {
-        if (a.g_qb) {        // q = tanh(.): the gradient leaves through tanh' = 1 - q^2, and its column sums are the bias gradient
+        if (a.g_qb || a.gw_rows) {   // q = tanh(.): the gradient leaves through tanh' = 1 - q^2, and its column sums are the bias gradient
           dqa[c] = make_float4(dqa[c].x * (1.f - qa[c].x * qa[c].x), dqa[c].y * (1.f - qa[c].y * qa[c].y),
                                dqa[c].z * (1.f - qa[c].z * qa[c].z), dqa[c].w * (1.f - qa[c].w * qa[c].w));
           dqb[c] = make_float4(dqb[c].x * (1.f - qb[c].x * qb[c].x), dqb[c].y * (1.f - qb[c].y * qb[c].y),
                                dqb[c].z * (1.f - qb[c].z * qb[c].z), dqb[c].w * (1.f - qb[c].w * qb[c].w));
-          atomic_add4(gw_lds + 2 * ldh + col, dqa[c]);
-          atomic_add4(gw_lds + 3 * ldh + col, dqb[c]);
+          if (!a.gw_rows) {
+            atomic_add4(gw_lds + 2 * ldh + col, dqa[c]);
+            atomic_add4(gw_lds + 3 * ldh + col, dqb[c]);
+          }
         }
         st4(a.dq + (long)b * ic + col, dqa[c]);
         st4(a.dq + (long)b * ic + ldh + col, dqb[c]);
-        atomic_add4(gw_lds + col, gw1[c]);
-        atomic_add4(gw_lds + ldh + col, gw2[c]);
+        if (a.gw_rows) {
+          st4(a.gw_rows + (long)b * ic + col, gw1[c]);
+          st4(a.gw_rows + (long)b * ic + ldh + col, gw2[c]);
+        } else {
+          atomic_add4(gw_lds + col, gw1[c]);
+          atomic_add4(gw_lds + ldh + col, gw2[c]);
+        }
       }
     }
   }
@@ -284,3 +293,24 @@ extern "C" int tcar_attn_pool_bwd_q(const tcar_dims_t* d, int B, int T, const fl
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
+
+// Order-fixed form: dq leaves through tanh'(q) as in tcar_attn_pool_bwd_q, but nothing is summed atomically — the per-session
+// rows d w_res1 | d w_res2 go to gw_rows [B, 2 * ldh]; tcar_colsum_det adds up their columns (and those of dq: the bias gradient
+// of query_trans2) in a fixed order.
+extern "C" int tcar_attn_pool_bwd_det(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                                      const float* pre1, const float* pre2, const float* q, const float* w_res1,
+                                      const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
+                                      float* dx_pt, float* dq, float* dpre1, float* dpre2, float* gw_rows, void* stream) {
+  if (!d || B <= 0 || T <= 0 || T > TCAR_POS_VOCAB || (d->ldh & 63) || d->ldh > 512 || 5 * d->ldt > 512 || !gw_rows) return TCAR_E_ARG;
+  PoolArgs a{};
+  a.B = B; a.T = T; a.H = d->H; a.ldh = d->ldh; a.ldt = d->ldt;
+  a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1; a.pre2 = pre2; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
+  a.alpha_in = alpha; a.dpooled = dpooled;
+  a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dq = dq; a.dpre1 = dpre1; a.dpre2 = dpre2; a.gw_rows = gw_rows;
+  const int grid = (B + 3) / 4;
+  if (d->ldh <= 256) TCAR_LAUNCH(attn_pool_bwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else TCAR_LAUNCH(attn_pool_bwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+

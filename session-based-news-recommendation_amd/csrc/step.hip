@@ -12,7 +12,7 @@ static int env_int(const char* name, int dflt) {
 static TcarTuning& tuning_storage() {
   static TcarTuning t = {env_int("TCAR_BF16_TILE", 0), env_int("TCAR_DX512", 1), env_int("TCAR_X3_XK", 0),
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
-                         env_int("TCAR_WGRAD_KS", 512), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
+                         env_int("TCAR_WGRAD_KS", 1536), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
                          env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0)};
   return t;
@@ -243,6 +243,16 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
 }  // namespace
 
 namespace {
+// bias gradients of the four linear_2d layers and the two residual-weight gradients as column sums in a fixed order
+int det_colsums(const tcar_ctx_t* c, const Geo& g, int B, void* stream) {
+  tcar_colsum_t cs[6] = {{c->dattout, g.ek, B, g.ic, G(c, TCAR_V_O_B)},
+                         {c->dattout + g.ic, g.ek, B, g.pt, G(c, TCAR_V_OT_B)},
+                         {c->dq, g.ic, B, g.ic, G(c, TCAR_V_Q2_B)},
+                         {c->dq1, g.ldh, B, g.ldh, G(c, TCAR_V_Q1_B)},
+                         {c->gw_rows, g.ic, B, g.ldh, G(c, TCAR_V_M_WRES)},
+                         {c->gw_rows + g.ldh, g.ic, B, g.ldh, G(c, TCAR_V_S_WRES)}};
+  return tcar_colsum_det(6, cs, stream);
+}
 int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream);
 int item_norm(const tcar_ctx_t* c, const Geo& g, void* stream);
 int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream);
@@ -339,8 +349,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // first use of the zeroed arena and of the negative term's forward outputs on the main stream
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
+  // order-fixed bias / residual-weight gradients (split-bf16 modes with the fused query chain and a row workspace): the
+  // producers below leave the column sums to ONE tcar_colsum_det launch behind the weight-gradient GEMM
+  const bool fusedq = c->scoring != 0 && tcar_tuning().fused_q;
+  const bool detc = fusedq && c->gw_rows != nullptr;
   RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
-                              c->dattout, G(c, TCAR_V_O_B), g.ic, G(c, TCAR_V_OT_B), stream));
+                              c->dattout, detc ? nullptr : G(c, TCAR_V_O_B), g.ic, detc ? nullptr : G(c, TCAR_V_OT_B), stream));
   if (!has_neg && hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
   if (de_late) {
     if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
@@ -357,14 +371,17 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // backward, relu' + bias gradient of query_trans1 in the epilogue of the GEMM that produces dq1, and that GEMM shares ONE
   // launch with the three input-gradient GEMMs of the projections (all four need only the pool backward's outputs); the
   // click-query input gradient (needs dq1) follows.  fp32 mode: the op-level sequence.
-  const bool fusedq = c->scoring != 0 && tcar_tuning().fused_q;
-  RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
-                           W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
-                           G(c, TCAR_V_M_WRES), G(c, TCAR_V_S_WRES), fusedq ? G(c, TCAR_V_Q2_B) : nullptr, stream));
+  if (detc)
+    RET(tcar_attn_pool_bwd_det(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
+                               c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream));
+  else
+    RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
+                             W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
+                             G(c, TCAR_V_M_WRES), G(c, TCAR_V_S_WRES), fusedq ? G(c, TCAR_V_Q2_B) : nullptr, stream));
   if (fusedq) {
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
-    p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = G(c, TCAR_V_Q1_B);
+    p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = detc ? nullptr : G(c, TCAR_V_Q1_B);
     // input gradients (only the ITEM half of dX_ic: content is frozen)
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
     p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
@@ -390,8 +407,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   } else if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
-    const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 512;
-    auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 2 ? 2 : (s > 16 ? 16 : s); };
+    const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 1536;
+    auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
     const int kb = ks(B), kr = ks(BT);
     const float* x_c = c->x_icp + g.ldh;
     tcar_gemm_desc_t p[9];
@@ -406,6 +423,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
     RET(small_gemm(c, 2, 9, p, sW));
   }
+  if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
   if (fuse_finish && s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, sW));
@@ -693,21 +711,26 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
   const int B = bt->B, T = bt->T, BT = B * T;
   const bool has_neg = bt->K > 0 && bt->neg && c->neg_coef && c->negpart;
   // dattout = (dX + the negative term's part) * tanh'(attout), + the bias gradients of both output transforms
+  const bool detc = c->gw_rows != nullptr;       // order-fixed bias / residual-weight gradients (see backward_impl)
   RET(tcar_splitk_reduce_dact(dx_rows, 1, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
-                              c->dattout, G(c, TCAR_V_O_B), g.ic, G(c, TCAR_V_OT_B), stream));
+                              c->dattout, detc ? nullptr : G(c, TCAR_V_O_B), g.ic, detc ? nullptr : G(c, TCAR_V_OT_B), stream));
   {
     tcar_gemm_desc_t p[2];
     p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->dpooled, g.ek);
     p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->dpooled + g.ic, g.ek);
     RET(small_gemm(c, 1, 2, p, stream));
   }
-  RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
-                           c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, G(c, TCAR_V_M_WRES),
-                           G(c, TCAR_V_S_WRES), G(c, TCAR_V_Q2_B), stream));
+  if (detc)
+    RET(tcar_attn_pool_bwd_det(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
+                               c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream));
+  else
+    RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
+                             c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, G(c, TCAR_V_M_WRES),
+                             G(c, TCAR_V_S_WRES), G(c, TCAR_V_Q2_B), stream));
   {
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
-    p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = G(c, TCAR_V_Q1_B);
+    p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = detc ? nullptr : G(c, TCAR_V_Q1_B);
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
     p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
@@ -718,8 +741,8 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
     RET(small_gemm(c, 1, 1, &p, stream));
   }
   {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
-    const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 512;
-    auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 2 ? 2 : (s > 16 ? 16 : s); };
+    const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 1536;
+    auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
     const int kb = ks(B), kr = ks(BT);
     const float* x_c = c->x_icp + g.ldh;
     tcar_gemm_desc_t p[9];
@@ -737,6 +760,7 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
     if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
       return TCAR_E_LAUNCH;
     RET(small_gemm(c, 2, 9, p, s2 ? (void*)s2 : stream));
+    if (detc) RET(det_colsums(c, g, B, s2 ? (void*)s2 : stream));
     if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
   tcar_tables_t tab;

@@ -39,9 +39,11 @@ VAR_ORDER = ["item_emb", "dec_pos"] + TIME_NAMES + ["duration_embedding",
              "cont_attention/input_linear_trans/w_3d", "cont_attention/cont_linear_trans/w_3d",
              "cont_attention/res_linear_trans/w_3d", "attout_pt_trans/w1", "attout_pt_trans/b1"]
 SLOT = {n: i for i, n in enumerate(VAR_ORDER)}
-# variables whose gradient is accumulated in a fixed order (bitwise repeatable from step to step and across replicas);
+# variables whose gradient is accumulated in a fixed order in the split-bf16 modes (bitwise repeatable from step to step): the
+# item table (sorted segmented sum), the nine weight matrices (un-split K up to 1,536 batch rows), the four biases and the
+# two residual weights (column sums in a fixed order).  The seven small session-side tables still go through float atomics.
 # tests/test_gpu_configs.py::test_same_step_twice_bitwise_report keeps this list honest
-DETERMINISTIC_GRADS: tuple = ("item_emb",)
+DETERMINISTIC_GRADS: tuple = ("item_emb",) + tuple(n for n in VAR_ORDER if n.endswith(("/w_3d", "/w1", "/b1")))
 
 
 def _ru(x: int, m: int) -> int:
@@ -379,6 +381,7 @@ class TcarEngine:
             self.dpooled = torch.empty(B, g.ek, **f32)
             self.dq = torch.empty(B, g.ic, **f32)
             self.dq1 = torch.empty(B, g.ldh, **f32)
+            self.gw_rows = torch.empty(B, g.ic, **f32)     # per-session d w_res rows (order-fixed column sums, tcar_colsum_det)
             self.dclick = torch.empty(B, g.ct, **f32)
             self.slabs = torch.empty(self.splitk, B, g.ek, **f32)
             if self.scoring_code:
@@ -743,6 +746,8 @@ class TcarEngine:
         c.et_perm = self.et_perm.data_ptr()
         c.adam_bitmap = self.adam_bitmap.data_ptr()
         c.scoring_bwd = self.scoring_bwd
+        if self.scoring_code and not os.environ.get("TCAR_ATOMIC_COLSUMS"):
+            c.gw_rows = self.gw_rows.data_ptr()
         if self.scoring_code:
             for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l"):
                 setattr(c, n, getattr(self, n).data_ptr())

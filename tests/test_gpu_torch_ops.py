@@ -132,6 +132,60 @@ def test_attn_pool_op(B, T):
         close(a.grad, b.grad, name="d " + name, atol_scale=max(1e-4, floor))
 
 
+def test_order_fixed_pool_backward_and_column_sums():
+    """tcar_attn_pool_bwd_det + tcar_colsum_det (the step driver's form in the split-bf16 modes) against the atomic form
+    tcar_attn_pool_bwd_q: same dx / dpre / dq, the column sums of gw_rows and dq equal the residual-weight and bias gradients,
+    and three runs agree bit for bit."""
+    _need_gpu()
+    import ctypes as C
+    from tcar_amd import _lib
+    from tcar_amd._lib import Dims
+    lib = _lib.load()
+
+    class Colsum(C.Structure):
+        _fields_ = [("x", C.c_void_p), ("ld", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32), ("dst", C.c_void_p)]
+    rng = np.random.RandomState(11)
+    B, T, H, ldh, pt = 301, 5, 250, 256, 320
+    ic = 2 * ldh
+    mk = lambda *s, sc=0.3: torch.tensor(rng.standard_normal(s).astype(np.float32) * sc, device=DEV)
+    x_icp, x_pt, pre1, pre2, q = mk(B * T, ic), mk(B * T, pt), mk(B * T, ldh, sc=1.0), mk(B * T, ldh, sc=1.0), torch.tanh(mk(B, ic))
+    w1, w2 = mk(ldh), mk(ldh)
+    w1[H:] = 0
+    w2[H:] = 0
+    dpooled = mk(B, ic + pt)
+    d = Dims(1, H, 64, ldh, 64)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    pooled, alpha = torch.empty(B, ic + pt, device=DEV), torch.empty(3, B * T, device=DEV)
+    assert lib.tcar_attn_pool_fwd(C.byref(d), B, T, p(x_icp), p(x_pt), p(pre1), p(pre2), p(q), p(w1), p(w2), p(pooled), p(alpha), None) == 0
+    outs = lambda: [torch.empty_like(x_icp), torch.empty_like(x_pt), torch.empty_like(q), torch.empty_like(pre1), torch.empty_like(pre2)]
+    ref = outs()
+    g1, g2, gq = torch.zeros(ldh, device=DEV), torch.zeros(ldh, device=DEV), torch.zeros(ic, device=DEV)
+    assert lib.tcar_attn_pool_bwd_q(C.byref(d), B, T, p(x_icp), p(x_pt), p(pre1), p(pre2), p(q), p(w1), p(w2), p(alpha), p(dpooled),
+                                    *[p(t) for t in ref], p(g1), p(g2), p(gq), None) == 0
+    runs = []
+    for _ in range(3):
+        got = outs()
+        gw = torch.full((B, ic), 7.0, device=DEV)
+        assert lib.tcar_attn_pool_bwd_det(C.byref(d), B, T, p(x_icp), p(x_pt), p(pre1), p(pre2), p(q), p(w1), p(w2), p(alpha), p(dpooled),
+                                          *[p(t) for t in got], p(gw), None) == 0
+        dst = torch.zeros(ic + 2 * ldh, device=DEV)
+        segs = (Colsum * 3)()
+        for i, (x, ld, cols, off) in enumerate(((got[2], ic, ic, 0), (gw, ic, ldh, ic), (gw[:, ldh:], ic, ldh, ic + ldh))):
+            segs[i].x, segs[i].ld, segs[i].rows, segs[i].cols, segs[i].dst = x.data_ptr(), ld, B, cols, dst.data_ptr() + 4 * off
+        assert lib.tcar_colsum_det(3, C.cast(segs, C.c_void_p), None) == 0
+        torch.cuda.synchronize()
+        runs.append([t.cpu().numpy() for t in got] + [dst.cpu().numpy()])
+    for a, b in zip(runs[0][:5], ref):
+        assert np.array_equal(a, b.cpu().numpy())                       # element-wise outputs: the same arithmetic
+    close(torch.tensor(runs[0][5][:ic]), gq.cpu().double(), name="d q-bias", atol_scale=1e-5)
+    close(torch.tensor(runs[0][5][ic:ic + ldh]), g1.cpu().double(), name="d w_res1", atol_scale=1e-5)
+    close(torch.tensor(runs[0][5][ic + ldh:]), g2.cpu().double(), name="d w_res2", atol_scale=1e-5)
+    want = np.concatenate([runs[0][2].astype(np.float64).sum(0)])
+    np.testing.assert_allclose(runs[0][5][:ic], want, rtol=1e-5, atol=1e-6)
+    for r in runs[1:]:
+        assert all(np.array_equal(x, y) for x, y in zip(r, runs[0]))
+
+
 def test_score_ce_and_score_rank_ops():
     _need_gpu()
     from tcar_amd import torch_ops  # noqa: F401
