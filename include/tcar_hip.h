@@ -75,6 +75,8 @@ typedef struct {
   float* norms_out;      /* NULL, or [B*T]: with it the squared norm of each item-row gradient is WRITTEN here instead of
                             being added (atomically) into sqn[slot_item] — summed later in a fixed order (segsum) */
   int64_t rows_ld;       /* row stride of rows_out in floats (0 = ldh): a packed exchange buffer keeps the row's id beside it */
+  int32_t skip_small;    /* != 0: tcar_gather_clip_bwd leaves the position / time / dwell tables and the click rows to
+                            tcar_small_tables_bwd_det (order-fixed) and handles the item rows only */
 } tcar_grads_t;
 
 /* One mini-batch = the feed_dict of model_combine.py:214-227 (int32, row-major). */
@@ -103,6 +105,15 @@ int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* tab, const t
 int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
                          const float* dx_icp, const float* dx_pt, const float* dx_act, const float* dclick,
                          const tcar_grads_t* g, void* stream);
+
+/* Order-fixed session-side backward of the SMALL tables (position, month..minute, dwell; the click rows of the week / hour
+ * tables): one workgroup per destination row sums its sources in source order (the clip Jacobian is applied once per row,
+ * from S = sum gy, Q = sum ||gy||^2, D2 = sum (x.gy)^2), one add per gradient element and per norm slot.  Same values as
+ * tcar_gather_clip_bwd up to rounding, bit-for-bit repeatable.  ws: tcar_small_det_ws_floats() floats. */
+int tcar_small_det_ws_floats(void);
+int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
+                              const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
+                              void* stream);
 
 /* tcar_scatter_add_rows: g_item[ids[r]-1, :] += rows[r, :] for r < R (ids 1-based like `seq`; id 0 = padding
  * row, skipped).  The "bucketed sparse-embedding exchange" applies the all-gathered (id, row) pairs with it. */
@@ -473,7 +484,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 11
+#define TCAR_ABI_VERSION 12
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */

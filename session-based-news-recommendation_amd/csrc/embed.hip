@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) sq[i] = 0.f;
 
-  for (int row = wave_g; row < BT + B; row += nwaves) {
+  const bool item_only = a.g.skip_small != 0;     // the order-fixed form (tcar_small_tables_bwd_det) owns every other table
+  for (int row = wave_g; row < (item_only ? BT : BT + B); row += nwaves) {
     if (row < BT) {
       const int t = row % T;
       const int n = clampi(a.bt.seq[row], 1, a.d.n_items) - 1;
@@ -336,8 +337,8 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
         const int kk = kval[it] ? it * gpw + grp : 0;
         const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
         const float* gp = (kk < 5) ? a.dx_pt + (long)row * pt + kk * ldt : a.dx_act + (long)row * ldt;
-        kx[it] = kact[it] ? ld4(tp + (long)kid[it] * ldt + lin * 4) : zero4();
-        kgy[it] = kval[it] ? ld4(gp + lin * 4) : zero4();
+        kx[it] = (kact[it] && !item_only) ? ld4(tp + (long)kid[it] * ldt + lin * 4) : zero4();
+        kgy[it] = (kval[it] && !item_only) ? ld4(gp + lin * 4) : zero4();
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -358,9 +359,11 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
           else sq[0] += dot4(gx, gx);
           if (a.g.rows_out) st4(a.g.rows_out + (long)row * (a.g.rows_ld ? a.g.rows_ld : (long)ldh) + col, gx);
           else atomic_add4(a.g.g_item + (long)n * ldh + col, gx);
-          float4 gp = fma4(xp[c], -bp, scale4(gi[c], ap));
-          sq[1] += dot4(gp, gp);
-          atomic_add4(pos_acc + t * ldh + col, gp);
+          if (!item_only) {
+            float4 gp = fma4(xp[c], -bp, scale4(gi[c], ap));
+            sq[1] += dot4(gp, gp);
+            atomic_add4(pos_acc + t * ldh + col, gp);
+          }
         }
       }
       if (a.g.norms_out) {
@@ -369,6 +372,7 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
       }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
+        if (item_only) break;
         const int kk = kval[it] ? it * gpw + grp : 0;
         const float4 x = kx[it], gyv = kgy[it];
         const float ss = group_sum(dot4(x, x), sub), dd = group_sum(dot4(x, gyv), sub);
@@ -686,6 +690,189 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(int ldh, int n_it
   }
 }
 
+// ---- order-fixed backward of the SMALL tables (position, five time tables, dwell) on the session side -----------------
+// Every source that gathers table row r sees the SAME clipped row x, so (as on the candidate side above) the sum of the
+// per-source clip Jacobians needs only S = sum gy, Q = sum ||gy||^2 and D2 = sum (x . gy)^2 over those sources:
+//   sum gx = S / n - x (x . S) / n^3,    sum ||gx||^2 = Q / n^2 - D2 / n^4      (n = ||x|| > 1; identity otherwise)
+// One workgroup of 16 waves per destination row: wave w walks the w-th sixteenth of the source rows IN ORDER (ids 64 at a
+// time, ballot, the matches' gradient slices four loads at a time), the 16 partial (S, Q, D2) are folded in wave order, the
+// Jacobian is applied once and the row is added to the gradient with ONE atomic per element (the candidate side adds its one
+// contribution to the same rows: two addends commute).  Nothing depends on the dispatch order.
+struct SmallDetArgs {
+  tcar_dims_t d;
+  tcar_tables_t tab;
+  tcar_batch_t bt;
+  const float* dx_icp; const float* dx_pt; const float* dx_act; const float* dclick;
+  float* g_pos; float* g_small;      // [40, ldh]; [150, ldt] = month | day | week | hour | minute | dwell
+  float* rowq;                        // [SMALL_DET_ROWS] per-row norm pieces (folded per table by small_norm_fold_kernel)
+};
+constexpr int SMALL_DET_ROWS = TCAR_POS_VOCAB + SMALL_ROWS + 1;   // + the out-of-range dwell bucket (norm only, S7)
+
+template <int NC>   // 64-column groups per lane: columns <= 64 * NC
+__global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallDetArgs a) {
+  __shared__ float partS[16][64 * NC];
+  __shared__ float partQ[16], partD[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int B = a.bt.B, T = a.bt.T, BT = B * T;
+  const int ldh = a.d.ldh, ldt = a.d.ldt, ic = 2 * ldh, pt = 5 * ldt, ct = 2 * ldt;
+  const int R = blockIdx.x;                     // [0, T) position rows | [T, T + 150) small-table rows | T + 150: dwell out of range
+  int kind, k = 0, v = 0, cols, sr = 0;
+  const float* xrow = nullptr;
+  if (R < T) { kind = 0; cols = ldh; xrow = a.tab.pos + (long)R * ldh; }
+  else if (R < T + SMALL_ROWS) {
+    kind = 1; sr = R - T; cols = ldt;
+    k = sr < 13 ? 0 : sr < 45 ? 1 : sr < 53 ? 2 : sr < 78 ? 3 : sr < 139 ? 4 : 5;
+    v = sr - time_rowoff(k);
+    xrow = (k < 5 ? pick5(a.tab.time, k) : a.tab.dur) + (long)v * ldt;
+  } else { kind = 2; k = 5; cols = ldt; }
+  float x[NC], S[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int col = lane + 64 * c;
+    x[c] = (xrow && col < cols) ? xrow[col] : 0.f;
+    S[c] = 0.f;
+  }
+  float ql = 0.f, D2 = 0.f;
+  // acc of up to 4 sources whose gradient slices start at p[0..n): loads first, then the sums in order
+  auto take4 = [&](const float* const* p, int n) {
+    float g[4][NC];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = lane + 64 * c;
+        g[u][c] = (u < n && col < cols) ? p[u][col] : 0.f;
+      }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (u >= n) break;
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) { S[c] += g[u][c]; ql += g[u][c] * g[u][c]; d += x[c] * g[u][c]; }
+      d = wave_sum(d);
+      D2 += d * d;
+    }
+  };
+  if (kind == 0) {
+    // position t = R: the sources are the rows b * T + t, no ids to match
+    const int per = (B + 15) / 16, b0 = wv * per, b1 = min(B, b0 + per);
+    for (int b = b0; b < b1; b += 4) {
+      const float* p[4];
+      const int n = min(4, b1 - b);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = a.dx_icp + ((long)(b + (u < n ? u : 0)) * T + R) * ic;
+      take4(p, n);
+    }
+  } else {
+    // session rows: id of table k at every source row; matches of this wave's sixteenth, in order
+    const int32_t* ids = (k < 5) ? pick5(a.bt.pub, k) : a.bt.gap;
+    const int per = (BT + 15) / 16, r0 = wv * per, r1 = min(BT, r0 + per);
+    for (int base = r0; base < r1; base += 64) {
+      const int row = base + lane;
+      bool hit = false;
+      if (row < r1) {
+        const int id = ids[row];
+        const bool oob = (k == 5) && (id >= TCAR_DUR_VOCAB || id < 0);
+        hit = (kind == 2) ? oob : (!oob && clampi(id, 0, time_vocab(k) - 1) == v);
+      }
+      unsigned long long m = __ballot(hit);
+      while (m) {
+        const float* p[4];
+        int n = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const long rr = base + j;
+            p[u] = (k < 5) ? a.dx_pt + rr * pt + k * ldt : a.dx_act + rr * ldt;
+            n = u + 1;
+          } else p[u] = p[0];
+        }
+        take4(p, n);
+      }
+    }
+    // click rows: the week table by cw, the hour table by ch (model_combine.py:94-97)
+    if (kind == 1 && (k == 2 || k == 3)) {
+      const int32_t* cid = (k == 2) ? a.bt.cw : a.bt.ch;
+      const int jj = (k == 2) ? 0 : 1;
+      const int perb = (B + 15) / 16, b0 = wv * perb, b1 = min(B, b0 + perb);
+      for (int base = b0; base < b1; base += 64) {
+        const int b = base + lane;
+        const bool hit = (b < b1) && clampi(cid[b], 0, time_vocab(k) - 1) == v;
+        unsigned long long m = __ballot(hit);
+        while (m) {
+          const float* p[4];
+          int n = 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (m) {
+              const int j = __builtin_ctzll(m);
+              m &= m - 1;
+              p[u] = a.dclick + (long)(base + j) * ct + jj * ldt;
+              n = u + 1;
+            } else p[u] = p[0];
+          }
+          take4(p, n);
+        }
+      }
+    }
+  }
+  ql = wave_sum(ql);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) partS[wv][lane + 64 * c] = S[c];
+  if (lane == 0) { partQ[wv] = ql; partD[wv] = D2; }
+  __syncthreads();
+  if (wv != 0) return;
+  float St[NC];
+  float Q = 0.f, D = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) St[c] = 0.f;
+  for (int w = 0; w < 16; ++w) {                // the sixteenths in order
+#pragma unroll
+    for (int c = 0; c < NC; ++c) St[c] += partS[w][lane + 64 * c];
+    Q += partQ[w];
+    D += partD[w];
+  }
+  float ss = 0.f, xs = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { ss += x[c] * x[c]; xs += x[c] * St[c]; }
+  ss = wave_sum(ss);
+  xs = wave_sum(xs);
+  float pc = Q;
+  float ca = 1.f, cb = 0.f;
+  if (kind != 2 && ss > 1.0f) {
+    const float inv = 1.0f / sqrtf(ss), inv2 = inv * inv;
+    ca = inv;
+    cb = xs * inv2 * inv;
+    pc = inv2 * Q - inv2 * inv2 * D;
+  }
+  if (kind != 2) {
+    float* dst = (kind == 0) ? a.g_pos + (long)R * ldh : a.g_small + (long)sr * ldt;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = lane + 64 * c;
+      const float gx = ca * St[c] - cb * x[c];
+      if (col < cols && gx != 0.f) atomicAdd(dst + col, gx);
+    }
+  }
+  if (lane == 0) a.rowq[kind == 0 ? R : TCAR_POS_VOCAB + (kind == 1 ? sr : SMALL_ROWS)] = pc;
+}
+
+// per-table norm pieces from the per-row ones, rows in order; one add per slot (the candidate side adds its one)
+__global__ __launch_bounds__(64) void small_norm_fold_kernel(const float* __restrict__ rowq, int T, float* __restrict__ sqn, int slot_pos,
+                                                             int s0, int s1, int s2, int s3, int s4, int slot_dur) {
+  const int k = threadIdx.x;          // 0: position, 1..5: month..minute, 6: dwell (+ its out-of-range bucket)
+  if (k > 6) return;
+  int lo, n, slot;
+  if (k == 0) { lo = 0; n = T; slot = slot_pos; }
+  else if (k <= 5) { lo = TCAR_POS_VOCAB + time_rowoff(k - 1); n = time_vocab(k - 1); slot = k == 1 ? s0 : k == 2 ? s1 : k == 3 ? s2 : k == 4 ? s3 : s4; }
+  else { lo = TCAR_POS_VOCAB + 139; n = TCAR_DUR_VOCAB + 1; slot = slot_dur; }
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += rowq[lo + i];
+  if (s != 0.f) atomicAdd(sqn + slot, s);
+}
+
 // packed form: the id rides behind its row (row stride ld), ids shifted by id0 (catalog shards)
 __global__ __launch_bounds__(256) void scatter_add_rows_packed_kernel(int ldh, int n_items, int id0, const float* __restrict__ packed,
                                                                       long ld, long R, float* __restrict__ g_item) {
@@ -857,6 +1044,30 @@ extern "C" int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_
   if (grid > 512) grid = 512;
   TCAR_SET_LDS_ONCE(cand_time_bwd_kernel, 160 * 1024);
   TCAR_LAUNCH(cand_time_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+// Order-fixed session-side backward of the position, time and dwell tables (see small_tables_bwd_det_kernel); the item rows
+// are tcar_gather_clip_bwd's with g->skip_small set.  ws: >= tcar_small_det_ws_floats() floats.
+extern "C" int tcar_small_det_ws_floats(void) { return SMALL_DET_ROWS; }
+extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
+                                         const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g,
+                                         float* ws, void* stream) {
+  if (check_dims(d) || !tab || !bt || !g || !ws || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
+  if (!dx_icp || !dx_pt || !dx_act || !dclick || !g->g_pos || !g->g_time[0] || !g->sqn) return TCAR_E_ARG;
+  SmallDetArgs a{};
+  a.d = *d; a.tab = *tab; a.bt = *bt;
+  a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;
+  a.g_pos = g->g_pos; a.g_small = g->g_time[0]; a.rowq = ws;
+  const int rows = bt->T + SMALL_ROWS + 1;
+  const int widest = d->ldh > d->ldt ? d->ldh : d->ldt;
+  hipStream_t st = (hipStream_t)stream;
+  if (widest <= 256) TCAR_LAUNCH(small_tables_bwd_det_kernel<4>, dim3(rows), dim3(1024), 0, st, a);
+  else TCAR_LAUNCH(small_tables_bwd_det_kernel<8>, dim3(rows), dim3(1024), 0, st, a);
+  TCAR_CHECK_LAUNCH();
+  TCAR_LAUNCH(small_norm_fold_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, bt->T, g->sqn, g->slot_pos, g->slot_time[0],
+              g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

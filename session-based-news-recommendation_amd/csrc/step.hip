@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 1536), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -31,7 +31,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}};
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}};
   for (auto& e : tab) {
     bool same = true;
     for (int i = 0; same; ++i) {
@@ -91,7 +91,7 @@ void grads_of(const tcar_ctx_t* c, tcar_grads_t& g) {
   g.g_dur = G(c, TCAR_V_DUR);
   g.sqn = c->Gx + c->arena_n;
   g.slot_item = c->slot_item; g.slot_pos = c->slot_of[TCAR_V_POS]; g.slot_dur = c->slot_of[TCAR_V_DUR];
-  g.rows_out = nullptr; g.norms_out = nullptr; g.rows_ld = 0;
+  g.rows_out = nullptr; g.norms_out = nullptr; g.rows_ld = 0; g.skip_small = 0;
 }
 
 // the small contractions follow the scoring precision: exact fp32 MFMA in "f32" mode, split-bf16 otherwise
@@ -440,6 +440,22 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
     RET(small_gemm(c, 1, 4, p, stream));
   }
+  // Order-fixed small tables (sorted mode, which implies an aux stream): every input gradient exists now and the item rows do
+  // not depend on them — they run beside the negative rows, the dense-norm partials and the item-row gradients of the main chain
+  const bool det_small = sorted && tcar_tuning().det_small != 0;
+  if (det_small) {
+    tcar_tables_t tab;
+    tcar_grads_t gr;
+    tables_of(c, tab);
+    grads_of(c, gr);
+    float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
+    // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
+    // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
+    if (hipEventRecord((hipEvent_t)c->ev[5], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[5], 0) != hipSuccess)
+      return TCAR_E_LAUNCH;
+    RET(tcar_small_tables_bwd_det(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2));
+    if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  }
   if (split_finish) {   // Gi is complete once dE has landed: negative rows (+ loss), then its norm BEFORE any row scatter (S5)
     if (hipStreamWaitEvent(st, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
     if (has_neg && sorted) {
@@ -467,6 +483,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       // adds the rows into Gi in sorted order and folds the norms — and the dense norm's partials — in a fixed order
       gr.rows_out = tcar_segsum_rows_buffer(&c->d, bt, c->segsum_ws);
       gr.norms_out = tcar_segsum_norms_buffer(&c->d, bt, c->segsum_ws);
+      gr.skip_small = det_small ? 1 : 0;
       RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
       RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, c->segsum_bytes, 0, gr.rows_out, nullptr, nullptr, 0, Gi,
                             c->Gx + c->arena_n + c->slot_item, c->sqn_dense + c->slot_item, nullptr, nullptr, 0.f, nullptr, stream));

@@ -66,6 +66,7 @@ struct TcarTuning {
   int sort_scatter;     // TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum
   int bf16_ks;          // TCAR_BF16_KS        64-deep LDS stages of the hi-only bf16 GEMM: 1 never, 2 dX / logits layouts, 3 all
   int de_late;          // TCAR_DE_LATE        1: the fused step starts dE after dX + slab reduce instead of beside them
+  int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
 };
 const TcarTuning& tcar_tuning();
 

@@ -39,11 +39,14 @@ VAR_ORDER = ["item_emb", "dec_pos"] + TIME_NAMES + ["duration_embedding",
              "cont_attention/input_linear_trans/w_3d", "cont_attention/cont_linear_trans/w_3d",
              "cont_attention/res_linear_trans/w_3d", "attout_pt_trans/w1", "attout_pt_trans/b1"]
 SLOT = {n: i for i, n in enumerate(VAR_ORDER)}
-# variables whose gradient is accumulated in a fixed order in the split-bf16 modes (bitwise repeatable from step to step): the
-# item table (sorted segmented sum), the nine weight matrices (un-split K up to 1,536 batch rows), the four biases and the
-# two residual weights (column sums in a fixed order).  The seven small session-side tables still go through float atomics.
-# tests/test_gpu_configs.py::test_same_step_twice_bitwise_report keeps this list honest
-DETERMINISTIC_GRADS: tuple = ("item_emb",) + tuple(n for n in VAR_ORDER if n.endswith(("/w_3d", "/w1", "/b1")))
+# Variables whose gradient is accumulated in a fixed order by the fused step of the split-bf16 modes (bitwise repeatable from
+# step to step): ALL of them — the item table (sorted segmented sum, csrc/segsum.hip), the seven small tables (one workgroup
+# per destination row, sources in order, embed.hip), the nine weight matrices (un-split K up to 1,536 batch rows: longer
+# batches split K with float atomics), the four biases and the two residual weights (column sums in a fixed order).  In fp32
+# mode the biases and residual weights still go through float atomics (ATOMIC_IN_F32).
+# tests/test_gpu_configs.py::test_same_step_twice_bitwise_report keeps both lists honest.
+DETERMINISTIC_GRADS: tuple = tuple(VAR_ORDER)
+ATOMIC_IN_F32: tuple = tuple(n for n in VAR_ORDER if n.endswith("/b1") or n.endswith("res_linear_trans/w_3d"))
 
 
 def _ru(x: int, m: int) -> int:

@@ -220,10 +220,10 @@ def test_stress_10m_items_d256_properties():
 @pytest.mark.parametrize("scoring", ["f32", "bf16x3"])
 def test_same_step_twice_bitwise_report(scoring):
     """SURVEY.md §5 'race detection' row: the same fused training step from the same state, three times.  Every quantity that
-    is accumulated in a fixed order must repeat bit for bit — engine.DETERMINISTIC_GRADS names them: the item table's
-    gradient (sorted segmented sum, csrc/segsum.hip), its norm and its rows after the update; the ones that still go through
-    float atomics are listed and must agree to rounding.  After a SECOND step everything may differ in the last bits (the
-    atomically summed variables feed the next forward pass).  The set of non-repeating variables may only shrink."""
+    is accumulated in a fixed order must repeat bit for bit — engine.DETERMINISTIC_GRADS names them (in the split-bf16 modes:
+    every gradient, every clip norm, every variable after one AND after two steps); what still goes through float atomics
+    (fp32 mode: biases and residual weights) is listed and must agree to rounding.  The set of non-repeating variables may
+    only shrink."""
     _need_gpu()
     from tcar_amd.engine import DETERMINISTIC_GRADS, TcarEngine, VAR_ORDER
     from tcar_amd.host.model import initial_variables
@@ -257,10 +257,14 @@ def test_same_step_twice_bitwise_report(scoring):
                 for r in runs[1:]:
                     close(r[i][k], runs[0][i][k], rtol=1e-4, atol_scale=2e-5 if i == 0 else 2e-4, name="%s %s repeat" % (tag, k))
     print("not bitwise repeatable:", differ)
-    # the order-fixed column sums and un-split weight gradients belong to the split-bf16 step; fp32 mode: the item table only
-    must = DETERMINISTIC_GRADS if scoring != "f32" else ("item_emb",)
-    assert len(DETERMINISTIC_GRADS) == 16
+    # split-bf16 modes: EVERYTHING repeats, also after the second step; fp32 mode keeps float atomics for the biases and the
+    # residual weights (the order-fixed column sums belong to the fused query chain of the split-bf16 step)
+    from tcar_amd.engine import ATOMIC_IN_F32
+    assert set(DETERMINISTIC_GRADS) == set(VAR_ORDER) and len(ATOMIC_IN_F32) == 6
+    must = DETERMINISTIC_GRADS if scoring != "f32" else tuple(k for k in VAR_ORDER if k not in ATOMIC_IN_F32)
     for k in must:
         assert k not in differ["grad"] and k not in differ["param"], ("lost determinism", k, differ)
         assert all(r[3][k] == runs[0][3][k] for r in runs[1:]), ("norm of %s not repeatable" % k, [r[3][k] for r in runs])
     assert set(differ["grad"]) <= set(VAR_ORDER) - set(must)
+    if scoring != "f32":
+        assert not differ["param after 2 steps"], differ

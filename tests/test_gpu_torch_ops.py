@@ -132,6 +132,60 @@ def test_attn_pool_op(B, T):
         close(a.grad, b.grad, name="d " + name, atol_scale=max(1e-4, floor))
 
 
+@pytest.mark.parametrize("B,T,skew", [(64, 5, False), (512, 3, True), (33, 40, False)])
+def test_order_fixed_small_table_backward(B, T, skew):
+    """tcar_small_tables_bwd_det (one workgroup per destination row, sources in order, clip Jacobian once per row) against
+    the atomic form inside tcar_gather_clip_bwd: position / time / dwell gradients and their norm pieces agree to rounding,
+    the item rows of the skip_small gather are unchanged, and repeated runs agree bit for bit.  skew: every session shares one
+    click time and one publish hour (MIND-like: one table row collects every source)."""
+    _need_gpu()
+    import ctypes as C
+    from tcar_amd import _lib, torch_ops
+    from tcar_amd._lib import Grads
+    lib = _lib.load()
+    rng = np.random.RandomState(B * 7 + T)
+    N, H, Ht = 300, 250, 64
+    E, pos, small, ldh, ldt, ek = _tables(N, H, Ht, rng, scale=0.2)
+    small *= 3.0                                                   # norms above 1: the clip Jacobian is active
+    seq, pub, gap, cw, ch, feed = _feed(B, T, N, rng)
+    if skew:
+        n = B * T
+        feed[4 * n:5 * n] = 7                                      # publish hour
+        feed[7 * n:7 * n + B] = 3                                  # click week
+        feed[7 * n + B:] = 11                                      # click hour
+    Et, post, smt, fd = (torch.tensor(a, device=DEV) for a in (E, pos, small, feed))
+    mk = lambda *s: torch.tensor(rng.standard_normal(s).astype(np.float32), device=DEV)
+    dx_icp, dx_pt, dx_act, dclick = mk(B * T, 2 * ldh), mk(B * T, 5 * ldt), mk(B * T, ldt), mk(B, 2 * ldt)
+    ref = torch.ops.tcar.gather_clip_bwd(Et, post, smt, fd, dx_icp, dx_pt, dx_act, dclick, B, T, H, Ht)     # atomic form
+    dims, _, _, _ = torch_ops._geom(Et, post, smt, H, Ht)
+    tab, bt = torch_ops._tables(Et, post, smt, ldt), torch_ops._batch(fd, B, T)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    runs = []
+    for _ in range(3):
+        g_item, g_pos = torch.zeros(N, ldh, device=DEV), torch.zeros(40, ldh, device=DEV)
+        g_small, sqn = torch.zeros(150, ldt, device=DEV), torch.zeros(_lib.NSLOT, device=DEV)
+        gr = Grads()
+        gr.g_item, gr.g_pos, gr.sqn = g_item.data_ptr(), g_pos.data_ptr(), sqn.data_ptr()
+        for k in range(5):
+            gr.g_time[k] = g_small.data_ptr() + 4 * torch_ops._ROWOFF[k] * ldt
+            gr.slot_time[k] = 2 + k
+        gr.g_dur = g_small.data_ptr() + 4 * torch_ops._ROWOFF[5] * ldt
+        gr.slot_item, gr.slot_pos, gr.slot_dur = 0, 1, 7
+        ws = torch.full((lib.tcar_small_det_ws_floats(),), 9.0, device=DEV)
+        assert lib.tcar_small_tables_bwd_det(C.byref(dims), C.byref(tab), C.byref(bt), p(dx_icp), p(dx_pt), p(dx_act), p(dclick),
+                                             C.byref(gr), p(ws), None) == 0
+        gr.skip_small = 1
+        assert lib.tcar_gather_clip_bwd(C.byref(dims), C.byref(tab), C.byref(bt), p(dx_icp), p(dx_pt), p(dx_act), p(dclick),
+                                        C.byref(gr), None) == 0
+        torch.cuda.synchronize()
+        runs.append([t.cpu().numpy() for t in (g_item, g_pos, g_small, sqn)])
+    for name, a, b in zip(("item rows", "position", "time / dwell", "norm pieces"), runs[0], ref):
+        close(a, b.cpu(), name=name, rtol=2e-4, atol_scale=2e-5)
+    for r in runs[1:]:
+        for name, x, y in zip(("pos", "small", "sqn"), (r[1], r[2], r[3][1:]), (runs[0][1], runs[0][2], runs[0][3][1:])):
+            assert np.array_equal(x, y), name                      # bit for bit (the item rows / slot 0 here still use atomics)
+
+
 def test_order_fixed_pool_backward_and_column_sums():
     """tcar_attn_pool_bwd_det + tcar_colsum_det (the step driver's form in the split-bf16 modes) against the atomic form
     tcar_attn_pool_bwd_q: same dx / dpre / dq, the column sums of gw_rows and dq equal the residual-weight and bias gradients,
