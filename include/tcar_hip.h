@@ -338,6 +338,12 @@ typedef struct {
   float* dst;
 } tcar_colsum_t;
 int tcar_colsum_det(int nseg, const tcar_colsum_t* segs /*host*/, void* stream);
+/* dst[e] += sum over k < ks of slabs[k * stride + e], k in order: the ordered fold of split-K slabs (weight gradients of
+ * batches longer than the un-split limit).  n, stride multiples of 4; up to 9 segments per launch. */
+typedef struct {
+  float* dst; const float* slabs; int64_t n; int32_t ks; int64_t stride;
+} tcar_fold_t;
+int tcar_fold_slabs(int nseg, const tcar_fold_t* segs /*host*/, void* stream);
 /* (segments of <= 262,144 floats: one workgroup each, fixed summation order — identical inputs give identical bits;
  *  longer segments: chunked with one float atomic per chunk) */
 int tcar_sqnorm(const float* g, const tcar_segments_t* segs /*host*/, float* sqn_dense, void* stream);
@@ -484,7 +490,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 12
+#define TCAR_ABI_VERSION 13
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -551,6 +557,9 @@ typedef struct {
   /* optional [B, 2*ldh] workspace: with it (split-bf16 modes) the bias gradients and the residual-weight gradients are column
    * sums in a fixed order (tcar_attn_pool_bwd_det + tcar_colsum_det) instead of float atomics */
   float* gw_rows;
+  /* optional slab workspace of the weight gradients (K splits of batches over 1,536 rows folded in split order instead of
+   * float atomics); 16 * (sum of the nine M*N) floats covers every batch */
+  float* wgrad_slabs; int64_t wgrad_slab_floats;
 } tcar_ctx_t;
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */

@@ -81,6 +81,24 @@ __global__ __launch_bounds__(1024) void sqnorm_seg_kernel(const float* __restric
   }
 }
 
+// ---- split-K slabs folded in split order: dst[e] += sum_k slabs[k * stride + e] ---------------------------------------
+struct FoldArgs {
+  int nseg;
+  float* dst[9]; const float* slabs[9]; long n[9]; int ks[9]; long stride[9]; long first[10];      // first: flat float4 offset
+};
+__global__ __launch_bounds__(256) void fold_slabs_kernel(const FoldArgs a) {
+  const long total = a.first[a.nseg];
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int seg = 0;
+    while (seg + 1 < a.nseg && i >= a.first[seg + 1]) ++seg;
+    const long e = (i - a.first[seg]) * 4;
+    const float* p = a.slabs[seg] + e;
+    float4 s = ld4(a.dst[seg] + e);
+    for (int k = 0; k < a.ks[seg]; ++k) s = add4(s, ld4(p + (long)k * a.stride[seg]));
+    st4(a.dst[seg] + e, s);
+  }
+}
+
 // ---- column sums in a fixed order (bias gradients, residual-weight gradients) ---------------------------------------
 // dst[c] += sum_r x[r, c]: a workgroup owns 64 columns; its 16 waves take the rows r = phase (mod 16) in order, eight loads
 // in flight, and the 16 partial sums are folded in phase order — the result depends on the data only.
@@ -452,6 +470,28 @@ extern "C" int tcar_colsum_det(int nseg, const tcar_colsum_t* segs, void* stream
   a.first_block[nseg] = blocks;
   a.nseg = nseg;
   TCAR_LAUNCH(colsum_det_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_fold_slabs(int nseg, const tcar_fold_t* segs, void* stream) {
+  if (nseg <= 0) return TCAR_OK;
+  if (nseg > 9 || !segs) return TCAR_E_ARG;
+  FoldArgs a{};
+  long at = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!segs[i].dst || !segs[i].slabs || segs[i].n <= 0 || (segs[i].n & 3) || segs[i].ks < 1 || (segs[i].stride & 3) ||
+        !tcar_aligned16(segs[i].dst) || !tcar_aligned16(segs[i].slabs))
+      return TCAR_E_ARG;
+    a.dst[i] = segs[i].dst; a.slabs[i] = segs[i].slabs; a.n[i] = (long)segs[i].n; a.ks[i] = segs[i].ks; a.stride[i] = (long)segs[i].stride;
+    a.first[i] = at;
+    at += segs[i].n / 4;
+  }
+  a.first[nseg] = at;
+  a.nseg = nseg;
+  long blocks = (at + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  TCAR_LAUNCH(fold_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -243,6 +243,47 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
 }  // namespace
 
 namespace {
+// The nine weight gradients x^T dy (K = batch rows, model_combine.py:156): ONE grouped launch.  K is not split up to wgrad_ks
+// (1,536) rows; longer batches split it — into slabs folded in split order when the context has the workspace (order-fixed:
+// tcar_fold_slabs), else with float atomics into the zeroed arena.
+int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream) {
+  const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 1536;
+  auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
+  const int kb = ks(B), kr = ks(BT);
+  const float* x_c = c->x_icp + g.ldh;
+  tcar_gemm_desc_t p[9];
+  p[0] = prob1(g.ic, g.ic, c->pooled, g.ek, c->dattout, g.ek, B, G(c, TCAR_V_O_W), g.ic, nullptr, 0, 0, kb, 1);
+  p[1] = prob1(g.pt, g.pt, c->pooled + g.ic, g.ek, c->dattout + g.ic, g.ek, B, G(c, TCAR_V_OT_W), g.pt, nullptr, 0, 0, kb, 1);
+  p[2] = prob1(g.ldh, g.ic, c->q1, g.ldh, c->dq, g.ic, B, G(c, TCAR_V_Q2_W), g.ic, nullptr, 0, 0, kb, 1);
+  p[3] = prob1(g.ct, g.ldh, c->click_t, g.ct, c->dq1, g.ldh, B, G(c, TCAR_V_Q1_W), g.ldh, nullptr, 0, 0, kb, 1);
+  p[4] = prob1(g.ic, g.ldh, c->x_icp, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WIN), g.ldh, nullptr, 0, 0, kr, 1);
+  p[5] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WC), g.ldh, nullptr, 0, 0, kr, 1);
+  p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
+  p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
+  p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
+  // slab form: problem i writes its splits to slabs_i [split][M][N]
+  tcar_fold_t f[9];
+  int nf = 0;
+  int64_t need = 0;
+  for (int i = 0; i < 9; ++i)
+    if (p[i].splitk > 1) need += (int64_t)p[i].splitk * p[i].M * p[i].N;
+  if (need > 0 && c->wgrad_slabs && c->wgrad_slab_floats >= need) {
+    float* at = c->wgrad_slabs;
+    for (int i = 0; i < 9; ++i) {
+      if (p[i].splitk <= 1) continue;
+      const int K = (i < 4) ? B : BT;
+      f[nf].dst = p[i].C; f[nf].slabs = at; f[nf].n = (int64_t)p[i].M * p[i].N;
+      f[nf].ks = tcar_gemm_splitk_effective(K, p[i].splitk); f[nf].stride = (int64_t)p[i].M * p[i].N;
+      ++nf;
+      p[i].C = at; p[i].atomic = 0;
+      at += (int64_t)p[i].splitk * p[i].M * p[i].N;
+    }
+  }
+  RET(small_gemm(c, 2, 9, p, stream));
+  if (nf) RET(tcar_fold_slabs(nf, f, stream));
+  return TCAR_OK;
+}
+
 // bias gradients of the four linear_2d layers and the two residual-weight gradients as column sums in a fixed order
 int det_colsums(const tcar_ctx_t* c, const Geo& g, int B, void* stream) {
   tcar_colsum_t cs[6] = {{c->dattout, g.ek, B, g.ic, G(c, TCAR_V_O_B)},
@@ -406,23 +447,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       return TCAR_E_LAUNCH;
   } else if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
-  {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
-    const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 1536;
-    auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
-    const int kb = ks(B), kr = ks(BT);
-    const float* x_c = c->x_icp + g.ldh;
-    tcar_gemm_desc_t p[9];
-    p[0] = prob1(g.ic, g.ic, c->pooled, g.ek, c->dattout, g.ek, B, G(c, TCAR_V_O_W), g.ic, nullptr, 0, 0, kb, 1);
-    p[1] = prob1(g.pt, g.pt, c->pooled + g.ic, g.ek, c->dattout + g.ic, g.ek, B, G(c, TCAR_V_OT_W), g.pt, nullptr, 0, 0, kb, 1);
-    p[2] = prob1(g.ldh, g.ic, c->q1, g.ldh, c->dq, g.ic, B, G(c, TCAR_V_Q2_W), g.ic, nullptr, 0, 0, kb, 1);
-    p[3] = prob1(g.ct, g.ldh, c->click_t, g.ct, c->dq1, g.ldh, B, G(c, TCAR_V_Q1_W), g.ldh, nullptr, 0, 0, kb, 1);
-    p[4] = prob1(g.ic, g.ldh, c->x_icp, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WIN), g.ldh, nullptr, 0, 0, kr, 1);
-    p[5] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WC), g.ldh, nullptr, 0, 0, kr, 1);
-    p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
-    p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
-    p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
-    RET(small_gemm(c, 2, 9, p, sW));
-  }
+  RET(weight_grads(c, g, B, BT, sW));
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
@@ -757,26 +782,12 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
     tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     RET(small_gemm(c, 1, 1, &p, stream));
   }
-  {  // the nine weight gradients x^T dy (K = batch rows): one launch, atomic split-K into the zeroed arena
-    const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 1536;
-    auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
-    const int kb = ks(B), kr = ks(BT);
-    const float* x_c = c->x_icp + g.ldh;
-    tcar_gemm_desc_t p[9];
-    p[0] = prob1(g.ic, g.ic, c->pooled, g.ek, c->dattout, g.ek, B, G(c, TCAR_V_O_W), g.ic, nullptr, 0, 0, kb, 1);
-    p[1] = prob1(g.pt, g.pt, c->pooled + g.ic, g.ek, c->dattout + g.ic, g.ek, B, G(c, TCAR_V_OT_W), g.pt, nullptr, 0, 0, kb, 1);
-    p[2] = prob1(g.ldh, g.ic, c->q1, g.ldh, c->dq, g.ic, B, G(c, TCAR_V_Q2_W), g.ic, nullptr, 0, 0, kb, 1);
-    p[3] = prob1(g.ct, g.ldh, c->click_t, g.ct, c->dq1, g.ldh, B, G(c, TCAR_V_Q1_W), g.ldh, nullptr, 0, 0, kb, 1);
-    p[4] = prob1(g.ic, g.ldh, c->x_icp, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WIN), g.ldh, nullptr, 0, 0, kr, 1);
-    p[5] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WC), g.ldh, nullptr, 0, 0, kr, 1);
-    p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
-    p[7] = prob1(g.pt, g.ldh, c->x_pt, g.pt, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WIN), g.ldh, nullptr, 0, 0, kr, 1);
-    p[8] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre2, g.ldh, BT, G(c, TCAR_V_S_WC), g.ldh, nullptr, 0, 0, kr, 1);
+  {
     // beside the row gradients on the aux stream (behind tcar_shard_finish there); tcar_shard_join covers it
     hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
     if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
       return TCAR_E_LAUNCH;
-    RET(small_gemm(c, 2, 9, p, s2 ? (void*)s2 : stream));
+    RET(weight_grads(c, g, B, BT, s2 ? (void*)s2 : stream));
     if (detc) RET(det_colsums(c, g, B, s2 ? (void*)s2 : stream));
     if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }

@@ -751,6 +751,13 @@ class TcarEngine:
         c.scoring_bwd = self.scoring_bwd
         if self.scoring_code and not os.environ.get("TCAR_ATOMIC_COLSUMS"):
             c.gw_rows = self.gw_rows.data_ptr()
+        if self.work_rows > 1536 and not os.environ.get("TCAR_ATOMIC_WGRAD"):
+            # batches of more than 1,536 rows split the K of the weight gradients: slabs folded in split order (order-fixed)
+            per = g.ic * g.ic + g.pt * g.pt + g.ldh * g.ic + g.ct * g.ldh + g.ic * g.ldh + 2 * g.ldh * g.ldh + g.ldt * g.ldh + g.pt * g.ldh
+            need = min(16, (self.work_rows + 1535) // 1536) * per
+            if getattr(self, "_wgrad_slabs", None) is None or self._wgrad_slabs.numel() < need:
+                self._wgrad_slabs = torch.empty(need, dtype=torch.float32, device=self.dev)
+            c.wgrad_slabs, c.wgrad_slab_floats = self._wgrad_slabs.data_ptr(), self._wgrad_slabs.numel()
         if self.scoring_code:
             for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l"):
                 setattr(c, n, getattr(self, n).data_ptr())

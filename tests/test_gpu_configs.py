@@ -217,8 +217,8 @@ def test_stress_10m_items_d256_properties():
         assert float(eng.E[:, H:g.ldh].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("scoring", ["f32", "bf16x3"])
-def test_same_step_twice_bitwise_report(scoring):
+@pytest.mark.parametrize("scoring,T", [("f32", 3), ("bf16x3", 3), ("bf16x3", 5), ("bf16x3-mixed", 7)])
+def test_same_step_twice_bitwise_report(scoring, T):
     """SURVEY.md §5 'race detection' row: the same fused training step from the same state, three times.  Every quantity that
     is accumulated in a fixed order must repeat bit for bit — engine.DETERMINISTIC_GRADS names them (in the split-bf16 modes:
     every gradient, every clip norm, every variable after one AND after two steps); what still goes through float atomics
@@ -229,8 +229,9 @@ def test_same_step_twice_bitwise_report(scoring):
     from tcar_amd.host.model import initial_variables
     from tcar_amd.host.synth import SynthFold
     N, H, Ht, B, K = 5000, 250, 64, 512, 20
-    fold = SynthFold(n_items=N, dim=H, n_train=8000, n_test=10, seed=5)      # Zipf items: popular rows repeat in a batch
-    idx = np.where(fold.train.in_len == 3)[0][:B]
+    fold = SynthFold(n_items=N, dim=H, n_train=80000, n_test=10, seed=5)     # Zipf items: popular rows repeat in a batch
+    idx = np.where(fold.train.in_len == T)[0][:B]        # T = 5, 7: more than 1,536 batch rows -> the weight gradients split K
+    assert len(idx) == B
     batch = fold.train.batch_arrays(idx, "click_delta")
     batch["neg"] = np.random.RandomState(2).randint(0, N, size=(len(idx), K)).astype(np.int32)
     batch["neg"][:, 0] = batch["neg"][0, 0]                                  # one negative row with 512 sources
@@ -268,3 +269,18 @@ def test_same_step_twice_bitwise_report(scoring):
     assert set(differ["grad"]) <= set(VAR_ORDER) - set(must)
     if scoring != "f32":
         assert not differ["param after 2 steps"], differ
+    if T > 3:
+        # the K splits of the weight gradients are slabs folded in split order: same values as the un-split launch, to rounding
+        import ctypes as C
+        from tcar_amd import _lib
+        lib = _lib.load()
+        old = lib.tcar_set_tuning(b"TCAR_WGRAD_KS", 1 << 20)
+        try:
+            eng = TcarEngine(params, fold.content, fold.mwdhm, scoring=scoring)
+            eng.train_step(batch)
+            g1 = eng.export_grads()
+        finally:
+            lib.tcar_set_tuning(b"TCAR_WGRAD_KS", old)
+        for k in VAR_ORDER:
+            if k.endswith("/w_3d") or k.endswith("/w1"):
+                close(runs[0][0][k], g1[k], rtol=1e-4, atol_scale=1e-5, name="split vs un-split " + k)

@@ -124,6 +124,27 @@ def test_bf16_gradient_gemms_keep_hr_and_mrr():
         assert abs(r["loss"] - ref["loss"]) <= 1e-3 * abs(ref["loss"]), (mode, r["loss"], ref["loss"])
 
 
+def test_two_training_runs_are_bit_identical():
+    """SURVEY.md §5 'race detection': the whole run — every length bucket (1 .. 20+ input clicks: un-split and split weight
+    gradients), uniform negatives, three epochs, evaluation — twice from the same seeds in the bench's precision: the printed
+    losses and every metric must be IDENTICAL, not close (no sum in the step depends on arrival order)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tcar_amd.host.cli import main
+    outs = []
+    for _ in range(2):
+        buf = io.StringIO()
+        with redirect_stdout(buf):
+            m = main(["--synthetic", "3000", "--synthetic_train", "30000", "--synthetic_test", "4000", "--epoch", "3",
+                      "--batch_size", "512", "--gap_mode", "click_delta", "--scoring", "bf16x3-mixed"])
+        losses = [l for l in buf.getvalue().splitlines() if l.startswith("\tloss:")]
+        outs.append((losses, dict(m.last_metrics), m.engine.export_params()))
+    assert len(outs[0][0]) == 3 and outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1], (outs[0][1], outs[1][1])
+    for k, v in outs[0][2].items():
+        assert np.array_equal(v, outs[1][2][k]), k
+
+
 def test_cli_runs_on_a_fold_in_the_reference_pickle_layout(tmp_path):
     """main.py --datapath/--dataset/--split_way/--foldnum on files written the way the reference's preprocessing writes
     them (util.py:20-56): load, tensorise, train one epoch, evaluate — the stdout contract of model_combine.py holds."""
