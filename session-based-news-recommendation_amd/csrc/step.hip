@@ -789,12 +789,14 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
       return TCAR_E_LAUNCH;
     RET(weight_grads(c, g, B, BT, s2 ? (void*)s2 : stream));
     if (detc) RET(det_colsums(c, g, B, s2 ? (void*)s2 : stream));
-    if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
   tcar_tables_t tab;
   tcar_grads_t gr;
   tables_of(c, tab);
   grads_of(c, gr);
+  // (the small tables keep their LDS + atomic form here: the aux stream of this path already carries the dE tail, the weight
+  // gradients and the column sums, and the order-fixed kernel behind them delays the join: 0.69 -> 0.72+ ms on one rank)
+  if (aux_stream(c) && hipEventRecord((hipEvent_t)c->ev[3], aux_stream(c)) != hipSuccess) return TCAR_E_LAUNCH;
   gr.rows_out = rows_out;
   gr.rows_ld = rows_ld;
   RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
