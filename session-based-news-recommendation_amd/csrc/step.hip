@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 1536), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -31,7 +31,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}};
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}};
   for (auto& e : tab) {
     bool same = true;
     for (int i = 0; same; ++i) {
@@ -307,7 +307,7 @@ int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream);
 // Every cross-stream join costs ~10 us of launch latency behind an event, so there are as few as the data flow allows.
 // Rank-local backward of the data-parallel step (fuse_finish = false): dE and the negative rows run FIRST on the main
 // stream (their all-reduce then overlaps everything else, dp.py); the finish is tcar_step_finish after the exchange.
-int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish) {
+int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish, bool join_tail = true) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
   const int B = bt->B, T = bt->T, BT = B * T, K = bt->K;
@@ -516,8 +516,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
     }
   }
-  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
-  if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
+  // (tcar_train_step joins later: the item table's update needs nothing of the other streams and runs first)
+  if (join_tail || !s2) {
+    if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
+    if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
+  }
   if (fuse_finish && !s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
   return TCAR_OK;
 }
@@ -575,8 +578,25 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
 
 extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {
   RET(forward_impl(c, bt, refresh_time, stream, -1.f, true));
-  RET(backward_impl(c, bt, stream, true));
-  return tcar_step_update(c, lr_t, stream);
+  hipStream_t s2 = aux_stream(c);
+  if (!s2 || !tcar_tuning().split_update) {
+    RET(backward_impl(c, bt, stream, true));
+    return tcar_step_update(c, lr_t, stream);
+  }
+  // TCAR_SPLIT_UPDATE=1 (experiment, off): the item table's gradient, norm and norm pieces are complete on the main stream
+  // before the other streams are, so its update (the 60-us HBM pass) can start at once with the cross-stream joins (~10 us of
+  // event latency) hidden under it and the arena following behind the join.  Same arithmetic as the one-launch update —
+  // and measured SLOWER (0.606 -> 0.615 ms): the second launch and its join cost more than the hidden bubble.
+  RET(backward_impl(c, bt, stream, true, false));
+  const Geo g(c->d);
+  const float* pieces = c->Gx + c->arena_n;
+  hipStream_t st = (hipStream_t)stream;
+  RET(tcar_clip_adam_2d_bf16(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip,
+                             lr_t, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, stream));
+  if (hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;
+  if (c->stream3 && c->ev3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;
+  return tcar_clip_adam(c->W, c->Gx, c->M, c->V, &c->segs_all, c->sqn_dense, pieces, c->use_dense, c->clip, lr_t, c->b1, c->b2, c->eps,
+                        stream);
 }
 
 extern "C" int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int pending,

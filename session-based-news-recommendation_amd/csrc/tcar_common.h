@@ -67,6 +67,7 @@ struct TcarTuning {
   int bf16_ks;          // TCAR_BF16_KS        64-deep LDS stages of the hi-only bf16 GEMM: 1 never, 2 dX / logits layouts, 3 all
   int de_late;          // TCAR_DE_LATE        1: the fused step starts dE after dX + slab reduce instead of beside them
   int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
+  int split_update;     // TCAR_SPLIT_UPDATE   1: item-table Adam before the cross-stream joins, arena after (measured slower)
 };
 const TcarTuning& tcar_tuning();
 
