@@ -298,12 +298,15 @@ int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream);
 int item_norm(const tcar_ctx_t* c, const Geo& g, void* stream);
 int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream);
 
-// Backward pass.  Two chains follow the softmax gradient (fused single-rank step; `main` is the caller's stream, which the
+// Backward pass.  Three chains follow the softmax gradient (fused single-rank step; `main` is the caller's stream, which the
 // engine makes a high-priority one so that its workgroups are dispatched first):
-//   main:  softmax -> dX = dlogits E -> slab reduce + tanh' + bias -> attention / projection / query backward -> input
-//          gradients -> negative rows + loss -> item norm -> row scatter -> [join] -> (update)
-//   aux:   zero arena, negative-term forward (beside the softmax) -> dE = dlogits^T attout (time block in inverted-index
-//          order) -> candidate-side time backward -> weight-gradient GEMM -> dense-weight norms
+//   main:   softmax -> dX = dlogits E -> slab reduce + tanh' -> attention / projection / query backward -> input gradients
+//           -> negative rows (sorted sum) + loss -> dense-norm partials -> item-row gradients -> session rows (sorted sum)
+//           + norm folds -> [join] -> (update)
+//   aux:    zero arena, negative-term forward (beside the softmax) -> dE = dlogits^T attout (time block in inverted-index
+//           order) -> candidate-side time backward -> position / time / dwell tables of the session side (order-fixed)
+//   third:  weight-gradient GEMM (+ slab fold) -> bias / residual-weight column sums -> dense-weight norms
+// No sum in these chains depends on arrival order (determinism); the atomic forms stay behind switches.
 // Every cross-stream join costs ~10 us of launch latency behind an event, so there are as few as the data flow allows.
 // Rank-local backward of the data-parallel step (fuse_finish = false): dE and the negative rows run FIRST on the main
 // stream (their all-reduce then overlaps everything else, dp.py); the finish is tcar_step_finish after the exchange.
