@@ -33,6 +33,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -65,6 +66,10 @@ class ShardedEngine(TcarEngine):
         nl = max(0, min(N, n0 + self.S) - n0)
         if nl <= 0:
             raise ValueError("more ranks than 128-row catalog blocks")
+        # dX of a shard contracts over N / W catalog rows for W * B sessions: W times more output tiles and a W times shorter
+        # K than the single-rank GEMM, so the split that fills the chip (and the slab bytes it writes) shrinks with W
+        if "splitk" not in kw and "TCAR_SPLITK" not in os.environ:
+            kw["splitk"] = max(2, -(-36 // self.world))
         super().__init__(params, content_emb, mwdhm, lr=lr, max_grad=max_grad, neg_weight=neg_weight, device=device,
                          scoring=scoring, shard=(n0, nl), **kw)
         self.n0, self.nl = n0, nl
