@@ -59,6 +59,12 @@ class ShardedEngine(TcarEngine):
         live = dist.is_available() and dist.is_initialized()
         self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
         self.dp_rank = rank if rank is not None else (dist.get_rank(group) if live else 0)
+        # TCAR_SIM_WORLD=W on ONE process without a process group (tools, bench.py with TCAR_FORCE_DP=1): the shapes of rank 0
+        # of a W-rank job — every "all-gather" repeats the local rows W times, the reduce-scatter keeps the first slice — to
+        # time the per-rank compute of a large job on one GPU.  Results are meaningless beyond their shapes.
+        self._sim = False
+        if not live and world is None and int(os.environ.get("TCAR_SIM_WORLD", "0")) > 1:
+            self.world, self.dp_rank, self._sim = int(os.environ["TCAR_SIM_WORLD"]), 0, True
         self._mwdhm_full = np.asarray(mwdhm)
         N = content_emb.shape[0] - 1
         self.S = shard_rows(N, self.world)
@@ -85,6 +91,8 @@ class ShardedEngine(TcarEngine):
         """[..] -> [W, ..] (rank-major); world 1: a view"""
         if self.world == 1:
             return t.unsqueeze(0)
+        if self._sim:
+            return t.unsqueeze(0).expand((self.world,) + tuple(t.shape)).contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group)
         self.bytes_moved[key] = out.numel() * out.element_size()
@@ -92,7 +100,7 @@ class ShardedEngine(TcarEngine):
 
     def _reduce_scatter_rows(self, full: torch.Tensor, cap: int, key: str) -> torch.Tensor:
         """sum over the ranks of full [W*cap, C]; returns this rank's rows [cap, C]"""
-        if self.world == 1:
+        if self.world == 1 or self._sim:
             return full[:cap]
         self.bytes_moved[key] = full.numel() * full.element_size()
         if self.backend == "nccl":
@@ -224,7 +232,7 @@ class ShardedEngine(TcarEngine):
         # ---- arena exchange (gradients + norm pieces incl. the shards' dense item norms), dense-weight norms, update.  The
         # dense-weight norms are summed in a fixed order (tcar_sqnorm, one workgroup per variable): identical gradients give
         # identical norms on every rank, the replicas stay bit-identical without a broadcast.
-        if W > 1:
+        if W > 1 and not self._sim:
             dist.all_reduce(self.Gx, group=self.group)
             self.bytes_moved["arena"] = self.Gx.numel() * 4
         check(lib.tcar_sqnorm(p(self.G), C.byref(self.segs_dense), p(self.sqn_dense), st), "tcar_sqnorm")
@@ -259,7 +267,7 @@ class ShardedEngine(TcarEngine):
         g = self.geo
         check(self.lib.tcar_step_update(C.byref(self._shard_ctx()), self._lr_t(), self._stream()), "tcar_step_update")
         self._after_update()
-        if self.world > 1:
+        if self.world > 1 and not self._sim:
             self._stage[self.dp_rank, :self.nl].copy_(self.E[self.n0:self.n0 + self.nl, :g.ldh])
             dist.all_gather_into_tensor(self._stage.view(-1), self._stage[self.dp_rank].reshape(-1).clone(), group=self.group)
             self.bytes_moved["item_rows"] = self._stage.numel() * 4
