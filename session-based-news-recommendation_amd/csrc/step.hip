@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 1536), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0), env_int("TCAR_Q_STREAM", 0)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -31,7 +31,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}};
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}, {"TCAR_Q_STREAM", &t.q_stream}};
   for (auto& e : tab) {
     bool same = true;
     for (int i = 0; same; ++i) {
@@ -139,6 +139,13 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   tables_of(c, tab);
   RET(tcar_gather_clip_fwd(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream));
   const float* x_c = c->x_icp + g.ldh;
+  // TCAR_Q_STREAM=1 (experiment, off): the click-query MLP (two small dependent GEMMs, modules.py:138-139) on the third
+  // stream beside the projections instead of behind them — takes a 14-us launch off the main chain and gives it back as
+  // fork / join latency: 0.604 -> 0.607 ms
+  hipStream_t st = (hipStream_t)stream;
+  hipStream_t sq = (tcar_tuning().q_stream && aux_stream(c) && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
+  if (sq && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sq, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+    return TCAR_E_LAUNCH;
   {  // pre1, pre2, q1 (modules.py:126-131, 94-96, 138)
     tcar_gemm_desc_t p[3];
     p[0] = prob(BT, g.ldh, c->pre1, g.ldh);
@@ -149,11 +156,18 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     seg(p[1], c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt);
     seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
     p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
-    RET(small_gemm(c, 0, 3, p, stream));
+    if (sq) {
+      RET(small_gemm(c, 0, 1, &p[2], (void*)sq));
+      RET(small_gemm(c, 0, 2, p, stream));
+    } else {
+      RET(small_gemm(c, 0, 3, p, stream));
+    }
   }
   {  // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
-    RET(small_gemm(c, 0, 1, &p, stream));
+    RET(small_gemm(c, 0, 1, &p, sq ? (void*)sq : stream));
+    if (sq && (hipEventRecord((hipEvent_t)c->ev3, sq) != hipSuccess || hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess))
+      return TCAR_E_LAUNCH;
   }
   RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
                          W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));

@@ -68,6 +68,7 @@ struct TcarTuning {
   int de_late;          // TCAR_DE_LATE        1: the fused step starts dE after dX + slab reduce instead of beside them
   int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
   int split_update;     // TCAR_SPLIT_UPDATE   1: item-table Adam before the cross-stream joins, arena after (measured slower)
+  int q_stream;         // TCAR_Q_STREAM       1: the click-query MLP of the forward pass on the third stream beside the projections
 };
 const TcarTuning& tcar_tuning();
 
