@@ -250,7 +250,8 @@ class Seq2SeqAttNN():
             print('Epoch {}'.format(epoch))
             batch = 0
             sampler = self._sampler(train_data, neighbor_dict, item_dict, args['neg_num'])
-            total = torch.zeros((), dtype=torch.float64, device=eng.dev)
+            # per-row fp64 accumulator of the epoch's losses: ONE small kernel per step (the reference sums python floats)
+            acc = torch.zeros(max(int(args['batch_size']), 1), dtype=torch.float64, device=eng.dev)
             count = 0
             t0 = time.time()
             if self.device_sampler:
@@ -261,7 +262,7 @@ class Seq2SeqAttNN():
                                                   K=args['neg_num'] if neighbor_dict else 0)
                     else:
                         crt_loss = eng.train_step(None, bt=bt)
-                    total += crt_loss.double().sum()
+                    acc[:crt_loss.numel()].add_(crt_loss)
                     count += crt_loss.numel()
             for feed in (() if self.device_sampler else prefetch_batches(sampler)):
                 batch += 1
@@ -273,10 +274,10 @@ class Seq2SeqAttNN():
                     crt_loss = eng.train_step(sub, cap_rows=cap * T, T=T, K=(feed["neg"].shape[1] if feed["neg"] is not None else 0))
                 else:
                     crt_loss = eng.train_step(feed)             # [b] on device; no host sync inside the loop
-                total += crt_loss.double().sum()
+                acc[:crt_loss.numel()].add_(crt_loss)
                 count += crt_loss.numel()
             eng.flush()                                         # the last step's deferred update
-            tot, cnt = self._allsum([float(total.item()), float(count)])
+            tot, cnt = self._allsum([float(acc.sum().item()), float(count)])
             avgc = tot / max(cnt, 1)
             self.train_seconds = time.time() - t0
             self.train_sessions = int(cnt)
