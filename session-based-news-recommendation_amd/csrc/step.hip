@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 1536), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0), env_int("TCAR_Q_STREAM", 0)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0), env_int("TCAR_Q_STREAM", 0), env_int("TCAR_EARLY_PROLOGUE", 0)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -31,7 +31,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}, {"TCAR_Q_STREAM", &t.q_stream}};
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}, {"TCAR_Q_STREAM", &t.q_stream}, {"TCAR_EARLY_PROLOGUE", &t.early_prologue}};
   for (auto& e : tab) {
     bool same = true;
     for (int i = 0; same; ++i) {
@@ -191,6 +191,18 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
 }  // namespace
 
 namespace {
+// zero the gradient arena and the norm slots, and the forward part of the sampled negative term (it needs only attout and E):
+// on the aux stream `sz`, ordered behind everything already on the main stream (the previous update read Gx)
+int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
+  if (sz != st && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sz, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+    return TCAR_E_LAUNCH;
+  if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
+  if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
+  if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
+    RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
+  return TCAR_OK;
+}
+
 int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream, float rest_lr, bool train_index) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
@@ -227,6 +239,12 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   }
   RET(session_forward(c, bt, g, stream, c->scoring && tcar_tuning().planes_epi));
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
+  if (train_index && s2 && tcar_tuning().early_prologue) {
+    // fused training step: the backward's aux-stream prologue needs attout only — it runs beside the logits GEMM, and the
+    // fork sits next to the join above instead of between the logits GEMM and the softmax
+    RET(backward_prologue(c, bt, s1, s2));
+    if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  }
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   int ei = -1;
   auto start_timer = [&]() {
@@ -324,7 +342,8 @@ int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream);
 // Every cross-stream join costs ~10 us of launch latency behind an event, so there are as few as the data flow allows.
 // Rank-local backward of the data-parallel step (fuse_finish = false): dE and the negative rows run FIRST on the main
 // stream (their all-reduce then overlaps everything else, dp.py); the finish is tcar_step_finish after the exchange.
-int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish, bool join_tail = true) {
+int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish, bool join_tail = true,
+                  bool prologue_done = false) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
   const int B = bt->B, T = bt->T, BT = B * T, K = bt->K;
@@ -337,17 +356,13 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // zero the gradient arena and the norm slots; with an aux stream this happens beside the softmax, not before it
   // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
   hipStream_t sz = s2 ? s2 : st;
-  if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
-    return TCAR_E_LAUNCH;
-  if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
-  if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
-  // the forward part of the sampled negative term needs only attout and E: it runs here, beside the softmax
-  if (has_neg)
-    RET(tcar_neg_fwd(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
+  if (!prologue_done) {
+    RET(backward_prologue(c, bt, st, sz));
+    if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  }
   // sorted segmented sum of the item-row gradients (deterministic); its index was built under the forward pass, on the aux
-  // stream — ev[1] below orders the main stream behind it
+  // stream — ev[1] (recorded behind the prologue) orders the main stream behind it
   const bool sorted = fuse_finish && sorted_rows(c, bt);
-  if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
   const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
@@ -597,14 +612,14 @@ extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int 
   RET(forward_impl(c, bt, refresh_time, stream, -1.f, true));
   hipStream_t s2 = aux_stream(c);
   if (!s2 || !tcar_tuning().split_update) {
-    RET(backward_impl(c, bt, stream, true));
+    RET(backward_impl(c, bt, stream, true, true, aux_stream(c) && tcar_tuning().early_prologue));
     return tcar_step_update(c, lr_t, stream);
   }
   // TCAR_SPLIT_UPDATE=1 (experiment, off): the item table's gradient, norm and norm pieces are complete on the main stream
   // before the other streams are, so its update (the 60-us HBM pass) can start at once with the cross-stream joins (~10 us of
   // event latency) hidden under it and the arena following behind the join.  Same arithmetic as the one-launch update —
   // and measured SLOWER (0.606 -> 0.615 ms): the second launch and its join cost more than the hidden bubble.
-  RET(backward_impl(c, bt, stream, true, false));
+  RET(backward_impl(c, bt, stream, true, false, tcar_tuning().early_prologue != 0));
   const Geo g(c->d);
   const float* pieces = c->Gx + c->arena_n;
   hipStream_t st = (hipStream_t)stream;
@@ -636,7 +651,7 @@ extern "C" int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t*
     }
   }
   RET(forward_impl(c, bt, refresh_time, stream, rest_lr, true));
-  return backward_impl(c, bt, stream, true);
+  return backward_impl(c, bt, stream, true, true, aux_stream(c) && tcar_tuning().early_prologue);
 }
 
 extern "C" int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream) {

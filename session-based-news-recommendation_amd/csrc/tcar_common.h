@@ -69,6 +69,7 @@ struct TcarTuning {
   int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
   int split_update;     // TCAR_SPLIT_UPDATE   1: item-table Adam before the cross-stream joins, arena after (measured slower)
   int q_stream;         // TCAR_Q_STREAM       1: the click-query MLP of the forward pass on the third stream beside the projections
+  int early_prologue;   // TCAR_EARLY_PROLOGUE 1: arena memsets + negative-term forward forked before the logits GEMM (measured neutral)
 };
 const TcarTuning& tcar_tuning();
 
