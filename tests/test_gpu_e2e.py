@@ -168,6 +168,16 @@ def test_cli_runs_on_a_fold_in_the_reference_pickle_layout(tmp_path):
         assert line in out, line
     assert 0.0 <= model.last_metrics["recall"] <= 1.0 and np.isfinite(model.last_metrics["loss"])
     assert model.last_metrics["ild"] > 0          # the category file was used
+    # the same fold without the files (SynthFold built in memory from the same seed): the loader + tensoriser must hand the
+    # engine the same sessions, so the run lands in the same place (bucket order differs -> different shuffles: not bitwise)
+    buf2 = io.StringIO()
+    with redirect_stdout(buf2):
+        mem = main(["--synthetic", "500", "--synthetic_train", "2500", "--synthetic_test", "300", "--seed", "11", "--epoch", "1",
+                    "--hidden_size", "48", "--time_hidden_size", "16", "--batch_size", "128", "--gap_mode", "active_t"])
+    a, b = model.last_metrics, mem.last_metrics
+    assert abs(a["loss"] - b["loss"]) <= 0.03 * abs(b["loss"]), (a["loss"], b["loss"])
+    assert abs(a["recall"] - b["recall"]) <= 0.06 and abs(a["mrr"] - b["mrr"]) <= 0.04, (a, b)
+    assert model.train_sessions == mem.train_sessions == 2500
 
 
 def test_cli_checkpoint_save_then_test_only(tmp_path):
