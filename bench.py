@@ -241,11 +241,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # TCAR_DEFER=1 (experiment): defer each step's Adam into the next step's forward pass (engine.train_step docstring);
-    # the last update is flushed INSIDE the timed region, so K timed steps contain exactly K updates.  Measured neutral.
-    defer = {"defer_update": True} if (os.environ.get("TCAR_DEFER") and world == 1 and not os.environ.get("TCAR_FORCE_DP")) else {}
+    # Single rank: each step's Adam is applied at the start of the NEXT train_step (engine.train_step(defer_update=True): the
+    # rows the next batch gathers first on the main stream, every other item row on the aux stream beside the next forward
+    # pass — bitwise the same arithmetic, tests/test_gpu_parity.py).  The last update is flushed INSIDE the timed region, so K
+    # timed steps contain exactly K forward passes, K backward passes and K updates.  TCAR_NO_DEFER=1: update inside its step.
+    defer = {"defer_update": True} if (world == 1 and not os.environ.get("TCAR_FORCE_DP") and not os.environ.get("TCAR_NO_DEFER")) else {}
     for i in range(args.warmup):
         eng.train_step(None, bt=resident[i % len(resident)], **defer)
+    eng.flush()                                  # the last warm-up step's update belongs to the warm-up
     if not args.no_kernel_timing:
         eng.enable_native_timing(args.steps)     # HIP events around the three scoring GEMMs inside the step driver
     sync()

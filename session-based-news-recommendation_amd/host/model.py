@@ -261,7 +261,7 @@ class Seq2SeqAttNN():
                         crt_loss = eng.train_step(None, bt=bt, cap_rows=cap_rows, T=int(sampler.store.in_len[_idx0(sampler, batch - 1)]),
                                                   K=args['neg_num'] if neighbor_dict else 0)
                     else:
-                        crt_loss = eng.train_step(None, bt=bt)
+                        crt_loss = eng.train_step(None, bt=bt, defer_update=True)   # applied inside the next step (flush below)
                     acc[:crt_loss.numel()].add_(crt_loss)
                     count += crt_loss.numel()
             for feed in (() if self.device_sampler else prefetch_batches(sampler)):
@@ -273,7 +273,7 @@ class Seq2SeqAttNN():
                     sub, cap = self._shard(feed)
                     crt_loss = eng.train_step(sub, cap_rows=cap * T, T=T, K=(feed["neg"].shape[1] if feed["neg"] is not None else 0))
                 else:
-                    crt_loss = eng.train_step(feed)             # [b] on device; no host sync inside the loop
+                    crt_loss = eng.train_step(feed, defer_update=True)   # [b] on device; no host sync inside the loop
                 acc[:crt_loss.numel()].add_(crt_loss)
                 count += crt_loss.numel()
             eng.flush()                                         # the last step's deferred update
