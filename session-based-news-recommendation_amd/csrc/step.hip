@@ -191,13 +191,33 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
 }  // namespace
 
 namespace {
+// the gradient arena (+ norm pieces) and the dense norm slots in ONE launch (two hipMemsetAsync calls cost more host time
+// and two blit kernels)
+__global__ __launch_bounds__(256) void zero2_kernel(float4* __restrict__ a, long na4, float* __restrict__ b, int nb) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na4; i += (long)gridDim.x * 256) a[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < nb) b[threadIdx.x] = 0.f;
+}
+int zero_arena(const tcar_ctx_t* c, hipStream_t s) {
+  const long n = (long)c->arena_n + TCAR_NSLOT;
+  if ((n & 3) || !tcar_aligned16(c->Gx) || TCAR_NSLOT > 256) {
+    if (hipMemsetAsync(c->Gx, 0, (size_t)n * sizeof(float), s) != hipSuccess) return TCAR_E_LAUNCH;
+    if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), s) != hipSuccess) return TCAR_E_LAUNCH;
+    return TCAR_OK;
+  }
+  long blocks = (n / 4 + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  TCAR_LAUNCH(zero2_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (float4*)c->Gx, n / 4, c->sqn_dense, (int)TCAR_NSLOT);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
 // zero the gradient arena and the norm slots, and the forward part of the sampled negative term (it needs only attout and E):
 // on the aux stream `sz`, ordered behind everything already on the main stream (the previous update read Gx)
 int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
   if (sz != st && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sz, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
-  if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
-  if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), sz) != hipSuccess) return TCAR_E_LAUNCH;
+  RET(zero_arena(c, sz));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
   return TCAR_OK;
@@ -693,8 +713,7 @@ extern "C" int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int
     RET(tcar_cand_time_fwd_bf16(&dc, tt, c->mwdhm, nullptr, c->e16h, c->e16l, (void*)s2));
     if (hipEventRecord((hipEvent_t)c->ev[5], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
-  if (hipMemsetAsync(c->Gx, 0, (size_t)(c->arena_n + TCAR_NSLOT) * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
-  if (hipMemsetAsync(c->sqn_dense, 0, TCAR_NSLOT * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
+  RET(zero_arena(c, st));
   if (!bt) return tcar_shard_pack_head(0, cap, g.ek, 0, Kc, nullptr, nullptr, nullptr, nullptr, head, ld_head, stream);
   RET(tcar_step_session_forward(c, bt, stream));
   const bool has_neg = bt->K > 0 && bt->neg && c->neg_coef && c->negpart;
