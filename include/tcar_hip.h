@@ -630,6 +630,9 @@ int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int K
  * tcar_scatter_add_rows_packed and the arena exchange */
 int tcar_shard_join(const tcar_ctx_t* c, void* stream);
 
+/* diagnostic: capture one fused step into a hipGraph and time its replay (tools/graph_probe.py); not a training path */
+int tcar_graph_probe(const tcar_ctx_t* c, const tcar_batch_t* bt, float lr_t, int iters, float* ms_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

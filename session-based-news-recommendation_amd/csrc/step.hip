@@ -876,3 +876,35 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
                             (ce_rows && has_neg) ? c->loss : nullptr, stream));
   return TCAR_OK;
 }
+
+
+// Diagnostic (tools/graph_probe.py): capture ONE fused training step (all three streams) into a hipGraph, replay it `iters`
+// times and time the replays with HIP events.  The captured step keeps the learning rate it was captured with — the probe
+// answers "what would graph replay cost per step", it is not a training path.  Returns the mean ms per replay in *ms_out.
+extern "C" int tcar_graph_probe(const tcar_ctx_t* c, const tcar_batch_t* bt, float lr_t, int iters, float* ms_out, void* stream) {
+  RET(check_ctx(c, bt));
+  if (!ms_out || iters <= 0) return TCAR_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  RET(tcar_train_step(c, bt, 1, lr_t, stream));             // eager once: first-use attribute calls happen outside the capture
+  if (hipStreamSynchronize(st) != hipSuccess) return TCAR_E_LAUNCH;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) return TCAR_E_LAUNCH;
+  const int rc = tcar_train_step(c, bt, 1, lr_t, stream);
+  const hipError_t e = hipStreamEndCapture(st, &graph);
+  if (rc != TCAR_OK || e != hipSuccess || !graph) return TCAR_E_LAUNCH;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); return TCAR_E_LAUNCH; }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  for (int i = 0; i < 5; ++i) (void)hipGraphLaunch(exec, st);
+  (void)hipEventRecord(e0, st);
+  for (int i = 0; i < iters; ++i) (void)hipGraphLaunch(exec, st);
+  (void)hipEventRecord(e1, st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *ms_out = ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph);
+  return TCAR_OK;
+}
