@@ -17,6 +17,7 @@ whole-job sessions/sec plus
                   events), against the dense bf16 MFMA peak (fp32 matrix peak for --scoring f32) of
                   /opt/skills/guides/MI355X_MICROARCH.md; "others" lists the other two the same way; "traffic" = HBM bytes
                   per launch from the committed rocprofv3 --pmc passes under profiles/ (null when the shape differs);
+  "gather_roofline"  the embedding-gather kernel at 655,360 rows against the 8 TB/s HBM peak (the north star's >= 70 % target);
   "cpu_baseline"  the CPU oracle (PyTorch-CPU fp32 restatement of the reference graph) on the host cores, on a bounded
                   sample of the same workload (rank 0, N = 1 only);
   "end_to_end_sessions_per_s"  one epoch through the trainer loop of main.py (host sampler + H2D + device step), N = 1.
@@ -128,6 +129,57 @@ def pmc_traffic(tag, nsplit, N, B):
     return None, None
 
 
+def gather_roofline(dev):
+    """The embedding-gather kernel against the HBM roofline (north star: >= 70 % on this kernel), measured here because the
+    training step itself gathers ~1,100 rows per launch (latency bound): 655,360 rows = 16,384 sessions x 40 clicks from a
+    2 M-item table (model_combine.py:54-107 forward: item + content + position + five time rows + dwell row per click, clipped
+    and concatenated; algorithmic bytes per session of SURVEY.md §8(d): read 3536 T + 512, written the same)."""
+    import ctypes as C
+    import torch
+    from tcar_amd import _lib
+    from tcar_amd._lib import Batch, Dims, Tables
+    lib = _lib.load()
+    N, B, T, H, Ht, ldh, ldt = 2_000_000, 16384, 40, 250, 64, 256, 64
+    ic, pt, ct, ek = 512, 320, 128, 832
+    g = torch.Generator(device="cpu").manual_seed(0)
+    ri = lambda lo, hi, *s: torch.randint(lo, hi, s, generator=g, dtype=torch.int32).to(dev)
+    E = torch.randn(N, ek, device=dev) * 0.05
+    small = [torch.randn(v, ldt, device=dev) * 0.3 for v in (13, 32, 8, 25, 61, 11)]
+    pos = torch.randn(40, ldh, device=dev) * 0.02
+    seq, pub = ri(1, N + 1, B, T), [ri(1, v, B, T) for v in (13, 32, 8, 25, 61)]
+    gap, cw, ch = ri(0, 11, B, T), ri(0, 7, B), ri(0, 24, B)
+    d = Dims(N, H, Ht, ldh, ldt)
+    tab = Tables()
+    tab.E, tab.pos, tab.dur = E.data_ptr(), pos.data_ptr(), small[5].data_ptr()
+    bt = Batch()
+    bt.B, bt.T, bt.K = B, T, 0
+    bt.seq, bt.cw, bt.ch, bt.gap = seq.data_ptr(), cw.data_ptr(), ch.data_ptr(), gap.data_ptr()
+    for k in range(5):
+        tab.time[k], bt.pub[k] = small[k].data_ptr(), pub[k].data_ptr()
+    outs = [torch.empty(B * T, ic, device=dev), torch.empty(B * T, pt, device=dev), torch.empty(B * T, ldt, device=dev),
+            torch.empty(B, ct, device=dev)]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    run = lambda: lib.tcar_gather_clip_fwd(C.byref(d), C.byref(tab), C.byref(bt), *[p(t) for t in outs], st)
+    for _ in range(3):
+        assert run() == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 10
+    e0.record(torch.cuda.current_stream(dev))
+    for _ in range(iters):
+        run()
+    e1.record(torch.cuda.current_stream(dev))
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = 2.0 * B * (3536.0 * T + 512)
+    gbs = nbytes / ms / 1e6
+    return {"kernel": "gather_clip_fwd (throughput form), model_combine.py:54-107", "bound": "hbm", "rows": B * T,
+            "bytes_per_launch": nbytes, "avg_ms": round(ms, 4), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "note": "algorithmic read + written bytes (SURVEY.md 8(d)) / HIP-event time of 10 launches; separate from the step, "
+                    "whose own gather is ~1,100 rows per launch"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +202,7 @@ def main():
                     help="multi-GPU exchange: replica = all-reduce of the dense item gradient; sharded = catalog-sharded scoring")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same_device", action="store_true", help="dry run: put every rank on cuda:0")
+    ap.add_argument("--no_gather_roofline", action="store_true", help="skip the embedding-gather HBM roofline measurement")
     ap.add_argument("--scoring", default="bf16x3-mixed", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
                     help="precision of the full-catalog scoring GEMMs.  bf16x3-mixed (default; BASELINE.json configs[1] is "
                          "quoted in bf16): logits from split-bf16 planes (three MFMAs per product, fp32-class: the 1e-3 "
@@ -391,6 +444,12 @@ def main():
                        "sampling, H2D, device step): host_sampler = vectorised numpy sampler on a prefetch thread + pinned H2D "
                        "of the feed; device_sampler = example indices only over PCIe, feed formed by tcar_form_batch"}
 
+    gather = None
+    quick = args.no_cpu_baseline and args.no_e2e                      # A/B runs of the tools: the step only
+    if rank == 0 and world == 1 and not args.no_gather_roofline and not quick and N <= 200000:
+        torch.cuda.empty_cache()
+        gather = gather_roofline(dev)      # ~9 GB of its own tables and outputs, after everything else is measured
+
     if rank == 0:
         labels = {"globo": "TCAR Globo-like fold 0", "adressa": "TCAR Adressa-like fold (active_t dwell, impression negatives)",
                   "mind": "TCAR MIND-like fold (one click time per session, neighbour negatives)",
@@ -403,7 +462,7 @@ def main():
                                       "full-catalog scoring, clip %d + Adam" %
                                       (labels[args.config], N, H, B, K, cfg["neg_mode"], mean_T, 150),
                           "name": args.config, "global_batch": B * world, "parallelism": "dp%d" % world},
-               "roofline": roof, "cpu_baseline": cpu, "end_to_end_sessions_per_s": e2e, "exchange": exchange,
+               "roofline": roof, "gather_roofline": gather, "cpu_baseline": cpu, "end_to_end_sessions_per_s": e2e, "exchange": exchange,
                "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
                "last_loss": round(last_loss, 4)}
         print(json.dumps(out))
