@@ -115,6 +115,12 @@ int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables_t* tab, co
                               const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
                               void* stream);
 
+/* tcar_gather_clip_bwd + the block partials of tcar_sqnorm_det (sum sq_g^2 into the last 4096 bytes of the segsum workspace) in
+ * ONE launch: extra workgroups beside the row gradients */
+int tcar_gather_clip_bwd_sqnorm(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
+                                const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g,
+                                const float* sq_g, int64_t sq_len, void* ws, int64_t ws_bytes, void* stream);
+
 /* tcar_scatter_add_rows: g_item[ids[r]-1, :] += rows[r, :] for r < R (ids 1-based like `seq`; id 0 = padding
  * row, skipped).  The "bucketed sparse-embedding exchange" applies the all-gathered (id, row) pairs with it. */
 int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float* rows, int64_t R, float* g_item,
@@ -490,7 +496,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 13
+#define TCAR_ABI_VERSION 14
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */

@@ -26,6 +26,9 @@ struct EmbArgs {
   float* x_icp; float* x_pt; float* x_act; float* click_t;
   const float* dx_icp; const float* dx_pt; const float* dx_act; const float* dclick;
   tcar_grads_t g;
+  // backward only: with n_gather > 0 the workgroups [n_gather, gridDim.x) compute block partials of sum sq_g^2 (the dense
+  // item norm, tcar_sqnorm_det's job) beside the row gradients instead of in a launch of their own
+  const float* sq_g; long sq_len; float* sq_part; int n_gather;
 };
 
 __device__ __forceinline__ int time_vocab(int k) {
@@ -282,8 +285,29 @@ template <int NCH, int LDT>   // LDT = ldt (64 / 128 / 256): the 16-lane-group g
 __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63;
+  const int ngb = a.n_gather > 0 ? a.n_gather : (int)gridDim.x;
+  if ((int)blockIdx.x >= ngb) {          // dense-norm role: partial j of nsq, fixed stripes (deterministic, segsum.hip folds them)
+    const int j = blockIdx.x - ngb, nsq = gridDim.x - ngb;
+    float s = 0.f;
+    for (long base = (long)j * 8192; base < a.sq_len; base += (long)nsq * 8192) {
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const long e = base + (i * 256 + tid) * 4;
+        v[i] = (e < a.sq_len) ? ld4(a.sq_g + e) : zero4();
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += dot4(v[i], v[i]);
+    }
+    s = wave_sum(s);
+    float* sh = lds;
+    if (lane == 0) sh[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) a.sq_part[j] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    return;
+  }
   const int wave_g = blockIdx.x * 4 + (tid >> 6);
-  const int nwaves = gridDim.x * 4;
+  const int nwaves = ngb * 4;
   const int B = a.bt.B, T = a.bt.T, BT = B * T;
   const int ldh = a.d.ldh;
   constexpr int ldt = LDT;
@@ -934,9 +958,10 @@ extern "C" int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* t
   return TCAR_OK;
 }
 
-extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
-                                    const float* dx_icp, const float* dx_pt, const float* dx_act,
-                                    const float* dclick, const tcar_grads_t* g, void* stream) {
+namespace {
+int gather_bwd_launch(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp, const float* dx_pt,
+                      const float* dx_act, const float* dclick, const tcar_grads_t* g, const float* sq_g, long sq_len,
+                      float* sq_part, int sq_blocks, void* stream) {
   if (check_dims(d) || !tab || !bt || !g || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   EmbArgs a{};
   a.d = *d; a.tab = *tab; a.bt = *bt; a.g = *g;
@@ -947,13 +972,15 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
   int grid = (int)((rows + 3) / 4);
   if (grid < 1) grid = 1;
   if (grid > 512) grid = 512;
+  if (sq_blocks > 0) { a.sq_g = sq_g; a.sq_len = sq_len; a.sq_part = sq_part; a.n_gather = grid; }
+  const int total = grid + (sq_blocks > 0 ? sq_blocks : 0);
   const size_t lds = ((size_t)bt->T * d->ldh + (size_t)SMALL_ROWS * d->ldt + 8) * sizeof(float);
   if (lds > 160 * 1024) return TCAR_E_ARG;
   hipStream_t st = (hipStream_t)stream;
 #define TCAR_GBWD(NCH_, LDT_)                                                                                         \
   do {                                                                                                                \
     TCAR_SET_LDS_ONCE((gather_clip_bwd_kernel<NCH_, LDT_>), 160 * 1024);                                              \
-    TCAR_LAUNCH((gather_clip_bwd_kernel<NCH_, LDT_>), dim3(grid), dim3(256), lds, st, a);                             \
+    TCAR_LAUNCH((gather_clip_bwd_kernel<NCH_, LDT_>), dim3(total), dim3(256), lds, st, a);                            \
   } while (0)
   if (d->ldh <= 256) {
     if (d->ldt == 64) TCAR_GBWD(1, 64); else if (d->ldt == 128) TCAR_GBWD(1, 128); else TCAR_GBWD(1, 256);
@@ -963,6 +990,25 @@ extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* t
 #undef TCAR_GBWD
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
+}
+}  // namespace
+
+extern "C" int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
+                                    const float* dx_icp, const float* dx_pt, const float* dx_act,
+                                    const float* dclick, const tcar_grads_t* g, void* stream) {
+  return gather_bwd_launch(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, nullptr, 0, nullptr, 0, stream);
+}
+
+// the same launch also computes tcar_sqnorm_det's block partials of sum sq_g[0:sq_len]^2 into the last 4096 bytes of the segsum
+// workspace `ws` (512 floats: one per extra workgroup): the two passes are independent and both sit between the negative rows and
+// the session rows of the sorted item-row sum
+extern "C" int tcar_gather_clip_bwd_sqnorm(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
+                                           const float* dx_icp, const float* dx_pt, const float* dx_act, const float* dclick,
+                                           const tcar_grads_t* g, const float* sq_g, int64_t sq_len, void* ws, int64_t ws_bytes,
+                                           void* stream) {
+  if (!sq_g || sq_len <= 0 || (sq_len & 3) || !tcar_aligned16(sq_g) || !ws || ws_bytes < 4096) return TCAR_E_ARG;
+  return gather_bwd_launch(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, sq_g, (long)sq_len, (float*)((char*)ws + ws_bytes - 4096),
+                           512, stream);
 }
 
 extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* inv_n,

@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 1536), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0), env_int("TCAR_Q_STREAM", 0), env_int("TCAR_EARLY_PROLOGUE", 0)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0), env_int("TCAR_Q_STREAM", 0), env_int("TCAR_EARLY_PROLOGUE", 0), env_int("TCAR_FUSE_SQNORM", 1)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -31,7 +31,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}, {"TCAR_Q_STREAM", &t.q_stream}, {"TCAR_EARLY_PROLOGUE", &t.early_prologue}};
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}, {"TCAR_Q_STREAM", &t.q_stream}, {"TCAR_EARLY_PROLOGUE", &t.early_prologue}, {"TCAR_FUSE_SQNORM", &t.fuse_sqnorm}};
   for (auto& e : tab) {
     bool same = true;
     for (int i = 0; same; ++i) {
@@ -541,9 +541,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     } else if (has_neg) {
       RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, stream));
     }
-    if (sorted)    // block partials of ||Gi||^2; the session-list pass below folds them (S5: BEFORE any session row lands)
-      RET(tcar_sqnorm_det(Gi, (int64_t)g.N * g.ldh, c->segsum_ws, c->segsum_bytes, stream));
-    else
+    if (sorted) {  // block partials of ||Gi||^2 (S5: BEFORE any session row lands): they ride in the launch of the item-row
+                   // gradients below (tcar_gather_clip_bwd_sqnorm) unless TCAR_FUSE_SQNORM=0; the session-list pass folds them
+      if (!tcar_tuning().fuse_sqnorm) RET(tcar_sqnorm_det(Gi, (int64_t)g.N * g.ldh, c->segsum_ws, c->segsum_bytes, stream));
+    } else
       RET(item_norm(c, g, stream));
   }
   // The row scatter needs the item norm (same stream) but NOT the candidate-time backward: both only add (atomically) into
@@ -561,7 +562,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       gr.rows_out = tcar_segsum_rows_buffer(&c->d, bt, c->segsum_ws);
       gr.norms_out = tcar_segsum_norms_buffer(&c->d, bt, c->segsum_ws);
       gr.skip_small = det_small ? 1 : 0;
-      RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
+      if (split_finish && tcar_tuning().fuse_sqnorm)
+        RET(tcar_gather_clip_bwd_sqnorm(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, Gi, (int64_t)g.N * g.ldh,
+                                        c->segsum_ws, c->segsum_bytes, stream));
+      else
+        RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
       RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, c->segsum_bytes, 0, gr.rows_out, nullptr, nullptr, 0, Gi,
                             c->Gx + c->arena_n + c->slot_item, c->sqn_dense + c->slot_item, nullptr, nullptr, 0.f, nullptr, stream));
     } else {

@@ -70,6 +70,7 @@ struct TcarTuning {
   int split_update;     // TCAR_SPLIT_UPDATE   1: item-table Adam before the cross-stream joins, arena after (measured slower)
   int q_stream;         // TCAR_Q_STREAM       1: the click-query MLP of the forward pass on the third stream beside the projections
   int early_prologue;   // TCAR_EARLY_PROLOGUE 1: arena memsets + negative-term forward forked before the logits GEMM (measured neutral)
+  int fuse_sqnorm;      // TCAR_FUSE_SQNORM    0: dense item-norm partials in their own launch instead of beside the item-row gradients
 };
 const TcarTuning& tcar_tuning();
 
