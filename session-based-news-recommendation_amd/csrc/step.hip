@@ -14,7 +14,7 @@ static TcarTuning& tuning_storage() {
                          env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
                          env_int("TCAR_WGRAD_KS", 1536), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
                          env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0), env_int("TCAR_Q_STREAM", 0), env_int("TCAR_EARLY_PROLOGUE", 0), env_int("TCAR_FUSE_SQNORM", 1)};
+                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0), env_int("TCAR_Q_STREAM", 0), env_int("TCAR_EARLY_PROLOGUE", 0), env_int("TCAR_FUSE_SQNORM", 1), env_int("TCAR_DCLICK_AUX", 0)};
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
@@ -31,7 +31,7 @@ extern "C" int tcar_set_tuning(const char* name, int value) {
                                               {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
                                               {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
                                               {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}, {"TCAR_Q_STREAM", &t.q_stream}, {"TCAR_EARLY_PROLOGUE", &t.early_prologue}, {"TCAR_FUSE_SQNORM", &t.fuse_sqnorm}};
+                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}, {"TCAR_Q_STREAM", &t.q_stream}, {"TCAR_EARLY_PROLOGUE", &t.early_prologue}, {"TCAR_FUSE_SQNORM", &t.fuse_sqnorm}, {"TCAR_DCLICK_AUX", &t.dclick_aux}};
   for (auto& e : tab) {
     bool same = true;
     for (int i = 0; same; ++i) {
@@ -499,6 +499,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       return TCAR_E_LAUNCH;
   } else if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
+  // Order-fixed small tables (sorted mode, which implies an aux stream): they — and the click-query input gradient, which only
+  // they consume — run on the aux stream behind the candidate-time backward, beside the rest of the main chain
+  const bool det_small = sorted && tcar_tuning().det_small != 0;
+  const bool dclick_aux = fusedq && det_small && tcar_tuning().dclick_aux != 0;
+  if (dclick_aux && s3 && hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess) return TCAR_E_LAUNCH;   // dq1 exists
   RET(weight_grads(c, g, B, BT, sW));
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
@@ -507,8 +512,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
-    tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
-    RET(small_gemm(c, 1, 1, &p, stream));
+    if (!dclick_aux) {
+      tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+      RET(small_gemm(c, 1, 1, &p, stream));
+    }
   } else {  // input gradients (only the ITEM half of dX_ic: content is frozen)
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
@@ -517,9 +524,6 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
     RET(small_gemm(c, 1, 4, p, stream));
   }
-  // Order-fixed small tables (sorted mode, which implies an aux stream): every input gradient exists now and the item rows do
-  // not depend on them — they run beside the negative rows, the dense-norm partials and the item-row gradients of the main chain
-  const bool det_small = sorted && tcar_tuning().det_small != 0;
   if (det_small) {
     tcar_tables_t tab;
     tcar_grads_t gr;
@@ -528,8 +532,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    if (hipEventRecord((hipEvent_t)c->ev[5], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[5], 0) != hipSuccess)
+    if (dclick_aux) {
+      tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+      RET(small_gemm(c, 1, 1, &p, (void*)s2));
+    } else if (hipEventRecord((hipEvent_t)c->ev[5], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[5], 0) != hipSuccess) {
       return TCAR_E_LAUNCH;
+    }
     RET(tcar_small_tables_bwd_det(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2));
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }

@@ -71,6 +71,7 @@ struct TcarTuning {
   int q_stream;         // TCAR_Q_STREAM       1: the click-query MLP of the forward pass on the third stream beside the projections
   int early_prologue;   // TCAR_EARLY_PROLOGUE 1: arena memsets + negative-term forward forked before the logits GEMM (measured neutral)
   int fuse_sqnorm;      // TCAR_FUSE_SQNORM    0: dense item-norm partials in their own launch instead of beside the item-row gradients
+  int dclick_aux;       // TCAR_DCLICK_AUX     1: the click-query input gradient GEMM on the aux stream (measured 5 us slower: the aux stream is co-critical)
 };
 const TcarTuning& tcar_tuning();
 
