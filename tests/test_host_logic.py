@@ -1,5 +1,6 @@
 """CPU tests of the host side: the C-ABI library loads and exports every declared symbol, parameter packing
 round-trips, the tensorised store equals the dict path, synthetic folds follow the data contract."""
+import ctypes as C
 import os
 import re
 
@@ -28,6 +29,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.tcar_build_id().decode() == _lib.source_build_id() == _lib.binary_build_id()
     assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
     assert lib.tcar_gemm_splitk_effective(64, 16) == 2
+
+
+def test_tuning_switch_defaults():
+    """Every TCAR_* switch of csrc/tcar_common.h is reachable by name and holds its documented default — the table in step.hip is
+    an aggregate initialiser, so a switch added out of order would silently swap two defaults."""
+    lib = _lib.load()
+    lib.tcar_set_tuning.argtypes = [C.c_char_p, C.c_int]
+    lib.tcar_set_tuning.restype = C.c_int
+    env = {k: v for k, v in os.environ.items() if k.startswith("TCAR_")}
+    want = {"TCAR_BF16_TILE": 0, "TCAR_DX512": 1, "TCAR_X3_XK": 0, "TCAR_X3_RING": 1, "TCAR_REST_GRID": 512, "TCAR_SOFTMAX_VARIANT": 1,
+            "TCAR_WGRAD_KS": 1536, "TCAR_TILE288": 0, "TCAR_GATHER_BIG_ROWS": 16384, "TCAR_GATHER_WG": 2, "TCAR_FUSED_Q": 1,
+            "TCAR_PLANES_EPI": 1, "TCAR_MHA_MFMA": 1, "TCAR_SORT_SCATTER": 1, "TCAR_BF16_KS": 2, "TCAR_DE_LATE": 0,
+            "TCAR_DET_SMALL": 1, "TCAR_SPLIT_UPDATE": 0, "TCAR_Q_STREAM": 0, "TCAR_EARLY_PROLOGUE": 0, "TCAR_FUSE_SQNORM": 1,
+            "TCAR_DCLICK_AUX": 0}
+    header = open(os.path.join(ROOT, "session-based-news-recommendation_amd", "csrc", "tcar_common.h")).read()
+    documented = set(re.findall(r"// (TCAR_[A-Z0-9_]+)\b", header[header.index("struct TcarTuning"):header.index("const TcarTuning& tcar_tuning()")]))
+    assert documented == set(want), documented ^ set(want)
+    for name, default in want.items():
+        if name in env:
+            continue                                     # the process was started with an override
+        old = lib.tcar_set_tuning(name.encode(), 12345)
+        assert old == default, (name, old, default)
+        assert lib.tcar_set_tuning(name.encode(), old) == 12345
+    assert lib.tcar_set_tuning(b"TCAR_NO_SUCH_SWITCH", 1) == -2147483648
 
 
 def test_c_abi_rejects_bad_arguments_without_touching_a_gpu():
