@@ -61,8 +61,9 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--neg_fast", default=0, type=int,
                     help="1: vectorised neighbour / impression negatives (same rules, not the reference's random.choice order)")
     # MI355X
-    ap.add_argument("--scoring", default="bf16x3", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
-                    help="precision of the full-catalog scoring GEMMs (bf16x3: split-bf16 planes, fp32-class accuracy)")
+    ap.add_argument("--scoring", default="bf16x3-mixed", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
+                    help="precision of the full-catalog scoring GEMMs (bf16x3-mixed = what bench.py measures: logits on split-bf16 planes, "
+                         "fp32-class; the two gradient GEMMs on plain bf16 operands.  bf16x3: all three fp32-class)")
     ap.add_argument("--gpus", default=1, type=int, help="data-parallel ranks (launch with torch.distributed.run)")
     ap.add_argument("--dp_mode", default="replica", choices=["replica", "sharded"],
                     help="multi-GPU exchange: replica = all-reduce of the dense item gradient (dp.py); sharded = catalog-sharded "

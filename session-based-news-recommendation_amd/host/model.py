@@ -160,7 +160,7 @@ class Seq2SeqAttNN():
                 from ..sharded import ShardedEngine
                 engine_cls = ShardedEngine
         self.engine = engine_cls(params, content, self.publish_time_MWDHM, lr=args['lr'], max_grad=args.get('max_grad'),
-                                 device=args.get('device', 'cuda:0'), scoring=args.get('scoring', 'bf16x3'), **kw)
+                                 device=args.get('device', 'cuda:0'), scoring=args.get('scoring', 'bf16x3-mixed'), **kw)
         self._cat = None
         self._store_cache = {}
         # data parallel (main.py --gpus N): every rank builds the SAME batches (same seeds) and keeps its contiguous shard

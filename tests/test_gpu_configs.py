@@ -39,7 +39,7 @@ CONFIGS = {
 }
 
 
-@pytest.mark.parametrize("scoring", ["f32", "bf16x3"])
+@pytest.mark.parametrize("scoring", ["f32", "bf16x3", "bf16x3-mixed"])
 @pytest.mark.parametrize("name", sorted(CONFIGS))
 def test_step_parity_with_reference_negative_modes(name, scoring):
     _need_gpu()
@@ -93,8 +93,10 @@ def test_step_parity_with_reference_negative_modes(name, scoring):
             # after Adam steps a few ill-conditioned coordinates have moved by +-lr per step on either side (see below):
             # the scores agree norm-wise and the batch loss at the gate
             d = logits.cpu().numpy().astype(np.float64) - lo.numpy()
-            assert np.sqrt((d * d).mean()) <= 2e-3 * np.sqrt((lo.numpy() ** 2).mean()), "logits after training"
-            assert abs(float(ce.mean()) - float(ce_o.mean())) <= 1e-3 * float(ce_o.mean())
+            # (mixed: four Adam steps on gradients with 1e-2 bf16 noise move more coordinates the other way)
+            loose = scoring == "bf16x3-mixed"
+            assert np.sqrt((d * d).mean()) <= (1e-2 if loose else 2e-3) * np.sqrt((lo.numpy() ** 2).mean()), "logits after training"
+            assert abs(float(ce.mean()) - float(ce_o.mean())) <= (3e-3 if loose else 1e-3) * float(ce_o.mean())
         lab = torch.as_tensor(tb["label"], dtype=torch.long)
         want_rank = ((lo > lo.gather(1, lab[:, None])).sum(1) + 1).numpy()
         r = rank.cpu().numpy()
@@ -120,14 +122,20 @@ def test_step_parity_with_reference_negative_modes(name, scoring):
     # so the dwell projection shifts all attention scores of a session alike): the absolute floor is 1e-7 of the largest
     # gradient entry of the step, far below anything the update can see.
     gmax = max(float(np.abs(v.numpy()).max()) for v in g_o.values())
+    mixed = scoring == "bf16x3-mixed"      # gradient GEMMs on plain bf16 operands: every gradient 1e-2 norm-wise, norms 2e-2
     for k in g_o:
         want = g_o[k].numpy()
+        if mixed:
+            err = float(np.linalg.norm(np.asarray(g_e[k], dtype=np.float64) - want))
+            assert err <= 1e-2 * np.linalg.norm(want) + 1e-7 * gmax * np.sqrt(want.size), ("grad " + k, err, float(np.linalg.norm(want)))
+            assert abs(sq_e[k] - sq_o[k]) <= 2e-2 * sq_o[k] + 1e-12 * gmax * gmax * want.size, ("sqnorm", k, sq_e[k], sq_o[k])
+            continue
         scale = max(5e-5, 1e-7 * gmax / max(1e-30, float(np.abs(want).max())))
         close(g_e[k], want, name="grad " + k, atol_scale=scale)
         assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12 * gmax * gmax * want.size, ("sqnorm", k, sq_e[k], sq_o[k])
     # training steps over all four batches
     for b in batches:
-        close(eng.train_step(b).cpu().numpy(), ora.train_step(b).numpy(), name="train loss")
+        close(eng.train_step(b).cpu().numpy(), ora.train_step(b).numpy(), name="train loss", rtol=3e-3 if mixed else RTOL)
     # Variables after the four Adam steps.  Adam normalises by sqrt(v): a coordinate whose gradient sits at rounding level
     # moves by ~lr per step with a rounding-determined sign, so a handful of coordinates may differ by up to 2 * lr * steps
     # while everything else holds the relative gate.
@@ -137,7 +145,7 @@ def test_step_parity_with_reference_negative_modes(name, scoring):
         ge, go = np.asarray(p_e[k], dtype=np.float64), np.asarray(p_o[k], dtype=np.float64)
         err = np.abs(ge - go)
         bad = err > 1e-4 * max(1e-30, np.abs(go).max()) + RTOL * np.abs(go)
-        if k == "item_emb" or k.startswith("attout_"):      # well-conditioned gradients (the scoring side)
+        if not mixed and (k == "item_emb" or k.startswith("attout_")):      # well-conditioned gradients (the scoring side)
             assert bad.sum() <= max(8, 2e-3 * bad.size), ("param", k, int(bad.sum()), bad.size)
         assert err.max() <= 2.2 * lr * steps, ("param", k, float(err.max()))
     check_eval(tight=False)

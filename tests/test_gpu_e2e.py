@@ -33,7 +33,7 @@ def test_train_eval_matches_oracle_run():
     np.random.seed(3)
     init = initial_variables(400, 32, 16, 0.3, 0.1)
     args = fold.model_args(batch_size=64, epoch=2, neg_num=8, hidden_size=32, time_hidden_size=16, lr=0.003,
-                           initial_variables=init, emb_stddev=0.3, stddev=0.1)
+                           initial_variables=init, emb_stddev=0.3, stddev=0.1, scoring="bf16x3")
     neighbor = {0: [0]}
     # ---- product path
     random.seed(5)
@@ -100,28 +100,72 @@ def test_cli_synthetic_runs():
     assert 0.0 <= model.last_metrics["recall"] <= 1.0 and np.isfinite(model.last_metrics["loss"])
 
 
-def test_bf16_gradient_gemms_keep_hr_and_mrr():
-    """north star: HR@20 within +-0.002 of the reference, logits / HR@20 / MRR@20 within 1e-3 relative.  The same run
-    (same fold, seeds, batches) in the four scoring modes: f32 is the reference precision; bf16x3 (all three GEMMs on
-    split-bf16 planes) and bf16x3-mixed (bench.py's default: gradient GEMMs in plain bf16) must land on its metrics.
-    20,000 test sessions: one session is 5e-5 of HR@20.  Atomic-order noise alone moves HR@20 by ~2e-4 between two runs."""
+def _oracle_run(fold, init, tr, te, epochs, lr, K, B):
+    """TcarOracle driven by OracleSampler over `epochs` epochs + evaluation: the reference's train / test loops
+    (model_combine.py:196-315) on the CPU, same seeds as the product run"""
+    from oracle.metrics_oracle import cau_metrics
+    from oracle.sampler_oracle import OracleSampler, batch_to_arrays
+    from oracle.tcar_oracle import TcarOracle
+    random.seed(5)
+    np.random.seed(5)
+    ora = TcarOracle(init, fold.content, fold.mwdhm, lr=lr)
+    trd, ted = (copy.deepcopy(tr[0]), tr[1], tr[2]), (copy.deepcopy(te[0]), te[1], te[2])
+    want = None
+    for _ in range(epochs):
+        s = OracleSampler(trd[0], trd[1], trd[2], {0: [0]}, fold.item_dict, K, batch_size=B)
+        while s.has_next():
+            ora.train_step(batch_to_arrays(s.next_batch()))
+        s = OracleSampler(ted[0], ted[1], ted[2], batch_size=B)
+        hits, mrrs, ndcgs, losses = [], [], [], []
+        while s.has_next():
+            b = batch_to_arrays(s.next_batch())
+            logits, ce = ora.eval_batch(b)
+            h, m, n = cau_metrics(logits.numpy(), b["label"], 20)
+            hits += h
+            mrrs += m
+            ndcgs += n
+            losses += ce.numpy().tolist()
+        want = {"recall": float(np.mean(hits)), "mrr": float(np.mean(mrrs)), "ndcg": float(np.mean(ndcgs)),
+                "loss": float(np.mean(losses))}
+    return want
+
+
+_ORACLE_RUN = {}
+
+
+@pytest.mark.parametrize("scoring", ["bf16x3", "bf16x3-mixed"])
+def test_split_bf16_training_run_matches_oracle_run(scoring):
+    """north star: HR@20 within +-0.002 of the reference run, MRR@20 within 1e-3 relative.  The ORACLE (fp64, CPU) trains two
+    epochs on a fold the host can afford (5,000 items, model dimensions of the benched configuration: H = 250, Ht = 64,
+    B = 512, K = 20; 20,000 training and 8,000 test sessions) and the product path trains the same fold from the same
+    variables, shuffles and negatives in bf16x3 and in bf16x3-mixed (the default of main.py and bench.py: gradient GEMMs on
+    plain bf16 operands)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from tcar_amd.host.cli import main
-    res = {}
-    for mode in ("f32", "bf16x3", "bf16x3-mixed"):
-        buf = io.StringIO()
-        with redirect_stdout(buf):
-            m = main(["--synthetic", "8000", "--synthetic_train", "60000", "--synthetic_test", "20000", "--epoch", "3",
-                      "--batch_size", "512", "--gap_mode", "click_delta", "--scoring", mode])
-        res[mode] = dict(m.last_metrics)
-    ref = res["f32"]
-    assert ref["recall"] > 0.1                                    # the run learns something: the comparison is not vacuous
-    for mode in ("bf16x3", "bf16x3-mixed"):
-        r = res[mode]
-        assert abs(r["recall"] - ref["recall"]) <= 0.002, (mode, r["recall"], ref["recall"])
-        assert abs(r["mrr"] - ref["mrr"]) <= 0.002, (mode, r["mrr"], ref["mrr"])
-        assert abs(r["loss"] - ref["loss"]) <= 1e-3 * abs(ref["loss"]), (mode, r["loss"], ref["loss"])
+    from tcar_amd.host.model import Seq2SeqAttNN, initial_variables
+    from tcar_amd.host.synth import SynthFold
+    N, H, Ht, B, K, lr, epochs = 5000, 250, 64, 512, 20, 0.003, 2
+    fold = SynthFold(n_items=N, dim=H, n_train=20000, n_test=8000, seed=17, active_t=True)
+    tr = fold.to_dicts(fold.train, with_active=True)
+    te = fold.to_dicts(fold.test, with_active=True)
+    np.random.seed(3)
+    init = initial_variables(N, H, Ht, 0.002, 0.05)
+    if "want" not in _ORACLE_RUN:
+        _ORACLE_RUN["want"] = _oracle_run(fold, init, tr, te, epochs, lr, K, B)
+    want = _ORACLE_RUN["want"]
+    assert want["recall"] > 0.2                                   # the run learns: the comparison is not vacuous
+    args = fold.model_args(batch_size=B, epoch=epochs, neg_num=K, hidden_size=H, time_hidden_size=Ht, lr=lr,
+                           initial_variables=init, scoring=scoring)
+    random.seed(5)
+    np.random.seed(5)
+    model = Seq2SeqAttNN(args)
+    with redirect_stdout(io.StringIO()):
+        model.train(None, fold.item_dict, (copy.deepcopy(tr[0]), tr[1], tr[2]), {0: [0]}, args,
+                    (copy.deepcopy(te[0]), te[1], te[2]), None)
+    got = model.last_metrics
+    assert abs(got["recall"] - want["recall"]) <= 0.002, (scoring, got, want)
+    assert abs(got["mrr"] - want["mrr"]) <= 1e-3 * want["mrr"] + 2.0 / 8000, (scoring, got, want)
+    assert abs(got["loss"] - want["loss"]) <= 1e-3 * want["loss"], (scoring, got, want)
 
 
 def test_two_training_runs_are_bit_identical():

@@ -209,10 +209,38 @@ CASES = [  # N, H, Ht, B, T, K
 ]
 
 
-@pytest.mark.parametrize("scoring", ["f32", "bf16x3"])
+def rel_norm(got, want):
+    """norm-wise relative error ||got - want|| / ||want||"""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300))
+
+
+# bf16x3-mixed (the precision bench.py and main.py default to): logits / loss at the 1e-3 gate, the two scoring-gradient
+# GEMMs on plain bf16 operands -> EVERY gradient within 1e-2 norm-wise, every clip norm within 2e-2
+MIXED_GRAD_RTOL = 1e-2
+MIXED_SQNORM_RTOL = 2e-2
+
+
+def check_grads(g_e, sq_e, g_o, sq_o, scoring, atol_scale=5e-5):
+    """all 23 gradients and their S5 clip norms against the oracle, at the gate of the scoring precision"""
+    gmax = max(float(np.abs(np.asarray(v)).max()) for v in g_o.values())
+    for k in g_o:
+        want = np.asarray(g_o[k], dtype=np.float64)
+        if scoring == "bf16x3-mixed":
+            # gradients that are rounding noise on both sides (zero in exact arithmetic) are compared on the step's scale
+            err = np.linalg.norm(np.asarray(g_e[k], dtype=np.float64) - want)
+            assert err <= MIXED_GRAD_RTOL * np.linalg.norm(want) + 1e-7 * gmax * np.sqrt(want.size), ("grad " + k, err, np.linalg.norm(want))
+            assert abs(sq_e[k] - sq_o[k]) <= MIXED_SQNORM_RTOL * sq_o[k] + 1e-12, ("sqnorm", k, sq_e[k], sq_o[k])
+        else:
+            close(g_e[k], want, name="grad " + k, atol_scale=atol_scale)
+            assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12, ("sqnorm", k, sq_e[k], sq_o[k])
+
+
+@pytest.mark.parametrize("scoring", ["f32", "bf16x3", "bf16x3-mixed"])
 @pytest.mark.parametrize("N,H,Ht,B,T,K", CASES)
 def test_step_matches_oracle(N, H, Ht, B, T, K, scoring):
-    """Both scoring precisions hold the SAME 1e-3 gate: bf16x3 carries fp32 operands as hi/lo bf16 planes."""
+    """All scoring precisions hold the SAME 1e-3 gate on logits and loss: bf16x3 carries fp32 operands as hi/lo bf16 planes;
+    bf16x3-mixed relaxes the gradients only (check_grads)."""
     _need_gpu()
     from oracle.tcar_oracle import TcarOracle
     from tcar_amd.engine import TcarEngine
@@ -232,23 +260,23 @@ def test_step_matches_oracle(N, H, Ht, B, T, K, scoring):
     o, g_o, sq_o = ora.loss_and_grads(batch)
     close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss")
     g_e, sq_e = eng.export_grads(), eng.export_sqnorms()
-    for k in g_o:
-        close(g_e[k], g_o[k].numpy(), name="grad " + k, atol_scale=5e-5)
-        assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12, ("sqnorm", k, sq_e[k], sq_o[k])
+    check_grads(g_e, sq_e, {k: v.numpy() for k, v in g_o.items()}, sq_o, scoring)
     # three optimizer steps
     for _ in range(3):
         le = eng.train_step(batch)
         lo = ora.train_step(batch)
-        close(le.cpu().numpy(), lo.numpy(), name="train loss")
+        close(le.cpu().numpy(), lo.numpy(), name="train loss", rtol=3e-3 if scoring == "bf16x3-mixed" else RTOL)
     # after Adam steps a coordinate whose gradient is at rounding level moves by ~lr with a rounding-determined sign
     # (Adam normalises by sqrt(v)); the split-bf16 mode has ~1e-5 relative gradient noise instead of ~1e-7
     p_e, p_o = eng.export_params(), ora.export()
     for k in p_o:
         if scoring == "f32":
             close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-4)
-        else:   # gradients were compared at 1e-3 above; here allow a quarter of the distance Adam can travel (lr * steps)
+        else:   # gradients were compared at 1e-3 above; here allow a quarter of the distance Adam can travel (lr * steps);
+            # mixed: a coordinate whose gradient is below the bf16 noise can move the full distance the other way
             d = np.abs(p_e[k] - p_o[k]).max()
-            assert d <= 1e-3 * np.abs(p_o[k]).max() + 0.25 * 1e-3 * 3, ("param " + k, d)
+            travel = 2.0 if scoring == "bf16x3-mixed" else 0.25
+            assert d <= 1e-3 * np.abs(p_o[k]).max() + travel * 1e-3 * 3, ("param " + k, d)
 
 
 def test_golden_fixture():
@@ -316,6 +344,47 @@ def test_full_size_properties(scoring):
     # (5) padding columns of the parameter arena stay exactly zero
     E = eng.E
     assert float(E[:, H:eng.geo.ldh].abs().max()) == 0.0 and float(E[N:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("scoring", ["bf16x3", "bf16x3-mixed"])
+@pytest.mark.parametrize("T", [2, 5])
+def test_globo_full_size_step_matches_oracle(scoring, T):
+    """The BENCHED configuration (BASELINE.json configs[1]: N = 46,033, H = 250, Ht = 64, B = 512, K = 20) against the fp64
+    oracle (model_combine.py:52-163) in the benched precision and in bf16x3: full-catalog logits and per-session loss at 1e-3
+    (north star), all 23 gradients and their S5 clip norms (bf16x3: 1e-3 element-wise; mixed: 1e-2 norm-wise on EVERY
+    variable), then two training steps through the fused deferred-update driver that bench.py times."""
+    _need_gpu()
+    from oracle.tcar_oracle import TcarOracle
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, K = 46033, 250, 64, 512, 20
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=1000 + T, emb_std=0.05, w_std=0.05)
+    eng = TcarEngine(params, content, mw, scoring=scoring)
+    ora = TcarOracle(params, content, mw)
+    rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
+    o_logits, o_ce = ora.eval_batch(batch)
+    close(logits.cpu().numpy(), o_logits.numpy(), name="logits")
+    close(ce.cpu().numpy(), o_ce.numpy(), name="ce")
+    # HR@20 / MRR@20 of the batch from the device ranks against the oracle's scores (ties within rounding may move a rank)
+    lab = torch.as_tensor(batch["label"], dtype=torch.long)
+    want_rank = ((o_logits > o_logits.gather(1, lab[:, None])).sum(1) + 1).numpy()
+    r = rank.cpu().numpy()
+    assert (r != want_rank).sum() <= 5, int((r != want_rank).sum())
+    assert abs(float((r <= 20).mean()) - float((want_rank <= 20).mean())) <= 0.002
+    loss = eng.loss_and_grads(batch)
+    o, g_o, sq_o = ora.loss_and_grads(batch)
+    close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss")
+    check_grads(eng.export_grads(), eng.export_sqnorms(), {k: v.numpy() for k, v in g_o.items()}, sq_o, scoring)
+    # the fused step of the training loops (deferred update, three streams): per-session losses of two consecutive steps
+    for _ in range(2):
+        le = eng.train_step(batch, defer_update=True)
+        lo = ora.train_step(batch)
+        close(le.cpu().numpy(), lo.numpy(), name="train loss", rtol=3e-3 if scoring == "bf16x3-mixed" else RTOL)
+    p_e, p_o = eng.export_params(), ora.export()
+    for k in p_o:      # two Adam steps move a coordinate by at most ~2 lr; well-conditioned ones agree far closer
+        d = np.abs(p_e[k] - p_o[k]).max()
+        mixed = scoring == "bf16x3-mixed"
+        assert d <= 1e-3 * np.abs(p_o[k]).max() + (2.0 if mixed else 0.5) * 1e-3 * 2, ("param " + k, d)
+        assert rel_norm(p_e[k], p_o[k]) <= (3e-2 if mixed else 2e-3), ("param " + k, rel_norm(p_e[k], p_o[k]))
 
 
 def test_dp_engine_single_rank_path_matches_oracle():
@@ -487,12 +556,9 @@ def test_mixed_precision_backward_mode():
     o_logits, o_ce = ora.eval_batch(batch)
     close(logits.cpu().numpy(), o_logits.numpy(), name="logits mixed")
     loss = eng.loss_and_grads(batch)
-    o, g_o, _ = ora.loss_and_grads(batch)
+    o, g_o, sq_o = ora.loss_and_grads(batch)
     close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss mixed")
-    g_e = eng.export_grads()
-    for k in ("item_emb", "attout_item_cont_trans/w1", "hour_embedding"):
-        rel = np.linalg.norm(g_e[k] - g_o[k].numpy()) / max(np.linalg.norm(g_o[k].numpy()), 1e-30)
-        assert rel < 1e-2, (k, rel)
+    check_grads(eng.export_grads(), eng.export_sqnorms(), {k: v.numpy() for k, v in g_o.items()}, sq_o, "bf16x3-mixed")
     l0 = float(eng.train_step(batch).sum())
     for _ in range(5):
         l1 = float(eng.train_step(batch).sum())
