@@ -106,6 +106,10 @@ def load_datas(args):
         base = args.datapath + args.dataset + args.split_way
         train_data, test_data, item_dict, neighbor, content_emb, publish_time, _ = load_fold(
             base, args.foldnum, args.neighbor_path)
+        if args.neg_mode == "neighbor" and not neighbor:
+            # no neighbor_<fold>.txt next to the fold and no --neighbor_path: build it as generate_neighbor.py does
+            from .data import build_neighbor
+            neighbor = build_neighbor(publish_time[0])
         freq = base + 'item_freq_dict_norm_' + str(args.foldnum) + '.txt'
         a['item_freq_dict_norm'] = pickle.load(open(freq, 'rb')) if os.path.exists(freq) else None
         a['reverse_item'] = {cnt - 1: idx for idx, cnt in item_dict.items()}

@@ -129,6 +129,27 @@ class SessionStore:
         }
 
 
+def build_neighbor(publish_time, window: int = 100) -> Dict[int, np.ndarray]:
+    """`get_neighbor` (generate_neighbor.py:7-21): the negative source of `Sampler.neg_neighbor` (sampler.py:133-140).
+    Items are ordered by publish time (`np.argsort` of the array as given, numpy's default sort — ties fall where the
+    reference's call puts them); the item at position p of that order gets positions [p - window, p + window): `window`
+    earlier items, ITSELF, and `window - 1` later ones, as a numpy slice of the order (clipped at both ends).  Lists shorter
+    than `window` (only when the catalog has fewer than `window` items) are padded with `random.sample(range(N - 1), ...)`
+    from the global `random` state, in dictionary order (generate_neighbor.py:18-20).  Keys and values are 0-based item
+    positions, as `neg_neighbor(label0)` expects (sampler.py:97)."""
+    import random
+    order = np.argsort(np.array(publish_time))
+    n = len(publish_time)
+    lo = np.maximum(np.arange(n) - window, 0)
+    hi = np.minimum(np.arange(n) + window, n)
+    out = {item: order[a:b] for item, a, b in zip(order, lo.tolist(), hi.tolist())}
+    for item, lst in out.items():
+        short = window - len(lst)
+        if short > 0:
+            out[item] = np.append(lst, np.array(random.sample(range(0, n - 1), short)))
+    return out
+
+
 def load_fold(fname: str, foldnum, neighbor_path: Optional[str] = None):
     """Counterpart of ``data_partition`` (util.py:20-56) without the hard-coded author path (util.py:47):
     the negative-source pickle is `neighbor_path` if given, else ``<fname>neighbor_<fold>.txt`` when it

@@ -119,18 +119,11 @@ class SynthFold:
         return store
 
     # ------------------------------------------------------------------------------- negative-source builders
-    def neighbor_dict(self, k=100) -> Dict[int, list]:
-        """`get_neighbor` (generate_neighbor.py:7-21): for each 0-based item the +-k items adjacent in
-        publish-time order."""
-        order = np.argsort(self.publish_ts, kind="stable")
-        rank = np.empty_like(order)
-        rank[order] = np.arange(len(order))
-        out = {}
-        for it in range(self.n_items):
-            r = int(rank[it])
-            lo, hi = max(0, r - k), min(self.n_items, r + k + 1)
-            out[it] = [int(x) for x in order[lo:hi] if x != it]
-        return out
+    def neighbor_dict(self, k=100) -> Dict[int, np.ndarray]:
+        """`get_neighbor` (generate_neighbor.py:7-21) over the fold's publish times: host/data.py:build_neighbor — `k` earlier
+        items, the item itself and `k - 1` later ones in publish-time order."""
+        from .data import build_neighbor
+        return build_neighbor(self.publish_ts, window=k)
 
     def impression_dict(self, store: SessionStore, lo=20, hi=60, unknown=0.1, seed=7) -> Dict[int, list]:
         """MIND-style impression lists (mind_preprocess.py:62-69,85): per raw session id 20-60 ORIGINAL article ids, about

@@ -7,6 +7,8 @@ feeds them a tiny synthetic dataset and writes inputs + outputs as JSON next to 
   reference_sampler.json   Sampler batches (train mode with uniform negatives, test mode), direct calls of
                            neg_neighbor / neg_neighbor_from_impre, bucketized(0..2000)
   reference_metrics.json   cau_metrics on random rows and tie cases
+  reference_neighbor.json  data_process/generate_neighbor.get_neighbor on three publish-time vectors (300 ints with ties,
+                           130 datetimes with duplicates, 60 ints: the pad-to-100 branch)
 No reference source is copied; the JSON holds data only.   Usage:  python tests/golden/make_reference_fixtures.py
 """
 import copy
@@ -142,7 +144,33 @@ def main():
                      "ndcg": [float(x) for x in ndcg]})
     with open(os.path.join(HERE, "reference_metrics.json"), "w") as fh:
         json.dump(_jsonable(mout), fh)
-    print("wrote reference_sampler.json, reference_metrics.json")
+    neighbor_fixture()
+    print("wrote reference_sampler.json, reference_metrics.json, reference_neighbor.json")
+
+
+def neighbor_fixture():
+    """(7) generate_neighbor.get_neighbor (generate_neighbor.py:7-21): the +-100 publish-time window incl. the item itself,
+    and the pad branch (reachable for 51 <= N < 100: random.sample from the global `random` state)."""
+    sys.path.insert(0, os.path.join(REF, "data_process"))
+    import generate_neighbor as ref_nb   # noqa
+    sys.path.remove(os.path.join(REF, "data_process"))
+    r = np.random.RandomState(42)
+    cases = []
+    pt = r.randint(0, 4000, size=300)                                   # ints, many ties
+    cases.append({"name": "ints300", "kind": "int", "publish_time": pt.tolist(), "seed": 1})
+    base = datetime.datetime(2017, 1, 1)
+    dts = [base + datetime.timedelta(minutes=int(m)) for m in r.randint(0, 600, size=130)]
+    cases.append({"name": "datetimes130", "kind": "datetime", "publish_time": [d.isoformat() for d in dts], "seed": 2})
+    pt60 = r.randint(0, 10 ** 6, size=60)
+    cases.append({"name": "ints60_pad", "kind": "int", "publish_time": pt60.tolist(), "seed": 77})
+    out = []
+    for c in cases:
+        arg = [datetime.datetime.fromisoformat(x) for x in c["publish_time"]] if c["kind"] == "datetime" else list(c["publish_time"])
+        random.seed(c["seed"])
+        d = ref_nb.get_neighbor(arg)
+        out.append(dict(c, keys=[int(k) for k in d.keys()], lists=[[int(x) for x in v] for v in d.values()]))
+    with open(os.path.join(HERE, "reference_neighbor.json"), "w") as fh:
+        json.dump(out, fh)
 
 
 if __name__ == "__main__":

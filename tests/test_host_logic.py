@@ -122,8 +122,8 @@ def test_synth_fold_contract():
     assert b["seq"].shape == (5, 2) and b["gap"].max() <= 11 and b["cw"].max() <= 6 and b["ch"].max() <= 23
     with pytest.raises(ValueError):
         st.batch_arrays(np.array([np.where(st.in_len == 1)[0][0], np.where(st.in_len == 2)[0][0]]))
-    nb = fold.neighbor_dict(k=3)
-    assert all(i not in v and 3 <= len(v) <= 6 for i, v in nb.items())
+    nb = fold.neighbor_dict(k=3)      # generate_neighbor.py:13-16 with a window of 3: 3 earlier + the item itself + 2 later
+    assert all(i in v and 3 <= len(v) <= 6 for i, v in nb.items())
 
 
 def test_load_fold_reads_the_reference_pickle_layout(tmp_path):
@@ -140,7 +140,9 @@ def test_load_fold_reads_the_reference_pickle_layout(tmp_path):
     item_dict = write_reference_fold(base, fold, foldnum=2)
     train, test, items, neighbor, content, publish_time, _ = load_fold(base, 2)
     assert items == item_dict and len(publish_time) == 2 and np.array_equal(publish_time[1], fold.mwdhm)
-    assert np.array_equal(content, fold.content) and neighbor == fold.neighbor_dict()
+    ref_nb = fold.neighbor_dict()
+    assert np.array_equal(content, fold.content) and set(neighbor) == set(ref_nb)
+    assert all(np.array_equal(neighbor[k], ref_nb[k]) for k in ref_nb)
     want = fold.to_dicts(fold.train, with_active=True)
     assert train[0] == want[0] and train[1] == want[1] and train[2] == want[2]
     assert set(test[0]) == set(fold.to_dicts(fold.test, with_active=True)[0])
@@ -218,3 +220,36 @@ def test_torch_ops_are_registered_without_a_gpu():
         assert "Tensor" in str(op.default._schema)
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.tcar.rank_topk(torch.zeros(2, 8), torch.zeros(2, dtype=torch.int32), 8, 3)     # CPU tensors: no fallback
+
+
+def test_build_neighbor_equals_the_reference_get_neighbor():
+    """host/data.py:build_neighbor against outputs of the REAL generate_neighbor.get_neighbor (generate_neighbor.py:7-21;
+    fixture written by tests/golden/make_reference_fixtures.py): key order, every list element for element — window of 100
+    earlier items + the item itself + 99 later ones, ties as numpy's default argsort leaves them, object-array (datetime)
+    input, and the pad branch with the reference's draws from `random`."""
+    import datetime
+    import json
+    import os
+    import random
+    from helpers import GOLD
+    from tcar_amd.host.data import build_neighbor
+    with open(os.path.join(GOLD, "reference_neighbor.json")) as fh:
+        cases = json.load(fh)
+    assert {c["name"] for c in cases} == {"ints300", "datetimes130", "ints60_pad"}
+    for c in cases:
+        pt = [datetime.datetime.fromisoformat(x) for x in c["publish_time"]] if c["kind"] == "datetime" else c["publish_time"]
+        random.seed(c["seed"])
+        got = build_neighbor(pt)
+        assert [int(k) for k in got.keys()] == c["keys"], c["name"]
+        for k, want in zip(c["keys"], c["lists"]):
+            assert [int(x) for x in got[k]] == want, (c["name"], k)
+        n = len(pt)
+        if n >= 200:       # interior items: 100 earlier + self + 99 later
+            mid = c["keys"][n // 2]
+            assert len(got[mid]) == 200 and int(got[mid][100]) == mid
+    # the synthetic folds and `--neg_mode neighbor` without a neighbour file go through the same function
+    from tcar_amd.host.synth import SynthFold
+    fold = SynthFold(n_items=300, dim=8, n_train=50, n_test=10, seed=3)
+    nb = fold.neighbor_dict()
+    ref = build_neighbor(fold.publish_ts)
+    assert all((nb[k] == ref[k]).all() for k in ref) and all(int(k) in set(int(x) for x in v) for k, v in nb.items())
