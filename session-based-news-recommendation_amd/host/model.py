@@ -288,18 +288,21 @@ class Seq2SeqAttNN():
             print('\tloss: {:.6f}'.format(avgc))
             if test_data is not None:
                 recall = self.test(sess, test_data, args)
-                if recall > threshold_acc and self.dp_rank == 0:       # replicas are identical: one writer
+                if recall > threshold_acc:       # every rank takes part (the sharded export is a collective), rank 0 writes
                     modelname = self.save(args)
-                    print('Model saved - {}'.format(modelname))
+                    if self.dp_rank == 0:
+                        print('Model saved - {}'.format(modelname))
 
     def save(self, args):
         suf = time.strftime("%Y%m%d%H%M", time.localtime()) + '-' + str(args.get('dataset', '')).replace('/', '_') \
             + '-' + str(args.get('split_way', '')).replace('/', '_') + '-' + str(args.get('foldnum', 0))
         path = os.path.join(args.get('modelpath', './ckpt/'), "model.ckpt-" + suf + ".npz")
-        os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
         # plain arrays only (variables, Adam moments, beta powers, step): loadable without unpickling anything.  NOT
         # interchangeable with the reference's tf.train.Saver checkpoints (README.md).
-        np.savez(path, **self.engine.export_state())
+        state = self.engine.export_state()          # catalog-sharded engine: all-gathers the owners' Adam moments
+        if self.dp_rank == 0:                       # replicas are identical: one writer
+            os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+            np.savez(path, **state)
         return path
 
     # --------------------------------------------------------------------------------------------- test

@@ -223,7 +223,7 @@ class ShardedEngine(TcarEngine):
             check(lib.tcar_step_session_backward(C.byref(ctx), C.byref(bt), p(dx_rows), p(rows), ldr, nr, p(ce_rows), st),
                   "tcar_step_session_backward")
         else:
-            rows.view(torch.int32)[:, g.ldh] = 0    # an empty rank contributes padding rows only (id 0)
+            rows.zero_()                            # an empty rank contributes padding rows only (id 0, zero payload)
         all_rows = self._allgather(rows, "rows+ids").view(-1, ldr)
         check(lib.tcar_shard_join(C.byref(ctx), st), "tcar_shard_join")
         # ids are 1-based: the rows of this shard become 1 .. nl, the rest (and the id-0 padding) fall out
@@ -283,6 +283,8 @@ class ShardedEngine(TcarEngine):
         schedule).  cap = rows every rank contributes to the all-gathers (>= the largest local batch of the step; default: the
         local batch size — weak-scaling runs with equal batches); cap_rows (dp.DPEngine's argument: cap * T) is accepted
         for drop-in use.  No metadata collective, no host synchronisation."""
+        # defer_update (TcarEngine's split update) is accepted for drop-in use and ignored: the sharded update is followed by
+        # the all-gather of the updated rows, which the next step's gathers need — there is nothing to defer it behind
         if bt is None and batch is not None:
             bt = self.upload(batch)
         if bt is not None:
@@ -340,17 +342,55 @@ class ShardedEngine(TcarEngine):
         return out + (self.ev_logits[:B, :g.N].clone(),) if keep_logits else out
 
     # ------------------------------------------------------------------------------ inspection (tests, export)
+    def _gather_shard_rows(self, local: torch.Tensor) -> np.ndarray:
+        """this rank's [nl, ldh] rows of a candidate-side table -> the whole [N + 1, H] table in the reference's shape (row 0
+        = the pad row, zero).  A COLLECTIVE: every rank calls it."""
+        g = self.geo
+        full = torch.zeros(self.world, self.S, g.ldh, dtype=torch.float32, device=self.dev)
+        full[self.dp_rank, :self.nl] = local
+        if self.world > 1 and not self._sim:
+            dist.all_gather_into_tensor(full.view(-1), full[self.dp_rank].reshape(-1).clone(), group=self.group)
+        item = np.zeros((g.N + 1, g.H), dtype=np.float32)
+        item[1:] = full.view(-1, g.ldh)[:g.N, :g.H].cpu().numpy()
+        return item
+
+    def export_state(self):
+        """TcarEngine.export_state for a sharded catalog: the Adam moments of the item table live on their owners, so this is
+        a COLLECTIVE — every rank calls it (and gets the full state); host/model.py lets rank 0 write the file."""
+        from .engine import VAR_ORDER
+        self.flush()
+        out = {"var/" + k: v for k, v in self.export_params().items()}         # E is whole on every rank
+        for tag, arena, item in (("m/", self.M, self.Mi), ("v/", self.V, self.Vi)):
+            d = self._unpack_arena(arena.cpu().numpy())
+            d["item_emb"] = self._gather_shard_rows(item)
+            out.update({tag + k: d[k] for k in VAR_ORDER})
+        out["meta/step"] = np.asarray(self.step, dtype=np.int64)
+        out["meta/beta_pow"] = np.asarray([self.b1_pow, self.b2_pow], dtype=np.float32)
+        return out
+
+    def load_state(self, st) -> None:
+        """inverse of export_state: every rank reads the same file and keeps the moment rows [n0, n0 + nl) of its shard"""
+        from .engine import VAR_ORDER
+        self.load_params({k[4:]: np.asarray(st[k]) for k in st if k.startswith("var/")})
+        g = self.geo
+        if all(("m/" + k) in st and ("v/" + k) in st for k in VAR_ORDER):
+            for tag, arena, item in (("m/", self.M, self.Mi), ("v/", self.V, self.Vi)):
+                vals = {k: np.asarray(st[tag + k]) for k in VAR_ORDER}
+                arena.copy_(torch.from_numpy(self._pack_arena(vals)))
+                it = np.zeros((self.nl, g.ldh), dtype=np.float32)
+                it[:, :g.H] = vals["item_emb"][1 + self.n0:1 + self.n0 + self.nl]
+                item.copy_(torch.from_numpy(it))
+        if "meta/step" in st:
+            self.step = int(np.asarray(st["meta/step"]))
+        if "meta/beta_pow" in st:
+            bp = np.asarray(st["meta/beta_pow"], dtype=np.float32)
+            self.b1_pow, self.b2_pow = np.float32(bp[0]), np.float32(bp[1])
+
     def export_grads(self):
         """summed dense gradients of the last backward, reference shapes (the item rows of every shard are all-gathered)"""
         g = self.geo
         out = self._unpack_arena(self.G.cpu().numpy())
-        gi = torch.zeros(self.world, self.S, g.ldh, dtype=torch.float32, device=self.dev)
-        gi[self.dp_rank, :self.nl] = self.Gi
-        if self.world > 1:
-            dist.all_gather_into_tensor(gi.view(-1), gi[self.dp_rank].reshape(-1).clone(), group=self.group)
-        item = np.zeros((g.N + 1, g.H), dtype=np.float32)
-        item[1:] = gi.view(-1, g.ldh)[:g.N, :g.H].cpu().numpy()
-        out["item_emb"] = item
+        out["item_emb"] = self._gather_shard_rows(self.Gi)
         from collections import OrderedDict
         from .engine import VAR_ORDER
         return OrderedDict((k, out[k]) for k in VAR_ORDER)

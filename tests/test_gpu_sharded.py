@@ -100,6 +100,24 @@ def _worker(rank, world, port, ret):
         assert torch.equal(other[0], other[1]), float((other[0] - other[1]).abs().max())     # replicas: bit for bit
         info = eng.exchange_info()
         assert info["mode"] == "sharded" and info["bytes_per_step"]["item_rows"] == 4 * 2 * 512 * 256
+        # checkpoint round trip (host/model.py: save() on every rank, rank 0 writes): export_state is a collective that gathers
+        # the owners' Adam moments of the item table; load_state keeps each rank's rows; a resumed engine continues bit for bit
+        st = eng.export_state()
+        assert st["m/item_emb"].shape == (N + 1, H) and st["v/item_emb"].shape == (N + 1, H)
+        assert np.abs(st["v/item_emb"][1:513]).max() > 0 and np.abs(st["v/item_emb"][513:]).max() > 0      # both shards are there
+        if rank == 0:
+            want_st = ref.export_state()
+            for k in ("m/item_emb", "v/item_emb", "m/attout_item_cont_trans/w1"):
+                assert np.abs(st[k] - want_st[k]).max() <= 2e-3 * np.abs(want_st[k]).max() + 1e-12, k
+        eng2 = ShardedEngine(params, content, mw, max_grad=2.0, group=dist.group.WORLD, scoring="bf16x3")
+        eng2.load_state(st)
+        assert eng2.step == eng.step and torch.equal(eng2.Mi, eng.Mi) and torch.equal(eng2.Vi, eng.Vi) and torch.equal(eng2.M, eng.M)
+        lo, hi, cap = shard_bounds(B, world, rank)
+        sub = {k: v[lo:hi] for k, v in batch.items()}
+        eng.train_step(sub, cap=cap, T=T, K=K)
+        eng2.train_step(sub, cap=cap, T=T, K=K)
+        a, b2 = eng.export_params(), eng2.export_params()
+        assert all(np.array_equal(a[k], b2[k]) for k in a)
         ret[rank] = "ok"
     except Exception as e:
         import traceback
