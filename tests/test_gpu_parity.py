@@ -262,10 +262,12 @@ def test_step_matches_oracle(N, H, Ht, B, T, K, scoring):
     g_e, sq_e = eng.export_grads(), eng.export_sqnorms()
     check_grads(g_e, sq_e, {k: v.numpy() for k, v in g_o.items()}, sq_o, scoring)
     # three optimizer steps
-    for _ in range(3):
+    for i in range(3):
         le = eng.train_step(batch)
         lo = ora.train_step(batch)
-        close(le.cpu().numpy(), lo.numpy(), name="train loss", rtol=3e-3 if scoring == "bf16x3-mixed" else RTOL)
+        # the first loss is the forward pass at the initial variables (1e-3 in every precision); later ones follow Adam steps
+        # on gradients that carry bf16 noise in mixed mode (a coordinate may move by lr the other way): 1e-2 there
+        close(le.cpu().numpy(), lo.numpy(), name="train loss %d" % i, rtol=1e-2 if (scoring == "bf16x3-mixed" and i) else RTOL)
     # after Adam steps a coordinate whose gradient is at rounding level moves by ~lr with a rounding-determined sign
     # (Adam normalises by sqrt(v)); the split-bf16 mode has ~1e-5 relative gradient noise instead of ~1e-7
     p_e, p_o = eng.export_params(), ora.export()
@@ -368,17 +370,21 @@ def test_globo_full_size_step_matches_oracle(scoring, T):
     lab = torch.as_tensor(batch["label"], dtype=torch.long)
     want_rank = ((o_logits > o_logits.gather(1, lab[:, None])).sum(1) + 1).numpy()
     r = rank.cpu().numpy()
-    assert (r != want_rank).sum() <= 5, int((r != want_rank).sum())
+    for i in np.nonzero(r != want_rank)[0]:      # a rank may move only across scores within fp32 rounding of the label's
+        row = o_logits[i].numpy()
+        near = int((np.abs(row - row[batch["label"][i]]) <= 2e-5 * np.abs(row).max()).sum())
+        assert abs(int(r[i]) - int(want_rank[i])) <= near, (i, int(r[i]), int(want_rank[i]), near)
     assert abs(float((r <= 20).mean()) - float((want_rank <= 20).mean())) <= 0.002
+    assert abs(float((1.0 / r * (r <= 20)).mean()) - float((1.0 / want_rank * (want_rank <= 20)).mean())) <= 1e-3
     loss = eng.loss_and_grads(batch)
     o, g_o, sq_o = ora.loss_and_grads(batch)
     close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss")
     check_grads(eng.export_grads(), eng.export_sqnorms(), {k: v.numpy() for k, v in g_o.items()}, sq_o, scoring)
     # the fused step of the training loops (deferred update, three streams): per-session losses of two consecutive steps
-    for _ in range(2):
+    for i in range(2):
         le = eng.train_step(batch, defer_update=True)
         lo = ora.train_step(batch)
-        close(le.cpu().numpy(), lo.numpy(), name="train loss", rtol=3e-3 if scoring == "bf16x3-mixed" else RTOL)
+        close(le.cpu().numpy(), lo.numpy(), name="train loss %d" % i, rtol=1e-2 if (scoring == "bf16x3-mixed" and i) else RTOL)
     p_e, p_o = eng.export_params(), ora.export()
     for k in p_o:      # two Adam steps move a coordinate by at most ~2 lr; well-conditioned ones agree far closer
         d = np.abs(p_e[k] - p_o[k]).max()
