@@ -263,6 +263,18 @@ int tcar_attn_pool_bwd_q(const tcar_dims_t* d, int B, int T, const float* x_icp,
                          const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
                          float* dx_pt, float* dq, float* dpre1, float* dpre2, float* g_wres1, float* g_wres2,
                          float* g_qbias, void* stream);
+/* tcar_attn_pool_fwd with pre1 / pre2 arriving as n1 / n2 split-K partial products (slab s at pre?_slabs + s * slab_stride,
+ * [B*T, ldh] each): folded in slab order while they are read; the sums are also written to pre1 / pre2 [B*T, ldh], which the
+ * backward pass re-reads (modules.py:94-96,126-131 -> :97-100,132-135) */
+int tcar_attn_pool_fwd_slabs(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1_slabs,
+                             int n1, const float* pre2_slabs, int n2, int64_t slab_stride, float* pre1, float* pre2,
+                             const float* q, const float* w_res1, const float* w_res2, float* pooled, float* alpha, void* stream);
+/* tcar_attn_pool_bwd_det with dpooled arriving as split-K partial products: nd_ic slabs for the item | content columns, nd_pt
+ * for the time columns, slab s at dpooled + s * dp_stride ([B, ek] each), folded in slab order (1, 1: plain dpooled) */
+int tcar_attn_pool_bwd_slabs(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1,
+                             const float* pre2, const float* q, const float* w_res1, const float* w_res2, const float* alpha,
+                             const float* dpooled, int nd_ic, int nd_pt, int64_t dp_stride, float* dx_icp, float* dx_pt, float* dq,
+                             float* dpre1, float* dpre2, float* gw_rows, void* stream);
 /* order-fixed form of the same: dq leaves through tanh'(q), the per-session rows d w_res1 | d w_res2 are written to gw_rows
  * [B, 2*ldh] and nothing is summed atomically (tcar_colsum_det folds gw_rows and dq into the three gradients) */
 int tcar_attn_pool_bwd_det(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1,
@@ -402,6 +414,11 @@ int tcar_layernorm_bwd(int64_t M, int C, const float* x, const float* gamma, con
  * item ids, repeats allowed: a bit per row in `bitmap` — zero on entry — makes every row update exactly once);
  * tcar_clip_adam_rest: every item row whose bit is clear, then clears the bitmap.  Together they equal
  * tcar_clip_adam_all; the step driver runs the second on the aux stream beside the next forward pass. */
+/* tcar_adam_mark_rows: the marks of a split update whose two passes run CONCURRENTLY (step driver): sets bit (id - 1) of `skip`
+ * for every listed 1-based item id — tcar_clip_adam_rest(bitmap = skip) then leaves those rows to the early pass without waiting
+ * for it — and clears the [ceil(rows / 32)] words of `own`, which tcar_clip_adam_early(bitmap = own) uses to update a repeated
+ * id once.  (With ONE bitmap for both passes, as above, the rest pass must be ordered behind the early one.) */
+int tcar_adam_mark_rows(const int32_t* ids, int64_t n_ids, int64_t rows, uint32_t* skip, uint32_t* own, void* stream);
 int tcar_clip_adam_early(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,
                          const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot,
                          const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t,
@@ -496,7 +513,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 14
+#define TCAR_ABI_VERSION 15
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -546,7 +563,7 @@ typedef struct {
   /* optional auxiliary stream + 4 events (hipStream_t / hipEvent_t, caller-created): the candidate-side time refresh
    * (forward) and the dE chain (backward) run on it concurrently with the session-side chain; NULL = one stream */
   void* stream2; void* ev[6];
-  uint32_t* adam_bitmap;    /* [ceil(N/32)] zeroed words: rows already updated by the early pass of a split update */
+  uint32_t* adam_bitmap;    /* 2 x [ceil(N/32) + 1] zeroed words: rows the early pass of a split update owns (tcar_adam_mark_rows: skip | own) */
   const int32_t* et_perm;   /* [5, N] position of (k, n) in the inverted index (bf16 scoring modes: dE writes d_et in that order) */
   /* optional device timing of the three full-catalog GEMMs: ev_start / ev_stop hold 3 * ev_n hipEvent_t each
    * ([kind][slot]: kind 0 = logits, 1 = dX = dlogits E, 2 = dE = dlogits^T attout), recorded on the stream the GEMM is
@@ -566,6 +583,11 @@ typedef struct {
   /* optional slab workspace of the weight gradients (K splits of batches over 1,536 rows folded in split order instead of
    * float atomics); 16 * (sum of the nine M*N) floats covers every batch */
   float* wgrad_slabs; int64_t wgrad_slab_floats;
+  /* optional slab workspace of the session-side small GEMMs (split-bf16 modes): with (ceil(2ldh/128) + 2 ceil(ldh/128) +
+   * ceil(ldt/128) + ceil(5ldt/128)) * B*T * ldh floats the projections of both attention layers (modules.py:94-96,126-131) run as
+   * one 128-deep K chunk per workgroup, each chunk into its own slab, folded in slab order by tcar_attn_pool_fwd_slabs; the
+   * backward pass reuses it for the input gradient of the output transforms (tcar_attn_pool_bwd_slabs) */
+  float* proj_slabs; int64_t proj_slab_floats;
 } tcar_ctx_t;
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */

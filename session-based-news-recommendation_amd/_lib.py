@@ -20,16 +20,16 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 14          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 15          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_adam_mark_rows", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
            "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range",
-           "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
+           "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_attn_pool_fwd_slabs", "tcar_attn_pool_bwd_slabs", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
 
 
@@ -193,7 +193,8 @@ class Ctx(C.Structure):
                 + [(n, C.c_void_p) for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l")]
                 + [("stream2", C.c_void_p), ("ev", C.c_void_p * 6), ("adam_bitmap", C.c_void_p), ("et_perm", C.c_void_p), ("ev_start", C.c_void_p), ("ev_stop", C.c_void_p),
                    ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p), ("stream3", C.c_void_p), ("ev3", C.c_void_p),
-                   ("segsum_ws", C.c_void_p), ("segsum_bytes", C.c_int64), ("gw_rows", C.c_void_p), ("wgrad_slabs", C.c_void_p), ("wgrad_slab_floats", C.c_int64)])
+                   ("segsum_ws", C.c_void_p), ("segsum_bytes", C.c_int64), ("gw_rows", C.c_void_p), ("wgrad_slabs", C.c_void_p), ("wgrad_slab_floats", C.c_int64),
+                   ("proj_slabs", C.c_void_p), ("proj_slab_floats", C.c_int64)])
 
 
 class TcarError(RuntimeError):
@@ -246,6 +247,8 @@ def load() -> C.CDLL:
     lib.tcar_attn_pool_bwd.argtypes = [P(Dims), i32, i32] + [vp] * 17
     lib.tcar_attn_pool_bwd_q.argtypes = [P(Dims), i32, i32] + [vp] * 18
     lib.tcar_attn_pool_bwd_det.argtypes = [P(Dims), i32, i32] + [vp] * 16
+    lib.tcar_attn_pool_fwd_slabs.argtypes = [P(Dims), i32, i32, vp, vp, vp, i32, vp, i32, i64] + [vp] * 8
+    lib.tcar_attn_pool_bwd_slabs.argtypes = [P(Dims), i32, i32] + [vp] * 9 + [i32, i32, i64] + [vp] * 7
     lib.tcar_colsum_det.argtypes = [i32, vp, vp]
     lib.tcar_graph_probe.argtypes = [P(Ctx), P(Batch), f32, i32, vp, vp]
     lib.tcar_small_tables_bwd_det.argtypes = [P(Dims), P(Tables), P(Batch), vp, vp, vp, vp, P(Grads), vp, vp]
@@ -265,6 +268,7 @@ def load() -> C.CDLL:
                                          f32, f32, f32, vp, vp, i64, vp, i64, vp, vp]
     lib.tcar_clip_adam_rest.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64,
                                         vp, vp]
+    lib.tcar_adam_mark_rows.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.tcar_layernorm_fwd.argtypes = [i64, i32, vp, vp, vp, f32, vp, vp, vp]
     lib.tcar_layernorm_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tcar_mha_core_fwd.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]

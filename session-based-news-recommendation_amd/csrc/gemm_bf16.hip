@@ -308,25 +308,11 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
     const long w384 = (long)((g.M + 255) / 256) * ((g.N + 383) / 384) * splitk;
     if (nsplit == 3 && (f == 384 || (f == 0 && w384 >= 200))) return launch_v<0, 0, 3, 2, 4, 4, 3>(g, splitk, st);
   }
-  if constexpr (MB == 1) {
-    // 256 x 288 (8 waves of 1 x 9 MFMA tiles, 144 accumulator registers, 139 KB of LDS for two 32-deep stages): OFF by
-    // default (TCAR_TILE288=1 / TCAR_BF16_TILE=288).  It moves 27-29 % fewer L2 -> LDS fill bytes per flop than dX's
-    // 512 x 128 and dE's 192 x 192 (1/TM + 1/TN = 0.00738 against 0.00977 / 0.0104) and was built on the reading that
-    // both GEMMs are fill bound; measured it is SLOWER (dX 136 -> 170 us, dE 92 -> 129 us alone, 270 -> 315 us co-running):
-    // eight waves per CU with one 139-KB workgroup hide the fill latency worse than 16 / 12 waves, so the limit is latency
-    // per resident wave, not bytes.  Kept as a measured negative result.
-    const int n288 = (g.N + 287) / 288 * 288;
-    const long w288 = (long)((g.M + 255) / 256) * (n288 / 288) * splitk;
-    const bool fits = (long)n288 * 100 <= (long)g.N * 105 && g.M > 128 && w288 >= 192;
-    if (f == 288 || (tcar_tuning().tile288 && f == 0 && fits))
-      return nsplit == 3 ? launch_v<MA, 1, 3, 8, 1, 1, 9>(g, splitk, st) : launch_v<MA, 1, 1, 8, 1, 1, 9>(g, splitk, st);
-  }
   if constexpr (MA == 0 && MB == 1) {
     // 512 x 128 (16 waves): the whole session batch is ONE M tile, so every dlogits stage is fetched once per N tile and
     // the fill bytes per flop drop 16 % against two 256 x 128 tiles (dX: 170 -> 147 us at split-K 36)
     const long w512 = (long)((g.M + 511) / 512) * ((g.N + 127) / 128) * splitk;
-    const bool dx512 = tcar_tuning().dx512 != 0;
-    if (f == 512 || (f == 0 && dx512 && g.M > 256 && w512 >= 192))
+    if (f == 512 || (f == 0 && g.M > 256 && w512 >= 192))
       return nsplit == 3 ? launch_v<0, 1, 3, 8, 2>(g, splitk, st) : launch_v<0, 1, 1, 8, 2>(g, splitk, st);
   }
   if constexpr (MB == 1) {

@@ -536,15 +536,21 @@ int launch_x3(GroupArgs& ga, hipStream_t st) {
     p.wg_begin = wg;
     wg += p.mt * p.nt * p.ksplit;
   }
-  const int force = tcar_tuning().x3_xk, ring = tcar_tuning().x3_ring;
-  if (force == 32) return launch_x3_v<LA, LB, 32, 3>(ga, wg, st);
-  if (force == 128) return launch_x3_v<LA, LB, 128, 2>(ga, wg, st);
-  // 64-deep stages (48 KB of LDS) by default: these launches run beside the dE GEMM, whose workgroups hold 96 KB of a CU's
-  // 160 KB — a 96-KB (128-deep) workgroup would have to wait for one of them to retire (measured: 0.704 / 0.690 / 0.680 ms
-  // per step with 128-deep / mixed / 64-deep stages)
-  if (ring == 1) return launch_x3_v<LA, LB, 64, 1>(ga, wg, st);
-  if (ring == 2) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st);
-  return launch_x3_v<LA, LB, 64, 3>(ga, wg, st);
+  // 64-deep stages (48 KB of LDS): these launches run beside the dE GEMM, whose workgroups hold 96 KB of a CU's 160 KB — a
+  // 96-KB (128-deep) workgroup would have to wait for one of them to retire (measured: 0.704 / 0.690 / 0.680 ms per step with
+  // 128-deep / mixed / 64-deep stages).  A register ring of 2-3 stages does not pay for long K (profiles/r02_x3_small_gemm_bench.txt:
+  // a stage costs 1.3 us of in-workgroup work), so the default keeps ONE stage in flight.
+  // Short-K launches (every workgroup has at most two 64-deep stages: the split-K "one-shot" problems of the step driver,
+  // K <= 128): both stages are requested up front (ring of 2) — a workgroup pays ONE global-memory round trip.
+  int max_stages = 0;
+  for (int i = 0; i < ga.nprob; ++i) {
+    const GemmProb& p = ga.p[i];
+    int n = 0;
+    for (int sg = 0; sg < p.nseg; ++sg) n += ((p.K[sg] < p.kchunk ? p.K[sg] : p.kchunk) + 63) / 64;
+    max_stages = n > max_stages ? n : max_stages;
+  }
+  if (max_stages <= 2 && tcar_tuning().x3_oneshot) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st);
+  return launch_x3_v<LA, LB, 64, 1>(ga, wg, st);
 }
 
 int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {

@@ -23,6 +23,10 @@ struct PoolArgs {
   const float* w1; const float* w2; const float* alpha_in; const float* dpooled;
   float* pooled; float* alpha;
   float* dx_icp; float* dx_pt; float* dq; float* dpre1; float* dpre2; float* g_w1; float* g_w2;
+  // split-K slabs (tcar_attn_pool_fwd_slabs / tcar_attn_pool_bwd_slabs): pre1 / pre2 arrive as n1 / n2 partial products of
+  // stride pre_stride floats — summed here in slab order, the sums written to pre1_out / pre2_out (the backward pass re-reads
+  // them); dpooled arrives as nd_ic (item | content columns) / nd_pt (time columns) slabs of stride dp_stride
+  int n1, n2, nd_ic, nd_pt; long pre_stride, dp_stride; float* pre1_out; float* pre2_out;
   float* g_qb;     // optional: bias gradient of query_trans2; dq then leaves multiplied by tanh'(q) (modules.py:139 backward)
   float* gw_rows;  // optional [B, 2 * ldh]: the per-session d w_res1 | d w_res2 rows are WRITTEN here (and dq leaves through
                    // tanh') instead of any atomic sum: tcar_colsum_det adds the columns up in a fixed order
@@ -66,8 +70,15 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
       if (col < ldh) {
-        s1 += dot4(mask4(sig4(ld4(a.pre1 + row * ldh + col)), col, H), w1[c]);
-        s3 += dot4(mask4(sig4(ld4(a.pre2 + row * ldh + col)), col, H), w2[c]);
+        float4 p1 = ld4(a.pre1 + row * ldh + col), p2 = ld4(a.pre2 + row * ldh + col);
+        if (a.pre1_out) {                // split-K partial products, folded in slab order
+          for (int sl = 1; sl < a.n1; ++sl) p1 = add4(p1, ld4(a.pre1 + sl * a.pre_stride + row * ldh + col));
+          for (int sl = 1; sl < a.n2; ++sl) p2 = add4(p2, ld4(a.pre2 + sl * a.pre_stride + row * ldh + col));
+          st4(a.pre1_out + row * ldh + col, p1);
+          st4(a.pre2_out + row * ldh + col, p2);
+        }
+        s1 += dot4(mask4(sig4(p1), col, H), w1[c]);
+        s3 += dot4(mask4(sig4(p2), col, H), w2[c]);
         s2 += dot4(ld4(a.x_icp + row * ic + col), qa[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), qb[c]);
       }
     }
@@ -146,11 +157,16 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
       qb[c] = ok ? ld4(a.q + (long)b * ic + ldh + col) : zero4();
       da[c] = ok ? ld4(dpo + col) : zero4();
       db[c] = ok ? ld4(dpo + ldh + col) : zero4();
+      for (int sl = 1; sl < a.nd_ic; ++sl) {        // split-K partial products of the output transform's input gradient
+        if (ok) { da[c] = add4(da[c], ld4(dpo + sl * a.dp_stride + col)); db[c] = add4(db[c], ld4(dpo + sl * a.dp_stride + ldh + col)); }
+      }
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int l4 = c * 64 + lane;
       dp[c] = (l4 < ptl) ? ld4(dpo + ic + l4 * 4) : zero4();
+      for (int sl = 1; sl < a.nd_pt; ++sl)
+        if (l4 < ptl) dp[c] = add4(dp[c], ld4(dpo + sl * a.dp_stride + ic + l4 * 4));
     }
     const bool on = lane < T;
     const float a1 = on ? a.alpha_in[(long)b * T + lane] : 0.f;
@@ -266,6 +282,24 @@ extern "C" int tcar_attn_pool_fwd(const tcar_dims_t* d, int B, int T, const floa
   return TCAR_OK;
 }
 
+extern "C" int tcar_attn_pool_fwd_slabs(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                                        const float* pre1_slabs, int n1, const float* pre2_slabs, int n2, int64_t slab_stride,
+                                        float* pre1, float* pre2, const float* q, const float* w_res1, const float* w_res2,
+                                        float* pooled, float* alpha, void* stream) {
+  if (!d || B <= 0 || T <= 0 || T > TCAR_POS_VOCAB || (d->ldh & 63) || d->ldh > 512 || 5 * d->ldt > 512) return TCAR_E_ARG;
+  if (n1 < 1 || n2 < 1 || !pre1 || !pre2 || slab_stride < (int64_t)B * T * d->ldh) return TCAR_E_ARG;
+  PoolArgs a{};
+  a.B = B; a.T = T; a.H = d->H; a.ldh = d->ldh; a.ldt = d->ldt;
+  a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1_slabs; a.pre2 = pre2_slabs; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
+  a.n1 = n1; a.n2 = n2; a.pre_stride = slab_stride; a.pre1_out = pre1; a.pre2_out = pre2;
+  a.pooled = pooled; a.alpha = alpha;
+  const int grid = (B + 3) / 4;
+  if (d->ldh <= 256) TCAR_LAUNCH(attn_pool_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else TCAR_LAUNCH(attn_pool_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
 extern "C" int tcar_attn_pool_bwd(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
                                   const float* pre1, const float* pre2, const float* q, const float* w_res1,
                                   const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
@@ -301,8 +335,19 @@ extern "C" int tcar_attn_pool_bwd_det(const tcar_dims_t* d, int B, int T, const 
                                       const float* pre1, const float* pre2, const float* q, const float* w_res1,
                                       const float* w_res2, const float* alpha, const float* dpooled, float* dx_icp,
                                       float* dx_pt, float* dq, float* dpre1, float* dpre2, float* gw_rows, void* stream) {
+  return tcar_attn_pool_bwd_slabs(d, B, T, x_icp, x_pt, pre1, pre2, q, w_res1, w_res2, alpha, dpooled, 1, 1, 0, dx_icp, dx_pt, dq,
+                                  dpre1, dpre2, gw_rows, stream);
+}
+
+extern "C" int tcar_attn_pool_bwd_slabs(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt,
+                                        const float* pre1, const float* pre2, const float* q, const float* w_res1,
+                                        const float* w_res2, const float* alpha, const float* dpooled, int nd_ic, int nd_pt,
+                                        int64_t dp_stride, float* dx_icp, float* dx_pt, float* dq, float* dpre1, float* dpre2,
+                                        float* gw_rows, void* stream) {
   if (!d || B <= 0 || T <= 0 || T > TCAR_POS_VOCAB || (d->ldh & 63) || d->ldh > 512 || 5 * d->ldt > 512 || !gw_rows) return TCAR_E_ARG;
+  if (nd_ic < 1 || nd_pt < 1) return TCAR_E_ARG;
   PoolArgs a{};
+  a.nd_ic = nd_ic; a.nd_pt = nd_pt; a.dp_stride = dp_stride;
   a.B = B; a.T = T; a.H = d->H; a.ldh = d->ldh; a.ldt = d->ldt;
   a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1; a.pre2 = pre2; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
   a.alpha_in = alpha; a.dpooled = dpooled;

@@ -9,36 +9,40 @@ static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return (v && *v) ? atoi(v) : dflt;
 }
+// ONE table: name, field, shipped default (a switch cannot be added out of order)
+namespace {
+struct Switch { const char* name; int TcarTuning::*field; int dflt; };
+const Switch kSwitches[] = {
+    {"TCAR_BF16_TILE", &TcarTuning::bf16_tile, 0},          {"TCAR_REST_GRID", &TcarTuning::rest_grid, 512},
+    {"TCAR_SOFTMAX_VARIANT", &TcarTuning::softmax_variant, 1}, {"TCAR_WGRAD_KS", &TcarTuning::wgrad_ks, 1536},
+    {"TCAR_GATHER_BIG_ROWS", &TcarTuning::gather_big_rows, 16384}, {"TCAR_GATHER_WG", &TcarTuning::gather_wg_per_cu, 2},
+    {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
+    {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
+    {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
+};
+}  // namespace
 static TcarTuning& tuning_storage() {
-  static TcarTuning t = {env_int("TCAR_BF16_TILE", 0), env_int("TCAR_DX512", 1), env_int("TCAR_X3_XK", 0),
-                         env_int("TCAR_X3_RING", 1), env_int("TCAR_REST_GRID", 512), env_int("TCAR_SOFTMAX_VARIANT", 1),
-                         env_int("TCAR_WGRAD_KS", 1536), env_int("TCAR_TILE288", 0), env_int("TCAR_GATHER_BIG_ROWS", 16384),
-                         env_int("TCAR_GATHER_WG", 2), env_int("TCAR_FUSED_Q", 1), env_int("TCAR_PLANES_EPI", 1),
-                         env_int("TCAR_MHA_MFMA", 1), env_int("TCAR_SORT_SCATTER", 1), env_int("TCAR_BF16_KS", 2), env_int("TCAR_DE_LATE", 0), env_int("TCAR_DET_SMALL", 1), env_int("TCAR_SPLIT_UPDATE", 0), env_int("TCAR_Q_STREAM", 0), env_int("TCAR_EARLY_PROLOGUE", 0), env_int("TCAR_FUSE_SQNORM", 1), env_int("TCAR_DCLICK_AUX", 0)};
+  static TcarTuning t = [] {
+    TcarTuning x{};
+    for (const Switch& sw : kSwitches) x.*(sw.field) = env_int(sw.name, sw.dflt);
+    return x;
+  }();
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
 
-// Diagnostic hook (tests, tools): override one switch at run time; returns the previous value, or INT_MIN for an unknown
-// name.  Not thread safe against concurrent launches — product code never calls it.
+// Diagnostic hook (tests, tools/): override one switch at run time; returns the previous value, or INT_MIN for an unknown
+// name.  Process-global and not thread safe against concurrent launches — the product path (engine, step driver) never calls it.
 extern "C" int tcar_set_tuning(const char* name, int value) {
   if (!name) return -2147483647 - 1;
   TcarTuning& t = tuning_storage();
-  struct { const char* n; int* p; } tab[] = {{"TCAR_BF16_TILE", &t.bf16_tile}, {"TCAR_DX512", &t.dx512}, {"TCAR_X3_XK", &t.x3_xk},
-                                              {"TCAR_X3_RING", &t.x3_ring},
-                                              {"TCAR_REST_GRID", &t.rest_grid}, {"TCAR_SOFTMAX_VARIANT", &t.softmax_variant},
-                                              {"TCAR_WGRAD_KS", &t.wgrad_ks}, {"TCAR_TILE288", &t.tile288},
-                                              {"TCAR_GATHER_BIG_ROWS", &t.gather_big_rows}, {"TCAR_GATHER_WG", &t.gather_wg_per_cu},
-                                              {"TCAR_FUSED_Q", &t.fused_q}, {"TCAR_PLANES_EPI", &t.planes_epi},
-                                              {"TCAR_MHA_MFMA", &t.mha_mfma},
-                                              {"TCAR_SORT_SCATTER", &t.sort_scatter}, {"TCAR_BF16_KS", &t.bf16_ks}, {"TCAR_DE_LATE", &t.de_late}, {"TCAR_DET_SMALL", &t.det_small}, {"TCAR_SPLIT_UPDATE", &t.split_update}, {"TCAR_Q_STREAM", &t.q_stream}, {"TCAR_EARLY_PROLOGUE", &t.early_prologue}, {"TCAR_FUSE_SQNORM", &t.fuse_sqnorm}, {"TCAR_DCLICK_AUX", &t.dclick_aux}};
-  for (auto& e : tab) {
+  for (const Switch& sw : kSwitches) {
     bool same = true;
     for (int i = 0; same; ++i) {
-      if (e.n[i] != name[i]) same = false;
-      else if (!e.n[i]) break;
+      if (sw.name[i] != name[i]) same = false;
+      else if (!sw.name[i]) break;
     }
-    if (same) { const int old = *e.p; *e.p = value; return old; }
+    if (same) { const int old = t.*(sw.field); t.*(sw.field) = value; return old; }
   }
   return -2147483647 - 1;
 }
@@ -59,6 +63,7 @@ struct Geo {
 };
 
 inline float* W(const tcar_ctx_t* c, int v) { return c->W + c->off[v]; }
+inline int units(int K) { return (K + 127) / 128; }     // 128-deep K chunks of a split small GEMM (two 64-deep stages each)
 inline float* G(const tcar_ctx_t* c, int v) { return c->Gx + c->off[v]; }
 
 tcar_gemm_desc_t prob(int M, int N, float* C, int64_t ldc, const float* bias = nullptr, int act = 0, int beta = 0,
@@ -139,14 +144,26 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   tables_of(c, tab);
   RET(tcar_gather_clip_fwd(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream));
   const float* x_c = c->x_icp + g.ldh;
-  // TCAR_Q_STREAM=1 (experiment, off): the click-query MLP (two small dependent GEMMs, modules.py:138-139) on the third
-  // stream beside the projections instead of behind them — takes a 14-us launch off the main chain and gives it back as
-  // fork / join latency: 0.604 -> 0.607 ms
-  hipStream_t st = (hipStream_t)stream;
-  hipStream_t sq = (tcar_tuning().q_stream && aux_stream(c) && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
-  if (sq && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sq, (hipEvent_t)c->ev[0], 0) != hipSuccess))
-    return TCAR_E_LAUNCH;
-  {  // pre1, pre2, q1 (modules.py:126-131, 94-96, 138)
+  // pre1, pre2, q1 (modules.py:126-131, 94-96, 138).  With the slab workspace (split-bf16 modes) every (operand pair, 128-deep K
+  // chunk) of the two projections is its OWN problem of the grouped launch writing its own slab: 7 + 5 chunks x 32-72 tiles
+  // instead of 2 x 32-72 workgroups walking 13 / 9 serial stages — a workgroup pays one global-memory round trip — and the pool
+  // kernel folds the slabs in slab order while it reads them (one writer per element: order-fixed)
+  const int n1 = units(g.ic) + units(g.ldh) + units(g.ldt), n2 = units(g.pt) + units(g.ldh);
+  const int64_t stride = (int64_t)BT * g.ldh;
+  const bool split = c->scoring && tcar_tuning().proj_split && c->proj_slabs && c->proj_slab_floats >= (n1 + n2) * stride;
+  if (split) {
+    float* s1 = c->proj_slabs;
+    float* s2 = c->proj_slabs + n1 * stride;
+    tcar_gemm_desc_t p[6];
+    p[0] = prob1(BT, g.ldh, c->x_icp, g.ic, W(c, TCAR_V_M_WIN), g.ldh, g.ic, s1, g.ldh, nullptr, 0, 0, units(g.ic));
+    p[1] = prob1(BT, g.ldh, x_c, g.ic, W(c, TCAR_V_M_WC), g.ldh, g.ldh, s1 + units(g.ic) * stride, g.ldh, nullptr, 0, 0, units(g.ldh));
+    p[2] = prob1(BT, g.ldh, c->x_act, g.ldt, W(c, TCAR_V_M_WINT), g.ldh, g.ldt, s1 + (units(g.ic) + units(g.ldh)) * stride, g.ldh,
+                 nullptr, 0, 0, units(g.ldt));
+    p[3] = prob1(BT, g.ldh, c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt, s2, g.ldh, nullptr, 0, 0, units(g.pt));
+    p[4] = prob1(BT, g.ldh, x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh, s2 + units(g.pt) * stride, g.ldh, nullptr, 0, 0, units(g.ldh));
+    p[5] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
+    RET(small_gemm(c, 0, 6, p, stream));
+  } else {
     tcar_gemm_desc_t p[3];
     p[0] = prob(BT, g.ldh, c->pre1, g.ldh);
     seg(p[0], c->x_icp, g.ic, W(c, TCAR_V_M_WIN), g.ldh, g.ic);
@@ -156,21 +173,18 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     seg(p[1], c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt);
     seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
     p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
-    if (sq) {
-      RET(small_gemm(c, 0, 1, &p[2], (void*)sq));
-      RET(small_gemm(c, 0, 2, p, stream));
-    } else {
-      RET(small_gemm(c, 0, 3, p, stream));
-    }
+    RET(small_gemm(c, 0, 3, p, stream));
   }
   {  // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
-    RET(small_gemm(c, 0, 1, &p, sq ? (void*)sq : stream));
-    if (sq && (hipEventRecord((hipEvent_t)c->ev3, sq) != hipSuccess || hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess))
-      return TCAR_E_LAUNCH;
+    RET(small_gemm(c, 0, 1, &p, stream));
   }
-  RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
-                         W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
+  if (split)
+    RET(tcar_attn_pool_fwd_slabs(&c->d, B, bt->T, c->x_icp, c->x_pt, c->proj_slabs, n1, c->proj_slabs + n1 * stride, n2, stride,
+                                 c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
+  else
+    RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
+                           W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
   {  // attout (model_combine.py:119,127,132)
     tcar_gemm_desc_t p[2];
     p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->attout, g.ek, W(c, TCAR_V_O_B), 2);
@@ -230,21 +244,44 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   // The candidate-side time block of E depends only on the time tables: it is rebuilt on the auxiliary stream while
   // the session side (gather, projections, pools) runs on the main one; the logits GEMM joins them.
   hipStream_t s1 = (hipStream_t)stream, s2 = aux_stream(c);
-  bool joined = true;
+  hipStream_t s3 = (s2 && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
+  bool joined = true, joined3 = true;
   if (refresh_time) {
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-    if (s2) {
+    hipStream_t st_time = s2;          // the stream that rebuilds the candidate-side time block
+    if (s2 && rest_lr >= 0.f) {
+      // The pending split update (tcar_train_step_deferred).  Three things start together:
+      //   main:  mark the rows this batch gathers -> EARLY pass (arena + those rows) -> gather ...
+      //   aux:   [after the marks]  REST pass over every other item row (the 60-us HBM-bound pass), sort index
+      //   third: [after the early pass: it updates the time tables]  candidate-side time refresh
+      // The rest pass no longer queues behind the early pass and the time refresh: it ends ~25 us earlier, and the logits GEMM
+      // waits for it.
+      const float* pieces = c->Gx + c->arena_n;
+      uint32_t* skip = c->adam_bitmap;
+      uint32_t* own = c->adam_bitmap + ((g.N + 31) / 32 + 1);
+      RET(tcar_adam_mark_rows(bt->seq, (int64_t)BT, g.N, skip, own, stream));
+      if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
+        return TCAR_E_LAUNCH;
+      RET(tcar_clip_adam_rest(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
+                              c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
+                              c->scoring ? c->e16l : nullptr, g.ek, skip, (void*)s2));
+      RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
+                               c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
+                               c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT, own,
+                               stream));
+      if (s3) st_time = s3;
+      if (hipEventRecord((hipEvent_t)c->ev[5], s1) != hipSuccess || hipStreamWaitEvent(st_time, (hipEvent_t)c->ev[5], 0) != hipSuccess)
+        return TCAR_E_LAUNCH;
+    } else if (s2) {
       if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
         return TCAR_E_LAUNCH;
     }
     RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
-                                s2 ? (void*)s2 : stream));
-    if (s2 && rest_lr >= 0.f) {
-      const float* pieces = c->Gx + c->arena_n;
-      RET(tcar_clip_adam_rest(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
-                              c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
-                              c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2));
+                                st_time ? (void*)st_time : stream));
+    if (st_time && st_time == s3) {
+      if (hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
+      joined3 = false;
     }
     if (s2) {
       if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
@@ -257,14 +294,9 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       return TCAR_E_LAUNCH;
     RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)s2));
   }
-  RET(session_forward(c, bt, g, stream, c->scoring && tcar_tuning().planes_epi));
+  RET(session_forward(c, bt, g, stream, c->scoring != 0));
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
-  if (train_index && s2 && tcar_tuning().early_prologue) {
-    // fused training step: the backward's aux-stream prologue needs attout only — it runs beside the logits GEMM, and the
-    // fork sits next to the join above instead of between the logits GEMM and the softmax
-    RET(backward_prologue(c, bt, s1, s2));
-    if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
-  }
+  if (!joined3 && hipStreamWaitEvent(s1, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   int ei = -1;
   auto start_timer = [&]() {
@@ -276,15 +308,10 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   };
   int rc;
   if (c->scoring) {
-    // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue (TCAR_PLANES_EPI=0: by
-    // their own launch)
-    rc = tcar_tuning().planes_epi ? TCAR_OK
-                                  : tcar_split_bf16(c->attout, g.ek, B, g.ek, c->a16h, c->a16l, g.ek, c->ap16h, c->ap16l,
-                                                    g.ldh + g.pt, g.ldh, g.ic, stream);
+    // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
-    if (!rc)
-      rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
-                          nullptr, 0, 0, c->scoring, 1, stream);
+    rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
+                        nullptr, 0, 0, c->scoring, 1, stream);
   } else {
     start_timer();
     rc = tcar_gemm_f32(1, B, g.N, g.ek, c->attout, g.ek, c->E, g.ek, c->logits, g.Npad, nullptr, 0, 0, 1, stream);
@@ -362,8 +389,7 @@ int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream);
 // Every cross-stream join costs ~10 us of launch latency behind an event, so there are as few as the data flow allows.
 // Rank-local backward of the data-parallel step (fuse_finish = false): dE and the negative rows run FIRST on the main
 // stream (their all-reduce then overlaps everything else, dp.py); the finish is tcar_step_finish after the exchange.
-int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish, bool join_tail = true,
-                  bool prologue_done = false) {
+int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
   const int B = bt->B, T = bt->T, BT = B * T, K = bt->K;
@@ -376,10 +402,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // zero the gradient arena and the norm slots; with an aux stream this happens beside the softmax, not before it
   // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
   hipStream_t sz = s2 ? s2 : st;
-  if (!prologue_done) {
-    RET(backward_prologue(c, bt, st, sz));
-    if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
-  }
+  RET(backward_prologue(c, bt, st, sz));
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   // sorted segmented sum of the item-row gradients (deterministic); its index was built under the forward pass, on the aux
   // stream — ev[1] (recorded behind the prologue) orders the main stream behind it
   const bool sorted = fuse_finish && sorted_rows(c, bt);
@@ -427,9 +451,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // chain B done
     return TCAR_OK;
   };
-  // TCAR_DE_LATE=1 (fused step): dE starts only after dX and its slab reduce, instead of beside them
-  const bool de_late = split_finish && tcar_tuning().de_late != 0;
-  if (!de_late) RET(chain_b());
+  RET(chain_b());
   // ---- chain A
   tick(1, false, stream);
   if (c->scoring) {
@@ -444,20 +466,21 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
   // order-fixed bias / residual-weight gradients (split-bf16 modes with the fused query chain and a row workspace): the
   // producers below leave the column sums to ONE tcar_colsum_det launch behind the weight-gradient GEMM
-  const bool fusedq = c->scoring != 0 && tcar_tuning().fused_q;
+  const bool fusedq = c->scoring != 0;
   const bool detc = fusedq && c->gw_rows != nullptr;
   RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
                               c->dattout, detc ? nullptr : G(c, TCAR_V_O_B), g.ic, detc ? nullptr : G(c, TCAR_V_OT_B), stream));
   if (!has_neg && hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
-  if (de_late) {
-    if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
-      return TCAR_E_LAUNCH;
-    RET(chain_b());
-  }
+  // dpooled = dattout W_o^T (both output transforms).  Split form (slab workspace + order-fixed pool backward): every 128-deep K
+  // chunk is its own set of workgroups writing its own slab, the pool backward folds them while it loads dpooled
+  const int nd_ic = units(g.ic), nd_pt = units(g.pt);
+  const int64_t dstride = (int64_t)B * g.ek;
+  const bool dsplit = detc && tcar_tuning().proj_split && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
   {
     tcar_gemm_desc_t p[2];
-    p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->dpooled, g.ek);
-    p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->dpooled + g.ic, g.ek);
+    float* dp = dsplit ? c->proj_slabs : c->dpooled;
+    p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, dp, g.ek, nullptr, 0, 0, dsplit ? nd_ic : 1);
+    p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, dp + g.ic, g.ek, nullptr, 0, 0, dsplit ? nd_pt : 1);
     RET(small_gemm(c, 1, 2, p, stream));
   }
   // query MLP backward (modules.py:138-139).  Split-bf16 modes: tanh' + bias gradient of query_trans2 ride in the pool
@@ -465,8 +488,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // launch with the three input-gradient GEMMs of the projections (all four need only the pool backward's outputs); the
   // click-query input gradient (needs dq1) follows.  fp32 mode: the op-level sequence.
   if (detc)
-    RET(tcar_attn_pool_bwd_det(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
-                               c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream));
+    RET(tcar_attn_pool_bwd_slabs(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
+                                 c->alpha, dsplit ? c->proj_slabs : c->dpooled, dsplit ? nd_ic : 1, dsplit ? nd_pt : 1, dstride,
+                                 c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream));
   else
     RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
                              W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
@@ -502,8 +526,6 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // Order-fixed small tables (sorted mode, which implies an aux stream): they — and the click-query input gradient, which only
   // they consume — run on the aux stream behind the candidate-time backward, beside the rest of the main chain
   const bool det_small = sorted && tcar_tuning().det_small != 0;
-  const bool dclick_aux = fusedq && det_small && tcar_tuning().dclick_aux != 0;
-  if (dclick_aux && s3 && hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess) return TCAR_E_LAUNCH;   // dq1 exists
   RET(weight_grads(c, g, B, BT, sW));
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
@@ -512,10 +534,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
-    if (!dclick_aux) {
-      tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
-      RET(small_gemm(c, 1, 1, &p, stream));
-    }
+    tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+    RET(small_gemm(c, 1, 1, &p, stream));
   } else {  // input gradients (only the ITEM half of dX_ic: content is frozen)
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
@@ -532,12 +552,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    if (dclick_aux) {
-      tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
-      RET(small_gemm(c, 1, 1, &p, (void*)s2));
-    } else if (hipEventRecord((hipEvent_t)c->ev[5], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[5], 0) != hipSuccess) {
+    if (hipEventRecord((hipEvent_t)c->ev[5], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[5], 0) != hipSuccess)
       return TCAR_E_LAUNCH;
-    }
     RET(tcar_small_tables_bwd_det(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2));
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
@@ -549,11 +565,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     } else if (has_neg) {
       RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, stream));
     }
-    if (sorted) {  // block partials of ||Gi||^2 (S5: BEFORE any session row lands): they ride in the launch of the item-row
-                   // gradients below (tcar_gather_clip_bwd_sqnorm) unless TCAR_FUSE_SQNORM=0; the session-list pass folds them
-      if (!tcar_tuning().fuse_sqnorm) RET(tcar_sqnorm_det(Gi, (int64_t)g.N * g.ldh, c->segsum_ws, c->segsum_bytes, stream));
-    } else
-      RET(item_norm(c, g, stream));
+    // sorted: the block partials of ||Gi||^2 (S5: BEFORE any session row lands) ride in the launch of the item-row gradients
+    // below (tcar_gather_clip_bwd_sqnorm); the session-list pass folds them
+    if (!sorted) RET(item_norm(c, g, stream));
   }
   // The row scatter needs the item norm (same stream) but NOT the candidate-time backward: both only add (atomically) into
   // the time-table gradients, and the final join below covers the whole aux stream.  Without the split, wait for chain B.
@@ -570,7 +584,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       gr.rows_out = tcar_segsum_rows_buffer(&c->d, bt, c->segsum_ws);
       gr.norms_out = tcar_segsum_norms_buffer(&c->d, bt, c->segsum_ws);
       gr.skip_small = det_small ? 1 : 0;
-      if (split_finish && tcar_tuning().fuse_sqnorm)
+      if (split_finish)
         RET(tcar_gather_clip_bwd_sqnorm(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, Gi, (int64_t)g.N * g.ldh,
                                         c->segsum_ws, c->segsum_bytes, stream));
       else
@@ -581,11 +595,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
     }
   }
-  // (tcar_train_step joins later: the item table's update needs nothing of the other streams and runs first)
-  if (join_tail || !s2) {
-    if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
-    if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
-  }
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
+  if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
   if (fuse_finish && !s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
   return TCAR_OK;
 }
@@ -643,25 +654,8 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
 
 extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {
   RET(forward_impl(c, bt, refresh_time, stream, -1.f, true));
-  hipStream_t s2 = aux_stream(c);
-  if (!s2 || !tcar_tuning().split_update) {
-    RET(backward_impl(c, bt, stream, true, true, aux_stream(c) && tcar_tuning().early_prologue));
-    return tcar_step_update(c, lr_t, stream);
-  }
-  // TCAR_SPLIT_UPDATE=1 (experiment, off): the item table's gradient, norm and norm pieces are complete on the main stream
-  // before the other streams are, so its update (the 60-us HBM pass) can start at once with the cross-stream joins (~10 us of
-  // event latency) hidden under it and the arena following behind the join.  Same arithmetic as the one-launch update —
-  // and measured SLOWER (0.606 -> 0.615 ms): the second launch and its join cost more than the hidden bubble.
-  RET(backward_impl(c, bt, stream, true, false, tcar_tuning().early_prologue != 0));
-  const Geo g(c->d);
-  const float* pieces = c->Gx + c->arena_n;
-  hipStream_t st = (hipStream_t)stream;
-  RET(tcar_clip_adam_2d_bf16(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip,
-                             lr_t, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, stream));
-  if (hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;
-  if (c->stream3 && c->ev3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;
-  return tcar_clip_adam(c->W, c->Gx, c->M, c->V, &c->segs_all, c->sqn_dense, pieces, c->use_dense, c->clip, lr_t, c->b1, c->b2, c->eps,
-                        stream);
+  RET(backward_impl(c, bt, stream, true));
+  return tcar_step_update(c, lr_t, stream);
 }
 
 extern "C" int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int pending,
@@ -671,20 +665,15 @@ extern "C" int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t*
   if (pending) {
     hipStream_t s2 = aux_stream(c);
     if (s2 && refresh_time && c->adam_bitmap) {
-      // EARLY part on the main stream: arena + the item rows this batch gathers; the REST runs inside the forward pass
-      const Geo g(c->d);
-      const float* pieces = c->Gx + c->arena_n;
-      RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
-                               c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, lr_pending, c->b1, c->b2, c->eps,
-                               c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq,
-                               (int64_t)bt->B * bt->T, c->adam_bitmap, stream));
+      // split update, issued by forward_impl: EARLY part on the main stream (arena + the item rows this batch gathers), the
+      // REST on the aux stream beside it and the session forward
       rest_lr = lr_pending;
     } else {
       RET(tcar_step_update(c, lr_pending, stream));
     }
   }
   RET(forward_impl(c, bt, refresh_time, stream, rest_lr, true));
-  return backward_impl(c, bt, stream, true, true, aux_stream(c) && tcar_tuning().early_prologue);
+  return backward_impl(c, bt, stream, true);
 }
 
 extern "C" int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream) {

@@ -50,28 +50,18 @@ static inline bool tcar_first_on_device(TcarOnce& o) {
 // Diagnostic tuning switches (environment, read ONCE per process at first use — C++11 thread-safe static — never per
 // launch).  Defaults are the shipped configuration; README.md lists them.  Defined in step.hip.
 struct TcarTuning {
-  int bf16_tile;        // TCAR_BF16_TILE      force a workgroup tile of the bf16 GEMM (0 = heuristic)
-  int dx512;            // TCAR_DX512          0 disables the 512 x 128 dX tile
-  int x3_xk;            // TCAR_X3_XK          stage depth of the small split-bf16 GEMM (0 = default)
-  int x3_ring;          // TCAR_X3_RING        stages the small GEMM keeps in flight in registers (1, 2 or 3)
+  int bf16_tile;        // TCAR_BF16_TILE      force a workgroup tile of the bf16 GEMM (0 = heuristic; tests pin every tile shape with it)
   int rest_grid;        // TCAR_REST_GRID      grid cap of the deferred Adam rest pass
   int softmax_variant;  // TCAR_SOFTMAX_VARIANT
   int wgrad_ks;         // TCAR_WGRAD_KS       K chunk of the weight-gradient split
-  int tile288;          // TCAR_TILE288        0 disables the 256 x 288 tile of the dX / dE GEMMs
   int gather_big_rows;  // TCAR_GATHER_BIG_ROWS  session rows from which the forward gather runs its throughput form
   int gather_wg_per_cu; // TCAR_GATHER_WG      1024-thread workgroups per CU of that form (2 x 78 KB of LDS fit)
-  int fused_q;          // TCAR_FUSED_Q        0: query-MLP backward as separate activation-backward launches
-  int planes_epi;       // TCAR_PLANES_EPI     0: attout's bf16 planes by tcar_split_bf16 instead of the GEMM epilogue
   int mha_mfma;         // TCAR_MHA_MFMA       0: multihead_attention core always in its scalar form
   int sort_scatter;     // TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum
   int bf16_ks;          // TCAR_BF16_KS        64-deep LDS stages of the hi-only bf16 GEMM: 1 never, 2 dX / logits layouts, 3 all
-  int de_late;          // TCAR_DE_LATE        1: the fused step starts dE after dX + slab reduce instead of beside them
   int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
-  int split_update;     // TCAR_SPLIT_UPDATE   1: item-table Adam before the cross-stream joins, arena after (measured slower)
-  int q_stream;         // TCAR_Q_STREAM       1: the click-query MLP of the forward pass on the third stream beside the projections
-  int early_prologue;   // TCAR_EARLY_PROLOGUE 1: arena memsets + negative-term forward forked before the logits GEMM (measured neutral)
-  int fuse_sqnorm;      // TCAR_FUSE_SQNORM    0: dense item-norm partials in their own launch instead of beside the item-row gradients
-  int dclick_aux;       // TCAR_DCLICK_AUX     1: the click-query input gradient GEMM on the aux stream (measured 5 us slower: the aux stream is co-critical)
+  int x3_oneshot;       // TCAR_X3_ONESHOT     0: short-K small-GEMM launches keep the one-stage register ring
+  int proj_split;       // TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs
 };
 const TcarTuning& tcar_tuning();
 

@@ -150,9 +150,8 @@ class TcarEngine:
         self.b1, self.b2, self.eps = 0.9, 0.999, 1e-8
         self.b1_pow, self.b2_pow = np.float32(self.b1), np.float32(self.b2)
         self.step = 0
-        # split-K of dX = dlogits E: 36 slabs with the 512 x 128 bf16 tile (7 N tiles x 36 = 252 workgroups), 16 in fp32;
-        # 42 with the optional 256 x 288 tile (TCAR_TILE288=1: 2 x 3 x 42 = 252)
-        self.splitk = splitk if splitk else (16 if scoring == "f32" else (42 if os.environ.get("TCAR_TILE288", "0") == "1" else 36))
+        # split-K of dX = dlogits E: 36 slabs with the 512 x 128 bf16 tile (7 N tiles x 36 = 252 workgroups), 16 in fp32
+        self.splitk = splitk if splitk else (16 if scoring == "f32" else 36)
         if os.environ.get("TCAR_SPLITK"):
             self.splitk = int(os.environ["TCAR_SPLITK"])
         # precision of the three full-catalog scoring GEMMs: "f32" (fp32 MFMA), "bf16x3" (split-bf16 planes, three
@@ -217,7 +216,7 @@ class TcarEngine:
         et_perm = np.empty(5 * nl, dtype=np.int32)
         et_perm[order] = np.arange(5 * nl, dtype=np.int32)
         self.et_perm = torch.tensor(et_perm, device=self.dev)
-        self.adam_bitmap = torch.zeros((nl + 31) // 32 + 1, dtype=torch.int32, device=self.dev)   # split update marks
+        self.adam_bitmap = torch.zeros(2 * ((nl + 31) // 32 + 1), dtype=torch.int32, device=self.dev)   # split update marks: skip | own
         self.ct_ws = torch.zeros(self.lib.tcar_cand_time_ws_floats(C.byref(self.dims_cand)), **f32)
         # segment tables for the optimizer kernels
         self.segs_all = self._segments([a[0] for a in ARENA])
@@ -761,6 +760,14 @@ class TcarEngine:
         if self.scoring_code:
             for n in ("e16h", "e16l", "a16h", "a16l", "ap16h", "ap16l", "dl16h", "dl16l"):
                 setattr(c, n, getattr(self, n).data_ptr())
+            # slab workspace of the split session-side GEMMs (forward projections: one slab per 128-deep K chunk; backward:
+            # the input gradient of the output transforms)
+            u = lambda k: (k + 127) // 128
+            need = max((u(g.ic) + 2 * u(g.ldh) + u(g.ldt) + u(g.pt)) * self.work_rows * g.ldh,
+                       max(u(g.ic), u(g.pt)) * self.work_B * g.ek)
+            if getattr(self, "_proj_slabs", None) is None or self._proj_slabs.numel() < need:
+                self._proj_slabs = torch.empty(need, dtype=torch.float32, device=self.dev)
+            c.proj_slabs, c.proj_slab_floats = self._proj_slabs.data_ptr(), self._proj_slabs.numel()
         if self.overlap:
             if not hasattr(self, "_aux"):
                 self._aux = torch.cuda.Stream(self.dev)

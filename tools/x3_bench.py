@@ -46,9 +46,7 @@ W = torch.randn(2048, N, device=dev) * 0.05
 Wt = torch.randn(512, 2048, device=dev) * 0.05
 Y = torch.empty(M, 512, device=dev)
 bias = torch.zeros(512, device=dev)
-for ring, xk in ((1, 0), (2, 0), (3, 0), (3, 32), (2, 128)):
-    lib.tcar_set_tuning(b"TCAR_X3_RING", ring)
-    lib.tcar_set_tuning(b"TCAR_X3_XK", xk)
+for ring, xk in ((1, 64),):      # (the ring-depth / stage-depth sweep of round 2 is in profiles/r02_x3_small_gemm_bench.txt)
     row = []
     for K in (64, 128, 256, 512, 1024, 2048):
         row.append("K=%d %.1f" % (K, timeit(0, [desc(M, N, [(X, 2048, W, N, K)], Y, 512)])))
