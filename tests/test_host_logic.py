@@ -41,30 +41,6 @@ def test_tuning_switch_defaults():
     want = {"TCAR_BF16_TILE": 0, "TCAR_REST_GRID": 512, "TCAR_SOFTMAX_VARIANT": 1, "TCAR_WGRAD_KS": 1536,
             "TCAR_GATHER_BIG_ROWS": 16384, "TCAR_GATHER_WG": 2, "TCAR_MHA_MFMA": 1, "TCAR_SORT_SCATTER": 1, "TCAR_BF16_KS": 2,
             "TCAR_DET_SMALL": 1, "TCAR_X3_ONESHOT": 1, "TCAR_PROJ_SPLIT": 1}
-    header = open(os.path.join(ROOT, "include", "tcar_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|int64_t|float\*|const char\*) (tcar_\w+)\(", header, flags=re.M))
-    assert declared == set(_lib.SYMBOLS)
-    for s in declared:
-        assert hasattr(lib, s)
-    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 15
-    # the binary carries the digest of the sources it was built from; the loader refuses a stale one
-    assert lib.tcar_build_id().decode() == _lib.source_build_id() == _lib.binary_build_id()
-    assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
-    assert lib.tcar_gemm_splitk_effective(64, 16) == 2
-
-
-def test_tuning_switch_defaults():
-    """Every TCAR_* switch of csrc/tcar_common.h is reachable by name and holds its documented default (one table in
-    step.hip: name, field, default)."""
-    lib = _lib.load()
-    lib.tcar_set_tuning.argtypes = [C.c_char_p, C.c_int]
-    lib.tcar_set_tuning.restype = C.c_int
-    env = {k: v for k, v in os.environ.items() if k.startswith("TCAR_")}
-    want = {"TCAR_BF16_TILE": 0, "TCAR_DX512": 1, "TCAR_X3_XK": 0, "TCAR_X3_RING": 1, "TCAR_REST_GRID": 512, "TCAR_SOFTMAX_VARIANT": 1,
-            "TCAR_WGRAD_KS": 1536, "TCAR_TILE288": 0, "TCAR_GATHER_BIG_ROWS": 16384, "TCAR_GATHER_WG": 2, "TCAR_FUSED_Q": 1,
-            "TCAR_PLANES_EPI": 1, "TCAR_MHA_MFMA": 1, "TCAR_SORT_SCATTER": 1, "TCAR_BF16_KS": 2, "TCAR_DE_LATE": 0,
-            "TCAR_DET_SMALL": 1, "TCAR_SPLIT_UPDATE": 0, "TCAR_Q_STREAM": 0, "TCAR_EARLY_PROLOGUE": 0, "TCAR_FUSE_SQNORM": 1,
-            "TCAR_DCLICK_AUX": 0}
     header = open(os.path.join(ROOT, "session-based-news-recommendation_amd", "csrc", "tcar_common.h")).read()
     documented = set(re.findall(r"// (TCAR_[A-Z0-9_]+)\b", header[header.index("struct TcarTuning"):header.index("const TcarTuning& tcar_tuning()")]))
     assert documented == set(want), documented ^ set(want)
