@@ -209,22 +209,38 @@ def main():
                          "logits / HR@20 / MRR@20 gate of the north star), the two gradient GEMMs in plain bf16, fp32 "
                          "accumulation and fp32 master state throughout; bf16x3: all three GEMMs fp32-class")
     ap.add_argument("--launch_check", action="store_true",
-                    help="CPU-only check of the rank launch: rendezvous over gloo, one all-reduce, print n_gpus (tests/)")
+                    help="only the rank launch + the three collectives of the exchanges on tiny tensors (dp.preflight): with "
+                         "--backend gloo on CPU (tests/), with nccl on the GPUs; prints n_gpus and the backend / RCCL versions")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))           # before any import of torch: this process never initialises a GPU
     if args.launch_check:
+        # the rank launch and the three collectives of the exchanges, nothing else: `--launch_check --backend gloo` runs on CPU
+        # tensors (tests/test_bench_launch.py), `--launch_check` (nccl = RCCL) puts rank r on cuda:r — a failing rendezvous or
+        # collective names itself here (backend, world, device, library versions) and exits non-zero
         import torch
         import torch.distributed as dist
+        import tcar_amd  # noqa: F401
+        from tcar_amd.dp import preflight
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if world > 1:
-            dist.init_process_group("gloo")
-            t = torch.ones(1)
-            dist.all_reduce(t)
-            assert int(t.item()) == world
+            on_gpu = args.backend == "nccl"
+            dev = None
+            if on_gpu:
+                lr = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+                torch.cuda.set_device(lr)
+                dev = "cuda:%d" % lr
+                dist.init_process_group("nccl", device_id=torch.device(dev))
+            else:
+                dist.init_process_group(args.backend)
+            try:
+                info = preflight(dist.group.WORLD, dev)
+            except Exception as e:
+                print("[tcar] launch_check FAILED on rank %s: %s" % (os.environ.get("RANK"), e), file=sys.stderr)
+                sys.exit(3)
             if dist.get_rank() == 0:
-                print(json.dumps({"metric": "launch_check", "n_gpus": world}))
+                print(json.dumps({"metric": "launch_check", "n_gpus": world, "collectives": info}))
             dist.destroy_process_group()
         else:
             print(json.dumps({"metric": "launch_check", "n_gpus": 1}))
@@ -254,6 +270,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # first contact: the three collectives of the exchanges on tiny tensors, before anything large is built; a job that
+        # cannot communicate says so here (backend, world, device, RCCL version) and exits non-zero
+        from tcar_amd.dp import preflight
+        try:
+            caps = preflight(dist.group.WORLD, dev)
+        except Exception as e:
+            print("[tcar] rank %d: %s" % (rank, e), file=sys.stderr)
+            sys.exit(3)
 
     B, K = args.batch_size, args.neg_num
     lean = bool(cfg["fold"].get("lean"))

@@ -84,6 +84,59 @@ class GradExchange:
         self.finish(all_ids, all_rows, sqnorm_item, cand_time_bwd, scatter_rows, sqnorm_dense)
 
 
+def preflight(group=None, device=None, verbose: bool = True) -> Dict[str, object]:
+    """First contact with the process group: ONE tiny all_gather_into_tensor, reduce_scatter_tensor and all_reduce (the three
+    collectives the two exchanges use) on `device`, checked against their known answers, before any large buffer exists.  A job
+    whose collectives cannot run fails HERE with the backend, world size, device and library versions in the message instead
+    of inside step 1.  Returns the capabilities ({"reduce_scatter": bool, ...}); `reduce_scatter` False (gloo has none) makes
+    ShardedEngine reduce dX with an all-reduce."""
+    import sys
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"world": 1, "backend": "none", "reduce_scatter": False}
+    world, rank, backend = dist.get_world_size(group), dist.get_rank(group), dist.get_backend(group)
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    info = {"world": world, "rank": rank, "backend": backend, "device": str(dev), "torch": torch.__version__,
+            "hip": getattr(torch.version, "hip", None), "reduce_scatter": False}
+    try:
+        if backend == "nccl":
+            info["rccl"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception as e:                                   # version query only: never fatal
+        info["rccl"] = "unknown (%s)" % type(e).__name__
+    step = "all_reduce"
+    try:
+        t = torch.full((4,), float(rank + 1), device=dev)
+        dist.all_reduce(t, group=group)
+        want = world * (world + 1) / 2.0
+        if not bool((t == want).all()):
+            raise RuntimeError("all_reduce returned %r, expected %r" % (t.tolist(), want))
+        step = "all_gather_into_tensor"
+        mine = torch.full((3,), float(rank), device=dev)
+        out = torch.empty(world * 3, device=dev)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        if out.view(world, 3)[:, 0].tolist() != [float(r) for r in range(world)]:
+            raise RuntimeError("all_gather_into_tensor returned %r" % out.tolist())
+        step = "reduce_scatter_tensor"
+        try:
+            full = torch.arange(world * 2, dtype=torch.float32, device=dev) + rank
+            part = torch.empty(2, device=dev)
+            dist.reduce_scatter_tensor(part, full, group=group)
+            exp = [world * (2 * rank + j) + world * (world - 1) / 2.0 for j in range(2)]
+            if part.tolist() != exp:
+                raise RuntimeError("reduce_scatter_tensor returned %r, expected %r" % (part.tolist(), exp))
+            info["reduce_scatter"] = True
+        except (RuntimeError, NotImplementedError) as e:
+            if backend == "nccl":
+                raise
+            info["reduce_scatter_error"] = "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:120])
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+    except Exception as e:
+        raise RuntimeError("collective preflight failed at %s (%s): %s: %s" % (step, info, type(e).__name__, e)) from e
+    if verbose and rank == 0:
+        print("[tcar] collective preflight ok: %s" % info, file=sys.stderr)
+    return info
+
+
 def shard_bounds(b: int, world: int, rank: int):
     """Contiguous split of a length-bucketed batch of b sessions (sampler.py:40-49) into `world` shards of
     ceil(b/world); trailing ranks may get fewer (or zero) rows.  Returns (lo, hi, cap)."""

@@ -82,6 +82,8 @@ class ShardedEngine(TcarEngine):
         self.nlpad = _ru(nl, 128)
         self.n_local_items = nl
         self.backend = dist.get_backend(group) if live and self.world > 1 else "none"
+        # dX is reduce-scattered where the backend can (RCCL); gloo (CPU tests, single-GPU dry runs) all-reduces it
+        self.use_reduce_scatter = self.backend == "nccl"
         self.cap = 0
         self._stage = torch.zeros(self.world, self.S, self.geo.ldh, dtype=torch.float32, device=self.dev)
         self.bytes_moved = {}
@@ -103,7 +105,7 @@ class ShardedEngine(TcarEngine):
         if self.world == 1 or self._sim:
             return full[:cap]
         self.bytes_moved[key] = full.numel() * full.element_size()
-        if self.backend == "nccl":
+        if self.use_reduce_scatter:
             out = torch.empty(cap, full.shape[1], dtype=full.dtype, device=full.device)
             dist.reduce_scatter_tensor(out, full, group=self.group)
             return out
