@@ -19,6 +19,7 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
+    {"TCAR_REST_EARLY", &TcarTuning::rest_early, 1},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -250,7 +251,23 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
     hipStream_t st_time = s2;          // the stream that rebuilds the candidate-side time block
-    if (s2 && rest_lr >= 0.f) {
+    if (s2 && rest_lr >= 0.f && !tcar_tuning().rest_early) {
+      // (A/B) round-2 order: early pass, then the time refresh and the rest pass on the aux stream
+      const float* pieces = c->Gx + c->arena_n;
+      RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
+                               c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
+                               c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT,
+                               c->adam_bitmap, stream));
+      if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
+        return TCAR_E_LAUNCH;
+      RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, (void*)s2));
+      RET(tcar_clip_adam_rest(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
+                              c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
+                              c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2));
+      if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+      joined = false;
+      st_time = nullptr;
+    } else if (s2 && rest_lr >= 0.f) {
       // The pending split update (tcar_train_step_deferred).  Three things start together:
       //   main:  mark the rows this batch gathers -> EARLY pass (arena + those rows) -> gather ...
       //   aux:   [after the marks]  REST pass over every other item row (the 60-us HBM-bound pass), sort index
@@ -277,13 +294,15 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
         return TCAR_E_LAUNCH;
     }
-    RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
-                                st_time ? (void*)st_time : stream));
+    const bool time_done = s2 && rest_lr >= 0.f && !tcar_tuning().rest_early;
+    if (!time_done)
+      RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
+                                  st_time ? (void*)st_time : stream));
     if (st_time && st_time == s3) {
       if (hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
       joined3 = false;
     }
-    if (s2) {
+    if (s2 && !time_done) {
       if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
       joined = false;
     }

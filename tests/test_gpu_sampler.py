@@ -72,7 +72,7 @@ def test_negative_modes_follow_the_reference_rules():
     assert np.array_equal(d, a[perm])                                       # keyed by the example, not by its batch row
     # ---- neighbour (sampler.py:133-140): picks from the label's list, never the label
     nb = fold.neighbor_dict(k=30)
-    nb[int(lab[0])] = nb[int(lab[0])] + [int(lab[0])] * 50                  # a list polluted with its own key
+    nb[int(lab[0])] = [int(x) for x in nb[int(lab[0])]] + [int(lab[0])] * 50   # a list polluted with its own key
     ds = DeviceSampler(eng, st, "neighbor", neighbor_dict=nb, seed=5)
     neg = ds.read_back(ds.form(idx, K))["neg"]
     assert (neg != lab[:, None]).all()
