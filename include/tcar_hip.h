@@ -231,6 +231,20 @@ int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* A_hi, const
                         int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C,
                         int64_t ldc, float* C2, int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit,
                         int splitk, void* stream);
+/* Logits GEMM with the softmax EPILOGUE (model_combine.py:138 + :145 without materialising [M, N] fp32 logits): layout 1 of
+ * tcar_gemm_bf16 (C = A B^T, both operands k-contiguous).  Instead of C the kernel writes
+ *   p_hi   bf16 KB32 plane [ceil128(M) rows, p_inner]: exp(x[m, n] - gmax[m, group(n)]), 0 for n >= N;
+ *   stats  [M, *ngroups, 2] floats: (group maximum, sum of the group's exponentials) — a group = *group_width (64 or 96)
+ *          consecutive columns, the slice one wave of the chosen workgroup tile owns; stats_floats >= M * (ceil(N/64) + 8) * 2;
+ *   lab_logit [M]: x[m, label[m]].
+ * tcar_ce_finish combines the groups of every row (lse, ce = lse - x_label), then rescales the plane IN PLACE to
+ * softmax - onehot (the dlogits operand of the two gradient GEMMs, hi plane only) and zeroes rows [B, ceil128(B)).  rowstat [B, 2]. */
+int tcar_gemm_bf16_ce(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows, const void* B_hi,
+                      const void* B_lo, int64_t b_inner, int64_t b_rows, void* p_hi, int64_t p_inner, int64_t p_rows, float* stats,
+                      int64_t stats_floats, const int32_t* label, float* lab_logit, int nsplit, int32_t* group_width /*host*/,
+                      int32_t* ngroups /*host*/, void* stream);
+int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
+                   float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream);
 /* Names the kernel instantiation (template arguments, workgroup tile, grid) that tcar_gemm_bf16 would launch for this
  * problem, without launching it (profiling tools match rocprofv3 kernel names with it).  buf: host, buflen >= 96. */
 int tcar_gemm_bf16_variant(int layout, int M, int N, int K, int nsplit, int splitk, char* buf /*host*/, int buflen);
@@ -513,7 +527,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 15
+#define TCAR_ABI_VERSION 16
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -588,6 +602,10 @@ typedef struct {
    * one 128-deep K chunk per workgroup, each chunk into its own slab, folded in slab order by tcar_attn_pool_fwd_slabs; the
    * backward pass reuses it for the input gradient of the output transforms (tcar_attn_pool_bwd_slabs) */
   float* proj_slabs; int64_t proj_slab_floats;
+  /* optional workspace of the softmax epilogue (training steps with scoring_bwd == 1): B * (ceil(N / 64) + 8) * 2 + 4 B floats,
+   * 16-byte aligned, and two HOST ints that carry the group geometry from the forward to the backward half of a step.  With it
+   * the logits GEMM of a training step does not write [B, N] fp32 logits (tcar_gemm_bf16_ce + tcar_ce_finish). */
+  float* ce_ws; int64_t ce_ws_floats; int32_t* ce_geo /*host*/;
 } tcar_ctx_t;
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */

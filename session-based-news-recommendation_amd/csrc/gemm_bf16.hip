@@ -45,6 +45,12 @@ struct BArgs {
   int n_fastest;               // tile order inside the XCD-contiguous id run: 1 = consecutive ids walk the N tiles
   const int32_t* perm;         // optional grouped row permutation of the C2 destination (see tcar_gemm_bf16), else NULL
   int pgroup;                  // columns per permutation group
+  // softmax epilogue (EPI = 1, tcar_gemm_bf16_ce): instead of C the kernel writes, per row and per column GROUP (the 32 * TNW
+  // columns one wave owns), the group maximum and the sum of exp(x - max), the exponentials themselves as a bf16 KB32 plane,
+  // and the label's score
+  __bf16* p_hi; int p_in32;    // plane [ceil128(M), 32 * p_in32]
+  float* stats; int ngroups;   // [M, ngroups, 2]
+  const int32_t* label; float* lab_logit;
 };
 
 typedef __attribute__((address_space(3))) void* lds_vp;
@@ -74,7 +80,7 @@ __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int
 // tiles = 192 registers, 2 waves per SIMD) for the 256 x 384 workgroup tile of the logits GEMM
 // KS = 32-deep k blocks per LDS stage: the hi-only (NSPLIT = 1) form has a third of the MFMA work between two barriers
 // and half the bytes per stage, so it takes 64-deep stages (same LDS as the two-plane form, half the barriers).
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1>
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1, int EPI = 0>
 __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW;
@@ -188,8 +194,50 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
     __syncthreads();
   }
 
-  float* C1 = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
   const int li = lane & 31, lh = lane >> 5;
+  if constexpr (EPI == 1) {
+    // Softmax epilogue (model_combine.py:145 without materialised logits).  The wave owns rows x GW = 32 * TNW columns; a row
+    // of an MFMA tile lives in the 32 lanes of one half wave (column = lane & 31), so group maximum and sum are TNW in-lane
+    // steps + 5 xor-shuffles.  exp(x - group max) <= 1 goes out as bf16; tcar_ce_finish combines the (max, sum) pairs of a
+    // row into its log-sum-exp and rescales the plane in place to softmax - onehot.
+    constexpr int GW = 32 * TNW;
+    const int gidx = (n0 + wn * GW) / GW;
+    const int cb = n0 + wn * GW + li;
+    const int pcols = g.p_in32 << 5;
+#pragma unroll
+    for (int u = 0; u < TMW; ++u) {
+      const int row0 = m0 + wm * (32 * TMW) + u * 32 + 4 * lh;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = row0 + (e & 3) + 8 * (e >> 2);
+        const bool live = row < g.M;
+        float v[TNW];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) {
+          v[t] = (cb + 32 * t < g.N) ? acc[u][t][e] : -INFINITY;
+          mx = fmaxf(mx, v[t]);
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const int lab = live ? g.label[row] : -1;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) {
+          const float pe = (v[t] == -INFINITY) ? 0.f : __expf(v[t] - mx);
+          sum += pe;
+          const int col = cb + 32 * t;
+          if (live && col < pcols) g.p_hi[kb32_off(row, col, g.p_in32)] = (__bf16)pe;
+          if (live && col == lab) g.lab_logit[row] = v[t];
+        }
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o);
+        if (live && li == 0) *reinterpret_cast<float2*>(g.stats + ((long)row * g.ngroups + gidx) * 2) = make_float2(mx, sum);
+      }
+    }
+    return;
+  }
+  float* C1 = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
 #pragma unroll
   for (int u = 0; u < TMW; ++u)
 #pragma unroll
@@ -263,6 +311,8 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 // instead of launched
 thread_local char* t_variant_out = nullptr;
 thread_local int t_variant_len = 0;
+// group geometry of the last softmax-epilogue launch of this host thread (tcar_gemm_bf16_ce returns it to its caller)
+thread_local int t_ce_gw = 0, t_ce_ngroups = 0;
 
 template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW, int TNW, int KS>
 int launch_k(BArgs& g, int splitk, hipStream_t st) {
@@ -274,6 +324,20 @@ int launch_k(BArgs& g, int splitk, hipStream_t st) {
     snprintf(t_variant_out, t_variant_len, "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d, %d> tile %dx%dx%d grid %d", MA, MB, NSPLIT,
              WMW, WNW, TMW, TNW, TM, TN, 32 * KS, g.mt * g.nt * splitk);
     return TCAR_OK;
+  }
+  if (g.p_hi) {      // softmax epilogue: logits layout only
+    if constexpr (MA == 0 && MB == 0) {
+      if (splitk != 1 || g.C2 != g.C) return TCAR_E_ARG;
+      g.ngroups = g.nt * WNW;
+      t_ce_gw = 32 * TNW;
+      t_ce_ngroups = g.ngroups;
+      TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1>), lds);
+      TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1>), dim3(g.mt * g.nt), dim3(NT), lds, st, g);
+      TCAR_CHECK_LAUNCH();
+      return TCAR_OK;
+    } else {
+      return TCAR_E_ARG;
+    }
   }
   TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS>), lds);
   TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
@@ -347,10 +411,48 @@ extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi,
                              csplit, nullptr, 0, nsplit, splitk, stream);
 }
 
+namespace {
+struct CeOut { void* p_hi; int64_t p_inner; float* stats; const int32_t* label; float* lab_logit; };
+int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
+                   const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
+                   int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit, int splitk, const CeOut* ce,
+                   void* stream);
+}  // namespace
+
 extern "C" int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner,
                                    int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows,
                                    float* C, int64_t ldc, float* C2, int64_t ldc2, int csplit, const int32_t* c2_perm,
                                    int c2_group, int nsplit, int splitk, void* stream) {
+  if (!C) return (M <= 0 || N <= 0 || K <= 0) ? TCAR_OK : TCAR_E_ARG;
+  return gemm_bf16_impl(layout, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, C, ldc, C2, ldc2, csplit,
+                        c2_perm, c2_group, nsplit, splitk, nullptr, stream);
+}
+
+extern "C" int tcar_gemm_bf16_ce(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
+                                 const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, void* p_hi, int64_t p_inner,
+                                 int64_t p_rows, float* stats, int64_t stats_floats, const int32_t* label, float* lab_logit,
+                                 int nsplit, int32_t* group_width, int32_t* ngroups, void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
+  if (!p_hi || !stats || !label || !lab_logit || !group_width || !ngroups || (p_inner & 31) || p_inner < N || p_rows < M ||
+      !tcar_aligned16(p_hi) || ((uintptr_t)stats & 7))
+    return TCAR_E_ARG;
+  // every tile of the logits layout has groups of at least 64 columns: [M, ceil(N / 64), 2] floats always suffice
+  if (stats_floats < (int64_t)M * ((N + 63) / 64 + 8) * 2) return TCAR_E_ARG;
+  const CeOut ce = {p_hi, p_inner, stats, label, lab_logit};
+  float dummy;
+  const int rc = gemm_bf16_impl(1, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, &dummy, N, nullptr, 0, 0,
+                                nullptr, 0, nsplit, 1, &ce, stream);
+  if (rc) return rc;
+  *group_width = t_ce_gw;
+  *ngroups = t_ce_ngroups;
+  return TCAR_OK;
+}
+
+namespace {
+int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
+                   const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
+                   int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit, int splitk, const CeOut* ce,
+                   void* stream) {
   if (c2_perm && (!C2 || c2_group <= 0 || splitk > 1)) return TCAR_E_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
   if (layout < 0 || layout > 2 || !A_hi || !B_hi || !C || (nsplit != 1 && nsplit != 3)) return TCAR_E_ARG;
@@ -368,6 +470,11 @@ extern "C" int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* 
   g.C = C; g.ldc = ldc;
   g.C2 = C2 ? C2 : C; g.ldc2 = C2 ? ldc2 : ldc; g.csplit = C2 ? csplit : N;
   g.perm = c2_perm; g.pgroup = c2_group;
+  g.p_hi = nullptr; g.p_in32 = 0; g.stats = nullptr; g.ngroups = 0; g.label = nullptr; g.lab_logit = nullptr;
+  if (ce) {
+    g.p_hi = (__bf16*)ce->p_hi; g.p_in32 = (int)(ce->p_inner >> 5); g.stats = ce->stats; g.label = ce->label;
+    g.lab_logit = ce->lab_logit;
+  }
   g.M = M; g.N = N; g.K = K;
   if (splitk < 1) splitk = 1;
   if (splitk > 1 && C2) return TCAR_E_ARG;
@@ -383,6 +490,7 @@ extern "C" int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* 
   if (layout == 1) return launch_b<0, 0>(g, nsplit, splitk, st);
   return launch_b<1, 1>(g, nsplit, splitk, st);
 }
+}  // namespace
 
 extern "C" int tcar_gemm_bf16_variant(int layout, int M, int N, int K, int nsplit, int splitk, char* buf, int buflen) {
   if (!buf || buflen < 8 || layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || (K & 31)) return TCAR_E_ARG;

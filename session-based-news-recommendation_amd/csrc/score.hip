@@ -174,6 +174,80 @@ __global__ __launch_bounds__(NT) void softmax_ce_rows_kernel(int B, int N, float
   }
 }
 
+// ---- softmax cross entropy from the logits GEMM's softmax epilogue (tcar_gemm_bf16_ce, gemm_bf16.hip) -----------------
+// The epilogue left, per session row and column group g, (m_g, s_g) = (group maximum, sum of exp(x - m_g)), the plane
+// e[b, n] = bf16(exp(x - m_g(n))) and the label's score.  Combine: M = max_g m_g, S = sum_g s_g exp(m_g - M),
+// lse = M + log S, ce = lse - x_label (model_combine.py:145).  One wave per row.
+__global__ __launch_bounds__(256) void ce_combine_kernel(int B, int ngroups, const float* __restrict__ stats,
+                                                         const float* __restrict__ lab_logit, float* __restrict__ rowstat,
+                                                         float* __restrict__ ce) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float2* st = reinterpret_cast<const float2*>(stats) + (long)b * ngroups;
+  float m = -INFINITY;
+  for (int g = lane; g < ngroups; g += 64) m = fmaxf(m, st[g].x);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int g = lane; g < ngroups; g += 64) {
+    const float2 v = st[g];
+    if (v.x != -INFINITY) s += v.y * expf(v.x - m);
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    rowstat[2 * b] = m;
+    rowstat[2 * b + 1] = 1.0f / s;
+    ce[b] = m + logf(s) - lab_logit[b];
+  }
+}
+// Rescale in place: plane[b, n] = bf16( e[b, n] * exp(m_g - M) / S - [n == label_b] ) = softmax - onehot, the gradient of the
+// SUM of the per-session losses (model_combine.py:147,156); rows [B, ceil128(B)) are zeroed (they are k-rows of dE).
+// One thread per (row, 32-column block) = 64 contiguous bytes of the KB32 plane: a wave streams 4 KB.
+template <int GW>
+__global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
+                                                         const float* __restrict__ rowstat, const int32_t* __restrict__ label,
+                                                         __bf16* __restrict__ plane, long nunits) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nunits) return;
+  const long blk = i >> 7;
+  const int r = (int)(i & 127);
+  const long rb = blk / in32;
+  const int kb = (int)(blk - rb * in32);
+  const long row = rb * 128 + r;
+  uint4* p = reinterpret_cast<uint4*>(plane + blk * 4096 + r * 32);
+  if (row >= B) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = z;
+    return;
+  }
+  uint4 v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = p[q];
+  const int col0 = kb * 32;
+  const float mg = stats[((long)row * ngroups + col0 / GW) * 2];
+  const float2 rs = *reinterpret_cast<const float2*>(rowstat + 2 * row);
+  const float c = (mg == -INFINITY) ? 0.f : expf(mg - rs.x) * rs.y;
+  const int lab = clampi(label[row], 0, N - 1) - col0;          // label's column inside this block, if 0 <= lab < 32
+  const int sw = (r >> 2) & 3;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int piece = q ^ sw;                                   // storage position q holds logical piece q ^ sw
+    unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // two bf16 per dword: low half = even element
+      float lo = __uint_as_float(w[j] << 16) * c, hi = __uint_as_float(w[j] & 0xffff0000u) * c;
+      const int k = piece * 8 + j * 2;
+      if (k == lab) lo -= 1.f;
+      if (k + 1 == lab) hi -= 1.f;
+      const __bf16 bl = (__bf16)lo, bh = (__bf16)hi;
+      w[j] = (unsigned)__builtin_bit_cast(unsigned short, bl) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+    }
+    p[q] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
 // ---- negative-feedback term (model_combine.py:142-143) ---------------------------------------------------
 // One wave per session: gathers K item|content rows of E (2 x 16 B per lane per row), dots them with attout_ic.
 template <int NCH>
@@ -608,6 +682,26 @@ extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, con
   }
   TCAR_LAUNCH(softmax_ce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, N, logits, (long)ld, label, ce,
               (__bf16*)dl_hi, (__bf16*)dl_lo);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit,
+                              const int32_t* label, float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (N <= 0 || !stats || !lab_logit || !label || !rowstat || !ce || !dl_hi || (inner & 31) || inner < N || ngroups <= 0 ||
+      (group_width != 64 && group_width != 96) || (long)ngroups * group_width < N || ((uintptr_t)rowstat & 7))
+    return TCAR_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  TCAR_LAUNCH(ce_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, ngroups, stats, lab_logit, rowstat, ce);
+  TCAR_CHECK_LAUNCH();
+  const int in32 = (int)(inner >> 5);
+  const long nunits = (((long)B + 127) >> 7) * in32 * 128;
+  const unsigned grid = (unsigned)((nunits + 255) / 256);
+  if (group_width == 96)
+    TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits);
+  else
+    TCAR_LAUNCH(ce_rescale_kernel<64>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

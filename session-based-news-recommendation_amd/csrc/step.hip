@@ -19,7 +19,7 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_REST_EARLY", &TcarTuning::rest_early, 1},
+    {"TCAR_REST_EARLY", &TcarTuning::rest_early, 1},         {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -103,6 +103,18 @@ void grads_of(const tcar_ctx_t* c, tcar_grads_t& g) {
 // the small contractions follow the scoring precision: exact fp32 MFMA in "f32" mode, split-bf16 otherwise
 inline int small_gemm(const tcar_ctx_t* c, int layout, int n, const tcar_gemm_desc_t* p, void* stream) {
   return c->scoring ? tcar_gemm_x3_grouped(layout, n, p, stream) : tcar_gemm_f32_grouped(layout, n, p, stream);
+}
+
+// softmax epilogue of the logits GEMM (training steps of the hi-only backward precision): workspace [rowstat 2B | label score B |
+// group stats]; the logits are not materialised
+struct CeWs { float* rowstat; float* lab; float* stats; int64_t stats_floats; };
+inline bool fused_ce(const tcar_ctx_t* c, int B, CeWs* w) {
+  if (!c->scoring || c->scoring_bwd != 1 || !c->ce_ws || !tcar_tuning().fused_ce) return false;
+  const int64_t head = 2L * B + ((B + 1) & ~1);
+  const int64_t need = (int64_t)B * ((c->d.n_items + 63) / 64 + 8) * 2;
+  if (c->ce_ws_floats < head + need) return false;
+  if (w) { w->rowstat = c->ce_ws; w->lab = c->ce_ws + 2L * B; w->stats = c->ce_ws + head; w->stats_floats = c->ce_ws_floats - head; }
+  return true;
 }
 
 inline hipStream_t aux_stream(const tcar_ctx_t* c) {
@@ -329,8 +341,19 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   if (c->scoring) {
     // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
-    rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
-                        nullptr, 0, 0, c->scoring, 1, stream);
+    CeWs w;
+    if (train_index && fused_ce(c, B, &w)) {
+      // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes
+      // dlogits, plus per-group (max, sum) — no [B, N] fp32 logits; backward_impl finishes with tcar_ce_finish
+      int32_t gw = 0, ng = 0;
+      rc = tcar_gemm_bf16_ce(B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->dl16h, g.Npad,
+                             (B + 127) & ~127, w.stats, w.stats_floats, bt->label, w.lab, c->scoring, &gw, &ng, stream);
+      if (!rc && c->ce_geo) { c->ce_geo[0] = gw; c->ce_geo[1] = ng; }
+      else if (!rc) rc = TCAR_E_ARG;
+    } else {
+      rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
+                          nullptr, 0, 0, c->scoring, 1, stream);
+    }
   } else {
     start_timer();
     rc = tcar_gemm_f32(1, B, g.N, g.ek, c->attout, g.ek, c->E, g.ek, c->logits, g.Npad, nullptr, 0, 0, 1, stream);
@@ -408,7 +431,7 @@ int cand_time_backward(const tcar_ctx_t* c, const Geo& g, void* stream);
 // Every cross-stream join costs ~10 us of launch latency behind an event, so there are as few as the data flow allows.
 // Rank-local backward of the data-parallel step (fuse_finish = false): dE and the negative rows run FIRST on the main
 // stream (their all-reduce then overlaps everything else, dp.py); the finish is tcar_step_finish after the exchange.
-int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish) {
+int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, bool fuse_finish, bool ce_epilogue = false) {
   RET(check_ctx(c, bt));
   const Geo g(c->d);
   const int B = bt->B, T = bt->T, BT = B * T, K = bt->K;
@@ -432,7 +455,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // backward precision: scoring_bwd (1 = hi planes only) or the forward precision
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   // hi-only backward (bf16x3-mixed, bf16): the lo plane of dlogits is never read — and not written
-  if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
+  CeWs cw;
+  if (ce_epilogue && fused_ce(c, B, &cw))   // the forward pass of THIS step ran the softmax epilogue (same predicate)
+    RET(tcar_ce_finish(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream));
+  else if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   if (s2) {
     if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
@@ -673,7 +699,7 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
 
 extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {
   RET(forward_impl(c, bt, refresh_time, stream, -1.f, true));
-  RET(backward_impl(c, bt, stream, true));
+  RET(backward_impl(c, bt, stream, true, true));
   return tcar_step_update(c, lr_t, stream);
 }
 
@@ -692,7 +718,7 @@ extern "C" int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t*
     }
   }
   RET(forward_impl(c, bt, refresh_time, stream, rest_lr, true));
-  return backward_impl(c, bt, stream, true);
+  return backward_impl(c, bt, stream, true, true);
 }
 
 extern "C" int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream) {

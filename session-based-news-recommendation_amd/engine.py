@@ -768,6 +768,13 @@ class TcarEngine:
             if getattr(self, "_proj_slabs", None) is None or self._proj_slabs.numel() < need:
                 self._proj_slabs = torch.empty(need, dtype=torch.float32, device=self.dev)
             c.proj_slabs, c.proj_slab_floats = self._proj_slabs.data_ptr(), self._proj_slabs.numel()
+            if self.scoring_bwd == 1:
+                # softmax epilogue of the logits GEMM (training steps): per-group (max, sum) pairs, label scores, row statistics
+                need = self.work_B * ((g.N + 63) // 64 + 8) * 2 + 4 * self.work_B + 8
+                if getattr(self, "_ce_ws", None) is None or self._ce_ws.numel() < need:
+                    self._ce_ws = torch.empty(need, dtype=torch.float32, device=self.dev)
+                    self._ce_geo = (C.c_int32 * 2)(0, 0)
+                c.ce_ws, c.ce_ws_floats, c.ce_geo = self._ce_ws.data_ptr(), self._ce_ws.numel(), C.cast(self._ce_geo, C.c_void_p)
         if self.overlap:
             if not hasattr(self, "_aux"):
                 self._aux = torch.cuda.Stream(self.dev)

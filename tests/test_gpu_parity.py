@@ -443,6 +443,63 @@ def _planes(lib, x):
     return hi, lo, inner, rows
 
 
+@pytest.mark.parametrize("M,N,K,nsplit", [(300, 1000, 64, 3), (77, 129, 96, 3), (512, 46033, 832, 3), (130, 5000, 832, 1)])
+def test_logits_gemm_softmax_epilogue(lib, M, N, K, nsplit):
+    """tcar_gemm_bf16_ce + tcar_ce_finish (model_combine.py:138,145 without materialised logits): per-group (max, sum) statistics,
+    the label's score, the cross entropy, and the in-place rescaled plane softmax - onehot against fp64 — on every workgroup
+    tile of the logits layout (group width 64 and 96), ragged M and N, padding rows / columns zero."""
+    rng = np.random.RandomState(M + N)
+    A = (rng.standard_normal((M, K)) * 0.7).astype(np.float32)
+    Bm = (rng.standard_normal((N, K)) * 0.6).astype(np.float32)
+    label = rng.randint(0, N, M).astype(np.int32)
+    label[0], label[-1] = 0, N - 1
+    x = A.astype(np.float64) @ Bm.astype(np.float64).T
+    if nsplit == 1:          # hi planes only: the reference rounds the operands the same way
+        x = torch.tensor(A).bfloat16().double().numpy() @ torch.tensor(Bm).bfloat16().double().numpy().T
+    ah, al, ai, ar = _planes(lib, A)
+    bh, bl, bi, br = _planes(lib, Bm)
+    Np, Mp = (N + 127) // 128 * 128, (M + 127) // 128 * 128
+    plane = torch.full((Mp * Np,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    nstat = M * ((N + 63) // 64 + 8) * 2
+    stats = torch.full((nstat,), float("nan"), device="cuda")
+    lab_d = torch.tensor(label).cuda()
+    lab_logit = torch.zeros(M, device="cuda")
+    rowstat, ce = torch.zeros(2 * M, device="cuda"), torch.zeros(M, device="cuda")
+    gw, ng = C.c_int32(0), C.c_int32(0)
+    assert lib.tcar_gemm_bf16_ce(M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr2(plane), Np, Mp, ptr(stats), nstat,
+                                 ptr2(lab_d), ptr(lab_logit), nsplit, C.byref(gw), C.byref(ng), None) == 0
+    gw, ng = gw.value, ng.value
+    assert gw in (64, 96) and ng * gw >= N
+    st = stats[:M * ng * 2].view(M, ng, 2).cpu().numpy().astype(np.float64)
+    xp = np.full((M, ng * gw), -np.inf)
+    xp[:, :N] = x
+    xg = xp.reshape(M, ng, gw)
+    gmax = xg.max(2)
+    tol = 1e-5 if nsplit == 3 else 1e-6
+    live = np.isfinite(gmax)
+    assert np.allclose(st[..., 0][live], gmax[live], rtol=tol, atol=tol * np.abs(x).max()) and (st[..., 0][~live] == -np.inf).all()
+    gsum = np.where(live, np.exp(xg - np.where(live, gmax, 0)[..., None]).sum(2), 0.0)
+    assert np.allclose(st[..., 1], gsum, rtol=2e-4, atol=1e-6)
+    assert np.allclose(lab_logit.cpu().numpy(), x[np.arange(M), label], rtol=tol, atol=tol * np.abs(x).max())
+    idx = torch.tensor(_kb32_index(Mp, Np), device="cuda")
+    e = plane[idx].float().cpu().numpy()[:M]
+    want_e = np.exp(xp[:, :ng * gw] - np.repeat(np.where(live, gmax, 0), gw, axis=1))[:, :N]
+    assert np.abs(e[:, :N] - want_e).max() <= 2.0 ** -8 and (e[:, N:] == 0).all()
+    assert lib.tcar_ce_finish(M, N, gw, ng, ptr(stats), ptr(lab_logit), ptr2(lab_d), ptr(rowstat), ptr(ce), ptr2(plane), Np, None) == 0
+    m = x.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(x - m).sum(1))
+    close(ce.cpu().numpy(), lse - x[np.arange(M), label], name="ce", rtol=1e-4, atol_scale=1e-5)
+    d = plane[idx].float().cpu().numpy()
+    want = np.exp(x - lse[:, None])
+    want[np.arange(M), label] -= 1.0
+    # bf16 plane of a value rounded twice (exp to bf16, product to bf16): 2^-7 relative, 2^-9 absolute at the label (p - 1)
+    err = np.abs(d[:M, :N] - want)
+    assert (err <= 2.0 ** -7 * np.abs(want) + 1e-30 + 2.0 ** -8 * (np.arange(N)[None, :] == label[:, None])).all(), float(err.max())
+    assert (d[:M, N:] == 0).all() and (d[M:] == 0).all()                      # padding columns and the k-rows of dE
+    rel = np.linalg.norm(d[:M, :N] - want) / np.linalg.norm(want)
+    assert rel < 4e-3, rel
+
+
 def test_split_bf16_planes_kb32_layout(lib):
     rng = np.random.RandomState(1)
     rows, cols = 137, 820
