@@ -50,6 +50,113 @@ def shard_rows(n_items: int, world: int):
     return _ru((n_items + world - 1) // world, 128)
 
 
+class ShardExchange:
+    """The collective schedule of the catalog-sharded step, independent of where the local pieces come from (the engine binds
+    them to the HIP entry points; tests/test_sharded_gloo.py drives the SAME schedule over gloo on CPU tensors with fp64
+    torch pieces).  Every rank — also one whose shard of the batch is empty — issues the same six collectives in the same
+    order with buffers of the same shape:
+
+      1 all-gather      packed session rows [cap, ld_head]                    -> [W * cap, ld_head]
+      2 all-gather      softmax statistics of the shard [W * cap, 3]          -> [W, W * cap, 3]
+      3 reduce-scatter  dX partial [W * cap, ek]  (all-reduce + slice where the backend has no reduce-scatter)
+      4 all-gather      packed item-row gradients [cap * T, ldr]              -> [W * cap * T, ldr]
+      5 all-reduce      arena gradients + norm pieces
+      6 all-gather      updated item rows of the shard [S, ldh]               -> [W, S, ldh]   (update steps only)
+
+    Collective 6 is issued asynchronously: nothing of the step that follows needs the other shards' rows before its session
+    gathers, so `wait_rows()` is called at the top of the next step (and by every other reader of the item table)."""
+
+    def __init__(self, group=None, world: Optional[int] = None, rank: Optional[int] = None, sim: bool = False,
+                 reduce_scatter: Optional[bool] = None):
+        live = dist.is_available() and dist.is_initialized()
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
+        self.rank = rank if rank is not None else (dist.get_rank(group) if live else 0)
+        self.sim = sim
+        self.backend = dist.get_backend(group) if live and self.world > 1 and not sim else "none"
+        self.use_reduce_scatter = (self.backend == "nccl") if reduce_scatter is None else bool(reduce_scatter)
+        self.bytes_moved: Dict[str, int] = {}
+        self.order = []                 # names of the collectives in issue order (tests)
+        self._pending_rows = None
+
+    def _note(self, key, t):
+        self.bytes_moved[key] = t.numel() * t.element_size()
+        self.order.append(key)
+
+    def allgather(self, t: torch.Tensor, key: str) -> torch.Tensor:
+        """[..] -> [W, ..] (rank-major); world 1: a view"""
+        if self.world == 1:
+            return t.unsqueeze(0)
+        if self.sim:
+            return t.unsqueeze(0).expand((self.world,) + tuple(t.shape)).contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group)
+        self._note(key, out)
+        return out
+
+    def reduce_scatter_rows(self, full: torch.Tensor, cap: int, key: str) -> torch.Tensor:
+        """sum over the ranks of full [W*cap, C]; returns this rank's rows [cap, C]"""
+        if self.world == 1 or self.sim:
+            return full[:cap]
+        self._note(key, full)
+        if self.use_reduce_scatter:
+            out = torch.empty(cap, full.shape[1], dtype=full.dtype, device=full.device)
+            dist.reduce_scatter_tensor(out, full, group=self.group)
+            return out
+        dist.all_reduce(full, group=self.group)              # gloo (CPU tests, single-GPU dry runs) has no reduce-scatter
+        return full[self.rank * cap:(self.rank + 1) * cap]
+
+    def allreduce(self, t: torch.Tensor, key: str) -> torch.Tensor:
+        if self.world > 1 and not self.sim:
+            dist.all_reduce(t, group=self.group)
+            self._note(key, t)
+        return t
+
+    def share_rows(self, stage: torch.Tensor, install) -> None:
+        """collective 6: `stage` [W, S, ldh] holds this rank's updated rows in slot `rank`; `install(stage)` copies the gathered
+        table into place once the collective has landed (wait_rows)"""
+        if self.world == 1 or self.sim:
+            return
+        mine = stage[self.rank].reshape(-1).clone()
+        work = dist.all_gather_into_tensor(stage.view(-1), mine, group=self.group, async_op=True)
+        self._note("item_rows", stage)
+        self._pending_rows = (work, stage, install, mine)
+
+    def wait_rows(self) -> None:
+        if self._pending_rows is not None:
+            work, stage, install, _ = self._pending_rows
+            self._pending_rows = None
+            work.wait()                       # NCCL: orders the current stream behind the collective, no host block
+            install(stage)
+
+    def step(self, pieces, cap: int, update: bool) -> None:
+        """one training step; `pieces` supplies the local compute between the exchanges:
+             begin() -> head [cap, ld]             score(head_all [W*cap, ld]) -> stats [W*cap, 3]
+             backward(stats_all [W, W*cap, 3]) -> dx_full [W*cap, ek]         (dE of the shard stays inside)
+             finish()                                                          (negative rows, shard norm, candidate-time grads)
+             session_backward(dx_rows [cap, ek]) -> rows [cap*T, ldr]
+             scatter(all_rows [W*cap*T, ldr])     arena() -> flat tensor      norms()
+             update() -> (stage [W, S, ldh], install) or None"""
+        self.order = []
+        self.wait_rows()
+        head = pieces.begin()
+        head_all = self.allgather(head, "attout+labels+negatives").view(self.world * cap, -1)
+        stats = pieces.score(head_all)
+        stats_all = self.allgather(stats, "softmax_stats")
+        dx_full = pieces.backward(stats_all)
+        pieces.finish()
+        dx_rows = self.reduce_scatter_rows(dx_full, cap, "dX")
+        rows = pieces.session_backward(dx_rows)
+        all_rows = self.allgather(rows, "rows+ids").view(-1, rows.shape[-1])
+        pieces.scatter(all_rows)
+        self.allreduce(pieces.arena(), "arena")
+        pieces.norms()
+        if update:
+            out = pieces.update()
+            if out is not None:
+                self.share_rows(*out)
+
+
 class ShardedEngine(TcarEngine):
     def __init__(self, params, content_emb, mwdhm, lr=1e-3, max_grad=150.0, neg_weight=0.01, device="cuda:0", group=None,
                  scoring="bf16x3", world: Optional[int] = None, rank: Optional[int] = None, **kw):
@@ -81,37 +188,14 @@ class ShardedEngine(TcarEngine):
         self.n0, self.nl = n0, nl
         self.nlpad = _ru(nl, 128)
         self.n_local_items = nl
-        self.backend = dist.get_backend(group) if live and self.world > 1 else "none"
-        # dX is reduce-scattered where the backend can (RCCL); gloo (CPU tests, single-GPU dry runs) all-reduces it
-        self.use_reduce_scatter = self.backend == "nccl"
+        # the collective schedule (device-agnostic; dX is reduce-scattered where the backend can — RCCL — and all-reduced over gloo)
+        self.xch = ShardExchange(group, self.world, self.dp_rank, sim=self._sim)
+        self.backend = self.xch.backend
         self.cap = 0
         self._stage = torch.zeros(self.world, self.S, self.geo.ldh, dtype=torch.float32, device=self.dev)
-        self.bytes_moved = {}
+        self.bytes_moved = self.xch.bytes_moved
 
     # ------------------------------------------------------------------------------------------ collectives
-    def _allgather(self, t: torch.Tensor, key: str) -> torch.Tensor:
-        """[..] -> [W, ..] (rank-major); world 1: a view"""
-        if self.world == 1:
-            return t.unsqueeze(0)
-        if self._sim:
-            return t.unsqueeze(0).expand((self.world,) + tuple(t.shape)).contiguous()
-        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group)
-        self.bytes_moved[key] = out.numel() * out.element_size()
-        return out
-
-    def _reduce_scatter_rows(self, full: torch.Tensor, cap: int, key: str) -> torch.Tensor:
-        """sum over the ranks of full [W*cap, C]; returns this rank's rows [cap, C]"""
-        if self.world == 1 or self._sim:
-            return full[:cap]
-        self.bytes_moved[key] = full.numel() * full.element_size()
-        if self.use_reduce_scatter:
-            out = torch.empty(cap, full.shape[1], dtype=full.dtype, device=full.device)
-            dist.reduce_scatter_tensor(out, full, group=self.group)
-            return out
-        dist.all_reduce(full, group=self.group)              # gloo (single-GPU dry runs) has no reduce-scatter
-        return full[self.dp_rank * cap:(self.dp_rank + 1) * cap]
-
     def exchange_info(self) -> Dict[str, object]:
         g = self.geo
         return {"mode": "sharded", "world": self.world, "shard_rows": self.S,
@@ -175,71 +259,94 @@ class ShardedEngine(TcarEngine):
     # ----------------------------------------------------------------------------------------------- step
     def _step(self, bt: Optional[Batch], cap: int, K: int, update: bool, T: int):
         """one training step; bt = None: a rank whose shard of the global batch is empty still joins every collective (T is
-        the step's input length: the row buffers of the exchanges have the same shape on every rank)"""
+        the step's input length: the row buffers of the exchanges have the same shape on every rank).  The collectives are
+        ShardExchange.step; the pieces between them are the C entry points of csrc/step.hip."""
         g, lib, p = self.geo, self.lib, self._p
-        W, n0, nl, nlpad = self.world, self.n0, self.nl, self.nlpad
+        W, n0, nl = self.world, self.n0, self.nl
         B = bt.B if bt is not None else 0
         cap = max(cap, B, 1)
         Bq = W * cap
+        self.xch.wait_rows()                       # the previous update's rows, before anything reads the item table
         self._ensure_work(max(B, 1), T)
         self._ensure_score(cap, K)
         has_neg = K > 0
         st = self._stream()
-        # ---- zero the arena, session forward, and ONE packed row per session for the exchange:
-        # [attout (ek) | label | coefficient of the negative term | K negatives | pad], ints as bits, row stride ld_head —
-        # one all-gather instead of four, packed / unpacked by one kernel each (tcar_shard_begin / tcar_shard_score)
         ctx, sctx = self._ctx(), self._shard_ctx()
         sh = self._shard_desc(cap)
         ldh_ = self.ld_head
-        head = self.head_loc[:cap]
         refresh = int(self._time_dirty)
-        check(lib.tcar_shard_begin(C.byref(ctx), C.byref(bt) if bt is not None else None, cap, self._kcap, p(head), ldh_, refresh,
-                                   nl, st), "tcar_shard_begin")
-        head_all = self._allgather(head, "attout+labels+negatives").view(Bq, ldh_)
-        sh.att_all, sh.ld_att, sh.head_K = head_all.data_ptr(), ldh_, (K if has_neg else 0)
-        # ---- scoring of the shard against every session; statistics exchange; gradients (dE stays here, dX goes home)
-        tk = self._tick3(0)
-        check(lib.tcar_shard_score(C.byref(sctx), C.byref(sh), refresh, st), "tcar_shard_score")
-        self._tock3(tk)
-        self._time_dirty = False
-        stats_all = self._allgather(self.s_stats[:Bq], "softmax_stats")
-        tk = self._tick3(1)
-        check(lib.tcar_shard_backward(C.byref(sctx), C.byref(sh), p(stats_all), st), "tcar_shard_backward")
-        self._tock3(tk)
-        # negative rows, shard norm, candidate-time backward: on the aux stream behind dE, beside the dX exchange and the
-        # session backward (tcar_shard_join orders the main stream behind them)
-        check(lib.tcar_shard_finish(C.byref(sctx), C.byref(sh), K if has_neg else 0, p(self.s_neg) if has_neg else None,
-                                    p(self.s_coef) if has_neg else None, st), "tcar_shard_finish")
-        dx_rows = self._reduce_scatter_rows(self.s_dx[:Bq], cap, "dX")
-        # ---- session backward (local) and the sparse-row exchange: packed rows [row (ldh) | id | pad], one all-gather
         nr = cap * T
         ldr = g.ldh + 4
         if getattr(self, "_rows_cap", 0) < nr:
             self._rows_buf = torch.zeros(nr, ldr, dtype=torch.float32, device=self.dev)
             self._rows_cap = nr
-        rows = self._rows_buf[:nr]
-        if bt is not None:
-            if not dx_rows.is_contiguous():
-                dx_rows = dx_rows.contiguous()
-            ce_rows = self.s_ce[self.dp_rank * cap:self.dp_rank * cap + B]
-            check(lib.tcar_step_session_backward(C.byref(ctx), C.byref(bt), p(dx_rows), p(rows), ldr, nr, p(ce_rows), st),
-                  "tcar_step_session_backward")
-        else:
-            rows.zero_()                            # an empty rank contributes padding rows only (id 0, zero payload)
-        all_rows = self._allgather(rows, "rows+ids").view(-1, ldr)
-        check(lib.tcar_shard_join(C.byref(ctx), st), "tcar_shard_join")
-        # ids are 1-based: the rows of this shard become 1 .. nl, the rest (and the id-0 padding) fall out
-        check(lib.tcar_scatter_add_rows_packed(C.byref(self.dims_cand), p(all_rows), ldr, all_rows.shape[0], n0, p(self.Gi), st),
-              "tcar_scatter_add_rows_packed")
-        # ---- arena exchange (gradients + norm pieces incl. the shards' dense item norms), dense-weight norms, update.  The
-        # dense-weight norms are summed in a fixed order (tcar_sqnorm, one workgroup per variable): identical gradients give
-        # identical norms on every rank, the replicas stay bit-identical without a broadcast.
-        if W > 1 and not self._sim:
-            dist.all_reduce(self.Gx, group=self.group)
-            self.bytes_moved["arena"] = self.Gx.numel() * 4
-        check(lib.tcar_sqnorm(p(self.G), C.byref(self.segs_dense), p(self.sqn_dense), st), "tcar_sqnorm")
-        if update:
-            self._update_and_share()
+        eng = self
+
+        class Pieces:
+            # zero the arena, session forward, ONE packed row per session: [attout (ek) | label | coefficient of the negative
+            # term | K negatives | pad], ints as bits, row stride ld_head (tcar_shard_begin packs, tcar_shard_score unpacks)
+            def begin(_):
+                head = eng.head_loc[:cap]
+                check(lib.tcar_shard_begin(C.byref(ctx), C.byref(bt) if bt is not None else None, cap, eng._kcap, p(head), ldh_,
+                                           refresh, nl, st), "tcar_shard_begin")
+                return head
+
+            # scoring of the shard against every session + softmax statistics of the shard
+            def score(_, head_all):
+                sh.att_all, sh.ld_att, sh.head_K = head_all.data_ptr(), ldh_, (K if has_neg else 0)
+                _._head_all = head_all
+                tk = eng._tick3(0)
+                check(lib.tcar_shard_score(C.byref(sctx), C.byref(sh), refresh, st), "tcar_shard_score")
+                eng._tock3(tk)
+                eng._time_dirty = False
+                return eng.s_stats[:Bq]
+
+            # lse, dlogits planes, dE of the shard (aux stream, stays here), dX partial (goes home)
+            def backward(_, stats_all):
+                _._stats_all = stats_all
+                tk = eng._tick3(1)
+                check(lib.tcar_shard_backward(C.byref(sctx), C.byref(sh), p(stats_all), st), "tcar_shard_backward")
+                eng._tock3(tk)
+                return eng.s_dx[:Bq]
+
+            # negative rows, shard norm, candidate-time backward: on the aux stream behind dE, beside the dX exchange and the
+            # session backward (tcar_shard_join orders the main stream behind them)
+            def finish(_):
+                check(lib.tcar_shard_finish(C.byref(sctx), C.byref(sh), K if has_neg else 0, p(eng.s_neg) if has_neg else None,
+                                            p(eng.s_coef) if has_neg else None, st), "tcar_shard_finish")
+
+            # session backward (local) -> packed rows [row (ldh) | id | pad]
+            def session_backward(_, dx_rows):
+                rows = eng._rows_buf[:nr]
+                if bt is not None:
+                    if not dx_rows.is_contiguous():
+                        dx_rows = dx_rows.contiguous()
+                    ce_rows = eng.s_ce[eng.dp_rank * cap:eng.dp_rank * cap + B]
+                    check(lib.tcar_step_session_backward(C.byref(ctx), C.byref(bt), p(dx_rows), p(rows), ldr, nr, p(ce_rows), st),
+                          "tcar_step_session_backward")
+                else:
+                    rows.zero_()                    # an empty rank contributes padding rows only (id 0, zero payload)
+                return rows
+
+            # ids are 1-based: the rows of this shard become 1 .. nl, the rest (and the id-0 padding) fall out
+            def scatter(_, all_rows):
+                check(lib.tcar_shard_join(C.byref(ctx), st), "tcar_shard_join")
+                check(lib.tcar_scatter_add_rows_packed(C.byref(eng.dims_cand), p(all_rows), ldr, all_rows.shape[0], n0, p(eng.Gi),
+                                                       st), "tcar_scatter_add_rows_packed")
+
+            # arena gradients + norm pieces incl. the shards' dense item norms
+            def arena(_):
+                return eng.Gx
+
+            # dense-weight norms, summed in a fixed order (one workgroup per variable): identical gradients give identical
+            # norms on every rank, the replicas stay bit-identical without a broadcast
+            def norms(_):
+                check(lib.tcar_sqnorm(p(eng.G), C.byref(eng.segs_dense), p(eng.sqn_dense), st), "tcar_sqnorm")
+
+            def update(_):
+                return eng._update_local()
+
+        self.xch.step(Pieces(), cap, update)
 
     def _shard_desc(self, cap: int) -> "_lib.Shard":
         key = (cap, self.s_logits.data_ptr())
@@ -265,15 +372,30 @@ class ShardedEngine(TcarEngine):
             self._sctx, self._sctx_src = s, c
         return self._sctx
 
-    def _update_and_share(self):
+    def _update_local(self):
+        """clip + Adam: arena on every rank, the item rows of the shard by their owner; returns the staging buffer of collective 6
+        (this rank's updated rows in its slot) and the installer that copies the gathered table into E"""
         g = self.geo
         check(self.lib.tcar_step_update(C.byref(self._shard_ctx()), self._lr_t(), self._stream()), "tcar_step_update")
         self._after_update()
-        if self.world > 1 and not self._sim:
-            self._stage[self.dp_rank, :self.nl].copy_(self.E[self.n0:self.n0 + self.nl, :g.ldh])
-            dist.all_gather_into_tensor(self._stage.view(-1), self._stage[self.dp_rank].reshape(-1).clone(), group=self.group)
-            self.bytes_moved["item_rows"] = self._stage.numel() * 4
-            self.E[:g.N, :g.ldh].copy_(self._stage.view(-1, g.ldh)[:g.N])
+        if self.world == 1 or self._sim:
+            return None
+        self._stage[self.dp_rank, :self.nl].copy_(self.E[self.n0:self.n0 + self.nl, :g.ldh])
+
+        def install(stage):
+            self.E[:g.N, :g.ldh].copy_(stage.view(-1, g.ldh)[:g.N])
+        return self._stage, install
+
+    def _update_and_share(self):
+        out = self._update_local()
+        if out is not None:
+            self.xch.share_rows(*out)
+
+    def flush(self):
+        """TcarEngine.flush + the pending item-row all-gather of the last update (every reader of the item table calls flush)"""
+        super().flush()
+        if getattr(self, "xch", None) is not None:
+            self.xch.wait_rows()
 
     # ------------------------------------------------------------------------------------------- public API
     score_batch = property(lambda self: self.world * max(self.cap, 1))
