@@ -428,11 +428,6 @@ int tcar_layernorm_bwd(int64_t M, int C, const float* x, const float* gamma, con
  * item ids, repeats allowed: a bit per row in `bitmap` — zero on entry — makes every row update exactly once);
  * tcar_clip_adam_rest: every item row whose bit is clear, then clears the bitmap.  Together they equal
  * tcar_clip_adam_all; the step driver runs the second on the aux stream beside the next forward pass. */
-/* tcar_adam_mark_rows: the marks of a split update whose two passes run CONCURRENTLY (step driver): sets bit (id - 1) of `skip`
- * for every listed 1-based item id — tcar_clip_adam_rest(bitmap = skip) then leaves those rows to the early pass without waiting
- * for it — and clears the [ceil(rows / 32)] words of `own`, which tcar_clip_adam_early(bitmap = own) uses to update a repeated
- * id once.  (With ONE bitmap for both passes, as above, the rest pass must be ordered behind the early one.) */
-int tcar_adam_mark_rows(const int32_t* ids, int64_t n_ids, int64_t rows, uint32_t* skip, uint32_t* own, void* stream);
 int tcar_clip_adam_early(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,
                          const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot,
                          const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t,
@@ -577,7 +572,7 @@ typedef struct {
   /* optional auxiliary stream + 4 events (hipStream_t / hipEvent_t, caller-created): the candidate-side time refresh
    * (forward) and the dE chain (backward) run on it concurrently with the session-side chain; NULL = one stream */
   void* stream2; void* ev[6];
-  uint32_t* adam_bitmap;    /* 2 x [ceil(N/32) + 1] zeroed words: rows the early pass of a split update owns (tcar_adam_mark_rows: skip | own) */
+  uint32_t* adam_bitmap;    /* [ceil(N/32) + 1] zeroed words: rows already updated by the early pass of a split update */
   const int32_t* et_perm;   /* [5, N] position of (k, n) in the inverted index (bf16 scoring modes: dE writes d_et in that order) */
   /* optional device timing of the three full-catalog GEMMs: ev_start / ev_stop hold 3 * ev_n hipEvent_t each
    * ([kind][slot]: kind 0 = logits, 1 = dX = dlogits E, 2 = dE = dlogits^T attout), recorded on the stream the GEMM is

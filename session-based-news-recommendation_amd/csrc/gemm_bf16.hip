@@ -175,11 +175,19 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
           for (int p = 0; p < NP; ++p) b[p] = frag<MB>(St + p * PL + A_BYTES, wn * (32 * TNW) + t2 * 32, s, lane);
 #pragma unroll
           for (int u = 0; u < TMW; ++u) {
-            if constexpr (NSPLIT == 3) {
-              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0], acc[u][t2], 0, 0, 0);
-              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1], acc[u][t2], 0, 0, 0);
+            if constexpr (EPI == 1) {     // transposed accumulator tile (rows = catalog columns, lane = session): see the epilogue
+              if constexpr (NSPLIT == 3) {
+                acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[NP - 1][u], acc[u][t2], 0, 0, 0);
+                acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[NP - 1], a[0][u], acc[u][t2], 0, 0, 0);
+              }
+              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0][u], acc[u][t2], 0, 0, 0);
+            } else {
+              if constexpr (NSPLIT == 3) {
+                acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0], acc[u][t2], 0, 0, 0);
+                acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1], acc[u][t2], 0, 0, 0);
+              }
+              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0], acc[u][t2], 0, 0, 0);
             }
-            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0], acc[u][t2], 0, 0, 0);
           }
         }
       }
@@ -196,44 +204,50 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
 
   const int li = lane & 31, lh = lane >> 5;
   if constexpr (EPI == 1) {
-    // Softmax epilogue (model_combine.py:145 without materialised logits).  The wave owns rows x GW = 32 * TNW columns; a row
-    // of an MFMA tile lives in the 32 lanes of one half wave (column = lane & 31), so group maximum and sum are TNW in-lane
-    // steps + 5 xor-shuffles.  exp(x - group max) <= 1 goes out as bf16; tcar_ce_finish combines the (max, sum) pairs of a
-    // row into its log-sum-exp and rescales the plane in place to softmax - onehot.
+    // Softmax epilogue (model_combine.py:145 without materialised logits).  The accumulators of this form are TRANSPOSED
+    // (compute() swaps the MFMA operands): a lane owns ONE session (column lane & 31 of the tile = row m of the logits) and its
+    // registers run over the wave's GW = 32 * TNW catalog columns — n = 4 (lane >> 5) + (e & 3) + 8 (e >> 2) inside each
+    // 32-wide tile.  Group maximum and sum are therefore in-register loops plus ONE exchange between the two half waves, and
+    // the exponentials leave as 8-byte stores of four consecutive catalog columns.  exp(x - group max) <= 1 goes out as bf16;
+    // tcar_ce_finish combines the (max, sum) pairs of a row into its log-sum-exp and rescales the plane to softmax - onehot.
     constexpr int GW = 32 * TNW;
     const int gidx = (n0 + wn * GW) / GW;
-    const int cb = n0 + wn * GW + li;
+    const int nb = n0 + wn * GW + 4 * lh;
     const int pcols = g.p_in32 << 5;
 #pragma unroll
     for (int u = 0; u < TMW; ++u) {
-      const int row0 = m0 + wm * (32 * TMW) + u * 32 + 4 * lh;
+      const int row = m0 + wm * (32 * TMW) + u * 32 + li;
+      const bool live = row < g.M;
+      float mx = -INFINITY;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = row0 + (e & 3) + 8 * (e >> 2);
-        const bool live = row < g.M;
-        float v[TNW];
-        float mx = -INFINITY;
+      for (int t = 0; t < TNW; ++t)
 #pragma unroll
-        for (int t = 0; t < TNW; ++t) {
-          v[t] = (cb + 32 * t < g.N) ? acc[u][t][e] : -INFINITY;
-          mx = fmaxf(mx, v[t]);
+        for (int e = 0; e < 16; ++e)
+          if (nb + 32 * t + (e & 3) + 8 * (e >> 2) < g.N) mx = fmaxf(mx, acc[u][t][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const int lab = live ? g.label[row] : -1;
+      float sum = 0.f, labv = 0.f;
+      bool has_lab = false;
+#pragma unroll
+      for (int t = 0; t < TNW; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n4 = nb + 32 * t + 8 * q;
+          bf16x4 pk;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = acc[u][t][4 * q + j];
+            const float pe = (n4 + j < g.N) ? __expf(v - mx) : 0.f;
+            sum += pe;
+            pk[j] = (__bf16)pe;
+            if (n4 + j == lab) { labv = v; has_lab = true; }
+          }
+          if (live && n4 < pcols) *reinterpret_cast<bf16x4*>(g.p_hi + kb32_off(row, n4, g.p_in32)) = pk;
         }
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        const int lab = live ? g.label[row] : -1;
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < TNW; ++t) {
-          const float pe = (v[t] == -INFINITY) ? 0.f : __expf(v[t] - mx);
-          sum += pe;
-          const int col = cb + 32 * t;
-          if (live && col < pcols) g.p_hi[kb32_off(row, col, g.p_in32)] = (__bf16)pe;
-          if (live && col == lab) g.lab_logit[row] = v[t];
-        }
-#pragma unroll
-        for (int o = 1; o < 32; o <<= 1) sum += __shfl_xor(sum, o);
-        if (live && li == 0) *reinterpret_cast<float2*>(g.stats + ((long)row * g.ngroups + gidx) * 2) = make_float2(mx, sum);
-      }
+      sum += __shfl_xor(sum, 32);
+      if (has_lab) g.lab_logit[row] = labv;
+      if (live && lh == 0) *reinterpret_cast<float2*>(g.stats + ((long)row * g.ngroups + gidx) * 2) = make_float2(mx, sum);
+      __builtin_amdgcn_sched_barrier(0);     // one session tile at a time: the accumulators leave no room for hoisted addresses
     }
     return;
   }

@@ -285,18 +285,6 @@ __global__ __launch_bounds__(256) void clip_adam_early_kernel(const AdamEarly e,
     }
   }
 }
-// marks of a split update whose REST pass starts at once (tcar_adam_mark_rows): bit r of `skip` = row r is on the early pass's
-// list; the words of `own` (the early pass's claim bits) are cleared for it
-__global__ __launch_bounds__(256) void adam_mark_kernel(const int32_t* __restrict__ ids, long n_ids, long rows,
-                                                        uint32_t* __restrict__ skip, uint32_t* __restrict__ own, long words) {
-  const long i0 = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
-  for (long w = i0; w < words; w += stride) own[w] = 0u;
-  for (long i = i0; i < n_ids; i += stride) {
-    long r = (long)ids[i] - 1;
-    r = r < 0 ? 0 : (r >= rows ? rows - 1 : r);
-    atomicOr(skip + (r >> 5), 1u << (r & 31));
-  }
-}
 __global__ __launch_bounds__(256) void clip_adam_rest_kernel(const AdamAll p, const uint32_t* __restrict__ skip) {
   item_adam_blocks(blockIdx.x, gridDim.x, p.w2, p.ldw, p.g2, p.m2, p.v2, p.rows, p.cols, p.slot, p.sqn_dense, p.sqn_pieces,
                    p.use_dense, p.clip, p.lr_t, p.b1, p.b2, p.eps, p.eh, p.el, p.ld16, skip);
@@ -443,16 +431,6 @@ extern "C" int tcar_clip_adam_early(float* w, const float* g, float* m, float* v
   const int grid = e.n_rowblk + e.p.gx * segs->nseg;
   if (grid <= 0) return TCAR_OK;
   TCAR_LAUNCH(clip_adam_early_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, e, a);
-  TCAR_CHECK_LAUNCH();
-  return TCAR_OK;
-}
-
-extern "C" int tcar_adam_mark_rows(const int32_t* ids, int64_t n_ids, int64_t rows, uint32_t* skip, uint32_t* own, void* stream) {
-  if (!skip || !own || rows <= 0 || n_ids < 0 || (n_ids > 0 && !ids)) return TCAR_E_ARG;
-  const long words = (rows + 31) / 32;
-  long blocks = ((n_ids > words ? n_ids : words) + 255) / 256;
-  blocks = blocks < 1 ? 1 : (blocks > 256 ? 256 : blocks);
-  TCAR_LAUNCH(adam_mark_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ids, (long)n_ids, (long)rows, skip, own, words);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

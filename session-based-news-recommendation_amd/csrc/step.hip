@@ -19,7 +19,7 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_REST_EARLY", &TcarTuning::rest_early, 1},         {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
+    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -257,14 +257,16 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   // The candidate-side time block of E depends only on the time tables: it is rebuilt on the auxiliary stream while
   // the session side (gather, projections, pools) runs on the main one; the logits GEMM joins them.
   hipStream_t s1 = (hipStream_t)stream, s2 = aux_stream(c);
-  hipStream_t s3 = (s2 && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
-  bool joined = true, joined3 = true;
+  bool joined = true;
   if (refresh_time) {
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-    hipStream_t st_time = s2;          // the stream that rebuilds the candidate-side time block
-    if (s2 && rest_lr >= 0.f && !tcar_tuning().rest_early) {
-      // (A/B) round-2 order: early pass, then the time refresh and the rest pass on the aux stream
+    if (s2 && rest_lr >= 0.f) {
+      // The pending split update (tcar_train_step_deferred): EARLY pass on the main stream (arena + the item rows this batch
+      // gathers), then — on the aux stream, beside the session forward — the time refresh and the REST pass over every other
+      // item row; the logits GEMM joins.  (Round 3 tried to start the rest pass at once, from row marks made by a small
+      // kernel, with the time refresh on the third stream: the 376-MB pass then runs beside the gather and the projections
+      // as well and slows them by more than it gains — 0.626 vs 0.618 ms per step)
       const float* pieces = c->Gx + c->arena_n;
       RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
                                c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
@@ -278,45 +280,15 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
                               c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2));
       if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
       joined = false;
-      st_time = nullptr;
-    } else if (s2 && rest_lr >= 0.f) {
-      // The pending split update (tcar_train_step_deferred).  Three things start together:
-      //   main:  mark the rows this batch gathers -> EARLY pass (arena + those rows) -> gather ...
-      //   aux:   [after the marks]  REST pass over every other item row (the 60-us HBM-bound pass), sort index
-      //   third: [after the early pass: it updates the time tables]  candidate-side time refresh
-      // The rest pass no longer queues behind the early pass and the time refresh: it ends ~25 us earlier, and the logits GEMM
-      // waits for it.
-      const float* pieces = c->Gx + c->arena_n;
-      uint32_t* skip = c->adam_bitmap;
-      uint32_t* own = c->adam_bitmap + ((g.N + 31) / 32 + 1);
-      RET(tcar_adam_mark_rows(bt->seq, (int64_t)BT, g.N, skip, own, stream));
-      if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
+    } else {
+      if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
         return TCAR_E_LAUNCH;
-      RET(tcar_clip_adam_rest(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
-                              c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
-                              c->scoring ? c->e16l : nullptr, g.ek, skip, (void*)s2));
-      RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
-                               c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
-                               c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT, own,
-                               stream));
-      if (s3) st_time = s3;
-      if (hipEventRecord((hipEvent_t)c->ev[5], s1) != hipSuccess || hipStreamWaitEvent(st_time, (hipEvent_t)c->ev[5], 0) != hipSuccess)
-        return TCAR_E_LAUNCH;
-    } else if (s2) {
-      if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
-        return TCAR_E_LAUNCH;
-    }
-    const bool time_done = s2 && rest_lr >= 0.f && !tcar_tuning().rest_early;
-    if (!time_done)
       RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
-                                  st_time ? (void*)st_time : stream));
-    if (st_time && st_time == s3) {
-      if (hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
-      joined3 = false;
-    }
-    if (s2 && !time_done) {
-      if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
-      joined = false;
+                                  s2 ? (void*)s2 : stream));
+      if (s2) {
+        if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+        joined = false;
+      }
     }
   }
   if (train_index && sorted_rows(c, bt)) {   // behind the join point: the logits GEMM does not wait for it, the backward does
@@ -327,7 +299,6 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   }
   RET(session_forward(c, bt, g, stream, c->scoring != 0));
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
-  if (!joined3 && hipStreamWaitEvent(s1, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   int ei = -1;
   auto start_timer = [&]() {

@@ -61,7 +61,6 @@ struct TcarTuning {
   int bf16_ks;          // TCAR_BF16_KS        64-deep LDS stages of the hi-only bf16 GEMM: 1 never, 2 dX / logits layouts, 3 all
   int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
   int x3_oneshot;       // TCAR_X3_ONESHOT     0: short-K small-GEMM launches keep the one-stage register ring
-  int rest_early;       // TCAR_REST_EARLY     0: the rest pass of a split update queues behind the early pass and the time refresh (round-2 order)
   int fused_ce;         // TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel
   int proj_split;       // TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs
 };

@@ -102,14 +102,38 @@ class DeviceSampler:
     def bytes_resident(self) -> int:
         return sum(t.numel() * t.element_size() for t in vars(self).values() if torch.is_tensor(t))
 
+    def _describe(self, feed: torch.Tensor, B: int, T: int, K: int) -> Batch:
+        """C batch descriptor over a formed feed buffer (layout of tcar_form_batch = TcarEngine.upload)"""
+        base = feed.data_ptr()
+        bt = Batch()
+        bt.B, bt.T, bt.K = B, T, K
+        n = B * T
+        bt.seq = base
+        for k in range(5):
+            bt.pub[k] = base + 4 * (k + 1) * n
+        bt.gap = base + 4 * 6 * n
+        bt.cw = base + 4 * 7 * n
+        bt.ch = base + 4 * (7 * n + B)
+        bt.label = base + 4 * (7 * n + 2 * B)
+        bt.neg = (base + 4 * (7 * n + 3 * B)) if K else None
+        bt._seq_t = feed[:n]
+        bt._keep = feed
+        return bt
+
+    def _launch(self, idx_ptr: int, B: int, T: int, K: int, gap_mode: str, counter: int, feed: torch.Tensor, stream) -> None:
+        if T > 40:
+            raise IndexError("session longer than the 40-row position table (model_combine.py:57)")
+        check(self.lib.tcar_form_batch(C.byref(self.eng.dims), C.byref(self.c_store), C.byref(self.c_src), C.c_void_p(idx_ptr),
+                                       B, T, K, 1 if gap_mode == "click_delta" else 0, C.c_uint64(self.seed),
+                                       C.c_uint64(int(counter)), C.c_void_p(feed.data_ptr()), C.c_void_p(stream.cuda_stream)),
+              "tcar_form_batch")
+
     def form(self, idx: np.ndarray, K: int, gap_mode: str = "active_t", counter: Optional[int] = None) -> Batch:
         """Feed of the batch whose examples are `idx` (all of one input length), formed on the device; returns the C batch
         descriptor for TcarEngine.train_step / eval_step (bt=...).  K = 0: no negatives (evaluation)."""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
         B = int(idx.shape[0])
         T = int(self.in_len[idx[0]])
-        if T > 40:
-            raise IndexError("session longer than the 40-row position table (model_combine.py:57)")
         need = 7 * B * T + 3 * B + B * K
         if self.feed is None or self.feed.numel() < need or self.idx_dev.numel() < B:
             n = max(need, 1 << 16)
@@ -130,25 +154,55 @@ class DeviceSampler:
         if counter is None:
             counter = self.counter
             self.counter += 1
-        check(self.lib.tcar_form_batch(C.byref(self.eng.dims), C.byref(self.c_store), C.byref(self.c_src),
-                                       C.c_void_p(self.idx_dev.data_ptr()), B, T, K, 1 if gap_mode == "click_delta" else 0,
-                                       C.c_uint64(self.seed), C.c_uint64(int(counter)), C.c_void_p(self.feed.data_ptr()),
-                                       C.c_void_p(st.cuda_stream)), "tcar_form_batch")
-        base = self.feed.data_ptr()
-        bt = Batch()
-        bt.B, bt.T, bt.K = B, T, K
-        n = B * T
-        bt.seq = base
-        for k in range(5):
-            bt.pub[k] = base + 4 * (k + 1) * n
-        bt.gap = base + 4 * 6 * n
-        bt.cw = base + 4 * 7 * n
-        bt.ch = base + 4 * (7 * n + B)
-        bt.label = base + 4 * (7 * n + 2 * B)
-        bt.neg = (base + 4 * (7 * n + 3 * B)) if K else None
-        bt._seq_t = self.feed[:n]
-        bt._keep = self.feed
-        return bt
+        self._launch(self.idx_dev.data_ptr(), B, T, K, gap_mode, counter, self.feed, st)
+        return self._describe(self.feed, B, T, K)
+
+    # ------------------------------------------------------------------------------------ a whole schedule, resident
+    def plan(self, batches) -> None:
+        """Upload the example indices of a whole schedule of batches (an epoch after the bucketed shuffle, sampler.py:40-49)
+        ONCE: afterwards a training loop moves nothing over PCIe — `planned()` forms every feed from HBM-resident data."""
+        lens = [int(len(b)) for b in batches]
+        self.plan_off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        flat = np.concatenate([np.asarray(b, dtype=np.int32) for b in batches]) if batches else np.zeros(0, np.int32)
+        self.plan_dev = torch.tensor(flat, device=self.dev)
+        self.plan_B = lens
+        self.plan_T = [int(self.in_len[int(b[0])]) for b in batches]
+
+    def planned(self, K: int, gap_mode: str = "active_t"):
+        """Yield the C batch descriptor of every planned batch.  Batch i + 1 is formed (tcar_form_batch: session rows and
+        negatives) on a side stream while the consumer's step i runs; two feed buffers alternate, events order the reuse.  The
+        consumer must enqueue its step on the current stream before asking for the next batch."""
+        n = len(self.plan_B)
+        if n == 0:
+            return
+        need = max(7 * b * t + 3 * b + b * K for b, t in zip(self.plan_B, self.plan_T))
+        if getattr(self, "_feeds", None) is None or self._feeds[0].numel() < need:
+            self._feeds = [torch.empty(max(need, 1 << 16), dtype=torch.int32, device=self.dev) for _ in range(2)]
+            self._side = torch.cuda.Stream(self.dev)
+            self._ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+        main = torch.cuda.current_stream(self.dev)
+        side, used = self._side, [False, False]
+        side.wait_stream(main)               # the plan's upload (and whatever wrote the stores) is on the main stream
+
+        def launch(i):
+            slot = i & 1
+            if used[slot]:
+                side.wait_event(self._ev_free[slot])      # the step that read this buffer has been enqueued in full
+            self._launch(self.plan_dev.data_ptr() + 4 * int(self.plan_off[i]), self.plan_B[i], self.plan_T[i], K, gap_mode,
+                         self.counter, self._feeds[slot], side)
+            self.counter += 1
+            self._ev_ready[slot].record(side)
+
+        launch(0)
+        for i in range(n):
+            slot = i & 1
+            if i + 1 < n:
+                launch(i + 1)
+            main.wait_event(self._ev_ready[slot])
+            yield self._describe(self._feeds[slot], self.plan_B[i], self.plan_T[i], K)
+            self._ev_free[slot].record(main)
+            used[slot] = True
 
     def read_back(self, bt: Batch) -> Dict[str, np.ndarray]:
         """The feed of `bt` as the host arrays of SessionStore.batch_arrays (+ "neg"): tests / debugging."""

@@ -212,6 +212,13 @@ class Seq2SeqAttNN():
             ds = self._ds_cache[key] = DeviceSampler(self.engine, store, mode, neighbor_dict if mode != "uniform" else None,
                                                      item_dict, seed=self.seed)
         k = K if (neighbor_dict and K) else 0
+        if self.dp_world == 1:
+            # the epoch's example indices go up ONCE; every feed is then formed from HBM-resident data, one batch ahead of the
+            # step on a side stream (DeviceSampler.planned) — nothing crosses PCIe inside the epoch
+            ds.plan([sampler.batch_indices(i) for i in range(sampler.batch_num)])
+            for bt in ds.planned(k, self.gap_mode):
+                yield bt, None, None
+            return
         for i in range(sampler.batch_num):
             idx = sampler.batch_indices(i)
             if self.dp_world > 1:
