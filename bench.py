@@ -8,9 +8,12 @@ N > 1: when the process is not already a rank of a torch.distributed.run job (WO
 before anything touches the GPU, relays the ranks' JSON line and exits with the child's return code; under
 torch.distributed.run (the driver's own launch form) it simply is one of the ranks.
 
-One "step" = one pass of the hot path (forward, loss, backward, per-variable clip, Adam: model_combine.py:231) over one
-mini-batch of B = 512 sessions per GPU whose int32 feed arrays are already resident in HBM.  Rank 0 prints ONE JSON line:
-whole-job sessions/sec plus
+One "step" = one pass of the training loop's body (model_combine.py:204-231: the sampler forms the next batch — session rows,
+time features, K negatives — then forward, loss, backward, per-variable clip, Adam) over one mini-batch of B = 512 sessions per
+GPU.  Everything the step reads is resident in HBM when the timed region starts: model state, the session store, the negative
+sources and the example indices of every batch of the schedule; the device sampler (tcar_form_batch) forms batch i + 1 on a side
+stream while step i runs.  `--resident_feed` times the loop over pre-formed feeds instead (no sampler inside: reported as
+"device_step_sessions_per_s" in the default run).  Rank 0 prints ONE JSON line: whole-job sessions/sec plus
   "roofline"      the kernel with the largest total time among the three full-catalog GEMMs (logits = attout E^T,
                   dX = dlogits E, dE = dlogits^T attout): algorithmic FLOPs per launch / mean HIP-event duration of that
                   launch measured IN the timed steps, on the stream the kernel is launched on (the C++ step driver records the
@@ -85,9 +88,10 @@ def launch_ranks(n: int) -> int:
     return rc if rc else (0 if last is not None else 1)
 
 
-def build_batches(fold, n_batches, B, K, rng, cfg):
+def build_batches(fold, n_batches, B, K, rng, cfg, with_ids=False):
     """Full batches of exactly B sessions in the fold's own length mix (sampler.py:40-49 bucketing); negatives in the
-    configuration's mode, drawn with the vectorised host rules of host/sampler.py (outside the timed region)."""
+    configuration's mode, drawn with the vectorised host rules of host/sampler.py (outside the timed region).
+    with_ids: also return the example indices of every batch (the device sampler forms the same batches from them)."""
     from tcar_amd.host.sampler import Sampler
     st = fold.train
     by_len = {}
@@ -103,7 +107,7 @@ def build_batches(fold, n_batches, B, K, rng, cfg):
         src = fold.neighbor_dict() if cfg["neg_mode"] == "neighbor" else fold.impression_dict(st)
         neg_sampler = Sampler({}, None, None, src, fold.item_dict, K, batch_size=B, gap_mode=cfg["gap_mode"],
                               neg_mode=cfg["neg_mode"], store=st, verbose=False, neg_fast=True)
-    out = []
+    out, out_ids = [], []
     state = np.random.get_state()
     np.random.seed(int(rng.randint(1 << 30)))
     for j in order[:n_batches]:
@@ -114,8 +118,9 @@ def build_batches(fold, n_batches, B, K, rng, cfg):
         else:
             b["neg"] = neg_sampler._negatives(ids.tolist(), b["label"], ids)
         out.append(b)
+        out_ids.append(np.asarray(ids, dtype=np.int32))
     np.random.set_state(state)
-    return out
+    return (out, out_ids) if with_ids else out
 
 
 def pmc_traffic(tag, nsplit, N, B):
@@ -203,6 +208,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
     ap.add_argument("--same_device", action="store_true", help="dry run: put every rank on cuda:0")
     ap.add_argument("--no_gather_roofline", action="store_true", help="skip the embedding-gather HBM roofline measurement")
+    ap.add_argument("--resident_feed", action="store_true",
+                    help="headline loop over pre-formed feeds (no sampler inside the timed steps); default: the device sampler "
+                         "forms every batch inside the loop (BASELINE.md §3: sampler + fwd + bwd + update)")
     ap.add_argument("--scoring", default="bf16x3-mixed", choices=["f32", "bf16x3", "bf16x3-mixed", "bf16"],
                     help="precision of the full-catalog scoring GEMMs.  bf16x3-mixed (default; BASELINE.json configs[1] is "
                          "quoted in bf16): logits from split-bf16 planes (three MFMAs per product, fp32-class: the 1e-3 "
@@ -284,16 +292,17 @@ def main():
     # every rank builds the same catalog (seed 2020) and its own shard of sessions (weak scaling: B per GPU)
     fold = SynthFold(n_items=N, dim=H, n_train=max(60000, 4 * B * args.n_batches), n_test=1000, seed=2020, **cfg["fold"])
     rng = np.random.RandomState(2020 + rank)
-    batches = build_batches(fold, args.n_batches, B, K, rng, cfg)
+    batches, batch_ids = build_batches(fold, args.n_batches, B, K, rng, cfg, with_ids=True)
     if world > 1:
         # ranks step in lock-step over buckets of the same length T: share rank 0's T schedule
         sched = torch.tensor([b["seq"].shape[1] for b in batches], device=dev)
         dist.broadcast(sched, 0)
         want = sched.cpu().tolist()
         pool = {}
-        for b in build_batches(fold, 10 ** 9, B, K, rng, cfg):
-            pool.setdefault(b["seq"].shape[1], []).append(b)
-        batches = [pool[T][i % len(pool[T])] for i, T in enumerate(want)]
+        for b, ids in zip(*build_batches(fold, 10 ** 9, B, K, rng, cfg, with_ids=True)):
+            pool.setdefault(b["seq"].shape[1], []).append((b, ids))
+        picked = [pool[T][i % len(pool[T])] for i, T in enumerate(want)]
+        batches, batch_ids = [x[0] for x in picked], [x[1] for x in picked]
 
     from tcar_amd.host.model import initial_variables     # the product's own initialiser (modules.py:32-34,50-51)
     np.random.seed(2020)
@@ -323,23 +332,53 @@ def main():
     # pass — bitwise the same arithmetic, tests/test_gpu_parity.py).  The last update is flushed INSIDE the timed region, so K
     # timed steps contain exactly K forward passes, K backward passes and K updates.  TCAR_NO_DEFER=1: update inside its step.
     defer = {"defer_update": True} if (world == 1 and not os.environ.get("TCAR_FORCE_DP") and not os.environ.get("TCAR_NO_DEFER")) else {}
-    for i in range(args.warmup):
-        eng.train_step(None, bt=resident[i % len(resident)], **defer)
-    eng.flush()                                  # the last warm-up step's update belongs to the warm-up
+    # The sampler of the step: everything it reads is RESIDENT in HBM before the timed region starts (session store, negative
+    # sources, and the example indices of every batch of the schedule: DeviceSampler.plan); inside the loop tcar_form_batch
+    # forms batch i + 1 (session rows, time features, K negatives) on a side stream while step i runs.
+    from tcar_amd.device_sampler import DeviceSampler
+    src = None if cfg["neg_mode"] == "uniform" else (fold.neighbor_dict() if cfg["neg_mode"] == "neighbor" else fold.impression_dict(fold.train))
+    ds = DeviceSampler(eng, fold.train, cfg["neg_mode"], src, fold.item_dict, seed=2020 + rank)
+    sched = lambda first, n: [batch_ids[(first + i) % len(batch_ids)] for i in range(n)]
+
+    def run(n, first, sampler_in_loop):
+        if sampler_in_loop:
+            ds.plan(sched(first, n))
+            for bt in ds.planned(K, cfg["gap_mode"]):
+                eng.train_step(None, bt=bt, **defer)
+        else:
+            for i in range(n):
+                eng.train_step(None, bt=resident[(first + i) % len(resident)], **defer)
+        eng.flush()                              # K steps contain exactly K updates
+
+    def timed(sampler_in_loop):
+        run(args.warmup, 0, sampler_in_loop)     # the last warm-up step's update belongs to the warm-up
+        if sampler_in_loop:
+            ds.plan(sched(args.warmup, args.steps))        # the timed schedule's indices: resident before the clock starts
+        sync()
+        t0 = time.perf_counter()
+        if sampler_in_loop:
+            for bt in ds.planned(K, cfg["gap_mode"]):
+                eng.train_step(None, bt=bt, **defer)
+            eng.flush()
+        else:
+            run(args.steps, args.warmup, False)
+        t_enq = time.perf_counter() - t0         # host time to enqueue every step (the loop never synchronises)
+        sync()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, t_enq
+
+    headline_sampler = not args.resident_feed
+    other = None
+    if not (args.no_cpu_baseline and args.no_e2e):          # (the A/B tools time the headline loop only)
+        dt_o, _ = timed(not headline_sampler)
+        other = B * world * args.steps / dt_o
     if not args.no_kernel_timing:
         eng.enable_native_timing(args.steps)     # HIP events around the three scoring GEMMs inside the step driver
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        eng.train_step(None, bt=resident[(args.warmup + i) % len(resident)], **defer)
-    eng.flush()
-    t_enq = time.perf_counter() - t0          # host time to enqueue every step (the loop never synchronises)
-    sync()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, t_enq = timed(headline_sampler)
     last_loss = float(eng.loss[:B].mean())
     if hasattr(eng, "exchange_info"):
         exchange = eng.exchange_info()        # after the timed steps: carries the bytes each collective moved per step
@@ -430,16 +469,31 @@ def main():
         hw = os.cpu_count() or 1
         cores = min(hw, args.cpu_threads)
         torch.set_num_threads(cores)
+        import random
+        from oracle.sampler_oracle import OracleSampler, batch_to_arrays
         ora = TcarOracle(params, fold.content, fold.mwdhm, dtype=torch.float32)
         ora.train_step(batches[0])                                  # warm-up
+        # the reference's loop (model_combine.py:196-231): its Python per-click sampler (sampler.py:52-113, restated in
+        # oracle/sampler_oracle.py) forms every batch inside the timed region, then one training step
+        take = [batch_ids[i % len(batch_ids)] for i in range(1, args.cpu_steps + 1)]
+        with_active = cfg["gap_mode"] == "active_t"
+        ld, sd, td = fold.to_dicts(fold.train, with_active=with_active, examples=np.unique(np.concatenate(take)))
+        neg_src = {0: [0]} if cfg["neg_mode"] == "uniform" else src
+        random.seed(2020)
+        np.random.seed(2020)
         c0 = time.perf_counter()
-        for i in range(args.cpu_steps):
-            ora.train_step(batches[(i + 1) % len(batches)])
+        smp = OracleSampler(ld, sd, td, neg_src, fold.item_dict, K, batch_size=B, gap_mode=cfg["gap_mode"], neg_mode=cfg["neg_mode"])
+        n_cpu = 0
+        while smp.has_next() and n_cpu < B * args.cpu_steps:
+            feed = batch_to_arrays(smp.next_batch())
+            ora.train_step(feed)
+            n_cpu += feed["seq"].shape[0]
         cdt = time.perf_counter() - c0
-        cpu = {"value": round(B * args.cpu_steps / cdt, 1), "unit": "sessions/s", "cores": cores, "host_threads": hw,
+        cpu = {"value": round(n_cpu / cdt, 1), "unit": "sessions/s", "cores": cores, "host_threads": hw,
                "kind": "port",
-               "sample": "%d training steps of B=%d (the same synthetic batches), PyTorch-CPU fp32 oracle on %d of the "
-                         "host's %d hardware threads (its fastest setting in a thread sweep)" % (args.cpu_steps, B, cores, hw)}
+               "sample": "%d sessions: the reference's loop on the CPU — per-click Python sampler (bucketed shuffle, batch "
+                         "formation, K negatives) + one training step per batch of <= %d — PyTorch-CPU fp32 oracle on %d of "
+                         "the host's %d hardware threads (its fastest setting in a thread sweep)" % (n_cpu, B, cores, hw)}
 
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e and N <= 200000 and not os.environ.get("TCAR_FORCE_DP"):
@@ -486,6 +540,11 @@ def main():
                                       "full-catalog scoring, clip %d + Adam" %
                                       (labels[args.config], N, H, B, K, cfg["neg_mode"], mean_T, 150),
                           "name": args.config, "global_batch": B * world, "parallelism": "dp%d" % world},
+               "timed_loop": ("device sampler (tcar_form_batch: batch formation + K negatives from HBM-resident stores) + "
+                              "forward + backward + clip + Adam per step" if headline_sampler else
+                              "forward + backward + clip + Adam per step over pre-formed resident feeds"),
+               ("device_step_sessions_per_s" if headline_sampler else "sampler_in_loop_sessions_per_s"):
+                   (round(other, 1) if other else None),
                "roofline": roof, "gather_roofline": gather, "cpu_baseline": cpu, "end_to_end_sessions_per_s": e2e, "exchange": exchange,
                "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
                "last_loss": round(last_loss, 4)}

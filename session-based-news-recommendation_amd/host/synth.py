@@ -137,10 +137,11 @@ class SynthFold:
             out[int(sid)] = ids.tolist()
         return out
 
-    def to_dicts(self, store: SessionStore, with_active=False) -> Tuple[dict, dict, dict]:
-        """Materialise (len_dict, session_dict, session_time_dict) in the reference's pickle form."""
+    def to_dicts(self, store: SessionStore, with_active=False, examples=None) -> Tuple[dict, dict, dict]:
+        """Materialise (len_dict, session_dict, session_time_dict) in the reference's pickle form (`examples`: only these rows
+        of the store)."""
         len_dict, sess, times = {}, {}, {}
-        for e in range(store.n):
+        for e in (range(store.n) if examples is None else [int(x) for x in examples]):
             o, o2 = int(store.off[e]), int(store.off[e + 1])
             key = store.keys[e]
             ids = store.items[o:o2].tolist()

@@ -124,6 +124,42 @@ def test_training_with_the_device_sampler_matches_the_oracle_on_the_same_feed():
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5)
 
 
+def test_planned_schedule_forms_the_same_feeds_one_batch_ahead():
+    """DeviceSampler.plan + planned (the trainer loop's path: indices resident, batch i + 1 formed on a side stream while step
+    i runs, two alternating feed buffers) yields, batch for batch, the feed that form() builds for the same examples and
+    counter — while training steps consume them."""
+    _need_gpu()
+    from tcar_amd.device_sampler import DeviceSampler
+    from tcar_amd.host.synth import SynthFold
+    fold = SynthFold(n_items=500, dim=32, n_train=3000, n_test=10, seed=4)
+    eng, _ = _engine(fold)
+    st = fold.train
+    sched = []
+    for T in (2, 1, 3, 2, 1):
+        ids = np.where(st.in_len == T)[0]
+        sched.append(ids[len(sched) * 7:len(sched) * 7 + (64 if T != 3 else 33)])
+    ref = DeviceSampler(eng, st, "uniform", seed=11)
+    want = [ref.read_back(ref.form(ids, 6, "click_delta", counter=i)) for i, ids in enumerate(sched)]
+    ds = DeviceSampler(eng, st, "uniform", seed=11)
+    ds.plan(sched)
+    got = []
+    for bt in ds.planned(6, "click_delta"):
+        eng.train_step(None, bt=bt, defer_update=True)          # the consumer's step reads the feed while the next one is formed
+        n = 7 * bt.B * bt.T + 3 * bt.B + bt.B * bt.K
+        got.append((bt.B, bt.T, bt._keep[:n].clone()))
+    eng.flush()
+    torch.cuda.synchronize()
+    assert len(got) == len(sched)
+    for (B, T, feed), w, ids in zip(got, want, sched):
+        assert B == len(ids) and T == w["seq"].shape[1]
+        f = feed.cpu().numpy()
+        n = B * T
+        assert np.array_equal(f[:n].reshape(B, T), w["seq"])
+        assert np.array_equal(f[7 * n + 2 * B:7 * n + 3 * B], w["label"])
+        assert np.array_equal(f[7 * n + 3 * B:].reshape(B, 6), w["neg"])
+        assert np.array_equal(f[6 * n:7 * n].reshape(B, T), w["gap"])
+
+
 def test_cli_trains_with_the_device_sampler():
     _need_gpu()
     from tcar_amd.host.cli import main
