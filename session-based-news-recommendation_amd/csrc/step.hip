@@ -19,7 +19,7 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
+    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_CHAIN_AFTER_DE", &TcarTuning::chain_after_de, 0},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -479,6 +479,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   tick(1, true, stream);
   // first use of the zeroed arena and of the negative term's forward outputs on the main stream
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
+  // TCAR_CHAIN_AFTER_DE=1 (A/B): the chain of small latency-bound kernels that follows dX starts only when dE has finished —
+  // beside the 106-MB write stream of dE every one of them runs ~2x slower than alone
+  if (split_finish && tcar_tuning().chain_after_de && hipStreamWaitEvent(st, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
   // order-fixed bias / residual-weight gradients (split-bf16 modes with the fused query chain and a row workspace): the
   // producers below leave the column sums to ONE tcar_colsum_det launch behind the weight-gradient GEMM
