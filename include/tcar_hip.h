@@ -442,7 +442,7 @@ int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, f
  * The IndexedSlices gradient of the item lookups (model_combine.py:54,142,156): B*T session rows + B*K negative rows.
  *   tcar_segsum_ws_bytes    workspace for up to max_sources = B*(T+K) sources
  *   tcar_segsum_index       sorts the sources of each list of `bt` (session clicks, negatives) by destination row, stably:
- *                           lists of up to 16384 sources by one workgroup each in LDS, longer ones through rocPRIM; depends
+ *                           lists of up to 16384 sources by one workgroup each in LDS, longer ones by the multi-workgroup form of the same sort; depends
  *                           on the feed only
  *   tcar_segsum_rows_buffer [B*T, ldh] buffer inside ws for the session sources' gradient rows (tcar_grads_t.rows_out)
  *   tcar_segsum_norms_buffer [B*T] buffer inside ws for their squared norms (tcar_grads_t.norms_out)

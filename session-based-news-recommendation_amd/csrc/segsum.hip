@@ -7,8 +7,8 @@
 // repeated runs differ in the last bit.  Here the order is fixed:
 //   1. index (depends on the feed only; the step driver runs it on the aux stream under the forward pass): the sources of
 //      each list — session clicks, negatives — sorted by destination row with a STABLE radix sort: lists of up to 16384
-//      sources in ONE workgroup each, keys and counters resident in LDS (no host-side library call on the step's path);
-//      longer lists through rocPRIM;
+//      sources in ONE workgroup each, keys and counters resident in LDS; longer lists through the same scheme spread over
+//      workgroups (count / offsets / scatter kernels per 4-bit pass) — no library call anywhere on the step's path;
 //   2. rows: every wave owns 4 sorted positions (a workgroup: 64) and sums the runs that START there, in sorted order =
 //      source order, then adds the sum into the dense gradient — ONE writer per destination row, no atomics, no partial
 //      rows in memory.  A run of more than 64 sources (a popular article) is summed by the 16 waves of its workgroup
@@ -17,10 +17,7 @@
 //      block partials of the dense norm are folded in index order by workgroup 0 of the session-list pass.
 // Bit-for-bit repeatable whatever the dispatch order.
 #include <cstring>
-#include <mutex>
-#include <unordered_map>
 #include "tcar_common.h"
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -31,7 +28,7 @@ constexpr int TAIL_BYTES = 4096;       // scratch at the end of the workspace: D
 
 struct SegWs {                         // carved out of the caller's workspace (all device pointers)
   unsigned* ks; unsigned* vs;          // sorted destination rows / source indices: session list [0, BT), negatives [BT, BT + BK)
-  unsigned* k_in; unsigned* v_in;      // unsorted (rocPRIM path only)
+  unsigned* k_in; unsigned* v_in;      // ping-pong partner of (ks, vs) in the multi-workgroup sort of long lists
   float* src_norm;                     // [B*T] squared norm of every session source row (written by the gather backward)
   float* rows;                         // [B*T, ldh] the session sources' gradient rows (written by the gather backward)
   void* sort_tmp; size_t sort_bytes;
@@ -49,19 +46,12 @@ size_t carve(SegWs& w, char* base, long n, int ldh, size_t sort_bytes) {
   return o;
 }
 
-// rocPRIM's size query walks its device configuration on the host: asked once per length
+// multi-workgroup sort of lists longer than SORT_MAX: 4096 sources per workgroup, 16 digit totals per workgroup and pass
+constexpr int RS_T = 256, RS_E = 16, RS_CHUNK = RS_T * RS_E;
 size_t sort_tmp_bytes(long n) {
   if (n <= SORT_MAX) return 0;
-  static std::mutex mu;
-  static std::unordered_map<long, size_t> cache;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = cache.find(n);
-  if (it != cache.end()) return it->second;
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned*)nullptr, (unsigned*)nullptr, (const unsigned*)nullptr,
-                                  (unsigned*)nullptr, (size_t)n, 0, 25, (hipStream_t)0);
-  cache[n] = bytes;
-  return bytes;
+  const long G = (n + RS_CHUNK - 1) / RS_CHUNK;
+  return (size_t)16 * G * sizeof(unsigned) + 256;
 }
 
 __device__ __forceinline__ unsigned key_of(int list, int id, int n_items) {
@@ -143,11 +133,122 @@ __global__ __launch_bounds__(SORT_T) void lds_sort_kernel(const SortArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void make_keys_kernel(long n, int list, int n_items, const int32_t* __restrict__ ids,
-                                                        unsigned* __restrict__ k, unsigned* __restrict__ v) {
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    k[i] = key_of(list, ids[i], n_items);
-    v[i] = (unsigned)i;
+// ---- lists longer than SORT_MAX: the same stable LSD radix sort (4 bits per pass), spread over workgroups ----------------
+// Workgroup b owns the 4096 consecutive positions [4096 b, 4096 b + 4096) of the pass's input order and thread t the 16
+// consecutive ones [16 t, 16 t + 16) of those, so equal digits keep their order everywhere.  Per pass:
+//   count    digit totals of every workgroup                       -> tot[digit][workgroup]
+//   offsets  ONE workgroup: exclusive scan of tot in digit-major order (= first output position of every (digit, workgroup))
+//   scatter  every workgroup re-counts per thread, scans (digit-major, as in lds_sort_kernel) and writes its elements in order.
+// Pass 0 reads the feed itself (key = destination row, value = source index); the buffers (k_in, v_in) / (ks, vs) alternate so
+// that the last pass lands in (ks, vs).
+struct RadixArgs {
+  const int32_t* ids; int list, n_items, first;
+  const unsigned* kin; const unsigned* vin; unsigned* kout; unsigned* vout;
+  long n; int shift, G; unsigned* tot;
+};
+__device__ __forceinline__ void radix_elem(const RadixArgs& a, long e, unsigned& k, unsigned& v) {
+  if (a.first) { k = key_of(a.list, a.ids[e], a.n_items); v = (unsigned)e; }
+  else { k = a.kin[e]; v = a.vin[e]; }
+}
+__global__ __launch_bounds__(RS_T) void radix_count_kernel(const RadixArgs a) {
+  __shared__ unsigned cnt[16 * RS_T];
+  const int tid = threadIdx.x;
+  const long e0 = (long)blockIdx.x * RS_CHUNK + (long)tid * RS_E;
+  unsigned c[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) c[d] = 0;
+  for (int i = 0; i < RS_E; ++i) {
+    const long e = e0 + i;
+    if (e < a.n) {
+      unsigned k, v;
+      radix_elem(a, e, k, v);
+      const unsigned dg = (k >> a.shift) & 15u;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) c[d] += (dg == (unsigned)d) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 16; ++d) cnt[d * RS_T + tid] = c[d];
+  __syncthreads();
+  if (tid < 16) {
+    unsigned t = 0;
+    for (int j = 0; j < RS_T; ++j) t += cnt[tid * RS_T + j];
+    a.tot[(long)tid * a.G + blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(1024) void radix_offsets_kernel(unsigned* __restrict__ tot, long m) {
+  __shared__ unsigned wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long per = (m + 1023) / 1024, lo = (long)tid * per < m ? (long)tid * per : m, hi = lo + per < m ? lo + per : m;
+  unsigned s = 0;
+  for (long i = lo; i < hi; ++i) s += tot[i];
+  unsigned inc = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned up = __shfl_up(inc, o);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wsum[wv] = inc;
+  __syncthreads();
+  unsigned base = inc - s;
+  for (int w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+  for (long i = lo; i < hi; ++i) { const unsigned t = tot[i]; tot[i] = base; base += t; }
+}
+__global__ __launch_bounds__(RS_T) void radix_scatter_kernel(const RadixArgs a) {
+  __shared__ unsigned cnt[16 * RS_T];
+  __shared__ unsigned wsum[RS_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long e0 = (long)blockIdx.x * RS_CHUNK + (long)tid * RS_E;
+  unsigned k[RS_E], v[RS_E];
+  unsigned c[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) c[d] = 0;
+#pragma unroll
+  for (int i = 0; i < RS_E; ++i) {
+    k[i] = 0xffffffffu; v[i] = 0;
+    if (e0 + i < a.n) {
+      radix_elem(a, e0 + i, k[i], v[i]);
+      const unsigned dg = (k[i] >> a.shift) & 15u;
+#pragma unroll
+      for (int d = 0; d < 16; ++d) c[d] += (dg == (unsigned)d) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 16; ++d) cnt[d * RS_T + tid] = c[d];
+  __syncthreads();
+  {  // exclusive scan of the 16 * 256 counters in digit-major order, in place (thread t owns entries [16 t, 16 t + 16))
+    unsigned cc[16], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { cc[j] = cnt[tid * 16 + j]; tot += cc[j]; }
+    unsigned inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(inc, o);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    unsigned base = inc - tot;
+    for (int w2 = 0; w2 < wv; ++w2) base += wsum[w2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { cnt[tid * 16 + j] = base; base += cc[j]; }
+  }
+  __syncthreads();
+  // position of this thread's first element of digit d: global base of (d, workgroup) + elements of digit d in earlier threads
+  unsigned off[16];
+#pragma unroll
+  for (int d = 0; d < 16; ++d) off[d] = a.tot[(long)d * a.G + blockIdx.x] + cnt[d * RS_T + tid] - cnt[d * RS_T];
+#pragma unroll
+  for (int i = 0; i < RS_E; ++i) {
+    if (e0 + i < a.n) {
+      const unsigned dg = (k[i] >> a.shift) & 15u;
+      unsigned pos = 0;
+#pragma unroll
+      for (int d = 0; d < 16; ++d)
+        if (dg == (unsigned)d) { pos = off[d]; off[d] += 1; }
+      a.kout[pos] = k[i];
+      a.vout[pos] = v[i];
+    }
   }
 }
 
@@ -364,13 +465,21 @@ extern "C" int tcar_segsum_index(const tcar_dims_t* d, const tcar_batch_t* bt, v
     const long nl = a.n[list];
     if (nl <= SORT_MAX) continue;
     if (!w.sort_tmp || sort_tmp_bytes(nl) > w.sort_bytes) return TCAR_E_ARG;    // carved for a sort of n >= nl elements
-    TCAR_LAUNCH(make_keys_kernel, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, st, nl, list, d->n_items, a.ids[list],
-                w.k_in + a.lo[list], w.v_in + a.lo[list]);
-    TCAR_CHECK_LAUNCH();
-    size_t bytes = w.sort_bytes;
-    if (rocprim::radix_sort_pairs(w.sort_tmp, bytes, (const unsigned*)(w.k_in + a.lo[list]), w.ks + a.lo[list],
-                                  (const unsigned*)(w.v_in + a.lo[list]), w.vs + a.lo[list], (size_t)nl, 0, 25, st) != hipSuccess)
-      return TCAR_E_LAUNCH;
+    RadixArgs r{};
+    r.ids = a.ids[list]; r.list = list; r.n_items = d->n_items; r.n = nl;
+    r.G = (int)((nl + RS_CHUNK - 1) / RS_CHUNK);
+    r.tot = (unsigned*)w.sort_tmp;
+    unsigned* bufk[2] = {w.k_in + a.lo[list], w.ks + a.lo[list]};
+    unsigned* bufv[2] = {w.v_in + a.lo[list], w.vs + a.lo[list]};
+    for (int pass = 0; pass < a.npass; ++pass) {
+      const int dst = ((a.npass - 1 - pass) & 1) ? 0 : 1;          // the last pass writes (ks, vs)
+      r.first = pass == 0; r.shift = 4 * pass;
+      r.kin = bufk[1 - dst]; r.vin = bufv[1 - dst]; r.kout = bufk[dst]; r.vout = bufv[dst];
+      TCAR_LAUNCH(radix_count_kernel, dim3((unsigned)r.G), dim3(RS_T), 0, st, r);
+      TCAR_LAUNCH(radix_offsets_kernel, dim3(1), dim3(1024), 0, st, r.tot, (long)16 * r.G);
+      TCAR_LAUNCH(radix_scatter_kernel, dim3((unsigned)r.G), dim3(RS_T), 0, st, r);
+      TCAR_CHECK_LAUNCH();
+    }
   }
   return TCAR_OK;
 }

@@ -1054,13 +1054,15 @@ def test_gather_forward_throughput_form_equals_latency_form(lib, B, T, H, Ht):
 
 @pytest.mark.parametrize("B,T,K,N,ldh", [(512, 2, 20, 3000, 256), (64, 40, 7, 50, 256), (300, 5, 0, 100000, 256), (1, 1, 3, 10, 256),
                                          (2048, 40, 2, 500, 256), (512, 32, 33, 2, 256), (128, 3, 4, 1_000_000, 512),
-                                         (4096, 4, 1, 70000, 320)])
+                                         (4096, 4, 1, 70000, 320), (1024, 40, 20, 70000, 256), (1024, 20, 0, 5000, 256)])
 def test_sorted_segmented_item_scatter(lib, B, T, K, N, ldh):
     """tcar_segsum_*: the item-row gradients of the gathers (mode 0) and of the negatives (mode 1) added into the dense
     gradient by sort + segmented sum — head-heavy ids (runs of hundreds: multi-chunk runs), against np.add.at in fp64, the
-    folds of the norms, and bit-for-bit repeatability.  Lists of up to 16384 sources are sorted in LDS, the last case takes
-    the rocPRIM path for its session list; its head article has a run of thousands (summed by a whole workgroup).  The last
-    three: a 2-item catalog with both lists at / over the LDS-sort limit (16,384 session sources exactly, 16,896 negatives:
+    folds of the norms, and bit-for-bit repeatability.  Lists of up to 16384 sources are sorted in ONE workgroup's LDS, longer
+    ones by the multi-workgroup form of the same stable radix sort (count / offsets / scatter per 4-bit pass; odd and even pass
+    counts: the ping-pong must end in the sorted buffers) — (2048, 40, 2, 500): session list of 81,920, its head article has a run
+    of thousands (summed by a whole workgroup); (1024, 40, 20, 70000): both lists long, five passes; (1024, 20, 0, 5000): four
+    passes.  Further: a 2-item catalog with both lists at / over the LDS-sort limit (16,384 session sources exactly, 16,896 negatives:
     one 1-bit pass, runs of thousands), a 1 M-item catalog (20 key bits: five passes) with 512-column rows (two column
     chunks per wave), and a row width that is not a multiple of 256."""
     from tcar_amd._lib import Batch, Dims
