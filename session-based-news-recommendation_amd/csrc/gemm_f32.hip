@@ -52,6 +52,8 @@ struct GemmProb {
 };
 struct GroupArgs {
   int nprob;
+  int wg0[MAXP];            // first workgroup id of every problem (INT_MAX past nprob): ONE contiguous scalar load finds a
+                            // workgroup's problem — a loop over p[i].wg_begin costs a dependent scalar-load round trip per problem
   GemmProb p[MAXP];
 };
 
@@ -124,9 +126,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GroupArgs ga) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   int pi = 0;
-#pragma unroll 1
-  for (int i = 1; i < ga.nprob; ++i)
-    if (id >= ga.p[i].wg_begin) pi = i;
+#pragma unroll
+  for (int i = 1; i < MAXP; ++i) pi += (id >= ga.wg0[i]) ? 1 : 0;
   const GemmProb& g = ga.p[pi];
   id -= g.wg_begin;
   const int tiles = g.mt * g.nt;
@@ -361,9 +362,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   int pi = 0;
-#pragma unroll 1
-  for (int i = 1; i < ga.nprob; ++i)
-    if (id >= ga.p[i].wg_begin) pi = i;
+#pragma unroll
+  for (int i = 1; i < MAXP; ++i) pi += (id >= ga.wg0[i]) ? 1 : 0;
   const GemmProb& g = ga.p[pi];
   id -= g.wg_begin;
   const int tiles = g.mt * g.nt;
@@ -511,8 +511,10 @@ int launch_layout(GroupArgs& ga, hipStream_t st) {
     p.mt = (p.M + T - 1) / T;
     p.nt = (p.N + T - 1) / T;
     p.wg_begin = wg;
+    ga.wg0[i] = wg;
     wg += p.mt * p.nt * p.ksplit;
   }
+  for (int i = ga.nprob; i < MAXP; ++i) ga.wg0[i] = 0x7fffffff;
   if (T == 128) return launch_variant<LA, LB, 128, 128>(ga, wg, st);
   return launch_variant<LA, LB, 64, 64>(ga, wg, st);
 }
@@ -534,8 +536,10 @@ int launch_x3(GroupArgs& ga, hipStream_t st) {
     p.mt = (p.M + 63) / 64;
     p.nt = (p.N + 63) / 64;
     p.wg_begin = wg;
+    ga.wg0[i] = wg;
     wg += p.mt * p.nt * p.ksplit;
   }
+  for (int i = ga.nprob; i < MAXP; ++i) ga.wg0[i] = 0x7fffffff;
   // 64-deep stages (48 KB of LDS): these launches run beside the dE GEMM, whose workgroups hold 96 KB of a CU's 160 KB — a
   // 96-KB (128-deep) workgroup would have to wait for one of them to retire (measured: 0.704 / 0.690 / 0.680 ms per step with
   // 128-deep / mixed / 64-deep stages).  A register ring of 2-3 stages does not pay for long K (profiles/r02_x3_small_gemm_bench.txt:

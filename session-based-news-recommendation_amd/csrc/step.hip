@@ -19,7 +19,8 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_CHAIN_AFTER_DE", &TcarTuning::chain_after_de, 0},
+    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
+    {"TCAR_NEG_S3", &TcarTuning::neg_s3, 1},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -468,6 +469,16 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     return TCAR_OK;
   };
   RET(chain_b());
+  // negative rows of the item gradient (sorted sum) + the loss: they need dE's item block and nothing of the main chain — on
+  // the third stream (idle until the weight gradients) the moment dE lands, instead of on the main chain behind its small GEMMs
+  const bool neg_s3 = split_finish && has_neg && sorted && c->stream3 && c->ev3 && tcar_tuning().neg_s3;
+  if (neg_s3) {
+    hipStream_t s3n = (hipStream_t)c->stream3;
+    if (hipStreamWaitEvent(s3n, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
+    RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, c->segsum_bytes, 1, nullptr, c->neg_coef, c->attout, g.ek, Gi, nullptr, nullptr,
+                          c->ce, c->neg_fb, c->neg_weight, c->loss, (void*)s3n));
+    if (hipEventRecord((hipEvent_t)c->ev[3], s3n) != hipSuccess) return TCAR_E_LAUNCH;
+  }
   // ---- chain A
   tick(1, false, stream);
   if (c->scoring) {
@@ -479,9 +490,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   tick(1, true, stream);
   // first use of the zeroed arena and of the negative term's forward outputs on the main stream
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
-  // TCAR_CHAIN_AFTER_DE=1 (A/B): the chain of small latency-bound kernels that follows dX starts only when dE has finished —
-  // beside the 106-MB write stream of dE every one of them runs ~2x slower than alone
-  if (split_finish && tcar_tuning().chain_after_de && hipStreamWaitEvent(st, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
+  // (Round 3 A/B: letting the chain of small kernels behind dX wait until dE has finished — every one of them runs ~2x slower
+  // beside dE's 106-MB write stream — loses more in idle time than the faster kernels give back: 0.647 vs 0.620 ms per step.)
   // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
   // order-fixed bias / residual-weight gradients (split-bf16 modes with the fused query chain and a row workspace): the
   // producers below leave the column sums to ONE tcar_colsum_det launch behind the weight-gradient GEMM
@@ -577,8 +587,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
   if (split_finish) {   // Gi is complete once dE has landed: negative rows (+ loss), then its norm BEFORE any row scatter (S5)
-    if (hipStreamWaitEvent(st, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
-    if (has_neg && sorted) {
+    if (hipStreamWaitEvent(st, (hipEvent_t)(neg_s3 ? c->ev[3] : c->ev[4]), 0) != hipSuccess) return TCAR_E_LAUNCH;
+    if (neg_s3) {
+      // (done on the third stream)
+    } else if (has_neg && sorted) {
       RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, c->segsum_bytes, 1, nullptr, c->neg_coef, c->attout, g.ek, Gi, nullptr, nullptr,
                             c->ce, c->neg_fb, c->neg_weight, c->loss, stream));
     } else if (has_neg) {
