@@ -415,6 +415,21 @@ def main():
             if not ms:
                 continue
             avg = float(np.mean(ms))
+            if tag == "session_proj":
+                # the grouped projection launch of both attention layers (modules.py:94-96,126-131: X W_in + C W_c + I W_int,
+                # X_t W'_in + C W'_c, and the first click-query layer) — the largest of the session-side small GEMMs
+                # (gemm_x3_kernel, fp32 operands split to bf16 hi/lo while staging: 3 MFMAs per product).  Algorithmic flops
+                # per SURVEY.md 8(d) at the schedule's mean input length; a latency-bound launch, priced against the MFMA peak.
+                fl = B * (2.0 * mean_T * ((2 * H + H + Ht) * H + (5 * Ht + H) * H) + 2.0 * (2 * Ht) * H)
+                ach = fl / (avg * 1e-3) / 1e12
+                ents.append({"kernel": "gemm_x3_kernel, grouped projections of both attention layers (modules.py:94-96,126-131)",
+                             "tag": tag, "bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                             "frac": round(ach / peak, 5), "frac_mfma_executed": round(3 * ach / peak, 5), "traffic": None,
+                             "flops_per_launch": fl, "launches": len(ms), "avg_ms": round(avg, 5), "total_ms": round(avg * len(ms), 3),
+                             "note": "latency bound: one 128-deep K chunk per workgroup (416 workgroups at T = 1), 7 such launches per step",
+                             "timing": "HIP events on the launch stream inside the timed steps"})
+                kernels[tag] = {"launches": len(ms), "avg_ms": round(avg, 5), "tflops": round(ach, 3)}
+                continue
             if tag.startswith("shard_"):
                 ach = flops[tag] / (avg * 1e-3) / 1e12
                 ents.append({"kernel": "tcar_%s: %s" % (tag, ref[tag]), "tag": tag, "bound": "mfma", "achieved": round(ach, 2),
@@ -436,7 +451,11 @@ def main():
             # result once
             opb = 4 if args.scoring == "f32" else 2 * (2 if mult == 3 else 1)
             n_rows = g.Npad if n_local == N else ((n_local + 127) // 128) * 128
-            alg_bytes = {"score_fwd": opb * (n_rows * g.ek + b_glob * g.ek) + 4 * b_glob * n_rows,
+            # (training steps of the mixed precision: the logits GEMM's softmax epilogue writes a bf16 plane + group statistics,
+            # not fp32 logits)
+            ce_epi = args.scoring == "bf16x3-mixed" and n_local == N and os.environ.get("TCAR_FUSED_CE", "1") != "0"
+            out_fwd = (2 * b_glob * n_rows + 8 * b_glob * (n_rows // 96)) if ce_epi else 4 * b_glob * n_rows
+            alg_bytes = {"score_fwd": opb * (n_rows * g.ek + b_glob * g.ek) + out_fwd,
                          "score_dx": opb * (b_glob * n_rows + n_rows * g.ek) + 4 * sk * b_glob * g.ek,
                          "score_dE": opb * (b_glob * n_rows + b_glob * (g.ldh + g.pt)) + 4 * n_local * (g.ldh + g.pt)}[tag]
             gbs = alg_bytes / (avg * 1e-3) / 1e9

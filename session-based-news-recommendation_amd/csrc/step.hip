@@ -152,7 +152,7 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
 namespace {
 // model_combine.py:52-132 for the sessions of `bt`: gather + clip, the three input projections, the click query, both
 // attention pools and the output transforms -> c->attout [B, ek] (+ its bf16 planes when `planes`)
-int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes) {
+int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei = -1) {
   const int B = bt->B, BT = bt->B * bt->T;
   tcar_tables_t tab;
   tables_of(c, tab);
@@ -176,7 +176,10 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     p[3] = prob1(BT, g.ldh, c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt, s2, g.ldh, nullptr, 0, 0, units(g.pt));
     p[4] = prob1(BT, g.ldh, x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh, s2 + units(g.pt) * stride, g.ldh, nullptr, 0, 0, units(g.ldh));
     p[5] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
+    // optional HIP events around exactly this launch (kind 3 of ev_start / ev_stop: the largest of the session-side small GEMMs)
+    if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[3 * c->ev_n + ei], (hipStream_t)stream);
     RET(small_gemm(c, 0, 6, p, stream));
+    if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[3 * c->ev_n + ei], (hipStream_t)stream);
   } else {
     tcar_gemm_desc_t p[3];
     p[0] = prob(BT, g.ldh, c->pre1, g.ldh);
@@ -298,16 +301,17 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       return TCAR_E_LAUNCH;
     RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)s2));
   }
-  RET(session_forward(c, bt, g, stream, c->scoring != 0));
+  // optional device timing (bench.py roofline): one slot per step, chosen here; the backward pass of this step uses the same slot
+  int ei = -1;
+  if (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) {
+    ei = c->ev_cursor[0]++ % c->ev_n;
+    c->ev_cursor[1] = ei;
+  }
+  RET(session_forward(c, bt, g, stream, c->scoring != 0, ei));
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
-  int ei = -1;
   auto start_timer = [&]() {
-    if (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) {
-      ei = c->ev_cursor[0]++ % c->ev_n;
-      c->ev_cursor[1] = ei;              // the backward pass of this step times dX / dE into the same slot
-      (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
-    }
+    if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
   };
   int rc;
   if (c->scoring) {

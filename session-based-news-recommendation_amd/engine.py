@@ -806,7 +806,7 @@ class TcarEngine:
 
     _ev = None
 
-    TIMED_KERNELS = ("score_fwd", "score_dx", "score_dE")      # kinds 0, 1, 2 of tcar_ctx_t.ev_start / ev_stop
+    TIMED_KERNELS = ("score_fwd", "score_dx", "score_dE", "session_proj")      # kinds 0..3 of tcar_ctx_t.ev_start / ev_stop
 
     def enable_native_timing(self, n: int):
         """HIP events around the three full-catalog GEMMs inside tcar_train_step (logits, dX, dE), each pair recorded on the
