@@ -20,7 +20,7 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
-    {"TCAR_NEG_S3", &TcarTuning::neg_s3, 1},
+    {"TCAR_REST_AFTER", &TcarTuning::rest_after, 0},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -152,7 +152,10 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
 namespace {
 // model_combine.py:52-132 for the sessions of `bt`: gather + clip, the three input projections, the click query, both
 // attention pools and the output transforms -> c->attout [B, ek] (+ its bf16 planes when `planes`)
-int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei = -1) {
+// `hook(stage)`: called behind the projection launch (1) and behind the click-query launch (2) — forward_impl forks the rest
+// pass of a pending split update there
+template <class Hook>
+int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei, Hook hook) {
   const int B = bt->B, BT = bt->B * bt->T;
   tcar_tables_t tab;
   tables_of(c, tab);
@@ -192,10 +195,12 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
     RET(small_gemm(c, 0, 3, p, stream));
   }
+  RET(hook(1));
   {  // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
     RET(small_gemm(c, 0, 1, &p, stream));
   }
+  RET(hook(2));
   if (split)
     RET(tcar_attn_pool_fwd_slabs(&c->d, B, bt->T, c->x_icp, c->x_pt, c->proj_slabs, n1, c->proj_slabs + n1 * stride, n2, stride,
                                  c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
@@ -262,6 +267,17 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   // the session side (gather, projections, pools) runs on the main one; the logits GEMM joins them.
   hipStream_t s1 = (hipStream_t)stream, s2 = aux_stream(c);
   bool joined = true;
+  int rest_stage = -1;
+  // REST pass of a pending split update, on the aux stream (behind whatever the main stream has enqueued so far when it is
+  // forked late); ev[1] = "aux stream ready for the logits GEMM"
+  auto launch_rest = [&]() -> int {
+    const float* pieces = c->Gx + c->arena_n;
+    RET(tcar_clip_adam_rest(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
+                            c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
+                            c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2));
+    if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+    return TCAR_OK;
+  };
   if (refresh_time) {
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
@@ -279,10 +295,8 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
         return TCAR_E_LAUNCH;
       RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, (void*)s2));
-      RET(tcar_clip_adam_rest(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
-                              c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
-                              c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2));
-      if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+      rest_stage = tcar_tuning().rest_after;      // 0: the rest pass follows at once; 1 / 2: behind the projection / query launch
+      if (rest_stage <= 0) RET(launch_rest());
       joined = false;
     } else {
       if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
@@ -307,7 +321,13 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     ei = c->ev_cursor[0]++ % c->ev_n;
     c->ev_cursor[1] = ei;
   }
-  RET(session_forward(c, bt, g, stream, c->scoring != 0, ei));
+  RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage) -> int {
+    if (stage != rest_stage) return TCAR_OK;
+    // late fork: the HBM-bound rest pass starts only now, so the launches before this point ran without it
+    if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
+      return TCAR_E_LAUNCH;
+    return launch_rest();
+  }));
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   auto start_timer = [&]() {
@@ -475,7 +495,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   RET(chain_b());
   // negative rows of the item gradient (sorted sum) + the loss: they need dE's item block and nothing of the main chain — on
   // the third stream (idle until the weight gradients) the moment dE lands, instead of on the main chain behind its small GEMMs
-  const bool neg_s3 = split_finish && has_neg && sorted && c->stream3 && c->ev3 && tcar_tuning().neg_s3;
+  const bool neg_s3 = split_finish && has_neg && sorted && c->stream3 && c->ev3;
   if (neg_s3) {
     hipStream_t s3n = (hipStream_t)c->stream3;
     if (hipStreamWaitEvent(s3n, (hipEvent_t)c->ev[4], 0) != hipSuccess) return TCAR_E_LAUNCH;
@@ -727,7 +747,7 @@ extern "C" int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t
   RET(check_ctx(c, bt));
   if (!c->scoring) return TCAR_E_ARG;                   // split-bf16 modes only
   const Geo g(c->d);
-  RET(session_forward(c, bt, g, stream, false));
+  RET(session_forward(c, bt, g, stream, false, -1, [](int) { return (int)TCAR_OK; }));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, stream));
   return TCAR_OK;
