@@ -309,12 +309,6 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       }
     }
   }
-  if (train_index && sorted_rows(c, bt)) {   // behind the join point: the logits GEMM does not wait for it, the backward does
-    if (!refresh_time &&
-        (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
-      return TCAR_E_LAUNCH;
-    RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)s2));
-  }
   // optional device timing (bench.py roofline): one slot per step, chosen here; the backward pass of this step uses the same slot
   int ei = -1;
   if (c->ev_n > 0 && c->ev_start && c->ev_stop && c->ev_cursor) {
@@ -328,6 +322,14 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       return TCAR_E_LAUNCH;
     return launch_rest();
   }));
+  // sort index of the item rows (feed only): on the aux stream BEHIND the rest pass — the logits GEMM does not wait for it (ev[1]
+  // was recorded in front of it), the backward does
+  if (train_index && sorted_rows(c, bt)) {
+    if (!refresh_time &&
+        (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+      return TCAR_E_LAUNCH;
+    RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)s2));
+  }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   auto start_timer = [&]() {
