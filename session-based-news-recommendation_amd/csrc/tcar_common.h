@@ -62,7 +62,6 @@ struct TcarTuning {
   int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
   int x3_oneshot;       // TCAR_X3_ONESHOT     0: short-K small-GEMM launches keep the one-stage register ring
   int fused_ce;         // TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel
-  int rest_after;       // TCAR_REST_AFTER     rest pass of a split update forked 0: at once, 1: behind the projections, 2: behind the query MLP
   int proj_split;       // TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs
 };
 const TcarTuning& tcar_tuning();
