@@ -61,6 +61,12 @@ def category_table(reverse_item: dict, category_id, n_items: int) -> np.ndarray:
         else:
             labels.append(None)
             missing.append(i)
+    if missing:
+        # the reference would raise KeyError the first time one of these is recommended (model_combine.py:180): say once that
+        # ILD / unexp are computed on a fold where the reference's evaluation could fail
+        import sys
+        print("[tcar] %d of %d catalog items have no category: each counts as a category of its own in ILD / unexp "
+              "(the reference raises KeyError when one is recommended)" % (len(missing), n_items), file=sys.stderr)
     out = np.empty(n_items, dtype=np.int64)
     known = [l for l in labels if l is not None]
     codes = {}

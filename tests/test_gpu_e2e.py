@@ -227,6 +227,26 @@ def test_cli_runs_on_a_fold_in_the_reference_pickle_layout(tmp_path):
     assert abs(a["loss"] - b["loss"]) <= 0.03 * abs(b["loss"]), (a["loss"], b["loss"])
     assert abs(a["recall"] - b["recall"]) <= 0.06 and abs(a["mrr"] - b["mrr"]) <= 0.04, (a, b)
     assert model.train_sessions == mem.train_sessions == 2500
+    # EXACT check of the tensoriser on the device path: the store built from the files equals the in-memory store example by
+    # example (matched through the session keys), and the feeds the device sampler forms from either are identical arrays
+    from tcar_amd.device_sampler import DeviceSampler
+    from tcar_amd.host.data import SessionStore, load_fold
+    train = load_fold(str(base) + "/", 1)[0]
+    fs, ms = SessionStore.from_dicts(train[1], train[2]), fold.train
+    where = np.asarray([fs.key_index[k] for k in ms.keys], dtype=np.int64)      # file-store row of every in-memory example
+    assert np.array_equal(fs.in_len[where], ms.in_len)
+
+    def clicks(st, rows):
+        return np.concatenate([np.arange(st.off[r], st.off[r + 1]) for r in rows])
+    cf, cm = clicks(fs, where), clicks(ms, np.arange(ms.n))
+    for name in ("items", "pub", "clk", "gap_active", "gap_delta"):
+        assert np.array_equal(getattr(fs, name)[cf], getattr(ms, name)[cm]), name
+    df, dm = DeviceSampler(model.engine, fs, "uniform", seed=3), DeviceSampler(mem.engine, ms, "uniform", seed=3)
+    for T in (1, 2, 3):
+        rows = np.where(ms.in_len == T)[0][:96]
+        a_, b_ = df.read_back(df.form(where[rows], 5, "active_t", counter=7)), dm.read_back(dm.form(rows, 5, "active_t", counter=7))
+        for k in ("seq", "pm", "pd", "pw", "ph", "pmi", "gap", "cw", "ch", "label"):
+            assert np.array_equal(a_[k], b_[k]), (T, k)
 
 
 def test_cli_checkpoint_save_then_test_only(tmp_path):
