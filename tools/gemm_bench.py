@@ -1,5 +1,5 @@
 """Micro-benchmark of the split-bf16 scoring GEMMs at the Globo shape (B=512, N=46033, K=832).
-Usage: python tools/gemm_bench.py [fwd|dx|de|both] [nsplit] [iters]
+Usage: python tools/gemm_bench.py [fwd|fwdce|dx|de|both] [nsplit] [iters]      (fwdce: the logits GEMM with its softmax epilogue)
 `both`: dX on a high-priority stream and dE on a second stream, concurrently, as the step driver runs them."""
 import ctypes as C
 import os
@@ -26,6 +26,11 @@ ap_h, ap_l = torch.randn(B, 576, **bf), torch.randn(B, 576, **bf) * 0.004
 logits = torch.empty(B, Npad, device="cuda")
 slabs = torch.empty(SK, B, EK, device="cuda")
 gi, det = torch.empty(N, 256, device="cuda"), torch.empty(N, 320, device="cuda")
+plane = torch.zeros(B, Npad, **bf)
+nstat = B * ((N + 63) // 64 + 8) * 2
+stats, lab_logit = torch.empty(nstat, device="cuda"), torch.empty(B, device="cuda")
+label = torch.randint(0, N, (B,), dtype=torch.int32, device="cuda")
+gw, ng = C.c_int32(0), C.c_int32(0)
 
 
 hp, s2 = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
@@ -50,6 +55,9 @@ def run():
         return run_both()
     if which == "fwd":
         return lib.tcar_gemm_bf16(1, B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, p(logits), Npad, None, 0, 0, nsplit, 1, None), 2.0 * B * N * 820
+    if which == "fwdce":
+        return lib.tcar_gemm_bf16_ce(B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, p(plane), Npad, B, p(stats), nstat,
+                                     p(label), p(lab_logit), nsplit, C.byref(gw), C.byref(ng), None), 2.0 * B * N * 820
     if which == "dx":
         return lib.tcar_gemm_bf16(0, B, EK, Npad, p(d_h), p(d_l), Npad, B, p(e_h), p(e_l), EK, Npad, p(slabs), EK, None, 0, 0, nsplit, SK, None), 2.0 * B * N * 820
     return lib.tcar_gemm_bf16(2, N, 576, B, p(d_h), p(d_l), Npad, B, p(ap_h), p(ap_l), 576, B, p(gi), 256, p(det), 320, 256, nsplit, 1, None), 2.0 * B * N * 570
