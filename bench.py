@@ -16,8 +16,8 @@ stream while step i runs.  `--resident_feed` times the loop over pre-formed feed
 "device_step_sessions_per_s" in the default run).  Rank 0 prints ONE JSON line: whole-job sessions/sec plus
   "roofline"      the kernel with the largest total time among the three full-catalog GEMMs (logits = attout E^T,
                   dX = dlogits E, dE = dlogits^T attout): algorithmic FLOPs per launch / mean HIP-event duration of that
-                  launch measured IN the timed steps, on the stream the kernel is launched on (the C++ step driver records the
-                  events), against the dense bf16 MFMA peak (fp32 matrix peak for --scoring f32) of
+                  launch, measured live in a second pass of the same K steps, on the stream the kernel is launched on (the C++
+                  step driver records the events; the headline pass runs without them), against the dense bf16 MFMA peak (fp32 matrix peak for --scoring f32) of
                   /opt/skills/guides/MI355X_MICROARCH.md; "others" lists the other two the same way; "traffic" = HBM bytes
                   per launch from the committed rocprofv3 --pmc passes under profiles/ (null when the shape differs);
   "gather_roofline"  the embedding-gather kernel at 655,360 rows against the 8 TB/s HBM peak (the north star's >= 70 % target);
@@ -376,10 +376,15 @@ def main():
     if not (args.no_cpu_baseline and args.no_e2e):          # (the A/B tools time the headline loop only)
         dt_o, _ = timed(not headline_sampler)
         other = B * world * args.steps / dt_o
-    if not args.no_kernel_timing:
-        eng.enable_native_timing(args.steps)     # HIP events around the three scoring GEMMs inside the step driver
     dt, t_enq = timed(headline_sampler)
     last_loss = float(eng.loss[:B].mean())
+    dt_ev = None
+    if not args.no_kernel_timing:
+        # kernel timing: a SECOND pass of the same K steps with HIP events around the three scoring GEMMs and the projection
+        # launch, recorded by the C++ step driver on the stream each kernel is launched on.  The events are kept out of the
+        # headline pass: every event pair in the middle of a stream's chain costs ~5-10 us of bubble (8 pairs per step = 2-3 %).
+        eng.enable_native_timing(args.steps)
+        dt_ev, _ = timed(headline_sampler)
     if hasattr(eng, "exchange_info"):
         exchange = eng.exchange_info()        # after the timed steps: carries the bytes each collective moved per step
     value = B * world * args.steps / dt
@@ -427,7 +432,7 @@ def main():
                              "frac": round(ach / peak, 5), "frac_mfma_executed": round(3 * ach / peak, 5), "traffic": None,
                              "flops_per_launch": fl, "launches": len(ms), "avg_ms": round(avg, 5), "total_ms": round(avg * len(ms), 3),
                              "note": "latency bound: one 128-deep K chunk per workgroup (416 workgroups at T = 1), 7 such launches per step",
-                             "timing": "HIP events on the launch stream inside the timed steps"})
+                             "timing": "HIP events on the launch stream, second pass of the same steps"})
                 kernels[tag] = {"launches": len(ms), "avg_ms": round(avg, 5), "tflops": round(ach, 3)}
                 continue
             if tag.startswith("shard_"):
@@ -436,7 +441,7 @@ def main():
                              "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                              "flops_per_launch": flops[tag], "launches": len(ms), "avg_ms": round(avg, 5),
                              "total_ms": round(avg * len(ms), 3),
-                             "timing": "HIP events around the C-ABI call (several kernels) inside the timed steps"})
+                             "timing": "HIP events around the C-ABI call (several kernels), second pass of the same steps"})
                 kernels[tag] = {"launches": len(ms), "avg_ms": round(avg, 5), "tflops": round(ach, 2)}
                 continue
             ach = flops[tag] / (avg * 1e-3) / 1e12
@@ -469,7 +474,7 @@ def main():
                         "launches": len(ms), "avg_ms": round(avg, 5), "total_ms": round(avg * len(ms), 3),
                         "tflops": round(ach, 2), "mfma_executed_tflops": round(ach * mult, 2), "frac_mfma_executed": round(f_mfma, 4),
                         "hbm_GBps_algorithmic": round(gbs, 1), "frac_hbm": round(f_hbm, 4),
-                        "timing": "HIP events on the launch stream inside the timed steps (other streams' kernels co-run)"})
+                        "timing": "HIP events on the launch stream in a second pass of the same steps (other streams kernels co-run)"})
             ents.append(ent)
             kernels[tag] = {"launches": len(ms), "avg_ms": round(avg, 5), "tflops": round(ach, 2)}
         if ents:
@@ -566,6 +571,7 @@ def main():
                    (round(other, 1) if other else None),
                "roofline": roof, "gather_roofline": gather, "cpu_baseline": cpu, "end_to_end_sessions_per_s": e2e, "exchange": exchange,
                "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
+               "ms_per_step_with_kernel_events": (round(dt_ev / args.steps * 1e3, 4) if dt_ev else None),
                "last_loss": round(last_loss, 4)}
         print(json.dumps(out))
         sys.stdout.flush()
