@@ -126,11 +126,12 @@ def build_batches(fold, n_batches, B, K, rng, cfg, with_ids=False):
 def pmc_traffic(tag, nsplit, N, B):
     """HBM bytes per launch of one scoring GEMM from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
     MI355X_MICROARCH.md §HBM; tools/pmc_gemm.sh); only valid for the shape and plane count it was collected on."""
-    p = os.path.join(ROOT, "profiles", "r02_pmc_%s_n%d.json" % (tag, nsplit))
-    if os.path.exists(p):
-        d = json.load(open(p))
-        if tuple(d.get("shape_N_B", ())) == (N, B):
-            return d.get("hbm_bytes_per_launch"), os.path.relpath(p, ROOT)
+    for rnd in ("r03", "r02"):                    # the newest committed pass for this kernel form
+        p = os.path.join(ROOT, "profiles", "%s_pmc_%s_n%d.json" % (rnd, tag, nsplit))
+        if os.path.exists(p):
+            d = json.load(open(p))
+            if tuple(d.get("shape_N_B", ())) == (N, B):
+                return d.get("hbm_bytes_per_launch"), os.path.relpath(p, ROOT)
     return None, None
 
 
@@ -178,9 +179,18 @@ def gather_roofline(dev):
     ms = e0.elapsed_time(e1) / iters
     nbytes = 2.0 * B * (3536.0 * T + 512)
     gbs = nbytes / ms / 1e6
+    real = None
+    pm = os.path.join(ROOT, "profiles", "r03_pmc_gather_fwd.json")
+    if os.path.exists(pm):
+        d_ = json.load(open(pm))
+        hb = d_["hbm_read_bytes"] + d_["hbm_write_bytes"]
+        real = {"hbm_bytes_per_launch_counters": hb, "source": os.path.relpath(pm, ROOT),
+                "frac_real_bytes": round(hb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                "note": "FETCH_SIZE x 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes over this launch: the six small tables "
+                        "(1,536 of the 3,536 algorithmic read bytes per click) are LDS-resident and never reach HBM"}
     return {"kernel": "gather_clip_fwd (throughput form), model_combine.py:54-107", "bound": "hbm", "rows": B * T,
             "bytes_per_launch": nbytes, "avg_ms": round(ms, 4), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": real,
             "note": "algorithmic read + written bytes (SURVEY.md 8(d)) / HIP-event time of 10 launches; separate from the step, "
                     "whose own gather is ~1,100 rows per launch"}
 
@@ -451,14 +461,15 @@ def main():
                 buf = C.create_string_buffer(160)
                 eng.lib.tcar_gemm_bf16_variant(lay, M_, N_, K_, 3 if mult == 3 else 1, sk, buf, 160)
                 name = buf.value.decode()
-            traffic, src = pmc_traffic(tag, 3 if mult == 3 else 1, N, B) if (world == 1 and args.scoring != "f32") else (None, None)
+            ce_form = tag == "score_fwd" and args.scoring == "bf16x3-mixed" and n_local == N and os.environ.get("TCAR_FUSED_CE", "1") != "0"
+            traffic, src = pmc_traffic(tag + ("_ce" if ce_form else ""), 3 if mult == 3 else 1, N, B) if (world == 1 and args.scoring != "f32") else (None, None)
             # algorithmic HBM bytes of the launch: every operand once (bf16 planes: 2 B per plane and element; fp32: 4 B), the
             # result once
             opb = 4 if args.scoring == "f32" else 2 * (2 if mult == 3 else 1)
             n_rows = g.Npad if n_local == N else ((n_local + 127) // 128) * 128
             # (training steps of the mixed precision: the logits GEMM's softmax epilogue writes a bf16 plane + group statistics,
             # not fp32 logits)
-            ce_epi = args.scoring == "bf16x3-mixed" and n_local == N and os.environ.get("TCAR_FUSED_CE", "1") != "0"
+            ce_epi = ce_form or (tag != "score_fwd" and args.scoring == "bf16x3-mixed" and n_local == N and os.environ.get("TCAR_FUSED_CE", "1") != "0")
             out_fwd = (2 * b_glob * n_rows + 8 * b_glob * (n_rows // 96)) if ce_epi else 4 * b_glob * n_rows
             alg_bytes = {"score_fwd": opb * (n_rows * g.ek + b_glob * g.ek) + out_fwd,
                          "score_dx": opb * (b_glob * n_rows + n_rows * g.ek) + 4 * sk * b_glob * g.ek,
