@@ -180,6 +180,7 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ w, c
 }
 
 // item table inside E: w [rows, cols] with leading dim ldw; g, m, v compact [rows, cols]; blocks [0, nblk) stride over it
+template <bool NT = false>
 __device__ __forceinline__ void item_adam_blocks(int blk, int nblk, float* __restrict__ w, long ldw,
                                                  const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                  long rows, int cols, int slot, const float* __restrict__ sqn_dense,
@@ -196,9 +197,12 @@ __device__ __forceinline__ void item_adam_blocks(int blk, int nblk, float* __res
     const int c = (int)(i - r * c4) * 4;
     const long p = r * cols + c;
     float* wp = w + r * ldw + c;
-    float4 ww = ld4(wp), mm = ld4(m + p), vv = ld4(v + p);
-    adam4(ww, ld4(g + p), mm, vv, sc, lr_t, b1, b2, eps);
-    st4(wp, ww); st4(m + p, mm); st4(v + p, vv);
+    float4 ww, mm, vv, gg;
+    if (NT) { ww = ld4_nt(wp); mm = ld4_nt(m + p); vv = ld4_nt(v + p); gg = ld4_nt(g + p); }
+    else { ww = ld4(wp); mm = ld4(m + p); vv = ld4(v + p); gg = ld4(g + p); }
+    adam4(ww, gg, mm, vv, sc, lr_t, b1, b2, eps);
+    if (NT) { st4_stream(wp, ww); st4_stream(m + p, mm); st4_stream(v + p, vv); }
+    else { st4(wp, ww); st4(m + p, mm); st4(v + p, vv); }
     if (eh) {   // keep the bf16 hi / lo planes of the candidate matrix in step with the fp32 master (gemm_bf16.hip)
       const float wv[4] = {ww.x, ww.y, ww.z, ww.w};
       bf16x4_t h, l;
@@ -285,9 +289,10 @@ __global__ __launch_bounds__(256) void clip_adam_early_kernel(const AdamEarly e,
     }
   }
 }
+template <bool NT>
 __global__ __launch_bounds__(256) void clip_adam_rest_kernel(const AdamAll p, const uint32_t* __restrict__ skip) {
-  item_adam_blocks(blockIdx.x, gridDim.x, p.w2, p.ldw, p.g2, p.m2, p.v2, p.rows, p.cols, p.slot, p.sqn_dense, p.sqn_pieces,
-                   p.use_dense, p.clip, p.lr_t, p.b1, p.b2, p.eps, p.eh, p.el, p.ld16, skip);
+  item_adam_blocks<NT>(blockIdx.x, gridDim.x, p.w2, p.ldw, p.g2, p.m2, p.v2, p.rows, p.cols, p.slot, p.sqn_dense, p.sqn_pieces,
+                       p.use_dense, p.clip, p.lr_t, p.b1, p.b2, p.eps, p.eh, p.el, p.ld16, skip);
 }
 
 int seg_grid_x(const tcar_segments_t* s) {
@@ -447,7 +452,8 @@ extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, fl
   // a modest grid: the pass shares the chip with the latency-bound kernels of the forward head and has ~100 us to finish
   const int cap = tcar_tuning().rest_grid;
   if (cap > 0 && p.n2d > cap) p.n2d = cap;
-  TCAR_LAUNCH(clip_adam_rest_kernel, dim3(p.n2d), dim3(256), 0, (hipStream_t)stream, p, (const uint32_t*)bitmap);
+  if (tcar_tuning().nt & 1) TCAR_LAUNCH(clip_adam_rest_kernel<true>, dim3(p.n2d), dim3(256), 0, (hipStream_t)stream, p, (const uint32_t*)bitmap);
+  else TCAR_LAUNCH(clip_adam_rest_kernel<false>, dim3(p.n2d), dim3(256), 0, (hipStream_t)stream, p, (const uint32_t*)bitmap);
   TCAR_CHECK_LAUNCH();
   // every row is up to date now: clear the marks for the next step (stream ordered behind the kernel)
   if (hipMemsetAsync(bitmap, 0, (size_t)((rows + 31) / 32) * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)

@@ -62,6 +62,7 @@ struct TcarTuning {
   int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
   int x3_oneshot;       // TCAR_X3_ONESHOT     0: short-K small-GEMM launches keep the one-stage register ring
   int fused_ce;         // TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel
+  int nt;               // TCAR_NT             bit 0: the Adam rest pass streams (non-temporal loads / stores); bit 1: dE's result stores
   int proj_split;       // TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs
 };
 const TcarTuning& tcar_tuning();
@@ -88,6 +89,17 @@ __device__ __forceinline__ float dot4(const float4 a, const float4 b) {
 }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// streaming (non-temporal) forms: data that is touched once per step by an HBM-bound pass should not evict what the
+// latency-bound kernels beside it keep in L2 / the Infinity Cache
+typedef float tcar_v4f_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+  const tcar_v4f_nt v = __builtin_nontemporal_load(reinterpret_cast<const tcar_v4f_nt*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+  const tcar_v4f_nt x = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(x, reinterpret_cast<tcar_v4f_nt*>(p));
+}
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
