@@ -29,7 +29,6 @@ struct EmbArgs {
   // backward only: with n_gather > 0 the workgroups [n_gather, gridDim.x) compute block partials of sum sq_g^2 (the dense
   // item norm, tcar_sqnorm_det's job) beside the row gradients instead of in a launch of their own
   const float* sq_g; long sq_len; float* sq_part; int n_gather;
-  int nt;                     // TCAR_NT bits: 8 = the dense-norm partials stream the gradient with non-temporal loads
 };
 
 __device__ __forceinline__ int time_vocab(int k) {
@@ -295,7 +294,7 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const long e = base + (i * 256 + tid) * 4;
-        v[i] = (e < a.sq_len) ? ((a.nt & 8) ? ld4_nt(a.sq_g + e) : ld4(a.sq_g + e)) : zero4();
+        v[i] = (e < a.sq_len) ? ld4(a.sq_g + e) : zero4();
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) s += dot4(v[i], v[i]);
@@ -469,7 +468,6 @@ struct CandArgs {
   const float* d_et;
   tcar_grads_t g;
   __bf16* eh; __bf16* el;     // optional bf16 hi / lo planes of E (same [Npad, ek] layout)
-  int nt;                     // TCAR_NT bits (host: tcar_tuning().nt): 4 = stream d_et with non-temporal loads
 };
 
 // E[n, ic + k*ldt ...] = clip(table_k[mwdhm[n,k]])   (model_combine.py:86-92)
@@ -618,7 +616,7 @@ __global__ __launch_bounds__(256) void cand_time_bwd_idx_kernel(const CandArgs a
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int i = i0 + u * groups;
-        gy[u] = (i < s1) ? ((a.nt & 4) ? ld4_nt(a.d_et + (long)i * ldt + lin * 4) : ld4(a.d_et + (long)i * ldt + lin * 4)) : zero4();
+        gy[u] = (i < s1) ? ld4(a.d_et + (long)i * ldt + lin * 4) : zero4();
       }
     } else {
 #pragma unroll
@@ -932,7 +930,6 @@ extern "C" int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* t
                                     float* x_icp, float* x_pt, float* x_act, float* click_t, void* stream) {
   if (check_dims(d) || !tab || !bt || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   EmbArgs a{};
-  a.nt = tcar_tuning().nt;
   a.d = *d; a.tab = *tab; a.bt = *bt;
   a.x_icp = x_icp; a.x_pt = x_pt; a.x_act = x_act; a.click_t = click_t;
   const long rows = (long)bt->B * bt->T;
@@ -967,7 +964,6 @@ int gather_bwd_launch(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar
                       float* sq_part, int sq_blocks, void* stream) {
   if (check_dims(d) || !tab || !bt || !g || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   EmbArgs a{};
-  a.nt = tcar_tuning().nt;
   a.d = *d; a.tab = *tab; a.bt = *bt; a.g = *g;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;
   long rows = (long)bt->B * bt->T + bt->B;
@@ -1020,7 +1016,6 @@ extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* con
                                          const tcar_grads_t* g, void* stream) {
   if (check_dims(d) || !time_tab || !inv_n || !inv_off || !d_et || !ws || !g) return TCAR_E_ARG;
   CandArgs a{};
-  a.nt = tcar_tuning().nt;
   a.d = *d;
   for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
   a.d_et = d_et; a.g = *g;
@@ -1068,7 +1063,6 @@ extern "C" int tcar_cand_time_fwd_bf16(const tcar_dims_t* d, const float* const 
                                        float* E, void* e16_hi, void* e16_lo, void* stream) {
   if (check_dims(d) || !time_tab || !mwdhm || (!E && !e16_hi) || (e16_hi && !e16_lo)) return TCAR_E_ARG;
   CandArgs a{};
-  a.nt = tcar_tuning().nt;
   a.d = *d;
   for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
   a.mwdhm = mwdhm; a.E = E; a.eh = (__bf16*)e16_hi; a.el = (__bf16*)e16_lo;
@@ -1085,7 +1079,6 @@ extern "C" int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_
                                   const float* d_et, const tcar_grads_t* g, void* stream) {
   if (check_dims(d) || !time_tab || !mwdhm || !d_et || !g) return TCAR_E_ARG;
   CandArgs a{};
-  a.nt = tcar_tuning().nt;
   a.d = *d;
   for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
   a.mwdhm = mwdhm; a.d_et = d_et; a.g = *g;

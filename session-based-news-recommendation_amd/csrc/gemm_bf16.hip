@@ -45,8 +45,6 @@ struct BArgs {
   int n_fastest;               // tile order inside the XCD-contiguous id run: 1 = consecutive ids walk the N tiles
   const int32_t* perm;         // optional grouped row permutation of the C2 destination (see tcar_gemm_bf16), else NULL
   int pgroup;                  // columns per permutation group
-  int nt_out;                  // result stores are non-temporal (a large result nobody re-reads soon: dE)
-  int nt_in;                   // dE: the dlogits plane (A operand, its last reader) is fetched with the nt policy
   // softmax epilogue (EPI = 1, tcar_gemm_bf16_ce): instead of C the kernel writes, per row and per column GROUP (the 32 * TNW
   // columns one wave owns), the group maximum and the sum of exp(x - max), the exponentials themselves as a bf16 KB32 plane,
   // and the label's score
@@ -154,11 +152,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
           src = ((long)(k0 >> 7) * in32 + cb) * 4096 + (k0 & 127) * 32 + (ci & 1) * 512;
         }
         char* dst = St + p * PL + (isA ? 0 : A_BYTES) + ci * 1024;
-        if (ok) {
-          // (aux = 2: nt — the operand is streamed; set for the A operand (the dlogits plane) of dE, its last reader)
-          if (MA == 1 && isA && g.nt_in) __builtin_amdgcn_global_load_lds((glb_vp)(P + src + lane * 8), (lds_vp)dst, 16, 0, 2);
-          else __builtin_amdgcn_global_load_lds((glb_vp)(P + src + lane * 8), (lds_vp)dst, 16, 0, 0);
-        }
+        if (ok) __builtin_amdgcn_global_load_lds((glb_vp)(P + src + lane * 8), (lds_vp)dst, 16, 0, 0);
       }
     }
   };
@@ -274,10 +268,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = row0 + (e & 3) + 8 * (e >> 2);
-          if (row < g.M) {
-            if (g.nt_out) __builtin_nontemporal_store(acc[u][t][e], pb + (long)pp[row] * g.pgroup);
-            else pb[(long)pp[row] * g.pgroup] = acc[u][t][e];
-          }
+          if (row < g.M) pb[(long)pp[row] * g.pgroup] = acc[u][t][e];
         }
         continue;
       }
@@ -285,13 +276,8 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
       const long ld = (col < g.csplit) ? g.ldc : g.ldc2;
       if (m0 + TM <= g.M) {            // interior tile (workgroup-uniform): 16 unguarded stores, no per-element branch
         float* pr = base + (long)row0 * ld;
-        if (g.nt_out) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) __builtin_nontemporal_store(acc[u][t][e], pr + (long)((e & 3) + 8 * (e >> 2)) * ld);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) pr[(long)((e & 3) + 8 * (e >> 2)) * ld] = acc[u][t][e];
-        }
+        for (int e = 0; e < 16; ++e) pr[(long)((e & 3) + 8 * (e >> 2)) * ld] = acc[u][t][e];
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -498,8 +484,6 @@ int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void
   g.C = C; g.ldc = ldc;
   g.C2 = C2 ? C2 : C; g.ldc2 = C2 ? ldc2 : ldc; g.csplit = C2 ? csplit : N;
   g.perm = c2_perm; g.pgroup = c2_group;
-  g.nt_out = (layout == 2 && (tcar_tuning().nt & 2)) ? 1 : 0;
-  g.nt_in = (layout == 2 && (tcar_tuning().nt & 32)) ? 1 : 0;
   g.p_hi = nullptr; g.p_in32 = 0; g.stats = nullptr; g.ngroups = 0; g.label = nullptr; g.lab_logit = nullptr;
   if (ce) {
     g.p_hi = (__bf16*)ce->p_hi; g.p_in32 = (int)(ce->p_inner >> 5); g.stats = ce->stats; g.label = ce->label;

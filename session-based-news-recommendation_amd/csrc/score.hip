@@ -360,7 +360,6 @@ __global__ __launch_bounds__(256) void neg_scatter_kernel(int B, int K, int n_it
 // One pass instead of four launches (slab reduce, negative term, two activation backward passes): tile = 16 rows x 64
 // columns (416 workgroups at B = 512, ek = 832), thread = (float4 column group, row); twelve slab loads are in flight per
 // thread before the first add (the pass is a 61-MB read at the Globo shape: 36 slabs of [512, 832]).
-template <bool NT>
 __global__ __launch_bounds__(256) void reduce_dact_kernel(const float* __restrict__ slabs, int S, int M, int N, long ld,
                                                           const float* __restrict__ addend, long ld_add, int n_add,
                                                           const float* __restrict__ y, long ldy, int act,
@@ -381,7 +380,7 @@ __global__ __launch_bounds__(256) void reduce_dact_kernel(const float* __restric
       for (; k + 12 <= S; k += 12) {
         float4 t[12];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) t[j] = NT ? ld4_nt(sp + (long)(k + j) * M * ld) : ld4(sp + (long)(k + j) * M * ld);
+        for (int j = 0; j < 12; ++j) t[j] = ld4(sp + (long)(k + j) * M * ld);
 #pragma unroll
         for (int j = 0; j < 12; ++j) acc = add4(acc, t[j]);
       }
@@ -759,12 +758,8 @@ extern "C" int tcar_splitk_reduce_dact(const float* slabs, int splitk, int M, in
   if ((N & 3) || (ld & 3) || !tcar_aligned16(slabs) || !tcar_aligned16(out) || splitk < 1 || (act && (!y || (ldy & 3))) ||
       (addend && ((ld_add & 3) || (n_add & 3) || !tcar_aligned16(addend))))
     return TCAR_E_ARG;
-  if (tcar_tuning().nt & 16)
-    TCAR_LAUNCH(reduce_dact_kernel<true>, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, N,
-                (long)ld, addend, (long)ld_add, n_add, y, (long)ldy, act, out, bias_grad0, split_col, bias_grad1);
-  else
-    TCAR_LAUNCH(reduce_dact_kernel<false>, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, N,
-                (long)ld, addend, (long)ld_add, n_add, y, (long)ldy, act, out, bias_grad0, split_col, bias_grad1);
+  TCAR_LAUNCH(reduce_dact_kernel, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, N,
+              (long)ld, addend, (long)ld_add, n_add, y, (long)ldy, act, out, bias_grad0, split_col, bias_grad1);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

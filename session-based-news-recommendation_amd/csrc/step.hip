@@ -19,7 +19,7 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_NT", &TcarTuning::nt, 0},
+    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
