@@ -137,15 +137,21 @@ __global__ __launch_bounds__(1024) void colsum_det_kernel(const ColsumArgs a) {
   }
 }
 
+// One Adam element (TF-1 form) with EVERY rounding pinned (explicit mul / fma / div intrinsics): the update is
+// compiled into several kernels (all-in-one, early, rest, streaming rest) that must agree bit for bit, so nothing is left to the
+// compiler's per-kernel contraction choices.
+__device__ __forceinline__ void adam1(float& w, float g, float& m, float& v, float sc, float lr_t, float b1, float b2, float eps) {
+  const float gx = __fmul_rn(g, sc);
+  m = __fmaf_rn(b1, m, __fmul_rn(1.f - b1, gx));
+  v = __fmaf_rn(b2, v, __fmul_rn(__fmul_rn(1.f - b2, gx), gx));
+  w = __fsub_rn(w, __fdiv_rn(__fmul_rn(lr_t, m), __fadd_rn(__fsqrt_rn(v), eps)));
+}
 __device__ __forceinline__ void adam4(float4& w, const float4 g, float4& m, float4& v, float sc, float lr_t, float b1,
                                       float b2, float eps) {
-  const float gx = g.x * sc, gy = g.y * sc, gz = g.z * sc, gw = g.w * sc;
-  m.x = b1 * m.x + (1.f - b1) * gx; m.y = b1 * m.y + (1.f - b1) * gy;
-  m.z = b1 * m.z + (1.f - b1) * gz; m.w = b1 * m.w + (1.f - b1) * gw;
-  v.x = b2 * v.x + (1.f - b2) * gx * gx; v.y = b2 * v.y + (1.f - b2) * gy * gy;
-  v.z = b2 * v.z + (1.f - b2) * gz * gz; v.w = b2 * v.w + (1.f - b2) * gw * gw;
-  w.x -= lr_t * m.x / (sqrtf(v.x) + eps); w.y -= lr_t * m.y / (sqrtf(v.y) + eps);
-  w.z -= lr_t * m.z / (sqrtf(v.z) + eps); w.w -= lr_t * m.w / (sqrtf(v.w) + eps);
+  adam1(w.x, g.x, m.x, v.x, sc, lr_t, b1, b2, eps);
+  adam1(w.y, g.y, m.y, v.y, sc, lr_t, b1, b2, eps);
+  adam1(w.z, g.z, m.z, v.z, sc, lr_t, b1, b2, eps);
+  adam1(w.w, g.w, m.w, v.w, sc, lr_t, b1, b2, eps);
 }
 
 __device__ __forceinline__ void arena_adam_block(int seg, int chunk, float* __restrict__ w, const float* __restrict__ g,
