@@ -437,6 +437,11 @@ int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, f
                         int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip,
                         float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap,
                         void* stream);
+/* the same without clearing the bitmap (the step driver records its join event first and clears behind it) */
+int tcar_clip_adam_rest_keep(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols,
+                        int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip,
+                        float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap,
+                        void* stream);
 
 /* ---- deterministic sparse backward of the item table: sort by row + segmented wavefront reduction -----------------------
  * The IndexedSlices gradient of the item lookups (model_combine.py:54,142,156): B*T session rows + B*K negative rows.

@@ -27,7 +27,7 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_clip_adam_rest_keep", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
            "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range",
            "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_attn_pool_fwd_slabs", "tcar_attn_pool_bwd_slabs", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]

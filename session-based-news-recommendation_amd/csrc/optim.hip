@@ -446,7 +446,7 @@ extern "C" int tcar_clip_adam_early(float* w, const float* g, float* m, float* v
   return TCAR_OK;
 }
 
-extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows,
+extern "C" int tcar_clip_adam_rest_keep(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows,
                                    int32_t cols, int32_t slot, const float* sqn_dense, const float* sqn_pieces,
                                    const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
                                    void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap, void* stream) {
@@ -464,12 +464,22 @@ extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, fl
   // within +-0.5 % and was not kept)
   TCAR_LAUNCH(clip_adam_rest_kernel<true>, dim3(p.n2d), dim3(256), 0, (hipStream_t)stream, p, (const uint32_t*)bitmap);
   TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+
+extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows,
+                                   int32_t cols, int32_t slot, const float* sqn_dense, const float* sqn_pieces,
+                                   const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
+                                   void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap, void* stream) {
+  const int rc = tcar_clip_adam_rest_keep(w2d, ldw, g2d, m2d, v2d, rows, cols, slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1,
+                                          b2, eps, e16_hi, e16_lo, ld16, bitmap, stream);
+  if (rc) return rc;
   // every row is up to date now: clear the marks for the next step (stream ordered behind the kernel)
   if (hipMemsetAsync(bitmap, 0, (size_t)((rows + 31) / 32) * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
     return TCAR_E_LAUNCH;
   return TCAR_OK;
 }
-
 
 extern "C" int tcar_colsum_det(int nseg, const tcar_colsum_t* segs, void* stream) {
   if (nseg <= 0) return TCAR_OK;
