@@ -19,7 +19,7 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_FEW_EVENTS", &TcarTuning::few_events, 1},
+    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -249,15 +249,14 @@ int zero_arena(const tcar_ctx_t* c, hipStream_t s) {
 
 // zero the gradient arena and the norm slots, and the forward part of the sampled negative term (it needs only attout and E):
 // on the aux stream `sz`, ordered behind everything already on the main stream (the previous update read Gx)
-// `fork`: order `sz` behind the main stream first (an event record on the main chain: a few us of bubble there).  The fused
-// training step passes fork = false: its forward pass left the aux stream ordered behind the pending update (which read Gx), the
-// arena is zeroed there without touching the main stream, and the negative term's forward — it needs attout — runs behind the
-// event that forks dE anyway (backward_impl).
-int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz, bool fork, bool with_neg) {
-  if (fork && sz != st && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sz, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+// (Round 3 A/B: saving this fork's event — arena zeroed on the already-ordered aux stream, the negative term's forward behind the
+// dE fork — and joining the three streams through ONE wait at the end of the step measured SLOWER, 0.635 vs 0.613 ms per step:
+// dE then starts behind the negative term and the final join becomes two hops.)
+int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
+  if (sz != st && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sz, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   RET(zero_arena(c, sz));
-  if (with_neg && bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
+  if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
   return TCAR_OK;
 }
@@ -331,11 +330,12 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   }));
   // sort index of the item rows (feed only): on the aux stream BEHIND the rest pass — the logits GEMM does not wait for it (ev[1]
   // was recorded in front of it), the backward does
-  // (a fused training step relies on the aux stream being ordered behind this call's start: backward_impl zeroes the arena there)
-  if (train_index && s2 && !refresh_time &&
-      (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
-    return TCAR_E_LAUNCH;
-  if (train_index && sorted_rows(c, bt)) RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)s2));
+  if (train_index && sorted_rows(c, bt)) {
+    if (!refresh_time &&
+        (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+      return TCAR_E_LAUNCH;
+    RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)s2));
+  }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   auto start_timer = [&]() {
@@ -448,11 +448,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // zero the gradient arena and the norm slots; with an aux stream this happens beside the softmax, not before it
   // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
   hipStream_t sz = s2 ? s2 : st;
-  // fused training step (ce_epilogue == called by tcar_train_step*: the forward pass of this very call chain ordered the aux
-  // stream): no fork event, the negative term's forward follows the dE fork below
-  const bool late_neg = ce_epilogue && fuse_finish && s2 != nullptr && tcar_tuning().few_events;
-  RET(backward_prologue(c, bt, st, sz, !late_neg, !late_neg));
-  if (s2 && !late_neg && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  RET(backward_prologue(c, bt, st, sz));
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   // sorted segmented sum of the item-row gradients (deterministic); its index was built under the forward pass, on the aux
   // stream — ev[1] (recorded behind the prologue) orders the main stream behind it
   const bool sorted = fuse_finish && sorted_rows(c, bt);
@@ -470,11 +467,6 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s2) {
     if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
       return TCAR_E_LAUNCH;
-    if (late_neg) {      // the negative term's forward (needs attout) + "prologue done" for the main chain's first use of the arena
-      if (has_neg)
-        RET(tcar_neg_fwd(&c->d, B, K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)s2));
-      if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
-    }
   }
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
@@ -666,15 +658,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
     }
   }
-  if (s2 && s3 && tcar_tuning().few_events) {
-    // ONE wait on the main stream: the third stream collects the aux stream first
-    if (hipStreamWaitEvent(s3, (hipEvent_t)c->ev[2], 0) != hipSuccess || hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess ||
-        hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess)
-      return TCAR_E_LAUNCH;
-  } else {
-    if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
-    if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
-  }
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
+  if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
   if (fuse_finish && !s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
   return TCAR_OK;
 }
