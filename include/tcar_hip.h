@@ -237,12 +237,24 @@ int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* A_hi, const
  *   stats  [M, *ngroups, 2] floats: (group maximum, sum of the group's exponentials) — a group = *group_width (64 or 96)
  *          consecutive columns, the slice one wave of the chosen workgroup tile owns; stats_floats >= M * (ceil(N/64) + 8) * 2;
  *   lab_logit [M]: x[m, label[m]].
+ * Optional SECOND K segment (B2_hi != NULL; nsplit 3): the contraction runs over K1 columns of (A, B) and then K - K1 columns of
+ * (A2 hi / lo, B2 hi) — planes of inner dimension inner2 with the same row counts — where B2 is exact in bf16 (ONE plane: two
+ * MFMAs per product).  The step driver uses it for the candidate-side time vectors (model_combine.py:86-92,135): A2 =
+ * tcar_time_scores, B2 = tcar_time_onehot, K1 = 2 ldh, K - K1 = 160 instead of 5 ldt = 320 two-plane columns.
  * tcar_ce_finish combines the groups of every row (lse, ce = lse - x_label), then rescales the plane IN PLACE to
  * softmax - onehot (the dlogits operand of the two gradient GEMMs, hi plane only) and zeroes rows [B, ceil128(B)).  rowstat [B, 2]. */
 int tcar_gemm_bf16_ce(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows, const void* B_hi,
-                      const void* B_lo, int64_t b_inner, int64_t b_rows, void* p_hi, int64_t p_inner, int64_t p_rows, float* stats,
+                      const void* B_lo, int64_t b_inner, int64_t b_rows, int K1, const void* A2_hi, const void* A2_lo,
+                      const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner, int64_t p_rows, float* stats,
                       int64_t stats_floats, const int32_t* label, float* lab_logit, int nsplit, int32_t* group_width /*host*/,
                       int32_t* ngroups /*host*/, void* stream);
+/* OH[n, r] = 1 for r = rowoff_k + publish_time_MWDHM[n, k] (k = 0..4; rows of the month | day | week | hour | minute tables numbered
+ * 0..138), else 0: bf16 KB32 plane [ceil128(N), inner >= 160].  Static per catalog. */
+int tcar_time_onehot(const tcar_dims_t* d, const int32_t* mwdhm, void* oh_hi, int64_t inner, void* stream);
+/* P[b, r] = attout[b, 2 ldh + k(r) ldt ...] . clip(time table row r) as bf16 hi / lo KB32 planes [ceil128(B), inner >= 160]:
+ * sum_k attout_tk[b] . candidate_publish_t_k[n] = (P OH^T)[b, n] */
+int tcar_time_scores(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* attout, int64_t ld_att, void* p_hi,
+                     void* p_lo, int64_t inner, void* stream);
 int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                    float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream);
 /* Names the kernel instantiation (template arguments, workgroup tile, grid) that tcar_gemm_bf16 would launch for this
@@ -527,7 +539,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 16
+#define TCAR_ABI_VERSION 17
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -607,6 +619,9 @@ typedef struct {
    * 16-byte aligned, and two HOST ints that carry the group geometry from the forward to the backward half of a step.  With it
    * the logits GEMM of a training step does not write [B, N] fp32 logits (tcar_gemm_bf16_ce + tcar_ce_finish). */
   float* ce_ws; int64_t ce_ws_floats; int32_t* ce_geo /*host*/;
+  /* optional planes of the one-hot form of the candidate-side time scores (training steps with the softmax epilogue): oh16
+   * [ceil128(N), 160] from tcar_time_onehot (static), p16h / p16l [ceil128(B), 160] written by tcar_time_scores every step */
+  void* oh16; void* p16h; void* p16l;
 } tcar_ctx_t;
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */

@@ -20,10 +20,10 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 16          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 17          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_time_onehot", "tcar_time_scores", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
@@ -195,7 +195,8 @@ class Ctx(C.Structure):
                    ("ev_n", C.c_int32), ("ev_cursor", C.c_void_p), ("stream3", C.c_void_p), ("ev3", C.c_void_p),
                    ("segsum_ws", C.c_void_p), ("segsum_bytes", C.c_int64), ("gw_rows", C.c_void_p), ("wgrad_slabs", C.c_void_p), ("wgrad_slab_floats", C.c_int64),
                    ("proj_slabs", C.c_void_p), ("proj_slab_floats", C.c_int64),
-                   ("ce_ws", C.c_void_p), ("ce_ws_floats", C.c_int64), ("ce_geo", C.c_void_p)])
+                   ("ce_ws", C.c_void_p), ("ce_ws_floats", C.c_int64), ("ce_geo", C.c_void_p),
+                   ("oh16", C.c_void_p), ("p16h", C.c_void_p), ("p16l", C.c_void_p)])
 
 
 class TcarError(RuntimeError):
@@ -269,7 +270,10 @@ def load() -> C.CDLL:
                                          f32, f32, f32, vp, vp, i64, vp, i64, vp, vp]
     lib.tcar_clip_adam_rest.argtypes = [vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32, f32, f32, f32, vp, vp, i64,
                                         vp, vp]
-    lib.tcar_gemm_bf16_ce.argtypes = [i32, i32, i32, vp, vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, i64, vp, vp, i32, vp, vp, vp]
+    lib.tcar_gemm_bf16_ce.argtypes = [i32, i32, i32, vp, vp, i64, i64, vp, vp, i64, i64, i32, vp, vp, vp, i64, vp, i64, i64, vp, i64, vp,
+                                      vp, i32, vp, vp, vp]
+    lib.tcar_time_onehot.argtypes = [P(Dims), vp, vp, i64, vp]
+    lib.tcar_time_scores.argtypes = [P(Dims), P(vp * 5), i32, vp, i64, vp, vp, i64, vp]
     lib.tcar_ce_finish.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.tcar_layernorm_fwd.argtypes = [i64, i32, vp, vp, vp, f32, vp, vp, vp]
     lib.tcar_layernorm_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]

@@ -530,6 +530,89 @@ __global__ __launch_bounds__(256) void cand_time_fwd_kernel(const CandArgs a) {
   }
 }
 
+// ---- candidate-side time scores through a one-hot contraction (round 3) ---------------------------------------------
+// logits[b, n] = attout_ic[b] . E_ic[n] + sum_k attout_tk[b] . clip(table_k[mwdhm[n, k]])      (model_combine.py:86-92,135-138)
+// The second term only takes 139 distinct values per session: P[b, r] = attout_t,k(r)[b] . clip(table row r), and
+// sum_k P[b, r_k(n)] = (P OH^T)[b, n] with the STATIC one-hot matrix OH[n, r] = [r in {r_0(n) .. r_4(n)}].  The logits GEMM then
+// contracts 512 + 160 columns instead of 512 + 320, and the one-hot block (exact in bf16: ONE plane, two MFMAs per product)
+// costs half the B-operand fill of a two-plane block.
+__global__ __launch_bounds__(256) void time_onehot_kernel(int n_items, const int32_t* __restrict__ mwdhm, __bf16* __restrict__ oh,
+                                                          int in32) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_items) return;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int id = clampi(mwdhm[n * 5 + k], 0, time_vocab(k) - 1);
+    oh[kb32_off(n, time_rowoff(k) + id, in32)] = (__bf16)1.0f;
+  }
+}
+struct ScoreArgs {
+  tcar_dims_t d;
+  const float* tab[5];
+  const float* attout; long ld_att;
+  int B, in32;
+  __bf16* ph; __bf16* pl;
+};
+// One workgroup = 16 session rows x ONE table (grid.y = 5): its raw rows (<= 61), their clip scales and the 16 x ldt block of
+// attout are staged with independent loads (one memory round trip), the dots run out of LDS — thread (b, rg) takes rows rg, rg +
+// 16, ... so that a wave reads 16 distinct attout rows and 4 broadcast table rows per instruction — and every score leaves as a
+// bf16 hi / lo pair.  P = (x . t) * scale(t): the clip's scale (modules.py embedding max_norm, oracle S2) on the dot.
+template <int LDT>
+__global__ __launch_bounds__(256) void time_scores_kernel(const ScoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int k = blockIdx.y;
+  const int off = time_rowoff(k), nk = time_rowoff(k + 1) - off;
+  constexpr int ldt = LDT, ls = LDT + 4;
+  const int ic = 2 * a.d.ldh;
+  float* tl = lds;                 // [61][ls]
+  float* sc = tl + 61 * ls;        // [64]
+  float* xl = sc + 64;             // [16][ls]
+  constexpr int sub = LDT >> 2;
+  const long b0 = (long)blockIdx.x * 16;
+  const float* tab = pick5(a.tab, k);
+  const int nf = nk * sub;
+#pragma unroll 2
+  for (int f0 = 0; f0 < nf; f0 += 256) {
+    const int f = f0 + tid;
+    const int row = f / sub, lin = f - row * sub;
+    const bool valid = row < nk;
+    const float4 x = valid ? ld4(tab + (long)row * ldt + lin * 4) : zero4();
+    const float ss = group_sum(dot4(x, x), sub);
+    if (valid) {
+      st4(tl + row * ls + lin * 4, x);
+      if (lin == 0) sc[row] = clip_scale(ss);
+    }
+  }
+  for (int f = tid; f < 16 * sub; f += 256) {
+    const int r = f / sub, c = f - r * sub;
+    const float4 x = b0 + r < a.B ? ld4(a.attout + (b0 + r) * a.ld_att + ic + k * ldt + c * 4) : zero4();
+    st4(xl + r * ls + c * 4, x);
+  }
+  __syncthreads();
+  const int b = tid & 15, rg = tid >> 4;
+  const float* x = xl + b * ls;
+  const int nz = k == 4 ? 160 - 139 : 0;         // the last table's workgroups also zero the padding columns
+#pragma unroll 2
+  for (int r = rg; r < nk + nz; r += 16) {
+    float v = 0.f;
+    if (r < nk) {
+      const float* t = tl + r * ls;
+      float4 s4 = zero4();
+#pragma unroll 16
+      for (int i = 0; i < ldt; i += 4) {
+        const float4 u = *reinterpret_cast<const float4*>(x + i), w = *reinterpret_cast<const float4*>(t + i);
+        s4.x = fmaf(u.x, w.x, s4.x); s4.y = fmaf(u.y, w.y, s4.y); s4.z = fmaf(u.z, w.z, s4.z); s4.w = fmaf(u.w, w.w, s4.w);
+      }
+      v = ((s4.x + s4.y) + (s4.z + s4.w)) * sc[r];
+    }
+    const __bf16 h = (__bf16)v;
+    const long o = kb32_off(b0 + b, off + r, a.in32);
+    a.ph[o] = h;
+    a.pl[o] = (__bf16)(v - (float)h);
+  }
+}
+
 // gradient of the candidate-side lookups: for every (n, k) clip-backward of d_et[n, k*ldt ...]
 __global__ __launch_bounds__(256) void cand_time_bwd_kernel(const CandArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [139, ldt] accumulators + [5] norms
@@ -1114,6 +1197,43 @@ extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables
   TCAR_CHECK_LAUNCH();
   TCAR_LAUNCH(small_norm_fold_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, bt->T, g->sqn, g->slot_pos, g->slot_time[0],
               g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+// OH[n, rowoff_k + mwdhm[n, k]] = 1 (k = 0..4), everything else 0: bf16 KB32 plane [ceil128(N), inner], inner >= 160.  Static: it
+// depends on publish_time_MWDHM only.
+extern "C" int tcar_time_onehot(const tcar_dims_t* d, const int32_t* mwdhm, void* oh_hi, int64_t inner, void* stream) {
+  if (check_dims(d) || !mwdhm || !oh_hi || (inner & 31) || inner < 160) return TCAR_E_ARG;
+  const long rows = ((long)d->n_items + 127) & ~127L;
+  if (hipMemsetAsync(oh_hi, 0, (size_t)rows * inner * 2, (hipStream_t)stream) != hipSuccess) return TCAR_E_LAUNCH;
+  TCAR_LAUNCH(time_onehot_kernel, dim3((unsigned)((d->n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d->n_items, mwdhm,
+              (__bf16*)oh_hi, (int)(inner >> 5));
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+// P[b, r] = attout[b, 2 ldh + k(r) ldt ...] . clip(time row r)  (r = 0..138 in month|day|week|hour|minute order) as bf16 hi / lo
+// KB32 planes [ceil128(B), inner] (columns >= 139 and rows >= B zero): the A operand of the one-hot K segment of the logits GEMM
+extern "C" int tcar_time_scores(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* attout, int64_t ld_att,
+                                void* p_hi, void* p_lo, int64_t inner, void* stream) {
+  if (check_dims(d) || !time_tab || B <= 0 || !attout || !p_hi || !p_lo || (inner & 31) || inner < 160 || (ld_att & 3)) return TCAR_E_ARG;
+  ScoreArgs a{};
+  a.d = *d;
+  for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
+  a.attout = attout; a.ld_att = ld_att; a.B = B; a.in32 = (int)(inner >> 5);
+  a.ph = (__bf16*)p_hi; a.pl = (__bf16*)p_lo;
+  const long Bp = ((long)B + 127) & ~127L;
+  const size_t lds = ((size_t)(61 + 16) * (d->ldt + 4) + 64) * sizeof(float);
+  const dim3 grid((unsigned)(Bp / 16), 5);
+  if (d->ldt == 64) {
+    TCAR_LAUNCH(time_scores_kernel<64>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  } else if (d->ldt == 128) {
+    TCAR_LAUNCH(time_scores_kernel<128>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  } else {
+    TCAR_SET_LDS_ONCE(time_scores_kernel<256>, lds);
+    TCAR_LAUNCH(time_scores_kernel<256>, grid, dim3(256), lds, (hipStream_t)stream, a);
+  }
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -22,6 +22,7 @@
 //   MODE 1  m/n-contiguous: fragments come from ds_read_b64_tr_b16, the gfx950 transposing LDS read (per 16-lane group
 //           it returns, to lane i, column i of a 4 (k) x 16 (col) block): no transposed copy of E or dlogits exists.
 // XCD-aware tile remap as in gemm_f32.hip; split-K (slabs) serves the catalog-long contraction of dX.
+#include <type_traits>
 #include "tcar_common.h"
 #include "tcar_bf16_layout.h"
 #include <stdlib.h>
@@ -48,6 +49,10 @@ struct BArgs {
   // softmax epilogue (EPI = 1, tcar_gemm_bf16_ce): instead of C the kernel writes, per row and per column GROUP (the 32 * TNW
   // columns one wave owns), the group maximum and the sum of exp(x - max), the exponentials themselves as a bf16 KB32 plane,
   // and the label's score
+  // second K segment (SEG2 = 1, logits layout only): the contraction continues over [K1, K) with OTHER planes — A2 hi / lo
+  // (inner a2_in32 * 32) and ONE B2 plane (inner b2_in32 * 32; its elements are exact in bf16: the one-hot time-index matrix),
+  // so that block costs two MFMAs per product and half the B fill bytes
+  const __bf16* A2[2]; const __bf16* B2; int a2_in32, b2_in32, a2_rb, b2_rb, K1;
   __bf16* p_hi; int p_in32;    // plane [ceil128(M), 32 * p_in32]
   float* stats; int ngroups;   // [M, ngroups, 2]
   const int32_t* label; float* lab_logit;
@@ -80,7 +85,7 @@ __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int
 // tiles = 192 registers, 2 waves per SIMD) for the 256 x 384 workgroup tile of the logits GEMM
 // KS = 32-deep k blocks per LDS stage: the hi-only (NSPLIT = 1) form has a third of the MFMA work between two barriers
 // and half the bytes per stage, so it takes 64-deep stages (same LDS as the two-plane form, half the barriers).
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1, int EPI = 0>
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1, int EPI = 0, int SEG2 = 0>
 __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW;
@@ -128,7 +133,9 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       if (KS > 1 && t * KS + j >= nkb) break;
-      const int k0 = ks + (t * KS + j) * KB;
+      int k0 = ks + (t * KS + j) * KB;
+      const bool seg2 = SEG2 && k0 >= g.K1;              // (workgroup-uniform) this stage lies in the second K segment
+      if (SEG2 && seg2) k0 -= g.K1;
       char* St = smem + (t & 1) * STAGE + j * SUB;
 #pragma unroll
       for (int i = 0; i < CPW; ++i) {
@@ -137,8 +144,10 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
         const int p = c / (A_CP + B_CP), rem = c - p * (A_CP + B_CP);
         const bool isA = rem < A_CP;
         const int ci = isA ? rem : rem - A_CP;
-        const __bf16* P = isA ? g.A[p] : g.B[p];
-        const int in32 = isA ? g.a_in32 : g.b_in32, nrb = isA ? g.a_rb : g.b_rb;
+        if (SEG2 && seg2 && !isA && p == 1) continue;    // the second segment's B operand has ONE plane
+        const __bf16* P = (SEG2 && seg2) ? (isA ? g.A2[p] : g.B2) : (isA ? g.A[p] : g.B[p]);
+        const int in32 = (SEG2 && seg2) ? (isA ? g.a2_in32 : g.b2_in32) : (isA ? g.a_in32 : g.b_in32);
+        const int nrb = (SEG2 && seg2) ? (isA ? g.a2_rb : g.b2_rb) : (isA ? g.a_rb : g.b_rb);
         const int mode = isA ? MA : MB, t0 = isA ? m0 : n0;
         long src;
         bool ok;
@@ -156,50 +165,66 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
       }
     }
   };
-  auto compute = [&](int t) {
+  // the MFMAs of one 32-column k-block; S2: the block lies in the second K segment (B has no lo plane: two MFMAs per product, and
+  // its lo fragments are not read).  Two fully unrolled bodies behind ONE uniform branch per k-block: a test around single MFMAs
+  // would break the interleaving of LDS reads and MFMAs.
+  auto block = [&](const char* St, auto s2) __attribute__((always_inline)) {
+    constexpr bool S2 = decltype(s2)::value;
+    constexpr int NPB = S2 ? 1 : NP;
 #pragma unroll
-    for (int j = 0; j < KS; ++j) {
-      if (KS > 1 && t * KS + j >= nkb) break;
-      const char* St = smem + (t & 1) * STAGE + j * SUB;
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 a[NP][TMW];
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 a[NP][TMW];
+      for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+        for (int u = 0; u < TMW; ++u) a[p][u] = frag<MA>(St + p * PL, wm * (32 * TMW) + u * 32, s, lane);
 #pragma unroll
-          for (int u = 0; u < TMW; ++u) a[p][u] = frag<MA>(St + p * PL, wm * (32 * TMW) + u * 32, s, lane);
+      for (int t2 = 0; t2 < TNW; ++t2) {          // one B tile at a time: its fragments die after TMW * NSPLIT MFMAs
+        bf16x8 b[NPB];
 #pragma unroll
-        for (int t2 = 0; t2 < TNW; ++t2) {          // one B tile at a time: its fragments die after TMW * NSPLIT MFMAs
-          bf16x8 b[NP];
+        for (int p = 0; p < NPB; ++p) b[p] = frag<MB>(St + p * PL + A_BYTES, wn * (32 * TNW) + t2 * 32, s, lane);
 #pragma unroll
-          for (int p = 0; p < NP; ++p) b[p] = frag<MB>(St + p * PL + A_BYTES, wn * (32 * TNW) + t2 * 32, s, lane);
-#pragma unroll
-          for (int u = 0; u < TMW; ++u) {
-            if constexpr (EPI == 1) {     // transposed accumulator tile (rows = catalog columns, lane = session): see the epilogue
-              if constexpr (NSPLIT == 3) {
-                acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[NP - 1][u], acc[u][t2], 0, 0, 0);
-                acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[NP - 1], a[0][u], acc[u][t2], 0, 0, 0);
-              }
-              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0][u], acc[u][t2], 0, 0, 0);
-            } else {
-              if constexpr (NSPLIT == 3) {
-                acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0], acc[u][t2], 0, 0, 0);
-                acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NP - 1], acc[u][t2], 0, 0, 0);
-              }
-              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0], acc[u][t2], 0, 0, 0);
+        for (int u = 0; u < TMW; ++u) {
+          if constexpr (EPI == 1) {     // transposed accumulator tile (rows = catalog columns, lane = session): see the epilogue
+            if constexpr (NSPLIT == 3) {
+              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[NP - 1][u], acc[u][t2], 0, 0, 0);
+              if constexpr (!S2) acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[NPB - 1], a[0][u], acc[u][t2], 0, 0, 0);
             }
+            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[0], a[0][u], acc[u][t2], 0, 0, 0);
+          } else {
+            if constexpr (NSPLIT == 3) {
+              acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[NP - 1][u], b[0], acc[u][t2], 0, 0, 0);
+              if constexpr (!S2) acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[NPB - 1], acc[u][t2], 0, 0, 0);
+            }
+            acc[u][t2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][u], b[0], acc[u][t2], 0, 0, 0);
           }
         }
       }
     }
   };
+  auto compute = [&](int t, auto s2) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      if (KS > 1 && t * KS + j >= nkb) break;
+      block(smem + (t & 1) * STAGE + j * SUB, s2);
+    }
+  };
 
   if (nit > 0) issue(0);
   __syncthreads();                       // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
-  for (int it = 0; it < nit; ++it) {
+  // two loops, one per K segment (the second is empty without SEG2; with it KS = 1 and there is no split-K): each has ONE body
+  const int nit1 = SEG2 ? min(nit, g.K1 / KB) : nit;
+  for (int it = 0; it < nit1; ++it) {
     if (it + 1 < nit) issue(it + 1);     // buffer (it+1)&1 was last read in iteration it-1, which ended with a barrier
-    compute(it);
+    compute(it, std::false_type{});
     __syncthreads();
+  }
+  if constexpr (SEG2 != 0) {
+    for (int it = nit1; it < nit; ++it) {
+      if (it + 1 < nit) issue(it + 1);
+      compute(it, std::true_type{});
+      __syncthreads();
+    }
   }
 
   const int li = lane & 31, lh = lane >> 5;
@@ -345,6 +370,16 @@ int launch_k(BArgs& g, int splitk, hipStream_t st) {
       g.ngroups = g.nt * WNW;
       t_ce_gw = 32 * TNW;
       t_ce_ngroups = g.ngroups;
+      if (g.B2) {
+        if constexpr (NSPLIT == 3 && KS == 1) {
+          TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1>), lds);
+          TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1>), dim3(g.mt * g.nt), dim3(NT), lds, st, g);
+          TCAR_CHECK_LAUNCH();
+          return TCAR_OK;
+        } else {
+          return TCAR_E_ARG;
+        }
+      }
       TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1>), lds);
       TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1>), dim3(g.mt * g.nt), dim3(NT), lds, st, g);
       TCAR_CHECK_LAUNCH();
@@ -426,7 +461,8 @@ extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi,
 }
 
 namespace {
-struct CeOut { void* p_hi; int64_t p_inner; float* stats; const int32_t* label; float* lab_logit; };
+struct CeOut { void* p_hi; int64_t p_inner; float* stats; const int32_t* label; float* lab_logit;
+               const void* A2_hi; const void* A2_lo; const void* B2_hi; int64_t inner2, a2_rows, b2_rows; int K1; };
 int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
                    const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
                    int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit, int splitk, const CeOut* ce,
@@ -443,17 +479,27 @@ extern "C" int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* 
 }
 
 extern "C" int tcar_gemm_bf16_ce(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
-                                 const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, void* p_hi, int64_t p_inner,
-                                 int64_t p_rows, float* stats, int64_t stats_floats, const int32_t* label, float* lab_logit,
-                                 int nsplit, int32_t* group_width, int32_t* ngroups, void* stream) {
+                                 const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, int K1, const void* A2_hi,
+                                 const void* A2_lo, const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner, int64_t p_rows,
+                                 float* stats, int64_t stats_floats, const int32_t* label, float* lab_logit, int nsplit,
+                                 int32_t* group_width, int32_t* ngroups, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
   if (!p_hi || !stats || !label || !lab_logit || !group_width || !ngroups || (p_inner & 31) || p_inner < N || p_rows < M ||
       !tcar_aligned16(p_hi) || ((uintptr_t)stats & 7))
     return TCAR_E_ARG;
   // every tile of the logits layout has groups of at least 64 columns: [M, ceil(N / 64), 2] floats always suffice
   if (stats_floats < (int64_t)M * ((N + 63) / 64 + 8) * 2) return TCAR_E_ARG;
-  const CeOut ce = {p_hi, p_inner, stats, label, lab_logit};
+  CeOut ce = {p_hi, p_inner, stats, label, lab_logit, nullptr, nullptr, nullptr, 0, 0, 0, K};
+  int k_first = K;
+  if (B2_hi) {      // second K segment: [K1, K) from (A2 hi / lo, B2 hi), planes of inner dimension inner2 >= K - K1
+    if (nsplit != 3 || !A2_hi || !A2_lo || K1 <= 0 || K1 >= K || (K1 & 31) || ((K - K1) & 31) || (inner2 & 31) || inner2 < K - K1 ||
+        !tcar_aligned16(A2_hi) || !tcar_aligned16(A2_lo) || !tcar_aligned16(B2_hi))
+      return TCAR_E_ARG;
+    ce.A2_hi = A2_hi; ce.A2_lo = A2_lo; ce.B2_hi = B2_hi; ce.inner2 = inner2; ce.a2_rows = a_rows; ce.b2_rows = b_rows; ce.K1 = K1;
+    k_first = K1;
+  }
   float dummy;
+  (void)k_first;
   const int rc = gemm_bf16_impl(1, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, &dummy, N, nullptr, 0, 0,
                                 nullptr, 0, nsplit, 1, &ce, stream);
   if (rc) return rc;
@@ -475,8 +521,9 @@ int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void
   // the planes must cover what the tiles touch: a k-contiguous operand has inner >= K and rows >= its M/N extent,
   // a transposed-read operand has inner >= its M/N extent and rows >= K
   const bool a_kc = (layout != 2), b_kc = (layout == 1);
-  if (a_kc ? (a_inner < K || a_rows < M) : (a_inner < M || a_rows < K)) return TCAR_E_ARG;
-  if (b_kc ? (b_inner < K || b_rows < N) : (b_inner < N || b_rows < K)) return TCAR_E_ARG;
+  const int Kp = (ce && ce->B2_hi) ? ce->K1 : K;      // the first K segment is what these planes must cover
+  if (a_kc ? (a_inner < Kp || a_rows < M) : (a_inner < M || a_rows < Kp)) return TCAR_E_ARG;
+  if (b_kc ? (b_inner < Kp || b_rows < N) : (b_inner < N || b_rows < Kp)) return TCAR_E_ARG;
   BArgs g;
   g.A[0] = (const __bf16*)A_hi; g.A[1] = (const __bf16*)A_lo; g.B[0] = (const __bf16*)B_hi; g.B[1] = (const __bf16*)B_lo;
   g.a_in32 = (int)(a_inner >> 5); g.b_in32 = (int)(b_inner >> 5);
@@ -485,9 +532,16 @@ int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void
   g.C2 = C2 ? C2 : C; g.ldc2 = C2 ? ldc2 : ldc; g.csplit = C2 ? csplit : N;
   g.perm = c2_perm; g.pgroup = c2_group;
   g.p_hi = nullptr; g.p_in32 = 0; g.stats = nullptr; g.ngroups = 0; g.label = nullptr; g.lab_logit = nullptr;
+  g.A2[0] = g.A2[1] = nullptr; g.B2 = nullptr; g.a2_in32 = g.b2_in32 = g.a2_rb = g.b2_rb = 0; g.K1 = K;
   if (ce) {
     g.p_hi = (__bf16*)ce->p_hi; g.p_in32 = (int)(ce->p_inner >> 5); g.stats = ce->stats; g.label = ce->label;
     g.lab_logit = ce->lab_logit;
+    if (ce->B2_hi) {
+      g.A2[0] = (const __bf16*)ce->A2_hi; g.A2[1] = (const __bf16*)ce->A2_lo; g.B2 = (const __bf16*)ce->B2_hi;
+      g.a2_in32 = g.b2_in32 = (int)(ce->inner2 >> 5);
+      g.a2_rb = (int)((ce->a2_rows + 127) >> 7); g.b2_rb = (int)((ce->b2_rows + 127) >> 7);
+      g.K1 = ce->K1;
+    }
   }
   g.M = M; g.N = N; g.K = K;
   if (splitk < 1) splitk = 1;

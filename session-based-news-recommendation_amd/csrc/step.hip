@@ -19,7 +19,7 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
+    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 1},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -336,6 +336,18 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       return TCAR_E_LAUNCH;
     RET(tcar_segsum_index(&c->d, bt, c->segsum_ws, c->segsum_bytes, (void*)s2));
   }
+  // candidate-side time scores through the one-hot contraction (embed.hip: tcar_time_scores / tcar_time_onehot): the logits
+  // GEMM of a training step then runs over 2 ldh + 160 columns instead of 2 ldh + 5 ldt, the one-hot block at two MFMAs and one
+  // B plane per product.  The scores need attout and the time tables (early part of the update, this stream) only: launched
+  // AHEAD of the join with the aux stream.
+  CeWs w;
+  const bool ce_epi = c->scoring && train_index && fused_ce(c, B, &w);
+  const bool onehot = ce_epi && c->oh16 && c->p16h && c->p16l && c->scoring == 3 && tcar_tuning().onehot_time;
+  if (onehot) {
+    const float* tt[5];
+    for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+    RET(tcar_time_scores(&c->d, tt, B, c->attout, g.ek, c->p16h, c->p16l, 160, stream));
+  }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
   auto start_timer = [&]() {
@@ -345,13 +357,19 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   if (c->scoring) {
     // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
-    CeWs w;
-    if (train_index && fused_ce(c, B, &w)) {
+    if (ce_epi) {
       // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes
       // dlogits, plus per-group (max, sum) — no [B, N] fp32 logits; backward_impl finishes with tcar_ce_finish
       int32_t gw = 0, ng = 0;
-      rc = tcar_gemm_bf16_ce(B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->dl16h, g.Npad,
-                             (B + 127) & ~127, w.stats, w.stats_floats, bt->label, w.lab, c->scoring, &gw, &ng, stream);
+      if (onehot) {
+        rc = tcar_gemm_bf16_ce(B, g.N, g.ic + 160, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, g.ic, c->p16h,
+                               c->p16l, c->oh16, 160, c->dl16h, g.Npad, (B + 127) & ~127, w.stats, w.stats_floats, bt->label,
+                               w.lab, c->scoring, &gw, &ng, stream);
+      } else {
+        rc = tcar_gemm_bf16_ce(B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, g.ek, nullptr, nullptr,
+                               nullptr, 0, c->dl16h, g.Npad, (B + 127) & ~127, w.stats, w.stats_floats, bt->label, w.lab,
+                               c->scoring, &gw, &ng, stream);
+      }
       if (!rc && c->ce_geo) { c->ce_geo[0] = gw; c->ce_geo[1] = ng; }
       else if (!rc) rc = TCAR_E_ARG;
     } else {

@@ -62,6 +62,7 @@ struct TcarTuning {
   int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
   int x3_oneshot;       // TCAR_X3_ONESHOT     0: short-K small-GEMM launches keep the one-stage register ring
   int fused_ce;         // TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel
+  int onehot_time;      // TCAR_ONEHOT_TIME    0: the logits GEMM of a training step contracts the 5 ldt clipped candidate time columns instead of the 160-column one-hot form
   int proj_split;       // TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs
 };
 const TcarTuning& tcar_tuning();

@@ -775,6 +775,17 @@ class TcarEngine:
                     self._ce_ws = torch.empty(need, dtype=torch.float32, device=self.dev)
                     self._ce_geo = (C.c_int32 * 2)(0, 0)
                 c.ce_ws, c.ce_ws_floats, c.ce_geo = self._ce_ws.data_ptr(), self._ce_ws.numel(), C.cast(self._ce_geo, C.c_void_p)
+                # one-hot form of the candidate-side time scores: static OH plane of publish_time_MWDHM, per-step score planes
+                if self.shard == (0, g.N) and not os.environ.get("TCAR_NO_ONEHOT"):
+                    if getattr(self, "_oh16", None) is None:
+                        self._oh16 = torch.empty(g.Npad * 160, dtype=torch.bfloat16, device=self.dev)
+                        check(self.lib.tcar_time_onehot(C.byref(self.dims), self._p(self.mwdhm), self._p(self._oh16), 160,
+                                                        self._stream()), "tcar_time_onehot")
+                    Bp = _ru(self.work_B, 128)
+                    if getattr(self, "_p16h", None) is None or self._p16h.numel() < Bp * 160:
+                        self._p16h = torch.zeros(Bp * 160, dtype=torch.bfloat16, device=self.dev)
+                        self._p16l = torch.zeros(Bp * 160, dtype=torch.bfloat16, device=self.dev)
+                    c.oh16, c.p16h, c.p16l = self._oh16.data_ptr(), self._p16h.data_ptr(), self._p16l.data_ptr()
         if self.overlap:
             if not hasattr(self, "_aux"):
                 self._aux = torch.cuda.Stream(self.dev)

@@ -443,11 +443,13 @@ def _planes(lib, x):
     return hi, lo, inner, rows
 
 
-@pytest.mark.parametrize("M,N,K,nsplit", [(300, 1000, 64, 3), (77, 129, 96, 3), (512, 46033, 832, 3), (130, 5000, 832, 1)])
-def test_logits_gemm_softmax_epilogue(lib, M, N, K, nsplit):
+@pytest.mark.parametrize("M,N,K,nsplit,K2", [(300, 1000, 64, 3, 0), (77, 129, 96, 3, 0), (512, 46033, 832, 3, 0), (130, 5000, 832, 1, 0),
+                                             (300, 1000, 64, 3, 139), (77, 129, 512, 3, 160), (512, 46033, 512, 3, 139)])
+def test_logits_gemm_softmax_epilogue(lib, M, N, K, nsplit, K2):
     """tcar_gemm_bf16_ce + tcar_ce_finish (model_combine.py:138,145 without materialised logits): per-group (max, sum) statistics,
     the label's score, the cross entropy, and the in-place rescaled plane softmax - onehot against fp64 — on every workgroup
-    tile of the logits layout (group width 64 and 96), ragged M and N, padding rows / columns zero."""
+    tile of the logits layout (group width 64 and 96), ragged M and N, padding rows / columns zero.  K2 > 0 adds the second K
+    segment (A2 in hi / lo planes, B2 exact in bf16 — 0 / 1 entries like the one-hot plane of the publish-time rows)."""
     rng = np.random.RandomState(M + N)
     A = (rng.standard_normal((M, K)) * 0.7).astype(np.float32)
     Bm = (rng.standard_normal((N, K)) * 0.6).astype(np.float32)
@@ -458,6 +460,15 @@ def test_logits_gemm_softmax_epilogue(lib, M, N, K, nsplit):
         x = torch.tensor(A).bfloat16().double().numpy() @ torch.tensor(Bm).bfloat16().double().numpy().T
     ah, al, ai, ar = _planes(lib, A)
     bh, bl, bi, br = _planes(lib, Bm)
+    seg2 = (K, None, None, None, 0)
+    if K2:
+        A2 = (rng.standard_normal((M, K2)) * 0.5).astype(np.float32)
+        B2 = (rng.uniform(size=(N, K2)) < 5.0 / K2).astype(np.float32)
+        x = x + A2.astype(np.float64) @ B2.astype(np.float64).T
+        a2h, a2l, a2i, _ = _planes(lib, A2)
+        b2h, b2l, b2i, _ = _planes(lib, B2)
+        assert a2i == b2i == 160 and float(b2l.float().abs().max()) == 0.0
+        seg2 = (K, ptr2(a2h), ptr2(a2l), ptr2(b2h), a2i)
     Np, Mp = (N + 127) // 128 * 128, (M + 127) // 128 * 128
     plane = torch.full((Mp * Np,), float("nan"), dtype=torch.bfloat16, device="cuda")
     nstat = M * ((N + 63) // 64 + 8) * 2
@@ -466,8 +477,8 @@ def test_logits_gemm_softmax_epilogue(lib, M, N, K, nsplit):
     lab_logit = torch.zeros(M, device="cuda")
     rowstat, ce = torch.zeros(2 * M, device="cuda"), torch.zeros(M, device="cuda")
     gw, ng = C.c_int32(0), C.c_int32(0)
-    assert lib.tcar_gemm_bf16_ce(M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr2(plane), Np, Mp, ptr(stats), nstat,
-                                 ptr2(lab_d), ptr(lab_logit), nsplit, C.byref(gw), C.byref(ng), None) == 0
+    assert lib.tcar_gemm_bf16_ce(M, N, K + (160 if K2 else 0), ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, *seg2, ptr2(plane),
+                                 Np, Mp, ptr(stats), nstat, ptr2(lab_d), ptr(lab_logit), nsplit, C.byref(gw), C.byref(ng), None) == 0
     gw, ng = gw.value, ng.value
     assert gw in (64, 96) and ng * gw >= N
     st = stats[:M * ng * 2].view(M, ng, 2).cpu().numpy().astype(np.float64)
@@ -498,6 +509,56 @@ def test_logits_gemm_softmax_epilogue(lib, M, N, K, nsplit):
     assert (d[:M, N:] == 0).all() and (d[M:] == 0).all()                      # padding columns and the k-rows of dE
     rel = np.linalg.norm(d[:M, :N] - want) / np.linalg.norm(want)
     assert rel < 4e-3, rel
+
+
+@pytest.mark.parametrize("N,H,Ht,B", [(3000, 250, 64, 77), (46033, 250, 64, 512), (500, 30, 100, 5), (700, 100, 200, 33)])
+def test_time_onehot_plane_and_time_scores(lib, N, H, Ht, B):
+    """tcar_time_onehot + tcar_time_scores (model_combine.py:86-92,135,138 — the candidate-side publish-time vectors' part of the
+    logits): OH is the exact one-hot plane of the five table rows of every item, P holds attout_t . clip(row) for every one of
+    the 139 rows, and (P OH^T)[b, n] equals sum_k attout_tk[b] . clip(table_k[mwdhm[n, k]]) in fp64 to the split-bf16 bound."""
+    from tcar_amd._lib import Dims
+    ldh, ldt = (H + 63) // 64 * 64, (Ht + 63) // 64 * 64
+    d = Dims(N, H, Ht, ldh, ldt)
+    rng = np.random.RandomState(N + B)
+    sizes = (13, 32, 8, 25, 61)
+    tabs = [np.zeros((n, ldt), np.float32) for n in sizes]
+    for t in tabs:
+        t[:, :Ht] = rng.standard_normal((t.shape[0], Ht)) * rng.choice([0.05, 0.4], (t.shape[0], 1))    # rows both sides of norm 1
+    mw = np.stack([rng.randint(0, n, N) for n in sizes], 1).astype(np.int32)
+    ek = 2 * ldh + 5 * ldt
+    att = np.tanh(rng.standard_normal((B, ek))).astype(np.float32)
+    tabs_d = [torch.tensor(t).cuda() for t in tabs]
+    arr = (C.c_void_p * 5)(*[t.data_ptr() for t in tabs_d])
+    Np, Bp = (N + 127) // 128 * 128, (B + 127) // 128 * 128
+    oh = torch.full((Np * 160,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ph = torch.full((Bp * 160,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    pl = torch.full((Bp * 160,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    mw_d, att_d = torch.tensor(mw).cuda(), torch.tensor(att).cuda()
+    assert lib.tcar_time_onehot(C.byref(d), ptr2(mw_d), ptr2(oh), 160, None) == 0
+    assert lib.tcar_time_scores(C.byref(d), C.byref(arr), B, ptr(att_d), ek, ptr2(ph), ptr2(pl), 160, None) == 0
+    off = np.concatenate([[0], np.cumsum(sizes)])[:5]
+    want_oh = np.zeros((Np, 160), np.float32)
+    want_oh[np.arange(N)[:, None], off[None, :] + mw] = 1.0
+    got_oh = oh[torch.tensor(_kb32_index(Np, 160), device="cuda")].float().cpu().numpy()
+    assert (got_oh == want_oh).all()
+    clipped = []
+    for t in tabs:
+        t64 = t.astype(np.float64)
+        nrm = np.sqrt((t64 * t64).sum(1, keepdims=True))
+        clipped.append(t64 * np.where(nrm > 1.0, 1.0 / (nrm + 1e-7), 1.0))
+    want_p = np.zeros((Bp, 160))
+    for k in range(5):
+        want_p[:B, off[k]:off[k] + sizes[k]] = att[:, 2 * ldh + k * ldt:2 * ldh + (k + 1) * ldt].astype(np.float64) @ clipped[k].T
+    idx = torch.tensor(_kb32_index(Bp, 160), device="cuda")
+    got_h, got_l = ph[idx].float().cpu().numpy().astype(np.float64), pl[idx].float().cpu().numpy().astype(np.float64)
+    assert (got_h[B:] == 0).all() and (got_l[B:] == 0).all() and (got_h[:, 139:] == 0).all() and (got_l[:, 139:] == 0).all()
+    scale = np.abs(want_p).max()
+    assert np.abs(got_h + got_l - want_p).max() <= 2.0 ** -16 * scale               # hi + lo planes: 16 mantissa bits
+    assert np.abs(got_h - want_p).max() <= 2.0 ** -8 * scale
+    # the contraction the logits GEMM runs over the two planes
+    scores = (got_h + got_l)[:B] @ want_oh[:N].T.astype(np.float64)
+    direct = sum(att[:, 2 * ldh + k * ldt:2 * ldh + (k + 1) * ldt].astype(np.float64) @ clipped[k][mw[:, k]].T for k in range(5))
+    assert np.abs(scores - direct).max() <= 1e-5 * np.abs(direct).max()
 
 
 def test_split_bf16_planes_kb32_layout(lib):

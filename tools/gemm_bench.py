@@ -31,6 +31,8 @@ nstat = B * ((N + 63) // 64 + 8) * 2
 stats, lab_logit = torch.empty(nstat, device="cuda"), torch.empty(B, device="cuda")
 label = torch.randint(0, N, (B,), dtype=torch.int32, device="cuda")
 gw, ng = C.c_int32(0), C.c_int32(0)
+p_h, p_l = torch.randn(B, 160, **bf), torch.randn(B, 160, **bf) * 0.004
+oh = (torch.rand(Npad, 160, device="cuda") < 5.0 / 160).to(torch.bfloat16)
 
 
 hp, s2 = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
@@ -56,8 +58,12 @@ def run():
     if which == "fwd":
         return lib.tcar_gemm_bf16(1, B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, p(logits), Npad, None, 0, 0, nsplit, 1, None), 2.0 * B * N * 820
     if which == "fwdce":
-        return lib.tcar_gemm_bf16_ce(B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, p(plane), Npad, B, p(stats), nstat,
-                                     p(label), p(lab_logit), nsplit, C.byref(gw), C.byref(ng), None), 2.0 * B * N * 820
+        return lib.tcar_gemm_bf16_ce(B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, EK, None, None, None, 0, p(plane), Npad, B,
+                                     p(stats), nstat, p(label), p(lab_logit), nsplit, C.byref(gw), C.byref(ng), None), 2.0 * B * N * 820
+    if which == "fwdce2":   # item | content columns + the 160-column one-hot segment of the publish-time rows
+        return lib.tcar_gemm_bf16_ce(B, N, 512 + 160, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, 512, p(p_h), p(p_l), p(oh), 160,
+                                     p(plane), Npad, B, p(stats), nstat, p(label), p(lab_logit), nsplit, C.byref(gw), C.byref(ng),
+                                     None), 2.0 * B * N * 820
     if which == "dx":
         return lib.tcar_gemm_bf16(0, B, EK, Npad, p(d_h), p(d_l), Npad, B, p(e_h), p(e_l), EK, Npad, p(slabs), EK, None, 0, 0, nsplit, SK, None), 2.0 * B * N * 820
     return lib.tcar_gemm_bf16(2, N, 576, B, p(d_h), p(d_l), Npad, B, p(ap_h), p(ap_l), 576, B, p(gi), 256, p(det), 320, 256, nsplit, 1, None), 2.0 * B * N * 570
