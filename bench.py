@@ -387,6 +387,7 @@ def main():
         dt_o, _ = timed(not headline_sampler)
         other = B * world * args.steps / dt_o
     dt, t_enq = timed(headline_sampler)
+    eng.check_forks()                          # (raises if a flag fork's poll ever timed out: the measurement would be void)
     last_loss = float(eng.loss[:B].mean())
     dt_ev = None
     if not args.no_kernel_timing:

@@ -539,7 +539,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 17
+#define TCAR_ABI_VERSION 18
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -622,6 +622,11 @@ typedef struct {
   /* optional planes of the one-hot form of the candidate-side time scores (training steps with the softmax epilogue): oh16
    * [ceil128(N), 160] from tcar_time_onehot (static), p16h / p16l [ceil128(B), 160] written by tcar_time_scores every step */
   void* oh16; void* p16h; void* p16l;
+  /* optional words of the flag forks (step.hip fork_arm / fork_go): sig_dev = 49 zeroed device words (16 workgroup counters,
+   * 16 flags, 1 error count, 16 XCD-cover words of the polling kernels), sig_epoch = ONE host word the driver counts forks in.  With them the main stream records no
+   * event where a side stream is forked: the producing kernel publishes a flag, a one-wave kernel of the side stream polls it.
+   * The engine must raise when sig_dev[32] != 0 (a poll gave up: the streams do not run concurrently). */
+  uint32_t* sig_dev; uint32_t* sig_epoch /*host*/;
 } tcar_ctx_t;
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */

@@ -20,7 +20,7 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 17          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 18          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_time_onehot", "tcar_time_scores", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
@@ -196,7 +196,8 @@ class Ctx(C.Structure):
                    ("segsum_ws", C.c_void_p), ("segsum_bytes", C.c_int64), ("gw_rows", C.c_void_p), ("wgrad_slabs", C.c_void_p), ("wgrad_slab_floats", C.c_int64),
                    ("proj_slabs", C.c_void_p), ("proj_slab_floats", C.c_int64),
                    ("ce_ws", C.c_void_p), ("ce_ws_floats", C.c_int64), ("ce_geo", C.c_void_p),
-                   ("oh16", C.c_void_p), ("p16h", C.c_void_p), ("p16l", C.c_void_p)])
+                   ("oh16", C.c_void_p), ("p16h", C.c_void_p), ("p16l", C.c_void_p),
+                   ("sig_dev", C.c_void_p), ("sig_epoch", C.c_void_p)])
 
 
 class TcarError(RuntimeError):

@@ -55,6 +55,7 @@ struct GroupArgs {
   int wg0[MAXP];            // first workgroup id of every problem (INT_MAX past nprob): ONE contiguous scalar load finds a
                             // workgroup's problem — a loop over p[i].wg_begin costs a dependent scalar-load round trip per problem
   GemmProb p[MAXP];
+  TcarSignal sig;           // completion flag (gemm_x3_kernel only; zero = none)
 };
 
 template <int LAY, int ROWS>   // ROWS = tile extent along the m/n dimension (64 or 128)
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
     csum += __shfl_xor(csum, 32);
     if (lane < 32 && col < g.N && csum != 0.f) atomicAdd(g.colsum + col, csum);
   }
+  tcar_signal_done(ga.sig);
 }
 
 namespace {
@@ -520,8 +522,9 @@ int launch_layout(GroupArgs& ga, hipStream_t st) {
 }
 
 template <int LA, int LB, int XK, int XD>
-int launch_x3_v(const GroupArgs& ga, int wg, hipStream_t st) {
+int launch_x3_v(GroupArgs& ga, int wg, hipStream_t st) {
   constexpr size_t lds = 4 * X3<XK>::PLANE;
+  ga.sig = tcar_take_signal();
   TCAR_SET_LDS_ONCE((gemm_x3_kernel<LA, LB, XK, XD>), lds);
   TCAR_LAUNCH((gemm_x3_kernel<LA, LB, XK, XD>), dim3(wg), dim3(256), lds, st, ga);
   TCAR_CHECK_LAUNCH();

@@ -260,7 +260,7 @@ struct AdamEarly {
   AdamAll p;
   const int32_t* ids; long n_ids; uint32_t* bitmap; int n_rowblk;
 };
-__global__ __launch_bounds__(256) void clip_adam_early_kernel(const AdamEarly e, const SegArgs a) {
+__device__ __forceinline__ void clip_adam_early_body(const AdamEarly& e, const SegArgs& a) {
   const AdamAll& p = e.p;
   if ((int)blockIdx.x >= e.n_rowblk) {
     const int idx = blockIdx.x - e.n_rowblk;
@@ -294,6 +294,10 @@ __global__ __launch_bounds__(256) void clip_adam_early_kernel(const AdamEarly e,
       *reinterpret_cast<bf16x4_t*>(p.el + o) = l;
     }
   }
+}
+__global__ __launch_bounds__(256) void clip_adam_early_kernel(const AdamEarly e, const SegArgs a, const TcarSignal sig) {
+  clip_adam_early_body(e, a);
+  tcar_signal_done(sig);        // the step driver forks the aux stream behind this launch (candidate-side time vectors)
 }
 template <bool NT>
 __global__ __launch_bounds__(256) void clip_adam_rest_kernel(const AdamAll p, const uint32_t* __restrict__ skip) {
@@ -441,7 +445,7 @@ extern "C" int tcar_clip_adam_early(float* w, const float* g, float* m, float* v
   a.s = *segs;
   const int grid = e.n_rowblk + e.p.gx * segs->nseg;
   if (grid <= 0) return TCAR_OK;
-  TCAR_LAUNCH(clip_adam_early_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, e, a);
+  TCAR_LAUNCH(clip_adam_early_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, e, a, tcar_take_signal());
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

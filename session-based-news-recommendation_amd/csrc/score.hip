@@ -204,9 +204,9 @@ __global__ __launch_bounds__(256) void ce_combine_kernel(int B, int ngroups, con
 // SUM of the per-session losses (model_combine.py:147,156); rows [B, ceil128(B)) are zeroed (they are k-rows of dE).
 // One thread per (row, 32-column block) = 64 contiguous bytes of the KB32 plane: a wave streams 4 KB.
 template <int GW>
-__global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
-                                                         const float* __restrict__ rowstat, const int32_t* __restrict__ label,
-                                                         __bf16* __restrict__ plane, long nunits) {
+__device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
+                                                const float* __restrict__ rowstat, const int32_t* __restrict__ label,
+                                                __bf16* __restrict__ plane, long nunits) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nunits) return;
   const long blk = i >> 7;
@@ -246,6 +246,13 @@ __global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32,
     }
     p[q] = make_uint4(w[0], w[1], w[2], w[3]);
   }
+}
+template <int GW>
+__global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
+                                                         const float* __restrict__ rowstat, const int32_t* __restrict__ label,
+                                                         __bf16* __restrict__ plane, long nunits, const TcarSignal sig) {
+  ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits);
+  tcar_signal_done(sig);        // the step driver forks the aux stream (dE) behind this launch
 }
 
 // ---- negative-feedback term (model_combine.py:142-143) ---------------------------------------------------
@@ -698,10 +705,11 @@ extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const 
   const int in32 = (int)(inner >> 5);
   const long nunits = (((long)B + 127) >> 7) * in32 * 128;
   const unsigned grid = (unsigned)((nunits + 255) / 256);
+  const TcarSignal sig = tcar_take_signal();
   if (group_width == 96)
-    TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits);
+    TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits, sig);
   else
-    TCAR_LAUNCH(ce_rescale_kernel<64>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits);
+    TCAR_LAUNCH(ce_rescale_kernel<64>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits, sig);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

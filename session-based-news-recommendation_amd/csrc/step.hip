@@ -20,6 +20,7 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 1},
+    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 48},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -31,6 +32,10 @@ static TcarTuning& tuning_storage() {
   return t;
 }
 const TcarTuning& tcar_tuning() { return tuning_storage(); }
+TcarSignal& tcar_pending_signal() {
+  thread_local TcarSignal pending{};
+  return pending;
+}
 
 // Diagnostic hook (tests, tools/): override one switch at run time; returns the previous value, or INT_MIN for an unknown
 // name.  Process-global and not thread safe against concurrent launches — the product path (engine, step driver) never calls it.
@@ -121,6 +126,74 @@ inline hipStream_t aux_stream(const tcar_ctx_t* c) {
   return (c->stream2 && c->ev[0] && c->ev[1] && c->ev[2] && c->ev[3] && c->ev[4]) ? (hipStream_t)c->stream2 : nullptr;
 }
 
+// ---- forks of the main stream without an event on it ---------------------------------------------------------------------------
+// fork_arm(slot) right before the launch whose END the side stream has to wait for (that launch takes the pending flag: the
+// small-GEMM, logits-GEMM, early-Adam and CE-rescale launches do); fork_go(slot, ...) where the event record + wait used to be:
+// a one-wave kernel on the side stream polls the flag.  A launch that did not take the flag (another kernel family on this
+// path) or a context without the flag words: the event pair, as before.  The poll gives up after POLL_TICKS of the 100-MHz
+// wall clock (streams that share one hardware queue, or a profiler that serialises kernels, would otherwise hang) and counts
+// the time-out in sig_dev[TCAR_SIG_ERR]; the engine raises on a non-zero count.
+// EIGHT one-wave workgroups — the dispatcher deals consecutive workgroups round-robin over the eight XCDs — each of which, once
+// the flag shows the epoch, writes back ITS XCD's L2 (the producer's workgroups only drained their stores into their L2s): the
+// agent-scope release of the hand-off, once per XCD instead of once per producing workgroup.  The XCD ids the eight waves ran
+// on are collected (HW_REG_XCC_ID); a launch that did not cover all eight counts as an error like a time-out, so a different
+// placement is loud, not stale.  The consumer kernels behind this one start with the runtime's usual acquire.
+constexpr int TCAR_SIG_SLOTS = 16, TCAR_SIG_ERR = 2 * TCAR_SIG_SLOTS, TCAR_SIG_POLL = TCAR_SIG_ERR + 1;   // + one cover word per slot
+constexpr long long POLL_TICKS = 100000000LL;      // 1 s of the 100-MHz wall clock
+__global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, unsigned* cover) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64();
+  bool ok = true;
+  while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > POLL_TICKS) { ok = false; break; }
+  }
+  asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // HW_REG_XCC_ID, bits 3:0
+  // ONE word, a 4-bit arrival count per XCD: the wave that completes the eight arrivals sees every count
+  const unsigned inc = 1u << (4 * (xcc & 7u));
+  const unsigned w = __hip_atomic_fetch_add(cover, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + inc;
+  unsigned n = 0;
+  for (int i = 0; i < 8; ++i) n += (w >> (4 * i)) & 15u;
+  if (!ok) atomicAdd(err, 1u);
+  if (n == gridDim.x) {
+    if (w != 0x11111111u) atomicAdd(err, 1u);
+    __hip_atomic_store(cover, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+enum { FK_EARLY = 0, FK_PROJ = 1, FK_LOGITS = 2, FK_SOFTMAX = 3, FK_INGRAD = 4, FK_DCLICK = 5 };
+struct Fork { TcarSignal sig; bool armed; const tcar_ctx_t* ctx; };
+inline Fork& fork_slot(int slot) {
+  thread_local Fork forks[TCAR_SIG_SLOTS] = {};
+  return forks[slot];
+}
+inline void fork_arm(const tcar_ctx_t* c, int slot) {
+  Fork& f = fork_slot(slot);
+  f.armed = false;
+  tcar_pending_signal() = TcarSignal{};
+  if (!c->sig_dev || !c->sig_epoch || !((tcar_tuning().flag_fork >> slot) & 1)) return;      // the switch is a mask over the slots
+  f.sig = TcarSignal{c->sig_dev + slot, c->sig_dev + TCAR_SIG_SLOTS + slot, ++c->sig_epoch[0], 0u};
+  f.armed = true;
+  f.ctx = c;
+  tcar_pending_signal() = f.sig;
+}
+inline void fork_disarm(int slot) { fork_slot(slot).armed = false; }
+inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev) {
+  Fork& f = fork_slot(slot);
+  TcarSignal& pend = tcar_pending_signal();
+  if (f.armed && f.ctx != c) f.armed = false;                           // armed by another context's step on this thread
+  const bool taken = f.armed && pend.cnt == nullptr;
+  if (f.armed && !taken) { pend = TcarSignal{}; f.armed = false; }      // the producing launch was not flag-capable
+  if (taken) {
+    TCAR_LAUNCH(poll_flag_kernel, dim3(8), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch, c->sig_dev + TCAR_SIG_ERR,
+                c->sig_dev + TCAR_SIG_POLL + slot);
+    TCAR_CHECK_LAUNCH();
+    return TCAR_OK;
+  }
+  if (hipEventRecord((hipEvent_t)ev, from) != hipSuccess || hipStreamWaitEvent(to, (hipEvent_t)ev, 0) != hipSuccess) return TCAR_E_LAUNCH;
+  return TCAR_OK;
+}
+
 int check_ctx(const tcar_ctx_t* c, const tcar_batch_t* bt) {
   if (!c || !bt || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   if (!c->E || !c->W || !c->Gx || !c->M || !c->V || !c->big || !c->Mi || !c->Vi) return TCAR_E_ARG;
@@ -151,8 +224,8 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
 namespace {
 // model_combine.py:52-132 for the sessions of `bt`: gather + clip, the three input projections, the click query, both
 // attention pools and the output transforms -> c->attout [B, ek] (+ its bf16 planes when `planes`)
-// `hook(stage)`: called behind the projection launch (1) and behind the click-query launch (2) — forward_impl forks the rest
-// pass of a pending split update there
+// `hook(stage)`: called in front of the projection launch (0), behind it (1) and behind the click-query launch (2) — forward_impl
+// forks the rest pass of a pending split update there
 template <class Hook>
 int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei, Hook hook) {
   const int B = bt->B, BT = bt->B * bt->T;
@@ -180,6 +253,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     p[5] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
     // optional HIP events around exactly this launch (kind 3 of ev_start / ev_stop: the largest of the session-side small GEMMs)
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[3 * c->ev_n + ei], (hipStream_t)stream);
+    RET(hook(0));
     RET(small_gemm(c, 0, 6, p, stream));
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[3 * c->ev_n + ei], (hipStream_t)stream);
   } else {
@@ -192,6 +266,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     seg(p[1], c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt);
     seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
     p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
+    RET(hook(0));
     RET(small_gemm(c, 0, 3, p, stream));
   }
   RET(hook(1));
@@ -253,8 +328,7 @@ int zero_arena(const tcar_ctx_t* c, hipStream_t s) {
 // dE fork — and joining the three streams through ONE wait at the end of the step measured SLOWER, 0.635 vs 0.613 ms per step:
 // dE then starts behind the negative term and the final join becomes two hops.)
 int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
-  if (sz != st && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sz, (hipEvent_t)c->ev[0], 0) != hipSuccess))
-    return TCAR_E_LAUNCH;
+  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0]));    // (armed by forward_impl in front of the logits GEMM)
   RET(zero_arena(c, sz));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
@@ -292,12 +366,12 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       // kernel, with the time refresh on the third stream: the 376-MB pass then runs beside the gather and the projections
       // as well and slows them by more than it gains — 0.626 vs 0.618 ms per step)
       const float* pieces = c->Gx + c->arena_n;
+      fork_arm(c, FK_EARLY);
       RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
                                c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
                                c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT,
                                c->adam_bitmap, stream));
-      if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
-        return TCAR_E_LAUNCH;
+      RET(fork_go(c, FK_EARLY, s1, s2, c->ev[0]));
       RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, (void*)s2));
       // the rest pass is forked BEHIND the projection launch: gather and projections run without the 376-MB stream beside
       // them (21 instead of 40 us for the projections), the pass still ends before the output transforms do.  Measured over
@@ -322,15 +396,16 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     c->ev_cursor[1] = ei;
   }
   RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage) -> int {
+    if (rest_stage == 1 && stage == 0) fork_arm(c, FK_PROJ);        // in front of the projection launch
     if (stage != rest_stage) return TCAR_OK;
     // late fork: the HBM-bound rest pass starts only now, so the launches before this point ran without it
-    if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
-      return TCAR_E_LAUNCH;
+    RET(fork_go(c, FK_PROJ, s1, s2, c->ev[0]));
     return launch_rest();
   }));
   // sort index of the item rows (feed only): on the aux stream BEHIND the rest pass — the logits GEMM does not wait for it (ev[1]
   // was recorded in front of it), the backward does
   if (train_index && sorted_rows(c, bt)) {
+    // (with a time refresh the aux stream was already forked from this step's main stream: it is behind the previous backward)
     if (!refresh_time &&
         (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
       return TCAR_E_LAUNCH;
@@ -354,9 +429,11 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
   };
   int rc;
+  fork_disarm(FK_LOGITS);
   if (c->scoring) {
     // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
+    if (ce_epi && s2) fork_arm(c, FK_LOGITS);       // backward_prologue forks the aux stream behind this launch
     if (ce_epi) {
       // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes
       // dlogits, plus per-group (max, sum) — no [B, N] fp32 logits; backward_impl finishes with tcar_ce_finish
@@ -478,14 +555,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   // hi-only backward (bf16x3-mixed, bf16): the lo plane of dlogits is never read — and not written
   CeWs cw;
+  if (s2) fork_arm(c, FK_SOFTMAX);         // (taken by the CE-rescale launch; the other softmax kernels leave it: event)
   if (ce_epilogue && fused_ce(c, B, &cw))   // the forward pass of THIS step ran the softmax epilogue (same predicate)
     RET(tcar_ce_finish(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream));
   else if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
-  if (s2) {
-    if (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess)
-      return TCAR_E_LAUNCH;
-  }
+  if (s2) RET(fork_go(c, FK_SOFTMAX, st, s2, c->ev[2]));
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // optional HIP events around exactly the dE and dX launches (slot chosen by the forward pass; kind 1 = dX, 2 = dE)
@@ -582,8 +657,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
     p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
+    if (s2 && fuse_finish && c->stream3 && c->ev3) fork_arm(c, FK_INGRAD);     // the third stream's fork below
     RET(small_gemm(c, 1, 4, p, stream));
   } else {
+    fork_disarm(FK_INGRAD);
     RET(tcar_dact_colsum(B, g.ic, g.ic, c->q, c->dq, G(c, TCAR_V_Q2_B), 2, stream));
     {
       tcar_gemm_desc_t p = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
@@ -597,9 +674,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   hipStream_t s3 = (s2 && fuse_finish && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
-    if (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s3, (hipEvent_t)c->ev[0], 0) != hipSuccess ||
-        hipStreamWaitEvent(s3, (hipEvent_t)c->ev[1], 0) != hipSuccess)
-      return TCAR_E_LAUNCH;
+    RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));
+    if (hipStreamWaitEvent(s3, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   } else if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   // Order-fixed small tables (sorted mode, which implies an aux stream): they — and the click-query input gradient, which only
@@ -614,8 +690,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
     tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+    if (det_small) fork_arm(c, FK_DCLICK);
     RET(small_gemm(c, 1, 1, &p, stream));
   } else {  // input gradients (only the ITEM half of dX_ic: content is frozen)
+    fork_disarm(FK_DCLICK);
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
@@ -631,8 +709,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    if (hipEventRecord((hipEvent_t)c->ev[5], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[5], 0) != hipSuccess)
-      return TCAR_E_LAUNCH;
+    RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5]));
     RET(tcar_small_tables_bwd_det(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2));
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }

@@ -64,8 +64,40 @@ struct TcarTuning {
   int fused_ce;         // TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel
   int onehot_time;      // TCAR_ONEHOT_TIME    0: the logits GEMM of a training step contracts the 5 ldt clipped candidate time columns instead of the 160-column one-hot form
   int proj_split;       // TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs
+  int flag_fork;        // TCAR_FLAG_FORK      0: every fork of the main stream records an event (6-7 us of bubble on it) instead of
+                        //                     letting the producing kernel publish a device flag a polling kernel of the side stream waits for
 };
 const TcarTuning& tcar_tuning();
+
+// Completion flag of a kernel (step.hip: fork_arm / fork_go).  A kernel that carries one publishes `epoch` to *flag when its
+// LAST workgroup is through: the side stream's consumers sit behind a one-wave polling kernel instead of behind an event the main
+// stream would have to record (measured, tools/micro/event_cost: a record between two kernels costs the recording stream 6.5 us,
+// the flag costs it nothing and releases the consumer 0.4 us after the producer's end).  cnt == nullptr: no flag.
+struct TcarSignal { unsigned* cnt; unsigned* flag; unsigned epoch; unsigned pad_; };
+// the flag the NEXT flag-capable launch of this host thread carries (it takes it: tcar_take_signal); defined in step.hip
+TcarSignal& tcar_pending_signal();
+inline TcarSignal tcar_take_signal() {
+  TcarSignal& p = tcar_pending_signal();
+  const TcarSignal s = p;
+  p = TcarSignal{};
+  return s;
+}
+// Every thread of every workgroup calls this as the kernel's last statement (no early returns ahead of it).  The workgroup's
+// stores are drained into its XCD's L2 (vmcnt) before it is counted; NO release fence here — an agent-scope release in every
+// workgroup is an L2 write-back per workgroup (measured: the CE-rescale kernel 24 -> 176 us, and every kernel beside it slower).
+// The write-back of the eight L2s is done ONCE per XCD by the polling kernel of the consumer stream (step.hip poll_flag_kernel),
+// after the flag and before the consumer's first kernel starts.
+__device__ __forceinline__ void tcar_signal_done(const TcarSignal& s) {
+  if (!s.cnt) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    if (__hip_atomic_fetch_add(s.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y * gridDim.z - 1u) {
+      __hip_atomic_store(s.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reusable by the slot's next launch
+      __hip_atomic_store(s.flag, s.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

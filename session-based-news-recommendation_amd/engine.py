@@ -276,11 +276,23 @@ class TcarEngine:
         return W
 
     # ------------------------------------------------------------------------------------- checkpoint state
+    def check_forks(self):
+        """Raise if a polling kernel of a flag fork (tcar_ctx_t.sig_dev) ever gave up waiting: the side streams did not run
+        beside the main stream (kernels serialised by a profiler's counter collection, or streams sharing one hardware queue),
+        and a consumer may have run ahead of its producer.  Synchronises the device; called where the host reads results
+        back (export_state, the training loop's epoch end, bench.py after its timed loop)."""
+        if getattr(self, "_sig", None) is not None:
+            n = int(self._sig[32].item())
+            if n:
+                raise RuntimeError(f"{n} flag-fork poll(s) timed out: the step's streams are not running concurrently "
+                                   "(set TCAR_FLAG_FORK=0 to fork with events)")
+
     def export_state(self) -> Dict[str, np.ndarray]:
         """Everything a resumed run needs, as plain arrays (np.savez, loadable with allow_pickle=False): the 23 variables
         `var/<name>`, the Adam moments `m/<name>`, `v/<name>` in the reference's shapes, the beta powers and the step
         count (tf.train.AdamOptimizer's beta1_power / beta2_power non-slot variables, model_combine.py:155)."""
         self.flush()
+        self.check_forks()
         g = self.geo
         out = {"var/" + k: v for k, v in self.export_params().items()}
         for tag, arena, item in (("m/", self.M, self.Mi), ("v/", self.V, self.Vi)):
@@ -326,6 +338,7 @@ class TcarEngine:
     def export_params(self) -> "OrderedDict[str, np.ndarray]":
         """All 23 trainable variables in the reference's shapes."""
         self.flush()
+        self.check_forks()
         g = self.geo
         out = self._unpack_arena(self.W.cpu().numpy())
         item = np.zeros((g.N + 1, g.H), dtype=np.float32)
@@ -807,6 +820,14 @@ class TcarEngine:
                     self._aux3_ev.record(torch.cuda.current_stream(self.dev))
                 c.stream3 = self._aux3.cuda_stream
                 c.ev3 = self._aux3_ev.cuda_event
+            # flag forks (tcar_ctx_t.sig_dev): single-process engines only — a polling kernel at the head of a side stream must
+            # never share a hardware queue with work the main stream waits for, and the collectives' streams of a multi-rank run
+            # are not ours to place (DPEngine / ShardedEngine keep the event forks)
+            if type(self) is TcarEngine and not os.environ.get("TCAR_NO_FLAG_FORK"):
+                if not hasattr(self, "_sig"):
+                    self._sig = torch.zeros(80, dtype=torch.int32, device=self.dev)
+                    self._sig_epoch = (C.c_uint32 * 1)(0)
+                c.sig_dev, c.sig_epoch = self._sig.data_ptr(), C.cast(self._sig_epoch, C.c_void_p)
         if self._ev is not None:
             c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
             c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)

@@ -284,6 +284,7 @@ class Seq2SeqAttNN():
                 acc[:crt_loss.numel()].add_(crt_loss)
                 count += crt_loss.numel()
             eng.flush()                                         # the last step's deferred update
+            eng.check_forks()
             tot, cnt = self._allsum([float(acc.sum().item()), float(count)])
             avgc = tot / max(cnt, 1)
             self.train_seconds = time.time() - t0
