@@ -98,6 +98,11 @@ typedef struct {
  *   click_t [B, ct].  Dwell id >= 11 yields a zero row. */
 int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
                          float* x_icp, float* x_pt, float* x_act, float* click_t, void* stream);
+/* Both layers of the click-query MLP in one launch (modules.py:138-139): q1 [B, ldh] = relu(click_t Wq1 + b1), q [B, 2 ldh] =
+ * tanh(q1 Wq2 + b2), fp32 FMAs in a fixed order.  Only for ldh == 256 and ldt == 64 (the reference's hidden sizes, padded);
+ * TCAR_E_ARG otherwise — run the layers through tcar_gemm_*_grouped then. */
+int tcar_query_mlp(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b, const float* q2_w,
+                   const float* q2_b, float* q1, float* q, void* stream);
 
 /* tcar_gather_clip_bwd: gradient of the above w.r.t. the tables (through the norm clip), i.e. the
  * IndexedSlices that tf.gradients builds for model_combine.py:156.  Adds into `g` (atomics) and adds
@@ -539,7 +544,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 18
+#define TCAR_ABI_VERSION 19
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */

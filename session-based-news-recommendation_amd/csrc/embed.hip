@@ -23,6 +23,7 @@ struct EmbArgs {
   tcar_dims_t d;
   tcar_tables_t tab;
   tcar_batch_t bt;
+  TcarSignal sig;      // completion flag (latency form of the forward gather only): click_t is then stored write-through
   float* x_icp; float* x_pt; float* x_act; float* click_t;
   const float* dx_icp; const float* dx_pt; const float* dx_act; const float* dclick;
   tcar_grads_t g;
@@ -139,9 +140,14 @@ __global__ __launch_bounds__(256) void gather_clip_fwd_kernel(const EmbArgs a) {
       const int id = clampi(jj == 0 ? a.bt.cw[b] : a.bt.ch[b], 0, time_vocab(kk) - 1);
       float4 x = valid ? ld4(pick5(a.tab.time, kk) + (long)id * ldt + lin * 4) : zero4();
       const float sx = clip_scale(group_sum(dot4(x, x), sub));
-      if (valid) st4(a.click_t + (long)b * ct + jj * ldt + lin * 4, scale4(x, sx));
+      if (valid) {
+        // with a completion flag the click rows are what the flag's consumer reads (the click-query MLP on a side stream)
+        if (a.sig.cnt) st4_sc1(a.click_t + (long)b * ct + jj * ldt + lin * 4, scale4(x, sx));
+        else st4(a.click_t + (long)b * ct + jj * ldt + lin * 4, scale4(x, sx));
+      }
     }
   }
+  tcar_signal_done(a.sig);
 }
 
 // ------------------------------------------------------------------------------- forward, throughput form
@@ -1035,6 +1041,7 @@ extern "C" int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* t
     return TCAR_OK;
   }
   const int grid = grid_for_rows((long)bt->B * bt->T + bt->B);
+  a.sig = tcar_take_signal();
   if (d->ldh <= 256) TCAR_LAUNCH(gather_clip_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else TCAR_LAUNCH(gather_clip_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();

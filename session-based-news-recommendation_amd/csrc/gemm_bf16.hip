@@ -23,6 +23,7 @@
 //           it returns, to lane i, column i of a 4 (k) x 16 (col) block): no transposed copy of E or dlogits exists.
 // XCD-aware tile remap as in gemm_f32.hip; split-K (slabs) serves the catalog-long contraction of dX.
 #include <type_traits>
+#include <cstdlib>
 #include "tcar_common.h"
 #include "tcar_bf16_layout.h"
 #include <stdlib.h>

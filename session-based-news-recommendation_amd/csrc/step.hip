@@ -20,7 +20,7 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 1},
-    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 48},
+    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 240},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -140,6 +140,8 @@ inline hipStream_t aux_stream(const tcar_ctx_t* c) {
 // placement is loud, not stale.  The consumer kernels behind this one start with the runtime's usual acquire.
 constexpr int TCAR_SIG_SLOTS = 16, TCAR_SIG_ERR = 2 * TCAR_SIG_SLOTS, TCAR_SIG_POLL = TCAR_SIG_ERR + 1;   // + one cover word per slot
 constexpr long long POLL_TICKS = 100000000LL;      // 1 s of the 100-MHz wall clock
+// FLUSH = false (one workgroup): the producer stored everything the consumer reads write-through (sc1) — nothing to write back.
+template <bool FLUSH>
 __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, unsigned* cover) {
   if (threadIdx.x != 0) return;
   const long long t0 = wall_clock64();
@@ -147,6 +149,10 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
   while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
     __builtin_amdgcn_s_sleep(2);
     if (wall_clock64() - t0 > POLL_TICKS) { ok = false; break; }
+  }
+  if (!FLUSH) {
+    if (!ok) atomicAdd(err, 1u);
+    return;
   }
   asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
   const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // HW_REG_XCC_ID, bits 3:0
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
     __hip_atomic_store(cover, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-enum { FK_EARLY = 0, FK_PROJ = 1, FK_LOGITS = 2, FK_SOFTMAX = 3, FK_INGRAD = 4, FK_DCLICK = 5 };
+enum { FK_EARLY = 0, FK_PROJ = 1, FK_LOGITS = 2, FK_SOFTMAX = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7 };
 struct Fork { TcarSignal sig; bool armed; const tcar_ctx_t* ctx; };
 inline Fork& fork_slot(int slot) {
   thread_local Fork forks[TCAR_SIG_SLOTS] = {};
@@ -178,15 +184,28 @@ inline void fork_arm(const tcar_ctx_t* c, int slot) {
   tcar_pending_signal() = f.sig;
 }
 inline void fork_disarm(int slot) { fork_slot(slot).armed = false; }
-inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev) {
+// did the launch behind fork_arm(slot) take the flag?  (false also clears a flag nobody took)
+inline bool fork_taken(const tcar_ctx_t* c, int slot) {
+  Fork& f = fork_slot(slot);
+  TcarSignal& pend = tcar_pending_signal();
+  if (f.armed && f.ctx == c && pend.cnt == nullptr) return true;
+  pend = TcarSignal{};
+  f.armed = false;
+  return false;
+}
+inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev, bool flush = true) {
   Fork& f = fork_slot(slot);
   TcarSignal& pend = tcar_pending_signal();
   if (f.armed && f.ctx != c) f.armed = false;                           // armed by another context's step on this thread
   const bool taken = f.armed && pend.cnt == nullptr;
   if (f.armed && !taken) { pend = TcarSignal{}; f.armed = false; }      // the producing launch was not flag-capable
   if (taken) {
-    TCAR_LAUNCH(poll_flag_kernel, dim3(8), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch, c->sig_dev + TCAR_SIG_ERR,
-                c->sig_dev + TCAR_SIG_POLL + slot);
+    if (flush)
+      TCAR_LAUNCH(poll_flag_kernel<true>, dim3(8), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch,
+                  c->sig_dev + TCAR_SIG_ERR, c->sig_dev + TCAR_SIG_POLL + slot);
+    else
+      TCAR_LAUNCH(poll_flag_kernel<false>, dim3(1), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch,
+                  c->sig_dev + TCAR_SIG_ERR, c->sig_dev + TCAR_SIG_POLL + slot);
     TCAR_CHECK_LAUNCH();
     return TCAR_OK;
   }
@@ -231,7 +250,23 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   const int B = bt->B, BT = bt->B * bt->T;
   tcar_tables_t tab;
   tables_of(c, tab);
+  // The click-query MLP (q1, q: modules.py:138-139) needs only the gathered click-time rows: with flag forks it runs as ONE
+  // launch (query.hip) on the third stream BESIDE the projections instead of as two small GEMMs between them and the pools
+  // (22 + 30 us on the main chain).  The gather publishes a flag for it, it publishes one for the pools; both producers store
+  // what the other stream reads write-through, so the polling kernels write back no L2.
+  const int fmask = tcar_tuning().flag_fork;
+  hipStream_t sq = (g.ldh == 256 && g.ldt == 64 && c->stream3 && c->ev3 && ((fmask >> FK_GATHER) & 1) && ((fmask >> FK_QUERY) & 1))
+                       ? (hipStream_t)c->stream3 : nullptr;
+  if (sq) fork_arm(c, FK_GATHER);
   RET(tcar_gather_clip_fwd(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream));
+  const bool qside = sq && fork_taken(c, FK_GATHER);       // (the throughput form of the gather carries no flag)
+  if (qside) {
+    RET(fork_go(c, FK_GATHER, (hipStream_t)stream, sq, c->ev3, false));
+    fork_arm(c, FK_QUERY);
+    RET(tcar_query_mlp(&c->d, B, c->click_t, W(c, TCAR_V_Q1_W), W(c, TCAR_V_Q1_B), W(c, TCAR_V_Q2_W), W(c, TCAR_V_Q2_B), c->q1,
+                       c->q, (void*)sq));
+    if (!fork_taken(c, FK_QUERY)) return TCAR_E_LAUNCH;
+  }
   const float* x_c = c->x_icp + g.ldh;
   // pre1, pre2, q1 (modules.py:126-131, 94-96, 138).  With the slab workspace (split-bf16 modes) every (operand pair, 128-deep K
   // chunk) of the two projections is its OWN problem of the grouped launch writing its own slab: 7 + 5 chunks x 32-72 tiles
@@ -254,7 +289,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     // optional HIP events around exactly this launch (kind 3 of ev_start / ev_stop: the largest of the session-side small GEMMs)
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[3 * c->ev_n + ei], (hipStream_t)stream);
     RET(hook(0));
-    RET(small_gemm(c, 0, 6, p, stream));
+    RET(small_gemm(c, 0, qside ? 5 : 6, p, stream));
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[3 * c->ev_n + ei], (hipStream_t)stream);
   } else {
     tcar_gemm_desc_t p[3];
@@ -267,10 +302,12 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
     p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
     RET(hook(0));
-    RET(small_gemm(c, 0, 3, p, stream));
+    RET(small_gemm(c, 0, qside ? 2 : 3, p, stream));
   }
   RET(hook(1));
-  {  // q = tanh(q1 Wq2 + b) (modules.py:139)
+  if (qside) {   // the pools wait for q: a polling kernel on this stream (no event)
+    RET(fork_go(c, FK_QUERY, sq, (hipStream_t)stream, c->ev3, false));
+  } else {       // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
     RET(small_gemm(c, 0, 1, &p, stream));
   }

@@ -82,6 +82,14 @@ inline TcarSignal tcar_take_signal() {
   p = TcarSignal{};
   return s;
 }
+// 16-byte write-through store (sc1): the bytes bypass the write-back state of this XCD's L2, so a consumer behind a completion
+// flag needs no release fence / L2 write-back from the producer (cdna_hip_programming.md Guideline 16, R1).  The compiler does not
+// count this store: drain with an explicit s_waitcnt vmcnt(0) before signalling (tcar_signal_done does).
+__device__ __forceinline__ void st4_sc1(float* p, float4 v) {
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  const f4_t x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+}
 // Every thread of every workgroup calls this as the kernel's last statement (no early returns ahead of it).  The workgroup's
 // stores are drained into its XCD's L2 (vmcnt) before it is counted; NO release fence here — an agent-scope release in every
 // workgroup is an L2 write-back per workgroup (measured: the CE-rescale kernel 24 -> 176 us, and every kernel beside it slower).

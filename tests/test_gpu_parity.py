@@ -561,6 +561,30 @@ def test_time_onehot_plane_and_time_scores(lib, N, H, Ht, B):
     assert np.abs(scores - direct).max() <= 1e-5 * np.abs(direct).max()
 
 
+@pytest.mark.parametrize("B", [1, 8, 77, 512])
+def test_click_query_mlp_in_one_launch(lib, B):
+    """tcar_query_mlp (modules.py:138-139): q1 = relu(click_t Wq1 + b1), q = tanh(q1 Wq2 + b2) in fp32 against fp64 — ragged
+    batch sizes (the workgroup owns eight sessions), other rows of the outputs untouched, unsupported hidden sizes refused."""
+    from tcar_amd._lib import Dims
+    rng = np.random.RandomState(B)
+    d = Dims(1000, 250, 64, 256, 64)
+    click = (rng.standard_normal((B, 128)) * 0.4).astype(np.float32)
+    w1, b1 = (rng.standard_normal((128, 256)) * 0.15).astype(np.float32), (rng.standard_normal(256) * 0.1).astype(np.float32)
+    w2, b2 = (rng.standard_normal((256, 512)) * 0.1).astype(np.float32), (rng.standard_normal(512) * 0.1).astype(np.float32)
+    dv = lambda x: torch.tensor(x).cuda()
+    cd, w1d, b1d, w2d, b2d = dv(click), dv(w1), dv(b1), dv(w2), dv(b2)
+    q1 = torch.full((B + 3, 256), 7.0, device="cuda")
+    q = torch.full((B + 3, 512), 7.0, device="cuda")
+    assert lib.tcar_query_mlp(C.byref(d), B, ptr(cd), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(q1), ptr(q), None) == 0
+    want1 = np.maximum(click.astype(np.float64) @ w1.astype(np.float64) + b1, 0.0)
+    want2 = np.tanh(want1 @ w2.astype(np.float64) + b2)
+    close(q1[:B].cpu().numpy(), want1, name="q1", rtol=1e-5, atol_scale=1e-6)
+    close(q[:B].cpu().numpy(), want2, name="q", rtol=1e-5, atol_scale=1e-6)
+    assert (q1[B:] == 7.0).all() and (q[B:] == 7.0).all()
+    for bad in (Dims(1000, 250, 100, 256, 128), Dims(1000, 300, 64, 320, 64)):
+        assert lib.tcar_query_mlp(C.byref(bad), B, ptr(cd), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(q1), ptr(q), None) != 0
+
+
 def test_split_bf16_planes_kb32_layout(lib):
     rng = np.random.RandomState(1)
     rows, cols = 137, 820
