@@ -213,6 +213,11 @@ def main():
     ap.add_argument("--cpu_steps", type=int, default=20)
     ap.add_argument("--cpu_threads", type=int, default=16)
     ap.add_argument("--no_kernel_timing", action="store_true")
+    ap.add_argument("--stall_ms", type=float, default=0.0,
+                    help="diagnostic (profiling): hold the main stream for this long at the start of the timed loop, so that the host "
+                         "enqueues the timed steps AHEAD of the device — under rocprofv3's kernel trace the host is otherwise the "
+                         "bottleneck and the timeline shows its launch latency, not the device's schedule.  The reported time "
+                         "then includes the stall: use only for timelines")
     ap.add_argument("--dp_mode", default="auto", choices=["auto", "replica", "sharded"],
                     help="multi-GPU exchange: replica = all-reduce of the dense item gradient; sharded = catalog-sharded scoring")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU dry runs)")
@@ -366,6 +371,8 @@ def main():
             ds.plan(sched(args.warmup, args.steps))        # the timed schedule's indices: resident before the clock starts
         sync()
         t0 = time.perf_counter()
+        if args.stall_ms > 0:
+            torch.cuda._sleep(int(args.stall_ms * 1e-3 * 2.0e9))        # (~2 GHz shader clock: the length is approximate)
         if sampler_in_loop:
             for bt in ds.planned(K, cfg["gap_mode"]):
                 eng.train_step(None, bt=bt, **defer)
@@ -472,12 +479,23 @@ def main():
             # not fp32 logits)
             ce_epi = ce_form or (tag != "score_fwd" and args.scoring == "bf16x3-mixed" and n_local == N and os.environ.get("TCAR_FUSED_CE", "1") != "0")
             out_fwd = (2 * b_glob * n_rows + 8 * b_glob * (n_rows // 96)) if ce_epi else 4 * b_glob * n_rows
-            alg_bytes = {"score_fwd": opb * (n_rows * g.ek + b_glob * g.ek) + out_fwd,
+            # one-hot form of the candidate time columns (training steps of the mixed precision, single rank): the GEMM reads the
+            # item | content columns of both operands, ONE 160-column one-hot plane and the two 160-column time-score planes, and
+            # runs 3 MFMAs per product over 2 ldh columns + 2 over 160 (executed / algorithmic flops = (3 * 512 + 2 * 160) / 820)
+            onehot = ce_form and g.ldt <= 128 and os.environ.get("TCAR_ONEHOT_TIME", "1") != "0"
+            in_fwd = (opb * (n_rows * g.ic + b_glob * g.ic) + 2 * n_rows * 160 + 4 * b_glob * 160) if onehot else opb * (n_rows * g.ek + b_glob * g.ek)
+            form = None
+            if onehot and tag == "score_fwd":
+                mult = (3.0 * g.ic + 2.0 * 160) / k_alg
+                form = "one-hot time segment: K = %d columns at 3 MFMAs per product + 160 at 2 (one B plane)" % g.ic
+            alg_bytes = {"score_fwd": in_fwd + out_fwd,
                          "score_dx": opb * (b_glob * n_rows + n_rows * g.ek) + 4 * sk * b_glob * g.ek,
                          "score_dE": opb * (b_glob * n_rows + b_glob * (g.ldh + g.pt)) + 4 * n_local * (g.ldh + g.pt)}[tag]
             gbs = alg_bytes / (avg * 1e-3) / 1e9
             f_mfma, f_hbm = ach * mult / peak, gbs / PEAK_HBM_GBS
             ent = {"kernel": "%s (%s)" % (name, ref[tag]), "tag": tag}
+            if form:
+                ent["form"] = form
             if f_hbm > f_mfma:       # the hi-only gradient GEMMs: a third of the MFMA work, the same fp32 result to write
                 ent.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(f_hbm, 4)})
             else:
