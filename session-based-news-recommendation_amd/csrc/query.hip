@@ -2,7 +2,7 @@
 //     q1 = relu(click_t Wq1 + b1)   [B, 256]      q = tanh(q1 Wq2 + b2)   [B, 512]
 // for the reference's hidden sizes (padded H = 256, time hidden 64: click_t has 128 columns).  As two grouped small GEMMs the two
 // layers are two dependent launches of 32 and 64 workgroups on the chain gather -> q1 -> q -> pools (22 + 30 us inside a step);
-// the work is 0.17 GFLOP.  Here a workgroup of 512 threads owns EIGHT sessions and walks both layers in fp32 FMAs: every
+// the work is 0.17 GFLOP.  Here a workgroup of 512 threads owns a few (QS) sessions and walks both layers in fp32 FMAs: every
 // thread keeps all of its weight loads of a phase in flight at once (16, then 2 x 32 sixteen-byte loads: one memory round trip
 // per phase instead of one per 64-deep GEMM stage), partial sums over the K groups are folded through LDS in a fixed order.
 // The step driver runs it on a side stream beside the input projections (step.hip: session_forward); both outputs are stored
@@ -10,7 +10,7 @@
 #include "tcar_common.h"
 
 namespace {
-constexpr int QS = 8;                       // sessions per workgroup
+constexpr int QS = 4;                       // sessions per workgroup (8: 42 us beside the projections — the FMAs of QS sessions per thread; 4: see DESIGN.md)
 constexpr int CT = 128, H1 = 256, H2 = 512; // click_t columns, q1 columns, q columns
 struct QMlpArgs {
   const float* click; const float* w1; const float* b1; const float* w2; const float* b2;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(512) void query_mlp_kernel(const QMlpArgs a) {
     for (int s = 0; s < QS; ++s) st4(part + (kq * QS + s) * H1 + cg * 4, acc[s]);
   }
   __syncthreads();
-  {   // q1[s][4 cg ..] = relu(b1 + sum over the 8 K groups, in group order)
+  if (t < QS * 64) {   // q1[s][4 cg ..] = relu(b1 + sum over the 8 K groups, in group order)
     const int s = t >> 6;
     float4 v = ld4(a.b1 + cg * 4);
 #pragma unroll
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(512) void query_mlp_kernel(const QMlpArgs a) {
   for (int s = 0; s < QS; ++s) st4(part + (k2 * QS + s) * H2 + c2 * 4, acc2[s]);
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {   // q[s][4 c ..] = tanh(b2 + sum over the 4 K groups)
+  for (int i = 0; i < QS / 4; ++i) {   // q[s][4 c ..] = tanh(b2 + sum over the 4 K groups)
     const int idx = t + i * 512, s = idx >> 7, c = idx & 127;
     float4 v = ld4(a.b2 + c * 4);
 #pragma unroll

@@ -20,7 +20,7 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 1},
-    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 240},
+    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 242},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -365,7 +365,9 @@ int zero_arena(const tcar_ctx_t* c, hipStream_t s) {
 // dE fork — and joining the three streams through ONE wait at the end of the step measured SLOWER, 0.635 vs 0.613 ms per step:
 // dE then starts behind the negative term and the final join becomes two hops.)
 int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
-  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0]));    // (armed by forward_impl in front of the logits GEMM)
+  // (armed by forward_impl in front of the logits GEMM; the consumers read nothing that GEMM writes — the arena, attout, E —
+  // so the polling kernel needs no write-back)
+  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], false));
   RET(zero_arena(c, sz));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
@@ -436,7 +438,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     if (rest_stage == 1 && stage == 0) fork_arm(c, FK_PROJ);        // in front of the projection launch
     if (stage != rest_stage) return TCAR_OK;
     // late fork: the HBM-bound rest pass starts only now, so the launches before this point ran without it
-    RET(fork_go(c, FK_PROJ, s1, s2, c->ev[0]));
+    RET(fork_go(c, FK_PROJ, s1, s2, c->ev[0], false));      // (the rest pass reads nothing the projections write: timing only)
     return launch_rest();
   }));
   // sort index of the item rows (feed only): on the aux stream BEHIND the rest pass — the logits GEMM does not wait for it (ev[1]
