@@ -410,7 +410,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
                                c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
                                c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT,
                                c->adam_bitmap, stream));
-      RET(fork_go(c, FK_EARLY, s1, s2, c->ev[0]));
+      RET(fork_go(c, FK_EARLY, s1, s2, c->ev[0], false));      // (the flagged launch stores the variables write-through)
       RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, (void*)s2));
       // the rest pass is forked BEHIND the projection launch: gather and projections run without the 376-MB stream beside
       // them (21 instead of 40 us for the projections), the pass still ends before the output transforms do.  Measured over
@@ -599,7 +599,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     RET(tcar_ce_finish(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream));
   else if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
-  if (s2) RET(fork_go(c, FK_SOFTMAX, st, s2, c->ev[2]));
+  if (s2) RET(fork_go(c, FK_SOFTMAX, st, s2, c->ev[2], false));      // (the flagged CE-rescale launch stores the plane write-through)
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // optional HIP events around exactly the dE and dX launches (slot chosen by the forward pass; kind 1 = dX, 2 = dE)
@@ -714,7 +714,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
     RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));
-    if (hipStreamWaitEvent(s3, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
+    // (with the negative rows on this stream it already waited for dE — ev[4], recorded on the aux stream BEHIND the arena zero —
+    // and a wait for a completed event still costs the stream a ~6-us barrier packet)
+    if (!neg_s3 && hipStreamWaitEvent(s3, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   } else if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   // Order-fixed small tables (sorted mode, which implies an aux stream): they — and the click-query input gradient, which only
