@@ -158,7 +158,7 @@ __device__ __forceinline__ void arena_adam_block(int seg, int chunk, float* __re
                                                  float* __restrict__ m, float* __restrict__ v, const SegArgs& a,
                                                  const float* __restrict__ sqn_dense, const float* __restrict__ sqn_pieces,
                                                  const int32_t* __restrict__ use_dense, float clip, float lr_t, float b1,
-                                                 float b2, float eps, bool wt = false) {
+                                                 float b2, float eps) {
   const long off = a.s.off[seg];
   const long len = a.s.len[seg];
   const long base = (long)chunk * 4096;
@@ -171,10 +171,7 @@ __device__ __forceinline__ void arena_adam_block(int seg, int chunk, float* __re
       const long p = off + e;
       float4 ww = ld4(w + p), mm = ld4(m + p), vv = ld4(v + p);
       adam4(ww, ld4(g + p), mm, vv, sc, lr_t, b1, b2, eps);
-      // wt: the variables leave write-through — a side stream behind this launch's completion flag reads them (the time tables)
-      if (wt) st4_sc1(w + p, ww);
-      else st4(w + p, ww);
-      st4(m + p, mm); st4(v + p, vv);
+      st4(w + p, ww); st4(m + p, mm); st4(v + p, vv);
     }
   }
 }
@@ -263,12 +260,12 @@ struct AdamEarly {
   AdamAll p;
   const int32_t* ids; long n_ids; uint32_t* bitmap; int n_rowblk;
 };
-__device__ __forceinline__ void clip_adam_early_body(const AdamEarly& e, const SegArgs& a, bool wt) {
+__device__ __forceinline__ void clip_adam_early_body(const AdamEarly& e, const SegArgs& a) {
   const AdamAll& p = e.p;
   if ((int)blockIdx.x >= e.n_rowblk) {
     const int idx = blockIdx.x - e.n_rowblk;
     arena_adam_block(idx / p.gx, idx % p.gx, p.w, p.g, p.m, p.v, a, p.sqn_dense, p.sqn_pieces, p.use_dense, p.clip, p.lr_t,
-                     p.b1, p.b2, p.eps, wt);
+                     p.b1, p.b2, p.eps);
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -298,9 +295,8 @@ __device__ __forceinline__ void clip_adam_early_body(const AdamEarly& e, const S
     }
   }
 }
-__global__ __launch_bounds__(256) void clip_adam_early_kernel(const AdamEarly e, const SegArgs a, const TcarSignal sig) {
-  clip_adam_early_body(e, a, sig.cnt != nullptr);
-  tcar_signal_done(sig);        // the step driver forks the aux stream behind this launch (candidate-side time vectors)
+__global__ __launch_bounds__(256) void clip_adam_early_kernel(const AdamEarly e, const SegArgs a) {
+  clip_adam_early_body(e, a);
 }
 template <bool NT>
 __global__ __launch_bounds__(256) void clip_adam_rest_kernel(const AdamAll p, const uint32_t* __restrict__ skip) {
@@ -448,7 +444,7 @@ extern "C" int tcar_clip_adam_early(float* w, const float* g, float* m, float* v
   a.s = *segs;
   const int grid = e.n_rowblk + e.p.gx * segs->nseg;
   if (grid <= 0) return TCAR_OK;
-  TCAR_LAUNCH(clip_adam_early_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, e, a, tcar_take_signal());
+  TCAR_LAUNCH(clip_adam_early_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, e, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

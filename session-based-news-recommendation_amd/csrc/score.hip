@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void ce_combine_kernel(int B, int ngroups, con
 template <int GW>
 __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
                                                 const float* __restrict__ rowstat, const int32_t* __restrict__ label,
-                                                __bf16* __restrict__ plane, long nunits, bool wt) {
+                                                __bf16* __restrict__ plane, long nunits) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nunits) return;
   const long blk = i >> 7;
@@ -218,7 +218,7 @@ __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngro
   if (row >= B) {
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { if (wt) st16_sc1(p + q, z); else p[q] = z; }
+    for (int q = 0; q < 4; ++q) p[q] = z;
     return;
   }
   uint4 v[4];
@@ -244,16 +244,14 @@ __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngro
       const __bf16 bl = (__bf16)lo, bh = (__bf16)hi;
       w[j] = (unsigned)__builtin_bit_cast(unsigned short, bl) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
     }
-    if (wt) st16_sc1(p + q, make_uint4(w[0], w[1], w[2], w[3]));      // (the dE GEMM of a side stream behind the completion flag reads it)
-    else p[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    p[q] = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 template <int GW>
 __global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
                                                          const float* __restrict__ rowstat, const int32_t* __restrict__ label,
-                                                         __bf16* __restrict__ plane, long nunits, const TcarSignal sig) {
-  ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits, sig.cnt != nullptr);
-  tcar_signal_done(sig);        // the step driver forks the aux stream (dE) behind this launch
+                                                         __bf16* __restrict__ plane, long nunits) {
+  ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits);
 }
 
 // ---- negative-feedback term (model_combine.py:142-143) ---------------------------------------------------
@@ -706,11 +704,10 @@ extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const 
   const int in32 = (int)(inner >> 5);
   const long nunits = (((long)B + 127) >> 7) * in32 * 128;
   const unsigned grid = (unsigned)((nunits + 255) / 256);
-  const TcarSignal sig = tcar_take_signal();
   if (group_width == 96)
-    TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits, sig);
+    TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits);
   else
-    TCAR_LAUNCH(ce_rescale_kernel<64>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits, sig);
+    TCAR_LAUNCH(ce_rescale_kernel<64>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

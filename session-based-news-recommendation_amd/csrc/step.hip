@@ -167,7 +167,10 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
     __hip_atomic_store(cover, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
-enum { FK_EARLY = 0, FK_PROJ = 1, FK_LOGITS = 2, FK_SOFTMAX = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7 };
+// slots (bits of TCAR_FLAG_FORK).  The other forks of the step — early Adam -> candidate refresh, logits -> arena zero, softmax
+// -> dE — stay events: released by a flag their consumers start a few us earlier, beside the critical chain, and the step is
+// slower (measured per fork, also with write-through producers and with start-of-kernel flags: DESIGN.md §4)
+enum { FK_PROJ = 1, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7 };
 struct Fork { TcarSignal sig; bool armed; const tcar_ctx_t* ctx; };
 inline Fork& fork_slot(int slot) {
   thread_local Fork forks[TCAR_SIG_SLOTS] = {};
@@ -365,9 +368,8 @@ int zero_arena(const tcar_ctx_t* c, hipStream_t s) {
 // dE fork — and joining the three streams through ONE wait at the end of the step measured SLOWER, 0.635 vs 0.613 ms per step:
 // dE then starts behind the negative term and the final join becomes two hops.)
 int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
-  // (armed by forward_impl in front of the logits GEMM; the consumers read nothing that GEMM writes — the arena, attout, E —
-  // so the polling kernel needs no write-back)
-  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], false));
+  if (sz != st && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sz, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+    return TCAR_E_LAUNCH;
   RET(zero_arena(c, sz));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
@@ -405,12 +407,12 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       // kernel, with the time refresh on the third stream: the 376-MB pass then runs beside the gather and the projections
       // as well and slows them by more than it gains — 0.626 vs 0.618 ms per step)
       const float* pieces = c->Gx + c->arena_n;
-      fork_arm(c, FK_EARLY);
       RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
                                c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
                                c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT,
                                c->adam_bitmap, stream));
-      RET(fork_go(c, FK_EARLY, s1, s2, c->ev[0], false));      // (the flagged launch stores the variables write-through)
+      if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
+        return TCAR_E_LAUNCH;
       RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, (void*)s2));
       // the rest pass is forked BEHIND the projection launch: gather and projections run without the 376-MB stream beside
       // them (21 instead of 40 us for the projections), the pass still ends before the output transforms do.  Measured over
@@ -468,11 +470,9 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
   };
   int rc;
-  fork_disarm(FK_LOGITS);
   if (c->scoring) {
     // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
-    if (ce_epi && s2) fork_arm(c, FK_LOGITS);       // backward_prologue forks the aux stream behind this launch
     if (ce_epi) {
       // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes
       // dlogits, plus per-group (max, sum) — no [B, N] fp32 logits; backward_impl finishes with tcar_ce_finish
@@ -594,12 +594,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   // hi-only backward (bf16x3-mixed, bf16): the lo plane of dlogits is never read — and not written
   CeWs cw;
-  if (s2) fork_arm(c, FK_SOFTMAX);         // (taken by the CE-rescale launch; the other softmax kernels leave it: event)
   if (ce_epilogue && fused_ce(c, B, &cw))   // the forward pass of THIS step ran the softmax epilogue (same predicate)
     RET(tcar_ce_finish(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream));
   else if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
-  if (s2) RET(fork_go(c, FK_SOFTMAX, st, s2, c->ev[2], false));      // (the flagged CE-rescale launch stores the plane write-through)
+  if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
+    return TCAR_E_LAUNCH;
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // optional HIP events around exactly the dE and dX launches (slot chosen by the forward pass; kind 1 = dX, 2 = dE)

@@ -90,11 +90,6 @@ __device__ __forceinline__ void st4_sc1(float* p, float4 v) {
   const f4_t x = {v.x, v.y, v.z, v.w};
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
 }
-__device__ __forceinline__ void st16_sc1(void* p, uint4 v) {
-  typedef unsigned u4_t __attribute__((ext_vector_type(4)));
-  const u4_t x = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
-}
 // Every thread of every workgroup calls this as the kernel's last statement (no early returns ahead of it).  The workgroup's
 // stores are drained into its XCD's L2 (vmcnt) before it is counted; NO release fence here — an agent-scope release in every
 // workgroup is an L2 write-back per workgroup (measured: the CE-rescale kernel 24 -> 176 us, and every kernel beside it slower).
