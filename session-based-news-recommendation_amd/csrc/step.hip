@@ -270,6 +270,12 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
                        c->q, (void*)sq));
     if (!fork_taken(c, FK_QUERY)) return TCAR_E_LAUNCH;
   }
+  // without the side stream (multi-rank engines, contexts without the flag words): the same ONE launch on this stream in
+  // place of the two small GEMMs of the split-bf16 modes
+  const bool qfused = qside || (g.ldh == 256 && g.ldt == 64 && c->scoring != 0);
+  if (qfused && !qside)
+    RET(tcar_query_mlp(&c->d, B, c->click_t, W(c, TCAR_V_Q1_W), W(c, TCAR_V_Q1_B), W(c, TCAR_V_Q2_W), W(c, TCAR_V_Q2_B), c->q1,
+                       c->q, stream));
   const float* x_c = c->x_icp + g.ldh;
   // pre1, pre2, q1 (modules.py:126-131, 94-96, 138).  With the slab workspace (split-bf16 modes) every (operand pair, 128-deep K
   // chunk) of the two projections is its OWN problem of the grouped launch writing its own slab: 7 + 5 chunks x 32-72 tiles
@@ -292,7 +298,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     // optional HIP events around exactly this launch (kind 3 of ev_start / ev_stop: the largest of the session-side small GEMMs)
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[3 * c->ev_n + ei], (hipStream_t)stream);
     RET(hook(0));
-    RET(small_gemm(c, 0, qside ? 5 : 6, p, stream));
+    RET(small_gemm(c, 0, qfused ? 5 : 6, p, stream));
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[3 * c->ev_n + ei], (hipStream_t)stream);
   } else {
     tcar_gemm_desc_t p[3];
@@ -305,12 +311,12 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
     p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
     RET(hook(0));
-    RET(small_gemm(c, 0, qside ? 2 : 3, p, stream));
+    RET(small_gemm(c, 0, qfused ? 2 : 3, p, stream));
   }
   RET(hook(1));
   if (qside) {   // the pools wait for q: a polling kernel on this stream (no event)
     RET(fork_go(c, FK_QUERY, sq, (hipStream_t)stream, c->ev3, false));
-  } else {       // q = tanh(q1 Wq2 + b) (modules.py:139)
+  } else if (!qfused) {       // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
     RET(small_gemm(c, 0, 1, &p, stream));
   }

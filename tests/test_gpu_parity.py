@@ -585,6 +585,27 @@ def test_click_query_mlp_in_one_launch(lib, B):
         assert lib.tcar_query_mlp(C.byref(bad), B, ptr(cd), ptr(w1d), ptr(b1d), ptr(w2d), ptr(b2d), ptr(q1), ptr(q), None) != 0
 
 
+def test_flag_fork_time_out_is_reported():
+    """A polling kernel of a flag fork that gives up counts in tcar_ctx_t.sig_dev[32]; engine.check_forks() (export, epoch end,
+    bench) must raise on it instead of letting a consumer that ran ahead of its producer go unnoticed — and stay silent
+    after ordinary steps."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 2000, 250, 64, 32, 2, 4
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=3)
+    eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+    for _ in range(3):
+        eng.train_step(batch, defer_update=True)
+    eng.flush()
+    eng.check_forks()                                   # flag forks ran (default mask), none timed out
+    assert eng._sig is not None and int(eng._sig_epoch[0]) > 0
+    eng._sig[32] = 2                                    # what two expired polls leave behind
+    with pytest.raises(RuntimeError, match="flag-fork"):
+        eng.check_forks()
+    with pytest.raises(RuntimeError, match="flag-fork"):
+        eng.export_params()
+
+
 def test_split_bf16_planes_kb32_layout(lib):
     rng = np.random.RandomState(1)
     rows, cols = 137, 820
