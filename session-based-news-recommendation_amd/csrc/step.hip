@@ -1092,6 +1092,12 @@ extern "C" int tcar_graph_probe(const tcar_ctx_t* c, const tcar_batch_t* bt, flo
   RET(check_ctx(c, bt));
   if (!ms_out || iters <= 0) return TCAR_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  // a replayed graph would poll the epochs of the captured step (long satisfied): capture the event forks only
+  struct NoFlags {
+    int prev;
+    NoFlags() : prev(tuning_storage().flag_fork) { tuning_storage().flag_fork = 0; }
+    ~NoFlags() { tuning_storage().flag_fork = prev; }
+  } no_flags;
   RET(tcar_train_step(c, bt, 1, lr_t, stream));             // eager once: first-use attribute calls happen outside the capture
   if (hipStreamSynchronize(st) != hipSuccess) return TCAR_E_LAUNCH;
   hipGraph_t graph = nullptr;
