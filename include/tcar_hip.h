@@ -544,7 +544,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
 int tcar_set_tuning(const char* name /*host*/, int value);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 19
+#define TCAR_ABI_VERSION 20
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -633,6 +633,11 @@ typedef struct {
    * The engine must raise when sig_dev[32] != 0 (a poll gave up: the streams do not run concurrently). */
   uint32_t* sig_dev; uint32_t* sig_epoch /*host*/;
 } tcar_ctx_t;
+
+/* Probe before setting tcar_ctx_t.sig_dev: does a polling kernel on `side_stream` run beside a kernel enqueued BEHIND it on
+ * `main_stream`?  *concurrent = 0 (a tool serialises kernels, or the two streams share a hardware queue): leave sig_dev NULL.
+ * Synchronises both streams; costs one 20-ms time-out when the answer is no. */
+int tcar_flag_fork_selftest(uint32_t* sig_dev, void* main_stream, void* side_stream, int32_t* concurrent);
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */
 int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream);

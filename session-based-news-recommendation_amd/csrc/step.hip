@@ -142,13 +142,14 @@ constexpr int TCAR_SIG_SLOTS = 16, TCAR_SIG_ERR = 2 * TCAR_SIG_SLOTS, TCAR_SIG_P
 constexpr long long POLL_TICKS = 100000000LL;      // 1 s of the 100-MHz wall clock
 // FLUSH = false (one workgroup): the producer stored everything the consumer reads write-through (sc1) — nothing to write back.
 template <bool FLUSH>
-__global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, unsigned* cover) {
+__global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, unsigned* cover,
+                                                       long long ticks = POLL_TICKS) {
   if (threadIdx.x != 0) return;
   const long long t0 = wall_clock64();
   bool ok = true;
   while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
     __builtin_amdgcn_s_sleep(2);
-    if (wall_clock64() - t0 > POLL_TICKS) { ok = false; break; }
+    if (wall_clock64() - t0 > ticks) { ok = false; break; }
   }
   if (!FLUSH) {
     if (!ok) atomicAdd(err, 1u);
@@ -216,6 +217,39 @@ inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t 
   return TCAR_OK;
 }
 
+__global__ void set_flag_kernel(unsigned* flag, unsigned epoch) {
+  if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+// Do a polling kernel on `side` and a kernel enqueued BEHIND it on `main` run concurrently?  They do not when a tool serialises
+// kernel execution (counter collection, AMD_SERIALIZE_KERNEL) or when both streams map to one hardware queue: every flag fork
+// would then sit out its time-out.  One probe with a 20-ms time-out; *concurrent = 0 means "leave sig_dev NULL" (events).
+// Synchronises both streams; the words of slot 15 and the error count are left as they were found.
+extern "C" int tcar_flag_fork_selftest(uint32_t* sig_dev, void* main_stream, void* side_stream, int32_t* concurrent) {
+  if (!sig_dev || !side_stream || !concurrent || main_stream == side_stream) return TCAR_E_ARG;
+  hipStream_t sm = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+  unsigned before[2] = {0, 0}, after = 0;
+  if (hipStreamSynchronize(sm) != hipSuccess || hipStreamSynchronize(ss) != hipSuccess) return TCAR_E_LAUNCH;
+  if (hipMemcpy(&before[0], sig_dev + TCAR_SIG_ERR, 4, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(&before[1], sig_dev + TCAR_SIG_SLOTS + 15, 4, hipMemcpyDeviceToHost) != hipSuccess)
+    return TCAR_E_LAUNCH;
+  const unsigned epoch = before[1] + 1u;
+  TCAR_LAUNCH(poll_flag_kernel<false>, dim3(1), dim3(64), 0, ss, (const unsigned*)(sig_dev + TCAR_SIG_SLOTS + 15), epoch,
+              sig_dev + TCAR_SIG_ERR, sig_dev + TCAR_SIG_POLL + 15, 2000000LL);
+  TCAR_CHECK_LAUNCH();
+  TCAR_LAUNCH(set_flag_kernel, dim3(1), dim3(64), 0, sm, sig_dev + TCAR_SIG_SLOTS + 15, epoch);
+  TCAR_CHECK_LAUNCH();
+  if (hipStreamSynchronize(sm) != hipSuccess || hipStreamSynchronize(ss) != hipSuccess) return TCAR_E_LAUNCH;
+  if (hipMemcpy(&after, sig_dev + TCAR_SIG_ERR, 4, hipMemcpyDeviceToHost) != hipSuccess) return TCAR_E_LAUNCH;
+  *concurrent = (after == before[0]) ? 1 : 0;
+  if (hipMemcpy(sig_dev + TCAR_SIG_ERR, &before[0], 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(sig_dev + TCAR_SIG_SLOTS + 15, &before[1], 4, hipMemcpyHostToDevice) != hipSuccess)
+    return TCAR_E_LAUNCH;
+  return TCAR_OK;
+}
+
+namespace {
 int check_ctx(const tcar_ctx_t* c, const tcar_batch_t* bt) {
   if (!c || !bt || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   if (!c->E || !c->W || !c->Gx || !c->M || !c->V || !c->big || !c->Mi || !c->Vi) return TCAR_E_ARG;

@@ -276,6 +276,13 @@ class TcarEngine:
         return W
 
     # ------------------------------------------------------------------------------------- checkpoint state
+    def _probe_flag_forks(self) -> bool:
+        """tcar_flag_fork_selftest: a polling kernel on the aux stream and a kernel enqueued behind it on the main stream"""
+        ok = C.c_int32(0)
+        check(self.lib.tcar_flag_fork_selftest(self._sig.data_ptr(), self._stream(), self._aux.cuda_stream, C.byref(ok)),
+              "tcar_flag_fork_selftest")
+        return bool(ok.value)
+
     def check_forks(self):
         """Raise if a polling kernel of a flag fork (tcar_ctx_t.sig_dev) ever gave up waiting: the side streams did not run
         beside the main stream (kernels serialised by a profiler's counter collection, or streams sharing one hardware queue),
@@ -827,7 +834,15 @@ class TcarEngine:
                 if not hasattr(self, "_sig"):
                     self._sig = torch.zeros(80, dtype=torch.int32, device=self.dev)
                     self._sig_epoch = (C.c_uint32 * 1)(0)
-                c.sig_dev, c.sig_epoch = self._sig.data_ptr(), C.cast(self._sig_epoch, C.c_void_p)
+                    # one probe: do the side streams run BESIDE the main stream here?  (Not under a counter-collecting
+                    # profiler or with serialised kernels: every poll would sit out its time-out — events then.)
+                    if not self._probe_flag_forks():
+                        import warnings
+                        warnings.warn("tcar: kernels of different streams do not run concurrently here (profiler counter "
+                                      "collection / serialised kernels / shared hardware queue): flag forks off, events instead")
+                        self._sig = None
+                if self._sig is not None:
+                    c.sig_dev, c.sig_epoch = self._sig.data_ptr(), C.cast(self._sig_epoch, C.c_void_p)
         if self._ev is not None:
             c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
             c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)

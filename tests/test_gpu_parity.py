@@ -606,6 +606,32 @@ def test_flag_fork_time_out_is_reported():
         eng.export_params()
 
 
+def test_flag_forks_fall_back_to_events_when_streams_do_not_overlap(monkeypatch):
+    """The engine probes once whether its side streams run beside the main stream (tcar_flag_fork_selftest: true on a plain
+    GPU box, and it leaves the flag words as it found them).  When the probe says no — counter-collecting profiler,
+    serialised kernels — the context gets no flag words, the step forks with events and computes the same step."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 3000, 250, 64, 64, 3, 5
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=11)
+    a = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+    la = [a.train_step(batch, defer_update=True).cpu().numpy() for _ in range(3)]
+    a.flush()
+    assert a._sig is not None and a._probe_flag_forks() and int(a._sig[32]) == 0
+    monkeypatch.setattr(TcarEngine, "_probe_flag_forks", lambda self: False)
+    with pytest.warns(UserWarning, match="flag forks off"):
+        b = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+        lb = [b.train_step(batch, defer_update=True).cpu().numpy() for _ in range(3)]
+    b.flush()
+    assert b._sig is None
+    b.check_forks()
+    for x, y in zip(la, lb):
+        close(x, y, name="loss", rtol=1e-5)        # (the click-query MLP runs the same fused kernel on either path)
+    pa, pb = a.export_params(), b.export_params()
+    for k in pa:
+        assert np.abs(pa[k] - pb[k]).max() <= 1e-5 * np.abs(pa[k]).max() + 1e-7, k
+
+
 def test_split_bf16_planes_kb32_layout(lib):
     rng = np.random.RandomState(1)
     rows, cols = 137, 820
