@@ -1,5 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag_fork or deferred or (step_matches_oracle and mixed)" 2>&1 | tail -4
-AMD_SERIALIZE_KERNEL=3 timeout 300 python bench.py --steps 50 --warmup 5 --no_cpu_baseline --no_e2e --no_kernel_timing 2>&1 | tail -3 | cut -c1-300
-timeout 300 bash tools/ab.sh 2 "" 2>&1 | tail -2
+mkdir -p gpurun_out
+TCAR_FLAG_FORK=250 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q -m gpu -k "step_matches_oracle or deferred or same_step_twice or full_size or negative_modes or bit_identical" 2>&1 | tail -3
+timeout 1500 bash tools/ab.sh 5 "" "TCAR_FLAG_FORK=250" 2>&1 | tee gpurun_out/r3r_ab12.txt
