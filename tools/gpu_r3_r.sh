@@ -1,4 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p gpurun_out
-timeout 900 bash tools/ab.sh 5 "" "TCAR_DBG_RD=0" 2>&1 | tee gpurun_out/r3r_ab13.txt
+for i in 1 2 3; do
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag_and_event or flag_forks_fall_back" 2>&1 | tail -3
+done
