@@ -974,16 +974,19 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
 
 // per-table norm pieces from the per-row ones, rows in order; one add per slot (the candidate side adds its one)
 __global__ __launch_bounds__(64) void small_norm_fold_kernel(const float* __restrict__ rowq, int T, float* __restrict__ sqn, int slot_pos,
-                                                             int s0, int s1, int s2, int s3, int s4, int slot_dur) {
+                                                             int s0, int s1, int s2, int s3, int s4, int slot_dur,
+                                                             const TcarSignal sig) {
   const int k = threadIdx.x;          // 0: position, 1..5: month..minute, 6: dwell (+ its out-of-range bucket)
-  if (k > 6) return;
-  int lo, n, slot;
-  if (k == 0) { lo = 0; n = T; slot = slot_pos; }
-  else if (k <= 5) { lo = TCAR_POS_VOCAB + time_rowoff(k - 1); n = time_vocab(k - 1); slot = k == 1 ? s0 : k == 2 ? s1 : k == 3 ? s2 : k == 4 ? s3 : s4; }
-  else { lo = TCAR_POS_VOCAB + 139; n = TCAR_DUR_VOCAB + 1; slot = slot_dur; }
-  float s = 0.f;
-  for (int i = 0; i < n; ++i) s += rowq[lo + i];
-  if (s != 0.f) atomicAdd(sqn + slot, s);
+  if (k <= 6) {
+    int lo, n, slot;
+    if (k == 0) { lo = 0; n = T; slot = slot_pos; }
+    else if (k <= 5) { lo = TCAR_POS_VOCAB + time_rowoff(k - 1); n = time_vocab(k - 1); slot = k == 1 ? s0 : k == 2 ? s1 : k == 3 ? s2 : k == 4 ? s3 : s4; }
+    else { lo = TCAR_POS_VOCAB + 139; n = TCAR_DUR_VOCAB + 1; slot = slot_dur; }
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += rowq[lo + i];
+    if (s != 0.f) atomicAdd(sqn + slot, s);
+  }
+  tcar_signal_done(sig);        // (the fused step joins the aux stream into the main one behind this launch)
 }
 
 // packed form: the id rides behind its row (row stride ld), ids shifted by id0 (catalog shards)
@@ -1203,7 +1206,7 @@ extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables
   else TCAR_LAUNCH(small_tables_bwd_det_kernel<8>, dim3(rows), dim3(1024), 0, st, a);
   TCAR_CHECK_LAUNCH();
   TCAR_LAUNCH(small_norm_fold_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, bt->T, g->sqn, g->slot_pos, g->slot_time[0],
-              g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur);
+              g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur, tcar_take_signal());
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

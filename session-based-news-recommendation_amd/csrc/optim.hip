@@ -55,7 +55,8 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
 // Small segments (the dense weights: <= 262,144 floats each): ONE workgroup of 1024 threads per segment, fixed summation
 // order (thread-strided partial sums, xor tree inside the wave, the 16 waves in order).  The result depends on the data
 // only, so ranks that hold identical gradients compute identical norms — no broadcast needed to keep them in step.
-__global__ __launch_bounds__(1024) void sqnorm_seg_kernel(const float* __restrict__ g, const SegArgs a, float* __restrict__ out) {
+__global__ __launch_bounds__(1024) void sqnorm_seg_kernel(const float* __restrict__ g, const SegArgs a, float* __restrict__ out,
+                                                          const TcarSignal sig) {
   __shared__ float sh[16];
   const int seg = blockIdx.x;
   const long off = a.s.off[seg];
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(1024) void sqnorm_seg_kernel(const float* __restric
     for (int w = 0; w < 16; ++w) t += sh[w];
     atomicAdd(out + a.s.slot[seg], t);                  // one add per segment
   }
+  tcar_signal_done(sig);        // (the fused step joins the third stream into the main one behind this launch)
 }
 
 // ---- split-K slabs folded in split order: dst[e] += sum_k slabs[k * stride + e] ---------------------------------------
@@ -333,7 +335,7 @@ extern "C" int tcar_sqnorm(const float* g, const tcar_segments_t* segs, float* s
   long longest = 0;
   for (int i = 0; i < segs->nseg; ++i) longest = segs->len[i] > longest ? segs->len[i] : longest;
   if (longest <= 262144)
-    TCAR_LAUNCH(sqnorm_seg_kernel, dim3(segs->nseg), dim3(1024), 0, (hipStream_t)stream, g, a, sqn_dense);
+    TCAR_LAUNCH(sqnorm_seg_kernel, dim3(segs->nseg), dim3(1024), 0, (hipStream_t)stream, g, a, sqn_dense, tcar_take_signal());
   else
     TCAR_LAUNCH(sqnorm_kernel, dim3(sqnorm_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
   TCAR_CHECK_LAUNCH();

@@ -20,7 +20,7 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 1},
-    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 242},
+    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 247},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -143,10 +143,17 @@ constexpr long long POLL_TICKS = 100000000LL;      // 1 s of the 100-MHz wall cl
 // FLUSH = false (one workgroup): the producer stored everything the consumer reads write-through (sc1) — nothing to write back.
 template <bool FLUSH>
 __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, unsigned* cover,
-                                                       long long ticks = POLL_TICKS) {
+                                                       long long ticks = POLL_TICKS, const unsigned* flag2 = nullptr,
+                                                       unsigned epoch2 = 0) {
   if (threadIdx.x != 0) return;
   const long long t0 = wall_clock64();
   bool ok = true;
+  if (flag2) {                        // a join of two streams: the second flag first, the usual loop below for the first
+    while ((int)(__hip_atomic_load(flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch2) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > ticks) { ok = false; break; }
+    }
+  }
   while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
     __builtin_amdgcn_s_sleep(2);
     if (wall_clock64() - t0 > ticks) { ok = false; break; }
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
 // slots (bits of TCAR_FLAG_FORK).  The other forks of the step — early Adam -> candidate refresh, logits -> arena zero, softmax
 // -> dE — stay events: released by a flag their consumers start a few us earlier, beside the critical chain, and the step is
 // slower (measured per fork, also with write-through producers and with start-of-kernel flags: DESIGN.md §4)
-enum { FK_PROJ = 1, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7 };
+enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7 };
 struct Fork { TcarSignal sig; bool armed; const tcar_ctx_t* ctx; };
 inline Fork& fork_slot(int slot) {
   thread_local Fork forks[TCAR_SIG_SLOTS] = {};
@@ -766,7 +773,15 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
+  // The step's LAST join (aux + third stream into the main one, in front of the next update): two event waits cost the main
+  // stream two barrier packets behind whichever chain ends last (16-20 us); with flag forks the last launch of either side
+  // stream publishes a flag and ONE flushing poll on the main stream waits for both.
+  const int tmask = tcar_tuning().flag_fork;
+  const bool tail_flags = s3 && fuse_finish && det_small && ((tmask >> FK_TAIL2) & 1) && ((tmask >> FK_TAIL3) & 1);
+  bool tail3 = false, tail2 = false;
+  if (tail_flags) fork_arm(c, FK_TAIL3);
   if (fuse_finish && s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, sW));
+  if (tail_flags) tail3 = fork_taken(c, FK_TAIL3);
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
@@ -791,7 +806,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
     RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5]));
+    if (tail3) fork_arm(c, FK_TAIL2);
     RET(tcar_small_tables_bwd_det(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2));
+    if (tail3) tail2 = fork_taken(c, FK_TAIL2);
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
   if (split_finish) {   // Gi is complete once dE has landed: negative rows (+ loss), then its norm BEFORE any row scatter (S5)
@@ -834,8 +851,16 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
     }
   }
-  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
-  if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
+  if (tail2 && tail3) {
+    const Fork& f2 = fork_slot(FK_TAIL2);
+    const Fork& f3 = fork_slot(FK_TAIL3);
+    TCAR_LAUNCH(poll_flag_kernel<true>, dim3(8), dim3(64), 0, st, (const unsigned*)f2.sig.flag, f2.sig.epoch, c->sig_dev + TCAR_SIG_ERR,
+                c->sig_dev + TCAR_SIG_POLL + FK_TAIL2, POLL_TICKS, (const unsigned*)f3.sig.flag, f3.sig.epoch);
+    TCAR_CHECK_LAUNCH();
+  } else {
+    if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
+    if (s3 && hipStreamWaitEvent(st, (hipEvent_t)c->ev3, 0) != hipSuccess) return TCAR_E_LAUNCH;       // weight gradients are in
+  }
   if (fuse_finish && !s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, stream));
   return TCAR_OK;
 }
