@@ -1,4 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
-for i in 1 2 3; do timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag_and_event or flag_forks_fall_back or same_step_twice" 2>&1 | tail -1; done
+mkdir -p gpurun_out
+TCAR_FLAG_FORK=2039 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag or same_step_twice or deferred or (step_matches_oracle and mixed)" 2>&1 | tail -2
+timeout 1700 bash tools/ab.sh 4 "" "TCAR_FLAG_FORK=503" "TCAR_FLAG_FORK=759" "TCAR_FLAG_FORK=1271" "TCAR_FLAG_FORK=2039" 2>&1 | tee gpurun_out/r3r_ab15.txt
