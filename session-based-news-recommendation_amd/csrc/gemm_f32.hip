@@ -441,6 +441,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the ring's trailing (masked) loads, before compiler-counted accesses
   float* Cs = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
+  const bool wt = ga.sig.cnt != nullptr;
   const int col = n0 + wn * 32 + (lane & 31);
   float csum = 0.f;
   if (col < g.N) {
@@ -466,7 +467,10 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
             csum += v;
           }
           if (g.beta) v += *p;
-          *p = v;
+          // a launch that carries a completion flag stores its result write-through (sc1): the consumer behind the flag needs no
+          // L2 write-back then (tcar_common.h)
+          if (wt) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *p = v;
           if (g.plane_hi) {
             const __bf16 h = (__bf16)v, l = (__bf16)(v - (float)h);
             const long o = kb32_off(row, gcol, g.plane_in32);

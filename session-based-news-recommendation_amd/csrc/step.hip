@@ -760,7 +760,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   hipStream_t s3 = (s2 && fuse_finish && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
-    RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));
+    RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0], false));        // (flagged small-GEMM launches store write-through)        // (flagged small-GEMM launches store write-through)
     // (with the negative rows on this stream it already waited for dE — ev[4], recorded on the aux stream BEHIND the arena zero —
     // and a wait for a completed event still costs the stream a ~6-us barrier packet)
     if (!neg_s3 && hipStreamWaitEvent(s3, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
@@ -805,7 +805,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5]));
+    RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5], false));
     if (tail3) fork_arm(c, FK_TAIL2);
     RET(tcar_small_tables_bwd_det(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2));
     if (tail3) tail2 = fork_taken(c, FK_TAIL2);

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-TCAR_FLAG_FORK=2039 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag or same_step_twice or deferred or (step_matches_oracle and mixed)" 2>&1 | tail -2
-timeout 1700 bash tools/ab.sh 4 "" "TCAR_FLAG_FORK=503" "TCAR_FLAG_FORK=759" "TCAR_FLAG_FORK=1271" "TCAR_FLAG_FORK=2039" 2>&1 | tee gpurun_out/r3r_ab15.txt
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag or same_step_twice or deferred or (step_matches_oracle and mixed) or gemm_grouped or gemm_epilogues" 2>&1 | tail -2
+timeout 1500 bash tools/ab.sh 5 "" "TCAR_DBG_FLUSH=1" 2>&1 | tee gpurun_out/r3r_ab16.txt
