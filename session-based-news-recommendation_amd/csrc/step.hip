@@ -775,7 +775,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // aux stream they follow the weight gradients there, beside the scatter
   // The step's LAST join (aux + third stream into the main one, in front of the next update): two event waits cost the main
   // stream two barrier packets behind whichever chain ends last (16-20 us); with flag forks the last launch of either side
-  // stream publishes a flag and ONE flushing poll on the main stream waits for both.
+  // stream publishes a flag and ONE poll on the main stream waits for both.
   const int tmask = tcar_tuning().flag_fork;
   const bool tail_flags = s3 && fuse_finish && det_small && ((tmask >> FK_TAIL2) & 1) && ((tmask >> FK_TAIL3) & 1);
   bool tail3 = false, tail2 = false;
@@ -854,7 +854,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (tail2 && tail3) {
     const Fork& f2 = fork_slot(FK_TAIL2);
     const Fork& f3 = fork_slot(FK_TAIL3);
-    TCAR_LAUNCH(poll_flag_kernel<true>, dim3(8), dim3(64), 0, st, (const unsigned*)f2.sig.flag, f2.sig.epoch, c->sig_dev + TCAR_SIG_ERR,
+    // light poll: both flagged launches publish their own results with atomics (norm slots), and everything else the update
+    // reads was written by EARLIER launches of those streams, released when they ended
+    TCAR_LAUNCH(poll_flag_kernel<false>, dim3(1), dim3(64), 0, st, (const unsigned*)f2.sig.flag, f2.sig.epoch, c->sig_dev + TCAR_SIG_ERR,
                 c->sig_dev + TCAR_SIG_POLL + FK_TAIL2, POLL_TICKS, (const unsigned*)f3.sig.flag, f3.sig.epoch);
     TCAR_CHECK_LAUNCH();
   } else {
