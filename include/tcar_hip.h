@@ -627,8 +627,8 @@ typedef struct {
   /* optional planes of the one-hot form of the candidate-side time scores (training steps with the softmax epilogue): oh16
    * [ceil128(N), 160] from tcar_time_onehot (static), p16h / p16l [ceil128(B), 160] written by tcar_time_scores every step */
   void* oh16; void* p16h; void* p16l;
-  /* optional words of the flag forks (step.hip fork_arm / fork_go): sig_dev = 49 zeroed device words (16 workgroup counters,
-   * 16 flags, 1 error count, 16 XCD-cover words of the polling kernels), sig_epoch = ONE host word the driver counts forks in.  With them the main stream records no
+  /* optional words of the flag forks (step.hip fork_arm / fork_go): sig_dev = 33 zeroed device words (16 workgroup counters,
+   * 16 flags, 1 error count), sig_epoch = ONE host word the driver counts forks in.  With them the main stream records no
    * event where a side stream is forked: the producing kernel publishes a flag, a one-wave kernel of the side stream polls it.
    * The engine must raise when sig_dev[32] != 0 (a poll gave up: the streams do not run concurrently). */
   uint32_t* sig_dev; uint32_t* sig_epoch /*host*/;

@@ -126,25 +126,22 @@ inline hipStream_t aux_stream(const tcar_ctx_t* c) {
   return (c->stream2 && c->ev[0] && c->ev[1] && c->ev[2] && c->ev[3] && c->ev[4]) ? (hipStream_t)c->stream2 : nullptr;
 }
 
-// ---- forks of the main stream without an event on it ---------------------------------------------------------------------------
-// fork_arm(slot) right before the launch whose END the side stream has to wait for (that launch takes the pending flag: the
-// small-GEMM, logits-GEMM, early-Adam and CE-rescale launches do); fork_go(slot, ...) where the event record + wait used to be:
-// a one-wave kernel on the side stream polls the flag.  A launch that did not take the flag (another kernel family on this
-// path) or a context without the flag words: the event pair, as before.  The poll gives up after POLL_TICKS of the 100-MHz
-// wall clock (streams that share one hardware queue, or a profiler that serialises kernels, would otherwise hang) and counts
-// the time-out in sig_dev[TCAR_SIG_ERR]; the engine raises on a non-zero count.
-// EIGHT one-wave workgroups — the dispatcher deals consecutive workgroups round-robin over the eight XCDs — each of which, once
-// the flag shows the epoch, writes back ITS XCD's L2 (the producer's workgroups only drained their stores into their L2s): the
-// agent-scope release of the hand-off, once per XCD instead of once per producing workgroup.  The XCD ids the eight waves ran
-// on are collected (HW_REG_XCC_ID); a launch that did not cover all eight counts as an error like a time-out, so a different
-// placement is loud, not stale.  The consumer kernels behind this one start with the runtime's usual acquire.
-constexpr int TCAR_SIG_SLOTS = 16, TCAR_SIG_ERR = 2 * TCAR_SIG_SLOTS, TCAR_SIG_POLL = TCAR_SIG_ERR + 1;   // + one cover word per slot
+// ---- forks and joins of the step's streams without an event on the producer's stream ----------------------------------------------
+// fork_arm(slot) right before the launch whose END the other stream has to wait for (that launch takes the pending flag: the
+// small-GEMM, gather, query-MLP, norm launches do); fork_go(slot, ...) where the event record + wait used to be: a one-wave
+// kernel on the consumer's stream polls the flag.  A launch that did not take the flag (another kernel family on this path) or a
+// context without the flag words: the event pair, as before.  The poll gives up after POLL_TICKS of the 100-MHz wall clock
+// (a profiler that serialises kernels would otherwise hang) and counts the time-out in sig_dev[TCAR_SIG_ERR]; the engine
+// raises on a non-zero count.
+// Visibility across the eight private L2s is the PRODUCER's business: whatever the consumer reads of the flagged launch's own
+// output is stored write-through (sc1 / agent-scope atomic stores) or with atomics, everything older was released when its
+// launch ended; the consumer kernels behind the poll start with the runtime's usual acquire.  (A first version let eight
+// polling workgroups write back their XCD's L2 instead — correct, but the write-back lands in the first kernels of the other
+// stream's next phase: 2-4 us slower per fork, and the reason three forks measured slower with flags than with events.)
+constexpr int TCAR_SIG_SLOTS = 16, TCAR_SIG_ERR = 2 * TCAR_SIG_SLOTS;
 constexpr long long POLL_TICKS = 100000000LL;      // 1 s of the 100-MHz wall clock
-// FLUSH = false (one workgroup): the producer stored everything the consumer reads write-through (sc1) — nothing to write back.
-template <bool FLUSH>
-__global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, unsigned* cover,
-                                                       long long ticks = POLL_TICKS, const unsigned* flag2 = nullptr,
-                                                       unsigned epoch2 = 0) {
+__global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, long long ticks = POLL_TICKS,
+                                                       const unsigned* flag2 = nullptr, unsigned epoch2 = 0) {
   if (threadIdx.x != 0) return;
   const long long t0 = wall_clock64();
   bool ok = true;
@@ -158,26 +155,11 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
     __builtin_amdgcn_s_sleep(2);
     if (wall_clock64() - t0 > ticks) { ok = false; break; }
   }
-  if (!FLUSH) {
-    if (!ok) atomicAdd(err, 1u);
-    return;
-  }
-  asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-  const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;       // HW_REG_XCC_ID, bits 3:0
-  // ONE word, a 4-bit arrival count per XCD: the wave that completes the eight arrivals sees every count
-  const unsigned inc = 1u << (4 * (xcc & 7u));
-  const unsigned w = __hip_atomic_fetch_add(cover, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + inc;
-  unsigned n = 0;
-  for (int i = 0; i < 8; ++i) n += (w >> (4 * i)) & 15u;
   if (!ok) atomicAdd(err, 1u);
-  if (n == gridDim.x) {
-    if (w != 0x11111111u) atomicAdd(err, 1u);
-    __hip_atomic_store(cover, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 // slots (bits of TCAR_FLAG_FORK).  The other forks of the step — early Adam -> candidate refresh, logits -> arena zero, softmax
 // -> dE — stay events: released by a flag their consumers start a few us earlier, beside the critical chain, and the step is
-// slower (measured per fork, also with write-through producers and with start-of-kernel flags: DESIGN.md §4)
+// slower (measured per fork, also with write-through producers, start-of-kernel flags and delayed polls: DESIGN.md §4)
 enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7 };
 struct Fork { TcarSignal sig; bool armed; const tcar_ctx_t* ctx; };
 inline Fork& fork_slot(int slot) {
@@ -204,19 +186,14 @@ inline bool fork_taken(const tcar_ctx_t* c, int slot) {
   f.armed = false;
   return false;
 }
-inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev, bool flush = true) {
+inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev) {
   Fork& f = fork_slot(slot);
   TcarSignal& pend = tcar_pending_signal();
   if (f.armed && f.ctx != c) f.armed = false;                           // armed by another context's step on this thread
   const bool taken = f.armed && pend.cnt == nullptr;
   if (f.armed && !taken) { pend = TcarSignal{}; f.armed = false; }      // the producing launch was not flag-capable
   if (taken) {
-    if (flush)
-      TCAR_LAUNCH(poll_flag_kernel<true>, dim3(8), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch,
-                  c->sig_dev + TCAR_SIG_ERR, c->sig_dev + TCAR_SIG_POLL + slot);
-    else
-      TCAR_LAUNCH(poll_flag_kernel<false>, dim3(1), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch,
-                  c->sig_dev + TCAR_SIG_ERR, c->sig_dev + TCAR_SIG_POLL + slot);
+    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch, c->sig_dev + TCAR_SIG_ERR);
     TCAR_CHECK_LAUNCH();
     return TCAR_OK;
   }
@@ -242,8 +219,8 @@ extern "C" int tcar_flag_fork_selftest(uint32_t* sig_dev, void* main_stream, voi
       hipMemcpy(&before[1], sig_dev + TCAR_SIG_SLOTS + 15, 4, hipMemcpyDeviceToHost) != hipSuccess)
     return TCAR_E_LAUNCH;
   const unsigned epoch = before[1] + 1u;
-  TCAR_LAUNCH(poll_flag_kernel<false>, dim3(1), dim3(64), 0, ss, (const unsigned*)(sig_dev + TCAR_SIG_SLOTS + 15), epoch,
-              sig_dev + TCAR_SIG_ERR, sig_dev + TCAR_SIG_POLL + 15, 2000000LL);
+  TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, ss, (const unsigned*)(sig_dev + TCAR_SIG_SLOTS + 15), epoch, sig_dev + TCAR_SIG_ERR,
+              2000000LL);
   TCAR_CHECK_LAUNCH();
   TCAR_LAUNCH(set_flag_kernel, dim3(1), dim3(64), 0, sm, sig_dev + TCAR_SIG_SLOTS + 15, epoch);
   TCAR_CHECK_LAUNCH();
@@ -305,7 +282,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   RET(tcar_gather_clip_fwd(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream));
   const bool qside = sq && fork_taken(c, FK_GATHER);       // (the throughput form of the gather carries no flag)
   if (qside) {
-    RET(fork_go(c, FK_GATHER, (hipStream_t)stream, sq, c->ev3, false));
+    RET(fork_go(c, FK_GATHER, (hipStream_t)stream, sq, c->ev3));
     fork_arm(c, FK_QUERY);
     RET(tcar_query_mlp(&c->d, B, c->click_t, W(c, TCAR_V_Q1_W), W(c, TCAR_V_Q1_B), W(c, TCAR_V_Q2_W), W(c, TCAR_V_Q2_B), c->q1,
                        c->q, (void*)sq));
@@ -356,7 +333,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   }
   RET(hook(1));
   if (qside) {   // the pools wait for q: a polling kernel on this stream (no event)
-    RET(fork_go(c, FK_QUERY, sq, (hipStream_t)stream, c->ev3, false));
+    RET(fork_go(c, FK_QUERY, sq, (hipStream_t)stream, c->ev3));
   } else if (!qfused) {       // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
     RET(small_gemm(c, 0, 1, &p, stream));
@@ -487,7 +464,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     if (rest_stage == 1 && stage == 0) fork_arm(c, FK_PROJ);        // in front of the projection launch
     if (stage != rest_stage) return TCAR_OK;
     // late fork: the HBM-bound rest pass starts only now, so the launches before this point ran without it
-    RET(fork_go(c, FK_PROJ, s1, s2, c->ev[0], false));      // (the rest pass reads nothing the projections write: timing only)
+    RET(fork_go(c, FK_PROJ, s1, s2, c->ev[0]));      // (the rest pass reads nothing the projections write: timing only)
     return launch_rest();
   }));
   // sort index of the item rows (feed only): on the aux stream BEHIND the rest pass — the logits GEMM does not wait for it (ev[1]
@@ -760,7 +737,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   hipStream_t s3 = (s2 && fuse_finish && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
-    RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0], false));        // (flagged small-GEMM launches store write-through)        // (flagged small-GEMM launches store write-through)
+    RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));        // (flagged small-GEMM launches store write-through)
     // (with the negative rows on this stream it already waited for dE — ev[4], recorded on the aux stream BEHIND the arena zero —
     // and a wait for a completed event still costs the stream a ~6-us barrier packet)
     if (!neg_s3 && hipStreamWaitEvent(s3, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
@@ -805,7 +782,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5], false));
+    RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5]));
     if (tail3) fork_arm(c, FK_TAIL2);
     RET(tcar_small_tables_bwd_det(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2));
     if (tail3) tail2 = fork_taken(c, FK_TAIL2);
@@ -856,8 +833,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     const Fork& f3 = fork_slot(FK_TAIL3);
     // light poll: both flagged launches publish their own results with atomics (norm slots), and everything else the update
     // reads was written by EARLIER launches of those streams, released when they ended
-    TCAR_LAUNCH(poll_flag_kernel<false>, dim3(1), dim3(64), 0, st, (const unsigned*)f2.sig.flag, f2.sig.epoch, c->sig_dev + TCAR_SIG_ERR,
-                c->sig_dev + TCAR_SIG_POLL + FK_TAIL2, POLL_TICKS, (const unsigned*)f3.sig.flag, f3.sig.epoch);
+    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)f2.sig.flag, f2.sig.epoch, c->sig_dev + TCAR_SIG_ERR, POLL_TICKS,
+                (const unsigned*)f3.sig.flag, f3.sig.epoch);
     TCAR_CHECK_LAUNCH();
   } else {
     if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
