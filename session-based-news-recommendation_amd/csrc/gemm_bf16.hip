@@ -54,6 +54,7 @@ struct BArgs {
   // (inner a2_in32 * 32) and ONE B2 plane (inner b2_in32 * 32; its elements are exact in bf16: the one-hot time-index matrix),
   // so that block costs two MFMAs per product and half the B fill bytes
   const __bf16* A2[2]; const __bf16* B2; int a2_in32, b2_in32, a2_rb, b2_rb, K1;
+  TcarSignal sig;      // completion flag (softmax-epilogue form only)
   __bf16* p_hi; int p_in32;    // plane [ceil128(M), 32 * p_in32]
   float* stats; int ngroups;   // [M, ngroups, 2]
   const int32_t* label; float* lab_logit;
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
       if (live && lh == 0) *reinterpret_cast<float2*>(g.stats + ((long)row * g.ngroups + gidx) * 2) = make_float2(mx, sum);
       __builtin_amdgcn_sched_barrier(0);     // one session tile at a time: the accumulators leave no room for hoisted addresses
     }
+    tcar_signal_done(g.sig);
     return;
   }
   float* C1 = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
@@ -371,6 +373,7 @@ int launch_k(BArgs& g, int splitk, hipStream_t st) {
       g.ngroups = g.nt * WNW;
       t_ce_gw = 32 * TNW;
       t_ce_ngroups = g.ngroups;
+      g.sig = tcar_take_signal();
       if (g.B2) {
         if constexpr (NSPLIT == 3 && KS == 1) {
           TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1>), lds);

@@ -20,7 +20,7 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 1},
-    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 247},
+    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 759},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
 };
 }  // namespace
 static TcarTuning& tuning_storage() {
@@ -141,7 +141,7 @@ inline hipStream_t aux_stream(const tcar_ctx_t* c) {
 constexpr int TCAR_SIG_SLOTS = 16, TCAR_SIG_ERR = 2 * TCAR_SIG_SLOTS;
 constexpr long long POLL_TICKS = 100000000LL;      // 1 s of the 100-MHz wall clock
 __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, long long ticks = POLL_TICKS,
-                                                       const unsigned* flag2 = nullptr, unsigned epoch2 = 0) {
+                                                       const unsigned* flag2 = nullptr, unsigned epoch2 = 0, int delay_ticks = 0) {
   if (threadIdx.x != 0) return;
   const long long t0 = wall_clock64();
   bool ok = true;
@@ -155,12 +155,17 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
     __builtin_amdgcn_s_sleep(2);
     if (wall_clock64() - t0 > ticks) { ok = false; break; }
   }
+  if (delay_ticks > 0) {             // DELAYED fork: hold the consumer back as the event it replaces did
+    const long long t1 = wall_clock64();
+    while (wall_clock64() - t1 < delay_ticks) __builtin_amdgcn_s_sleep(8);
+  }
   if (!ok) atomicAdd(err, 1u);
 }
-// slots (bits of TCAR_FLAG_FORK).  The other forks of the step — early Adam -> candidate refresh, logits -> arena zero, softmax
-// -> dE — stay events: released by a flag their consumers start a few us earlier, beside the critical chain, and the step is
-// slower (measured per fork, also with write-through producers, start-of-kernel flags and delayed polls: DESIGN.md §4)
-enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7 };
+// slots (bits of TCAR_FLAG_FORK).  Two forks of the step — early Adam -> candidate refresh, softmax -> dE — stay events: with a
+// flag the step is slower in every form tried (write-through producers, start-of-kernel flags, delayed polls: DESIGN.md §4).
+// The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits GEMM writes, and held back
+// TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main stream records nothing.
+enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_LOGITS = 9 };
 struct Fork { TcarSignal sig; bool armed; const tcar_ctx_t* ctx; };
 inline Fork& fork_slot(int slot) {
   thread_local Fork forks[TCAR_SIG_SLOTS] = {};
@@ -186,14 +191,15 @@ inline bool fork_taken(const tcar_ctx_t* c, int slot) {
   f.armed = false;
   return false;
 }
-inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev) {
+inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev, int delay_us = 0) {
   Fork& f = fork_slot(slot);
   TcarSignal& pend = tcar_pending_signal();
   if (f.armed && f.ctx != c) f.armed = false;                           // armed by another context's step on this thread
   const bool taken = f.armed && pend.cnt == nullptr;
   if (f.armed && !taken) { pend = TcarSignal{}; f.armed = false; }      // the producing launch was not flag-capable
   if (taken) {
-    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch, c->sig_dev + TCAR_SIG_ERR);
+    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch, c->sig_dev + TCAR_SIG_ERR, POLL_TICKS,
+                (const unsigned*)nullptr, 0u, delay_us * 100);
     TCAR_CHECK_LAUNCH();
     return TCAR_OK;
   }
@@ -392,8 +398,8 @@ int zero_arena(const tcar_ctx_t* c, hipStream_t s) {
 // dE fork — and joining the three streams through ONE wait at the end of the step measured SLOWER, 0.635 vs 0.613 ms per step:
 // dE then starts behind the negative term and the final join becomes two hops.)
 int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
-  if (sz != st && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(sz, (hipEvent_t)c->ev[0], 0) != hipSuccess))
-    return TCAR_E_LAUNCH;
+  // (armed by forward_impl in front of the logits GEMM of a softmax-epilogue step; an event otherwise)
+  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], tcar_tuning().fork_delay));
   RET(zero_arena(c, sz));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
@@ -497,6 +503,8 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   if (c->scoring) {
     // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
+    fork_disarm(FK_LOGITS);
+    if (ce_epi && s2) fork_arm(c, FK_LOGITS);       // backward_prologue releases the aux stream behind this launch
     if (ce_epi) {
       // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes
       // dlogits, plus per-group (max, sum) — no [B, N] fp32 logits; backward_impl finishes with tcar_ce_finish

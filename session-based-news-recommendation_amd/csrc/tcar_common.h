@@ -64,6 +64,7 @@ struct TcarTuning {
   int fused_ce;         // TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel
   int onehot_time;      // TCAR_ONEHOT_TIME    0: the logits GEMM of a training step contracts the 5 ldt clipped candidate time columns instead of the 160-column one-hot form
   int proj_split;       // TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs
+  int fork_delay;       // TCAR_FORK_DELAY     us a DELAYED flag fork holds its consumer back behind the producer's end (step.hip)
   int flag_fork;        // TCAR_FLAG_FORK      0: every fork of the main stream records an event (6-7 us of bubble on it) instead of
                         //                     letting the producing kernel publish a device flag a polling kernel of the side stream waits for
 };
