@@ -186,7 +186,7 @@ inline void fork_disarm(int slot) { fork_slot(slot).armed = false; }
 inline bool fork_taken(const tcar_ctx_t* c, int slot) {
   Fork& f = fork_slot(slot);
   TcarSignal& pend = tcar_pending_signal();
-  if (f.armed && f.ctx == c && pend.cnt == nullptr) return true;
+  if (f.armed && f.ctx == c && f.sig.cnt == c->sig_dev + slot && pend.cnt == nullptr) return true;
   pend = TcarSignal{};
   f.armed = false;
   return false;
@@ -194,7 +194,8 @@ inline bool fork_taken(const tcar_ctx_t* c, int slot) {
 inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev, int delay_us = 0) {
   Fork& f = fork_slot(slot);
   TcarSignal& pend = tcar_pending_signal();
-  if (f.armed && f.ctx != c) f.armed = false;                           // armed by another context's step on this thread
+  // armed by another context's step on this thread (the context struct's address can be reused: compare the device words too)
+  if (f.armed && (f.ctx != c || f.sig.cnt != c->sig_dev + slot)) f.armed = false;
   const bool taken = f.armed && pend.cnt == nullptr;
   if (f.armed && !taken) { pend = TcarSignal{}; f.armed = false; }      // the producing launch was not flag-capable
   if (taken) {
@@ -398,7 +399,12 @@ int zero_arena(const tcar_ctx_t* c, hipStream_t s) {
 // dE fork — and joining the three streams through ONE wait at the end of the step measured SLOWER, 0.635 vs 0.613 ms per step:
 // dE then starts behind the negative term and the final join becomes two hops.)
 int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
-  // (armed by forward_impl in front of the logits GEMM of a softmax-epilogue step; an event otherwise)
+  // (armed by forward_impl in front of the logits GEMM of a softmax-epilogue step; an event otherwise.  The arm must be THIS
+  // context's latest fork action — nothing else forks between that launch and here —, else it is a leftover: event)
+  {
+    Fork& f = fork_slot(FK_LOGITS);
+    if (f.armed && (!c->sig_epoch || f.sig.epoch != c->sig_epoch[0])) f.armed = false;
+  }
   if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], tcar_tuning().fork_delay));
   RET(zero_arena(c, sz));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
@@ -500,10 +506,10 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
   };
   int rc;
+  fork_disarm(FK_LOGITS);              // (EVERY forward pass: the slot is the one fork whose arm and go sit in different calls)
   if (c->scoring) {
     // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
-    fork_disarm(FK_LOGITS);
     if (ce_epi && s2) fork_arm(c, FK_LOGITS);       // backward_prologue releases the aux stream behind this launch
     if (ce_epi) {
       // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes

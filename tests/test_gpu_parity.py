@@ -634,6 +634,43 @@ def test_flag_forks_fall_back_to_events_when_streams_do_not_overlap(monkeypatch)
         assert (pa[k] == pb[k]).all(), k
 
 
+def test_fork_state_does_not_leak_between_engines():
+    """The logits -> arena-zero fork is armed in the forward call and used in the backward call (thread-local state in the
+    library).  A training forward of one engine must not leave an arm behind that a LATER engine's backward takes for its own
+    (same context address after garbage collection: the aux stream's negative-term forward then ran ahead of attout — seen
+    once as 6 % wrong item-gradient rows in the fp32 mode).  Alternate short-lived engines of both kinds and check the fp32
+    engine's gradients against a single-stream run of the same engine class."""
+    _need_gpu()
+    import gc
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, T, K = 3000, 250, 64, 128, 3, 20
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=31)
+    other = _case(N, H, Ht, B, T, K, seed=32)[3]         # a different batch in between: a stale attout would show
+    os.environ["TCAR_NO_OVERLAP"] = "1"
+    try:
+        ref = TcarEngine(params, content, mw, scoring="f32")
+        ref.loss_and_grads(batch)
+        want = ref.export_grads()
+    finally:
+        del os.environ["TCAR_NO_OVERLAP"]
+    del ref
+    for rep in range(8):
+        a = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+        a.train_step(batch)                      # arms the cross-call fork slot
+        del a
+        gc.collect()
+        b = TcarEngine(params, content, mw, scoring="f32")
+        rb, ro = b.make_resident(batch), b.make_resident(other)
+        for _ in range(3):
+            b.loss_and_grads(None, bt=ro)        # (no host synchronisation between the two calls)
+            b.loss_and_grads(None, bt=rb)
+            got = b.export_grads()
+            for k in want:
+                close(got[k], want[k], name="rep %d grad %s" % (rep, k), rtol=1e-4, atol_scale=1e-5)
+        del b, rb, ro
+        gc.collect()
+
+
 def test_flag_and_event_forks_agree_bitwise_over_a_long_run(monkeypatch):
     """Race hunt at the benched size: 60 deferred steps over batches of different lengths, once with the flag forks and once
     with events only; losses of every step and all 23 variables + Adam moments at the end are bitwise equal."""
