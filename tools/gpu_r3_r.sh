@@ -1,4 +1,4 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for i in 1 2 3; do timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fork_state_does_not_leak or flag_and_event or flag_forks_fall_back" 2>&1 | tail -1; done
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+mkdir -p gpurun_out
+timeout 1500 bash tools/ab.sh 5 "" "TCAR_ONEHOT_TIME=0" "TCAR_FLAG_FORK=0" 2>&1 | tee gpurun_out/r3r_ab20.txt
