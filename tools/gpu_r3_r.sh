@@ -1,4 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
-timeout 1500 bash tools/ab.sh 5 "" "TCAR_ONEHOT_TIME=0" "TCAR_FLAG_FORK=0" 2>&1 | tee gpurun_out/r3r_ab20.txt
+TCAR_FLAG_FORK=767 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag or fork or same_step_twice or deferred or split_adam or (step_matches_oracle and mixed)" 2>&1 | tail -2
+timeout 1500 bash tools/ab.sh 5 "" "TCAR_FLAG_FORK=767" 2>&1 | tee gpurun_out/r3r_ab21.txt
