@@ -36,6 +36,10 @@ TcarSignal& tcar_pending_signal() {
   thread_local TcarSignal pending{};
   return pending;
 }
+unsigned& tcar_taken_epoch(unsigned slot) {
+  thread_local unsigned taken[16] = {};
+  return taken[slot & 15u];
+}
 
 // Diagnostic hook (tests, tools/): override one switch at run time; returns the previous value, or INT_MIN for an unknown
 // name.  Process-global and not thread safe against concurrent launches — the product path (engine, step driver) never calls it.
@@ -176,7 +180,8 @@ inline void fork_arm(const tcar_ctx_t* c, int slot) {
   f.armed = false;
   tcar_pending_signal() = TcarSignal{};
   if (!c->sig_dev || !c->sig_epoch || !((tcar_tuning().flag_fork >> slot) & 1)) return;      // the switch is a mask over the slots
-  f.sig = TcarSignal{c->sig_dev + slot, c->sig_dev + TCAR_SIG_SLOTS + slot, ++c->sig_epoch[0], 0u};
+  f.sig = TcarSignal{c->sig_dev + slot, c->sig_dev + TCAR_SIG_SLOTS + slot, ++c->sig_epoch[0], (unsigned)slot};
+  tcar_taken_epoch(slot) = f.sig.epoch - 1u;            // (not yet taken)
   f.armed = true;
   f.ctx = c;
   tcar_pending_signal() = f.sig;
@@ -186,8 +191,8 @@ inline void fork_disarm(int slot) { fork_slot(slot).armed = false; }
 inline bool fork_taken(const tcar_ctx_t* c, int slot) {
   Fork& f = fork_slot(slot);
   TcarSignal& pend = tcar_pending_signal();
-  if (f.armed && f.ctx == c && f.sig.cnt == c->sig_dev + slot && pend.cnt == nullptr) return true;
-  pend = TcarSignal{};
+  if (f.armed && f.ctx == c && f.sig.cnt == c->sig_dev + slot && tcar_taken_epoch(slot) == f.sig.epoch) return true;
+  if (pend.cnt == f.sig.cnt) pend = TcarSignal{};       // nobody took it
   f.armed = false;
   return false;
 }
@@ -196,8 +201,11 @@ inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t 
   TcarSignal& pend = tcar_pending_signal();
   // armed by another context's step on this thread (the context struct's address can be reused: compare the device words too)
   if (f.armed && (f.ctx != c || f.sig.cnt != c->sig_dev + slot)) f.armed = false;
-  const bool taken = f.armed && pend.cnt == nullptr;
-  if (f.armed && !taken) { pend = TcarSignal{}; f.armed = false; }      // the producing launch was not flag-capable
+  const bool taken = f.armed && tcar_taken_epoch(slot) == f.sig.epoch;  // the producing launch really carries this flag
+  if (f.armed && !taken) {                                              // it was not flag-capable
+    if (pend.cnt == f.sig.cnt) pend = TcarSignal{};
+    f.armed = false;
+  }
   if (taken) {
     TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch, c->sig_dev + TCAR_SIG_ERR, POLL_TICKS,
                 (const unsigned*)nullptr, 0u, delay_us * 100);

@@ -74,13 +74,17 @@ const TcarTuning& tcar_tuning();
 // LAST workgroup is through: the side stream's consumers sit behind a one-wave polling kernel instead of behind an event the main
 // stream would have to record (measured, tools/micro/event_cost: a record between two kernels costs the recording stream 6.5 us,
 // the flag costs it nothing and releases the consumer 0.4 us after the producer's end).  cnt == nullptr: no flag.
-struct TcarSignal { unsigned* cnt; unsigned* flag; unsigned epoch; unsigned pad_; };
+struct TcarSignal { unsigned* cnt; unsigned* flag; unsigned epoch; unsigned slot; };
 // the flag the NEXT flag-capable launch of this host thread carries (it takes it: tcar_take_signal); defined in step.hip
 TcarSignal& tcar_pending_signal();
+// the epoch of the flag the launches of this host thread last TOOK for a slot (step.hip: a fork is released by a polling kernel
+// only when the producing launch really carries its flag, whatever else happened to the pending one in between)
+unsigned& tcar_taken_epoch(unsigned slot);
 inline TcarSignal tcar_take_signal() {
   TcarSignal& p = tcar_pending_signal();
   const TcarSignal s = p;
   p = TcarSignal{};
+  if (s.cnt) tcar_taken_epoch(s.slot) = s.epoch;
   return s;
 }
 // 16-byte write-through store (sc1): the bytes bypass the write-back state of this XCD's L2, so a consumer behind a completion

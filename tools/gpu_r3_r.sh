@@ -1,5 +1,3 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p gpurun_out
-TCAR_FLAG_FORK=767 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag or fork or same_step_twice or deferred or split_adam or (step_matches_oracle and mixed)" 2>&1 | tail -2
-timeout 1500 bash tools/ab.sh 5 "" "TCAR_FLAG_FORK=767" 2>&1 | tee gpurun_out/r3r_ab21.txt
+timeout 600 bash tools/ab.sh 3 "" "TCAR_FLAG_FORK=0" 2>&1 | tail -6
