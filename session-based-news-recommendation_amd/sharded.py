@@ -78,6 +78,39 @@ class ShardExchange:
         self.bytes_moved: Dict[str, int] = {}
         self.order = []                 # names of the collectives in issue order (tests)
         self._pending_rows = None
+        # optional per-collective timing (bench.py's second, event-instrumented pass; never in the headline pass: an event pair
+        # costs its stream a few us): key -> list of (start, end) — CUDA events on the issuing stream, or host seconds on CPU
+        self.timing = False
+        self._times: Dict[str, list] = {}
+
+    def _timed(self, key, t, fn):
+        """run collective `fn` and, when timing is on, bracket it (for an async collective: the issue only)"""
+        if not self.timing:
+            return fn()
+        if t.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn()
+            e1.record()
+            self._times.setdefault(key, []).append((e0, e1))
+        else:
+            import time
+            t0 = time.perf_counter()
+            out = fn()
+            self._times.setdefault(key, []).append((t0, time.perf_counter()))
+        return out
+
+    def collective_ms(self) -> Dict[str, float]:
+        """mean milliseconds per collective over the timed steps (call after a device synchronise)"""
+        out = {}
+        for key, spans in self._times.items():
+            if not spans:
+                continue
+            if isinstance(spans[0][0], float):
+                out[key] = round(1e3 * sum(b - a for a, b in spans) / len(spans), 4)
+            else:
+                out[key] = round(sum(a.elapsed_time(b) for a, b in spans) / len(spans), 4)
+        return out
 
     def _note(self, key, t):
         self.bytes_moved[key] = t.numel() * t.element_size()
@@ -90,7 +123,7 @@ class ShardExchange:
         if self.sim:
             return t.unsqueeze(0).expand((self.world,) + tuple(t.shape)).contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group)
+        self._timed(key, t, lambda: dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group))
         self._note(key, out)
         return out
 
@@ -101,14 +134,14 @@ class ShardExchange:
         self._note(key, full)
         if self.use_reduce_scatter:
             out = torch.empty(cap, full.shape[1], dtype=full.dtype, device=full.device)
-            dist.reduce_scatter_tensor(out, full, group=self.group)
+            self._timed(key, full, lambda: dist.reduce_scatter_tensor(out, full, group=self.group))
             return out
-        dist.all_reduce(full, group=self.group)              # gloo (CPU tests, single-GPU dry runs) has no reduce-scatter
+        self._timed(key, full, lambda: dist.all_reduce(full, group=self.group))     # gloo (CPU tests, single-GPU dry runs) has no reduce-scatter
         return full[self.rank * cap:(self.rank + 1) * cap]
 
     def allreduce(self, t: torch.Tensor, key: str) -> torch.Tensor:
         if self.world > 1 and not self.sim:
-            dist.all_reduce(t, group=self.group)
+            self._timed(key, t, lambda: dist.all_reduce(t, group=self.group))
             self._note(key, t)
         return t
 
@@ -118,7 +151,8 @@ class ShardExchange:
         if self.world == 1 or self.sim:
             return
         mine = stage[self.rank].reshape(-1).clone()
-        work = dist.all_gather_into_tensor(stage.view(-1), mine, group=self.group, async_op=True)
+        work = self._timed("item_rows (issue)", stage,
+                           lambda: dist.all_gather_into_tensor(stage.view(-1), mine, group=self.group, async_op=True))
         self._note("item_rows", stage)
         self._pending_rows = (work, stage, install, mine)
 
@@ -200,6 +234,7 @@ class ShardedEngine(TcarEngine):
         g = self.geo
         return {"mode": "sharded", "world": self.world, "shard_rows": self.S,
                 "bytes_per_step": dict(self.bytes_moved),
+                "ms_per_collective": self.xch.collective_ms(),      # filled by the event-instrumented pass (enable_native_timing)
                 "item_rows_allgather_bytes": 4 * self.world * self.S * g.ldh,
                 "replica_mode_allreduce_bytes": 4 * (g.N * (g.ldh + g.pt) + self.arena_n + _lib.NSLOT),
                 "collectives_per_step": 6,
@@ -238,6 +273,7 @@ class ShardedEngine(TcarEngine):
     # ------------------------------------------------------------- timing of the scoring pieces (bench.py)
     def enable_native_timing(self, n: int):
         self._tm = {"n": n, "ev": [[], [], []]}
+        self.xch.timing = True
 
     def _tick3(self, kind):
         tm = getattr(self, "_tm", None)

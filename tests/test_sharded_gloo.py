@@ -168,6 +168,16 @@ def _worker(rank, world, port, ret):
         if rank == 0:
             one = torch.nn.functional.cross_entropy((att[:1] @ E.T), lab[:1], reduction="none")
             assert torch.allclose(st["ce"][:1], one, rtol=1e-12, atol=1e-12)
+        # per-collective timing (bench.py's event-instrumented pass): off by default, one span per collective and step when on
+        assert xch.collective_ms() == {}
+        xch.timing = True
+        lo, hi, cap = shard_bounds(B, world, rank)
+        nloc = hi - lo
+        xch.step(Pieces(), cap, update=True)
+        xch.wait_rows()
+        ms = xch.collective_ms()
+        assert set(ms) == {"attout+labels+negatives", "softmax_stats", "dX", "rows+ids", "arena", "item_rows (issue)"}
+        assert all(v >= 0.0 for v in ms.values())
         ret[rank] = "ok"
     except Exception as e:
         import traceback

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p gpurun_out
-TCAR_FLAG_FORK=1015 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "flag or fork or same_step_twice or deferred or (step_matches_oracle and mixed)" 2>&1 | tail -2
-timeout 1500 bash tools/ab.sh 5 "" "TCAR_FLAG_FORK=1015" 2>&1 | tee gpurun_out/r3r_ab22.txt
+timeout 600 python -m pytest tests/test_gpu_sharded.py -x -q -m gpu 2>&1 | tail -2
+timeout 300 python bench.py --gpus 2 --same_device --backend gloo --steps 10 --warmup 2 --no_cpu_baseline --dp_mode sharded 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], json.dumps(d['exchange'].get('ms_per_collective')))"
+TCAR_FORCE_DP=1 timeout 200 python bench.py --no_cpu_baseline --no_e2e --dp_mode sharded --steps 50 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], json.dumps(d['exchange'].get('ms_per_collective')))"
