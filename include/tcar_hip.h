@@ -12,8 +12,9 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller unless marked "host"; no entry point allocates;
  *   - `stream` is a hipStream_t passed as void*; calls are stream-ordered and re-entrant; the library keeps no mutable
- *     state except idempotent per-device kernel attributes (set once per device, thread-safe) and the diagnostic
- *     TCAR_* environment switches, which are read once per process (README.md);
+ *     state: per-device kernel attributes are idempotent (set once per device, thread-safe), the diagnostic TCAR_*
+ *     environment switches are read once per process and never written (tcar_tuning_t), and everything a step carries
+ *     from one call to the next lives in buffers of the caller's tcar_ctx_t;
  *   - return value: 0 = ok, negative = TCAR_E_* (never throws across the boundary);
  *   - device layout ("padded-concat space"): H is padded to ldh, Ht to ldt (multiples of 64, zero filled);
  *       ic = 2*ldh   item | content           (model_combine.py:111  seq_item_cont)
@@ -37,6 +38,35 @@ extern "C" {
 #define TCAR_OK 0
 #define TCAR_E_ARG (-1)     /* bad argument (alignment, range, unsupported size) */
 #define TCAR_E_LAUNCH (-2)  /* hip launch error */
+
+/* Diagnostic tuning switches.  The process-wide values are the shipped defaults overridden by the TCAR_* environment
+ * variables of the same names, read ONCE per process and immutable afterwards (README.md).  A caller that wants other values
+ * for ONE context (tcar_ctx_t.tune) or ONE call (the *_tuned entry points) passes its own copy: the library keeps no
+ * mutable switch state.  Field <-> variable: lower-case name without the TCAR_ prefix, except gather_wg_per_cu = TCAR_GATHER_WG. */
+typedef struct {
+  int32_t bf16_tile;        /* TCAR_BF16_TILE      force a workgroup tile of the bf16 GEMM (0 = heuristic; tests pin every tile shape with it) */
+  int32_t rest_grid;        /* TCAR_REST_GRID      grid cap of the deferred Adam rest pass */
+  int32_t softmax_variant;  /* TCAR_SOFTMAX_VARIANT */
+  int32_t wgrad_ks;         /* TCAR_WGRAD_KS       K chunk of the weight-gradient split */
+  int32_t gather_big_rows;  /* TCAR_GATHER_BIG_ROWS  session rows from which the forward gather runs its throughput form */
+  int32_t gather_wg_per_cu; /* TCAR_GATHER_WG      1024-thread workgroups per CU of that form (2 x 78 KB of LDS fit) */
+  int32_t mha_mfma;         /* TCAR_MHA_MFMA       0: multihead_attention core always in its scalar form */
+  int32_t sort_scatter;     /* TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum */
+  int32_t bf16_ks;          /* TCAR_BF16_KS        64-deep LDS stages of the hi-only bf16 GEMM: 1 never, 2 dX / logits layouts, 3 all */
+  int32_t det_small;        /* TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode) */
+  int32_t x3_oneshot;       /* TCAR_X3_ONESHOT     0: short-K small-GEMM launches keep the one-stage register ring */
+  int32_t fused_ce;         /* TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel */
+  int32_t onehot_time;      /* TCAR_ONEHOT_TIME    0: the scoring GEMMs of a training step contract the 5 ldt clipped candidate time columns instead of the 160-column one-hot form */
+  int32_t proj_split;       /* TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs */
+  int32_t fork_delay;       /* TCAR_FORK_DELAY     us a DELAYED flag fork holds its consumer back behind the producer's end (step.hip) */
+  int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
+                                                   bubble on it) instead of letting the producing kernel publish a device flag a polling
+                                                   kernel of the side stream waits for */
+} tcar_tuning_t;
+/* *out = the process-wide values (shipped defaults + TCAR_* environment) */
+int tcar_tuning_defaults(tcar_tuning_t* out /*host*/);
+/* sets the switch called `name` ("TCAR_BF16_TILE", ...) in the CALLER's copy; returns the previous value, INT_MIN for an unknown name */
+int tcar_tuning_set(tcar_tuning_t* t /*host*/, const char* name /*host*/, int value);
 
 #define TCAR_POS_VOCAB 40   /* model_combine.py:57 */
 #define TCAR_DUR_VOCAB 11   /* model_combine.py:106 */
@@ -98,6 +128,10 @@ typedef struct {
  *   click_t [B, ct].  Dwell id >= 11 yields a zero row. */
 int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
                          float* x_icp, float* x_pt, float* x_act, float* click_t, void* stream);
+/* ..._tuned: with the caller's switch values (gather_big_rows / gather_wg_per_cu choose between the latency form and the
+ * throughput form; both give the same bits) */
+int tcar_gather_clip_fwd_tuned(const tcar_tuning_t* tune, const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
+                               float* x_icp, float* x_pt, float* x_act, float* click_t, void* stream);
 /* Both layers of the click-query MLP in one launch (modules.py:138-139): q1 [B, ldh] = relu(click_t Wq1 + b1), q [B, 2 ldh] =
  * tanh(q1 Wq2 + b2), fp32 FMAs in a fixed order.  Only for ldh == 256 and ldt == 64 (the reference's hidden sizes, padded);
  * TCAR_E_ARG otherwise — run the layers through tcar_gemm_*_grouped then. */
@@ -228,6 +262,11 @@ int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi, const void
                    const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
                    int64_t ldc2, int csplit, int nsplit, int splitk, void* stream);
 
+/* ..._tuned: with the caller's switch values (bf16_tile pins the workgroup tile, bf16_ks the stage depth) */
+int tcar_gemm_bf16_tuned(const tcar_tuning_t* tune, int layout, int M, int N, int K, const void* A_hi, const void* A_lo,
+                         int64_t a_inner, int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows,
+                         float* C, int64_t ldc, float* C2, int64_t ldc2, int csplit, int nsplit, int splitk, void* stream);
+
 /* ..._perm: as tcar_gemm_bf16, with a grouped row permutation of the SECOND destination: element (m, cc) of the C2 block
  * (cc = column - csplit) is stored at C2[c2_perm[(cc / c2_group) * M + m] * c2_group + cc % c2_group] (ldc2 unused).
  * The dE GEMM writes the candidate-time block this way, in the order of the static inverted index of
@@ -260,8 +299,41 @@ int tcar_time_onehot(const tcar_dims_t* d, const int32_t* mwdhm, void* oh_hi, in
  * sum_k attout_tk[b] . candidate_publish_t_k[n] = (P OH^T)[b, n] */
 int tcar_time_scores(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* attout, int64_t ld_att, void* p_hi,
                      void* p_lo, int64_t inner, void* stream);
+/* ..._clip: additionally writes the clipped table rows the scores were taken against — tclip [160 ldt + 320] floats: row r of the
+ * month | day | week | hour | minute tables after max_norm = 1 (rows 139..159 untouched), then scale[160] = 1 / max(||row||, 1) and
+ * clipped[160] = 1.0 where ||row|| > 1 — for the one-hot form of the scoring GRADIENTS (tcar_gemm_bf16_de_qz, tcar_reduce_dact_onehot,
+ * tcar_cand_time_bwd_onehot) */
+int tcar_time_scores_clip(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* attout, int64_t ld_att,
+                          void* p_hi, void* p_lo, int64_t inner, float* tclip, void* stream);
 int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                    float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream);
+/* ---- one-hot form of the two scoring GRADIENT GEMMs (training steps, hi planes only) -------------------------------------------
+ * The candidate-side time columns of items_emb (model_combine.py:86-92,135-136) are five clipped table rows per item, selected by
+ * publish_time_MWDHM: E_time = OH T_clip with the static 0/1 matrix OH [N, 160] (tcar_time_onehot) and the 139 clipped rows
+ * T_clip (tcar_time_scores_clip).  Gradient of model_combine.py:138 through that factorisation:
+ *   tcar_gemm_bf16_dx_onehot   slabs[s] = dlogits [E_item | E_content | OH]  (layout 0 of tcar_gemm_bf16; N1 = 2 ldh columns from the
+ *                              planes B, then 160 from the one-hot plane B2): split-K slabs [splitk_eff, M, ldc], ldc >= N1 + 160
+ *   tcar_reduce_dact_onehot    tcar_splitk_reduce_dact for those slabs: d attout [M, ic + 320] (the time columns expanded as
+ *                              (dlogits OH) T_clip, everything through tanh') and dP = dlogits OH [M, 160]
+ *   tcar_gemm_bf16_de_qz       dE = dlogits^T [attout_item | attout_time] (layout 2): the item block [M = N, ldh] goes to C; the time
+ *                              block is NOT stored — per (n, k): qz[perm[k N + n]] = (||gy||^2, x . gy), gy = its 64-column gradient
+ *                              block, x = the clipped row item n looks up in table k.  perm = position of (k, n) in the inverted index
+ *   tcar_cand_time_bwd_onehot  the IndexedSlices gradient of the five time tables' candidate-side lookups and its norm pieces
+ *                               from qz, dP and attout — what tcar_cand_time_bwd_indexed computes from a stored
+ *                              [N, 5 ldt] block.  ldt must be 64.
+ * Against the materialised form this moves 118 MB less per step at the Globo catalog (no [N, 320] fp32 block written and re-read)
+ * and the dX GEMM contracts 160 instead of 320 time columns. */
+int tcar_gemm_bf16_dx_onehot(int M, int N1, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi,
+                             int64_t b_inner, int64_t b_rows, const void* B2_hi, int64_t inner2, float* C, int64_t ldc, int splitk,
+                             void* stream);
+int tcar_reduce_dact_onehot(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
+                            const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo, float* dP, float* bias_grad0,
+                            float* bias_grad1, void* stream);
+int tcar_gemm_bf16_de_qz(int M, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi, int64_t b_inner,
+                         int64_t b_rows, int ldh, float* C, int64_t ldc, const int32_t* mwdhm, const int32_t* perm, const float* tclip,
+                         float* qz, int tile /* 0: 192 x 192 workgroup tile (9 waves), 256: 256 x 192 (12 waves) */, void* stream);
+int tcar_cand_time_bwd_onehot(const tcar_dims_t* d, int B, const int32_t* inv_off, const float* qz, const float* dP,
+                              const float* attout, int64_t ld_att, const float* tclip, float* ws, const tcar_grads_t* g, void* stream);
 /* Names the kernel instantiation (template arguments, workgroup tile, grid) that tcar_gemm_bf16 would launch for this
  * problem, without launching it (profiling tools match rocprofv3 kernel names with it).  buf: host, buflen >= 96. */
 int tcar_gemm_bf16_variant(int layout, int M, int N, int K, int nsplit, int splitk, char* buf /*host*/, int buflen);
@@ -369,6 +441,18 @@ int tcar_rank_topk(int B, int N, const float* logits, int64_t ld, const int32_t*
 int tcar_eval_rows(int B, int N, const float* logits, int64_t ld, const int32_t* label, int k, int32_t* rank, int32_t* topk,
                    float* ce, void* stream);
 
+/* tcar_eval_diversity: the diversity metrics of the evaluation loop on the device, from the top-k lists tcar_eval_rows wrote.
+ *   getILD    (model_combine.py:174-182)  ild_cnt[b]   = #{(i, j), i != j : cat[topk[b,i]] != cat[topk[b,j]]}
+ *   getUnexp  (model_combine.py:184-194)  unexp_cnt[b] = #{(i, t) : cat[topk[b,i]] != cat[seq[b,t] - 1]}      (seq is 1-based)
+ *   resultItemDict (:305-306,313)         seen[n] = 1 for every recommended item n (byte map [n_items], caller-zeroed per
+ *                                         evaluation; coverage = its sum; ranks union it with a MAX all-reduce); may be NULL
+ *   n_rec[b] = entries of the list (topk entries < 0 — a catalog shorter than k — are not in it); may be NULL.
+ * cat [n_items] int32 = category code of item n (category_id[reverse_item[n]], any injective coding: only != is used).
+ * The counts are exact integers; the reference's score / (n (n - 1)) and score / (n len(inSeq)) are left to the host
+ * (int / int in double precision, as Python does).  k <= 64. */
+int tcar_eval_diversity(int B, int T, int k, int n_items, const int32_t* topk, const int32_t* seq, const int32_t* cat,
+                        int32_t* ild_cnt, int32_t* unexp_cnt, int32_t* n_rec, uint8_t* seen, void* stream);
+
 /* ---- optimizer (model_combine.py:155-163) ---------------------------------------------------------------------
  * Segments of one flat fp32 arena (identical offsets in w, g, m, v). */
 typedef struct {
@@ -432,6 +516,14 @@ int tcar_mha_core_fwd(int N, int Tq, int Tk, int C, int heads, int causal, const
 int tcar_mha_core_bwd(int N, int Tq, int Tk, int C, int heads, int causal, const float* Q, const float* K, const float* V,
                       const float* P, const float* key_mask, const float* query_mask, const float* dO, float* dQ, float* dK,
                       float* dV, void* stream);
+
+/* ..._tuned: mha_mfma = 0 forces the scalar form */
+int tcar_mha_core_fwd_tuned(const tcar_tuning_t* tune, int N, int Tq, int Tk, int C, int heads, int causal, const float* Q,
+                            const float* K, const float* V, const float* key_mask, const float* query_mask, float* O, float* P,
+                            void* stream);
+int tcar_mha_core_bwd_tuned(const tcar_tuning_t* tune, int N, int Tq, int Tk, int C, int heads, int causal, const float* Q,
+                            const float* K, const float* V, const float* P, const float* key_mask, const float* query_mask,
+                            const float* dO, float* dQ, float* dK, float* dV, void* stream);
 
 /* ---- optional op, NOT on TCAR's executed graph: `normalize` of modules.py:194-218 (layer normalisation over the last axis):
  * y = gamma * (x - mean) / sqrt(var + eps) + beta with the biased variance of tf.nn.moments; stats [M, 2] = (mean, 1/std) is
@@ -539,12 +631,8 @@ int tcar_shard_unpack_head(int Bq, int ek, int K, const float* head, int64_t ld,
 int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t* seq, float* rows, int64_t ld, int B,
                         const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
-/* Diagnostic hook (tests, profiling tools): override one of the TCAR_* tuning switches at run time (they are otherwise read
- * from the environment once per process).  Returns the previous value, INT_MIN for an unknown name.  Not for product code. */
-int tcar_set_tuning(const char* name /*host*/, int value);
-
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 20
+#define TCAR_ABI_VERSION 21
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -627,17 +715,32 @@ typedef struct {
   /* optional planes of the one-hot form of the candidate-side time scores (training steps with the softmax epilogue): oh16
    * [ceil128(N), 160] from tcar_time_onehot (static), p16h / p16l [ceil128(B), 160] written by tcar_time_scores every step */
   void* oh16; void* p16h; void* p16l;
+  /* optional buffers of the one-hot form of the scoring GRADIENTS (with oh16 / p16*; ldt = 64): tclip [160 ldt + 320] clipped time
+   * rows + scales (tcar_time_scores_clip), dP [B, 160] = dlogits OH, qz [5 N, 2] the per-candidate (||gy||^2, x . gy) pairs.  With
+   * them a training step writes no [N, 5 ldt] block of dE, its dX contracts 2 ldh + 160 columns, and the candidate-side time planes
+   * of E are NOT refreshed by training steps (nothing of a training step reads them; evaluation refreshes them) */
+  float* tclip; float* dP; float* qz;
   /* optional words of the flag forks (step.hip fork_arm / fork_go): sig_dev = 33 zeroed device words (16 workgroup counters,
-   * 16 flags, 1 error count), sig_epoch = ONE host word the driver counts forks in.  With them the main stream records no
-   * event where a side stream is forked: the producing kernel publishes a flag, a one-wave kernel of the side stream polls it.
-   * The engine must raise when sig_dev[32] != 0 (a poll gave up: the streams do not run concurrently). */
-  uint32_t* sig_dev; uint32_t* sig_epoch /*host*/;
+   * 16 flags, 1 error count), fork_host = tcar_fork_state_bytes() zeroed HOST bytes owned by this context (the driver's fork
+   * slots and epoch counter live there — nothing is kept per thread or per process, so contexts may be stepped from different
+   * host threads).  With them the main stream records no event where a side stream is forked: the producing kernel publishes a
+   * flag, a one-wave kernel of the side stream polls it.  sig_err_host: optional DEVICE-ACCESSIBLE HOST word (pinned, mapped),
+   * zeroed: a poll that gives up (the streams do not run concurrently) also counts there with a system-scope atomic, so the
+   * host can test it after every step without synchronising; the engine raises when it or sig_dev[32] is non-zero. */
+  uint32_t* sig_dev; void* fork_host /*host*/; uint32_t* sig_err_host;
+  /* optional tuning copy of THIS context (NULL = the process-wide values, tcar_tuning_defaults) */
+  const tcar_tuning_t* tune /*host*/;
 } tcar_ctx_t;
 
 /* Probe before setting tcar_ctx_t.sig_dev: does a polling kernel on `side_stream` run beside a kernel enqueued BEHIND it on
  * `main_stream`?  *concurrent = 0 (a tool serialises kernels, or the two streams share a hardware queue): leave sig_dev NULL.
  * Synchronises both streams; costs one 20-ms time-out when the answer is no. */
 int tcar_flag_fork_selftest(uint32_t* sig_dev, void* main_stream, void* side_stream, int32_t* concurrent);
+/* bytes of tcar_ctx_t.fork_host */
+int64_t tcar_fork_state_bytes(void);
+/* diagnostic: one polling kernel on `stream` that gives up after ~10 us (it waits for an epoch nobody publishes): sig_dev[32] and
+ * *err_host (may be NULL) each count one time-out — what a step whose streams do not overlap leaves behind */
+int tcar_flag_poll_expire(uint32_t* sig_dev, uint32_t* err_host /* device-accessible host word */, void* stream);
 
 /* forward through the full-catalog logits (model_combine.py:52-138); refresh_time != 0 rebuilds E[:, ic:ek] first */
 int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream);

@@ -20,14 +20,14 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 20          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 21          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_time_onehot", "tcar_time_scores", "tcar_query_mlp", "tcar_flag_fork_selftest", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_time_onehot", "tcar_time_scores", "tcar_time_scores_clip", "tcar_gemm_bf16_dx_onehot", "tcar_reduce_dact_onehot", "tcar_gemm_bf16_de_qz", "tcar_cand_time_bwd_onehot", "tcar_query_mlp", "tcar_flag_fork_selftest", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
-           "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows",
+           "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows", "tcar_eval_diversity",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_clip_adam_rest_keep", "tcar_abi_version", "tcar_build_id", "tcar_set_tuning", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_clip_adam_rest_keep", "tcar_abi_version", "tcar_build_id", "tcar_tuning_defaults", "tcar_tuning_set", "tcar_fork_state_bytes", "tcar_flag_poll_expire", "tcar_gather_clip_fwd_tuned", "tcar_gemm_bf16_tuned", "tcar_mha_core_fwd_tuned", "tcar_mha_core_bwd_tuned", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
            "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_grad", "tcar_neg_scatter_range",
            "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_attn_pool_fwd_slabs", "tcar_attn_pool_bwd_slabs", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
@@ -197,7 +197,35 @@ class Ctx(C.Structure):
                    ("proj_slabs", C.c_void_p), ("proj_slab_floats", C.c_int64),
                    ("ce_ws", C.c_void_p), ("ce_ws_floats", C.c_int64), ("ce_geo", C.c_void_p),
                    ("oh16", C.c_void_p), ("p16h", C.c_void_p), ("p16l", C.c_void_p),
-                   ("sig_dev", C.c_void_p), ("sig_epoch", C.c_void_p)])
+                   ("tclip", C.c_void_p), ("dP", C.c_void_p), ("qz", C.c_void_p),
+                   ("sig_dev", C.c_void_p), ("fork_host", C.c_void_p), ("sig_err_host", C.c_void_p), ("tune", C.c_void_p)])
+
+
+TUNING_FIELDS = ["bf16_tile", "rest_grid", "softmax_variant", "wgrad_ks", "gather_big_rows", "gather_wg_per_cu", "mha_mfma",
+                 "sort_scatter", "bf16_ks", "det_small", "x3_oneshot", "fused_ce", "onehot_time", "proj_split", "fork_delay",
+                 "flag_fork"]
+
+
+class Tuning(C.Structure):
+    """mirror of tcar_tuning_t: a caller-owned copy of the TCAR_* switches (tcar_ctx_t.tune, the *_tuned entry points)"""
+    _fields_ = [(n, C.c_int32) for n in TUNING_FIELDS]
+
+
+def tuning(**overrides) -> Tuning:
+    """The process-wide switch values (shipped defaults + TCAR_* environment) with `overrides` applied, e.g.
+    tuning(TCAR_BF16_TILE=384) or tuning(bf16_tile=384).  The library itself keeps no mutable switch."""
+    lib = load()
+    t = Tuning()
+    check(lib.tcar_tuning_defaults(C.byref(t)), "tcar_tuning_defaults")
+    for k, v in overrides.items():
+        if k.startswith("TCAR_"):
+            if lib.tcar_tuning_set(C.byref(t), k.encode(), int(v)) == -2 ** 31:
+                raise KeyError(k)
+        else:
+            if k not in TUNING_FIELDS:
+                raise KeyError(k)
+            setattr(t, k, int(v))
+    return t
 
 
 class TcarError(RuntimeError):
@@ -265,6 +293,7 @@ def load() -> C.CDLL:
     lib.tcar_dact_colsum.argtypes = [i32, i32, i64, vp, vp, vp, i32, vp]
     lib.tcar_rank_topk.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp, vp]
     lib.tcar_eval_rows.argtypes = [i32, i32, vp, i64, vp, i32, vp, vp, vp, vp]
+    lib.tcar_eval_diversity.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.tcar_sqnorm.argtypes = [vp, P(Segments), vp, vp]
     lib.tcar_clip_adam.argtypes = [vp, vp, vp, vp, P(Segments), vp, vp, vp, f32, f32, f32, f32, f32, vp]
     lib.tcar_clip_adam_all.argtypes = [vp, vp, vp, vp, P(Segments), vp, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp, f32, f32,
@@ -277,6 +306,11 @@ def load() -> C.CDLL:
                                       vp, i32, vp, vp, vp]
     lib.tcar_time_onehot.argtypes = [P(Dims), vp, vp, i64, vp]
     lib.tcar_time_scores.argtypes = [P(Dims), P(vp * 5), i32, vp, i64, vp, vp, i64, vp]
+    lib.tcar_time_scores_clip.argtypes = [P(Dims), P(vp * 5), i32, vp, i64, vp, vp, i64, vp, vp]
+    lib.tcar_gemm_bf16_dx_onehot.argtypes = [i32, i32, i32, vp, i64, i64, vp, i64, i64, vp, i64, vp, i64, i32, vp]
+    lib.tcar_reduce_dact_onehot.argtypes = [vp, i32, i32, i32, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp]
+    lib.tcar_gemm_bf16_de_qz.argtypes = [i32, i32, vp, i64, i64, vp, i64, i64, i32, vp, i64, vp, vp, vp, vp, i32, vp]
+    lib.tcar_cand_time_bwd_onehot.argtypes = [P(Dims), i32, vp, vp, vp, vp, i64, vp, vp, P(Grads), vp]
     lib.tcar_ce_finish.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.tcar_layernorm_fwd.argtypes = [i64, i32, vp, vp, vp, f32, vp, vp, vp]
     lib.tcar_layernorm_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -305,7 +339,15 @@ def load() -> C.CDLL:
     lib.tcar_segsum_norms_buffer.argtypes = [P(Dims), P(Batch), vp]
     lib.tcar_segsum_apply.argtypes = [P(Dims), P(Batch), vp, i64, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, f32, vp, vp]
     lib.tcar_sqnorm_det.argtypes = [vp, i64, vp, i64, vp]
-    lib.tcar_set_tuning.argtypes = [C.c_char_p, i32]
+    lib.tcar_tuning_defaults.argtypes = [vp]
+    lib.tcar_tuning_set.argtypes = [vp, C.c_char_p, i32]
+    lib.tcar_fork_state_bytes.restype = C.c_int64
+    lib.tcar_fork_state_bytes.argtypes = []
+    lib.tcar_flag_poll_expire.argtypes = [vp, vp, vp]
+    lib.tcar_gather_clip_fwd_tuned.argtypes = [vp] + lib.tcar_gather_clip_fwd.argtypes
+    lib.tcar_gemm_bf16_tuned.argtypes = [vp] + lib.tcar_gemm_bf16.argtypes
+    lib.tcar_mha_core_fwd_tuned.argtypes = [vp] + lib.tcar_mha_core_fwd.argtypes
+    lib.tcar_mha_core_bwd_tuned.argtypes = [vp] + lib.tcar_mha_core_bwd.argtypes
     lib.tcar_step_session_forward.argtypes = [P(Ctx), P(Batch), vp]
     lib.tcar_shard_score.argtypes = [P(Ctx), P(Shard), i32, vp]
     lib.tcar_shard_backward.argtypes = [P(Ctx), P(Shard), vp, vp]

@@ -558,6 +558,7 @@ struct ScoreArgs {
   const float* attout; long ld_att;
   int B, in32;
   __bf16* ph; __bf16* pl;
+  float* tclip;        // optional [160 ldt | 160 | 160]: clipped table rows, their clip scales, 1.0 where the clip is active
 };
 // One workgroup = 16 session rows x ONE table (grid.y = 5): its raw rows (<= 61), their clip scales and the 16 x ldt block of
 // attout are staged with independent loads (one memory round trip), the dots run out of LDS — thread (b, rg) takes rows rg, rg +
@@ -588,6 +589,13 @@ __global__ __launch_bounds__(256) void time_scores_kernel(const ScoreArgs a) {
     if (valid) {
       st4(tl + row * ls + lin * 4, x);
       if (lin == 0) sc[row] = clip_scale(ss);
+      if (a.tclip && blockIdx.x == 0) {      // the step's backward kernels read the clipped rows from here (one writer per table)
+        st4(a.tclip + (long)(off + row) * ldt + lin * 4, scale4(x, clip_scale(ss)));
+        if (lin == 0) {
+          a.tclip[160 * ldt + off + row] = clip_scale(ss);
+          a.tclip[160 * ldt + 160 + off + row] = ss > 1.0f ? 1.0f : 0.0f;
+        }
+      }
     }
   }
   for (int f = tid; f < 16 * sub; f += 256) {
@@ -786,6 +794,57 @@ __global__ __launch_bounds__(64) void cand_time_bwd_piece_kernel(const CandArgs 
   const float* pc = ws + (long)139 * CT_CHUNKS * (a.d.ldt + 4) + time_rowoff(k);
   const float s = wave_sum(lane < time_vocab(k) ? pc[lane] : 0.f);
   if (lane == 0) atomicAdd(a.g.sqn + pick5(a.g.slot_time, k), s);
+}
+
+// ---- candidate-side time gradient of the ONE-HOT form (round 4): no [N, 5 ldt] block of dE exists ---------------------------------
+// The dE GEMM's epilogue (gemm_bf16.hip, EPI = 2) left, per (candidate n, table k) in the order of the inverted index,
+// (q, z) = (||gy||^2, x . gy) for gy = dE[n, time block k] and x = the CLIPPED row the candidate looks up; the dX GEMM left
+// dP = dlogits OH [B, 160] (summed over its split-K slabs by tcar_reduce_dact_onehot).  With the list of row r:
+//   Q = sum q,  D2c = sum z^2,  S = sum_n gy_n = sum_b dP[b, r] attout_t,k[b, :]          (the list sum is LINEAR in dlogits)
+//   clipped row (x = raw * sc, sc = 1 / ||raw||):  sum gx = sc (S - x (x . S)),  sum ||gx||^2 = sc^2 (Q - D2c);  else S, Q
+// One workgroup per table row, fixed summation orders (bit-for-bit repeatable).  ldt = 64.
+__global__ __launch_bounds__(256) void cand_time_bwd_onehot_kernel(int B, int ek, int ic, const float2* __restrict__ qz,
+                                                                  const int32_t* __restrict__ inv_off, const float* __restrict__ dP,
+                                                                  const float* __restrict__ attout, const float* __restrict__ tclip,
+                                                                  float* __restrict__ g_time, float* __restrict__ pc_out) {
+  __shared__ __attribute__((aligned(16))) float shS[16 * 64];
+  __shared__ float shQ[256], shD[256];
+  const int tid = threadIdx.x;
+  const int r = blockIdx.x;
+  const int k = r < 13 ? 0 : r < 45 ? 1 : r < 53 ? 2 : r < 78 ? 3 : 4;
+  const int lo = inv_off[r], hi = inv_off[r + 1];
+  float Q = 0.f, D2 = 0.f;
+  for (int i = lo + tid; i < hi; i += 256) {
+    const float2 v = qz[i];
+    Q += v.x;
+    D2 = fmaf(v.y, v.y, D2);
+  }
+  shQ[tid] = Q; shD[tid] = D2;
+  const int j4 = tid & 15, bg = tid >> 4;
+  float4 S = zero4();
+  const float* ap = attout + ic + k * 64 + j4 * 4;
+  for (int b = bg; b < B; b += 16) S = fma4(ld4(ap + (long)b * ek), dP[(long)b * 160 + r], S);
+  st4(shS + bg * 64 + j4 * 4, S);
+  __syncthreads();
+  if (tid < 16) {
+    S = zero4(); Q = 0.f; D2 = 0.f;
+    for (int g2 = 0; g2 < 16; ++g2) S = add4(S, ld4(shS + g2 * 64 + tid * 4));
+    for (int t = tid; t < 256; t += 16) { Q += shQ[t]; D2 += shD[t]; }     // lane t of 16 takes every 16th partial, in order
+    Q = group_sum(Q, 16);
+    D2 = group_sum(D2, 16);
+    const float4 x = ld4(tclip + (long)r * 64 + tid * 4);
+    const float sc = tclip[160 * 64 + r];
+    const bool clipped = tclip[160 * 64 + 160 + r] != 0.f;
+    const float xs = group_sum(dot4(x, S), 16);
+    float4 gx = S;
+    float pc = Q;
+    if (clipped) {
+      gx = scale4(fma4(x, -xs, S), sc);
+      pc = sc * sc * (Q - D2);
+    }
+    atomic_add4(g_time + (long)r * 64 + tid * 4, gx);      // (the session-side small-table backward adds into the same rows)
+    if (tid == 0) pc_out[r] = pc;
+  }
 }
 
 // g_item[ids[r]-1] += rows[r]: one wave per row, 256-byte-contiguous float atomics
@@ -1020,18 +1079,31 @@ int grid_for_rows(long rows) {
 
 extern "C" int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt,
                                     float* x_icp, float* x_pt, float* x_act, float* click_t, void* stream) {
+  return tcar_gather_clip_fwd_o(d, tab, bt, x_icp, x_pt, x_act, click_t, stream, nullptr);
+}
+extern "C" int tcar_gather_clip_fwd_tuned(const tcar_tuning_t* tune, const tcar_dims_t* d, const tcar_tables_t* tab,
+                                          const tcar_batch_t* bt, float* x_icp, float* x_pt, float* x_act, float* click_t,
+                                          void* stream) {
+  TcarOpt o;
+  o.tune = tune;
+  return tcar_gather_clip_fwd_o(d, tab, bt, x_icp, x_pt, x_act, click_t, stream, &o);
+}
+// (flag-capable in the latency form: the click rows leave write-through when the launch carries a flag; the throughput form is not)
+int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, float* x_icp, float* x_pt,
+                           float* x_act, float* click_t, void* stream, TcarOpt* o) {
+  const TcarTuning& tn = tcar_tn(o);
   if (check_dims(d) || !tab || !bt || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   EmbArgs a{};
   a.d = *d; a.tab = *tab; a.bt = *bt;
   a.x_icp = x_icp; a.x_pt = x_pt; a.x_act = x_act; a.click_t = click_t;
   const long rows = (long)bt->B * bt->T;
   const size_t big_lds = ((size_t)TCAR_POS_VOCAB * d->ldh + (size_t)SMALL_ROWS * d->ldt) * sizeof(float);
-  if (rows >= tcar_tuning().gather_big_rows && big_lds <= 160 * 1024) {
+  if (rows >= tn.gather_big_rows && big_lds <= 160 * 1024) {
     // throughput form: one 16-wave workgroup per CU (the clipped small tables live in its LDS)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     long g = (rows + 16 * 4 - 1) / (16 * 4);
-    const long cap = (long)cus * (tcar_tuning().gather_wg_per_cu > 0 ? tcar_tuning().gather_wg_per_cu : 1);
+    const long cap = (long)cus * (tn.gather_wg_per_cu > 0 ? tn.gather_wg_per_cu : 1);
     if (g > cap) g = cap;
     if (d->ldh <= 256) {
       TCAR_SET_LDS_ONCE(gather_clip_fwd_big_kernel<1>, 160 * 1024);
@@ -1044,7 +1116,7 @@ extern "C" int tcar_gather_clip_fwd(const tcar_dims_t* d, const tcar_tables_t* t
     return TCAR_OK;
   }
   const int grid = grid_for_rows((long)bt->B * bt->T + bt->B);
-  a.sig = tcar_take_signal();
+  a.sig = tcar_sig(o);
   if (d->ldh <= 256) TCAR_LAUNCH(gather_clip_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   else TCAR_LAUNCH(gather_clip_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
@@ -1121,6 +1193,28 @@ extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* con
   return TCAR_OK;
 }
 
+// One-hot form of tcar_cand_time_bwd_indexed (see cand_time_bwd_onehot_kernel): qz [5 N] float2 in inverted-index order from
+// tcar_gemm_bf16_de_qz, dP [B, 160] from tcar_reduce_dact_onehot, tclip from tcar_time_scores_clip; adds into g->g_time and the
+// norm pieces exactly as tcar_cand_time_bwd_indexed does (same workspace ws).  ldt must be 64.
+extern "C" int tcar_cand_time_bwd_onehot(const tcar_dims_t* d, int B, const int32_t* inv_off, const float* qz, const float* dP,
+                                         const float* attout, int64_t ld_att, const float* tclip, float* ws, const tcar_grads_t* g,
+                                         void* stream) {
+  if (check_dims(d) || d->ldt != 64 || B <= 0 || !inv_off || !qz || !dP || !attout || !tclip || !ws || !g || (ld_att & 3) ||
+      !tcar_aligned16(attout) || !tcar_aligned16(tclip))
+    return TCAR_E_ARG;
+  CandArgs a{};
+  a.d = *d;
+  a.g = *g;
+  float* pc = ws + (long)139 * CT_CHUNKS * (d->ldt + 4);
+  hipStream_t st = (hipStream_t)stream;
+  TCAR_LAUNCH(cand_time_bwd_onehot_kernel, dim3(139), dim3(256), 0, st, B, (int)ld_att, 2 * d->ldh, (const float2*)qz, inv_off, dP,
+              attout, tclip, g->g_time[0], pc);
+  TCAR_CHECK_LAUNCH();
+  TCAR_LAUNCH(cand_time_bwd_piece_kernel, dim3(5), dim3(64), 0, st, a, (const float*)ws);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
 extern "C" int tcar_cand_time_ws_floats(const tcar_dims_t* d) { return d ? 139 * CT_CHUNKS * (d->ldt + 4) + 144 : 0; }
 
 extern "C" int tcar_scatter_add_rows(const tcar_dims_t* d, const int32_t* ids, const float* rows, int64_t R,
@@ -1193,6 +1287,12 @@ extern "C" int tcar_small_det_ws_floats(void) { return SMALL_DET_ROWS; }
 extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                          const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g,
                                          float* ws, void* stream) {
+  return tcar_small_tables_bwd_det_o(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, ws, stream, nullptr);
+}
+// (flag-capable: the norm fold, its last launch, publishes its slots with atomics)
+int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
+                                const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
+                                void* stream, TcarOpt* o) {
   if (check_dims(d) || !tab || !bt || !g || !ws || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   if (!dx_icp || !dx_pt || !dx_act || !dclick || !g->g_pos || !g->g_time[0] || !g->sqn) return TCAR_E_ARG;
   SmallDetArgs a{};
@@ -1206,7 +1306,7 @@ extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables
   else TCAR_LAUNCH(small_tables_bwd_det_kernel<8>, dim3(rows), dim3(1024), 0, st, a);
   TCAR_CHECK_LAUNCH();
   TCAR_LAUNCH(small_norm_fold_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, bt->T, g->sqn, g->slot_pos, g->slot_time[0],
-              g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur, tcar_take_signal());
+              g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur, tcar_sig(o));
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -1227,12 +1327,17 @@ extern "C" int tcar_time_onehot(const tcar_dims_t* d, const int32_t* mwdhm, void
 // KB32 planes [ceil128(B), inner] (columns >= 139 and rows >= B zero): the A operand of the one-hot K segment of the logits GEMM
 extern "C" int tcar_time_scores(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* attout, int64_t ld_att,
                                 void* p_hi, void* p_lo, int64_t inner, void* stream) {
+  return tcar_time_scores_clip(d, time_tab, B, attout, ld_att, p_hi, p_lo, inner, nullptr, stream);
+}
+extern "C" int tcar_time_scores_clip(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* attout,
+                                     int64_t ld_att, void* p_hi, void* p_lo, int64_t inner, float* tclip, void* stream) {
   if (check_dims(d) || !time_tab || B <= 0 || !attout || !p_hi || !p_lo || (inner & 31) || inner < 160 || (ld_att & 3)) return TCAR_E_ARG;
   ScoreArgs a{};
   a.d = *d;
   for (int k = 0; k < 5; ++k) a.tab[k] = time_tab[k];
   a.attout = attout; a.ld_att = ld_att; a.B = B; a.in32 = (int)(inner >> 5);
   a.ph = (__bf16*)p_hi; a.pl = (__bf16*)p_lo;
+  a.tclip = tclip;
   const long Bp = ((long)B + 127) & ~127L;
   const size_t lds = ((size_t)(61 + 16) * (d->ldt + 4) + 64) * sizeof(float);
   const dim3 grid((unsigned)(Bp / 16), 5);

@@ -58,7 +58,21 @@ struct BArgs {
   __bf16* p_hi; int p_in32;    // plane [ceil128(M), 32 * p_in32]
   float* stats; int ngroups;   // [M, ngroups, 2]
   const int32_t* label; float* lab_logit;
+  // dX of the one-hot form (layout 0, hi planes only): N tiles at or beyond column n_b2 (a multiple of the tile width) read their B
+  // operand from the plane B2 (inner b2_in32 * 32, rows as B) at column n0 - n_b2 — the static one-hot matrix of
+  // publish_time_MWDHM, so that those output columns are dP = dlogits OH instead of dlogits E_time.  0: unused.
+  int n_b2;
+  // dE with the (q, z) epilogue (EPI = 2, tcar_gemm_bf16_de_qz): output columns >= csplit are the candidate-side time block; it is
+  // not stored — per catalog row n and table k the kernel leaves q = ||gy||^2 and z = clip(table row) . gy of the 64-column
+  // gradient gy = dE[n, csplit + 64 k ...] at qz[perm[k * M + n]] (perm: position in the inverted index of publish_time_MWDHM)
+  const int32_t* mwdhm; const float* tclip; float2* qz;
 };
+// rows of the month | day | week | hour | minute tables (model_combine.py:73-81) inside their concatenation
+__device__ __forceinline__ int cand_row(const int32_t* __restrict__ mwdhm, long n, int k) {
+  const int voc = k == 0 ? 13 : k == 1 ? 32 : k == 2 ? 8 : k == 3 ? 25 : 61;
+  const int off = k == 0 ? 0 : k == 1 ? 13 : k == 2 ? 45 : k == 3 ? 53 : 78;
+  return off + clampi(mwdhm[n * 5 + k], 0, voc - 1);
+}
 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef __attribute__((address_space(1))) const void* glb_vp;
@@ -117,6 +131,17 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
   int tm, tn;
   if (g.n_fastest) { tm = id / g.nt; tn = id - tm * g.nt; } else { tn = id / g.mt; tm = id - tn * g.mt; }
   const int m0 = tm * TM, n0 = tn * TN;
+  // (workgroup-uniform) this N tile reads the second B plane: dX columns of the one-hot time block
+  const bool b2tile = (SEG2 == 0 && NSPLIT == 1) && g.n_b2 > 0 && n0 >= g.n_b2;
+  // (wave-uniform, EPI = 2) this wave's 64 output columns are one table's block of the candidate-side time gradient: the two
+  // operand roles are SWAPPED for it — fragments of the B tile go in as the MFMA's first operand — so that its accumulators come
+  // out transposed (a lane owns one catalog row, its registers run over the 64 columns) and the row reductions of the epilogue
+  // are in-register sums.  Both operands of this layout are read with the same transposing fragment loader: the swap is two
+  // base pointers, the K loop is unchanged.
+  const bool tw = (EPI == 2) && (n0 + wn * (32 * TNW) >= g.csplit);
+  static_assert(EPI != 2 || (MA == 1 && MB == 1 && TMW == TNW && TNW == 2 && NSPLIT == 1), "EPI = 2: dE layout, 64 x 64 per wave, hi planes");
+  const int a_off = tw ? A_BYTES : 0, b_off = tw ? 0 : A_BYTES;
+  const int a_base = tw ? wn * (32 * TNW) : wm * (32 * TMW), b_base = tw ? wm * (32 * TMW) : wn * (32 * TNW);
   const int ks = split * g.kchunk;
   const int ke = min(g.K, ks + g.kchunk);
   const int nkb = (ke - ks) / KB;
@@ -147,10 +172,10 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
         const bool isA = rem < A_CP;
         const int ci = isA ? rem : rem - A_CP;
         if (SEG2 && seg2 && !isA && p == 1) continue;    // the second segment's B operand has ONE plane
-        const __bf16* P = (SEG2 && seg2) ? (isA ? g.A2[p] : g.B2) : (isA ? g.A[p] : g.B[p]);
-        const int in32 = (SEG2 && seg2) ? (isA ? g.a2_in32 : g.b2_in32) : (isA ? g.a_in32 : g.b_in32);
+        const __bf16* P = (SEG2 && seg2) ? (isA ? g.A2[p] : g.B2) : (isA ? g.A[p] : (b2tile ? g.B2 : g.B[p]));
+        const int in32 = (SEG2 && seg2) ? (isA ? g.a2_in32 : g.b2_in32) : (isA ? g.a_in32 : (b2tile ? g.b2_in32 : g.b_in32));
         const int nrb = (SEG2 && seg2) ? (isA ? g.a2_rb : g.b2_rb) : (isA ? g.a_rb : g.b_rb);
-        const int mode = isA ? MA : MB, t0 = isA ? m0 : n0;
+        const int mode = isA ? MA : MB, t0 = isA ? m0 : (b2tile ? n0 - g.n_b2 : n0);
         long src;
         bool ok;
         if (mode == 0) {          // k-contiguous: 8 copies per 8-KB block (rows t0.., inner block k0/32)
@@ -179,12 +204,12 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
 #pragma unroll
       for (int p = 0; p < NP; ++p)
 #pragma unroll
-        for (int u = 0; u < TMW; ++u) a[p][u] = frag<MA>(St + p * PL, wm * (32 * TMW) + u * 32, s, lane);
+        for (int u = 0; u < TMW; ++u) a[p][u] = frag<MA>(St + p * PL + (EPI == 2 ? a_off : 0), (EPI == 2 ? a_base : wm * (32 * TMW)) + u * 32, s, lane);
 #pragma unroll
       for (int t2 = 0; t2 < TNW; ++t2) {          // one B tile at a time: its fragments die after TMW * NSPLIT MFMAs
         bf16x8 b[NPB];
 #pragma unroll
-        for (int p = 0; p < NPB; ++p) b[p] = frag<MB>(St + p * PL + A_BYTES, wn * (32 * TNW) + t2 * 32, s, lane);
+        for (int p = 0; p < NPB; ++p) b[p] = frag<MB>(St + p * PL + (EPI == 2 ? b_off : A_BYTES), (EPI == 2 ? b_base : wn * (32 * TNW)) + t2 * 32, s, lane);
 #pragma unroll
         for (int u = 0; u < TMW; ++u) {
           if constexpr (EPI == 1) {     // transposed accumulator tile (rows = catalog columns, lane = session): see the epilogue
@@ -279,6 +304,34 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
     tcar_signal_done(g.sig);
     return;
   }
+  if constexpr (EPI == 2) {
+    if (tw) {
+      // (q, z) epilogue of a time-block wave.  acc[u][t2][e]: lane li owns catalog row n of row block t2, its registers run over the
+      // table's columns c = 32 u + 4 lh + (e & 3) + 8 (e >> 2).  The Jacobian of max_norm = 1 needs, per (n, k), only
+      // q = ||gy||^2 and z = x . gy against the clipped table row x the candidate looked up (embed.hip: cand_time_bwd_onehot).
+      const int k = (n0 + wn * (32 * TNW) - g.csplit) >> 6;
+#pragma unroll
+      for (int t2 = 0; t2 < TNW; ++t2) {
+        const long n = m0 + wm * (32 * TMW) + t2 * 32 + li;
+        const bool live = n < g.M;
+        const float* xr = g.tclip + (long)(live ? cand_row(g.mwdhm, n, k) : 0) * 64 + 4 * lh;
+        float q = 0.f, z = 0.f;
+#pragma unroll
+        for (int u = 0; u < TMW; ++u)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const float4 xv = ld4(xr + 32 * u + 8 * q4);
+            const float v0 = acc[u][t2][4 * q4], v1 = acc[u][t2][4 * q4 + 1], v2 = acc[u][t2][4 * q4 + 2], v3 = acc[u][t2][4 * q4 + 3];
+            q = fmaf(v0, v0, q); q = fmaf(v1, v1, q); q = fmaf(v2, v2, q); q = fmaf(v3, v3, q);
+            z = fmaf(v0, xv.x, z); z = fmaf(v1, xv.y, z); z = fmaf(v2, xv.z, z); z = fmaf(v3, xv.w, z);
+          }
+        q += __shfl_xor(q, 32);
+        z += __shfl_xor(z, 32);
+        if (live && lh == 0) g.qz[g.perm[(long)k * g.M + n]] = make_float2(q, z);
+      }
+      return;
+    }
+  }
   float* C1 = g.C + (g.mode == 1 ? (long)split * g.M * g.ldc : 0L);
 #pragma unroll
   for (int u = 0; u < TMW; ++u)
@@ -349,21 +402,24 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
-// dry-run sink of tcar_gemm_bf16_variant: when set (host, per call, thread local) the chosen instantiation is named
-// instead of launched
-thread_local char* t_variant_out = nullptr;
-thread_local int t_variant_len = 0;
-// group geometry of the last softmax-epilogue launch of this host thread (tcar_gemm_bf16_ce returns it to its caller)
-thread_local int t_ce_gw = 0, t_ce_ngroups = 0;
+// host-side state of ONE launch call (on the caller's stack): launch options (tuning copy, completion flag), the dry-run sink of
+// tcar_gemm_bf16_variant (when set the chosen instantiation is named instead of launched) and the group geometry a
+// softmax-epilogue launch reports back to tcar_gemm_bf16_ce
+struct LaunchCall {
+  TcarOpt* o = nullptr;
+  char* variant_out = nullptr;
+  int variant_len = 0;
+  int ce_gw = 0, ce_ngroups = 0;
+};
 
 template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW, int TNW, int KS>
-int launch_k(BArgs& g, int splitk, hipStream_t st) {
+int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
   constexpr int NT = 64 * WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW, NP = (NSPLIT == 1) ? 1 : 2;
   constexpr size_t lds = 2 * KS * NP * (TM + TN) * 64;
   g.mt = (g.M + TM - 1) / TM;
   g.nt = (g.N + TN - 1) / TN;
-  if (t_variant_out) {
-    snprintf(t_variant_out, t_variant_len, "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d, %d> tile %dx%dx%d grid %d", MA, MB, NSPLIT,
+  if (lc.variant_out) {
+    snprintf(lc.variant_out, lc.variant_len, "gemm_bf16_kernel<%d, %d, %d, %d, %d, %d, %d> tile %dx%dx%d grid %d", MA, MB, NSPLIT,
              WMW, WNW, TMW, TNW, TM, TN, 32 * KS, g.mt * g.nt * splitk);
     return TCAR_OK;
   }
@@ -371,9 +427,9 @@ int launch_k(BArgs& g, int splitk, hipStream_t st) {
     if constexpr (MA == 0 && MB == 0) {
       if (splitk != 1 || g.C2 != g.C) return TCAR_E_ARG;
       g.ngroups = g.nt * WNW;
-      t_ce_gw = 32 * TNW;
-      t_ce_ngroups = g.ngroups;
-      g.sig = tcar_take_signal();
+      lc.ce_gw = 32 * TNW;
+      lc.ce_ngroups = g.ngroups;
+      g.sig = tcar_sig(lc.o);
       if (g.B2) {
         if constexpr (NSPLIT == 3 && KS == 1) {
           TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1>), lds);
@@ -399,23 +455,23 @@ int launch_k(BArgs& g, int splitk, hipStream_t st) {
 }
 
 template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2>
-int launch_v(BArgs& g, int splitk, hipStream_t st) {
+int launch_v(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
   // measured at the Globo shape (hi-only backward): dX 68 -> 59 us with 64-deep stages; dE (192 x 192 tiles, three
   // workgroups per CU at 48 KB) loses its occupancy with 96 KB and slows down 129 -> 136 us, so it keeps 32-deep stages
   // (TCAR_BF16_KS: 1 = never, 2 = k-contiguous A operand only, 3 = always)
   if constexpr (NSPLIT == 1) {
-    const int ks = tcar_tuning().bf16_ks;
-    if (ks == 3 || (ks == 2 && MA == 0)) return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 2>(g, splitk, st);
+    const int ks = tcar_tn(lc.o).bf16_ks;
+    if (ks == 3 || (ks == 2 && MA == 0)) return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 2>(g, splitk, st, lc);
   }
-  return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 1>(g, splitk, st);
+  return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 1>(g, splitk, st, lc);
 }
 
 template <int MA, int MB>
-int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
+int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st, LaunchCall& lc) {
   // Tile choice.  The kernel is bound by the per-CU load path (~70 GB/s from L2): bytes per flop fall with the tile
   // area/perimeter ratio, so take the largest tile that still gives the chip about a full wave of workgroups:
   // 256 x 256 (16 waves, 64 KB per stage), then 256 x 128 (8 waves), else 128 x 128 (4 waves).
-  const int f = tcar_tuning().bf16_tile;
+  const int f = tcar_tn(lc.o).bf16_tile;
   const long w256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splitk;
   const long w128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
   if constexpr (MA == 0 && MB == 0) {
@@ -423,14 +479,14 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
     // shape moves 17 % fewer bytes per flop than 256 x 256; at the Globo catalog it is also ONE round of 240 workgroups
     // instead of 360 workgroups in 1.4 rounds
     const long w384 = (long)((g.M + 255) / 256) * ((g.N + 383) / 384) * splitk;
-    if (nsplit == 3 && (f == 384 || (f == 0 && w384 >= 200))) return launch_v<0, 0, 3, 2, 4, 4, 3>(g, splitk, st);
+    if (nsplit == 3 && (f == 384 || (f == 0 && w384 >= 200))) return launch_v<0, 0, 3, 2, 4, 4, 3>(g, splitk, st, lc);
   }
   if constexpr (MA == 0 && MB == 1) {
     // 512 x 128 (16 waves): the whole session batch is ONE M tile, so every dlogits stage is fetched once per N tile and
     // the fill bytes per flop drop 16 % against two 256 x 128 tiles (dX: 170 -> 147 us at split-K 36)
     const long w512 = (long)((g.M + 511) / 512) * ((g.N + 127) / 128) * splitk;
     if (f == 512 || (f == 0 && g.M > 256 && w512 >= 192))
-      return nsplit == 3 ? launch_v<0, 1, 3, 8, 2>(g, splitk, st) : launch_v<0, 1, 1, 8, 2>(g, splitk, st);
+      return nsplit == 3 ? launch_v<0, 1, 3, 8, 2>(g, splitk, st, lc) : launch_v<0, 1, 1, 8, 2>(g, splitk, st, lc);
   }
   if constexpr (MB == 1) {
     // 256 x 192 (12 waves): an N extent such as 576 = 3 x 192 wastes no MFMA work on padding columns (256-wide tiles
@@ -443,16 +499,16 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st) {
       const long r256 = (w256 > 0 ? ((long)((g.M + 255) / 256) * (n192 / 192) * splitk + 255) / 256 : 0) * 4;   // rounds x size
       const long r192 = ((w192 + 255) / 256) * 3;
       if (f == 193 || (f == 0 && w256 >= 224 && n192 < n256 && r192 < r256))
-        return nsplit == 3 ? launch_v<1, 1, 3, 6, 2, 1, 3>(g, splitk, st) : launch_v<1, 1, 1, 6, 2, 1, 3>(g, splitk, st);
+        return nsplit == 3 ? launch_v<1, 1, 3, 6, 2, 1, 3>(g, splitk, st, lc) : launch_v<1, 1, 1, 6, 2, 1, 3>(g, splitk, st, lc);
     }
     if (f == 192 || (f == 0 && w256 >= 224 && n192 < n256))
-      return nsplit == 3 ? launch_v<MA, MB, 3, 4, 3>(g, splitk, st) : launch_v<MA, MB, 1, 4, 3>(g, splitk, st);
+      return nsplit == 3 ? launch_v<MA, MB, 3, 4, 3>(g, splitk, st, lc) : launch_v<MA, MB, 1, 4, 3>(g, splitk, st, lc);
   }
   if (f == 256 || (f == 0 && w256 >= 224))
-    return nsplit == 3 ? launch_v<MA, MB, 3, 4, 4>(g, splitk, st) : launch_v<MA, MB, 1, 4, 4>(g, splitk, st);
+    return nsplit == 3 ? launch_v<MA, MB, 3, 4, 4>(g, splitk, st, lc) : launch_v<MA, MB, 1, 4, 4>(g, splitk, st, lc);
   if (f == 128 || (f == 0 && w128 >= 192))
-    return nsplit == 3 ? launch_v<MA, MB, 3, 4, 2>(g, splitk, st) : launch_v<MA, MB, 1, 4, 2>(g, splitk, st);
-  return nsplit == 3 ? launch_v<MA, MB, 3, 2, 2>(g, splitk, st) : launch_v<MA, MB, 1, 2, 2>(g, splitk, st);
+    return nsplit == 3 ? launch_v<MA, MB, 3, 4, 2>(g, splitk, st, lc) : launch_v<MA, MB, 1, 4, 2>(g, splitk, st, lc);
+  return nsplit == 3 ? launch_v<MA, MB, 3, 2, 2>(g, splitk, st, lc) : launch_v<MA, MB, 1, 2, 2>(g, splitk, st, lc);
 }
 
 }  // namespace
@@ -463,6 +519,15 @@ extern "C" int tcar_gemm_bf16(int layout, int M, int N, int K, const void* A_hi,
   return tcar_gemm_bf16_perm(layout, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, C, ldc, C2, ldc2,
                              csplit, nullptr, 0, nsplit, splitk, stream);
 }
+extern "C" int tcar_gemm_bf16_tuned(const tcar_tuning_t* tune, int layout, int M, int N, int K, const void* A_hi, const void* A_lo,
+                                    int64_t a_inner, int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner,
+                                    int64_t b_rows, float* C, int64_t ldc, float* C2, int64_t ldc2, int csplit, int nsplit,
+                                    int splitk, void* stream) {
+  TcarOpt o;
+  o.tune = tune;
+  return tcar_gemm_bf16_perm_o(layout, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, C, ldc, C2, ldc2, csplit,
+                               nullptr, 0, nsplit, splitk, stream, &o);
+}
 
 namespace {
 struct CeOut { void* p_hi; int64_t p_inner; float* stats; const int32_t* label; float* lab_logit;
@@ -470,16 +535,25 @@ struct CeOut { void* p_hi; int64_t p_inner; float* stats; const int32_t* label; 
 int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
                    const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
                    int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit, int splitk, const CeOut* ce,
-                   void* stream);
+                   void* stream, LaunchCall& lc);
 }  // namespace
 
 extern "C" int tcar_gemm_bf16_perm(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner,
                                    int64_t a_rows, const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows,
                                    float* C, int64_t ldc, float* C2, int64_t ldc2, int csplit, const int32_t* c2_perm,
                                    int c2_group, int nsplit, int splitk, void* stream) {
+  return tcar_gemm_bf16_perm_o(layout, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, C, ldc, C2, ldc2, csplit,
+                               c2_perm, c2_group, nsplit, splitk, stream, nullptr);
+}
+int tcar_gemm_bf16_perm_o(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
+                          const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
+                          int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit, int splitk, void* stream,
+                          TcarOpt* o) {
   if (!C) return (M <= 0 || N <= 0 || K <= 0) ? TCAR_OK : TCAR_E_ARG;
+  LaunchCall lc;
+  lc.o = o;
   return gemm_bf16_impl(layout, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, C, ldc, C2, ldc2, csplit,
-                        c2_perm, c2_group, nsplit, splitk, nullptr, stream);
+                        c2_perm, c2_group, nsplit, splitk, nullptr, stream, lc);
 }
 
 extern "C" int tcar_gemm_bf16_ce(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
@@ -487,6 +561,15 @@ extern "C" int tcar_gemm_bf16_ce(int M, int N, int K, const void* A_hi, const vo
                                  const void* A2_lo, const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner, int64_t p_rows,
                                  float* stats, int64_t stats_floats, const int32_t* label, float* lab_logit, int nsplit,
                                  int32_t* group_width, int32_t* ngroups, void* stream) {
+  return tcar_gemm_bf16_ce_o(M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, K1, A2_hi, A2_lo, B2_hi, inner2, p_hi,
+                             p_inner, p_rows, stats, stats_floats, label, lab_logit, nsplit, group_width, ngroups, stream, nullptr);
+}
+// (flag-capable: consumers behind its flag read nothing this launch writes — the flag only times the arena zero)
+int tcar_gemm_bf16_ce_o(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows, const void* B_hi,
+                        const void* B_lo, int64_t b_inner, int64_t b_rows, int K1, const void* A2_hi, const void* A2_lo,
+                        const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner, int64_t p_rows, float* stats,
+                        int64_t stats_floats, const int32_t* label, float* lab_logit, int nsplit, int32_t* group_width,
+                        int32_t* ngroups, void* stream, TcarOpt* o) {
   if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
   if (!p_hi || !stats || !label || !lab_logit || !group_width || !ngroups || (p_inner & 31) || p_inner < N || p_rows < M ||
       !tcar_aligned16(p_hi) || ((uintptr_t)stats & 7))
@@ -504,11 +587,13 @@ extern "C" int tcar_gemm_bf16_ce(int M, int N, int K, const void* A_hi, const vo
   }
   float dummy;
   (void)k_first;
+  LaunchCall lc;
+  lc.o = o;
   const int rc = gemm_bf16_impl(1, M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, &dummy, N, nullptr, 0, 0,
-                                nullptr, 0, nsplit, 1, &ce, stream);
+                                nullptr, 0, nsplit, 1, &ce, stream, lc);
   if (rc) return rc;
-  *group_width = t_ce_gw;
-  *ngroups = t_ce_ngroups;
+  *group_width = lc.ce_gw;
+  *ngroups = lc.ce_ngroups;
   return TCAR_OK;
 }
 
@@ -516,7 +601,7 @@ namespace {
 int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
                    const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
                    int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit, int splitk, const CeOut* ce,
-                   void* stream) {
+                   void* stream, LaunchCall& lc) {
   if (c2_perm && (!C2 || c2_group <= 0 || splitk > 1)) return TCAR_E_ARG;
   if (M <= 0 || N <= 0 || K <= 0) return TCAR_OK;
   if (layout < 0 || layout > 2 || !A_hi || !B_hi || !C || (nsplit != 1 && nsplit != 3)) return TCAR_E_ARG;
@@ -558,28 +643,110 @@ int gemm_bf16_impl(int layout, int M, int N, int K, const void* A_hi, const void
   g.nsk = splitk;
   g.n_fastest = (layout != 1);        // layouts 0 / 2 stream dlogits tiles that several N tiles re-read
   hipStream_t st = (hipStream_t)stream;
-  if (layout == 0) return launch_b<0, 1>(g, nsplit, splitk, st);
-  if (layout == 1) return launch_b<0, 0>(g, nsplit, splitk, st);
-  return launch_b<1, 1>(g, nsplit, splitk, st);
+  if (layout == 0) return launch_b<0, 1>(g, nsplit, splitk, st, lc);
+  if (layout == 1) return launch_b<0, 0>(g, nsplit, splitk, st, lc);
+  return launch_b<1, 1>(g, nsplit, splitk, st, lc);
 }
 }  // namespace
 
+// ---- one-hot form of the two scoring GRADIENT GEMMs (hi planes only) ------------------------------------------------
+// dX' = dlogits [E_item | E_content | OH]: the candidate-side time columns of the candidate matrix are five clipped table rows
+// per item, selected by publish_time_MWDHM (139 distinct rows), so dlogits E_time = (dlogits OH) T_clip with the static 0/1 matrix
+// OH [N, 160]: the GEMM contracts N against 2 ldh + 160 columns instead of 2 ldh + 5 ldt, and its last 160 columns are
+// dP [B, 160] (tcar_reduce_dact_onehot expands them).  Layout 0 of tcar_gemm_bf16; B2 = OH plane [Npad rows, inner2 >= 160].
+int tcar_gemm_bf16_dx_onehot_o(int M, int N1, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi,
+                               int64_t b_inner, int64_t b_rows, const void* B2_hi, int64_t inner2, float* C, int64_t ldc, int splitk,
+                               void* stream, TcarOpt* o) {
+  if (M <= 0 || N1 <= 0 || K <= 0) return TCAR_OK;
+  if (!A_hi || !B_hi || !B2_hi || !C || (a_inner & 31) || (b_inner & 31) || (inner2 & 31) || (K & 31) || (N1 & 127) || inner2 < 160 ||
+      a_inner < K || a_rows < M || b_inner < N1 || b_rows < K || ldc < N1 + 160 || !tcar_aligned16(A_hi) || !tcar_aligned16(B_hi) ||
+      !tcar_aligned16(B2_hi))
+    return TCAR_E_ARG;
+  BArgs g{};
+  g.A[0] = (const __bf16*)A_hi; g.B[0] = (const __bf16*)B_hi; g.B2 = (const __bf16*)B2_hi;
+  g.a_in32 = (int)(a_inner >> 5); g.b_in32 = (int)(b_inner >> 5); g.b2_in32 = (int)(inner2 >> 5);
+  g.a_rb = (int)((a_rows + 127) >> 7); g.b_rb = (int)((b_rows + 127) >> 7);
+  g.C = C; g.ldc = ldc; g.C2 = C; g.ldc2 = ldc; g.csplit = N1 + 160;
+  g.M = M; g.N = N1 + 160; g.K = K; g.K1 = K; g.n_b2 = N1;
+  if (splitk < 1) splitk = 1;
+  int kchunk = (K + splitk - 1) / splitk;
+  kchunk = ((kchunk + KB - 1) / KB) * KB;
+  g.kchunk = kchunk;
+  splitk = (K + kchunk - 1) / kchunk;
+  g.mode = splitk > 1 ? 1 : 0;
+  g.nsk = splitk;
+  g.n_fastest = 1;
+  LaunchCall lc;
+  lc.o = o;
+  return launch_b<0, 1>(g, 1, splitk, (hipStream_t)stream, lc);
+}
+extern "C" int tcar_gemm_bf16_dx_onehot(int M, int N1, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi,
+                                        int64_t b_inner, int64_t b_rows, const void* B2_hi, int64_t inner2, float* C, int64_t ldc,
+                                        int splitk, void* stream) {
+  return tcar_gemm_bf16_dx_onehot_o(M, N1, K, A_hi, a_inner, a_rows, B_hi, b_inner, b_rows, B2_hi, inner2, C, ldc, splitk, stream, nullptr);
+}
+
+// dE' = dlogits^T [attout_item | attout_time] with the (q, z) epilogue: the item block [M, ldh] goes to C as in tcar_gemm_bf16
+// (layout 2); the time block [M, 5 * 64] is NOT stored — per catalog row n and table k: qz[perm[k M + n]] = (||gy||^2, x . gy) with
+// gy = the 64-column gradient block and x = tclip row the candidate looks up.  A plane = dlogits [K rows = sessions, inner >= M],
+// B plane = packed attout [K rows, inner >= ldh + 320]; ldt must be 64.  tile: 0 = 192 x 192 (9 waves), 256 = 256 x 192 (12).
+int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi, int64_t b_inner,
+                           int64_t b_rows, int ldh, float* C, int64_t ldc, const int32_t* mwdhm, const int32_t* perm,
+                           const float* tclip, float* qz, int tile, void* stream, TcarOpt* o) {
+  if (M <= 0 || K <= 0) return TCAR_OK;
+  const int N = ldh + 320;
+  if (!A_hi || !B_hi || !C || !mwdhm || !perm || !tclip || !qz || ldh <= 0 || (ldh & 63) || (a_inner & 31) || (b_inner & 31) ||
+      (K & 31) || a_inner < M || a_rows < K || b_inner < N || b_rows < K || ldc < ldh || !tcar_aligned16(A_hi) ||
+      !tcar_aligned16(B_hi) || !tcar_aligned16(tclip) || ((uintptr_t)qz & 7))
+    return TCAR_E_ARG;
+  BArgs g{};
+  g.A[0] = (const __bf16*)A_hi; g.B[0] = (const __bf16*)B_hi;
+  g.a_in32 = (int)(a_inner >> 5); g.b_in32 = (int)(b_inner >> 5);
+  g.a_rb = (int)((a_rows + 127) >> 7); g.b_rb = (int)((b_rows + 127) >> 7);
+  g.C = C; g.ldc = ldc; g.C2 = C; g.ldc2 = ldc; g.csplit = ldh;
+  g.perm = perm; g.pgroup = 64;
+  g.M = M; g.N = N; g.K = K; g.K1 = K; g.kchunk = K; g.mode = 0; g.nsk = 1; g.n_fastest = 1;
+  g.mwdhm = mwdhm; g.tclip = tclip; g.qz = (float2*)qz;
+  hipStream_t st = (hipStream_t)stream;
+  (void)o;
+  if (tile == 256) {
+    constexpr int TM = 256, TN = 192;
+    constexpr size_t lds = 2 * (TM + TN) * 64;
+    g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
+    TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 4, 3, 2, 2, 1, 2, 0>), lds);
+    TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 4, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 12), lds, st, g);
+  } else {
+    constexpr int TM = 192, TN = 192;
+    constexpr size_t lds = 2 * (TM + TN) * 64;
+    g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
+    TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0>), lds);
+    TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 9), lds, st, g);
+  }
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+extern "C" int tcar_gemm_bf16_de_qz(int M, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi, int64_t b_inner,
+                                    int64_t b_rows, int ldh, float* C, int64_t ldc, const int32_t* mwdhm, const int32_t* perm,
+                                    const float* tclip, float* qz, int tile, void* stream) {
+  return tcar_gemm_bf16_de_qz_o(M, K, A_hi, a_inner, a_rows, B_hi, b_inner, b_rows, ldh, C, ldc, mwdhm, perm, tclip, qz, tile, stream,
+                                nullptr);
+}
+
 extern "C" int tcar_gemm_bf16_variant(int layout, int M, int N, int K, int nsplit, int splitk, char* buf, int buflen) {
   if (!buf || buflen < 8 || layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || (K & 31)) return TCAR_E_ARG;
-  t_variant_out = buf;
-  t_variant_len = buflen;
+  LaunchCall lc;
+  lc.variant_out = buf;
+  lc.variant_len = buflen;
   buf[0] = 0;
   // plane geometry as tcar_gemm_bf16 requires it; the pointers are never dereferenced on the dry path
   const bool a_kc = (layout != 2), b_kc = (layout == 1);
   const int64_t r32 = 31;
   const int64_t a_inner = ((a_kc ? K : M) + r32) & ~r32, a_rows = a_kc ? M : K;
   const int64_t b_inner = ((b_kc ? K : N) + r32) & ~r32, b_rows = b_kc ? N : K;
-  static const char dummy[16] __attribute__((aligned(16))) = {0};
+  alignas(16) const char dummy[16] = {0};
   float c = 0.f;
-  const int rc = tcar_gemm_bf16(layout, M, N, K, dummy, dummy, a_inner, a_rows, dummy, dummy, b_inner, b_rows, &c, N, nullptr, 0,
-                                0, nsplit, splitk, nullptr);
-  t_variant_out = nullptr;
-  return rc;
+  return gemm_bf16_impl(layout, M, N, K, dummy, dummy, a_inner, a_rows, dummy, dummy, b_inner, b_rows, &c, N, nullptr, 0, 0, nullptr,
+                        0, nsplit, splitk, nullptr, nullptr, lc);
 }
 
 extern "C" int tcar_split_bf16(const float* x, int64_t ld, int rows, int cols, void* hi, void* lo, int64_t inner,

@@ -526,9 +526,14 @@ int launch_layout(GroupArgs& ga, hipStream_t st) {
 }
 
 template <int LA, int LB, int XK, int XD>
-int launch_x3_v(GroupArgs& ga, int wg, hipStream_t st) {
+int launch_x3_v(GroupArgs& ga, int wg, hipStream_t st, TcarOpt* o) {
   constexpr size_t lds = 4 * X3<XK>::PLANE;
-  ga.sig = tcar_take_signal();
+  // A launch that carries a completion flag stores C write-through (agent-scope stores); its bf16 plane / pack outputs would
+  // still be plain stores, which a consumer on another XCD could read stale behind the flag: refused, not silently allowed.
+  if (o && o->sig.cnt)
+    for (int i = 0; i < ga.nprob; ++i)
+      if (ga.p[i].plane_hi || ga.p[i].pack_hi) return TCAR_E_ARG;
+  ga.sig = tcar_sig(o);
   TCAR_SET_LDS_ONCE((gemm_x3_kernel<LA, LB, XK, XD>), lds);
   TCAR_LAUNCH((gemm_x3_kernel<LA, LB, XK, XD>), dim3(wg), dim3(256), lds, st, ga);
   TCAR_CHECK_LAUNCH();
@@ -536,7 +541,7 @@ int launch_x3_v(GroupArgs& ga, int wg, hipStream_t st) {
 }
 
 template <int LA, int LB>
-int launch_x3(GroupArgs& ga, hipStream_t st) {
+int launch_x3(GroupArgs& ga, hipStream_t st, TcarOpt* o) {
   int wg = 0;
   for (int i = 0; i < ga.nprob; ++i) {
     GemmProb& p = ga.p[i];
@@ -560,8 +565,8 @@ int launch_x3(GroupArgs& ga, hipStream_t st) {
     for (int sg = 0; sg < p.nseg; ++sg) n += ((p.K[sg] < p.kchunk ? p.K[sg] : p.kchunk) + 63) / 64;
     max_stages = n > max_stages ? n : max_stages;
   }
-  if (max_stages <= 2 && tcar_tuning().x3_oneshot) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st);
-  return launch_x3_v<LA, LB, 64, 1>(ga, wg, st);
+  if (max_stages <= 2 && tcar_tn(o).x3_oneshot) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st, o);
+  return launch_x3_v<LA, LB, 64, 1>(ga, wg, st, o);
 }
 
 int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {
@@ -618,6 +623,9 @@ extern "C" int tcar_gemm_f32_grouped(int layout, int nprob, const tcar_gemm_desc
 }
 
 extern "C" int tcar_gemm_x3_grouped(int layout, int nprob, const tcar_gemm_desc_t* descs, void* stream) {
+  return tcar_gemm_x3_grouped_o(layout, nprob, descs, stream, nullptr);
+}
+int tcar_gemm_x3_grouped_o(int layout, int nprob, const tcar_gemm_desc_t* descs, void* stream, TcarOpt* o) {
   if (nprob <= 0) return TCAR_OK;
   if (layout < 0 || layout > 2 || nprob > MAXP || !descs) return TCAR_E_ARG;
   GroupArgs ga;
@@ -630,9 +638,9 @@ extern "C" int tcar_gemm_x3_grouped(int layout, int nprob, const tcar_gemm_desc_
   }
   if (ga.nprob == 0) return TCAR_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (layout == 0) return launch_x3<0, 1>(ga, st);
-  if (layout == 1) return launch_x3<0, 0>(ga, st);
-  return launch_x3<1, 1>(ga, st);
+  if (layout == 0) return launch_x3<0, 1>(ga, st, o);
+  if (layout == 1) return launch_x3<0, 0>(ga, st, o);
+  return launch_x3<1, 1>(ga, st, o);
 }
 
 extern "C" int tcar_gemm_f32(int layout, int M, int N, int K, const float* A, int64_t lda, const float* B, int64_t ldb,

@@ -339,11 +339,17 @@ int launch_mha_bwd(int N, int Tq, int Tk, int C, int heads, int causal, const fl
 extern "C" int tcar_mha_core_fwd(int N, int Tq, int Tk, int C, int heads, int causal, const float* Q, const float* K,
                                  const float* V, const float* key_mask, const float* query_mask, float* O, float* P,
                                  void* stream) {
+  return tcar_mha_core_fwd_tuned(nullptr, N, Tq, Tk, C, heads, causal, Q, K, V, key_mask, query_mask, O, P, stream);
+}
+extern "C" int tcar_mha_core_fwd_tuned(const tcar_tuning_t* tune, int N, int Tq, int Tk, int C, int heads, int causal,
+                                       const float* Q, const float* K, const float* V, const float* key_mask,
+                                       const float* query_mask, float* O, float* P, void* stream) {
+  const TcarTuning& tn = tune ? *tune : tcar_tuning();
   if (N <= 0 || Tq <= 0 || Tk <= 0) return TCAR_OK;
   if (!Q || !K || !V || !key_mask || !query_mask || !O || !P || heads <= 0 || C <= 0 || C % heads || Tq > 64 || Tk > 64)
     return TCAR_E_ARG;
   const int dh = C / heads;
-  if (tcar_tuning().mha_mfma && (dh == 32 || dh == 64)) {     // matrix-core form: one wave per (n, h)
+  if (tn.mha_mfma && (dh == 32 || dh == 64)) {     // matrix-core form: one wave per (n, h)
     if (dh == 32) return launch_mha_fwd<32, 4>(N, Tq, Tk, C, heads, causal, Q, K, V, key_mask, query_mask, O, P, (hipStream_t)stream);
     return launch_mha_fwd<64, 2>(N, Tq, Tk, C, heads, causal, Q, K, V, key_mask, query_mask, O, P, (hipStream_t)stream);
   }
@@ -357,12 +363,18 @@ extern "C" int tcar_mha_core_fwd(int N, int Tq, int Tk, int C, int heads, int ca
 extern "C" int tcar_mha_core_bwd(int N, int Tq, int Tk, int C, int heads, int causal, const float* Q, const float* K,
                                  const float* V, const float* P, const float* key_mask, const float* query_mask,
                                  const float* dO, float* dQ, float* dK, float* dV, void* stream) {
+  return tcar_mha_core_bwd_tuned(nullptr, N, Tq, Tk, C, heads, causal, Q, K, V, P, key_mask, query_mask, dO, dQ, dK, dV, stream);
+}
+extern "C" int tcar_mha_core_bwd_tuned(const tcar_tuning_t* tune, int N, int Tq, int Tk, int C, int heads, int causal,
+                                       const float* Q, const float* K, const float* V, const float* P, const float* key_mask,
+                                       const float* query_mask, const float* dO, float* dQ, float* dK, float* dV, void* stream) {
+  const TcarTuning& tn = tune ? *tune : tcar_tuning();
   if (N <= 0 || Tq <= 0 || Tk <= 0) return TCAR_OK;
   if (!Q || !K || !V || !P || !key_mask || !query_mask || !dO || !dQ || !dK || !dV || heads <= 0 || C <= 0 || C % heads || Tq > 64 ||
       Tk > 64)
     return TCAR_E_ARG;
   const int dh = C / heads;
-  if (tcar_tuning().mha_mfma && (dh == 32 || dh == 64)) {
+  if (tn.mha_mfma && (dh == 32 || dh == 64)) {
     if (dh == 32)
       return launch_mha_bwd<32, 2>(N, Tq, Tk, C, heads, causal, key_mask, Q, K, V, P, query_mask, dO, dQ, dK, dV, (hipStream_t)stream);
     return launch_mha_bwd<64, 1>(N, Tq, Tk, C, heads, causal, key_mask, Q, K, V, P, query_mask, dO, dQ, dK, dV, (hipStream_t)stream);

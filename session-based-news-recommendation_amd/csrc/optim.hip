@@ -328,6 +328,10 @@ static int sqnorm_grid_x(const tcar_segments_t* segs) {
 }
 
 extern "C" int tcar_sqnorm(const float* g, const tcar_segments_t* segs, float* sqn_dense, void* stream) {
+  return tcar_sqnorm_o(g, segs, sqn_dense, stream, nullptr);
+}
+// (flag-capable in its one-workgroup-per-segment form: the norm slots are published with atomics)
+int tcar_sqnorm_o(const float* g, const tcar_segments_t* segs, float* sqn_dense, void* stream, TcarOpt* o) {
   if (check_segs(segs) || !g || !sqn_dense || !tcar_aligned16(g)) return TCAR_E_ARG;
   if (segs->nseg == 0) return TCAR_OK;
   SegArgs a;
@@ -335,7 +339,7 @@ extern "C" int tcar_sqnorm(const float* g, const tcar_segments_t* segs, float* s
   long longest = 0;
   for (int i = 0; i < segs->nseg; ++i) longest = segs->len[i] > longest ? segs->len[i] : longest;
   if (longest <= 262144)
-    TCAR_LAUNCH(sqnorm_seg_kernel, dim3(segs->nseg), dim3(1024), 0, (hipStream_t)stream, g, a, sqn_dense, tcar_take_signal());
+    TCAR_LAUNCH(sqnorm_seg_kernel, dim3(segs->nseg), dim3(1024), 0, (hipStream_t)stream, g, a, sqn_dense, tcar_sig(o));
   else
     TCAR_LAUNCH(sqnorm_kernel, dim3(sqnorm_grid_x(segs), segs->nseg), dim3(256), 0, (hipStream_t)stream, g, a, sqn_dense);
   TCAR_CHECK_LAUNCH();
@@ -455,13 +459,20 @@ extern "C" int tcar_clip_adam_rest_keep(float* w2d, int64_t ldw, const float* g2
                                    int32_t cols, int32_t slot, const float* sqn_dense, const float* sqn_pieces,
                                    const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
                                    void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap, void* stream) {
+  return tcar_clip_adam_rest_keep_o(w2d, ldw, g2d, m2d, v2d, rows, cols, slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2,
+                                    eps, e16_hi, e16_lo, ld16, bitmap, stream, tcar_tuning().rest_grid);
+}
+int tcar_clip_adam_rest_keep_o(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols,
+                               int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip,
+                               float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16,
+                               uint32_t* bitmap, void* stream, int rest_grid) {
   if (!bitmap) return TCAR_E_ARG;
   AdamAll p;
   const int rc = fill_adam_all(p, nullptr, nullptr, nullptr, nullptr, nullptr, w2d, ldw, g2d, m2d, v2d, rows, cols, slot,
                                sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2, eps, e16_hi, e16_lo, ld16);
   if (rc) return rc;
   // a modest grid: the pass shares the chip with the latency-bound kernels of the forward head and has ~100 us to finish
-  const int cap = tcar_tuning().rest_grid;
+  const int cap = rest_grid;
   if (cap > 0 && p.n2d > cap) p.n2d = cap;
   // the pass streams 376 MB once: non-temporal loads and stores, so that it does not evict the weights and activations of the
   // latency-bound session-side kernels it runs beside (A/B over three interleaved rounds: 0.6197 vs 0.6327 ms per step; the same

@@ -114,6 +114,11 @@ __global__ __launch_bounds__(512) void query_mlp_kernel(const QMlpArgs a) {
 // as small GEMMs.  Carries a pending completion flag (tcar_common.h).
 extern "C" int tcar_query_mlp(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b,
                               const float* q2_w, const float* q2_b, float* q1, float* q, void* stream) {
+  return tcar_query_mlp_o(d, B, click_t, q1_w, q1_b, q2_w, q2_b, q1, q, stream, nullptr);
+}
+// (flag-capable: q1 and q leave write-through when the launch carries a flag)
+int tcar_query_mlp_o(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b, const float* q2_w,
+                     const float* q2_b, float* q1, float* q, void* stream, TcarOpt* o) {
   if (!d || d->ldh != H1 || d->ldt * 2 != CT || B <= 0) return TCAR_E_ARG;
   if (!click_t || !q1_w || !q1_b || !q2_w || !q2_b || !q1 || !q) return TCAR_E_ARG;
   if (!tcar_aligned16(click_t) || !tcar_aligned16(q1_w) || !tcar_aligned16(q1_b) || !tcar_aligned16(q2_w) || !tcar_aligned16(q2_b) ||
@@ -121,7 +126,7 @@ extern "C" int tcar_query_mlp(const tcar_dims_t* d, int B, const float* click_t,
     return TCAR_E_ARG;
   QMlpArgs a{};
   a.click = click_t; a.w1 = q1_w; a.b1 = q1_b; a.w2 = q2_w; a.b2 = q2_b; a.q1 = q1; a.q = q; a.B = B;
-  a.sig = tcar_take_signal();
+  a.sig = tcar_sig(o);
   constexpr size_t lds = (size_t)(QS * CT + QS * H1 + 4 * QS * H2) * sizeof(float);     // 76 KB
   TCAR_SET_LDS_ONCE(query_mlp_kernel, lds);
   TCAR_LAUNCH(query_mlp_kernel, dim3((unsigned)((B + QS - 1) / QS)), dim3(512), lds, (hipStream_t)stream, a);

@@ -423,6 +423,101 @@ __global__ __launch_bounds__(256) void reduce_dact_kernel(const float* __restric
   }
 }
 
+// ---- the same for the ONE-HOT form of dX (round 4): slabs [S][M][lds] hold dlogits [E_item | E_content | OH] -------------------
+// Column blocks 0 .. ic/64 - 1: as reduce_dact_kernel.  Block ic/64 + k (k = 0..4): dP[m, rows of table k] = sum of the slabs'
+// one-hot columns (written to dP [M, 160] for the candidate-side table gradients, embed.hip), expanded on the spot to the time
+// columns of dattout: d attout_t,k[m, :] = sum_r dP[m, r] clip(table_k row r)  (dlogits E_time = (dlogits OH) T_clip), then tanh'.
+__global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __restrict__ slabs, int S, int M, int ic, long lds_,
+                                                                 const float* __restrict__ addend, long ld_add,
+                                                                 const float* __restrict__ y, long ldy, const float* __restrict__ tclip,
+                                                                 float* __restrict__ out, long ldo, float* __restrict__ dP,
+                                                                 float* __restrict__ bg0, float* __restrict__ bg1, TcarSignal sig) {
+  __shared__ float4 sh[256];
+  __shared__ float dpl[16 * 64];
+  __shared__ __attribute__((aligned(16))) float tl[61 * 64];
+  const int tid = threadIdx.x, cg = tid & 15, rp = tid >> 4;
+  const int nic = ic >> 6;
+  const int r0 = blockIdx.y * 16, row = r0 + rp;
+  float4 cs = zero4();
+  int col;                                   // output column of this thread's float4
+  if ((int)blockIdx.x < nic) {
+    col = blockIdx.x * 64 + cg * 4;
+    if (row < M) {
+      float4 acc = addend ? ld4(addend + (long)row * ld_add + col) : zero4();
+      const float* sp = slabs + (long)row * lds_ + col;
+      int k = 0;
+      for (; k + 12 <= S; k += 12) {
+        float4 t[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) t[j] = ld4(sp + (long)(k + j) * M * lds_);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc = add4(acc, t[j]);
+      }
+      for (; k < S; ++k) acc = add4(acc, ld4(sp + (long)k * M * lds_));
+      const float4 yy = ld4(y + (long)row * ldy + col);
+      acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+      st4(out + (long)row * ldo + col, acc);
+      cs = acc;
+    }
+  } else {
+    const int k = blockIdx.x - nic;
+    const int off = k == 0 ? 0 : k == 1 ? 13 : k == 2 ? 45 : k == 3 ? 53 : 78;
+    const int nk = k == 0 ? 13 : k == 1 ? 32 : k == 2 ? 8 : k == 3 ? 25 : 61;
+    col = ic + k * 64 + cg * 4;
+    // the clipped rows of table k (written by tcar_time_scores_clip in the forward pass)
+    for (int i = tid; i < nk * 16; i += 256) st4(tl + i * 4, ld4(tclip + (long)off * 64 + i * 4));
+    // dP tile: 16 rows x nk one-hot columns, summed over the slabs in slab order (thread: row rp, columns cg, cg + 16, ...)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cg + 16 * j;
+      float v = 0.f;
+      if (row < M && c < nk) {
+        const float* sp = slabs + (long)row * lds_ + ic + off + c;
+        int q = 0;
+        for (; q + 6 <= S; q += 6) {
+          float t[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) t[u] = sp[(long)(q + u) * M * lds_];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) v += t[u];
+        }
+        for (; q < S; ++q) v += sp[(long)q * M * lds_];
+        if (sig.cnt) __hip_atomic_store(dP + (long)row * 160 + off + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dP[(long)row * 160 + off + c] = v;
+      }
+      dpl[rp * 64 + c] = v;
+    }
+    __syncthreads();
+    if (row < M) {
+      float4 acc = zero4();
+      for (int r = 0; r < nk; ++r) acc = fma4(*reinterpret_cast<const float4*>(tl + r * 64 + cg * 4), dpl[rp * 64 + r], acc);
+      const float4 yy = ld4(y + (long)row * ldy + col);
+      acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+      st4(out + (long)row * ldo + col, acc);
+      cs = acc;
+    }
+  }
+  if (bg0 || bg1) {
+    sh[tid] = cs;
+    __syncthreads();
+    if (tid < 64) {                                // thread = one column of the tile: sum its 16 row phases
+      const int g4 = tid >> 2, j = tid & 3;
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 t = sh[q * 16 + g4];
+        v += (j == 0) ? t.x : (j == 1) ? t.y : (j == 2) ? t.z : t.w;
+      }
+      const int c = (col - cg * 4) + tid;
+      if (v != 0.f) {
+        if (c < ic) { if (bg0) atomicAdd(bg0 + c, v); }
+        else if (bg1) atomicAdd(bg1 + (c - ic), v);
+      }
+    }
+  }
+  tcar_signal_done(sig);
+}
+
 // ---- dz = dy * act'(y), bias_grad += column sums (modules.py:52-54 backward) ------------------------------
 // grid = (ncol/64 column blocks, row chunks); 256 threads = 64 columns x 4 row phases; one atomic per column
 // and workgroup into the (zeroed) bias gradient.
@@ -665,11 +760,14 @@ extern "C" int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const in
 
 extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce,
                                     void* dl_hi, void* dl_lo, void* stream) {
+  return tcar_softmax_ce_bf16_o(B, N, logits, ld, label, ce, dl_hi, dl_lo, stream, tcar_tuning().softmax_variant);
+}
+int tcar_softmax_ce_bf16_o(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* dl_hi, void* dl_lo,
+                           void* stream, int variant) {
   if (B <= 0) return TCAR_OK;
   if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && (ld & 31)) || (dl_lo && !dl_hi))
     return TCAR_E_ARG;
   const int grid = dl_hi ? ((B + 127) & ~127) : B;
-  const int variant = tcar_tuning().softmax_variant;
   if (variant == 2 && ld <= 1024L * 4 * 12) {
     TCAR_LAUNCH((softmax_ce_rows_kernel<1024, 12>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, B, N, logits, (long)ld,
                 label, ce, (__bf16*)dl_hi, (__bf16*)dl_lo);
@@ -770,6 +868,30 @@ extern "C" int tcar_splitk_reduce_dact(const float* slabs, int splitk, int M, in
   return TCAR_OK;
 }
 
+// tcar_splitk_reduce_dact for the one-hot form of dX (tcar_gemm_bf16_dx_onehot): slabs [splitk, M, ld] with ld >= ic + 160;
+// out [M, ldo] gets all ic + 5 * 64 columns of d attout (through tanh' of y = attout), dP [M, 160] the summed one-hot columns.
+// addend [M, ic] (the negative term's part) may be NULL; bias_grad0 / 1 as tcar_splitk_reduce_dact (NULL: order-fixed column sums
+// elsewhere).  ldt = 64.
+int tcar_reduce_dact_onehot_o(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
+                              const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo, float* dP, float* bias_grad0,
+                              float* bias_grad1, void* stream, TcarOpt* o) {
+  if (M <= 0) return TCAR_OK;
+  if (!slabs || splitk <= 0 || ic <= 0 || (ic & 63) || ld < ic + 160 || (ld & 3) || (ldy & 3) || (ldo & 3) || (addend && (ld_add & 3)) ||
+      !y || !tclip || !out || !dP || !tcar_aligned16(slabs) || !tcar_aligned16(y) || !tcar_aligned16(out) || !tcar_aligned16(tclip) ||
+      (addend && !tcar_aligned16(addend)))
+    return TCAR_E_ARG;
+  TCAR_LAUNCH(reduce_dact_onehot_kernel, dim3(ic / 64 + 5, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, ic,
+              (long)ld, addend, (long)ld_add, y, (long)ldy, tclip, out, (long)ldo, dP, bias_grad0, bias_grad1, tcar_sig(o));
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+extern "C" int tcar_reduce_dact_onehot(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
+                                       const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo, float* dP,
+                                       float* bias_grad0, float* bias_grad1, void* stream) {
+  return tcar_reduce_dact_onehot_o(slabs, splitk, M, ic, ld, addend, ld_add, y, ldy, tclip, out, ldo, dP, bias_grad0, bias_grad1, stream,
+                                   nullptr);
+}
+
 extern "C" int tcar_dact_colsum(int M, int ncol, int64_t ld, const float* y, float* dy, float* bias_grad, int act,
                                 void* stream) {
   if (M <= 0 || ncol <= 0) return TCAR_OK;
@@ -805,6 +927,60 @@ extern "C" int tcar_eval_rows(int B, int N, const float* logits, int64_t ld, con
   }
   if (ce) return TCAR_E_ARG;        // the streaming fallback has no fused CE: call tcar_softmax_ce
   TCAR_LAUNCH(rank_topk_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, N, logits, (long)ld, label, k, rank, topk);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+// ---- diversity metrics of the evaluation loop (model_combine.py:174-194,301-313) on the device ---------------------------
+// getILD: ordered pairs (i != j) of the top-k list whose categories differ; getUnexp: (recommended, input click) pairs whose
+// categories differ; resultItemDict: the set of recommended items.  One wave per session, lane = one recommended item
+// (k <= 64): its category against the k - 1 others (cross-lane reads) and against the T input clicks.  The kernel leaves the
+// INTEGER counts (the reference divides Python ints: score / (n (n - 1)), score / (n len(inSeq)) — the host divides the same
+// ints in double precision, so the metrics are bit-exact) and marks seen[item] = 1 (a byte map: idempotent plain stores, and
+// ranks can union it with a MAX all-reduce).  Entries < 0 of topk (a catalog shorter than k) are not in the list.
+__global__ __launch_bounds__(256) void eval_diversity_kernel(int B, int T, int k, int n_items, const int32_t* __restrict__ topk,
+                                                             const int32_t* __restrict__ seq, const int32_t* __restrict__ cat,
+                                                             int32_t* __restrict__ ild_cnt, int32_t* __restrict__ unexp_cnt,
+                                                             int32_t* __restrict__ n_rec, uint8_t* __restrict__ seen) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int item = lane < k ? topk[(long)b * k + lane] : -1;
+  const bool valid = item >= 0 && item < n_items;
+  const int c = valid ? cat[item] : 0;
+  if (valid && seen) seen[item] = 1;
+  int ild = 0;
+  for (int j = 0; j < k; ++j) {
+    const int cj = __shfl(c, j);
+    const int vj = __shfl(valid ? 1 : 0, j);
+    ild += (valid && vj && j != lane && c != cj) ? 1 : 0;
+  }
+  int un = 0;
+  for (int t = 0; t < T; ++t) {
+    const int id = seq[(long)b * T + t];              // 1-based (sampler.py:68): category of item id - 1 (model_combine.py:192)
+    const int ct = cat[clampi(id - 1, 0, n_items - 1)];
+    un += (valid && c != ct) ? 1 : 0;
+  }
+  int nv = valid ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ild += __shfl_xor(ild, o);
+    un += __shfl_xor(un, o);
+    nv += __shfl_xor(nv, o);
+  }
+  if (lane == 0) {
+    ild_cnt[b] = ild;
+    unexp_cnt[b] = un;
+    if (n_rec) n_rec[b] = nv;
+  }
+}
+
+extern "C" int tcar_eval_diversity(int B, int T, int k, int n_items, const int32_t* topk, const int32_t* seq, const int32_t* cat,
+                                   int32_t* ild_cnt, int32_t* unexp_cnt, int32_t* n_rec, uint8_t* seen, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (T <= 0 || k <= 0 || k > 64 || n_items <= 0 || !topk || !seq || !cat || !ild_cnt || !unexp_cnt) return TCAR_E_ARG;
+  TCAR_LAUNCH(eval_diversity_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, B, T, k, n_items, topk, seq,
+              cat, ild_cnt, unexp_cnt, n_rec, seen);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

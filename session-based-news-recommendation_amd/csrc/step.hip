@@ -11,7 +11,7 @@ static int env_int(const char* name, int dflt) {
 }
 // ONE table: name, field, shipped default (a switch cannot be added out of order)
 namespace {
-struct Switch { const char* name; int TcarTuning::*field; int dflt; };
+struct Switch { const char* name; int32_t TcarTuning::*field; int dflt; };
 const Switch kSwitches[] = {
     {"TCAR_BF16_TILE", &TcarTuning::bf16_tile, 0},          {"TCAR_REST_GRID", &TcarTuning::rest_grid, 512},
     {"TCAR_SOFTMAX_VARIANT", &TcarTuning::softmax_variant, 1}, {"TCAR_WGRAD_KS", &TcarTuning::wgrad_ks, 1536},
@@ -19,40 +19,35 @@ const Switch kSwitches[] = {
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 1},
+    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
     {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 759},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
 };
 }  // namespace
-static TcarTuning& tuning_storage() {
-  static TcarTuning t = [] {
+// the process snapshot: written once by the initialiser of this function-local static, const ever after
+const TcarTuning& tcar_tuning() {
+  static const TcarTuning t = [] {
     TcarTuning x{};
     for (const Switch& sw : kSwitches) x.*(sw.field) = env_int(sw.name, sw.dflt);
     return x;
   }();
   return t;
 }
-const TcarTuning& tcar_tuning() { return tuning_storage(); }
-TcarSignal& tcar_pending_signal() {
-  thread_local TcarSignal pending{};
-  return pending;
+extern "C" int tcar_tuning_defaults(tcar_tuning_t* out) {
+  if (!out) return TCAR_E_ARG;
+  *out = tcar_tuning();
+  return TCAR_OK;
 }
-unsigned& tcar_taken_epoch(unsigned slot) {
-  thread_local unsigned taken[16] = {};
-  return taken[slot & 15u];
-}
-
-// Diagnostic hook (tests, tools/): override one switch at run time; returns the previous value, or INT_MIN for an unknown
-// name.  Process-global and not thread safe against concurrent launches — the product path (engine, step driver) never calls it.
-extern "C" int tcar_set_tuning(const char* name, int value) {
-  if (!name) return -2147483647 - 1;
-  TcarTuning& t = tuning_storage();
+// sets one switch in the CALLER's copy (tests and tools build a context with it); returns the previous value, INT_MIN for an
+// unknown name
+extern "C" int tcar_tuning_set(tcar_tuning_t* t, const char* name, int value) {
+  if (!t || !name) return -2147483647 - 1;
   for (const Switch& sw : kSwitches) {
     bool same = true;
     for (int i = 0; same; ++i) {
       if (sw.name[i] != name[i]) same = false;
       else if (!sw.name[i]) break;
     }
-    if (same) { const int old = t.*(sw.field); t.*(sw.field) = value; return old; }
+    if (same) { const int old = t->*(sw.field); t->*(sw.field) = value; return old; }
   }
   return -2147483647 - 1;
 }
@@ -110,15 +105,18 @@ void grads_of(const tcar_ctx_t* c, tcar_grads_t& g) {
 }
 
 // the small contractions follow the scoring precision: exact fp32 MFMA in "f32" mode, split-bf16 otherwise
-inline int small_gemm(const tcar_ctx_t* c, int layout, int n, const tcar_gemm_desc_t* p, void* stream) {
-  return c->scoring ? tcar_gemm_x3_grouped(layout, n, p, stream) : tcar_gemm_f32_grouped(layout, n, p, stream);
+// `o`: launch options (context tuning; the completion flag this launch is to carry — split-bf16 form only)
+inline int small_gemm(const tcar_ctx_t* c, int layout, int n, const tcar_gemm_desc_t* p, void* stream, TcarOpt* o = nullptr) {
+  TcarOpt plain;
+  if (!o) { plain.tune = c->tune; o = &plain; }
+  return c->scoring ? tcar_gemm_x3_grouped_o(layout, n, p, stream, o) : tcar_gemm_f32_grouped(layout, n, p, stream);
 }
 
 // softmax epilogue of the logits GEMM (training steps of the hi-only backward precision): workspace [rowstat 2B | label score B |
 // group stats]; the logits are not materialised
 struct CeWs { float* rowstat; float* lab; float* stats; int64_t stats_floats; };
 inline bool fused_ce(const tcar_ctx_t* c, int B, CeWs* w) {
-  if (!c->scoring || c->scoring_bwd != 1 || !c->ce_ws || !tcar_tuning().fused_ce) return false;
+  if (!c->scoring || c->scoring_bwd != 1 || !c->ce_ws || !(c->tune ? c->tune->fused_ce : tcar_tuning().fused_ce)) return false;
   const int64_t head = 2L * B + ((B + 1) & ~1);
   const int64_t need = (int64_t)B * ((c->d.n_items + 63) / 64 + 8) * 2;
   if (c->ce_ws_floats < head + need) return false;
@@ -131,21 +129,25 @@ inline hipStream_t aux_stream(const tcar_ctx_t* c) {
 }
 
 // ---- forks and joins of the step's streams without an event on the producer's stream ----------------------------------------------
-// fork_arm(slot) right before the launch whose END the other stream has to wait for (that launch takes the pending flag: the
-// small-GEMM, gather, query-MLP, norm launches do); fork_go(slot, ...) where the event record + wait used to be: a one-wave
-// kernel on the consumer's stream polls the flag.  A launch that did not take the flag (another kernel family on this path) or a
-// context without the flag words: the event pair, as before.  The poll gives up after POLL_TICKS of the 100-MHz wall clock
-// (a profiler that serialises kernels would otherwise hang) and counts the time-out in sig_dev[TCAR_SIG_ERR]; the engine
-// raises on a non-zero count.
+// sig = fork_arm(c, slot) right before the launch whose END the other stream has to wait for; the signal is handed to THAT launch
+// explicitly (TcarOpt.sig of its `_o` form) and fork_commit(c, slot, opt) records whether the kernel form it chose carries the
+// flag; fork_go(slot, ...) where the event record + wait used to be: a one-wave kernel on the consumer's stream polls the flag.
+// A launch that did not carry the flag, a slot masked off in TCAR_FLAG_FORK or a context without the flag words: the event
+// pair, as before.  ALL of this state lives in the context's own host block (tcar_ctx_t.fork_host): nothing per thread, nothing
+// per process — two contexts stepped alternately, or from two host threads, cannot see each other's forks.
+// The poll gives up after POLL_TICKS of the 100-MHz wall clock (a profiler that serialises kernels would otherwise hang) and
+// counts the time-out in sig_dev[TCAR_SIG_ERR] AND, with a system-scope atomic, in the context's host-visible word
+// (sig_err_host): the engine tests that word after every step without synchronising and raises.
 // Visibility across the eight private L2s is the PRODUCER's business: whatever the consumer reads of the flagged launch's own
 // output is stored write-through (sc1 / agent-scope atomic stores) or with atomics, everything older was released when its
-// launch ended; the consumer kernels behind the poll start with the runtime's usual acquire.  (A first version let eight
-// polling workgroups write back their XCD's L2 instead — correct, but the write-back lands in the first kernels of the other
-// stream's next phase: 2-4 us slower per fork, and the reason three forks measured slower with flags than with events.)
+// launch ended; the consumer kernels behind the poll start with the runtime's usual acquire.  Which kernels may carry a flag,
+// and what each stores write-through: TcarOpt in tcar_common.h; a small-GEMM launch with bf16 plane outputs (plain stores)
+// REFUSES a flag (TCAR_E_ARG).
 constexpr int TCAR_SIG_SLOTS = 16, TCAR_SIG_ERR = 2 * TCAR_SIG_SLOTS;
 constexpr long long POLL_TICKS = 100000000LL;      // 1 s of the 100-MHz wall clock
-__global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, long long ticks = POLL_TICKS,
-                                                       const unsigned* flag2 = nullptr, unsigned epoch2 = 0, int delay_ticks = 0) {
+__global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, unsigned epoch, unsigned* err, unsigned* err_host,
+                                                       long long ticks = POLL_TICKS, const unsigned* flag2 = nullptr,
+                                                       unsigned epoch2 = 0, int delay_ticks = 0) {
   if (threadIdx.x != 0) return;
   const long long t0 = wall_clock64();
   bool ok = true;
@@ -163,52 +165,51 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
     const long long t1 = wall_clock64();
     while (wall_clock64() - t1 < delay_ticks) __builtin_amdgcn_s_sleep(8);
   }
-  if (!ok) atomicAdd(err, 1u);
+  if (!ok) {
+    atomicAdd(err, 1u);
+    if (err_host) __hip_atomic_fetch_add(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 // slots (bits of TCAR_FLAG_FORK).  Two forks of the step — early Adam -> candidate refresh, softmax -> dE — stay events: with a
-// flag the step is slower in every form tried (write-through producers, start-of-kernel flags, delayed polls: DESIGN.md §4).
-// The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits GEMM writes, and held back
-// TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main stream records nothing.
+// flag the step is slower in every form tried (write-through producers, start-of-kernel flags, delayed polls:
+// profiles/r03_ab_experiments.txt).  The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits
+// GEMM writes, and held back TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main
+// stream records nothing.
 enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_LOGITS = 9 };
-struct Fork { TcarSignal sig; bool armed; const tcar_ctx_t* ctx; };
-inline Fork& fork_slot(int slot) {
-  thread_local Fork forks[TCAR_SIG_SLOTS] = {};
-  return forks[slot];
+// host-side fork state of ONE context (tcar_ctx_t.fork_host: caller-owned, zeroed, tcar_fork_state_bytes() bytes)
+struct ForkSlot { TcarSignal sig; uint32_t live; uint32_t pad; };     // live: the launch armed last for this slot carries sig
+struct ForkHost { uint32_t epoch; uint32_t pad[3]; ForkSlot slot[TCAR_SIG_SLOTS]; };
+inline ForkHost* fork_host(const tcar_ctx_t* c) { return c->sig_dev ? static_cast<ForkHost*>(c->fork_host) : nullptr; }
+inline const TcarTuning& tn(const tcar_ctx_t* c) { return c->tune ? *c->tune : tcar_tuning(); }
+inline TcarOpt opt_of(const tcar_ctx_t* c) { TcarOpt o; o.tune = c->tune; return o; }
+// the flag the producing launch is asked to carry; empty: this fork is an event fork
+inline TcarSignal fork_arm(const tcar_ctx_t* c, int slot) {
+  ForkHost* f = fork_host(c);
+  if (!f) return TcarSignal{};
+  f->slot[slot].live = 0;
+  if (!((tn(c).flag_fork >> slot) & 1)) return TcarSignal{};      // the switch is a mask over the slots
+  f->slot[slot].sig = TcarSignal{c->sig_dev + slot, c->sig_dev + TCAR_SIG_SLOTS + slot, ++f->epoch, (unsigned)slot};
+  return f->slot[slot].sig;
 }
-inline void fork_arm(const tcar_ctx_t* c, int slot) {
-  Fork& f = fork_slot(slot);
-  f.armed = false;
-  tcar_pending_signal() = TcarSignal{};
-  if (!c->sig_dev || !c->sig_epoch || !((tcar_tuning().flag_fork >> slot) & 1)) return;      // the switch is a mask over the slots
-  f.sig = TcarSignal{c->sig_dev + slot, c->sig_dev + TCAR_SIG_SLOTS + slot, ++c->sig_epoch[0], (unsigned)slot};
-  tcar_taken_epoch(slot) = f.sig.epoch - 1u;            // (not yet taken)
-  f.armed = true;
-  f.ctx = c;
-  tcar_pending_signal() = f.sig;
+// behind the producing launch: does it really carry the flag armed for `slot`?  (false: fork_go records an event)
+inline bool fork_commit(const tcar_ctx_t* c, int slot, const TcarOpt& o) {
+  ForkHost* f = fork_host(c);
+  if (!f) return false;
+  ForkSlot& s = f->slot[slot];
+  s.live = (o.carried && o.sig.cnt && o.sig.cnt == s.sig.cnt && o.sig.epoch == s.sig.epoch) ? 1u : 0u;
+  return s.live != 0;
 }
-inline void fork_disarm(int slot) { fork_slot(slot).armed = false; }
-// did the launch behind fork_arm(slot) take the flag?  (false also clears a flag nobody took)
-inline bool fork_taken(const tcar_ctx_t* c, int slot) {
-  Fork& f = fork_slot(slot);
-  TcarSignal& pend = tcar_pending_signal();
-  if (f.armed && f.ctx == c && f.sig.cnt == c->sig_dev + slot && tcar_taken_epoch(slot) == f.sig.epoch) return true;
-  if (pend.cnt == f.sig.cnt) pend = TcarSignal{};       // nobody took it
-  f.armed = false;
-  return false;
+inline void fork_disarm(const tcar_ctx_t* c, int slot) {
+  if (ForkHost* f = fork_host(c)) f->slot[slot].live = 0;
+}
+inline const ForkSlot* fork_live(const tcar_ctx_t* c, int slot) {
+  ForkHost* f = fork_host(c);
+  return (f && f->slot[slot].live) ? &f->slot[slot] : nullptr;
 }
 inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t to, void* ev, int delay_us = 0) {
-  Fork& f = fork_slot(slot);
-  TcarSignal& pend = tcar_pending_signal();
-  // armed by another context's step on this thread (the context struct's address can be reused: compare the device words too)
-  if (f.armed && (f.ctx != c || f.sig.cnt != c->sig_dev + slot)) f.armed = false;
-  const bool taken = f.armed && tcar_taken_epoch(slot) == f.sig.epoch;  // the producing launch really carries this flag
-  if (f.armed && !taken) {                                              // it was not flag-capable
-    if (pend.cnt == f.sig.cnt) pend = TcarSignal{};
-    f.armed = false;
-  }
-  if (taken) {
-    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, to, (const unsigned*)f.sig.flag, f.sig.epoch, c->sig_dev + TCAR_SIG_ERR, POLL_TICKS,
-                (const unsigned*)nullptr, 0u, delay_us * 100);
+  if (const ForkSlot* s = fork_live(c, slot)) {
+    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, to, (const unsigned*)s->sig.flag, s->sig.epoch, c->sig_dev + TCAR_SIG_ERR,
+                c->sig_err_host, POLL_TICKS, (const unsigned*)nullptr, 0u, delay_us * 100);
     TCAR_CHECK_LAUNCH();
     return TCAR_OK;
   }
@@ -235,7 +236,7 @@ extern "C" int tcar_flag_fork_selftest(uint32_t* sig_dev, void* main_stream, voi
     return TCAR_E_LAUNCH;
   const unsigned epoch = before[1] + 1u;
   TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, ss, (const unsigned*)(sig_dev + TCAR_SIG_SLOTS + 15), epoch, sig_dev + TCAR_SIG_ERR,
-              2000000LL);
+              (unsigned*)nullptr, 2000000LL);
   TCAR_CHECK_LAUNCH();
   TCAR_LAUNCH(set_flag_kernel, dim3(1), dim3(64), 0, sm, sig_dev + TCAR_SIG_SLOTS + 15, epoch);
   TCAR_CHECK_LAUNCH();
@@ -245,6 +246,19 @@ extern "C" int tcar_flag_fork_selftest(uint32_t* sig_dev, void* main_stream, voi
   if (hipMemcpy(sig_dev + TCAR_SIG_ERR, &before[0], 4, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(sig_dev + TCAR_SIG_SLOTS + 15, &before[1], 4, hipMemcpyHostToDevice) != hipSuccess)
     return TCAR_E_LAUNCH;
+  return TCAR_OK;
+}
+
+extern "C" int64_t tcar_fork_state_bytes(void) { return (int64_t)sizeof(ForkHost); }
+
+// Diagnostic: ONE polling kernel on `stream` that waits ~10 us for an epoch of slot 15 nobody will publish, i.e. a poll that
+// gives up — exactly what a step leaves behind when its streams do not overlap: sig_dev[32] += 1 and, with err_host, the
+// host-visible mirror += 1 (system-scope atomic).  Engines test their fail-fast path with it.
+extern "C" int tcar_flag_poll_expire(uint32_t* sig_dev, uint32_t* err_host, void* stream) {
+  if (!sig_dev) return TCAR_E_ARG;
+  TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned*)(sig_dev + TCAR_SIG_SLOTS + 15), 0x7fffffffu,
+              sig_dev + TCAR_SIG_ERR, err_host, 1000LL, (const unsigned*)nullptr, 0u, 0);
+  TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
 
@@ -266,9 +280,23 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
 
 // does the fused step add the item-row gradients through the sorted segmented sum?
 bool sorted_rows(const tcar_ctx_t* c, const tcar_batch_t* bt) {
-  if (!aux_stream(c) || !c->segsum_ws || !tcar_tuning().sort_scatter || c->d.ldh > 512) return false;
+  if (!aux_stream(c) || !c->segsum_ws || !tn(c).sort_scatter || c->d.ldh > 512) return false;
   const bool has_neg = bt->K > 0 && bt->neg && c->neg_coef && c->negpart;
   return c->segsum_bytes >= tcar_segsum_ws_bytes(&c->d, (int64_t)bt->B * (bt->T + (has_neg ? bt->K : 0)));
+}
+}  // namespace
+
+namespace {
+// One-hot form of the candidate-side time columns in a fused training step.  Forward: the logits GEMM contracts
+// 2 ldh + 160 columns (P OH^T).  Backward (TCAR_ONEHOT_TIME >= 2, ldt = 64, the order-fixed schedule): dX = dlogits [E_ic | OH],
+// dE keeps only its item block + per-candidate (q, z) pairs, and no launch of the step reads the time planes of E — they are
+// not refreshed by such a step.  Both halves of a step evaluate these predicates on the same (context, batch).
+bool onehot_fwd(const tcar_ctx_t* c, int B) {
+  return fused_ce(c, B, nullptr) && c->oh16 && c->p16h && c->p16l && c->scoring == 3 && tn(c).onehot_time != 0;
+}
+bool onehot_bwd(const tcar_ctx_t* c, const tcar_batch_t* bt) {
+  return onehot_fwd(c, bt->B) && tn(c).onehot_time >= 2 && c->tclip && c->dP && c->qz && c->d.ldt == 64 && c->et_perm && c->inv_off &&
+         c->ct_ws && c->stream3 && c->ev3 && c->gw_rows && sorted_rows(c, bt) && tn(c).det_small != 0;
 }
 }  // namespace
 
@@ -279,8 +307,9 @@ extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, in
 namespace {
 // model_combine.py:52-132 for the sessions of `bt`: gather + clip, the three input projections, the click query, both
 // attention pools and the output transforms -> c->attout [B, ek] (+ its bf16 planes when `planes`)
-// `hook(stage)`: called in front of the projection launch (0), behind it (1) and behind the click-query launch (2) — forward_impl
-// forks the rest pass of a pending split update there
+// `hook(stage, o)`: called in front of the projection launch (0: it may put a completion flag into o->sig for that launch to carry),
+// behind it (1: o->carried says whether it did) and behind the click-query launch (2) — forward_impl forks the rest pass of a
+// pending split update there
 template <class Hook>
 int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei, Hook hook) {
   const int B = bt->B, BT = bt->B * bt->T;
@@ -290,18 +319,21 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   // launch (query.hip) on the third stream BESIDE the projections instead of as two small GEMMs between them and the pools
   // (22 + 30 us on the main chain).  The gather publishes a flag for it, it publishes one for the pools; both producers store
   // what the other stream reads write-through, so the polling kernels write back no L2.
-  const int fmask = tcar_tuning().flag_fork;
-  hipStream_t sq = (g.ldh == 256 && g.ldt == 64 && c->stream3 && c->ev3 && ((fmask >> FK_GATHER) & 1) && ((fmask >> FK_QUERY) & 1))
+  const int fmask = tn(c).flag_fork;
+  hipStream_t sq = (g.ldh == 256 && g.ldt == 64 && c->stream3 && c->ev3 && fork_host(c) && ((fmask >> FK_GATHER) & 1) &&
+                    ((fmask >> FK_QUERY) & 1))
                        ? (hipStream_t)c->stream3 : nullptr;
-  if (sq) fork_arm(c, FK_GATHER);
-  RET(tcar_gather_clip_fwd(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream));
-  const bool qside = sq && fork_taken(c, FK_GATHER);       // (the throughput form of the gather carries no flag)
+  TcarOpt og = opt_of(c);
+  if (sq) og.sig = fork_arm(c, FK_GATHER);
+  RET(tcar_gather_clip_fwd_o(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream, &og));
+  const bool qside = sq && fork_commit(c, FK_GATHER, og);       // (the throughput form of the gather carries no flag)
   if (qside) {
     RET(fork_go(c, FK_GATHER, (hipStream_t)stream, sq, c->ev3));
-    fork_arm(c, FK_QUERY);
-    RET(tcar_query_mlp(&c->d, B, c->click_t, W(c, TCAR_V_Q1_W), W(c, TCAR_V_Q1_B), W(c, TCAR_V_Q2_W), W(c, TCAR_V_Q2_B), c->q1,
-                       c->q, (void*)sq));
-    if (!fork_taken(c, FK_QUERY)) return TCAR_E_LAUNCH;
+    TcarOpt oq = opt_of(c);
+    oq.sig = fork_arm(c, FK_QUERY);
+    RET(tcar_query_mlp_o(&c->d, B, c->click_t, W(c, TCAR_V_Q1_W), W(c, TCAR_V_Q1_B), W(c, TCAR_V_Q2_W), W(c, TCAR_V_Q2_B), c->q1,
+                         c->q, (void*)sq, &oq));
+    if (!fork_commit(c, FK_QUERY, oq)) return TCAR_E_LAUNCH;
   }
   // without the side stream (multi-rank engines, contexts without the flag words): the same ONE launch on this stream in
   // place of the two small GEMMs of the split-bf16 modes
@@ -316,7 +348,8 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   // kernel folds the slabs in slab order while it reads them (one writer per element: order-fixed)
   const int n1 = units(g.ic) + units(g.ldh) + units(g.ldt), n2 = units(g.pt) + units(g.ldh);
   const int64_t stride = (int64_t)BT * g.ldh;
-  const bool split = c->scoring && tcar_tuning().proj_split && c->proj_slabs && c->proj_slab_floats >= (n1 + n2) * stride;
+  const bool split = c->scoring && tn(c).proj_split && c->proj_slabs && c->proj_slab_floats >= (n1 + n2) * stride;
+  TcarOpt op = opt_of(c);          // the projection launch: the hook may hand it a completion flag
   if (split) {
     float* s1 = c->proj_slabs;
     float* s2 = c->proj_slabs + n1 * stride;
@@ -330,8 +363,8 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     p[5] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
     // optional HIP events around exactly this launch (kind 3 of ev_start / ev_stop: the largest of the session-side small GEMMs)
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[3 * c->ev_n + ei], (hipStream_t)stream);
-    RET(hook(0));
-    RET(small_gemm(c, 0, qfused ? 5 : 6, p, stream));
+    RET(hook(0, &op));
+    RET(small_gemm(c, 0, qfused ? 5 : 6, p, stream, &op));
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[3 * c->ev_n + ei], (hipStream_t)stream);
   } else {
     tcar_gemm_desc_t p[3];
@@ -343,17 +376,17 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     seg(p[1], c->x_pt, g.pt, W(c, TCAR_V_S_WIN), g.ldh, g.pt);
     seg(p[1], x_c, g.ic, W(c, TCAR_V_S_WC), g.ldh, g.ldh);
     p[2] = prob1(B, g.ldh, c->click_t, g.ct, W(c, TCAR_V_Q1_W), g.ldh, g.ct, c->q1, g.ldh, W(c, TCAR_V_Q1_B), 1);
-    RET(hook(0));
-    RET(small_gemm(c, 0, qfused ? 2 : 3, p, stream));
+    RET(hook(0, &op));
+    RET(small_gemm(c, 0, qfused ? 2 : 3, p, stream, &op));
   }
-  RET(hook(1));
+  RET(hook(1, &op));
   if (qside) {   // the pools wait for q: a polling kernel on this stream (no event)
     RET(fork_go(c, FK_QUERY, sq, (hipStream_t)stream, c->ev3));
   } else if (!qfused) {       // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
     RET(small_gemm(c, 0, 1, &p, stream));
   }
-  RET(hook(2));
+  RET(hook(2, &op));
   if (split)
     RET(tcar_attn_pool_fwd_slabs(&c->d, B, bt->T, c->x_icp, c->x_pt, c->proj_slabs, n1, c->proj_slabs + n1 * stride, n2, stride,
                                  c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
@@ -409,11 +442,9 @@ int zero_arena(const tcar_ctx_t* c, hipStream_t s) {
 int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t st, hipStream_t sz) {
   // (armed by forward_impl in front of the logits GEMM of a softmax-epilogue step; an event otherwise.  The arm must be THIS
   // context's latest fork action — nothing else forks between that launch and here —, else it is a leftover: event)
-  {
-    Fork& f = fork_slot(FK_LOGITS);
-    if (f.armed && (!c->sig_epoch || f.sig.epoch != c->sig_epoch[0])) f.armed = false;
-  }
-  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], tcar_tuning().fork_delay));
+  if (const ForkSlot* f = fork_live(c, FK_LOGITS))
+    if (f->sig.epoch != fork_host(c)->epoch) fork_disarm(c, FK_LOGITS);
+  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], tn(c).fork_delay));
   RET(zero_arena(c, sz));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
@@ -429,13 +460,16 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   hipStream_t s1 = (hipStream_t)stream, s2 = aux_stream(c);
   bool joined = true;
   int rest_stage = -1;
+  // a fused training step in the one-hot form reads the candidate-side time planes of E nowhere: their refresh is left to the
+  // next entry point that does (evaluation, the op-level paths: the engine keeps refresh_time set until one of them ran)
+  const bool oh_bwd = train_index && onehot_bwd(c, bt);
   // REST pass of a pending split update, on the aux stream (behind whatever the main stream has enqueued so far when it is
   // forked late); ev[1] = "aux stream ready for the logits GEMM"
   auto launch_rest = [&]() -> int {
     const float* pieces = c->Gx + c->arena_n;
-    RET(tcar_clip_adam_rest_keep(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
-                                 c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
-                                 c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2));
+    RET(tcar_clip_adam_rest_keep_o(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
+                                   c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
+                                   c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2, tn(c).rest_grid));
     if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
     // the marks are cleared BEHIND the event the logits GEMM waits for (the clear is a launch of its own)
     if (hipMemsetAsync(c->adam_bitmap, 0, (size_t)((g.N + 31) / 32) * sizeof(uint32_t), s2) != hipSuccess) return TCAR_E_LAUNCH;
@@ -457,7 +491,8 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
                                c->adam_bitmap, stream));
       if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
         return TCAR_E_LAUNCH;
-      RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, (void*)s2));
+      if (!oh_bwd)
+        RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, (void*)s2));
       // the rest pass is forked BEHIND the projection launch: gather and projections run without the 376-MB stream beside
       // them (21 instead of 40 us for the projections), the pass still ends before the output transforms do.  Measured over
       // three interleaved rounds: 0.6158 ms per step against 0.6213 forked at once and 0.628 forked behind the query MLP.
@@ -466,8 +501,9 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     } else {
       if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
         return TCAR_E_LAUNCH;
-      RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
-                                  s2 ? (void*)s2 : stream));
+      if (!oh_bwd)
+        RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr,
+                                    s2 ? (void*)s2 : stream));
       if (s2) {
         if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
         joined = false;
@@ -480,10 +516,11 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     ei = c->ev_cursor[0]++ % c->ev_n;
     c->ev_cursor[1] = ei;
   }
-  RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage) -> int {
-    if (rest_stage == 1 && stage == 0) fork_arm(c, FK_PROJ);        // in front of the projection launch
+  RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage, TcarOpt* o) -> int {
+    if (rest_stage == 1 && stage == 0) o->sig = fork_arm(c, FK_PROJ);        // the projection launch carries the flag
     if (stage != rest_stage) return TCAR_OK;
     // late fork: the HBM-bound rest pass starts only now, so the launches before this point ran without it
+    (void)fork_commit(c, FK_PROJ, *o);
     RET(fork_go(c, FK_PROJ, s1, s2, c->ev[0]));      // (the rest pass reads nothing the projections write: timing only)
     return launch_rest();
   }));
@@ -502,11 +539,11 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   // AHEAD of the join with the aux stream.
   CeWs w;
   const bool ce_epi = c->scoring && train_index && fused_ce(c, B, &w);
-  const bool onehot = ce_epi && c->oh16 && c->p16h && c->p16l && c->scoring == 3 && tcar_tuning().onehot_time;
+  const bool onehot = ce_epi && onehot_fwd(c, B);
   if (onehot) {
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-    RET(tcar_time_scores(&c->d, tt, B, c->attout, g.ek, c->p16h, c->p16l, 160, stream));
+    RET(tcar_time_scores_clip(&c->d, tt, B, c->attout, g.ek, c->p16h, c->p16l, 160, oh_bwd ? c->tclip : nullptr, stream));
   }
   if (!joined && hipStreamWaitEvent(s1, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // logits = attout E^T (model_combine.py:138).  Optional HIP events bracket exactly the GEMM launch (bench.py roofline).
@@ -514,29 +551,31 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[ei], (hipStream_t)stream);
   };
   int rc;
-  fork_disarm(FK_LOGITS);              // (EVERY forward pass: the slot is the one fork whose arm and go sit in different calls)
+  fork_disarm(c, FK_LOGITS);           // (EVERY forward pass: the slot is the one fork whose arm and go sit in different calls)
+  TcarOpt ol = opt_of(c);
   if (c->scoring) {
     // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
-    if (ce_epi && s2) fork_arm(c, FK_LOGITS);       // backward_prologue releases the aux stream behind this launch
+    if (ce_epi && s2) ol.sig = fork_arm(c, FK_LOGITS);       // backward_prologue releases the aux stream behind this launch
     if (ce_epi) {
       // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes
       // dlogits, plus per-group (max, sum) — no [B, N] fp32 logits; backward_impl finishes with tcar_ce_finish
       int32_t gw = 0, ng = 0;
       if (onehot) {
-        rc = tcar_gemm_bf16_ce(B, g.N, g.ic + 160, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, g.ic, c->p16h,
-                               c->p16l, c->oh16, 160, c->dl16h, g.Npad, (B + 127) & ~127, w.stats, w.stats_floats, bt->label,
-                               w.lab, c->scoring, &gw, &ng, stream);
+        rc = tcar_gemm_bf16_ce_o(B, g.N, g.ic + 160, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, g.ic, c->p16h,
+                                 c->p16l, c->oh16, 160, c->dl16h, g.Npad, (B + 127) & ~127, w.stats, w.stats_floats, bt->label,
+                                 w.lab, c->scoring, &gw, &ng, stream, &ol);
       } else {
-        rc = tcar_gemm_bf16_ce(B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, g.ek, nullptr, nullptr,
-                               nullptr, 0, c->dl16h, g.Npad, (B + 127) & ~127, w.stats, w.stats_floats, bt->label, w.lab,
-                               c->scoring, &gw, &ng, stream);
+        rc = tcar_gemm_bf16_ce_o(B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, g.ek, nullptr, nullptr,
+                                 nullptr, 0, c->dl16h, g.Npad, (B + 127) & ~127, w.stats, w.stats_floats, bt->label, w.lab,
+                                 c->scoring, &gw, &ng, stream, &ol);
       }
+      if (!rc) (void)fork_commit(c, FK_LOGITS, ol);
       if (!rc && c->ce_geo) { c->ce_geo[0] = gw; c->ce_geo[1] = ng; }
       else if (!rc) rc = TCAR_E_ARG;
     } else {
-      rc = tcar_gemm_bf16(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
-                          nullptr, 0, 0, c->scoring, 1, stream);
+      rc = tcar_gemm_bf16_perm_o(1, B, g.N, g.ek, c->a16h, c->a16l, g.ek, B, c->e16h, c->e16l, g.ek, g.Npad, c->logits, g.Npad,
+                                 nullptr, 0, 0, nullptr, 0, c->scoring, 1, stream, &ol);
     }
   } else {
     start_timer();
@@ -552,7 +591,7 @@ namespace {
 // (1,536) rows; longer batches split it — into slabs folded in split order when the context has the workspace (order-fixed:
 // tcar_fold_slabs), else with float atomics into the zeroed arena.
 int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream) {
-  const int ksdiv = tcar_tuning().wgrad_ks > 0 ? tcar_tuning().wgrad_ks : 1536;
+  const int ksdiv = tn(c).wgrad_ks > 0 ? tn(c).wgrad_ks : 1536;
   auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
   const int kb = ks(B), kr = ks(BT);
   const float* x_c = c->x_icp + g.ldh;
@@ -633,6 +672,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // sorted segmented sum of the item-row gradients (deterministic); its index was built under the forward pass, on the aux
   // stream — ev[1] (recorded behind the prologue) orders the main stream behind it
   const bool sorted = fuse_finish && sorted_rows(c, bt);
+  // one-hot form of the two gradient GEMMs (the forward half of this step made the same decision: onehot_bwd)
+  const bool ohb = ce_epilogue && fuse_finish && onehot_bwd(c, bt);
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
   const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
@@ -642,7 +683,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   CeWs cw;
   if (ce_epilogue && fused_ce(c, B, &cw))   // the forward pass of THIS step ran the softmax epilogue (same predicate)
     RET(tcar_ce_finish(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream));
-  else if (c->scoring) RET(tcar_softmax_ce_bf16(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
+  else if (c->scoring) RET(tcar_softmax_ce_bf16_o(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream, tn(c).softmax_variant));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
@@ -656,11 +697,17 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const bool split_finish = fuse_finish && s2;
   auto chain_b = [&]() -> int {
     tick(2, false, sB);
-    if (c->scoring) {
+    if (ohb) {
+      // item block only; the time block leaves as per-candidate (||gy||^2, x . gy) pairs in the order of the inverted index
+      TcarOpt ob = opt_of(c);
+      RET(tcar_gemm_bf16_de_qz_o(g.N, (B + 31) & ~31, c->dl16h, g.Npad, (B + 127) & ~127, c->ap16h, g.ldh + g.pt, (B + 127) & ~127,
+                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, tn(c).bf16_tile == 256 ? 256 : 0, sB, &ob));
+    } else if (c->scoring) {
       // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
-      RET(tcar_gemm_bf16_perm(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h,
-                              c->ap16l, g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, c->et_perm, g.ldt, nsb, 1,
-                              sB));
+      TcarOpt ob = opt_of(c);
+      RET(tcar_gemm_bf16_perm_o(2, g.N, g.ldh + g.pt, (B + 31) & ~31, c->dl16h, c->dl16l, g.Npad, (B + 127) & ~127, c->ap16h,
+                                c->ap16l, g.ldh + g.pt, (B + 127) & ~127, Gi, g.ldh, d_et, g.pt, g.ldh, c->et_perm, g.ldt, nsb, 1,
+                                sB, &ob));
     } else {  // dE = dlogits^T attout: item block and time block (content is frozen)
       tcar_gemm_desc_t p[2];
       p[0] = prob1(g.N, g.ldh, c->logits, g.Npad, c->attout, g.ek, B, Gi, g.ldh);
@@ -674,7 +721,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     if (split_finish && hipEventRecord((hipEvent_t)c->ev[4], s2) != hipSuccess) return TCAR_E_LAUNCH;         // dE done
     if (has_neg && !split_finish)
       RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, sB));
-    if (fuse_finish) RET(split_finish ? cand_time_backward(c, g, sB) : finish_dense_side(c, g, sB));
+    // (one-hot form: the candidate-side table gradients need dP of the dX chain too — they follow on this stream further down)
+    if (fuse_finish && !ohb) RET(split_finish ? cand_time_backward(c, g, sB) : finish_dense_side(c, g, sB));
     if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // chain B done
     return TCAR_OK;
   };
@@ -691,9 +739,14 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   }
   // ---- chain A
   tick(1, false, stream);
-  if (c->scoring) {
-    RET(tcar_gemm_bf16(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
-                       nullptr, 0, 0, nsb, c->splitk, stream));
+  if (ohb) {
+    TcarOpt ox = opt_of(c);
+    RET(tcar_gemm_bf16_dx_onehot_o(B, g.ic, g.Npad, c->dl16h, g.Npad, B, c->e16h, g.ek, g.Npad, c->oh16, 160, c->slabs, g.ic + 160,
+                                   c->splitk, stream, &ox));
+  } else if (c->scoring) {
+    TcarOpt ox = opt_of(c);
+    RET(tcar_gemm_bf16_perm_o(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
+                              nullptr, 0, 0, nullptr, 0, nsb, c->splitk, stream, &ox));
   } else {
     RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
   }
@@ -707,14 +760,19 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // producers below leave the column sums to ONE tcar_colsum_det launch behind the weight-gradient GEMM
   const bool fusedq = c->scoring != 0;
   const bool detc = fusedq && c->gw_rows != nullptr;
-  RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
-                              c->dattout, detc ? nullptr : G(c, TCAR_V_O_B), g.ic, detc ? nullptr : G(c, TCAR_V_OT_B), stream));
+  if (ohb)      // ... and the one-hot columns: dP = their slab sum, expanded to the time columns of dattout on the spot
+    RET(tcar_reduce_dact_onehot_o(c->slabs, S, B, g.ic, g.ic + 160, has_neg ? c->negpart : nullptr, g.ic, c->attout, g.ek, c->tclip,
+                                  c->dattout, g.ek, c->dP, detc ? nullptr : G(c, TCAR_V_O_B), detc ? nullptr : G(c, TCAR_V_OT_B), stream,
+                                  nullptr));
+  else
+    RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
+                                c->dattout, detc ? nullptr : G(c, TCAR_V_O_B), g.ic, detc ? nullptr : G(c, TCAR_V_OT_B), stream));
   if (!has_neg && hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
   // dpooled = dattout W_o^T (both output transforms).  Split form (slab workspace + order-fixed pool backward): every 128-deep K
   // chunk is its own set of workgroups writing its own slab, the pool backward folds them while it loads dpooled
   const int nd_ic = units(g.ic), nd_pt = units(g.pt);
   const int64_t dstride = (int64_t)B * g.ek;
-  const bool dsplit = detc && tcar_tuning().proj_split && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
+  const bool dsplit = detc && tn(c).proj_split && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
   {
     tcar_gemm_desc_t p[2];
     float* dp = dsplit ? c->proj_slabs : c->dpooled;
@@ -742,10 +800,13 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
     p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
-    if (s2 && fuse_finish && c->stream3 && c->ev3) fork_arm(c, FK_INGRAD);     // the third stream's fork below
-    RET(small_gemm(c, 1, 4, p, stream));
+    TcarOpt oi = opt_of(c);
+    if (s2 && fuse_finish && c->stream3 && c->ev3) oi.sig = fork_arm(c, FK_INGRAD);     // the third stream's fork below
+    else fork_disarm(c, FK_INGRAD);
+    RET(small_gemm(c, 1, 4, p, stream, &oi));
+    (void)fork_commit(c, FK_INGRAD, oi);
   } else {
-    fork_disarm(FK_INGRAD);
+    fork_disarm(c, FK_INGRAD);
     RET(tcar_dact_colsum(B, g.ic, g.ic, c->q, c->dq, G(c, TCAR_V_Q2_B), 2, stream));
     {
       tcar_gemm_desc_t p = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
@@ -767,7 +828,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     return TCAR_E_LAUNCH;
   // Order-fixed small tables (sorted mode, which implies an aux stream): they — and the click-query input gradient, which only
   // they consume — run on the aux stream behind the candidate-time backward, beside the rest of the main chain
-  const bool det_small = sorted && tcar_tuning().det_small != 0;
+  const bool det_small = sorted && tn(c).det_small != 0;
   RET(weight_grads(c, g, B, BT, sW));
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
@@ -775,20 +836,26 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // The step's LAST join (aux + third stream into the main one, in front of the next update): two event waits cost the main
   // stream two barrier packets behind whichever chain ends last (16-20 us); with flag forks the last launch of either side
   // stream publishes a flag and ONE poll on the main stream waits for both.
-  const int tmask = tcar_tuning().flag_fork;
+  const int tmask = tn(c).flag_fork;
   const bool tail_flags = s3 && fuse_finish && det_small && ((tmask >> FK_TAIL2) & 1) && ((tmask >> FK_TAIL3) & 1);
   bool tail3 = false, tail2 = false;
-  if (tail_flags) fork_arm(c, FK_TAIL3);
-  if (fuse_finish && s2) RET(tcar_sqnorm(c->Gx, &c->segs_dense, c->sqn_dense, sW));
-  if (tail_flags) tail3 = fork_taken(c, FK_TAIL3);
+  if (fuse_finish && s2) {
+    TcarOpt o3 = opt_of(c);
+    if (tail_flags) o3.sig = fork_arm(c, FK_TAIL3);
+    RET(tcar_sqnorm_o(c->Gx, &c->segs_dense, c->sqn_dense, sW, &o3));
+    if (tail_flags) tail3 = fork_commit(c, FK_TAIL3, o3);
+  }
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
     tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
-    if (det_small) fork_arm(c, FK_DCLICK);
-    RET(small_gemm(c, 1, 1, &p, stream));
+    TcarOpt od = opt_of(c);
+    if (det_small) od.sig = fork_arm(c, FK_DCLICK);
+    else fork_disarm(c, FK_DCLICK);
+    RET(small_gemm(c, 1, 1, &p, stream, &od));
+    (void)fork_commit(c, FK_DCLICK, od);
   } else {  // input gradients (only the ITEM half of dX_ic: content is frozen)
-    fork_disarm(FK_DCLICK);
+    fork_disarm(c, FK_DCLICK);
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
@@ -805,9 +872,13 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
     RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5]));
-    if (tail3) fork_arm(c, FK_TAIL2);
-    RET(tcar_small_tables_bwd_det(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2));
-    if (tail3) tail2 = fork_taken(c, FK_TAIL2);
+    // one-hot form: the candidate-side time-table gradients, from dE's (q, z) pairs (this stream) and dP (main chain, long done)
+    if (ohb)
+      RET(tcar_cand_time_bwd_onehot(&c->d, B, c->inv_off, c->qz, c->dP, c->attout, g.ek, c->tclip, c->ct_ws, &gr, (void*)s2));
+    TcarOpt o2 = opt_of(c);
+    if (tail3) o2.sig = fork_arm(c, FK_TAIL2);
+    RET(tcar_small_tables_bwd_det_o(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2, &o2));
+    if (tail3) tail2 = fork_commit(c, FK_TAIL2, o2);
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
   if (split_finish) {   // Gi is complete once dE has landed: negative rows (+ loss), then its norm BEFORE any row scatter (S5)
@@ -851,12 +922,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     }
   }
   if (tail2 && tail3) {
-    const Fork& f2 = fork_slot(FK_TAIL2);
-    const Fork& f3 = fork_slot(FK_TAIL3);
+    const ForkSlot& f2 = fork_host(c)->slot[FK_TAIL2];
+    const ForkSlot& f3 = fork_host(c)->slot[FK_TAIL3];
     // light poll: both flagged launches publish their own results with atomics (norm slots), and everything else the update
     // reads was written by EARLIER launches of those streams, released when they ended
-    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)f2.sig.flag, f2.sig.epoch, c->sig_dev + TCAR_SIG_ERR, POLL_TICKS,
-                (const unsigned*)f3.sig.flag, f3.sig.epoch);
+    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)f2.sig.flag, f2.sig.epoch, c->sig_dev + TCAR_SIG_ERR,
+                c->sig_err_host, POLL_TICKS, (const unsigned*)f3.sig.flag, f3.sig.epoch, 0);
     TCAR_CHECK_LAUNCH();
   } else {
     if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;    // the aux stream is done
@@ -957,7 +1028,7 @@ extern "C" int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t
   RET(check_ctx(c, bt));
   if (!c->scoring) return TCAR_E_ARG;                   // split-bf16 modes only
   const Geo g(c->d);
-  RET(session_forward(c, bt, g, stream, false, -1, [](int) { return (int)TCAR_OK; }));
+  RET(session_forward(c, bt, g, stream, false, -1, [](int, TcarOpt*) { return (int)TCAR_OK; }));
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
     RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, stream));
   return TCAR_OK;
@@ -1153,11 +1224,11 @@ extern "C" int tcar_graph_probe(const tcar_ctx_t* c, const tcar_batch_t* bt, flo
   if (!ms_out || iters <= 0) return TCAR_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   // a replayed graph would poll the epochs of the captured step (long satisfied): capture the event forks only
-  struct NoFlags {
-    int prev;
-    NoFlags() : prev(tuning_storage().flag_fork) { tuning_storage().flag_fork = 0; }
-    ~NoFlags() { tuning_storage().flag_fork = prev; }
-  } no_flags;
+  tcar_ctx_t cc = *c;
+  TcarTuning no_flags = tn(c);
+  no_flags.flag_fork = 0;
+  cc.tune = &no_flags;
+  c = &cc;
   RET(tcar_train_step(c, bt, 1, lr_t, stream));             // eager once: first-use attribute calls happen outside the capture
   if (hipStreamSynchronize(st) != hipSuccess) return TCAR_E_LAUNCH;
   hipGraph_t graph = nullptr;

@@ -47,27 +47,10 @@ static inline bool tcar_first_on_device(TcarOnce& o) {
       (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
   } while (0)
 
-// Diagnostic tuning switches (environment, read ONCE per process at first use — C++11 thread-safe static — never per
-// launch).  Defaults are the shipped configuration; README.md lists them.  Defined in step.hip.
-struct TcarTuning {
-  int bf16_tile;        // TCAR_BF16_TILE      force a workgroup tile of the bf16 GEMM (0 = heuristic; tests pin every tile shape with it)
-  int rest_grid;        // TCAR_REST_GRID      grid cap of the deferred Adam rest pass
-  int softmax_variant;  // TCAR_SOFTMAX_VARIANT
-  int wgrad_ks;         // TCAR_WGRAD_KS       K chunk of the weight-gradient split
-  int gather_big_rows;  // TCAR_GATHER_BIG_ROWS  session rows from which the forward gather runs its throughput form
-  int gather_wg_per_cu; // TCAR_GATHER_WG      1024-thread workgroups per CU of that form (2 x 78 KB of LDS fit)
-  int mha_mfma;         // TCAR_MHA_MFMA       0: multihead_attention core always in its scalar form
-  int sort_scatter;     // TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum
-  int bf16_ks;          // TCAR_BF16_KS        64-deep LDS stages of the hi-only bf16 GEMM: 1 never, 2 dX / logits layouts, 3 all
-  int det_small;        // TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode)
-  int x3_oneshot;       // TCAR_X3_ONESHOT     0: short-K small-GEMM launches keep the one-stage register ring
-  int fused_ce;         // TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel
-  int onehot_time;      // TCAR_ONEHOT_TIME    0: the logits GEMM of a training step contracts the 5 ldt clipped candidate time columns instead of the 160-column one-hot form
-  int proj_split;       // TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs
-  int fork_delay;       // TCAR_FORK_DELAY     us a DELAYED flag fork holds its consumer back behind the producer's end (step.hip)
-  int flag_fork;        // TCAR_FLAG_FORK      0: every fork of the main stream records an event (6-7 us of bubble on it) instead of
-                        //                     letting the producing kernel publish a device flag a polling kernel of the side stream waits for
-};
+// Diagnostic tuning switches: tcar_tuning_t of include/tcar_hip.h.  tcar_tuning() is the PROCESS snapshot — shipped defaults
+// overridden by the TCAR_* environment, read ONCE at first use (C++11 thread-safe static) and never written again; a context
+// (tcar_ctx_t.tune) or a *_tuned entry point may carry its own copy instead.  Defined in step.hip.
+typedef tcar_tuning_t TcarTuning;
 const TcarTuning& tcar_tuning();
 
 // Completion flag of a kernel (step.hip: fork_arm / fork_go).  A kernel that carries one publishes `epoch` to *flag when its
@@ -75,18 +58,59 @@ const TcarTuning& tcar_tuning();
 // stream would have to record (measured, tools/micro/event_cost: a record between two kernels costs the recording stream 6.5 us,
 // the flag costs it nothing and releases the consumer 0.4 us after the producer's end).  cnt == nullptr: no flag.
 struct TcarSignal { unsigned* cnt; unsigned* flag; unsigned epoch; unsigned slot; };
-// the flag the NEXT flag-capable launch of this host thread carries (it takes it: tcar_take_signal); defined in step.hip
-TcarSignal& tcar_pending_signal();
-// the epoch of the flag the launches of this host thread last TOOK for a slot (step.hip: a fork is released by a polling kernel
-// only when the producing launch really carries its flag, whatever else happened to the pending one in between)
-unsigned& tcar_taken_epoch(unsigned slot);
-inline TcarSignal tcar_take_signal() {
-  TcarSignal& p = tcar_pending_signal();
-  const TcarSignal s = p;
-  p = TcarSignal{};
-  if (s.cnt) tcar_taken_epoch(s.slot) = s.epoch;
-  return s;
+// Launch options of the internal (C++) forms of the entry points, `..._o`: the tuning copy to consult (NULL = process snapshot)
+// and the completion flag THIS launch is to carry — passed explicitly, there is no per-thread "pending" state.  The launcher
+// sets `carried` when the kernel form it chose publishes the flag (flag-capable forms: the latency form of the forward gather,
+// the click-query MLP, small-GEMM launches WITHOUT bf16 plane outputs, the softmax-epilogue logits GEMM, sqnorm_seg, the
+// small-table norm fold); a launch that cannot carry it leaves `carried` false and the driver forks with an event.
+struct TcarOpt {
+  const tcar_tuning_t* tune = nullptr;
+  TcarSignal sig{};
+  bool carried = false;
+  const TcarTuning& tn() const { return tune ? *tune : tcar_tuning(); }
+};
+inline const TcarTuning& tcar_tn(const TcarOpt* o) { return o ? o->tn() : tcar_tuning(); }
+inline TcarSignal tcar_sig(TcarOpt* o) {       // the flag a flag-capable launch carries (marks it carried)
+  if (!o || !o->sig.cnt) return TcarSignal{};
+  o->carried = true;
+  return o->sig;
 }
+// ---- internal (C++ linkage) forms of entry points that consult a switch or can carry a completion flag; the extern "C" names of
+// include/tcar_hip.h call them with the process snapshot and no flag
+int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, float* x_icp, float* x_pt,
+                           float* x_act, float* click_t, void* stream, TcarOpt* o);
+int tcar_query_mlp_o(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b, const float* q2_w,
+                     const float* q2_b, float* q1, float* q, void* stream, TcarOpt* o);
+int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
+                                const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
+                                void* stream, TcarOpt* o);
+int tcar_sqnorm_o(const float* g, const tcar_segments_t* segs, float* sqn_dense, void* stream, TcarOpt* o);
+int tcar_gemm_x3_grouped_o(int layout, int nprob, const tcar_gemm_desc_t* descs, void* stream, TcarOpt* o);
+int tcar_gemm_bf16_perm_o(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
+                          const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
+                          int64_t ldc2, int csplit, const int32_t* c2_perm, int c2_group, int nsplit, int splitk, void* stream,
+                          TcarOpt* o);
+int tcar_gemm_bf16_ce_o(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows, const void* B_hi,
+                        const void* B_lo, int64_t b_inner, int64_t b_rows, int K1, const void* A2_hi, const void* A2_lo,
+                        const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner, int64_t p_rows, float* stats,
+                        int64_t stats_floats, const int32_t* label, float* lab_logit, int nsplit, int32_t* group_width,
+                        int32_t* ngroups, void* stream, TcarOpt* o);
+int tcar_gemm_bf16_dx_onehot_o(int M, int N1, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi,
+                               int64_t b_inner, int64_t b_rows, const void* B2_hi, int64_t inner2, float* C, int64_t ldc, int splitk,
+                               void* stream, TcarOpt* o);
+int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi, int64_t b_inner,
+                           int64_t b_rows, int ldh, float* C, int64_t ldc, const int32_t* mwdhm, const int32_t* perm,
+                           const float* tclip, float* qz, int tile, void* stream, TcarOpt* o);
+int tcar_reduce_dact_onehot_o(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
+                              const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo, float* dP, float* bias_grad0,
+                              float* bias_grad1, void* stream, TcarOpt* o);
+int tcar_clip_adam_rest_keep_o(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols,
+                               int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip,
+                               float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16,
+                               uint32_t* bitmap, void* stream, int rest_grid);
+int tcar_softmax_ce_bf16_o(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* dl_hi, void* dl_lo,
+                           void* stream, int variant);
+
 // 16-byte write-through store (sc1): the bytes bypass the write-back state of this XCD's L2, so a consumer behind a completion
 // flag needs no release fence / L2 write-back from the producer (cdna_hip_programming.md Guideline 16, R1).  The compiler does not
 // count this store: drain with an explicit s_waitcnt vmcnt(0) before signalling (tcar_signal_done does).

@@ -283,16 +283,28 @@ class TcarEngine:
               "tcar_flag_fork_selftest")
         return bool(ok.value)
 
+    _FORK_MSG = ("%d flag-fork poll(s) timed out: the step's streams are not running concurrently and a consumer may have run "
+                 "ahead of its producer — results since the last check are invalid (set TCAR_FLAG_FORK=0 to fork with events)")
+
+    def poll_fork_errors(self):
+        """Fail fast, WITHOUT synchronising: a poll that gives up also counts in a pinned host word (tcar_ctx_t.sig_err_host,
+        system-scope atomic), which the host reads here after every step.  A time-out is seen at most a step or two after it
+        happened (the host runs ahead of the device by that much), long before an epoch ends or anything is reported."""
+        eh = getattr(self, "_sig_err_np", None)
+        if eh is not None and eh[0]:
+            raise RuntimeError(self._FORK_MSG % int(eh[0]))
+
     def check_forks(self):
         """Raise if a polling kernel of a flag fork (tcar_ctx_t.sig_dev) ever gave up waiting: the side streams did not run
         beside the main stream (kernels serialised by a profiler's counter collection, or streams sharing one hardware queue),
-        and a consumer may have run ahead of its producer.  Synchronises the device; called where the host reads results
-        back (export_state, the training loop's epoch end, bench.py after its timed loop)."""
+        and a consumer may have run ahead of its producer.  Synchronises the device; called wherever the host reads results
+        back: every evaluation step, export_state / export_params (checkpoints), the training loop's epoch end, bench.py after
+        its timed loop.  Between those, poll_fork_errors() tests the host-visible mirror after every training step."""
         if getattr(self, "_sig", None) is not None:
             n = int(self._sig[32].item())
             if n:
-                raise RuntimeError(f"{n} flag-fork poll(s) timed out: the step's streams are not running concurrently "
-                                   "(set TCAR_FLAG_FORK=0 to fork with events)")
+                raise RuntimeError(self._FORK_MSG % n)
+        self.poll_fork_errors()
 
     def export_state(self) -> Dict[str, np.ndarray]:
         """Everything a resumed run needs, as plain arrays (np.savez, loadable with allow_pickle=False): the 23 variables
@@ -806,6 +818,14 @@ class TcarEngine:
                         self._p16h = torch.zeros(Bp * 160, dtype=torch.bfloat16, device=self.dev)
                         self._p16l = torch.zeros(Bp * 160, dtype=torch.bfloat16, device=self.dev)
                     c.oh16, c.p16h, c.p16l = self._oh16.data_ptr(), self._p16h.data_ptr(), self._p16l.data_ptr()
+                    # one-hot form of the scoring gradients: clipped time rows, dP = dlogits OH, per-candidate (q, z) pairs
+                    if g.ldt == 64 and not os.environ.get("TCAR_NO_ONEHOT_BWD"):
+                        if getattr(self, "_tclip", None) is None:
+                            self._tclip = torch.zeros(160 * g.ldt + 320, dtype=torch.float32, device=self.dev)
+                            self._qz = torch.zeros(5 * g.N * 2, dtype=torch.float32, device=self.dev)
+                        if getattr(self, "_dP", None) is None or self._dP.numel() < self.work_B * 160:
+                            self._dP = torch.zeros(self.work_B * 160, dtype=torch.float32, device=self.dev)
+                        c.tclip, c.dP, c.qz = self._tclip.data_ptr(), self._dP.data_ptr(), self._qz.data_ptr()
         if self.overlap:
             if not hasattr(self, "_aux"):
                 self._aux = torch.cuda.Stream(self.dev)
@@ -833,7 +853,11 @@ class TcarEngine:
             if type(self) is TcarEngine and not os.environ.get("TCAR_NO_FLAG_FORK"):
                 if not hasattr(self, "_sig"):
                     self._sig = torch.zeros(80, dtype=torch.int32, device=self.dev)
-                    self._sig_epoch = (C.c_uint32 * 1)(0)
+                    # the driver's fork slots and epoch counter: host memory owned by THIS engine (nothing per thread / process)
+                    self._fork_host = (C.c_uint8 * int(self.lib.tcar_fork_state_bytes()))()
+                    # time-outs are mirrored into a pinned, device-visible host word: poll_fork_errors() reads it without a sync
+                    self._sig_err = torch.zeros(16, dtype=torch.int32).pin_memory()
+                    self._sig_err_np = self._sig_err.numpy()
                     # one probe: do the side streams run BESIDE the main stream here?  (Not under a counter-collecting
                     # profiler or with serialised kernels: every poll would sit out its time-out — events then.)
                     if not self._probe_flag_forks():
@@ -842,7 +866,10 @@ class TcarEngine:
                                       "collection / serialised kernels / shared hardware queue): flag forks off, events instead")
                         self._sig = None
                 if self._sig is not None:
-                    c.sig_dev, c.sig_epoch = self._sig.data_ptr(), C.cast(self._sig_epoch, C.c_void_p)
+                    c.sig_dev, c.fork_host = self._sig.data_ptr(), C.cast(self._fork_host, C.c_void_p)
+                    c.sig_err_host = self._sig_err.data_ptr()
+        if self.tune is not None:
+            c.tune = C.cast(C.pointer(self.tune), C.c_void_p)
         if self._ev is not None:
             c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
             c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)
@@ -852,6 +879,14 @@ class TcarEngine:
         return c
 
     _ev = None
+    tune = None          # optional _lib.Tuning copy of THIS engine (set_tuning); None = the process-wide switch values
+
+    def set_tuning(self, **overrides):
+        """Give this engine its own copy of the TCAR_* switches with `overrides` applied (tests, tools: e.g.
+        set_tuning(TCAR_FLAG_FORK=0)); other engines and the process-wide values are untouched."""
+        self.flush()
+        self.tune = _lib.tuning(**overrides)
+        self._ctx_key = None
 
     TIMED_KERNELS = ("score_fwd", "score_dx", "score_dE", "session_proj")      # kinds 0..3 of tcar_ctx_t.ev_start / ev_stop
 
@@ -917,12 +952,14 @@ class TcarEngine:
                                                         self._stream()), "tcar_train_step_deferred")
                 self._pending_lr = self._lr_t()
                 self._after_update()              # step count / beta powers advance now; the device work is owed
+                self.poll_fork_errors()
                 if not defer_update:
                     self.flush()
             else:
                 check(self.lib.tcar_train_step(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), self._lr_t(),
                                                self._stream()), "tcar_train_step")
                 self._after_update()
+                self.poll_fork_errors()
         else:
             self.flush()
             self.forward(bt)
@@ -945,6 +982,34 @@ class TcarEngine:
             self.backward(bt)
         return self._loss_view(bt)
 
+    # ---- diversity metrics of the evaluation loop on the device (model_combine.py:174-194,301-313)
+    def set_categories(self, cat_of_item: np.ndarray):
+        """cat_of_item [N]: integer category code of every 0-based item (host/metrics.category_table); also allocates the
+        byte map of recommended items behind `coverage()`."""
+        cat = np.ascontiguousarray(np.asarray(cat_of_item).reshape(-1), dtype=np.int32)
+        if cat.shape[0] != self.geo.N:
+            raise ValueError("category table must have one entry per catalog item")
+        self._cat = torch.tensor(cat, device=self.dev)
+        self._seen = torch.zeros(self.geo.N, dtype=torch.uint8, device=self.dev)
+
+    def reset_coverage(self):
+        self._seen.zero_()
+
+    def eval_diversity(self, bt: Batch, topk: torch.Tensor):
+        """getILD / getUnexp pair counts of the sessions of `bt` for their top-k lists (int32 [B] each, on the device) and
+        the recommended items marked in the coverage map; divide with host.metrics.diversity_from_counts."""
+        B, k = bt.B, int(topk.shape[1])
+        topk = topk[:B].contiguous()
+        out = torch.empty(3, B, dtype=torch.int32, device=self.dev)
+        p = self._p
+        check(self.lib.tcar_eval_diversity(B, bt.T, k, self.geo.N, p(topk), C.c_void_p(bt.seq), p(self._cat), p(out[0]), p(out[1]),
+                                           p(out[2]), C.c_void_p(self._seen.data_ptr()), self._stream()), "tcar_eval_diversity")
+        return out[0], out[1], out[2]
+
+    def coverage(self) -> int:
+        """number of distinct items recommended since reset_coverage() (len(resultItemDict), model_combine.py:313)"""
+        return int(self._seen.sum(dtype=torch.int64).item())
+
     def eval_step(self, batch, k: int = 20, bt: Optional[Batch] = None, keep_logits: bool = False):
         """sess.run([softmax_input, cross_loss]) (model_combine.py:283) + rank / top-k on device.
         Returns (rank[B] int32, topk[B,k] int32, ce[B] f32[, logits [B,N]])."""
@@ -958,6 +1023,7 @@ class TcarEngine:
             check(self.lib.tcar_eval_step(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), k, self._stream()),
                   "tcar_eval_step")
             self._time_dirty = False
+            self.poll_fork_errors()
             return (self.rank[:B], self.topk[:B], self.ce[:B])
         if self.native:
             check(self.lib.tcar_step_forward(C.byref(self._ctx()), C.byref(bt), int(self._time_dirty), self._stream()),

@@ -48,6 +48,17 @@ def unexp_batch(seq: np.ndarray, topk: np.ndarray, cat_of_item: np.ndarray) -> n
     return diff / float(cr.shape[1] * ci.shape[1])
 
 
+def diversity_from_counts(ild_cnt, unexp_cnt, n_rec, T: int):
+    """The divisions of getILD / getUnexp (model_combine.py:182,194) on the integer pair counts the device kernel
+    tcar_eval_diversity returns: score / (n (n - 1)) and score / (n len(inSeq)) — Python int / int, i.e. double precision."""
+    ild_cnt = np.asarray(ild_cnt, dtype=np.int64)
+    unexp_cnt = np.asarray(unexp_cnt, dtype=np.int64)
+    n = np.asarray(n_rec, dtype=np.int64)
+    ild = ild_cnt / (n * (n - 1)).astype(np.float64)
+    unexp = np.where(n > 0, unexp_cnt / np.maximum(n * int(T), 1).astype(np.float64), 0.0)      # getUnexp returns 0 for n == 0
+    return ild, unexp
+
+
 def category_table(reverse_item: dict, category_id, n_items: int) -> np.ndarray:
     """int table cat[item0] = code of category_id[reverse_item[item0]] (the double lookup of model_combine.py:180).
     The reference only ever compares categories with `!=`, so any label type works (MIND's categories are strings): the

@@ -321,15 +321,21 @@ class Seq2SeqAttNN():
         hits, mrrs, ndcgs, ilds, unexps, losses = [], [], [], [], [], []
         sampler = self._sampler(test_data)
         batch = 0
-        result_items = set()
         pending = []
+        # ILD / unexp pair counts and the set of recommended items stay on the device (tcar_eval_diversity)
+        if getattr(self, "_cat_on_engine", None) is not cat:
+            eng.set_categories(cat)
+            self._cat_on_engine = cat
+        eng.reset_coverage()
         for feed in prefetch_batches(sampler):
             batch += 1
             feed, _cap = self._shard(feed)           # data parallel: every rank scores its shard of the batch
             if feed is None:
                 continue
-            rank, topk, ce = eng.eval_step(feed, k=20)
-            pending.append((feed, rank.clone(), topk.clone(), ce.clone()))     # device results; drained below
+            bt = eng.upload(feed)
+            rank, topk, ce = eng.eval_step(None, k=20, bt=bt)
+            ild_c, unexp_c, n_rec = eng.eval_diversity(bt, topk)
+            pending.append((feed, rank.clone(), topk.clone() if args.get('is_print') else None, ce.clone(), ild_c, unexp_c, n_rec))     # device results; drained below
             if batch < 3:
                 tk = topk[0].cpu().numpy().tolist()
                 print('batch_in:', feed["seq"][0].tolist())
@@ -337,34 +343,33 @@ class Seq2SeqAttNN():
                 print('input_click_week:', int(feed["cw"][0]))
                 print('batch_out:', int(feed["label"][0]), args['publish_time'][int(feed["label"][0])])
                 print('batch pred:', tk[:10])
-        for feed, rank, topk, ce in pending:
+        eng.check_forks()             # (synchronises) nothing below is reported from a run whose flag forks timed out
+        for feed, rank, topk, ce, ild_c, unexp_c, n_rec in pending:
             r = rank.cpu().numpy()
-            tk = topk.cpu().numpy().astype(np.int64)
             h, m, n = M.metrics_from_ranks(r, 20)
             hits += h.tolist()
             mrrs += m.tolist()
             ndcgs += n.tolist()
             losses += ce.cpu().numpy().tolist()
-            ilds += M.ild_batch(tk, cat).tolist()
-            unexps += M.unexp_batch(feed["seq"], tk, cat).tolist()
-            result_items.update(np.unique(tk).tolist())
+            il, un = M.diversity_from_counts(ild_c.cpu().numpy(), unexp_c.cpu().numpy(), n_rec.cpu().numpy(), feed["seq"].shape[1])
+            ilds += il.tolist()
+            unexps += un.tolist()
             if args.get('is_print'):
                 self.printData(str(args['foldnum']) + '_' + str(self.curEpoch), feed["seq"].tolist(),
-                               feed["label"].tolist(), tk.tolist())
+                               feed["label"].tolist(), topk.cpu().numpy().astype(np.int64).tolist())
         # sums over this rank's sessions, then over the ranks; coverage = union of the recommended items
         sums = self._allsum([float(np.sum(x)) for x in (losses, ilds, unexps, mrrs, hits, ndcgs)] + [float(len(hits))])
         n = max(sums[6], 1.0)
         if self.dp_world > 1:
             import torch.distributed as dist
-            parts = [None] * self.dp_world
-            dist.all_gather_object(parts, sorted(result_items), group=self.dp_group)
-            result_items = set().union(*[set(p) for p in parts])
+            dist.all_reduce(eng._seen, op=dist.ReduceOp.MAX, group=self.dp_group)      # union of the ranks' byte maps
+        n_covered = eng.coverage()
         m_loss, m_ild, m_unexp, m_mrr, m_hit, m_ndcg = [v / n for v in sums[:6]]
         print('avg loss...', m_loss)
         print('avg ILD...', m_ild)
         print('avg unexp...', m_unexp)
-        print('len of result dict: ', len(result_items))
+        print('len of result dict: ', n_covered)
         print('MRR@20: {}, Recall@20: {}, nDCG@20: {}'.format(m_mrr, m_hit, m_ndcg))
         self.last_metrics = {"mrr": m_mrr, "recall": m_hit, "ndcg": m_ndcg, "loss": m_loss, "ild": m_ild,
-                             "unexp": m_unexp, "coverage": len(result_items)}
+                             "unexp": m_unexp, "coverage": n_covered}
         return m_hit

@@ -546,6 +546,16 @@ def _ln_backward(ctx, dy, _ds):
 normalize.register_autograd(_ln_backward, setup_context=_ln_setup)
 
 
+# optional _lib.Tuning copy the optional ops below pass to the library (tests pin the scalar / MFMA form of mha_core with it);
+# None = the process-wide switch values.  Python-side state of this module: the library itself keeps no mutable switch.
+TUNING = None
+
+
+def _tune_ptr():
+    import ctypes as _C
+    return _C.cast(_C.pointer(TUNING), _C.c_void_p) if TUNING is not None else None
+
+
 @torch.library.custom_op("tcar::mha_core", mutates_args=(), device_types="cuda")
 def mha_core(Q: Tensor, K: Tensor, V: Tensor, key_mask: Tensor, query_mask: Tensor, heads: int, causal: bool) -> Tuple[Tensor, Tensor]:
     """the attention core of modules.py:256-292 (scores, key / causal masks, softmax, query mask, weighted sum) on the
@@ -555,8 +565,8 @@ def mha_core(Q: Tensor, K: Tensor, V: Tensor, key_mask: Tensor, query_mask: Tens
     Tk = K.shape[1]
     O = torch.empty_like(Q)
     P = torch.empty(N * heads, Tq, Tk, dtype=torch.float32, device=Q.device)
-    check(_lib_().tcar_mha_core_fwd(N, Tq, Tk, Cc, heads, int(causal), _p(Q), _p(K), _p(V), _p(key_mask), _p(query_mask), _p(O),
-                                    _p(P), _st(Q)), "tcar_mha_core_fwd")
+    check(_lib_().tcar_mha_core_fwd_tuned(_tune_ptr(), N, Tq, Tk, Cc, heads, int(causal), _p(Q), _p(K), _p(V), _p(key_mask),
+                                          _p(query_mask), _p(O), _p(P), _st(Q)), "tcar_mha_core_fwd")
     return O, P
 
 
@@ -571,8 +581,8 @@ def mha_core_bwd(Q: Tensor, K: Tensor, V: Tensor, P: Tensor, key_mask: Tensor, q
     _chk(Q, K, V, P, key_mask, query_mask, dO)
     N, Tq, Cc = Q.shape
     dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
-    check(_lib_().tcar_mha_core_bwd(N, Tq, K.shape[1], Cc, heads, int(causal), _p(Q), _p(K), _p(V), _p(P), _p(key_mask),
-                                    _p(query_mask), _p(dO), _p(dQ), _p(dK), _p(dV), _st(Q)), "tcar_mha_core_bwd")
+    check(_lib_().tcar_mha_core_bwd_tuned(_tune_ptr(), N, Tq, K.shape[1], Cc, heads, int(causal), _p(Q), _p(K), _p(V), _p(P),
+                                          _p(key_mask), _p(query_mask), _p(dO), _p(dQ), _p(dK), _p(dV), _st(Q)), "tcar_mha_core_bwd")
     return dQ, dK, dV
 
 

@@ -288,16 +288,10 @@ def test_same_step_twice_bitwise_report(scoring, T):
         assert not differ["param after 2 steps"], differ
     if T > 3:
         # the K splits of the weight gradients are slabs folded in split order: same values as the un-split launch, to rounding
-        import ctypes as C
-        from tcar_amd import _lib
-        lib = _lib.load()
-        old = lib.tcar_set_tuning(b"TCAR_WGRAD_KS", 1 << 20)
-        try:
-            eng = TcarEngine(params, fold.content, fold.mwdhm, scoring=scoring)
-            eng.train_step(batch)
-            g1 = eng.export_grads()
-        finally:
-            lib.tcar_set_tuning(b"TCAR_WGRAD_KS", old)
+        eng = TcarEngine(params, fold.content, fold.mwdhm, scoring=scoring)
+        eng.set_tuning(TCAR_WGRAD_KS=1 << 20)          # this engine's own copy of the switches
+        eng.train_step(batch)
+        g1 = eng.export_grads()
         for k in VAR_ORDER:
             if k.endswith("/w_3d") or k.endswith("/w1"):
                 close(runs[0][0][k], g1[k], rtol=1e-4, atol_scale=1e-5, name="split vs un-split " + k)

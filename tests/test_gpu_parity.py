@@ -9,6 +9,7 @@ import pytest
 import torch
 
 import tcar_amd  # noqa: F401
+from tcar_amd import _lib
 from helpers import GOLD
 
 pytestmark = pytest.mark.gpu
@@ -598,12 +599,33 @@ def test_flag_fork_time_out_is_reported():
         eng.train_step(batch, defer_update=True)
     eng.flush()
     eng.check_forks()                                   # flag forks ran (default mask), none timed out
-    assert eng._sig is not None and int(eng._sig_epoch[0]) > 0
+    epoch = int(np.frombuffer(eng._fork_host, dtype=np.uint32, count=1)[0])      # the context's own fork counter (host)
+    assert eng._sig is not None and epoch > 0
     eng._sig[32] = 2                                    # what two expired polls leave behind
     with pytest.raises(RuntimeError, match="flag-fork"):
         eng.check_forks()
     with pytest.raises(RuntimeError, match="flag-fork"):
         eng.export_params()
+    eng._sig[32] = 0
+    eng.check_forks()
+    # the host-visible mirror (pinned word, system-scope atomic of the polling kernel): tested after EVERY training step and
+    # every evaluation step without a synchronisation — no metric leaves an engine whose forks timed out
+    eng._sig_err_np[0] = 1
+    with pytest.raises(RuntimeError, match="flag-fork"):
+        eng.train_step(batch, defer_update=True)
+    with pytest.raises(RuntimeError, match="flag-fork"):
+        eng.eval_step(batch)
+    eng._sig_err_np[0] = 0
+    eng.flush()
+    # and the DEVICE really writes both words: a polling kernel that gives up (it waits for an epoch nobody publishes)
+    assert eng.lib.tcar_flag_poll_expire(eng._sig.data_ptr(), eng._sig_err.data_ptr(),
+                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+    assert int(eng._sig[32]) == 1 and int(eng._sig_err_np[0]) == 1
+    with pytest.raises(RuntimeError, match="flag-fork"):
+        eng.poll_fork_errors()
+    eng._sig[32] = 0
+    eng._sig_err_np[0] = 0
 
 
 def test_flag_forks_fall_back_to_events_when_streams_do_not_overlap(monkeypatch):
@@ -635,10 +657,11 @@ def test_flag_forks_fall_back_to_events_when_streams_do_not_overlap(monkeypatch)
 
 
 def test_fork_state_does_not_leak_between_engines():
-    """The logits -> arena-zero fork is armed in the forward call and used in the backward call (thread-local state in the
-    library).  A training forward of one engine must not leave an arm behind that a LATER engine's backward takes for its own
-    (same context address after garbage collection: the aux stream's negative-term forward then ran ahead of attout — seen
-    once as 6 % wrong item-gradient rows in the fp32 mode).  Alternate short-lived engines of both kinds and check the fp32
+    """The logits -> arena-zero fork is armed in the forward call and used in the backward call.  Its state lives in the
+    CONTEXT's own host block (tcar_ctx_t.fork_host; round 3 kept it in thread-local slots of the library): a training forward
+    of one engine cannot leave an arm behind that a LATER engine's backward takes for its own (round 3: same context address
+    after garbage collection, the aux stream's negative-term forward then ran ahead of attout — seen once as 6 % wrong
+    item-gradient rows in the fp32 mode).  Alternate short-lived engines of both kinds and check the fp32
     engine's gradients against a single-stream run of the same engine class."""
     _need_gpu()
     import gc
@@ -671,33 +694,93 @@ def test_fork_state_does_not_leak_between_engines():
         gc.collect()
 
 
-def test_flag_and_event_forks_agree_bitwise_over_a_long_run(monkeypatch):
-    """Race hunt at the benched size: 60 deferred steps over batches of different lengths, once with the flag forks and once
-    with events only; losses of every step and all 23 variables + Adam moments at the end are bitwise equal."""
+def test_flag_and_event_forks_agree_bitwise_over_a_long_run():
+    """Race hunt at the benched size: 300 deferred steps over batches of different lengths, once with the flag forks (default
+    mask 759) and once with events only (this engine's own switch copy: TCAR_FLAG_FORK = 0); losses of every step and all 23
+    variables + Adam moments at the end are bitwise equal — the two schedules run the same kernels in the same per-stream
+    order with order-fixed sums, so a consumer that read a stale line behind a flag would show up here."""
     _need_gpu()
     from tcar_amd.engine import TcarEngine
     N, H, Ht, B, K = 46033, 250, 64, 512, 20
     params, content, mw, _ = _case(N, H, Ht, 8, 2, K, seed=21)
     batches = [_case(N, H, Ht, B, T, K, seed=100 + T)[3] for T in (1, 2, 3, 5, 2, 1)]
     runs = []
-    for flags in (True, False):
-        if not flags:
-            monkeypatch.setattr(TcarEngine, "_probe_flag_forks", lambda self: False)
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
-            res = [eng.make_resident(b) for b in batches]
-            losses = [eng.train_step(None, bt=res[i % len(res)], defer_update=True).clone() for i in range(60)]
-            eng.flush()
+    for mask in (None, 0):
+        eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+        if mask is not None:
+            eng.set_tuning(TCAR_FLAG_FORK=mask)
+        res = [eng.make_resident(b) for b in batches]
+        losses = [eng.train_step(None, bt=res[i % len(res)], defer_update=True).clone() for i in range(300)]
+        eng.flush()
         eng.check_forks()
-        assert (eng._sig is not None) == flags
+        epoch = int(np.frombuffer(eng._fork_host, dtype=np.uint32, count=1)[0])
+        assert (epoch > 0) == (mask is None), epoch          # flags really were / were not in use
         runs.append((torch.stack([l[:B] for l in losses]).cpu().numpy(), eng.export_state()))
         del eng, res
         torch.cuda.empty_cache()
     assert (runs[0][0] == runs[1][0]).all()
     for k in runs[0][1]:
         assert np.array_equal(runs[0][1][k], runs[1][1][k]), k
+
+
+def test_two_engines_stepped_from_two_host_threads_match_their_solo_runs(monkeypatch):
+    """Re-entrancy of the boundary (no global mutable state, per-device handles passed in).  Two engines of
+    different shapes, each with its own context, fork words and streams, are stepped from two Python threads at the same
+    time — a barrier per step makes the two step calls overlap on the host, so every fork_arm / launch / fork_go of one
+    interleaves with the other's — and each ends bit for bit where the same engine ends when it runs alone.  With the fork
+    slots in per-thread or per-process state (round 3) one engine's launch could take the other's flag."""
+    _need_gpu()
+    import threading
+    from tcar_amd.engine import TcarEngine
+    monkeypatch.setenv("TCAR_NO_PRIO", "1")          # each engine keeps the (priority) stream its thread hands it
+    H, Ht, K, steps = 250, 64, 20, 40
+    cases = [_case(46033, H, Ht, 512, 2, K, seed=61), _case(9000, H, Ht, 256, 3, K, seed=62)]
+
+    def run(case, stream, barrier=None, out=None, slot=0):
+        params, content, mw, batch = case
+        with torch.cuda.stream(stream):
+            eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+            bt = eng.make_resident(batch)
+            losses = []
+            for _ in range(steps):
+                if barrier is not None:
+                    barrier.wait()
+                losses.append(eng.train_step(None, bt=bt, defer_update=True).clone())
+            eng.flush()
+            eng.check_forks()
+            assert int(np.frombuffer(eng._fork_host, dtype=np.uint32, count=1)[0]) > 0       # flag forks in use
+            res = (torch.stack(losses).cpu().numpy(), eng.export_state())
+        if out is not None:
+            out[slot] = res
+        return res
+
+    solo = [run(c, torch.cuda.Stream(priority=-1)) for c in cases]
+    again = [run(c, torch.cuda.Stream(priority=-1)) for c in cases]
+    torch.cuda.synchronize()
+    for i in range(2):        # precondition: each engine alone is bit-for-bit repeatable (else the comparison below says nothing)
+        assert (solo[i][0] == again[i][0]).all(), "solo losses of engine %d are not repeatable" % i
+        for k in solo[i][1]:
+            assert np.array_equal(solo[i][1][k], again[i][1][k]), ("solo run not repeatable", i, k)
+    both, errs = [None, None], []
+    barrier = threading.Barrier(2)
+
+    def worker(i):
+        try:
+            run(cases[i], torch.cuda.Stream(priority=-1), barrier, both, i)
+        except BaseException as e:      # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert (solo[i][0] == both[i][0]).all(), "losses of engine %d differ" % i
+        for k in solo[i][1]:
+            assert np.array_equal(solo[i][1][k], both[i][1][k]), (i, k)
 
 
 def test_split_bf16_planes_kb32_layout(lib):
@@ -1003,14 +1086,11 @@ def test_gemm_bf16_large_n_tiles(lib, M, N, K):
     ldc = (N + 127) // 128 * 128
     dC = torch.full((M, ldc), 7.0, device="cuda")
     for env in ("384", "256"):
-        prev = lib.tcar_set_tuning(b"TCAR_BF16_TILE", int(env))
-        try:
-            dC.fill_(7.0)
-            assert lib.tcar_gemm_bf16(1, M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(dC), ldc, None, 0,
-                                      0, 3, 1, None) == 0
-            got = dC.cpu().numpy()
-        finally:
-            lib.tcar_set_tuning(b"TCAR_BF16_TILE", prev)
+        tune = _lib.tuning(TCAR_BF16_TILE=int(env))          # a caller-owned copy of the switches: the library keeps none
+        dC.fill_(7.0)
+        assert lib.tcar_gemm_bf16_tuned(C.byref(tune), 1, M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(dC),
+                                        ldc, None, 0, 0, 3, 1, None) == 0
+        got = dC.cpu().numpy()
         close(got[:, :N], want, rtol=1e-3, atol_scale=2e-5, name="bf16 gemm tile " + env)
         assert (got[:, N:] == 7.0).all()
 
@@ -1028,13 +1108,10 @@ def test_gemm_bf16_de_tiles(lib, tile):
     bh, bl, bi, br = _planes(lib, Bm)
     c1 = torch.full((M, 260), 7.0, device="cuda")
     c2 = torch.full((M, 324), 7.0, device="cuda")
-    prev = lib.tcar_set_tuning(b"TCAR_BF16_TILE", int(tile))
-    try:
-        assert lib.tcar_gemm_bf16(2, M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(c1), 260, ptr(c2), 324,
-                                  256, 3, 1, None) == 0
-        g1, g2 = c1.cpu().numpy(), c2.cpu().numpy()
-    finally:
-        lib.tcar_set_tuning(b"TCAR_BF16_TILE", prev)
+    tune = _lib.tuning(TCAR_BF16_TILE=int(tile))
+    assert lib.tcar_gemm_bf16_tuned(C.byref(tune), 2, M, N, K, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, ptr(c1), 260,
+                                    ptr(c2), 324, 256, 3, 1, None) == 0
+    g1, g2 = c1.cpu().numpy(), c2.cpu().numpy()
     close(g1[:, :256], want[:, :256], rtol=1e-3, atol_scale=2e-5, name="dE item block")
     close(g2[:, :320], want[:, 256:], rtol=1e-3, atol_scale=2e-5, name="dE time block")
     assert (g1[:, 256:] == 7.0).all() and (g2[:, 320:] == 7.0).all()
@@ -1238,13 +1315,10 @@ def test_gather_forward_throughput_form_equals_latency_form(lib, B, T, H, Ht):
     for big in (1 << 30, 1):
         x_icp, x_pt = torch.full((B * T, ic), 7.0, device=dev), torch.full((B * T, pt), 7.0, device=dev)
         x_act, click = torch.full((B * T, ldt), 7.0, device=dev), torch.full((B, ct), 7.0, device=dev)
-        prev = lib.tcar_set_tuning(b"TCAR_GATHER_BIG_ROWS", big)
-        try:
-            assert lib.tcar_gather_clip_fwd(C.byref(d), C.byref(tab), C.byref(bt), ptr(x_icp), ptr(x_pt), ptr(x_act), ptr(click),
-                                            None) == 0
-            torch.cuda.synchronize()
-        finally:
-            lib.tcar_set_tuning(b"TCAR_GATHER_BIG_ROWS", prev)
+        tune = _lib.tuning(TCAR_GATHER_BIG_ROWS=big)
+        assert lib.tcar_gather_clip_fwd_tuned(C.byref(tune), C.byref(d), C.byref(tab), C.byref(bt), ptr(x_icp), ptr(x_pt),
+                                              ptr(x_act), ptr(click), None) == 0
+        torch.cuda.synchronize()
         outs.append([t.cpu().numpy() for t in (x_icp, x_pt, x_act, click)])
     for name, a, b in zip(("x_icp", "x_pt", "x_act", "click_t"), outs[0], outs[1]):
         bad = np.argwhere(a != b)
@@ -1326,3 +1400,185 @@ def test_sorted_segmented_item_scatter(lib, B, T, K, N, ldh):
     for o in outs[1:]:
         assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])        # bit for bit
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,k,N,ncat", [(64, 1, 20, 500, 7), (200, 7, 20, 46033, 40), (5, 40, 20, 30, 3), (33, 3, 20, 12, 2),
+                                          (257, 2, 20, 1000, 1), (16, 5, 64, 3000, 500)])
+def test_eval_diversity_kernel_equals_the_reference_loops(lib, B, T, k, N, ncat):
+    """tcar_eval_diversity (ILD / unexp pair counts + the coverage map, model_combine.py:174-194,301-313) against the oracle's
+    literal double loops (oracle/metrics_oracle.py: getILD / getUnexp restated line by line) on random top-k lists: few
+    categories (many equal pairs), one category (all zero), T = 1, a catalog SHORTER than k (the list then has N entries:
+    topk pads with -1), k = 64.  The counts are integers and the host divides int by int in double precision like Python:
+    the metrics must agree EXACTLY, not to a tolerance."""
+    _need_gpu()
+    from oracle import metrics_oracle
+    from tcar_amd.host import metrics as host_metrics
+    r = np.random.RandomState(B * 7 + T)
+    cat = r.randint(0, ncat, size=N).astype(np.int32)
+    reverse_item = {i: "art%d" % i for i in range(N)}
+    category_id = {"art%d" % i: int(cat[i]) for i in range(N)}
+    n_list = min(k, N)
+    topk = np.full((B, k), -1, dtype=np.int32)
+    for b in range(B):
+        topk[b, :n_list] = r.permutation(N)[:n_list]
+    seq = r.randint(1, N + 1, size=(B, T)).astype(np.int32)
+    dev = "cuda"
+    d_topk, d_seq, d_cat = (torch.tensor(x, device=dev) for x in (topk, seq, cat))
+    out = torch.full((3, B), -7, dtype=torch.int32, device=dev)
+    seen = torch.zeros(N, dtype=torch.uint8, device=dev)
+    assert lib.tcar_eval_diversity(B, T, k, N, ptr(d_topk), ptr(d_seq), ptr(d_cat), ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                                   C.c_void_p(seen.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    ild_c, un_c, n_rec = (x.cpu().numpy() for x in out)
+    assert (n_rec == n_list).all()
+    ild, un = host_metrics.diversity_from_counts(ild_c, un_c, n_rec, T)
+    for b in range(B):
+        rec = topk[b, :n_list].tolist()
+        assert ild[b] == metrics_oracle.ild(rec, reverse_item, category_id), b
+        assert un[b] == metrics_oracle.unexp(seq[b].tolist(), rec, reverse_item, category_id), b
+    want_seen = np.zeros(N, dtype=np.uint8)
+    want_seen[np.unique(topk[topk >= 0])] = 1
+    assert (seen.cpu().numpy() == want_seen).all()
+    # bad arguments are refused before any launch
+    assert lib.tcar_eval_diversity(B, T, 65, N, ptr(d_topk), ptr(d_seq), ptr(d_cat), ptr(out[0]), ptr(out[1]), None, None, None) == -1
+    assert lib.tcar_eval_diversity(B, 0, k, N, ptr(d_topk), ptr(d_seq), ptr(d_cat), ptr(out[0]), ptr(out[1]), None, None, None) == -1
+
+
+def _bf(x):
+    """fp32 -> the value of its bf16 hi plane (round to nearest even), as fp64"""
+    return torch.tensor(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+
+
+@pytest.mark.parametrize("N,B,tile", [(3000, 100, 0), (46033, 512, 0), (46033, 512, 256), (700, 33, 0)])
+def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
+    """The one-hot form of the two scoring GRADIENT GEMMs (round 4) at op level, through the C-ABI, against fp64 numpy on the
+    bf16-rounded operands AND against the materialised form it replaces:
+      tcar_gemm_bf16_dx_onehot + tcar_reduce_dact_onehot  ==  dlogits [E_ic | E_time] through tanh'  (E_time = OH T_clip)
+      tcar_gemm_bf16_de_qz + tcar_cand_time_bwd_onehot    ==  tcar_gemm_bf16_perm + tcar_cand_time_bwd_indexed
+    i.e. the IndexedSlices gradient of the five time tables' candidate-side lookups through the max_norm clip and its S5 norm
+    pieces (model_combine.py:86-92,135-138,156), table rows with norm > 1 and < 1, ragged N and B."""
+    from tcar_amd._lib import Dims, Grads
+    rng = np.random.RandomState(N + B)
+    ldh, ldt, ic, pt = 256, 64, 512, 320
+    ek = ic + pt
+    d = Dims(N, 250, 64, ldh, ldt)
+    Bp, Npad = (B + 127) // 128 * 128, (N + 127) // 128 * 128
+    vocab, rowoff = [13, 32, 8, 25, 61], [0, 13, 45, 53, 78]
+    tabs = [(rng.standard_normal((v, ldt)) * (0.2 if k % 2 else 0.08)).astype(np.float32) for k, v in enumerate(vocab)]
+    for t in tabs:
+        t[0] = 0.0                                         # zero-pad rows exist (modules.py:33-34) and are looked up
+    mw = np.stack([rng.randint(0, v, N) for v in vocab], 1).astype(np.int32)
+    dl = (rng.standard_normal((B, N)) * 0.01).astype(np.float32)
+    att = np.tanh(rng.standard_normal((B, ek))).astype(np.float32)
+    E = (rng.standard_normal((N, ek)) * 0.3).astype(np.float32)
+    raw = np.concatenate(tabs, 0).astype(np.float64)
+    nrm = np.sqrt((raw ** 2).sum(1))
+    sc = np.where(nrm > 1, 1.0 / np.maximum(nrm, 1e-30), 1.0)
+    tclip_np = raw * sc[:, None]
+    assert (nrm > 1).any() and (nrm < 1).any()
+    rows = np.stack([rowoff[k] + mw[:, k] for k in range(5)], 1)              # [N, 5] table row of every candidate
+    E[:, ic:] = tclip_np[rows].reshape(N, pt).astype(np.float32)               # candidate_publish_t (model_combine.py:86-92)
+    dev = "cuda"
+    T = lambda x, dt=None: torch.tensor(np.ascontiguousarray(x), device=dev) if dt is None else torch.tensor(np.ascontiguousarray(x), device=dev, dtype=dt)
+    d_tabs = [T(t) for t in tabs]
+    tt = (C.c_void_p * 5)(*[t.data_ptr() for t in d_tabs])
+    d_mw, d_att = T(mw), T(att)
+    # planes: dlogits [B rows, N inner], E [N rows, ek inner], packed attout [B rows, ldh + pt], one-hot [N rows, 160], scores
+    dlh, _, dl_in, _ = _planes(lib, dl)
+    eh, _, e_in, _ = _planes(lib, E)
+    aph, _, ap_in, _ = _planes(lib, np.concatenate([att[:, :ldh], att[:, ic:]], 1))
+    oh = torch.zeros(Npad * 160, dtype=torch.bfloat16, device=dev)
+    assert lib.tcar_time_onehot(C.byref(d), ptr(d_mw), ptr2(oh), 160, None) == 0
+    ph, pl = torch.zeros(Bp * 160, dtype=torch.bfloat16, device=dev), torch.zeros(Bp * 160, dtype=torch.bfloat16, device=dev)
+    tclip = torch.zeros(160 * ldt + 320, device=dev)
+    assert lib.tcar_time_scores_clip(C.byref(d), C.byref(tt), B, ptr(d_att), ek, ptr2(ph), ptr2(pl), 160, ptr(tclip), None) == 0
+    tc = tclip.cpu().numpy()
+    close(tc[:139 * ldt].reshape(139, ldt), tclip_np, rtol=1e-6, atol_scale=1e-7, name="clipped rows")
+    close(tc[160 * ldt:160 * ldt + 139], sc, rtol=1e-6, name="clip scales")
+    assert (tc[160 * ldt + 160:160 * ldt + 160 + 139] == (nrm > 1)).all()
+    dlb, Eb, attb = _bf(dl), _bf(E), _bf(att)
+    # ---- dX: slabs of dlogits [E_ic | OH], then the reduce + expansion + tanh'
+    splitk = 7
+    S = lib.tcar_gemm_splitk_effective(Npad, splitk)
+    slabs = torch.full((S, B, ic + 160), 7.0, device=dev)
+    assert lib.tcar_gemm_bf16_dx_onehot(B, ic, Npad, ptr2(dlh), dl_in, B, ptr2(eh), e_in, N, ptr2(oh), 160, ptr(slabs), ic + 160,
+                                        splitk, None) == 0
+    OH = np.zeros((N, 160))
+    OH[np.arange(N)[:, None], rows] = 1.0
+    want_dp = dlb @ OH
+    got = slabs.sum(0).cpu().numpy()
+    close(got[:, :ic], dlb @ Eb[:, :ic], rtol=1e-3, atol_scale=1e-5, name="dX item|content columns")
+    close(got[:, ic:ic + 139], want_dp[:, :139], rtol=1e-3, atol_scale=1e-5, name="dP = dlogits OH")
+    negpart = (rng.standard_normal((B, ic)) * 0.01).astype(np.float32)
+    dattout, dP = torch.full((B, ek), 7.0, device=dev), torch.full((B, 160), 7.0, device=dev)
+    assert lib.tcar_reduce_dact_onehot(ptr(slabs), S, B, ic, ic + 160, ptr(T(negpart)), ic, ptr(d_att), ek, ptr(tclip), ptr(dattout),
+                                       ek, ptr(dP), None, None, None) == 0
+    dact = 1.0 - att.astype(np.float64) ** 2
+    want_dx = np.concatenate([dlb @ Eb[:, :ic] + negpart, want_dp[:, :139] @ tclip_np], 1) * dact
+    close(dattout.cpu().numpy(), want_dx, rtol=1e-3, atol_scale=1e-5, name="d attout (one-hot form)")
+    close(dP.cpu().numpy()[:, :139], want_dp[:, :139], rtol=1e-3, atol_scale=1e-5, name="dP buffer")
+    # (the materialised form reads the time planes of E in bf16: the same columns to bf16 rounding of T_clip)
+    close(dattout.cpu().numpy()[:, ic:], (dlb @ Eb[:, ic:]) * dact[:, ic:], rtol=2e-2, atol_scale=5e-3, name="vs dlogits E_time (bf16 planes)")
+    # ---- dE: item block + (q, z) pairs, then the table gradients; against fp64 and against the materialised launch pair
+    order = np.argsort((rows.T.reshape(-1)), kind="stable")                   # inverted index: (k, n) pairs sorted by table row
+    inv_off = np.zeros(140, dtype=np.int32)
+    inv_off[1:] = np.cumsum(np.bincount(rows.T.reshape(-1), minlength=139))
+    et_perm = np.empty(5 * N, dtype=np.int32)
+    et_perm[order] = np.arange(5 * N, dtype=np.int32)
+    d_perm, d_off, d_invn = T(et_perm), T(inv_off), T((order % N).astype(np.int32))
+    Gi = torch.full((N, ldh), 7.0, device=dev)
+    qz = torch.full((5 * N, 2), 7.0, device=dev)
+    K = (B + 31) & ~31
+    assert lib.tcar_gemm_bf16_de_qz(N, K, ptr2(dlh), dl_in, Bp, ptr2(aph), ap_in, Bp, ldh, ptr(Gi), ldh, ptr(d_mw), ptr(d_perm), ptr(tclip),
+                                    ptr(qz), tile, None) == 0
+    gy = (dlb.T @ attb[:, ic:]).reshape(N, 5, ldt)                            # [N, k, 64] time block of dE (never stored)
+    close(Gi.cpu().numpy(), dlb.T @ attb[:, :ldh], rtol=1e-3, atol_scale=1e-5, name="dE item block")
+    want_q, want_z = (gy ** 2).sum(2), (gy * tclip_np[rows]).sum(2)          # [N, 5]
+    got_qz = qz.cpu().numpy()[et_perm.reshape(5, N)]                           # [5, N, 2]
+    close(got_qz[..., 0].T, want_q, rtol=1e-3, atol_scale=1e-5, name="q = ||gy||^2")
+    close(got_qz[..., 1].T, want_z, rtol=1e-3, atol_scale=1e-5, name="z = x . gy")
+    NSLOT = _lib.NSLOT
+
+    def grads():
+        gsm, sqn = torch.zeros(150 * ldt, device=dev), torch.zeros(NSLOT, device=dev)
+        gr = Grads()
+        gr.g_pos, gr.g_dur, gr.sqn = gsm.data_ptr(), gsm.data_ptr() + 4 * 139 * ldt, sqn.data_ptr()
+        for k in range(5):
+            gr.g_time[k] = gsm.data_ptr() + 4 * rowoff[k] * ldt
+            gr.slot_time[k] = 2 + k
+        return gsm, sqn, gr
+
+    ws = torch.zeros(int(lib.tcar_cand_time_ws_floats(C.byref(d))), device=dev)
+    gsm, sqn, gr = grads()
+    assert lib.tcar_cand_time_bwd_onehot(C.byref(d), B, ptr(d_off), ptr(qz), ptr(dP), ptr(d_att), ek, ptr(tclip), ptr(ws), C.byref(gr),
+                                         None) == 0
+    # fp64 restatement: per (n, k) slice gx = J(row)^T gy (S1); table gradient = sum of the slices, norm piece = sum ||gx||^2 (S5)
+    want_g, want_n = np.zeros((139, ldt)), np.zeros(5)
+    S_exact = want_dp[:, :139].T @ np.concatenate([att[:, ic:].astype(np.float64)], 1)     # [139, 320]: row r uses block k(r)
+    for k in range(5):
+        for v in range(vocab[k]):
+            r = rowoff[k] + v
+            sel = rows[:, k] == r
+            Ssum = S_exact[r, k * ldt:(k + 1) * ldt]
+            x = tclip_np[r]
+            if nrm[r] > 1:
+                want_g[r] = sc[r] * (Ssum - x * (x @ Ssum))
+                want_n[k] += sc[r] ** 2 * (want_q[sel, k].sum() - (want_z[sel, k] ** 2).sum())
+            else:
+                want_g[r] = Ssum
+                want_n[k] += want_q[sel, k].sum()
+    got_g = gsm.cpu().numpy()[:139 * ldt].reshape(139, ldt)
+    close(got_g, want_g, rtol=2e-3, atol_scale=2e-5, name="time-table gradients (one-hot form)")
+    close(sqn.cpu().numpy()[2:7], want_n, rtol=2e-3, name="S5 norm pieces (one-hot form)")
+    # the materialised pair: dE with its [N, 5 ldt] block in list order + the indexed backward
+    det = torch.zeros(5 * N * ldt, device=dev)
+    Gi2 = torch.zeros(N, ldh, device=dev)
+    assert lib.tcar_gemm_bf16_perm(2, N, ldh + pt, K, ptr2(dlh), None, dl_in, Bp, ptr2(aph), None, ap_in, Bp, ptr(Gi2), ldh, ptr(det), pt,
+                                   ldh, ptr(d_perm), ldt, 1, 1, None) == 0
+    gsm2, sqn2, gr2 = grads()
+    assert lib.tcar_cand_time_bwd_indexed(C.byref(d), C.byref(tt), ptr(d_invn), ptr(d_off), ptr(det), 1, ptr(ws), C.byref(gr2), None) == 0
+    close(Gi.cpu().numpy(), Gi2.cpu().numpy(), rtol=1e-5, atol_scale=1e-6, name="item block: both forms")
+    # (the list SUM uses fp32 attout in the one-hot form, the bf16 plane in the materialised one: bf16-level agreement)
+    close(got_g, gsm2.cpu().numpy()[:139 * ldt].reshape(139, ldt), rtol=2e-2, atol_scale=5e-3, name="table gradients: both forms")
+    close(sqn.cpu().numpy()[2:7], sqn2.cpu().numpy()[2:7], rtol=1e-3, name="norm pieces: both forms")

@@ -435,20 +435,20 @@ def test_multihead_attention_block_on_the_matrix_cores(N, T, C_, h, causal):
         close(a.grad, b.grad, name="d " + name, atol_scale=max(2e-4, floor))
     if C_ // h in (32, 64):
         # the MFMA form against the scalar form of the same entry point
-        lib = torch_ops._lib_()
+        from tcar_amd import _lib as _lib_mod
         Q = torch.tensor(mk(N, T, C_), device=DEV)
         Kt, V = torch.tensor(mk(N, T, C_), device=DEV), torch.tensor(mk(N, T, C_), device=DEV)
         km = torch.sign(torch.tensor(k_np, device=DEV).sum(-1).abs()).contiguous()
         qm = torch.sign(torch.tensor(q_np, device=DEV).sum(-1).abs()).contiguous()
         outs = []
         for flag in (1, 0):
-            prev = lib.tcar_set_tuning(b"TCAR_MHA_MFMA", flag)
+            torch_ops.TUNING = _lib_mod.tuning(TCAR_MHA_MFMA=flag)
             try:
                 O, P = torch.ops.tcar.mha_core(Q, Kt, V, km, qm, h, causal)
                 g = torch.ops.tcar.mha_core_bwd(Q, Kt, V, P, km, qm, torch.ones_like(O), h, causal)
                 torch.cuda.synchronize()
             finally:
-                lib.tcar_set_tuning(b"TCAR_MHA_MFMA", prev)
+                torch_ops.TUNING = None
             outs.append([O, P] + list(g))
         for name, a, b in zip(("O", "P", "dQ", "dK", "dV"), outs[0], outs[1]):
             close(a, b, name="mfma vs scalar " + name, atol_scale=1e-5)

@@ -140,6 +140,13 @@ def test_ild_unexp_host_vs_oracle():
     want_un = [metrics_oracle.unexp(s.tolist(), t.tolist(), reverse_item, category_id) for s, t in zip(seq, topk)]
     np.testing.assert_allclose(host_metrics.ild_batch(topk, table), want_ild, rtol=1e-12)
     np.testing.assert_allclose(host_metrics.unexp_batch(seq, topk, table), want_un, rtol=1e-12)
+    # the product path: integer pair counts (device kernel tcar_eval_diversity; restated here in numpy) divided on the host
+    c = table[topk]
+    ild_cnt = (c[:, :, None] != c[:, None, :]).sum((1, 2))
+    un_cnt = (c[:, :, None] != table[seq - 1][:, None, :]).sum((1, 2))
+    ild, un = host_metrics.diversity_from_counts(ild_cnt, un_cnt, np.full(6, 20), 3)
+    assert ild.tolist() == want_ild and un.tolist() == want_un          # exact: int / int in double precision, as Python
+    assert host_metrics.diversity_from_counts([0], [0], [0], 3)[1].tolist() == [0.0]      # getUnexp: n == 0 -> 0
 
 
 @pytest.mark.parametrize("mode", ["neighbor", "impression"])
