@@ -126,7 +126,7 @@ def build_batches(fold, n_batches, B, K, rng, cfg, with_ids=False):
 def pmc_traffic(tag, nsplit, N, B):
     """HBM bytes per launch of one scoring GEMM from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
     MI355X_MICROARCH.md §HBM; tools/pmc_gemm.sh); only valid for the shape and plane count it was collected on."""
-    for rnd in ("r03", "r02"):                    # the newest committed pass for this kernel form
+    for rnd in ("r04", "r03", "r02"):             # the newest committed pass for this kernel form
         p = os.path.join(ROOT, "profiles", "%s_pmc_%s_n%d.json" % (rnd, tag, nsplit))
         if os.path.exists(p):
             d = json.load(open(p))
@@ -179,20 +179,29 @@ def gather_roofline(dev):
     ms = e0.elapsed_time(e1) / iters
     nbytes = 2.0 * B * (3536.0 * T + 512)
     gbs = nbytes / ms / 1e6
-    real = None
-    pm = os.path.join(ROOT, "profiles", "r03_pmc_gather_fwd.json")
-    if os.path.exists(pm):
-        d_ = json.load(open(pm))
-        hb = d_["hbm_read_bytes"] + d_["hbm_write_bytes"]
-        real = {"hbm_bytes_per_launch_counters": hb, "source": os.path.relpath(pm, ROOT),
-                "frac_real_bytes": round(hb / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
-                "note": "FETCH_SIZE x 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes over this launch: the six small tables "
-                        "(1,536 of the 3,536 algorithmic read bytes per click) are LDS-resident and never reach HBM"}
-    return {"kernel": "gather_clip_fwd (throughput form), model_combine.py:54-107", "bound": "hbm", "rows": B * T,
-            "bytes_per_launch": nbytes, "avg_ms": round(ms, 4), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": real,
-            "note": "algorithmic read + written bytes (SURVEY.md 8(d)) / HIP-event time of 10 launches; separate from the step, "
-                    "whose own gather is ~1,100 rows per launch"}
+    # HEADLINE = counter-verified REAL bytes: FETCH_SIZE x 2 + WRITE_SIZE of the committed rocprofv3 --pmc passes over exactly this
+    # launch (the six small tables — 1,536 of the 3,536 algorithmic read bytes per click — are LDS-resident and never reach HBM, so
+    # the algorithmic figure of SURVEY.md 8(d) overstates what the memory system moves); the algorithmic figure sits beside it
+    real, src = None, None
+    for rnd in ("r04", "r03"):
+        pm = os.path.join(ROOT, "profiles", rnd + "_pmc_gather_fwd.json")
+        if os.path.exists(pm):
+            d_ = json.load(open(pm))
+            real, src = d_["hbm_read_bytes"] + d_["hbm_write_bytes"], os.path.relpath(pm, ROOT)
+            break
+    out = {"kernel": "gather_clip_fwd (throughput form), model_combine.py:54-107", "bound": "hbm", "rows": B * T, "avg_ms": round(ms, 4),
+           "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "algorithmic": {"bytes_per_launch": nbytes, "achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4),
+                           "note": "read + written bytes of SURVEY.md 8(d): 2 x (3536 T + 512) per session"},
+           "note": "HIP-event time of 10 launches; separate from the step, whose own gather is latency bound (in_step below)"}
+    if real is not None:
+        rg = real / (ms * 1e-3) / 1e9
+        out.update({"achieved": round(rg, 1), "frac": round(rg / PEAK_HBM_GBS, 4), "bytes_per_launch": real, "traffic": real,
+                    "traffic_source": src, "basis": "counter-verified HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) / this run's time"})
+    else:
+        out.update({"achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4), "bytes_per_launch": nbytes, "traffic": None,
+                    "basis": "algorithmic bytes (no committed counter pass for this launch)"})
+    return out
 
 
 def main():
@@ -211,7 +220,8 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_e2e", action="store_true", help="skip the end-to-end epoch through the trainer loop")
     ap.add_argument("--cpu_steps", type=int, default=20)
-    ap.add_argument("--cpu_threads", type=int, default=16)
+    ap.add_argument("--cpu_threads", type=int, default=0,
+                    help="host threads of the CPU baseline; 0 (default) = the best of a short sweep over 8 / 16 / 32 / 64")
     ap.add_argument("--no_kernel_timing", action="store_true")
     ap.add_argument("--stall_ms", type=float, default=0.0,
                     help="diagnostic (profiling): hold the main stream for this long at the start of the timed loop, so that the host "
@@ -406,6 +416,7 @@ def main():
     if hasattr(eng, "exchange_info"):
         exchange = eng.exchange_info()        # after the timed steps: carries the bytes each collective moved per step
     value = B * world * args.steps / dt
+    eng_splitk = getattr(eng, "splitk", 36)
 
     # ---- roofline of the three full-catalog GEMMs, timed live inside the timed steps -------------------------------
     Ht = args.time_hidden_size
@@ -438,6 +449,12 @@ def main():
             if not ms:
                 continue
             avg = float(np.mean(ms))
+            if tag == "gather_fwd":
+                # the step's OWN embedding gather (model_combine.py:54-107): ~B * mean_T rows per launch, latency bound — reported
+                # beside the throughput form of gather_roofline
+                kernels[tag] = {"launches": len(ms), "avg_ms": round(avg, 5), "rows_per_launch": round(B * mean_T, 1),
+                                "algorithmic_GBps": round(2.0 * B * (3536.0 * mean_T + 512) / (avg * 1e-3) / 1e9, 1)}
+                continue
             if tag == "session_proj":
                 # the grouped projection launch of both attention layers (modules.py:94-96,126-131: X W_in + C W_c + I W_int,
                 # X_t W'_in + C W'_c, and the first click-query layer) — the largest of the session-side small GEMMs
@@ -488,9 +505,22 @@ def main():
             if onehot and tag == "score_fwd":
                 mult = (3.0 * g.ic + 2.0 * 160) / k_alg
                 form = "one-hot time segment: K = %d columns at 3 MFMAs per product + 160 at 2 (one B plane)" % g.ic
+            # one-hot form of the two gradient GEMMs (default of the mixed precision on one rank): dX reads the item | content planes
+            # of E + the 160-column one-hot plane and writes slabs of 2 ldh + 160 columns; dE writes its item block + 5 (q, z) pairs
+            # per candidate instead of the [N, 5 ldt] time block
+            oh_bwd = (onehot or (tag != "score_fwd" and ce_epi and g.ldt == 64 and os.environ.get("TCAR_ONEHOT_TIME", "2") not in ("0", "1")
+                                 and not os.environ.get("TCAR_NO_ONEHOT_BWD") and not os.environ.get("TCAR_NO_ONEHOT")))
+            oh_bwd = oh_bwd and tag != "score_fwd" and g.ldt == 64 and os.environ.get("TCAR_ONEHOT_TIME", "2") not in ("0", "1")
+            if oh_bwd:
+                form = {"score_dx": "one-hot form: dlogits [E_item | E_content | OH], %d + 160 columns" % g.ic,
+                        "score_dE": "one-hot form: item block + per-candidate (||gy||^2, x.gy) pairs, no [N, 5 ldt] block"}[tag]
+                name = {"score_dx": name, "score_dE": "gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0> tile 192x192x32, (q, z) epilogue"}[tag]
+                traffic, src = pmc_traffic({"score_dx": "score_dx_onehot", "score_dE": "score_dE_qz"}[tag], 1, N, B) if world == 1 else (None, None)
             alg_bytes = {"score_fwd": in_fwd + out_fwd,
-                         "score_dx": opb * (b_glob * n_rows + n_rows * g.ek) + 4 * sk * b_glob * g.ek,
-                         "score_dE": opb * (b_glob * n_rows + b_glob * (g.ldh + g.pt)) + 4 * n_local * (g.ldh + g.pt)}[tag]
+                         "score_dx": (opb * (b_glob * n_rows + n_rows * g.ic) + 2 * n_rows * 160 + 4 * sk * b_glob * (g.ic + 160)) if oh_bwd
+                         else opb * (b_glob * n_rows + n_rows * g.ek) + 4 * sk * b_glob * g.ek,
+                         "score_dE": (opb * (b_glob * n_rows + b_glob * (g.ldh + g.pt)) + 4 * n_local * g.ldh + 40 * n_local) if oh_bwd
+                         else opb * (b_glob * n_rows + b_glob * (g.ldh + g.pt)) + 4 * n_local * (g.ldh + g.pt)}[tag]
             gbs = alg_bytes / (avg * 1e-3) / 1e9
             f_mfma, f_hbm = ach * mult / peak, gbs / PEAK_HBM_GBS
             ent = {"kernel": "%s (%s)" % (name, ref[tag]), "tag": tag}
@@ -521,7 +551,7 @@ def main():
         # thread sweep on the GPU box host (256 hw threads): 8/16/32/64/128 threads -> 945/1066/991/592/208
         # sessions/s; more threads oversubscribe the many small ops, so the baseline runs at its best setting
         hw = os.cpu_count() or 1
-        cores = min(hw, args.cpu_threads)
+        cores = min(hw, args.cpu_threads if args.cpu_threads > 0 else 16)
         torch.set_num_threads(cores)
         import random
         from oracle.sampler_oracle import OracleSampler, batch_to_arrays
@@ -535,19 +565,43 @@ def main():
         neg_src = {0: [0]} if cfg["neg_mode"] == "uniform" else src
         random.seed(2020)
         np.random.seed(2020)
-        c0 = time.perf_counter()
+        # thread sweep, 3 steps per setting (the many small ops of the graph oversubscribe quickly): the baseline runs at the best
+        sweep = {}
+        if args.cpu_threads <= 0:
+            for th in [t for t in (8, 16, 32, 64) if t <= hw]:
+                torch.set_num_threads(th)
+                ora.train_step(batches[0])
+                w0 = time.perf_counter()
+                for i in range(3):
+                    ora.train_step(batches[1 + i % (len(batches) - 1)])
+                sweep[str(th)] = round(3 * B / (time.perf_counter() - w0), 1)
+            cores = int(max(sweep, key=lambda t: sweep[t]))
+            torch.set_num_threads(cores)
+        # same scope as the GPU headline: the sampler object (bucketing, shuffle) is built outside the clock, as DeviceSampler and
+        # its plan are on the GPU side; batch formation + negatives + the training step are inside
         smp = OracleSampler(ld, sd, td, neg_src, fold.item_dict, K, batch_size=B, gap_mode=cfg["gap_mode"], neg_mode=cfg["neg_mode"])
+        c0 = time.perf_counter()
         n_cpu = 0
         while smp.has_next() and n_cpu < B * args.cpu_steps:
             feed = batch_to_arrays(smp.next_batch())
             ora.train_step(feed)
             n_cpu += feed["seq"].shape[0]
         cdt = time.perf_counter() - c0
-        cpu = {"value": round(n_cpu / cdt, 1), "unit": "sessions/s", "cores": cores, "host_threads": hw,
+        cpu_model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
+        cpu = {"value": round(n_cpu / cdt, 1), "unit": "sessions/s", "cores": cores, "host_threads": hw, "cpu_model": cpu_model,
+               "thread_sweep_sessions_per_s": sweep or None,
                "kind": "port",
-               "sample": "%d sessions: the reference's loop on the CPU — per-click Python sampler (bucketed shuffle, batch "
-                         "formation, K negatives) + one training step per batch of <= %d — PyTorch-CPU fp32 oracle on %d of "
-                         "the host's %d hardware threads (its fastest setting in a thread sweep)" % (n_cpu, B, cores, hw)}
+               "sample": "%d sessions: the reference's loop on the CPU — per-click Python sampler (batch formation, K negatives; "
+                         "its construction = bucketing + shuffle is outside the clock, like the GPU side's) + one training step per "
+                         "batch of <= %d — PyTorch-CPU fp32 oracle on %d of the host's %d hardware threads (the fastest setting of "
+                         "thread_sweep_sessions_per_s)" % (n_cpu, B, cores, hw)}
 
     e2e = None
     if rank == 0 and world == 1 and not args.no_e2e and N <= 200000 and not os.environ.get("TCAR_FORCE_DP"):
@@ -582,6 +636,32 @@ def main():
         torch.cuda.empty_cache()
         gather = gather_roofline(dev)      # ~9 GB of its own tables and outputs, after everything else is measured
 
+    # ---- the whole step against both rooflines (tracked per round): algorithmic flops and bytes of ONE step / ms_per_step ----------
+    step_roof = None
+    if world == 1 and not os.environ.get("TCAR_FORCE_DP"):
+        Npad_ = ((N + 127) // 128) * 128
+        ldh_, ldt_ = ((H + 63) // 64) * 64, 64
+        ic_, pt_ = 2 * ldh_, 5 * ldt_
+        n_par = Npad_ * ldh_
+        opb_ = 4 if args.scoring == "f32" else (4 if args.scoring == "bf16x3" else 2)
+        fl_step = B * (2.0 * N * (k_alg + k_alg + (H + 5 * Ht)) + 3.0e6 * (0.70 * mean_T + 1.02))
+        by = {"logits (E planes + attout planes in, exp plane + statistics out)": 4 * (Npad_ * ic_ + B * ic_) + 2 * Npad_ * 160 + 4 * B * 160 + 2 * B * Npad_ + 8 * B * (Npad_ // 96),
+              "ce rescale (plane in place)": 4 * B * Npad_,
+              "dX (dlogits + E planes in, split-K slabs out and back in)": opb_ * (B * Npad_ + Npad_ * ic_) + 2 * Npad_ * 160 + 8 * eng_splitk * B * (ic_ + 160),
+              "dE (dlogits + attout planes in, item block + (q, z) out)": opb_ * (B * Npad_ + B * (ldh_ + pt_)) + 4 * N * ldh_ + 40 * N,
+              "clip + Adam over the item table (g, m, v, w in; m, v, w + bf16 planes out)": 32 * n_par,
+              "gather fwd + bwd, negatives (SURVEY.md 8(d))": int(B * (2 * (3536.0 * mean_T + 512) + 3 * (2536.0 * mean_T + 512) + 40000 + 60000)),
+              "dense arena (857k weights: w, g, m, v)": 28 * 880000}
+        tot = float(sum(by.values()))
+        t_s = dt / args.steps
+        step_roof = {"flops_per_step": fl_step, "bytes_per_step": tot, "bytes_by_part": {k: int(v) for k, v in by.items()},
+                     "achieved_TFLOPs": round(fl_step / t_s / 1e12, 1), "frac_mfma": round(fl_step / t_s / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
+                     "achieved_GBps": round(tot / t_s / 1e9, 1), "frac_hbm": round(tot / t_s / 1e9 / PEAK_HBM_GBS, 4),
+                     "note": "algorithmic flops (SURVEY.md 8(d): scoring 2N(820 + 820 + 570) + session side 3 (0.70 T + 1.02) MFLOP per "
+                             "session) and algorithmic HBM bytes of one step in the default precision's data layout (every operand and "
+                             "result of the big kernels once), divided by the headline ms_per_step"}
+    if gather is not None and "gather_fwd" in kernels:
+        gather["in_step"] = dict(kernels["gather_fwd"], note="the step's own gather launch (HIP events on its stream, second pass): latency bound")
     if rank == 0:
         labels = {"globo": "TCAR Globo-like fold 0", "adressa": "TCAR Adressa-like fold (active_t dwell, impression negatives)",
                   "mind": "TCAR MIND-like fold (one click time per session, neighbour negatives)",
@@ -599,6 +679,11 @@ def main():
                               "forward + backward + clip + Adam per step over pre-formed resident feeds"),
                ("device_step_sessions_per_s" if headline_sampler else "sampler_in_loop_sessions_per_s"):
                    (round(other, 1) if other else None),
+               "batches": "full batches of exactly B sessions only (the per-bucket tail batches of sampler.py:46-48 are in "
+                          "end_to_end_sessions_per_s, which runs the trainer loop over the whole fold)",
+               "roofline_pass": "per-kernel times (roofline, kernels) come from a SECOND, event-instrumented pass of the same steps "
+                                "(ms_per_step_with_kernel_events); value / ms_per_step come from the un-instrumented headline pass",
+               "step_roofline": step_roof,
                "roofline": roof, "gather_roofline": gather, "cpu_baseline": cpu, "end_to_end_sessions_per_s": e2e, "exchange": exchange,
                "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
                "ms_per_step_with_kernel_events": (round(dt_ev / args.steps * 1e3, 4) if dt_ev else None),

@@ -684,9 +684,10 @@ typedef struct {
   void* stream2; void* ev[6];
   uint32_t* adam_bitmap;    /* [ceil(N/32) + 1] zeroed words: rows already updated by the early pass of a split update */
   const int32_t* et_perm;   /* [5, N] position of (k, n) in the inverted index (bf16 scoring modes: dE writes d_et in that order) */
-  /* optional device timing of the three full-catalog GEMMs and of the largest session-side small GEMM: ev_start / ev_stop hold
-   * 4 * ev_n hipEvent_t each ([kind][slot]: kind 0 = logits, 1 = dX = dlogits E, 2 = dE = dlogits^T attout, 3 = the grouped
-   * projection launch of both attention layers, modules.py:94-96,126-131), recorded on the stream the GEMM is
+  /* optional device timing of the three full-catalog GEMMs, of the largest session-side small GEMM and of the gather: ev_start /
+   * ev_stop hold 5 * ev_n hipEvent_t each ([kind][slot]: kind 0 = logits, 1 = dX = dlogits E, 2 = dE = dlogits^T attout, 3 = the
+   * grouped projection launch of both attention layers, modules.py:94-96,126-131, 4 = the step's embedding gather,
+   * model_combine.py:54-107), recorded on the stream the kernel is
    * launched on; slots are used round-robin through the host counter ev_cursor[0] (ev_cursor[1] = slot of the step in
    * flight, written by the forward pass); ev_n = 0 disables it */
   void* const* ev_start; void* const* ev_stop; int32_t ev_n; int32_t* ev_cursor;

@@ -814,16 +814,31 @@ __global__ __launch_bounds__(256) void cand_time_bwd_onehot_kernel(int B, int ek
   const int k = r < 13 ? 0 : r < 45 ? 1 : r < 53 ? 2 : r < 78 ? 3 : 4;
   const int lo = inv_off[r], hi = inv_off[r + 1];
   float Q = 0.f, D2 = 0.f;
-  for (int i = lo + tid; i < hi; i += 256) {
-    const float2 v = qz[i];
-    Q += v.x;
-    D2 = fmaf(v.y, v.y, D2);
+  // (all loads of a trip are issued before the first use: the kernel is a handful of dependent memory round trips, not bytes)
+  for (int i0 = lo + tid; i0 < hi; i0 += 256 * 8) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (i0 + 256 * u < hi) ? qz[i0 + 256 * u] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { Q += v[u].x; D2 = fmaf(v[u].y, v[u].y, D2); }
   }
   shQ[tid] = Q; shD[tid] = D2;
   const int j4 = tid & 15, bg = tid >> 4;
   float4 S = zero4();
   const float* ap = attout + ic + k * 64 + j4 * 4;
-  for (int b = bg; b < B; b += 16) S = fma4(ld4(ap + (long)b * ek), dP[(long)b * 160 + r], S);
+  for (int b0 = bg; b0 < B; b0 += 16 * 8) {
+    float4 x[8];
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int b = b0 + 16 * u;
+      const bool ok = b < B;
+      x[u] = ok ? ld4(ap + (long)b * ek) : zero4();
+      w[u] = ok ? dP[(long)b * 160 + r] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) S = fma4(x[u], w[u], S);
+  }
   st4(shS + bg * 64 + j4 * 4, S);
   __syncthreads();
   if (tid < 16) {

@@ -102,7 +102,10 @@ __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int
 // KS = 32-deep k blocks per LDS stage: the hi-only (NSPLIT = 1) form has a third of the MFMA work between two barriers
 // and half the bytes per stage, so it takes 64-deep stages (same LDS as the two-plane form, half the barriers).
 template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1, int EPI = 0, int SEG2 = 0>
-__global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g) {
+// (EPI = 2, the dE form with the (q, z) epilogue: two 9-wave workgroups per CU need five waves per SIMD, i.e. <= 96 registers per
+//  lane; without the bound the compiler takes 102 — four waves per SIMD, ONE workgroup per CU, 64 us alone.  At 80 registers, which
+//  two 12-wave workgroups would need, it spills)
+__global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4) : 1)) void gemm_bf16_kernel(const BArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NW = WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW;
   constexpr int NP = (NSPLIT == 1) ? 1 : 2;                 // planes per operand
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(64 * WMW * WNW) void gemm_bf16_kernel(const BArgs g
         for (int e = 0; e < 16; ++e)
           if (nb + 32 * t + (e & 3) + 8 * (e >> 2) < g.N) mx = fmaxf(mx, acc[u][t][e]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const int lab = live ? g.label[row] : -1;
+      const int lab = live ? clampi(g.label[row], 0, g.N - 1) : -1;      // (clamped like tcar_ce_finish: lab_logit is always written)
       float sum = 0.f, labv = 0.f;
       bool has_lab = false;
 #pragma unroll
@@ -715,6 +718,12 @@ int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int6
     g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
     TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 4, 3, 2, 2, 1, 2, 0>), lds);
     TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 4, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 12), lds, st, g);
+  } else if (tile == 128) {
+    constexpr int TM = 128, TN = 192;
+    constexpr size_t lds = 2 * (TM + TN) * 64;
+    g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
+    TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 2, 3, 2, 2, 1, 2, 0>), lds);
+    TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 2, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 6), lds, st, g);
   } else {
     constexpr int TM = 192, TN = 192;
     constexpr size_t lds = 2 * (TM + TN) * 64;

@@ -225,7 +225,10 @@ __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngro
 #pragma unroll
   for (int q = 0; q < 4; ++q) v[q] = p[q];
   const int col0 = kb * 32;
-  const float mg = stats[((long)row * ngroups + col0 / GW) * 2];
+  // (padding blocks of the plane — columns at or beyond N, or beyond the groups the GEMM wrote statistics for — scale to zero:
+  //  no statistic outside [0, ngroups) is ever read)
+  const int gi = col0 / GW;
+  const float mg = (gi < ngroups && col0 < N) ? stats[((long)row * ngroups + gi) * 2] : -INFINITY;
   const float2 rs = *reinterpret_cast<const float2*>(rowstat + 2 * row);
   const float c = (mg == -INFINITY) ? 0.f : expf(mg - rs.x) * rs.y;
   const int lab = clampi(label[row], 0, N - 1) - col0;          // label's column inside this block, if 0 <= lab < 32
@@ -432,9 +435,7 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
                                                                  const float* __restrict__ y, long ldy, const float* __restrict__ tclip,
                                                                  float* __restrict__ out, long ldo, float* __restrict__ dP,
                                                                  float* __restrict__ bg0, float* __restrict__ bg1, TcarSignal sig) {
-  __shared__ float4 sh[256];
-  __shared__ float dpl[16 * 64];
-  __shared__ __attribute__((aligned(16))) float tl[61 * 64];
+  __shared__ float4 sh[256];           // (bias column sums only: the atomic mode)
   const int tid = threadIdx.x, cg = tid & 15, rp = tid >> 4;
   const int nic = ic >> 6;
   const int r0 = blockIdx.y * 16, row = r0 + rp;
@@ -464,13 +465,13 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
     const int off = k == 0 ? 0 : k == 1 ? 13 : k == 2 ? 45 : k == 3 ? 53 : 78;
     const int nk = k == 0 ? 13 : k == 1 ? 32 : k == 2 ? 8 : k == 3 ? 25 : 61;
     col = ic + k * 64 + cg * 4;
-    // the clipped rows of table k (written by tcar_time_scores_clip in the forward pass)
-    for (int i = tid; i < nk * 16; i += 256) st4(tl + i * 4, ld4(tclip + (long)off * 64 + i * 4));
-    // dP tile: 16 rows x nk one-hot columns, summed over the slabs in slab order (thread: row rp, columns cg, cg + 16, ...)
+    // dP tile: 16 rows x nk one-hot columns, summed over the slabs in slab order: thread (row rp, lane cg of its 16-lane group)
+    // holds the columns cg, cg + 16, cg + 32, cg + 48 of its row in registers
+    float v[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = cg + 16 * j;
-      float v = 0.f;
+      v[j] = 0.f;
       if (row < M && c < nk) {
         const float* sp = slabs + (long)row * lds_ + ic + off + c;
         int q = 0;
@@ -479,18 +480,31 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
 #pragma unroll
           for (int u = 0; u < 6; ++u) t[u] = sp[(long)(q + u) * M * lds_];
 #pragma unroll
-          for (int u = 0; u < 6; ++u) v += t[u];
+          for (int u = 0; u < 6; ++u) v[j] += t[u];
         }
-        for (; q < S; ++q) v += sp[(long)q * M * lds_];
-        if (sig.cnt) __hip_atomic_store(dP + (long)row * 160 + off + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else dP[(long)row * 160 + off + c] = v;
+        for (; q < S; ++q) v[j] += sp[(long)q * M * lds_];
+        if (sig.cnt) __hip_atomic_store(dP + (long)row * 160 + off + c, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dP[(long)row * 160 + off + c] = v[j];
       }
-      dpl[rp * 64 + c] = v;
     }
-    __syncthreads();
+    // expansion d attout_t,k[row, 4 cg ..] = sum_r dP[row, r] clip(table_k row r)[4 cg ..]: dP[row, r] comes out of the registers of
+    // the row's own 16-lane group (a cross-lane read), the clipped rows (<= 61 x 256 B, written by tcar_time_scores_clip in the
+    // forward pass) straight from L1 / L2 — every row group of the chip reads the same 15 KB.  NO LDS in this kernel: a first
+    // version staged both through LDS and, running beside the dE GEMM's LDS-DMA workgroups in the step, dropped single terms of
+    // single rows now and then (bit-for-bit repeatable alone; tools/det_probe.py, profiles/r04_ab_experiments.txt)
+    const int lane = tid & 63, g0 = lane & 48;
+    float4 acc = zero4();
+    const float* tp = tclip + (long)off * 64 + cg * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (16 * j >= nk) break;
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const float sdp = __shfl(v[j], g0 + i);
+        if (16 * j + i < nk) acc = fma4(ld4(tp + (long)(16 * j + i) * 64), sdp, acc);
+      }
+    }
     if (row < M) {
-      float4 acc = zero4();
-      for (int r = 0; r < nk; ++r) acc = fma4(*reinterpret_cast<const float4*>(tl + r * 64 + cg * 4), dpl[rp * 64 + r], acc);
       const float4 yy = ld4(y + (long)row * ldy + col);
       acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
       st4(out + (long)row * ldo + col, acc);

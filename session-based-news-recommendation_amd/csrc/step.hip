@@ -20,7 +20,7 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
-    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 759},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
+    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 767},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
 // profiles/r03_ab_experiments.txt).  The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits
 // GEMM writes, and held back TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main
 // stream records nothing.
-enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_LOGITS = 9 };
+enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_LOGITS = 9 };
 // host-side fork state of ONE context (tcar_ctx_t.fork_host: caller-owned, zeroed, tcar_fork_state_bytes() bytes)
 struct ForkSlot { TcarSignal sig; uint32_t live; uint32_t pad; };     // live: the launch armed last for this slot carries sig
 struct ForkHost { uint32_t epoch; uint32_t pad[3]; ForkSlot slot[TCAR_SIG_SLOTS]; };
@@ -325,7 +325,9 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
                        ? (hipStream_t)c->stream3 : nullptr;
   TcarOpt og = opt_of(c);
   if (sq) og.sig = fork_arm(c, FK_GATHER);
+  if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_start[4 * c->ev_n + ei], (hipStream_t)stream);     // kind 4: the step's own gather
   RET(tcar_gather_clip_fwd_o(&c->d, &tab, bt, c->x_icp, c->x_pt, c->x_act, c->click_t, stream, &og));
+  if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[4 * c->ev_n + ei], (hipStream_t)stream);
   const bool qside = sq && fork_commit(c, FK_GATHER, og);       // (the throughput form of the gather carries no flag)
   if (qside) {
     RET(fork_go(c, FK_GATHER, (hipStream_t)stream, sq, c->ev3));
@@ -701,7 +703,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       // item block only; the time block leaves as per-candidate (||gy||^2, x . gy) pairs in the order of the inverted index
       TcarOpt ob = opt_of(c);
       RET(tcar_gemm_bf16_de_qz_o(g.N, (B + 31) & ~31, c->dl16h, g.Npad, (B + 127) & ~127, c->ap16h, g.ldh + g.pt, (B + 127) & ~127,
-                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, tn(c).bf16_tile == 256 ? 256 : 0, sB, &ob));
+                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, (tn(c).bf16_tile == 256 || tn(c).bf16_tile == 128) ? tn(c).bf16_tile : 0, sB, &ob));
     } else if (c->scoring) {
       // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
       TcarOpt ob = opt_of(c);
@@ -760,11 +762,20 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // producers below leave the column sums to ONE tcar_colsum_det launch behind the weight-gradient GEMM
   const bool fusedq = c->scoring != 0;
   const bool detc = fusedq && c->gw_rows != nullptr;
-  if (ohb)      // ... and the one-hot columns: dP = their slab sum, expanded to the time columns of dattout on the spot
+  if (ohb) {    // ... and the one-hot columns: dP = their slab sum, expanded to the time columns of dattout on the spot
+    TcarOpt orr = opt_of(c);
+    orr.sig = fork_arm(c, FK_REDUCE);          // (dP leaves write-through when the launch carries the flag)
     RET(tcar_reduce_dact_onehot_o(c->slabs, S, B, g.ic, g.ic + 160, has_neg ? c->negpart : nullptr, g.ic, c->attout, g.ek, c->tclip,
                                   c->dattout, g.ek, c->dP, detc ? nullptr : G(c, TCAR_V_O_B), detc ? nullptr : G(c, TCAR_V_OT_B), stream,
-                                  nullptr));
-  else
+                                  &orr));
+    (void)fork_commit(c, FK_REDUCE, orr);
+    // candidate-side time-table gradients: on the aux stream behind dE (its (q, z) pairs: stream order) and behind this launch
+    // (dP: a flag, no event on the main chain) — beside the session backward, ahead of the small tables' order-fixed pass
+    RET(fork_go(c, FK_REDUCE, st, s2, c->ev[5]));
+    tcar_grads_t gr;
+    grads_of(c, gr);
+    RET(tcar_cand_time_bwd_onehot(&c->d, B, c->inv_off, c->qz, c->dP, c->attout, g.ek, c->tclip, c->ct_ws, &gr, (void*)s2));
+  } else
     RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
                                 c->dattout, detc ? nullptr : G(c, TCAR_V_O_B), g.ic, detc ? nullptr : G(c, TCAR_V_OT_B), stream));
   if (!has_neg && hipMemsetAsync(c->neg_fb, 0, (size_t)B * sizeof(float), st) != hipSuccess) return TCAR_E_LAUNCH;
@@ -829,6 +840,19 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // Order-fixed small tables (sorted mode, which implies an aux stream): they — and the click-query input gradient, which only
   // they consume — run on the aux stream behind the candidate-time backward, beside the rest of the main chain
   const bool det_small = sorted && tn(c).det_small != 0;
+  // The click-query input gradient dclick = dq1 Wq1^T is consumed by the small tables' pass (aux stream) ONLY: with a third stream
+  // and the order-fixed small tables it runs there, in front of the weight gradients (it needs dq1 of the launch the third stream
+  // has just been ordered behind), instead of on the main chain (round 4: 17 us off the critical path)
+  const bool dclick_s3 = fusedq && det_small && s3 != nullptr;
+  hipStream_t s_dclick = st;
+  if (dclick_s3) {
+    tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+    TcarOpt od = opt_of(c);
+    od.sig = fork_arm(c, FK_DCLICK);
+    RET(small_gemm(c, 1, 1, &p, (void*)s3, &od));
+    (void)fork_commit(c, FK_DCLICK, od);
+    s_dclick = s3;
+  }
   RET(weight_grads(c, g, B, BT, sW));
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
@@ -847,7 +871,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   }
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
   if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
-  if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
+  if (dclick_s3) {
+    // (launched on the third stream above)
+  } else if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
     tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     TcarOpt od = opt_of(c);
     if (det_small) od.sig = fork_arm(c, FK_DCLICK);
@@ -871,10 +897,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5]));
-    // one-hot form: the candidate-side time-table gradients, from dE's (q, z) pairs (this stream) and dP (main chain, long done)
-    if (ohb)
-      RET(tcar_cand_time_bwd_onehot(&c->d, B, c->inv_off, c->qz, c->dP, c->attout, g.ek, c->tclip, c->ct_ws, &gr, (void*)s2));
+    RET(fork_go(c, FK_DCLICK, s_dclick, s2, c->ev[5]));
     TcarOpt o2 = opt_of(c);
     if (tail3) o2.sig = fork_arm(c, FK_TAIL2);
     RET(tcar_small_tables_bwd_det_o(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2, &o2));

@@ -888,7 +888,7 @@ class TcarEngine:
         self.tune = _lib.tuning(**overrides)
         self._ctx_key = None
 
-    TIMED_KERNELS = ("score_fwd", "score_dx", "score_dE", "session_proj")      # kinds 0..3 of tcar_ctx_t.ev_start / ev_stop
+    TIMED_KERNELS = ("score_fwd", "score_dx", "score_dE", "session_proj", "gather_fwd")      # kinds 0..4 of tcar_ctx_t.ev_start / ev_stop
 
     def enable_native_timing(self, n: int):
         """HIP events around the three full-catalog GEMMs inside tcar_train_step (logits, dX, dE), each pair recorded on the

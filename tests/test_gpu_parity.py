@@ -696,7 +696,7 @@ def test_fork_state_does_not_leak_between_engines():
 
 def test_flag_and_event_forks_agree_bitwise_over_a_long_run():
     """Race hunt at the benched size: 300 deferred steps over batches of different lengths, once with the flag forks (default
-    mask 759) and once with events only (this engine's own switch copy: TCAR_FLAG_FORK = 0); losses of every step and all 23
+    mask 767) and once with events only (this engine's own switch copy: TCAR_FLAG_FORK = 0); losses of every step and all 23
     variables + Adam moments at the end are bitwise equal — the two schedules run the same kernels in the same per-stream
     order with order-fixed sums, so a consumer that read a stale line behind a flag would show up here."""
     _need_gpu()
@@ -1450,7 +1450,7 @@ def _bf(x):
     return torch.tensor(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
 
 
-@pytest.mark.parametrize("N,B,tile", [(3000, 100, 0), (46033, 512, 0), (46033, 512, 256), (700, 33, 0)])
+@pytest.mark.parametrize("N,B,tile", [(3000, 100, 0), (46033, 512, 0), (46033, 512, 256), (46033, 512, 128), (700, 33, 0)])
 def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
     """The one-hot form of the two scoring GRADIENT GEMMs (round 4) at op level, through the C-ABI, against fp64 numpy on the
     bf16-rounded operands AND against the materialised form it replaces:
@@ -1485,8 +1485,12 @@ def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
     tt = (C.c_void_p * 5)(*[t.data_ptr() for t in d_tabs])
     d_mw, d_att = T(mw), T(att)
     # planes: dlogits [B rows, N inner], E [N rows, ek inner], packed attout [B rows, ldh + pt], one-hot [N rows, 160], scores
-    dlh, _, dl_in, _ = _planes(lib, dl)
-    eh, _, e_in, _ = _planes(lib, E)
+    dl_p = np.zeros((B, Npad), np.float32)                   # the engine's planes are [*, Npad]: catalog padded to 128 rows / columns
+    dl_p[:, :N] = dl
+    E_p = np.zeros((Npad, ek), np.float32)
+    E_p[:N] = E
+    dlh, _, dl_in, _ = _planes(lib, dl_p)
+    eh, _, e_in, _ = _planes(lib, E_p)
     aph, _, ap_in, _ = _planes(lib, np.concatenate([att[:, :ldh], att[:, ic:]], 1))
     oh = torch.zeros(Npad * 160, dtype=torch.bfloat16, device=dev)
     assert lib.tcar_time_onehot(C.byref(d), ptr(d_mw), ptr2(oh), 160, None) == 0
@@ -1502,7 +1506,7 @@ def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
     splitk = 7
     S = lib.tcar_gemm_splitk_effective(Npad, splitk)
     slabs = torch.full((S, B, ic + 160), 7.0, device=dev)
-    assert lib.tcar_gemm_bf16_dx_onehot(B, ic, Npad, ptr2(dlh), dl_in, B, ptr2(eh), e_in, N, ptr2(oh), 160, ptr(slabs), ic + 160,
+    assert lib.tcar_gemm_bf16_dx_onehot(B, ic, Npad, ptr2(dlh), dl_in, B, ptr2(eh), e_in, Npad, ptr2(oh), 160, ptr(slabs), ic + 160,
                                         splitk, None) == 0
     OH = np.zeros((N, 160))
     OH[np.arange(N)[:, None], rows] = 1.0
@@ -1515,7 +1519,8 @@ def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
     assert lib.tcar_reduce_dact_onehot(ptr(slabs), S, B, ic, ic + 160, ptr(T(negpart)), ic, ptr(d_att), ek, ptr(tclip), ptr(dattout),
                                        ek, ptr(dP), None, None, None) == 0
     dact = 1.0 - att.astype(np.float64) ** 2
-    want_dx = np.concatenate([dlb @ Eb[:, :ic] + negpart, want_dp[:, :139] @ tclip_np], 1) * dact
+    want_t = np.concatenate([want_dp[:, rowoff[k]:rowoff[k] + vocab[k]] @ tclip_np[rowoff[k]:rowoff[k] + vocab[k]] for k in range(5)], 1)
+    want_dx = np.concatenate([dlb @ Eb[:, :ic] + negpart, want_t], 1) * dact
     close(dattout.cpu().numpy(), want_dx, rtol=1e-3, atol_scale=1e-5, name="d attout (one-hot form)")
     close(dP.cpu().numpy()[:, :139], want_dp[:, :139], rtol=1e-3, atol_scale=1e-5, name="dP buffer")
     # (the materialised form reads the time planes of E in bf16: the same columns to bf16 rounding of T_clip)

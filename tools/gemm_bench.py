@@ -1,5 +1,7 @@
 """Micro-benchmark of the split-bf16 scoring GEMMs at the Globo shape (B=512, N=46033, K=832).
-Usage: python tools/gemm_bench.py [fwd|fwdce|dx|de|both] [nsplit] [iters]      (fwdce: the logits GEMM with its softmax epilogue)
+Usage: python tools/gemm_bench.py [fwd|fwdce|fwdce2|dx|de|dx2|de2|both|both2] [nsplit] [iters]
+(fwdce: the logits GEMM with its softmax epilogue; fwdce2: + one-hot time segment; dx2 / de2: the one-hot form of the gradient GEMMs,
+ hi planes only — tcar_gemm_bf16_dx_onehot, tcar_gemm_bf16_de_qz; both2: dx2 and de2 concurrently)
 `both`: dX on a high-priority stream and dE on a second stream, concurrently, as the step driver runs them."""
 import ctypes as C
 import os
@@ -35,7 +37,29 @@ p_h, p_l = torch.randn(B, 160, **bf), torch.randn(B, 160, **bf) * 0.004
 oh = (torch.rand(Npad, 160, device="cuda") < 5.0 / 160).to(torch.bfloat16)
 
 
+mw = torch.stack([torch.randint(0, v, (N,), device="cuda") for v in (13, 32, 8, 25, 61)], 1).to(torch.int32).contiguous()
+rows = (mw.long() + torch.tensor([0, 13, 45, 53, 78], device="cuda")).t().reshape(-1)
+order = torch.argsort(rows, stable=True)
+et_perm = torch.empty(5 * N, dtype=torch.int32, device="cuda")
+et_perm[order] = torch.arange(5 * N, dtype=torch.int32, device="cuda")
+tclip = torch.randn(160 * 64 + 320, device="cuda") * 0.1
+qz = torch.empty(5 * N, 2, device="cuda")
+slabs2 = torch.empty(SK, B, 672, device="cuda")
+TILE = int(os.environ.get("GB_TILE", 0))
 hp, s2 = torch.cuda.Stream(priority=-1), torch.cuda.Stream()
+
+
+def run_both2():
+    cur = torch.cuda.current_stream()
+    hp.wait_stream(cur)
+    s2.wait_stream(cur)
+    rc1 = lib.tcar_gemm_bf16_de_qz(N, B, p(d_h), Npad, B, p(ap_h), 576, B, 256, p(gi), 256, p(mw), p(et_perm), p(tclip), p(qz), TILE,
+                                   C.c_void_p(s2.cuda_stream))
+    rc0 = lib.tcar_gemm_bf16_dx_onehot(B, 512, Npad, p(d_h), Npad, B, p(e_h), EK, Npad, p(oh), 160, p(slabs2), 672, SK,
+                                       C.c_void_p(hp.cuda_stream))
+    cur.wait_stream(hp)
+    cur.wait_stream(s2)
+    return rc0 or rc1, 2.0 * B * N * (820 + 570)
 
 
 def run_both():
@@ -55,6 +79,13 @@ def run_both():
 def run():
     if which == "both":
         return run_both()
+    if which == "both2":
+        return run_both2()
+    if which == "dx2":
+        return lib.tcar_gemm_bf16_dx_onehot(B, 512, Npad, p(d_h), Npad, B, p(e_h), EK, Npad, p(oh), 160, p(slabs2), 672, SK, None), 2.0 * B * N * 820
+    if which == "de2":
+        return lib.tcar_gemm_bf16_de_qz(N, B, p(d_h), Npad, B, p(ap_h), 576, B, 256, p(gi), 256, p(mw), p(et_perm), p(tclip), p(qz), TILE,
+                                        None), 2.0 * B * N * 570
     if which == "fwd":
         return lib.tcar_gemm_bf16(1, B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, p(logits), Npad, None, 0, 0, nsplit, 1, None), 2.0 * B * N * 820
     if which == "fwdce":

@@ -7,7 +7,8 @@ mode, ns = sys.argv[1], int(sys.argv[2])
 root = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 N, B, EK = int(os.environ.get("GB_N", 46033)), 512, 832
 Npad = (N + 127) // 128 * 128
-tag = {"fwd": "score_fwd", "fwdce": "score_fwd_ce_classic", "fwdce2": "score_fwd_ce", "dx": "score_dx", "de": "score_dE"}[mode]
+tag = {"fwd": "score_fwd", "fwdce": "score_fwd_ce_classic", "fwdce2": "score_fwd_ce", "dx": "score_dx", "de": "score_dE",
+       "dx2": "score_dx_onehot", "de2": "score_dE_qz"}[mode]
 get = lambda s: json.load(open(os.path.join(root, "gpurun_out", "pmc_%s_n%d_%s.json" % (mode, ns, s))))
 f, w, q, t = get("FETCH_SIZE"), get("WRITE_SIZE"), get("SQ_VALU_MFMA_BUSY_CYCLES"), get("TCC_HIT_sum")
 planes = 2 if ns == 3 else 1
@@ -17,8 +18,13 @@ alg = {"fwd": planes * 2 * (Npad * EK + B * EK) + 4 * B * Npad,                 
        # the time-score planes (160 columns, hi + lo) in; bf16 exp plane + group statistics out
        "fwdce2": 4 * (Npad * 512 + B * 512) + 2 * Npad * 160 + 4 * B * 160 + 2 * B * Npad + 8 * B * (Npad // 96),
        "dx": planes * 2 * (B * Npad + Npad * EK) + 4 * int(os.environ.get("GB_SPLITK", 36)) * B * EK,   # dlogits + E planes in, slabs out
-       "de": planes * 2 * (B * Npad + B * 576) + 4 * N * 576}[mode]                  # dlogits + packed attout planes in, dE out
-flops = {"fwd": 2.0 * B * N * 820, "fwdce": 2.0 * B * N * 820, "fwdce2": 2.0 * B * N * 820, "dx": 2.0 * B * N * 820, "de": 2.0 * B * N * 570}[mode]
+       "de": planes * 2 * (B * Npad + B * 576) + 4 * N * 576,                        # dlogits + packed attout planes in, dE out
+       # one-hot form (hi planes): dlogits + item | content planes of E + the one-hot plane in, slabs of 672 columns out
+       "dx2": 2 * (B * Npad + Npad * 512 + Npad * 160) + 4 * int(os.environ.get("GB_SPLITK", 36)) * B * 672,
+       # dlogits + packed attout planes in; item block of dE + 5 (q, z) pairs per candidate out
+       "de2": 2 * (B * Npad + B * 576) + 4 * N * 256 + 8 * 5 * N}[mode]
+flops = {"fwd": 2.0 * B * N * 820, "fwdce": 2.0 * B * N * 820, "fwdce2": 2.0 * B * N * 820, "dx": 2.0 * B * N * 820, "de": 2.0 * B * N * 570,
+         "dx2": 2.0 * B * N * 820, "de2": 2.0 * B * N * 570}[mode]
 hbm = int(2 * f["FETCH_SIZE"] * 1024 + w["WRITE_SIZE"] * 1024)
 dur = q.get("avg_duration_us") or f.get("avg_duration_us")
 out = {"tag": tag, "nsplit": ns, "shape_N_B": [N, B],
