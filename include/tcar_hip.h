@@ -59,6 +59,9 @@ typedef struct {
   int32_t onehot_time;      /* TCAR_ONEHOT_TIME    0: the scoring GEMMs of a training step contract the 5 ldt clipped candidate time columns instead of the 160-column one-hot form */
   int32_t proj_split;       /* TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs */
   int32_t fork_delay;       /* TCAR_FORK_DELAY     us a DELAYED flag fork holds its consumer back behind the producer's end (step.hip) */
+  int32_t inkernel_wait;    /* TCAR_INKERNEL_WAIT  1: kernels that can wait for a producer's flag themselves do (attention pools: click query;
+                                                   slab reduce: negative term; candidate-side time gradients: dP) instead of sitting
+                                                   behind a polling kernel / an event.  Default 0: measured 9 us SLOWER per step */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
                                                    kernel of the side stream waits for */

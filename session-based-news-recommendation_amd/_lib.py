@@ -203,7 +203,7 @@ class Ctx(C.Structure):
 
 TUNING_FIELDS = ["bf16_tile", "rest_grid", "softmax_variant", "wgrad_ks", "gather_big_rows", "gather_wg_per_cu", "mha_mfma",
                  "sort_scatter", "bf16_ks", "det_small", "x3_oneshot", "fused_ce", "onehot_time", "proj_split", "fork_delay",
-                 "flag_fork"]
+                 "inkernel_wait", "flag_fork"]
 
 
 class Tuning(C.Structure):

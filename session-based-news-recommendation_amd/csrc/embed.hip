@@ -806,7 +806,8 @@ __global__ __launch_bounds__(64) void cand_time_bwd_piece_kernel(const CandArgs 
 __global__ __launch_bounds__(256) void cand_time_bwd_onehot_kernel(int B, int ek, int ic, const float2* __restrict__ qz,
                                                                   const int32_t* __restrict__ inv_off, const float* __restrict__ dP,
                                                                   const float* __restrict__ attout, const float* __restrict__ tclip,
-                                                                  float* __restrict__ g_time, float* __restrict__ pc_out) {
+                                                                  float* __restrict__ g_time, float* __restrict__ pc_out,
+                                                                  const TcarWait wait_dp) {
   __shared__ __attribute__((aligned(16))) float shS[16 * 64];
   __shared__ float shQ[256], shD[256];
   const int tid = threadIdx.x;
@@ -823,6 +824,7 @@ __global__ __launch_bounds__(256) void cand_time_bwd_onehot_kernel(int B, int ek
     for (int u = 0; u < 8; ++u) { Q += v[u].x; D2 = fmaf(v[u].y, v[u].y, D2); }
   }
   shQ[tid] = Q; shD[tid] = D2;
+  tcar_wave_wait(wait_dp);       // dP comes from the main chain's slab reduce: waited for here, behind the list pass above
   const int j4 = tid & 15, bg = tid >> 4;
   float4 S = zero4();
   const float* ap = attout + ic + k * 64 + j4 * 4;
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(256) void cand_time_bwd_onehot_kernel(int B, int ek
       const int b = b0 + 16 * u;
       const bool ok = b < B;
       x[u] = ok ? ld4(ap + (long)b * ek) : zero4();
-      w[u] = ok ? dP[(long)b * 160 + r] : 0.f;
+      w[u] = ok ? (wait_dp.flag ? ld1_sc1(dP + (long)b * 160 + r) : dP[(long)b * 160 + r]) : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) S = fma4(x[u], w[u], S);
@@ -1049,16 +1051,22 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
 // per-table norm pieces from the per-row ones, rows in order; one add per slot (the candidate side adds its one)
 __global__ __launch_bounds__(64) void small_norm_fold_kernel(const float* __restrict__ rowq, int T, float* __restrict__ sqn, int slot_pos,
                                                              int s0, int s1, int s2, int s3, int s4, int slot_dur,
-                                                             const TcarSignal sig) {
-  const int k = threadIdx.x;          // 0: position, 1..5: month..minute, 6: dwell (+ its out-of-range bucket)
-  if (k <= 6) {
+                                                             const TcarSignal sig, const float* __restrict__ cand_pc) {
+  // one 64-lane wave: table k = 0 position, 1..5 month..minute, 6 dwell (+ its out-of-range bucket); lane i takes row i of the
+  // table (every table has <= 64 rows) — the session side's piece plus, in the one-hot form, the candidate side's piece of the
+  // same row (cand_time_bwd_onehot_kernel) — and the wave's shuffle tree adds them up: a fixed order, one memory round trip
+  // (the round-3 form walked the rows in a dependent scalar loop: 6 us, 19 us with the candidate pieces)
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k <= 6; ++k) {
     int lo, n, slot;
     if (k == 0) { lo = 0; n = T; slot = slot_pos; }
     else if (k <= 5) { lo = TCAR_POS_VOCAB + time_rowoff(k - 1); n = time_vocab(k - 1); slot = k == 1 ? s0 : k == 2 ? s1 : k == 3 ? s2 : k == 4 ? s3 : s4; }
     else { lo = TCAR_POS_VOCAB + 139; n = TCAR_DUR_VOCAB + 1; slot = slot_dur; }
-    float s = 0.f;
-    for (int i = 0; i < n; ++i) s += rowq[lo + i];
-    if (s != 0.f) atomicAdd(sqn + slot, s);
+    float v = lane < n ? rowq[lo + lane] : 0.f;
+    if (cand_pc && k >= 1 && k <= 5 && lane < n) v += cand_pc[time_rowoff(k - 1) + lane];
+    const float s = wave_sum(v);
+    if (lane == 0 && s != 0.f) atomicAdd(sqn + slot, s);
   }
   tcar_signal_done(sig);        // (the fused step joins the aux stream into the main one behind this launch)
 }
@@ -1214,6 +1222,13 @@ extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* con
 extern "C" int tcar_cand_time_bwd_onehot(const tcar_dims_t* d, int B, const int32_t* inv_off, const float* qz, const float* dP,
                                          const float* attout, int64_t ld_att, const float* tclip, float* ws, const tcar_grads_t* g,
                                          void* stream) {
+  return tcar_cand_time_bwd_onehot_w(d, B, inv_off, qz, dP, attout, ld_att, tclip, ws, g, stream, TcarWait{}, 1);
+}
+// wait_dp: dP is produced on another stream behind a completion flag (the kernel waits itself); with_pieces = 0 leaves the
+// per-table fold of the norm pieces to tcar_small_tables_bwd_det_o (cand_pc), one launch less on the chain
+int tcar_cand_time_bwd_onehot_w(const tcar_dims_t* d, int B, const int32_t* inv_off, const float* qz, const float* dP,
+                                const float* attout, int64_t ld_att, const float* tclip, float* ws, const tcar_grads_t* g, void* stream,
+                                const TcarWait& wait_dp, int with_pieces) {
   if (check_dims(d) || d->ldt != 64 || B <= 0 || !inv_off || !qz || !dP || !attout || !tclip || !ws || !g || (ld_att & 3) ||
       !tcar_aligned16(attout) || !tcar_aligned16(tclip))
     return TCAR_E_ARG;
@@ -1223,10 +1238,12 @@ extern "C" int tcar_cand_time_bwd_onehot(const tcar_dims_t* d, int B, const int3
   float* pc = ws + (long)139 * CT_CHUNKS * (d->ldt + 4);
   hipStream_t st = (hipStream_t)stream;
   TCAR_LAUNCH(cand_time_bwd_onehot_kernel, dim3(139), dim3(256), 0, st, B, (int)ld_att, 2 * d->ldh, (const float2*)qz, inv_off, dP,
-              attout, tclip, g->g_time[0], pc);
+              attout, tclip, g->g_time[0], pc, wait_dp);
   TCAR_CHECK_LAUNCH();
-  TCAR_LAUNCH(cand_time_bwd_piece_kernel, dim3(5), dim3(64), 0, st, a, (const float*)ws);
-  TCAR_CHECK_LAUNCH();
+  if (with_pieces) {
+    TCAR_LAUNCH(cand_time_bwd_piece_kernel, dim3(5), dim3(64), 0, st, a, (const float*)ws);
+    TCAR_CHECK_LAUNCH();
+  }
   return TCAR_OK;
 }
 
@@ -1302,12 +1319,12 @@ extern "C" int tcar_small_det_ws_floats(void) { return SMALL_DET_ROWS; }
 extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                          const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g,
                                          float* ws, void* stream) {
-  return tcar_small_tables_bwd_det_o(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, ws, stream, nullptr);
+  return tcar_small_tables_bwd_det_o(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, ws, stream, nullptr, nullptr);
 }
 // (flag-capable: the norm fold, its last launch, publishes its slots with atomics)
 int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                 const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
-                                void* stream, TcarOpt* o) {
+                                void* stream, TcarOpt* o, const float* cand_pc) {
   if (check_dims(d) || !tab || !bt || !g || !ws || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   if (!dx_icp || !dx_pt || !dx_act || !dclick || !g->g_pos || !g->g_time[0] || !g->sqn) return TCAR_E_ARG;
   SmallDetArgs a{};
@@ -1321,7 +1338,7 @@ int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, 
   else TCAR_LAUNCH(small_tables_bwd_det_kernel<8>, dim3(rows), dim3(1024), 0, st, a);
   TCAR_CHECK_LAUNCH();
   TCAR_LAUNCH(small_norm_fold_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, bt->T, g->sqn, g->slot_pos, g->slot_time[0],
-              g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur, tcar_sig(o));
+              g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur, tcar_sig(o), cand_pc);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

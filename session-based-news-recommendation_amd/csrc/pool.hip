@@ -30,6 +30,8 @@ struct PoolArgs {
   float* g_qb;     // optional: bias gradient of query_trans2; dq then leaves multiplied by tanh'(q) (modules.py:139 backward)
   float* gw_rows;  // optional [B, 2 * ldh]: the per-session d w_res1 | d w_res2 rows are WRITTEN here (and dq leaves through
                    // tanh') instead of any atomic sum: tcar_colsum_det adds the columns up in a fixed order
+  TcarWait wait_q; // forward, optional: the click query q comes from another stream behind a completion flag — every wave waits
+                   // for it itself, after the part of its work that does not need q (the slab fold, alpha1 / alpha_t scores)
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -59,10 +61,17 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
     const bool ok = col < ldh;
     w1[c] = ok ? ld4(a.w1 + col) : zero4();
     w2[c] = ok ? ld4(a.w2 + col) : zero4();
-    qa[c] = ok ? ld4(a.q + (long)b * ic + col) : zero4();
-    qb[c] = ok ? ld4(a.q + (long)b * ic + ldh + col) : zero4();
+    qa[c] = zero4(); qb[c] = zero4();
   }
   float e1 = 0.f, e2 = 0.f, e3 = 0.f;     // lane t keeps the scores of position t
+  const bool late_q = a.wait_q.flag != nullptr;      // (kernel-uniform) q arrives behind a flag: its scores in a second loop
+  if (!late_q) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) { qa[c] = ld4(a.q + (long)b * ic + col); qb[c] = ld4(a.q + (long)b * ic + ldh + col); }
+    }
+  }
   for (int t = 0; t < T; ++t) {
     const long row = (long)b * T + t;
     float s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -79,11 +88,30 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
         }
         s1 += dot4(mask4(sig4(p1), col, H), w1[c]);
         s3 += dot4(mask4(sig4(p2), col, H), w2[c]);
-        s2 += dot4(ld4(a.x_icp + row * ic + col), qa[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), qb[c]);
+        if (!late_q) s2 += dot4(ld4(a.x_icp + row * ic + col), qa[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), qb[c]);
       }
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
     if (lane == t) { e1 = s1; e2 = s2; e3 = s3; }
+  }
+  if (late_q) {       // alpha2 scores X_ic . q (modules.py:140-141), behind the producer's flag: same sums in the same order
+    tcar_wave_wait(a.wait_q);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) { qa[c] = ld4_sc1(a.q + (long)b * ic + col); qb[c] = ld4_sc1(a.q + (long)b * ic + ldh + col); }
+    }
+    for (int t = 0; t < T; ++t) {
+      const long row = (long)b * T + t;
+      float s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) s2 += dot4(ld4(a.x_icp + row * ic + col), qa[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), qb[c]);
+      }
+      s2 = wave_sum(s2);
+      if (lane == t) e2 = s2;
+    }
   }
   const bool on = lane < T;
   const float x1 = on ? expf(e1) : 0.f, x2 = on ? expf(e2) : 0.f, x3 = on ? expf(e3) : 0.f;
@@ -286,9 +314,18 @@ extern "C" int tcar_attn_pool_fwd_slabs(const tcar_dims_t* d, int B, int T, cons
                                         const float* pre1_slabs, int n1, const float* pre2_slabs, int n2, int64_t slab_stride,
                                         float* pre1, float* pre2, const float* q, const float* w_res1, const float* w_res2,
                                         float* pooled, float* alpha, void* stream) {
+  return tcar_attn_pool_fwd_slabs_w(d, B, T, x_icp, x_pt, pre1_slabs, n1, pre2_slabs, n2, slab_stride, pre1, pre2, q, w_res1, w_res2,
+                                    pooled, alpha, stream, TcarWait{});
+}
+// wait_q: q is produced on another stream behind a completion flag; the kernel waits for it itself (tcar_wave_wait)
+int tcar_attn_pool_fwd_slabs_w(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1_slabs,
+                               int n1, const float* pre2_slabs, int n2, int64_t slab_stride, float* pre1, float* pre2, const float* q,
+                               const float* w_res1, const float* w_res2, float* pooled, float* alpha, void* stream,
+                               const TcarWait& wait_q) {
   if (!d || B <= 0 || T <= 0 || T > TCAR_POS_VOCAB || (d->ldh & 63) || d->ldh > 512 || 5 * d->ldt > 512) return TCAR_E_ARG;
   if (n1 < 1 || n2 < 1 || !pre1 || !pre2 || slab_stride < (int64_t)B * T * d->ldh) return TCAR_E_ARG;
   PoolArgs a{};
+  a.wait_q = wait_q;
   a.B = B; a.T = T; a.H = d->H; a.ldh = d->ldh; a.ldt = d->ldt;
   a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1_slabs; a.pre2 = pre2_slabs; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
   a.n1 = n1; a.n2 = n2; a.pre_stride = slab_stride; a.pre1_out = pre1; a.pre2_out = pre2;

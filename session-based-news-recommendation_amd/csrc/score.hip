@@ -5,6 +5,7 @@
 // modules.py:52-54 (bias + activation), util.py:8-18 and model_combine.py:301 (rank, top-20).
 // All four are HBM/L2-bandwidth bound passes over [B, N] or gathered rows; they use 16-byte accesses with one
 // workgroup (or wave) per session and wave-shuffle reductions.
+#include <utility>
 #include "tcar_common.h"
 #include "tcar_bf16_layout.h"
 #include <stdlib.h>
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
                                                        float* __restrict__ neg_fb, float* __restrict__ dattout,
                                                        float* __restrict__ g_item, const float* __restrict__ ce,
                                                        float* __restrict__ loss, float* __restrict__ coef_out,
-                                                       long datt_ld, int datt_overwrite) {
+                                                       long datt_ld, int datt_overwrite, TcarSignal sig) {
   // one WORKGROUP per session: the 4 waves split the K negatives (independent row gathers in flight), partial
   // dot / row sums meet in LDS, every wave then scatters its own negatives' gradient rows
   __shared__ __attribute__((aligned(16))) float part[4 * 2 * 512];   // [wave][item|content sums]
@@ -329,7 +330,9 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
     for (int col = tid * 4; col < ic; col += 1024) {
       const float4 s = add4(add4(ld4(part + col), ld4(part + ic + col)), add4(ld4(part + 2 * ic + col), ld4(part + 3 * ic + col)));
       float* p = dattout + (long)b * datt_ld + col;
-      st4(p, datt_overwrite ? scale4(s, coef) : fma4(s, coef, ld4(p)));
+      // (behind a completion flag the other stream reads this row: write-through, tcar_common.h)
+      if (sig.cnt) st4_sc1(p, datt_overwrite ? scale4(s, coef) : fma4(s, coef, ld4(p)));
+      else st4(p, datt_overwrite ? scale4(s, coef) : fma4(s, coef, ld4(p)));
     }
   }
   if (g_item) {
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(256) void neg_term_kernel(int B, int K, int n_items
       }
     }
   }
+  tcar_signal_done(sig);
 }
 
 // ---- negative rows of the item-table gradient: g_item[neg[b,k], :] += coef[b] * attout[b, 0:ldh] --------------
@@ -426,6 +430,16 @@ __global__ __launch_bounds__(256) void reduce_dact_kernel(const float* __restric
   }
 }
 
+// DPP row_share: lane I of every 16-lane row broadcast to its row (full-rate VALU, no LDS crossbar)
+template <int I>
+__device__ __forceinline__ float row_share(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + I, 0xf, 0xf, false));
+}
+template <int... I>
+__device__ __forceinline__ void expand16(float4& acc, const float4 (&xr)[16], float v, std::integer_sequence<int, I...>) {
+  ((acc = fma4(xr[I], row_share<I>(v), acc)), ...);
+}
+
 // ---- the same for the ONE-HOT form of dX (round 4): slabs [S][M][lds] hold dlogits [E_item | E_content | OH] -------------------
 // Column blocks 0 .. ic/64 - 1: as reduce_dact_kernel.  Block ic/64 + k (k = 0..4): dP[m, rows of table k] = sum of the slabs'
 // one-hot columns (written to dP [M, 160] for the candidate-side table gradients, embed.hip), expanded on the spot to the time
@@ -434,7 +448,8 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
                                                                  const float* __restrict__ addend, long ld_add,
                                                                  const float* __restrict__ y, long ldy, const float* __restrict__ tclip,
                                                                  float* __restrict__ out, long ldo, float* __restrict__ dP,
-                                                                 float* __restrict__ bg0, float* __restrict__ bg1, TcarSignal sig) {
+                                                                 float* __restrict__ bg0, float* __restrict__ bg1, TcarSignal sig,
+                                                                 const TcarWait wait_add) {
   __shared__ float4 sh[256];           // (bias column sums only: the atomic mode)
   const int tid = threadIdx.x, cg = tid & 15, rp = tid >> 4;
   const int nic = ic >> 6;
@@ -443,8 +458,8 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
   int col;                                   // output column of this thread's float4
   if ((int)blockIdx.x < nic) {
     col = blockIdx.x * 64 + cg * 4;
+    float4 acc = zero4();
     if (row < M) {
-      float4 acc = addend ? ld4(addend + (long)row * ld_add + col) : zero4();
       const float* sp = slabs + (long)row * lds_ + col;
       int k = 0;
       for (; k + 12 <= S; k += 12) {
@@ -455,6 +470,11 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
         for (int j = 0; j < 12; ++j) acc = add4(acc, t[j]);
       }
       for (; k < S; ++k) acc = add4(acc, ld4(sp + (long)k * M * lds_));
+    }
+    // the negative term's part comes from the aux stream: behind its flag, waited for HERE (after the slab sum), or an event
+    if (addend) tcar_wave_wait(wait_add);
+    if (row < M) {
+      if (addend) acc = add4(wait_add.flag ? ld4_sc1(addend + (long)row * ld_add + col) : ld4(addend + (long)row * ld_add + col), acc);
       const float4 yy = ld4(y + (long)row * ldy + col);
       acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
       st4(out + (long)row * ldo + col, acc);
@@ -495,14 +515,14 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
     const int lane = tid & 63, g0 = lane & 48;
     float4 acc = zero4();
     const float* tp = tclip + (long)off * 64 + cg * 4;
+    (void)g0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (16 * j >= nk) break;
-#pragma unroll 4
-      for (int i = 0; i < 16; ++i) {
-        const float sdp = __shfl(v[j], g0 + i);
-        if (16 * j + i < nk) acc = fma4(ld4(tp + (long)(16 * j + i) * 64), sdp, acc);
-      }
+      if (16 * j >= nk) break;                                    // (workgroup-uniform)
+      float4 xr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xr[i] = (16 * j + i < nk) ? ld4(tp + (long)(16 * j + i) * 64) : zero4();      // 16 rows in flight
+      expand16(acc, xr, v[j], std::make_integer_sequence<int, 16>{});
     }
     if (row < M) {
       const float4 yy = ld4(y + (long)row * ldy + col);
@@ -833,25 +853,31 @@ extern "C" int tcar_neg_term(const tcar_dims_t* d, int B, int K, const float* E,
   const int grid = B;          // one workgroup per session
   if (d->ldh <= 256)
     TCAR_LAUNCH(neg_term_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
-                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss, (float*)nullptr, (long)ek, 0);
+                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss, (float*)nullptr, (long)ek, 0, TcarSignal{});
   else
     TCAR_LAUNCH(neg_term_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E,
-                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss, (float*)nullptr, (long)ek, 0);
+                       neg, attout, weight, neg_fb, dattout, g_item, ce, loss, (float*)nullptr, (long)ek, 0, TcarSignal{});
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
 
 extern "C" int tcar_neg_fwd(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg, const float* attout,
                             float weight, float* neg_fb, float* coef, float* negpart, void* stream) {
+  return tcar_neg_fwd_o(d, B, K, E, neg, attout, weight, neg_fb, coef, negpart, stream, nullptr);
+}
+// (flag-capable: negpart — what the main chain's slab reduce reads — leaves write-through when the launch carries a flag)
+int tcar_neg_fwd_o(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg, const float* attout, float weight,
+                   float* neg_fb, float* coef, float* negpart, void* stream, TcarOpt* o) {
   if (!d || B <= 0 || K <= 0) return TCAR_OK;
   if (!E || !neg || !attout || !coef || !negpart || (d->ldh & 63) || d->ldh > 512) return TCAR_E_ARG;
   const int ek = 2 * d->ldh + 5 * d->ldt;
+  const TcarSignal sg = tcar_sig(o);
   if (d->ldh <= 256)
     TCAR_LAUNCH(neg_term_kernel<1>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E, neg, attout,
-                weight, neg_fb, negpart, (float*)nullptr, (const float*)nullptr, (float*)nullptr, coef, (long)(2 * d->ldh), 1);
+                weight, neg_fb, negpart, (float*)nullptr, (const float*)nullptr, (float*)nullptr, coef, (long)(2 * d->ldh), 1, sg);
   else
     TCAR_LAUNCH(neg_term_kernel<2>, dim3(B), dim3(256), 0, (hipStream_t)stream, B, K, d->n_items, d->ldh, ek, E, neg, attout,
-                weight, neg_fb, negpart, (float*)nullptr, (const float*)nullptr, (float*)nullptr, coef, (long)(2 * d->ldh), 1);
+                weight, neg_fb, negpart, (float*)nullptr, (const float*)nullptr, (float*)nullptr, coef, (long)(2 * d->ldh), 1, sg);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -895,7 +921,8 @@ int tcar_reduce_dact_onehot_o(const float* slabs, int splitk, int M, int ic, int
       (addend && !tcar_aligned16(addend)))
     return TCAR_E_ARG;
   TCAR_LAUNCH(reduce_dact_onehot_kernel, dim3(ic / 64 + 5, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, ic,
-              (long)ld, addend, (long)ld_add, y, (long)ldy, tclip, out, (long)ldo, dP, bias_grad0, bias_grad1, tcar_sig(o));
+              (long)ld, addend, (long)ld_add, y, (long)ldy, tclip, out, (long)ldo, dP, bias_grad0, bias_grad1, tcar_sig(o),
+              o ? o->wait : TcarWait{});
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

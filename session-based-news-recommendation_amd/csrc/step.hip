@@ -20,7 +20,8 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
-    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 767},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
+    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 1023},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
+    {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
 // profiles/r03_ab_experiments.txt).  The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits
 // GEMM writes, and held back TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main
 // stream records nothing.
-enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_LOGITS = 9 };
+enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_NEG = 8, FK_LOGITS = 9 };
 // host-side fork state of ONE context (tcar_ctx_t.fork_host: caller-owned, zeroed, tcar_fork_state_bytes() bytes)
 struct ForkSlot { TcarSignal sig; uint32_t live; uint32_t pad; };     // live: the launch armed last for this slot carries sig
 struct ForkHost { uint32_t epoch; uint32_t pad[3]; ForkSlot slot[TCAR_SIG_SLOTS]; };
@@ -382,16 +383,23 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     RET(small_gemm(c, 0, qfused ? 2 : 3, p, stream, &op));
   }
   RET(hook(1, &op));
-  if (qside) {   // the pools wait for q: a polling kernel on this stream (no event)
+  // the pools wait for q.  With the slab form the pool kernel waits ITSELF (tcar_wave_wait: every wave polls the query MLP's flag
+  // after its slab fold and alpha1 / alpha_t scores, so the wait overlaps that work and no polling kernel sits on this stream:
+  // ~8 us of launch + poll off the chain); otherwise a polling kernel / an event
+  TcarWait wq{};
+  if (qside && split && tn(c).inkernel_wait) {
+    if (const ForkSlot* f = fork_live(c, FK_QUERY)) wq = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
+  }
+  if (qside && !wq.flag) {
     RET(fork_go(c, FK_QUERY, sq, (hipStream_t)stream, c->ev3));
-  } else if (!qfused) {       // q = tanh(q1 Wq2 + b) (modules.py:139)
+  } else if (!qside && !qfused) {       // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
     RET(small_gemm(c, 0, 1, &p, stream));
   }
   RET(hook(2, &op));
   if (split)
-    RET(tcar_attn_pool_fwd_slabs(&c->d, B, bt->T, c->x_icp, c->x_pt, c->proj_slabs, n1, c->proj_slabs + n1 * stride, n2, stride,
-                                 c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
+    RET(tcar_attn_pool_fwd_slabs_w(&c->d, B, bt->T, c->x_icp, c->x_pt, c->proj_slabs, n1, c->proj_slabs + n1 * stride, n2, stride,
+                                   c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream, wq));
   else
     RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
                            W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
@@ -448,8 +456,14 @@ int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t s
     if (f->sig.epoch != fork_host(c)->epoch) fork_disarm(c, FK_LOGITS);
   if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], tn(c).fork_delay));
   RET(zero_arena(c, sz));
-  if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart)
-    RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz));
+  fork_disarm(c, FK_NEG);
+  if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart) {
+    // (the main chain's slab reduce reads negpart: with a flag it waits for this launch in-kernel instead of behind an event)
+    TcarOpt on = opt_of(c);
+    if (sz != st) on.sig = fork_arm(c, FK_NEG);
+    RET(tcar_neg_fwd_o(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz, &on));
+    (void)fork_commit(c, FK_NEG, on);
+  }
   return TCAR_OK;
 }
 
@@ -491,7 +505,9 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
                                c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
                                c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT,
                                c->adam_bitmap, stream));
-      if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
+      // (one-hot form: nothing is launched on the aux stream here — the rest pass is forked behind the projection launch, which is
+      //  behind the early pass on this stream: no event on the main chain at the top of the step)
+      if (!oh_bwd && (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
         return TCAR_E_LAUNCH;
       if (!oh_bwd)
         RET(tcar_cand_time_fwd_bf16(&c->d, tt, c->mwdhm, c->scoring ? nullptr : c->E, c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, (void*)s2));
@@ -592,7 +608,7 @@ namespace {
 // The nine weight gradients x^T dy (K = batch rows, model_combine.py:156): ONE grouped launch.  K is not split up to wgrad_ks
 // (1,536) rows; longer batches split it — into slabs folded in split order when the context has the workspace (order-fixed:
 // tcar_fold_slabs), else with float atomics into the zeroed arena.
-int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream) {
+int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream, TcarOpt* o = nullptr) {
   const int ksdiv = tn(c).wgrad_ks > 0 ? tn(c).wgrad_ks : 1536;
   auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
   const int kb = ks(B), kr = ks(BT);
@@ -625,7 +641,7 @@ int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream)
       at += (int64_t)p[i].splitk * p[i].M * p[i].N;
     }
   }
-  RET(small_gemm(c, 2, 9, p, stream));
+  RET(small_gemm(c, 2, 9, p, stream, o));
   if (nf) RET(tcar_fold_slabs(nf, f, stream));
   return TCAR_OK;
 }
@@ -670,12 +686,17 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // (the aux stream is first ordered behind everything already on the main stream: the previous update read Gx)
   hipStream_t sz = s2 ? s2 : st;
   RET(backward_prologue(c, bt, st, sz));
-  if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   // sorted segmented sum of the item-row gradients (deterministic); its index was built under the forward pass, on the aux
   // stream — ev[1] (recorded behind the prologue) orders the main stream behind it
   const bool sorted = fuse_finish && sorted_rows(c, bt);
   // one-hot form of the two gradient GEMMs (the forward half of this step made the same decision: onehot_bwd)
   const bool ohb = ce_epilogue && fuse_finish && onehot_bwd(c, bt);
+  // ev[1] = "aux prologue done" (arena zeroed, negative term's forward): in the one-hot schedule its only reader on the main chain is
+  // the slab reduce (negpart), which waits for the negative term's FLAG in-kernel when that launch carries one — then neither the
+  // record (aux chain, in front of dE) nor the wait (main chain) exists.  Everything else that needs the zeroed arena sits behind
+  // dE on its own stream (stream order / ev[4]).
+  const bool neg_flag = ohb && has_neg && c->gw_rows && c->stream3 && c->ev3 && tn(c).inkernel_wait && fork_live(c, FK_NEG) != nullptr;
+  if (s2 && !neg_flag && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
   const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
@@ -725,7 +746,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       RET(tcar_neg_scatter(&c->d, B, K, bt->neg, c->attout, c->neg_coef, Gi, c->neg_fb, c->ce, c->neg_weight, c->loss, sB));
     // (one-hot form: the candidate-side table gradients need dP of the dX chain too — they follow on this stream further down)
     if (fuse_finish && !ohb) RET(split_finish ? cand_time_backward(c, g, sB) : finish_dense_side(c, g, sB));
-    if (s2 && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;   // chain B done
+    // chain B done (read only where the main stream waits for the whole chain: not in the fused step's split finish — every
+    // event record between two kernels costs its stream ~7 us)
+    if (s2 && !split_finish && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;
     return TCAR_OK;
   };
   RET(chain_b());
@@ -754,7 +777,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   }
   tick(1, true, stream);
   // first use of the zeroed arena and of the negative term's forward outputs on the main stream
-  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
+  if (s2 && !neg_flag && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // (Round 3 A/B: letting the chain of small kernels behind dX wait until dE has finished — every one of them runs ~2x slower
   // beside dE's 106-MB write stream — loses more in idle time than the faster kernels give back: 0.647 vs 0.620 ms per step.)
   // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
@@ -765,16 +788,25 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (ohb) {    // ... and the one-hot columns: dP = their slab sum, expanded to the time columns of dattout on the spot
     TcarOpt orr = opt_of(c);
     orr.sig = fork_arm(c, FK_REDUCE);          // (dP leaves write-through when the launch carries the flag)
+    if (neg_flag) {
+      const ForkSlot* f = fork_live(c, FK_NEG);
+      orr.wait = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
+    }
     RET(tcar_reduce_dact_onehot_o(c->slabs, S, B, g.ic, g.ic + 160, has_neg ? c->negpart : nullptr, g.ic, c->attout, g.ek, c->tclip,
                                   c->dattout, g.ek, c->dP, detc ? nullptr : G(c, TCAR_V_O_B), detc ? nullptr : G(c, TCAR_V_OT_B), stream,
                                   &orr));
     (void)fork_commit(c, FK_REDUCE, orr);
     // candidate-side time-table gradients: on the aux stream behind dE (its (q, z) pairs: stream order) and behind this launch
     // (dP: a flag, no event on the main chain) — beside the session backward, ahead of the small tables' order-fixed pass
-    RET(fork_go(c, FK_REDUCE, st, s2, c->ev[5]));
+    // (the kernel waits for the reduce's flag ITSELF, behind its pass over the (q, z) lists: no polling kernel on the aux chain; its
+    // per-table norm pieces are folded by the small tables' last launch: no launch of their own)
+    TcarWait wdp{};
+    if (tn(c).inkernel_wait)
+      if (const ForkSlot* f = fork_live(c, FK_REDUCE)) wdp = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
+    if (!wdp.flag) RET(fork_go(c, FK_REDUCE, st, s2, c->ev[5]));
     tcar_grads_t gr;
     grads_of(c, gr);
-    RET(tcar_cand_time_bwd_onehot(&c->d, B, c->inv_off, c->qz, c->dP, c->attout, g.ek, c->tclip, c->ct_ws, &gr, (void*)s2));
+    RET(tcar_cand_time_bwd_onehot_w(&c->d, B, c->inv_off, c->qz, c->dP, c->attout, g.ek, c->tclip, c->ct_ws, &gr, (void*)s2, wdp, 0));
   } else
     RET(tcar_splitk_reduce_dact(c->slabs, S, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
                                 c->dattout, detc ? nullptr : G(c, TCAR_V_O_B), g.ic, detc ? nullptr : G(c, TCAR_V_OT_B), stream));
@@ -829,6 +861,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // on the third stream when the context has one (fused step: the aux stream is still busy with the candidate-time
   // backward, which only became ready when dE finished), else on the aux stream behind chain B.
   hipStream_t s3 = (s2 && fuse_finish && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
+  TcarOpt ow = opt_of(c);
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
     RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));        // (flagged small-GEMM launches store write-through)
@@ -840,20 +873,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // Order-fixed small tables (sorted mode, which implies an aux stream): they — and the click-query input gradient, which only
   // they consume — run on the aux stream behind the candidate-time backward, beside the rest of the main chain
   const bool det_small = sorted && tn(c).det_small != 0;
-  // The click-query input gradient dclick = dq1 Wq1^T is consumed by the small tables' pass (aux stream) ONLY: with a third stream
-  // and the order-fixed small tables it runs there, in front of the weight gradients (it needs dq1 of the launch the third stream
-  // has just been ordered behind), instead of on the main chain (round 4: 17 us off the critical path)
-  const bool dclick_s3 = fusedq && det_small && s3 != nullptr;
-  hipStream_t s_dclick = st;
-  if (dclick_s3) {
-    tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
-    TcarOpt od = opt_of(c);
-    od.sig = fork_arm(c, FK_DCLICK);
-    RET(small_gemm(c, 1, 1, &p, (void*)s3, &od));
-    (void)fork_commit(c, FK_DCLICK, od);
-    s_dclick = s3;
-  }
-  RET(weight_grads(c, g, B, BT, sW));
+  // The click-query input gradient dclick = dq1 Wq1^T is consumed by the small tables' pass (aux stream) ONLY: with the
+  // order-fixed small tables it runs THERE, right in front of them, behind a second poll of the input-gradient launch's flag
+  // (it needs dq1 of that launch) — off the main chain (round 4: 17 us) and off the third stream, whose weight gradients, column
+  // sums and norms are the step's last chain
+  const bool dclick_aux = fusedq && det_small && s3 != nullptr;
+  RET(weight_grads(c, g, B, BT, sW, &ow));
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
@@ -870,9 +895,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     if (tail_flags) tail3 = fork_commit(c, FK_TAIL3, o3);
   }
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
-  if (s2 && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
-  if (dclick_s3) {
-    // (launched on the third stream above)
+  // (with the order-fixed small tables the aux stream's "done" event is recorded behind them, below)
+  if (s2 && !det_small && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  if (dclick_aux) {
+    // (launched on the aux stream below, in front of the small tables)
   } else if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
     tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     TcarOpt od = opt_of(c);
@@ -897,10 +923,17 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    RET(fork_go(c, FK_DCLICK, s_dclick, s2, c->ev[5]));
+    if (dclick_aux) {
+      RET(fork_go(c, FK_INGRAD, st, s2, c->ev[5]));       // (the same flag the third stream polled: dq1, dx_* of that launch)
+      tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+      RET(small_gemm(c, 1, 1, &p, (void*)s2));
+    } else {
+      RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5]));
+    }
     TcarOpt o2 = opt_of(c);
     if (tail3) o2.sig = fork_arm(c, FK_TAIL2);
-    RET(tcar_small_tables_bwd_det_o(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2, &o2));
+    RET(tcar_small_tables_bwd_det_o(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2, &o2,
+                                    ohb ? tcar_cand_pieces(&c->d, c->ct_ws) : nullptr));
     if (tail3) tail2 = fork_commit(c, FK_TAIL2, o2);
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }

@@ -58,6 +58,36 @@ const TcarTuning& tcar_tuning();
 // stream would have to record (measured, tools/micro/event_cost: a record between two kernels costs the recording stream 6.5 us,
 // the flag costs it nothing and releases the consumer 0.4 us after the producer's end).  cnt == nullptr: no flag.
 struct TcarSignal { unsigned* cnt; unsigned* flag; unsigned epoch; unsigned slot; };
+// In-kernel form of the consumer side of a flag fork: instead of a polling kernel in front of it, the consuming kernel waits itself,
+// at the point where it first needs the producer's bytes (everything before that point overlaps the wait).  EVERY lane of a wave
+// calls tcar_wave_wait: lane 0 polls the flag word (relaxed agent-scope loads + s_sleep, bounded like poll_flag_kernel and counting
+// a time-out in the same error words).  NO acquire fence follows (a buffer_inv sc1 per wave, in hundreds of workgroups, measured
+// +17 us on the slab reduce and slowed every kernel beside it): the caller reads the producer's bytes — a few KB at most, stored
+// write-through by a flag-capable kernel — with sc1 loads (ld4_sc1 / ld1_sc1: served by L2 / memory, never by this CU's L1), the
+// form cdna_hip_programming.md Guideline 16 lists beside the acquire.  flag == nullptr: no wait.
+struct TcarWait { const unsigned* flag; unsigned epoch; unsigned* err; unsigned* err_host; };
+__device__ __forceinline__ void tcar_wave_wait(const TcarWait& w) {
+  if (!w.flag) return;
+  if ((threadIdx.x & 63) == 0) {
+    const long long t0 = wall_clock64();
+    while ((int)(__hip_atomic_load(w.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - w.epoch) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > 100000000LL) {            // 1 s of the 100-MHz wall clock
+        atomicAdd(w.err, 1u);
+        if (w.err_host) __hip_atomic_fetch_add(w.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+}
+__device__ __forceinline__ float4 ld4_sc1(const float* p) {
+  typedef float f4_t __attribute__((ext_vector_type(4)));
+  f4_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ float ld1_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // Launch options of the internal (C++) forms of the entry points, `..._o`: the tuning copy to consult (NULL = process snapshot)
 // and the completion flag THIS launch is to carry — passed explicitly, there is no per-thread "pending" state.  The launcher
 // sets `carried` when the kernel form it chose publishes the flag (flag-capable forms: the latency form of the forward gather,
@@ -67,6 +97,7 @@ struct TcarOpt {
   const tcar_tuning_t* tune = nullptr;
   TcarSignal sig{};
   bool carried = false;
+  TcarWait wait{};       // a flag the launch waits for IN the kernel (launchers that support it: the one-hot slab reduce)
   const TcarTuning& tn() const { return tune ? *tune : tcar_tuning(); }
 };
 inline const TcarTuning& tcar_tn(const TcarOpt* o) { return o ? o->tn() : tcar_tuning(); }
@@ -83,8 +114,16 @@ int tcar_query_mlp_o(const tcar_dims_t* d, int B, const float* click_t, const fl
                      const float* q2_b, float* q1, float* q, void* stream, TcarOpt* o);
 int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                 const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
-                                void* stream, TcarOpt* o);
+                                void* stream, TcarOpt* o, const float* cand_pc /* optional [139]: candidate-side norm pieces */);
+int tcar_cand_time_bwd_onehot_w(const tcar_dims_t* d, int B, const int32_t* inv_off, const float* qz, const float* dP,
+                                const float* attout, int64_t ld_att, const float* tclip, float* ws, const tcar_grads_t* g, void* stream,
+                                const TcarWait& wait_dp, int with_pieces);
+inline const float* tcar_cand_pieces(const tcar_dims_t* d, const float* ws) { return ws + (long)139 * 32 * (d->ldt + 4); }
 int tcar_sqnorm_o(const float* g, const tcar_segments_t* segs, float* sqn_dense, void* stream, TcarOpt* o);
+int tcar_attn_pool_fwd_slabs_w(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1_slabs,
+                               int n1, const float* pre2_slabs, int n2, int64_t slab_stride, float* pre1, float* pre2, const float* q,
+                               const float* w_res1, const float* w_res2, float* pooled, float* alpha, void* stream,
+                               const TcarWait& wait_q);
 int tcar_gemm_x3_grouped_o(int layout, int nprob, const tcar_gemm_desc_t* descs, void* stream, TcarOpt* o);
 int tcar_gemm_bf16_perm_o(int layout, int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
                           const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, float* C, int64_t ldc, float* C2,
@@ -104,6 +143,8 @@ int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int6
 int tcar_reduce_dact_onehot_o(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
                               const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo, float* dP, float* bias_grad0,
                               float* bias_grad1, void* stream, TcarOpt* o);
+int tcar_neg_fwd_o(const tcar_dims_t* d, int B, int K, const float* E, const int32_t* neg, const float* attout, float weight,
+                   float* neg_fb, float* coef, float* negpart, void* stream, TcarOpt* o);
 int tcar_clip_adam_rest_keep_o(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols,
                                int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip,
                                float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16,

@@ -19,6 +19,7 @@ generators is what the host sampler is for).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -168,39 +169,50 @@ class DeviceSampler:
         self.plan_B = lens
         self.plan_T = [int(self.in_len[int(b[0])]) for b in batches]
 
+    # batches formed per hand-off between the side stream and the consumer's stream (planned()); TCAR_FEED_CHUNK overrides (A/B)
+    CHUNK = int(os.environ.get("TCAR_FEED_CHUNK", "16"))
+
     def planned(self, K: int, gap_mode: str = "active_t"):
-        """Yield the C batch descriptor of every planned batch.  Batch i + 1 is formed (tcar_form_batch: session rows and
-        negatives) on a side stream while the consumer's step i runs; two feed buffers alternate, events order the reuse.  The
-        consumer must enqueue its step on the current stream before asking for the next batch."""
+        """Yield the C batch descriptor of every planned batch.  The batches are formed (tcar_form_batch: session rows and
+        negatives) on a side stream in CHUNKS of `CHUNK` batches, one chunk ahead of the consumer: while the consumer's steps of
+        chunk j run, the feeds of chunk j + 1 are formed; two chunk buffers alternate, ONE event pair per chunk orders their
+        reuse.  (Round 3 handed over every single batch: a wait and a record on the consumer's stream per step — two barrier
+        packets, ~12-14 us of every 0.55-ms step, MI355X event costs in profiles/r03_event_cost.txt.)  The consumer must enqueue
+        its step on the current stream before asking for the next batch."""
         n = len(self.plan_B)
         if n == 0:
             return
         need = max(7 * b * t + 3 * b + b * K for b, t in zip(self.plan_B, self.plan_T))
-        if getattr(self, "_feeds", None) is None or self._feeds[0].numel() < need:
-            self._feeds = [torch.empty(max(need, 1 << 16), dtype=torch.int32, device=self.dev) for _ in range(2)]
+        need = (need + 63) // 64 * 64
+        ch = max(1, int(self.CHUNK))
+        if getattr(self, "_feeds", None) is None or self._feeds[0].numel() < need * ch:
+            self._feeds = [torch.empty(need * ch, dtype=torch.int32, device=self.dev) for _ in range(2)]
             self._side = torch.cuda.Stream(self.dev)
             self._ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
             self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
         main = torch.cuda.current_stream(self.dev)
         side, used = self._side, [False, False]
         side.wait_stream(main)               # the plan's upload (and whatever wrote the stores) is on the main stream
+        nchunk = (n + ch - 1) // ch
 
-        def launch(i):
-            slot = i & 1
+        def launch(j):
+            slot = j & 1
             if used[slot]:
-                side.wait_event(self._ev_free[slot])      # the step that read this buffer has been enqueued in full
-            self._launch(self.plan_dev.data_ptr() + 4 * int(self.plan_off[i]), self.plan_B[i], self.plan_T[i], K, gap_mode,
-                         self.counter, self._feeds[slot], side)
-            self.counter += 1
+                side.wait_event(self._ev_free[slot])      # the steps that read this chunk buffer have been enqueued in full
+            for i in range(j * ch, min(n, (j + 1) * ch)):
+                self._launch(self.plan_dev.data_ptr() + 4 * int(self.plan_off[i]), self.plan_B[i], self.plan_T[i], K, gap_mode,
+                             self.counter, self._feeds[slot][(i - j * ch) * need:], side)
+                self.counter += 1
             self._ev_ready[slot].record(side)
 
         launch(0)
-        for i in range(n):
-            slot = i & 1
-            if i + 1 < n:
-                launch(i + 1)
+        for j in range(nchunk):
+            slot = j & 1
+            if j + 1 < nchunk:
+                launch(j + 1)
             main.wait_event(self._ev_ready[slot])
-            yield self._describe(self._feeds[slot], self.plan_B[i], self.plan_T[i], K)
+            for i in range(j * ch, min(n, (j + 1) * ch)):
+                yield self._describe(self._feeds[slot][(i - j * ch) * need:], self.plan_B[i], self.plan_T[i], K)
             self._ev_free[slot].record(main)
             used[slot] = True
 

@@ -124,10 +124,12 @@ def test_training_with_the_device_sampler_matches_the_oracle_on_the_same_feed():
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-5)
 
 
-def test_planned_schedule_forms_the_same_feeds_one_batch_ahead():
-    """DeviceSampler.plan + planned (the trainer loop's path: indices resident, batch i + 1 formed on a side stream while step
-    i runs, two alternating feed buffers) yields, batch for batch, the feed that form() builds for the same examples and
-    counter — while training steps consume them."""
+@pytest.mark.parametrize("chunk", [1, 2, 16])
+def test_planned_schedule_forms_the_same_feeds_one_chunk_ahead(chunk):
+    """DeviceSampler.plan + planned (the trainer loop's path: indices resident, the feeds of chunk j + 1 formed on a side stream
+    while the steps of chunk j run, two alternating chunk buffers, one event pair per chunk) yields, batch for batch, the feed
+    that form() builds for the same examples and counter — while training steps consume them.  chunk = 1: a hand-off per batch
+    (round 3's form), 2: the buffers alternate within the schedule, 16: one chunk."""
     _need_gpu()
     from tcar_amd.device_sampler import DeviceSampler
     from tcar_amd.host.synth import SynthFold
@@ -141,6 +143,7 @@ def test_planned_schedule_forms_the_same_feeds_one_batch_ahead():
     ref = DeviceSampler(eng, st, "uniform", seed=11)
     want = [ref.read_back(ref.form(ids, 6, "click_delta", counter=i)) for i, ids in enumerate(sched)]
     ds = DeviceSampler(eng, st, "uniform", seed=11)
+    ds.CHUNK = chunk
     ds.plan(sched)
     got = []
     for bt in ds.planned(6, "click_delta"):
