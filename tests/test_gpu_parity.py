@@ -724,20 +724,23 @@ def test_flag_and_event_forks_agree_bitwise_over_a_long_run():
 
 
 def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_runs(monkeypatch):
-    """Re-entrancy of the boundary (no global mutable state, per-device handles passed in).  Two engines of
-    different shapes, each with its own context, fork words and streams, are stepped ALTERNATELY from two Python threads — A's
-    step k, then B's step k, then A's step k + 1 ... (a baton of two semaphores), so every fork_arm / launch / fork_go of one
-    engine happens on another host thread than the other engine's and between two of its own steps — and each stays on the
-    trajectory of the same engine running alone (bound below; usually bit for bit).  With the fork slots in per-thread state
-    (round 3) a context changing threads, or two contexts on one thread, could take each other's flags.
-    (Two engines submitting at the SAME time from two threads — tools/thread_probe.py — is a different matter: the Globo-size
-    engine then differs from its solo run in a few sessions per step, with flag forks and with events alike, while both stay
-    repeatable alone and under this alternating schedule: DESIGN.md §7, profiles/r04_thread_probe.txt.)"""
+    """Re-entrancy of the boundary on the HOST (no global mutable state, per-device handles passed in).  Two
+    engines of different shapes, each with its own context, fork words and streams, are stepped ALTERNATELY from two Python
+    threads — A's step k, then B's step k, then A's step k + 1 ... (a baton of two semaphores; the thread that holds the baton
+    drains the device before it hands it on) — so every fork_arm / launch / fork_go of one engine happens on another host thread
+    than the other engine's and between two of its own steps, and each engine ends BIT FOR BIT where it ends when it runs alone.
+    With the fork slots in per-thread state (round 3) a context that changes threads, or two contexts on one thread, could take
+    each other's flags.
+    What this test does NOT cover, on purpose: two engines whose DEVICE work overlaps on one GPU.  tools/thread_probe.py runs
+    that: each engine alone, and two engines alternating without the drain on one host thread, repeat bit for bit, but with
+    another engine's kernels in flight the Globo-size engine differs from its solo run in a few sessions per step (flag forks
+    and events alike, AMD_SERIALIZE_KERNEL=1 and GPU_MAX_HW_QUEUES=16 alike) — an open observation, reported in DESIGN.md §7
+    and profiles/r04_thread_probe.txt, not hidden behind a tolerance here.  The product runs one engine per process and GPU."""
     _need_gpu()
     import threading
     from tcar_amd.engine import TcarEngine
     monkeypatch.setenv("TCAR_NO_PRIO", "1")          # each engine keeps the (priority) stream its thread hands it
-    H, Ht, K, steps = 250, 64, 20, 40
+    H, Ht, K, steps = 250, 64, 20, 30
     cases = [_case(46033, H, Ht, 512, 2, K, seed=61), _case(9000, H, Ht, 256, 3, K, seed=62)]
 
     def run(case, stream, mine=None, other=None, out=None, slot=0):
@@ -751,6 +754,7 @@ def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_
                     assert mine.acquire(timeout=120)
                 losses.append(eng.train_step(None, bt=bt, defer_update=True).clone())
                 if other is not None:
+                    torch.cuda.synchronize()          # the other engine's step starts on an idle device
                     other.release()
             eng.flush()
             eng.check_forks()
@@ -778,20 +782,10 @@ def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_
     for t in th:
         t.join()
     assert not errs, errs
-    # What the fork state of round 3 did when two contexts met on one thread was GROSS (a consumer released by the other
-    # context's flag: wrong gradient rows, time-outs).  The gate here is therefore the trajectory, not the last bit: with another
-    # engine's kernels in flight on the same GPU the Globo-size engine is NOT always bit-identical to its solo run (a few sessions
-    # per step move by ~1e-4 relative, with flag forks and with events alike, while each engine alone, and two engines
-    # alternating on ONE host thread, repeat bit for bit: tools/thread_probe.py, profiles/r04_thread_probe.txt) —
-    # an open observation that this test reports and bounds instead of hiding.
     for i in range(2):
-        exact = bool((solo[i][0] == both[i][0]).all())
-        print("engine %d: losses bit-identical to the solo run: %s" % (i, exact))
-        scale = float(np.abs(solo[i][0]).max())
-        assert float(np.abs(solo[i][0] - both[i][0]).max()) <= 5e-3 * scale, "losses of engine %d left their solo trajectory" % i
+        assert (solo[i][0] == both[i][0]).all(), "losses of engine %d differ" % i
         for k in solo[i][1]:
-            a, b_ = np.asarray(solo[i][1][k], dtype=np.float64), np.asarray(both[i][1][k], dtype=np.float64)
-            assert float(np.abs(a - b_).max()) <= 5e-3 * max(float(np.abs(a).max()), 1e-30) + 1e-6, (i, k)
+            assert np.array_equal(solo[i][1][k], both[i][1][k]), (i, k)
 
 
 def test_split_bf16_planes_kb32_layout(lib):
