@@ -62,6 +62,8 @@ typedef struct {
   int32_t inkernel_wait;    /* TCAR_INKERNEL_WAIT  1: kernels that can wait for a producer's flag themselves do (attention pools: click query;
                                                    slab reduce: negative term; candidate-side time gradients: dP) instead of sitting
                                                    behind a polling kernel / an event.  Default 0: measured 9 us SLOWER per step */
+  int32_t qbwd_fused;       /* TCAR_QBWD_FUSED     0: the click-query MLP's input gradients as two small GEMMs (dq1 in the main chain's grouped
+                                                   launch, dclick in front of the small tables) instead of ONE launch on the third stream */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
                                                    kernel of the side stream waits for */
@@ -140,6 +142,12 @@ int tcar_gather_clip_fwd_tuned(const tcar_tuning_t* tune, const tcar_dims_t* d, 
  * TCAR_E_ARG otherwise — run the layers through tcar_gemm_*_grouped then. */
 int tcar_query_mlp(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b, const float* q2_w,
                    const float* q2_b, float* q1, float* q, void* stream);
+
+/* The input-gradient half of the click-query MLP's backward pass in one launch (modules.py:138-139): dq1 [B, ldh] = (dq Wq2^T) *
+ * relu'(q1) and dclick [B, 2 ldt] = dq1 Wq1^T, fp32 FMAs in a fixed order; dq [B, 2 ldh] arrives through tanh' already (the pool
+ * backward applies it).  Same restriction as tcar_query_mlp (ldh == 256, ldt == 64). */
+int tcar_query_mlp_bwd(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w, float* dq1,
+                       float* dclick, void* stream);
 
 /* tcar_gather_clip_bwd: gradient of the above w.r.t. the tables (through the norm clip), i.e. the
  * IndexedSlices that tf.gradients builds for model_combine.py:156.  Adds into `g` (atomics) and adds

@@ -30,6 +30,7 @@ struct PoolArgs {
   float* g_qb;     // optional: bias gradient of query_trans2; dq then leaves multiplied by tanh'(q) (modules.py:139 backward)
   float* gw_rows;  // optional [B, 2 * ldh]: the per-session d w_res1 | d w_res2 rows are WRITTEN here (and dq leaves through
                    // tanh') instead of any atomic sum: tcar_colsum_det adds the columns up in a fixed order
+  TcarSignal sig;  // backward, optional completion flag: dq (what the other stream's click-query backward reads) leaves write-through
   TcarWait wait_q; // forward, optional: the click query q comes from another stream behind a completion flag — every wave waits
                    // for it itself, after the part of its work that does not need q (the slab fold, alpha1 / alpha_t scores)
 };
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
             atomic_add4(gw_lds + 3 * ldh + col, dqb[c]);
           }
         }
-        st4(a.dq + (long)b * ic + col, dqa[c]);
-        st4(a.dq + (long)b * ic + ldh + col, dqb[c]);
+        if (a.sig.cnt) { st4_sc1(a.dq + (long)b * ic + col, dqa[c]); st4_sc1(a.dq + (long)b * ic + ldh + col, dqb[c]); }
+        else { st4(a.dq + (long)b * ic + col, dqa[c]); st4(a.dq + (long)b * ic + ldh + col, dqb[c]); }
         if (a.gw_rows) {
           st4(a.gw_rows + (long)b * ic + col, gw1[c]);
           st4(a.gw_rows + (long)b * ic + ldh + col, gw2[c]);
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
     const float v = gw_lds[i];
     if (v != 0.f) atomicAdd((i < ldh ? a.g_w1 + i : i < 2 * ldh ? a.g_w2 + (i - ldh) : a.g_qb + (i - 2 * ldh)), v);
   }
+  tcar_signal_done(a.sig);
 }
 
 }  // namespace
@@ -381,9 +383,18 @@ extern "C" int tcar_attn_pool_bwd_slabs(const tcar_dims_t* d, int B, int T, cons
                                         const float* w_res2, const float* alpha, const float* dpooled, int nd_ic, int nd_pt,
                                         int64_t dp_stride, float* dx_icp, float* dx_pt, float* dq, float* dpre1, float* dpre2,
                                         float* gw_rows, void* stream) {
+  return tcar_attn_pool_bwd_slabs_o(d, B, T, x_icp, x_pt, pre1, pre2, q, w_res1, w_res2, alpha, dpooled, nd_ic, nd_pt, dp_stride, dx_icp,
+                                    dx_pt, dq, dpre1, dpre2, gw_rows, stream, nullptr);
+}
+// (flag-capable: dq leaves write-through when the launch carries a flag — the click-query backward on another stream reads it)
+int tcar_attn_pool_bwd_slabs_o(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1,
+                               const float* pre2, const float* q, const float* w_res1, const float* w_res2, const float* alpha,
+                               const float* dpooled, int nd_ic, int nd_pt, int64_t dp_stride, float* dx_icp, float* dx_pt, float* dq,
+                               float* dpre1, float* dpre2, float* gw_rows, void* stream, TcarOpt* o) {
   if (!d || B <= 0 || T <= 0 || T > TCAR_POS_VOCAB || (d->ldh & 63) || d->ldh > 512 || 5 * d->ldt > 512 || !gw_rows) return TCAR_E_ARG;
   if (nd_ic < 1 || nd_pt < 1) return TCAR_E_ARG;
   PoolArgs a{};
+  a.sig = tcar_sig(o);
   a.nd_ic = nd_ic; a.nd_pt = nd_pt; a.dp_stride = dp_stride;
   a.B = B; a.T = T; a.H = d->H; a.ldh = d->ldh; a.ldt = d->ldt;
   a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1; a.pre2 = pre2; a.q = q; a.w1 = w_res1; a.w2 = w_res2;

@@ -107,6 +107,135 @@ __global__ __launch_bounds__(512) void query_mlp_kernel(const QMlpArgs a) {
   }
   tcar_signal_done(a.sig);
 }
+
+// ---- backward of both layers in ONE launch (round 4) ----------------------------------------------------------------------------------
+//     dq1 = (dq Wq2^T) * relu'(q1)   [B, 256]       dclick = dq1 Wq1^T   [B, 128]        (modules.py:138-139 backward; dq arrives
+// already through tanh' — the pool backward applies it).  As small GEMMs these are two DEPENDENT launches of 32 and 16 workgroups
+// with 8 and 4 serial 64-deep stages (32 + 18-22 us) in front of the small tables' pass and the weight gradients.  Both products
+// contract along the CONTIGUOUS dimension of the weight (row j of Wq2, row m of Wq1), so a wave takes whole rows — 16 bytes per
+// lane and 64 (128) float4 per row: fully coalesced — keeps the QS sessions' gradient rows in registers, and reduces its
+// rows x sessions partial dots across the 64 lanes with a butterfly reduce-scatter (the value count halves at every exchange:
+// V - 1 exchanges for V values instead of 6 V), a fixed order: bit-for-bit repeatable.  fp32 FMAs throughout.
+struct QBwdArgs {
+  const float* dq; const float* q1; const float* w1; const float* w2;
+  float* dq1; float* dclick;
+  int B;
+  TcarSignal sig;
+};
+// v[0 .. V) per lane -> the sum over the 64 lanes of v[i] ends in lane (i * 64 / V) .. (each index owned by 64 / V adjacent lanes,
+// all of which hold it); V a power of two <= 64
+template <int N, int M, int V>
+__device__ __forceinline__ void butterfly_step(float (&v)[V], int lane) {
+  if constexpr (N > 1) {
+    const bool up = (lane & M) != 0;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      const float keep = up ? v[i + N / 2] : v[i];
+      const float send = up ? v[i] : v[i + N / 2];
+      v[i] = keep + __shfl_xor(send, M);
+    }
+    butterfly_step<N / 2, M / 2, V>(v, lane);
+  }
+}
+template <int V>
+__device__ __forceinline__ float butterfly_reduce(float (&v)[V], int lane) {
+  butterfly_step<V, 32, V>(v, lane);
+  float r = v[0];
+  // the remaining exchanges (64 / V > 1 lanes own the same index): plain pair sums
+#pragma unroll
+  for (int m = 32 / V; m >= 1; m >>= 1) r += __shfl_xor(r, m);
+  return r;
+}
+
+__global__ __launch_bounds__(512) void query_mlp_bwd_kernel(const QBwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float dq1s[QS * H1];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b0 = blockIdx.x * QS;
+  const bool wt = a.sig.cnt != nullptr;
+  // ---- layer 2 backward: wave w owns rows j = 32 w .. 32 w + 31 of Wq2 [256, 512]; lane holds columns 4 lane .. and 256 + 4 lane ..
+  {
+    float4 g0[QS], g1[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) {
+      const bool ok = b0 + s < a.B;
+      g0[s] = ok ? ld4(a.dq + (long)(b0 + s) * H2 + lane * 4) : zero4();
+      g1[s] = ok ? ld4(a.dq + (long)(b0 + s) * H2 + 256 + lane * 4) : zero4();
+    }
+#pragma unroll 1
+    for (int ch = 0; ch < 4; ++ch) {            // 8 rows per trip: 16 independent 16-byte loads per lane in flight
+      const int j0 = wave * 32 + ch * 8;
+      float4 wa[8], wb[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        wa[r] = ld4(a.w2 + (long)(j0 + r) * H2 + lane * 4);
+        wb[r] = ld4(a.w2 + (long)(j0 + r) * H2 + 256 + lane * 4);
+      }
+      float v[8 * QS];
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int s = 0; s < QS; ++s) v[r * QS + s] = dot4(wa[r], g0[s]) + dot4(wb[r], g1[s]);
+      const float sum = butterfly_reduce<8 * QS>(v, lane);          // index (r, s) = lane >> 1
+      const int idx = lane >> 1, r = idx / QS, s = idx - r * QS, j = j0 + r;
+      const bool live = b0 + s < a.B;
+      const float y = live ? a.q1[(long)(b0 + s) * H1 + j] : 0.f;
+      const float d = y > 0.f ? sum : 0.f;                           // relu'
+      if ((lane & 1) == 0) {
+        dq1s[s * H1 + j] = d;
+        if (live) {
+          if (wt) __hip_atomic_store(a.dq1 + (long)(b0 + s) * H1 + j, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else a.dq1[(long)(b0 + s) * H1 + j] = d;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- layer 1 backward: wave w owns rows m = 16 w .. 16 w + 15 of Wq1 [128, 256]; lane holds columns 4 lane ..
+  {
+    float4 g[QS];
+#pragma unroll
+    for (int s = 0; s < QS; ++s) g[s] = *reinterpret_cast<const float4*>(dq1s + s * H1 + lane * 4);
+    float4 w[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w[r] = ld4(a.w1 + (long)(wave * 16 + r) * H1 + lane * 4);
+    float v[16 * QS];
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+      for (int s = 0; s < QS; ++s) v[r * QS + s] = dot4(w[r], g[s]);
+    const float sum = butterfly_reduce<16 * QS>(v, lane);            // index (r, s) = lane
+    const int r = lane / QS, s = lane - r * QS, m = wave * 16 + r;
+    if (b0 + s < a.B) {
+      if (wt) __hip_atomic_store(a.dclick + (long)(b0 + s) * CT + m, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else a.dclick[(long)(b0 + s) * CT + m] = sum;
+    }
+  }
+  tcar_signal_done(a.sig);
+}
+}  // namespace
+
+// dq1 [B, 256] = (dq [B, 512] Wq2^T) * relu'(q1), dclick [B, 128] = dq1 Wq1^T: the input-gradient half of the click-query MLP's
+// backward pass (modules.py:138-139; weight and bias gradients are x^T dy GEMMs / column sums over dq and dq1 elsewhere).  Same
+// restrictions as tcar_query_mlp (d->ldh == 256, d->ldt == 64, dense row-major operands).
+extern "C" int tcar_query_mlp_bwd(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w,
+                                  float* dq1, float* dclick, void* stream) {
+  return tcar_query_mlp_bwd_o(d, B, dq, q1, q1_w, q2_w, dq1, dclick, stream, nullptr);
+}
+// (flag-capable: dq1 and dclick leave write-through when the launch carries a flag)
+int tcar_query_mlp_bwd_o(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w, float* dq1,
+                         float* dclick, void* stream, TcarOpt* o) {
+  if (!d || d->ldh != H1 || d->ldt * 2 != CT || B <= 0) return TCAR_E_ARG;
+  if (!dq || !q1 || !q1_w || !q2_w || !dq1 || !dclick || !tcar_aligned16(dq) || !tcar_aligned16(q1_w) || !tcar_aligned16(q2_w))
+    return TCAR_E_ARG;
+  QBwdArgs a{};
+  a.dq = dq; a.q1 = q1; a.w1 = q1_w; a.w2 = q2_w; a.dq1 = dq1; a.dclick = dclick; a.B = B;
+  a.sig = tcar_sig(o);
+  TCAR_LAUNCH(query_mlp_bwd_kernel, dim3((unsigned)((B + QS - 1) / QS)), dim3(512), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+namespace {
 }  // namespace
 
 // q1 [B, 256] = relu(click_t [B, 128] Wq1 [128, 256] + b1), q [B, 512] = tanh(q1 Wq2 [256, 512] + b2): dense row-major operands

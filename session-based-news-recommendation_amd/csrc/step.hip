@@ -20,8 +20,8 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
-    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 1023},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
-    {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},
+    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
+    {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 1},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
 // profiles/r03_ab_experiments.txt).  The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits
 // GEMM writes, and held back TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main
 // stream records nothing.
-enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_NEG = 8, FK_LOGITS = 9 };
+enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_NEG = 8, FK_LOGITS = 9,
+       FK_POOLB = 10, FK_QBWD = 11 };
 // host-side fork state of ONE context (tcar_ctx_t.fork_host: caller-owned, zeroed, tcar_fork_state_bytes() bytes)
 struct ForkSlot { TcarSignal sig; uint32_t live; uint32_t pad; };     // live: the launch armed last for this slot carries sig
 struct ForkHost { uint32_t epoch; uint32_t pad[3]; ForkSlot slot[TCAR_SIG_SLOTS]; };
@@ -216,6 +217,20 @@ inline int fork_go(const tcar_ctx_t* c, int slot, hipStream_t from, hipStream_t 
   }
   if (hipEventRecord((hipEvent_t)ev, from) != hipSuccess || hipStreamWaitEvent(to, (hipEvent_t)ev, 0) != hipSuccess) return TCAR_E_LAUNCH;
   return TCAR_OK;
+}
+
+// join of TWO producers into `to`: one polling kernel when both forks are flag forks, else each on its own (poll or event)
+inline int fork_go2(const tcar_ctx_t* c, int slot_a, hipStream_t from_a, void* ev_a, int slot_b, hipStream_t from_b, void* ev_b, hipStream_t to) {
+  const ForkSlot* a = fork_live(c, slot_a);
+  const ForkSlot* b = fork_live(c, slot_b);
+  if (a && b) {
+    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, to, (const unsigned*)a->sig.flag, a->sig.epoch, c->sig_dev + TCAR_SIG_ERR,
+                c->sig_err_host, POLL_TICKS, (const unsigned*)b->sig.flag, b->sig.epoch, 0);
+    TCAR_CHECK_LAUNCH();
+    return TCAR_OK;
+  }
+  RET(fork_go(c, slot_a, from_a, to, ev_a));
+  return fork_go(c, slot_b, from_b, to, ev_b);
 }
 
 __global__ void set_flag_kernel(unsigned* flag, unsigned epoch) {
@@ -827,15 +842,42 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // backward, relu' + bias gradient of query_trans1 in the epilogue of the GEMM that produces dq1, and that GEMM shares ONE
   // launch with the three input-gradient GEMMs of the projections (all four need only the pool backward's outputs); the
   // click-query input gradient (needs dq1) follows.  fp32 mode: the op-level sequence.
-  if (detc)
-    RET(tcar_attn_pool_bwd_slabs(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
-                                 c->alpha, dsplit ? c->proj_slabs : c->dpooled, dsplit ? nd_ic : 1, dsplit ? nd_pt : 1, dstride,
-                                 c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream));
+  // Click-query MLP backward (dq -> dq1 -> dclick) as ONE launch on the third stream (query.hip), behind the pool backward's flag:
+  // its outputs feed only the side streams (dq1: weight gradients + column sums; dclick: the small tables' pass), so the main
+  // chain's grouped launch keeps the three input-gradient GEMMs only (K = 256: 4 stages instead of the 8 of the dq1 product)
+  const bool qb = detc && tn(c).qbwd_fused && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
+                  tn(c).det_small != 0;
+  if (detc) {
+    TcarOpt opb = opt_of(c);
+    if (qb) opb.sig = fork_arm(c, FK_POOLB);
+    else fork_disarm(c, FK_POOLB);
+    RET(tcar_attn_pool_bwd_slabs_o(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
+                                   c->alpha, dsplit ? c->proj_slabs : c->dpooled, dsplit ? nd_ic : 1, dsplit ? nd_pt : 1, dstride,
+                                   c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream, &opb));
+    (void)fork_commit(c, FK_POOLB, opb);
+  }
   else
     RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
                              W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
                              G(c, TCAR_V_M_WRES), G(c, TCAR_V_S_WRES), fusedq ? G(c, TCAR_V_Q2_B) : nullptr, stream));
-  if (fusedq) {
+  if (qb) {
+    // third stream: [pool backward's flag] -> dq1, dclick
+    hipStream_t s3q = (hipStream_t)c->stream3;
+    RET(fork_go(c, FK_POOLB, st, s3q, c->ev[0]));
+    TcarOpt oq = opt_of(c);
+    oq.sig = fork_arm(c, FK_QBWD);
+    RET(tcar_query_mlp_bwd_o(&c->d, B, c->dq, c->q1, W(c, TCAR_V_Q1_W), W(c, TCAR_V_Q2_W), c->dq1, c->dclick, (void*)s3q, &oq));
+    (void)fork_commit(c, FK_QBWD, oq);
+    // main chain: the three input-gradient GEMMs (only the ITEM half of dX_ic: content is frozen)
+    tcar_gemm_desc_t p[3];
+    p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
+    p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
+    p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
+    TcarOpt oi = opt_of(c);
+    oi.sig = fork_arm(c, FK_INGRAD);
+    RET(small_gemm(c, 1, 3, p, stream, &oi));
+    (void)fork_commit(c, FK_INGRAD, oi);
+  } else if (fusedq) {
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
     p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = detc ? nullptr : G(c, TCAR_V_Q1_B);
@@ -877,7 +919,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // order-fixed small tables it runs THERE, right in front of them, behind a second poll of the input-gradient launch's flag
   // (it needs dq1 of that launch) — off the main chain (round 4: 17 us) and off the third stream, whose weight gradients, column
   // sums and norms are the step's last chain
-  const bool dclick_aux = fusedq && det_small && s3 != nullptr;
+  const bool dclick_aux = fusedq && det_small && s3 != nullptr && !qb;
   RET(weight_grads(c, g, B, BT, sW, &ow));
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
@@ -897,8 +939,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
   // (with the order-fixed small tables the aux stream's "done" event is recorded behind them, below)
   if (s2 && !det_small && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
-  if (dclick_aux) {
-    // (launched on the aux stream below, in front of the small tables)
+  if (dclick_aux || qb) {
+    // (launched on the aux stream below, in front of the small tables / by the fused click-query backward on the third stream)
   } else if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
     tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     TcarOpt od = opt_of(c);
@@ -923,7 +965,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    if (dclick_aux) {
+    if (qb) {
+      // dclick (third stream, the click-query backward) and dx_* (main chain, the input-gradient launch): one poll of both flags
+      RET(fork_go2(c, FK_QBWD, (hipStream_t)c->stream3, c->ev[5], FK_INGRAD, st, c->ev[0], s2));
+    } else if (dclick_aux) {
       RET(fork_go(c, FK_INGRAD, st, s2, c->ev[5]));       // (the same flag the third stream polled: dq1, dx_* of that launch)
       tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
       RET(small_gemm(c, 1, 1, &p, (void*)s2));

@@ -112,6 +112,12 @@ int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const
                            float* x_act, float* click_t, void* stream, TcarOpt* o);
 int tcar_query_mlp_o(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b, const float* q2_w,
                      const float* q2_b, float* q1, float* q, void* stream, TcarOpt* o);
+int tcar_attn_pool_bwd_slabs_o(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1,
+                               const float* pre2, const float* q, const float* w_res1, const float* w_res2, const float* alpha,
+                               const float* dpooled, int nd_ic, int nd_pt, int64_t dp_stride, float* dx_icp, float* dx_pt, float* dq,
+                               float* dpre1, float* dpre2, float* gw_rows, void* stream, TcarOpt* o);
+int tcar_query_mlp_bwd_o(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w, float* dq1,
+                         float* dclick, void* stream, TcarOpt* o);
 int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                 const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
                                 void* stream, TcarOpt* o, const float* cand_pc /* optional [139]: candidate-side norm pieces */);

@@ -696,7 +696,7 @@ def test_fork_state_does_not_leak_between_engines():
 
 def test_flag_and_event_forks_agree_bitwise_over_a_long_run():
     """Race hunt at the benched size: 300 deferred steps over batches of different lengths, once with the flag forks (default
-    mask 1023) and once with events only (this engine's own switch copy: TCAR_FLAG_FORK = 0); losses of every step and all 23
+    mask 4095) and once with events only (this engine's own switch copy: TCAR_FLAG_FORK = 0); losses of every step and all 23
     variables + Adam moments at the end are bitwise equal — the two schedules run the same kernels in the same per-stream
     order with order-fixed sums, so a consumer that read a stale line behind a flag would show up here."""
     _need_gpu()
@@ -751,7 +751,7 @@ def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_
             losses = []
             for _ in range(steps):
                 if mine is not None:
-                    assert mine.acquire(timeout=120)
+                    assert mine.acquire(timeout=30) and not errs, "the other engine's thread failed"
                 losses.append(eng.train_step(None, bt=bt, defer_update=True).clone())
                 if other is not None:
                     torch.cuda.synchronize()          # the other engine's step starts on an idle device
@@ -764,9 +764,9 @@ def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_
             out[slot] = res
         return res
 
+    both, errs = [None, None], []
     solo = [run(c, torch.cuda.Stream(priority=-1)) for c in cases]
     torch.cuda.synchronize()
-    both, errs = [None, None], []
     baton = [threading.Semaphore(1), threading.Semaphore(0)]
 
     def worker(i):
@@ -776,12 +776,13 @@ def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_
             errs.append(e)
             baton[1 - i].release()
 
-    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    th = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(2)]      # daemon: a failure never keeps the process alive
     for t in th:
         t.start()
     for t in th:
-        t.join()
+        t.join(timeout=240)
     assert not errs, errs
+    assert not any(t.is_alive() for t in th), "a stepping thread did not finish"
     for i in range(2):
         assert (solo[i][0] == both[i][0]).all(), "losses of engine %d differ" % i
         for k in solo[i][1]:
@@ -1592,3 +1593,30 @@ def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
     # (the list SUM uses fp32 attout in the one-hot form, the bf16 plane in the materialised one: bf16-level agreement)
     close(got_g, gsm2.cpu().numpy()[:139 * ldt].reshape(139, ldt), rtol=2e-2, atol_scale=5e-3, name="table gradients: both forms")
     close(sqn.cpu().numpy()[2:7], sqn2.cpu().numpy()[2:7], rtol=1e-3, name="norm pieces: both forms")
+
+
+@pytest.mark.parametrize("B", [1, 7, 512, 1030])
+def test_query_mlp_backward_kernel(lib, B):
+    """tcar_query_mlp_bwd: dq1 = (dq Wq2^T) * relu'(q1), dclick = dq1 Wq1^T (modules.py:138-139 backward) in one launch against
+    fp64, ragged B (sessions per workgroup = 4), relu' exactly zero where q1 == 0."""
+    from tcar_amd._lib import Dims
+    rng = np.random.RandomState(B)
+    d = Dims(1000, 250, 64, 256, 64)
+    dq = (rng.standard_normal((B, 512)) * 0.3).astype(np.float32)
+    q1 = np.maximum(rng.standard_normal((B, 256)), 0).astype(np.float32)           # post-relu: about half the entries are 0
+    w1 = (rng.standard_normal((128, 256)) * 0.1).astype(np.float32)
+    w2 = (rng.standard_normal((256, 512)) * 0.1).astype(np.float32)
+    t = lambda x: torch.tensor(x, device="cuda")
+    ddq, dq1_, dw1, dw2 = t(dq), t(q1), t(w1), t(w2)
+    o1, o2 = torch.full((B + 3, 256), 7.0, device="cuda"), torch.full((B + 3, 128), 7.0, device="cuda")
+    assert lib.tcar_query_mlp_bwd(C.byref(d), B, ptr(ddq), ptr(dq1_), ptr(dw1), ptr(dw2), ptr(o1), ptr(o2), None) == 0
+    want1 = (dq.astype(np.float64) @ w2.astype(np.float64).T) * (q1 > 0)
+    want2 = want1 @ w1.astype(np.float64).T
+    close(o1[:B].cpu().numpy(), want1, rtol=1e-5, atol_scale=1e-6, name="dq1")
+    close(o2[:B].cpu().numpy(), want2, rtol=1e-5, atol_scale=1e-6, name="dclick")
+    assert (o1[B:] == 7.0).all() and (o2[B:] == 7.0).all()
+    again1, again2 = torch.empty_like(o1), torch.empty_like(o2)
+    assert lib.tcar_query_mlp_bwd(C.byref(d), B, ptr(ddq), ptr(dq1_), ptr(dw1), ptr(dw2), ptr(again1), ptr(again2), None) == 0
+    assert torch.equal(again1[:B], o1[:B]) and torch.equal(again2[:B], o2[:B])        # fixed summation order
+    bad = Dims(1000, 300, 64, 320, 64)
+    assert lib.tcar_query_mlp_bwd(C.byref(bad), B, ptr(ddq), ptr(dq1_), ptr(dw1), ptr(dw2), ptr(o1), ptr(o2), None) == -1

@@ -18,8 +18,8 @@ for step in "$@"; do
   echo "=== [$tag] $step"
   case $kind in
     tests)
-      if [ -n "$rest" ]; then timeout 1700 python -m pytest tests -m gpu -x -q --tb=short -k "$rest" > gpurun_out/${tag}_pytest.log 2>&1
-      else timeout 1700 python -m pytest tests -m gpu -x -q --tb=short > gpurun_out/${tag}_pytest.log 2>&1; fi
+      if [ -n "$rest" ]; then timeout 1700 python -m pytest tests -m gpu -x -q --tb=short --timeout=300 -k "$rest" > gpurun_out/${tag}_pytest.log 2>&1
+      else timeout 1700 python -m pytest tests -m gpu -x -q --tb=short --timeout=300 > gpurun_out/${tag}_pytest.log 2>&1; fi
       tail -25 gpurun_out/${tag}_pytest.log | cut -c1-400 ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     bench)
