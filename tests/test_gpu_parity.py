@@ -694,6 +694,30 @@ def test_fork_state_does_not_leak_between_engines():
         gc.collect()
 
 
+def test_step_with_the_fused_query_backward_launch_tracks_the_default_schedule():
+    """TCAR_QBWD_FUSED=1 (off by default: profiles/r04_ab_experiments.txt) replaces two grouped-GEMM problems of the step by
+    query_mlp_bwd on the third stream behind the pool backward's flag; the sums are fp32 in another order, so 40 deferred
+    steps agree with the default schedule to 2e-4 of the loss scale rather than bitwise."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, K = 46033, 250, 64, 512, 20
+    params, content, mw, _ = _case(N, H, Ht, 8, 2, K, seed=23)
+    batches = [_case(N, H, Ht, B, T, K, seed=300 + T)[3] for T in (2, 3, 1)]
+    runs = []
+    for fused in (0, 1):
+        eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+        eng.set_tuning(TCAR_QBWD_FUSED=fused)
+        res = [eng.make_resident(b) for b in batches]
+        losses = [eng.train_step(None, bt=res[i % len(res)], defer_update=True).clone() for i in range(40)]
+        eng.flush()
+        eng.check_forks()
+        runs.append(torch.stack([l[:B] for l in losses]).cpu().numpy())
+        del eng, res
+        torch.cuda.empty_cache()
+    assert np.isfinite(runs[1]).all()
+    assert np.abs(runs[0] - runs[1]).max() <= 2e-4 * np.abs(runs[0]).max(), np.abs(runs[0] - runs[1]).max()
+
+
 def test_flag_and_event_forks_agree_bitwise_over_a_long_run():
     """Race hunt at the benched size: 300 deferred steps over batches of different lengths, once with the flag forks (default
     mask 4095) and once with events only (this engine's own switch copy: TCAR_FLAG_FORK = 0); losses of every step and all 23

@@ -5,6 +5,7 @@
 #   tests[:<pytest -k expr>]   pytest -m gpu (optionally filtered)        -> <tag>_pytest.log
 #   smoke                      __graft_entry__.smoke()
 #   bench[:<name>[:<bench.py args>]]   one bench line                     -> <tag>_bench_<name>.json
+#                              (args may start with environment assignments: "bench:dp1:TCAR_FORCE_DP=1 --dp_mode sharded")
 #   ab:<rounds>:<env A>|<env B>|...    interleaved A/B of environment settings (headline loop only), ms/step per run
 #   trace[:<bench.py args>]    rocprofv3 --kernel-trace of the default bench -> <tag>_kernel_stats.csv/.txt, <tag>_timeline.txt
 #   pmc:<variant>:<nsplit>     tools/pmc_gemm.sh                          -> <tag>_pmc_<variant>.log (+ gpurun_out/pmc_*.json)
@@ -24,7 +25,8 @@ for step in "$@"; do
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
     bench)
       name=${rest%%:*}; args=${rest#*:}; [ "$args" == "$rest" ] && args=""; [ -z "$name" ] && name=default
-      python bench.py $args > gpurun_out/${tag}_bench_${name}.json 2> gpurun_out/${tag}_bench_${name}.err
+      envs=""; while [[ "$args" =~ ^([A-Z_0-9]+=[^ ]*)\ ?(.*)$ ]]; do envs="$envs ${BASH_REMATCH[1]}"; args="${BASH_REMATCH[2]}"; done
+      env $envs python bench.py $args > gpurun_out/${tag}_bench_${name}.json 2> gpurun_out/${tag}_bench_${name}.err
       python - <<PY
 import json
 try:
@@ -45,7 +47,8 @@ PY
         echo "round $r [$s] $out" | tee -a gpurun_out/${tag}_ab.txt
       done; done ;;
     trace)
-      ( cd /tmp && export TMPDIR=/tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_${tag} -o tr -- python3 $OLDPWD/bench.py --steps 200 --warmup 20 --no_cpu_baseline --no_e2e $rest > $OLDPWD/gpurun_out/${tag}_trace.log 2>&1 )
+      envs=""; while [[ "$rest" =~ ^([A-Z_0-9]+=[^ ]*)\ ?(.*)$ ]]; do envs="$envs ${BASH_REMATCH[1]}"; rest="${BASH_REMATCH[2]}"; done
+      ( cd /tmp && export TMPDIR=/tmp $envs && timeout 400 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_${tag} -o tr -- python3 $OLDPWD/bench.py --steps 200 --warmup 20 --no_cpu_baseline --no_e2e $rest > $OLDPWD/gpurun_out/${tag}_trace.log 2>&1 )
       db=$(ls gpurun_out/prof_${tag}/*/tr_results.db gpurun_out/prof_${tag}/tr_results.db 2>/dev/null | head -1)
       python tools/kstats.py $db gpurun_out/${tag}_kernel_stats.csv > gpurun_out/${tag}_kernel_stats.txt
       python tools/timeline.py $db ${TL_STEP:-100} > gpurun_out/${tag}_timeline.txt
