@@ -318,6 +318,16 @@ int tcar_time_scores_clip(const tcar_dims_t* d, const float* const time_tab[5], 
                           void* p_hi, void* p_lo, int64_t inner, float* tclip, void* stream);
 int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                    float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream);
+/* The two halves of tcar_ce_finish for the catalog-sharded step (sharded.py), where the row statistics cross the ranks in between:
+ *   tcar_ce_shard_stats  out3[b] = (max, sum exp(x - max), label score) of THIS shard's columns from the epilogue's per-group pairs;
+ *                        the label score is 0 unless label[b] lies in [n0, n0 + n_loc)  (= tcar_softmax_stats without the logits)
+ *   tcar_ce_rescale      plane[b, n] = e[b, n] exp(m_g - rowstat[b].x) rowstat[b].y - [n == label[b] - lab_off]; lab_window != 0: a
+ *                        label outside [lab_off, lab_off + N) belongs to another shard, nothing is subtracted (0: clamped, as
+ *                        tcar_ce_finish).  rowstat = (lse, 1) from tcar_softmax_combine_rowstat. */
+int tcar_ce_shard_stats(int B, int ngroups, const float* stats, const float* lab_logit, const int32_t* label, int n0, int n_loc,
+                        float* out3, void* stream);
+int tcar_ce_rescale(int B, int N, int group_width, int ngroups, const float* stats, const float* rowstat, const int32_t* label,
+                    int lab_off, int lab_window, void* dl_hi, int64_t inner, void* stream);
 /* ---- one-hot form of the two scoring GRADIENT GEMMs (training steps, hi planes only) -------------------------------------------
  * The candidate-side time columns of items_emb (model_combine.py:86-92,135-136) are five clipped table rows per item, selected by
  * publish_time_MWDHM: E_time = OH T_clip with the static 0/1 matrix OH [N, 160] (tcar_time_onehot) and the 139 clipped rows
@@ -625,6 +635,9 @@ int tcar_form_batch(const tcar_dims_t* d, const tcar_store_t* st, const tcar_neg
  *   tcar_neg_scatter_range  g_item[neg[b,k] - n0, 0:ldh] += coef[b] * attout[b, 0:ldh] for the negatives inside the shard */
 int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld, const int32_t* label, int n0, float* stats, void* stream);
 int tcar_softmax_combine(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce, void* stream);
+/* ... and rowstat [B, 2] = (lse, 1) — +inf for a padding session — for tcar_ce_rescale (softmax-epilogue form of the shard's scoring) */
+int tcar_softmax_combine_rowstat(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce, float* rowstat,
+                                 void* stream);
 int tcar_softmax_grad(int B, int N, const float* logits, int64_t ld, const float* lse, const int32_t* label, int n0, void* dl_hi,
                       void* dl_lo, void* stream);
 int tcar_neg_scatter_range(const tcar_dims_t* d, int64_t B, int K, int n0, int n_loc, const int32_t* neg, const float* attout,
@@ -643,7 +656,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
                         const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 21
+#define TCAR_ABI_VERSION 22
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -797,7 +810,12 @@ typedef struct {
 } tcar_shard_t;
 /* forward of the local sessions up to attout (+ the negative term's forward part when bt->K > 0) */
 int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream);
-/* attout planes, logits = att_all E_shard^T, per-shard softmax statistics; refresh_time != 0 rebuilds the shard's time planes */
+/* attout planes, logits = att_all E_shard^T, per-shard softmax statistics; refresh_time != 0 rebuilds the shard's time planes.
+ * With the workspaces of the benchmarked single-GPU schedule in the context — ce_ws sized for world*cap rows, the shard's one-hot
+ * plane oh16, p16h / p16l for world*cap rows, tclip, dP [world*cap, 160], qz [5 n_loc] — and scoring 3 / scoring_bwd 1 / ldt 64,
+ * tcar_shard_score / _backward / _finish run THAT schedule on the shard: the logits GEMM with the softmax epilogue and the one-hot
+ * time segment (no fp32 logits; s->logits may then be NULL), tcar_ce_rescale, the one-hot forms of dX and dE and
+ * tcar_cand_time_bwd_onehot; the time planes of the shard are never read (pass refresh_time = 0). */
 int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int refresh_time, void* stream);
 /* stats_all [world, world*cap, 3] -> lse / ce; dlogits planes; dE of the shard (item | time block, local for good);
  * dX partial of every session -> s->dx */

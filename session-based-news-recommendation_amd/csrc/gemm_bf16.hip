@@ -58,6 +58,7 @@ struct BArgs {
   __bf16* p_hi; int p_in32;    // plane [ceil128(M), 32 * p_in32]
   float* stats; int ngroups;   // [M, ngroups, 2]
   const int32_t* label; float* lab_logit;
+  int lab_off, lab_window;     // TcarOpt: column of the label = label[m] - lab_off; window: outside [0, N) = not in this shard
   // dX of the one-hot form (layout 0, hi planes only): N tiles at or beyond column n_b2 (a multiple of the tile width) read their B
   // operand from the plane B2 (inner b2_in32 * 32, rows as B) at column n0 - n_b2 — the static one-hot matrix of
   // publish_time_MWDHM, so that those output columns are dP = dlogits OH instead of dlogits E_time.  0: unused.
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
         for (int e = 0; e < 16; ++e)
           if (nb + 32 * t + (e & 3) + 8 * (e >> 2) < g.N) mx = fmaxf(mx, acc[u][t][e]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const int lab = live ? clampi(g.label[row], 0, g.N - 1) : -1;      // (clamped like tcar_ce_finish: lab_logit is always written)
+      // (clamped like tcar_ce_finish: lab_logit is always written; with a label window — catalog shard — a label outside it matches
+      //  no column and lab_logit[row] is left alone)
+      const int lraw = live ? g.label[row] - g.lab_off : -1;
+      const int lab = !live ? -1 : g.lab_window ? ((lraw >= 0 && lraw < g.N) ? lraw : -1) : clampi(lraw, 0, g.N - 1);
       float sum = 0.f, labv = 0.f;
       bool has_lab = false;
 #pragma unroll
@@ -433,6 +437,8 @@ int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
       lc.ce_gw = 32 * TNW;
       lc.ce_ngroups = g.ngroups;
       g.sig = tcar_sig(lc.o);
+      g.lab_off = lc.o ? lc.o->lab_off : 0;
+      g.lab_window = lc.o ? lc.o->lab_window : 0;
       if (g.B2) {
         if constexpr (NSPLIT == 3 && KS == 1) {
           TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1>), lds);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void ce_combine_kernel(int B, int ngroups, con
 template <int GW>
 __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
                                                 const float* __restrict__ rowstat, const int32_t* __restrict__ label,
-                                                __bf16* __restrict__ plane, long nunits) {
+                                                __bf16* __restrict__ plane, long nunits, int lab_off, int lab_window) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nunits) return;
   const long blk = i >> 7;
@@ -232,7 +232,9 @@ __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngro
   const float mg = (gi < ngroups && col0 < N) ? stats[((long)row * ngroups + gi) * 2] : -INFINITY;
   const float2 rs = *reinterpret_cast<const float2*>(rowstat + 2 * row);
   const float c = (mg == -INFINITY) ? 0.f : expf(mg - rs.x) * rs.y;
-  const int lab = clampi(label[row], 0, N - 1) - col0;          // label's column inside this block, if 0 <= lab < 32
+  // label's column inside this block, if 0 <= lab < 32 (label window — catalog shard —: a label of another shard matches nothing)
+  const int lraw = label[row] - lab_off;
+  const int lab = (lab_window ? ((lraw >= 0 && lraw < N) ? lraw : -(1 << 30)) : clampi(lraw, 0, N - 1)) - col0;
   const int sw = (r >> 2) & 3;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -254,8 +256,33 @@ __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngro
 template <int GW>
 __global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
                                                          const float* __restrict__ rowstat, const int32_t* __restrict__ label,
-                                                         __bf16* __restrict__ plane, long nunits) {
-  ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits);
+                                                         __bf16* __restrict__ plane, long nunits, int lab_off, int lab_window) {
+  ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits, lab_off, lab_window);
+}
+// Catalog-sharded step: the shard's (max, sum exp, label score) per session from the epilogue's per-group pairs — the row of the
+// statistics all-gather (shard.hip: softmax_combine).  The label's score is 0 unless the label lies in [n0, n0 + n_loc).
+__global__ __launch_bounds__(256) void ce_shard_stats_kernel(int B, int ngroups, const float* __restrict__ stats,
+                                                             const float* __restrict__ lab_logit, const int32_t* __restrict__ label,
+                                                             int n0, int n_loc, float* __restrict__ out3) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float2* st = reinterpret_cast<const float2*>(stats) + (long)b * ngroups;
+  float m = -INFINITY;
+  for (int g = lane; g < ngroups; g += 64) m = fmaxf(m, st[g].x);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int g = lane; g < ngroups; g += 64) {
+    const float2 v = st[g];
+    if (v.x != -INFINITY) s += v.y * expf(v.x - m);
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    const int l = label[b] - n0;
+    out3[3L * b] = m;
+    out3[3L * b + 1] = s;
+    out3[3L * b + 2] = (l >= 0 && l < n_loc) ? lab_logit[b] : 0.f;
+  }
 }
 
 // ---- negative-feedback term (model_combine.py:142-143) ---------------------------------------------------
@@ -475,8 +502,10 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
     if (addend) tcar_wave_wait(wait_add);
     if (row < M) {
       if (addend) acc = add4(wait_add.flag ? ld4_sc1(addend + (long)row * ld_add + col) : ld4(addend + (long)row * ld_add + col), acc);
-      const float4 yy = ld4(y + (long)row * ldy + col);
-      acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+      if (y) {          // (y = NULL, catalog-sharded step: the partial sums leave before tanh' — it follows the exchange)
+        const float4 yy = ld4(y + (long)row * ldy + col);
+        acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+      }
       st4(out + (long)row * ldo + col, acc);
       cs = acc;
     }
@@ -525,8 +554,10 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
       expand16(acc, xr, v[j], std::make_integer_sequence<int, 16>{});
     }
     if (row < M) {
-      const float4 yy = ld4(y + (long)row * ldy + col);
-      acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+      if (y) {
+        const float4 yy = ld4(y + (long)row * ldy + col);
+        acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+      }
       st4(out + (long)row * ldo + col, acc);
       cs = acc;
     }
@@ -833,13 +864,38 @@ extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const 
   hipStream_t st = (hipStream_t)stream;
   TCAR_LAUNCH(ce_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, ngroups, stats, lab_logit, rowstat, ce);
   TCAR_CHECK_LAUNCH();
+  return tcar_ce_rescale(B, N, group_width, ngroups, stats, rowstat, label, 0, 0, dl_hi, inner, stream);
+}
+
+// second half of tcar_ce_finish on its own (catalog-sharded step: the row statistics come from the statistics exchange):
+// plane[b, n] = e[b, n] * exp(m_g - rowstat[b].x) * rowstat[b].y - [n == label[b] - lab_off]; lab_window != 0: a label outside
+// [lab_off, lab_off + N) belongs to another shard and nothing is subtracted
+extern "C" int tcar_ce_rescale(int B, int N, int group_width, int ngroups, const float* stats, const float* rowstat,
+                               const int32_t* label, int lab_off, int lab_window, void* dl_hi, int64_t inner, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (N <= 0 || !stats || !label || !rowstat || !dl_hi || (inner & 31) || inner < N || ngroups <= 0 ||
+      (group_width != 64 && group_width != 96) || (long)ngroups * group_width < N || ((uintptr_t)rowstat & 7))
+    return TCAR_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
   const int in32 = (int)(inner >> 5);
   const long nunits = (((long)B + 127) >> 7) * in32 * 128;
   const unsigned grid = (unsigned)((nunits + 255) / 256);
   if (group_width == 96)
-    TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits);
+    TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits,
+                lab_off, lab_window);
   else
-    TCAR_LAUNCH(ce_rescale_kernel<64>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits);
+    TCAR_LAUNCH(ce_rescale_kernel<64>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits,
+                lab_off, lab_window);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+extern "C" int tcar_ce_shard_stats(int B, int ngroups, const float* stats, const float* lab_logit, const int32_t* label, int n0,
+                                   int n_loc, float* out3, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (ngroups <= 0 || !stats || !lab_logit || !label || !out3 || ((uintptr_t)stats & 7)) return TCAR_E_ARG;
+  TCAR_LAUNCH(ce_shard_stats_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, ngroups, stats, lab_logit, label, n0,
+              n_loc, out3);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -917,7 +973,7 @@ int tcar_reduce_dact_onehot_o(const float* slabs, int splitk, int M, int ic, int
                               float* bias_grad1, void* stream, TcarOpt* o) {
   if (M <= 0) return TCAR_OK;
   if (!slabs || splitk <= 0 || ic <= 0 || (ic & 63) || ld < ic + 160 || (ld & 3) || (ldy & 3) || (ldo & 3) || (addend && (ld_add & 3)) ||
-      !y || !tclip || !out || !dP || !tcar_aligned16(slabs) || !tcar_aligned16(y) || !tcar_aligned16(out) || !tcar_aligned16(tclip) ||
+      !tclip || !out || !dP || !tcar_aligned16(slabs) || (y && !tcar_aligned16(y)) || !tcar_aligned16(out) || !tcar_aligned16(tclip) ||
       (addend && !tcar_aligned16(addend)))
     return TCAR_E_ARG;
   TCAR_LAUNCH(reduce_dact_onehot_kernel, dim3(ic / 64 + 5, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, ic,

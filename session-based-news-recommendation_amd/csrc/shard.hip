@@ -100,11 +100,14 @@ __global__ __launch_bounds__(NT) void softmax_stats_rows_kernel(int B, int N, co
 // stats_all [W, B, 3] -> lse [B], ce [B] = lse - label logit (the label lives in exactly one shard; the others sent 0)
 __global__ __launch_bounds__(256) void softmax_combine_kernel(int W, int B, const float* __restrict__ stats_all,
                                                               const int32_t* __restrict__ label, float* __restrict__ lse,
-                                                              float* __restrict__ ce) {
+                                                              float* __restrict__ ce, float* __restrict__ rowstat) {
   const int b = blockIdx.x * 256 + threadIdx.x;
   if (b >= B) return;
+  // rowstat (softmax-epilogue form): the pair tcar_ce_rescale scales the exp plane with — exp(m_g - lse) * 1
+  if (rowstat) rowstat[2 * b + 1] = 1.f;
   if (label && label[b] < 0) {          // padding session of an uneven shard: lse = +inf makes its gradient row exactly zero
     lse[b] = INFINITY;
+    if (rowstat) rowstat[2 * b] = INFINITY;
     if (ce) ce[b] = 0.f;
     return;
   }
@@ -118,6 +121,7 @@ __global__ __launch_bounds__(256) void softmax_combine_kernel(int W, int B, cons
   }
   const float l = m + logf(s);
   lse[b] = l;
+  if (rowstat) rowstat[2 * b] = l;
   if (ce) ce[b] = l - lab;
 }
 
@@ -234,9 +238,14 @@ extern "C" int tcar_softmax_stats(int B, int N, const float* logits, int64_t ld,
 
 extern "C" int tcar_softmax_combine(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce,
                                     void* stream) {
+  return tcar_softmax_combine_rowstat(W, B, stats_all, label, lse, ce, nullptr, stream);
+}
+extern "C" int tcar_softmax_combine_rowstat(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce,
+                                            float* rowstat, void* stream) {
   if (B <= 0) return TCAR_OK;
   if (W <= 0 || !stats_all || !lse) return TCAR_E_ARG;
-  TCAR_LAUNCH(softmax_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, B, stats_all, label, lse, ce);
+  TCAR_LAUNCH(softmax_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, B, stats_all, label, lse, ce,
+              rowstat);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

@@ -1161,11 +1161,20 @@ extern "C" int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int
 }
 
 namespace {
+// The shard runs the benchmarked single-GPU schedule (softmax epilogue + one-hot forms) when the context carries its workspaces,
+// sized for the world*cap session rows of the exchange, and the precision is the benchmarked one (bf16x3 forward, hi-only backward)
+bool shard_onehot(const tcar_ctx_t* c, const tcar_shard_t* s, CeWs* w) {
+  tcar_ctx_t cc = *c;
+  cc.d.n_items = s->n_loc;
+  return c->scoring == 3 && c->d.ldt == 64 && fused_ce(&cc, s->world * s->cap, w) && c->ce_geo && c->oh16 && c->p16h && c->p16l &&
+         c->tclip && c->dP && c->qz && c->inv_off && c->ct_ws && c->mwdhm && tn(c).onehot_time >= 2;
+}
 int check_shard(const tcar_ctx_t* c, const tcar_shard_t* s) {
   if (!c || !s || !c->scoring || s->world <= 0 || s->cap <= 0 || s->n_loc <= 0 || s->n0 < 0) return TCAR_E_ARG;
-  if (!s->att_all || !s->lab_all || !s->logits || !s->stats || !s->lse || !s->ce || !s->a16h || !s->a16l || !s->ap16h ||
+  if (!s->att_all || !s->lab_all || !s->stats || !s->lse || !s->ce || !s->a16h || !s->a16l || !s->ap16h ||
       !s->ap16l || !s->dl16h || !s->dl16l || !s->slabs || !s->dx || !c->e16h || !c->e16l || !c->big || !c->et_perm)
     return TCAR_E_ARG;
+  if (!s->logits && !shard_onehot(c, s, nullptr)) return TCAR_E_ARG;
   return TCAR_OK;
 }
 }  // namespace
@@ -1190,6 +1199,25 @@ extern "C" int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int 
     RET(tcar_shard_unpack_head(Bq, g.ek, s->head_K, s->att_all, s->ld_att, const_cast<int32_t*>(s->lab_all), s->coef_all, s->neg_all,
                                stream));
   RET(tcar_split_bf16(s->att_all, s->ld_att ? s->ld_att : g.ek, Bq, g.ek, s->a16h, s->a16l, g.ek, s->ap16h, s->ap16l, g.ldh + g.pt, g.ldh, g.ic, stream));
+  CeWs w;
+  if (shard_onehot(c, s, &w)) {
+    // the benchmarked schedule on the shard: time scores through the one-hot contraction (+ the clipped table rows for the
+    // backward), ONE GEMM over 2 ldh + 160 columns whose epilogue leaves exp(x - group max) as the plane that becomes dlogits and
+    // per-group (max, sum) pairs — no [W*cap, n_loc] fp32 logits —, then the shard's row of the statistics exchange
+    const float* tt[5];
+    for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+    const int64_t lda = s->ld_att ? s->ld_att : g.ek;
+    RET(tcar_time_scores_clip(&dc, tt, Bq, s->att_all, lda, c->p16h, c->p16l, 160, c->tclip, stream));
+    TcarOpt ol = opt_of(c);
+    ol.lab_off = s->n0;
+    ol.lab_window = 1;
+    int32_t gw = 0, ng = 0;
+    RET(tcar_gemm_bf16_ce_o(Bq, nl, g.ic + 160, s->a16h, s->a16l, g.ek, Bq, c->e16h, c->e16l, g.ek, nlpad, g.ic, c->p16h, c->p16l,
+                            c->oh16, 160, s->dl16h, nlpad, (Bq + 127) & ~127, w.stats, w.stats_floats, s->lab_all, w.lab, c->scoring,
+                            &gw, &ng, stream, &ol));
+    c->ce_geo[0] = gw; c->ce_geo[1] = ng;
+    return tcar_ce_shard_stats(Bq, ng, w.stats, w.lab, s->lab_all, s->n0, nl, s->stats, stream);
+  }
   RET(tcar_gemm_bf16(1, Bq, nl, g.ek, s->a16h, s->a16l, g.ek, Bq, c->e16h, c->e16l, g.ek, nlpad, s->logits, nlpad, nullptr, 0, 0,
                      c->scoring, 1, stream));
   return tcar_softmax_stats(Bq, nl, s->logits, nlpad, s->lab_all, s->n0, s->stats, stream);
@@ -1201,6 +1229,33 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
   const Geo g(c->d);
   const int Bq = s->world * s->cap, nl = s->n_loc, nlpad = (nl + 127) & ~127, Bp = (Bq + 127) & ~127;
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
+  CeWs w;
+  if (shard_onehot(c, s, &w)) {
+    // lse from the exchanged statistics, the exp plane rescaled in place to dlogits of the shard's columns; then the one-hot forms:
+    // dE (aux stream) keeps its item block and leaves (||gy||^2, x . gy) pairs for the time block; dX contracts the shard against
+    // [E_item | E_content | OH]; the slab reduce expands dP to the time columns WITHOUT tanh' (it follows the exchange)
+    RET(tcar_softmax_combine_rowstat(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, w.rowstat, stream));
+    RET(tcar_ce_rescale(Bq, nl, c->ce_geo[0], c->ce_geo[1], w.stats, w.rowstat, s->lab_all, s->n0, 1, s->dl16h, nlpad, stream));
+    hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
+    if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+      return TCAR_E_LAUNCH;
+    TcarOpt ob = opt_of(c);
+    // (a short shard leaves the 192-row tiles too few workgroups for the chip: 128-row tiles then)
+    const int forced = tn(c).bf16_tile;
+    const int tile = (forced == 256 || forced == 128) ? forced : (((nl + 191) / 192) * 3 < 200 ? 128 : 0);
+    RET(tcar_gemm_bf16_de_qz_o(nl, (Bq + 31) & ~31, s->dl16h, nlpad, Bp, s->ap16h, g.ldh + g.pt, Bp, g.ldh, c->big, g.ldh, c->mwdhm,
+                               c->et_perm, c->tclip, c->qz, tile, s2 ? (void*)s2 : stream, &ob));
+    TcarOpt ox = opt_of(c);
+    RET(tcar_gemm_bf16_dx_onehot_o(Bq, g.ic, nlpad, s->dl16h, nlpad, Bq, c->e16h, g.ek, nlpad, c->oh16, 160, s->slabs, g.ic + 160,
+                                   c->splitk, stream, &ox));
+    const int S1 = tcar_gemm_splitk_effective(nlpad, c->splitk);
+    TcarOpt orr = opt_of(c);
+    RET(tcar_reduce_dact_onehot_o(s->slabs, S1, Bq, g.ic, g.ic + 160, nullptr, 0, nullptr, 0, c->tclip, s->dx, g.ek, c->dP, nullptr,
+                                  nullptr, stream, &orr));
+    // dP is complete: tcar_shard_finish lets the candidate-side table gradients (aux stream, behind dE) wait for this point
+    if (s2 && hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess) return TCAR_E_LAUNCH;
+    return TCAR_OK;
+  }
   RET(tcar_softmax_combine(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, stream));
   RET(tcar_softmax_grad(Bq, nl, s->logits, nlpad, s->lse, s->lab_all, s->n0, s->dl16h, nsb == 1 ? nullptr : s->dl16l, stream));
   float* Gi = c->big;
@@ -1242,7 +1297,14 @@ extern "C" int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int
   grads_of(c, gr);
   const float* tt[5];
   for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-  RET(tcar_cand_time_bwd_indexed(&dc, tt, c->inv_n, c->inv_off, c->big + (size_t)nl * g.ldh, 1, c->ct_ws, &gr, sf));
+  if (shard_onehot(c, s, nullptr)) {
+    // from the (q, z) pairs of dE (this stream) and dP of the slab reduce (main stream: ev[2] of tcar_shard_backward)
+    if (s2 && hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;
+    RET(tcar_cand_time_bwd_onehot_w(&dc, s->world * s->cap, c->inv_off, c->qz, c->dP, s->att_all, s->ld_att ? s->ld_att : g.ek,
+                                    c->tclip, c->ct_ws, &gr, sf, TcarWait{}, 1));
+  } else {
+    RET(tcar_cand_time_bwd_indexed(&dc, tt, c->inv_n, c->inv_off, c->big + (size_t)nl * g.ldh, 1, c->ct_ws, &gr, sf));
+  }
   if (s2 && hipEventRecord((hipEvent_t)c->ev[3], s2) != hipSuccess) return TCAR_E_LAUNCH;
   return TCAR_OK;
 }
@@ -1289,16 +1351,18 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
     RET(small_gemm(c, 1, 4, p, stream));
   }
   {
-    tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
-    RET(small_gemm(c, 1, 1, &p, stream));
-  }
-  {
-    // beside the row gradients on the aux stream (behind tcar_shard_finish there); tcar_shard_join covers it
+    // beside the row gradients on the aux stream (behind tcar_shard_finish there); tcar_shard_join covers it.  Forked IN FRONT of
+    // the click-query input gradient: the weight gradients need dq1 of the launch above, not dclick (round 4 timeline: the aux
+    // chain — weight gradients, column sums — ends the piece; 20 us earlier here is 20 us off the join)
     hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
     if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
       return TCAR_E_LAUNCH;
     RET(weight_grads(c, g, B, BT, s2 ? (void*)s2 : stream));
     if (detc) RET(det_colsums(c, g, B, s2 ? (void*)s2 : stream));
+  }
+  {
+    tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+    RET(small_gemm(c, 1, 1, &p, stream));
   }
   tcar_tables_t tab;
   tcar_grads_t gr;

@@ -98,6 +98,9 @@ struct TcarOpt {
   TcarSignal sig{};
   bool carried = false;
   TcarWait wait{};       // a flag the launch waits for IN the kernel (launchers that support it: the one-hot slab reduce)
+  // label window of the softmax-epilogue logits GEMM (catalog-sharded step): the column of row m's label is label[m] - lab_off,
+  // and a label outside [0, N) is in another shard — no label score is written for it (lab_window = 0: labels are clamped)
+  int lab_off = 0, lab_window = 0;
   const TcarTuning& tn() const { return tune ? *tune : tcar_tuning(); }
 };
 inline const TcarTuning& tcar_tn(const TcarOpt* o) { return o ? o->tn() : tcar_tuning(); }

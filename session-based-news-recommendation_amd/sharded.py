@@ -257,7 +257,27 @@ class ShardedEngine(TcarEngine):
             self.s_lab = torch.full((Bq,), -1, dtype=torch.int32, device=self.dev)      # unpacked by tcar_shard_score
             self.s_neg = torch.full((Bq, kc), -1, dtype=torch.int32, device=self.dev)
             self.s_coef = torch.zeros(Bq, **f32)
-            self.s_logits = torch.empty(Bq, self.nlpad, **f32)
+            # the benchmarked single-GPU schedule on the shard (tcar_hip.h: tcar_shard_score): softmax epilogue + one-hot forms —
+            # no fp32 logits; their workspaces are sized for the W * cap session rows of the exchange
+            self.onehot = (self.scoring_code == 3 and self.scoring_bwd == 1 and g.ldt == 64
+                           and not os.environ.get("TCAR_SHARD_MATERIALISED") and not os.environ.get("TCAR_NO_ONEHOT")
+                           and not os.environ.get("TCAR_NO_ONEHOT_BWD"))
+            if self.onehot:
+                self.s_logits = None
+                need = Bq * ((self.nl + 63) // 64 + 8) * 2 + 4 * Bq + 8
+                self.s_ce_ws = torch.empty(need, **f32)
+                self.s_ce_geo = (C.c_int32 * 2)(0, 0)
+                if getattr(self, "s_oh16", None) is None:
+                    self.s_oh16 = torch.empty(self.nlpad * 160, dtype=torch.bfloat16, device=self.dev)
+                    check(self.lib.tcar_time_onehot(C.byref(self.dims_cand), self._p(self.mwdhm), self._p(self.s_oh16), 160,
+                                                    self._stream()), "tcar_time_onehot")
+                    self.s_tclip = torch.zeros(160 * g.ldt + 320, **f32)
+                    self.s_qz = torch.zeros(5 * self.nl * 2, **f32)
+                self.s_p16h, self.s_p16l = torch.zeros(Bp * 160, **bf), torch.zeros(Bp * 160, **bf)
+                self.s_dP = torch.zeros(Bq * 160, **f32)
+            else:
+                self.s_logits = torch.empty(Bq, self.nlpad, **f32)
+            self._sctx_src = None            # the shard context carries these pointers
             self.s_stats = torch.empty(Bq, 3, **f32)
             self.s_lse, self.s_ce = torch.empty(Bq, **f32), torch.empty(Bq, **f32)
             self.s_a16h, self.s_a16l = torch.zeros(Bp, g.ek, **bf), torch.zeros(Bp, g.ek, **bf)
@@ -310,7 +330,8 @@ class ShardedEngine(TcarEngine):
         ctx, sctx = self._ctx(), self._shard_ctx()
         sh = self._shard_desc(cap)
         ldh_ = self.ld_head
-        refresh = int(self._time_dirty)
+        # (the one-hot schedule reads the shard's time planes nowhere; eval_step rebuilds the fp32 time columns itself)
+        refresh = 0 if self.onehot else int(self._time_dirty)
         nr = cap * T
         ldr = g.ldh + 4
         if getattr(self, "_rows_cap", 0) < nr:
@@ -385,11 +406,13 @@ class ShardedEngine(TcarEngine):
         self.xch.step(Pieces(), cap, update)
 
     def _shard_desc(self, cap: int) -> "_lib.Shard":
-        key = (cap, self.s_logits.data_ptr())
+        key = (cap, self.s_dl16h.data_ptr())
         if getattr(self, "_sh_key", None) != key:
             sh = _lib.Shard()
             sh.world, sh.cap, sh.n0, sh.n_loc = self.world, cap, self.n0, self.nl
-            for n, t in (("logits", self.s_logits), ("stats", self.s_stats), ("lse", self.s_lse), ("ce", self.s_ce),
+            if self.s_logits is not None:
+                sh.logits = self.s_logits.data_ptr()
+            for n, t in (("stats", self.s_stats), ("lse", self.s_lse), ("ce", self.s_ce),
                          ("a16h", self.s_a16h), ("a16l", self.s_a16l), ("ap16h", self.s_ap16h), ("ap16l", self.s_ap16l),
                          ("dl16h", self.s_dl16h), ("dl16l", self.s_dl16l), ("slabs", self.s_slabs), ("dx", self.s_dx),
                          ("lab_all", self.s_lab), ("neg_all", self.s_neg), ("coef_all", self.s_coef)):
@@ -405,6 +428,13 @@ class ShardedEngine(TcarEngine):
             C.memmove(C.byref(s), C.byref(c), C.sizeof(_lib.Ctx))
             s.d = self.dims_cand
             s.E = self.E.data_ptr() + 4 * self.n0 * self.geo.ek
+            if getattr(self, "onehot", False):
+                s.ce_ws, s.ce_ws_floats = self.s_ce_ws.data_ptr(), self.s_ce_ws.numel()
+                s.ce_geo = C.cast(self.s_ce_geo, C.c_void_p)
+                s.oh16, s.p16h, s.p16l = self.s_oh16.data_ptr(), self.s_p16h.data_ptr(), self.s_p16l.data_ptr()
+                s.tclip, s.dP, s.qz = self.s_tclip.data_ptr(), self.s_dP.data_ptr(), self.s_qz.data_ptr()
+            else:
+                s.oh16 = s.tclip = s.dP = s.qz = None
             self._sctx, self._sctx_src = s, c
         return self._sctx
 

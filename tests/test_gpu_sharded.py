@@ -30,39 +30,45 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("K", [7, 0])
-def test_single_rank_sharded_path_matches_oracle(K):
+@pytest.mark.parametrize("K,scoring", [(7, "bf16x3"), (0, "bf16x3"), (7, "bf16x3-mixed"), (0, "bf16x3-mixed")])
+def test_single_rank_sharded_path_matches_oracle(K, scoring):
+    """bf16x3: materialised logits of the shard; bf16x3-mixed (the benchmarked precision): the shard runs the single-GPU schedule —
+    softmax epilogue with a label window, one-hot time segment, (q, z) form of dE, dP form of dX — between the same exchanges"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import tcar_amd  # noqa: F401
     from oracle.tcar_oracle import TcarOracle
     from tcar_amd.sharded import ShardedEngine
-    from test_gpu_parity import _case, close
+    from test_gpu_parity import _case, check_grads, close
     N, H, Ht, B, T = 1000, 250, 64, 33, 5
     params, content, mw, batch = _case(N, H, Ht, B, T, max(K, 1), seed=321)
     if K == 0:
         batch = {k: v for k, v in batch.items() if k != "neg"}
-    eng = ShardedEngine(params, content, mw, max_grad=2.0, scoring="bf16x3", world=1, rank=0)
+    mixed = scoring == "bf16x3-mixed"
+    eng = ShardedEngine(params, content, mw, max_grad=2.0, scoring=scoring, world=1, rank=0)
     ora = TcarOracle(params, content, mw, max_grad=2.0)
     loss = eng.loss_and_grads(batch, cap=B + 3)                      # padded session capacity, as an uneven shard has
+    assert eng.onehot == mixed and (eng.s_logits is None) == mixed   # the one-hot schedule keeps no fp32 logits
     o, g_o, sq_o = ora.loss_and_grads(batch)
     close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss")
-    g_e, sq_e = eng.export_grads(), eng.export_sqnorms()
-    for k in g_o:
-        close(g_e[k], g_o[k].numpy(), name="grad " + k, atol_scale=5e-5)
-        assert abs(sq_e[k] - sq_o[k]) <= 2e-3 * sq_o[k] + 1e-12, ("sqnorm", k, sq_e[k], sq_o[k])
-    for _ in range(2):
-        close(eng.train_step(batch).cpu().numpy(), ora.train_step(batch).numpy(), name="train loss")
+    check_grads(eng.export_grads(), eng.export_sqnorms(), {k: v.numpy() for k, v in g_o.items()}, sq_o, scoring)
+    for i in range(2):
+        close(eng.train_step(batch).cpu().numpy(), ora.train_step(batch).numpy(), name="train loss", rtol=1e-2 if (mixed and i) else 1e-3)
     p_e, p_o = eng.export_params(), ora.export()
     for k in p_o:      # two Adam steps at lr 1e-3: a rounding-level gradient coordinate may move by up to ~2e-3 * |w| scale
-        close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-3)
+        if mixed:      # (bound of test_gpu_parity.test_step_matches_oracle: bf16 noise may flip a coordinate's direction)
+            d = np.abs(p_e[k] - p_o[k]).max()
+            assert d <= 1e-3 * np.abs(p_o[k]).max() + 2.0 * 1e-3 * 2, ("param " + k, d)
+        else:
+            close(p_e[k], p_o[k], name="param " + k, atol_scale=1e-3)
     rank, topk, ce, logits = eng.eval_step(batch, keep_logits=True)
     lo, ce_o = ora.eval_batch(batch)
-    close(logits.cpu().numpy(), lo.numpy(), name="eval logits", atol_scale=1e-4)
-    close(ce.cpu().numpy(), ce_o.numpy(), name="eval ce")
+    # (after two Adam steps: in mixed mode the variables carry the bf16 noise of the scoring gradients, bounded above)
+    close(logits.cpu().numpy(), lo.numpy(), name="eval logits", atol_scale=2e-3 if mixed else 1e-4, rtol=1e-2 if mixed else 1e-3)
+    close(ce.cpu().numpy(), ce_o.numpy(), name="eval ce", rtol=1e-2 if mixed else 1e-3)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, scoring="bf16x3"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -75,7 +81,7 @@ def _worker(rank, world, port, ret):
         N, H, Ht, B, T, K = 1000, 250, 64, 37, 4, 6          # 37 sessions: uneven shards (19 + 18)
         params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=5)
         _, _, _, tiny = _case(N, H, Ht, 1, 2, K, seed=6)      # a batch of ONE session: rank 1's shard is empty
-        eng = ShardedEngine(params, content, mw, max_grad=2.0, group=dist.group.WORLD, scoring="bf16x3")
+        eng = ShardedEngine(params, content, mw, max_grad=2.0, group=dist.group.WORLD, scoring=scoring)
         assert eng.S == 512 and eng.nl == (512 if rank == 0 else 488)
         for step in range(4):
             full = tiny if step == 2 else batch
@@ -86,7 +92,7 @@ def _worker(rank, world, port, ret):
         torch.cuda.synchronize()
         got = eng.export_params()
         if rank == 0:
-            ref = TcarEngine(params, content, mw, max_grad=2.0, scoring="bf16x3")
+            ref = TcarEngine(params, content, mw, max_grad=2.0, scoring=scoring)
             for step in range(4):
                 ref.train_step(tiny if step == 2 else batch)
             want = ref.export_params()
@@ -109,7 +115,7 @@ def _worker(rank, world, port, ret):
             want_st = ref.export_state()
             for k in ("m/item_emb", "v/item_emb", "m/attout_item_cont_trans/w1"):
                 assert np.abs(st[k] - want_st[k]).max() <= 2e-3 * np.abs(want_st[k]).max() + 1e-12, k
-        eng2 = ShardedEngine(params, content, mw, max_grad=2.0, group=dist.group.WORLD, scoring="bf16x3")
+        eng2 = ShardedEngine(params, content, mw, max_grad=2.0, group=dist.group.WORLD, scoring=scoring)
         eng2.load_state(st)
         assert eng2.step == eng.step and torch.equal(eng2.Mi, eng.Mi) and torch.equal(eng2.Vi, eng.Vi) and torch.equal(eng2.M, eng.M)
         lo, hi, cap = shard_bounds(B, world, rank)
@@ -127,14 +133,15 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_two_ranks_sharded_match_single_engine():
+@pytest.mark.parametrize("scoring", ["bf16x3", "bf16x3-mixed"])
+def test_two_ranks_sharded_match_single_engine(scoring):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, scoring), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", ret.get(r)
 
