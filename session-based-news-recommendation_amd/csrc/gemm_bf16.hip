@@ -151,6 +151,20 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   const int nkb = (ke - ks) / KB;
   const int nit = (nkb + KS - 1) / KS;
 
+  // (EPI = 2, time-block waves) the epilogue's two dependent index loads — the table row each of this lane's catalog rows looks up and
+  // its position in the inverted index — are issued HERE, ahead of the K loop, so that only the clipped-row loads follow the loop
+  int qz_row[TNW], qz_pos[TNW];
+  if constexpr (EPI == 2) {
+#pragma unroll
+    for (int t2 = 0; t2 < TNW; ++t2) {
+      qz_row[t2] = 0; qz_pos[t2] = -1;
+      if (tw) {
+        const int k = (n0 + wn * (32 * TNW) - g.csplit) >> 6;
+        const long n = m0 + wm * (32 * TMW) + t2 * 32 + (lane & 31);
+        if (n < g.M) { qz_row[t2] = cand_row(g.mwdhm, n, k); qz_pos[t2] = g.perm[(long)k * g.M + n]; }
+      }
+    }
+  }
   f32x16 acc[TMW][TNW];
 #pragma unroll
   for (int a = 0; a < TMW; ++a)
@@ -316,12 +330,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
       // (q, z) epilogue of a time-block wave.  acc[u][t2][e]: lane li owns catalog row n of row block t2, its registers run over the
       // table's columns c = 32 u + 4 lh + (e & 3) + 8 (e >> 2).  The Jacobian of max_norm = 1 needs, per (n, k), only
       // q = ||gy||^2 and z = x . gy against the clipped table row x the candidate looked up (embed.hip: cand_time_bwd_onehot).
-      const int k = (n0 + wn * (32 * TNW) - g.csplit) >> 6;
 #pragma unroll
       for (int t2 = 0; t2 < TNW; ++t2) {
-        const long n = m0 + wm * (32 * TMW) + t2 * 32 + li;
-        const bool live = n < g.M;
-        const float* xr = g.tclip + (long)(live ? cand_row(g.mwdhm, n, k) : 0) * 64 + 4 * lh;
+        const bool live = qz_pos[t2] >= 0;
+        const float* xr = g.tclip + (long)qz_row[t2] * 64 + 4 * lh;
         float q = 0.f, z = 0.f;
 #pragma unroll
         for (int u = 0; u < TMW; ++u)
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
           }
         q += __shfl_xor(q, 32);
         z += __shfl_xor(z, 32);
-        if (live && lh == 0) g.qz[g.perm[(long)k * g.M + n]] = make_float2(q, z);
+        if (live && lh == 0) g.qz[qz_pos[t2]] = make_float2(q, z);
       }
       return;
     }
