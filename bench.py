@@ -376,6 +376,15 @@ def main():
         eng.flush()                              # K steps contain exactly K updates
 
     def timed(sampler_in_loop):
+        import gc
+        gc.collect()
+        gc.disable()                             # no collector pause inside a loop of a few milliseconds
+        try:
+            return timed_body(sampler_in_loop)
+        finally:
+            gc.enable()
+
+    def timed_body(sampler_in_loop):
         run(args.warmup, 0, sampler_in_loop)     # the last warm-up step's update belongs to the warm-up
         if sampler_in_loop:
             ds.plan(sched(args.warmup, args.steps))        # the timed schedule's indices: resident before the clock starts

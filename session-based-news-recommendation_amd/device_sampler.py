@@ -168,6 +168,31 @@ class DeviceSampler:
         self.plan_dev = torch.tensor(flat, device=self.dev)
         self.plan_B = lens
         self.plan_T = [int(self.in_len[int(b[0])]) for b in batches]
+        # the feed buffers of planned() are sized HERE, with the schedule (outside a caller's timed loop): a longer length bucket
+        # first met inside the loop must not re-allocate there (a 20-step bench loop whose 5 warm-up steps saw only T <= 2 paid
+        # ~0.7 ms for it: profiles/r04_ab_experiments.txt)
+        if lens:
+            self._ensure_feeds(getattr(self, "_k_hint", 32))
+
+    def _feed_need(self, K: int) -> int:
+        need = max(7 * b * t + 3 * b + b * K for b, t in zip(self.plan_B, self.plan_T))
+        return (need + 63) // 64 * 64
+
+    def _ensure_feeds(self, K: int) -> int:
+        """two chunk buffers for the current plan at K negatives (grown, never shrunk); the side stream and its events are made once"""
+        need = self._feed_need(K)
+        ch = max(1, int(self.CHUNK))
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(self.dev)
+            self._ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
+        if getattr(self, "_feeds", None) is None or self._feeds[0].numel() < need * ch:
+            if getattr(self, "_feeds", None) is not None:
+                torch.cuda.current_stream(self.dev).synchronize()      # (steps still reading the old buffers)
+                self._side.synchronize()
+            self._feeds = [torch.empty(need * ch, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self._k_hint = K
+        return need
 
     # batches formed per hand-off between the side stream and the consumer's stream (planned()); TCAR_FEED_CHUNK overrides (A/B)
     CHUNK = int(os.environ.get("TCAR_FEED_CHUNK", "16"))
@@ -182,26 +207,24 @@ class DeviceSampler:
         n = len(self.plan_B)
         if n == 0:
             return
-        need = max(7 * b * t + 3 * b + b * K for b, t in zip(self.plan_B, self.plan_T))
-        need = (need + 63) // 64 * 64
+        need = self._ensure_feeds(K)
         ch = max(1, int(self.CHUNK))
-        if getattr(self, "_feeds", None) is None or self._feeds[0].numel() < need * ch:
-            self._feeds = [torch.empty(need * ch, dtype=torch.int32, device=self.dev) for _ in range(2)]
-            self._side = torch.cuda.Stream(self.dev)
-            self._ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
-            self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
         main = torch.cuda.current_stream(self.dev)
         side, used = self._side, [False, False]
         side.wait_stream(main)               # the plan's upload (and whatever wrote the stores) is on the main stream
-        nchunk = (n + ch - 1) // ch
+        # chunk boundaries: a SHORT first chunk (the consumer's first step waits for the whole first chunk: 16 batches are ~0.2 ms
+        # of form + sample launches, which a 20-step loop would pay in full), full chunks after it
+        lo = [0] + list(range(min(2, ch), n, ch))
+        hi = lo[1:] + [n]
+        nchunk = len(lo)
 
         def launch(j):
             slot = j & 1
             if used[slot]:
                 side.wait_event(self._ev_free[slot])      # the steps that read this chunk buffer have been enqueued in full
-            for i in range(j * ch, min(n, (j + 1) * ch)):
+            for i in range(lo[j], hi[j]):
                 self._launch(self.plan_dev.data_ptr() + 4 * int(self.plan_off[i]), self.plan_B[i], self.plan_T[i], K, gap_mode,
-                             self.counter, self._feeds[slot][(i - j * ch) * need:], side)
+                             self.counter, self._feeds[slot][(i - lo[j]) * need:], side)
                 self.counter += 1
             self._ev_ready[slot].record(side)
 
@@ -211,8 +234,8 @@ class DeviceSampler:
             if j + 1 < nchunk:
                 launch(j + 1)
             main.wait_event(self._ev_ready[slot])
-            for i in range(j * ch, min(n, (j + 1) * ch)):
-                yield self._describe(self._feeds[slot][(i - j * ch) * need:], self.plan_B[i], self.plan_T[i], K)
+            for i in range(lo[j], hi[j]):
+                yield self._describe(self._feeds[slot][(i - lo[j]) * need:], self.plan_B[i], self.plan_T[i], K)
             self._ev_free[slot].record(main)
             used[slot] = True
 

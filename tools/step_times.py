@@ -24,12 +24,17 @@ eng._ensure_work(B, max(b["seq"].shape[1] for b in batches))
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(46)]
 torch.cuda.synchronize()
 ev[0].record()
+import time
+host = []
 for i in range(45):
+    h0 = time.perf_counter()
     eng.train_step(None, bt=res[i % len(res)], defer_update=True)
+    host.append((time.perf_counter() - h0) * 1e3)
     ev[i + 1].record()
 eng.flush()
 torch.cuda.synchronize()
 ts = [ev[i].elapsed_time(ev[i + 1]) for i in range(45)]
+print("host ms per step:", " ".join("%.3f" % t for t in host))
 print("T of the batches:", [b["seq"].shape[1] for b in batches[:45]])
 print("ms per step:", " ".join("%.3f" % t for t in ts))
 print("mean steps 0-4 %.4f | 5-24 %.4f | 25-44 %.4f" % (np.mean(ts[:5]), np.mean(ts[5:25]), np.mean(ts[25:45])))
