@@ -62,8 +62,10 @@ typedef struct {
   int32_t inkernel_wait;    /* TCAR_INKERNEL_WAIT  1: kernels that can wait for a producer's flag themselves do (attention pools: click query;
                                                    slab reduce: negative term; candidate-side time gradients: dP) instead of sitting
                                                    behind a polling kernel / an event.  Default 0: measured 9 us SLOWER per step */
-  int32_t qbwd_fused;       /* TCAR_QBWD_FUSED     0: the click-query MLP's input gradients as two small GEMMs (dq1 in the main chain's grouped
-                                                   launch, dclick in front of the small tables) instead of ONE launch on the third stream */
+  int32_t qbwd_fused;       /* TCAR_QBWD_FUSED     the click-query MLP's input gradients: 0 = two small GEMMs (dq1 in the main chain's grouped
+                                                   launch, dclick in front of the small tables); 1 = ONE launch on the third stream
+                                                   (tcar_query_mlp_bwd; measured slower); 2 (default) = dq1 as in 0, dclick by the layer-1
+                                                   half of tcar_query_mlp_bwd on the aux stream */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
                                                    kernel of the side stream waits for */
@@ -145,7 +147,8 @@ int tcar_query_mlp(const tcar_dims_t* d, int B, const float* click_t, const floa
 
 /* The input-gradient half of the click-query MLP's backward pass in one launch (modules.py:138-139): dq1 [B, ldh] = (dq Wq2^T) *
  * relu'(q1) and dclick [B, 2 ldt] = dq1 Wq1^T, fp32 FMAs in a fixed order; dq [B, 2 ldh] arrives through tanh' already (the pool
- * backward applies it).  Same restriction as tcar_query_mlp (ldh == 256, ldt == 64). */
+ * backward applies it).  dq == NULL: dq1 is an INPUT and only dclick is computed (q1, q2_w unused) — the form the fused step
+ * runs on its aux stream in front of the small tables' pass.  Same restriction as tcar_query_mlp (ldh == 256, ldt == 64). */
 int tcar_query_mlp_bwd(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w, float* dq1,
                        float* dclick, void* stream);
 
@@ -755,6 +758,10 @@ typedef struct {
   uint32_t* sig_dev; void* fork_host /*host*/; uint32_t* sig_err_host;
   /* optional tuning copy of THIS context (NULL = the process-wide values, tcar_tuning_defaults) */
   const tcar_tuning_t* tune /*host*/;
+  /* optional: zeroed device words for order-fixed last-arrival folds (word 0 = arrival counter, back to zero when a launch ends;
+   * then one float per 32,768-float chunk of the dense weights: 36 for the reference's shapes).  With it the dense-weight norms of
+   * the fused step run several workgroups per variable (tcar_sqnorm: one) — same bits on every rank and every run either way. */
+  uint32_t* fold_scratch; int32_t fold_scratch_words;
 } tcar_ctx_t;
 
 /* Probe before setting tcar_ctx_t.sig_dev: does a polling kernel on `side_stream` run beside a kernel enqueued BEHIND it on
@@ -763,6 +770,8 @@ typedef struct {
 int tcar_flag_fork_selftest(uint32_t* sig_dev, void* main_stream, void* side_stream, int32_t* concurrent);
 /* bytes of tcar_ctx_t.fork_host */
 int64_t tcar_fork_state_bytes(void);
+/* sizeof(tcar_ctx_t) of this build: a binding that mirrors the struct checks its own size against it when it loads the library */
+int64_t tcar_ctx_bytes(void);
 /* diagnostic: one polling kernel on `stream` that gives up after ~10 us (it waits for an epoch nobody publishes): sig_dev[32] and
  * *err_host (may be NULL) each count one time-out — what a step whose streams do not overlap leaves behind */
 int tcar_flag_poll_expire(uint32_t* sig_dev, uint32_t* err_host /* device-accessible host word */, void* stream);

@@ -27,7 +27,7 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows", "tcar_eval_diversity",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
-           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_clip_adam_rest_keep", "tcar_abi_version", "tcar_build_id", "tcar_tuning_defaults", "tcar_tuning_set", "tcar_fork_state_bytes", "tcar_flag_poll_expire", "tcar_gather_clip_fwd_tuned", "tcar_gemm_bf16_tuned", "tcar_mha_core_fwd_tuned", "tcar_mha_core_bwd_tuned", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
+           "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_clip_adam_rest_keep", "tcar_abi_version", "tcar_build_id", "tcar_tuning_defaults", "tcar_tuning_set", "tcar_fork_state_bytes", "tcar_ctx_bytes", "tcar_flag_poll_expire", "tcar_gather_clip_fwd_tuned", "tcar_gemm_bf16_tuned", "tcar_mha_core_fwd_tuned", "tcar_mha_core_bwd_tuned", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
            "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_combine_rowstat", "tcar_softmax_grad", "tcar_neg_scatter_range",
            "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_attn_pool_fwd_slabs", "tcar_attn_pool_bwd_slabs", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step"]
@@ -198,7 +198,8 @@ class Ctx(C.Structure):
                    ("ce_ws", C.c_void_p), ("ce_ws_floats", C.c_int64), ("ce_geo", C.c_void_p),
                    ("oh16", C.c_void_p), ("p16h", C.c_void_p), ("p16l", C.c_void_p),
                    ("tclip", C.c_void_p), ("dP", C.c_void_p), ("qz", C.c_void_p),
-                   ("sig_dev", C.c_void_p), ("fork_host", C.c_void_p), ("sig_err_host", C.c_void_p), ("tune", C.c_void_p)])
+                   ("sig_dev", C.c_void_p), ("fork_host", C.c_void_p), ("sig_err_host", C.c_void_p), ("tune", C.c_void_p),
+                   ("fold_scratch", C.c_void_p), ("fold_scratch_words", C.c_int32)])
 
 
 TUNING_FIELDS = ["bf16_tile", "rest_grid", "softmax_variant", "wgrad_ks", "gather_big_rows", "gather_wg_per_cu", "mha_mfma",
@@ -346,6 +347,11 @@ def load() -> C.CDLL:
     lib.tcar_tuning_set.argtypes = [vp, C.c_char_p, i32]
     lib.tcar_fork_state_bytes.restype = C.c_int64
     lib.tcar_fork_state_bytes.argtypes = []
+    lib.tcar_ctx_bytes.restype = C.c_int64
+    lib.tcar_ctx_bytes.argtypes = []
+    if lib.tcar_ctx_bytes() != C.sizeof(Ctx):
+        raise RuntimeError("tcar_ctx_t is %d bytes in libtcar_hip.so and %d in the ctypes mirror (_lib.Ctx): the mirror is stale"
+                           % (lib.tcar_ctx_bytes(), C.sizeof(Ctx)))
     lib.tcar_flag_poll_expire.argtypes = [vp, vp, vp]
     lib.tcar_gather_clip_fwd_tuned.argtypes = [vp] + lib.tcar_gather_clip_fwd.argtypes
     lib.tcar_gemm_bf16_tuned.argtypes = [vp] + lib.tcar_gemm_bf16.argtypes

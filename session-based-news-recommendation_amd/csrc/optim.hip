@@ -62,15 +62,15 @@ __global__ __launch_bounds__(1024) void sqnorm_seg_kernel(const float* __restric
   const long off = a.s.off[seg];
   const long len = a.s.len[seg];
   float s = 0.f;
-  for (long base = 0; base < len; base += 1024 * 4 * 4) {
-    float4 v[4];                      // 4 loads in flight per thread
+  for (long base = 0; base < len; base += 1024 * 4 * 8) {
+    float4 v[8];                      // 8 loads in flight per thread: the largest weight (1 MB) is 8 dependent trips, not 16
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 8; ++i) {
       const long e = base + (i * 1024 + threadIdx.x) * 4;
       v[i] = (e < len) ? ld4(g + off + e) : zero4();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s += dot4(v[i], v[i]);
+    for (int i = 0; i < 8; ++i) s += dot4(v[i], v[i]);
   }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
@@ -81,6 +81,60 @@ __global__ __launch_bounds__(1024) void sqnorm_seg_kernel(const float* __restric
     atomicAdd(out + a.s.slot[seg], t);                  // one add per segment
   }
   tcar_signal_done(sig);        // (the fused step joins the third stream into the main one behind this launch)
+}
+
+// The same norms with SEVERAL workgroups per segment (round 4): one workgroup reads its 1-MB weight at one CU's load rate
+// (12.5 us in the step, the last launch of the third stream's chain).  Here every 32,768-float chunk is a workgroup (35 for the
+// reference's shapes): one trip of 8 loads per thread, chunk partial to scratch; the LAST workgroup to arrive folds each segment's
+// partials in CHUNK order — fixed order, bit-for-bit repeatable, identical on ranks with identical gradients — and adds once per
+// segment.  scratch: [0] arrival counter (zero between launches), [1 ..] chunk partials.
+constexpr int SQ_CHUNK = 32768;
+struct Seg2Args {
+  tcar_segments_t s;
+  int first[TCAR_NSLOT + 1];          // first chunk of every segment (prefix sums)
+};
+__global__ __launch_bounds__(1024) void sqnorm_seg2_kernel(const float* __restrict__ g, const Seg2Args a, float* __restrict__ out,
+                                                           unsigned* __restrict__ scratch, const TcarSignal sig) {
+  __shared__ float sh[16];
+  __shared__ int last;
+  const int nchunks = gridDim.x;
+  int seg = 0;
+  while (seg + 1 < a.s.nseg && (int)blockIdx.x >= a.first[seg + 1]) ++seg;
+  const long c0 = (long)((int)blockIdx.x - a.first[seg]) * SQ_CHUNK;
+  const long len = a.s.len[seg] - c0 < SQ_CHUNK ? a.s.len[seg] - c0 : (long)SQ_CHUNK;
+  const float* p = g + a.s.off[seg] + c0;
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long e = (long)(i * 1024 + (int)threadIdx.x) * 4;
+    v[i] = (e < len) ? ld4(p + e) : zero4();
+  }
+  float sm = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) sm += dot4(v[i], v[i]);
+  sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sm;
+  __syncthreads();
+  float* part = reinterpret_cast<float*>(scratch + 1);
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    __hip_atomic_store(part + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release the partial, acquire everybody else's when this is the last arrival
+    const unsigned old = __hip_atomic_fetch_add(scratch, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = (old == (unsigned)nchunks - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (last && threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    if (l < a.s.nseg) {
+      float t = 0.f;
+      for (int c = a.first[l]; c < a.first[l + 1]; ++c) t += __hip_atomic_load(part + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicAdd(out + a.s.slot[l], t);                 // one add per segment
+    }
+    if (l == 0) __hip_atomic_store(scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // reusable by the next launch
+  }
+  tcar_signal_done(sig);
 }
 
 // ---- split-K slabs folded in split order: dst[e] += sum_k slabs[k * stride + e] ---------------------------------------
@@ -338,6 +392,19 @@ int tcar_sqnorm_o(const float* g, const tcar_segments_t* segs, float* sqn_dense,
   a.s = *segs;
   long longest = 0;
   for (int i = 0; i < segs->nseg; ++i) longest = segs->len[i] > longest ? segs->len[i] : longest;
+  if (o && o->scratch && o->scratch_words > 1 && segs->nseg <= 64) {
+    // several workgroups per segment + an order-fixed fold by the last arrival (needs zeroed scratch words of the context)
+    Seg2Args b;
+    b.s = *segs;
+    int n = 0;
+    for (int i = 0; i < segs->nseg; ++i) { b.first[i] = n; n += (int)((segs->len[i] + SQ_CHUNK - 1) / SQ_CHUNK); }
+    b.first[segs->nseg] = n;
+    if (n > 0 && n + 1 <= o->scratch_words) {
+      TCAR_LAUNCH(sqnorm_seg2_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream, g, b, sqn_dense, o->scratch, tcar_sig(o));
+      TCAR_CHECK_LAUNCH();
+      return TCAR_OK;
+    }
+  }
   if (longest <= 262144)
     TCAR_LAUNCH(sqnorm_seg_kernel, dim3(segs->nseg), dim3(1024), 0, (hipStream_t)stream, g, a, sqn_dense, tcar_sig(o));
   else

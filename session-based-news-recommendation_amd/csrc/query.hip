@@ -153,7 +153,8 @@ __global__ __launch_bounds__(512) void query_mlp_bwd_kernel(const QBwdArgs a) {
   const int b0 = blockIdx.x * QS;
   const bool wt = a.sig.cnt != nullptr;
   // ---- layer 2 backward: wave w owns rows j = 32 w .. 32 w + 31 of Wq2 [256, 512]; lane holds columns 4 lane .. and 256 + 4 lane ..
-  {
+  // (a.dq == NULL: dq1 is an INPUT — written by the main chain's grouped GEMM — and only the layer-1 half below runs)
+  if (a.dq) {
     float4 g0[QS], g1[QS];
 #pragma unroll
     for (int s = 0; s < QS; ++s) {
@@ -194,7 +195,9 @@ __global__ __launch_bounds__(512) void query_mlp_bwd_kernel(const QBwdArgs a) {
   {
     float4 g[QS];
 #pragma unroll
-    for (int s = 0; s < QS; ++s) g[s] = *reinterpret_cast<const float4*>(dq1s + s * H1 + lane * 4);
+    for (int s = 0; s < QS; ++s)
+      g[s] = a.dq ? *reinterpret_cast<const float4*>(dq1s + s * H1 + lane * 4)
+                  : (b0 + s < a.B ? ld4(a.dq1 + (long)(b0 + s) * H1 + lane * 4) : zero4());
     float4 w[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) w[r] = ld4(a.w1 + (long)(wave * 16 + r) * H1 + lane * 4);
@@ -225,8 +228,8 @@ extern "C" int tcar_query_mlp_bwd(const tcar_dims_t* d, int B, const float* dq, 
 int tcar_query_mlp_bwd_o(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w, float* dq1,
                          float* dclick, void* stream, TcarOpt* o) {
   if (!d || d->ldh != H1 || d->ldt * 2 != CT || B <= 0) return TCAR_E_ARG;
-  if (!dq || !q1 || !q1_w || !q2_w || !dq1 || !dclick || !tcar_aligned16(dq) || !tcar_aligned16(q1_w) || !tcar_aligned16(q2_w))
-    return TCAR_E_ARG;
+  if (!q1_w || !dq1 || !dclick || !tcar_aligned16(q1_w) || !tcar_aligned16(dq1)) return TCAR_E_ARG;
+  if (dq && (!q1 || !q2_w || !tcar_aligned16(dq) || !tcar_aligned16(q2_w))) return TCAR_E_ARG;
   QBwdArgs a{};
   a.dq = dq; a.q1 = q1; a.w1 = q1_w; a.w2 = q2_w; a.dq1 = dq1; a.dclick = dclick; a.B = B;
   a.sig = tcar_sig(o);

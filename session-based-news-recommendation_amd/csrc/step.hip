@@ -21,7 +21,7 @@ const Switch kSwitches[] = {
     {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 1},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
     {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
-    {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 0},
+    {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -266,6 +266,7 @@ extern "C" int tcar_flag_fork_selftest(uint32_t* sig_dev, void* main_stream, voi
 }
 
 extern "C" int64_t tcar_fork_state_bytes(void) { return (int64_t)sizeof(ForkHost); }
+extern "C" int64_t tcar_ctx_bytes(void) { return (int64_t)sizeof(tcar_ctx_t); }
 
 // Diagnostic: ONE polling kernel on `stream` that waits ~10 us for an epoch of slot 15 nobody will publish, i.e. a poll that
 // gives up — exactly what a step leaves behind when its streams do not overlap: sig_dev[32] += 1 and, with err_host, the
@@ -845,7 +846,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // Click-query MLP backward (dq -> dq1 -> dclick) as ONE launch on the third stream (query.hip), behind the pool backward's flag:
   // its outputs feed only the side streams (dq1: weight gradients + column sums; dclick: the small tables' pass), so the main
   // chain's grouped launch keeps the three input-gradient GEMMs only (K = 256: 4 stages instead of the 8 of the dq1 product)
-  const bool qb = detc && tn(c).qbwd_fused && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
+  const bool qb = detc && tn(c).qbwd_fused == 1 && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
                   tn(c).det_small != 0;
   if (detc) {
     TcarOpt opb = opt_of(c);
@@ -933,6 +934,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (fuse_finish && s2) {
     TcarOpt o3 = opt_of(c);
     if (tail_flags) o3.sig = fork_arm(c, FK_TAIL3);
+    if (c->fold_scratch) { o3.scratch = c->fold_scratch; o3.scratch_words = c->fold_scratch_words; }
     RET(tcar_sqnorm_o(c->Gx, &c->segs_dense, c->sqn_dense, sW, &o3));
     if (tail_flags) tail3 = fork_commit(c, FK_TAIL3, o3);
   }
@@ -970,8 +972,14 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       RET(fork_go2(c, FK_QBWD, (hipStream_t)c->stream3, c->ev[5], FK_INGRAD, st, c->ev[0], s2));
     } else if (dclick_aux) {
       RET(fork_go(c, FK_INGRAD, st, s2, c->ev[5]));       // (the same flag the third stream polled: dq1, dx_* of that launch)
-      tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
-      RET(small_gemm(c, 1, 1, &p, (void*)s2));
+      if (tn(c).qbwd_fused == 2 && g.ldh == 256 && g.ldt == 64) {
+        // dclick = dq1 Wq1^T as ONE fp32 launch of whole-row dots (query.hip: the layer-1 half of the click-query backward): 7 us
+        // where the 16-workgroup small GEMM walks four serial 64-deep stages (20 us), on the chain that ends the step
+        RET(tcar_query_mlp_bwd_o(&c->d, B, nullptr, nullptr, W(c, TCAR_V_Q1_W), nullptr, c->dq1, c->dclick, (void*)s2, nullptr));
+      } else {
+        tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
+        RET(small_gemm(c, 1, 1, &p, (void*)s2));
+      }
     } else {
       RET(fork_go(c, FK_DCLICK, st, s2, c->ev[5]));
     }

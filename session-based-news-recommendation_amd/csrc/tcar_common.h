@@ -101,6 +101,10 @@ struct TcarOpt {
   // label window of the softmax-epilogue logits GEMM (catalog-sharded step): the column of row m's label is label[m] - lab_off,
   // and a label outside [0, N) is in another shard — no label score is written for it (lab_window = 0: labels are clamped)
   int lab_off = 0, lab_window = 0;
+  // zeroed device words a launch may use for an order-fixed last-arrival fold (tcar_sqnorm_o: word 0 = arrival counter, kept zero
+  // between launches; then one float per 32,768-float chunk): tcar_ctx_t.fold_scratch
+  unsigned* scratch = nullptr;
+  int scratch_words = 0;
   const TcarTuning& tn() const { return tune ? *tune : tcar_tuning(); }
 };
 inline const TcarTuning& tcar_tn(const TcarOpt* o) { return o ? o->tn() : tcar_tuning(); }

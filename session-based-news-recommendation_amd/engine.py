@@ -782,10 +782,11 @@ class TcarEngine:
         c.scoring_bwd = self.scoring_bwd
         if self.scoring_code and not os.environ.get("TCAR_ATOMIC_COLSUMS"):
             c.gw_rows = self.gw_rows.data_ptr()
-        if self.work_rows > 1536 and not os.environ.get("TCAR_ATOMIC_WGRAD"):
-            # batches of more than 1,536 rows split the K of the weight gradients: slabs folded in split order (order-fixed)
+        wks = max(1, int((self.tune if self.tune is not None else _lib.tuning()).wgrad_ks))
+        if self.work_rows > wks and not os.environ.get("TCAR_ATOMIC_WGRAD"):
+            # batches of more than TCAR_WGRAD_KS (1,536) rows split the K of the weight gradients: slabs folded in split order (order-fixed)
             per = g.ic * g.ic + g.pt * g.pt + g.ldh * g.ic + g.ct * g.ldh + g.ic * g.ldh + 2 * g.ldh * g.ldh + g.ldt * g.ldh + g.pt * g.ldh
-            need = min(16, (self.work_rows + 1535) // 1536) * per
+            need = min(16, (self.work_rows + wks - 1) // wks) * per
             if getattr(self, "_wgrad_slabs", None) is None or self._wgrad_slabs.numel() < need:
                 self._wgrad_slabs = torch.empty(need, dtype=torch.float32, device=self.dev)
             c.wgrad_slabs, c.wgrad_slab_floats = self._wgrad_slabs.data_ptr(), self._wgrad_slabs.numel()
@@ -870,6 +871,11 @@ class TcarEngine:
                     c.sig_err_host = self._sig_err.data_ptr()
         if self.tune is not None:
             c.tune = C.cast(C.pointer(self.tune), C.c_void_p)
+        if not os.environ.get("TCAR_NO_FOLD_SCRATCH"):
+            # zeroed words of the order-fixed last-arrival fold (dense-weight norms of the fused step: several workgroups per variable)
+            if getattr(self, "_fold_scratch", None) is None:
+                self._fold_scratch = torch.zeros(128, dtype=torch.int32, device=self.dev)
+            c.fold_scratch, c.fold_scratch_words = self._fold_scratch.data_ptr(), self._fold_scratch.numel()
         if self._ev is not None:
             c.ev_start = C.cast(self._ev["start_arr"], C.c_void_p)
             c.ev_stop = C.cast(self._ev["stop_arr"], C.c_void_p)
