@@ -355,7 +355,7 @@ int tcar_reduce_dact_onehot(const float* slabs, int splitk, int M, int ic, int64
                             float* bias_grad1, void* stream);
 int tcar_gemm_bf16_de_qz(int M, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi, int64_t b_inner,
                          int64_t b_rows, int ldh, float* C, int64_t ldc, const int32_t* mwdhm, const int32_t* perm, const float* tclip,
-                         float* qz, int tile /* 0: 192 x 192 workgroup tile (9 waves), 256: 256 x 192 (12 waves) */, void* stream);
+                         float* qz, int tile /* 0: 192 x 192 workgroup tile (9 waves), 256: 256 x 192 (12), 128: 128 x 192 (6), 64: 64 x 192 (3) */, void* stream);
 int tcar_cand_time_bwd_onehot(const tcar_dims_t* d, int B, const int32_t* inv_off, const float* qz, const float* dP,
                               const float* attout, int64_t ld_att, const float* tclip, float* ws, const tcar_grads_t* g, void* stream);
 /* Names the kernel instantiation (template arguments, workgroup tile, grid) that tcar_gemm_bf16 would launch for this

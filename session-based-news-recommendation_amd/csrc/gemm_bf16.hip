@@ -710,7 +710,8 @@ extern "C" int tcar_gemm_bf16_dx_onehot(int M, int N1, int K, const void* A_hi, 
 // dE' = dlogits^T [attout_item | attout_time] with the (q, z) epilogue: the item block [M, ldh] goes to C as in tcar_gemm_bf16
 // (layout 2); the time block [M, 5 * 64] is NOT stored — per catalog row n and table k: qz[perm[k M + n]] = (||gy||^2, x . gy) with
 // gy = the 64-column gradient block and x = tclip row the candidate looks up.  A plane = dlogits [K rows = sessions, inner >= M],
-// B plane = packed attout [K rows, inner >= ldh + 320]; ldt must be 64.  tile: 0 = 192 x 192 (9 waves), 256 = 256 x 192 (12).
+// B plane = packed attout [K rows, inner >= ldh + 320]; ldt must be 64.  tile: 0 = 192 x 192 (9 waves), 256 = 256 x 192 (12),
+// 128 = 128 x 192 (6), 64 = 64 x 192 (3).
 int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi, int64_t b_inner,
                            int64_t b_rows, int ldh, float* C, int64_t ldc, const int32_t* mwdhm, const int32_t* perm,
                            const float* tclip, float* qz, int tile, void* stream, TcarOpt* o) {
@@ -736,6 +737,14 @@ int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int6
     g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
     TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 4, 3, 2, 2, 1, 2, 0>), lds);
     TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 4, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 12), lds, st, g);
+  } else if (tile == 64) {
+    // (short catalog shards with many sessions — the sharded step at 8 ranks: 5,760 rows x 4,096 sessions — want MORE workgroups
+    //  than 128-row tiles give: 3 waves, 32 KB of LDS, several per CU)
+    constexpr int TM = 64, TN = 192;
+    constexpr size_t lds = 2 * (TM + TN) * 64;
+    g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
+    TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 1, 3, 2, 2, 1, 2, 0>), lds);
+    TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 1, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 3), lds, st, g);
   } else if (tile == 128) {
     constexpr int TM = 128, TN = 192;
     constexpr size_t lds = 2 * (TM + TN) * 64;

@@ -1497,7 +1497,7 @@ def _bf(x):
     return torch.tensor(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
 
 
-@pytest.mark.parametrize("N,B,tile", [(3000, 100, 0), (46033, 512, 0), (46033, 512, 256), (46033, 512, 128), (700, 33, 0)])
+@pytest.mark.parametrize("N,B,tile", [(3000, 100, 0), (46033, 512, 0), (46033, 512, 256), (46033, 512, 128), (5754, 600, 64), (700, 33, 0)])
 def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
     """The one-hot form of the two scoring GRADIENT GEMMs (round 4) at op level, through the C-ABI, against fp64 numpy on the
     bf16-rounded operands AND against the materialised form it replaces:
