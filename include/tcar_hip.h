@@ -66,6 +66,9 @@ typedef struct {
                                                    launch, dclick in front of the small tables); 1 = ONE launch on the third stream
                                                    (tcar_query_mlp_bwd; measured slower); 2 (default) = dq1 as in 0, dclick by the layer-1
                                                    half of tcar_query_mlp_bwd on the aux stream */
+  int32_t attout_split;     /* TCAR_ATTOUT_SPLIT   0: the two output transforms as one un-split grouped GEMM with bias + tanh + plane epilogue and a
+                                                   separate time-score launch, instead of split-K slabs finished (+ scored) by
+                                                   tcar_attout_finish_scores */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
                                                    kernel of the side stream waits for */
@@ -313,6 +316,15 @@ int tcar_time_onehot(const tcar_dims_t* d, const int32_t* mwdhm, void* oh_hi, in
  * sum_k attout_tk[b] . candidate_publish_t_k[n] = (P OH^T)[b, n] */
 int tcar_time_scores(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* attout, int64_t ld_att, void* p_hi,
                      void* p_lo, int64_t inner, void* stream);
+/* Output transforms of the session side finished in one launch: attout [B, 2 ldh + 5 ldt] = tanh(sum of split-K slabs + bias)
+ * (model_combine.py:119,127,132) from the slabs tcar_gemm_x3_grouped leaves with splitk = nd_ic / nd_pt (slab k of the item|content
+ * problem at slabs + k stride, of the time problem at slabs + 2 ldh + k stride; row stride 2 ldh + 5 ldt), folded in slab order;
+ * optional hi / lo planes of attout (a_*), packed [item | time] planes (ap_*: the dE operand), time scores P (p_*) and clipped
+ * table rows (tclip) as tcar_time_scores_clip computes them.  ldt == 64, ldh % 64 == 0. */
+int tcar_attout_finish_scores(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* slabs, int nd_ic, int nd_pt,
+                              int64_t stride, const float* bias_o, const float* bias_ot, float* attout, int64_t ld_out, void* a_hi,
+                              void* a_lo, int64_t a_inner, void* ap_hi, void* ap_lo, int64_t ap_inner, void* p_hi, void* p_lo,
+                              int64_t p_inner, float* tclip, void* stream);
 /* ..._clip: additionally writes the clipped table rows the scores were taken against — tclip [160 ldt + 320] floats: row r of the
  * month | day | week | hour | minute tables after max_norm = 1 (rows 139..159 untouched), then scale[160] = 1 / max(||row||, 1) and
  * clipped[160] = 1.0 where ||row|| > 1 — for the one-hot form of the scoring GRADIENTS (tcar_gemm_bf16_de_qz, tcar_reduce_dact_onehot,

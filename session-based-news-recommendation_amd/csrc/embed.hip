@@ -627,6 +627,114 @@ __global__ __launch_bounds__(256) void time_scores_kernel(const ScoreArgs a) {
   }
 }
 
+// ---- output transforms finished + time scores in ONE launch (round 4) ------------------------------------------------------------
+// attout = tanh(pooled W + b) (model_combine.py:119,127,132) used to be one grouped small GEMM of 104 workgroups walking 8 / 5
+// serial 64-deep stages (41 us beside the deferred Adam rest pass, 23 alone) followed by the time-score launch.  Now the GEMM runs
+// as ONE 128-deep K chunk per workgroup into split-K slabs (376 workgroups, the form of the projections and of the backward's
+// dpooled) and THIS kernel folds the slabs in slab order, adds the bias, applies tanh, writes attout, its hi / lo planes and the
+// packed item | time planes (operand of dE), and — in the workgroups that own a time table's 64 columns — goes straight on to the
+// scores of tcar_time_scores_clip with the rows still in LDS.  grid = (16-session blocks, 5 tables + ic / 64 column blocks).
+struct FinishArgs {
+  ScoreArgs s;                    // tab, B, ph / pl (may be NULL: no scores), in32, tclip; attout = output here
+  const float* slabs; int nd_ic, nd_pt; long stride;      // slab k of the item|content problem at slabs + k * stride (columns [0, ic)),
+                                                          // of the time problem at slabs + ic + k * stride (columns [ic, ek)); row stride ek
+  const float* b_o; const float* b_ot;
+  float* out; long ld_out;
+  __bf16* a_hi; __bf16* a_lo; int a_in32;                 // planes of attout (may be NULL)
+  __bf16* ap_hi; __bf16* ap_lo; int ap_in32;              // packed [item | time] planes (may be NULL)
+};
+__device__ __forceinline__ void store_planes4(__bf16* hi, __bf16* lo, long o, float4 y) {
+  typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_f;
+  const bf16x4_f h = {(__bf16)y.x, (__bf16)y.y, (__bf16)y.z, (__bf16)y.w};
+  const bf16x4_f l = {(__bf16)(y.x - (float)h[0]), (__bf16)(y.y - (float)h[1]), (__bf16)(y.z - (float)h[2]), (__bf16)(y.w - (float)h[3])};
+  *reinterpret_cast<bf16x4_f*>(hi + o) = h;
+  *reinterpret_cast<bf16x4_f*>(lo + o) = l;
+}
+__global__ __launch_bounds__(256) void attout_finish_kernel(const FinishArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int ldt = 64, ls = 68, sub = 16;
+  const int tid = threadIdx.x;
+  const int ldh = a.s.d.ldh, ic = 2 * ldh, ek = ic + 5 * ldt;
+  const long b0 = (long)blockIdx.x * 16;
+  const int y = blockIdx.y;
+  const bool timeblk = y < 5;
+  const int col0 = timeblk ? ic + y * ldt : (y - 5) * 64;
+  float* tl = lds;                 // [61][ls]
+  float* sc = tl + 61 * ls;        // [64]
+  float* xl = sc + 64;             // [16][ls]
+  const bool scores = timeblk && a.s.ph != nullptr;
+  int off = 0, nk = 0;
+  if (timeblk) {
+    off = time_rowoff(y); nk = time_rowoff(y + 1) - off;
+    if (scores || (a.s.tclip && blockIdx.x == 0)) {
+      const float* tab = pick5(a.s.tab, y);
+      const int nf = nk * sub;
+#pragma unroll 2
+      for (int f0 = 0; f0 < nf; f0 += 256) {
+        const int f = f0 + tid;
+        const int row = f / sub, lin = f - row * sub;
+        const bool valid = row < nk;
+        const float4 x = valid ? ld4(tab + (long)row * ldt + lin * 4) : zero4();
+        const float ss = group_sum(dot4(x, x), sub);
+        if (valid) {
+          st4(tl + row * ls + lin * 4, x);
+          if (lin == 0) sc[row] = clip_scale(ss);
+          if (a.s.tclip && blockIdx.x == 0) {
+            st4(a.s.tclip + (long)(off + row) * ldt + lin * 4, scale4(x, clip_scale(ss)));
+            if (lin == 0) {
+              a.s.tclip[160 * ldt + off + row] = clip_scale(ss);
+              a.s.tclip[160 * ldt + 160 + off + row] = ss > 1.0f ? 1.0f : 0.0f;
+            }
+          }
+        }
+      }
+    }
+  }
+  // fold + bias + tanh of this workgroup's 16 x 64 block: thread (r, c) = one float4
+  {
+    const int r = tid >> 4, c = tid & 15;
+    const long row = b0 + r;
+    const int col = col0 + c * 4;
+    float4 yv = zero4();
+    if (row < a.s.B) {
+      const float* sp = a.slabs + row * ek + col;
+      const int nd = timeblk ? a.nd_pt : a.nd_ic;
+      float4 acc = ld4(sp);
+      for (int k = 1; k < nd; ++k) acc = add4(acc, ld4(sp + (long)k * a.stride));          // slab order: fixed
+      const float4 bb = timeblk ? ld4(a.b_ot + (col - ic)) : ld4(a.b_o + col);
+      yv = make_float4(tanhf(acc.x + bb.x), tanhf(acc.y + bb.y), tanhf(acc.z + bb.z), tanhf(acc.w + bb.w));
+      st4(a.out + row * a.ld_out + col, yv);
+      if (a.a_hi) store_planes4(a.a_hi, a.a_lo, kb32_off(row, col, a.a_in32), yv);
+      if (a.ap_hi && (col < ldh || col >= ic))
+        store_planes4(a.ap_hi, a.ap_lo, kb32_off(row, col < ldh ? col : col - (ic - ldh), a.ap_in32), yv);
+    }
+    if (scores) st4(xl + r * ls + c * 4, yv);
+  }
+  if (!scores) return;
+  __syncthreads();
+  const int b = tid & 15, rg = tid >> 4;
+  const float* x = xl + b * ls;
+  const int nz = y == 4 ? 160 - 139 : 0;         // the last table's workgroups also zero the padding columns
+#pragma unroll 2
+  for (int r = rg; r < nk + nz; r += 16) {
+    float v = 0.f;
+    if (r < nk) {
+      const float* t = tl + r * ls;
+      float4 s4 = zero4();
+#pragma unroll 16
+      for (int i = 0; i < ldt; i += 4) {
+        const float4 u = *reinterpret_cast<const float4*>(x + i), w = *reinterpret_cast<const float4*>(t + i);
+        s4.x = fmaf(u.x, w.x, s4.x); s4.y = fmaf(u.y, w.y, s4.y); s4.z = fmaf(u.z, w.z, s4.z); s4.w = fmaf(u.w, w.w, s4.w);
+      }
+      v = ((s4.x + s4.y) + (s4.z + s4.w)) * sc[r];
+    }
+    const __bf16 h = (__bf16)v;
+    const long o = kb32_off(b0 + b, off + r, a.s.in32);
+    a.s.ph[o] = h;
+    a.s.pl[o] = (__bf16)(v - (float)h);
+  }
+}
+
 // gradient of the candidate-side lookups: for every (n, k) clip-backward of d_et[n, k*ldt ...]
 __global__ __launch_bounds__(256) void cand_time_bwd_kernel(const CandArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [139, ldt] accumulators + [5] norms
@@ -1361,6 +1469,35 @@ extern "C" int tcar_time_scores(const tcar_dims_t* d, const float* const time_ta
                                 void* p_hi, void* p_lo, int64_t inner, void* stream) {
   return tcar_time_scores_clip(d, time_tab, B, attout, ld_att, p_hi, p_lo, inner, nullptr, stream);
 }
+// attout [B, ek] (row stride ld_out) = tanh(sum_k slabs_k + bias): slabs of the two output transforms as tcar_gemm_x3_grouped leaves
+// them with splitk = nd_ic / nd_pt (slab k at slabs + k * stride, row stride ek, the time problem's columns at + 2 ldh); optional
+// bf16 hi / lo planes of attout (inner a_inner) and packed [item | time] planes (inner ap_inner = ldh + 5 ldt); optional time scores
+// P (p_hi / p_lo, inner >= 160) and clipped rows (tclip) exactly as tcar_time_scores_clip computes them.  ldt == 64, ldh % 64 == 0.
+extern "C" int tcar_attout_finish_scores(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* slabs, int nd_ic,
+                                         int nd_pt, int64_t stride, const float* bias_o, const float* bias_ot, float* attout,
+                                         int64_t ld_out, void* a_hi, void* a_lo, int64_t a_inner, void* ap_hi, void* ap_lo,
+                                         int64_t ap_inner, void* p_hi, void* p_lo, int64_t p_inner, float* tclip, void* stream) {
+  if (check_dims(d) || d->ldt != 64 || (d->ldh & 63) || !time_tab || B <= 0 || !slabs || nd_ic <= 0 || nd_pt <= 0 || !bias_o || !bias_ot ||
+      !attout || (ld_out & 3) || !tcar_aligned16(slabs) || !tcar_aligned16(attout) || (stride & 3))
+    return TCAR_E_ARG;
+  if (a_hi && (!a_lo || (a_inner & 31) || a_inner < 2 * d->ldh + 5 * d->ldt)) return TCAR_E_ARG;
+  if (ap_hi && (!ap_lo || (ap_inner & 31) || ap_inner < d->ldh + 5 * d->ldt)) return TCAR_E_ARG;
+  if (p_hi && (!p_lo || (p_inner & 31) || p_inner < 160)) return TCAR_E_ARG;
+  FinishArgs a{};
+  a.s.d = *d;
+  for (int k = 0; k < 5; ++k) a.s.tab[k] = time_tab[k];
+  a.s.B = B; a.s.in32 = (int)(p_inner >> 5); a.s.ph = (__bf16*)p_hi; a.s.pl = (__bf16*)p_lo; a.s.tclip = tclip;
+  a.slabs = slabs; a.nd_ic = nd_ic; a.nd_pt = nd_pt; a.stride = (long)stride; a.b_o = bias_o; a.b_ot = bias_ot;
+  a.out = attout; a.ld_out = (long)ld_out;
+  a.a_hi = (__bf16*)a_hi; a.a_lo = (__bf16*)a_lo; a.a_in32 = (int)(a_inner >> 5);
+  a.ap_hi = (__bf16*)ap_hi; a.ap_lo = (__bf16*)ap_lo; a.ap_in32 = (int)(ap_inner >> 5);
+  const long Bp = p_hi ? (((long)B + 127) & ~127L) : (((long)B + 15) & ~15L);      // the score planes' padding rows are written (zeros)
+  const size_t lds = ((size_t)(61 + 16) * 68 + 64) * sizeof(float);
+  TCAR_LAUNCH(attout_finish_kernel, dim3((unsigned)(Bp / 16), 5 + 2 * d->ldh / 64), dim3(256), lds, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
 extern "C" int tcar_time_scores_clip(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* attout,
                                      int64_t ld_att, void* p_hi, void* p_lo, int64_t inner, float* tclip, void* stream) {
   if (check_dims(d) || !time_tab || B <= 0 || !attout || !p_hi || !p_lo || (inner & 31) || inner < 160 || (ld_att & 3)) return TCAR_E_ARG;

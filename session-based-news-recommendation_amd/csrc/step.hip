@@ -22,6 +22,7 @@ const Switch kSwitches[] = {
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
     {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
+    {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -327,8 +328,12 @@ namespace {
 // `hook(stage, o)`: called in front of the projection launch (0: it may put a completion flag into o->sig for that launch to carry),
 // behind it (1: o->carried says whether it did) and behind the click-query launch (2) — forward_impl forks the rest pass of a
 // pending split update there
+// `so`: where the one-hot time scores of the logits GEMM go (forward_impl of a training step); when the output transforms run in
+// their split form the finishing launch computes them too and sets so->done — the caller then skips tcar_time_scores_clip
+struct ScoreOut { void* p_hi; void* p_lo; float* tclip; bool done; };
 template <class Hook>
-int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei, Hook hook) {
+int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei, Hook hook,
+                    ScoreOut* so = nullptr) {
   const int B = bt->B, BT = bt->B * bt->T;
   tcar_tables_t tab;
   tables_of(c, tab);
@@ -419,7 +424,27 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   else
     RET(tcar_attn_pool_fwd(&c->d, B, bt->T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
                            W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream));
-  {  // attout (model_combine.py:119,127,132)
+  // attout (model_combine.py:119,127,132).  Split form (slab workspace, ldt = 64): every 128-deep K chunk of the two output
+  // transforms is its own set of workgroups (376 instead of 104 walking 8 / 5 serial stages), and ONE launch folds the slabs, adds
+  // the bias, applies tanh, writes attout + its planes and goes on to the one-hot time scores (embed.hip: attout_finish_kernel)
+  const int na_ic = units(g.ic), na_pt = units(g.pt);
+  const int64_t astride = (int64_t)B * g.ek;
+  if (split && tn(c).attout_split && g.ldt == 64 && (g.ldh & 63) == 0 &&
+      c->proj_slab_floats >= (na_ic > na_pt ? na_ic : na_pt) * astride) {
+    tcar_gemm_desc_t p[2];
+    p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->proj_slabs, g.ek, nullptr, 0, 0, na_ic);
+    p[1] = prob1(B, g.pt, c->pooled + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->proj_slabs + g.ic, g.ek, nullptr, 0, 0, na_pt);
+    RET(small_gemm(c, 0, 2, p, stream));
+    const float* tt[5];
+    for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+    RET(tcar_attout_finish_scores(&c->d, tt, B, c->proj_slabs, na_ic, na_pt, astride, W(c, TCAR_V_O_B), W(c, TCAR_V_OT_B), c->attout,
+                                  g.ek, planes ? c->a16h : nullptr, planes ? c->a16l : nullptr, g.ek, planes ? c->ap16h : nullptr,
+                                  planes ? c->ap16l : nullptr, g.ldh + g.pt, so ? so->p_hi : nullptr, so ? so->p_lo : nullptr, 160,
+                                  so ? so->tclip : nullptr, stream));
+    if (so) so->done = true;
+    return TCAR_OK;
+  }
+  {
     tcar_gemm_desc_t p[2];
     p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->attout, g.ek, W(c, TCAR_V_O_B), 2);
     p[1] = prob1(B, g.pt, c->pooled + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->attout + g.ic, g.ek,
@@ -550,6 +575,10 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     ei = c->ev_cursor[0]++ % c->ev_n;
     c->ev_cursor[1] = ei;
   }
+  CeWs w;
+  const bool ce_epi = c->scoring && train_index && fused_ce(c, B, &w);
+  const bool onehot = ce_epi && onehot_fwd(c, B);
+  ScoreOut so{c->p16h, c->p16l, oh_bwd ? c->tclip : nullptr, false};
   RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage, TcarOpt* o) -> int {
     if (rest_stage == 1 && stage == 0) o->sig = fork_arm(c, FK_PROJ);        // the projection launch carries the flag
     if (stage != rest_stage) return TCAR_OK;
@@ -557,7 +586,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     (void)fork_commit(c, FK_PROJ, *o);
     RET(fork_go(c, FK_PROJ, s1, s2, c->ev[0]));      // (the rest pass reads nothing the projections write: timing only)
     return launch_rest();
-  }));
+  }, onehot ? &so : nullptr));
   // sort index of the item rows (feed only): on the aux stream BEHIND the rest pass — the logits GEMM does not wait for it (ev[1]
   // was recorded in front of it), the backward does
   if (train_index && sorted_rows(c, bt)) {
@@ -571,10 +600,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   // GEMM of a training step then runs over 2 ldh + 160 columns instead of 2 ldh + 5 ldt, the one-hot block at two MFMAs and one
   // B plane per product.  The scores need attout and the time tables (early part of the update, this stream) only: launched
   // AHEAD of the join with the aux stream.
-  CeWs w;
-  const bool ce_epi = c->scoring && train_index && fused_ce(c, B, &w);
-  const bool onehot = ce_epi && onehot_fwd(c, B);
-  if (onehot) {
+  if (onehot && !so.done) {
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
     RET(tcar_time_scores_clip(&c->d, tt, B, c->attout, g.ek, c->p16h, c->p16l, 160, oh_bwd ? c->tclip : nullptr, stream));
@@ -724,6 +750,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     RET(tcar_ce_finish(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream));
   else if (c->scoring) RET(tcar_softmax_ce_bf16_o(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream, tn(c).softmax_variant));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
+  // (forking dE behind dX instead — dX then runs without dE beside it — was re-measured in round 4: dX is no faster alone, dE ends
+  //  13 us later: 0.529 vs 0.516 ms per step, profiles/r04_ab_experiments.txt)
   if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
@@ -767,6 +795,22 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     if (s2 && !split_finish && hipEventRecord((hipEvent_t)c->ev[3], (hipStream_t)sB) != hipSuccess) return TCAR_E_LAUNCH;
     return TCAR_OK;
   };
+  auto chain_a_dx = [&]() -> int {
+    tick(1, false, stream);
+    if (ohb) {
+      TcarOpt ox = opt_of(c);
+      RET(tcar_gemm_bf16_dx_onehot_o(B, g.ic, g.Npad, c->dl16h, g.Npad, B, c->e16h, g.ek, g.Npad, c->oh16, 160, c->slabs, g.ic + 160,
+                                     c->splitk, stream, &ox));
+    } else if (c->scoring) {
+      TcarOpt ox = opt_of(c);
+      RET(tcar_gemm_bf16_perm_o(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
+                                nullptr, 0, 0, nullptr, 0, nsb, c->splitk, stream, &ox));
+    } else {
+      RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
+    }
+    tick(1, true, stream);
+    return TCAR_OK;
+  };
   RET(chain_b());
   // negative rows of the item gradient (sorted sum) + the loss: they need dE's item block and nothing of the main chain — on
   // the third stream (idle until the weight gradients) the moment dE lands, instead of on the main chain behind its small GEMMs
@@ -779,19 +823,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     if (hipEventRecord((hipEvent_t)c->ev[3], s3n) != hipSuccess) return TCAR_E_LAUNCH;
   }
   // ---- chain A
-  tick(1, false, stream);
-  if (ohb) {
-    TcarOpt ox = opt_of(c);
-    RET(tcar_gemm_bf16_dx_onehot_o(B, g.ic, g.Npad, c->dl16h, g.Npad, B, c->e16h, g.ek, g.Npad, c->oh16, 160, c->slabs, g.ic + 160,
-                                   c->splitk, stream, &ox));
-  } else if (c->scoring) {
-    TcarOpt ox = opt_of(c);
-    RET(tcar_gemm_bf16_perm_o(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
-                              nullptr, 0, 0, nullptr, 0, nsb, c->splitk, stream, &ox));
-  } else {
-    RET(tcar_gemm_f32(0, B, g.ek, g.Npad, c->logits, g.Npad, c->E, g.ek, c->slabs, g.ek, nullptr, 0, 0, c->splitk, stream));
-  }
-  tick(1, true, stream);
+  RET(chain_a_dx());
   // first use of the zeroed arena and of the negative term's forward outputs on the main stream
   if (s2 && !neg_flag && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // (Round 3 A/B: letting the chain of small kernels behind dX wait until dE has finished — every one of them runs ~2x slower

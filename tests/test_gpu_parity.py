@@ -578,6 +578,62 @@ def test_time_onehot_plane_and_time_scores(lib, N, H, Ht, B):
     assert np.abs(scores - direct).max() <= 1e-5 * np.abs(direct).max()
 
 
+@pytest.mark.parametrize("B", [5, 77, 512])
+def test_attout_finish_scores_kernel(lib, B):
+    """tcar_attout_finish_scores (model_combine.py:119,127,132 + the one-hot time scores): attout = tanh(sum of split-K slabs + bias)
+    folded in slab order, its hi / lo planes, the packed [item | time] planes, and P / tclip bit-for-bit what tcar_time_scores_clip
+    computes from the same attout; rows beyond B stay untouched (attout, planes) or zero (score planes)."""
+    from tcar_amd._lib import Dims
+    N, H, Ht, ldh, ldt = 1000, 250, 64, 256, 64
+    d = Dims(N, H, Ht, ldh, ldt)
+    ic, pt, ek = 2 * ldh, 5 * ldt, 2 * ldh + 5 * ldt
+    nd_ic, nd_pt = 4, 3
+    rng = np.random.RandomState(B)
+    slabs = (rng.standard_normal((4, B, ek)) * 0.4).astype(np.float32)
+    slabs[3, :, ic:] = np.nan                                   # the time problem has three slabs only: never read
+    b_o, b_ot = (rng.standard_normal(ic) * 0.1).astype(np.float32), (rng.standard_normal(pt) * 0.1).astype(np.float32)
+    sizes = (13, 32, 8, 25, 61)
+    tabs = [(rng.standard_normal((n, ldt)) * rng.choice([0.05, 0.4], (n, 1))).astype(np.float32) for n in sizes]
+    tabs_d = [torch.tensor(t).cuda() for t in tabs]
+    arr = (C.c_void_p * 5)(*[t.data_ptr() for t in tabs_d])
+    Bp = (B + 127) // 128 * 128
+    t = lambda x: torch.tensor(x, device="cuda")
+    sl, bo, bot = t(slabs), t(b_o), t(b_ot)
+    att = torch.full((B + 2, ek), 7.0, device="cuda")
+    mk = lambda n: torch.full((n,), 3.0, dtype=torch.bfloat16, device="cuda")
+    ah, al, aph, apl = mk(Bp * ek), mk(Bp * ek), mk(Bp * (ldh + pt)), mk(Bp * (ldh + pt))
+    ph, pl = mk(Bp * 160), mk(Bp * 160)
+    tclip = torch.zeros(160 * ldt + 320, device="cuda")
+    assert lib.tcar_attout_finish_scores(C.byref(d), C.byref(arr), B, ptr(sl), nd_ic, nd_pt, B * ek, ptr(bo), ptr(bot), ptr(att), ek,
+                                         ptr2(ah), ptr2(al), ek, ptr2(aph), ptr2(apl), ldh + pt, ptr2(ph), ptr2(pl), 160, ptr(tclip),
+                                         None) == 0
+    pre = slabs[:3].astype(np.float64).sum(0)
+    pre[:, :ic] += slabs[3, :, :ic]
+    want = np.tanh(pre + np.concatenate([b_o, b_ot]).astype(np.float64))
+    got = att.cpu().numpy()
+    close(got[:B], want, rtol=1e-5, atol_scale=1e-6, name="attout")
+    assert (got[B:] == 7.0).all()
+    idx = torch.tensor(_kb32_index(Bp, ek), device="cuda")
+    h, l = ah[idx].float().cpu().numpy(), al[idx].float().cpu().numpy()
+    assert np.abs(h[:B].astype(np.float64) + l[:B] - got[:B]).max() <= 2.0 ** -16 and (h[B:] == 3.0).all()      # hi + lo of the fp32 value
+    want_h = torch.tensor(got[:B]).bfloat16().float().numpy()
+    assert (h[:B] == want_h).all()
+    pidx = torch.tensor(_kb32_index(Bp, ldh + pt), device="cuda")
+    ph_ = aph[pidx].float().cpu().numpy()
+    assert (ph_[:B, :ldh] == want_h[:, :ldh]).all() and (ph_[:B, ldh:] == want_h[:, ic:]).all()
+    # scores and clipped rows: the same bits as the stand-alone launch on this attout
+    ph2, pl2 = mk(Bp * 160), mk(Bp * 160)
+    tclip2 = torch.zeros_like(tclip)
+    assert lib.tcar_time_scores_clip(C.byref(d), C.byref(arr), B, ptr(att), ek, ptr2(ph2), ptr2(pl2), 160, ptr(tclip2), None) == 0
+    assert torch.equal(ph.view(torch.int16), ph2.view(torch.int16)) and torch.equal(pl.view(torch.int16), pl2.view(torch.int16))
+    assert torch.equal(tclip, tclip2)
+    # without planes / scores (the catalog-sharded step's begin): attout alone, the same bits
+    att2 = torch.full((B + 2, ek), 7.0, device="cuda")
+    assert lib.tcar_attout_finish_scores(C.byref(d), C.byref(arr), B, ptr(sl), nd_ic, nd_pt, B * ek, ptr(bo), ptr(bot), ptr(att2), ek,
+                                         None, None, 0, None, None, 0, None, None, 0, None, None) == 0
+    assert torch.equal(att2, att)
+
+
 @pytest.mark.parametrize("B", [1, 8, 77, 512])
 def test_click_query_mlp_in_one_launch(lib, B):
     """tcar_query_mlp (modules.py:138-139): q1 = relu(click_t Wq1 + b1), q = tanh(q1 Wq2 + b2) in fp32 against fp64 — ragged
