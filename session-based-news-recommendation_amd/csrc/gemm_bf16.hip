@@ -173,41 +173,68 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+  // ---- this wave's share of the DMA copies.  Everything about a copy except its position along K is fixed for a K segment, so it is
+  // worked out ONCE (copy_setup: plane, row / column block, validity, LDS slot) and kept as a wave-uniform source pointer that
+  // advances by one k-block per use.  (Round 4: the previous form recomputed plane selection, block indices, a 64-bit product and
+  // the validity test for each of the ~10 copies in EVERY stage — ~400 scalar instructions, 30 kernel-argument loads and 77 spilled
+  // SGPR reads per 72 MFMAs in the logits loop, on the one scalar unit the CU's waves share.)
+  //   k-contiguous operand (MODE 0): the next k-block is the next 8-KB block: + 4096 elements
+  //   transposed-read operand (MODE 1): + 1024 elements inside a 128-row block, + in32 * 4096 - 3072 when the block is used up
+  const __bf16* cp_src[CPW];
+  int cp_dst[CPW];                 // byte offset of the copy inside a sub-stage, -1: nothing to copy
+  int cp_wrap[CPW];                // increment when the k-block index crosses a multiple of 4 (MODE 1), else = the plain one
+  int kq_next = 0;                 // k-block index (k0 / 32, segment relative) of the next sub-stage to issue
+  auto copy_setup = [&](bool seg2, int k0) {
+    kq_next = k0 >> 5;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = wave + NW * i;                     // copy index in [0, NCOPY)   (wave-uniform)
+      cp_dst[i] = -1; cp_src[i] = g.A[0]; cp_wrap[i] = 0;
+      if (NCOPY % NW != 0 && c >= NCOPY) continue;
+      const int p = c / (A_CP + B_CP), rem = c - p * (A_CP + B_CP);
+      const bool isA = rem < A_CP;
+      const int ci = isA ? rem : rem - A_CP;
+      if (SEG2 && seg2 && !isA && p == 1) continue;    // the second segment's B operand has ONE plane
+      const __bf16* P = (SEG2 && seg2) ? (isA ? g.A2[p] : g.B2) : (isA ? g.A[p] : (b2tile ? g.B2 : g.B[p]));
+      const int in32 = (SEG2 && seg2) ? (isA ? g.a2_in32 : g.b2_in32) : (isA ? g.a_in32 : (b2tile ? g.b2_in32 : g.b_in32));
+      const int nrb = (SEG2 && seg2) ? (isA ? g.a2_rb : g.b2_rb) : (isA ? g.a_rb : g.b_rb);
+      const int mode = isA ? MA : MB, t0 = isA ? m0 : (b2tile ? n0 - g.n_b2 : n0);
+      long src;
+      bool ok;
+      if (mode == 0) {          // k-contiguous: 8 copies per 8-KB block (rows t0.., inner block k0/32)
+        const int rb = (t0 >> 7) + (ci >> 3);
+        ok = rb < nrb;
+        src = ((long)rb * in32 + (k0 >> 5)) * 4096 + (ci & 7) * 512;
+        cp_wrap[i] = 4096;
+      } else {                  // transposed-read: 2 copies per 2-KB chunk (32 rows k0.. of inner block t0/32 + j)
+        const int cb = (t0 >> 5) + (ci >> 1);
+        ok = cb < in32;
+        src = ((long)(k0 >> 7) * in32 + cb) * 4096 + (k0 & 127) * 32 + (ci & 1) * 512;
+        cp_wrap[i] = in32 * 4096 - 3072;
+      }
+      if (ok) {
+        cp_src[i] = P + src;
+        cp_dst[i] = p * PL + (isA ? 0 : A_BYTES) + ci * 1024;
+      }
+    }
+  };
+  // one sub-stage (32-deep k-block) into the LDS image at St; advances every source pointer to the next k-block
+  auto copy_substage = [&](char* St) {
+    const bool wrap = (kq_next & 3) == 3;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      if (cp_dst[i] >= 0) __builtin_amdgcn_global_load_lds((glb_vp)(cp_src[i] + lane * 8), (lds_vp)(St + cp_dst[i]), 16, 0, 0);
+      const int mode_inc = (MA == 0 && MB == 0) ? 4096 : ((cp_wrap[i] == 4096) ? 4096 : (wrap ? cp_wrap[i] : 1024));
+      cp_src[i] += mode_inc;
+    }
+    ++kq_next;
+  };
   // issue this wave's share of the DMA copies of k-stage `t` into LDS stage buffer t & 1
   auto issue = [&](int t) {
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
       if (KS > 1 && t * KS + j >= nkb) break;
-      int k0 = ks + (t * KS + j) * KB;
-      const bool seg2 = SEG2 && k0 >= g.K1;              // (workgroup-uniform) this stage lies in the second K segment
-      if (SEG2 && seg2) k0 -= g.K1;
-      char* St = smem + (t & 1) * STAGE + j * SUB;
-#pragma unroll
-      for (int i = 0; i < CPW; ++i) {
-        const int c = wave + NW * i;                     // copy index in [0, NCOPY)   (wave-uniform)
-        if (NCOPY % NW != 0 && c >= NCOPY) break;
-        const int p = c / (A_CP + B_CP), rem = c - p * (A_CP + B_CP);
-        const bool isA = rem < A_CP;
-        const int ci = isA ? rem : rem - A_CP;
-        if (SEG2 && seg2 && !isA && p == 1) continue;    // the second segment's B operand has ONE plane
-        const __bf16* P = (SEG2 && seg2) ? (isA ? g.A2[p] : g.B2) : (isA ? g.A[p] : (b2tile ? g.B2 : g.B[p]));
-        const int in32 = (SEG2 && seg2) ? (isA ? g.a2_in32 : g.b2_in32) : (isA ? g.a_in32 : (b2tile ? g.b2_in32 : g.b_in32));
-        const int nrb = (SEG2 && seg2) ? (isA ? g.a2_rb : g.b2_rb) : (isA ? g.a_rb : g.b_rb);
-        const int mode = isA ? MA : MB, t0 = isA ? m0 : (b2tile ? n0 - g.n_b2 : n0);
-        long src;
-        bool ok;
-        if (mode == 0) {          // k-contiguous: 8 copies per 8-KB block (rows t0.., inner block k0/32)
-          const int rb = (t0 >> 7) + (ci >> 3);
-          ok = rb < nrb;
-          src = ((long)rb * in32 + (k0 >> 5)) * 4096 + (ci & 7) * 512;
-        } else {                  // transposed-read: 2 copies per 2-KB chunk (32 rows k0.. of inner block t0/32 + j)
-          const int cb = (t0 >> 5) + (ci >> 1);
-          ok = cb < in32;
-          src = ((long)(k0 >> 7) * in32 + cb) * 4096 + (k0 & 127) * 32 + (ci & 1) * 512;
-        }
-        char* dst = St + p * PL + (isA ? 0 : A_BYTES) + ci * 1024;
-        if (ok) __builtin_amdgcn_global_load_lds((glb_vp)(P + src + lane * 8), (lds_vp)dst, 16, 0, 0);
-      }
+      copy_substage(smem + (t & 1) * STAGE + j * SUB);
     }
   };
   // the MFMAs of one 32-column k-block; S2: the block lies in the second K segment (B has no lo plane: two MFMAs per product, and
@@ -255,12 +282,16 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
     }
   };
 
-  if (nit > 0) issue(0);
-  __syncthreads();                       // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
   // two loops, one per K segment (the second is empty without SEG2; with it KS = 1 and there is no split-K): each has ONE body
   const int nit1 = SEG2 ? min(nit, g.K1 / KB) : nit;
+  copy_setup(SEG2 && nit1 == 0, (SEG2 && nit1 == 0) ? 0 : ks);
+  if (nit > 0) issue(0);
+  __syncthreads();                       // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
   for (int it = 0; it < nit1; ++it) {
-    if (it + 1 < nit) issue(it + 1);     // buffer (it+1)&1 was last read in iteration it-1, which ended with a barrier
+    if (it + 1 < nit) {                  // buffer (it+1)&1 was last read in iteration it-1, which ended with a barrier
+      if (SEG2 && it + 1 == nit1) copy_setup(true, 0);      // the next stage is the first of the second K segment
+      issue(it + 1);
+    }
     compute(it, std::false_type{});
     __syncthreads();
   }
