@@ -93,11 +93,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         src = os.path.join(CSRC, s)
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
         objs.append(o)
-        dig = _digest([src] + HEADERS) + (":" + want if s == BUILD_ID_TU else "")
+        extra = os.environ.get("TCAR_HIPCC_FLAGS", "").split()      # e.g. -DTCAR_GEMM_DIAG (diagnostic kernel forms, tools/gemm_variants.sh)
+        dig = _digest([src] + HEADERS) + (":" + want if s == BUILD_ID_TU else "") + (":" + " ".join(extra) if extra else "")
         stamp = o + ".digest"
         if not force and os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == dig:
             continue
-        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-c", src, "-o", o]
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"] + extra + ["-c", src, "-o", o]
         if s == BUILD_ID_TU:
             cmd.insert(1, '-DTCAR_BUILD_ID="%s"' % want)
         procs.append((cmd, stamp, dig, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

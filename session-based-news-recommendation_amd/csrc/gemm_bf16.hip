@@ -78,13 +78,20 @@ __device__ __forceinline__ int cand_row(const int32_t* __restrict__ mwdhm, long 
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef __attribute__((address_space(1))) const void* glb_vp;
 
-// fragment of the 32-row block starting at tile row/col `base`, k16 sub-step s (0/1) of the 32-deep stage
-template <int MODE>
+// fragment of the 32-row block starting at tile row/col `base`, k16 sub-step s (0/1) of the 32-deep stage.
+// PERM (k-contiguous operands only): MFMA row i = 8 a + 4 h + j takes tile row 16 h + 4 a + j instead of row i.  Fed as the
+// FIRST operand of a 32x32 MFMA this makes a lane's 16 accumulator registers 16 CONSECUTIVE tile rows (16 (lane >> 5) + e) instead
+// of four runs of four — the softmax epilogue stores 16 bytes per lane.  The swizzled image stays conflict-free: each 16-lane
+// group of ds_read_b128 ({0-3, 12-15, 20-27}, ...) still meets all four values of (row >> 2) & 3.
+template <int MODE, bool PERM = false>
 __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int s, int lane) {
   if (MODE == 0) {
-    const int rr = base + (lane & 31), r = rr & 127;
-    const int piece = (s * 2 + (lane >> 5)) ^ ((r >> 2) & 3);
-    return *reinterpret_cast<const bf16x8*>(S + (rr >> 7) * 8192 + r * 64 + piece * 16);
+    // (128-row blocks of 8 KB, 64-byte rows: (rr >> 7) * 8192 + (rr & 127) * 64 == rr * 64 — one linear address per lane, the tile
+    //  and plane offsets fold into the instruction's immediate)
+    const int l5 = lane & 31;
+    const int rr = base + (PERM ? ((((l5 >> 2) & 1) << 4) | ((l5 >> 3) << 2) | (l5 & 3)) : l5);
+    const int piece = (s * 2 + (lane >> 5)) ^ ((rr >> 2) & 3);
+    return *reinterpret_cast<const bf16x8*>(S + rr * 64 + piece * 16);
   } else {
     const int g = lane >> 4, i = lane & 15;
     const int q = i >> 2, p = i & 3;
@@ -102,7 +109,11 @@ __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int
 // tiles = 192 registers, 2 waves per SIMD) for the 256 x 384 workgroup tile of the logits GEMM
 // KS = 32-deep k blocks per LDS stage: the hi-only (NSPLIT = 1) form has a third of the MFMA work between two barriers
 // and half the bytes per stage, so it takes 64-deep stages (same LDS as the two-plane form, half the barriers).
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1, int EPI = 0, int SEG2 = 0>
+// VAR: 0 = the product kernel.  Diagnostic forms of the softmax-epilogue kernel (built only with -DTCAR_GEMM_DIAG, selected by
+// TCAR_BF16_TILE = 387 / 388 / 393 / 395; tools/gemm_variants.sh): 2 = no fills after stage 1 (compute side alone), 3 = fills and
+// barriers only, 6 = epilogue only, 8 = K loop without the epilogue.  Round 4: 97.5 / 49 / 57 / 74 us of a 102-us launch — the K
+// loop runs at ~1.29 PF executed, the practical bf16 rate of the chip on random data; the epilogue was 30 us of the launch.
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1, int EPI = 0, int SEG2 = 0, int VAR = 0>
 // (EPI = 2, the dE form with the (q, z) epilogue: two 9-wave workgroups per CU need five waves per SIMD, i.e. <= 96 registers per
 //  lane; without the bound the compiler takes 102 — four waves per SIMD, ONE workgroup per CU, 64 us alone.  At 80 registers, which
 //  two 12-wave workgroups would need, it spills)
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   const int ks = split * g.kchunk;
   const int ke = min(g.K, ks + g.kchunk);
   const int nkb = (ke - ks) / KB;
-  const int nit = (nkb + KS - 1) / KS;
+  const int nit = (VAR == 6) ? 0 : (nkb + KS - 1) / KS;
 
   // (EPI = 2, time-block waves) the epilogue's two dependent index loads — the table row each of this lane's catalog rows looks up and
   // its position in the inverted index — are issued HERE, ahead of the K loop, so that only the clipped-row loads follow the loop
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
       for (int t2 = 0; t2 < TNW; ++t2) {          // one B tile at a time: its fragments die after TMW * NSPLIT MFMAs
         bf16x8 b[NPB];
 #pragma unroll
-        for (int p = 0; p < NPB; ++p) b[p] = frag<MB>(St + p * PL + (EPI == 2 ? b_off : A_BYTES), (EPI == 2 ? b_base : wn * (32 * TNW)) + t2 * 32, s, lane);
+        for (int p = 0; p < NPB; ++p) b[p] = frag<MB, EPI == 1>(St + p * PL + (EPI == 2 ? b_off : A_BYTES), (EPI == 2 ? b_base : wn * (32 * TNW)) + t2 * 32, s, lane);
 #pragma unroll
         for (int u = 0; u < TMW; ++u) {
           if constexpr (EPI == 1) {     // transposed accumulator tile (rows = catalog columns, lane = session): see the epilogue
@@ -288,71 +299,105 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   if (nit > 0) issue(0);
   __syncthreads();                       // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
   for (int it = 0; it < nit1; ++it) {
-    if (it + 1 < nit) {                  // buffer (it+1)&1 was last read in iteration it-1, which ended with a barrier
+    if (it + 1 < nit && (VAR != 2 || it < 1)) {      // buffer (it+1)&1 was last read in iteration it-1, which ended with a barrier
       if (SEG2 && it + 1 == nit1) copy_setup(true, 0);      // the next stage is the first of the second K segment
       issue(it + 1);
     }
-    compute(it, std::false_type{});
+    if (VAR != 3) compute(it, std::false_type{});
     __syncthreads();
   }
   if constexpr (SEG2 != 0) {
     for (int it = nit1; it < nit; ++it) {
-      if (it + 1 < nit) issue(it + 1);
-      compute(it, std::true_type{});
+      if (it + 1 < nit && VAR != 2) issue(it + 1);
+      if (VAR != 3) compute(it, std::true_type{});
       __syncthreads();
     }
   }
 
   const int li = lane & 31, lh = lane >> 5;
+  if constexpr (EPI == 1 && VAR == 8) {      // DIAGNOSTIC: K loop without the epilogue (the accumulators must stay live)
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < TMW; ++u)
+#pragma unroll
+      for (int b2 = 0; b2 < TNW; ++b2)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[u][b2][e];
+    if (t == 12345.678f) g.lab_logit[0] = t;
+    tcar_signal_done(g.sig);
+    return;
+  }
   if constexpr (EPI == 1) {
     // Softmax epilogue (model_combine.py:145 without materialised logits).  The accumulators of this form are TRANSPOSED
-    // (compute() swaps the MFMA operands): a lane owns ONE session (column lane & 31 of the tile = row m of the logits) and its
-    // registers run over the wave's GW = 32 * TNW catalog columns — n = 4 (lane >> 5) + (e & 3) + 8 (e >> 2) inside each
-    // 32-wide tile.  Group maximum and sum are therefore in-register loops plus ONE exchange between the two half waves, and
-    // the exponentials leave as 8-byte stores of four consecutive catalog columns.  exp(x - group max) <= 1 goes out as bf16;
-    // tcar_ce_finish combines the (max, sum) pairs of a row into its log-sum-exp and rescales the plane to softmax - onehot.
+    // (compute() swaps the MFMA operands) and the B fragments are read with the row permutation of frag<., PERM>: a lane owns ONE
+    // session (column lane & 31 of the tile = row m of the logits) and its 16 registers of catalog tile t are the 16 CONSECUTIVE
+    // columns n = 32 t + 16 (lane >> 5) + e of the wave's GW = 32 * TNW.  Group maximum and sum are in-register loops plus ONE
+    // v_permlane32_swap between the two half waves, and the exponentials leave as 16-byte stores of eight consecutive catalog columns
+    // (a wave instruction fills 32 bytes of 32 plane rows; round 4: the 8-byte form took 15 us of a 102-us launch).
+    // exp(x - group max) <= 1 goes out as bf16; tcar_ce_finish combines the (max, sum) pairs of a row into its log-sum-exp and rescales
+    // the plane to softmax - onehot.  Interior workgroups (every row and column of the tile inside M x N: all but the last column of
+    // tiles) run a body without bounds tests; the label's score is picked by a scan only in waves where a lane's label falls into
+    // its columns (a 7 % event at the Globo shape).
     constexpr int GW = 32 * TNW;
+    constexpr float LOG2E = 1.4426950408889634f;
     const int gidx = (n0 + wn * GW) / GW;
-    const int nb = n0 + wn * GW + 4 * lh;
+    const int nb = n0 + wn * GW + 16 * lh;
     const int pcols = g.p_in32 << 5;
+    const bool interior = (m0 + TM <= g.M) && (n0 + TN <= g.N) && (n0 + TN <= pcols);      // workgroup-uniform
+    auto xhalf = [](float x, auto op) __attribute__((always_inline)) {      // op(x of this lane, x of lane ^ 32): the same bits in both
+      const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+      return op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    };
+    auto epi = [&](auto fast_) __attribute__((always_inline)) {
+      constexpr bool FAST = decltype(fast_)::value;
 #pragma unroll
-    for (int u = 0; u < TMW; ++u) {
-      const int row = m0 + wm * (32 * TMW) + u * 32 + li;
-      const bool live = row < g.M;
-      float mx = -INFINITY;
+      for (int u = 0; u < TMW; ++u) {
+        const int row = m0 + wm * (32 * TMW) + u * 32 + li;
+        const bool live = FAST || row < g.M;
+        float mx = -INFINITY;
 #pragma unroll
-      for (int t = 0; t < TNW; ++t)
+        for (int t = 0; t < TNW; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-          if (nb + 32 * t + (e & 3) + 8 * (e >> 2) < g.N) mx = fmaxf(mx, acc[u][t][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      // (clamped like tcar_ce_finish: lab_logit is always written; with a label window — catalog shard — a label outside it matches
-      //  no column and lab_logit[row] is left alone)
-      const int lraw = live ? g.label[row] - g.lab_off : -1;
-      const int lab = !live ? -1 : g.lab_window ? ((lraw >= 0 && lraw < g.N) ? lraw : -1) : clampi(lraw, 0, g.N - 1);
-      float sum = 0.f, labv = 0.f;
-      bool has_lab = false;
+          for (int e = 0; e < 16; ++e)
+            if (FAST || nb + 32 * t + e < g.N) mx = fmaxf(mx, acc[u][t][e]);
+        mx = xhalf(mx, [](float a, float b) { return fmaxf(a, b); });
+        // (clamped like tcar_ce_finish: lab_logit is always written; with a label window — catalog shard — a label outside it matches
+        //  no column and lab_logit[row] is left alone)
+        const int lraw = live ? g.label[row] - g.lab_off : -1;
+        const int lab = !live ? -1 : g.lab_window ? ((lraw >= 0 && lraw < g.N) ? lraw : -1) : clampi(lraw, 0, g.N - 1);
+        const int d = lab - nb;                        // the label among this lane's columns: tile d >> 5, register d & 31 (< 16)
+        const bool has_lab = lab >= 0 && d >= 0 && d < GW && (d & 16) == 0;
+        if (__any(has_lab)) {
+          float labv = 0.f;
 #pragma unroll
-      for (int t = 0; t < TNW; ++t)
+          for (int t = 0; t < TNW; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n4 = nb + 32 * t + 8 * q;
-          bf16x4 pk;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float v = acc[u][t][4 * q + j];
-            const float pe = (n4 + j < g.N) ? __expf(v - mx) : 0.f;
-            sum += pe;
-            pk[j] = (__bf16)pe;
-            if (n4 + j == lab) { labv = v; has_lab = true; }
-          }
-          if (live && n4 < pcols) *reinterpret_cast<bf16x4*>(g.p_hi + kb32_off(row, n4, g.p_in32)) = pk;
+            for (int e = 0; e < 16; ++e) labv = (32 * t + e == d) ? acc[u][t][e] : labv;
+          if (has_lab) g.lab_logit[row] = labv;
         }
-      sum += __shfl_xor(sum, 32);
-      if (has_lab) g.lab_logit[row] = labv;
-      if (live && lh == 0) *reinterpret_cast<float2*>(g.stats + ((long)row * g.ngroups + gidx) * 2) = make_float2(mx, sum);
-      __builtin_amdgcn_sched_barrier(0);     // one session tile at a time: the accumulators leave no room for hoisted addresses
-    }
+        const float c = -mx * LOG2E;
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < TNW; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int n8 = nb + 32 * t + 8 * h;
+            bf16x8 pk;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float pe = (FAST || n8 + j < g.N) ? __builtin_amdgcn_exp2f(fmaf(acc[u][t][8 * h + j], LOG2E, c)) : 0.f;
+              sum += pe;
+              pk[j] = (__bf16)pe;
+            }
+            if (VAR == 7 ? (sum == 12345.678f) : (live && (FAST || n8 < pcols)))
+              *reinterpret_cast<bf16x8*>(g.p_hi + kb32_off(row, n8, g.p_in32)) = pk;
+          }
+        sum = xhalf(sum, [](float a, float b) { return a + b; });
+        if (live && lh == 0) *reinterpret_cast<float2*>(g.stats + ((long)row * g.ngroups + gidx) * 2) = make_float2(mx, sum);
+        __builtin_amdgcn_sched_barrier(0);     // one session tile at a time: the accumulators leave no room for hoisted addresses
+      }
+    };
+    if (interior) epi(std::true_type{}); else epi(std::false_type{});
     tcar_signal_done(g.sig);
     return;
   }
@@ -462,7 +507,7 @@ struct LaunchCall {
   int ce_gw = 0, ce_ngroups = 0;
 };
 
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW, int TNW, int KS>
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW, int TNW, int KS, int VAR = 0>
 int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
   constexpr int NT = 64 * WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW, NP = (NSPLIT == 1) ? 1 : 2;
   constexpr size_t lds = 2 * KS * NP * (TM + TN) * 64;
@@ -484,8 +529,8 @@ int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
       g.lab_window = lc.o ? lc.o->lab_window : 0;
       if (g.B2) {
         if constexpr (NSPLIT == 3 && KS == 1) {
-          TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1>), lds);
-          TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1>), dim3(g.mt * g.nt), dim3(NT), lds, st, g);
+          TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1, VAR>), lds);
+          TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1, VAR>), dim3(g.mt * g.nt), dim3(NT), lds, st, g);
           TCAR_CHECK_LAUNCH();
           return TCAR_OK;
         } else {
@@ -506,7 +551,7 @@ int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
   return TCAR_OK;
 }
 
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2>
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int VAR = 0>
 int launch_v(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
   // measured at the Globo shape (hi-only backward): dX 68 -> 59 us with 64-deep stages; dE (192 x 192 tiles, three
   // workgroups per CU at 48 KB) loses its occupancy with 96 KB and slows down 129 -> 136 us, so it keeps 32-deep stages
@@ -515,7 +560,7 @@ int launch_v(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
     const int ks = tcar_tn(lc.o).bf16_ks;
     if (ks == 3 || (ks == 2 && MA == 0)) return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 2>(g, splitk, st, lc);
   }
-  return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 1>(g, splitk, st, lc);
+  return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 1, VAR>(g, splitk, st, lc);
 }
 
 template <int MA, int MB>
@@ -531,6 +576,13 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st, LaunchCall& lc) {
     // shape moves 17 % fewer bytes per flop than 256 x 256; at the Globo catalog it is also ONE round of 240 workgroups
     // instead of 360 workgroups in 1.4 rounds
     const long w384 = (long)((g.M + 255) / 256) * ((g.N + 383) / 384) * splitk;
+#ifdef TCAR_GEMM_DIAG
+    if (nsplit == 3 && f == 387) return launch_v<0, 0, 3, 2, 4, 4, 3, 2>(g, splitk, st, lc);
+    if (nsplit == 3 && f == 388) return launch_v<0, 0, 3, 2, 4, 4, 3, 3>(g, splitk, st, lc);
+    if (nsplit == 3 && f == 393) return launch_v<0, 0, 3, 2, 4, 4, 3, 6>(g, splitk, st, lc);
+    if (nsplit == 3 && f == 394) return launch_v<0, 0, 3, 2, 4, 4, 3, 7>(g, splitk, st, lc);
+    if (nsplit == 3 && f == 395) return launch_v<0, 0, 3, 2, 4, 4, 3, 8>(g, splitk, st, lc);
+#endif
     if (nsplit == 3 && (f == 384 || (f == 0 && w384 >= 200))) return launch_v<0, 0, 3, 2, 4, 4, 3>(g, splitk, st, lc);
   }
   if constexpr (MA == 0 && MB == 1) {

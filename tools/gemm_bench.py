@@ -13,6 +13,7 @@ import tcar_amd  # noqa
 from tcar_amd import _lib
 
 lib = _lib.load()
+torch.manual_seed(1234)
 which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 nsplit = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
@@ -111,5 +112,10 @@ for _ in range(iters):
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / iters
+if os.environ.get("GB_SUM") and which.startswith("fwdce"):    # checksum of the outputs: variants of one kernel must agree bit for bit
+    ng_, gw_ = ng.value, gw.value
+    st = stats[: B * ng_ * 2].view(B, ng_, 2)
+    print("checksum plane %.10e stats %.10e lab %.10e tile=%s " % (plane.double().abs().sum().item(), st.double().sum().item(),
+                                                                lab_logit.double().sum().item(), os.environ.get("TCAR_BF16_TILE", "0")), end="")
 print("N=%d sk=%d " % (N, SK), end="")
 print("%s nsplit=%d: %.1f us  alg %.0f TF  executed %.0f TF" % (which, nsplit, ms * 1e3, fl / ms / 1e9, fl * (3 if nsplit == 3 else 1) / ms / 1e9))
