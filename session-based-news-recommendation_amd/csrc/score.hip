@@ -203,54 +203,60 @@ __global__ __launch_bounds__(256) void ce_combine_kernel(int B, int ngroups, con
 }
 // Rescale in place: plane[b, n] = bf16( e[b, n] * exp(m_g - M) / S - [n == label_b] ) = softmax - onehot, the gradient of the
 // SUM of the per-session losses (model_combine.py:147,156); rows [B, ceil128(B)) are zeroed (they are k-rows of dE).
-// One thread per (row, 32-column block) = 64 contiguous bytes of the KB32 plane: a wave streams 4 KB.
+// One thread per 16-byte piece position (row, q) of CE_KPT consecutive 32-column blocks: a wave instruction moves 1 KB of
+// CONTIGUOUS plane (16 rows x 64 bytes) and the CE_KPT loads of a thread are independent (round 4: one thread per 64-byte row
+// read its four pieces with four instructions of 64-byte lane stride — 26 us for the 94 MB of the Globo plane).
+constexpr int CE_KPT = 4;
 template <int GW>
 __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
                                                 const float* __restrict__ rowstat, const int32_t* __restrict__ label,
                                                 __bf16* __restrict__ plane, long nunits, int lab_off, int lab_window) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nunits) return;
-  const long blk = i >> 7;
-  const int r = (int)(i & 127);
-  const long rb = blk / in32;
-  const int kb = (int)(blk - rb * in32);
+  const int q = (int)(i & 3), r = (int)((i >> 2) & 127);
+  const long chunk = i >> 9;
+  const int nch = (in32 + CE_KPT - 1) / CE_KPT;
+  const long rb = chunk / nch;
+  const int kb0 = (int)(chunk - rb * nch) * CE_KPT;
   const long row = rb * 128 + r;
-  uint4* p = reinterpret_cast<uint4*>(plane + blk * 4096 + r * 32);
+  uint4* p = reinterpret_cast<uint4*>(plane + (rb * in32 + kb0) * 4096 + r * 32 + q * 8);      // block kb0 + j: p + 512 j
   if (row >= B) {
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) p[q] = z;
+    for (int j = 0; j < CE_KPT; ++j)
+      if (kb0 + j < in32) p[512 * j] = z;
     return;
   }
-  uint4 v[4];
+  uint4 v[CE_KPT];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) v[q] = p[q];
-  const int col0 = kb * 32;
-  // (padding blocks of the plane — columns at or beyond N, or beyond the groups the GEMM wrote statistics for — scale to zero:
-  //  no statistic outside [0, ngroups) is ever read)
-  const int gi = col0 / GW;
-  const float mg = (gi < ngroups && col0 < N) ? stats[((long)row * ngroups + gi) * 2] : -INFINITY;
+  for (int j = 0; j < CE_KPT; ++j)
+    if (kb0 + j < in32) v[j] = p[512 * j];
   const float2 rs = *reinterpret_cast<const float2*>(rowstat + 2 * row);
-  const float c = (mg == -INFINITY) ? 0.f : expf(mg - rs.x) * rs.y;
-  // label's column inside this block, if 0 <= lab < 32 (label window — catalog shard —: a label of another shard matches nothing)
+  // label's column, if inside the catalog (label window — catalog shard —: a label of another shard matches nothing)
   const int lraw = label[row] - lab_off;
-  const int lab = (lab_window ? ((lraw >= 0 && lraw < N) ? lraw : -(1 << 30)) : clampi(lraw, 0, N - 1)) - col0;
-  const int sw = (r >> 2) & 3;
+  const int labc = lab_window ? ((lraw >= 0 && lraw < N) ? lraw : -(1 << 30)) : clampi(lraw, 0, N - 1);
+  const int piece = q ^ ((r >> 2) & 3);                           // storage position q holds logical piece q ^ sw
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int piece = q ^ sw;                                   // storage position q holds logical piece q ^ sw
-    unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+  for (int j = 0; j < CE_KPT; ++j) {
+    if (kb0 + j >= in32) break;
+    const int col0 = (kb0 + j) * 32;
+    // (padding blocks of the plane — columns at or beyond N, or beyond the groups the GEMM wrote statistics for — scale to zero:
+    //  no statistic outside [0, ngroups) is ever read)
+    const int gi = col0 / GW;
+    const float mg = (gi < ngroups && col0 < N) ? stats[((long)row * ngroups + gi) * 2] : -INFINITY;
+    const float c = (mg == -INFINITY) ? 0.f : expf(mg - rs.x) * rs.y;
+    const int lab = labc - col0 - piece * 8;                      // the label among this piece's eight columns, if 0 <= lab < 8
+    unsigned w[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int e = 0; e < 4; ++e) {
       // two bf16 per dword: low half = even element
-      float lo = __uint_as_float(w[j] << 16) * c, hi = __uint_as_float(w[j] & 0xffff0000u) * c;
-      const int k = piece * 8 + j * 2;
-      if (k == lab) lo -= 1.f;
-      if (k + 1 == lab) hi -= 1.f;
+      float lo = __uint_as_float(w[e] << 16) * c, hi = __uint_as_float(w[e] & 0xffff0000u) * c;
+      if (2 * e == lab) lo -= 1.f;
+      if (2 * e + 1 == lab) hi -= 1.f;
       const __bf16 bl = (__bf16)lo, bh = (__bf16)hi;
-      w[j] = (unsigned)__builtin_bit_cast(unsigned short, bl) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+      w[e] = (unsigned)__builtin_bit_cast(unsigned short, bl) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
     }
-    p[q] = make_uint4(w[0], w[1], w[2], w[3]);
+    p[512 * j] = make_uint4(w[0], w[1], w[2], w[3]);
   }
 }
 template <int GW>
@@ -878,7 +884,7 @@ extern "C" int tcar_ce_rescale(int B, int N, int group_width, int ngroups, const
     return TCAR_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int in32 = (int)(inner >> 5);
-  const long nunits = (((long)B + 127) >> 7) * in32 * 128;
+  const long nunits = (((long)B + 127) >> 7) * ((in32 + CE_KPT - 1) / CE_KPT) * 512;
   const unsigned grid = (unsigned)((nunits + 255) / 256);
   if (group_width == 96)
     TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits,
