@@ -699,9 +699,17 @@ __global__ __launch_bounds__(256) void attout_finish_kernel(const FinishArgs a) 
     if (row < a.s.B) {
       const float* sp = a.slabs + row * ek + col;
       const int nd = timeblk ? a.nd_pt : a.nd_ic;
-      float4 acc = ld4(sp);
-      for (int k = 1; k < nd; ++k) acc = add4(acc, ld4(sp + (long)k * a.stride));          // slab order: fixed
+      // (slab order: fixed; the first MS slabs' loads are issued together, not as a chain of dependent round trips)
+      constexpr int MS = 8;
+      float4 ts[MS];
+#pragma unroll
+      for (int k = 0; k < MS; ++k) ts[k] = (k == 0 || k < nd) ? ld4(sp + (long)k * a.stride) : zero4();
       const float4 bb = timeblk ? ld4(a.b_ot + (col - ic)) : ld4(a.b_o + col);
+      float4 acc = ts[0];
+#pragma unroll
+      for (int k = 1; k < MS; ++k)
+        if (k < nd) acc = add4(acc, ts[k]);
+      for (int k = MS; k < nd; ++k) acc = add4(acc, ld4(sp + (long)k * a.stride));
       yv = make_float4(tanhf(acc.x + bb.x), tanhf(acc.y + bb.y), tanhf(acc.z + bb.z), tanhf(acc.w + bb.w));
       st4(a.out + row * a.ld_out + col, yv);
       if (a.a_hi) store_planes4(a.a_hi, a.a_lo, kb32_off(row, col, a.a_in32), yv);

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   }
 
   const int li = lane & 31, lh = lane >> 5;
-  if constexpr (EPI == 1 && VAR == 8) {      // DIAGNOSTIC: K loop without the epilogue (the accumulators must stay live)
+  if constexpr (VAR == 8) {      // DIAGNOSTIC: K loop without the epilogue (the accumulators must stay live)
     float t = 0.f;
 #pragma unroll
     for (int u = 0; u < TMW; ++u)
@@ -323,8 +323,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
       for (int b2 = 0; b2 < TNW; ++b2)
 #pragma unroll
         for (int e = 0; e < 16; ++e) t += acc[u][b2][e];
-    if (t == 12345.678f) g.lab_logit[0] = t;
-    tcar_signal_done(g.sig);
+    if (t == 12345.678f) g.C[0] = t;
+    if constexpr (EPI == 1) tcar_signal_done(g.sig);
     return;
   }
   if constexpr (EPI == 1) {
@@ -834,6 +834,20 @@ int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int6
     g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
     TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 2, 3, 2, 2, 1, 2, 0>), lds);
     TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 2, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 6), lds, st, g);
+#ifdef TCAR_GEMM_DIAG
+  } else if (tile >= 1002 && tile <= 1008) {
+    constexpr int TM = 192, TN = 192;
+    constexpr size_t lds = 2 * (TM + TN) * 64;
+    g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
+    if (tile == 1002) { TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 2>), lds);
+      TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 2>), dim3(g.mt * g.nt), dim3(64 * 9), lds, st, g); }
+    else if (tile == 1003) { TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 3>), lds);
+      TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 3>), dim3(g.mt * g.nt), dim3(64 * 9), lds, st, g); }
+    else if (tile == 1006) { TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 6>), lds);
+      TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 6>), dim3(g.mt * g.nt), dim3(64 * 9), lds, st, g); }
+    else { TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 8>), lds);
+      TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 8>), dim3(g.mt * g.nt), dim3(64 * 9), lds, st, g); }
+#endif
   } else {
     constexpr int TM = 192, TN = 192;
     constexpr size_t lds = 2 * (TM + TN) * 64;

@@ -73,27 +73,75 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
       if (col < ldh) { qa[c] = ld4(a.q + (long)b * ic + col); qb[c] = ld4(a.q + (long)b * ic + ldh + col); }
     }
   }
-  for (int t = 0; t < T; ++t) {
-    const long row = (long)b * T + t;
-    float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  // Round 4: every load of a pair of positions — up to MS split-K slabs of each projection, the item | content row, the publish-time
+  // row — is ISSUED before the first is used (the slab fold was a loop of 7 + 5 dependent round trips per position: 10 us alone and
+  // 24-38 us beside the Adam rest pass, whose traffic lengthens each trip); the rows of the first TC positions stay in registers for
+  // the weighted sums below.  The sums keep their order: slabs in slab order, positions in position order.
+  constexpr int MS = 8, TU = (NCH == 1) ? 2 : 1, TC = (NCH == 1) ? 4 : 0;
+  float4 xa[TC > 0 ? TC : 1][NCH], xb[TC > 0 ? TC : 1][NCH], xp[TC > 0 ? TC : 1][2];
+  const int n1 = a.pre1_out ? a.n1 : 1, n2 = a.pre1_out ? a.n2 : 1;
+  for (int t0 = 0; t0 < T; t0 += TU) {
+    float4 t1[TU][NCH][MS], t2[TU][NCH][MS], ya[TU][NCH], yb[TU][NCH], yp[TU][2];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (col < ldh) {
-        float4 p1 = ld4(a.pre1 + row * ldh + col), p2 = ld4(a.pre2 + row * ldh + col);
-        if (a.pre1_out) {                // split-K partial products, folded in slab order
-          for (int sl = 1; sl < a.n1; ++sl) p1 = add4(p1, ld4(a.pre1 + sl * a.pre_stride + row * ldh + col));
-          for (int sl = 1; sl < a.n2; ++sl) p2 = add4(p2, ld4(a.pre2 + sl * a.pre_stride + row * ldh + col));
-          st4(a.pre1_out + row * ldh + col, p1);
-          st4(a.pre2_out + row * ldh + col, p2);
+    for (int u = 0; u < TU; ++u) {
+      const int t = t0 + u;
+      const long row = (long)b * T + t;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = t < T && col < ldh;
+#pragma unroll
+        for (int sl = 0; sl < MS; ++sl) {
+          t1[u][c][sl] = (ok && sl < n1) ? ld4(a.pre1 + sl * a.pre_stride + row * ldh + col) : zero4();
+          t2[u][c][sl] = (ok && sl < n2) ? ld4(a.pre2 + sl * a.pre_stride + row * ldh + col) : zero4();
         }
-        s1 += dot4(mask4(sig4(p1), col, H), w1[c]);
-        s3 += dot4(mask4(sig4(p2), col, H), w2[c]);
-        if (!late_q) s2 += dot4(ld4(a.x_icp + row * ic + col), qa[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), qb[c]);
+        ya[u][c] = ok ? ld4(a.x_icp + row * ic + col) : zero4();
+        yb[u][c] = ok ? ld4(a.x_icp + row * ic + ldh + col) : zero4();
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int l4 = c * 64 + lane;
+        yp[u][c] = (TC > 0 && t < T && l4 < ptl) ? ld4(a.x_pt + row * pt + l4 * 4) : zero4();
       }
     }
-    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
-    if (lane == t) { e1 = s1; e2 = s2; e3 = s3; }
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      const int t = t0 + u;
+      if (t >= T) break;
+      const long row = (long)b * T + t;
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) {
+          float4 p1 = t1[u][c][0], p2 = t2[u][c][0];
+          if (a.pre1_out) {                // split-K partial products, folded in slab order
+#pragma unroll
+            for (int sl = 1; sl < MS; ++sl) if (sl < n1) p1 = add4(p1, t1[u][c][sl]);
+            for (int sl = MS; sl < n1; ++sl) p1 = add4(p1, ld4(a.pre1 + sl * a.pre_stride + row * ldh + col));
+#pragma unroll
+            for (int sl = 1; sl < MS; ++sl) if (sl < n2) p2 = add4(p2, t2[u][c][sl]);
+            for (int sl = MS; sl < n2; ++sl) p2 = add4(p2, ld4(a.pre2 + sl * a.pre_stride + row * ldh + col));
+            st4(a.pre1_out + row * ldh + col, p1);
+            st4(a.pre2_out + row * ldh + col, p2);
+          }
+          s1 += dot4(mask4(sig4(p1), col, H), w1[c]);
+          s3 += dot4(mask4(sig4(p2), col, H), w2[c]);
+          if (!late_q) s2 += dot4(ya[u][c], qa[c]) + dot4(yb[u][c], qb[c]);
+        }
+      }
+      s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+      if (lane == t) { e1 = s1; e2 = s2; e3 = s3; }
+      if constexpr (TC > 0) {
+#pragma unroll
+        for (int k = 0; k < TC; ++k)      // (t is a runtime value: a compare chain instead of a dynamically indexed register array)
+          if (k == t) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { xa[k][c] = ya[u][c]; xb[k][c] = yb[u][c]; }
+            xp[k][0] = yp[u][0]; xp[k][1] = yp[u][1];
+          }
+      }
+    }
   }
   if (late_q) {       // alpha2 scores X_ic . q (modules.py:140-141), behind the producer's flag: same sums in the same order
     tcar_wave_wait(a.wait_q);
@@ -130,7 +178,22 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
 #pragma unroll
   for (int c = 0; c < NCH; ++c) { pa[c] = zero4(); pb[c] = zero4(); }
   pp[0] = zero4(); pp[1] = zero4();
-  for (int t = 0; t < T; ++t) {
+#pragma unroll
+  for (int t = 0; t < TC; ++t) {             // positions whose rows are still in registers
+    if (t >= T) break;
+    const float wt = __shfl(a12, t), wt3 = __shfl(a3, t);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = c * 256 + lane * 4;
+      if (col < ldh) { pa[c] = fma4(xa[t][c], wt, pa[c]); pb[c] = fma4(xb[t][c], wt, pb[c]); }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int l4 = c * 64 + lane;
+      if (l4 < ptl) pp[c] = fma4(xp[t][c], wt3, pp[c]);
+    }
+  }
+  for (int t = TC; t < T; ++t) {
     const long row = (long)b * T + t;
     const float wt = __shfl(a12, t), wt3 = __shfl(a3, t);
 #pragma unroll
@@ -184,17 +247,36 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
       w2[c] = ok ? ld4(a.w2 + col) : zero4();
       qa[c] = ok ? ld4(a.q + (long)b * ic + col) : zero4();
       qb[c] = ok ? ld4(a.q + (long)b * ic + ldh + col) : zero4();
-      da[c] = ok ? ld4(dpo + col) : zero4();
-      db[c] = ok ? ld4(dpo + ldh + col) : zero4();
-      for (int sl = 1; sl < a.nd_ic; ++sl) {        // split-K partial products of the output transform's input gradient
+      // split-K partial products of the output transform's input gradient, folded in slab order; the first MS slabs' loads are
+      // issued together (round 4: the fold was a chain of dependent round trips)
+      constexpr int MS = 8;
+      float4 ta[MS], tb[MS];
+#pragma unroll
+      for (int sl = 0; sl < MS; ++sl) {
+        const bool on = ok && (sl == 0 || sl < a.nd_ic);
+        ta[sl] = on ? ld4(dpo + sl * a.dp_stride + col) : zero4();
+        tb[sl] = on ? ld4(dpo + sl * a.dp_stride + ldh + col) : zero4();
+      }
+      da[c] = ta[0]; db[c] = tb[0];
+#pragma unroll
+      for (int sl = 1; sl < MS; ++sl)
+        if (ok && sl < a.nd_ic) { da[c] = add4(da[c], ta[sl]); db[c] = add4(db[c], tb[sl]); }
+      for (int sl = MS; sl < a.nd_ic; ++sl) {
         if (ok) { da[c] = add4(da[c], ld4(dpo + sl * a.dp_stride + col)); db[c] = add4(db[c], ld4(dpo + sl * a.dp_stride + ldh + col)); }
       }
     }
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int l4 = c * 64 + lane;
-      dp[c] = (l4 < ptl) ? ld4(dpo + ic + l4 * 4) : zero4();
-      for (int sl = 1; sl < a.nd_pt; ++sl)
+      constexpr int MS = 8;
+      float4 tp[MS];
+#pragma unroll
+      for (int sl = 0; sl < MS; ++sl) tp[sl] = (l4 < ptl && (sl == 0 || sl < a.nd_pt)) ? ld4(dpo + sl * a.dp_stride + ic + l4 * 4) : zero4();
+      dp[c] = tp[0];
+#pragma unroll
+      for (int sl = 1; sl < MS; ++sl)
+        if (l4 < ptl && sl < a.nd_pt) dp[c] = add4(dp[c], tp[sl]);
+      for (int sl = MS; sl < a.nd_pt; ++sl)
         if (l4 < ptl) dp[c] = add4(dp[c], ld4(dpo + sl * a.dp_stride + ic + l4 * 4));
     }
     const bool on = lane < T;
