@@ -54,7 +54,7 @@ typedef struct {
   int32_t sort_scatter;     /* TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum */
   int32_t bf16_ks;          /* TCAR_BF16_KS        64-deep LDS stages of the hi-only bf16 GEMM: 1 never, 2 dX / logits layouts, 3 all */
   int32_t det_small;        /* TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode) */
-  int32_t x3_oneshot;       /* TCAR_X3_ONESHOT     0: short-K small-GEMM launches keep the one-stage register ring */
+  int32_t x3_oneshot;       /* TCAR_X3_ONESHOT     n: small-GEMM launches of at most max(n, 2) 64-deep stages per workgroup keep two stages in flight; 0: one */
   int32_t fused_ce;         /* TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel */
   int32_t onehot_time;      /* TCAR_ONEHOT_TIME    0: the scoring GEMMs of a training step contract the 5 ldt clipped candidate time columns instead of the 160-column one-hot form */
   int32_t proj_split;       /* TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs */

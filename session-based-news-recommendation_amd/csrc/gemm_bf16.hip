@@ -545,8 +545,8 @@ int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
       return TCAR_E_ARG;
     }
   }
-  TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS>), lds);
-  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
+  TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 0, 0, VAR>), lds);
+  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 0, 0, VAR>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -558,7 +558,7 @@ int launch_v(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
   // (TCAR_BF16_KS: 1 = never, 2 = k-contiguous A operand only, 3 = always)
   if constexpr (NSPLIT == 1) {
     const int ks = tcar_tn(lc.o).bf16_ks;
-    if (ks == 3 || (ks == 2 && MA == 0)) return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 2>(g, splitk, st, lc);
+    if (ks == 3 || (ks == 2 && MA == 0)) return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 2, VAR>(g, splitk, st, lc);
   }
   return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 1, VAR>(g, splitk, st, lc);
 }
@@ -589,6 +589,12 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st, LaunchCall& lc) {
     // 512 x 128 (16 waves): the whole session batch is ONE M tile, so every dlogits stage is fetched once per N tile and
     // the fill bytes per flop drop 16 % against two 256 x 128 tiles (dX: 170 -> 147 us at split-K 36)
     const long w512 = (long)((g.M + 511) / 512) * ((g.N + 127) / 128) * splitk;
+#ifdef TCAR_GEMM_DIAG
+    if (nsplit == 1 && f == 1002) return launch_v<0, 1, 1, 8, 2, 2, 2, 2>(g, splitk, st, lc);
+    if (nsplit == 1 && f == 1003) return launch_v<0, 1, 1, 8, 2, 2, 2, 3>(g, splitk, st, lc);
+    if (nsplit == 1 && f == 1006) return launch_v<0, 1, 1, 8, 2, 2, 2, 6>(g, splitk, st, lc);
+    if (nsplit == 1 && f == 1008) return launch_v<0, 1, 1, 8, 2, 2, 2, 8>(g, splitk, st, lc);
+#endif
     if (f == 512 || (f == 0 && g.M > 256 && w512 >= 192))
       return nsplit == 3 ? launch_v<0, 1, 3, 8, 2>(g, splitk, st, lc) : launch_v<0, 1, 1, 8, 2>(g, splitk, st, lc);
   }
