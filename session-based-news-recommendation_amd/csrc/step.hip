@@ -22,7 +22,7 @@ const Switch kSwitches[] = {
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
     {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
-    {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},
+    {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_REST_EARLY", &TcarTuning::rest_early, 0},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -359,6 +359,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
                          c->q, (void*)sq, &oq));
     if (!fork_commit(c, FK_QUERY, oq)) return TCAR_E_LAUNCH;
   }
+  RET(hook(3, &og));        // (the deferred update's rest pass may fork here, off the gather's flag)
   // without the side stream (multi-rank engines, contexts without the flag words): the same ONE launch on this stream in
   // place of the two small GEMMs of the split-bf16 modes
   const bool qfused = qside || (g.ldh == 256 && g.ldt == 64 && c->scoring != 0);
@@ -557,6 +558,15 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       // three interleaved rounds: 0.6158 ms per step against 0.6213 forked at once and 0.628 forked behind the query MLP.
       rest_stage = 1;
       joined = false;
+      // Round 4 (last session), re-measured on the shorter head (TCAR_REST_EARLY, one box, ms per step): behind the projections
+      // 0.4687 0.4683 0.4677 | = 1, behind the GATHER (hook stage 3: a second poll of the flag the gather publishes for the click-query
+      // stream) 0.4802 0.4759 0.4798 | = 2, at once behind an event 0.4671 0.4689 0.4745 -> the placement stays
+      if (oh_bwd && tn(c).rest_early == 1) rest_stage = 3;
+      if (oh_bwd && tn(c).rest_early == 2) {        // at once, in front of the gather, behind an event of the main stream
+        if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess) return TCAR_E_LAUNCH;
+        RET(launch_rest());
+        rest_stage = -1;
+      }
     } else {
       if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
         return TCAR_E_LAUNCH;
@@ -580,6 +590,13 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   const bool onehot = ce_epi && onehot_fwd(c, B);
   ScoreOut so{c->p16h, c->p16l, oh_bwd ? c->tclip : nullptr, false};
   RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage, TcarOpt* o) -> int {
+    if (stage == 3) {                      // behind the gather launch (o = its options: the flag it took, if any)
+      if (rest_stage != 3) return TCAR_OK;
+      if (!fork_live(c, FK_GATHER)) { rest_stage = 1; return TCAR_OK; }      // no flag on the gather: behind the projections, as before
+      RET(fork_go(c, FK_GATHER, s1, s2, c->ev[0]));       // (the rest pass reads nothing the gather writes: timing only)
+      rest_stage = -1;
+      return launch_rest();
+    }
     if (rest_stage == 1 && stage == 0) o->sig = fork_arm(c, FK_PROJ);        // the projection launch carries the flag
     if (stage != rest_stage) return TCAR_OK;
     // late fork: the HBM-bound rest pass starts only now, so the launches before this point ran without it
