@@ -574,7 +574,8 @@ int tcar_layernorm_bwd(int64_t M, int C, const float* x, const float* gamma, con
 
 /* Split update.  tcar_clip_adam_early: tcar_clip_adam over the arena segments plus the item rows listed in `ids` (1-based
  * item ids, repeats allowed: a bit per row in `bitmap` — zero on entry — makes every row update exactly once);
- * tcar_clip_adam_rest: every item row whose bit is clear, then clears the bitmap.  Together they equal
+ * tcar_clip_adam_rest: every item row whose bit is clear, then clears the bitmap — `bitmap` holds ceil(rows / 32) words rounded UP to
+ * a multiple of 16 (whole 64-byte units: the clear is one fill).  Together they equal
  * tcar_clip_adam_all; the step driver runs the second on the aux stream beside the next forward pass. */
 int tcar_clip_adam_early(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,
                          const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot,
@@ -724,7 +725,7 @@ typedef struct {
   /* optional auxiliary stream + 4 events (hipStream_t / hipEvent_t, caller-created): the candidate-side time refresh
    * (forward) and the dE chain (backward) run on it concurrently with the session-side chain; NULL = one stream */
   void* stream2; void* ev[6];
-  uint32_t* adam_bitmap;    /* [ceil(N/32) + 1] zeroed words: rows already updated by the early pass of a split update */
+  uint32_t* adam_bitmap;    /* [ceil16(ceil(N/32))] zeroed words (whole 64-byte units): rows already updated by the early pass of a split update */
   const int32_t* et_perm;   /* [5, N] position of (k, n) in the inverted index (bf16 scoring modes: dE writes d_et in that order) */
   /* optional device timing of the three full-catalog GEMMs, of the largest session-side small GEMM and of the gather: ev_start /
    * ev_stop hold 5 * ev_n hipEvent_t each ([kind][slot]: kind 0 = logits, 1 = dX = dlogits E, 2 = dE = dlogits^T attout, 3 = the

@@ -251,6 +251,8 @@ __device__ __forceinline__ void item_adam_blocks(int blk, int nblk, float* __res
                                                  __bf16* __restrict__ eh, __bf16* __restrict__ el, long ld16,
                                                  const uint32_t* __restrict__ skip = nullptr) {
   const float sc = clip_factor(sqn_dense, sqn_pieces, use_dense, slot, clip);
+  // (eight columns per thread — eight 16-byte loads in flight, 16-byte plane stores — measured SLOWER for the streaming rest pass:
+  //  85 against 65-70 us, profiles/r04_ab_experiments.txt)
   const int c4 = cols >> 2;
   const long total = rows * c4;
   for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)nblk * 256) {
@@ -559,7 +561,7 @@ extern "C" int tcar_clip_adam_rest(float* w2d, int64_t ldw, const float* g2d, fl
                                           b2, eps, e16_hi, e16_lo, ld16, bitmap, stream);
   if (rc) return rc;
   // every row is up to date now: clear the marks for the next step (stream ordered behind the kernel)
-  if (hipMemsetAsync(bitmap, 0, (size_t)((rows + 31) / 32) * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
+  if (hipMemsetAsync(bitmap, 0, (size_t)(((rows + 31) / 32 + 15) & ~15) * sizeof(uint32_t), (hipStream_t)stream) != hipSuccess)
     return TCAR_E_LAUNCH;
   return TCAR_OK;
 }

@@ -530,7 +530,8 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
                                    c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2, tn(c).rest_grid));
     if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
     // the marks are cleared BEHIND the event the logits GEMM waits for (the clear is a launch of its own)
-    if (hipMemsetAsync(c->adam_bitmap, 0, (size_t)((g.N + 31) / 32) * sizeof(uint32_t), s2) != hipSuccess) return TCAR_E_LAUNCH;
+    // (the map is allocated in whole 64-byte units, tcar_hip.h: ONE fill kernel — a size that is no multiple of 16 bytes costs a second one)
+    if (hipMemsetAsync(c->adam_bitmap, 0, (size_t)(((g.N + 31) / 32 + 15) & ~15) * sizeof(uint32_t), s2) != hipSuccess) return TCAR_E_LAUNCH;
     return TCAR_OK;
   };
   if (refresh_time) {

@@ -216,7 +216,7 @@ class TcarEngine:
         et_perm = np.empty(5 * nl, dtype=np.int32)
         et_perm[order] = np.arange(5 * nl, dtype=np.int32)
         self.et_perm = torch.tensor(et_perm, device=self.dev)
-        self.adam_bitmap = torch.zeros((nl + 31) // 32 + 1, dtype=torch.int32, device=self.dev)   # split update marks
+        self.adam_bitmap = torch.zeros(((nl + 31) // 32 + 15) // 16 * 16, dtype=torch.int32, device=self.dev)   # split update marks, whole 64-byte units
         self.ct_ws = torch.zeros(self.lib.tcar_cand_time_ws_floats(C.byref(self.dims_cand)), **f32)
         # segment tables for the optimizer kernels
         self.segs_all = self._segments([a[0] for a in ARENA])

@@ -1364,7 +1364,7 @@ def test_split_adam_kernels_equal_the_single_launch_bitwise(lib):
         dG, dGi = t(G), t(Gi)
         eh = torch.zeros(Npad * ek, dtype=torch.bfloat16, device="cuda")
         el = torch.zeros_like(eh)
-        bm = torch.zeros((N + 31) // 32 + 1, dtype=torch.int32, device="cuda")
+        bm = torch.zeros(((N + 31) // 32 + 15) // 16 * 16, dtype=torch.int32, device="cuda")      # whole 64-byte units (tcar_hip.h)
         pieces = C.c_void_p(dG.data_ptr() + 4 * arena_n)
         if split:
             assert lib.tcar_clip_adam_early(ptr(W), ptr(dG), ptr(M), ptr(V), C.byref(segs), ptr(E), ek, ptr(dGi), ptr(Mi), ptr(Vi),
