@@ -428,7 +428,7 @@ def main():
     if hasattr(eng, "exchange_info"):
         exchange = eng.exchange_info()        # after the timed steps: carries the bytes each collective moved per step
     value = B * world * args.steps / dt
-    eng_splitk = getattr(eng, "splitk", 36)
+    eng_splitk = getattr(eng, "splitk", 18)
 
     # ---- roofline of the three full-catalog GEMMs, timed live inside the timed steps -------------------------------
     Ht = args.time_hidden_size

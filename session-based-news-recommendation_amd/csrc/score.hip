@@ -495,12 +495,12 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
     if (row < M) {
       const float* sp = slabs + (long)row * lds_ + col;
       int k = 0;
-      for (; k + 12 <= S; k += 12) {
-        float4 t[12];
+      for (; k + 9 <= S; k += 9) {           // (18 slabs by default: two rounds of nine loads in flight, no dependent tail)
+        float4 t[9];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) t[j] = ld4(sp + (long)(k + j) * M * lds_);
+        for (int j = 0; j < 9; ++j) t[j] = ld4(sp + (long)(k + j) * M * lds_);
 #pragma unroll
-        for (int j = 0; j < 12; ++j) acc = add4(acc, t[j]);
+        for (int j = 0; j < 9; ++j) acc = add4(acc, t[j]);
       }
       for (; k < S; ++k) acc = add4(acc, ld4(sp + (long)k * M * lds_));
     }

@@ -151,7 +151,12 @@ class TcarEngine:
         self.b1_pow, self.b2_pow = np.float32(self.b1), np.float32(self.b2)
         self.step = 0
         # split-K of dX = dlogits E: 36 slabs with the 512 x 128 bf16 tile (7 N tiles x 36 = 252 workgroups), 16 in fp32
-        self.splitk = splitk if splitk else (16 if scoring == "f32" else 36)
+        # split-K of the dX GEMM (bf16 modes): 18 slabs of 256 x 128 tiles = 216 workgroups at B = 512 — the same grid as 36 slabs of
+        # 512 x 128 tiles, half the slab bytes for the GEMM to write and the slab reduce to read back (round 4: -9 us per step at the
+        # Globo, Adressa and MIND shapes; 12 / 16 / 20 / 24 measured worse, profiles/r04_ab_experiments.txt)
+        # (the materialised-logits modes — bf16x3, bf16 — contract 832 columns with other tiles: 36 stays better there, 0.649 / 0.509
+        #  against 0.671 / 0.517 ms per step)
+        self.splitk = splitk if splitk else (16 if scoring == "f32" else 18 if scoring == "bf16x3-mixed" else 36)
         if os.environ.get("TCAR_SPLITK"):
             self.splitk = int(os.environ["TCAR_SPLITK"])
         # precision of the three full-catalog scoring GEMMs: "f32" (fp32 MFMA), "bf16x3" (split-bf16 planes, three

@@ -18,7 +18,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 nsplit = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 N = int(os.environ.get("GB_N", 46033))
-SK = int(os.environ.get("GB_SPLITK", 36))
+SK = int(os.environ.get("GB_SPLITK", 18))
 B, Npad, EK = 512, (N + 127) // 128 * 128, 832
 bf = dict(dtype=torch.bfloat16, device="cuda")
 p = lambda t: C.c_void_p(t.data_ptr())

@@ -17,10 +17,10 @@ alg = {"fwd": planes * 2 * (Npad * EK + B * EK) + 4 * B * Npad,                 
        # one-hot form: item | content planes (512 columns, hi + lo) of E and attout, the one-hot plane (160 columns, ONE plane) and
        # the time-score planes (160 columns, hi + lo) in; bf16 exp plane + group statistics out
        "fwdce2": 4 * (Npad * 512 + B * 512) + 2 * Npad * 160 + 4 * B * 160 + 2 * B * Npad + 8 * B * (Npad // 96),
-       "dx": planes * 2 * (B * Npad + Npad * EK) + 4 * int(os.environ.get("GB_SPLITK", 36)) * B * EK,   # dlogits + E planes in, slabs out
+       "dx": planes * 2 * (B * Npad + Npad * EK) + 4 * int(os.environ.get("GB_SPLITK", 18)) * B * EK,   # dlogits + E planes in, slabs out
        "de": planes * 2 * (B * Npad + B * 576) + 4 * N * 576,                        # dlogits + packed attout planes in, dE out
        # one-hot form (hi planes): dlogits + item | content planes of E + the one-hot plane in, slabs of 672 columns out
-       "dx2": 2 * (B * Npad + Npad * 512 + Npad * 160) + 4 * int(os.environ.get("GB_SPLITK", 36)) * B * 672,
+       "dx2": 2 * (B * Npad + Npad * 512 + Npad * 160) + 4 * int(os.environ.get("GB_SPLITK", 18)) * B * 672,
        # dlogits + packed attout planes in; item block of dE + 5 (q, z) pairs per candidate out
        "de2": 2 * (B * Npad + B * 576) + 4 * N * 256 + 8 * 5 * N}[mode]
 flops = {"fwd": 2.0 * B * N * 820, "fwdce": 2.0 * B * N * 820, "fwdce2": 2.0 * B * N * 820, "dx": 2.0 * B * N * 820, "de": 2.0 * B * N * 570,
