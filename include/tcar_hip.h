@@ -72,6 +72,9 @@ typedef struct {
   int32_t rest_early;       /* TCAR_REST_EARLY     where the deferred Adam rest pass is forked: 0 (default) behind the projection launch, 1 behind the
                                                    step's gather (second poll of its flag), 2 at once behind an event — 1 and 2 measured
                                                    slower / equal (profiles/r04_ab_experiments.txt) */
+  int32_t wgrad_split;      /* TCAR_WGRAD_SPLIT    1: the weight-gradient GEMMs as two grouped launches on the third stream — eight problems
+                                                   behind the pool backward's flag, dW_q1 behind the input-gradient launch — instead of
+                                                   all nine behind the input-gradient launch.  Default 0: measured 15 us SLOWER per step */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
                                                    kernel of the side stream waits for */
@@ -675,7 +678,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
                         const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 23
+#define TCAR_ABI_VERSION 24
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */

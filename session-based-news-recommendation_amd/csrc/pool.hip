@@ -329,12 +329,14 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
           gw1[c] = fma4(s1, g1, gw1[c]);
           gw2[c] = fma4(s2, g3, gw2[c]);
           // dpre = de * w * sig * (1 - sig)   (0 in padding columns: w = 0 there and sig is masked)
-          st4(a.dpre1 + row * ldh + col,
-              make_float4(g1 * w1[c].x * s1.x * (1.f - s1.x), g1 * w1[c].y * s1.y * (1.f - s1.y),
-                          g1 * w1[c].z * s1.z * (1.f - s1.z), g1 * w1[c].w * s1.w * (1.f - s1.w)));
-          st4(a.dpre2 + row * ldh + col,
-              make_float4(g3 * w2[c].x * s2.x * (1.f - s2.x), g3 * w2[c].y * s2.y * (1.f - s2.y),
-                          g3 * w2[c].z * s2.z * (1.f - s2.z), g3 * w2[c].w * s2.w * (1.f - s2.w)));
+          const float4 dp1 = make_float4(g1 * w1[c].x * s1.x * (1.f - s1.x), g1 * w1[c].y * s1.y * (1.f - s1.y),
+                                         g1 * w1[c].z * s1.z * (1.f - s1.z), g1 * w1[c].w * s1.w * (1.f - s1.w));
+          const float4 dp2 = make_float4(g3 * w2[c].x * s2.x * (1.f - s2.x), g3 * w2[c].y * s2.y * (1.f - s2.y),
+                                         g3 * w2[c].z * s2.z * (1.f - s2.z), g3 * w2[c].w * s2.w * (1.f - s2.w));
+          // (a launch that carries a completion flag stores what the flag's consumers read write-through: dq below for the fused
+          //  click-query backward, dpre1 / dpre2 for the weight gradients forked off this launch — tcar_common.h)
+          if (a.sig.cnt) { st4_sc1(a.dpre1 + row * ldh + col, dp1); st4_sc1(a.dpre2 + row * ldh + col, dp2); }
+          else { st4(a.dpre1 + row * ldh + col, dp1); st4(a.dpre2 + row * ldh + col, dp2); }
         }
       }
 #pragma unroll

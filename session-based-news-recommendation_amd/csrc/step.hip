@@ -23,6 +23,7 @@ const Switch kSwitches[] = {
     {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
     {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_REST_EARLY", &TcarTuning::rest_early, 0},
+    {"TCAR_WGRAD_SPLIT", &TcarTuning::wgrad_split, 0},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -668,7 +669,9 @@ namespace {
 // The nine weight gradients x^T dy (K = batch rows, model_combine.py:156): ONE grouped launch.  K is not split up to wgrad_ks
 // (1,536) rows; longer batches split it — into slabs folded in split order when the context has the workspace (order-fixed:
 // tcar_fold_slabs), else with float atomics into the zeroed arena.
-int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream, TcarOpt* o = nullptr) {
+// part: 0 = all nine problems; 1 = the eight that need nothing of the input-gradient launch (dattout, dq, dpre1, dpre2: ready behind
+// the pool backward); 2 = dW_q1 = click_t^T dq1 alone (dq1 comes out of the input-gradient launch)
+int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream, TcarOpt* o = nullptr, int part = 0) {
   const int ksdiv = tn(c).wgrad_ks > 0 ? tn(c).wgrad_ks : 1536;
   auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
   const int kb = ks(B), kr = ks(BT);
@@ -701,8 +704,25 @@ int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream,
       at += (int64_t)p[i].splitk * p[i].M * p[i].N;
     }
   }
-  RET(small_gemm(c, 2, 9, p, stream, o));
-  if (nf) RET(tcar_fold_slabs(nf, f, stream));
+  if (part == 0) {
+    RET(small_gemm(c, 2, 9, p, stream, o));
+    if (nf) RET(tcar_fold_slabs(nf, f, stream));
+    return TCAR_OK;
+  }
+  tcar_gemm_desc_t q[9];
+  tcar_fold_t fq[9];
+  int nq = 0, nfq = 0, fi = 0;
+  for (int i = 0; i < 9; ++i) {
+    const bool split = p[i].splitk > 1 && nf > 0;
+    const bool mine = (part == 2) == (i == 3);
+    if (mine) {
+      q[nq++] = p[i];
+      if (split) fq[nfq++] = f[fi];
+    }
+    if (split) ++fi;
+  }
+  RET(small_gemm(c, 2, nq, q, stream, o));
+  if (nfq) RET(tcar_fold_slabs(nfq, fq, stream));
   return TCAR_OK;
 }
 
@@ -898,14 +918,30 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // chain's grouped launch keeps the three input-gradient GEMMs only (K = 256: 4 stages instead of the 8 of the dq1 product)
   const bool qb = detc && tn(c).qbwd_fused == 1 && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
                   tn(c).det_small != 0;
+  // Weight gradients in two launches (TCAR_WGRAD_SPLIT = 1; measured, OFF): eight of the nine problems need only what exists behind
+  // the pool backward — they can start on the third stream behind ITS flag, ~25 us before the input-gradient launch ends; dW_q1
+  // (needs dq1) follows behind that launch.  The third stream's chain (weight gradients -> column sums -> dense norms) is the
+  // step's last by ~15 us, but the early launch runs beside the main chain's input-gradient GEMM and slows it by more:
+  // 0.4618 0.4607 0.4653 against 0.4470 0.4462 0.4466 ms per step (profiles/r04_ab_experiments.txt).  Flag forks only; needs the
+  // negative rows on the third stream (their wait for dE orders it behind the arena zero).
+  const bool wsplit = detc && !qb && tn(c).wgrad_split && s2 && fuse_finish && c->stream3 && c->ev3 && neg_s3 && fork_host(c) &&
+                      ((tn(c).flag_fork >> FK_POOLB) & 1) && ((tn(c).flag_fork >> FK_INGRAD) & 1);
+  bool wgrad_early = false;
   if (detc) {
     TcarOpt opb = opt_of(c);
-    if (qb) opb.sig = fork_arm(c, FK_POOLB);
+    if (qb || wsplit) opb.sig = fork_arm(c, FK_POOLB);
     else fork_disarm(c, FK_POOLB);
     RET(tcar_attn_pool_bwd_slabs_o(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
                                    c->alpha, dsplit ? c->proj_slabs : c->dpooled, dsplit ? nd_ic : 1, dsplit ? nd_pt : 1, dstride,
                                    c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream, &opb));
     (void)fork_commit(c, FK_POOLB, opb);
+    if (wsplit && fork_live(c, FK_POOLB)) {
+      hipStream_t s3w = (hipStream_t)c->stream3;
+      RET(fork_go(c, FK_POOLB, st, s3w, c->ev[0]));
+      TcarOpt ow1 = opt_of(c);
+      RET(weight_grads(c, g, B, BT, (void*)s3w, &ow1, 1));
+      wgrad_early = true;
+    }
   }
   else
     RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
@@ -971,7 +1007,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // (it needs dq1 of that launch) — off the main chain (round 4: 17 us) and off the third stream, whose weight gradients, column
   // sums and norms are the step's last chain
   const bool dclick_aux = fusedq && det_small && s3 != nullptr && !qb;
-  RET(weight_grads(c, g, B, BT, sW, &ow));
+  RET(weight_grads(c, g, B, BT, sW, &ow, wgrad_early ? 2 : 0));
   if (detc) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
