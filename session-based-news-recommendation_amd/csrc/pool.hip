@@ -13,6 +13,7 @@
 // re-reads the T rows (L2 hits: they were just read for the scores).  Everything stays in registers — no LDS,
 // no cross-wave traffic.  This is the only softmax-attention on the executed graph (a single query per session),
 // far too small for MFMA: it is bound by the row reads.
+#include <type_traits>
 #include "tcar_common.h"
 
 namespace {
@@ -283,9 +284,48 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
     const float a1 = on ? a.alpha_in[(long)b * T + lane] : 0.f;
     const float a2 = on ? a.alpha_in[(long)BT + (long)b * T + lane] : 0.f;
     const float a3 = on ? a.alpha_in[2L * BT + (long)b * T + lane] : 0.f;
+    // the rows of the first TC positions — item | content, publish time, both pre-activations — are fetched ONCE, all loads issued
+    // together, and serve both passes (round 4: each pass walked the positions with dependent loads)
+    constexpr int TC = (NCH == 1) ? 4 : 0;
+    float4 xa[TC > 0 ? TC : 1][NCH], xb[TC > 0 ? TC : 1][NCH], xp[TC > 0 ? TC : 1][2], r1[TC > 0 ? TC : 1][NCH], r2[TC > 0 ? TC : 1][NCH];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      const long row = (long)b * T + t;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = t < T && col < ldh;
+        xa[t][c] = ok ? ld4(a.x_icp + row * ic + col) : zero4();
+        xb[t][c] = ok ? ld4(a.x_icp + row * ic + ldh + col) : zero4();
+        r1[t][c] = ok ? ld4(a.pre1 + row * ldh + col) : zero4();
+        r2[t][c] = ok ? ld4(a.pre2 + row * ldh + col) : zero4();
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int l4 = c * 64 + lane;
+        xp[t][c] = (t < T && l4 < ptl) ? ld4(a.x_pt + row * pt + l4 * 4) : zero4();
+      }
+    }
     // pass A: d alpha[t] = dpooled . X[t]   (alpha1 and alpha2 share it: alpha = alpha1 + alpha2)
     float dal = 0.f, dal3 = 0.f;
-    for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      if (t >= T) break;
+      float s = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) s += dot4(xa[t][c], da[c]) + dot4(xb[t][c], db[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int l4 = c * 64 + lane;
+        if (l4 < ptl) s3 += dot4(xp[t][c], dp[c]);
+      }
+      s = wave_sum(s); s3 = wave_sum(s3);
+      if (lane == t) { dal = s; dal3 = s3; }
+    }
+    for (int t = TC; t < T; ++t) {
       const long row = (long)b * T + t;
       float s = 0.f, s3 = 0.f;
 #pragma unroll
@@ -311,7 +351,9 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
     float4 dqa[NCH], dqb[NCH], gw1[NCH], gw2[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { dqa[c] = zero4(); dqb[c] = zero4(); gw1[c] = zero4(); gw2[c] = zero4(); }
-    for (int t = 0; t < T; ++t) {
+    auto pass_b = [&](int t, auto cached_) __attribute__((always_inline)) {
+      constexpr bool CACHED = decltype(cached_)::value;
+      const int tc = CACHED ? t : 0;
       const long row = (long)b * T + t;
       const float wt = __shfl(a12, t), wt3 = __shfl(a3, t);
       const float g1 = __shfl(de1, t), g2 = __shfl(de2, t), g3 = __shfl(de3, t);
@@ -319,13 +361,14 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
       for (int c = 0; c < NCH; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < ldh) {
-          const float4 xa = ld4(a.x_icp + row * ic + col), xb = ld4(a.x_icp + row * ic + ldh + col);
+          const float4 xa_ = CACHED ? xa[tc][c] : ld4(a.x_icp + row * ic + col);
+          const float4 xb_ = CACHED ? xb[tc][c] : ld4(a.x_icp + row * ic + ldh + col);
           st4(a.dx_icp + row * ic + col, fma4(qa[c], g2, scale4(da[c], wt)));
           st4(a.dx_icp + row * ic + ldh + col, fma4(qb[c], g2, scale4(db[c], wt)));
-          dqa[c] = fma4(xa, g2, dqa[c]);
-          dqb[c] = fma4(xb, g2, dqb[c]);
-          const float4 s1 = mask4(sig4(ld4(a.pre1 + row * ldh + col)), col, H);
-          const float4 s2 = mask4(sig4(ld4(a.pre2 + row * ldh + col)), col, H);
+          dqa[c] = fma4(xa_, g2, dqa[c]);
+          dqb[c] = fma4(xb_, g2, dqb[c]);
+          const float4 s1 = mask4(sig4(CACHED ? r1[tc][c] : ld4(a.pre1 + row * ldh + col)), col, H);
+          const float4 s2 = mask4(sig4(CACHED ? r2[tc][c] : ld4(a.pre2 + row * ldh + col)), col, H);
           gw1[c] = fma4(s1, g1, gw1[c]);
           gw2[c] = fma4(s2, g3, gw2[c]);
           // dpre = de * w * sig * (1 - sig)   (0 in padding columns: w = 0 there and sig is masked)
@@ -344,7 +387,13 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
         const int l4 = c * 64 + lane;
         if (l4 < ptl) st4(a.dx_pt + row * pt + l4 * 4, scale4(dp[c], wt3));
       }
+    };
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      if (t >= T) break;
+      pass_b(t, std::true_type{});
     }
+    for (int t = TC; t < T; ++t) pass_b(t, std::false_type{});
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
