@@ -207,10 +207,20 @@ __global__ __launch_bounds__(256) void ce_combine_kernel(int B, int ngroups, con
 // CONTIGUOUS plane (16 rows x 64 bytes) and the CE_KPT loads of a thread are independent (round 4: one thread per 64-byte row
 // read its four pieces with four instructions of 64-byte lane stride — 26 us for the 94 MB of the Globo plane).
 constexpr int CE_KPT = 4;
+// (a launch that carries a completion flag — the fork to the dE GEMM's stream — stores the plane write-through; tcar_common.h)
+__device__ __forceinline__ void ce_store16(uint4* p, uint4 v, bool wt) {
+  if (wt) {
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    const u4_t x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(x) : "memory");
+  } else {
+    *p = v;
+  }
+}
 template <int GW>
 __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
                                                 const float* __restrict__ rowstat, const int32_t* __restrict__ label,
-                                                __bf16* __restrict__ plane, long nunits, int lab_off, int lab_window) {
+                                                __bf16* __restrict__ plane, long nunits, int lab_off, int lab_window, bool wt) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= nunits) return;
   const int q = (int)(i & 3), r = (int)((i >> 2) & 127);
@@ -224,7 +234,7 @@ __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngro
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int j = 0; j < CE_KPT; ++j)
-      if (kb0 + j < in32) p[512 * j] = z;
+      if (kb0 + j < in32) ce_store16(p + 512 * j, z, wt);
     return;
   }
   uint4 v[CE_KPT];
@@ -256,14 +266,16 @@ __device__ __forceinline__ void ce_rescale_body(int B, int N, int in32, int ngro
       const __bf16 bl = (__bf16)lo, bh = (__bf16)hi;
       w[e] = (unsigned)__builtin_bit_cast(unsigned short, bl) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
     }
-    p[512 * j] = make_uint4(w[0], w[1], w[2], w[3]);
+    ce_store16(p + 512 * j, make_uint4(w[0], w[1], w[2], w[3]), wt);
   }
 }
 template <int GW>
 __global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
                                                          const float* __restrict__ rowstat, const int32_t* __restrict__ label,
-                                                         __bf16* __restrict__ plane, long nunits, int lab_off, int lab_window) {
-  ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits, lab_off, lab_window);
+                                                         __bf16* __restrict__ plane, long nunits, int lab_off, int lab_window,
+                                                         const TcarSignal sig) {
+  ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits, lab_off, lab_window, sig.cnt != nullptr);
+  tcar_signal_done(sig);        // (the body is a function: its early returns end up here)
 }
 // Catalog-sharded step: the shard's (max, sum exp, label score) per session from the epilogue's per-group pairs — the row of the
 // statistics all-gather (shard.hip: softmax_combine).  The label's score is 0 unless the label lies in [n0, n0 + n_loc).
@@ -861,8 +873,12 @@ int tcar_softmax_ce_bf16_o(int B, int N, float* logits, int64_t ld, const int32_
   return TCAR_OK;
 }
 
-extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit,
-                              const int32_t* label, float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream) {
+int tcar_ce_rescale_o(int B, int N, int group_width, int ngroups, const float* stats, const float* rowstat, const int32_t* label,
+                      int lab_off, int lab_window, void* dl_hi, int64_t inner, void* stream, TcarOpt* o);
+// (flag-capable: with a completion flag the rescale stores the plane write-through — what the flag's consumer, the dE GEMM on the aux
+//  stream, reads)
+int tcar_ce_finish_o(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
+                     float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream, TcarOpt* o) {
   if (B <= 0) return TCAR_OK;
   if (N <= 0 || !stats || !lab_logit || !label || !rowstat || !ce || !dl_hi || (inner & 31) || inner < N || ngroups <= 0 ||
       (group_width != 64 && group_width != 96) || (long)ngroups * group_width < N || ((uintptr_t)rowstat & 7))
@@ -870,14 +886,18 @@ extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const 
   hipStream_t st = (hipStream_t)stream;
   TCAR_LAUNCH(ce_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, ngroups, stats, lab_logit, rowstat, ce);
   TCAR_CHECK_LAUNCH();
-  return tcar_ce_rescale(B, N, group_width, ngroups, stats, rowstat, label, 0, 0, dl_hi, inner, stream);
+  return tcar_ce_rescale_o(B, N, group_width, ngroups, stats, rowstat, label, 0, 0, dl_hi, inner, stream, o);
+}
+extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit,
+                              const int32_t* label, float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream) {
+  return tcar_ce_finish_o(B, N, group_width, ngroups, stats, lab_logit, label, rowstat, ce, dl_hi, inner, stream, nullptr);
 }
 
 // second half of tcar_ce_finish on its own (catalog-sharded step: the row statistics come from the statistics exchange):
 // plane[b, n] = e[b, n] * exp(m_g - rowstat[b].x) * rowstat[b].y - [n == label[b] - lab_off]; lab_window != 0: a label outside
 // [lab_off, lab_off + N) belongs to another shard and nothing is subtracted
-extern "C" int tcar_ce_rescale(int B, int N, int group_width, int ngroups, const float* stats, const float* rowstat,
-                               const int32_t* label, int lab_off, int lab_window, void* dl_hi, int64_t inner, void* stream) {
+int tcar_ce_rescale_o(int B, int N, int group_width, int ngroups, const float* stats, const float* rowstat, const int32_t* label,
+                      int lab_off, int lab_window, void* dl_hi, int64_t inner, void* stream, TcarOpt* o) {
   if (B <= 0) return TCAR_OK;
   if (N <= 0 || !stats || !label || !rowstat || !dl_hi || (inner & 31) || inner < N || ngroups <= 0 ||
       (group_width != 64 && group_width != 96) || (long)ngroups * group_width < N || ((uintptr_t)rowstat & 7))
@@ -886,14 +906,19 @@ extern "C" int tcar_ce_rescale(int B, int N, int group_width, int ngroups, const
   const int in32 = (int)(inner >> 5);
   const long nunits = (((long)B + 127) >> 7) * ((in32 + CE_KPT - 1) / CE_KPT) * 512;
   const unsigned grid = (unsigned)((nunits + 255) / 256);
+  const TcarSignal sig = tcar_sig(o);
   if (group_width == 96)
     TCAR_LAUNCH(ce_rescale_kernel<96>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits,
-                lab_off, lab_window);
+                lab_off, lab_window, sig);
   else
     TCAR_LAUNCH(ce_rescale_kernel<64>, dim3(grid), dim3(256), 0, st, B, N, in32, ngroups, stats, rowstat, label, (__bf16*)dl_hi, nunits,
-                lab_off, lab_window);
+                lab_off, lab_window, sig);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
+}
+extern "C" int tcar_ce_rescale(int B, int N, int group_width, int ngroups, const float* stats, const float* rowstat,
+                               const int32_t* label, int lab_off, int lab_window, void* dl_hi, int64_t inner, void* stream) {
+  return tcar_ce_rescale_o(B, N, group_width, ngroups, stats, rowstat, label, lab_off, lab_window, dl_hi, inner, stream, nullptr);
 }
 
 extern "C" int tcar_ce_shard_stats(int B, int ngroups, const float* stats, const float* lab_logit, const int32_t* label, int n0,

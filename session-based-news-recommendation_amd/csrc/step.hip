@@ -179,7 +179,8 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
 // GEMM writes, and held back TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main
 // stream records nothing.
 enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_NEG = 8, FK_LOGITS = 9,
-       FK_POOLB = 10, FK_QBWD = 11 };
+       FK_POOLB = 10, FK_QBWD = 11,
+       FK_SOFTMAX = 12 };      // (softmax gradient -> dE's stream: bit 12 is NOT in the default mask — TCAR_FLAG_FORK=8191 turns it on)
 // host-side fork state of ONE context (tcar_ctx_t.fork_host: caller-owned, zeroed, tcar_fork_state_bytes() bytes)
 struct ForkSlot { TcarSignal sig; uint32_t live; uint32_t pad; };     // live: the launch armed last for this slot carries sig
 struct ForkHost { uint32_t epoch; uint32_t pad[3]; ForkSlot slot[TCAR_SIG_SLOTS]; };
@@ -784,13 +785,21 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   // hi-only backward (bf16x3-mixed, bf16): the lo plane of dlogits is never read — and not written
   CeWs cw;
-  if (ce_epilogue && fused_ce(c, B, &cw))   // the forward pass of THIS step ran the softmax epilogue (same predicate)
-    RET(tcar_ce_finish(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream));
+  bool sm_flag = false;
+  if (ce_epilogue && fused_ce(c, B, &cw)) { // the forward pass of THIS step ran the softmax epilogue (same predicate)
+    // (slot FK_SOFTMAX: the rescale launch publishes a flag for dE's stream and stores the plane write-through — instead of an event
+    //  record between it and dX on this stream)
+    TcarOpt os = opt_of(c);
+    if (s2) os.sig = fork_arm(c, FK_SOFTMAX);
+    RET(tcar_ce_finish_o(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream, &os));
+    sm_flag = s2 && fork_commit(c, FK_SOFTMAX, os);
+  }
   else if (c->scoring) RET(tcar_softmax_ce_bf16_o(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream, tn(c).softmax_variant));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   // (forking dE behind dX instead — dX then runs without dE beside it — was re-measured in round 4: dX is no faster alone, dE ends
   //  13 us later: 0.529 vs 0.516 ms per step, profiles/r04_ab_experiments.txt)
-  if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
+  if (s2 && sm_flag) RET(fork_go(c, FK_SOFTMAX, st, s2, c->ev[2]));
+  else if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;

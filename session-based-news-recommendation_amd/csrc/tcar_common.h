@@ -115,6 +115,8 @@ inline TcarSignal tcar_sig(TcarOpt* o) {       // the flag a flag-capable launch
 }
 // ---- internal (C++ linkage) forms of entry points that consult a switch or can carry a completion flag; the extern "C" names of
 // include/tcar_hip.h call them with the process snapshot and no flag
+int tcar_ce_finish_o(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
+                     float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream, TcarOpt* o);
 int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, float* x_icp, float* x_pt,
                            float* x_act, float* click_t, void* stream, TcarOpt* o);
 int tcar_query_mlp_o(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b, const float* q2_w,
