@@ -59,9 +59,10 @@ typedef struct {
   int32_t onehot_time;      /* TCAR_ONEHOT_TIME    0: the scoring GEMMs of a training step contract the 5 ldt clipped candidate time columns instead of the 160-column one-hot form */
   int32_t proj_split;       /* TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs */
   int32_t fork_delay;       /* TCAR_FORK_DELAY     us a DELAYED flag fork holds its consumer back behind the producer's end (step.hip) */
-  int32_t inkernel_wait;    /* TCAR_INKERNEL_WAIT  1: kernels that can wait for a producer's flag themselves do (attention pools: click query;
-                                                   slab reduce: negative term; candidate-side time gradients: dP) instead of sitting
-                                                   behind a polling kernel / an event.  Default 0: measured 9 us SLOWER per step */
+  int32_t inkernel_wait;    /* TCAR_INKERNEL_WAIT  MASK: kernels that can wait for a producer's flag themselves do, instead of sitting behind a
+                                                   polling kernel / an event — 1: attention pools (click query), 2: slab reduce (negative
+                                                   term), 4: candidate-side time gradients (dP).  Default 0: no bit measured faster
+                                                   (profiles/r04_ab_experiments.txt) */
   int32_t qbwd_fused;       /* TCAR_QBWD_FUSED     the click-query MLP's input gradients: 0 = two small GEMMs (dq1 in the main chain's grouped
                                                    launch, dclick in front of the small tables); 1 = ONE launch on the third stream
                                                    (tcar_query_mlp_bwd; measured slower); 2 (default) = dq1 as in 0, dclick by the layer-1

@@ -151,7 +151,19 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
       const int col = c * 256 + lane * 4;
       if (col < ldh) { qa[c] = ld4_sc1(a.q + (long)b * ic + col); qb[c] = ld4_sc1(a.q + (long)b * ic + ldh + col); }
     }
-    for (int t = 0; t < T; ++t) {
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {          // (rows still in registers)
+      if (t >= T) break;
+      float s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) s2 += dot4(xa[t][c], qa[c]) + dot4(xb[t][c], qb[c]);
+      }
+      s2 = wave_sum(s2);
+      if (lane == t) e2 = s2;
+    }
+    for (int t = TC; t < T; ++t) {
       const long row = (long)b * T + t;
       float s2 = 0.f;
 #pragma unroll

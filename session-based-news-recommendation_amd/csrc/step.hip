@@ -411,7 +411,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   // after its slab fold and alpha1 / alpha_t scores, so the wait overlaps that work and no polling kernel sits on this stream:
   // ~8 us of launch + poll off the chain); otherwise a polling kernel / an event
   TcarWait wq{};
-  if (qside && split && tn(c).inkernel_wait) {
+  if (qside && split && (tn(c).inkernel_wait & 1)) {
     if (const ForkSlot* f = fork_live(c, FK_QUERY)) wq = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
   }
   if (qside && !wq.flag) {
@@ -776,7 +776,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // the slab reduce (negpart), which waits for the negative term's FLAG in-kernel when that launch carries one — then neither the
   // record (aux chain, in front of dE) nor the wait (main chain) exists.  Everything else that needs the zeroed arena sits behind
   // dE on its own stream (stream order / ev[4]).
-  const bool neg_flag = ohb && has_neg && c->gw_rows && c->stream3 && c->ev3 && tn(c).inkernel_wait && fork_live(c, FK_NEG) != nullptr;
+  const bool neg_flag = ohb && has_neg && c->gw_rows && c->stream3 && c->ev3 && (tn(c).inkernel_wait & 2) && fork_live(c, FK_NEG) != nullptr;
   if (s2 && !neg_flag && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
@@ -896,7 +896,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     // (the kernel waits for the reduce's flag ITSELF, behind its pass over the (q, z) lists: no polling kernel on the aux chain; its
     // per-table norm pieces are folded by the small tables' last launch: no launch of their own)
     TcarWait wdp{};
-    if (tn(c).inkernel_wait)
+    if (tn(c).inkernel_wait & 4)
       if (const ForkSlot* f = fork_live(c, FK_REDUCE)) wdp = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
     if (!wdp.flag) RET(fork_go(c, FK_REDUCE, st, s2, c->ev[5]));
     tcar_grads_t gr;
