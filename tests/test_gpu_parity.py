@@ -820,6 +820,41 @@ def test_flag_and_event_forks_agree_bitwise_over_a_long_run():
         assert np.array_equal(runs[0][1][k], runs[1][1][k]), k
 
 
+def test_schedule_switches_of_round_4_agree_bitwise_with_the_default_schedule():
+    """The placement switches added late in round 4 change WHERE launches run, not what they compute: the Adam rest pass forked behind
+    the gather / at once (TCAR_REST_EARLY), the weight gradients as two launches (TCAR_WGRAD_SPLIT; the pool backward then carries a
+    flag and stores dpre1 / dpre2 write-through), the softmax gradient -> dE fork through a flag (fork slot 12: the rescale stores the
+    plane write-through), each in-kernel wait on its own (TCAR_INKERNEL_WAIT mask), the two-stage register ring for every small GEMM
+    (TCAR_X3_ONESHOT).  60 deferred steps at the benched size over batches of different lengths end in the same bits as the
+    default schedule: every loss, all variables, all Adam moments."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, K = 46033, 250, 64, 512, 20
+    params, content, mw, _ = _case(N, H, Ht, 8, 2, K, seed=29)
+    batches = [_case(N, H, Ht, B, T, K, seed=500 + T)[3] for T in (2, 1, 5, 3)]
+    variants = [{}, {"TCAR_REST_EARLY": 1}, {"TCAR_REST_EARLY": 2}, {"TCAR_WGRAD_SPLIT": 1}, {"TCAR_FLAG_FORK": 8191},
+                {"TCAR_INKERNEL_WAIT": 1}, {"TCAR_INKERNEL_WAIT": 2}, {"TCAR_INKERNEL_WAIT": 4}, {"TCAR_X3_ONESHOT": 100},
+                {"TCAR_X3_ONESHOT": 1}]
+    base = None
+    for sw in variants:
+        eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+        if sw:
+            eng.set_tuning(**sw)
+        res = [eng.make_resident(b) for b in batches]
+        losses = [eng.train_step(None, bt=res[i % len(res)], defer_update=True).clone() for i in range(60)]
+        eng.flush()
+        eng.check_forks()
+        run = (torch.stack([l[:B] for l in losses]).cpu().numpy(), eng.export_state())
+        del eng, res
+        torch.cuda.empty_cache()
+        if base is None:
+            base = run
+            continue
+        assert (base[0] == run[0]).all(), sw
+        for k in base[1]:
+            assert np.array_equal(base[1][k], run[1][k]), (sw, k)
+
+
 def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_runs(monkeypatch):
     """Re-entrancy of the boundary on the HOST (no global mutable state, per-device handles passed in).  Two
     engines of different shapes, each with its own context, fork words and streams, are stepped ALTERNATELY from two Python
