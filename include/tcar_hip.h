@@ -76,6 +76,8 @@ typedef struct {
   int32_t wgrad_split;      /* TCAR_WGRAD_SPLIT    1: the weight-gradient GEMMs as two grouped launches on the third stream — eight problems
                                                    behind the pool backward's flag, dW_q1 behind the input-gradient launch — instead of
                                                    all nine behind the input-gradient launch.  Default 0: measured 15 us SLOWER per step */
+  int32_t colsum_fused;     /* TCAR_COLSUM_FUSED   1 (default): the order-fixed column sums (bias / residual-weight gradients) and the dense-weight
+                                                   norms of a fused step in ONE launch instead of two — the end of the step's last chain */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
                                                    kernel of the side stream waits for */
@@ -679,7 +681,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
                         const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 24
+#define TCAR_ABI_VERSION 25
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */

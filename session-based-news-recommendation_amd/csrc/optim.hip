@@ -193,6 +193,106 @@ __global__ __launch_bounds__(1024) void colsum_det_kernel(const ColsumArgs a) {
   }
 }
 
+// ---- column sums AND the dense norms in ONE launch (the last two launches of the step's last chain) ------------------------------
+// Workgroups [0, ncs) are column-sum workgroups (as colsum_det_kernel); each also leaves the squared norm of the <= 64 gradient
+// elements it has just written.  Workgroups [ncs, ncs + nchunks) are norm chunks (as sqnorm_seg2_kernel) of the segments NO column
+// sum writes.  The last arrival folds every segment's partials in a fixed order — a column-sum segment from its column-sum
+// workgroups in workgroup order, the others from their chunks in chunk order — and adds once per segment.
+struct CsSqArgs {
+  Seg2Args sq;                       // first[] counts chunks of the chunked segments only
+  ColsumArgs cs;
+  int ncs;                           // column-sum workgroups
+  int seg_cs[TCAR_NSLOT];            // dense segment -> column-sum segment that writes it, or -1
+};
+__global__ __launch_bounds__(1024) void colsum_sqnorm_kernel(const float* __restrict__ g, const CsSqArgs a, float* __restrict__ out,
+                                                             unsigned* __restrict__ scratch, const TcarSignal sig) {
+  __shared__ float sh[16][64];
+  __shared__ int last;
+  const int nblk = gridDim.x;
+  float partial = 0.f;               // (valid in thread 0)
+  if ((int)blockIdx.x < a.ncs) {
+    int seg = 0;
+    while (seg + 1 < a.cs.nseg && (int)blockIdx.x >= a.cs.first_block[seg + 1]) ++seg;
+    const int col = ((int)blockIdx.x - a.cs.first_block[seg]) * 64 + (threadIdx.x & 63);
+    const int phase = threadIdx.x >> 6;
+    const float* x = a.cs.x[seg];
+    const long ld = a.cs.ld[seg];
+    const int rows = a.cs.rows[seg];
+    const bool ok = col < a.cs.cols[seg];
+    float s = 0.f;
+    for (int r0 = phase; r0 < rows; r0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = r0 + 16 * j;
+        v[j] = (ok && r < rows) ? x[(long)r * ld + col] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    sh[phase][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (phase == 0) {                // the first wave: fold in phase order, write, norm of what was written
+      float val = 0.f;
+      if (ok) {
+        float t = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) t += sh[p][threadIdx.x];
+        val = a.cs.dst[seg][col] + t;
+        a.cs.dst[seg][col] = val;
+      }
+      partial = wave_sum(val * val);
+    }
+  } else {
+    const int chunk = (int)blockIdx.x - a.ncs;
+    int seg = 0;
+    while (seg + 1 < a.sq.s.nseg && chunk >= a.sq.first[seg + 1]) ++seg;
+    const long c0 = (long)(chunk - a.sq.first[seg]) * SQ_CHUNK;
+    const long len = a.sq.s.len[seg] - c0 < SQ_CHUNK ? a.sq.s.len[seg] - c0 : (long)SQ_CHUNK;
+    const float* p = g + a.sq.s.off[seg] + c0;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long e = (long)(i * 1024 + (int)threadIdx.x) * 4;
+      v[i] = (e < len) ? ld4(p + e) : zero4();
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sm += dot4(v[i], v[i]);
+    sm = wave_sum(sm);
+    if ((threadIdx.x & 63) == 0) sh[0][threadIdx.x >> 6] = sm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+      for (int w = 0; w < 16; ++w) t += sh[0][w];
+      partial = t;
+    }
+  }
+  float* part = reinterpret_cast<float*>(scratch + 1);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(part + blockIdx.x, partial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // release the partial, acquire everybody else's when this is the last arrival
+    const unsigned old = __hip_atomic_fetch_add(scratch, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = (old == (unsigned)nblk - 1u) ? 1 : 0;
+  }
+  __syncthreads();
+  if (last && threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    if (l < a.sq.s.nseg) {
+      float t = 0.f;
+      const int j = a.seg_cs[l];
+      if (j >= 0) {
+        for (int b = a.cs.first_block[j]; b < a.cs.first_block[j + 1]; ++b) t += __hip_atomic_load(part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        for (int c = a.sq.first[l]; c < a.sq.first[l + 1]; ++c) t += __hip_atomic_load(part + a.ncs + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      atomicAdd(out + a.sq.s.slot[l], t);                 // one add per segment
+    }
+    if (l == 0) __hip_atomic_store(scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // reusable by the next launch
+  }
+  tcar_signal_done(sig);
+}
+
 // One Adam element (TF-1 form) with EVERY rounding pinned (explicit mul / fma / div intrinsics): the update is
 // compiled into several kernels (all-in-one, early, rest, streaming rest) that must agree bit for bit, so nothing is left to the
 // compiler's per-kernel contraction choices.
@@ -580,6 +680,44 @@ extern "C" int tcar_colsum_det(int nseg, const tcar_colsum_t* segs, void* stream
   a.first_block[nseg] = blocks;
   a.nseg = nseg;
   TCAR_LAUNCH(colsum_det_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+// tcar_colsum_det + tcar_sqnorm in one launch (internal; the step driver's last chain).  Every column-sum destination must be the
+// START of one segment of `segs` (its gradient vector) with cols <= that segment's length; TCAR_E_ARG otherwise, or when the scratch
+// words of `o` do not hold 1 + workgroups — the caller then launches the two separately.  Flag-capable like tcar_sqnorm_o.
+int tcar_colsum_sqnorm_o(const float* g, const tcar_segments_t* segs, int ncs, const tcar_colsum_t* cs, float* sqn_dense, void* stream,
+                         TcarOpt* o) {
+  if (check_segs(segs) || !g || !sqn_dense || !tcar_aligned16(g) || ncs <= 0 || ncs > 8 || !cs || !o || !o->scratch || segs->nseg > 64)
+    return TCAR_E_ARG;
+  CsSqArgs a{};
+  a.sq.s = *segs;
+  for (int i = 0; i < TCAR_NSLOT; ++i) a.seg_cs[i] = -1;
+  int blocks = 0;
+  a.cs.nseg = ncs;
+  for (int j = 0; j < ncs; ++j) {
+    if (!cs[j].x || !cs[j].dst || cs[j].rows < 0 || cs[j].cols <= 0 || cs[j].ld < cs[j].cols) return TCAR_E_ARG;
+    int hit = -1;
+    for (int i = 0; i < segs->nseg; ++i)
+      if (g + segs->off[i] == cs[j].dst && cs[j].cols <= segs->len[i] && a.seg_cs[i] < 0) { hit = i; break; }
+    if (hit < 0) return TCAR_E_ARG;
+    a.seg_cs[hit] = j;
+    a.cs.x[j] = cs[j].x; a.cs.ld[j] = (long)cs[j].ld; a.cs.rows[j] = cs[j].rows; a.cs.cols[j] = cs[j].cols; a.cs.dst[j] = cs[j].dst;
+    a.cs.first_block[j] = blocks;
+    blocks += (cs[j].cols + 63) / 64;
+  }
+  a.cs.first_block[ncs] = blocks;
+  a.ncs = blocks;
+  int n = 0;
+  for (int i = 0; i < segs->nseg; ++i) {
+    a.sq.first[i] = n;
+    // (a column-sum segment whose vector is shorter than its segment: the rest of the segment is padding the arena keeps zero)
+    if (a.seg_cs[i] < 0) n += (int)((segs->len[i] + SQ_CHUNK - 1) / SQ_CHUNK);
+  }
+  a.sq.first[segs->nseg] = n;
+  if (blocks + n + 1 > o->scratch_words) return TCAR_E_ARG;
+  TCAR_LAUNCH(colsum_sqnorm_kernel, dim3(blocks + n), dim3(1024), 0, (hipStream_t)stream, g, a, sqn_dense, o->scratch, tcar_sig(o));
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

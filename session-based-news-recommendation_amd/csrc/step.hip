@@ -23,7 +23,7 @@ const Switch kSwitches[] = {
     {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
     {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_REST_EARLY", &TcarTuning::rest_early, 0},
-    {"TCAR_WGRAD_SPLIT", &TcarTuning::wgrad_split, 0},
+    {"TCAR_WGRAD_SPLIT", &TcarTuning::wgrad_split, 0},      {"TCAR_COLSUM_FUSED", &TcarTuning::colsum_fused, 1},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -728,13 +728,18 @@ int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream,
 }
 
 // bias gradients of the four linear_2d layers and the two residual-weight gradients as column sums in a fixed order
+void det_colsum_list(const tcar_ctx_t* c, const Geo& g, int B, tcar_colsum_t (&cs)[6]) {
+  const tcar_colsum_t v[6] = {{c->dattout, g.ek, B, g.ic, G(c, TCAR_V_O_B)},
+                              {c->dattout + g.ic, g.ek, B, g.pt, G(c, TCAR_V_OT_B)},
+                              {c->dq, g.ic, B, g.ic, G(c, TCAR_V_Q2_B)},
+                              {c->dq1, g.ldh, B, g.ldh, G(c, TCAR_V_Q1_B)},
+                              {c->gw_rows, g.ic, B, g.ldh, G(c, TCAR_V_M_WRES)},
+                              {c->gw_rows + g.ldh, g.ic, B, g.ldh, G(c, TCAR_V_S_WRES)}};
+  for (int i = 0; i < 6; ++i) cs[i] = v[i];
+}
 int det_colsums(const tcar_ctx_t* c, const Geo& g, int B, void* stream) {
-  tcar_colsum_t cs[6] = {{c->dattout, g.ek, B, g.ic, G(c, TCAR_V_O_B)},
-                         {c->dattout + g.ic, g.ek, B, g.pt, G(c, TCAR_V_OT_B)},
-                         {c->dq, g.ic, B, g.ic, G(c, TCAR_V_Q2_B)},
-                         {c->dq1, g.ldh, B, g.ldh, G(c, TCAR_V_Q1_B)},
-                         {c->gw_rows, g.ic, B, g.ldh, G(c, TCAR_V_M_WRES)},
-                         {c->gw_rows + g.ldh, g.ic, B, g.ldh, G(c, TCAR_V_S_WRES)}};
+  tcar_colsum_t cs[6];
+  det_colsum_list(c, g, B, cs);
   return tcar_colsum_det(6, cs, stream);
 }
 int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream);
@@ -1017,7 +1022,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // sums and norms are the step's last chain
   const bool dclick_aux = fusedq && det_small && s3 != nullptr && !qb;
   RET(weight_grads(c, g, B, BT, sW, &ow, wgrad_early ? 2 : 0));
-  if (detc) RET(det_colsums(c, g, B, sW));
+  // column sums and dense norms are the last two launches of the step's last chain: ONE launch when the context has the fold scratch
+  // (optim.hip: colsum_sqnorm_kernel; TCAR_COLSUM_FUSED)
+  const bool cs_fused = detc && fuse_finish && s2 && c->fold_scratch && tn(c).colsum_fused;
+  if (detc && !cs_fused) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
   // The step's LAST join (aux + third stream into the main one, in front of the next update): two event waits cost the main
@@ -1030,7 +1038,16 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     TcarOpt o3 = opt_of(c);
     if (tail_flags) o3.sig = fork_arm(c, FK_TAIL3);
     if (c->fold_scratch) { o3.scratch = c->fold_scratch; o3.scratch_words = c->fold_scratch_words; }
-    RET(tcar_sqnorm_o(c->Gx, &c->segs_dense, c->sqn_dense, sW, &o3));
+    bool fused_done = false;
+    if (cs_fused) {
+      tcar_colsum_t cs[6];
+      det_colsum_list(c, g, B, cs);
+      const int rc = tcar_colsum_sqnorm_o(c->Gx, &c->segs_dense, 6, cs, c->sqn_dense, sW, &o3);
+      if (rc == TCAR_OK) fused_done = true;
+      else if (rc != TCAR_E_ARG) return rc;
+      else { o3.carried = false; RET(det_colsums(c, g, B, sW)); }       // (a layout the fused form does not take: the two launches)
+    }
+    if (!fused_done) RET(tcar_sqnorm_o(c->Gx, &c->segs_dense, c->sqn_dense, sW, &o3));
     if (tail_flags) tail3 = fork_commit(c, FK_TAIL3, o3);
   }
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;

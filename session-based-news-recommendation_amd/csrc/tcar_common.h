@@ -135,6 +135,8 @@ int tcar_cand_time_bwd_onehot_w(const tcar_dims_t* d, int B, const int32_t* inv_
                                 const TcarWait& wait_dp, int with_pieces);
 inline const float* tcar_cand_pieces(const tcar_dims_t* d, const float* ws) { return ws + (long)139 * 32 * (d->ldt + 4); }
 int tcar_sqnorm_o(const float* g, const tcar_segments_t* segs, float* sqn_dense, void* stream, TcarOpt* o);
+int tcar_colsum_sqnorm_o(const float* g, const tcar_segments_t* segs, int ncs, const tcar_colsum_t* cs, float* sqn_dense, void* stream,
+                         TcarOpt* o);
 int tcar_attn_pool_fwd_slabs_w(const tcar_dims_t* d, int B, int T, const float* x_icp, const float* x_pt, const float* pre1_slabs,
                                int n1, const float* pre2_slabs, int n2, int64_t slab_stride, float* pre1, float* pre2, const float* q,
                                const float* w_res1, const float* w_res2, float* pooled, float* alpha, void* stream,
