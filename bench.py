@@ -455,6 +455,10 @@ def main():
         flops["shard_backward"] = flops["score_dx"] + flops["score_dE"]
         ref["shard_score"] = "attout planes + logits of the shard + softmax statistics (sharded.py)"
         ref["shard_backward"] = "lse combine + dlogits planes + dE of the shard + dX partial + slab reduce (sharded.py)"
+        # the form the step driver itself chose for these batches (tcar_step_form: fused CE / one-hot segment / one-hot backward) —
+        # asked of the engine, not re-derived from the environment
+        form_ = eng.step_form(resident[0]) if (world == 1 and hasattr(eng, "step_form") and not os.environ.get("TCAR_FORCE_DP")) else \
+            {"fused_ce": False, "onehot_fwd": False, "onehot_bwd": False, "sorted_rows": False}
         ents = []
         for kind, tag in enumerate(eng.TIMED_KERNELS):
             ms = [m for m in eng.native_timing_ms(kind) if m > 0]
@@ -498,7 +502,7 @@ def main():
                 buf = C.create_string_buffer(160)
                 eng.lib.tcar_gemm_bf16_variant(lay, M_, N_, K_, 3 if mult == 3 else 1, sk, buf, 160)
                 name = buf.value.decode()
-            ce_form = tag == "score_fwd" and args.scoring == "bf16x3-mixed" and n_local == N and os.environ.get("TCAR_FUSED_CE", "1") != "0"
+            ce_form = tag == "score_fwd" and n_local == N and form_["fused_ce"]
             traffic, src = pmc_traffic(tag + ("_ce" if ce_form else ""), 3 if mult == 3 else 1, N, B) if (world == 1 and args.scoring != "f32") else (None, None)
             # algorithmic HBM bytes of the launch: every operand once (bf16 planes: 2 B per plane and element; fp32: 4 B), the
             # result once
@@ -506,12 +510,12 @@ def main():
             n_rows = g.Npad if n_local == N else ((n_local + 127) // 128) * 128
             # (training steps of the mixed precision: the logits GEMM's softmax epilogue writes a bf16 plane + group statistics,
             # not fp32 logits)
-            ce_epi = ce_form or (tag != "score_fwd" and args.scoring == "bf16x3-mixed" and n_local == N and os.environ.get("TCAR_FUSED_CE", "1") != "0")
+            ce_epi = ce_form or (tag != "score_fwd" and n_local == N and form_["fused_ce"])
             out_fwd = (2 * b_glob * n_rows + 8 * b_glob * (n_rows // 96)) if ce_epi else 4 * b_glob * n_rows
             # one-hot form of the candidate time columns (training steps of the mixed precision, single rank): the GEMM reads the
             # item | content columns of both operands, ONE 160-column one-hot plane and the two 160-column time-score planes, and
             # runs 3 MFMAs per product over 2 ldh columns + 2 over 160 (executed / algorithmic flops = (3 * 512 + 2 * 160) / 820)
-            onehot = ce_form and g.ldt <= 128 and os.environ.get("TCAR_ONEHOT_TIME", "1") != "0"
+            onehot = ce_form and form_["onehot_fwd"]
             in_fwd = (opb * (n_rows * g.ic + b_glob * g.ic) + 2 * n_rows * 160 + 4 * b_glob * 160) if onehot else opb * (n_rows * g.ek + b_glob * g.ek)
             form = None
             if onehot and tag == "score_fwd":
@@ -520,9 +524,7 @@ def main():
             # one-hot form of the two gradient GEMMs (default of the mixed precision on one rank): dX reads the item | content planes
             # of E + the 160-column one-hot plane and writes slabs of 2 ldh + 160 columns; dE writes its item block + 5 (q, z) pairs
             # per candidate instead of the [N, 5 ldt] time block
-            oh_bwd = (onehot or (tag != "score_fwd" and ce_epi and g.ldt == 64 and os.environ.get("TCAR_ONEHOT_TIME", "2") not in ("0", "1")
-                                 and not os.environ.get("TCAR_NO_ONEHOT_BWD") and not os.environ.get("TCAR_NO_ONEHOT")))
-            oh_bwd = oh_bwd and tag != "score_fwd" and g.ldt == 64 and os.environ.get("TCAR_ONEHOT_TIME", "2") not in ("0", "1")
+            oh_bwd = tag != "score_fwd" and n_local == N and form_["onehot_bwd"]
             if oh_bwd:
                 form = {"score_dx": "one-hot form: dlogits [E_item | E_content | OH], %d + 160 columns" % g.ic,
                         "score_dE": "one-hot form: item block + per-candidate (||gy||^2, x.gy) pairs, no [N, 5 ldt] block"}[tag]

@@ -81,6 +81,13 @@ typedef struct {
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
                                                    kernel of the side stream waits for */
+  int32_t ce_fold;          /* TCAR_CE_FOLD        w > 0 (default 1024): tcar_ce_finish as ONE launch of about w workgroups — each folds the (max, sum)
+                                                   pairs of its own 16 session rows, then rescales its slice of the plane — instead of a combine
+                                                   launch + a rescale launch (0); the same bits either way */
+  int32_t ingrad_split;     /* TCAR_INGRAD_SPLIT   1 (default): the three input-gradient GEMMs of the projections (main chain of the fused
+                                                   step) as 128-deep split-K slabs — one global-memory round trip per workgroup — that the
+                                                   row-gradient and small-table kernels fold in slab order; dq1 (relu' epilogue: no split) runs as
+                                                   its own launch on the third stream behind the pool backward's flag.  0: one grouped launch */
 } tcar_tuning_t;
 /* *out = the process-wide values (shipped defaults + TCAR_* environment) */
 int tcar_tuning_defaults(tcar_tuning_t* out /*host*/);
@@ -681,7 +688,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
                         const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 25
+#define TCAR_ABI_VERSION 26
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -814,6 +821,10 @@ int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_tim
  * The caller owes one tcar_step_update (or a further deferred step) for `bt`.  Same results as tcar_train_step. */
 int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int pending, float lr_pending,
                              void* stream);
+/* The form a fused training step of `bt` takes on this context — the driver's own predicates, nothing is launched: form[0] softmax
+ * epilogue in the logits GEMM (no fp32 logits), form[1] one-hot time segment in the logits GEMM, form[2] one-hot form of the two
+ * scoring-gradient GEMMs, form[3] order-fixed (sorted) item-row sum.  For tools that label measurements (bench.py). */
+int tcar_step_form(const tcar_ctx_t* c, const tcar_batch_t* bt, int32_t* form /*host, 4 ints*/);
 /* rank [B], topk [B,k], ce [B] (the logits buffer is consumed) */
 int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream);
 

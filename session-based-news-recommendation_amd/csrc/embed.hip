@@ -30,6 +30,7 @@ struct EmbArgs {
   // backward only: with n_gather > 0 the workgroups [n_gather, gridDim.x) compute block partials of sum sq_g^2 (the dense
   // item norm, tcar_sqnorm_det's job) beside the row gradients instead of in a launch of their own
   const float* sq_g; long sq_len; float* sq_part; int n_gather;
+  TcarDxSlabs sl;      // backward only: split-K slabs of the input gradients, folded while the rows are read (n = 0: none)
 };
 
 __device__ __forceinline__ int time_vocab(int k) {
@@ -362,13 +363,30 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
         xp[c] = ok ? ld4(a.tab.pos + (long)t * ldh + col) : zero4();
         gi[c] = ok ? ld4(gy + col) : zero4();
       }
+      // split-K slabs of the input-gradient GEMM (at most two): loaded beside the rows, added in slab order
+      float4 gs[2][NCH];
+#pragma unroll
+      for (int sI = 0; sI < 2; ++sI)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          gs[sI][c] = (sI < a.sl.n && col < ldh) ? ld4(a.sl.icp + sI * a.sl.s_icp + (long)row * ic + col) : zero4();
+        }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int kk = kval[it] ? it * gpw + grp : 0;
         const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
-        const float* gp = (kk < 5) ? a.dx_pt + (long)row * pt + kk * ldt : a.dx_act + (long)row * ldt;
+        const long goff = (kk < 5) ? (long)row * pt + kk * ldt : (long)row * ldt;
+        const float* gp = ((kk < 5) ? a.dx_pt : a.dx_act) + goff;
         kx[it] = (kact[it] && !item_only) ? ld4(tp + (long)kid[it] * ldt + lin * 4) : zero4();
-        kgy[it] = (kval[it] && !item_only) ? ld4(gp + lin * 4) : zero4();
+        kgy[it] = (kval[it] && !item_only && (kk < 5 || a.sl.n == 0 || a.sl.act_base)) ? ld4(gp + lin * 4) : zero4();
+        if (!item_only)
+          for (int sI = 0; sI < a.sl.n; ++sI)
+            if (kval[it]) kgy[it] = add4(kgy[it], ld4(((kk < 5) ? a.sl.pt + sI * a.sl.s_pt : a.sl.act + sI * a.sl.s_act) + goff + lin * 4));
+      }
+      if (a.sl.n > 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) gi[c] = add4(add4(gi[c], gs[0][c]), gs[1][c]);
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -1010,6 +1028,7 @@ struct SmallDetArgs {
   const float* dx_icp; const float* dx_pt; const float* dx_act; const float* dclick;
   float* g_pos; float* g_small;      // [40, ldh]; [150, ldt] = month | day | week | hour | minute | dwell
   float* rowq;                        // [SMALL_DET_ROWS] per-row norm pieces (folded per table by small_norm_fold_kernel)
+  TcarDxSlabs sl;                     // split-K slabs of the input gradients, added in slab order while the sources are read
 };
 constexpr int SMALL_DET_ROWS = TCAR_POS_VOCAB + SMALL_ROWS + 1;   // + the out-of-range dwell bucket (norm only, S7)
 
@@ -1039,15 +1058,33 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
   }
   float ql = 0.f, D2 = 0.f;
   // acc of up to 4 sources whose gradient slices start at p[0..n): loads first, then the sums in order
-  auto take4 = [&](const float* const* p, int n) {
+  // (base / sbase / sstride: the array the slices live in and its slab copies — the same offsets in every slab; sbase = nullptr: none)
+  auto take4 = [&](const float* const* p, int n, const float* base = nullptr, const float* sbase = nullptr, long sstride = 0,
+                   bool use_base = true) {
     float g[4][NC];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int col = lane + 64 * c;
-        g[u][c] = (u < n && col < cols) ? p[u][col] : 0.f;
+        g[u][c] = (use_base && u < n && col < cols) ? p[u][col] : 0.f;
       }
+    if (sbase) {
+      for (int sI = 0; sI < a.sl.n; ++sI) {
+        float h[4][NC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int col = lane + 64 * c;
+            h[u][c] = (u < n && col < cols) ? (sbase + sI * sstride + (p[u] - base))[col] : 0.f;
+          }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) g[u][c] += h[u][c];
+      }
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u >= n) break;
@@ -1066,7 +1103,7 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
       const int n = min(4, b1 - b);
 #pragma unroll
       for (int u = 0; u < 4; ++u) p[u] = a.dx_icp + ((long)(b + (u < n ? u : 0)) * T + R) * ic;
-      take4(p, n);
+      take4(p, n, a.dx_icp, a.sl.n > 0 ? a.sl.icp : nullptr, a.sl.s_icp);
     }
   } else {
     // session rows: id of table k at every source row; matches of this wave's sixteenth, in order
@@ -1094,7 +1131,8 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
             n = u + 1;
           } else p[u] = p[0];
         }
-        take4(p, n);
+        take4(p, n, (k < 5) ? a.dx_pt : a.dx_act, a.sl.n > 0 ? ((k < 5) ? a.sl.pt : a.sl.act) : nullptr, (k < 5) ? a.sl.s_pt : a.sl.s_act,
+              k < 5 || a.sl.n == 0 || a.sl.act_base != 0);
       }
     }
     // click rows: the week table by cw, the hour table by ch (model_combine.py:94-97)
@@ -1265,9 +1303,11 @@ int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const
 namespace {
 int gather_bwd_launch(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp, const float* dx_pt,
                       const float* dx_act, const float* dclick, const tcar_grads_t* g, const float* sq_g, long sq_len,
-                      float* sq_part, int sq_blocks, void* stream) {
+                      float* sq_part, int sq_blocks, void* stream, const TcarDxSlabs* sl = nullptr) {
   if (check_dims(d) || !tab || !bt || !g || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
+  if (sl && sl->n > 0 && (sl->n > 2 || !sl->icp || (!g->skip_small && (!sl->pt || !sl->act)))) return TCAR_E_ARG;
   EmbArgs a{};
+  if (sl) a.sl = *sl;
   a.d = *d; a.tab = *tab; a.bt = *bt; a.g = *g;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;
   long rows = (long)bt->B * bt->T + bt->B;
@@ -1313,6 +1353,14 @@ extern "C" int tcar_gather_clip_bwd_sqnorm(const tcar_dims_t* d, const tcar_tabl
   if (!sq_g || sq_len <= 0 || (sq_len & 3) || !tcar_aligned16(sq_g) || !ws || ws_bytes < 4096) return TCAR_E_ARG;
   return gather_bwd_launch(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, sq_g, (long)sq_len, (float*)((char*)ws + ws_bytes - 4096),
                            512, stream);
+}
+// ... with the split-K slabs of the input gradients folded while the rows are read (step.hip, TCAR_INGRAD_SPLIT)
+int tcar_gather_clip_bwd_sqnorm_s(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
+                                  const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, const float* sq_g,
+                                  int64_t sq_len, void* ws, int64_t ws_bytes, void* stream, const TcarDxSlabs* sl) {
+  if (!sq_g || sq_len <= 0 || (sq_len & 3) || !tcar_aligned16(sq_g) || !ws || ws_bytes < 4096) return TCAR_E_ARG;
+  return gather_bwd_launch(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, sq_g, (long)sq_len, (float*)((char*)ws + ws_bytes - 4096),
+                           512, stream, sl);
 }
 
 extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* inv_n,
@@ -1440,10 +1488,12 @@ extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables
 // (flag-capable: the norm fold, its last launch, publishes its slots with atomics)
 int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                 const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
-                                void* stream, TcarOpt* o, const float* cand_pc) {
+                                void* stream, TcarOpt* o, const float* cand_pc, const TcarDxSlabs* sl) {
   if (check_dims(d) || !tab || !bt || !g || !ws || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   if (!dx_icp || !dx_pt || !dx_act || !dclick || !g->g_pos || !g->g_time[0] || !g->sqn) return TCAR_E_ARG;
+  if (sl && sl->n > 0 && (sl->n > 2 || !sl->icp || !sl->pt || !sl->act)) return TCAR_E_ARG;
   SmallDetArgs a{};
+  if (sl) a.sl = *sl;
   a.d = *d; a.tab = *tab; a.bt = *bt;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;
   a.g_pos = g->g_pos; a.g_small = g->g_time[0]; a.rowq = ws;

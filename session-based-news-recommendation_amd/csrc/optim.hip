@@ -239,7 +239,10 @@ __global__ __launch_bounds__(1024) void colsum_sqnorm_kernel(const float* __rest
 #pragma unroll
         for (int p = 0; p < 16; ++p) t += sh[p][threadIdx.x];
         val = a.cs.dst[seg][col] + t;
-        a.cs.dst[seg][col] = val;
+        // behind a completion flag (the step's tail join is a light poll: no L2 write-back) the Adam update of ANOTHER stream reads
+        // these vectors: write-through, like every other output of a flag-carrying launch (tcar_common.h; gemm_x3_kernel)
+        if (sig.cnt) __hip_atomic_store(&a.cs.dst[seg][col], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.cs.dst[seg][col] = val;
       }
       partial = wave_sum(val * val);
     }

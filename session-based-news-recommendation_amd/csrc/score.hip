@@ -277,6 +277,113 @@ __global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32,
   ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits, lab_off, lab_window, sig.cnt != nullptr);
   tcar_signal_done(sig);        // (the body is a function: its early returns end up here)
 }
+// ce_combine + ce_rescale in ONE launch (round 5; TCAR_CE_FOLD): a workgroup owns 16 session rows x one slice of the plane's
+// column blocks.  It folds ITS rows' (max, sum) pairs itself — ngroups * 8 bytes per row out of L2, the same lane-strided loops and
+// shuffle trees as ce_combine_kernel, so lse / ce / the scale come out in the same bits — and then streams its slice: a wave
+// instruction is one 128 x 32 block's 16 rows x 64 bytes = 1 KB contiguous (lane = (row, 16-byte piece)), CE_FKPT independent
+// loads in flight per wave, issued BEFORE the fold (they do not depend on it).  Slice 0 also writes rowstat and ce.  The launch
+// saves the combine kernel (7.6 us) and its boundary on the step's critical chain; the pairs are re-read once per slice.
+constexpr int CE_FKPT = 8;
+template <int GW>
+__global__ __launch_bounds__(256) void ce_fold_rescale_kernel(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
+                                                              const float* __restrict__ lab_logit, const int32_t* __restrict__ label,
+                                                              float* __restrict__ rowstat, float* __restrict__ ce,
+                                                              __bf16* __restrict__ plane, int nslice, int lab_off, int lab_window,
+                                                              const TcarSignal sig) {
+  __shared__ float sM[16], sR[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int rg = blockIdx.x / nslice, sl = blockIdx.x - rg * nslice;
+  const int row0 = rg * 16;                                    // 16 rows of one 128-row block (16 divides 128)
+  const int per = (in32 + nslice - 1) / nslice;
+  const int kb_lo = sl * per, kb_hi = min(in32, kb_lo + per);
+  const bool wt = sig.cnt != nullptr;
+  const int r = (row0 & 127) + (lane >> 2), q = lane & 3;
+  const long row = row0 + (lane >> 2);
+  // block kb of this wave's 16 rows: 16 bytes per lane, 1 KB per wave instruction
+  uint4* p0 = reinterpret_cast<uint4*>(plane + ((long)(row0 >> 7) * in32) * 4096 + r * 32 + q * 8);
+  const int kb_first = kb_lo + wv;                             // wave w takes blocks kb_lo + w, + 4, ...
+  if (row0 >= B) {                                             // pad rows of the last 128-row block: zero (they are k-rows of dE)
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int kb = kb_first; kb < kb_hi; kb += 4) ce_store16(p0 + 512L * kb, z, wt);
+    tcar_signal_done(sig);
+    return;
+  }
+  uint4 v[CE_FKPT];
+#pragma unroll
+  for (int j = 0; j < CE_FKPT; ++j) {
+    const int kb = kb_first + 4 * j;
+    if (kb < kb_hi) v[j] = p0[512L * kb];
+  }
+  // ---- fold: wave w takes rows row0 + 4 w .. + 3 (the loops of ce_combine_kernel)
+#pragma unroll 1
+  for (int i = 0; i < 4; ++i) {
+    const int b = row0 + 4 * wv + i;
+    if (b >= B) break;
+    const float2* st = reinterpret_cast<const float2*>(stats) + (long)b * ngroups;
+    float m = -INFINITY;
+    for (int g = lane; g < ngroups; g += 64) m = fmaxf(m, st[g].x);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int g = lane; g < ngroups; g += 64) {
+      const float2 x = st[g];
+      if (x.x != -INFINITY) s += x.y * expf(x.x - m);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+      const float inv = 1.0f / s;
+      sM[4 * wv + i] = m;
+      sR[4 * wv + i] = inv;
+      if (sl == 0) {
+        if (rowstat) { rowstat[2 * b] = m; rowstat[2 * b + 1] = inv; }
+        ce[b] = m + logf(s) - lab_logit[b];
+      }
+    }
+  }
+  __syncthreads();
+  const bool live = row < B;
+  const float rsx = live ? sM[lane >> 2] : 0.f, rsy = live ? sR[lane >> 2] : 0.f;
+  int labc = -(1 << 30);
+  if (live) {
+    const int lraw = label[row] - lab_off;
+    labc = lab_window ? ((lraw >= 0 && lraw < N) ? lraw : -(1 << 30)) : clampi(lraw, 0, N - 1);
+  }
+  const int piece = q ^ ((r >> 2) & 3);                         // storage position q holds logical piece q ^ sw
+  const float* strow = stats + (long)(live ? row : 0) * ngroups * 2;
+  auto rescale1 = [&](uint4 x, int kb) -> uint4 {
+    const int col0 = kb * 32;
+    const int gi = col0 / GW;
+    const float mg = (live && gi < ngroups && col0 < N) ? strow[2 * gi] : -INFINITY;
+    const float c = (mg == -INFINITY) ? 0.f : expf(mg - rsx) * rsy;
+    const int lab = labc - col0 - piece * 8;
+    unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float lo = __uint_as_float(w[e] << 16) * c, hi = __uint_as_float(w[e] & 0xffff0000u) * c;
+      if (2 * e == lab) lo -= 1.f;
+      if (2 * e + 1 == lab) hi -= 1.f;
+      const __bf16 bl = (__bf16)lo, bh = (__bf16)hi;
+      w[e] = (unsigned)__builtin_bit_cast(unsigned short, bl) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+    }
+    return live ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
+  };
+  for (int kb0 = kb_first; kb0 < kb_hi; kb0 += 4 * CE_FKPT) {
+    uint4 nx[CE_FKPT];
+#pragma unroll
+    for (int j = 0; j < CE_FKPT; ++j) {                        // the next trip's loads ahead of this trip's arithmetic
+      const int kb = kb0 + 4 * (CE_FKPT + j);
+      if (kb < kb_hi) nx[j] = p0[512L * kb];
+    }
+#pragma unroll
+    for (int j = 0; j < CE_FKPT; ++j) {
+      const int kb = kb0 + 4 * j;
+      if (kb < kb_hi) ce_store16(p0 + 512L * kb, rescale1(v[j], kb), wt);
+    }
+#pragma unroll
+    for (int j = 0; j < CE_FKPT; ++j) v[j] = nx[j];
+  }
+  tcar_signal_done(sig);
+}
+
 // Catalog-sharded step: the shard's (max, sum exp, label score) per session from the epilogue's per-group pairs — the row of the
 // statistics all-gather (shard.hip: softmax_combine).  The label's score is 0 unless the label lies in [n0, n0 + n_loc).
 __global__ __launch_bounds__(256) void ce_shard_stats_kernel(int B, int ngroups, const float* __restrict__ stats,
@@ -884,6 +991,27 @@ int tcar_ce_finish_o(int B, int N, int group_width, int ngroups, const float* st
       (group_width != 64 && group_width != 96) || (long)ngroups * group_width < N || ((uintptr_t)rowstat & 7))
     return TCAR_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  // TCAR_CE_FOLD = w > 0 (default 1024): ONE launch of about w workgroups, each folding its own 16 rows' pairs (ce_fold_rescale_kernel);
+  // 0: the combine launch + the rescale launch (same bits either way)
+  // (every slice re-reads its rows' pairs: fine while the [B, ngroups, 2] statistics sit in the L2s — 2 MB at the Globo shape —, a
+  //  multiple of the plane's own traffic beyond; a 10 M-item catalog keeps the two launches)
+  const int fold = tcar_tn(o).ce_fold;
+  if (fold > 0 && (int64_t)B * ngroups * 8 <= (8LL << 20)) {
+    const int in32 = (int)(inner >> 5);
+    const int rgroups = (((B + 127) >> 7) << 7) / 16;
+    int nslice = fold / rgroups;
+    if (nslice > in32 / 4) nslice = in32 / 4;
+    if (nslice < 1) nslice = 1;
+    const TcarSignal sig = tcar_sig(o);
+    if (group_width == 96)
+      TCAR_LAUNCH(ce_fold_rescale_kernel<96>, dim3(rgroups * nslice), dim3(256), 0, st, B, N, in32, ngroups, stats, lab_logit, label,
+                  rowstat, ce, (__bf16*)dl_hi, nslice, 0, 0, sig);
+    else
+      TCAR_LAUNCH(ce_fold_rescale_kernel<64>, dim3(rgroups * nslice), dim3(256), 0, st, B, N, in32, ngroups, stats, lab_logit, label,
+                  rowstat, ce, (__bf16*)dl_hi, nslice, 0, 0, sig);
+    TCAR_CHECK_LAUNCH();
+    return TCAR_OK;
+  }
   TCAR_LAUNCH(ce_combine_kernel, dim3((B + 3) / 4), dim3(256), 0, st, B, ngroups, stats, lab_logit, rowstat, ce);
   TCAR_CHECK_LAUNCH();
   return tcar_ce_rescale_o(B, N, group_width, ngroups, stats, rowstat, label, 0, 0, dl_hi, inner, stream, o);
@@ -1085,7 +1213,10 @@ __global__ __launch_bounds__(256) void eval_diversity_kernel(int B, int T, int k
   }
   int un = 0;
   for (int t = 0; t < T; ++t) {
-    const int id = seq[(long)b * T + t];              // 1-based (sampler.py:68): category of item id - 1 (model_combine.py:192)
+    // 1-based (sampler.py:68): category of item id - 1 (model_combine.py:192).  Ids outside [1, n_items] cannot reach this kernel
+    // through the engine (upload() raises on them, as the reference's dict lookup would); a raw caller's out-of-range id is
+    // CLAMPED to the nearest item — id 0 compares as item 0, not as Python's reverse_item[-1]
+    const int id = seq[(long)b * T + t];
     const int ct = cat[clampi(id - 1, 0, n_items - 1)];
     un += (valid && c != ct) ? 1 : 0;
   }

@@ -24,6 +24,7 @@ const Switch kSwitches[] = {
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
     {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_REST_EARLY", &TcarTuning::rest_early, 0},
     {"TCAR_WGRAD_SPLIT", &TcarTuning::wgrad_split, 0},      {"TCAR_COLSUM_FUSED", &TcarTuning::colsum_fused, 1},
+    {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},           {"TCAR_INGRAD_SPLIT", &TcarTuning::ingrad_split, 1},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -940,10 +941,29 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // negative rows on the third stream (their wait for dE orders it behind the arena zero).
   const bool wsplit = detc && !qb && tn(c).wgrad_split && s2 && fuse_finish && c->stream3 && c->ev3 && neg_s3 && fork_host(c) &&
                       ((tn(c).flag_fork >> FK_POOLB) & 1) && ((tn(c).flag_fork >> FK_INGRAD) & 1);
+  // Input gradients as split-K slabs (TCAR_INGRAD_SPLIT, round 5).  The grouped launch [dq1 | three input-gradient GEMMs] walked 4-8
+  // serial 64-deep stages per workgroup on the step's critical chain (29.6 us beside dE).  Now: the three input-gradient GEMMs
+  // (K = ldh) as 128-deep chunks, each chunk its own set of workgroups writing its own slab — ONE global-memory round trip per
+  // workgroup, like the projections — and their consumers (row gradients on this chain, small tables on the aux stream) add the
+  // slabs in slab order while they read.  dq1 = relu'(q1) (dq Wq2^T) cannot split (activation backward in the epilogue) and has no
+  // consumer on this chain: its own launch on the third stream behind the pool backward's flag, in front of the weight gradients.
+  const int nis = tcar_gemm_splitk_effective(g.ldh, units(g.ldh));
+  const int fm = tn(c).flag_fork;
+  const bool isplit = detc && !qb && !wsplit && tn(c).ingrad_split && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
+                      tn(c).det_small != 0 && nis <= 2 && c->proj_slabs &&
+                      c->proj_slab_floats >= (int64_t)nis * BT * (g.ic + g.pt + g.ldt) && fork_host(c) && ((fm >> FK_POOLB) & 1) &&
+                      ((fm >> FK_INGRAD) & 1) && ((fm >> FK_QBWD) & 1);
+  TcarDxSlabs dxs{};
+  if (isplit) {
+    dxs.n = nis;
+    dxs.icp = c->proj_slabs; dxs.s_icp = (long)BT * g.ic;
+    dxs.pt = dxs.icp + nis * dxs.s_icp; dxs.s_pt = (long)BT * g.pt;
+    dxs.act = dxs.pt + nis * dxs.s_pt; dxs.s_act = (long)BT * g.ldt;
+  }
   bool wgrad_early = false;
   if (detc) {
     TcarOpt opb = opt_of(c);
-    if (qb || wsplit) opb.sig = fork_arm(c, FK_POOLB);
+    if (qb || wsplit || isplit) opb.sig = fork_arm(c, FK_POOLB);
     else fork_disarm(c, FK_POOLB);
     RET(tcar_attn_pool_bwd_slabs_o(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
                                    c->alpha, dsplit ? c->proj_slabs : c->dpooled, dsplit ? nd_ic : 1, dsplit ? nd_pt : 1, dstride,
@@ -978,6 +998,25 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     oi.sig = fork_arm(c, FK_INGRAD);
     RET(small_gemm(c, 1, 3, p, stream, &oi));
     (void)fork_commit(c, FK_INGRAD, oi);
+  } else if (isplit) {
+    // third stream: [pool backward's flag] -> dq1 (its consumers: weight gradients + column sums there, dclick on the aux stream)
+    hipStream_t s3q = (hipStream_t)c->stream3;
+    RET(fork_go(c, FK_POOLB, st, s3q, c->ev[0]));
+    tcar_gemm_desc_t pq = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
+    pq.dact = 1; pq.dact_y = c->q1; pq.ld_dact_y = g.ldh; pq.colsum = nullptr;
+    TcarOpt oq = opt_of(c);
+    oq.sig = fork_arm(c, FK_QBWD);
+    RET(small_gemm(c, 1, 1, &pq, (void*)s3q, &oq));
+    (void)fork_commit(c, FK_QBWD, oq);
+    // main chain: the three input-gradient GEMMs into their slabs (only the ITEM half of dX_ic: content is frozen)
+    tcar_gemm_desc_t p[3];
+    p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, const_cast<float*>(dxs.icp), g.ic, nullptr, 0, 0, units(g.ldh));
+    p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, const_cast<float*>(dxs.act), g.ldt, nullptr, 0, 0, units(g.ldh));
+    p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, const_cast<float*>(dxs.pt), g.pt, nullptr, 0, 0, units(g.ldh));
+    TcarOpt oi = opt_of(c);
+    oi.sig = fork_arm(c, FK_INGRAD);
+    RET(small_gemm(c, 1, 3, p, stream, &oi));
+    (void)fork_commit(c, FK_INGRAD, oi);
   } else if (fusedq) {
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
@@ -1007,6 +1046,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   TcarOpt ow = opt_of(c);
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
+    // (TCAR_INGRAD_SPLIT = 2: the weight gradients read nothing of the input-gradient launch any more — dq1 is ahead of them on this
+    //  stream — and start behind dq1; = 1 keeps them behind that launch's flag: they then run beside the row scatter, not beside it)
+    if (!(isplit && tn(c).ingrad_split >= 2))
     RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));        // (flagged small-GEMM launches store write-through)
     // (with the negative rows on this stream it already waited for dE — ev[4], recorded on the aux stream BEHIND the arena zero —
     // and a wait for a completed event still costs the stream a ~6-us barrier packet)
@@ -1083,6 +1125,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       // dclick (third stream, the click-query backward) and dx_* (main chain, the input-gradient launch): one poll of both flags
       RET(fork_go2(c, FK_QBWD, (hipStream_t)c->stream3, c->ev[5], FK_INGRAD, st, c->ev[0], s2));
     } else if (dclick_aux) {
+      // (split input gradients: dq1 comes from the third stream's launch, the dx slabs from the main chain's — one poll of both flags)
+      if (isplit) RET(fork_go2(c, FK_QBWD, (hipStream_t)c->stream3, c->ev[5], FK_INGRAD, st, c->ev[0], s2));
+      else
       RET(fork_go(c, FK_INGRAD, st, s2, c->ev[5]));       // (the same flag the third stream polled: dq1, dx_* of that launch)
       if (tn(c).qbwd_fused == 2 && g.ldh == 256 && g.ldt == 64) {
         // dclick = dq1 Wq1^T as ONE fp32 launch of whole-row dots (query.hip: the layer-1 half of the click-query backward): 7 us
@@ -1098,7 +1143,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     TcarOpt o2 = opt_of(c);
     if (tail3) o2.sig = fork_arm(c, FK_TAIL2);
     RET(tcar_small_tables_bwd_det_o(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2, &o2,
-                                    ohb ? tcar_cand_pieces(&c->d, c->ct_ws) : nullptr));
+                                    ohb ? tcar_cand_pieces(&c->d, c->ct_ws) : nullptr, isplit ? &dxs : nullptr));
     if (tail3) tail2 = fork_commit(c, FK_TAIL2, o2);
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
@@ -1132,8 +1177,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       gr.norms_out = tcar_segsum_norms_buffer(&c->d, bt, c->segsum_ws);
       gr.skip_small = det_small ? 1 : 0;
       if (split_finish)
-        RET(tcar_gather_clip_bwd_sqnorm(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, Gi, (int64_t)g.N * g.ldh,
-                                        c->segsum_ws, c->segsum_bytes, stream));
+        RET(tcar_gather_clip_bwd_sqnorm_s(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, Gi, (int64_t)g.N * g.ldh,
+                                          c->segsum_ws, c->segsum_bytes, stream, isplit ? &dxs : nullptr));
       else
         RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
       RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, c->segsum_bytes, 0, gr.rows_out, nullptr, nullptr, 0, Gi,
@@ -1145,8 +1190,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (tail2 && tail3) {
     const ForkSlot& f2 = fork_host(c)->slot[FK_TAIL2];
     const ForkSlot& f3 = fork_host(c)->slot[FK_TAIL3];
-    // light poll: both flagged launches publish their own results with atomics (norm slots), and everything else the update
-    // reads was written by EARLIER launches of those streams, released when they ended
+    // light poll (no L2 write-back): the flagged launches publish their OWN results with atomics (norm slots; the small tables'
+    // rows) or write-through stores (colsum_sqnorm_kernel: the six bias / residual-weight gradients), and everything else the
+    // update reads was written by EARLIER launches of those streams, released when they ended
     TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, st, (const unsigned*)f2.sig.flag, f2.sig.epoch, c->sig_dev + TCAR_SIG_ERR,
                 c->sig_err_host, POLL_TICKS, (const unsigned*)f3.sig.flag, f3.sig.epoch, 0);
     TCAR_CHECK_LAUNCH();
@@ -1207,6 +1253,19 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
   return tcar_clip_adam_all(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item,
                             c->sqn_dense, pieces, c->use_dense, c->clip, lr_t, c->b1, c->b2, c->eps,
                             c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, stream);
+}
+
+// Which form would a fused training step of `bt` take on this context?  The predicates the driver itself evaluates, for tools
+// that label measurements (bench.py's roofline entries): form[0] softmax epilogue in the logits GEMM, [1] one-hot time segment of
+// the logits GEMM, [2] one-hot form of the two gradient GEMMs, [3] sorted (order-fixed) item-row sum.  Launches nothing.
+extern "C" int tcar_step_form(const tcar_ctx_t* c, const tcar_batch_t* bt, int32_t* form /*host, 4 ints*/) {
+  if (!form) return TCAR_E_ARG;
+  RET(check_ctx(c, bt));
+  form[0] = (c->scoring && fused_ce(c, bt->B, nullptr)) ? 1 : 0;
+  form[1] = (form[0] && onehot_fwd(c, bt->B)) ? 1 : 0;
+  form[2] = onehot_bwd(c, bt) ? 1 : 0;
+  form[3] = sorted_rows(c, bt) ? 1 : 0;
+  return TCAR_OK;
 }
 
 extern "C" int tcar_train_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, float lr_t, void* stream) {

@@ -920,6 +920,15 @@ class TcarEngine:
         used = min(self._ev["cursor"][0], n)
         return [self._ev["starts"][kind * n + i].elapsed_time(self._ev["stops"][kind * n + i]) for i in range(used)]
 
+    def step_form(self, bt: Batch) -> Dict[str, bool]:
+        """The form a fused training step of `bt` takes on this engine (tcar_step_form: the driver's own predicates) —
+        {"fused_ce", "onehot_fwd", "onehot_bwd", "sorted_rows"}.  Tools that label measurements ask this instead of re-deriving
+        it from the environment."""
+        self._ensure_work(bt.B, bt.T)
+        out = (C.c_int32 * 4)()
+        check(self.lib.tcar_step_form(C.byref(self._ctx()), C.byref(bt), out), "tcar_step_form")
+        return {"fused_ce": bool(out[0]), "onehot_fwd": bool(out[1]), "onehot_bwd": bool(out[2]), "sorted_rows": bool(out[3])}
+
     def _lr_t(self) -> float:
         return float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.b2_pow) / (np.float32(1) - self.b1_pow))
 

@@ -54,6 +54,9 @@ def diversity_from_counts(ild_cnt, unexp_cnt, n_rec, T: int):
     ild_cnt = np.asarray(ild_cnt, dtype=np.int64)
     unexp_cnt = np.asarray(unexp_cnt, dtype=np.int64)
     n = np.asarray(n_rec, dtype=np.int64)
+    if n.size and int(n.min()) <= 1:
+        # getILD divides by n (n - 1) unguarded (model_combine.py:182): a recommendation list of 0 or 1 items raises there, and here
+        raise ZeroDivisionError("getILD: a recommendation list of %d item(s) (model_combine.py:182 divides by n (n - 1))" % int(n.min()))
     ild = ild_cnt / (n * (n - 1)).astype(np.float64)
     unexp = np.where(n > 0, unexp_cnt / np.maximum(n * int(T), 1).astype(np.float64), 0.0)      # getUnexp returns 0 for n == 0
     return ild, unexp

@@ -355,7 +355,8 @@ class ShardedEngine(TcarEngine):
                 tk = eng._tick3(0)
                 check(lib.tcar_shard_score(C.byref(sctx), C.byref(sh), refresh, st), "tcar_shard_score")
                 eng._tock3(tk)
-                eng._time_dirty = False
+                if refresh:        # (the one-hot schedule issues no refresh: the planes stay dirty for the next op-level reader)
+                    eng._time_dirty = False
                 return eng.s_stats[:Bq]
 
             # lse, dlogits planes, dE of the shard (aux stream, stays here), dX partial (goes home)

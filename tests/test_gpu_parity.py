@@ -855,6 +855,47 @@ def test_schedule_switches_of_round_4_agree_bitwise_with_the_default_schedule():
             assert np.array_equal(base[1][k], run[1][k]), (sw, k)
 
 
+def test_schedule_switches_of_round_5_agree_with_the_default_schedule():
+    """Round 5: (a) tcar_ce_finish as ONE launch whose workgroups fold their own rows' (max, sum) pairs (TCAR_CE_FOLD = w > 0) against
+    the combine launch + rescale launch (0), at two grid sizes — the same lane-strided loops and shuffle trees, so BIT FOR BIT;
+    (b) the input-gradient GEMMs of the projections as split-K slabs folded by their consumers (TCAR_INGRAD_SPLIT = 1, default) with
+    the weight gradients behind dq1 instead of behind the slab launch (= 2): placement only, bit for bit; (c) the un-split grouped
+    launch (= 0) sums K in ONE chain instead of two slabs: the same numbers up to fp32 rounding of that sum — losses within 1e-5
+    after 40 steps (Adam turns last-bit gradient differences into last-bit variable differences; nothing amplifies them here) —
+    and itself bit-for-bit repeatable."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, K = 46033, 250, 64, 512, 20
+    params, content, mw, _ = _case(N, H, Ht, 8, 2, K, seed=31)
+    batches = [_case(N, H, Ht, B, T, K, seed=600 + T)[3] for T in (2, 1, 5, 3)]
+
+    def run(sw):
+        eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+        if sw:
+            eng.set_tuning(**sw)
+        res = [eng.make_resident(b) for b in batches]
+        losses = [eng.train_step(None, bt=res[i % len(res)], defer_update=True).clone() for i in range(40)]
+        eng.flush()
+        eng.check_forks()
+        out = (torch.stack([l[:B] for l in losses]).cpu().numpy(), eng.export_state())
+        del eng, res
+        torch.cuda.empty_cache()
+        return out
+
+    base = run({})
+    for sw in ({"TCAR_CE_FOLD": 0}, {"TCAR_CE_FOLD": 256}, {"TCAR_CE_FOLD": 4096}, {"TCAR_INGRAD_SPLIT": 2}):
+        got = run(sw)
+        assert (base[0] == got[0]).all(), sw
+        for k in base[1]:
+            assert np.array_equal(base[1][k], got[1][k]), (sw, k)
+    un = run({"TCAR_INGRAD_SPLIT": 0})
+    un2 = run({"TCAR_INGRAD_SPLIT": 0})
+    assert (un[0] == un2[0]).all()
+    for k in un[1]:
+        assert np.array_equal(un[1][k], un2[1][k]), k
+    np.testing.assert_allclose(un[0], base[0], rtol=1e-5, atol=1e-6)
+
+
 def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_runs(monkeypatch):
     """Re-entrancy of the boundary on the HOST (no global mutable state, per-device handles passed in).  Two
     engines of different shapes, each with its own context, fork words and streams, are stepped ALTERNATELY from two Python

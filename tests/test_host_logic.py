@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 25
+    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 26
     # the binary carries the digest of the sources it was built from; the loader refuses a stale one
     assert lib.tcar_build_id().decode() == _lib.source_build_id() == _lib.binary_build_id()
     assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
@@ -40,7 +40,8 @@ def test_tuning_switch_defaults():
     want = {"TCAR_BF16_TILE": 0, "TCAR_REST_GRID": 512, "TCAR_SOFTMAX_VARIANT": 1, "TCAR_WGRAD_KS": 1536,
             "TCAR_GATHER_BIG_ROWS": 16384, "TCAR_GATHER_WG": 2, "TCAR_MHA_MFMA": 1, "TCAR_SORT_SCATTER": 1, "TCAR_BF16_KS": 2,
             "TCAR_DET_SMALL": 1, "TCAR_X3_ONESHOT": 4, "TCAR_PROJ_SPLIT": 1, "TCAR_FUSED_CE": 1, "TCAR_ONEHOT_TIME": 2, "TCAR_FLAG_FORK": 4095, "TCAR_FORK_DELAY": 7,
-            "TCAR_INKERNEL_WAIT": 0, "TCAR_QBWD_FUSED": 2, "TCAR_ATTOUT_SPLIT": 1, "TCAR_REST_EARLY": 0, "TCAR_WGRAD_SPLIT": 0, "TCAR_COLSUM_FUSED": 1}
+            "TCAR_INKERNEL_WAIT": 0, "TCAR_QBWD_FUSED": 2, "TCAR_ATTOUT_SPLIT": 1, "TCAR_REST_EARLY": 0, "TCAR_WGRAD_SPLIT": 0, "TCAR_COLSUM_FUSED": 1,
+            "TCAR_CE_FOLD": 1024, "TCAR_INGRAD_SPLIT": 1}
     header = open(os.path.join(ROOT, "include", "tcar_hip.h")).read()
     block = header[header.index("typedef struct {\n  int32_t bf16_tile"):header.index("} tcar_tuning_t;")]
     documented = set(re.findall(r"/\* (TCAR_[A-Z0-9_]+)\b", block))

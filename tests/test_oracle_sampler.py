@@ -146,7 +146,13 @@ def test_ild_unexp_host_vs_oracle():
     un_cnt = (c[:, :, None] != table[seq - 1][:, None, :]).sum((1, 2))
     ild, un = host_metrics.diversity_from_counts(ild_cnt, un_cnt, np.full(6, 20), 3)
     assert ild.tolist() == want_ild and un.tolist() == want_un          # exact: int / int in double precision, as Python
-    assert host_metrics.diversity_from_counts([0], [0], [0], 3)[1].tolist() == [0.0]      # getUnexp: n == 0 -> 0
+    # a list of 0 or 1 recommended items: getILD divides by n (n - 1) before getUnexp is reached (model_combine.py:182,304-305) —
+    # the reference raises ZeroDivisionError, and so does the product path (no inf / nan leaks into the printed averages)
+    for n_short in (0, 1):
+        with pytest.raises(ZeroDivisionError):
+            host_metrics.diversity_from_counts([0], [0], [n_short], 3)
+        with pytest.raises(ZeroDivisionError):
+            metrics_oracle.ild(list(range(n_short)), reverse_item, category_id)
 
 
 @pytest.mark.parametrize("mode", ["neighbor", "impression"])
