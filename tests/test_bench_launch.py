@@ -29,6 +29,17 @@ def test_plain_invocation_with_gpus_2_launches_two_ranks():
     assert "collective preflight ok" in r.stderr
 
 
+def test_plain_invocation_with_gpus_8_launches_eight_ranks():
+    # the node shape of BASELINE.json's metric ("at 1/2/4/8 MI355X"): eight ranks rendezvous on 127.0.0.1 and run the preflight
+    r = _run(["--gpus", "8", "--launch_check", "--backend", "gloo"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["metric"] == "launch_check" and d["n_gpus"] == 8 and d["collectives"]["world"] == 8
+    assert r.stderr.count("collective preflight ok") >= 1
+
+
 def test_under_torch_distributed_run_it_is_a_rank_not_a_launcher():
     # the driver's own launch form: bench.py must not spawn again when WORLD_SIZE is already set
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

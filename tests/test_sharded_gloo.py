@@ -1,4 +1,4 @@
-"""The exchange of the catalog-sharded data-parallel step on CPU, world size 2 over gloo: the PRODUCT's collective schedule
+"""The exchange of the catalog-sharded data-parallel step on CPU, world sizes 2 and 8 over gloo: the PRODUCT's collective schedule
 (tcar_amd.sharded.ShardExchange.step — the same object ShardedEngine drives with the HIP entry points) with fp64 torch pieces,
 against the single-process computation on the concatenated batch (no GPU, no HIP library: this pins the sequencing, the buffer
 shapes of uneven / empty shards, the asynchronous item-row all-gather, and the ALGEBRA of the split —
@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, N=300, B=7):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,7 +33,7 @@ def _worker(rank, world, port, ret):
         from tcar_amd.dp import shard_bounds
         from tcar_amd.sharded import ShardExchange, shard_rows
         torch.manual_seed(3)
-        N, ek, ldh, B, K, T = 300, 24, 8, 7, 5, 2               # 7 sessions over 2 ranks: 4 + 3, cap = 4 (one padding session)
+        ek, ldh, K, T = 24, 8, 5, 2                              # world 2: 7 sessions = 4 + 3, cap = 4 (one padding session)
         E = torch.randn(N, ek, dtype=torch.float64) * 0.3
         att = torch.tanh(torch.randn(B, ek, dtype=torch.float64))
         lab = torch.randint(0, N, (B,))
@@ -57,9 +57,11 @@ def _worker(rank, world, port, ret):
         arena_ref = ar.grad.sum(0)                                  # a dense-weight gradient: the sum over ALL sessions
         # ---- the product's exchange schedule (ShardExchange.step) with fp64 torch pieces
         S = shard_rows(N, world)
-        assert S == 256
+        assert S == (256 if world == 2 else 5760)
         n0 = rank * S
         nl = min(N, n0 + S) - n0
+        if world == 8:                                            # the Globo catalog at 8 ranks: seven 5,760-row shards + a SHORT last one
+            assert nl == (5760 if rank < 7 else 46033 - 7 * 5760) and 0 < 46033 - 7 * 5760 < 5760
         lo, hi, cap = shard_bounds(B, world, rank)
         nloc = hi - lo
         ld_head = ek + 2 + K
@@ -158,11 +160,11 @@ def _worker(rank, world, port, ret):
         full = st["stage"].view(-1, ldh)[:N]
         assert torch.allclose(full, E[:, :ldh] - 0.5 * item_ref, rtol=1e-11, atol=1e-13)
         assert xch.bytes_moved["item_rows"] == world * S * ldh * 8
-        # an EMPTY rank: a batch of one session — rank 1 contributes padding only and still joins every collective
+        # EMPTY ranks: a batch of one session — every rank but 0 contributes padding only and still joins every collective
         B1 = 1
         lo, hi, cap = shard_bounds(B1, world, rank)
         nloc = hi - lo
-        assert (rank == 0 and nloc == 1) or (rank == 1 and nloc == 0)
+        assert (rank == 0 and nloc == 1) or (rank > 0 and nloc == 0)
         xch.step(Pieces(), cap, update=False)
         assert xch.order == ["attout+labels+negatives", "softmax_stats", "dX", "rows+ids", "arena"]
         if rank == 0:
@@ -186,11 +188,22 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_sharded_exchange_algebra_two_ranks_gloo():
+def _run(world, N, B):
     import torch.multiprocessing as mp
-    world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, N, B), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", ret.get(r)
+
+
+def test_sharded_exchange_algebra_two_ranks_gloo():
+    _run(2, 300, 7)
+
+
+def test_sharded_exchange_seams_eight_ranks_gloo():
+    """The W = 8 seams of the benchmarked job: the Globo catalog cut into seven 5,760-row shards and a SHORT
+    last shard (5,713 rows), 21 sessions over 8 ranks (cap 3: seven full ranks and an EMPTY eighth, three padding rows in the
+    all-gathered batch), labels / negatives / gathered rows falling into every shard — the same ShardExchange.step the GPU engine
+    drives, against the single-process computation; then a one-session batch (seven empty ranks)."""
+    _run(8, 46033, 21)
