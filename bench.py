@@ -204,6 +204,19 @@ def gather_roofline(dev):
     return out
 
 
+def bucket_batch(fold, T, B, K, rng):
+    """One full batch of the length bucket T (sampler.py:40-49 buckets by exact input length): items from the fold's Zipf popularity
+    law, their publish fields from the catalog, click fields / gap buckets / labels / K uniform negatives at random."""
+    n = fold.n_items
+    ranks = np.searchsorted(fold._cdf, rng.random_sample(B * T)).clip(0, n - 1)
+    items0 = fold._perm[ranks].reshape(B, T)
+    pub = fold.mwdhm[items0]                                   # [B, T, 5]: month, day, isoweekday, hour + 1, minute + 1
+    b = {"seq": items0 + 1, "label": fold._perm[np.searchsorted(fold._cdf, rng.random_sample(B)).clip(0, n - 1)],
+         "pm": pub[..., 0], "pd": pub[..., 1], "pw": pub[..., 2], "ph": pub[..., 3], "pmi": pub[..., 4],
+         "cw": rng.randint(0, 7, B), "ch": rng.randint(0, 24, B), "gap": rng.randint(0, 11, (B, T)), "neg": rng.randint(0, n, (B, K))}
+    return {k: np.ascontiguousarray(v).astype(np.int32) for k, v in b.items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +254,7 @@ def main():
                          "quoted in bf16): logits from split-bf16 planes (three MFMAs per product, fp32-class: the 1e-3 "
                          "logits / HR@20 / MRR@20 gate of the north star), the two gradient GEMMs in plain bf16, fp32 "
                          "accumulation and fp32 master state throughout; bf16x3: all three GEMMs fp32-class")
+    ap.add_argument("--no_by_T", action="store_true", help="skip ms_per_step_by_T (step time per input-length bucket T = 1, 2, 5, 10, 40)")
     ap.add_argument("--launch_check", action="store_true",
                     help="only the rank launch + the three collectives of the exchanges on tiny tensors (dp.preflight): with "
                          "--backend gloo on CPU (tests/), with nccl on the GPUs; prints n_gpus and the backend / RCCL versions")
@@ -425,6 +439,29 @@ def main():
         # headline pass: every event pair in the middle of a stream's chain costs ~5-10 us of bubble (8 pairs per step = 2-3 %).
         eng.enable_native_timing(args.steps)
         dt_ev, _ = timed(headline_sampler)
+    # ---- step time per length bucket: the sampler buckets by EXACT input length (sampler.py:40-49), the headline is
+    # quoted at the fold's mean length while the session-side head and tail of the step scale with B * T.  Same engine, same loop body
+    # (deferred update, resident feeds of ONE length each, items drawn from the fold's popularity law), 60 timed steps after 15.
+    by_T = None
+    if world == 1 and not os.environ.get("TCAR_FORCE_DP") and not args.no_by_T and not (args.no_cpu_baseline and args.no_e2e) \
+            and N <= 200000:
+        by_T = {}
+        rng_t = np.random.RandomState(77)
+        for T_ in (1, 2, 5, 10, 40):
+            feeds = [eng.make_resident(bucket_batch(fold, T_, B, K, rng_t)) for _ in range(4)]
+            eng._ensure_work(B, T_)
+            for i in range(15):
+                eng.train_step(None, bt=feeds[i % 4], **defer)
+            eng.flush()
+            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            for i in range(60):
+                eng.train_step(None, bt=feeds[i % 4], **defer)
+            eng.flush()
+            torch.cuda.synchronize()
+            by_T[str(T_)] = round((time.perf_counter() - w0) / 60 * 1e3, 4)
+            del feeds
+        eng.check_forks()
     if hasattr(eng, "exchange_info"):
         exchange = eng.exchange_info()        # after the timed steps: carries the bytes each collective moved per step
     value = B * world * args.steps / dt
@@ -697,6 +734,7 @@ def main():
                           "end_to_end_sessions_per_s, which runs the trainer loop over the whole fold)",
                "roofline_pass": "per-kernel times (roofline, kernels) come from a SECOND, event-instrumented pass of the same steps "
                                 "(ms_per_step_with_kernel_events); value / ms_per_step come from the un-instrumented headline pass",
+               "ms_per_step_by_T": by_T,
                "step_roofline": step_roof,
                "roofline": roof, "gather_roofline": gather, "cpu_baseline": cpu, "end_to_end_sessions_per_s": e2e, "exchange": exchange,
                "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),

@@ -84,10 +84,10 @@ typedef struct {
   int32_t ce_fold;          /* TCAR_CE_FOLD        w > 0 (default 1024): tcar_ce_finish as ONE launch of about w workgroups — each folds the (max, sum)
                                                    pairs of its own 16 session rows, then rescales its slice of the plane — instead of a combine
                                                    launch + a rescale launch (0); the same bits either way */
-  int32_t ingrad_split;     /* TCAR_INGRAD_SPLIT   1 (default): the three input-gradient GEMMs of the projections (main chain of the fused
-                                                   step) as 128-deep split-K slabs — one global-memory round trip per workgroup — that the
-                                                   row-gradient and small-table kernels fold in slab order; dq1 (relu' epilogue: no split) runs as
-                                                   its own launch on the third stream behind the pool backward's flag.  0: one grouped launch */
+  int32_t ingrad_split;     /* TCAR_INGRAD_SPLIT   1 (default): the grouped launch [dq1 | three input-gradient GEMMs of the projections] on the main
+                                                   chain of the fused step as split-K slabs of at most four 64-deep stages per workgroup (the
+                                                   activation backward of dq1 applied per slab); the consumers (row gradients, small tables,
+                                                   dclick, dW_q1, the Q1 bias column sum) add the slabs in slab order.  0: un-split (4-8 stages) */
 } tcar_tuning_t;
 /* *out = the process-wide values (shipped defaults + TCAR_* environment) */
 int tcar_tuning_defaults(tcar_tuning_t* out /*host*/);

@@ -314,28 +314,67 @@ __global__ __launch_bounds__(256) void ce_fold_rescale_kernel(int B, int N, int 
     const int kb = kb_first + 4 * j;
     if (kb < kb_hi) v[j] = p0[512L * kb];
   }
-  // ---- fold: wave w takes rows row0 + 4 w .. + 3 (the loops of ce_combine_kernel)
-#pragma unroll 1
-  for (int i = 0; i < 4; ++i) {
-    const int b = row0 + 4 * wv + i;
-    if (b >= B) break;
-    const float2* st = reinterpret_cast<const float2*>(stats) + (long)b * ngroups;
-    float m = -INFINITY;
-    for (int g = lane; g < ngroups; g += 64) m = fmaxf(m, st[g].x);
-    m = wave_max(m);
-    float s = 0.f;
-    for (int g = lane; g < ngroups; g += 64) {
-      const float2 x = st[g];
-      if (x.x != -INFINITY) s += x.y * expf(x.x - m);
+  // ---- fold: wave w takes rows row0 + 4 w .. + 3.  ce_combine_kernel's arithmetic (per lane: groups lane, lane + 64, ... in order;
+  // then the shuffle trees), but every pair of the wave's four rows is LOADED before the first use: one L2 round trip per workgroup
+  // (the first version walked two dependent loops per row — 64 serial round trips, 46 us for the launch)
+  constexpr int NG = 8;                                         // pairs per lane and row held in registers: ngroups <= 512
+  if (ngroups <= 64 * NG) {
+    float2 pr[4][NG];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = min(row0 + 4 * wv + i, B - 1);
+      const float2* st = reinterpret_cast<const float2*>(stats) + (long)b * ngroups;
+#pragma unroll
+      for (int j = 0; j < NG; ++j) {
+        const int g = lane + 64 * j;
+        pr[i][j] = g < ngroups ? st[g] : make_float2(-INFINITY, 0.f);
+      }
     }
-    s = wave_sum(s);
-    if (lane == 0) {
-      const float inv = 1.0f / s;
-      sM[4 * wv + i] = m;
-      sR[4 * wv + i] = inv;
-      if (sl == 0) {
-        if (rowstat) { rowstat[2 * b] = m; rowstat[2 * b + 1] = inv; }
-        ce[b] = m + logf(s) - lab_logit[b];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = row0 + 4 * wv + i;
+      float m = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NG; ++j) m = fmaxf(m, pr[i][j].x);
+      m = wave_max(m);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NG; ++j)
+        if (pr[i][j].x != -INFINITY) s += pr[i][j].y * expf(pr[i][j].x - m);
+      s = wave_sum(s);
+      if (lane == 0 && b < B) {
+        const float inv = 1.0f / s;
+        sM[4 * wv + i] = m;
+        sR[4 * wv + i] = inv;
+        if (sl == 0) {
+          if (rowstat) { rowstat[2 * b] = m; rowstat[2 * b + 1] = inv; }
+          ce[b] = m + logf(s) - lab_logit[b];
+        }
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int i = 0; i < 4; ++i) {
+      const int b = row0 + 4 * wv + i;
+      if (b >= B) break;
+      const float2* st = reinterpret_cast<const float2*>(stats) + (long)b * ngroups;
+      float m = -INFINITY;
+      for (int g = lane; g < ngroups; g += 64) m = fmaxf(m, st[g].x);
+      m = wave_max(m);
+      float s = 0.f;
+      for (int g = lane; g < ngroups; g += 64) {
+        const float2 x = st[g];
+        if (x.x != -INFINITY) s += x.y * expf(x.x - m);
+      }
+      s = wave_sum(s);
+      if (lane == 0) {
+        const float inv = 1.0f / s;
+        sM[4 * wv + i] = m;
+        sR[4 * wv + i] = inv;
+        if (sl == 0) {
+          if (rowstat) { rowstat[2 * b] = m; rowstat[2 * b + 1] = inv; }
+          ce[b] = m + logf(s) - lab_logit[b];
+        }
       }
     }
   }
@@ -367,19 +406,18 @@ __global__ __launch_bounds__(256) void ce_fold_rescale_kernel(int B, int N, int 
     return live ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
   };
   for (int kb0 = kb_first; kb0 < kb_hi; kb0 += 4 * CE_FKPT) {
-    uint4 nx[CE_FKPT];
+    if (kb0 != kb_first) {                                     // (the first trip's loads were issued ahead of the fold)
 #pragma unroll
-    for (int j = 0; j < CE_FKPT; ++j) {                        // the next trip's loads ahead of this trip's arithmetic
-      const int kb = kb0 + 4 * (CE_FKPT + j);
-      if (kb < kb_hi) nx[j] = p0[512L * kb];
+      for (int j = 0; j < CE_FKPT; ++j) {
+        const int kb = kb0 + 4 * j;
+        if (kb < kb_hi) v[j] = p0[512L * kb];
+      }
     }
 #pragma unroll
     for (int j = 0; j < CE_FKPT; ++j) {
       const int kb = kb0 + 4 * j;
       if (kb < kb_hi) ce_store16(p0 + 512L * kb, rescale1(v[j], kb), wt);
     }
-#pragma unroll
-    for (int j = 0; j < CE_FKPT; ++j) v[j] = nx[j];
   }
   tcar_signal_done(sig);
 }

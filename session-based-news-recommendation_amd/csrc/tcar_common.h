@@ -130,7 +130,7 @@ int tcar_attn_pool_bwd_slabs_o(const tcar_dims_t* d, int B, int T, const float* 
                                const float* dpooled, int nd_ic, int nd_pt, int64_t dp_stride, float* dx_icp, float* dx_pt, float* dq,
                                float* dpre1, float* dpre2, float* gw_rows, void* stream, TcarOpt* o);
 int tcar_query_mlp_bwd_o(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w, float* dq1,
-                         float* dclick, void* stream, TcarOpt* o);
+                         float* dclick, void* stream, TcarOpt* o, const float* dq1_slab2 = nullptr /* dq == NULL: dq1 = dq1 + this */);
 // Split-K slabs of the three input-gradient GEMMs of the projections (step.hip, TCAR_INGRAD_SPLIT): the gradient a consumer reads is
 // dx_X[row, col] + sum_{s < n} X[s * s_X + row * ld_X + col] in slab order, with the leading dimension of the base array
 // (X = icp: 2 ldh, item half only; pt: 5 ldt; act: ldt).  n = 0: no slabs.

@@ -11,6 +11,7 @@
 #   pmc:<variant>:<nsplit>     tools/pmc_gemm.sh                          -> <tag>_pmc_<variant>.log (+ gpurun_out/pmc_*.json)
 #   head                       tools/head_bench.py                        -> <tag>_head_bench.txt
 #   py:<script and args>       any python tool                            -> <tag>_py.log (appended)
+#   sh:<command line>          any shell command (e.g. a tools/micro binary)  -> <tag>_sh.log (appended)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 tag=$1; shift
@@ -59,6 +60,7 @@ PY
       bash tools/pmc_gemm.sh $v $n > gpurun_out/${tag}_pmc_${v}.log 2>&1; tail -5 gpurun_out/${tag}_pmc_${v}.log ;;
     head) python tools/head_bench.py 2 2>&1 | grep -v Warning | tee gpurun_out/${tag}_head_bench.txt ;;
     py) python $rest 2>&1 | tee -a gpurun_out/${tag}_py.log | tail -40 ;;
+    sh) timeout 600 bash -c "$rest" 2>&1 | tee -a gpurun_out/${tag}_sh.log | tail -60 ;;
     *) echo "unknown step $step" ;;
   esac
 done
