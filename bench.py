@@ -464,6 +464,11 @@ def main():
         eng.check_forks()
     if hasattr(eng, "exchange_info"):
         exchange = eng.exchange_info()        # after the timed steps: carries the bytes each collective moved per step
+        if dist is not None:
+            # what the BACKEND saw: world size and rank as the process group reports them, backend, RCCL /
+            # HIP versions, reduce-scatter capability — from the three preflight collectives of this very job
+            exchange["process_group"] = {k: caps.get(k) for k in ("world", "backend", "rccl", "hip", "torch", "device", "reduce_scatter")}
+            exchange["process_group"]["ranks_seen_by_all_gather"] = dist.get_world_size()
     value = B * world * args.steps / dt
     eng_splitk = getattr(eng, "splitk", 18)
 

@@ -12,7 +12,9 @@ from typing import List
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libtcar_hip.so")
+# (TCAR_LIB: load THIS binary instead — a diagnostic build of the same sources, e.g. tools/obs1_probe.py's -DTCAR_OBS1_DIAG library;
+#  it must carry the same source digest and ABI, and it is never built or overwritten by build())
+LIB_PATH = os.environ.get("TCAR_LIB") or os.path.join(PKG_DIR, "libtcar_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_bf16.hip", "embed.hip", "pool.hip", "score.hip", "optim.hip", "step.hip", "mha.hip",
            "sampler.hip", "norm.hip", "shard.hip", "segsum.hip", "query.hip", "buildid.hip"]
 BUILD_ID_TU = "buildid.hip"        # the one translation unit that carries the digest of all sources

@@ -1069,21 +1069,24 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
         const int col = lane + 64 * c;
         g[u][c] = (use_base && u < n && col < cols) ? p[u][col] : 0.f;
       }
-    if (sbase) {
-      for (int sI = 0; sI < a.sl.n; ++sI) {
-        float h[4][NC];
+    if (sbase) {        // both slabs' slices are requested before the first add (one round trip, not one per slab)
+      float h[2][4][NC];
+#pragma unroll
+      for (int sI = 0; sI < 2; ++sI)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
           for (int c = 0; c < NC; ++c) {
             const int col = lane + 64 * c;
-            h[u][c] = (u < n && col < cols) ? (sbase + sI * sstride + (p[u] - base))[col] : 0.f;
+            h[sI][u][c] = (sI < a.sl.n && u < n && col < cols) ? (sbase + sI * sstride + (p[u] - base))[col] : 0.f;
           }
+#pragma unroll
+      for (int sI = 0; sI < 2; ++sI)
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int c = 0; c < NC; ++c) g[u][c] += h[u][c];
-      }
+          for (int c = 0; c < NC; ++c)
+            if (sI < a.sl.n) g[u][c] += h[sI][u][c];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {

@@ -746,6 +746,77 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
   tcar_signal_done(sig);
 }
 
+#ifdef TCAR_OBS1_DIAG
+// DIAGNOSTIC ONLY (-DTCAR_OBS1_DIAG, tools/obs1_probe.py): round 4's FIRST form of the kernel above (git f933989), which staged the
+// clipped rows and the dP tile through LDS and — in the step, beside the dE GEMM — "dropped single terms of single rows now and
+// then" (observation 1).  Kept out of the product build; selected at run time by TCAR_OBS1_LDS=1 in a diagnostic build.
+__global__ __launch_bounds__(256) void reduce_dact_onehot_lds_kernel(const float* __restrict__ slabs, int S, int M, int ic, long lds_,
+                                                                     const float* __restrict__ addend, long ld_add,
+                                                                     const float* __restrict__ y, long ldy, const float* __restrict__ tclip,
+                                                                     float* __restrict__ out, long ldo, float* __restrict__ dP, TcarSignal sig) {
+  __shared__ float dpl[16 * 64];
+  __shared__ __attribute__((aligned(16))) float tl[61 * 64];
+  const int tid = threadIdx.x, cg = tid & 15, rp = tid >> 4;
+  const int nic = ic >> 6;
+  const int r0 = blockIdx.y * 16, row = r0 + rp;
+  int col;
+  if ((int)blockIdx.x < nic) {
+    col = blockIdx.x * 64 + cg * 4;
+    if (row < M) {
+      float4 acc = addend ? ld4(addend + (long)row * ld_add + col) : zero4();
+      const float* sp = slabs + (long)row * lds_ + col;
+      int k = 0;
+      for (; k + 12 <= S; k += 12) {
+        float4 t[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) t[j] = ld4(sp + (long)(k + j) * M * lds_);
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc = add4(acc, t[j]);
+      }
+      for (; k < S; ++k) acc = add4(acc, ld4(sp + (long)k * M * lds_));
+      const float4 yy = ld4(y + (long)row * ldy + col);
+      acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+      st4(out + (long)row * ldo + col, acc);
+    }
+  } else {
+    const int k = blockIdx.x - nic;
+    const int off = k == 0 ? 0 : k == 1 ? 13 : k == 2 ? 45 : k == 3 ? 53 : 78;
+    const int nk = k == 0 ? 13 : k == 1 ? 32 : k == 2 ? 8 : k == 3 ? 25 : 61;
+    col = ic + k * 64 + cg * 4;
+    for (int i = tid; i < nk * 16; i += 256) st4(tl + i * 4, ld4(tclip + (long)off * 64 + i * 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cg + 16 * j;
+      float v = 0.f;
+      if (row < M && c < nk) {
+        const float* sp = slabs + (long)row * lds_ + ic + off + c;
+        int q = 0;
+        for (; q + 6 <= S; q += 6) {
+          float t[6];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) t[u] = sp[(long)(q + u) * M * lds_];
+#pragma unroll
+          for (int u = 0; u < 6; ++u) v += t[u];
+        }
+        for (; q < S; ++q) v += sp[(long)q * M * lds_];
+        if (sig.cnt) __hip_atomic_store(dP + (long)row * 160 + off + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dP[(long)row * 160 + off + c] = v;
+      }
+      dpl[rp * 64 + c] = v;
+    }
+    __syncthreads();
+    if (row < M) {
+      float4 acc = zero4();
+      for (int r = 0; r < nk; ++r) acc = fma4(*reinterpret_cast<const float4*>(tl + r * 64 + cg * 4), dpl[rp * 64 + r], acc);
+      const float4 yy = ld4(y + (long)row * ldy + col);
+      acc.x *= 1.f - yy.x * yy.x; acc.y *= 1.f - yy.y * yy.y; acc.z *= 1.f - yy.z * yy.z; acc.w *= 1.f - yy.w * yy.w;
+      st4(out + (long)row * ldo + col, acc);
+    }
+  }
+  tcar_signal_done(sig);
+}
+#endif
+
 // ---- dz = dy * act'(y), bias_grad += column sums (modules.py:52-54 backward) ------------------------------
 // grid = (ncol/64 column blocks, row chunks); 256 threads = 64 columns x 4 row phases; one atomic per column
 // and workgroup into the (zeroed) bias gradient.
@@ -1173,6 +1244,14 @@ int tcar_reduce_dact_onehot_o(const float* slabs, int splitk, int M, int ic, int
       !tclip || !out || !dP || !tcar_aligned16(slabs) || (y && !tcar_aligned16(y)) || !tcar_aligned16(out) || !tcar_aligned16(tclip) ||
       (addend && !tcar_aligned16(addend)))
     return TCAR_E_ARG;
+#ifdef TCAR_OBS1_DIAG
+  if (getenv("TCAR_OBS1_LDS") && y && !bias_grad0 && !bias_grad1 && !(o && o->wait.flag)) {
+    TCAR_LAUNCH(reduce_dact_onehot_lds_kernel, dim3(ic / 64 + 5, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, ic,
+                (long)ld, addend, (long)ld_add, y, (long)ldy, tclip, out, (long)ldo, dP, tcar_sig(o));
+    TCAR_CHECK_LAUNCH();
+    return TCAR_OK;
+  }
+#endif
   TCAR_LAUNCH(reduce_dact_onehot_kernel, dim3(ic / 64 + 5, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, ic,
               (long)ld, addend, (long)ld_add, y, (long)ldy, tclip, out, (long)ldo, dP, bias_grad0, bias_grad1, tcar_sig(o),
               o ? o->wait : TcarWait{});

@@ -935,8 +935,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // Click-query MLP backward (dq -> dq1 -> dclick) as ONE launch on the third stream (query.hip), behind the pool backward's flag:
   // its outputs feed only the side streams (dq1: weight gradients + column sums; dclick: the small tables' pass), so the main
   // chain's grouped launch keeps the three input-gradient GEMMs only (K = 256: 4 stages instead of the 8 of the dq1 product)
-  const bool qb = detc && tn(c).qbwd_fused == 1 && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
-                  tn(c).det_small != 0;
+  // (TCAR_INGRAD_SPLIT = 2 takes this flow too, with the three input-gradient GEMMs as split-K slabs: below)
+  const bool qb = detc && (tn(c).qbwd_fused == 1 || tn(c).ingrad_split == 2) && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish &&
+                  c->stream3 && c->ev3 && sorted && tn(c).det_small != 0;
   // Weight gradients in two launches (TCAR_WGRAD_SPLIT = 1; measured, OFF): eight of the nine problems need only what exists behind
   // the pool backward — they can start on the third stream behind ITS flag, ~25 us before the input-gradient launch ends; dW_q1
   // (needs dq1) follows behind that launch.  The third stream's chain (weight gradients -> column sums -> dense norms) is the
@@ -954,8 +955,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // gradient dW_q1 = click_t^T dq1 as a K-concatenation over the two slabs, the bias gradient as a column sum over 2 B rows.
   const int nis = tcar_gemm_splitk_effective(g.ldh, units(g.ldh));
   const int64_t dx_floats = (int64_t)nis * BT * (g.ic + g.pt + g.ldt);
-  const bool isplit = detc && !qb && !wsplit && tn(c).ingrad_split && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
-                      tn(c).det_small != 0 && nis <= 2 && g.ldh == 256 && g.ldt == 64 && tn(c).qbwd_fused == 2 && c->proj_slabs &&
+  // TCAR_INGRAD_SPLIT = 2: the click-query backward flow (qb: dq1 AND dclick by ONE fp32 launch on the third stream behind the pool
+  // backward's flag; the weight gradients follow it there and wait for nothing of this chain) with the three input-gradient GEMMs
+  // of the main chain as slabs — dq1 stays un-split.
+  const int ism = tn(c).ingrad_split;
+  const bool isplit = detc && ism != 0 && (ism == 2 ? qb : !qb) && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
+                      tn(c).det_small != 0 && nis <= 2 && g.ldh == 256 && g.ldt == 64 && (qb || tn(c).qbwd_fused == 2) && c->proj_slabs &&
                       B <= (tn(c).wgrad_ks > 0 ? tn(c).wgrad_ks : 1536) && c->proj_slab_floats >= dx_floats + 2LL * B * g.ldh;
   TcarDxSlabs dxs{};
   float* dq1_slabs = nullptr;          // [2][B][ldh]
@@ -964,7 +969,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     dxs.icp = c->proj_slabs; dxs.s_icp = (long)BT * g.ic;
     dxs.pt = dxs.icp + nis * dxs.s_icp; dxs.s_pt = (long)BT * g.pt;
     dxs.act = dxs.pt + nis * dxs.s_pt; dxs.s_act = (long)BT * g.ldt;
-    dq1_slabs = c->proj_slabs + dx_floats;
+    if (!qb) dq1_slabs = c->proj_slabs + dx_floats;
   }
   bool wgrad_early = false;
   if (detc) {
@@ -997,9 +1002,15 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     (void)fork_commit(c, FK_QBWD, oq);
     // main chain: the three input-gradient GEMMs (only the ITEM half of dX_ic: content is frozen)
     tcar_gemm_desc_t p[3];
-    p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
-    p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
-    p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
+    if (isplit) {     // split-K slabs, folded by the consumers (row gradients here, small tables on the aux stream)
+      p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, const_cast<float*>(dxs.icp), g.ic, nullptr, 0, 0, units(g.ldh));
+      p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, const_cast<float*>(dxs.act), g.ldt, nullptr, 0, 0, units(g.ldh));
+      p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, const_cast<float*>(dxs.pt), g.pt, nullptr, 0, 0, units(g.ldh));
+    } else {
+      p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
+      p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
+      p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
+    }
     TcarOpt oi = opt_of(c);
     oi.sig = fork_arm(c, FK_INGRAD);
     RET(small_gemm(c, 1, 3, p, stream, &oi));
@@ -1045,6 +1056,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   TcarOpt ow = opt_of(c);
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
+    // (TCAR_INGRAD_SPLIT = 2: dq1 is ahead of the weight gradients on this stream and nothing else of theirs comes from the
+    //  input-gradient launch: no second poll)
+    if (!(isplit && qb))
     RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));        // (flagged small-GEMM launches store write-through)
     // (with the negative rows on this stream it already waited for dE — ev[4], recorded on the aux stream BEHIND the arena zero —
     // and a wait for a completed event still costs the stream a ~6-us barrier packet)
