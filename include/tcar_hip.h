@@ -84,13 +84,6 @@ typedef struct {
   int32_t ce_fold;          /* TCAR_CE_FOLD        w > 0 (default 1024): tcar_ce_finish as ONE launch of about w workgroups — each folds the (max, sum)
                                                    pairs of its own 16 session rows, then rescales its slice of the plane — instead of a combine
                                                    launch + a rescale launch (0); the same bits either way */
-  int32_t ingrad_split;     /* TCAR_INGRAD_SPLIT   1 (default): the grouped launch [dq1 | three input-gradient GEMMs of the projections] on the main
-                                                   chain of the fused step as split-K slabs of at most four 64-deep stages per workgroup (the
-                                                   activation backward of dq1 applied per slab); the consumers (row gradients, small tables,
-                                                   dclick, dW_q1, the Q1 bias column sum) add the slabs in slab order.  0: un-split (4-8 stages).
-                                                   2: dq1 + dclick by ONE fp32 launch on the third stream behind the pool backward's flag (the
-                                                   TCAR_QBWD_FUSED = 1 flow; the weight gradients follow it and wait for nothing of the main
-                                                   chain), the three input-gradient GEMMs alone on the main chain, as slabs */
 } tcar_tuning_t;
 /* *out = the process-wide values (shipped defaults + TCAR_* environment) */
 int tcar_tuning_defaults(tcar_tuning_t* out /*host*/);

@@ -30,7 +30,6 @@ struct EmbArgs {
   // backward only: with n_gather > 0 the workgroups [n_gather, gridDim.x) compute block partials of sum sq_g^2 (the dense
   // item norm, tcar_sqnorm_det's job) beside the row gradients instead of in a launch of their own
   const float* sq_g; long sq_len; float* sq_part; int n_gather;
-  TcarDxSlabs sl;      // backward only: split-K slabs of the input gradients, folded while the rows are read (n = 0: none)
 };
 
 __device__ __forceinline__ int time_vocab(int k) {
@@ -167,8 +166,11 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
   __builtin_nontemporal_store(x, reinterpret_cast<v4f_e*>(p));
 }
 
-template <int NCH>
+// R: consecutive session rows per wave and trip; PLAIN: plain stores instead of non-temporal ones (tools/gather_sweep.sh measures the
+// forms; the launcher's default is the fastest)
+template <int NCH, int R = 4, bool PLAIN = false>
 __global__ __launch_bounds__(1024) void gather_clip_fwd_big_kernel(const EmbArgs a) {
+  auto st_out = [](float* p, float4 v) { if (PLAIN) st4(p, v); else st4_nt(p, v); };
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -207,7 +209,6 @@ __global__ __launch_bounds__(1024) void gather_clip_fwd_big_kernel(const EmbArgs
   }
   __syncthreads();
 
-  constexpr int R = 4;
   const long wave_g = (long)blockIdx.x * 16 + wave;
   const long stride = (long)gridDim.x * 16 * R;
   int ids[R], ids_n[R];
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(1024) void gather_clip_fwd_big_kernel(const EmbArgs
       const float4 x = oob ? zero4() : ld4(lsm + (time_rowoff(kk) + id) * ldt + lin * 4);
       if (valid) {
         float* dst = (kk < 5) ? a.x_pt + row * pt + kk * ldt : a.x_act + row * ldt;
-        st4_nt(dst + lin * 4, x);
+        st_out(dst + lin * 4, x);
       }
     }
 #pragma unroll
@@ -266,8 +267,8 @@ __global__ __launch_bounds__(1024) void gather_clip_fwd_big_kernel(const EmbArgs
         for (int c = 0; c < NCH; ++c) {
           const int col = c * 256 + lane * 4;
           if (col < ldh) {
-            st4_nt(o + col, fma4(xi[u][c], si, ld4(lpos + t * ldh + col)));
-            st4_nt(o + ldh + col, scale4(xc[u][c], sc));
+            st_out(o + col, fma4(xi[u][c], si, ld4(lpos + t * ldh + col)));
+            st_out(o + ldh + col, scale4(xc[u][c], sc));
           }
         }
       }
@@ -363,30 +364,13 @@ __global__ __launch_bounds__(256) void gather_clip_bwd_kernel(const EmbArgs a) {
         xp[c] = ok ? ld4(a.tab.pos + (long)t * ldh + col) : zero4();
         gi[c] = ok ? ld4(gy + col) : zero4();
       }
-      // split-K slabs of the input-gradient GEMM (at most two): loaded beside the rows, added in slab order
-      float4 gs[2][NCH];
-#pragma unroll
-      for (int sI = 0; sI < 2; ++sI)
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int col = c * 256 + lane * 4;
-          gs[sI][c] = (sI < a.sl.n && col < ldh) ? ld4(a.sl.icp + sI * a.sl.s_icp + (long)row * ic + col) : zero4();
-        }
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int kk = kval[it] ? it * gpw + grp : 0;
         const float* tp = (kk < 5) ? pick5(a.tab.time, kk) : a.tab.dur;
-        const long goff = (kk < 5) ? (long)row * pt + kk * ldt : (long)row * ldt;
-        const float* gp = ((kk < 5) ? a.dx_pt : a.dx_act) + goff;
+        const float* gp = (kk < 5) ? a.dx_pt + (long)row * pt + kk * ldt : a.dx_act + (long)row * ldt;
         kx[it] = (kact[it] && !item_only) ? ld4(tp + (long)kid[it] * ldt + lin * 4) : zero4();
-        kgy[it] = (kval[it] && !item_only && (kk < 5 || a.sl.n == 0 || a.sl.act_base)) ? ld4(gp + lin * 4) : zero4();
-        if (!item_only)
-          for (int sI = 0; sI < a.sl.n; ++sI)
-            if (kval[it]) kgy[it] = add4(kgy[it], ld4(((kk < 5) ? a.sl.pt + sI * a.sl.s_pt : a.sl.act + sI * a.sl.s_act) + goff + lin * 4));
-      }
-      if (a.sl.n > 0) {
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) gi[c] = add4(add4(gi[c], gs[0][c]), gs[1][c]);
+        kgy[it] = (kval[it] && !item_only) ? ld4(gp + lin * 4) : zero4();
       }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
@@ -1028,7 +1012,6 @@ struct SmallDetArgs {
   const float* dx_icp; const float* dx_pt; const float* dx_act; const float* dclick;
   float* g_pos; float* g_small;      // [40, ldh]; [150, ldt] = month | day | week | hour | minute | dwell
   float* rowq;                        // [SMALL_DET_ROWS] per-row norm pieces (folded per table by small_norm_fold_kernel)
-  TcarDxSlabs sl;                     // split-K slabs of the input gradients, added in slab order while the sources are read
 };
 constexpr int SMALL_DET_ROWS = TCAR_POS_VOCAB + SMALL_ROWS + 1;   // + the out-of-range dwell bucket (norm only, S7)
 
@@ -1058,36 +1041,15 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
   }
   float ql = 0.f, D2 = 0.f;
   // acc of up to 4 sources whose gradient slices start at p[0..n): loads first, then the sums in order
-  // (base / sbase / sstride: the array the slices live in and its slab copies — the same offsets in every slab; sbase = nullptr: none)
-  auto take4 = [&](const float* const* p, int n, const float* base = nullptr, const float* sbase = nullptr, long sstride = 0,
-                   bool use_base = true) {
+  auto take4 = [&](const float* const* p, int n) {
     float g[4][NC];
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int col = lane + 64 * c;
-        g[u][c] = (use_base && u < n && col < cols) ? p[u][col] : 0.f;
+        g[u][c] = (u < n && col < cols) ? p[u][col] : 0.f;
       }
-    if (sbase) {        // both slabs' slices are requested before the first add (one round trip, not one per slab)
-      float h[2][4][NC];
-#pragma unroll
-      for (int sI = 0; sI < 2; ++sI)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const int col = lane + 64 * c;
-            h[sI][u][c] = (sI < a.sl.n && u < n && col < cols) ? (sbase + sI * sstride + (p[u] - base))[col] : 0.f;
-          }
-#pragma unroll
-      for (int sI = 0; sI < 2; ++sI)
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int c = 0; c < NC; ++c)
-            if (sI < a.sl.n) g[u][c] += h[sI][u][c];
-    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       if (u >= n) break;
@@ -1106,7 +1068,7 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
       const int n = min(4, b1 - b);
 #pragma unroll
       for (int u = 0; u < 4; ++u) p[u] = a.dx_icp + ((long)(b + (u < n ? u : 0)) * T + R) * ic;
-      take4(p, n, a.dx_icp, a.sl.n > 0 ? a.sl.icp : nullptr, a.sl.s_icp);
+      take4(p, n);
     }
   } else {
     // session rows: id of table k at every source row; matches of this wave's sixteenth, in order
@@ -1134,8 +1096,7 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
             n = u + 1;
           } else p[u] = p[0];
         }
-        take4(p, n, (k < 5) ? a.dx_pt : a.dx_act, a.sl.n > 0 ? ((k < 5) ? a.sl.pt : a.sl.act) : nullptr, (k < 5) ? a.sl.s_pt : a.sl.s_act,
-              k < 5 || a.sl.n == 0 || a.sl.act_base != 0);
+        take4(p, n);
       }
     }
     // click rows: the week table by cw, the hour table by ch (model_combine.py:94-97)
@@ -1282,10 +1243,21 @@ int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const
     // throughput form: one 16-wave workgroup per CU (the clipped small tables live in its LDS)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    long g = (rows + 16 * 4 - 1) / (16 * 4);
-    const long cap = (long)cus * (tn.gather_wg_per_cu > 0 ? tn.gather_wg_per_cu : 1);
+    // (TCAR_GATHER_WG = workgroups per CU + 16 * form; forms 1-3 exist for the sweep of tools/gather_sweep.sh: 1 plain stores,
+    //  2 eight rows per wave and trip, 3 two rows)
+    const int wgpc = tn.gather_wg_per_cu & 15, form = tn.gather_wg_per_cu >> 4;
+    const int rpw = form == 2 ? 8 : form == 3 ? 2 : 4;
+    long g = (rows + 16 * rpw - 1) / (16 * rpw);
+    const long cap = (long)cus * (wgpc > 0 ? wgpc : 1);
     if (g > cap) g = cap;
-    if (d->ldh <= 256) {
+    if (d->ldh <= 256 && form >= 1 && form <= 3) {
+      if (form == 1) { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 4, true>), 160 * 1024);
+        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 4, true>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
+      else if (form == 2) { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 8, false>), 160 * 1024);
+        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 8, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
+      else { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 2, false>), 160 * 1024);
+        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 2, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
+    } else if (d->ldh <= 256) {
       TCAR_SET_LDS_ONCE(gather_clip_fwd_big_kernel<1>, 160 * 1024);
       TCAR_LAUNCH(gather_clip_fwd_big_kernel<1>, dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a);
     } else {
@@ -1306,11 +1278,9 @@ int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const
 namespace {
 int gather_bwd_launch(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp, const float* dx_pt,
                       const float* dx_act, const float* dclick, const tcar_grads_t* g, const float* sq_g, long sq_len,
-                      float* sq_part, int sq_blocks, void* stream, const TcarDxSlabs* sl = nullptr) {
+                      float* sq_part, int sq_blocks, void* stream) {
   if (check_dims(d) || !tab || !bt || !g || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
-  if (sl && sl->n > 0 && (sl->n > 2 || !sl->icp || (!g->skip_small && (!sl->pt || !sl->act)))) return TCAR_E_ARG;
   EmbArgs a{};
-  if (sl) a.sl = *sl;
   a.d = *d; a.tab = *tab; a.bt = *bt; a.g = *g;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;
   long rows = (long)bt->B * bt->T + bt->B;
@@ -1357,15 +1327,6 @@ extern "C" int tcar_gather_clip_bwd_sqnorm(const tcar_dims_t* d, const tcar_tabl
   return gather_bwd_launch(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, sq_g, (long)sq_len, (float*)((char*)ws + ws_bytes - 4096),
                            512, stream);
 }
-// ... with the split-K slabs of the input gradients folded while the rows are read (step.hip, TCAR_INGRAD_SPLIT)
-int tcar_gather_clip_bwd_sqnorm_s(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
-                                  const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, const float* sq_g,
-                                  int64_t sq_len, void* ws, int64_t ws_bytes, void* stream, const TcarDxSlabs* sl) {
-  if (!sq_g || sq_len <= 0 || (sq_len & 3) || !tcar_aligned16(sq_g) || !ws || ws_bytes < 4096) return TCAR_E_ARG;
-  return gather_bwd_launch(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, sq_g, (long)sq_len, (float*)((char*)ws + ws_bytes - 4096),
-                           512, stream, sl);
-}
-
 extern "C" int tcar_cand_time_bwd_indexed(const tcar_dims_t* d, const float* const time_tab[5], const int32_t* inv_n,
                                          const int32_t* inv_off, const float* d_et, int permuted, float* ws,
                                          const tcar_grads_t* g, void* stream) {
@@ -1491,12 +1452,10 @@ extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables
 // (flag-capable: the norm fold, its last launch, publishes its slots with atomics)
 int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                 const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
-                                void* stream, TcarOpt* o, const float* cand_pc, const TcarDxSlabs* sl) {
+                                void* stream, TcarOpt* o, const float* cand_pc) {
   if (check_dims(d) || !tab || !bt || !g || !ws || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
   if (!dx_icp || !dx_pt || !dx_act || !dclick || !g->g_pos || !g->g_time[0] || !g->sqn) return TCAR_E_ARG;
-  if (sl && sl->n > 0 && (sl->n > 2 || !sl->icp || !sl->pt || !sl->act)) return TCAR_E_ARG;
   SmallDetArgs a{};
-  if (sl) a.sl = *sl;
   a.d = *d; a.tab = *tab; a.bt = *bt;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;
   a.g_pos = g->g_pos; a.g_small = g->g_time[0]; a.rowq = ws;

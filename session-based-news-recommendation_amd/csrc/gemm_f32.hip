@@ -590,10 +590,7 @@ int fill_prob(GemmProb& p, int layout, const tcar_gemm_desc_t& d) {
   p.pack_c0 = d.pack_c0; p.pack_c1 = d.pack_c1;
   if (d.plane_hi && (!d.plane_lo || (d.plane_inner & 31) || d.plane_col0 < 0 || d.plane_col0 + d.N > d.plane_inner)) return TCAR_E_ARG;
   if (d.pack_hi && (!d.plane_hi || !d.pack_lo || (d.pack_inner & 31) || d.pack_c0 > d.pack_c1)) return TCAR_E_ARG;
-  // (activation backward is a factor that depends on dact_y only — linear in the K sum: in SLAB mode it is applied per slab and the
-  //  consumer's slab sum is the full result; not with atomics, and no column sums from partial products)
-  if (d.plane_hi && d.splitk > 1) return TCAR_E_ARG;
-  if (d.dact && d.splitk > 1 && (d.atomic || d.colsum)) return TCAR_E_ARG;
+  if ((d.dact || d.plane_hi) && d.splitk > 1) return TCAR_E_ARG;
   int splitk = d.splitk < 1 ? 1 : d.splitk;
   p.mode = splitk > 1 ? (d.atomic ? 2 : 1) : 0;
   if (splitk > 1 && (d.nseg != 1 || d.bias || d.act || d.beta)) return TCAR_E_ARG;

@@ -121,7 +121,6 @@ struct QBwdArgs {
   float* dq1; float* dclick;
   int B;
   TcarSignal sig;
-  const float* dq1b;      // dq == NULL only: second split-K slab of dq1 (the layer-1 half reads dq1 + dq1b); NULL: none
 };
 // v[0 .. V) per lane -> the sum over the 64 lanes of v[i] ends in lane (i * 64 / V) .. (each index owned by 64 / V adjacent lanes,
 // all of which hold it); V a power of two <= 64
@@ -198,9 +197,7 @@ __global__ __launch_bounds__(512) void query_mlp_bwd_kernel(const QBwdArgs a) {
 #pragma unroll
     for (int s = 0; s < QS; ++s)
       g[s] = a.dq ? *reinterpret_cast<const float4*>(dq1s + s * H1 + lane * 4)
-                  : (b0 + s < a.B ? (a.dq1b ? add4(ld4(a.dq1 + (long)(b0 + s) * H1 + lane * 4), ld4(a.dq1b + (long)(b0 + s) * H1 + lane * 4))
-                                             : ld4(a.dq1 + (long)(b0 + s) * H1 + lane * 4))
-                                   : zero4());
+                  : (b0 + s < a.B ? ld4(a.dq1 + (long)(b0 + s) * H1 + lane * 4) : zero4());
     float4 w[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) w[r] = ld4(a.w1 + (long)(wave * 16 + r) * H1 + lane * 4);
@@ -229,14 +226,12 @@ extern "C" int tcar_query_mlp_bwd(const tcar_dims_t* d, int B, const float* dq, 
 }
 // (flag-capable: dq1 and dclick leave write-through when the launch carries a flag)
 int tcar_query_mlp_bwd_o(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w, float* dq1,
-                         float* dclick, void* stream, TcarOpt* o, const float* dq1_slab2) {
+                         float* dclick, void* stream, TcarOpt* o) {
   if (!d || d->ldh != H1 || d->ldt * 2 != CT || B <= 0) return TCAR_E_ARG;
   if (!q1_w || !dq1 || !dclick || !tcar_aligned16(q1_w) || !tcar_aligned16(dq1)) return TCAR_E_ARG;
   if (dq && (!q1 || !q2_w || !tcar_aligned16(dq) || !tcar_aligned16(q2_w))) return TCAR_E_ARG;
   QBwdArgs a{};
   a.dq = dq; a.q1 = q1; a.w1 = q1_w; a.w2 = q2_w; a.dq1 = dq1; a.dclick = dclick; a.B = B;
-  if (dq1_slab2 && (dq || !tcar_aligned16(dq1_slab2))) return TCAR_E_ARG;
-  a.dq1b = dq1_slab2;
   a.sig = tcar_sig(o);
   TCAR_LAUNCH(query_mlp_bwd_kernel, dim3((unsigned)((B + QS - 1) / QS)), dim3(512), 0, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();

@@ -24,7 +24,7 @@ const Switch kSwitches[] = {
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
     {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_REST_EARLY", &TcarTuning::rest_early, 0},
     {"TCAR_WGRAD_SPLIT", &TcarTuning::wgrad_split, 0},      {"TCAR_COLSUM_FUSED", &TcarTuning::colsum_fused, 1},
-    {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},           {"TCAR_INGRAD_SPLIT", &TcarTuning::ingrad_split, 1},
+    {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -673,9 +673,7 @@ namespace {
 // tcar_fold_slabs), else with float atomics into the zeroed arena.
 // part: 0 = all nine problems; 1 = the eight that need nothing of the input-gradient launch (dattout, dq, dpre1, dpre2: ready behind
 // the pool backward); 2 = dW_q1 = click_t^T dq1 alone (dq1 comes out of the input-gradient launch)
-// dq1_slabs: dq1 arrives as two split-K slabs [2][B][ldh] (TCAR_INGRAD_SPLIT): dW_q1 = click_t^T (slab 0 + slab 1) as a K-concatenation
-int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream, TcarOpt* o = nullptr, int part = 0,
-                 const float* dq1_slabs = nullptr) {
+int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream, TcarOpt* o = nullptr, int part = 0) {
   const int ksdiv = tn(c).wgrad_ks > 0 ? tn(c).wgrad_ks : 1536;
   auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
   const int kb = ks(B), kr = ks(BT);
@@ -684,8 +682,7 @@ int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream,
   p[0] = prob1(g.ic, g.ic, c->pooled, g.ek, c->dattout, g.ek, B, G(c, TCAR_V_O_W), g.ic, nullptr, 0, 0, kb, 1);
   p[1] = prob1(g.pt, g.pt, c->pooled + g.ic, g.ek, c->dattout + g.ic, g.ek, B, G(c, TCAR_V_OT_W), g.pt, nullptr, 0, 0, kb, 1);
   p[2] = prob1(g.ldh, g.ic, c->q1, g.ldh, c->dq, g.ic, B, G(c, TCAR_V_Q2_W), g.ic, nullptr, 0, 0, kb, 1);
-  p[3] = prob1(g.ct, g.ldh, c->click_t, g.ct, dq1_slabs ? dq1_slabs : c->dq1, g.ldh, B, G(c, TCAR_V_Q1_W), g.ldh, nullptr, 0, 0, kb, 1);
-  if (dq1_slabs) seg(p[3], c->click_t, g.ct, dq1_slabs + (long)B * g.ldh, g.ldh, B);       // (kb == 1 there: the caller checks B)
+  p[3] = prob1(g.ct, g.ldh, c->click_t, g.ct, c->dq1, g.ldh, B, G(c, TCAR_V_Q1_W), g.ldh, nullptr, 0, 0, kb, 1);
   p[4] = prob1(g.ic, g.ldh, c->x_icp, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WIN), g.ldh, nullptr, 0, 0, kr, 1);
   p[5] = prob1(g.ldh, g.ldh, x_c, g.ic, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WC), g.ldh, nullptr, 0, 0, kr, 1);
   p[6] = prob1(g.ldt, g.ldh, c->x_act, g.ldt, c->dpre1, g.ldh, BT, G(c, TCAR_V_M_WINT), g.ldh, nullptr, 0, 0, kr, 1);
@@ -732,19 +729,18 @@ int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream,
 }
 
 // bias gradients of the four linear_2d layers and the two residual-weight gradients as column sums in a fixed order
-void det_colsum_list(const tcar_ctx_t* c, const Geo& g, int B, tcar_colsum_t (&cs)[6], const float* dq1_slabs = nullptr) {
+void det_colsum_list(const tcar_ctx_t* c, const Geo& g, int B, tcar_colsum_t (&cs)[6]) {
   const tcar_colsum_t v[6] = {{c->dattout, g.ek, B, g.ic, G(c, TCAR_V_O_B)},
                               {c->dattout + g.ic, g.ek, B, g.pt, G(c, TCAR_V_OT_B)},
                               {c->dq, g.ic, B, g.ic, G(c, TCAR_V_Q2_B)},
-                              // (dq1 as two slabs [2][B][ldh]: the column sum runs over 2 B rows — slab 0's rows, then slab 1's)
-                              {dq1_slabs ? dq1_slabs : c->dq1, g.ldh, dq1_slabs ? 2 * B : B, g.ldh, G(c, TCAR_V_Q1_B)},
+                              {c->dq1, g.ldh, B, g.ldh, G(c, TCAR_V_Q1_B)},
                               {c->gw_rows, g.ic, B, g.ldh, G(c, TCAR_V_M_WRES)},
                               {c->gw_rows + g.ldh, g.ic, B, g.ldh, G(c, TCAR_V_S_WRES)}};
   for (int i = 0; i < 6; ++i) cs[i] = v[i];
 }
-int det_colsums(const tcar_ctx_t* c, const Geo& g, int B, void* stream, const float* dq1_slabs = nullptr) {
+int det_colsums(const tcar_ctx_t* c, const Geo& g, int B, void* stream) {
   tcar_colsum_t cs[6];
-  det_colsum_list(c, g, B, cs, dq1_slabs);
+  det_colsum_list(c, g, B, cs);
   return tcar_colsum_det(6, cs, stream);
 }
 int finish_dense_side(const tcar_ctx_t* c, const Geo& g, void* stream);
@@ -935,9 +931,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // Click-query MLP backward (dq -> dq1 -> dclick) as ONE launch on the third stream (query.hip), behind the pool backward's flag:
   // its outputs feed only the side streams (dq1: weight gradients + column sums; dclick: the small tables' pass), so the main
   // chain's grouped launch keeps the three input-gradient GEMMs only (K = 256: 4 stages instead of the 8 of the dq1 product)
-  // (TCAR_INGRAD_SPLIT = 2 takes this flow too, with the three input-gradient GEMMs as split-K slabs: below)
-  const bool qb = detc && (tn(c).qbwd_fused == 1 || tn(c).ingrad_split == 2) && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish &&
-                  c->stream3 && c->ev3 && sorted && tn(c).det_small != 0;
+  const bool qb = detc && tn(c).qbwd_fused == 1 && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
+                  tn(c).det_small != 0;
   // Weight gradients in two launches (TCAR_WGRAD_SPLIT = 1; measured, OFF): eight of the nine problems need only what exists behind
   // the pool backward — they can start on the third stream behind ITS flag, ~25 us before the input-gradient launch ends; dW_q1
   // (needs dq1) follows behind that launch.  The third stream's chain (weight gradients -> column sums -> dense norms) is the
@@ -946,31 +941,6 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // negative rows on the third stream (their wait for dE orders it behind the arena zero).
   const bool wsplit = detc && !qb && tn(c).wgrad_split && s2 && fuse_finish && c->stream3 && c->ev3 && neg_s3 && fork_host(c) &&
                       ((tn(c).flag_fork >> FK_POOLB) & 1) && ((tn(c).flag_fork >> FK_INGRAD) & 1);
-  // Input gradients as split-K slabs (TCAR_INGRAD_SPLIT, round 5).  The grouped launch [dq1 | three input-gradient GEMMs] walks 4-8
-  // serial 64-deep stages per workgroup on the step's critical chain (29.6 us beside dE).  Split form: every problem of that launch
-  // as split-K slabs of at most four stages (the launch then takes the two-stage register ring: half the round trips) —
-  // the three input-gradient GEMMs (K = ldh) as 128-deep chunks, dq1 = relu'(q1) (dq Wq2^T) (K = 2 ldh) as two 256-deep chunks
-  // with the activation backward applied PER SLAB (it is a factor that depends on q1 only: linear in the sum) — and every consumer
-  // adds the slabs in slab order while it reads: row gradients (this chain), small tables + dclick (aux stream), the weight
-  // gradient dW_q1 = click_t^T dq1 as a K-concatenation over the two slabs, the bias gradient as a column sum over 2 B rows.
-  const int nis = tcar_gemm_splitk_effective(g.ldh, units(g.ldh));
-  const int64_t dx_floats = (int64_t)nis * BT * (g.ic + g.pt + g.ldt);
-  // TCAR_INGRAD_SPLIT = 2: the click-query backward flow (qb: dq1 AND dclick by ONE fp32 launch on the third stream behind the pool
-  // backward's flag; the weight gradients follow it there and wait for nothing of this chain) with the three input-gradient GEMMs
-  // of the main chain as slabs — dq1 stays un-split.
-  const int ism = tn(c).ingrad_split;
-  const bool isplit = detc && ism != 0 && (ism == 2 ? qb : !qb) && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
-                      tn(c).det_small != 0 && nis <= 2 && g.ldh == 256 && g.ldt == 64 && (qb || tn(c).qbwd_fused == 2) && c->proj_slabs &&
-                      B <= (tn(c).wgrad_ks > 0 ? tn(c).wgrad_ks : 1536) && c->proj_slab_floats >= dx_floats + 2LL * B * g.ldh;
-  TcarDxSlabs dxs{};
-  float* dq1_slabs = nullptr;          // [2][B][ldh]
-  if (isplit) {
-    dxs.n = nis;
-    dxs.icp = c->proj_slabs; dxs.s_icp = (long)BT * g.ic;
-    dxs.pt = dxs.icp + nis * dxs.s_icp; dxs.s_pt = (long)BT * g.pt;
-    dxs.act = dxs.pt + nis * dxs.s_pt; dxs.s_act = (long)BT * g.ldt;
-    if (!qb) dq1_slabs = c->proj_slabs + dx_floats;
-  }
   bool wgrad_early = false;
   if (detc) {
     TcarOpt opb = opt_of(c);
@@ -1002,30 +972,12 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     (void)fork_commit(c, FK_QBWD, oq);
     // main chain: the three input-gradient GEMMs (only the ITEM half of dX_ic: content is frozen)
     tcar_gemm_desc_t p[3];
-    if (isplit) {     // split-K slabs, folded by the consumers (row gradients here, small tables on the aux stream)
-      p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, const_cast<float*>(dxs.icp), g.ic, nullptr, 0, 0, units(g.ldh));
-      p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, const_cast<float*>(dxs.act), g.ldt, nullptr, 0, 0, units(g.ldh));
-      p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, const_cast<float*>(dxs.pt), g.pt, nullptr, 0, 0, units(g.ldh));
-    } else {
-      p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
-      p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
-      p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
-    }
+    p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
+    p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
+    p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
     TcarOpt oi = opt_of(c);
     oi.sig = fork_arm(c, FK_INGRAD);
     RET(small_gemm(c, 1, 3, p, stream, &oi));
-    (void)fork_commit(c, FK_INGRAD, oi);
-  } else if (isplit) {
-    tcar_gemm_desc_t p[4];
-    p[0] = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, dq1_slabs, g.ldh, nullptr, 0, 0, 2);
-    p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = nullptr;
-    // (only the ITEM half of dX_ic: content is frozen)
-    p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, const_cast<float*>(dxs.icp), g.ic, nullptr, 0, 0, units(g.ldh));
-    p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, const_cast<float*>(dxs.act), g.ldt, nullptr, 0, 0, units(g.ldh));
-    p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, const_cast<float*>(dxs.pt), g.pt, nullptr, 0, 0, units(g.ldh));
-    TcarOpt oi = opt_of(c);
-    oi.sig = fork_arm(c, FK_INGRAD);     // the third stream's and the aux stream's forks below
-    RET(small_gemm(c, 1, 4, p, stream, &oi));
     (void)fork_commit(c, FK_INGRAD, oi);
   } else if (fusedq) {
     tcar_gemm_desc_t p[4];
@@ -1056,9 +1008,6 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   TcarOpt ow = opt_of(c);
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
-    // (TCAR_INGRAD_SPLIT = 2: dq1 is ahead of the weight gradients on this stream and nothing else of theirs comes from the
-    //  input-gradient launch: no second poll)
-    if (!(isplit && qb))
     RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));        // (flagged small-GEMM launches store write-through)
     // (with the negative rows on this stream it already waited for dE — ev[4], recorded on the aux stream BEHIND the arena zero —
     // and a wait for a completed event still costs the stream a ~6-us barrier packet)
@@ -1073,11 +1022,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // (it needs dq1 of that launch) — off the main chain (round 4: 17 us) and off the third stream, whose weight gradients, column
   // sums and norms are the step's last chain
   const bool dclick_aux = fusedq && det_small && s3 != nullptr && !qb;
-  RET(weight_grads(c, g, B, BT, sW, &ow, wgrad_early ? 2 : 0, dq1_slabs));
+  RET(weight_grads(c, g, B, BT, sW, &ow, wgrad_early ? 2 : 0));
   // column sums and dense norms are the last two launches of the step's last chain: ONE launch when the context has the fold scratch
   // (optim.hip: colsum_sqnorm_kernel; TCAR_COLSUM_FUSED)
   const bool cs_fused = detc && fuse_finish && s2 && c->fold_scratch && tn(c).colsum_fused;
-  if (detc && !cs_fused) RET(det_colsums(c, g, B, sW, dq1_slabs));
+  if (detc && !cs_fused) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
   // The step's LAST join (aux + third stream into the main one, in front of the next update): two event waits cost the main
@@ -1093,11 +1042,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     bool fused_done = false;
     if (cs_fused) {
       tcar_colsum_t cs[6];
-      det_colsum_list(c, g, B, cs, dq1_slabs);
+      det_colsum_list(c, g, B, cs);
       const int rc = tcar_colsum_sqnorm_o(c->Gx, &c->segs_dense, 6, cs, c->sqn_dense, sW, &o3);
       if (rc == TCAR_OK) fused_done = true;
       else if (rc != TCAR_E_ARG) return rc;
-      else { o3.carried = false; RET(det_colsums(c, g, B, sW, dq1_slabs)); }       // (a layout the fused form does not take: the two launches)
+      else { o3.carried = false; RET(det_colsums(c, g, B, sW)); }       // (a layout the fused form does not take: the two launches)
     }
     if (!fused_done) RET(tcar_sqnorm_o(c->Gx, &c->segs_dense, c->sqn_dense, sW, &o3));
     if (tail_flags) tail3 = fork_commit(c, FK_TAIL3, o3);
@@ -1139,9 +1088,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       if (tn(c).qbwd_fused == 2 && g.ldh == 256 && g.ldt == 64) {
         // dclick = dq1 Wq1^T as ONE fp32 launch of whole-row dots (query.hip: the layer-1 half of the click-query backward): 7 us
         // where the 16-workgroup small GEMM walks four serial 64-deep stages (20 us), on the chain that ends the step
-        // (split input gradients: dq1 arrives as two slabs, added while the rows are read)
-        RET(tcar_query_mlp_bwd_o(&c->d, B, nullptr, nullptr, W(c, TCAR_V_Q1_W), nullptr, isplit ? dq1_slabs : c->dq1, c->dclick, (void*)s2,
-                                 nullptr, isplit ? dq1_slabs + (long)B * g.ldh : nullptr));
+        RET(tcar_query_mlp_bwd_o(&c->d, B, nullptr, nullptr, W(c, TCAR_V_Q1_W), nullptr, c->dq1, c->dclick, (void*)s2, nullptr));
       } else {
         tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
         RET(small_gemm(c, 1, 1, &p, (void*)s2));
@@ -1152,7 +1099,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     TcarOpt o2 = opt_of(c);
     if (tail3) o2.sig = fork_arm(c, FK_TAIL2);
     RET(tcar_small_tables_bwd_det_o(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2, &o2,
-                                    ohb ? tcar_cand_pieces(&c->d, c->ct_ws) : nullptr, isplit ? &dxs : nullptr));
+                                    ohb ? tcar_cand_pieces(&c->d, c->ct_ws) : nullptr));
     if (tail3) tail2 = fork_commit(c, FK_TAIL2, o2);
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }
@@ -1186,8 +1133,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       gr.norms_out = tcar_segsum_norms_buffer(&c->d, bt, c->segsum_ws);
       gr.skip_small = det_small ? 1 : 0;
       if (split_finish)
-        RET(tcar_gather_clip_bwd_sqnorm_s(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, Gi, (int64_t)g.N * g.ldh,
-                                          c->segsum_ws, c->segsum_bytes, stream, isplit ? &dxs : nullptr));
+        RET(tcar_gather_clip_bwd_sqnorm(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, Gi, (int64_t)g.N * g.ldh,
+                                        c->segsum_ws, c->segsum_bytes, stream));
       else
         RET(tcar_gather_clip_bwd(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, stream));
       RET(tcar_segsum_apply(&c->d, bt, c->segsum_ws, c->segsum_bytes, 0, gr.rows_out, nullptr, nullptr, 0, Gi,

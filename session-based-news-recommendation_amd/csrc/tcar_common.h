@@ -130,19 +130,10 @@ int tcar_attn_pool_bwd_slabs_o(const tcar_dims_t* d, int B, int T, const float* 
                                const float* dpooled, int nd_ic, int nd_pt, int64_t dp_stride, float* dx_icp, float* dx_pt, float* dq,
                                float* dpre1, float* dpre2, float* gw_rows, void* stream, TcarOpt* o);
 int tcar_query_mlp_bwd_o(const tcar_dims_t* d, int B, const float* dq, const float* q1, const float* q1_w, const float* q2_w, float* dq1,
-                         float* dclick, void* stream, TcarOpt* o, const float* dq1_slab2 = nullptr /* dq == NULL: dq1 = dq1 + this */);
-// Split-K slabs of the three input-gradient GEMMs of the projections (step.hip, TCAR_INGRAD_SPLIT): the gradient a consumer reads is
-// dx_X[row, col] + sum_{s < n} X[s * s_X + row * ld_X + col] in slab order, with the leading dimension of the base array
-// (X = icp: 2 ldh, item half only; pt: 5 ldt; act: ldt).  n = 0: no slabs.
-// act_base = 0: dx_act has NO base part (its un-split GEMM overwrote it: nothing but the slabs) and the base array is not read.
-struct TcarDxSlabs { int n; const float* icp; const float* pt; const float* act; long s_icp, s_pt, s_act; int act_base; };
+                         float* dclick, void* stream, TcarOpt* o);
 int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                 const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
-                                void* stream, TcarOpt* o, const float* cand_pc /* optional [139]: candidate-side norm pieces */,
-                                const TcarDxSlabs* sl = nullptr);
-int tcar_gather_clip_bwd_sqnorm_s(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
-                                  const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, const float* sq_g,
-                                  int64_t sq_len, void* ws, int64_t ws_bytes, void* stream, const TcarDxSlabs* sl);
+                                void* stream, TcarOpt* o, const float* cand_pc /* optional [139]: candidate-side norm pieces */);
 int tcar_cand_time_bwd_onehot_w(const tcar_dims_t* d, int B, const int32_t* inv_off, const float* qz, const float* dP,
                                 const float* attout, int64_t ld_att, const float* tclip, float* ws, const tcar_grads_t* g, void* stream,
                                 const TcarWait& wait_dp, int with_pieces);

@@ -855,13 +855,10 @@ def test_schedule_switches_of_round_4_agree_bitwise_with_the_default_schedule():
             assert np.array_equal(base[1][k], run[1][k]), (sw, k)
 
 
-def test_schedule_switches_of_round_5_agree_with_the_default_schedule():
-    """Round 5: (a) tcar_ce_finish as ONE launch whose workgroups fold their own rows' (max, sum) pairs (TCAR_CE_FOLD = w > 0) against
-    the combine launch + rescale launch (0), at two grid sizes — the same lane-strided loops and shuffle trees, so BIT FOR BIT;
-    (b) the grouped launch [dq1 | input-gradient GEMMs of the projections] as split-K slabs folded by their consumers
-    (TCAR_INGRAD_SPLIT = 1, default) against the un-split launch (= 0), which sums K in ONE chain instead of two slabs: the same
-    numbers up to fp32 rounding of that sum — losses within 1e-5 after 40 steps (Adam turns last-bit gradient differences into
-    last-bit variable differences; nothing amplifies them here) — and each form bit-for-bit repeatable."""
+def test_ce_finish_as_one_launch_agrees_bitwise_with_the_two_launches():
+    """Round 5: tcar_ce_finish as ONE launch whose workgroups fold their own rows' (max, sum) pairs (TCAR_CE_FOLD = w > 0, default
+    1024) against the combine launch + rescale launch (0), at three grid sizes — the same lane-strided sums and shuffle trees, so the
+    plane, the losses, every variable and every Adam moment after 40 deferred steps agree BIT FOR BIT."""
     _need_gpu()
     from tcar_amd.engine import TcarEngine
     N, H, Ht, B, K = 46033, 250, 64, 512, 20
@@ -882,17 +879,11 @@ def test_schedule_switches_of_round_5_agree_with_the_default_schedule():
         return out
 
     base = run({})
-    for sw in ({"TCAR_CE_FOLD": 0}, {"TCAR_CE_FOLD": 256}, {"TCAR_CE_FOLD": 4096}, {}):
+    for sw in ({"TCAR_CE_FOLD": 0}, {"TCAR_CE_FOLD": 256}, {"TCAR_CE_FOLD": 4096}):
         got = run(sw)
         assert (base[0] == got[0]).all(), sw
         for k in base[1]:
             assert np.array_equal(base[1][k], got[1][k]), (sw, k)
-    un = run({"TCAR_INGRAD_SPLIT": 0})
-    un2 = run({"TCAR_INGRAD_SPLIT": 0})
-    assert (un[0] == un2[0]).all()
-    for k in un[1]:
-        assert np.array_equal(un[1][k], un2[1][k]), k
-    np.testing.assert_allclose(un[0], base[0], rtol=1e-5, atol=1e-6)
 
 
 def test_two_engines_stepped_alternately_from_two_host_threads_match_their_solo_runs(monkeypatch):
