@@ -439,29 +439,6 @@ def main():
         # headline pass: every event pair in the middle of a stream's chain costs ~5-10 us of bubble (8 pairs per step = 2-3 %).
         eng.enable_native_timing(args.steps)
         dt_ev, _ = timed(headline_sampler)
-    # ---- step time per length bucket (VERDICT r04 item 6): the sampler buckets by EXACT input length (sampler.py:40-49), the headline is
-    # quoted at the fold's mean length while the session-side head and tail of the step scale with B * T.  Same engine, same loop body
-    # (deferred update, resident feeds of ONE length each, items drawn from the fold's popularity law), 60 timed steps after 15.
-    by_T = None
-    if world == 1 and not os.environ.get("TCAR_FORCE_DP") and not args.no_by_T and not (args.no_cpu_baseline and args.no_e2e) \
-            and N <= 200000:
-        by_T = {}
-        rng_t = np.random.RandomState(77)
-        for T_ in (1, 2, 5, 10, 40):
-            feeds = [eng.make_resident(bucket_batch(fold, T_, B, K, rng_t)) for _ in range(4)]
-            eng._ensure_work(B, T_)
-            for i in range(15):
-                eng.train_step(None, bt=feeds[i % 4], **defer)
-            eng.flush()
-            torch.cuda.synchronize()
-            w0 = time.perf_counter()
-            for i in range(60):
-                eng.train_step(None, bt=feeds[i % 4], **defer)
-            eng.flush()
-            torch.cuda.synchronize()
-            by_T[str(T_)] = round((time.perf_counter() - w0) / 60 * 1e3, 4)
-            del feeds
-        eng.check_forks()
     if hasattr(eng, "exchange_info"):
         exchange = eng.exchange_info()        # after the timed steps: carries the bytes each collective moved per step
         if dist is not None:
@@ -483,6 +460,7 @@ def main():
            "score_dx": "dX = dlogits E (gradient of :138 w.r.t. attout)",
            "score_dE": "dE = dlogits^T attout (gradient of :138 w.r.t. the item table and candidate time vectors)"}
     roof, kernels = None, {}
+    by_T = None
     if not args.no_kernel_timing and hasattr(eng, "native_timing_ms"):
         import ctypes as C
         g = eng.geo
@@ -601,6 +579,33 @@ def main():
         eng._tm = None
         eng._ctx_key = None
 
+    # ---- step time per length bucket (VERDICT r04 item 6): the sampler buckets by EXACT input length (sampler.py:40-49), the headline is
+    # quoted at the fold's mean length while the session-side head and tail of the step scale with B * T.  Same engine, same loop body
+    # (deferred update, resident feeds of ONE length each, items drawn from the fold's popularity law), 40 timed steps after 15, best of two.
+    # (Runs AFTER the roofline pass has been read out: its steps would otherwise overwrite that pass's event slots.)
+    if world == 1 and not os.environ.get("TCAR_FORCE_DP") and not args.no_by_T and not (args.no_cpu_baseline and args.no_e2e) \
+            and N <= 200000:
+        by_T = {}
+        rng_t = np.random.RandomState(77)
+        for T_ in (1, 2, 5, 10, 40):
+            feeds = [eng.make_resident(bucket_batch(fold, T_, B, K, rng_t)) for _ in range(4)]
+            eng._ensure_work(B, T_)
+            for i in range(15):
+                eng.train_step(None, bt=feeds[i % 4], **defer)
+            eng.flush()
+            best = None
+            for rep in range(2):                     # (best of two: a run of 40 steps is short enough for one host hiccup to show)
+                torch.cuda.synchronize()
+                w0 = time.perf_counter()
+                for i in range(40):
+                    eng.train_step(None, bt=feeds[i % 4], **defer)
+                eng.flush()
+                torch.cuda.synchronize()
+                t_ = (time.perf_counter() - w0) / 40 * 1e3
+                best = t_ if best is None else min(best, t_)
+            by_T[str(T_)] = round(best, 4)
+            del feeds
+        eng.check_forks()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and N <= 200000:
         from oracle.tcar_oracle import TcarOracle

@@ -1,0 +1,302 @@
+// Erratum repro (observation 1): a loop of ds_read_b128 + counted s_waitcnt lgkmcnt(N) + v_pk_fma_f32 ... op_sel:[0,1,0]
+// — what hipcc's SLP vectorizer makes of   acc = fma4(tl[r][4 cg ..], dpl[rp][r], acc)   with a runtime trip count — drops the
+// LOW-half product of the op_sel:[0,1,0] instruction (the r = 1 mod 4 term of the float4's x component) in lanes 48-63, now and then,
+// when other kernels run beside it.  The victim is the expansion phase of round 4's first reduce_dact_onehot_kernel (git f933989),
+// verbatim; its result is compared with the same fmaf chain over global-memory reads (no LDS, scalar FMAs in the reference's loop are
+// irrelevant: the products and their order are the same, fma rounding is the same).
+//   hipcc --offload-arch=gfx950 -O3 -o pkfma_lds_slp pkfma_lds.hip ; hipcc ... -fno-slp-vectorize -o pkfma_lds_noslp pkfma_lds.hip
+//   ./pkfma_lds_slp [seconds per experiment]
+// Aggressors on a second stream: none | dma (LDS-DMA fills + transposing reads, the dE GEMM's staging) | regstage (the same bytes
+// through VGPRs + ds_write) | ldsrw (LDS traffic only, no global memory) | hbm (a streaming copy, no LDS).
+// VARIANTS of the victim: 0 = as compiled from the C++ loop; 1 = scalar FMAs behind s_waitcnt lgkmcnt(0); 2 = the failing loop's exact
+// instructions (inline assembly); 3 = the same, every LDS read landed first; 4 = the same without op_sel:[0,1,0].
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef __attribute__((address_space(1))) const void* glb_vp;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+struct Report { unsigned mism; unsigned iters; unsigned first[8]; unsigned by_lane16[4]; unsigned by_comp[4]; unsigned by_r4[4]; };
+
+__device__ __forceinline__ float4 fma4(float4 a, float s, float4 c) {
+  return make_float4(fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z), fmaf(a.w, s, c.w));
+}
+// ------------------------------------------------------------------------------------------------ victim
+template <int VAR>
+__global__ __launch_bounds__(256) void victim_kernel(int iters, int M, int nk_arg, const float* __restrict__ tclip, const float* __restrict__ coef,
+                                                     float* __restrict__ out, Report* rep) {
+  __shared__ __attribute__((aligned(16))) float lds_all[61 * 64 + 16 * 64];
+  float* tl = lds_all;                                     // (tl at LDS offset 0, dpl at 0x3d00: the layout of the step's kernel)
+  float* dpl = lds_all + 61 * 64;
+  const int tid = threadIdx.x, cg = tid & 15, rp = tid >> 4;
+  const int nk = nk_arg;                                   // RUNTIME trip count, as in the kernel of the step
+  for (int it = 0; it < iters; ++it) {
+    const int r0 = ((blockIdx.x + it * 37) % (M / 16)) * 16, row = r0 + rp;
+    for (int i = tid; i < nk * 16; i += 256) *reinterpret_cast<float4*>(tl + i * 4) = *reinterpret_cast<const float4*>(tclip + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = cg + 16 * j;
+      float v = 0.f;
+      if (c < nk) v = coef[(long)row * 64 + c];
+      dpl[rp * 64 + c] = v;
+    }
+    __syncthreads();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (VAR >= 2) {
+    } else if (VAR == 0) {
+      for (int r = 0; r < nk; ++r) acc = fma4(*reinterpret_cast<const float4*>(tl + r * 64 + cg * 4), dpl[rp * 64 + r], acc);
+    } else {
+      int r = 0;
+      for (; r + 4 <= nk; r += 4) {
+        float4 t0 = *reinterpret_cast<const float4*>(tl + (r + 0) * 64 + cg * 4), t1 = *reinterpret_cast<const float4*>(tl + (r + 1) * 64 + cg * 4);
+        float4 t2 = *reinterpret_cast<const float4*>(tl + (r + 2) * 64 + cg * 4), t3 = *reinterpret_cast<const float4*>(tl + (r + 3) * 64 + cg * 4);
+        float4 s = *reinterpret_cast<const float4*>(dpl + rp * 64 + r);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t0.x), "+v"(t1.x), "+v"(t2.x), "+v"(t3.x), "+v"(s.x), "+v"(s.y), "+v"(s.z), "+v"(s.w) :: "memory");
+        acc = fma4(t0, s.x, acc); acc = fma4(t1, s.y, acc); acc = fma4(t2, s.z, acc); acc = fma4(t3, s.w, acc);
+      }
+      for (; r < nk; ++r) acc = fma4(*reinterpret_cast<const float4*>(tl + r * 64 + cg * 4), dpl[rp * 64 + r], acc);
+    }
+    if (VAR >= 2) {
+      // VAR 2: the EXACT instruction sequence of the failing loop (score.hip -DTCAR_OBS1_DIAG, hipcc 7.2 -O3), eight rows per trip, hard
+      // registers as compiled: x | y in v[2:3], z in v11, w in v5.  VAR 3: the same with every LDS read landed before the first FMA
+      // (s_waitcnt lgkmcnt(0) up front).  VAR 4: the two op_sel:[0,1,0] instructions replaced by the v_mov + op_sel_hi:[1,0,1] form the
+      // compiler uses for the r = 3 mod 4 rows.  (nk must be a multiple of 8 here.)
+      typedef __attribute__((address_space(3))) float* lp;
+      unsigned pt = (unsigned)(size_t)(lp)(tl + cg * 4), pd = (unsigned)(size_t)(lp)(dpl + rp * 64);
+      float x = 0.f, y = 0.f, z = 0.f, w = 0.f;
+      for (int r = 0; r < nk; r += 8) {
+#define RD "ds_read_b128 v[12:15], %5\n ds_read_b128 v[16:19], %5 offset:16\n ds_read_b128 v[24:27], %4\n ds_read_b128 v[28:31], %4 offset:256\n" \
+           "ds_read_b128 v[32:35], %4 offset:512\n ds_read_b128 v[36:39], %4 offset:768\n ds_read_b128 v[40:43], %4 offset:1024\n" \
+           "ds_read_b128 v[44:47], %4 offset:1280\n ds_read_b128 v[48:51], %4 offset:1536\n ds_read_b128 v[52:55], %4 offset:1792\n"
+#define PRE "v_mov_b32 v2, %0\n v_mov_b32 v3, %1\n v_mov_b32 v11, %2\n v_mov_b32 v5, %3\n"
+#define POST "v_mov_b32 %0, v2\n v_mov_b32 %1, v3\n v_mov_b32 %2, v11\n v_mov_b32 %3, v5\n"
+#define R0(W) W "v_pk_fma_f32 v[2:3], v[24:25], v[12:13], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v26, v12\n v_fmac_f32_e32 v5, v27, v12\n"
+#define R1(W) W "v_pk_fma_f32 v[2:3], v[28:29], v[12:13], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v30, v13\n v_fmac_f32_e32 v5, v31, v13\n v_mov_b32_e32 v10, v15\n"
+#define R1B(W) W "v_mov_b32_e32 v22, v13\n s_nop 0\n v_pk_fma_f32 v[2:3], v[28:29], v[22:23], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v30, v13\n v_fmac_f32_e32 v5, v31, v13\n v_mov_b32_e32 v10, v15\n"
+#define R2(W) W "v_pk_fma_f32 v[2:3], v[32:33], v[14:15], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v34, v14\n v_fmac_f32_e32 v5, v35, v14\n"
+#define R3(W) W "v_pk_fma_f32 v[2:3], v[36:37], v[10:11], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v38, v15\n v_fmac_f32_e32 v5, v39, v15\n"
+#define R4(W) W "v_pk_fma_f32 v[2:3], v[40:41], v[16:17], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v42, v16\n v_fmac_f32_e32 v5, v43, v16\n"
+#define R5(W) W "v_pk_fma_f32 v[2:3], v[44:45], v[16:17], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v46, v17\n v_fmac_f32_e32 v5, v47, v17\n v_mov_b32_e32 v20, v19\n"
+#define R5B(W) W "v_mov_b32_e32 v22, v17\n s_nop 0\n v_pk_fma_f32 v[2:3], v[44:45], v[22:23], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v46, v17\n v_fmac_f32_e32 v5, v47, v17\n v_mov_b32_e32 v20, v19\n"
+#define R6(W) W "v_pk_fma_f32 v[2:3], v[48:49], v[18:19], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v50, v18\n v_fmac_f32_e32 v5, v51, v18\n"
+#define R7(W) W "v_pk_fma_f32 v[2:3], v[52:53], v[20:21], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v54, v19\n v_fmac_f32_e32 v5, v55, v19\n"
+#define CLOB "v2", "v3", "v5", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+             "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
+             "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "memory"
+        if (VAR == 2)
+          asm volatile(PRE RD R0("s_waitcnt lgkmcnt(7)\n") R1("s_waitcnt lgkmcnt(6)\n") R2("s_waitcnt lgkmcnt(5)\n") R3("s_waitcnt lgkmcnt(4)\n")
+                       R4("s_waitcnt lgkmcnt(3)\n") R5("s_waitcnt lgkmcnt(2)\n") R6("s_waitcnt lgkmcnt(1)\n") R7("s_waitcnt lgkmcnt(0)\n") POST
+                       : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+        else if (VAR == 3)
+          asm volatile(PRE RD "s_waitcnt lgkmcnt(0)\n" R0("") R1("") R2("") R3("") R4("") R5("") R6("") R7("") POST
+                       : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+        else
+          asm volatile(PRE RD R0("s_waitcnt lgkmcnt(7)\n") R1B("s_waitcnt lgkmcnt(6)\n") R2("s_waitcnt lgkmcnt(5)\n") R3("s_waitcnt lgkmcnt(4)\n")
+                       R4("s_waitcnt lgkmcnt(3)\n") R5B("s_waitcnt lgkmcnt(2)\n") R6("s_waitcnt lgkmcnt(1)\n") R7("s_waitcnt lgkmcnt(0)\n") POST
+                       : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+        pt += 0x800; pd += 32;
+      }
+      acc = make_float4(x, y, z, w);
+    }
+    // reference: the same chain from global memory
+    float rx = 0.f, ry = 0.f, rz = 0.f, rw = 0.f;
+    for (int r = 0; r < nk; ++r) {
+      const float* t = tclip + r * 64 + cg * 4;
+      const float s = coef[(long)row * 64 + r];
+      asm volatile("" : "+v"(rx), "+v"(ry), "+v"(rz), "+v"(rw));            // keep the reference scalar (no SLP packing of these)
+      rx = fmaf(t[0], s, rx); ry = fmaf(t[1], s, ry); rz = fmaf(t[2], s, rz); rw = fmaf(t[3], s, rw);
+    }
+    const float g[4] = {acc.x, acc.y, acc.z, acc.w}, w[4] = {rx, ry, rz, rw};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (__float_as_uint(g[j]) != __float_as_uint(w[j])) {
+        // which single term explains the difference?
+        int best = -1; float bd = 3.4e38f;
+        for (int r = 0; r < nk; ++r) {
+          const float term = tclip[r * 64 + cg * 4 + j] * coef[(long)row * 64 + r];
+          const float d = fabsf((w[j] - g[j]) - term);
+          if (d < bd) { bd = d; best = r; }
+        }
+        if (atomicAdd(&rep->mism, 1u) == 0u) {
+          rep->first[0] = blockIdx.x; rep->first[1] = it; rep->first[2] = j; rep->first[3] = __float_as_uint(g[j]);
+          rep->first[4] = __float_as_uint(w[j]); rep->first[5] = tid; rep->first[6] = best;
+        }
+        atomicAdd(&rep->by_lane16[(tid & 63) >> 4], 1u); atomicAdd(&rep->by_comp[j], 1u); atomicAdd(&rep->by_r4[best & 3], 1u);
+      }
+    if (it == 0 && blockIdx.x == 0) { out[tid * 4] = acc.x; }
+    __syncthreads();
+  }
+  if (tid == 0) atomicAdd(&rep->iters, (unsigned)iters);
+}
+
+// ------------------------------------------------------------------------------------------------ aggressors
+template <int NW, int STAGE_COPIES>
+__global__ __launch_bounds__(64 * NW) void dma_kernel(const char* __restrict__ src, long src_kb, int iters, unsigned* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = STAGE_COPIES * 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int CPW = (STAGE_COPIES + NW - 1) / NW;
+  long kb = ((long)blockIdx.x * 7919) % src_kb;
+  auto issue = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = wave + NW * i;
+      if (c < STAGE_COPIES) {
+        const long k = (kb + c) % src_kb;
+        __builtin_amdgcn_global_load_lds((glb_vp)(src + k * 1024 + lane * 16), (lds_vp)(smem + st * STAGE + c * 1024), 16, 0, 0);
+      }
+    }
+    kb = (kb + STAGE_COPIES) % src_kb;
+  };
+  unsigned acc = 0;
+  issue(0);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    if (it + 1 < iters) issue((it + 1) & 1);
+    const char* St = smem + (it & 1) * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      typedef __attribute__((address_space(3))) bf16x4* lds_p;
+      const int off = ((wave * 4 + j) * 2048 + (lane & 15) * 64 + (lane >> 4) * 8) % (STAGE - 512);
+      const bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(St + (off & ~7)));
+      acc += (unsigned)__builtin_bit_cast(unsigned short, v[0]) + (unsigned)__builtin_bit_cast(unsigned short, v[3]);
+    }
+    __syncthreads();
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+template <int NW, int STAGE_COPIES>
+__global__ __launch_bounds__(64 * NW) void regstage_kernel(const char* __restrict__ src, long src_kb, int iters, unsigned* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = STAGE_COPIES * 1024;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int CPW = (STAGE_COPIES + NW - 1) / NW;
+  long kb = ((long)blockIdx.x * 7919) % src_kb;
+  unsigned acc = 0;
+  for (int it = 0; it < iters; ++it) {
+    const int st = it & 1;
+    for (int i = 0; i < CPW; ++i) {
+      const int c = wave + NW * i;
+      if (c < STAGE_COPIES) {
+        const long k = (kb + c) % src_kb;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + k * 1024 + lane * 16);
+        *reinterpret_cast<uint4*>(smem + st * STAGE + c * 1024 + lane * 16) = v;
+      }
+    }
+    kb = (kb + STAGE_COPIES) % src_kb;
+    __syncthreads();
+    acc += *reinterpret_cast<const unsigned*>(smem + st * STAGE + ((tid * 52) % STAGE & ~3));
+    __syncthreads();
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+__global__ __launch_bounds__(512) void ldsrw_kernel(int iters, unsigned* __restrict__ sink) {
+  __shared__ __attribute__((aligned(16))) unsigned buf[12288];          // 48 KB
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 12288; i += 512) buf[i] = i * 2654435761u;
+  __syncthreads();
+  uint4 a = make_uint4(0, 0, 0, 0);
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll 8
+    for (int j = 0; j < 24; ++j) {
+      const uint4 v = *reinterpret_cast<const uint4*>(buf + ((tid * 4 + j * 2048 + it * 64) % 12288 & ~3));
+      a.x += v.x; a.y ^= v.y; a.z += v.z; a.w ^= v.w;
+    }
+    *reinterpret_cast<uint4*>(buf + ((tid * 4 + it * 52) % 12288 & ~3)) = a;
+    __syncthreads();
+  }
+  if (a.x == 0x12345678u) sink[0] = a.x;
+}
+__global__ __launch_bounds__(256) void hbm_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
+int main(int argc, char** argv) {
+  const double seconds = argc > 1 ? atof(argv[1]) : 0.5;
+  hipStream_t s1, s2;
+  CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  const long src_kb = 256 * 1024;
+  char *src, *dst; CK(hipMalloc(&src, src_kb * 1024)); CK(hipMalloc(&dst, src_kb * 1024));
+  CK(hipMemset(src, 0x5a, src_kb * 1024));
+  unsigned* sink; CK(hipMalloc(&sink, 64)); CK(hipMemset(sink, 0, 64));
+  Report* rep; CK(hipMalloc(&rep, sizeof(Report)));
+  const int M = 512;
+  float *tclip, *coef, *out;
+  CK(hipMalloc(&tclip, 61 * 64 * 4)); CK(hipMalloc(&coef, (size_t)M * 64 * 4)); CK(hipMalloc(&out, 4096 * 4));
+  {
+    std::vector<float> a(61 * 64), b((size_t)M * 64);
+    unsigned x = 12345;
+    auto rnd = [&]() { x = x * 1664525u + 1013904223u; return ((x >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+    for (auto& v : a) v = rnd();
+    for (auto& v : b) v = rnd() * 1e-3f;
+    CK(hipMemcpy(tclip, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(coef, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+  }
+  CK(hipFuncSetAttribute((const void*)dma_kernel<9, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  CK(hipFuncSetAttribute((const void*)regstage_kernel<9, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  const char* aggr[] = {"none", "dma", "regstage", "ldsrw", "hbm"};
+  const int nks[] = {61, 32, 13};
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int var = 0; var < 5; ++var)
+    for (int a = 0; a < 5; ++a)
+      for (int ki = 0; ki < 3; ++ki) {
+        if (var == 1 && ki != 0) continue;
+        if (var >= 2 && ki != 1) continue;                 // the asm forms take eight rows per trip: nk = 32
+        const int nk = nks[ki];
+        CK(hipMemset(rep, 0, sizeof(Report)));
+        CK(hipDeviceSynchronize());
+        int launches = 0, alaunches = 0;
+        CK(hipEventRecord(e0, s2));
+        const int chunk = 100;
+        double elapsed = 0;
+        hipEvent_t ea, ev; CK(hipEventCreate(&ea)); CK(hipEventCreate(&ev));
+        bool a_pending = false;
+        auto launch_aggr = [&]() {
+          for (int i = 0; i < chunk; ++i) {
+            if (a == 1) hipLaunchKernelGGL((dma_kernel<9, 24>), dim3(720), dim3(576), 2 * 24 * 1024, s1, src, src_kb, 16, sink);
+            if (a == 2) hipLaunchKernelGGL((regstage_kernel<9, 24>), dim3(720), dim3(576), 2 * 24 * 1024, s1, src, src_kb, 16, sink);
+            if (a == 3) hipLaunchKernelGGL(ldsrw_kernel, dim3(512), dim3(512), 0, s1, 40, sink);
+            if (a == 4) hipLaunchKernelGGL(hbm_kernel, dim3(2048), dim3(256), 0, s1, (const uint4*)src, (uint4*)dst, (long)(64L << 20) / 16);
+          }
+          alaunches += chunk;
+          CK(hipEventRecord(ea, s1));
+          a_pending = true;
+        };
+        while (elapsed < seconds * 1e3) {
+          if (a != 0) launch_aggr();
+          for (int i = 0; i < chunk; ++i) {
+            if (var == 0) hipLaunchKernelGGL((victim_kernel<0>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 1) hipLaunchKernelGGL((victim_kernel<1>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 2) hipLaunchKernelGGL((victim_kernel<2>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 3) hipLaunchKernelGGL((victim_kernel<3>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else hipLaunchKernelGGL((victim_kernel<4>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+          }
+          launches += chunk;
+          CK(hipEventRecord(ev, s2));
+          while (hipEventQuery(ev) == hipErrorNotReady) {
+            if (a != 0 && a_pending && hipEventQuery(ea) == hipSuccess) launch_aggr();
+          }
+          CK(hipEventRecord(e1, s2));
+          CK(hipStreamSynchronize(s2));
+          float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+          elapsed = ms;
+        }
+        CK(hipStreamSynchronize(s1));
+        CK(hipEventDestroy(ea)); CK(hipEventDestroy(ev));
+        CK(hipGetLastError());
+        Report h; CK(hipMemcpy(&h, rep, sizeof(h), hipMemcpyDeviceToHost));
+        printf("victim form %d nk %2d | aggressor %-8s | launches %5d (aggressor %5d) wg-iterations %8u | mismatches %u", var, nk, aggr[a], launches,
+               alaunches, h.iters, h.mism);
+        if (h.mism)
+          printf("  by 16-lane group %u/%u/%u/%u  by component %u/%u/%u/%u  by (missing term r)%%4 %u/%u/%u/%u  first: wg %u it %u comp %u tid %u r %u",
+                 h.by_lane16[0], h.by_lane16[1], h.by_lane16[2], h.by_lane16[3], h.by_comp[0], h.by_comp[1], h.by_comp[2], h.by_comp[3],
+                 h.by_r4[0], h.by_r4[1], h.by_r4[2], h.by_r4[3], h.first[0], h.first[1], h.first[2], h.first[5], h.first[6]);
+        printf("\n");
+        fflush(stdout);
+      }
+  return 0;
+}
