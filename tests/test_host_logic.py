@@ -276,3 +276,43 @@ def test_build_neighbor_equals_the_reference_get_neighbor():
     nb = fold.neighbor_dict()
     ref = build_neighbor(fold.publish_ts)
     assert all((nb[k] == ref[k]).all() for k in ref) and all(int(k) in set(int(x) for x in v) for k, v in nb.items())
+
+
+def test_built_library_has_no_packed_f32_op_with_a_low_from_high_operand_select(tmp_path):
+    """DESIGN.md §7, observation 1 (root-caused in round 5): on gfx950 `v_pk_fma_f32 ... op_sel:[0,1,0]` — hipcc's SLP vectorizer
+    emits it for `acc = fma(row, s[r], acc)` — loses its low-half product in lanes 48-63 while another wave of the SIMD issues
+    MFMAs (tools/micro/pkfma_lds.hip, tools/obs1_probe.py).  The library is therefore built with -fno-slp-vectorize (_lib.SAFE_FLAGS);
+    this test disassembles EVERY gfx950 code object of the built binary and refuses any packed-f32 instruction that carries an
+    `op_sel:[...]` modifier (a low result fed from a high dword); plain packed ops and op_sel_hi forms, which the same loops ran
+    billions of times without a fault, are allowed."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not all(os.path.exists(t) for t in tools):
+        pytest.skip("ROCm LLVM binutils not found")
+    assert "-fno-slp-vectorize" in _lib.SAFE_FLAGS
+    lib = _lib.build()
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([tools[0], "--dump-section", ".hip_fatbin=" + fat, lib], check=True)
+    data = open(fat, "rb").read()
+    starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+    assert len(_lib.SOURCES) - 1 <= len(starts) <= len(_lib.SOURCES)        # one bundle per translation unit with device code (buildid.hip has none)
+    n_pk, bad = 0, []
+    for i, st in enumerate(starts):
+        part = str(tmp_path / ("b%d.bin" % i))
+        with open(part, "wb") as fh:
+            fh.write(data[st:starts[i + 1] if i + 1 < len(starts) else len(data)])
+        co = str(tmp_path / ("b%d.co" % i))
+        subprocess.run([tools[1], "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + part,
+                        "--output=" + co], check=True)
+        if not os.path.exists(co) or os.path.getsize(co) == 0:
+            continue                                                       # a translation unit without device code
+        dis = subprocess.run([tools[2], "-d", co], check=True, stdout=subprocess.PIPE).stdout.decode(errors="replace")
+        for line in dis.splitlines():
+            if re.search(r"\bv_pk_(fma|mul|add)_f32\b", line):
+                n_pk += 1
+                if "op_sel:[" in line:
+                    bad.append(line.strip())
+    assert not bad, bad[:5]
+    assert n_pk < 400        # (what is left comes from explicit float2 arithmetic: ~120 plain v_pk_add / v_pk_mul in segsum.hip and mha.hip)

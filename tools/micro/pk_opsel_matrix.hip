@@ -1,0 +1,152 @@
+// Which packed-f32 operand selects are affected?  (observation 1: v_pk_fma_f32 ... op_sel:[0,1,0] loses its LOW-half
+// product in lanes 48-63 while another wave of the SIMD issues MFMAs.)  Every op_sel pattern of v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 (op_sel bit i = the LOW result takes the HIGH dword of source i; op_sel_hi left at its default, all ones, and for
+// FMA also the [1,0,1] form hipcc emits for a broadcast multiplier), checked bit for bit against scalar fmaf / mul / add, alone and
+// beside a dense v_mfma_f32_32x32x16_bf16 loop on a second stream.
+//   hipcc --offload-arch=gfx950 -O3 -o pk_opsel_matrix pk_opsel_matrix.hip ; ./pk_opsel_matrix [seconds per cell]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+typedef __attribute__((ext_vector_type(2))) float f2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+struct Report { unsigned mism, iters, lo_bad, hi_bad, by_lane16[4]; };
+
+__device__ __forceinline__ float rnd(unsigned& x) { x = x * 1664525u + 1013904223u; return ((x >> 9) & 0x7FFF) / 32768.0f + 0.25f; }
+
+// OP: 0 fma, 1 mul, 2 add.  SEL: op_sel bits (bit i = source i).  HI101: op_sel_hi:[1,0,1] instead of the default.
+template <int OP, int SEL, int HI101, int CHAIN>
+__global__ __launch_bounds__(256) void victim(int iters, Report* rep) {
+  unsigned seed = threadIdx.x * 977u + blockIdx.x * 131071u + 12345u;
+  unsigned bad = 0;
+  f2 prev = {0.5f, 0.75f};
+  for (int it = 0; it < iters; ++it) {
+    // CHAIN: the addend (FMA) / first source (mul, add) is the previous iteration's result, as in an accumulation loop
+    f2 a = {rnd(seed), rnd(seed)}, b = {rnd(seed), rnd(seed)}, c = {rnd(seed), rnd(seed)}, d;
+    if (CHAIN) { if (OP == 0) c = prev; else a = prev; }
+    constexpr int s0 = SEL & 1, s1 = (SEL >> 1) & 1, s2 = (SEL >> 2) & 1;
+    if (OP == 0) {
+      if (HI101) {
+        if (SEL == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        if (SEL == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+      } else {
+        if (SEL == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        if (SEL == 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        if (SEL == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        if (SEL == 3) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        if (SEL == 4) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        if (SEL == 5) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        if (SEL == 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+        if (SEL == 7) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+      }
+    } else if (OP == 1) {
+      if (SEL == 0) asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+      if (SEL == 1) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+      if (SEL == 2) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+      if (SEL == 3) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    } else {
+      if (SEL == 0) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+      if (SEL == 1) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+      if (SEL == 2) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+      if (SEL == 3) asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    }
+    const float a_lo = s0 ? a.y : a.x, b_lo = s1 ? b.y : b.x, c_lo = s2 ? c.y : c.x;
+    const float b_hi = HI101 ? b.x : b.y;
+    float want_lo, want_hi;
+    if (OP == 0) { want_lo = fmaf(a_lo, b_lo, c_lo); want_hi = fmaf(a.y, b_hi, c.y); }
+    else if (OP == 1) { want_lo = a_lo * b_lo; want_hi = a.y * b.y; }
+    else { want_lo = a_lo + b_lo; want_hi = a.y + b.y; }
+    const bool bl = __float_as_uint(d.x) != __float_as_uint(want_lo), bh = __float_as_uint(d.y) != __float_as_uint(want_hi);
+    prev = d;
+    if (CHAIN && OP != 0) { prev.x = prev.x * 0.5f + 0.3f; prev.y = prev.y * 0.5f + 0.3f; }
+    if (CHAIN && OP == 0) { prev.x *= 0.5f; prev.y *= 0.5f; }
+    if (bl || bh) {
+      atomicAdd(&rep->mism, 1u);
+      if (bl) atomicAdd(&rep->lo_bad, 1u);
+      if (bh) atomicAdd(&rep->hi_bad, 1u);
+      atomicAdd(&rep->by_lane16[(threadIdx.x & 63) >> 4], 1u);
+      ++bad;
+    }
+  }
+  if (threadIdx.x == 0) atomicAdd(&rep->iters, (unsigned)iters);
+  if (bad == 0xFFFFFFFFu) rep->mism = bad;
+}
+
+__global__ __launch_bounds__(512) void mfma_kernel(int iters, unsigned* __restrict__ sink) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x ^ j)); }
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
+  }
+  if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.678f) sink[0] = 1;
+}
+
+template <int OP, int SEL, int HI101, int CHAIN = 0>
+void cell(const char* name, double seconds, hipStream_t s1, hipStream_t s2, Report* rep, unsigned* sink) {
+  for (int aggr = 0; aggr < 2; ++aggr) {
+    CK(hipMemset(rep, 0, sizeof(Report)));
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1, ea, ev;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&ea)); CK(hipEventCreate(&ev));
+    CK(hipEventRecord(e0, s2));
+    double elapsed = 0;
+    bool pending = false;
+    auto la = [&]() { for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(mfma_kernel, dim3(512), dim3(512), 0, s1, 400, sink);
+                      CK(hipEventRecord(ea, s1)); pending = true; };
+    while (elapsed < seconds * 1e3) {
+      if (aggr) la();
+      for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((victim<OP, SEL, HI101, CHAIN>), dim3(1024), dim3(256), 0, s2, 2000, rep);
+      CK(hipEventRecord(ev, s2));
+      while (hipEventQuery(ev) == hipErrorNotReady) if (aggr && pending && hipEventQuery(ea) == hipSuccess) la();
+      CK(hipEventRecord(e1, s2));
+      CK(hipStreamSynchronize(s2));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); elapsed = ms;
+    }
+    CK(hipStreamSynchronize(s1));
+    Report h; CK(hipMemcpy(&h, rep, sizeof(h), hipMemcpyDeviceToHost));
+    printf("%-52s | %-10s | %5.2f G ops | wrong %8u (low half %u, high half %u; lanes 0-15 / 16-31 / 32-47 / 48-63: %u / %u / %u / %u)\n", name,
+           aggr ? "beside MFMA" : "alone", (double)h.iters * 256 / 1e9, h.mism, h.lo_bad, h.hi_bad, h.by_lane16[0], h.by_lane16[1],
+           h.by_lane16[2], h.by_lane16[3]);
+    fflush(stdout);
+    CK(hipEventDestroy(e0)); CK(hipEventDestroy(e1)); CK(hipEventDestroy(ea)); CK(hipEventDestroy(ev));
+  }
+}
+
+int main(int argc, char** argv) {
+  const double sec = argc > 1 ? atof(argv[1]) : 0.3;
+  hipStream_t s1, s2;
+  CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+  CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+  Report* rep; CK(hipMalloc(&rep, sizeof(Report)));
+  unsigned* sink; CK(hipMalloc(&sink, 64));
+  cell<0, 0, 0>("v_pk_fma_f32 (no op_sel)", sec, s1, s2, rep, sink);
+  cell<0, 1, 0>("v_pk_fma_f32 op_sel:[1,0,0]", sec, s1, s2, rep, sink);
+  cell<0, 2, 0>("v_pk_fma_f32 op_sel:[0,1,0]   (the failing form)", sec, s1, s2, rep, sink);
+  cell<0, 3, 0>("v_pk_fma_f32 op_sel:[1,1,0]", sec, s1, s2, rep, sink);
+  cell<0, 4, 0>("v_pk_fma_f32 op_sel:[0,0,1]", sec, s1, s2, rep, sink);
+  cell<0, 5, 0>("v_pk_fma_f32 op_sel:[1,0,1]", sec, s1, s2, rep, sink);
+  cell<0, 6, 0>("v_pk_fma_f32 op_sel:[0,1,1]", sec, s1, s2, rep, sink);
+  cell<0, 7, 0>("v_pk_fma_f32 op_sel:[1,1,1]", sec, s1, s2, rep, sink);
+  cell<0, 0, 1>("v_pk_fma_f32 op_sel_hi:[1,0,1]", sec, s1, s2, rep, sink);
+  cell<0, 2, 1>("v_pk_fma_f32 op_sel:[0,1,0] op_sel_hi:[1,0,1]", sec, s1, s2, rep, sink);
+  cell<0, 0, 0, 1>("chained: v_pk_fma_f32 (no op_sel)", sec, s1, s2, rep, sink);
+  cell<0, 2, 0, 1>("chained: v_pk_fma_f32 op_sel:[0,1,0]", sec, s1, s2, rep, sink);
+  cell<0, 1, 0, 1>("chained: v_pk_fma_f32 op_sel:[1,0,0]", sec, s1, s2, rep, sink);
+  cell<0, 4, 0, 1>("chained: v_pk_fma_f32 op_sel:[0,0,1]", sec, s1, s2, rep, sink);
+  cell<0, 0, 1, 1>("chained: v_pk_fma_f32 op_sel_hi:[1,0,1]", sec, s1, s2, rep, sink);
+  cell<1, 0, 0>("v_pk_mul_f32 (no op_sel)", sec, s1, s2, rep, sink);
+  cell<1, 1, 0>("v_pk_mul_f32 op_sel:[1,0]", sec, s1, s2, rep, sink);
+  cell<1, 2, 0>("v_pk_mul_f32 op_sel:[0,1]", sec, s1, s2, rep, sink);
+  cell<1, 3, 0>("v_pk_mul_f32 op_sel:[1,1]", sec, s1, s2, rep, sink);
+  cell<2, 0, 0>("v_pk_add_f32 (no op_sel)", sec, s1, s2, rep, sink);
+  cell<2, 1, 0>("v_pk_add_f32 op_sel:[1,0]", sec, s1, s2, rep, sink);
+  cell<2, 2, 0>("v_pk_add_f32 op_sel:[0,1]", sec, s1, s2, rep, sink);
+  cell<2, 3, 0>("v_pk_add_f32 op_sel:[1,1]", sec, s1, s2, rep, sink);
+  return 0;
+}

@@ -7,7 +7,8 @@
 //   hipcc --offload-arch=gfx950 -O3 -o pkfma_lds_slp pkfma_lds.hip ; hipcc ... -fno-slp-vectorize -o pkfma_lds_noslp pkfma_lds.hip
 //   ./pkfma_lds_slp [seconds per experiment]
 // Aggressors on a second stream: none | dma (LDS-DMA fills + transposing reads, the dE GEMM's staging) | regstage (the same bytes
-// through VGPRs + ds_write) | ldsrw (LDS traffic only, no global memory) | hbm (a streaming copy, no LDS).
+// through VGPRs + ds_write) | ldsrw (LDS traffic only, no global memory) | hbm (a streaming copy, no LDS) | mfma (the matrix pipe only)
+// | dma+mfma (fills + transposing reads + MFMAs: the dE GEMM's mix).   argv[2]: first aggressor to run (skip the earlier ones).
 // VARIANTS of the victim: 0 = as compiled from the C++ loop; 1 = scalar FMAs behind s_waitcnt lgkmcnt(0); 2 = the failing loop's exact
 // instructions (inline assembly); 3 = the same, every LDS read landed first; 4 = the same without op_sel:[0,1,0].
 #include <hip/hip_runtime.h>
@@ -210,6 +211,69 @@ __global__ __launch_bounds__(512) void ldsrw_kernel(int iters, unsigned* __restr
   }
   if (a.x == 0x12345678u) sink[0] = a.x;
 }
+// MFMA only: no memory traffic at all, the matrix pipe of every SIMD busy (8 waves per workgroup, 2 per SIMD)
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+__global__ __launch_bounds__(512) void mfma_kernel(int iters, unsigned* __restrict__ sink) {
+  bf16x8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x + j)); b[j] = (__bf16)(0.002f * (threadIdx.x ^ j)); }
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  for (int it = 0; it < iters; ++it) {
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, a, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, b, c3, 0, 0, 0);
+  }
+  if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.678f) sink[0] = 1;
+}
+// the dE GEMM's mix: LDS-DMA fills + transposing LDS reads + MFMAs on what was read (9 waves, 48 KB, two workgroups per CU)
+template <int NW, int STAGE_COPIES>
+__global__ __launch_bounds__(64 * NW) void dma_mfma_kernel(const char* __restrict__ src, long src_kb, int iters, unsigned* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGE = STAGE_COPIES * 1024;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int CPW = (STAGE_COPIES + NW - 1) / NW;
+  long kb = ((long)blockIdx.x * 7919) % src_kb;
+  auto issue = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int c = wave + NW * i;
+      if (c < STAGE_COPIES) {
+        const long k = (kb + c) % src_kb;
+        __builtin_amdgcn_global_load_lds((glb_vp)(src + k * 1024 + lane * 16), (lds_vp)(smem + st * STAGE + c * 1024), 16, 0, 0);
+      }
+    }
+    kb = (kb + STAGE_COPIES) % src_kb;
+  };
+  f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
+  issue(0);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    if (it + 1 < iters) issue((it + 1) & 1);
+    const char* St = smem + (it & 1) * STAGE;
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    bf16x8 f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int off = ((wave * 4 + j) * 2048 + (lane & 15) * 64 + (lane >> 4) * 8) % (STAGE - 1024);
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(St + (off & ~7)));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(St + (off & ~7) + 256));
+      f[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], f[1], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], f[2], c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], f[3], c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[3], f[0], c3, 0, 0, 0);
+    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[0], f[2], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[1], f[3], c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[2], f[0], c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[3], f[1], c3, 0, 0, 0);
+    __syncthreads();
+  }
+  if (c0[0] + c1[1] + c2[2] + c3[3] == 12345.678f) sink[0] = 1;
+}
 __global__ __launch_bounds__(256) void hbm_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
 }
@@ -238,11 +302,13 @@ int main(int argc, char** argv) {
   }
   CK(hipFuncSetAttribute((const void*)dma_kernel<9, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   CK(hipFuncSetAttribute((const void*)regstage_kernel<9, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-  const char* aggr[] = {"none", "dma", "regstage", "ldsrw", "hbm"};
+  CK(hipFuncSetAttribute((const void*)dma_mfma_kernel<9, 24>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  const char* aggr[] = {"none", "dma", "regstage", "ldsrw", "hbm", "mfma", "dma+mfma"};
+  const int first_aggr = argc > 2 ? atoi(argv[2]) : 0;
   const int nks[] = {61, 32, 13};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   for (int var = 0; var < 5; ++var)
-    for (int a = 0; a < 5; ++a)
+    for (int a = first_aggr; a < 7; ++a)
       for (int ki = 0; ki < 3; ++ki) {
         if (var == 1 && ki != 0) continue;
         if (var >= 2 && ki != 1) continue;                 // the asm forms take eight rows per trip: nk = 32
@@ -261,6 +327,8 @@ int main(int argc, char** argv) {
             if (a == 2) hipLaunchKernelGGL((regstage_kernel<9, 24>), dim3(720), dim3(576), 2 * 24 * 1024, s1, src, src_kb, 16, sink);
             if (a == 3) hipLaunchKernelGGL(ldsrw_kernel, dim3(512), dim3(512), 0, s1, 40, sink);
             if (a == 4) hipLaunchKernelGGL(hbm_kernel, dim3(2048), dim3(256), 0, s1, (const uint4*)src, (uint4*)dst, (long)(64L << 20) / 16);
+            if (a == 5) hipLaunchKernelGGL(mfma_kernel, dim3(512), dim3(512), 0, s1, 400, sink);
+            if (a == 6) hipLaunchKernelGGL((dma_mfma_kernel<9, 24>), dim3(720), dim3(576), 2 * 24 * 1024, s1, src, src_kb, 16, sink);
           }
           alaunches += chunk;
           CK(hipEventRecord(ea, s1));
