@@ -156,8 +156,8 @@ __global__ __launch_bounds__(256) void gather_clip_fwd_kernel(const EmbArgs a) {
 // (2.5 KB of L1/L2 traffic beside 2 KB of HBM reads) with a shuffle reduction each.  Here:
 //   * the <= 190 small rows (position, 5 time tables, dwell) are clipped ONCE per workgroup into LDS (78 KB for H = 250,
 //     Ht = 64): a session row then costs two HBM row reads, two wave reductions and seven LDS reads;
-//   * one 1024-thread workgroup per CU (16 waves), every wave owns R = 4 CONSECUTIVE session rows per trip: 8 KB of HBM
-//     reads in flight per wave, 128 KB per CU, and 14 KB of contiguous output per trip;
+//   * 1024-thread workgroups (16 waves), two per CU, every wave owns R = 2 CONSECUTIVE session rows per trip (round 5: 2.4 % faster
+//     than 4 rows in five interleaved rounds; 8 rows and 1 row slower): 4 KB of HBM reads in flight per wave, 128 KB per CU;
 //   * the ids of the next trip are fetched (scalar loads: the row index is wave uniform) before the current one is reduced;
 //   * outputs leave with non-temporal stores (3.5 KB written per 2 KB read: they would only evict the table rows).
 typedef float v4f_e __attribute__((ext_vector_type(4)));
@@ -168,7 +168,7 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
 
 // R: consecutive session rows per wave and trip; PLAIN: plain stores instead of non-temporal ones (tools/gather_sweep.sh measures the
 // forms; the launcher's default is the fastest)
-template <int NCH, int R = 4, bool PLAIN = false>
+template <int NCH, int R = 2, bool PLAIN = false>
 __global__ __launch_bounds__(1024) void gather_clip_fwd_big_kernel(const EmbArgs a) {
   auto st_out = [](float* p, float4 v) { if (PLAIN) st4(p, v); else st4_nt(p, v); };
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1243,20 +1243,23 @@ int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const
     // throughput form: one 16-wave workgroup per CU (the clipped small tables live in its LDS)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    // (TCAR_GATHER_WG = workgroups per CU + 16 * form; forms 1-3 exist for the sweep of tools/gather_sweep.sh: 1 plain stores,
-    //  2 eight rows per wave and trip, 3 two rows)
+    // (TCAR_GATHER_WG = workgroups per CU + 16 * form.  Form 0 = shipped: TWO consecutive rows per wave and trip, non-temporal stores —
+    //  round 5, tools/gather_sweep.sh: 0.680-0.717 ms at 655,360 rows against 0.702-0.728 for four rows, five interleaved rounds.
+    //  Forms 1-4 stay for that sweep: 1 plain stores, 2 eight rows, 3 four rows (the shipped form until round 4), 4 one row)
     const int wgpc = tn.gather_wg_per_cu & 15, form = tn.gather_wg_per_cu >> 4;
-    const int rpw = form == 2 ? 8 : form == 3 ? 2 : 4;
+    const int rpw = form == 2 ? 8 : form == 3 ? 4 : form == 4 ? 1 : form == 1 ? 4 : 2;
     long g = (rows + 16 * rpw - 1) / (16 * rpw);
     const long cap = (long)cus * (wgpc > 0 ? wgpc : 1);
     if (g > cap) g = cap;
-    if (d->ldh <= 256 && form >= 1 && form <= 3) {
+    if (d->ldh <= 256 && form >= 1 && form <= 4) {
       if (form == 1) { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 4, true>), 160 * 1024);
         TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 4, true>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
       else if (form == 2) { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 8, false>), 160 * 1024);
         TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 8, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
-      else { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 2, false>), 160 * 1024);
-        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 2, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
+      else if (form == 3) { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 4, false>), 160 * 1024);
+        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 4, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
+      else { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 1, false>), 160 * 1024);
+        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 1, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
     } else if (d->ldh <= 256) {
       TCAR_SET_LDS_ONCE(gather_clip_fwd_big_kernel<1>, 160 * 1024);
       TCAR_LAUNCH(gather_clip_fwd_big_kernel<1>, dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a);
