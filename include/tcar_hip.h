@@ -84,6 +84,9 @@ typedef struct {
   int32_t ce_fold;          /* TCAR_CE_FOLD        w > 0 (default 1024): tcar_ce_finish as ONE launch of about w workgroups — each folds the (max, sum)
                                                    pairs of its own 16 session rows, then rescales its slice of the plane — instead of a combine
                                                    launch + a rescale launch (0); the same bits either way */
+  int32_t logits_mfma16;    /* TCAR_LOGITS_MFMA16  1: the softmax-epilogue logits GEMM (256 x 384 tile) on v_mfma_f32_16x16x32_bf16 instead of
+                                                   32x32x16 — same tile, staging, products and epilogue contract; results differ by fp32 rounding
+                                                   of the k sums only */
 } tcar_tuning_t;
 /* *out = the process-wide values (shipped defaults + TCAR_* environment) */
 int tcar_tuning_defaults(tcar_tuning_t* out /*host*/);

@@ -24,7 +24,7 @@ const Switch kSwitches[] = {
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
     {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_REST_EARLY", &TcarTuning::rest_early, 0},
     {"TCAR_WGRAD_SPLIT", &TcarTuning::wgrad_split, 0},      {"TCAR_COLSUM_FUSED", &TcarTuning::colsum_fused, 1},
-    {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},
+    {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},           {"TCAR_LOGITS_MFMA16", &TcarTuning::logits_mfma16, 0},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
