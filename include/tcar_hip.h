@@ -70,12 +70,6 @@ typedef struct {
   int32_t attout_split;     /* TCAR_ATTOUT_SPLIT   0: the two output transforms as one un-split grouped GEMM with bias + tanh + plane epilogue and a
                                                    separate time-score launch, instead of split-K slabs finished (+ scored) by
                                                    tcar_attout_finish_scores */
-  int32_t rest_early;       /* TCAR_REST_EARLY     where the deferred Adam rest pass is forked: 0 (default) behind the projection launch, 1 behind the
-                                                   step's gather (second poll of its flag), 2 at once behind an event — 1 and 2 measured
-                                                   slower / equal (profiles/r04_ab_experiments.txt) */
-  int32_t wgrad_split;      /* TCAR_WGRAD_SPLIT    1: the weight-gradient GEMMs as two grouped launches on the third stream — eight problems
-                                                   behind the pool backward's flag, dW_q1 behind the input-gradient launch — instead of
-                                                   all nine behind the input-gradient launch.  Default 0: measured 15 us SLOWER per step */
   int32_t colsum_fused;     /* TCAR_COLSUM_FUSED   1 (default): the order-fixed column sums (bias / residual-weight gradients) and the dense-weight
                                                    norms of a fused step in ONE launch instead of two — the end of the step's last chain */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of

@@ -220,7 +220,7 @@ class Ctx(C.Structure):
 
 TUNING_FIELDS = ["bf16_tile", "rest_grid", "softmax_variant", "wgrad_ks", "gather_big_rows", "gather_wg_per_cu", "mha_mfma",
                  "sort_scatter", "bf16_ks", "det_small", "x3_oneshot", "fused_ce", "onehot_time", "proj_split", "fork_delay",
-                 "inkernel_wait", "qbwd_fused", "attout_split", "rest_early", "wgrad_split", "colsum_fused", "flag_fork", "ce_fold", "logits_mfma16"]
+                 "inkernel_wait", "qbwd_fused", "attout_split", "colsum_fused", "flag_fork", "ce_fold", "logits_mfma16"]
 
 
 class Tuning(C.Structure):

@@ -22,8 +22,7 @@ const Switch kSwitches[] = {
     {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
     {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
-    {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_REST_EARLY", &TcarTuning::rest_early, 0},
-    {"TCAR_WGRAD_SPLIT", &TcarTuning::wgrad_split, 0},      {"TCAR_COLSUM_FUSED", &TcarTuning::colsum_fused, 1},
+    {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_COLSUM_FUSED", &TcarTuning::colsum_fused, 1},
     {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},           {"TCAR_LOGITS_MFMA16", &TcarTuning::logits_mfma16, 0},
 };
 }  // namespace
@@ -180,8 +179,8 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
 // GEMM writes, and held back TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main
 // stream records nothing.
 enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_NEG = 8, FK_LOGITS = 9,
-       FK_POOLB = 10, FK_QBWD = 11,
-       FK_SOFTMAX = 12 };      // (softmax gradient -> dE's stream: bit 12 is NOT in the default mask — TCAR_FLAG_FORK=8191 turns it on)
+       FK_POOLB = 10, FK_QBWD = 11 };
+// (a thirteenth slot, softmax gradient -> dE's stream with the plane stored write-through, measured +17 .. +21 us in rounds 3 and 4: removed)
 // host-side fork state of ONE context (tcar_ctx_t.fork_host: caller-owned, zeroed, tcar_fork_state_bytes() bytes)
 struct ForkSlot { TcarSignal sig; uint32_t live; uint32_t pad; };     // live: the launch armed last for this slot carries sig
 struct ForkHost { uint32_t epoch; uint32_t pad[3]; ForkSlot slot[TCAR_SIG_SLOTS]; };
@@ -362,7 +361,6 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
                          c->q, (void*)sq, &oq));
     if (!fork_commit(c, FK_QUERY, oq)) return TCAR_E_LAUNCH;
   }
-  RET(hook(3, &og));        // (the deferred update's rest pass may fork here, off the gather's flag)
   // without the side stream (multi-rank engines, contexts without the flag words): the same ONE launch on this stream in
   // place of the two small GEMMs of the split-bf16 modes
   const bool qfused = qside || (g.ldh == 256 && g.ldt == 64 && c->scoring != 0);
@@ -562,15 +560,8 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       // three interleaved rounds: 0.6158 ms per step against 0.6213 forked at once and 0.628 forked behind the query MLP.
       rest_stage = 1;
       joined = false;
-      // Round 4 (last session), re-measured on the shorter head (TCAR_REST_EARLY, one box, ms per step): behind the projections
-      // 0.4687 0.4683 0.4677 | = 1, behind the GATHER (hook stage 3: a second poll of the flag the gather publishes for the click-query
-      // stream) 0.4802 0.4759 0.4798 | = 2, at once behind an event 0.4671 0.4689 0.4745 -> the placement stays
-      if (oh_bwd && tn(c).rest_early == 1) rest_stage = 3;
-      if (oh_bwd && tn(c).rest_early == 2) {        // at once, in front of the gather, behind an event of the main stream
-        if (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess) return TCAR_E_LAUNCH;
-        RET(launch_rest());
-        rest_stage = -1;
-      }
+      // (Round 4 re-measured the placement on the shorter head — behind the gather through a second poll of its flag: +11 us; at once
+      //  behind an event: equal — and round 5 removed those two forms: profiles/r04_ab_experiments.txt.)
     } else {
       if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
         return TCAR_E_LAUNCH;
@@ -594,13 +585,6 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   const bool onehot = ce_epi && onehot_fwd(c, B);
   ScoreOut so{c->p16h, c->p16l, oh_bwd ? c->tclip : nullptr, false};
   RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage, TcarOpt* o) -> int {
-    if (stage == 3) {                      // behind the gather launch (o = its options: the flag it took, if any)
-      if (rest_stage != 3) return TCAR_OK;
-      if (!fork_live(c, FK_GATHER)) { rest_stage = 1; return TCAR_OK; }      // no flag on the gather: behind the projections, as before
-      RET(fork_go(c, FK_GATHER, s1, s2, c->ev[0]));       // (the rest pass reads nothing the gather writes: timing only)
-      rest_stage = -1;
-      return launch_rest();
-    }
     if (rest_stage == 1 && stage == 0) o->sig = fork_arm(c, FK_PROJ);        // the projection launch carries the flag
     if (stage != rest_stage) return TCAR_OK;
     // late fork: the HBM-bound rest pass starts only now, so the launches before this point ran without it
@@ -671,9 +655,7 @@ namespace {
 // The nine weight gradients x^T dy (K = batch rows, model_combine.py:156): ONE grouped launch.  K is not split up to wgrad_ks
 // (1,536) rows; longer batches split it — into slabs folded in split order when the context has the workspace (order-fixed:
 // tcar_fold_slabs), else with float atomics into the zeroed arena.
-// part: 0 = all nine problems; 1 = the eight that need nothing of the input-gradient launch (dattout, dq, dpre1, dpre2: ready behind
-// the pool backward); 2 = dW_q1 = click_t^T dq1 alone (dq1 comes out of the input-gradient launch)
-int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream, TcarOpt* o = nullptr, int part = 0) {
+int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream, TcarOpt* o = nullptr) {
   const int ksdiv = tn(c).wgrad_ks > 0 ? tn(c).wgrad_ks : 1536;
   auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
   const int kb = ks(B), kr = ks(BT);
@@ -706,25 +688,8 @@ int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream,
       at += (int64_t)p[i].splitk * p[i].M * p[i].N;
     }
   }
-  if (part == 0) {
-    RET(small_gemm(c, 2, 9, p, stream, o));
-    if (nf) RET(tcar_fold_slabs(nf, f, stream));
-    return TCAR_OK;
-  }
-  tcar_gemm_desc_t q[9];
-  tcar_fold_t fq[9];
-  int nq = 0, nfq = 0, fi = 0;
-  for (int i = 0; i < 9; ++i) {
-    const bool split = p[i].splitk > 1 && nf > 0;
-    const bool mine = (part == 2) == (i == 3);
-    if (mine) {
-      q[nq++] = p[i];
-      if (split) fq[nfq++] = f[fi];
-    }
-    if (split) ++fi;
-  }
-  RET(small_gemm(c, 2, nq, q, stream, o));
-  if (nfq) RET(tcar_fold_slabs(nfq, fq, stream));
+  RET(small_gemm(c, 2, 9, p, stream, o));
+  if (nf) RET(tcar_fold_slabs(nf, f, stream));
   return TCAR_OK;
 }
 
@@ -791,21 +756,15 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   // hi-only backward (bf16x3-mixed, bf16): the lo plane of dlogits is never read — and not written
   CeWs cw;
-  bool sm_flag = false;
   if (ce_epilogue && fused_ce(c, B, &cw)) { // the forward pass of THIS step ran the softmax epilogue (same predicate)
-    // (slot FK_SOFTMAX: the rescale launch publishes a flag for dE's stream and stores the plane write-through — instead of an event
-    //  record between it and dX on this stream)
     TcarOpt os = opt_of(c);
-    if (s2) os.sig = fork_arm(c, FK_SOFTMAX);
     RET(tcar_ce_finish_o(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream, &os));
-    sm_flag = s2 && fork_commit(c, FK_SOFTMAX, os);
   }
   else if (c->scoring) RET(tcar_softmax_ce_bf16_o(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream, tn(c).softmax_variant));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   // (forking dE behind dX instead — dX then runs without dE beside it — was re-measured in round 4: dX is no faster alone, dE ends
   //  13 us later: 0.529 vs 0.516 ms per step, profiles/r04_ab_experiments.txt)
-  if (s2 && sm_flag) RET(fork_go(c, FK_SOFTMAX, st, s2, c->ev[2]));
-  else if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
+  if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
@@ -933,30 +892,16 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // chain's grouped launch keeps the three input-gradient GEMMs only (K = 256: 4 stages instead of the 8 of the dq1 product)
   const bool qb = detc && tn(c).qbwd_fused == 1 && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
                   tn(c).det_small != 0;
-  // Weight gradients in two launches (TCAR_WGRAD_SPLIT = 1; measured, OFF): eight of the nine problems need only what exists behind
-  // the pool backward — they can start on the third stream behind ITS flag, ~25 us before the input-gradient launch ends; dW_q1
-  // (needs dq1) follows behind that launch.  The third stream's chain (weight gradients -> column sums -> dense norms) is the
-  // step's last by ~15 us, but the early launch runs beside the main chain's input-gradient GEMM and slows it by more:
-  // 0.4618 0.4607 0.4653 against 0.4470 0.4462 0.4466 ms per step (profiles/r04_ab_experiments.txt).  Flag forks only; needs the
-  // negative rows on the third stream (their wait for dE orders it behind the arena zero).
-  const bool wsplit = detc && !qb && tn(c).wgrad_split && s2 && fuse_finish && c->stream3 && c->ev3 && neg_s3 && fork_host(c) &&
-                      ((tn(c).flag_fork >> FK_POOLB) & 1) && ((tn(c).flag_fork >> FK_INGRAD) & 1);
-  bool wgrad_early = false;
+  // (Weight gradients in two launches — eight of the nine problems behind the pool backward's flag — were measured twice, 5 us and
+  //  15 us SLOWER per step: the early launch runs beside the main chain's input-gradient GEMM.  Removed in round 5.)
   if (detc) {
     TcarOpt opb = opt_of(c);
-    if (qb || wsplit) opb.sig = fork_arm(c, FK_POOLB);
+    if (qb) opb.sig = fork_arm(c, FK_POOLB);
     else fork_disarm(c, FK_POOLB);
     RET(tcar_attn_pool_bwd_slabs_o(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
                                    c->alpha, dsplit ? c->proj_slabs : c->dpooled, dsplit ? nd_ic : 1, dsplit ? nd_pt : 1, dstride,
                                    c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream, &opb));
     (void)fork_commit(c, FK_POOLB, opb);
-    if (wsplit && fork_live(c, FK_POOLB)) {
-      hipStream_t s3w = (hipStream_t)c->stream3;
-      RET(fork_go(c, FK_POOLB, st, s3w, c->ev[0]));
-      TcarOpt ow1 = opt_of(c);
-      RET(weight_grads(c, g, B, BT, (void*)s3w, &ow1, 1));
-      wgrad_early = true;
-    }
   }
   else
     RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
@@ -1022,7 +967,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // (it needs dq1 of that launch) — off the main chain (round 4: 17 us) and off the third stream, whose weight gradients, column
   // sums and norms are the step's last chain
   const bool dclick_aux = fusedq && det_small && s3 != nullptr && !qb;
-  RET(weight_grads(c, g, B, BT, sW, &ow, wgrad_early ? 2 : 0));
+  RET(weight_grads(c, g, B, BT, sW, &ow));
   // column sums and dense norms are the last two launches of the step's last chain: ONE launch when the context has the fold scratch
   // (optim.hip: colsum_sqnorm_kernel; TCAR_COLSUM_FUSED)
   const bool cs_fused = detc && fuse_finish && s2 && c->fold_scratch && tn(c).colsum_fused;

@@ -1,5 +1,7 @@
 """Diagnostic: two engines stepped from two host threads at once vs each alone (tests/test_gpu_parity.py::
-test_two_engines_stepped_from_two_host_threads_match_their_solo_runs).  Prints, per engine, the first step whose losses differ and
+test_two_engines_in_flight_at_once_match_their_solo_runs).  Round 4: the Globo-size engine differed from its solo run in most steps
+(observation 2); round 5: identical — the cause was hipcc's SLP-packed v_pk_fma_f32 op_sel:[0,1,0] beside another
+engine's MFMA waves (profiles/r05_obs1_erratum.txt), and the library is built without the SLP vectorizer now.  Prints, per engine, the first step whose losses differ and
 by how much.  Usage: python tools/thread_probe.py [flag_fork_mask|-1 for the default] [steps]"""
 import os
 import sys
