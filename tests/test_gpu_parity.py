@@ -879,7 +879,7 @@ def test_schedule_switches_agree_bitwise_with_the_default_schedule():
     params, content, mw, _ = _case(N, H, Ht, 8, 2, K, seed=29)
     batches = [_case(N, H, Ht, B, T, K, seed=500 + T)[3] for T in (2, 1, 5, 3)]
     variants = [{}, {"TCAR_INKERNEL_WAIT": 1}, {"TCAR_INKERNEL_WAIT": 2}, {"TCAR_INKERNEL_WAIT": 4}, {"TCAR_X3_ONESHOT": 100},
-                {"TCAR_X3_ONESHOT": 1}, {"TCAR_COLSUM_FUSED": 0}]
+                {"TCAR_X3_ONESHOT": 1}]
     base = None
     for sw in variants:
         eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
