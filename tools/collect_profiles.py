@@ -11,7 +11,7 @@ go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 n = 0
 for src in sorted(glob.glob(os.path.join(go, "final_*"))):
     base = os.path.basename(src)[len("final_"):]
-    if base.endswith((".err", "_trace.log", "_pmc_gather.log")) or base in ("timeline.txt", "kernel_stats.txt", "kernel_stats.csv", "py.log", "ab.txt"):
+    if base.endswith((".err", "_trace.log", "_pmc_gather.log")) or base in ("timeline.txt", "kernel_stats.txt", "kernel_stats.csv", "py.log", "ab.txt", "trace.log", "sh.log"):
         continue
     if base.startswith("pmc_") and base.endswith(".log"):
         continue
