@@ -370,7 +370,10 @@ def main():
     # rows the next batch gathers first on the main stream, every other item row on the aux stream beside the next forward
     # pass — bitwise the same arithmetic, tests/test_gpu_parity.py).  The last update is flushed INSIDE the timed region, so K
     # timed steps contain exactly K forward passes, K backward passes and K updates.  TCAR_NO_DEFER=1: update inside its step.
-    defer = {"defer_update": True} if (world == 1 and not os.environ.get("TCAR_FORCE_DP") and not os.environ.get("TCAR_NO_DEFER")) else {}
+    # (the catalog-sharded engine on ONE rank takes the same split update — ShardedEngine.can_defer; with more ranks its update is
+    #  followed by the exchange of the owned rows and stays inside the step)
+    defer = {"defer_update": True} if (world == 1 and not os.environ.get("TCAR_NO_DEFER") and
+                                       (not os.environ.get("TCAR_FORCE_DP") or getattr(eng, "can_defer", False))) else {}
     # The sampler of the step: everything it reads is RESIDENT in HBM before the timed region starts (session store, negative
     # sources, and the example indices of every batch of the schedule: DeviceSampler.plan); inside the loop tcar_form_batch
     # forms batch i + 1 (session rows, time features, K negatives) on a side stream while step i runs.

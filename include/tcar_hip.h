@@ -681,7 +681,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
                         const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 26
+#define TCAR_ABI_VERSION 27
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -867,10 +867,16 @@ int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, cons
                                                      padding rows B*T <= r < rows_total */,
                                const float* ce_rows /* NULL, or [B]: also loss = ce_rows + neg_weight * neg_fb */, void* stream);
 /* first piece of the catalog-sharded step: zero the gradient arena, session forward (+ negative-term forward) of the local
- * sessions — bt may be NULL on a rank whose shard of the batch is empty — and the packed exchange rows (tcar_shard_pack_head) */
+ * sessions — bt may be NULL on a rank whose shard of the batch is empty — and the packed exchange rows (tcar_shard_pack_head).
+ * lr_pending >= 0 (ONE rank only: n_loc = n_items, an aux stream, the update marks): the previous step's optimizer update is still
+ * owed and is applied here as the single-GPU step's split update (tcar_train_step_deferred) — arena + the item rows this batch
+ * gathers first, every other row and the arena zero on the aux stream beside the session forward; < 0: nothing pending */
 int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int Kc, float* head, int64_t ld_head,
                      int refresh_time /* as for tcar_shard_score: with an aux stream the shard's time planes are rebuilt there */,
-                     int n_loc, void* stream);
+                     int n_loc, float lr_pending, void* stream);
+/* squared norms of the dense variables' gradients (arena) in a fixed summation order — the sharded step calls it behind the arena
+ * exchange; tcar_sqnorm over the context's dense segments, several workgroups per variable when the context has the fold scratch */
+int tcar_step_dense_norms(const tcar_ctx_t* c, void* stream);
 /* orders `stream` behind the aux-stream work of the step (tcar_shard_finish, weight gradients): call before
  * tcar_scatter_add_rows_packed and the arena exchange */
 int tcar_shard_join(const tcar_ctx_t* c, void* stream);

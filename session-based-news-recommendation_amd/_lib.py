@@ -22,7 +22,7 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 26          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 27          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_ce_shard_stats", "tcar_ce_rescale", "tcar_time_onehot", "tcar_time_scores", "tcar_time_scores_clip", "tcar_attout_finish_scores", "tcar_gemm_bf16_dx_onehot", "tcar_reduce_dact_onehot", "tcar_gemm_bf16_de_qz", "tcar_cand_time_bwd_onehot", "tcar_query_mlp", "tcar_query_mlp_bwd", "tcar_flag_fork_selftest", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
@@ -33,7 +33,7 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_combine_rowstat", "tcar_softmax_grad", "tcar_neg_scatter_range",
            "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_attn_pool_fwd_slabs", "tcar_attn_pool_bwd_slabs", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step",
-           "tcar_step_form"]
+           "tcar_step_form", "tcar_step_dense_norms"]
 
 
 def _hipcc() -> str:
@@ -381,7 +381,8 @@ def load() -> C.CDLL:
     lib.tcar_shard_backward.argtypes = [P(Ctx), P(Shard), vp, vp]
     lib.tcar_shard_finish.argtypes = [P(Ctx), P(Shard), i32, vp, vp, vp]
     lib.tcar_step_session_backward.argtypes = [P(Ctx), P(Batch), vp, vp, i64, i64, vp, vp]
-    lib.tcar_shard_begin.argtypes = [P(Ctx), P(Batch), i32, i32, vp, i64, i32, i32, vp]
+    lib.tcar_step_dense_norms.argtypes = [P(Ctx), vp]
+    lib.tcar_shard_begin.argtypes = [P(Ctx), P(Batch), i32, i32, vp, i64, i32, i32, f32, vp]
     lib.tcar_shard_join.argtypes = [P(Ctx), vp]
     lib.tcar_shard_pack_head.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp]
     lib.tcar_shard_unpack_head.argtypes = [i32, i32, i32, vp, i64, vp, vp, vp, vp]

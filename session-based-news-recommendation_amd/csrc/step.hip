@@ -1218,26 +1218,56 @@ extern "C" int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t
 }
 
 extern "C" int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int Kc, float* head, int64_t ld_head,
-                                int refresh_time, int n_loc, void* stream) {
+                                int refresh_time, int n_loc, float lr_pending, void* stream) {
   if (!c || !c->scoring || !c->Gx || !c->sqn_dense || !head || cap <= 0 || n_loc <= 0) return TCAR_E_ARG;
+  if (bt) RET(check_ctx(c, bt));
   const Geo g(c->d);
   hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
-  if (refresh_time && s2) {
+  // A pending SPLIT update (one rank: the shard is the whole table, nothing is exchanged behind the update): the single-GPU step's
+  // early pass here — arena + the item rows this batch gathers —, the REST pass over every other row, then the arena zero, on the aux
+  // stream beside the session forward; ev[5] = "aux stream done" orders the negative term (it reads rows of the rest pass) and
+  // everything after it behind both.  With more ranks the owned rows are exchanged before the next gather: the caller updates
+  // inside the step (tcar_step_update) and passes lr_pending < 0.
+  const bool split_update = lr_pending >= 0.f;
+  if (split_update) {
+    if (!bt || !s2 || !c->adam_bitmap || n_loc != (int)g.N) return TCAR_E_ARG;
+    const float* pieces = c->Gx + c->arena_n;
+    RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item,
+                             c->sqn_dense, pieces, c->use_dense, c->clip, lr_pending, c->b1, c->b2, c->eps, c->e16h, c->e16l, g.ek,
+                             bt->seq, (int64_t)bt->B * bt->T, c->adam_bitmap, stream));
+  }
+  if ((refresh_time || split_update) && s2) {
     // the candidate-side time planes of the shard depend on the time tables only: rebuilt on the aux stream beside the session
     // forward pass and the first all-gather (tcar_shard_score joins)
-    tcar_dims_t dc = c->d;
-    dc.n_items = n_loc;
-    const float* tt[5];
-    for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
     if (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess)
       return TCAR_E_LAUNCH;
-    RET(tcar_cand_time_fwd_bf16(&dc, tt, c->mwdhm, nullptr, c->e16h, c->e16l, (void*)s2));
+    if (refresh_time) {
+      tcar_dims_t dc = c->d;
+      dc.n_items = n_loc;
+      const float* tt[5];
+      for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
+      RET(tcar_cand_time_fwd_bf16(&dc, tt, c->mwdhm, nullptr, c->e16h, c->e16l, (void*)s2));
+    }
+    if (split_update) {
+      const float* pieces = c->Gx + c->arena_n;
+      RET(tcar_clip_adam_rest_keep_o(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
+                                     c->clip, lr_pending, c->b1, c->b2, c->eps, c->e16h, c->e16l, g.ek, c->adam_bitmap, (void*)s2,
+                                     tn(c).rest_grid));
+      RET(zero_arena(c, s2));              // (behind the rest pass: it reads the norm slots and pieces the zero clears)
+    }
     if (hipEventRecord((hipEvent_t)c->ev[5], s2) != hipSuccess) return TCAR_E_LAUNCH;
+    if (split_update &&        // the marks are cleared BEHIND the event the main stream waits for (the clear is a launch of its own)
+        hipMemsetAsync(c->adam_bitmap, 0, (size_t)(((g.N + 31) / 32 + 15) & ~15) * sizeof(uint32_t), s2) != hipSuccess)
+      return TCAR_E_LAUNCH;
   }
-  RET(zero_arena(c, st));
+  if (!split_update) RET(zero_arena(c, st));
   if (!bt) return tcar_shard_pack_head(0, cap, g.ek, 0, Kc, nullptr, nullptr, nullptr, nullptr, head, ld_head, stream);
-  RET(tcar_step_session_forward(c, bt, stream));
+  RET(session_forward(c, bt, g, stream, false, -1, [](int, TcarOpt*) { return (int)TCAR_OK; }));
+  // (split update: the negative term gathers item rows the rest pass may still be writing — and the arena is zeroed there)
+  if (split_update && hipStreamWaitEvent(st, (hipEvent_t)c->ev[5], 0) != hipSuccess) return TCAR_E_LAUNCH;
   const bool has_neg = bt->K > 0 && bt->neg && c->neg_coef && c->negpart;
+  if (has_neg)
+    RET(tcar_neg_fwd(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, stream));
   return tcar_shard_pack_head(bt->B, cap, g.ek, has_neg ? bt->K : 0, Kc, c->attout, bt->label, has_neg ? c->neg_coef : nullptr,
                               has_neg ? bt->neg : nullptr, head, ld_head, stream);
 }
@@ -1312,6 +1342,7 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
   const int Bq = s->world * s->cap, nl = s->n_loc, nlpad = (nl + 127) & ~127, Bp = (Bq + 127) & ~127;
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   CeWs w;
+  fork_disarm(c, FK_REDUCE);          // (tcar_shard_finish asks this slot: never a leftover of another step's form)
   if (shard_onehot(c, s, &w)) {
     // lse from the exchanged statistics, the exp plane rescaled in place to dlogits of the shard's columns; then the one-hot forms:
     // dE (aux stream) keeps its item block and leaves (||gy||^2, x . gy) pairs for the time block; dX contracts the shard against
@@ -1333,10 +1364,13 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
                                    c->splitk, stream, &ox));
     const int S1 = tcar_gemm_splitk_effective(nlpad, c->splitk);
     TcarOpt orr = opt_of(c);
+    if (s2) orr.sig = fork_arm(c, FK_REDUCE);          // (dP leaves write-through when the launch carries the flag)
     RET(tcar_reduce_dact_onehot_o(s->slabs, S1, Bq, g.ic, g.ic + 160, nullptr, 0, nullptr, 0, c->tclip, s->dx, g.ek, c->dP, nullptr,
                                   nullptr, stream, &orr));
-    // dP is complete: tcar_shard_finish lets the candidate-side table gradients (aux stream, behind dE) wait for this point
-    if (s2 && hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess) return TCAR_E_LAUNCH;
+    // dP is complete: tcar_shard_finish lets the candidate-side table gradients (aux stream, behind dE) wait for this point — for
+    // the launch's own flag when it carries one (a context with flag forks: no event record on this chain, which heads for the dX
+    // exchange), else for ev[2]
+    if (s2 && !fork_commit(c, FK_REDUCE, orr) && hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess) return TCAR_E_LAUNCH;
     return TCAR_OK;
   }
   RET(tcar_softmax_combine(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, stream));
@@ -1381,8 +1415,11 @@ extern "C" int tcar_shard_finish(const tcar_ctx_t* c, const tcar_shard_t* s, int
   const float* tt[5];
   for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
   if (shard_onehot(c, s, nullptr)) {
-    // from the (q, z) pairs of dE (this stream) and dP of the slab reduce (main stream: ev[2] of tcar_shard_backward)
-    if (s2 && hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;
+    // from the (q, z) pairs of dE (this stream) and dP of the slab reduce (main stream: its flag or ev[2], tcar_shard_backward)
+    if (s2) {
+      if (fork_live(c, FK_REDUCE)) RET(fork_go(c, FK_REDUCE, (hipStream_t)stream, s2, c->ev[2]));
+      else if (hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess) return TCAR_E_LAUNCH;
+    }
     RET(tcar_cand_time_bwd_onehot_w(&dc, s->world * s->cap, c->inv_off, c->qz, c->dP, s->att_all, s->ld_att ? s->ld_att : g.ek,
                                     c->tclip, c->ct_ws, &gr, sf, TcarWait{}, 1));
   } else {
@@ -1411,15 +1448,23 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
   const bool detc = c->gw_rows != nullptr;       // order-fixed bias / residual-weight gradients (see backward_impl)
   RET(tcar_splitk_reduce_dact(dx_rows, 1, B, g.ek, g.ek, has_neg ? c->negpart : nullptr, g.ic, g.ic, c->attout, g.ek, 2,
                               c->dattout, detc ? nullptr : G(c, TCAR_V_O_B), g.ic, detc ? nullptr : G(c, TCAR_V_OT_B), stream));
+  // dpooled = dattout W_o^T in the split form of the fused step (backward_impl): every 128-deep K chunk is its own set of workgroups
+  // writing its own slab, the pool backward folds them in slab order while it loads dpooled (round 5: 376 workgroups and one global
+  // round trip instead of 104 walking 8 / 5 serial stages — 30 -> 19 us on this chain)
+  const int nd_ic = units(g.ic), nd_pt = units(g.pt);
+  const int64_t dstride = (int64_t)B * g.ek;
+  const bool dsplit = detc && tn(c).proj_split && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
   {
     tcar_gemm_desc_t p[2];
-    p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->dpooled, g.ek);
-    p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, c->dpooled + g.ic, g.ek);
+    float* dp = dsplit ? c->proj_slabs : c->dpooled;
+    p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, dp, g.ek, nullptr, 0, 0, dsplit ? nd_ic : 1);
+    p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, dp + g.ic, g.ek, nullptr, 0, 0, dsplit ? nd_pt : 1);
     RET(small_gemm(c, 1, 2, p, stream));
   }
   if (detc)
-    RET(tcar_attn_pool_bwd_det(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
-                               c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream));
+    RET(tcar_attn_pool_bwd_slabs_o(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
+                                   c->alpha, dsplit ? c->proj_slabs : c->dpooled, dsplit ? nd_ic : 1, dsplit ? nd_pt : 1, dstride,
+                                   c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream, nullptr));
   else
     RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
                              c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, G(c, TCAR_V_M_WRES),
@@ -1431,19 +1476,27 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
     p[1] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
     p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
-    RET(small_gemm(c, 1, 4, p, stream));
+    TcarOpt oi = opt_of(c);
+    if (aux_stream(c)) oi.sig = fork_arm(c, FK_INGRAD);      // the weight-gradient fork below (flagged launches store write-through)
+    else fork_disarm(c, FK_INGRAD);
+    RET(small_gemm(c, 1, 4, p, stream, &oi));
+    (void)fork_commit(c, FK_INGRAD, oi);
   }
   {
     // beside the row gradients on the aux stream (behind tcar_shard_finish there); tcar_shard_join covers it.  Forked IN FRONT of
     // the click-query input gradient: the weight gradients need dq1 of the launch above, not dclick (round 4 timeline: the aux
-    // chain — weight gradients, column sums — ends the piece; 20 us earlier here is 20 us off the join)
+    // chain — weight gradients, column sums — ends the piece; 20 us earlier here is 20 us off the join).  Through the launch's flag
+    // where the context has flag forks (round 5: no event record on the main chain, the aux stream starts ~10 us earlier)
     hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
-    if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
-      return TCAR_E_LAUNCH;
+    if (s2) RET(fork_go(c, FK_INGRAD, st, s2, c->ev[0]));
     RET(weight_grads(c, g, B, BT, s2 ? (void*)s2 : stream));
     if (detc) RET(det_colsums(c, g, B, s2 ? (void*)s2 : stream));
   }
-  {
+  if (tn(c).qbwd_fused == 2 && g.ldh == 256 && g.ldt == 64) {
+    // dclick = dq1 Wq1^T as ONE fp32 launch of whole-row dots (query.hip: the layer-1 half of the click-query backward, as in the
+    // fused step): 7 us where the 16-workgroup small GEMM walks four serial 64-deep stages (16-20 us) on this chain
+    RET(tcar_query_mlp_bwd_o(&c->d, B, nullptr, nullptr, W(c, TCAR_V_Q1_W), nullptr, c->dq1, c->dclick, stream, nullptr));
+  } else {
     tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     RET(small_gemm(c, 1, 1, &p, stream));
   }
@@ -1463,6 +1516,16 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
   return TCAR_OK;
 }
 
+
+// dense-weight norms of the arena gradients (after the arena exchange of the catalog-sharded step), summed in a fixed order: several
+// workgroups per variable + the order-fixed fold of the last arrival when the context carries the fold scratch (one workgroup per
+// variable otherwise) — identical gradients give identical norms on every rank
+extern "C" int tcar_step_dense_norms(const tcar_ctx_t* c, void* stream) {
+  if (!c || !c->Gx || !c->sqn_dense) return TCAR_E_ARG;
+  TcarOpt o = opt_of(c);
+  if (c->fold_scratch) { o.scratch = c->fold_scratch; o.scratch_words = c->fold_scratch_words; }
+  return tcar_sqnorm_o(c->Gx, &c->segs_dense, c->sqn_dense, stream, &o);
+}
 
 // Diagnostic (tools/graph_probe.py): capture ONE fused training step (all three streams) into a hipGraph, replay it `iters`
 // times and time the replays with HIP events.  The captured step keeps the learning rate it was captured with — the probe

@@ -150,6 +150,8 @@ class DPEngine(TcarEngine):
     """TcarEngine whose backward ends with the `GradExchange` schedule.  All ranks must call train_step with
     batches of the SAME input length T (they walk the same bucket schedule)."""
 
+    flag_forks = False   # (the gradient exchange is enqueued inside the fused backward: event forks)
+
     def __init__(self, *a, group=None, **kw):
         super().__init__(*a, **kw)
         self.group = group

@@ -853,10 +853,12 @@ class TcarEngine:
                     self._aux3_ev.record(torch.cuda.current_stream(self.dev))
                 c.stream3 = self._aux3.cuda_stream
                 c.ev3 = self._aux3_ev.cuda_event
-            # flag forks (tcar_ctx_t.sig_dev): single-process engines only — a polling kernel at the head of a side stream must
-            # never share a hardware queue with work the main stream waits for, and the collectives' streams of a multi-rank run
-            # are not ours to place (DPEngine / ShardedEngine keep the event forks)
-            if type(self) is TcarEngine and not os.environ.get("TCAR_NO_FLAG_FORK"):
+            # flag forks (tcar_ctx_t.sig_dev): a polling kernel must never sit in FRONT of the work it waits for in a hardware queue.
+            # Every poll of the step is enqueued BEHIND its producer's launch, and a producer depends only on work enqueued before
+            # it — so whatever shares the poll's queue ahead of it (another of our streams, a collective's stream) never waits for
+            # the poll: the single-process engine and the catalog-sharded one (whose pieces between the collectives fork and join
+            # our own streams only) use them; DPEngine, whose exchange is enqueued in the middle of the fused backward, keeps events
+            if self.flag_forks and not os.environ.get("TCAR_NO_FLAG_FORK"):
                 if not hasattr(self, "_sig"):
                     self._sig = torch.zeros(80, dtype=torch.int32, device=self.dev)
                     # the driver's fork slots and epoch counter: host memory owned by THIS engine (nothing per thread / process)
@@ -889,6 +891,7 @@ class TcarEngine:
         self._ctx_key, self._ctx_obj = key, c
         return c
 
+    flag_forks = True    # may this engine class fork / join its streams through device flags (see _ctx)
     _ev = None
     tune = None          # optional _lib.Tuning copy of THIS engine (set_tuning); None = the process-wide switch values
 

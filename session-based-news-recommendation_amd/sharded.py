@@ -313,10 +313,11 @@ class ShardedEngine(TcarEngine):
         return [a.elapsed_time(b) for a, b in tm["ev"][kind]] if tm else []
 
     # ----------------------------------------------------------------------------------------------- step
-    def _step(self, bt: Optional[Batch], cap: int, K: int, update: bool, T: int):
+    def _step(self, bt: Optional[Batch], cap: int, K: int, update: bool, T: int, lr_pending: float = -1.0):
         """one training step; bt = None: a rank whose shard of the global batch is empty still joins every collective (T is
         the step's input length: the row buffers of the exchanges have the same shape on every rank).  The collectives are
-        ShardExchange.step; the pieces between them are the C entry points of csrc/step.hip."""
+        ShardExchange.step; the pieces between them are the C entry points of csrc/step.hip.  lr_pending >= 0 (one rank): the
+        previous step's update is owed and rides in tcar_shard_begin as the split update of the single-GPU step."""
         g, lib, p = self.geo, self.lib, self._p
         W, n0, nl = self.world, self.n0, self.nl
         B = bt.B if bt is not None else 0
@@ -345,7 +346,7 @@ class ShardedEngine(TcarEngine):
             def begin(_):
                 head = eng.head_loc[:cap]
                 check(lib.tcar_shard_begin(C.byref(ctx), C.byref(bt) if bt is not None else None, cap, eng._kcap, p(head), ldh_,
-                                           refresh, nl, st), "tcar_shard_begin")
+                                           refresh, nl, lr_pending, st), "tcar_shard_begin")
                 return head
 
             # scoring of the shard against every session + softmax statistics of the shard
@@ -399,7 +400,7 @@ class ShardedEngine(TcarEngine):
             # dense-weight norms, summed in a fixed order (one workgroup per variable): identical gradients give identical
             # norms on every rank, the replicas stay bit-identical without a broadcast
             def norms(_):
-                check(lib.tcar_sqnorm(p(eng.G), C.byref(eng.segs_dense), p(eng.sqn_dense), st), "tcar_sqnorm")
+                check(lib.tcar_step_dense_norms(C.byref(ctx), st), "tcar_step_dense_norms")
 
             def update(_):
                 return eng._update_local()
@@ -459,10 +460,20 @@ class ShardedEngine(TcarEngine):
             self.xch.share_rows(*out)
 
     def flush(self):
-        """TcarEngine.flush + the pending item-row all-gather of the last update (every reader of the item table calls flush)"""
-        super().flush()
+        """a deferred update (one rank, train_step(defer_update=True)) applied now + the pending item-row all-gather of the last
+        update (every reader of the item table calls flush)"""
+        if self._pending_lr is not None:
+            lr, self._pending_lr = self._pending_lr, None
+            check(self.lib.tcar_step_update(C.byref(self._shard_ctx()), lr, self._stream()), "tcar_step_update")
         if getattr(self, "xch", None) is not None:
             self.xch.wait_rows()
+
+    @property
+    def can_defer(self) -> bool:
+        """the split (deferred) update of the single-GPU step applies when this rank owns the whole table and nothing is exchanged
+        behind the update: ONE rank.  With more ranks the owned rows must reach the other ranks before their next gather, so the
+        update (1 / world of the table) stays inside its step."""
+        return self.world == 1 and not self._sim and self.overlap and hasattr(self, "adam_bitmap")
 
     # ------------------------------------------------------------------------------------------- public API
     score_batch = property(lambda self: self.world * max(self.cap, 1))
@@ -474,8 +485,9 @@ class ShardedEngine(TcarEngine):
         schedule).  cap = rows every rank contributes to the all-gathers (>= the largest local batch of the step; default: the
         local batch size — weak-scaling runs with equal batches); cap_rows (dp.DPEngine's argument: cap * T) is accepted
         for drop-in use.  No metadata collective, no host synchronisation."""
-        # defer_update (TcarEngine's split update) is accepted for drop-in use and ignored: the sharded update is followed by
-        # the all-gather of the updated rows, which the next step's gathers need — there is nothing to defer it behind
+        # defer_update (TcarEngine's split update): on ONE rank the update of this step is applied at the start of the next one
+        # (tcar_shard_begin) or by flush(), as in the single-GPU step; with more ranks it is ignored — the sharded update is followed
+        # by the all-gather of the updated rows, which the next step's gathers need: there is nothing to defer it behind
         if bt is None and batch is not None:
             bt = self.upload(batch)
         if bt is not None:
@@ -485,8 +497,18 @@ class ShardedEngine(TcarEngine):
             raise ValueError("an empty rank needs the step's T and K")
         if cap is None:
             cap = (cap_rows // max(T, 1)) if cap_rows else (bt.B if bt is not None else 1)
+        if bt is not None and self.can_defer and (defer_update or self._pending_lr is not None):
+            lr_p, self._pending_lr = (self._pending_lr if self._pending_lr is not None else -1.0), None
+            self._step(bt, cap, K, False, T, lr_pending=lr_p)
+            self._pending_lr = self._lr_t()
+            self._after_update()                  # step count / beta powers advance now; the device work is owed
+            self.poll_fork_errors()
+            if not defer_update:
+                self.flush()
+            return self._loss_rows(bt, cap, K)
         self.flush()
         self._step(bt, cap, K, True, T)
+        self.poll_fork_errors()                   # (a flag fork of this step's pieces that timed out: never silent)
         if bt is None:
             return torch.zeros(0, device=self.dev)
         return self._loss_rows(bt, cap, K)

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 26
+    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 27
     # the binary carries the digest of the sources it was built from; the loader refuses a stale one
     assert lib.tcar_build_id().decode() == _lib.source_build_id() == _lib.binary_build_id()
     assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
