@@ -81,6 +81,10 @@ typedef struct {
   int32_t logits_mfma16;    /* TCAR_LOGITS_MFMA16  1: the softmax-epilogue logits GEMM (256 x 384 tile) on v_mfma_f32_16x16x32_bf16 instead of
                                                    32x32x16 — same tile, staging, products and epilogue contract; results differ by fp32 rounding
                                                    of the k sums only */
+  int32_t proj_split_rows;  /* TCAR_PROJ_SPLIT_ROWS  the session-side projections take their split-K slab form (TCAR_PROJ_SPLIT) only for
+                                                   batches of at most this many rows B * T: the form trades one global round trip per workgroup
+                                                   for 12 slabs of [B*T, ldh] fp32 that the pool kernel folds — right for the latency-bound short
+                                                   buckets, 5 .. 17 % slower per step from T = 5 up (profiles/r05_ab_experiments.txt) */
 } tcar_tuning_t;
 /* *out = the process-wide values (shipped defaults + TCAR_* environment) */
 int tcar_tuning_defaults(tcar_tuning_t* out /*host*/);
@@ -174,7 +178,9 @@ int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const t
 /* Order-fixed session-side backward of the SMALL tables (position, month..minute, dwell; the click rows of the week / hour
  * tables): one workgroup per destination row sums its sources in source order (the clip Jacobian is applied once per row,
  * from S = sum gy, Q = sum ||gy||^2, D2 = sum (x.gy)^2), one add per gradient element and per norm slot.  Same values as
- * tcar_gather_clip_bwd up to rounding, bit-for-bit repeatable.  ws: tcar_small_det_ws_floats() floats. */
+ * tcar_gather_clip_bwd up to rounding, bit-for-bit repeatable.  ws: tcar_small_det_ws_floats() floats (any contents: the row pieces +
+ * the chunk partials of long buckets, B * T >= 2,048, where every table row's sources are cut into ~1,024-row chunks with a
+ * workgroup each and one wave per row adds the chunks in order). */
 int tcar_small_det_ws_floats(void);
 int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                               const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
@@ -784,6 +790,10 @@ typedef struct {
    * then one float per 32,768-float chunk of the dense weights: 36 for the reference's shapes).  With it the dense-weight norms of
    * the fused step run several workgroups per variable (tcar_sqnorm: one) — same bits on every rank and every run either way. */
   uint32_t* fold_scratch; int32_t fold_scratch_words;
+  /* optional: tcar_small_det_ws_floats() floats for the order-fixed small-table backward of the fused step — with it a long bucket
+   * (B * T >= 2,048) splits every table row's sources into chunks with a workgroup each (tcar_small_tables_bwd_det); without it the
+   * step keeps the row pieces in the tail of segsum_ws and one workgroup per table row */
+  float* small_det_ws; int64_t small_det_ws_floats;
 } tcar_ctx_t;
 
 /* Probe before setting tcar_ctx_t.sig_dev: does a polling kernel on `side_stream` run beside a kernel enqueued BEHIND it on

@@ -215,12 +215,13 @@ class Ctx(C.Structure):
                    ("oh16", C.c_void_p), ("p16h", C.c_void_p), ("p16l", C.c_void_p),
                    ("tclip", C.c_void_p), ("dP", C.c_void_p), ("qz", C.c_void_p),
                    ("sig_dev", C.c_void_p), ("fork_host", C.c_void_p), ("sig_err_host", C.c_void_p), ("tune", C.c_void_p),
-                   ("fold_scratch", C.c_void_p), ("fold_scratch_words", C.c_int32)])
+                   ("fold_scratch", C.c_void_p), ("fold_scratch_words", C.c_int32),
+                   ("small_det_ws", C.c_void_p), ("small_det_ws_floats", C.c_int64)])
 
 
 TUNING_FIELDS = ["bf16_tile", "rest_grid", "softmax_variant", "wgrad_ks", "gather_big_rows", "gather_wg_per_cu", "mha_mfma",
                  "sort_scatter", "bf16_ks", "det_small", "x3_oneshot", "fused_ce", "onehot_time", "proj_split", "fork_delay",
-                 "inkernel_wait", "qbwd_fused", "attout_split", "colsum_fused", "flag_fork", "ce_fold", "logits_mfma16"]
+                 "inkernel_wait", "qbwd_fused", "attout_split", "colsum_fused", "flag_fork", "ce_fold", "logits_mfma16", "proj_split_rows"]
 
 
 class Tuning(C.Structure):

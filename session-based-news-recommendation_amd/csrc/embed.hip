@@ -1012,8 +1012,62 @@ struct SmallDetArgs {
   const float* dx_icp; const float* dx_pt; const float* dx_act; const float* dclick;
   float* g_pos; float* g_small;      // [40, ldh]; [150, ldt] = month | day | week | hour | minute | dwell
   float* rowq;                        // [SMALL_DET_ROWS] per-row norm pieces (folded per table by small_norm_fold_kernel)
+  int CH; float* part;                // CH > 1: the sources of every row in CH chunks, each its own workgroup leaving (S, q, D) in part
 };
 constexpr int SMALL_DET_ROWS = TCAR_POS_VOCAB + SMALL_ROWS + 1;   // + the out-of-range dwell bucket (norm only, S7)
+constexpr int SMALL_DET_CH = 16;                                  // most chunks per row (workspace: rows x chunks x (64 NC + 2) floats)
+constexpr int SMALL_DET_PW = 64 * 8 + 2;                          // floats of one partial (NC <= 8)
+// the ch-th of CH equal parts of [0, n), and the wv-th sixteenth of that part
+__device__ __forceinline__ void det_range(int n, int CH, int ch, int wv, int& r0, int& r1) {
+  const int perc = (n + CH - 1) / CH, c0 = min(n, ch * perc), c1 = min(n, c0 + perc);
+  const int per = (c1 - c0 + 15) / 16;
+  r0 = min(c1, c0 + wv * per);
+  r1 = min(c1, r0 + per);
+}
+// what a destination row R is: kind 0 position row, 1 time / dwell row sr of table k (value v), 2 the out-of-range dwell bucket
+struct DetRow { int kind, k, v, cols, sr; const float* xrow; };
+__device__ __forceinline__ DetRow det_row(const SmallDetArgs& a, int R, int T) {
+  DetRow r{0, 0, 0, 0, 0, nullptr};
+  const int ldh = a.d.ldh, ldt = a.d.ldt;
+  if (R < T) { r.kind = 0; r.cols = ldh; r.xrow = a.tab.pos + (long)R * ldh; }
+  else if (R < T + SMALL_ROWS) {
+    r.kind = 1; r.sr = R - T; r.cols = ldt;
+    const int sr = r.sr;
+    r.k = sr < 13 ? 0 : sr < 45 ? 1 : sr < 53 ? 2 : sr < 78 ? 3 : sr < 139 ? 4 : 5;
+    r.v = sr - time_rowoff(r.k);
+    r.xrow = (r.k < 5 ? pick5(a.tab.time, r.k) : a.tab.dur) + (long)r.v * ldt;
+  } else { r.kind = 2; r.k = 5; r.cols = ldt; }
+  return r;
+}
+// the end of a destination row (one wave): clip Jacobian once per row on the summed sources, the gradient row, the norm piece
+template <int NC>
+__device__ __forceinline__ void det_finish(const SmallDetArgs& a, const DetRow& r, int R, int lane, const float (&x)[NC],
+                                           const float (&St)[NC], float Q, float D) {
+  const int ldh = a.d.ldh, ldt = a.d.ldt;
+  float ss = 0.f, xs = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { ss += x[c] * x[c]; xs += x[c] * St[c]; }
+  ss = wave_sum(ss);
+  xs = wave_sum(xs);
+  float pc = Q;
+  float ca = 1.f, cb = 0.f;
+  if (r.kind != 2 && ss > 1.0f) {
+    const float inv = 1.0f / sqrtf(ss), inv2 = inv * inv;
+    ca = inv;
+    cb = xs * inv2 * inv;
+    pc = inv2 * Q - inv2 * inv2 * D;
+  }
+  if (r.kind != 2) {
+    float* dst = (r.kind == 0) ? a.g_pos + (long)R * ldh : a.g_small + (long)r.sr * ldt;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int col = lane + 64 * c;
+      const float gx = ca * St[c] - cb * x[c];
+      if (col < r.cols && gx != 0.f) atomicAdd(dst + col, gx);
+    }
+  }
+  if (lane == 0) a.rowq[r.kind == 0 ? R : TCAR_POS_VOCAB + (r.kind == 1 ? r.sr : SMALL_ROWS)] = pc;
+}
 
 template <int NC>   // 64-column groups per lane: columns <= 64 * NC
 __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallDetArgs a) {
@@ -1022,16 +1076,13 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int B = a.bt.B, T = a.bt.T, BT = B * T;
   const int ldh = a.d.ldh, ldt = a.d.ldt, ic = 2 * ldh, pt = 5 * ldt, ct = 2 * ldt;
-  const int R = blockIdx.x;                     // [0, T) position rows | [T, T + 150) small-table rows | T + 150: dwell out of range
-  int kind, k = 0, v = 0, cols, sr = 0;
-  const float* xrow = nullptr;
-  if (R < T) { kind = 0; cols = ldh; xrow = a.tab.pos + (long)R * ldh; }
-  else if (R < T + SMALL_ROWS) {
-    kind = 1; sr = R - T; cols = ldt;
-    k = sr < 13 ? 0 : sr < 45 ? 1 : sr < 53 ? 2 : sr < 78 ? 3 : sr < 139 ? 4 : 5;
-    v = sr - time_rowoff(k);
-    xrow = (k < 5 ? pick5(a.tab.time, k) : a.tab.dur) + (long)v * ldt;
-  } else { kind = 2; k = 5; cols = ldt; }
+  // [0, T) position rows | [T, T + 150) small-table rows | T + 150: dwell out of range; CH > 1: chunk ch of the row's sources
+  const int nrows = T + SMALL_ROWS + 1;
+  const int R = blockIdx.x % nrows, ch = blockIdx.x / nrows, CH = a.CH;
+  const DetRow dr = det_row(a, R, T);
+  const int kind = dr.kind, k = dr.k, v = dr.v, cols = dr.cols;
+  const float* xrow = dr.xrow;
+  (void)ldh;
   float x[NC], S[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -1040,18 +1091,22 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
     S[c] = 0.f;
   }
   float ql = 0.f, D2 = 0.f;
-  // acc of up to 4 sources whose gradient slices start at p[0..n): loads first, then the sums in order
-  auto take4 = [&](const float* const* p, int n) {
-    float g[4][NC];
+  // acc of up to U sources whose gradient slices start at p[0..n): ALL loads first (one memory round trip for the group), then the sums
+  // in source order — the order of the sums does not depend on U.  Position rows are ldh wide (NC registers per source, 8 in flight);
+  // the time / dwell rows are ldt <= 64 wide: one register per source, 16 in flight (round 5: a wave of the week table's workgroups
+  // walks (B*T / 7) / 16 matches — 4 at a time that was 8 dependent round trips at T = 7, 46 at T = 40: 72 / 400 us on the chain
+  // that ends the step)
+  auto takeP = [&](const float* const* p, int n) {
+    float g[8][NC];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
         const int col = lane + 64 * c;
         g[u][c] = (u < n && col < cols) ? p[u][col] : 0.f;
       }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       if (u >= n) break;
       float d = 0.f;
 #pragma unroll
@@ -1060,20 +1115,45 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
       D2 += d * d;
     }
   };
+  // (up to 16 matches of the ballot mask m, in ascending lane order; src(j) = gradient slice of the match at lane j.  cols <= 64:
+  //  column group 0 only — x and S of the other groups stay 0)
+  auto takeS = [&](unsigned long long& m, auto&& src) {
+    float g[16], d[16];
+    int n = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const bool v = m != 0;                   // (wave-uniform)
+      const int j = v ? __builtin_ctzll(m) : 0;
+      if (v) { m &= m - 1; n = u + 1; }
+      const float* q = src(j);
+      g[u] = (v && lane < cols) ? q[lane] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) d[u] = wave_sum(x[0] * g[u]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (u < n) {
+        S[0] += g[u]; ql += g[u] * g[u];
+        D2 += d[u] * d[u];
+      }
+    }
+  };
   if (kind == 0) {
     // position t = R: the sources are the rows b * T + t, no ids to match
-    const int per = (B + 15) / 16, b0 = wv * per, b1 = min(B, b0 + per);
-    for (int b = b0; b < b1; b += 4) {
-      const float* p[4];
-      const int n = min(4, b1 - b);
+    int b0, b1;
+    det_range(B, CH, ch, wv, b0, b1);
+    for (int b = b0; b < b1; b += 8) {
+      const float* p[8];
+      const int n = min(8, b1 - b);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p[u] = a.dx_icp + ((long)(b + (u < n ? u : 0)) * T + R) * ic;
-      take4(p, n);
+      for (int u = 0; u < 8; ++u) p[u] = a.dx_icp + ((long)(b + (u < n ? u : 0)) * T + R) * ic;
+      takeP(p, n);
     }
   } else {
     // session rows: id of table k at every source row; matches of this wave's sixteenth, in order
     const int32_t* ids = (k < 5) ? pick5(a.bt.pub, k) : a.bt.gap;
-    const int per = (BT + 15) / 16, r0 = wv * per, r1 = min(BT, r0 + per);
+    int r0, r1;
+    det_range(BT, CH, ch, wv, r0, r1);
     for (int base = r0; base < r1; base += 64) {
       const int row = base + lane;
       bool hit = false;
@@ -1083,45 +1163,23 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
         hit = (kind == 2) ? oob : (!oob && clampi(id, 0, time_vocab(k) - 1) == v);
       }
       unsigned long long m = __ballot(hit);
-      while (m) {
-        const float* p[4];
-        int n = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            const long rr = base + j;
-            p[u] = (k < 5) ? a.dx_pt + rr * pt + k * ldt : a.dx_act + rr * ldt;
-            n = u + 1;
-          } else p[u] = p[0];
-        }
-        take4(p, n);
-      }
+      while (m)
+        takeS(m, [&](int j) {
+          const long rr = base + j;
+          return (k < 5) ? a.dx_pt + rr * pt + k * ldt : a.dx_act + rr * ldt;
+        });
     }
     // click rows: the week table by cw, the hour table by ch (model_combine.py:94-97)
     if (kind == 1 && (k == 2 || k == 3)) {
       const int32_t* cid = (k == 2) ? a.bt.cw : a.bt.ch;
       const int jj = (k == 2) ? 0 : 1;
-      const int perb = (B + 15) / 16, b0 = wv * perb, b1 = min(B, b0 + perb);
+      int b0, b1;
+      det_range(B, CH, ch, wv, b0, b1);
       for (int base = b0; base < b1; base += 64) {
         const int b = base + lane;
         const bool hit = (b < b1) && clampi(cid[b], 0, time_vocab(k) - 1) == v;
         unsigned long long m = __ballot(hit);
-        while (m) {
-          const float* p[4];
-          int n = 0;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (m) {
-              const int j = __builtin_ctzll(m);
-              m &= m - 1;
-              p[u] = a.dclick + (long)(base + j) * ct + jj * ldt;
-              n = u + 1;
-            } else p[u] = p[0];
-          }
-          take4(p, n);
-        }
+        while (m) takeS(m, [&](int j) { return a.dclick + (long)(base + j) * ct + jj * ldt; });
       }
     }
   }
@@ -1141,29 +1199,37 @@ __global__ __launch_bounds__(1024) void small_tables_bwd_det_kernel(const SmallD
     Q += partQ[w];
     D += partD[w];
   }
-  float ss = 0.f, xs = 0.f;
+  if (CH > 1) {                                  // this chunk's partial; small_tables_fold_kernel adds the chunks in order
+    float* pp = a.part + ((long)R * CH + ch) * SMALL_DET_PW;
 #pragma unroll
-  for (int c = 0; c < NC; ++c) { ss += x[c] * x[c]; xs += x[c] * St[c]; }
-  ss = wave_sum(ss);
-  xs = wave_sum(xs);
-  float pc = Q;
-  float ca = 1.f, cb = 0.f;
-  if (kind != 2 && ss > 1.0f) {
-    const float inv = 1.0f / sqrtf(ss), inv2 = inv * inv;
-    ca = inv;
-    cb = xs * inv2 * inv;
-    pc = inv2 * Q - inv2 * inv2 * D;
+    for (int c = 0; c < NC; ++c) pp[lane + 64 * c] = St[c];
+    if (lane == 0) { pp[64 * NC] = Q; pp[64 * NC + 1] = D; }
+    return;
   }
-  if (kind != 2) {
-    float* dst = (kind == 0) ? a.g_pos + (long)R * ldh : a.g_small + (long)sr * ldt;
+  det_finish<NC>(a, dr, R, lane, x, St, Q, D);
+}
+
+// CH > 1: one wave per destination row adds the CH chunk partials in chunk order and ends the row
+template <int NC>
+__global__ __launch_bounds__(64) void small_tables_fold_kernel(const SmallDetArgs a) {
+  const int lane = threadIdx.x, R = blockIdx.x, T = a.bt.T, CH = a.CH;
+  const DetRow dr = det_row(a, R, T);
+  float x[NC], St[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const int col = lane + 64 * c;
-      const float gx = ca * St[c] - cb * x[c];
-      if (col < cols && gx != 0.f) atomicAdd(dst + col, gx);
-    }
+  for (int c = 0; c < NC; ++c) {
+    const int col = lane + 64 * c;
+    x[c] = (dr.xrow && col < dr.cols) ? dr.xrow[col] : 0.f;
+    St[c] = 0.f;
   }
-  if (lane == 0) a.rowq[kind == 0 ? R : TCAR_POS_VOCAB + (kind == 1 ? sr : SMALL_ROWS)] = pc;
+  float Q = 0.f, D = 0.f;
+  const float* pp = a.part + (long)R * CH * SMALL_DET_PW;
+  for (int ch = 0; ch < CH; ++ch, pp += SMALL_DET_PW) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) St[c] += pp[lane + 64 * c];
+    Q += pp[64 * NC];
+    D += pp[64 * NC + 1];
+  }
+  det_finish<NC>(a, dr, R, lane, x, St, Q, D);
 }
 
 // per-table norm pieces from the per-row ones, rows in order; one add per slot (the candidate side adds its one)
@@ -1446,17 +1512,18 @@ extern "C" int tcar_cand_time_bwd(const tcar_dims_t* d, const float* const time_
 
 // Order-fixed session-side backward of the position, time and dwell tables (see small_tables_bwd_det_kernel); the item rows
 // are tcar_gather_clip_bwd's with g->skip_small set.  ws: >= tcar_small_det_ws_floats() floats.
-extern "C" int tcar_small_det_ws_floats(void) { return SMALL_DET_ROWS; }
+extern "C" int tcar_small_det_ws_floats(void) { return SMALL_DET_ROWS + SMALL_DET_ROWS * SMALL_DET_CH * SMALL_DET_PW; }
 extern "C" int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                          const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g,
                                          float* ws, void* stream) {
-  return tcar_small_tables_bwd_det_o(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, ws, stream, nullptr, nullptr);
+  return tcar_small_tables_bwd_det_o(d, tab, bt, dx_icp, dx_pt, dx_act, dclick, g, ws, stream, nullptr, nullptr, tcar_small_det_ws_floats());
 }
 // (flag-capable: the norm fold, its last launch, publishes its slots with atomics)
 int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                 const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
-                                void* stream, TcarOpt* o, const float* cand_pc) {
-  if (check_dims(d) || !tab || !bt || !g || !ws || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB) return TCAR_E_ARG;
+                                void* stream, TcarOpt* o, const float* cand_pc, int64_t ws_floats) {
+  if (check_dims(d) || !tab || !bt || !g || !ws || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB || ws_floats < SMALL_DET_ROWS)
+    return TCAR_E_ARG;
   if (!dx_icp || !dx_pt || !dx_act || !dclick || !g->g_pos || !g->g_time[0] || !g->sqn) return TCAR_E_ARG;
   SmallDetArgs a{};
   a.d = *d; a.tab = *tab; a.bt = *bt;
@@ -1465,9 +1532,23 @@ int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, 
   const int rows = bt->T + SMALL_ROWS + 1;
   const int widest = d->ldh > d->ldt ? d->ldh : d->ldt;
   hipStream_t st = (hipStream_t)stream;
-  if (widest <= 256) TCAR_LAUNCH(small_tables_bwd_det_kernel<4>, dim3(rows), dim3(1024), 0, st, a);
-  else TCAR_LAUNCH(small_tables_bwd_det_kernel<8>, dim3(rows), dim3(1024), 0, st, a);
+  // Long buckets: the sources of every destination row in CH chunks of ~1,024 rows, each chunk its own workgroup, and one wave per row
+  // that adds the chunk partials in chunk order (a fixed order again).  A fold where every session shares a month — every real one —
+  // sends ALL B * T sources to one row of that table: one workgroup then walks them all (71 us at T = 7, 365 us at T = 40, on the
+  // chain that ends the step; tools/small_det_bench.py).  Short buckets (B * T < 2,048) keep the single pass and its bits.
+  const long BT = (long)bt->B * bt->T;
+  int CH = BT >= 2048 ? (int)(BT / 1024) : 1;
+  if (CH > SMALL_DET_CH) CH = SMALL_DET_CH;
+  if (ws_floats < (int64_t)SMALL_DET_ROWS + (int64_t)SMALL_DET_ROWS * CH * SMALL_DET_PW) CH = 1;      // (a caller with the row pieces only)
+  a.CH = CH; a.part = ws + SMALL_DET_ROWS;
+  if (widest <= 256) TCAR_LAUNCH(small_tables_bwd_det_kernel<4>, dim3(rows * CH), dim3(1024), 0, st, a);
+  else TCAR_LAUNCH(small_tables_bwd_det_kernel<8>, dim3(rows * CH), dim3(1024), 0, st, a);
   TCAR_CHECK_LAUNCH();
+  if (CH > 1) {
+    if (widest <= 256) TCAR_LAUNCH(small_tables_fold_kernel<4>, dim3(rows), dim3(64), 0, st, a);
+    else TCAR_LAUNCH(small_tables_fold_kernel<8>, dim3(rows), dim3(64), 0, st, a);
+    TCAR_CHECK_LAUNCH();
+  }
   TCAR_LAUNCH(small_norm_fold_kernel, dim3(1), dim3(64), 0, st, (const float*)ws, bt->T, g->sqn, g->slot_pos, g->slot_time[0],
               g->slot_time[1], g->slot_time[2], g->slot_time[3], g->slot_time[4], g->slot_dur, tcar_sig(o), cand_pc);
   TCAR_CHECK_LAUNCH();

@@ -24,6 +24,7 @@ const Switch kSwitches[] = {
     {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
     {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_COLSUM_FUSED", &TcarTuning::colsum_fused, 1},
     {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},           {"TCAR_LOGITS_MFMA16", &TcarTuning::logits_mfma16, 0},
+    {"TCAR_PROJ_SPLIT_ROWS", &TcarTuning::proj_split_rows, 1024},
 };
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
@@ -375,8 +376,12 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   const int n1 = units(g.ic) + units(g.ldh) + units(g.ldt), n2 = units(g.pt) + units(g.ldh);
   const int64_t stride = (int64_t)BT * g.ldh;
   const bool split = c->scoring && tn(c).proj_split && c->proj_slabs && c->proj_slab_floats >= (n1 + n2) * stride;
+  // (the slab form of the PROJECTIONS only up to TCAR_PROJ_SPLIT_ROWS rows: from there the launch has workgroups enough without the
+  //  split, and 12 slabs of [BT, ldh] written and folded again cost more than the serial stages they save; the output transforms
+  //  below are B-row problems and keep their split at every T)
+  const bool psplit = split && BT <= tn(c).proj_split_rows;
   TcarOpt op = opt_of(c);          // the projection launch: the hook may hand it a completion flag
-  if (split) {
+  if (psplit) {
     float* s1 = c->proj_slabs;
     float* s2 = c->proj_slabs + n1 * stride;
     tcar_gemm_desc_t p[6];
@@ -412,7 +417,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   // after its slab fold and alpha1 / alpha_t scores, so the wait overlaps that work and no polling kernel sits on this stream:
   // ~8 us of launch + poll off the chain); otherwise a polling kernel / an event
   TcarWait wq{};
-  if (qside && split && (tn(c).inkernel_wait & 1)) {
+  if (qside && psplit && (tn(c).inkernel_wait & 1)) {
     if (const ForkSlot* f = fork_live(c, FK_QUERY)) wq = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
   }
   if (qside && !wq.flag) {
@@ -422,7 +427,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     RET(small_gemm(c, 0, 1, &p, stream));
   }
   RET(hook(2, &op));
-  if (split)
+  if (psplit)
     RET(tcar_attn_pool_fwd_slabs_w(&c->d, B, bt->T, c->x_icp, c->x_pt, c->proj_slabs, n1, c->proj_slabs + n1 * stride, n2, stride,
                                    c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES), c->pooled, c->alpha, stream, wq));
   else
@@ -1024,7 +1029,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     tcar_grads_t gr;
     tables_of(c, tab);
     grads_of(c, gr);
-    float* rowq = (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);       // second half of the workspace tail
+    // row pieces (+ chunk partials of long buckets) in the context's own workspace, else the second half of the segsum tail
+    float* rowq = c->small_det_ws ? c->small_det_ws : (float*)((char*)c->segsum_ws + c->segsum_bytes - 2048);
+    const int64_t rowq_floats = c->small_det_ws ? c->small_det_ws_floats : 512;
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
     if (qb) {
@@ -1046,7 +1053,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     TcarOpt o2 = opt_of(c);
     if (tail3) o2.sig = fork_arm(c, FK_TAIL2);
     RET(tcar_small_tables_bwd_det_o(&c->d, &tab, bt, c->dx_icp, c->dx_pt, c->dx_act, c->dclick, &gr, rowq, (void*)s2, &o2,
-                                    ohb ? tcar_cand_pieces(&c->d, c->ct_ws) : nullptr));
+                                    ohb ? tcar_cand_pieces(&c->d, c->ct_ws) : nullptr, rowq_floats));
     if (tail3) tail2 = fork_commit(c, FK_TAIL2, o2);
     if (hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
   }

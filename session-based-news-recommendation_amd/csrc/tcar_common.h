@@ -133,7 +133,8 @@ int tcar_query_mlp_bwd_o(const tcar_dims_t* d, int B, const float* dq, const flo
                          float* dclick, void* stream, TcarOpt* o);
 int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                                 const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
-                                void* stream, TcarOpt* o, const float* cand_pc /* optional [139]: candidate-side norm pieces */);
+                                void* stream, TcarOpt* o, const float* cand_pc /* optional [139]: candidate-side norm pieces */,
+                                int64_t ws_floats /* of ws: below tcar_small_det_ws_floats() the single-pass form only */);
 int tcar_cand_time_bwd_onehot_w(const tcar_dims_t* d, int B, const int32_t* inv_off, const float* qz, const float* dP,
                                 const float* attout, int64_t ld_att, const float* tclip, float* ws, const tcar_grads_t* g, void* stream,
                                 const TcarWait& wait_dp, int with_pieces);

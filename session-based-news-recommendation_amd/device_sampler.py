@@ -212,9 +212,16 @@ class DeviceSampler:
         main = torch.cuda.current_stream(self.dev)
         side, used = self._side, [False, False]
         side.wait_stream(main)               # the plan's upload (and whatever wrote the stores) is on the main stream
-        # chunk boundaries: a SHORT first chunk (the consumer's first step waits for the whole first chunk: 16 batches are ~0.2 ms
-        # of form + sample launches, which a 20-step loop would pay in full), full chunks after it
-        lo = [0] + list(range(min(2, ch), n, ch))
+        # chunk boundaries: SHORT first chunks that double up to the full size (2, 2, 4, 8, 16, 16, ...).  Forming a chunk is two
+        # launches per batch on the host (~0.25 ms for 16 batches): the consumer's first step waits for the whole first chunk, and the
+        # host can only afford the launches of a chunk once it is that far ahead of the device — it gains ~0.1 ms per step.  (Round 4
+        # formed 2 then 16 batches BEFORE the first step was enqueued: the device idled ~0.25 ms at the top of every loop, 12 us per
+        # step of a 20-step run — profiles/r05_ab_experiments.txt, tools/short_form_trace.sh.)
+        lo, size = [0], min(2, ch)
+        while lo[-1] + size < n:
+            lo.append(lo[-1] + size)
+            if len(lo) > 2:
+                size = min(2 * size, ch)
         hi = lo[1:] + [n]
         nchunk = len(lo)
 
@@ -231,11 +238,13 @@ class DeviceSampler:
         launch(0)
         for j in range(nchunk):
             slot = j & 1
-            if j + 1 < nchunk:
-                launch(j + 1)
             main.wait_event(self._ev_ready[slot])
             for i in range(lo[j], hi[j]):
                 yield self._describe(self._feeds[slot][(i - lo[j]) * need:], self.plan_B[i], self.plan_T[i], K)
+                if i == lo[j] and j + 1 < nchunk:
+                    # the next chunk is formed once the consumer has enqueued the FIRST step of this one: the device has work while
+                    # the host spends the launches (the other buffer is free: its steps were enqueued before this chunk's wait)
+                    launch(j + 1)
             self._ev_free[slot].record(main)
             used[slot] = True
 

@@ -846,6 +846,10 @@ class TcarEngine:
             if getattr(self, "_segsum_ws", None) is None or self._segsum_ws.numel() < need:
                 self._segsum_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
             c.segsum_ws, c.segsum_bytes = self._segsum_ws.data_ptr(), self._segsum_ws.numel()
+            # row pieces + chunk partials of the order-fixed small-table backward (long buckets: a workgroup per ~1,024 sources)
+            if getattr(self, "_small_det_ws", None) is None:
+                self._small_det_ws = torch.empty(int(self.lib.tcar_small_det_ws_floats()), dtype=torch.float32, device=self.dev)
+            c.small_det_ws, c.small_det_ws_floats = self._small_det_ws.data_ptr(), self._small_det_ws.numel()
             if not os.environ.get("TCAR_NO_STREAM3"):
                 if not hasattr(self, "_aux3"):
                     self._aux3 = torch.cuda.Stream(self.dev)

@@ -132,12 +132,14 @@ def test_attn_pool_op(B, T):
         close(a.grad, b.grad, name="d " + name, atol_scale=max(1e-4, floor))
 
 
-@pytest.mark.parametrize("B,T,skew", [(64, 5, False), (512, 3, True), (33, 40, False)])
+@pytest.mark.parametrize("B,T,skew", [(64, 5, False), (512, 3, True), (33, 40, False), (512, 7, True), (500, 40, True), (300, 9, False)])
 def test_order_fixed_small_table_backward(B, T, skew):
     """tcar_small_tables_bwd_det (one workgroup per destination row, sources in order, clip Jacobian once per row) against
     the atomic form inside tcar_gather_clip_bwd: position / time / dwell gradients and their norm pieces agree to rounding,
     the item rows of the skip_small gather are unchanged, and repeated runs agree bit for bit.  skew: every session shares one
-    click time and one publish hour (MIND-like: one table row collects every source)."""
+    click time and one publish hour (MIND-like: one table row collects every source).  B * T >= 2,048: the chunked form — every table
+    row's sources in chunks of ~1,024 with a workgroup each, one wave per row adding the chunk partials in order (3, 16 and 2 chunks
+    here)."""
     _need_gpu()
     import ctypes as C
     from tcar_amd import _lib, torch_ops

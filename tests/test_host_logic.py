@@ -41,7 +41,7 @@ def test_tuning_switch_defaults():
             "TCAR_GATHER_BIG_ROWS": 16384, "TCAR_GATHER_WG": 2, "TCAR_MHA_MFMA": 1, "TCAR_SORT_SCATTER": 1, "TCAR_BF16_KS": 2,
             "TCAR_DET_SMALL": 1, "TCAR_X3_ONESHOT": 4, "TCAR_PROJ_SPLIT": 1, "TCAR_FUSED_CE": 1, "TCAR_ONEHOT_TIME": 2, "TCAR_FLAG_FORK": 4095, "TCAR_FORK_DELAY": 7,
             "TCAR_INKERNEL_WAIT": 0, "TCAR_QBWD_FUSED": 2, "TCAR_ATTOUT_SPLIT": 1, "TCAR_COLSUM_FUSED": 1,
-            "TCAR_CE_FOLD": 1024, "TCAR_LOGITS_MFMA16": 0}
+            "TCAR_CE_FOLD": 1024, "TCAR_LOGITS_MFMA16": 0, "TCAR_PROJ_SPLIT_ROWS": 1024}
     header = open(os.path.join(ROOT, "include", "tcar_hip.h")).read()
     block = header[header.index("typedef struct {\n  int32_t bf16_tile"):header.index("} tcar_tuning_t;")]
     documented = set(re.findall(r"/\* (TCAR_[A-Z0-9_]+)\b", block))
