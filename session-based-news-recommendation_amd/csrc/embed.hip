@@ -1015,7 +1015,7 @@ struct SmallDetArgs {
   int CH; float* part;                // CH > 1: the sources of every row in CH chunks, each its own workgroup leaving (S, q, D) in part
 };
 constexpr int SMALL_DET_ROWS = TCAR_POS_VOCAB + SMALL_ROWS + 1;   // + the out-of-range dwell bucket (norm only, S7)
-constexpr int SMALL_DET_CH = 16;                                  // most chunks per row (workspace: rows x chunks x (64 NC + 2) floats)
+constexpr int SMALL_DET_CH = 32;                                  // most chunks per row (workspace: rows x chunks x (64 NC + 2) floats)
 constexpr int SMALL_DET_PW = 64 * 8 + 2;                          // floats of one partial (NC <= 8)
 // the ch-th of CH equal parts of [0, n), and the wv-th sixteenth of that part
 __device__ __forceinline__ void det_range(int n, int CH, int ch, int wv, int& r0, int& r1) {
@@ -1537,6 +1537,7 @@ int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, 
   // sends ALL B * T sources to one row of that table: one workgroup then walks them all (71 us at T = 7, 365 us at T = 40, on the
   // chain that ends the step; tools/small_det_bench.py).  Short buckets (B * T < 2,048) keep the single pass and its bits.
   const long BT = (long)bt->B * bt->T;
+  // (chunks of 512 / 256 / 128 sources measured 42 / 61 / 94 us at T = 7 against 41 us: a 1,024-thread workgroup costs ~15 us whatever it finds)
   int CH = BT >= 2048 ? (int)(BT / 1024) : 1;
   if (CH > SMALL_DET_CH) CH = SMALL_DET_CH;
   if (ws_floats < (int64_t)SMALL_DET_ROWS + (int64_t)SMALL_DET_ROWS * CH * SMALL_DET_PW) CH = 1;      // (a caller with the row pieces only)
