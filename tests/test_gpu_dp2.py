@@ -72,7 +72,7 @@ def test_two_ranks_match_single_engine(scoring):
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     world = 2
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # (a SPAWNED server: a fork of this process would inherit its GPU state)
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), scoring, ret), nprocs=world, join=True)
     for r in range(world):
@@ -107,7 +107,7 @@ def test_cli_two_ranks_shard_batches_and_agree_with_one_rank(extra):
     import torch.multiprocessing as mp
     argv = ["--synthetic", "700", "--synthetic_train", "3000", "--synthetic_test", "600", "--epoch", "2",
             "--hidden_size", "48", "--time_hidden_size", "16", "--batch_size", "128", "--gap_mode", "click_delta"]
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # (a SPAWNED server: a fork of this process would inherit its GPU state)
     ret = mgr.dict()
     mp.spawn(_cli_worker, args=(2, _free_port(), argv + extra, ret), nprocs=2, join=True)
     for r in range(2):

@@ -199,7 +199,7 @@ def test_two_ranks_sharded_match_single_engine(scoring):
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     world = 2
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()      # (a SPAWNED server: a fork of this process would inherit its GPU state)
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret, scoring), nprocs=world, join=True)
     for r in range(world):

@@ -29,6 +29,9 @@ case $1 in
     cp gpurun_out/final_timeline.txt gpurun_out/final_timeline_sharded_simworld8.txt
     $S "py:tools/thread_probe.py -1 40"
     cp gpurun_out/final_py.log gpurun_out/final_thread_probe.txt
+    python tools/small_det_bench.py 2>&1 | grep "^T =" > gpurun_out/final_small_det_bench.txt; tail -3 gpurun_out/final_small_det_bench.txt
+    python tools/step_times.py sampler 2>&1 | grep -v amdgpu.ids > gpurun_out/final_short_form_steps.txt; head -2 gpurun_out/final_short_form_steps.txt
+    bash tools/trace_T.sh; cp gpurun_out/T_timelines.txt gpurun_out/final_timelines_T7_T4_T1.txt
     $S "bench:stress10m:--config stress10m --steps 10 --warmup 2 --no_cpu_baseline --no_e2e"
     ;;
   *) echo "usage: $0 part1|part2" ;;
