@@ -362,7 +362,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
                          c->q, (void*)sq, &oq));
     if (!fork_commit(c, FK_QUERY, oq)) return TCAR_E_LAUNCH;
   }
-  // without the side stream (multi-rank engines, contexts without the flag words): the same ONE launch on this stream in
+  // without the side stream (the replica engine, contexts without the flag words): the same ONE launch on this stream in
   // place of the two small GEMMs of the split-bf16 modes
   const bool qfused = qside || (g.ldh == 256 && g.ldt == 64 && c->scoring != 0);
   if (qfused && !qside)
