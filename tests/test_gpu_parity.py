@@ -207,6 +207,7 @@ CASES = [  # N, H, Ht, B, T, K
     (1000, 256, 64, 5, 3, 2),
     (129, 250, 64, 130, 3, 1),          # N just past one 128-row block, B past one 128-row plane block, a single negative
     (1000, 250, 64, 513, 2, 33),        # B = 512 + 1: a second (one-row) M tile in every scoring GEMM; K > 32 negatives
+    (1000, 250, 64, 300, 8, 5),         # B * T = 2,400: a LONG bucket — un-split projections (> TCAR_PROJ_SPLIT_ROWS), small-table backward in chunks
 ]
 
 
