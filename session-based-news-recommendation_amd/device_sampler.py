@@ -197,6 +197,16 @@ class DeviceSampler:
     # batches formed per hand-off between the side stream and the consumer's stream (planned()); TCAR_FEED_CHUNK overrides (A/B)
     CHUNK = int(os.environ.get("TCAR_FEED_CHUNK", "16"))
 
+    @staticmethod
+    def chunk_bounds(n: int, ch: int):
+        """[lo, hi) of the chunks the planned batches are formed in: 2, 2, 4, 8, ... doubling up to `ch` batches (see planned)"""
+        lo, size = [0], min(2, ch)
+        while lo[-1] + size < n:
+            lo.append(lo[-1] + size)
+            if len(lo) > 2:
+                size = min(2 * size, ch)
+        return lo, lo[1:] + [n]
+
     def planned(self, K: int, gap_mode: str = "active_t"):
         """Yield the C batch descriptor of every planned batch.  The batches are formed (tcar_form_batch: session rows and
         negatives) on a side stream in CHUNKS of `CHUNK` batches, one chunk ahead of the consumer: while the consumer's steps of
@@ -217,12 +227,7 @@ class DeviceSampler:
         # host can only afford the launches of a chunk once it is that far ahead of the device — it gains ~0.1 ms per step.  (Round 4
         # formed 2 then 16 batches BEFORE the first step was enqueued: the device idled ~0.25 ms at the top of every loop, 12 us per
         # step of a 20-step run — profiles/r05_ab_experiments.txt, tools/short_form_trace.sh.)
-        lo, size = [0], min(2, ch)
-        while lo[-1] + size < n:
-            lo.append(lo[-1] + size)
-            if len(lo) > 2:
-                size = min(2 * size, ch)
-        hi = lo[1:] + [n]
+        lo, hi = self.chunk_bounds(n, ch)
         nchunk = len(lo)
 
         def launch(j):

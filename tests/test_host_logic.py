@@ -316,3 +316,16 @@ def test_built_library_has_no_packed_f32_op_with_a_low_from_high_operand_select(
                     bad.append(line.strip())
     assert not bad, bad[:5]
     assert n_pk < 400        # (what is left comes from explicit float2 arithmetic: ~120 plain v_pk_add / v_pk_mul in segsum.hip and mha.hip)
+
+
+def test_device_sampler_chunks_grow_to_the_full_size_and_tile_the_plan():
+    """DeviceSampler.planned forms the planned batches in chunks of 2, 2, 4, 8, ... up to CHUNK batches (a loop's first step waits for
+    two batches only, and the host launches a 16-batch chunk only once it is that far ahead): the chunks tile [0, n) in order, none
+    is empty or larger than CHUNK, sizes never shrink before the last chunk."""
+    from tcar_amd.device_sampler import DeviceSampler
+    for n, ch, want in ((20, 16, [2, 2, 4, 8, 4]), (200, 16, [2, 2, 4, 8] + [16] * 11 + [8]), (1, 16, [1]), (2, 16, [2]), (3, 16, [2, 1]),
+                        (5, 1, [1] * 5), (40, 4, [2, 2] + [4] * 9)):
+        lo, hi = DeviceSampler.chunk_bounds(n, ch)
+        assert [h - l for l, h in zip(lo, hi)] == want
+        assert lo[0] == 0 and hi[-1] == n and lo[1:] == hi[:-1]
+        assert all(0 < h - l <= max(ch, 1) for l, h in zip(lo, hi))
