@@ -255,6 +255,7 @@ def main():
                          "logits / HR@20 / MRR@20 gate of the north star), the two gradient GEMMs in plain bf16, fp32 "
                          "accumulation and fp32 master state throughout; bf16x3: all three GEMMs fp32-class")
     ap.add_argument("--no_by_T", action="store_true", help="skip ms_per_step_by_T (step time per input-length bucket T = 1, 2, 5, 10, 40)")
+    ap.add_argument("--by_T", type=str, default="1,2,5,10,40", help="the bucket lengths of ms_per_step_by_T")
     ap.add_argument("--launch_check", action="store_true",
                     help="only the rank launch + the three collectives of the exchanges on tiny tensors (dp.preflight): with "
                          "--backend gloo on CPU (tests/), with nccl on the GPUs; prints n_gpus and the backend / RCCL versions")
@@ -590,7 +591,7 @@ def main():
             and N <= 200000:
         by_T = {}
         rng_t = np.random.RandomState(77)
-        for T_ in (1, 2, 5, 10, 40):
+        for T_ in [int(x) for x in args.by_T.split(",") if x]:
             feeds = [eng.make_resident(bucket_batch(fold, T_, B, K, rng_t)) for _ in range(4)]
             eng._ensure_work(B, T_)
             for i in range(15):
