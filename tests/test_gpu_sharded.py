@@ -99,6 +99,12 @@ def test_single_rank_sharded_split_update_matches_the_update_inside_the_step(sco
             b.flush()                                  # (an update applied by flush: the next step has nothing pending)
             assert b._pending_lr is None
     assert a.step == b.step == e.step == len(batches)
+    # an entry point that reads the variables applies the owed update first: evaluation with an update pending
+    assert b._pending_lr is not None
+    ra, rb = a.eval_step(batches[0]), b.eval_step(batches[0])
+    assert b._pending_lr is None
+    assert float((ra[2] - rb[2]).abs().max()) <= 1e-4 * float(ra[2].abs().max())          # per-session CE
+    assert float((ra[0] != rb[0]).float().mean()) <= 0.02                                  # ranks of the labels (ties at rounding level)
     for x, y in zip(la, le):
         assert float((x - y).abs().max()) <= 1e-4 * float(x.abs().max())
     e.flush()
