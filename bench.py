@@ -587,8 +587,7 @@ def main():
     # quoted at the fold's mean length while the session-side head and tail of the step scale with B * T.  Same engine, same loop body
     # (deferred update, resident feeds of ONE length each, items drawn from the fold's popularity law), 40 timed steps after 15, best of two.
     # (Runs AFTER the roofline pass has been read out: its steps would otherwise overwrite that pass's event slots.)
-    if world == 1 and not os.environ.get("TCAR_FORCE_DP") and not args.no_by_T and not (args.no_cpu_baseline and args.no_e2e) \
-            and N <= 200000:
+    if world == 1 and not os.environ.get("TCAR_FORCE_DP") and not args.no_by_T and not args.no_kernel_timing and N <= 200000:
         by_T = {}
         rng_t = np.random.RandomState(77)
         for T_ in [int(x) for x in args.by_T.split(",") if x]:

@@ -45,7 +45,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int col, int H) {
   return make_float4(col + 0 < H ? v.x : 0.f, col + 1 < H ? v.y : 0.f, col + 2 < H ? v.z : 0.f, col + 3 < H ? v.w : 0.f);
 }
 
-template <int NCH>  // NCH = ceil(ldh/256)
+template <int NCH, bool SLABS = true>  // NCH = ceil(ldh/256); SLABS: the projections arrive as split-K slabs (else: finished rows)
 __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -78,9 +78,11 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
   // row — is ISSUED before the first is used (the slab fold was a loop of 7 + 5 dependent round trips per position: 10 us alone and
   // 24-38 us beside the Adam rest pass, whose traffic lengthens each trip); the rows of the first TC positions stay in registers for
   // the weighted sums below.  The sums keep their order: slabs in slab order, positions in position order.
-  constexpr int MS = 8, TU = (NCH == 1) ? 2 : 1, TC = (NCH == 1) ? 4 : 0;
+  // (Round 5: finished rows — the un-split projections of the long buckets — need one load per projection and position: FOUR positions
+  //  per trip there, and every loop over the positions behind the cached ones below walks them four at a time, loads first.)
+  constexpr int MS = SLABS ? 8 : 1, TU = (NCH == 1) ? (SLABS ? 2 : 4) : 1, TC = (NCH == 1) ? 4 : 0;
   float4 xa[TC > 0 ? TC : 1][NCH], xb[TC > 0 ? TC : 1][NCH], xp[TC > 0 ? TC : 1][2];
-  const int n1 = a.pre1_out ? a.n1 : 1, n2 = a.pre1_out ? a.n2 : 1;
+  const int n1 = (SLABS && a.pre1_out) ? a.n1 : 1, n2 = (SLABS && a.pre1_out) ? a.n2 : 1;
   for (int t0 = 0; t0 < T; t0 += TU) {
     float4 t1[TU][NCH][MS], t2[TU][NCH][MS], ya[TU][NCH], yb[TU][NCH], yp[TU][2];
 #pragma unroll
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
         const int col = c * 256 + lane * 4;
         if (col < ldh) {
           float4 p1 = t1[u][c][0], p2 = t2[u][c][0];
-          if (a.pre1_out) {                // split-K partial products, folded in slab order
+          if (SLABS && a.pre1_out) {       // split-K partial products, folded in slab order
 #pragma unroll
             for (int sl = 1; sl < MS; ++sl) if (sl < n1) p1 = add4(p1, t1[u][c][sl]);
             for (int sl = MS; sl < n1; ++sl) p1 = add4(p1, ld4(a.pre1 + sl * a.pre_stride + row * ldh + col));
@@ -163,16 +165,32 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
       s2 = wave_sum(s2);
       if (lane == t) e2 = s2;
     }
-    for (int t = TC; t < T; ++t) {
-      const long row = (long)b * T + t;
-      float s2 = 0.f;
+    for (int t0 = TC; t0 < T; t0 += 4) {          // four positions per trip, loads first
+      float4 ra[4][NCH], rb[4][NCH];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int col = c * 256 + lane * 4;
-        if (col < ldh) s2 += dot4(ld4(a.x_icp + row * ic + col), qa[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), qb[c]);
+      for (int u = 0; u < 4; ++u) {
+        const long row = (long)b * T + t0 + u;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          const bool ok = t0 + u < T && col < ldh;
+          ra[u][c] = ok ? ld4(a.x_icp + row * ic + col) : zero4();
+          rb[u][c] = ok ? ld4(a.x_icp + row * ic + ldh + col) : zero4();
+        }
       }
-      s2 = wave_sum(s2);
-      if (lane == t) e2 = s2;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u;
+        if (t >= T) break;
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          if (col < ldh) s2 += dot4(ra[u][c], qa[c]) + dot4(rb[u][c], qb[c]);
+        }
+        s2 = wave_sum(s2);
+        if (lane == t) e2 = s2;
+      }
     }
   }
   const bool on = lane < T;
@@ -206,21 +224,40 @@ __global__ __launch_bounds__(256) void attn_pool_fwd_kernel(const PoolArgs a) {
       if (l4 < ptl) pp[c] = fma4(xp[t][c], wt3, pp[c]);
     }
   }
-  for (int t = TC; t < T; ++t) {
-    const long row = (long)b * T + t;
-    const float wt = __shfl(a12, t), wt3 = __shfl(a3, t);
+  for (int t0 = TC; t0 < T; t0 += 4) {            // four positions per trip, loads first; the sums stay in position order
+    float4 ra[4][NCH], rb[4][NCH], rp[4][2];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const int col = c * 256 + lane * 4;
-      if (col < ldh) {
-        pa[c] = fma4(ld4(a.x_icp + row * ic + col), wt, pa[c]);
-        pb[c] = fma4(ld4(a.x_icp + row * ic + ldh + col), wt, pb[c]);
+    for (int u = 0; u < 4; ++u) {
+      const long row = (long)b * T + t0 + u;
+      const bool in = t0 + u < T;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        const bool ok = in && col < ldh;
+        ra[u][c] = ok ? ld4(a.x_icp + row * ic + col) : zero4();
+        rb[u][c] = ok ? ld4(a.x_icp + row * ic + ldh + col) : zero4();
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int l4 = c * 64 + lane;
+        rp[u][c] = (in && l4 < ptl) ? ld4(a.x_pt + row * pt + l4 * 4) : zero4();
       }
     }
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int l4 = c * 64 + lane;
-      if (l4 < ptl) pp[c] = fma4(ld4(a.x_pt + row * pt + l4 * 4), wt3, pp[c]);
+    for (int u = 0; u < 4; ++u) {
+      const int t = t0 + u;
+      if (t >= T) break;
+      const float wt = __shfl(a12, t), wt3 = __shfl(a3, t);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int col = c * 256 + lane * 4;
+        if (col < ldh) { pa[c] = fma4(ra[u][c], wt, pa[c]); pb[c] = fma4(rb[u][c], wt, pb[c]); }
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int l4 = c * 64 + lane;
+        if (l4 < ptl) pp[c] = fma4(rp[u][c], wt3, pp[c]);
+      }
     }
   }
   float* o = a.pooled + (long)b * ek;
@@ -337,22 +374,43 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
       s = wave_sum(s); s3 = wave_sum(s3);
       if (lane == t) { dal = s; dal3 = s3; }
     }
-    for (int t = TC; t < T; ++t) {
-      const long row = (long)b * T + t;
-      float s = 0.f, s3 = 0.f;
+    for (int t0 = TC; t0 < T; t0 += 4) {          // (round 5) four positions per trip, loads first
+      float4 ra[4][NCH], rb[4][NCH], rp[4][2];
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        const int col = c * 256 + lane * 4;
-        if (col < ldh)
-          s += dot4(ld4(a.x_icp + row * ic + col), da[c]) + dot4(ld4(a.x_icp + row * ic + ldh + col), db[c]);
+      for (int u = 0; u < 4; ++u) {
+        const long row = (long)b * T + t0 + u;
+        const bool in = t0 + u < T;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          const bool ok = in && col < ldh;
+          ra[u][c] = ok ? ld4(a.x_icp + row * ic + col) : zero4();
+          rb[u][c] = ok ? ld4(a.x_icp + row * ic + ldh + col) : zero4();
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int l4 = c * 64 + lane;
+          rp[u][c] = (in && l4 < ptl) ? ld4(a.x_pt + row * pt + l4 * 4) : zero4();
+        }
       }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const int l4 = c * 64 + lane;
-        if (l4 < ptl) s3 += dot4(ld4(a.x_pt + row * pt + l4 * 4), dp[c]);
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u;
+        if (t >= T) break;
+        float s = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          if (col < ldh) s += dot4(ra[u][c], da[c]) + dot4(rb[u][c], db[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int l4 = c * 64 + lane;
+          if (l4 < ptl) s3 += dot4(rp[u][c], dp[c]);
+        }
+        s = wave_sum(s); s3 = wave_sum(s3);
+        if (lane == t) { dal = s; dal3 = s3; }
       }
-      s = wave_sum(s); s3 = wave_sum(s3);
-      if (lane == t) { dal = s; dal3 = s3; }
     }
     // exp-normaliser backward: de = alpha * (dalpha - sum_s dalpha_s alpha_s)   (epsilon included exactly)
     const float de1 = a1 * (dal - wave_sum(dal * a1));
@@ -363,7 +421,9 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
     float4 dqa[NCH], dqb[NCH], gw1[NCH], gw2[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { dqa[c] = zero4(); dqb[c] = zero4(); gw1[c] = zero4(); gw2[c] = zero4(); }
-    auto pass_b = [&](int t, auto cached_) __attribute__((always_inline)) {
+    // (the rows of position t: from the register cache, or pre-loaded by the caller — pr_* — two positions at a time)
+    auto pass_b = [&](int t, auto cached_, const float4 (&pr_xa)[NCH], const float4 (&pr_xb)[NCH], const float4 (&pr_r1)[NCH],
+                      const float4 (&pr_r2)[NCH]) __attribute__((always_inline)) {
       constexpr bool CACHED = decltype(cached_)::value;
       const int tc = CACHED ? t : 0;
       const long row = (long)b * T + t;
@@ -373,14 +433,14 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
       for (int c = 0; c < NCH; ++c) {
         const int col = c * 256 + lane * 4;
         if (col < ldh) {
-          const float4 xa_ = CACHED ? xa[tc][c] : ld4(a.x_icp + row * ic + col);
-          const float4 xb_ = CACHED ? xb[tc][c] : ld4(a.x_icp + row * ic + ldh + col);
+          const float4 xa_ = CACHED ? xa[tc][c] : pr_xa[c];
+          const float4 xb_ = CACHED ? xb[tc][c] : pr_xb[c];
           st4(a.dx_icp + row * ic + col, fma4(qa[c], g2, scale4(da[c], wt)));
           st4(a.dx_icp + row * ic + ldh + col, fma4(qb[c], g2, scale4(db[c], wt)));
           dqa[c] = fma4(xa_, g2, dqa[c]);
           dqb[c] = fma4(xb_, g2, dqb[c]);
-          const float4 s1 = mask4(sig4(CACHED ? r1[tc][c] : ld4(a.pre1 + row * ldh + col)), col, H);
-          const float4 s2 = mask4(sig4(CACHED ? r2[tc][c] : ld4(a.pre2 + row * ldh + col)), col, H);
+          const float4 s1 = mask4(sig4(CACHED ? r1[tc][c] : pr_r1[c]), col, H);
+          const float4 s2 = mask4(sig4(CACHED ? r2[tc][c] : pr_r2[c]), col, H);
           gw1[c] = fma4(s1, g1, gw1[c]);
           gw2[c] = fma4(s2, g3, gw2[c]);
           // dpre = de * w * sig * (1 - sig)   (0 in padding columns: w = 0 there and sig is masked)
@@ -400,12 +460,35 @@ __global__ __launch_bounds__(256) void attn_pool_bwd_kernel(const PoolArgs a) {
         if (l4 < ptl) st4(a.dx_pt + row * pt + l4 * 4, scale4(dp[c], wt3));
       }
     };
+    {
+      float4 none[NCH];
 #pragma unroll
-    for (int t = 0; t < TC; ++t) {
-      if (t >= T) break;
-      pass_b(t, std::true_type{});
+      for (int c = 0; c < NCH; ++c) none[c] = zero4();
+#pragma unroll
+      for (int t = 0; t < TC; ++t) {
+        if (t >= T) break;
+        pass_b(t, std::true_type{}, none, none, none, none);
+      }
     }
-    for (int t = TC; t < T; ++t) pass_b(t, std::false_type{});
+    for (int t0 = TC; t0 < T; t0 += 2) {          // (round 5) two positions per trip, their four rows loaded first
+      float4 ra[2][NCH], rb[2][NCH], q1[2][NCH], q2[2][NCH];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const long row = (long)b * T + t0 + u;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int col = c * 256 + lane * 4;
+          const bool ok = t0 + u < T && col < ldh;
+          ra[u][c] = ok ? ld4(a.x_icp + row * ic + col) : zero4();
+          rb[u][c] = ok ? ld4(a.x_icp + row * ic + ldh + col) : zero4();
+          q1[u][c] = ok ? ld4(a.pre1 + row * ldh + col) : zero4();
+          q2[u][c] = ok ? ld4(a.pre2 + row * ldh + col) : zero4();
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (t0 + u < T) pass_b(t0 + u, std::false_type{}, ra[u], rb[u], q1[u], q2[u]);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int col = c * 256 + lane * 4;
@@ -451,8 +534,8 @@ extern "C" int tcar_attn_pool_fwd(const tcar_dims_t* d, int B, int T, const floa
   a.x_icp = x_icp; a.x_pt = x_pt; a.pre1 = pre1; a.pre2 = pre2; a.q = q; a.w1 = w_res1; a.w2 = w_res2;
   a.pooled = pooled; a.alpha = alpha;
   const int grid = (B + 3) / 4;
-  if (d->ldh <= 256) TCAR_LAUNCH(attn_pool_fwd_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
-  else TCAR_LAUNCH(attn_pool_fwd_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  if (d->ldh <= 256) TCAR_LAUNCH((attn_pool_fwd_kernel<1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  else TCAR_LAUNCH((attn_pool_fwd_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
