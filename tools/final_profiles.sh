@@ -23,8 +23,8 @@ traces2() {
 }
 case $1 in
   traces) traces1; traces2 ;;
-  part1)
-    $S tests
+  part1|part1_benches)
+    [ "$1" == part1 ] && $S tests
     $S bench:default "bench:default_20_5:--steps 20 --warmup 5" "bench:resident_feed:--resident_feed --no_cpu_baseline --no_e2e"
     $S "bench:adressa:--config adressa" "bench:mind:--config mind"
     $S "bench:globo_bf16x3:--scoring bf16x3 --no_cpu_baseline --no_e2e" "bench:globo_bf16:--scoring bf16 --no_cpu_baseline --no_e2e" "bench:globo_f32:--scoring f32 --no_cpu_baseline --no_e2e"
@@ -44,5 +44,5 @@ case $1 in
     bash tools/trace_T.sh; cp gpurun_out/T_timelines.txt gpurun_out/final_timelines_T7_T4_T1.txt
     $S "bench:stress10m:--config stress10m --steps 10 --warmup 2 --no_cpu_baseline --no_e2e"
     ;;
-  *) echo "usage: $0 part1|part2|traces" ;;
+  *) echo "usage: $0 part1|part1_benches|part2|traces" ;;
 esac

@@ -49,7 +49,7 @@ PY
       done; done ;;
     trace)
       envs=""; while [[ "$rest" =~ ^([A-Z_0-9]+=[^ ]*)\ ?(.*)$ ]]; do envs="$envs ${BASH_REMATCH[1]}"; rest="${BASH_REMATCH[2]}"; done
-      ( cd /tmp && export TMPDIR=/tmp $envs && timeout 400 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_${tag} -o tr -- python3 $OLDPWD/bench.py --steps 200 --warmup 20 --no_cpu_baseline --no_e2e $rest > $OLDPWD/gpurun_out/${tag}_trace.log 2>&1 )
+      ( cd /tmp && export TMPDIR=/tmp $envs && timeout 400 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_${tag} -o tr -- python3 $OLDPWD/bench.py --steps 200 --warmup 20 --no_cpu_baseline --no_e2e --no_by_T $rest > $OLDPWD/gpurun_out/${tag}_trace.log 2>&1 )
       db=$(ls gpurun_out/prof_${tag}/*/tr_results.db gpurun_out/prof_${tag}/tr_results.db 2>/dev/null | head -1)
       python tools/kstats.py $db gpurun_out/${tag}_kernel_stats.csv > gpurun_out/${tag}_kernel_stats.txt
       python tools/timeline.py $db ${TL_STEP:-100} > gpurun_out/${tag}_timeline.txt
