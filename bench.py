@@ -254,7 +254,8 @@ def main():
                          "quoted in bf16): logits from split-bf16 planes (three MFMAs per product, fp32-class: the 1e-3 "
                          "logits / HR@20 / MRR@20 gate of the north star), the two gradient GEMMs in plain bf16, fp32 "
                          "accumulation and fp32 master state throughout; bf16x3: all three GEMMs fp32-class")
-    ap.add_argument("--no_by_T", action="store_true", help="skip ms_per_step_by_T (step time per input-length bucket T = 1, 2, 5, 10, 40)")
+    ap.add_argument("--no_by_T", action="store_true", help="skip ms_per_step_by_T (step time per input-length bucket T = 1, 2, 5, 10, 40; "
+                                                             "it is also skipped by --no_kernel_timing, by TCAR_FORCE_DP and for N > 1)")
     ap.add_argument("--by_T", type=str, default="1,2,5,10,40", help="the bucket lengths of ms_per_step_by_T")
     ap.add_argument("--launch_check", action="store_true",
                     help="only the rank launch + the three collectives of the exchanges on tiny tensors (dp.preflight): with "
@@ -311,7 +312,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     dist = None
-    if world > 1:
+    # TCAR_FORCE_COLLECTIVES=1 on ONE rank: a process group of one over the chosen backend, and the data-parallel engines issue every
+    # collective of their exchange (identity results) — RCCL under the N > 1 code path on the one GPU a box has
+    force_coll = world == 1 and bool(int(os.environ.get("TCAR_FORCE_COLLECTIVES", "0") or 0))
+    if force_coll:
+        os.environ.setdefault("TCAR_FORCE_DP", "1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+    if world > 1 or force_coll:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -590,6 +597,9 @@ def main():
     if world == 1 and not os.environ.get("TCAR_FORCE_DP") and not args.no_by_T and not args.no_kernel_timing and N <= 200000:
         by_T = {}
         rng_t = np.random.RandomState(77)
+        # (its 4 x 95 steps per length train on synthetic buckets: the engine's variables and Adam state are put back afterwards, so
+        #  nothing that runs later sees a model perturbed by them — ADVICE r05)
+        state_before_by_T = eng.export_state()
         for T_ in [int(x) for x in args.by_T.split(",") if x]:
             feeds = [eng.make_resident(bucket_batch(fold, T_, B, K, rng_t)) for _ in range(4)]
             eng._ensure_work(B, T_)
@@ -609,6 +619,8 @@ def main():
             by_T[str(T_)] = round(best, 4)
             del feeds
         eng.check_forks()
+        eng.load_state(state_before_by_T)
+        del state_before_by_T
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and N <= 200000:
         from oracle.tcar_oracle import TcarOracle
@@ -731,7 +743,11 @@ def main():
                   "mind": "TCAR MIND-like fold (one click time per session, neighbour negatives)",
                   "stress10m": "synthetic 10M-item catalog"}
         out = {"metric": "sessions/sec TCAR train on Globo (synthetic %s fold)" % args.config, "value": round(value, 1),
-               "unit": "sessions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "sessions/s",
+               # what a user of main.py gets: the trainer loop over the whole fold, tail batches of every length bucket included
+               # (details under end_to_end_sessions_per_s); `value` is the loop body over full batches of B sessions
+               "trainer_loop_sessions_per_s": (e2e["value"] if e2e else None),
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": DTYPE_NOTE[args.scoring], "scoring": args.scoring, "data": "synthetic",
                "config": {"workload": "%s: N=%d items, %d-d content, B=%d/GPU, K=%d %s negatives, mean input length %.2f, "

@@ -180,7 +180,8 @@ int tcar_gather_clip_bwd(const tcar_dims_t* d, const tcar_tables_t* tab, const t
  * from S = sum gy, Q = sum ||gy||^2, D2 = sum (x.gy)^2), one add per gradient element and per norm slot.  Same values as
  * tcar_gather_clip_bwd up to rounding, bit-for-bit repeatable.  ws: tcar_small_det_ws_floats() floats (any contents: the row pieces +
  * the chunk partials of long buckets, B * T >= 2,048, where every table row's sources are cut into ~1,024-row chunks with a
- * workgroup each and one wave per row adds the chunks in order). */
+ * workgroup each and one wave per row adds the chunks in order).  d->ldt must be 64 (TCAR_E_ARG otherwise: the time / dwell /
+ * click rows are summed one 64-column group per row). */
 int tcar_small_det_ws_floats(void);
 int tcar_small_tables_bwd_det(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, const float* dx_icp,
                               const float* dx_pt, const float* dx_act, const float* dclick, const tcar_grads_t* g, float* ws,
@@ -880,7 +881,12 @@ int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_t* bt, cons
  * sessions — bt may be NULL on a rank whose shard of the batch is empty — and the packed exchange rows (tcar_shard_pack_head).
  * lr_pending >= 0 (ONE rank only: n_loc = n_items, an aux stream, the update marks): the previous step's optimizer update is still
  * owed and is applied here as the single-GPU step's split update (tcar_train_step_deferred) — arena + the item rows this batch
- * gathers first, every other row and the arena zero on the aux stream beside the session forward; < 0: nothing pending */
+ * gathers first, every other row and the arena zero on the aux stream beside the session forward; < 0: nothing pending.
+ * CROSS-CALL INVARIANT of the split update: the update marks (tcar_ctx_t.adam_bitmap) are cleared on the AUX stream behind the event
+ * this call's main stream waits for, so no event of THIS call orders the clear before a later reader.  The next reader of the marks
+ * — the next tcar_shard_begin's early pass, or tcar_step_update — runs on the main stream, which must have been joined with the aux
+ * stream in between: tcar_shard_join does that, and every step of the sharded schedule calls it (sharded.py: Pieces.scatter, also on a
+ * rank whose batch shard is empty).  A caller that sequences these pieces itself must keep that join between two begins. */
 int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int cap, int Kc, float* head, int64_t ld_head,
                      int refresh_time /* as for tcar_shard_score: with an aux stream the shard's time planes are rebuilt there */,
                      int n_loc, float lr_pending, void* stream);

@@ -100,6 +100,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not have_sources():
         raise FileNotFoundError("HIP sources missing under " + CSRC)
     want = source_build_id()
+    if os.environ.get("TCAR_LIB"):
+        # a diagnostic binary named by TCAR_LIB is only ever VERIFIED here: build() never links over it (its flags differ from
+        # SAFE_FLAGS on purpose — tools/micro/build_obs1.sh), a stale one is an error, not something to overwrite
+        if not os.path.exists(LIB_PATH) or binary_build_id() != want:
+            raise RuntimeError("TCAR_LIB=%s does not carry the digest of the sources next to it (%s): rebuild it with the script "
+                               "that made it, or unset TCAR_LIB" % (LIB_PATH, want))
+        return LIB_PATH
     if not force and os.path.exists(LIB_PATH) and binary_build_id() == want:
         return LIB_PATH
     objs = []

@@ -1525,6 +1525,9 @@ int tcar_small_tables_bwd_det_o(const tcar_dims_t* d, const tcar_tables_t* tab, 
   if (check_dims(d) || !tab || !bt || !g || !ws || bt->B <= 0 || bt->T <= 0 || bt->T > TCAR_POS_VOCAB || ws_floats < SMALL_DET_ROWS)
     return TCAR_E_ARG;
   if (!dx_icp || !dx_pt || !dx_act || !dclick || !g->g_pos || !g->g_time[0] || !g->sqn) return TCAR_E_ARG;
+  // (the time / dwell / click rows take the one-column-group path, takeS: a lane owns one of 64 columns.  A wider time hidden size
+  //  would leave columns >= 64 out of the sums — refused, not silently wrong)
+  if (d->ldt != 64) return TCAR_E_ARG;
   SmallDetArgs a{};
   a.d = *d; a.tab = *tab; a.bt = *bt;
   a.dx_icp = dx_icp; a.dx_pt = dx_pt; a.dx_act = dx_act; a.dclick = dclick;

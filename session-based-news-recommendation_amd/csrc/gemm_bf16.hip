@@ -113,7 +113,12 @@ __device__ __forceinline__ bf16x8 frag(const char* __restrict__ S, int base, int
 // TCAR_BF16_TILE = 387 / 388 / 393 / 395; tools/gemm_variants.sh): 2 = no fills after stage 1 (compute side alone), 3 = fills and
 // barriers only, 6 = epilogue only, 8 = K loop without the epilogue.  Round 4: 97.5 / 49 / 57 / 74 us of a 102-us launch — the K
 // loop runs at ~1.29 PF executed, the practical bf16 rate of the chip on random data; the epilogue was 30 us of the launch.
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1, int EPI = 0, int SEG2 = 0, int VAR = 0>
+// NST = LDS stages of the ring (round 6).  2: double buffer — the copies of stage t + 1 are issued at the top of iteration t and must
+// have landed at its end (s_waitcnt vmcnt(0) + s_barrier), so an iteration cannot be shorter than one L2 -> LDS round trip: a short
+// K loop of small stages (dE: K = 512 sessions = 16 stages of 24 KB) is paced by that latency, not by the MFMAs or the fill rate.
+// 3: the copies of stage t + 2 are issued at the top of iteration t and the wave waits only for ITS copies of stage t + 1 (counted
+// vmcnt: the copies of one stage are a wave-uniform count, the same for every stage of a K segment) — two iterations of slack per copy.
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW = 2, int TNW = 2, int KS = 1, int EPI = 0, int SEG2 = 0, int VAR = 0, int NST = 2>
 // (EPI = 2, the dE form with the (q, z) epilogue: two 9-wave workgroups per CU need five waves per SIMD, i.e. <= 96 registers per
 //  lane; without the bound the compiler takes 102 — four waves per SIMD, ONE workgroup per CU, 64 us alone.  At 80 registers, which
 //  two 12-wave workgroups would need, it spills)
@@ -134,7 +139,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   // dynamic LDS every launcher requests (launch_k / tcar_gemm_bf16_de_qz_o: 2 * KS * NP * (TM + TN) * 64).  (VERDICT r04 item 2:
   // hypothesis "a destination beyond the stage" — ruled out by construction.)
   static_assert(A_BYTES % 1024 == 0 && B_BYTES % 1024 == 0 && NCOPY * 1024 == SUB, "1-KB copies tile a sub-stage exactly");
-  static_assert(2 * STAGE == 2 * KS * NP * (TM + TN) * 64 && 2 * STAGE <= 160 * 1024, "two stages = the launch's dynamic LDS <= 160 KB");
+  static_assert(NST * STAGE == NST * KS * NP * (TM + TN) * 64 && NST * STAGE <= 160 * 1024, "NST stages = the launch's dynamic LDS <= 160 KB");
+  static_assert(NST == 2 || (NST == 3 && SEG2 == 0 && KS == 1), "the three-stage ring: one K segment, one k block per stage");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNW, wn = wave - wm * WNW;
@@ -302,6 +308,40 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   // two loops, one per K segment (the second is empty without SEG2; with it KS = 1 and there is no split-K): each has ONE body
   const int nit1 = SEG2 ? min(nit, g.K1 / KB) : nit;
   copy_setup(SEG2 && nit1 == 0, (SEG2 && nit1 == 0) ? 0 : ks);
+  if constexpr (NST == 3) {
+    // ---- three-stage ring.  ncp = this wave's copies per stage (wave-uniform; KS = 1: one sub-stage per stage).  At the end of
+    // iteration t the wave lets the ncp copies of stage t + 2 stay in flight and waits for its older ones (stage t + 1), then the
+    // barrier makes every wave's share of stage t + 1 visible AND retires buffer t % 3, which iteration t + 1 refills with stage t + 3.
+    int ncp = 0;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) ncp += (cp_dst[i] >= 0) ? 1 : 0;
+    ncp = __builtin_amdgcn_readfirstlane(ncp);
+    auto wait_keep = [&](int keep) __attribute__((always_inline)) {      // s_waitcnt vmcnt(keep), keep wave-uniform in [0, CPW]
+      static_assert(CPW <= 6, "extend wait_keep");
+      if (keep <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (CPW < 2 || keep == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else if (CPW < 3 || keep == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (CPW < 4 || keep == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (CPW < 5 || keep == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (CPW < 6 || keep == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    };
+    if (nit > 0) copy_substage(smem);
+    if (nit > 1) copy_substage(smem + STAGE);
+    wait_keep(nit > 1 ? ncp : 0);
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, fill = 2 * STAGE;         // byte offsets of the buffer being multiplied / the one refilled next (wave-uniform)
+    for (int it = 0; it < nit; ++it) {
+      const bool more = it + 2 < nit;
+      if (more) copy_substage(smem + fill);      // this buffer was last read in iteration it - 1, which ended with a barrier
+      block(smem + cur, std::false_type{});
+      wait_keep(more ? ncp : 0);           // stage it + 1 has landed for this wave (stage it + 2 may still be in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's LDS reads of the current buffer have returned
+      __builtin_amdgcn_s_barrier();
+      fill = cur;
+      cur = (cur == 2 * STAGE) ? 0 : cur + STAGE;
+    }
+  } else {
   if (nit > 0) issue(0);
   __syncthreads();                       // s_waitcnt vmcnt(0) + s_barrier: stage 0 has landed for every wave
   for (int it = 0; it < nit1; ++it) {
@@ -319,6 +359,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
       __syncthreads();
     }
   }
+  }      // NST == 2
 
   const int li = lane & 31, lh = lane >> 5;
   if constexpr (VAR == 8) {      // DIAGNOSTIC: K loop without the epilogue (the accumulators must stay live)
@@ -714,10 +755,10 @@ struct LaunchCall {
   int ce_gw = 0, ce_ngroups = 0;
 };
 
-template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW, int TNW, int KS, int VAR = 0>
+template <int MA, int MB, int NSPLIT, int WMW, int WNW, int TMW, int TNW, int KS, int VAR = 0, int NST = 2>
 int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
   constexpr int NT = 64 * WMW * WNW, TM = 32 * TMW * WMW, TN = 32 * TNW * WNW, NP = (NSPLIT == 1) ? 1 : 2;
-  constexpr size_t lds = 2 * KS * NP * (TM + TN) * 64;
+  constexpr size_t lds = NST * KS * NP * (TM + TN) * 64;
   g.mt = (g.M + TM - 1) / TM;
   g.nt = (g.N + TN - 1) / TN;
   if (lc.variant_out) {
@@ -767,8 +808,8 @@ int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
       return TCAR_E_ARG;
     }
   }
-  TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 0, 0, VAR>), lds);
-  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 0, 0, VAR>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
+  TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 0, 0, VAR, NST>), lds);
+  TCAR_LAUNCH((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 0, 0, VAR, NST>), dim3(g.mt * g.nt * splitk), dim3(NT), lds, st, g);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -780,6 +821,11 @@ int launch_v(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
   // (TCAR_BF16_KS: 1 = never, 2 = k-contiguous A operand only, 3 = always)
   if constexpr (NSPLIT == 1) {
     const int ks = tcar_tn(lc.o).bf16_ks;
+    // (TCAR_BF16_KS=4: the 256 x 128 dX tile as a three-stage ring of 32-deep stages — 72 KB instead of 96 KB of LDS, two
+    //  iterations of slack per copy instead of one)
+    if constexpr (MA == 0 && MB == 1 && WMW == 4 && WNW == 2 && TMW == 2 && TNW == 2 && VAR == 0) {
+      if (ks == 4 && !g.p_hi) return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 1, 0, 3>(g, splitk, st, lc);
+    }
     if (ks == 3 || (ks == 2 && MA == 0)) return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 2, VAR>(g, splitk, st, lc);
   }
   return launch_k<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, 1, VAR>(g, splitk, st, lc);
@@ -790,7 +836,8 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st, LaunchCall& lc) {
   // Tile choice.  The kernel is bound by the per-CU load path (~70 GB/s from L2): bytes per flop fall with the tile
   // area/perimeter ratio, so take the largest tile that still gives the chip about a full wave of workgroups:
   // 256 x 256 (16 waves, 64 KB per stage), then 256 x 128 (8 waves), else 128 x 128 (4 waves).
-  const int f = tcar_tn(lc.o).bf16_tile;
+  const int f0 = tcar_tn(lc.o).bf16_tile;
+  const int f = (f0 == 1922 || f0 == 1923 || f0 == 1283) ? 0 : f0;      // (codes of the dE (q, z) launcher only: heuristic here)
   const long w256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splitk;
   const long w128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
   if constexpr (MA == 0 && MB == 0) {
@@ -1062,6 +1109,26 @@ int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int6
     g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
     TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 2, 3, 2, 2, 1, 2, 0>), lds);
     TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 2, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 6), lds, st, g);
+  } else if (tile == 1922) {
+    // (the double-buffered 192 x 192 form, kept for A/B against the ring: TCAR_BF16_TILE=1922)
+    constexpr int TM = 192, TN = 192;
+    constexpr size_t lds = 2 * (TM + TN) * 64;
+    g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
+    TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0>), lds);
+    TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0>), dim3(g.mt * g.nt), dim3(64 * 9), lds, st, g);
+  } else if (tile == 1283) {
+    constexpr int TM = 128, TN = 192;
+    constexpr size_t lds = 3 * (TM + TN) * 64;
+    g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
+    TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 2, 3, 2, 2, 1, 2, 0, 0, 3>), lds);
+    TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 2, 3, 2, 2, 1, 2, 0, 0, 3>), dim3(g.mt * g.nt), dim3(64 * 6), lds, st, g);
+  } else if (tile == 1923) {
+    // 192 x 192, three-stage ring (72 KB: still two workgroups per CU)
+    constexpr int TM = 192, TN = 192;
+    constexpr size_t lds = 3 * (TM + TN) * 64;
+    g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;
+    TCAR_SET_LDS_ONCE((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 0, 3>), lds);
+    TCAR_LAUNCH((gemm_bf16_kernel<1, 1, 1, 3, 3, 2, 2, 1, 2, 0, 0, 3>), dim3(g.mt * g.nt), dim3(64 * 9), lds, st, g);
 #ifdef TCAR_GEMM_DIAG
   } else if (tile >= 1002 && tile <= 1008) {
     constexpr int TM = 192, TN = 192;

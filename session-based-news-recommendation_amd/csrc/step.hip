@@ -787,7 +787,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       // item block only; the time block leaves as per-candidate (||gy||^2, x . gy) pairs in the order of the inverted index
       TcarOpt ob = opt_of(c);
       RET(tcar_gemm_bf16_de_qz_o(g.N, (B + 31) & ~31, c->dl16h, g.Npad, (B + 127) & ~127, c->ap16h, g.ldh + g.pt, (B + 127) & ~127,
-                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, (tn(c).bf16_tile == 256 || tn(c).bf16_tile == 128) ? tn(c).bf16_tile : 0, sB, &ob));
+                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, (tn(c).bf16_tile == 256 || tn(c).bf16_tile == 128 || tn(c).bf16_tile == 1922 || tn(c).bf16_tile == 1923 || tn(c).bf16_tile == 1283) ? tn(c).bf16_tile : 0, sB, &ob));
     } else if (c->scoring) {
       // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
       TcarOpt ob = opt_of(c);

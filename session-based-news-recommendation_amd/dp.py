@@ -45,9 +45,16 @@ from .engine import SLOT, TcarEngine
 class GradExchange:
     """The collective schedule above, independent of where the local pieces come from."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force=None):
+        import os
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        live = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if live else 1
+        # force (TCAR_FORCE_COLLECTIVES=1): a process group of ONE rank still issues every collective (identity results) — the
+        # calls, streams and staging buffers of an N-rank job on the one GPU there is
+        if force is None:
+            force = bool(int(os.environ.get("TCAR_FORCE_COLLECTIVES", "0") or 0))
+        self.collective = live and (self.world > 1 or bool(force))
 
     def communicate(self, big: torch.Tensor, arena_pieces: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor,
                     big_done: bool = False):
@@ -55,7 +62,7 @@ class GradExchange:
         all-reduce big (1) -> all-gather ids, rows (5) -> all-reduce arena (3).  None of them depends on another one's
         result, so a caller may issue them back to back on a communication stream.  `big_done`: (1) was already issued."""
         g = self.group
-        if self.world <= 1:
+        if not self.collective:
             return ids.reshape(-1), rows.reshape(-1, rows.shape[-1])
         if not big_done:
             for part in (big if isinstance(big, (list, tuple)) else (big,)):
@@ -152,10 +159,10 @@ class DPEngine(TcarEngine):
 
     flag_forks = False   # (the gradient exchange is enqueued inside the fused backward: event forks)
 
-    def __init__(self, *a, group=None, **kw):
+    def __init__(self, *a, group=None, force_collectives=None, **kw):
         super().__init__(*a, **kw)
         self.group = group
-        self.xch = GradExchange(group)
+        self.xch = GradExchange(group, force=force_collectives)
         g = self.geo
         # step 1 in two parts, the candidate-time block FIRST: its clip backward can then run (into a scratch copy of the
         # time-table gradients) while the item block is still being reduced
@@ -231,7 +238,7 @@ class DPEngine(TcarEngine):
         driver, recorded after the dE GEMM + negative rows) so that it overlaps chain A.  Falls back to the in-line
         all-reduce when there is no aux stream / single rank."""
         self._comm_busy = False
-        if self.xch.world <= 1 or not self.big.is_cuda or not getattr(self, "_aux_ev", None):
+        if not self.xch.collective or not self.big.is_cuda or not getattr(self, "_aux_ev", None):
             return
         if not hasattr(self, "_comm"):
             self._comm = torch.cuda.Stream(self.dev)

@@ -67,13 +67,19 @@ class ShardExchange:
     gathers, so `wait_rows()` is called at the top of the next step (and by every other reader of the item table)."""
 
     def __init__(self, group=None, world: Optional[int] = None, rank: Optional[int] = None, sim: bool = False,
-                 reduce_scatter: Optional[bool] = None):
+                 reduce_scatter: Optional[bool] = None, force: Optional[bool] = None):
         live = dist.is_available() and dist.is_initialized()
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
         self.rank = rank if rank is not None else (dist.get_rank(group) if live else 0)
         self.sim = sim
-        self.backend = dist.get_backend(group) if live and self.world > 1 and not sim else "none"
+        # force (TCAR_FORCE_COLLECTIVES=1): a process group of ONE rank still issues every collective of the schedule — the code
+        # an N-rank job runs (RCCL calls, their stream, the staging copies), with identity results.  Default: a single rank
+        # short-circuits them.
+        if force is None:
+            force = bool(int(os.environ.get("TCAR_FORCE_COLLECTIVES", "0") or 0))
+        self.collective = live and not sim and (self.world > 1 or bool(force))
+        self.backend = dist.get_backend(group) if self.collective else "none"
         self.use_reduce_scatter = (self.backend == "nccl") if reduce_scatter is None else bool(reduce_scatter)
         self.bytes_moved: Dict[str, int] = {}
         self.order = []                 # names of the collectives in issue order (tests)
@@ -118,10 +124,10 @@ class ShardExchange:
 
     def allgather(self, t: torch.Tensor, key: str) -> torch.Tensor:
         """[..] -> [W, ..] (rank-major); world 1: a view"""
-        if self.world == 1:
-            return t.unsqueeze(0)
         if self.sim:
             return t.unsqueeze(0).expand((self.world,) + tuple(t.shape)).contiguous()
+        if not self.collective:
+            return t.unsqueeze(0)
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         self._timed(key, t, lambda: dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group))
         self._note(key, out)
@@ -129,7 +135,7 @@ class ShardExchange:
 
     def reduce_scatter_rows(self, full: torch.Tensor, cap: int, key: str) -> torch.Tensor:
         """sum over the ranks of full [W*cap, C]; returns this rank's rows [cap, C]"""
-        if self.world == 1 or self.sim:
+        if not self.collective:
             return full[:cap]
         self._note(key, full)
         if self.use_reduce_scatter:
@@ -140,7 +146,7 @@ class ShardExchange:
         return full[self.rank * cap:(self.rank + 1) * cap]
 
     def allreduce(self, t: torch.Tensor, key: str) -> torch.Tensor:
-        if self.world > 1 and not self.sim:
+        if self.collective:
             self._timed(key, t, lambda: dist.all_reduce(t, group=self.group))
             self._note(key, t)
         return t
@@ -148,7 +154,7 @@ class ShardExchange:
     def share_rows(self, stage: torch.Tensor, install) -> None:
         """collective 6: `stage` [W, S, ldh] holds this rank's updated rows in slot `rank`; `install(stage)` copies the gathered
         table into place once the collective has landed (wait_rows)"""
-        if self.world == 1 or self.sim:
+        if not self.collective:
             return
         mine = stage[self.rank].reshape(-1).clone()
         work = self._timed("item_rows (issue)", stage,
@@ -193,7 +199,8 @@ class ShardExchange:
 
 class ShardedEngine(TcarEngine):
     def __init__(self, params, content_emb, mwdhm, lr=1e-3, max_grad=150.0, neg_weight=0.01, device="cuda:0", group=None,
-                 scoring="bf16x3", world: Optional[int] = None, rank: Optional[int] = None, **kw):
+                 scoring="bf16x3", world: Optional[int] = None, rank: Optional[int] = None,
+                 force_collectives: Optional[bool] = None, **kw):
         if scoring == "f32":
             raise ValueError("the catalog-sharded step runs the split-bf16 scoring modes (use mode='replica' for f32)")
         self.group = group
@@ -223,8 +230,15 @@ class ShardedEngine(TcarEngine):
         self.nlpad = _ru(nl, 128)
         self.n_local_items = nl
         # the collective schedule (device-agnostic; dX is reduce-scattered where the backend can — RCCL — and all-reduced over gloo)
-        self.xch = ShardExchange(group, self.world, self.dp_rank, sim=self._sim)
+        self.xch = ShardExchange(group, self.world, self.dp_rank, sim=self._sim, force=force_collectives)
         self.backend = self.xch.backend
+        if self.xch.collective and self.tune is None and not os.environ.get("TCAR_SHARD_ALL_FLAGS"):
+            # Flag forks whose PRODUCER sits behind a collective: the gather behind the item-row all-gather of the
+            # previous update (FK_GATHER), the slab reduce and the input-gradient launch behind the dX reduce-scatter (FK_REDUCE,
+            # FK_INGRAD).  A peer whose host stalls holds those producers back for as long as it likes, and a poll gives up after
+            # 1 s — so these three fork through events whenever collectives are live; the others depend on local work only.
+            mask = int(_lib.tuning().flag_fork) & ~((1 << 3) | (1 << 4) | (1 << 6))
+            self.set_tuning(TCAR_FLAG_FORK=mask)
         self.cap = 0
         self._stage = torch.zeros(self.world, self.S, self.geo.ldh, dtype=torch.float32, device=self.dev)
         self.bytes_moved = self.xch.bytes_moved
@@ -403,6 +417,7 @@ class ShardedEngine(TcarEngine):
                 check(lib.tcar_step_dense_norms(C.byref(ctx), st), "tcar_step_dense_norms")
 
             def update(_):
+                eng.poll_fork_errors()              # a fork of this step that has already timed out: raise BEFORE the variables move
                 return eng._update_local()
 
         self.xch.step(Pieces(), cap, update)
@@ -446,7 +461,7 @@ class ShardedEngine(TcarEngine):
         g = self.geo
         check(self.lib.tcar_step_update(C.byref(self._shard_ctx()), self._lr_t(), self._stream()), "tcar_step_update")
         self._after_update()
-        if self.world == 1 or self._sim:
+        if not self.xch.collective:
             return None
         self._stage[self.dp_rank, :self.nl].copy_(self.E[self.n0:self.n0 + self.nl, :g.ldh])
 
@@ -473,7 +488,7 @@ class ShardedEngine(TcarEngine):
         """the split (deferred) update of the single-GPU step applies when this rank owns the whole table and nothing is exchanged
         behind the update: ONE rank.  With more ranks the owned rows must reach the other ranks before their next gather, so the
         update (1 / world of the table) stays inside its step."""
-        return self.world == 1 and not self._sim and self.overlap and hasattr(self, "adam_bitmap")
+        return self.world == 1 and not self._sim and not self.xch.collective and self.overlap and hasattr(self, "adam_bitmap")
 
     # ------------------------------------------------------------------------------------------- public API
     score_batch = property(lambda self: self.world * max(self.cap, 1))
@@ -561,7 +576,7 @@ class ShardedEngine(TcarEngine):
         g = self.geo
         full = torch.zeros(self.world, self.S, g.ldh, dtype=torch.float32, device=self.dev)
         full[self.dp_rank, :self.nl] = local
-        if self.world > 1 and not self._sim:
+        if self.xch.collective:
             dist.all_gather_into_tensor(full.view(-1), full[self.dp_rank].reshape(-1).clone(), group=self.group)
         item = np.zeros((g.N + 1, g.H), dtype=np.float32)
         item[1:] = full.view(-1, g.ldh)[:g.N, :g.H].cpu().numpy()

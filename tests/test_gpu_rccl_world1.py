@@ -1,0 +1,146 @@
+"""The N > 1 exchanges on RCCL — on the ONE GPU a box has.
+
+A process group of a single rank over the `nccl` backend (= RCCL), and `force_collectives=True`: both exchanges then issue every
+collective of their schedule (all_gather_into_tensor, reduce_scatter_tensor, all_reduce — async item-row all-gather included)
+instead of short-circuiting at world size 1.  With one rank every collective is the identity, so the run must reproduce the
+engines that issue none:
+
+* catalog-sharded engine (ShardExchange: six collectives per step) against the same engine without collectives and against the
+  single-GPU engine, 200 steps over batches of different lengths, flag forks live (the three slots whose producer sits behind a
+  collective fork through events — ADVICE r05), check_forks() clean;
+* replica engine (GradExchange: dense all-reduce on the communication stream beside the aux stream, sparse-row all-gather,
+  arena all-reduce) against the single-GPU engine.
+
+The child process owns the process group: the pytest process never initialises one."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CHILD = r'''
+import os, sys, json
+import numpy as np
+import torch
+import torch.distributed as dist
+ROOT = sys.argv[1]
+mode, steps = sys.argv[2], int(sys.argv[3])
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+import tcar_amd  # noqa: F401
+from tcar_amd.dp import DPEngine, preflight
+from tcar_amd.engine import TcarEngine
+from tcar_amd.sharded import ShardedEngine
+from test_gpu_parity import _case
+
+caps = preflight(dist.group.WORLD, "cuda:0", verbose=False)
+assert caps["backend"] == "nccl" and caps["world"] == 1 and caps["reduce_scatter"], caps
+N, H, Ht, B, K = 3000, 250, 64, 48, 5
+params, content, mw, b0 = _case(N, H, Ht, B, 3, K, seed=11)
+batches = [b0] + [_case(N, H, Ht, B, T, K, seed=12 + i)[3] for i, T in enumerate((1, 3, 6, 2, 9))]
+batches.append({k: v for k, v in batches[1].items() if k != "neg"})        # a step without negatives
+out = {"caps": {k: caps.get(k) for k in ("backend", "world", "rccl", "reduce_scatter")}}
+scoring = "bf16x3-mixed"
+ref = TcarEngine(params, content, mw, max_grad=2.0, scoring=scoring)
+if mode == "sharded":
+    eng = ShardedEngine(params, content, mw, max_grad=2.0, scoring=scoring, group=dist.group.WORLD, force_collectives=True)
+    plain = ShardedEngine(params, content, mw, max_grad=2.0, scoring=scoring, world=1, rank=0, force_collectives=False)
+    assert eng.xch.collective and eng.backend == "nccl" and not plain.xch.collective and not eng.can_defer
+else:
+    eng = DPEngine(params, content, mw, max_grad=2.0, scoring="bf16x3", group=dist.group.WORLD, force_collectives=True)
+    ref = TcarEngine(params, content, mw, max_grad=2.0, scoring="bf16x3")
+    plain = None
+    assert eng.xch.collective
+worst_ref = worst_plain = 0.0
+bit_equal_losses = True
+REF_STEPS = 30        # against the single-GPU engine: a different summation order, so only while Adam has not amplified the noise
+for i in range(steps):
+    bt = batches[i % len(batches)]
+    l = eng.train_step(bt).clone()
+    if i < REF_STEPS:
+        lr = ref.train_step(bt).clone()
+        worst_ref = max(worst_ref, float((l - lr).abs().max() / lr.abs().max()))
+    if i == REF_STEPS - 1:
+        pe, pr = eng.export_params(), ref.export_params()
+        for k in pr:
+            d = np.abs(pe[k] - pr[k]).max()
+            assert d <= 1e-3 * np.abs(pr[k]).max() + 0.25 * 1e-3 * REF_STEPS, (k, float(d))
+    if plain is not None:
+        lp = plain.train_step(bt).clone()
+        worst_plain = max(worst_plain, float((l - lp).abs().max() / lp.abs().max()))
+        bit_equal_losses = bit_equal_losses and bool(torch.equal(l, lp))
+    if mode == "sharded" and i == 0:
+        order = list(eng.xch.order)
+        assert order == ["attout+labels+negatives", "softmax_stats", "dX", "rows+ids", "arena", "item_rows"], order
+torch.cuda.synchronize()
+eng.check_forks()
+ref.check_forks()
+out["worst_rel_loss_vs_single_engine"] = worst_ref
+out["worst_rel_loss_vs_no_collectives"] = worst_plain
+out["losses_bit_equal_to_no_collectives"] = bit_equal_losses
+# a trajectory of `steps` Adam steps: the sharded / replica paths sum the gathered rows with float atomics, so they agree with the
+# single engine to rounding noise amplified by Adam (the bound of the two-rank tests, per step count) — and must not drift
+assert worst_ref <= 2e-2, worst_ref
+if plain is not None:
+    assert worst_plain <= 2e-2, worst_plain
+pe = eng.export_params()
+if plain is not None:
+    pp = plain.export_params()
+    out["params_bit_equal_to_no_collectives"] = bool(all(np.array_equal(pe[k], pp[k]) for k in pp))
+    worst_m = 0.0
+    for name, x, y in (("M", eng.M, plain.M), ("V", eng.V, plain.V), ("Mi", eng.Mi, plain.Mi), ("Vi", eng.Vi, plain.Vi)):
+        worst_m = max(worst_m, float((x - y).abs().max()) / float(x.abs().max()))
+        assert float((x - y).abs().max()) <= 2e-2 * float(x.abs().max()), name
+    out["worst_rel_moment_vs_no_collectives"] = worst_m
+    info = eng.exchange_info()
+    assert info["bytes_per_step"]["item_rows"] == 4 * eng.S * 256, info["bytes_per_step"]
+    assert set(info["bytes_per_step"]) == {"attout+labels+negatives", "softmax_stats", "dX", "rows+ids", "arena", "item_rows"}
+    out["bytes_per_step"] = info["bytes_per_step"]
+    assert eng._sig is not None and eng.tune is not None and (int(eng.tune.flag_fork) & ((1 << 3) | (1 << 4) | (1 << 6))) == 0
+    # the state exchange of a checkpoint is a collective too
+    st = eng.export_state()
+    assert st["m/item_emb"].shape == (N + 1, H)
+else:
+    assert eng.async_exchanges == steps, (eng.async_exchanges, steps)     # the big all-reduce ran on the communication stream
+    out["async_exchanges"] = eng.async_exchanges
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(mode, steps):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ)
+    env.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    env.pop("TCAR_FORCE_COLLECTIVES", None)
+    r = subprocess.run([sys.executable, "-c", CHILD, ROOT, mode, str(steps)], env=env, capture_output=True, text=True, timeout=280)
+    tail = (r.stdout[-3000:] + "\n--- stderr ---\n" + r.stderr[-3000:])
+    assert r.returncode == 0, tail
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, tail
+    print(line[-1])
+
+
+def test_sharded_exchange_runs_every_collective_on_rccl_at_world_one():
+    _run("sharded", 200)
+
+
+def test_replica_exchange_runs_every_collective_on_rccl_at_world_one():
+    _run("replica", 60)

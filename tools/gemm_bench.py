@@ -117,7 +117,9 @@ if os.environ.get("GB_SUM") and which.startswith("fwdce"):    # checksum of the 
     st = stats[: B * ng_ * 2].view(B, ng_, 2)
     print("checksum plane %.10e stats %.10e lab %.10e tile=%s " % (plane.double().abs().sum().item(), st.double().sum().item(),
                                                                 lab_logit.double().sum().item(), os.environ.get("TCAR_BF16_TILE", "0")), end="")
-if os.environ.get("GB_SUM") and which == "dx2":
+if os.environ.get("GB_SUM") and which in ("de2", "both2"):
+    print("checksum gi %.10e qz %.10e " % (gi.double().abs().sum().item(), qz.double().abs().sum().item()), end="")
+if os.environ.get("GB_SUM") and which in ("dx2", "both2"):
     print("checksum slabs %.10e abs %.10e " % (slabs2.double().sum().item(), slabs2.double().abs().sum().item()), end="")
 print("N=%d sk=%d " % (N, SK), end="")
 print("%s nsplit=%d: %.1f us  alg %.0f TF  executed %.0f TF" % (which, nsplit, ms * 1e3, fl / ms / 1e9, fl * (3 if nsplit == 3 else 1) / ms / 1e9))
