@@ -378,6 +378,11 @@ int tcar_ce_rescale(int B, int N, int group_width, int ngroups, const float* sta
 int tcar_gemm_bf16_dx_onehot(int M, int N1, int K, const void* A_hi, int64_t a_inner, int64_t a_rows, const void* B_hi,
                              int64_t b_inner, int64_t b_rows, const void* B2_hi, int64_t inner2, float* C, int64_t ldc, int splitk,
                              void* stream);
+/* the same with the caller's copy of the switches (TCAR_BF16_TILE = 384: the 256 x 384 tile of long contractions, whose second
+ * column tile straddles the boundary between the B and B2 planes; TCAR_BF16_KS) */
+int tcar_gemm_bf16_dx_onehot_tuned(const tcar_tuning_t* tune, int M, int N1, int K, const void* A_hi, int64_t a_inner, int64_t a_rows,
+                                   const void* B_hi, int64_t b_inner, int64_t b_rows, const void* B2_hi, int64_t inner2, float* C,
+                                   int64_t ldc, int splitk, void* stream);
 int tcar_reduce_dact_onehot(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
                             const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo, float* dP, float* bias_grad0,
                             float* bias_grad1, void* stream);
@@ -896,6 +901,16 @@ int tcar_step_dense_norms(const tcar_ctx_t* c, void* stream);
 /* orders `stream` behind the aux-stream work of the step (tcar_shard_finish, weight gradients): call before
  * tcar_scatter_add_rows_packed and the arena exchange */
 int tcar_shard_join(const tcar_ctx_t* c, void* stream);
+
+/* The catalog-sharded step of a rank that exchanges nothing (ONE rank, no live collectives), sequenced in C++: tcar_shard_begin ->
+ * _score -> _backward (stats_all = s->stats) -> _finish -> tcar_step_session_backward (dx_rows = s->dx, ce_rows = s->ce) ->
+ * tcar_shard_join -> tcar_scatter_add_rows_packed(d_cand, rows, ldr, rows_total, s->n0, c->big) -> tcar_step_dense_norms
+ * [-> tcar_step_update(sc, lr_update) when lr_update >= 0].  c: the engine's context, sc: the shard's; s->world must be 1 and
+ * s->att_all / ld_att / head_K describe `head`.  Mirrors sharded.ShardExchange.step (session-based-news-recommendation_amd/sharded.py), which
+ * stays the sequencer wherever a collective sits between the pieces. */
+int tcar_shard_step_local(const tcar_ctx_t* c, const tcar_ctx_t* sc, const tcar_shard_t* s, const tcar_batch_t* bt, int Kc, float* head,
+                          int64_t ld_head, int refresh_time, float lr_pending, float* rows, int64_t ldr, int64_t rows_total,
+                          const tcar_dims_t* d_cand, float lr_update, void* stream);
 
 /* diagnostic: capture one fused step into a hipGraph and time its replay (tools/graph_probe.py); not a training path */
 int tcar_graph_probe(const tcar_ctx_t* c, const tcar_batch_t* bt, float lr_t, int iters, float* ms_out, void* stream);

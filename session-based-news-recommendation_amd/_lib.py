@@ -25,13 +25,13 @@ NSLOT = 32
 ABI_VERSION = 27          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_ce_shard_stats", "tcar_ce_rescale", "tcar_time_onehot", "tcar_time_scores", "tcar_time_scores_clip", "tcar_attout_finish_scores", "tcar_gemm_bf16_dx_onehot", "tcar_reduce_dact_onehot", "tcar_gemm_bf16_de_qz", "tcar_cand_time_bwd_onehot", "tcar_query_mlp", "tcar_query_mlp_bwd", "tcar_flag_fork_selftest", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_ce_shard_stats", "tcar_ce_rescale", "tcar_time_onehot", "tcar_time_scores", "tcar_time_scores_clip", "tcar_attout_finish_scores", "tcar_gemm_bf16_dx_onehot", "tcar_gemm_bf16_dx_onehot_tuned", "tcar_reduce_dact_onehot", "tcar_gemm_bf16_de_qz", "tcar_cand_time_bwd_onehot", "tcar_query_mlp", "tcar_query_mlp_bwd", "tcar_flag_fork_selftest", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows", "tcar_eval_diversity",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
            "tcar_mha_core_fwd", "tcar_mha_core_bwd", "tcar_layernorm_fwd", "tcar_layernorm_bwd", "tcar_clip_adam_all", "tcar_clip_adam_early", "tcar_clip_adam_rest", "tcar_clip_adam_rest_keep", "tcar_abi_version", "tcar_build_id", "tcar_tuning_defaults", "tcar_tuning_set", "tcar_fork_state_bytes", "tcar_ctx_bytes", "tcar_flag_poll_expire", "tcar_gather_clip_fwd_tuned", "tcar_gemm_bf16_tuned", "tcar_mha_core_fwd_tuned", "tcar_mha_core_bwd_tuned", "tcar_form_batch", "tcar_segsum_ws_bytes", "tcar_segsum_index", "tcar_segsum_rows_buffer", "tcar_segsum_norms_buffer",
            "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_combine_rowstat", "tcar_softmax_grad", "tcar_neg_scatter_range",
-           "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_attn_pool_fwd_slabs", "tcar_attn_pool_bwd_slabs", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
+           "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_shard_step_local", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_attn_pool_fwd_slabs", "tcar_attn_pool_bwd_slabs", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step",
            "tcar_step_form", "tcar_step_dense_norms"]
 
@@ -382,6 +382,7 @@ def load() -> C.CDLL:
     lib.tcar_flag_poll_expire.argtypes = [vp, vp, vp]
     lib.tcar_gather_clip_fwd_tuned.argtypes = [vp] + lib.tcar_gather_clip_fwd.argtypes
     lib.tcar_gemm_bf16_tuned.argtypes = [vp] + lib.tcar_gemm_bf16.argtypes
+    lib.tcar_gemm_bf16_dx_onehot_tuned.argtypes = [vp] + lib.tcar_gemm_bf16_dx_onehot.argtypes
     lib.tcar_mha_core_fwd_tuned.argtypes = [vp] + lib.tcar_mha_core_fwd.argtypes
     lib.tcar_mha_core_bwd_tuned.argtypes = [vp] + lib.tcar_mha_core_bwd.argtypes
     lib.tcar_step_session_forward.argtypes = [P(Ctx), P(Batch), vp]
@@ -392,6 +393,7 @@ def load() -> C.CDLL:
     lib.tcar_step_dense_norms.argtypes = [P(Ctx), vp]
     lib.tcar_shard_begin.argtypes = [P(Ctx), P(Batch), i32, i32, vp, i64, i32, i32, f32, vp]
     lib.tcar_shard_join.argtypes = [P(Ctx), vp]
+    lib.tcar_shard_step_local.argtypes = [P(Ctx), P(Ctx), P(Shard), P(Batch), i32, vp, i64, i32, f32, vp, i64, i64, P(Dims), f32, vp]
     lib.tcar_shard_pack_head.argtypes = [i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, i64, vp]
     lib.tcar_shard_unpack_head.argtypes = [i32, i32, i32, vp, i64, vp, vp, vp, vp]
     lib.tcar_shard_pack_ids.argtypes = [i64, i64, i32, vp, vp, i64, i32, vp, vp, f32, vp, vp]

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   if (g.n_fastest) { tm = id / g.nt; tn = id - tm * g.nt; } else { tn = id / g.mt; tm = id - tn * g.mt; }
   const int m0 = tm * TM, n0 = tn * TN;
   // (workgroup-uniform) this N tile reads the second B plane: dX columns of the one-hot time block
-  const bool b2tile = (SEG2 == 0 && NSPLIT == 1) && g.n_b2 > 0 && n0 >= g.n_b2;
+  const bool b2any = (SEG2 == 0 && NSPLIT == 1 && MB == 1) && g.n_b2 > 0 && n0 + TN > g.n_b2;
   // (wave-uniform, EPI = 2) this wave's 64 output columns are one table's block of the candidate-side time gradient: the two
   // operand roles are SWAPPED for it — fragments of the B tile go in as the MFMA's first operand — so that its accumulators come
   // out transposed (a lane owns one catalog row, its registers run over the 64 columns) and the row reductions of the epilogue
@@ -218,10 +218,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
       const bool isA = rem < A_CP;
       const int ci = isA ? rem : rem - A_CP;
       if (SEG2 && seg2 && !isA && p == 1) continue;    // the second segment's B operand has ONE plane
-      const __bf16* P = (SEG2 && seg2) ? (isA ? g.A2[p] : g.B2) : (isA ? g.A[p] : (b2tile ? g.B2 : g.B[p]));
-      const int in32 = (SEG2 && seg2) ? (isA ? g.a2_in32 : g.b2_in32) : (isA ? g.a_in32 : (b2tile ? g.b2_in32 : g.b_in32));
+      // (one-hot dX: the B operand of output columns >= n_b2 is the plane B2.  Decided per COPY — a copy of this layout is one
+      //  32-column block — so a tile may straddle n_b2: the 384-column tiles of the large-catalog form, n_b2 = 512)
+      const bool b2copy = b2any && !isA && (n0 + (ci >> 1) * 32 >= g.n_b2);
+      const __bf16* P = (SEG2 && seg2) ? (isA ? g.A2[p] : g.B2) : (isA ? g.A[p] : (b2copy ? g.B2 : g.B[p]));
+      const int in32 = (SEG2 && seg2) ? (isA ? g.a2_in32 : g.b2_in32) : (isA ? g.a_in32 : (b2copy ? g.b2_in32 : g.b_in32));
       const int nrb = (SEG2 && seg2) ? (isA ? g.a2_rb : g.b2_rb) : (isA ? g.a_rb : g.b_rb);
-      const int mode = isA ? MA : MB, t0 = isA ? m0 : (b2tile ? n0 - g.n_b2 : n0);
+      const int mode = isA ? MA : MB, t0 = isA ? m0 : (b2copy ? n0 - g.n_b2 : n0);
       long src;
       bool ok;
       if (mode == 0) {          // k-contiguous: 8 copies per 8-KB block (rows t0.., inner block k0/32)
@@ -837,7 +840,7 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st, LaunchCall& lc) {
   // area/perimeter ratio, so take the largest tile that still gives the chip about a full wave of workgroups:
   // 256 x 256 (16 waves, 64 KB per stage), then 256 x 128 (8 waves), else 128 x 128 (4 waves).
   const int f0 = tcar_tn(lc.o).bf16_tile;
-  const int f = (f0 == 1922 || f0 == 1923 || f0 == 1283) ? 0 : f0;      // (codes of the dE (q, z) launcher only: heuristic here)
+  const int f = (f0 == 1922 || f0 == 1923 || f0 == 1283 || f0 == 2562) ? 0 : f0;      // (codes of the dE (q, z) launcher only: heuristic here)
   const long w256 = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * splitk;
   const long w128 = (long)((g.M + 255) / 256) * ((g.N + 127) / 128) * splitk;
   if constexpr (MA == 0 && MB == 0) {
@@ -864,6 +867,13 @@ int launch_b(BArgs& g, int nsplit, int splitk, hipStream_t st, LaunchCall& lc) {
     if (nsplit == 1 && f == 1006) return launch_v<0, 1, 1, 8, 2, 2, 2, 6>(g, splitk, st, lc);
     if (nsplit == 1 && f == 1008) return launch_v<0, 1, 1, 8, 2, 2, 2, 8>(g, splitk, st, lc);
 #endif
+    // 256 x 384 (8 waves of 4 x 3 MFMA tiles, the logits GEMM's shape; hi planes only): 44 % fewer fill bytes per flop than 256 x 128.
+    // Its 4 output tiles need a split-K of ~64 to fill the chip, i.e. 64 slabs of [M, N] fp32 — 3.5 x the slab bytes of the default
+    // form: right where the contraction is long enough for the slabs not to matter (K = catalog rows >= 2^20: the 10 M-item
+    // configuration), wrong at the Globo catalog (85 MB of slabs against 25)
+    const long w384 = (long)((g.M + 255) / 256) * ((g.N + 383) / 384) * splitk;
+    if (nsplit == 1 && (f == 384 || (f == 0 && g.K >= (1 << 20) && w384 >= 192)))
+      return launch_v<0, 1, 1, 2, 4, 4, 3>(g, splitk, st, lc);
     if (f == 512 || (f == 0 && g.M > 256 && w512 >= 192))
       return nsplit == 3 ? launch_v<0, 1, 3, 8, 2>(g, splitk, st, lc) : launch_v<0, 1, 1, 8, 2>(g, splitk, st, lc);
   }
@@ -1065,6 +1075,14 @@ extern "C" int tcar_gemm_bf16_dx_onehot(int M, int N1, int K, const void* A_hi, 
   return tcar_gemm_bf16_dx_onehot_o(M, N1, K, A_hi, a_inner, a_rows, B_hi, b_inner, b_rows, B2_hi, inner2, C, ldc, splitk, stream, nullptr);
 }
 
+extern "C" int tcar_gemm_bf16_dx_onehot_tuned(const tcar_tuning_t* tune, int M, int N1, int K, const void* A_hi, int64_t a_inner,
+                                              int64_t a_rows, const void* B_hi, int64_t b_inner, int64_t b_rows, const void* B2_hi,
+                                              int64_t inner2, float* C, int64_t ldc, int splitk, void* stream) {
+  TcarOpt o;
+  o.tune = tune;
+  return tcar_gemm_bf16_dx_onehot_o(M, N1, K, A_hi, a_inner, a_rows, B_hi, b_inner, b_rows, B2_hi, inner2, C, ldc, splitk, stream, &o);
+}
+
 // dE' = dlogits^T [attout_item | attout_time] with the (q, z) epilogue: the item block [M, ldh] goes to C as in tcar_gemm_bf16
 // (layout 2); the time block [M, 5 * 64] is NOT stored — per catalog row n and table k: qz[perm[k M + n]] = (||gy||^2, x . gy) with
 // gy = the 64-column gradient block and x = tclip row the candidate looks up.  A plane = dlogits [K rows = sessions, inner >= M],
@@ -1089,7 +1107,7 @@ int tcar_gemm_bf16_de_qz_o(int M, int K, const void* A_hi, int64_t a_inner, int6
   g.mwdhm = mwdhm; g.tclip = tclip; g.qz = (float2*)qz;
   hipStream_t st = (hipStream_t)stream;
   (void)o;
-  if (tile == 256) {
+  if (tile == 256 || tile == 2562) {
     constexpr int TM = 256, TN = 192;
     constexpr size_t lds = 2 * (TM + TN) * 64;
     g.mt = (M + TM - 1) / TM; g.nt = (N + TN - 1) / TN;

@@ -787,7 +787,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       // item block only; the time block leaves as per-candidate (||gy||^2, x . gy) pairs in the order of the inverted index
       TcarOpt ob = opt_of(c);
       RET(tcar_gemm_bf16_de_qz_o(g.N, (B + 31) & ~31, c->dl16h, g.Npad, (B + 127) & ~127, c->ap16h, g.ldh + g.pt, (B + 127) & ~127,
-                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, (tn(c).bf16_tile == 256 || tn(c).bf16_tile == 128 || tn(c).bf16_tile == 1922 || tn(c).bf16_tile == 1923 || tn(c).bf16_tile == 1283) ? tn(c).bf16_tile : 0, sB, &ob));
+                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, (tn(c).bf16_tile == 256 || tn(c).bf16_tile == 128 || tn(c).bf16_tile == 1922 || tn(c).bf16_tile == 1923 || tn(c).bf16_tile == 1283 || tn(c).bf16_tile == 2562) ? tn(c).bf16_tile : 0, sB, &ob));
     } else if (c->scoring) {
       // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
       TcarOpt ob = opt_of(c);
@@ -1532,6 +1532,30 @@ extern "C" int tcar_step_dense_norms(const tcar_ctx_t* c, void* stream) {
   TcarOpt o = opt_of(c);
   if (c->fold_scratch) { o.scratch = c->fold_scratch; o.scratch_words = c->fold_scratch_words; }
   return tcar_sqnorm_o(c->Gx, &c->segs_dense, c->sqn_dense, stream, &o);
+}
+
+// The whole catalog-sharded step of a rank that exchanges nothing (ONE rank without a live process group: every all-gather is a
+// view, the reduce-scatter keeps the only slice), sequenced here instead of piece by piece from Python (round 6: nine ctypes calls,
+// their argument marshalling and the tensor views between them were ~0.2 ms of host time per step).  Same pieces, same order, same
+// streams as ShardExchange.step drives them: begin -> score -> backward -> finish -> session backward -> join -> scatter of the
+// packed rows -> dense norms [-> update].  sc = the shard's context (tcar_shard_score / _backward / _finish / tcar_step_update);
+// s->att_all / ld_att / head_K must already point at `head`.  lr_update < 0: no update inside the step (the caller defers it).
+extern "C" int tcar_shard_step_local(const tcar_ctx_t* c, const tcar_ctx_t* sc, const tcar_shard_t* s, const tcar_batch_t* bt, int Kc,
+                                     float* head, int64_t ld_head, int refresh_time, float lr_pending, float* rows, int64_t ldr,
+                                     int64_t rows_total, const tcar_dims_t* d_cand, float lr_update, void* stream) {
+  if (!c || !sc || !s || !bt || !head || !rows || !d_cand || s->world != 1 || s->att_all != head || s->ld_att != ld_head) return TCAR_E_ARG;
+  const int K = (bt->K > 0 && bt->neg) ? bt->K : 0;
+  if (s->head_K != K) return TCAR_E_ARG;
+  RET(tcar_shard_begin(c, bt, s->cap, Kc, head, ld_head, refresh_time, s->n_loc, lr_pending, stream));
+  RET(tcar_shard_score(sc, s, refresh_time, stream));
+  RET(tcar_shard_backward(sc, s, s->stats, stream));
+  RET(tcar_shard_finish(sc, s, K, K ? s->neg_all : nullptr, K ? s->coef_all : nullptr, stream));
+  RET(tcar_step_session_backward(c, bt, s->dx, rows, ldr, rows_total, s->ce, stream));
+  RET(tcar_shard_join(c, stream));
+  RET(tcar_scatter_add_rows_packed(d_cand, rows, ldr, rows_total, s->n0, c->big, stream));
+  RET(tcar_step_dense_norms(c, stream));
+  if (lr_update >= 0.f) RET(tcar_step_update(sc, lr_update, stream));
+  return TCAR_OK;
 }
 
 // Diagnostic (tools/graph_probe.py): capture ONE fused training step (all three streams) into a hipGraph, replay it `iters`

@@ -197,6 +197,94 @@ class ShardExchange:
                 self.share_rows(*out)
 
 
+class _Pieces:
+    """The local compute between the exchanges of ShardExchange.step, bound to the C entry points of csrc/step.hip.  ONE object per
+    engine, re-armed per step (a class statement and eight closures per step were host time the step cannot hide behind)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+
+    def arm(self, bt, cap, K, nr, ldr, refresh, lr_pending, ctx, sctx, sh):
+        e = self.eng
+        self.bt, self.cap, self.K, self.nr, self.ldr, self.refresh, self.lr_pending = bt, cap, K, nr, ldr, refresh, lr_pending
+        self.ctx, self.sctx, self.sh, self.st = ctx, sctx, sh, e._stream()
+        self.B = bt.B if bt is not None else 0
+        self.Bq = e.world * cap
+        self.has_neg = K > 0
+
+    # zero the arena, session forward, ONE packed row per session: [attout (ek) | label | coefficient of the negative
+    # term | K negatives | pad], ints as bits, row stride ld_head (tcar_shard_begin packs, tcar_shard_score unpacks)
+    def begin(self):
+        e, bt = self.eng, self.bt
+        head = e.head_loc[:self.cap]
+        check(e.lib.tcar_shard_begin(C.byref(self.ctx), C.byref(bt) if bt is not None else None, self.cap, e._kcap, e._p(head),
+                                     e.ld_head, self.refresh, e.nl, self.lr_pending, self.st), "tcar_shard_begin")
+        return head
+
+    # scoring of the shard against every session + softmax statistics of the shard
+    def score(self, head_all):
+        e, sh = self.eng, self.sh
+        sh.att_all, sh.ld_att, sh.head_K = head_all.data_ptr(), e.ld_head, (self.K if self.has_neg else 0)
+        self._head_all = head_all
+        tk = e._tick3(0)
+        check(e.lib.tcar_shard_score(C.byref(self.sctx), C.byref(sh), self.refresh, self.st), "tcar_shard_score")
+        e._tock3(tk)
+        if self.refresh:        # (the one-hot schedule issues no refresh: the planes stay dirty for the next op-level reader)
+            e._time_dirty = False
+        return e.s_stats[:self.Bq]
+
+    # lse, dlogits planes, dE of the shard (aux stream, stays here), dX partial (goes home)
+    def backward(self, stats_all):
+        e = self.eng
+        self._stats_all = stats_all
+        tk = e._tick3(1)
+        check(e.lib.tcar_shard_backward(C.byref(self.sctx), C.byref(self.sh), e._p(stats_all), self.st), "tcar_shard_backward")
+        e._tock3(tk)
+        return e.s_dx[:self.Bq]
+
+    # negative rows, shard norm, candidate-time backward: on the aux stream behind dE, beside the dX exchange and the
+    # session backward (tcar_shard_join orders the main stream behind them)
+    def finish(self):
+        e = self.eng
+        check(e.lib.tcar_shard_finish(C.byref(self.sctx), C.byref(self.sh), self.K if self.has_neg else 0,
+                                      e._p(e.s_neg) if self.has_neg else None, e._p(e.s_coef) if self.has_neg else None, self.st),
+              "tcar_shard_finish")
+
+    # session backward (local) -> packed rows [row (ldh) | id | pad]
+    def session_backward(self, dx_rows):
+        e, bt = self.eng, self.bt
+        rows = e._rows_buf[:self.nr]
+        if bt is not None:
+            if not dx_rows.is_contiguous():
+                dx_rows = dx_rows.contiguous()
+            ce_rows = e.s_ce[e.dp_rank * self.cap:e.dp_rank * self.cap + self.B]
+            check(e.lib.tcar_step_session_backward(C.byref(self.ctx), C.byref(bt), e._p(dx_rows), e._p(rows), self.ldr, self.nr,
+                                                   e._p(ce_rows), self.st), "tcar_step_session_backward")
+        else:
+            rows.zero_()                    # an empty rank contributes padding rows only (id 0, zero payload)
+        return rows
+
+    # ids are 1-based: the rows of this shard become 1 .. nl, the rest (and the id-0 padding) fall out
+    def scatter(self, all_rows):
+        e = self.eng
+        check(e.lib.tcar_shard_join(C.byref(self.ctx), self.st), "tcar_shard_join")
+        check(e.lib.tcar_scatter_add_rows_packed(C.byref(e.dims_cand), e._p(all_rows), self.ldr, all_rows.shape[0], e.n0, e._p(e.Gi),
+                                                 self.st), "tcar_scatter_add_rows_packed")
+
+    # arena gradients + norm pieces incl. the shards' dense item norms
+    def arena(self):
+        return self.eng.Gx
+
+    # dense-weight norms, summed in a fixed order (one workgroup per variable): identical gradients give identical
+    # norms on every rank, the replicas stay bit-identical without a broadcast
+    def norms(self):
+        check(self.eng.lib.tcar_step_dense_norms(C.byref(self.ctx), self.st), "tcar_step_dense_norms")
+
+    def update(self):
+        self.eng.poll_fork_errors()              # a fork of this step that has already timed out: raise BEFORE the variables move
+        return self.eng._update_local()
+
+
 class ShardedEngine(TcarEngine):
     def __init__(self, params, content_emb, mwdhm, lr=1e-3, max_grad=150.0, neg_weight=0.01, device="cuda:0", group=None,
                  scoring="bf16x3", world: Optional[int] = None, rank: Optional[int] = None,
@@ -330,97 +418,46 @@ class ShardedEngine(TcarEngine):
     def _step(self, bt: Optional[Batch], cap: int, K: int, update: bool, T: int, lr_pending: float = -1.0):
         """one training step; bt = None: a rank whose shard of the global batch is empty still joins every collective (T is
         the step's input length: the row buffers of the exchanges have the same shape on every rank).  The collectives are
-        ShardExchange.step; the pieces between them are the C entry points of csrc/step.hip.  lr_pending >= 0 (one rank): the
-        previous step's update is owed and rides in tcar_shard_begin as the split update of the single-GPU step."""
-        g, lib, p = self.geo, self.lib, self._p
-        W, n0, nl = self.world, self.n0, self.nl
+        ShardExchange.step; the pieces between them are the C entry points of csrc/step.hip (`_Pieces`).  lr_pending >= 0 (one
+        rank): the previous step's update is owed and rides in tcar_shard_begin as the split update of the single-GPU step.
+        A rank that exchanges nothing (one rank, no live collectives) makes ONE call: tcar_shard_step_local sequences the same
+        pieces in C++ (round 6: the Python sequencing was ~0.2 ms of host time per step)."""
+        g = self.geo
         B = bt.B if bt is not None else 0
         cap = max(cap, B, 1)
-        Bq = W * cap
         self.xch.wait_rows()                       # the previous update's rows, before anything reads the item table
         self._ensure_work(max(B, 1), T)
         self._ensure_score(cap, K)
-        has_neg = K > 0
-        st = self._stream()
-        ctx, sctx = self._ctx(), self._shard_ctx()
-        sh = self._shard_desc(cap)
-        ldh_ = self.ld_head
-        # (the one-hot schedule reads the shard's time planes nowhere; eval_step rebuilds the fp32 time columns itself)
-        refresh = 0 if self.onehot else int(self._time_dirty)
         nr = cap * T
         ldr = g.ldh + 4
         if getattr(self, "_rows_cap", 0) < nr:
             self._rows_buf = torch.zeros(nr, ldr, dtype=torch.float32, device=self.dev)
             self._rows_cap = nr
-        eng = self
-
-        class Pieces:
-            # zero the arena, session forward, ONE packed row per session: [attout (ek) | label | coefficient of the negative
-            # term | K negatives | pad], ints as bits, row stride ld_head (tcar_shard_begin packs, tcar_shard_score unpacks)
-            def begin(_):
-                head = eng.head_loc[:cap]
-                check(lib.tcar_shard_begin(C.byref(ctx), C.byref(bt) if bt is not None else None, cap, eng._kcap, p(head), ldh_,
-                                           refresh, nl, lr_pending, st), "tcar_shard_begin")
-                return head
-
-            # scoring of the shard against every session + softmax statistics of the shard
-            def score(_, head_all):
-                sh.att_all, sh.ld_att, sh.head_K = head_all.data_ptr(), ldh_, (K if has_neg else 0)
-                _._head_all = head_all
-                tk = eng._tick3(0)
-                check(lib.tcar_shard_score(C.byref(sctx), C.byref(sh), refresh, st), "tcar_shard_score")
-                eng._tock3(tk)
-                if refresh:        # (the one-hot schedule issues no refresh: the planes stay dirty for the next op-level reader)
-                    eng._time_dirty = False
-                return eng.s_stats[:Bq]
-
-            # lse, dlogits planes, dE of the shard (aux stream, stays here), dX partial (goes home)
-            def backward(_, stats_all):
-                _._stats_all = stats_all
-                tk = eng._tick3(1)
-                check(lib.tcar_shard_backward(C.byref(sctx), C.byref(sh), p(stats_all), st), "tcar_shard_backward")
-                eng._tock3(tk)
-                return eng.s_dx[:Bq]
-
-            # negative rows, shard norm, candidate-time backward: on the aux stream behind dE, beside the dX exchange and the
-            # session backward (tcar_shard_join orders the main stream behind them)
-            def finish(_):
-                check(lib.tcar_shard_finish(C.byref(sctx), C.byref(sh), K if has_neg else 0, p(eng.s_neg) if has_neg else None,
-                                            p(eng.s_coef) if has_neg else None, st), "tcar_shard_finish")
-
-            # session backward (local) -> packed rows [row (ldh) | id | pad]
-            def session_backward(_, dx_rows):
-                rows = eng._rows_buf[:nr]
-                if bt is not None:
-                    if not dx_rows.is_contiguous():
-                        dx_rows = dx_rows.contiguous()
-                    ce_rows = eng.s_ce[eng.dp_rank * cap:eng.dp_rank * cap + B]
-                    check(lib.tcar_step_session_backward(C.byref(ctx), C.byref(bt), p(dx_rows), p(rows), ldr, nr, p(ce_rows), st),
-                          "tcar_step_session_backward")
-                else:
-                    rows.zero_()                    # an empty rank contributes padding rows only (id 0, zero payload)
-                return rows
-
-            # ids are 1-based: the rows of this shard become 1 .. nl, the rest (and the id-0 padding) fall out
-            def scatter(_, all_rows):
-                check(lib.tcar_shard_join(C.byref(ctx), st), "tcar_shard_join")
-                check(lib.tcar_scatter_add_rows_packed(C.byref(eng.dims_cand), p(all_rows), ldr, all_rows.shape[0], n0, p(eng.Gi),
-                                                       st), "tcar_scatter_add_rows_packed")
-
-            # arena gradients + norm pieces incl. the shards' dense item norms
-            def arena(_):
-                return eng.Gx
-
-            # dense-weight norms, summed in a fixed order (one workgroup per variable): identical gradients give identical
-            # norms on every rank, the replicas stay bit-identical without a broadcast
-            def norms(_):
-                check(lib.tcar_step_dense_norms(C.byref(ctx), st), "tcar_step_dense_norms")
-
-            def update(_):
-                eng.poll_fork_errors()              # a fork of this step that has already timed out: raise BEFORE the variables move
-                return eng._update_local()
-
-        self.xch.step(Pieces(), cap, update)
+        # (the one-hot schedule reads the shard's time planes nowhere; eval_step rebuilds the fp32 time columns itself)
+        refresh = 0 if self.onehot else int(self._time_dirty)
+        ctx, sctx = self._ctx(), self._shard_ctx()
+        sh = self._shard_desc(cap)
+        if (bt is not None and not self.xch.collective and not self._sim and self.world == 1 and getattr(self, "_tm", None) is None
+                and not os.environ.get("TCAR_SHARD_PY_STEP")):
+            sh.att_all, sh.ld_att, sh.head_K = self.head_loc.data_ptr(), self.ld_head, K
+            lr_u = -1.0
+            if update:
+                self.poll_fork_errors()
+                lr_u = self._lr_t()
+            check(self.lib.tcar_shard_step_local(C.byref(ctx), C.byref(sctx), C.byref(sh), C.byref(bt), self._kcap,
+                                                 C.c_void_p(self.head_loc.data_ptr()), self.ld_head, refresh, lr_pending,
+                                                 C.c_void_p(self._rows_buf.data_ptr()), ldr, nr, C.byref(self.dims_cand), lr_u,
+                                                 self._stream()), "tcar_shard_step_local")
+            if refresh:
+                self._time_dirty = False
+            if update:
+                self._after_update()
+            return
+        pc = getattr(self, "_pieces", None)
+        if pc is None:
+            pc = self._pieces = _Pieces(self)
+        pc.arm(bt, cap, K, nr, ldr, refresh, lr_pending, ctx, sctx, sh)
+        self.xch.step(pc, cap, update)
 
     def _shard_desc(self, cap: int) -> "_lib.Shard":
         key = (cap, self.s_dl16h.data_ptr())

@@ -1695,7 +1695,10 @@ def _bf(x):
     return torch.tensor(np.asarray(x, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
 
 
-@pytest.mark.parametrize("N,B,tile", [(3000, 100, 0), (46033, 512, 0), (46033, 512, 256), (46033, 512, 128), (5754, 600, 64), (700, 33, 0)])
+# (tile: the dE launcher's code — 0 / 256 / 128 / 64 = row tiles of the double-buffered form; 1923 / 1283 = the three-stage LDS ring
+#  of round 6 on 192- / 128-row tiles, 1922 / 2562 = the double-buffered 192- / 256-row tiles under their A/B codes)
+@pytest.mark.parametrize("N,B,tile", [(3000, 100, 0), (46033, 512, 0), (46033, 512, 256), (46033, 512, 128), (5754, 600, 64), (700, 33, 0),
+                                      (46033, 512, 1923), (3000, 100, 1923), (5754, 600, 1283), (46033, 512, 2562), (700, 33, 1922)])
 def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
     """The one-hot form of the two scoring GRADIENT GEMMs (round 4) at op level, through the C-ABI, against fp64 numpy on the
     bf16-rounded operands AND against the materialised form it replaces:
@@ -1759,6 +1762,19 @@ def test_onehot_gradient_gemms_and_candidate_time_backward(lib, N, B, tile):
     got = slabs.sum(0).cpu().numpy()
     close(got[:, :ic], dlb @ Eb[:, :ic], rtol=1e-3, atol_scale=1e-5, name="dX item|content columns")
     close(got[:, ic:ic + 139], want_dp[:, :139], rtol=1e-3, atol_scale=1e-5, name="dP = dlogits OH")
+    # the other tile shapes of this GEMM through the caller's switch copy: 256 x 384 (round 6, long contractions: its second column
+    # tile takes columns 384..511 from the E plane and 512..671 from the one-hot plane), 512 x 128, and the three-stage ring of
+    # 32-deep stages on the default tile (TCAR_BF16_KS = 4) — the same sums up to the order of the k blocks
+    for sw in (dict(TCAR_BF16_TILE=384), dict(TCAR_BF16_TILE=512), dict(TCAR_BF16_KS=4), dict(TCAR_BF16_TILE=384, TCAR_BF16_KS=1)):
+        tune = _lib.tuning(**sw)
+        slabs_v = torch.full((S, B, ic + 160), 7.0, device=dev)
+        assert lib.tcar_gemm_bf16_dx_onehot_tuned(C.byref(tune), B, ic, Npad, ptr2(dlh), dl_in, B, ptr2(eh), e_in, Npad, ptr2(oh), 160,
+                                                  ptr(slabs_v), ic + 160, splitk, None) == 0
+        got_v = slabs_v.sum(0).cpu().numpy()
+        close(got_v[:, :ic], dlb @ Eb[:, :ic], rtol=1e-3, atol_scale=1e-5, name="dX item|content columns %r" % sw)
+        close(got_v[:, ic:ic + 139], want_dp[:, :139], rtol=1e-3, atol_scale=1e-5, name="dP = dlogits OH %r" % sw)
+        if sw == dict(TCAR_BF16_KS=4):      # same tile, same k order inside a slab: the ring changes WHEN a stage lands, not what is summed
+            assert torch.equal(slabs_v, slabs)
     negpart = (rng.standard_normal((B, ic)) * 0.01).astype(np.float32)
     dattout, dP = torch.full((B, ek), 7.0, device=dev), torch.full((B, 160), 7.0, device=dev)
     assert lib.tcar_reduce_dact_onehot(ptr(slabs), S, B, ic, ic + 160, ptr(T(negpart)), ic, ptr(d_att), ek, ptr(tclip), ptr(dattout),
