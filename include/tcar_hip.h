@@ -42,49 +42,32 @@ extern "C" {
 /* Diagnostic tuning switches.  The process-wide values are the shipped defaults overridden by the TCAR_* environment
  * variables of the same names, read ONCE per process and immutable afterwards (README.md).  A caller that wants other values
  * for ONE context (tcar_ctx_t.tune) or ONE call (the *_tuned entry points) passes its own copy: the library keeps no
- * mutable switch state.  Field <-> variable: lower-case name without the TCAR_ prefix, except gather_wg_per_cu = TCAR_GATHER_WG. */
+ * mutable switch state.  Field <-> variable: lower-case name without the TCAR_ prefix.  Twelve switches (round 6; the eleven others of
+ * round 5 — rest-pass grid, softmax variant, gather workgroups, small-GEMM ring, projection / output-transform splits, fork delay,
+ * in-kernel waits, fused query backward, fused column sums, 16x16x32 logits — had settled A/Bs and are constants of the build now). */
 typedef struct {
-  int32_t bf16_tile;        /* TCAR_BF16_TILE      force a workgroup tile of the bf16 GEMM (0 = heuristic; tests pin every tile shape with it) */
-  int32_t rest_grid;        /* TCAR_REST_GRID      grid cap of the deferred Adam rest pass */
-  int32_t softmax_variant;  /* TCAR_SOFTMAX_VARIANT */
+  int32_t bf16_tile;        /* TCAR_BF16_TILE      force a workgroup tile of the bf16 GEMMs (0 = heuristic; tests pin every tile shape with it): 128 / 192 / 193 /
+                                                   256 / 384 / 512 = tiles of tcar_gemm_bf16 and the one-hot dX; 1922 / 1923 / 1283 / 2562 = codes of the dE (q, z)
+                                                   launcher only (192-row double buffer / 192-row three-stage ring / 128-row ring / 256-row double buffer) */
+  int32_t bf16_ks;          /* TCAR_BF16_KS        LDS stages of the hi-only bf16 GEMM: 1 = 32-deep double buffer, 2 = 64-deep for the dX / logits layouts (default),
+                                                   3 = 64-deep everywhere, 4 = three-stage ring of 32-deep stages for the 256 x 128 dX tile (round 6) */
   int32_t wgrad_ks;         /* TCAR_WGRAD_KS       K chunk of the weight-gradient split */
   int32_t gather_big_rows;  /* TCAR_GATHER_BIG_ROWS  session rows from which the forward gather runs its throughput form */
-  int32_t gather_wg_per_cu; /* TCAR_GATHER_WG      1024-thread workgroups per CU of that form (2 x 78 KB of LDS fit) */
   int32_t mha_mfma;         /* TCAR_MHA_MFMA       0: multihead_attention core always in its scalar form */
   int32_t sort_scatter;     /* TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum */
-  int32_t bf16_ks;          /* TCAR_BF16_KS        64-deep LDS stages of the hi-only bf16 GEMM: 1 never, 2 dX / logits layouts, 3 all */
   int32_t det_small;        /* TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode) */
-  int32_t x3_oneshot;       /* TCAR_X3_ONESHOT     n: small-GEMM launches of at most max(n, 2) 64-deep stages per workgroup keep two stages in flight; 0: one */
   int32_t fused_ce;         /* TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel */
   int32_t onehot_time;      /* TCAR_ONEHOT_TIME    0: the scoring GEMMs of a training step contract the 5 ldt clipped candidate time columns instead of the 160-column one-hot form */
-  int32_t proj_split;       /* TCAR_PROJ_SPLIT     0: the session-side projections / output-transform input gradients as un-split GEMMs */
-  int32_t fork_delay;       /* TCAR_FORK_DELAY     us a DELAYED flag fork holds its consumer back behind the producer's end (step.hip) */
-  int32_t inkernel_wait;    /* TCAR_INKERNEL_WAIT  MASK: kernels that can wait for a producer's flag themselves do, instead of sitting behind a
-                                                   polling kernel / an event — 1: attention pools (click query), 2: slab reduce (negative
-                                                   term), 4: candidate-side time gradients (dP).  Default 0: no bit measured faster
-                                                   (profiles/r04_ab_experiments.txt) */
-  int32_t qbwd_fused;       /* TCAR_QBWD_FUSED     the click-query MLP's input gradients: 0 = two small GEMMs (dq1 in the main chain's grouped
-                                                   launch, dclick in front of the small tables); 1 = ONE launch on the third stream
-                                                   (tcar_query_mlp_bwd; measured slower); 2 (default) = dq1 as in 0, dclick by the layer-1
-                                                   half of tcar_query_mlp_bwd on the aux stream */
-  int32_t attout_split;     /* TCAR_ATTOUT_SPLIT   0: the two output transforms as one un-split grouped GEMM with bias + tanh + plane epilogue and a
-                                                   separate time-score launch, instead of split-K slabs finished (+ scored) by
-                                                   tcar_attout_finish_scores */
-  int32_t colsum_fused;     /* TCAR_COLSUM_FUSED   1 (default): the order-fixed column sums (bias / residual-weight gradients) and the dense-weight
-                                                   norms of a fused step in ONE launch instead of two — the end of the step's last chain */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
                                                    kernel of the side stream waits for */
   int32_t ce_fold;          /* TCAR_CE_FOLD        w > 0 (default 1024): tcar_ce_finish as ONE launch of about w workgroups — each folds the (max, sum)
                                                    pairs of its own 16 session rows, then rescales its slice of the plane — instead of a combine
                                                    launch + a rescale launch (0); the same bits either way */
-  int32_t logits_mfma16;    /* TCAR_LOGITS_MFMA16  1: the softmax-epilogue logits GEMM (256 x 384 tile) on v_mfma_f32_16x16x32_bf16 instead of
-                                                   32x32x16 — same tile, staging, products and epilogue contract; results differ by fp32 rounding
-                                                   of the k sums only */
-  int32_t proj_split_rows;  /* TCAR_PROJ_SPLIT_ROWS  the session-side projections take their split-K slab form (TCAR_PROJ_SPLIT) only for
-                                                   batches of at most this many rows B * T: the form trades one global round trip per workgroup
-                                                   for 12 slabs of [B*T, ldh] fp32 that the pool kernel folds — right for the latency-bound short
-                                                   buckets, 5 .. 17 % slower per step from T = 5 up (profiles/r05_ab_experiments.txt) */
+  int32_t proj_split_rows;  /* TCAR_PROJ_SPLIT_ROWS  the session-side projections take their split-K slab form only for batches of at most this many
+                                                   rows B * T: the form trades one global round trip per workgroup for 12 slabs of [B*T, ldh] fp32 that
+                                                   the pool kernel folds — right for the latency-bound short buckets, 5 .. 17 % slower per step from
+                                                   T = 5 up (profiles/r05_ab_experiments.txt) */
 } tcar_tuning_t;
 /* *out = the process-wide values (shipped defaults + TCAR_* environment) */
 int tcar_tuning_defaults(tcar_tuning_t* out /*host*/);
@@ -693,7 +676,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
                         const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 27
+#define TCAR_ABI_VERSION 28
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */

@@ -22,7 +22,7 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 27          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 28          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
            "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_ce_shard_stats", "tcar_ce_rescale", "tcar_time_onehot", "tcar_time_scores", "tcar_time_scores_clip", "tcar_attout_finish_scores", "tcar_gemm_bf16_dx_onehot", "tcar_gemm_bf16_dx_onehot_tuned", "tcar_reduce_dact_onehot", "tcar_gemm_bf16_de_qz", "tcar_cand_time_bwd_onehot", "tcar_query_mlp", "tcar_query_mlp_bwd", "tcar_flag_fork_selftest", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
@@ -226,9 +226,8 @@ class Ctx(C.Structure):
                    ("small_det_ws", C.c_void_p), ("small_det_ws_floats", C.c_int64)])
 
 
-TUNING_FIELDS = ["bf16_tile", "rest_grid", "softmax_variant", "wgrad_ks", "gather_big_rows", "gather_wg_per_cu", "mha_mfma",
-                 "sort_scatter", "bf16_ks", "det_small", "x3_oneshot", "fused_ce", "onehot_time", "proj_split", "fork_delay",
-                 "inkernel_wait", "qbwd_fused", "attout_split", "colsum_fused", "flag_fork", "ce_fold", "logits_mfma16", "proj_split_rows"]
+TUNING_FIELDS = ["bf16_tile", "bf16_ks", "wgrad_ks", "gather_big_rows", "mha_mfma", "sort_scatter", "det_small", "fused_ce", "onehot_time",
+                 "flag_fork", "ce_fold", "proj_split_rows"]
 
 
 class Tuning(C.Structure):

@@ -166,8 +166,8 @@ __device__ __forceinline__ void st4_nt(float* p, float4 v) {
   __builtin_nontemporal_store(x, reinterpret_cast<v4f_e*>(p));
 }
 
-// R: consecutive session rows per wave and trip; PLAIN: plain stores instead of non-temporal ones (tools/gather_sweep.sh measures the
-// forms; the launcher's default is the fastest)
+// R: consecutive session rows per wave and trip; PLAIN: plain stores instead of non-temporal ones (round 5 measured R = 1 / 4 / 8 and
+// plain stores slower than the defaults: profiles/r05_ab_experiments.txt)
 template <int NCH, int R = 2, bool PLAIN = false>
 __global__ __launch_bounds__(1024) void gather_clip_fwd_big_kernel(const EmbArgs a) {
   auto st_out = [](float* p, float4 v) { if (PLAIN) st4(p, v); else st4_nt(p, v); };
@@ -1309,24 +1309,13 @@ int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const
     // throughput form: one 16-wave workgroup per CU (the clipped small tables live in its LDS)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    // (TCAR_GATHER_WG = workgroups per CU + 16 * form.  Form 0 = shipped: TWO consecutive rows per wave and trip, non-temporal stores —
-    //  round 5, tools/gather_sweep.sh: 0.680-0.717 ms at 655,360 rows against 0.702-0.728 for four rows, five interleaved rounds.
-    //  Forms 1-4 stay for that sweep: 1 plain stores, 2 eight rows, 3 four rows (the shipped form until round 4), 4 one row)
-    const int wgpc = tn.gather_wg_per_cu & 15, form = tn.gather_wg_per_cu >> 4;
-    const int rpw = form == 2 ? 8 : form == 3 ? 4 : form == 4 ? 1 : form == 1 ? 4 : 2;
+    // (TWO consecutive rows per wave and trip, non-temporal stores, two workgroups per CU — round 5, tools/gather_bench.py: 0.680-0.717 ms
+    //  at 655,360 rows against 0.702-0.728 for four rows; eight rows, one row, plain stores and one workgroup per CU all measured slower)
+    const int rpw = 2;
     long g = (rows + 16 * rpw - 1) / (16 * rpw);
-    const long cap = (long)cus * (wgpc > 0 ? wgpc : 1);
+    const long cap = (long)cus * tcar_fixed::gather_wg;
     if (g > cap) g = cap;
-    if (d->ldh <= 256 && form >= 1 && form <= 4) {
-      if (form == 1) { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 4, true>), 160 * 1024);
-        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 4, true>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
-      else if (form == 2) { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 8, false>), 160 * 1024);
-        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 8, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
-      else if (form == 3) { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 4, false>), 160 * 1024);
-        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 4, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
-      else { TCAR_SET_LDS_ONCE((gather_clip_fwd_big_kernel<1, 1, false>), 160 * 1024);
-        TCAR_LAUNCH((gather_clip_fwd_big_kernel<1, 1, false>), dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a); }
-    } else if (d->ldh <= 256) {
+    if (d->ldh <= 256) {
       TCAR_SET_LDS_ONCE(gather_clip_fwd_big_kernel<1>, 160 * 1024);
       TCAR_LAUNCH(gather_clip_fwd_big_kernel<1>, dim3((int)g), dim3(1024), big_lds, (hipStream_t)stream, a);
     } else {

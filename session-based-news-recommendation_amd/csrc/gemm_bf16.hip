@@ -514,206 +514,9 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
     }
 }
 
-// ---- the logits GEMM with its softmax epilogue on v_mfma_f32_16x16x32_bf16 (round 5; TCAR_LOGITS_MFMA16) ------------------------------
-// Same workgroup tile (256 sessions x 384 catalog columns, 8 waves of 128 x 96), same staging (LDS-DMA, two stages of 32-deep k
-// blocks), same arithmetic per product (b_hi a_lo + b_lo a_hi + b_hi a_hi), same epilogue CONTRACT as gemm_bf16_kernel<0, 0, 3, 2, 4,
-// 4, 3, 1, 1, SEG2> — on the 16 x 16 x 32 instruction: at equal cycles per flop the chip holds a higher clock on it under load
-// (MI355X_MICROARCH.md, DVFS give-back item 7: 1.12-1.15 x the flop/s of the 32 x 32 x 16 loop on LDS-fed operands).
-//   * MFMA operands swapped as in the 32 x 32 form (first = catalog fragment, second = session fragment): a lane owns ONE session
-//     (column lane & 15 of the 16 x 16 tile) and, per tile, the four catalog rows 4 (lane >> 4) .. + 3.
-//   * catalog fragments are read PAIR-PERMUTED: of a 32-column pair of tiles (T = 0, 1), MFMA row i of tile T takes catalog column
-//     8 (i >> 2) + 4 T + (i & 3), so that a lane's 4 + 4 registers of the pair are the EIGHT consecutive columns 8 (lane >> 4) ..
-//     + 7 — one 16-byte store, and a wave instruction stores 16 sessions x 64 bytes = 1 KB contiguous of the KB32 plane;
-//   * session fragments take session sigma(lane & 15) with sigma = swap of bits 1 and 2: with the plain order the 16-lane groups
-//     of ds_read_b128 meet two-way bank conflicts on the swizzled 64-byte-row image, with sigma (and with the pair permutation)
-//     every group hits 16 distinct 16-byte slots (checked exhaustively: DESIGN.md §4).
-//   * per 32-deep k block a wave multiplies 8 session tiles x 6 catalog tiles: the session fragments of FOUR tiles (2 planes x 4 x
-//     4 registers) stay in registers while the six catalog tiles stream through, twice per block — 40 ds_read_b128 per wave and
-//     block instead of 28 (the LDS array is 10-17 % busy in this kernel), 192 accumulator + 40 fragment registers as before.
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-__device__ __forceinline__ int sess_sigma(int i) { return (i & 9) | ((i & 2) << 1) | ((i & 4) >> 1); }
-__device__ __forceinline__ bf16x8 frag16_sess(const char* __restrict__ S, int base, int lane) {
-  const int rr = base + sess_sigma(lane & 15);
-  const int piece = (lane >> 4) ^ ((rr >> 2) & 3);
-  return *reinterpret_cast<const bf16x8*>(S + rr * 64 + piece * 16);
-}
-__device__ __forceinline__ bf16x8 frag16_cat(const char* __restrict__ S, int base32, int T, int lane) {
-  const int i = lane & 15;
-  const int rr = base32 + ((i >> 2) << 3) + (T << 2) + (i & 3);
-  const int piece = (lane >> 4) ^ ((rr >> 2) & 3);
-  return *reinterpret_cast<const bf16x8*>(S + rr * 64 + piece * 16);
-}
-
-template <int SEG2>
-__global__ __launch_bounds__(512, 1) void gemm_bf16_ce16_kernel(const BArgs g) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NW = 8, WNW = 4, TM = 256, TN = 384, NP = 2;
-  constexpr int A_BYTES = TM * 64, B_BYTES = TN * 64, PL = A_BYTES + B_BYTES, SUB = NP * PL, STAGE = SUB;
-  constexpr int A_CP = A_BYTES / 1024, B_CP = B_BYTES / 1024, NCOPY = NP * (A_CP + B_CP), CPW = (NCOPY + NW - 1) / NW;
-  static_assert(NCOPY * 1024 == SUB && 2 * STAGE == 160 * 1024, "two stages of 1-KB copies = the launch's 160 KB of dynamic LDS");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WNW, wn = wave - wm * WNW;
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-  int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  const int tn = id / g.mt, tm = id - tn * g.mt;              // M fastest: the workgroups sharing an E tile are neighbours on one XCD
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int nkb = g.K / KB;
-  const int nit = nkb, nit1 = SEG2 ? min(nit, g.K1 / KB) : nit;
-
-  f32x4 acc[8][6];
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-#pragma unroll
-    for (int t = 0; t < 6; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // ---- DMA copies: as gemm_bf16_kernel (k-contiguous operands only: the next k block is the next 8-KB block)
-  const __bf16* cp_src[CPW];
-  int cp_dst[CPW];
-  auto copy_setup = [&](bool seg2, int k0) {
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-      const int c = wave + NW * i;
-      cp_dst[i] = -1; cp_src[i] = g.A[0];
-      if (NCOPY % NW != 0 && c >= NCOPY) continue;
-      const int p = c / (A_CP + B_CP), rem = c - p * (A_CP + B_CP);
-      const bool isA = rem < A_CP;
-      const int ci = isA ? rem : rem - A_CP;
-      if (SEG2 && seg2 && !isA && p == 1) continue;    // the second segment's B operand has ONE plane
-      const __bf16* P = (SEG2 && seg2) ? (isA ? g.A2[p] : g.B2) : (isA ? g.A[p] : g.B[p]);
-      const int in32 = (SEG2 && seg2) ? (isA ? g.a2_in32 : g.b2_in32) : (isA ? g.a_in32 : g.b_in32);
-      const int nrb = (SEG2 && seg2) ? (isA ? g.a2_rb : g.b2_rb) : (isA ? g.a_rb : g.b_rb);
-      const int t0 = isA ? m0 : n0;
-      const int rb = (t0 >> 7) + (ci >> 3);
-      if (rb < nrb) {
-        cp_src[i] = P + ((long)rb * in32 + (k0 >> 5)) * 4096 + (ci & 7) * 512;
-        cp_dst[i] = p * PL + (isA ? 0 : A_BYTES) + ci * 1024;
-      }
-    }
-  };
-  auto issue = [&](int t) {
-    char* St = smem + (t & 1) * STAGE;
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-      if (cp_dst[i] >= 0) __builtin_amdgcn_global_load_lds((glb_vp)(cp_src[i] + lane * 8), (lds_vp)(St + cp_dst[i]), 16, 0, 0);
-      cp_src[i] += 4096;
-    }
-  };
-  // the MFMAs of one 32-deep k block; S2: second K segment (B has no lo plane: two MFMAs per product)
-  auto block = [&](const char* St, auto s2) __attribute__((always_inline)) {
-    constexpr bool S2 = decltype(s2)::value;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      // (no fragment of the other half may be hoisted above this point: 192 accumulator registers leave room for ONE half's eight)
-      __builtin_amdgcn_sched_barrier(0);
-      bf16x8 a[NP][4];
-#pragma unroll
-      for (int p = 0; p < NP; ++p)
-#pragma unroll
-        for (int uu = 0; uu < 4; ++uu) a[p][uu] = frag16_sess(St + p * PL, wm * 128 + (4 * h + uu) * 16, lane);
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const bf16x8 b0 = frag16_cat(St + A_BYTES, wn * 96 + (t >> 1) * 32, t & 1, lane);
-        bf16x8 b1 = b0;
-        if constexpr (!S2) b1 = frag16_cat(St + PL + A_BYTES, wn * 96 + (t >> 1) * 32, t & 1, lane);
-#pragma unroll
-        for (int uu = 0; uu < 4; ++uu) {
-          f32x4 c = acc[4 * h + uu][t];
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[1][uu], c, 0, 0, 0);
-          if constexpr (!S2) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a[0][uu], c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, a[0][uu], c, 0, 0, 0);
-          acc[4 * h + uu][t] = c;
-        }
-      }
-    }
-  };
-
-  copy_setup(SEG2 && nit1 == 0, 0);
-  if (nit > 0) issue(0);
-  __syncthreads();
-  for (int it = 0; it < nit1; ++it) {
-    if (it + 1 < nit) {
-      if (SEG2 && it + 1 == nit1) copy_setup(true, 0);
-      issue(it + 1);
-    }
-    block(smem + (it & 1) * STAGE, std::false_type{});
-    __syncthreads();
-  }
-  if constexpr (SEG2 != 0) {
-    for (int it = nit1; it < nit; ++it) {
-      if (it + 1 < nit) issue(it + 1);
-      block(smem + (it & 1) * STAGE, std::true_type{});
-      __syncthreads();
-    }
-  }
-
-  // ---- softmax epilogue (the contract of gemm_bf16_kernel's EPI = 1): per session and 96-column group (max, sum of exp(x - max)),
-  // the exponentials as bf16 in the KB32 plane, the label's score
-  constexpr int GW = 96;
-  constexpr float LOG2E = 1.4426950408889634f;
-  const int g4 = lane >> 4;
-  const int gidx = (n0 + wn * GW) / GW;
-  const int nb0 = n0 + wn * GW;
-  const int pcols = g.p_in32 << 5;
-  const bool interior = (m0 + TM <= g.M) && (n0 + TN <= g.N) && (n0 + TN <= pcols);
-  auto x16 = [](float x, auto op) __attribute__((always_inline)) {          // op over the lanes l ^ 16
-    const auto rr = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return op(__uint_as_float(rr[0]), __uint_as_float(rr[1]));
-  };
-  auto x32 = [](float x, auto op) __attribute__((always_inline)) {          // ... l ^ 32
-    const auto rr = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return op(__uint_as_float(rr[0]), __uint_as_float(rr[1]));
-  };
-  auto fmx = [](float a, float b) { return fmaxf(a, b); };
-  auto fad = [](float a, float b) { return a + b; };
-  auto epi = [&](auto fast_) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(fast_)::value;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int row = m0 + wm * 128 + u * 16 + sess_sigma(lane & 15);
-      const bool live = FAST || row < g.M;
-      float mx = -INFINITY;
-#pragma unroll
-      for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (FAST || nb0 + (t >> 1) * 32 + 8 * g4 + 4 * (t & 1) + e < g.N) mx = fmaxf(mx, acc[u][t][e]);
-      mx = x32(x16(mx, fmx), fmx);
-      const int lraw = live ? g.label[row] - g.lab_off : -1;
-      const int lab = !live ? -1 : g.lab_window ? ((lraw >= 0 && lraw < g.N) ? lraw : -1) : clampi(lraw, 0, g.N - 1);
-      const int d = lab - nb0;                          // the label among the group's 96 columns: pair d >> 5, lane group (d & 31) >> 3
-      const bool has_lab = lab >= 0 && d >= 0 && d < GW && ((d & 31) >> 3) == g4;
-      if (__any(has_lab)) {
-        float labv = 0.f;
-#pragma unroll
-        for (int t = 0; t < 6; ++t)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) labv = ((t >> 1) * 32 + 8 * g4 + 4 * (t & 1) + e == d) ? acc[u][t][e] : labv;
-        if (has_lab) g.lab_logit[row] = labv;
-      }
-      const float c = -mx * LOG2E;
-      float sum = 0.f;
-#pragma unroll
-      for (int pr = 0; pr < 3; ++pr) {
-        const int n8 = nb0 + 32 * pr + 8 * g4;
-        bf16x8 pk;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float pe = (FAST || n8 + j < g.N) ? __builtin_amdgcn_exp2f(fmaf(acc[u][2 * pr + (j >> 2)][j & 3], LOG2E, c)) : 0.f;
-          sum += pe;
-          pk[j] = (__bf16)pe;
-        }
-        if (live && (FAST || n8 < pcols)) *reinterpret_cast<bf16x8*>(g.p_hi + kb32_off(row, n8, g.p_in32)) = pk;
-      }
-      sum = x32(x16(sum, fad), fad);
-      if (live && g4 == 0) *reinterpret_cast<float2*>(g.stats + ((long)row * g.ngroups + gidx) * 2) = make_float2(mx, sum);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  if (interior) epi(std::true_type{}); else epi(std::false_type{});
-  tcar_signal_done(g.sig);
-}
+// (Round 5 built this GEMM on v_mfma_f32_16x16x32_bf16 as well — same tile, pair-permuted catalog fragments, 16-byte plane stores —
+// and measured it 2-4 us SLOWER in the step: 40 instead of 28 fragment reads per k block.  Removed in round 6; the kernel and its
+// measurements are in git history (2c5f4a0) and profiles/r05_ab_experiments.txt.)
 
 // fp32 [rows, cols] (ld) -> bf16 hi / lo planes in the KB32 layout with inner dimension in16 (>= cols, % 32 == 0);
 // rows [rows, ceil128(rows)) and columns [cols, in16) are zero filled.  Optional second, PACKED output pair taking
@@ -778,21 +581,6 @@ int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
       g.sig = tcar_sig(lc.o);
       g.lab_off = lc.o ? lc.o->lab_off : 0;
       g.lab_window = lc.o ? lc.o->lab_window : 0;
-      // (TCAR_LOGITS_MFMA16: the 16 x 16 x 32 form of the 256 x 384 logits tile — same tile, same outputs up to fp32 rounding of the
-      //  k sums)
-      if constexpr (NSPLIT == 3 && KS == 1 && WMW == 2 && WNW == 4 && TMW == 4 && TNW == 3 && VAR == 0) {
-        if (tcar_tn(lc.o).logits_mfma16 && (g.K & 31) == 0 && (!g.B2 || (g.K1 & 31) == 0)) {
-          if (g.B2) {
-            TCAR_SET_LDS_ONCE((gemm_bf16_ce16_kernel<1>), lds);
-            TCAR_LAUNCH((gemm_bf16_ce16_kernel<1>), dim3(g.mt * g.nt), dim3(NT), lds, st, g);
-          } else {
-            TCAR_SET_LDS_ONCE((gemm_bf16_ce16_kernel<0>), lds);
-            TCAR_LAUNCH((gemm_bf16_ce16_kernel<0>), dim3(g.mt * g.nt), dim3(NT), lds, st, g);
-          }
-          TCAR_CHECK_LAUNCH();
-          return TCAR_OK;
-        }
-      }
       if (g.B2) {
         if constexpr (NSPLIT == 3 && KS == 1) {
           TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1, VAR>), lds);

@@ -565,9 +565,8 @@ int launch_x3(GroupArgs& ga, hipStream_t st, TcarOpt* o) {
     for (int sg = 0; sg < p.nseg; ++sg) n += ((p.K[sg] < p.kchunk ? p.K[sg] : p.kchunk) + 63) / 64;
     max_stages = n > max_stages ? n : max_stages;
   }
-  // (TCAR_X3_ONESHOT = n > 1: the ring of 2 for every launch of at most n stages per workgroup)
-  const int os = tcar_tn(o).x3_oneshot;
-  if (os && max_stages <= (os > 2 ? os : 2)) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st, o);
+  // (the ring of 2 for every launch of at most tcar_fixed::x3_oneshot stages per workgroup)
+  if (max_stages <= tcar_fixed::x3_oneshot) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st, o);
   return launch_x3_v<LA, LB, 64, 1>(ga, wg, st, o);
 }
 

@@ -632,7 +632,7 @@ extern "C" int tcar_clip_adam_rest_keep(float* w2d, int64_t ldw, const float* g2
                                    const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
                                    void* e16_hi, void* e16_lo, int64_t ld16, uint32_t* bitmap, void* stream) {
   return tcar_clip_adam_rest_keep_o(w2d, ldw, g2d, m2d, v2d, rows, cols, slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t, b1, b2,
-                                    eps, e16_hi, e16_lo, ld16, bitmap, stream, tcar_tuning().rest_grid);
+                                    eps, e16_hi, e16_lo, ld16, bitmap, stream, tcar_fixed::rest_grid);
 }
 int tcar_clip_adam_rest_keep_o(float* w2d, int64_t ldw, const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols,
                                int32_t slot, const float* sqn_dense, const float* sqn_pieces, const int32_t* use_dense, float clip,

@@ -1059,21 +1059,15 @@ extern "C" int tcar_softmax_ce(int B, int N, float* logits, int64_t ld, const in
 
 extern "C" int tcar_softmax_ce_bf16(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce,
                                     void* dl_hi, void* dl_lo, void* stream) {
-  return tcar_softmax_ce_bf16_o(B, N, logits, ld, label, ce, dl_hi, dl_lo, stream, tcar_tuning().softmax_variant);
+  return tcar_softmax_ce_bf16_o(B, N, logits, ld, label, ce, dl_hi, dl_lo, stream);
 }
 int tcar_softmax_ce_bf16_o(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* dl_hi, void* dl_lo,
-                           void* stream, int variant) {
+                           void* stream) {
   if (B <= 0) return TCAR_OK;
   if (N <= 0 || ld < N || (ld & 3) || !tcar_aligned16(logits) || !label || !ce || (dl_hi && (ld & 31)) || (dl_lo && !dl_hi))
     return TCAR_E_ARG;
   const int grid = dl_hi ? ((B + 127) & ~127) : B;
-  if (variant == 2 && ld <= 1024L * 4 * 12) {
-    TCAR_LAUNCH((softmax_ce_rows_kernel<1024, 12>), dim3(grid), dim3(1024), 0, (hipStream_t)stream, B, N, logits, (long)ld,
-                label, ce, (__bf16*)dl_hi, (__bf16*)dl_lo);
-    TCAR_CHECK_LAUNCH();
-    return TCAR_OK;
-  }
-  if (variant && ld <= 512L * 4 * 24) {      // the row fits the register-resident variant (catalogs up to 49,152 items)
+  if (ld <= 512L * 4 * 24) {      // the row fits the register-resident variant (catalogs up to 49,152 items)
     if (ld <= 512L * 4 * 8)
       TCAR_LAUNCH((softmax_ce_rows_kernel<512, 8>), dim3(grid), dim3(512), 0, (hipStream_t)stream, B, N, logits, (long)ld,
                   label, ce, (__bf16*)dl_hi, (__bf16*)dl_lo);

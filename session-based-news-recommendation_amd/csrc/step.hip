@@ -13,19 +13,14 @@ static int env_int(const char* name, int dflt) {
 namespace {
 struct Switch { const char* name; int32_t TcarTuning::*field; int dflt; };
 const Switch kSwitches[] = {
-    {"TCAR_BF16_TILE", &TcarTuning::bf16_tile, 0},          {"TCAR_REST_GRID", &TcarTuning::rest_grid, 512},
-    {"TCAR_SOFTMAX_VARIANT", &TcarTuning::softmax_variant, 1}, {"TCAR_WGRAD_KS", &TcarTuning::wgrad_ks, 1536},
-    {"TCAR_GATHER_BIG_ROWS", &TcarTuning::gather_big_rows, 16384}, {"TCAR_GATHER_WG", &TcarTuning::gather_wg_per_cu, 2},
+    {"TCAR_BF16_TILE", &TcarTuning::bf16_tile, 0},          {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},
+    {"TCAR_WGRAD_KS", &TcarTuning::wgrad_ks, 1536},         {"TCAR_GATHER_BIG_ROWS", &TcarTuning::gather_big_rows, 16384},
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
-    {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},              {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},
-    {"TCAR_X3_ONESHOT", &TcarTuning::x3_oneshot, 4},        {"TCAR_PROJ_SPLIT", &TcarTuning::proj_split, 1},
-    {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},            {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},
-    {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},           {"TCAR_FORK_DELAY", &TcarTuning::fork_delay, 7},
-    {"TCAR_INKERNEL_WAIT", &TcarTuning::inkernel_wait, 0},   {"TCAR_QBWD_FUSED", &TcarTuning::qbwd_fused, 2},
-    {"TCAR_ATTOUT_SPLIT", &TcarTuning::attout_split, 1},  {"TCAR_COLSUM_FUSED", &TcarTuning::colsum_fused, 1},
-    {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},           {"TCAR_LOGITS_MFMA16", &TcarTuning::logits_mfma16, 0},
-    {"TCAR_PROJ_SPLIT_ROWS", &TcarTuning::proj_split_rows, 1024},
+    {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},          {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
+    {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},      {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},
+    {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},           {"TCAR_PROJ_SPLIT_ROWS", &TcarTuning::proj_split_rows, 1024},
 };
+static_assert(sizeof(kSwitches) / sizeof(kSwitches[0]) == 12 && sizeof(TcarTuning) == 12 * sizeof(int32_t), "twelve switches, one table");
 }  // namespace
 // the process snapshot: written once by the initialiser of this function-local static, const ever after
 const TcarTuning& tcar_tuning() {
@@ -179,8 +174,9 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
 // profiles/r03_ab_experiments.txt).  The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits
 // GEMM writes, and held back TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main
 // stream records nothing.
-enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_NEG = 8, FK_LOGITS = 9,
-       FK_POOLB = 10, FK_QBWD = 11 };
+// (slots 8, 10 and 11 — negative term -> slab reduce, pool backward -> fused click-query backward and its join — were retired in round 6
+//  with the forms that used them; the numbering of the others, which TCAR_FLAG_FORK masks, is unchanged)
+enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_LOGITS = 9 };
 // (a thirteenth slot, softmax gradient -> dE's stream with the plane stored write-through, measured +17 .. +21 us in rounds 3 and 4: removed)
 // host-side fork state of ONE context (tcar_ctx_t.fork_host: caller-owned, zeroed, tcar_fork_state_bytes() bytes)
 struct ForkSlot { TcarSignal sig; uint32_t live; uint32_t pad; };     // live: the launch armed last for this slot carries sig
@@ -375,7 +371,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   // kernel folds the slabs in slab order while it reads them (one writer per element: order-fixed)
   const int n1 = units(g.ic) + units(g.ldh) + units(g.ldt), n2 = units(g.pt) + units(g.ldh);
   const int64_t stride = (int64_t)BT * g.ldh;
-  const bool split = c->scoring && tn(c).proj_split && c->proj_slabs && c->proj_slab_floats >= (n1 + n2) * stride;
+  const bool split = c->scoring && c->proj_slabs && c->proj_slab_floats >= (n1 + n2) * stride;
   // (the slab form of the PROJECTIONS only up to TCAR_PROJ_SPLIT_ROWS rows: from there the launch has workgroups enough without the
   //  split, and 12 slabs of [BT, ldh] written and folded again cost more than the serial stages they save; the output transforms
   //  below are B-row problems and keep their split at every T)
@@ -413,14 +409,10 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     if (ei >= 0) (void)hipEventRecord((hipEvent_t)c->ev_stop[3 * c->ev_n + ei], (hipStream_t)stream);
   }
   RET(hook(1, &op));
-  // the pools wait for q.  With the slab form the pool kernel waits ITSELF (tcar_wave_wait: every wave polls the query MLP's flag
-  // after its slab fold and alpha1 / alpha_t scores, so the wait overlaps that work and no polling kernel sits on this stream:
-  // ~8 us of launch + poll off the chain); otherwise a polling kernel / an event
-  TcarWait wq{};
-  if (qside && psplit && (tn(c).inkernel_wait & 1)) {
-    if (const ForkSlot* f = fork_live(c, FK_QUERY)) wq = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
-  }
-  if (qside && !wq.flag) {
+  // the pools wait for q: a polling kernel behind the query MLP's flag, or an event.  (The pool kernel can also wait for that flag
+  // ITSELF, behind its slab fold — tcar_attn_pool_fwd_slabs_w's wait argument; measured no faster in rounds 4 and 5, not used here.)
+  const TcarWait wq{};
+  if (qside) {
     RET(fork_go(c, FK_QUERY, sq, (hipStream_t)stream, c->ev3));
   } else if (!qside && !qfused) {       // q = tanh(q1 Wq2 + b) (modules.py:139)
     tcar_gemm_desc_t p = prob1(B, g.ic, c->q1, g.ldh, W(c, TCAR_V_Q2_W), g.ic, g.ldh, c->q, g.ic, W(c, TCAR_V_Q2_B), 2);
@@ -438,7 +430,7 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
   // the bias, applies tanh, writes attout + its planes and goes on to the one-hot time scores (embed.hip: attout_finish_kernel)
   const int na_ic = units(g.ic), na_pt = units(g.pt);
   const int64_t astride = (int64_t)B * g.ek;
-  if (split && tn(c).attout_split && g.ldt == 64 && (g.ldh & 63) == 0 &&
+  if (split && g.ldt == 64 && (g.ldh & 63) == 0 &&
       c->proj_slab_floats >= (na_ic > na_pt ? na_ic : na_pt) * astride) {
     tcar_gemm_desc_t p[2];
     p[0] = prob1(B, g.ic, c->pooled, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, c->proj_slabs, g.ek, nullptr, 0, 0, na_ic);
@@ -504,15 +496,11 @@ int backward_prologue(const tcar_ctx_t* c, const tcar_batch_t* bt, hipStream_t s
   // context's latest fork action — nothing else forks between that launch and here —, else it is a leftover: event)
   if (const ForkSlot* f = fork_live(c, FK_LOGITS))
     if (f->sig.epoch != fork_host(c)->epoch) fork_disarm(c, FK_LOGITS);
-  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], tn(c).fork_delay));
+  if (sz != st) RET(fork_go(c, FK_LOGITS, st, sz, c->ev[0], tcar_fixed::fork_delay));
   RET(zero_arena(c, sz));
-  fork_disarm(c, FK_NEG);
   if (bt->K > 0 && bt->neg && c->neg_coef && c->negpart) {
-    // (the main chain's slab reduce reads negpart: with a flag it waits for this launch in-kernel instead of behind an event)
     TcarOpt on = opt_of(c);
-    if (sz != st) on.sig = fork_arm(c, FK_NEG);
     RET(tcar_neg_fwd_o(&c->d, bt->B, bt->K, c->E, bt->neg, c->attout, c->neg_weight, c->neg_fb, c->neg_coef, c->negpart, (void*)sz, &on));
-    (void)fork_commit(c, FK_NEG, on);
   }
   return TCAR_OK;
 }
@@ -535,7 +523,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     const float* pieces = c->Gx + c->arena_n;
     RET(tcar_clip_adam_rest_keep_o(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
                                    c->clip, rest_lr, c->b1, c->b2, c->eps, c->scoring ? c->e16h : nullptr,
-                                   c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2, tn(c).rest_grid));
+                                   c->scoring ? c->e16l : nullptr, g.ek, c->adam_bitmap, (void*)s2, tcar_fixed::rest_grid));
     if (hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
     // the marks are cleared BEHIND the event the logits GEMM waits for (the clear is a launch of its own)
     // (the map is allocated in whole 64-byte units, tcar_hip.h: ONE fill kernel — a size that is no multiple of 16 bytes costs a second one)
@@ -751,11 +739,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // one-hot form of the two gradient GEMMs (the forward half of this step made the same decision: onehot_bwd)
   const bool ohb = ce_epilogue && fuse_finish && onehot_bwd(c, bt);
   // ev[1] = "aux prologue done" (arena zeroed, negative term's forward): in the one-hot schedule its only reader on the main chain is
-  // the slab reduce (negpart), which waits for the negative term's FLAG in-kernel when that launch carries one — then neither the
-  // record (aux chain, in front of dE) nor the wait (main chain) exists.  Everything else that needs the zeroed arena sits behind
-  // dE on its own stream (stream order / ev[4]).
-  const bool neg_flag = ohb && has_neg && c->gw_rows && c->stream3 && c->ev3 && (tn(c).inkernel_wait & 2) && fork_live(c, FK_NEG) != nullptr;
-  if (s2 && !neg_flag && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
+  // the slab reduce (negpart).  Everything else that needs the zeroed arena sits behind dE on its own stream (stream order / ev[4]).
+  // (The slab reduce can also wait for the negative term's flag in-kernel — tcar_reduce_dact_onehot_o's wait —: measured no faster.)
+  if (s2 && hipEventRecord((hipEvent_t)c->ev[1], s2) != hipSuccess) return TCAR_E_LAUNCH;
   float* Gi = c->big;
   float* d_et = c->big + (size_t)g.N * g.ldh;
   const int S = tcar_gemm_splitk_effective(g.Npad, c->splitk);
@@ -767,7 +753,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     TcarOpt os = opt_of(c);
     RET(tcar_ce_finish_o(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream, &os));
   }
-  else if (c->scoring) RET(tcar_softmax_ce_bf16_o(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream, tn(c).softmax_variant));
+  else if (c->scoring) RET(tcar_softmax_ce_bf16_o(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   // (forking dE behind dX instead — dX then runs without dE beside it — was re-measured in round 4: dX is no faster alone, dE ends
   //  13 us later: 0.529 vs 0.516 ms per step, profiles/r04_ab_experiments.txt)
@@ -844,7 +830,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // ---- chain A
   RET(chain_a_dx());
   // first use of the zeroed arena and of the negative term's forward outputs on the main stream
-  if (s2 && !neg_flag && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
+  if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // (Round 3 A/B: letting the chain of small kernels behind dX wait until dE has finished — every one of them runs ~2x slower
   // beside dE's 106-MB write stream — loses more in idle time than the faster kernels give back: 0.647 vs 0.620 ms per step.)
   // dattout = slabs summed + the negative term's part, through tanh' of both output transforms, + their bias gradients
@@ -855,22 +841,15 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (ohb) {    // ... and the one-hot columns: dP = their slab sum, expanded to the time columns of dattout on the spot
     TcarOpt orr = opt_of(c);
     orr.sig = fork_arm(c, FK_REDUCE);          // (dP leaves write-through when the launch carries the flag)
-    if (neg_flag) {
-      const ForkSlot* f = fork_live(c, FK_NEG);
-      orr.wait = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
-    }
     RET(tcar_reduce_dact_onehot_o(c->slabs, S, B, g.ic, g.ic + 160, has_neg ? c->negpart : nullptr, g.ic, c->attout, g.ek, c->tclip,
                                   c->dattout, g.ek, c->dP, detc ? nullptr : G(c, TCAR_V_O_B), detc ? nullptr : G(c, TCAR_V_OT_B), stream,
                                   &orr));
     (void)fork_commit(c, FK_REDUCE, orr);
     // candidate-side time-table gradients: on the aux stream behind dE (its (q, z) pairs: stream order) and behind this launch
     // (dP: a flag, no event on the main chain) — beside the session backward, ahead of the small tables' order-fixed pass
-    // (the kernel waits for the reduce's flag ITSELF, behind its pass over the (q, z) lists: no polling kernel on the aux chain; its
-    // per-table norm pieces are folded by the small tables' last launch: no launch of their own)
-    TcarWait wdp{};
-    if (tn(c).inkernel_wait & 4)
-      if (const ForkSlot* f = fork_live(c, FK_REDUCE)) wdp = TcarWait{f->sig.flag, f->sig.epoch, c->sig_dev + TCAR_SIG_ERR, c->sig_err_host};
-    if (!wdp.flag) RET(fork_go(c, FK_REDUCE, st, s2, c->ev[5]));
+    // (its per-table norm pieces are folded by the small tables' last launch: no launch of their own)
+    const TcarWait wdp{};
+    RET(fork_go(c, FK_REDUCE, st, s2, c->ev[5]));
     tcar_grads_t gr;
     grads_of(c, gr);
     RET(tcar_cand_time_bwd_onehot_w(&c->d, B, c->inv_off, c->qz, c->dP, c->attout, g.ek, c->tclip, c->ct_ws, &gr, (void*)s2, wdp, 0));
@@ -882,7 +861,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // chunk is its own set of workgroups writing its own slab, the pool backward folds them while it loads dpooled
   const int nd_ic = units(g.ic), nd_pt = units(g.pt);
   const int64_t dstride = (int64_t)B * g.ek;
-  const bool dsplit = detc && tn(c).proj_split && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
+  const bool dsplit = detc && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
   {
     tcar_gemm_desc_t p[2];
     float* dp = dsplit ? c->proj_slabs : c->dpooled;
@@ -894,44 +873,21 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // backward, relu' + bias gradient of query_trans1 in the epilogue of the GEMM that produces dq1, and that GEMM shares ONE
   // launch with the three input-gradient GEMMs of the projections (all four need only the pool backward's outputs); the
   // click-query input gradient (needs dq1) follows.  fp32 mode: the op-level sequence.
-  // Click-query MLP backward (dq -> dq1 -> dclick) as ONE launch on the third stream (query.hip), behind the pool backward's flag:
-  // its outputs feed only the side streams (dq1: weight gradients + column sums; dclick: the small tables' pass), so the main
-  // chain's grouped launch keeps the three input-gradient GEMMs only (K = 256: 4 stages instead of the 8 of the dq1 product)
-  const bool qb = detc && tn(c).qbwd_fused == 1 && g.ldh == 256 && g.ldt == 64 && s2 && fuse_finish && c->stream3 && c->ev3 && sorted &&
-                  tn(c).det_small != 0;
+  // (The whole click-query MLP backward, dq -> dq1 -> dclick, as ONE launch on the third stream behind the pool backward's flag —
+  //  tcar_query_mlp_bwd with both layers — measured slower in rounds 4 and 5; the driver runs only its layer-1 half, further down.)
   // (Weight gradients in two launches — eight of the nine problems behind the pool backward's flag — were measured twice, 5 us and
   //  15 us SLOWER per step: the early launch runs beside the main chain's input-gradient GEMM.  Removed in round 5.)
   if (detc) {
     TcarOpt opb = opt_of(c);
-    if (qb) opb.sig = fork_arm(c, FK_POOLB);
-    else fork_disarm(c, FK_POOLB);
     RET(tcar_attn_pool_bwd_slabs_o(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES), W(c, TCAR_V_S_WRES),
                                    c->alpha, dsplit ? c->proj_slabs : c->dpooled, dsplit ? nd_ic : 1, dsplit ? nd_pt : 1, dstride,
                                    c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2, c->gw_rows, stream, &opb));
-    (void)fork_commit(c, FK_POOLB, opb);
   }
   else
     RET(tcar_attn_pool_bwd_q(&c->d, B, T, c->x_icp, c->x_pt, c->pre1, c->pre2, c->q, W(c, TCAR_V_M_WRES),
                              W(c, TCAR_V_S_WRES), c->alpha, c->dpooled, c->dx_icp, c->dx_pt, c->dq, c->dpre1, c->dpre2,
                              G(c, TCAR_V_M_WRES), G(c, TCAR_V_S_WRES), fusedq ? G(c, TCAR_V_Q2_B) : nullptr, stream));
-  if (qb) {
-    // third stream: [pool backward's flag] -> dq1, dclick
-    hipStream_t s3q = (hipStream_t)c->stream3;
-    RET(fork_go(c, FK_POOLB, st, s3q, c->ev[0]));
-    TcarOpt oq = opt_of(c);
-    oq.sig = fork_arm(c, FK_QBWD);
-    RET(tcar_query_mlp_bwd_o(&c->d, B, c->dq, c->q1, W(c, TCAR_V_Q1_W), W(c, TCAR_V_Q2_W), c->dq1, c->dclick, (void*)s3q, &oq));
-    (void)fork_commit(c, FK_QBWD, oq);
-    // main chain: the three input-gradient GEMMs (only the ITEM half of dX_ic: content is frozen)
-    tcar_gemm_desc_t p[3];
-    p[0] = prob1(BT, g.ldh, c->dpre1, g.ldh, W(c, TCAR_V_M_WIN), g.ldh, g.ldh, c->dx_icp, g.ic, nullptr, 0, 1);
-    p[1] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
-    p[2] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
-    TcarOpt oi = opt_of(c);
-    oi.sig = fork_arm(c, FK_INGRAD);
-    RET(small_gemm(c, 1, 3, p, stream, &oi));
-    (void)fork_commit(c, FK_INGRAD, oi);
-  } else if (fusedq) {
+  if (fusedq) {
     tcar_gemm_desc_t p[4];
     p[0] = prob1(B, g.ldh, c->dq, g.ic, W(c, TCAR_V_Q2_W), g.ic, g.ic, c->dq1, g.ldh);
     p[0].dact = 1; p[0].dact_y = c->q1; p[0].ld_dact_y = g.ldh; p[0].colsum = detc ? nullptr : G(c, TCAR_V_Q1_B);
@@ -973,11 +929,11 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // order-fixed small tables it runs THERE, right in front of them, behind a second poll of the input-gradient launch's flag
   // (it needs dq1 of that launch) — off the main chain (round 4: 17 us) and off the third stream, whose weight gradients, column
   // sums and norms are the step's last chain
-  const bool dclick_aux = fusedq && det_small && s3 != nullptr && !qb;
+  const bool dclick_aux = fusedq && det_small && s3 != nullptr;
   RET(weight_grads(c, g, B, BT, sW, &ow));
   // column sums and dense norms are the last two launches of the step's last chain: ONE launch when the context has the fold scratch
-  // (optim.hip: colsum_sqnorm_kernel; TCAR_COLSUM_FUSED)
-  const bool cs_fused = detc && fuse_finish && s2 && c->fold_scratch && tn(c).colsum_fused;
+  // (optim.hip: colsum_sqnorm_kernel)
+  const bool cs_fused = detc && fuse_finish && s2 && c->fold_scratch;
   if (detc && !cs_fused) RET(det_colsums(c, g, B, sW));
   // the dense-weight norms need nothing from the row scatter (tables are normed through their row pieces, S5): with an
   // aux stream they follow the weight gradients there, beside the scatter
@@ -1006,8 +962,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (s3 && hipEventRecord((hipEvent_t)c->ev3, s3) != hipSuccess) return TCAR_E_LAUNCH;
   // (with the order-fixed small tables the aux stream's "done" event is recorded behind them, below)
   if (s2 && !det_small && hipEventRecord((hipEvent_t)c->ev[2], s2) != hipSuccess) return TCAR_E_LAUNCH;
-  if (dclick_aux || qb) {
-    // (launched on the aux stream below, in front of the small tables / by the fused click-query backward on the third stream)
+  if (dclick_aux) {
+    // (launched on the aux stream below, in front of the small tables)
   } else if (fusedq) {   // the click-query input gradient (the projections' input gradients went with dq1)
     tcar_gemm_desc_t p = prob1(B, g.ct, c->dq1, g.ldh, W(c, TCAR_V_Q1_W), g.ldh, g.ldh, c->dclick, g.ct);
     TcarOpt od = opt_of(c);
@@ -1034,12 +990,9 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     const int64_t rowq_floats = c->small_det_ws ? c->small_det_ws_floats : 512;
     // on the AUX stream: it is idle once the candidate-time backward is through (the third stream still holds the weight
     // gradients, the column sums and the dense norms); the final join below waits for ev[2], re-recorded here
-    if (qb) {
-      // dclick (third stream, the click-query backward) and dx_* (main chain, the input-gradient launch): one poll of both flags
-      RET(fork_go2(c, FK_QBWD, (hipStream_t)c->stream3, c->ev[5], FK_INGRAD, st, c->ev[0], s2));
-    } else if (dclick_aux) {
+    if (dclick_aux) {
       RET(fork_go(c, FK_INGRAD, st, s2, c->ev[5]));       // (the same flag the third stream polled: dq1, dx_* of that launch)
-      if (tn(c).qbwd_fused == 2 && g.ldh == 256 && g.ldt == 64) {
+      if (g.ldh == 256 && g.ldt == 64) {
         // dclick = dq1 Wq1^T as ONE fp32 launch of whole-row dots (query.hip: the layer-1 half of the click-query backward): 7 us
         // where the 16-workgroup small GEMM walks four serial 64-deep stages (20 us), on the chain that ends the step
         RET(tcar_query_mlp_bwd_o(&c->d, B, nullptr, nullptr, W(c, TCAR_V_Q1_W), nullptr, c->dq1, c->dclick, (void*)s2, nullptr));
@@ -1259,7 +1212,7 @@ extern "C" int tcar_shard_begin(const tcar_ctx_t* c, const tcar_batch_t* bt, int
       const float* pieces = c->Gx + c->arena_n;
       RET(tcar_clip_adam_rest_keep_o(c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh, c->slot_item, c->sqn_dense, pieces, c->use_dense,
                                      c->clip, lr_pending, c->b1, c->b2, c->eps, c->e16h, c->e16l, g.ek, c->adam_bitmap, (void*)s2,
-                                     tn(c).rest_grid));
+                                     tcar_fixed::rest_grid));
       RET(zero_arena(c, s2));              // (behind the rest pass: it reads the norm slots and pieces the zero clears)
     }
     if (hipEventRecord((hipEvent_t)c->ev[5], s2) != hipSuccess) return TCAR_E_LAUNCH;
@@ -1460,7 +1413,7 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
   // round trip instead of 104 walking 8 / 5 serial stages — 30 -> 19 us on this chain)
   const int nd_ic = units(g.ic), nd_pt = units(g.pt);
   const int64_t dstride = (int64_t)B * g.ek;
-  const bool dsplit = detc && tn(c).proj_split && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
+  const bool dsplit = detc && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
   {
     tcar_gemm_desc_t p[2];
     float* dp = dsplit ? c->proj_slabs : c->dpooled;
@@ -1499,7 +1452,7 @@ extern "C" int tcar_step_session_backward(const tcar_ctx_t* c, const tcar_batch_
     RET(weight_grads(c, g, B, BT, s2 ? (void*)s2 : stream));
     if (detc) RET(det_colsums(c, g, B, s2 ? (void*)s2 : stream));
   }
-  if (tn(c).qbwd_fused == 2 && g.ldh == 256 && g.ldt == 64) {
+  if (g.ldh == 256 && g.ldt == 64) {
     // dclick = dq1 Wq1^T as ONE fp32 launch of whole-row dots (query.hip: the layer-1 half of the click-query backward, as in the
     // fused step): 7 us where the 16-workgroup small GEMM walks four serial 64-deep stages (16-20 us) on this chain
     RET(tcar_query_mlp_bwd_o(&c->d, B, nullptr, nullptr, W(c, TCAR_V_Q1_W), nullptr, c->dq1, c->dclick, stream, nullptr));

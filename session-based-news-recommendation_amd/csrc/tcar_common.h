@@ -51,6 +51,14 @@ static inline bool tcar_first_on_device(TcarOnce& o) {
 // overridden by the TCAR_* environment, read ONCE at first use (C++11 thread-safe static) and never written again; a context
 // (tcar_ctx_t.tune) or a *_tuned entry point may carry its own copy instead.  Defined in step.hip.
 typedef tcar_tuning_t TcarTuning;
+// Choices that were TCAR_* switches until round 6 — each A/B'd at least twice (profiles/experiments_log.md) — are constants of the build
+// now; tcar_tuning_t keeps the twelve switches that select between forms a test pins or a user may need.
+namespace tcar_fixed {
+constexpr int rest_grid = 512;     // grid cap of the deferred Adam rest pass (it runs beside the next step's session forward)
+constexpr int fork_delay = 7;      // us the aux prologue's flag fork holds its consumer back behind the end of the logits GEMM
+constexpr int x3_oneshot = 4;      // small-GEMM launches of at most this many 64-deep stages per workgroup keep two stages in flight
+constexpr int gather_wg = 2;       // 1024-thread workgroups per CU of the gather's throughput form (2 x 78 KB of LDS fit)
+}  // namespace tcar_fixed
 const TcarTuning& tcar_tuning();
 
 // Completion flag of a kernel (step.hip: fork_arm / fork_go).  A kernel that carries one publishes `epoch` to *flag when its
@@ -172,7 +180,7 @@ int tcar_clip_adam_rest_keep_o(float* w2d, int64_t ldw, const float* g2d, float*
                                float lr_t, float b1, float b2, float eps, void* e16_hi, void* e16_lo, int64_t ld16,
                                uint32_t* bitmap, void* stream, int rest_grid);
 int tcar_softmax_ce_bf16_o(int B, int N, float* logits, int64_t ld, const int32_t* label, float* ce, void* dl_hi, void* dl_lo,
-                           void* stream, int variant);
+                           void* stream);
 
 // 16-byte write-through store (sc1): the bytes bypass the write-back state of this XCD's L2, so a consumer behind a completion
 // flag needs no release fence / L2 write-back from the producer (cdna_hip_programming.md Guideline 16, R1).  The compiler does not

@@ -81,7 +81,6 @@ split = [D(BT, g.ldh, [(p(eng.x_icp), g.ic, eng._w("m_win"), g.ldh, g.ic)], ps(0
 timeit("proj split (6 problems, 12 slabs)", lambda: gg(0, split))
 timeit("proj split, first problem only", lambda: gg(0, split[:1]))
 timeit("proj split, q1 only (K=128)", lambda: gg(0, split[5:]))
-# (the one-shot / register-ring choice of the small GEMM is a process switch: run this tool with TCAR_X3_ONESHOT=0 for the ring)
 qd = [D(B, g.ic, [(p(eng.q1), g.ldh, eng._w("q2_w"), g.ic, g.ldh)], p(eng.q), g.ic, bias=eng._w("q2_b"), act=2)]
 timeit("q = tanh(q1 Wq2 + b)  K=256", lambda: gg(0, qd))
 timeit("attn_pool_fwd (plain)", lambda: lib.tcar_attn_pool_fwd(C.byref(eng.dims), B, T, p(eng.x_icp), p(eng.x_pt), p(eng.pre1), p(eng.pre2), p(eng.q), eng._w("m_wres"), eng._w("s_wres"), p(eng.pooled), p(eng.alpha), stream))

@@ -11,6 +11,13 @@
 // | dma+mfma (fills + transposing reads + MFMAs: the dE GEMM's mix).   argv[2]: first aggressor to run (skip the earlier ones).
 // VARIANTS of the victim: 0 = as compiled from the C++ loop; 1 = scalar FMAs behind s_waitcnt lgkmcnt(0); 2 = the failing loop's exact
 // instructions (inline assembly); 3 = the same, every LDS read landed first; 4 = the same without op_sel:[0,1,0].
+// Round 6 — ONE change each to failing form 2, beside the mfma aggressor:
+//   5 = the op_sel instruction writes ANOTHER register pair (vD != vC; the next packed FMA takes it back)
+//   6 = the v_mov of the multiplier quad's last dword (v10 <- v15 / v20 <- v19) moved IN FRONT of the op_sel instruction
+//   7 = s_nop 4 in front of the op_sel instruction          8 = s_nop 4 behind it
+//   9 = the whole loop under EXEC = lanes 48-63 only (the other lanes are not compared)
+//  10 = op_sel:[0,1,0] kept, but its multiplier comes from a register pair written by a v_mov (not from the LDS-loaded quad)
+//  11 = the two v_fmac behind the op_sel instruction read a COPY of the multiplier (no other VALU op reads v13 / v17 near it)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -83,7 +90,21 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, int M, int nk_ar
 #define R5B(W) W "v_mov_b32_e32 v22, v17\n s_nop 0\n v_pk_fma_f32 v[2:3], v[44:45], v[22:23], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v46, v17\n v_fmac_f32_e32 v5, v47, v17\n v_mov_b32_e32 v20, v19\n"
 #define R6(W) W "v_pk_fma_f32 v[2:3], v[48:49], v[18:19], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v50, v18\n v_fmac_f32_e32 v5, v51, v18\n"
 #define R7(W) W "v_pk_fma_f32 v[2:3], v[52:53], v[20:21], v[2:3] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v54, v19\n v_fmac_f32_e32 v5, v55, v19\n"
-#define CLOB "v2", "v3", "v5", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
+#define R1O(W) W "v_pk_fma_f32 v[6:7], v[28:29], v[12:13], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v30, v13\n v_fmac_f32_e32 v5, v31, v13\n v_mov_b32_e32 v10, v15\n"
+#define R2O(W) W "v_pk_fma_f32 v[2:3], v[32:33], v[14:15], v[6:7] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v34, v14\n v_fmac_f32_e32 v5, v35, v14\n"
+#define R5O(W) W "v_pk_fma_f32 v[6:7], v[44:45], v[16:17], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v46, v17\n v_fmac_f32_e32 v5, v47, v17\n v_mov_b32_e32 v20, v19\n"
+#define R6O(W) W "v_pk_fma_f32 v[2:3], v[48:49], v[18:19], v[6:7] op_sel_hi:[1,0,1]\n v_fmac_f32_e32 v11, v50, v18\n v_fmac_f32_e32 v5, v51, v18\n"
+#define R1M(W) W "v_mov_b32_e32 v10, v15\n v_pk_fma_f32 v[2:3], v[28:29], v[12:13], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v30, v13\n v_fmac_f32_e32 v5, v31, v13\n"
+#define R5M(W) W "v_mov_b32_e32 v20, v19\n v_pk_fma_f32 v[2:3], v[44:45], v[16:17], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v46, v17\n v_fmac_f32_e32 v5, v47, v17\n"
+#define R1N(W) W "s_nop 4\n v_pk_fma_f32 v[2:3], v[28:29], v[12:13], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v30, v13\n v_fmac_f32_e32 v5, v31, v13\n v_mov_b32_e32 v10, v15\n"
+#define R5N(W) W "s_nop 4\n v_pk_fma_f32 v[2:3], v[44:45], v[16:17], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v46, v17\n v_fmac_f32_e32 v5, v47, v17\n v_mov_b32_e32 v20, v19\n"
+#define R1A(W) W "v_pk_fma_f32 v[2:3], v[28:29], v[12:13], v[2:3] op_sel:[0,1,0]\n s_nop 4\n v_fmac_f32_e32 v11, v30, v13\n v_fmac_f32_e32 v5, v31, v13\n v_mov_b32_e32 v10, v15\n"
+#define R5A(W) W "v_pk_fma_f32 v[2:3], v[44:45], v[16:17], v[2:3] op_sel:[0,1,0]\n s_nop 4\n v_fmac_f32_e32 v11, v46, v17\n v_fmac_f32_e32 v5, v47, v17\n v_mov_b32_e32 v20, v19\n"
+#define R1C(W) W "v_mov_b32_e32 v23, v13\n s_nop 0\n v_pk_fma_f32 v[2:3], v[28:29], v[22:23], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v30, v13\n v_fmac_f32_e32 v5, v31, v13\n v_mov_b32_e32 v10, v15\n"
+#define R5C(W) W "v_mov_b32_e32 v23, v17\n s_nop 0\n v_pk_fma_f32 v[2:3], v[44:45], v[22:23], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v46, v17\n v_fmac_f32_e32 v5, v47, v17\n v_mov_b32_e32 v20, v19\n"
+#define R1D(W) W "v_mov_b32_e32 v23, v13\n s_nop 0\n v_pk_fma_f32 v[2:3], v[28:29], v[12:13], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v30, v23\n v_fmac_f32_e32 v5, v31, v23\n v_mov_b32_e32 v10, v15\n"
+#define R5D(W) W "v_mov_b32_e32 v23, v17\n s_nop 0\n v_pk_fma_f32 v[2:3], v[44:45], v[16:17], v[2:3] op_sel:[0,1,0]\n v_fmac_f32_e32 v11, v46, v23\n v_fmac_f32_e32 v5, v47, v23\n v_mov_b32_e32 v20, v19\n"
+#define CLOB "v6", "v7", "v2", "v3", "v5", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", \
              "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", \
              "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "memory"
         if (VAR == 2)
@@ -93,6 +114,23 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, int M, int nk_ar
         else if (VAR == 3)
           asm volatile(PRE RD "s_waitcnt lgkmcnt(0)\n" R0("") R1("") R2("") R3("") R4("") R5("") R6("") R7("") POST
                        : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+#define BODY(A1, A2, A5, A6) PRE RD R0("s_waitcnt lgkmcnt(7)\n") A1("s_waitcnt lgkmcnt(6)\n") A2("s_waitcnt lgkmcnt(5)\n") R3("s_waitcnt lgkmcnt(4)\n") \
+                       R4("s_waitcnt lgkmcnt(3)\n") A5("s_waitcnt lgkmcnt(2)\n") A6("s_waitcnt lgkmcnt(1)\n") R7("s_waitcnt lgkmcnt(0)\n") POST
+        else if (VAR == 5)
+          asm volatile(BODY(R1O, R2O, R5O, R6O) : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+        else if (VAR == 6)
+          asm volatile(BODY(R1M, R2, R5M, R6) : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+        else if (VAR == 7)
+          asm volatile(BODY(R1N, R2, R5N, R6) : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+        else if (VAR == 8)
+          asm volatile(BODY(R1A, R2, R5A, R6) : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+        else if (VAR == 9)
+          asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b32 exec_lo, 0\n s_mov_b32 exec_hi, 0xffff0000\n" BODY(R1, R2, R5, R6) "s_mov_b64 exec, s[20:21]\n"
+                       : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : "s20", "s21", CLOB);
+        else if (VAR == 10)
+          asm volatile(BODY(R1C, R2, R5C, R6) : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
+        else if (VAR == 11)
+          asm volatile(BODY(R1D, R2, R5D, R6) : "+v"(x), "+v"(y), "+v"(z), "+v"(w) : "v"(pt), "v"(pd) : CLOB);
         else
           asm volatile(PRE RD R0("s_waitcnt lgkmcnt(7)\n") R1B("s_waitcnt lgkmcnt(6)\n") R2("s_waitcnt lgkmcnt(5)\n") R3("s_waitcnt lgkmcnt(4)\n")
                        R4("s_waitcnt lgkmcnt(3)\n") R5B("s_waitcnt lgkmcnt(2)\n") R6("s_waitcnt lgkmcnt(1)\n") R7("s_waitcnt lgkmcnt(0)\n") POST
@@ -109,6 +147,7 @@ __global__ __launch_bounds__(256) void victim_kernel(int iters, int M, int nk_ar
       asm volatile("" : "+v"(rx), "+v"(ry), "+v"(rz), "+v"(rw));            // keep the reference scalar (no SLP packing of these)
       rx = fmaf(t[0], s, rx); ry = fmaf(t[1], s, ry); rz = fmaf(t[2], s, rz); rw = fmaf(t[3], s, rw);
     }
+    if (VAR == 9 && (tid & 63) < 48) acc = make_float4(rx, ry, rz, rw);      // (those lanes were masked off: not compared)
     const float g[4] = {acc.x, acc.y, acc.z, acc.w}, w[4] = {rx, ry, rz, rw};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -307,7 +346,8 @@ int main(int argc, char** argv) {
   const int first_aggr = argc > 2 ? atoi(argv[2]) : 0;
   const int nks[] = {61, 32, 13};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int var = 0; var < 5; ++var)
+  const int first_var = argc > 3 ? atoi(argv[3]) : 0;
+  for (int var = first_var; var < 12; ++var)
     for (int a = first_aggr; a < 7; ++a)
       for (int ki = 0; ki < 3; ++ki) {
         if (var == 1 && ki != 0) continue;
@@ -341,7 +381,14 @@ int main(int argc, char** argv) {
             else if (var == 1) hipLaunchKernelGGL((victim_kernel<1>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
             else if (var == 2) hipLaunchKernelGGL((victim_kernel<2>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
             else if (var == 3) hipLaunchKernelGGL((victim_kernel<3>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
-            else hipLaunchKernelGGL((victim_kernel<4>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 4) hipLaunchKernelGGL((victim_kernel<4>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 5) hipLaunchKernelGGL((victim_kernel<5>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 6) hipLaunchKernelGGL((victim_kernel<6>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 7) hipLaunchKernelGGL((victim_kernel<7>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 8) hipLaunchKernelGGL((victim_kernel<8>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 9) hipLaunchKernelGGL((victim_kernel<9>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else if (var == 10) hipLaunchKernelGGL((victim_kernel<10>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
+            else hipLaunchKernelGGL((victim_kernel<11>), dim3(416), dim3(256), 0, s2, 8, M, nk, tclip, coef, out, rep);
           }
           launches += chunk;
           CK(hipEventRecord(ev, s2));

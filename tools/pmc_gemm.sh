@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes (each counter set in its own run, kernel-trace only — MI355X_MICROARCH.md, HBM / rocprofv3) over
 # tools/gemm_bench.py <mode> <nsplit>; raw output under gpurun_out/pmc_<mode>_n<nsplit>_<set>, packed by tools/pmc_pack.py
-# (PMC_KERNEL=<substring>: the kernel to summarise when it is not gemm_bf16_kernel, e.g. gemm_bf16_ce16_kernel with TCAR_LOGITS_MFMA16=1)
+# (PMC_KERNEL=<substring>: the kernel to summarise when it is not gemm_bf16_kernel)
 # usage: tools/pmc_gemm.sh <fwd|fwdce|fwdce2|dx|de|dx2|de2> [nsplit=3] [iters=5]   (fwdce2 = the step's form: one-hot time segment)
 MODE=$1; NS=${2:-3}; IT=${3:-5}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
