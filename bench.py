@@ -769,6 +769,14 @@ def main():
                "kernels": kernels, "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 4),
                "ms_per_step_with_kernel_events": (round(dt_ev / args.steps * 1e3, 4) if dt_ev else None),
                "last_loss": round(last_loss, 4)}
+        if dist is not None:
+            # RCCL writes its version banner through C stdio, which is block-buffered when stdout is a file and would land BEHIND
+            # the JSON line at exit: drain it first, so that the JSON line is the last thing this process prints
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

@@ -45,7 +45,7 @@ from .engine import SLOT, TcarEngine
 class GradExchange:
     """The collective schedule above, independent of where the local pieces come from."""
 
-    def __init__(self, group=None, force=None):
+    def __init__(self, group=None, force=None, direct=None):
         import os
         self.group = group
         live = dist.is_available() and dist.is_initialized()
@@ -55,6 +55,14 @@ class GradExchange:
         if force is None:
             force = bool(int(os.environ.get("TCAR_FORCE_COLLECTIVES", "0") or 0))
         self.collective = live and (self.world > 1 or bool(force))
+        # RCCL directly on the issuing stream instead of through the process group (rccl.py; sharded.ShardExchange has the account)
+        self.direct = None
+        if self.collective and dist.get_backend(group) == "nccl" and direct is not False:
+            from . import rccl
+            got = rccl.make_direct(group, n=1)
+            self.direct = got[0] if got else None
+            if direct is True and self.direct is None:
+                raise RuntimeError("the direct RCCL path was required and could not be built")
 
     def communicate(self, big: torch.Tensor, arena_pieces: torch.Tensor, ids: torch.Tensor, rows: torch.Tensor,
                     big_done: bool = False):
@@ -64,15 +72,27 @@ class GradExchange:
         g = self.group
         if not self.collective:
             return ids.reshape(-1), rows.reshape(-1, rows.shape[-1])
+        d = self.direct
         if not big_done:
             for part in (big if isinstance(big, (list, tuple)) else (big,)):
-                dist.all_reduce(part, group=g)                              # 1  (parts in the caller's canonical order)
+                self.all_reduce(part)                                       # 1  (parts in the caller's canonical order)
         all_ids = torch.empty((self.world,) + tuple(ids.shape), dtype=ids.dtype, device=ids.device)
         all_rows = torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
-        dist.all_gather_into_tensor(all_ids.view(-1), ids.reshape(-1).contiguous(), group=g)      # 5
-        dist.all_gather_into_tensor(all_rows.view(-1), rows.reshape(-1).contiguous(), group=g)
-        dist.all_reduce(arena_pieces, group=g)                              # 3
+        if d is not None:
+            d.all_gather(ids.reshape(-1).contiguous(), all_ids.view(-1))    # 5
+            d.all_gather(rows.reshape(-1).contiguous(), all_rows.view(-1))
+        else:
+            dist.all_gather_into_tensor(all_ids.view(-1), ids.reshape(-1).contiguous(), group=g)      # 5
+            dist.all_gather_into_tensor(all_rows.view(-1), rows.reshape(-1).contiguous(), group=g)
+        self.all_reduce(arena_pieces)                                       # 3
         return all_ids.view(-1), all_rows.view(-1, rows.shape[-1])
+
+    def all_reduce(self, t: torch.Tensor):
+        """in-place sum over the ranks on torch's CURRENT stream (direct RCCL) / through the process group"""
+        if self.direct is not None:
+            self.direct.all_reduce(t)                  # (asserts contiguity: an in-place collective on a copy would be lost)
+        else:
+            dist.all_reduce(t, group=self.group)
 
     @staticmethod
     def finish(all_ids: torch.Tensor, all_rows: torch.Tensor, sqnorm_item: Callable[[], None],
@@ -159,10 +179,10 @@ class DPEngine(TcarEngine):
 
     flag_forks = False   # (the gradient exchange is enqueued inside the fused backward: event forks)
 
-    def __init__(self, *a, group=None, force_collectives=None, **kw):
+    def __init__(self, *a, group=None, force_collectives=None, direct_rccl=None, **kw):
         super().__init__(*a, **kw)
         self.group = group
-        self.xch = GradExchange(group, force=force_collectives)
+        self.xch = GradExchange(group, force=force_collectives, direct=direct_rccl)
         g = self.geo
         # step 1 in two parts, the candidate-time block FIRST: its clip backward can then run (into a scratch copy of the
         # time-table gradients) while the item block is still being reduced
@@ -244,10 +264,10 @@ class DPEngine(TcarEngine):
             self._comm = torch.cuda.Stream(self.dev)
         self._comm.wait_event(self._aux_ev[3])
         with torch.cuda.stream(self._comm):
-            dist.all_reduce(self.big_parts[0], group=self.group)        # candidate-time block
+            self.xch.all_reduce(self.big_parts[0])                      # candidate-time block
             det_done = torch.cuda.Event()
             det_done.record(self._comm)
-            dist.all_reduce(self.big_parts[1], group=self.group)        # item block
+            self.xch.all_reduce(self.big_parts[1])                      # item block
         # candidate-side clip backward of the reduced time block, on the aux stream beside the item block's all-reduce,
         # into a scratch copy of the time-table gradients / norm pieces (added to the arena after ITS all-reduce)
         self._aux.wait_event(det_done)
@@ -320,6 +340,9 @@ class DPEngine(TcarEngine):
         big = 4 * g.N * (g.ldh + g.pt)
         arena = 4 * (self.arena_n + _lib.NSLOT)
         return {"mode": "replica", "world": self.xch.world, "allreduce_bytes": big + arena,
+                "collectives": ("none" if not self.xch.collective else
+                                "RCCL C API on the issuing stream (rccl.py)" if self.xch.direct is not None else
+                                "torch.distributed process group"),
                 "allgather_bytes_per_session_row": 4 * (g.ldh + 1),
                 "note": "all-reduce of the dense item-table block + candidate-time block of dE, all-reduce of the arena, "
                         "all-gather of the (id, row) sparse item rows"}

@@ -67,7 +67,7 @@ class ShardExchange:
     gathers, so `wait_rows()` is called at the top of the next step (and by every other reader of the item table)."""
 
     def __init__(self, group=None, world: Optional[int] = None, rank: Optional[int] = None, sim: bool = False,
-                 reduce_scatter: Optional[bool] = None, force: Optional[bool] = None):
+                 reduce_scatter: Optional[bool] = None, force: Optional[bool] = None, direct: Optional[bool] = None):
         live = dist.is_available() and dist.is_initialized()
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if live else 1)
@@ -80,6 +80,17 @@ class ShardExchange:
             force = bool(int(os.environ.get("TCAR_FORCE_COLLECTIVES", "0") or 0))
         self.collective = live and not sim and (self.world > 1 or bool(force))
         self.backend = dist.get_backend(group) if self.collective else "none"
+        # RCCL called directly on the step's stream (rccl.py) instead of through the process group: one C call per collective where
+        # ProcessGroupNCCL spends ~150 us of host time — six per step left the step host-bound (round 6).  Two communicators: the
+        # item-row all-gather of collective 6 runs on a side stream beside the next step's first collectives.  `direct`: None =
+        # default (on for the nccl backend, TCAR_RCCL_DIRECT=0 switches it off), False = process group, True = required.
+        self.direct = None
+        if self.collective and self.backend == "nccl" and direct is not False:
+            from . import rccl
+            self.direct = rccl.make_direct(group, n=2)
+            if direct is True and self.direct is None:
+                raise RuntimeError("the direct RCCL path was required and could not be built")
+        self._cs = None                 # side stream of collective 6 (direct path)
         self.use_reduce_scatter = (self.backend == "nccl") if reduce_scatter is None else bool(reduce_scatter)
         self.bytes_moved: Dict[str, int] = {}
         self.order = []                 # names of the collectives in issue order (tests)
@@ -129,7 +140,10 @@ class ShardExchange:
         if not self.collective:
             return t.unsqueeze(0)
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self._timed(key, t, lambda: dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group))
+        if self.direct is not None:
+            self._timed(key, t, lambda: self.direct[0].all_gather(t.contiguous(), out))
+        else:
+            self._timed(key, t, lambda: dist.all_gather_into_tensor(out.view(-1), t.reshape(-1).contiguous(), group=self.group))
         self._note(key, out)
         return out
 
@@ -138,6 +152,10 @@ class ShardExchange:
         if not self.collective:
             return full[:cap]
         self._note(key, full)
+        if self.direct is not None:
+            out = torch.empty(cap, full.shape[1], dtype=full.dtype, device=full.device)
+            self._timed(key, full, lambda: self.direct[0].reduce_scatter(full.contiguous(), out))
+            return out
         if self.use_reduce_scatter:
             out = torch.empty(cap, full.shape[1], dtype=full.dtype, device=full.device)
             self._timed(key, full, lambda: dist.reduce_scatter_tensor(out, full, group=self.group))
@@ -147,7 +165,10 @@ class ShardExchange:
 
     def allreduce(self, t: torch.Tensor, key: str) -> torch.Tensor:
         if self.collective:
-            self._timed(key, t, lambda: dist.all_reduce(t, group=self.group))
+            if self.direct is not None:
+                self._timed(key, t, lambda: self.direct[0].all_reduce(t))
+            else:
+                self._timed(key, t, lambda: dist.all_reduce(t, group=self.group))
             self._note(key, t)
         return t
 
@@ -157,8 +178,19 @@ class ShardExchange:
         if not self.collective:
             return
         mine = stage[self.rank].reshape(-1).clone()
-        work = self._timed("item_rows (issue)", stage,
-                           lambda: dist.all_gather_into_tensor(stage.view(-1), mine, group=self.group, async_op=True))
+        if self.direct is not None:
+            # second communicator, side stream: ordered behind the update that produced `mine`, an event for the next reader
+            cur = torch.cuda.current_stream(stage.device)
+            if self._cs is None:
+                self._cs = torch.cuda.Stream(stage.device)
+                self._cs_ev = torch.cuda.Event()
+            self._cs.wait_stream(cur)
+            self._timed("item_rows (issue)", stage, lambda: self.direct[1].all_gather(mine, stage.view(-1), stream=self._cs.cuda_stream))
+            self._cs_ev.record(self._cs)
+            work = self._cs_ev
+        else:
+            work = self._timed("item_rows (issue)", stage,
+                               lambda: dist.all_gather_into_tensor(stage.view(-1), mine, group=self.group, async_op=True))
         self._note("item_rows", stage)
         self._pending_rows = (work, stage, install, mine)
 
@@ -166,7 +198,10 @@ class ShardExchange:
         if self._pending_rows is not None:
             work, stage, install, _ = self._pending_rows
             self._pending_rows = None
-            work.wait()                       # NCCL: orders the current stream behind the collective, no host block
+            if self.direct is not None:
+                torch.cuda.current_stream(stage.device).wait_event(work)
+            else:
+                work.wait()                   # NCCL: orders the current stream behind the collective, no host block
             install(stage)
 
     def step(self, pieces, cap: int, update: bool) -> None:
@@ -288,7 +323,7 @@ class _Pieces:
 class ShardedEngine(TcarEngine):
     def __init__(self, params, content_emb, mwdhm, lr=1e-3, max_grad=150.0, neg_weight=0.01, device="cuda:0", group=None,
                  scoring="bf16x3", world: Optional[int] = None, rank: Optional[int] = None,
-                 force_collectives: Optional[bool] = None, **kw):
+                 force_collectives: Optional[bool] = None, direct_rccl: Optional[bool] = None, **kw):
         if scoring == "f32":
             raise ValueError("the catalog-sharded step runs the split-bf16 scoring modes (use mode='replica' for f32)")
         self.group = group
@@ -318,7 +353,7 @@ class ShardedEngine(TcarEngine):
         self.nlpad = _ru(nl, 128)
         self.n_local_items = nl
         # the collective schedule (device-agnostic; dX is reduce-scattered where the backend can — RCCL — and all-reduced over gloo)
-        self.xch = ShardExchange(group, self.world, self.dp_rank, sim=self._sim, force=force_collectives)
+        self.xch = ShardExchange(group, self.world, self.dp_rank, sim=self._sim, force=force_collectives, direct=direct_rccl)
         self.backend = self.xch.backend
         if self.xch.collective and self.tune is None and not os.environ.get("TCAR_SHARD_ALL_FLAGS"):
             # Flag forks whose PRODUCER sits behind a collective: the gather behind the item-row all-gather of the
@@ -335,6 +370,9 @@ class ShardedEngine(TcarEngine):
     def exchange_info(self) -> Dict[str, object]:
         g = self.geo
         return {"mode": "sharded", "world": self.world, "shard_rows": self.S,
+                "collectives": ("none" if not self.xch.collective else
+                                "RCCL C API on the step's stream (rccl.py)" if self.xch.direct is not None else
+                                "torch.distributed process group (%s)" % self.xch.backend),
                 "bytes_per_step": dict(self.bytes_moved),
                 "ms_per_collective": self.xch.collective_ms(),      # filled by the event-instrumented pass (enable_native_timing)
                 "item_rows_allgather_bytes": 4 * self.world * self.S * g.ldh,

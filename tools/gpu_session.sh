@@ -31,7 +31,7 @@ for step in "$@"; do
       python - <<PY
 import json
 try:
-    d = json.load(open("gpurun_out/${tag}_bench_${name}.json"))
+    d = json.loads([l for l in open("gpurun_out/${tag}_bench_${name}.json").read().splitlines() if l.startswith("{")][-1])
     r = d.get("roofline") or {}
     print("${name}", "ms/step", d["ms_per_step"], "sessions/s", d["value"], "device-step", d.get("device_step_sessions_per_s"),
           "e2e", (d.get("end_to_end_sessions_per_s") or {}).get("value"), "roofline", r.get("tag"), r.get("frac"),
