@@ -650,6 +650,16 @@ namespace {
 // The nine weight gradients x^T dy (K = batch rows, model_combine.py:156): ONE grouped launch.  K is not split up to wgrad_ks
 // (1,536) rows; longer batches split it — into slabs folded in split order when the context has the workspace (order-fixed:
 // tcar_fold_slabs), else with float atomics into the zeroed arena.
+// tile code of the dE (q, z) launcher: a forced one (TCAR_BF16_TILE), else by catalog size.  Up to ~1 M rows the dlogits plane sits in
+// the Infinity Cache and the double-buffered 192-row tile is fastest (50.9 us alone at 46 k rows; the three-stage ring: 57.7).  Beyond,
+// the plane streams from HBM and the deeper ring pays: 10 M rows alone 11.1 ms (192 x 192 double buffer) / 9.65 (192-row ring) /
+// 9.27 (128-row ring) — profiles/r06_ab_experiments.txt
+int de_tile(const tcar_ctx_t* c, long n_rows) {
+  const int f = tn(c).bf16_tile;
+  if (f == 256 || f == 128 || f == 64 || f == 1922 || f == 1923 || f == 1283 || f == 2562) return f;
+  return n_rows >= (1L << 20) ? 1283 : 0;
+}
+
 int weight_grads(const tcar_ctx_t* c, const Geo& g, int B, int BT, void* stream, TcarOpt* o = nullptr) {
   const int ksdiv = tn(c).wgrad_ks > 0 ? tn(c).wgrad_ks : 1536;
   auto ks = [ksdiv](int K) { int s = (K + ksdiv - 1) / ksdiv; return s < 1 ? 1 : (s > 16 ? 16 : s); };
@@ -773,7 +783,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
       // item block only; the time block leaves as per-candidate (||gy||^2, x . gy) pairs in the order of the inverted index
       TcarOpt ob = opt_of(c);
       RET(tcar_gemm_bf16_de_qz_o(g.N, (B + 31) & ~31, c->dl16h, g.Npad, (B + 127) & ~127, c->ap16h, g.ldh + g.pt, (B + 127) & ~127,
-                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, (tn(c).bf16_tile == 256 || tn(c).bf16_tile == 128 || tn(c).bf16_tile == 1922 || tn(c).bf16_tile == 1923 || tn(c).bf16_tile == 1283 || tn(c).bf16_tile == 2562) ? tn(c).bf16_tile : 0, sB, &ob));
+                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, de_tile(c, g.N), sB, &ob));
     } else if (c->scoring) {
       // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
       TcarOpt ob = opt_of(c);

@@ -156,7 +156,10 @@ class TcarEngine:
         # Globo, Adressa and MIND shapes; 12 / 16 / 20 / 24 measured worse, profiles/r04_ab_experiments.txt)
         # (the materialised-logits modes — bf16x3, bf16 — contract 832 columns with other tiles: 36 stays better there, 0.649 / 0.509
         #  against 0.671 / 0.517 ms per step)
-        self.splitk = splitk if splitk else (16 if scoring == "f32" else 18 if scoring == "bf16x3-mixed" else 36)
+        # (catalogs from 2^20 rows: 64 slabs — the dX GEMM then takes its 256 x 384 tile, 44 % fewer fill bytes per flop, and 64 slabs of
+        #  [B, 672] are noise beside a contraction that long: 10 M items 13.7 -> 7.2 ms, profiles/r06_ab_experiments.txt)
+        big_catalog = int(np.asarray(content_emb).shape[0]) - 1 >= (1 << 20)
+        self.splitk = splitk if splitk else (16 if scoring == "f32" else (64 if big_catalog else 18) if scoring == "bf16x3-mixed" else 36)
         if os.environ.get("TCAR_SPLITK"):
             self.splitk = int(os.environ["TCAR_SPLITK"])
         # precision of the three full-catalog scoring GEMMs: "f32" (fp32 MFMA), "bf16x3" (split-bf16 planes, three
