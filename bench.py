@@ -126,7 +126,7 @@ def build_batches(fold, n_batches, B, K, rng, cfg, with_ids=False):
 def pmc_traffic(tag, nsplit, N, B):
     """HBM bytes per launch of one scoring GEMM from the committed rocprofv3 --pmc passes (FETCH_SIZE x 2 + WRITE_SIZE,
     MI355X_MICROARCH.md §HBM; tools/pmc_gemm.sh); only valid for the shape and plane count it was collected on."""
-    for rnd in ("r05", "r04", "r03", "r02"):      # the newest committed pass for this kernel form
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):      # the newest committed pass for this kernel form
         p = os.path.join(ROOT, "profiles", "%s_pmc_%s_n%d.json" % (rnd, tag, nsplit))
         if os.path.exists(p):
             d = json.load(open(p))
@@ -183,7 +183,7 @@ def gather_roofline(dev):
     # launch (the six small tables — 1,536 of the 3,536 algorithmic read bytes per click — are LDS-resident and never reach HBM, so
     # the algorithmic figure of SURVEY.md 8(d) overstates what the memory system moves); the algorithmic figure sits beside it
     real, src = None, None
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in ("r06", "r05", "r04", "r03"):
         pm = os.path.join(ROOT, "profiles", rnd + "_pmc_gather_fwd.json")
         if os.path.exists(pm):
             d_ = json.load(open(pm))

@@ -1,10 +1,12 @@
 """RCCL's C API through ctypes: the collectives of the two exchanges issued DIRECTLY on the stream the step runs on.
 
-Why (round 6, `profiles/r06_bench_dp1rank_sharded_rccl_pg.json`): through `torch.distributed` every collective costs the host
-~150 us (ProcessGroupNCCL: work object, event record, hop to its own stream and back) — six per step made the catalog-sharded
-step HOST-bound at 1.34 ms of enqueue time per step on a world-1 communicator, against 0.44 ms for the same step without
-collectives.  `ncclAllGather` / `ncclReduceScatter` / `ncclAllReduce` on OUR stream are one C call each: stream-ordered behind the
-kernels that produced their input and in front of the kernels that read their output, no event, no second stream.
+Why (round 6, `profiles/r06_ab_experiments.txt` section 4): `torch.distributed` runs every collective on a stream of
+ProcessGroupNCCL's own.  The training step already keeps four streams busy (main, aux, third, the sampler's) and HIP multiplexes
+streams onto FOUR hardware queues by default: with a fifth stream two of them share a queue, and — which two depends on creation
+order and on GPU_MAX_HW_QUEUES — the catalog-sharded step with live collectives ran at 1.6-1.9 ms instead of 0.65-0.73 ms on a
+world-1 communicator.  `ncclAllGather` / `ncclReduceScatter` / `ncclAllReduce` issued on OUR stream add no stream: they are
+stream-ordered behind the kernels that produced their input and in front of the kernels that read their output, no event, no hop
+(and one C call each: ~10 us of host time against ~30 through the process group).
 
 The communicator is built once per exchange from a `ncclUniqueId` that rank 0 creates and `torch.distributed` broadcasts (the
 process group stays the rendezvous and the fallback: `selftest()` runs the three collectives on tiny tensors against their known

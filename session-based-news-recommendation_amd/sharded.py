@@ -80,17 +80,19 @@ class ShardExchange:
             force = bool(int(os.environ.get("TCAR_FORCE_COLLECTIVES", "0") or 0))
         self.collective = live and not sim and (self.world > 1 or bool(force))
         self.backend = dist.get_backend(group) if self.collective else "none"
-        # RCCL called directly on the step's stream (rccl.py) instead of through the process group: one C call per collective where
-        # ProcessGroupNCCL spends ~150 us of host time — six per step left the step host-bound (round 6).  Two communicators: the
-        # item-row all-gather of collective 6 runs on a side stream beside the next step's first collectives.  `direct`: None =
-        # default (on for the nccl backend, TCAR_RCCL_DIRECT=0 switches it off), False = process group, True = required.
+        # RCCL called directly on the step's OWN stream (rccl.py) instead of through the process group.  Not for the host time of a
+        # call (measured: 10 us against ~30) but for the STREAMS: ProcessGroupNCCL runs every collective on a stream of its own, and
+        # the step already keeps four busy (main, aux, third, the sampler's).  HIP multiplexes streams onto 4 hardware queues by
+        # default; with a fifth, two of them share a queue and — which two depends on creation order — the step ran at 1.6-1.9 ms
+        # instead of 0.65-0.73 (profiles/r06_ab_experiments.txt, GPU_MAX_HW_QUEUES = 4 / 6 / 8 / 12).  Direct calls add NO stream:
+        # every collective, also the item-row all-gather of collective 6, is issued on the stream the step runs on.  `direct`: None
+        # = default (on for the nccl backend, TCAR_RCCL_DIRECT=0 switches it off), False = process group, True = required.
         self.direct = None
         if self.collective and self.backend == "nccl" and direct is not False:
             from . import rccl
-            self.direct = rccl.make_direct(group, n=2)
+            self.direct = rccl.make_direct(group, n=1)
             if direct is True and self.direct is None:
                 raise RuntimeError("the direct RCCL path was required and could not be built")
-        self._cs = None                 # side stream of collective 6 (direct path)
         self.use_reduce_scatter = (self.backend == "nccl") if reduce_scatter is None else bool(reduce_scatter)
         self.bytes_moved: Dict[str, int] = {}
         self.order = []                 # names of the collectives in issue order (tests)
@@ -179,15 +181,10 @@ class ShardExchange:
             return
         mine = stage[self.rank].reshape(-1).clone()
         if self.direct is not None:
-            # second communicator, side stream: ordered behind the update that produced `mine`, an event for the next reader
-            cur = torch.cuda.current_stream(stage.device)
-            if self._cs is None:
-                self._cs = torch.cuda.Stream(stage.device)
-                self._cs_ev = torch.cuda.Event()
-            self._cs.wait_stream(cur)
-            self._timed("item_rows (issue)", stage, lambda: self.direct[1].all_gather(mine, stage.view(-1), stream=self._cs.cuda_stream))
-            self._cs_ev.record(self._cs)
-            work = self._cs_ev
+            # on the step's own stream: nothing of this rank runs between the update and the next step's gathers, which need the
+            # rows anyway — a side stream would buy no overlap and cost a hardware queue (see __init__)
+            self._timed("item_rows (issue)", stage, lambda: self.direct[0].all_gather(mine, stage.view(-1)))
+            work = None
         else:
             work = self._timed("item_rows (issue)", stage,
                                lambda: dist.all_gather_into_tensor(stage.view(-1), mine, group=self.group, async_op=True))
@@ -198,9 +195,7 @@ class ShardExchange:
         if self._pending_rows is not None:
             work, stage, install, _ = self._pending_rows
             self._pending_rows = None
-            if self.direct is not None:
-                torch.cuda.current_stream(stage.device).wait_event(work)
-            else:
+            if work is not None:
                 work.wait()                   # NCCL: orders the current stream behind the collective, no host block
             install(stage)
 
