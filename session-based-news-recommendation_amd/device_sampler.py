@@ -183,7 +183,17 @@ class DeviceSampler:
         need = self._feed_need(K)
         ch = max(1, int(self.CHUNK))
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(self.dev)
+            # (diagnostic, round 6: TCAR_SAMPLER_STREAM=third | aux forms the chunks on one of the engine's own side streams instead of
+            #  a stream of the sampler's — one stream less for HIP to map onto its hardware queues)
+            which = os.environ.get("TCAR_SAMPLER_STREAM", "")
+            borrowed = None
+            if which in ("third", "aux"):
+                try:
+                    self.eng._ctx()
+                    borrowed = getattr(self.eng, "_aux3" if which == "third" else "_aux", None)
+                except Exception:
+                    borrowed = None
+            self._side = borrowed if borrowed is not None else torch.cuda.Stream(self.dev)
             self._ev_ready = [torch.cuda.Event(), torch.cuda.Event()]
             self._ev_free = [torch.cuda.Event(), torch.cuda.Event()]
         if getattr(self, "_feeds", None) is None or self._feeds[0].numel() < need * ch:

@@ -180,6 +180,11 @@ class DPEngine(TcarEngine):
     flag_forks = False   # (the gradient exchange is enqueued inside the fused backward: event forks)
 
     def __init__(self, *a, group=None, force_collectives=None, direct_rccl=None, **kw):
+        import os
+        live = dist.is_available() and dist.is_initialized()
+        fc = force_collectives if force_collectives is not None else bool(int(os.environ.get("TCAR_FORCE_COLLECTIVES", "0") or 0))
+        if live and (dist.get_world_size(group) > 1 or fc):
+            self.priority_stream = False          # (TcarEngine.priority_stream: no priority stream beside live collectives)
         super().__init__(*a, **kw)
         self.group = group
         self.xch = GradExchange(group, force=force_collectives, direct=direct_rccl)

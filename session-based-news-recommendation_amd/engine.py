@@ -141,7 +141,7 @@ class TcarEngine:
             raise _lib.TcarError("TcarEngine needs an MI355X (no CPU fallback)")
         self.dev = torch.device(device)
         self.is_cuda = self.dev.type == "cuda"
-        if self.is_cuda and self.overlap and self.native and not os.environ.get("TCAR_NO_PRIO"):
+        if self.is_cuda and self.overlap and self.native and self.priority_stream and not os.environ.get("TCAR_NO_PRIO"):
             use_priority_stream(self.dev)
         N, H = content_emb.shape[0] - 1, content_emb.shape[1]
         Ht = params["month_embedding"].shape[1]
@@ -899,6 +899,11 @@ class TcarEngine:
         return c
 
     flag_forks = True    # may this engine class fork / join its streams through device flags (see _ctx)
+    # does the engine make a process-wide high-priority stream the current one (use_priority_stream)?  The data-parallel engines
+    # switch it off while collectives are live: with RCCL's copies / kernels on a priority stream AND the device sampler forming
+    # batches on its normal-priority side stream, the step ran at 1.39 ms instead of 0.74 (round 6, one rank, every collective
+    # forced: profiles/r06_ab_experiments.txt section 4)
+    priority_stream = True
     _ev = None
     tune = None          # optional _lib.Tuning copy of THIS engine (set_tuning); None = the process-wide switch values
 

@@ -179,13 +179,15 @@ class ShardExchange:
         table into place once the collective has landed (wait_rows)"""
         if not self.collective:
             return
-        mine = stage[self.rank].reshape(-1).clone()
         if self.direct is not None:
             # on the step's own stream: nothing of this rank runs between the update and the next step's gathers, which need the
-            # rows anyway — a side stream would buy no overlap and cost a hardware queue (see __init__)
+            # rows anyway — a side stream would buy no overlap and cost a hardware queue (see __init__).  IN PLACE: this rank's rows
+            # already sit in their slot of the gathered table (RCCL: sendbuff == recvbuff + rank * sendcount), no staging copy
+            mine = stage[self.rank].reshape(-1)
             self._timed("item_rows (issue)", stage, lambda: self.direct[0].all_gather(mine, stage.view(-1)))
             work = None
         else:
+            mine = stage[self.rank].reshape(-1).clone()
             work = self._timed("item_rows (issue)", stage,
                                lambda: dist.all_gather_into_tensor(stage.view(-1), mine, group=self.group, async_op=True))
         self._note("item_rows", stage)
@@ -342,6 +344,10 @@ class ShardedEngine(TcarEngine):
         # K than the single-rank GEMM, so the split that fills the chip (and the slab bytes it writes) shrinks with W
         if "splitk" not in kw and "TCAR_SPLITK" not in os.environ:
             kw["splitk"] = max(2, -(-36 // self.world))
+        if force_collectives is None:
+            force_collectives = bool(int(os.environ.get("TCAR_FORCE_COLLECTIVES", "0") or 0))
+        if live and not self._sim and (self.world > 1 or force_collectives):
+            self.priority_stream = False          # (TcarEngine.priority_stream: no priority stream beside live collectives)
         super().__init__(params, content_emb, mwdhm, lr=lr, max_grad=max_grad, neg_weight=neg_weight, device=device,
                          scoring=scoring, shard=(n0, nl), **kw)
         self.n0, self.nl = n0, nl
