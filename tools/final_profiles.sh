@@ -5,6 +5,7 @@
 #       gpurun --timeout 3000 -- 'bash tools/final_profiles.sh part2'      PMC packs, data-parallel code paths, the 10 M-item configuration
 #   then, in the build container:  python tools/collect_profiles.py r06    copies gpurun_out/final_* to profiles/r06_* (and README rows)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
+python -c "import __graft_entry__ as g; g.build()" 2>&1 | tail -1
 S="bash tools/gpu_session.sh final"
 # (timelines: a step in the MIDDLE of a sampler chunk — under the tracer the host is barely ahead of the device, and the step in which it
 #  launches the next chunk of 16 batches shows that as a gap)
