@@ -67,6 +67,8 @@ struct BArgs {
   // not stored — per catalog row n and table k the kernel leaves q = ||gy||^2 and z = clip(table row) . gy of the 64-column
   // gradient gy = dE[n, csplit + 64 k ...] at qz[perm[k * M + n]] (perm: position in the inverted index of publish_time_MWDHM)
   const int32_t* mwdhm; const float* tclip; float2* qz;
+  // START flag (TcarOpt::start): workgroup 0 publishes start_epoch as its first action
+  unsigned* start_flag; unsigned start_epoch;
 };
 // rows of the month | day | week | hour | minute tables (model_combine.py:73-81) inside their concatenation
 __device__ __forceinline__ int cand_row(const int32_t* __restrict__ mwdhm, long n, int k) {
@@ -144,6 +146,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WNW, wn = wave - wm * WNW;
+  if (EPI == 0 && g.start_flag && blockIdx.x == 0 && tid == 0)
+    __hip_atomic_store(g.start_flag, g.start_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // 1-D grid over (split, tile): the bijective XCD remap hands each XCD a contiguous run of logical ids, and the
   // tile order inside the run is chosen by the caller so that the workgroups which re-read the SAME large operand
@@ -853,6 +857,7 @@ int tcar_gemm_bf16_dx_onehot_o(int M, int N1, int K, const void* A_hi, int64_t a
   g.mode = splitk > 1 ? 1 : 0;
   g.nsk = splitk;
   g.n_fastest = 1;
+  if (o && o->start.flag) { g.start_flag = o->start.flag; g.start_epoch = o->start.epoch; o->started = true; }
   LaunchCall lc;
   lc.o = o;
   return launch_b<0, 1>(g, 1, splitk, (hipStream_t)stream, lc);

@@ -169,14 +169,16 @@ __global__ __launch_bounds__(64) void poll_flag_kernel(const unsigned* flag, uns
     if (err_host) __hip_atomic_fetch_add(err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
-// slots (bits of TCAR_FLAG_FORK).  Two forks of the step — early Adam -> candidate refresh, softmax -> dE — stay events: with a
-// flag the step is slower in every form tried (write-through producers, start-of-kernel flags, delayed polls:
-// profiles/r03_ab_experiments.txt).  The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits
+// slots (bits of TCAR_FLAG_FORK).  The early Adam -> candidate refresh fork stays an event: with a flag the step is slower in every
+// form tried (write-through producers, delayed polls: profiles/r03_ab_experiments.txt).  The softmax -> dE fork is the START flag of
+// the dX GEMM since round 6 (slot 8: neutral in round 3's longer step, -6.5 us per step now: profiles/r06_ab_experiments.txt section 10).  The logits -> arena-zero fork is a DELAYED flag fork: its consumers read nothing the logits
 // GEMM writes, and held back TCAR_FORK_DELAY us behind the GEMM's end they start when the event released them, while the main
 // stream records nothing.
 // (slots 8, 10 and 11 — negative term -> slab reduce, pool backward -> fused click-query backward and its join — were retired in round 6
 //  with the forms that used them; the numbering of the others, which TCAR_FLAG_FORK masks, is unchanged)
-enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_LOGITS = 9 };
+// (slot 8 since: the dX GEMM's START flag — softmax gradient -> dE's stream without an event record between the softmax finish and dX)
+enum { FK_TAIL2 = 0, FK_PROJ = 1, FK_TAIL3 = 2, FK_REDUCE = 3, FK_INGRAD = 4, FK_DCLICK = 5, FK_GATHER = 6, FK_QUERY = 7, FK_DXSTART = 8,
+       FK_LOGITS = 9 };
 // (a thirteenth slot, softmax gradient -> dE's stream with the plane stored write-through, measured +17 .. +21 us in rounds 3 and 4: removed)
 // host-side fork state of ONE context (tcar_ctx_t.fork_host: caller-owned, zeroed, tcar_fork_state_bytes() bytes)
 struct ForkSlot { TcarSignal sig; uint32_t live; uint32_t pad; };     // live: the launch armed last for this slot carries sig
@@ -767,7 +769,14 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
   // (forking dE behind dX instead — dX then runs without dE beside it — was re-measured in round 4: dX is no faster alone, dE ends
   //  13 us later: 0.529 vs 0.516 ms per step, profiles/r04_ab_experiments.txt)
-  if (s2 && (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
+  // dE (aux stream) reads the softmax gradient the launch above has just written.  One-hot schedule with flag forks: dX is launched
+  // FIRST and carries a START flag — a dX workgroup that runs has the softmax finish behind it, complete and released — and the aux
+  // stream polls that word: no event record between the softmax finish and dX on the main chain (round 6: ~7 us of it, median, in
+  // profiles/r05_main_stream_gaps.txt), no write-through plane (the round-3/4 form that lost: slot 12).  Else: an event.
+  TcarSignal dx_start{};
+  if (ohb && s2 && sB != stream) dx_start = fork_arm(c, FK_DXSTART);
+  if (!dx_start.flag && s2 &&
+      (hipEventRecord((hipEvent_t)c->ev[2], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[2], 0) != hipSuccess))
     return TCAR_E_LAUNCH;
   // ---- chain B  (when it runs on the main stream it is the first user of the aux stream's prologue there)
   if (s2 && sB == stream && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
@@ -814,8 +823,10 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     tick(1, false, stream);
     if (ohb) {
       TcarOpt ox = opt_of(c);
+      ox.start = dx_start;
       RET(tcar_gemm_bf16_dx_onehot_o(B, g.ic, g.Npad, c->dl16h, g.Npad, B, c->e16h, g.ek, g.Npad, c->oh16, 160, c->slabs, g.ic + 160,
                                      c->splitk, stream, &ox));
+      if (dx_start.flag && !ox.started) return TCAR_E_ARG;      // (every form of this launcher publishes the start flag)
     } else if (c->scoring) {
       TcarOpt ox = opt_of(c);
       RET(tcar_gemm_bf16_perm_o(0, B, g.ek, g.Npad, c->dl16h, c->dl16l, g.Npad, B, c->e16h, c->e16l, g.ek, g.Npad, c->slabs, g.ek,
@@ -826,6 +837,13 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     tick(1, true, stream);
     return TCAR_OK;
   };
+  if (dx_start.flag) {
+    // dX first (it carries the start flag), then the aux stream's poll in front of dE
+    RET(chain_a_dx());
+    TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, s2, (const unsigned*)dx_start.flag, dx_start.epoch, c->sig_dev + TCAR_SIG_ERR,
+                c->sig_err_host, POLL_TICKS, (const unsigned*)nullptr, 0u, 0);
+    TCAR_CHECK_LAUNCH();
+  }
   RET(chain_b());
   // negative rows of the item gradient (sorted sum) + the loss: they need dE's item block and nothing of the main chain — on
   // the third stream (idle until the weight gradients) the moment dE lands, instead of on the main chain behind its small GEMMs
@@ -838,7 +856,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     if (hipEventRecord((hipEvent_t)c->ev[3], s3n) != hipSuccess) return TCAR_E_LAUNCH;
   }
   // ---- chain A
-  RET(chain_a_dx());
+  if (!dx_start.flag) RET(chain_a_dx());
   // first use of the zeroed arena and of the negative term's forward outputs on the main stream
   if (s2 && hipStreamWaitEvent(st, (hipEvent_t)c->ev[1], 0) != hipSuccess) return TCAR_E_LAUNCH;
   // (Round 3 A/B: letting the chain of small kernels behind dX wait until dE has finished — every one of them runs ~2x slower
@@ -1320,7 +1338,21 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
     RET(tcar_softmax_combine_rowstat(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, w.rowstat, stream));
     RET(tcar_ce_rescale(Bq, nl, c->ce_geo[0], c->ce_geo[1], w.stats, w.rowstat, s->lab_all, s->n0, 1, s->dl16h, nlpad, stream));
     hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
-    if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+    // dE (aux stream) behind the rescale: through the START flag of dX where the context has flag forks (backward_impl: no event
+    // record between the rescale and dX on this chain, which heads for the dX exchange), else an event.  Both the rescale and dX are
+    // local work of this rank — no collective sits between the poll and its producer.
+    TcarSignal dx_start{};
+    if (s2) dx_start = fork_arm(c, FK_DXSTART);
+    TcarOpt ox = opt_of(c);
+    ox.start = dx_start;
+    if (dx_start.flag) {
+      RET(tcar_gemm_bf16_dx_onehot_o(Bq, g.ic, nlpad, s->dl16h, nlpad, Bq, c->e16h, g.ek, nlpad, c->oh16, 160, s->slabs, g.ic + 160,
+                                     c->splitk, stream, &ox));
+      if (!ox.started) return TCAR_E_ARG;
+      TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, s2, (const unsigned*)dx_start.flag, dx_start.epoch, c->sig_dev + TCAR_SIG_ERR,
+                  c->sig_err_host, POLL_TICKS, (const unsigned*)nullptr, 0u, 0);
+      TCAR_CHECK_LAUNCH();
+    } else if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
       return TCAR_E_LAUNCH;
     TcarOpt ob = opt_of(c);
     // (a short shard leaves the 192-row tiles too few workgroups for the chip: 128-row tiles then)
@@ -1329,9 +1361,9 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
     const int tile = (forced == 256 || forced == 128 || forced == 64) ? forced : (((nl + 191) / 192) * 3 < 200 ? 128 : 0);
     RET(tcar_gemm_bf16_de_qz_o(nl, (Bq + 31) & ~31, s->dl16h, nlpad, Bp, s->ap16h, g.ldh + g.pt, Bp, g.ldh, c->big, g.ldh, c->mwdhm,
                                c->et_perm, c->tclip, c->qz, tile, s2 ? (void*)s2 : stream, &ob));
-    TcarOpt ox = opt_of(c);
-    RET(tcar_gemm_bf16_dx_onehot_o(Bq, g.ic, nlpad, s->dl16h, nlpad, Bq, c->e16h, g.ek, nlpad, c->oh16, 160, s->slabs, g.ic + 160,
-                                   c->splitk, stream, &ox));
+    if (!dx_start.flag)
+      RET(tcar_gemm_bf16_dx_onehot_o(Bq, g.ic, nlpad, s->dl16h, nlpad, Bq, c->e16h, g.ek, nlpad, c->oh16, 160, s->slabs, g.ic + 160,
+                                     c->splitk, stream, &ox));
     const int S1 = tcar_gemm_splitk_effective(nlpad, c->splitk);
     TcarOpt orr = opt_of(c);
     if (s2) orr.sig = fork_arm(c, FK_REDUCE);          // (dP leaves write-through when the launch carries the flag)

@@ -110,6 +110,12 @@ struct TcarOpt {
   TcarSignal sig{};
   bool carried = false;
   TcarWait wait{};       // a flag the launch waits for IN the kernel (launchers that support it: the one-hot slab reduce)
+  // START flag (round 6): the kernel's first workgroup publishes `start.epoch` to *start.flag as its first action.  A kernel that has
+  // started has every predecessor of its stream behind it, COMPLETE and released — so a side stream that polls this word is ordered
+  // behind the PREDECESSOR of this launch without an event record on this stream (6.5 us between two kernels) and without write-through
+  // stores in the predecessor.  Launchers that support it (the one-hot dX GEMM) set `started`.
+  TcarSignal start{};
+  bool started = false;
   // label window of the softmax-epilogue logits GEMM (catalog-sharded step): the column of row m's label is label[m] - lab_off,
   // and a label outside [0, N) is in another shard — no label score is written for it (lab_window = 0: labels are clamped)
   int lab_off = 0, lab_window = 0;
