@@ -56,7 +56,10 @@ typedef tcar_tuning_t TcarTuning;
 namespace tcar_fixed {
 constexpr int rest_grid = 512;     // grid cap of the deferred Adam rest pass (it runs beside the next step's session forward)
 constexpr int fork_delay = 7;      // us the aux prologue's flag fork holds its consumer back behind the end of the logits GEMM
-constexpr int x3_oneshot = 4;      // small-GEMM launches of at most this many 64-deep stages per workgroup keep two stages in flight
+#ifndef TCAR_FIX_X3_ONESHOT
+#define TCAR_FIX_X3_ONESHOT 4      // (diagnostic builds override it: tools/micro/build_x3ring.sh)
+#endif
+constexpr int x3_oneshot = TCAR_FIX_X3_ONESHOT;      // small-GEMM launches of at most this many 64-deep stages per workgroup keep two stages in flight
 constexpr int gather_wg = 2;       // 1024-thread workgroups per CU of the gather's throughput form (2 x 78 KB of LDS fit)
 }  // namespace tcar_fixed
 const TcarTuning& tcar_tuning();
