@@ -1338,22 +1338,12 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
     RET(tcar_softmax_combine_rowstat(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, w.rowstat, stream));
     RET(tcar_ce_rescale(Bq, nl, c->ce_geo[0], c->ce_geo[1], w.stats, w.rowstat, s->lab_all, s->n0, 1, s->dl16h, nlpad, stream));
     hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
-    // dE (aux stream) behind the rescale: through the START flag of dX where the context has flag forks (backward_impl: no event
-    // record between the rescale and dX on this chain, which heads for the dX exchange), else an event.  Both the rescale and dX are
-    // local work of this rank — no collective sits between the poll and its producer.
-    TcarSignal dx_start{};
-    if (s2) dx_start = fork_arm(c, FK_DXSTART);
-    TcarOpt ox = opt_of(c);
-    ox.start = dx_start;
-    if (dx_start.flag) {
-      RET(tcar_gemm_bf16_dx_onehot_o(Bq, g.ic, nlpad, s->dl16h, nlpad, Bq, c->e16h, g.ek, nlpad, c->oh16, 160, s->slabs, g.ic + 160,
-                                     c->splitk, stream, &ox));
-      if (!ox.started) return TCAR_E_ARG;
-      TCAR_LAUNCH(poll_flag_kernel, dim3(1), dim3(64), 0, s2, (const unsigned*)dx_start.flag, dx_start.epoch, c->sig_dev + TCAR_SIG_ERR,
-                  c->sig_err_host, POLL_TICKS, (const unsigned*)nullptr, 0u, 0);
-      TCAR_CHECK_LAUNCH();
-    } else if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
+    // dE (aux stream) behind the rescale through an EVENT, dE launched first.  (backward_impl orders dE behind dX's START flag instead;
+    // here that form — dX first, the poll, then dE — measured 14 us per step SLOWER on the one-rank shard, 0.548 against 0.534 ms in
+    // 4 of 4 interleaved rounds, and neutral at the 8-rank shape: profiles/r06_ab_experiments.txt section 13.)
+    if (s2 && (hipEventRecord((hipEvent_t)c->ev[0], st) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
       return TCAR_E_LAUNCH;
+    TcarOpt ox = opt_of(c);
     TcarOpt ob = opt_of(c);
     // (a short shard leaves the 192-row tiles too few workgroups for the chip: 128-row tiles then)
     const int forced = tn(c).bf16_tile;
@@ -1361,9 +1351,8 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
     const int tile = (forced == 256 || forced == 128 || forced == 64) ? forced : (((nl + 191) / 192) * 3 < 200 ? 128 : 0);
     RET(tcar_gemm_bf16_de_qz_o(nl, (Bq + 31) & ~31, s->dl16h, nlpad, Bp, s->ap16h, g.ldh + g.pt, Bp, g.ldh, c->big, g.ldh, c->mwdhm,
                                c->et_perm, c->tclip, c->qz, tile, s2 ? (void*)s2 : stream, &ob));
-    if (!dx_start.flag)
-      RET(tcar_gemm_bf16_dx_onehot_o(Bq, g.ic, nlpad, s->dl16h, nlpad, Bq, c->e16h, g.ek, nlpad, c->oh16, 160, s->slabs, g.ic + 160,
-                                     c->splitk, stream, &ox));
+    RET(tcar_gemm_bf16_dx_onehot_o(Bq, g.ic, nlpad, s->dl16h, nlpad, Bq, c->e16h, g.ek, nlpad, c->oh16, 160, s->slabs, g.ic + 160,
+                                   c->splitk, stream, &ox));
     const int S1 = tcar_gemm_splitk_effective(nlpad, c->splitk);
     TcarOpt orr = opt_of(c);
     if (s2) orr.sig = fork_arm(c, FK_REDUCE);          // (dP leaves write-through when the launch carries the flag)
