@@ -51,5 +51,13 @@ case $1 in
     for T in 10 40; do bash tools/trace_T40.sh $T > /dev/null; cp gpurun_out/T40_timeline.txt gpurun_out/final_timeline_T$T.txt; cp gpurun_out/T40_kernel_stats.txt gpurun_out/final_kernel_stats_T$T.txt; done
     $S "bench:stress10m:--config stress10m --steps 10 --warmup 2 --no_cpu_baseline --no_e2e"
     ;;
-  *) echo "usage: $0 part1|part1_benches|part2|traces" ;;
+  sharded)      # only what the catalog-sharded code path touches (after a change confined to tcar_shard_*)
+    python -m pytest tests -q -m gpu -k "sharded or rccl or dp" 2>&1 | tail -3 | tee gpurun_out/final_tests_sharded.txt
+    $S "bench:dp1rank_sharded:TCAR_FORCE_DP=1 --dp_mode sharded --no_cpu_baseline --no_e2e"
+    for w in 2 4 8; do $S "bench:sharded_simworld$w:TCAR_FORCE_DP=1 TCAR_SIM_WORLD=$w --dp_mode sharded --no_cpu_baseline --no_e2e"; done
+    $S "bench:2ranks_one_gpu_gloo_sharded:--gpus 2 --same_device --backend gloo --dp_mode sharded --steps 30 --no_cpu_baseline --no_e2e"
+    $S "bench:dp1rank_sharded_rccl_direct:TCAR_FORCE_COLLECTIVES=1 --dp_mode sharded --no_cpu_baseline --no_e2e" "bench:dp1rank_sharded_rccl_pg:TCAR_FORCE_COLLECTIVES=1 TCAR_RCCL_DIRECT=0 --dp_mode sharded --no_cpu_baseline --no_e2e"
+    traces2
+    ;;
+  *) echo "usage: $0 part1|part1_benches|part2|sharded|traces" ;;
 esac
