@@ -56,7 +56,10 @@ typedef struct {
   int32_t mha_mfma;         /* TCAR_MHA_MFMA       0: multihead_attention core always in its scalar form */
   int32_t sort_scatter;     /* TCAR_SORT_SCATTER   0: item-row scatter with float atomics instead of the sorted segmented sum */
   int32_t det_small;        /* TCAR_DET_SMALL      0: position / time / dwell table gradients through LDS + float atomics (sorted mode) */
-  int32_t fused_ce;         /* TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel */
+  int32_t fused_ce;         /* TCAR_FUSED_CE       0: training steps materialise the fp32 logits and run the row-resident softmax kernel;
+                                                   1: softmax epilogue with group maxima + the rescale pass over the plane (tcar_ce_finish);
+                                                   2 (default): ANCHORED epilogue where the step's form allows it (tcar_ce_anchor_fold: no
+                                                   pass over the plane), else as 1 */
   int32_t onehot_time;      /* TCAR_ONEHOT_TIME    0: the scoring GEMMs of a training step contract the 5 ldt clipped candidate time columns instead of the 160-column one-hot form */
   int32_t flag_fork;        /* TCAR_FLAG_FORK      mask over the fork slots: 0 = every fork of the main stream records an event (6-7 us of
                                                    bubble on it) instead of letting the producing kernel publish a device flag a polling
@@ -332,6 +335,32 @@ int tcar_time_scores_clip(const tcar_dims_t* d, const float* const time_tab[5], 
                           void* p_hi, void* p_lo, int64_t inner, float* tclip, void* stream);
 int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                    float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream);
+/* ANCHORED form of the softmax epilogue + finish (round 6).  When the logits GEMM is handed a per-row reference a[b] (the fused step:
+ * the label's score up to rounding, from the forward pass's finishing launch) its plane is exp(x - a[b]) and every group's statistic
+ * is (a[b], sum): all groups of a row share ONE scale, and the plane never needs the rescale pass.  tcar_ce_anchor_fold (one wave per
+ * row; B a multiple of 128) folds the group sums in a fixed order: S_b, lse = a + log S_b, ce = lse - lab_logit; writes
+ * rowstat[b] = (a, 1 / S_b) (may be NULL); puts the label's -1 into the plane as v = bf16(e_l - S_b); writes
+ * scale2[b] = (1 / S_b, ((e_l - S_b) - v) / S_b) for the consumer that is linear in the plane's rows (the slab reduce of dX,
+ * tcar_reduce_dact_onehot_scaled: softmax part scaled exactly, the one-hot's rounding residual added back in fp32); and writes
+ * aps = bf16((ap_hi + ap_lo)[b, :] / S') with S' = e_l - v, the per-row scaled copy of the packed attout planes [B, ap_cols]
+ * (inner ap_inner) that the dE GEMM contracts the UNSCALED plane with — v / S' = e_l / S' - 1 exactly: the one-hot part of dE is
+ * exact, the rounding of v becomes a common factor 1 +- 2^-8 on the row's softmax part.  S_b >= ~1 by construction of the anchor; a
+ * term overflows only where a logit exceeds the label's score by more than 88 (a per-session loss > 88). */
+int tcar_ce_anchor_fold(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
+                        float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner, const void* ap_hi, const void* ap_lo,
+                        void* aps_hi, int ap_cols, int64_t ap_inner, void* stream);
+/* tcar_gemm_bf16_ce with the anchored epilogue: anchor [M, anchor_n] partial sums of the row's reference (added in index order) */
+int tcar_gemm_bf16_ce_anchor(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
+                             const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, int K1, const void* A2_hi,
+                             const void* A2_lo, const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner, int64_t p_rows,
+                             float* stats, int64_t stats_floats, const int32_t* label, float* lab_logit, int nsplit,
+                             int32_t* group_width, int32_t* ngroups, const float* anchor, int anchor_n, void* stream);
+/* tcar_reduce_dact_onehot for the anchored form: the slab sums (and dP) of row m times scale2[m].x, plus scale2[m].y times
+ * [E[label[m], 0 .. ic) | onehot(mwdhm[label[m]])] (E: fp32 candidate rows [n_items, ldE]), in front of the addend; no bias column sums */
+int tcar_reduce_dact_onehot_scaled(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
+                                   const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo, float* dP,
+                                   const float* scale2, const int32_t* label, const float* E, int64_t ldE, const int32_t* mwdhm,
+                                   int n_items, void* stream);
 /* The two halves of tcar_ce_finish for the catalog-sharded step (sharded.py), where the row statistics cross the ranks in between:
  *   tcar_ce_shard_stats  out3[b] = (max, sum exp(x - max), label score) of THIS shard's columns from the epilogue's per-group pairs;
  *                        the label score is 0 unless label[b] lies in [n0, n0 + n_loc)  (= tcar_softmax_stats without the logits)
@@ -676,7 +705,7 @@ int tcar_shard_pack_ids(int64_t n_live, int64_t n_total, int ldh, const int32_t*
                         const float* ce, const float* neg_fb, float weight, float* loss, void* stream);
 
 /* bumped whenever a struct layout or a signature in this header changes; the loader refuses a mismatch */
-#define TCAR_ABI_VERSION 28
+#define TCAR_ABI_VERSION 29
 int tcar_abi_version(void);
 /* hex digest of the sources this binary was compiled from (every .hip and .h under csrc, and this header): loaders compare it with the
  * digest of the sources they sit next to, so a stale binary is detected ("unknown" when built without the in-tree builder) */
@@ -783,6 +812,12 @@ typedef struct {
    * (B * T >= 2,048) splits every table row's sources into chunks with a workgroup each (tcar_small_tables_bwd_det); without it the
    * step keeps the row pieces in the tail of segsum_ws and one workgroup per table row */
   float* small_det_ws; int64_t small_det_ws_floats;
+  /* optional buffers of the ANCHORED softmax form (fused training steps in the one-hot form with B a multiple of 128;
+   * TCAR_FUSED_CE = 2; tcar_ce_anchor_fold): ce_anchor [B, 2 ldh / 64] partial label scores written by the forward pass's
+   * finishing launch, ce_rowscale [B, 2] = (1 / S_b, one-hot residual), aps16h = the packed attout plane scaled per row, [ceil128(B), ldh + 5 ldt] bf16
+   * (KB32), ce_form = ONE host int that carries the form the forward half of a step chose to its backward half.  With them a
+   * step's plane of exponentials is never rescaled: 94 MB of traffic and one [B, N] pass less per step at the Globo shape. */
+  float* ce_anchor; float* ce_rowscale; void* aps16h; int32_t* ce_form /*host*/;
 } tcar_ctx_t;
 
 /* Probe before setting tcar_ctx_t.sig_dev: does a polling kernel on `side_stream` run beside a kernel enqueued BEHIND it on
@@ -815,8 +850,9 @@ int tcar_train_step_deferred(const tcar_ctx_t* c, const tcar_batch_t* bt, int re
                              void* stream);
 /* The form a fused training step of `bt` takes on this context — the driver's own predicates, nothing is launched: form[0] softmax
  * epilogue in the logits GEMM (no fp32 logits), form[1] one-hot time segment in the logits GEMM, form[2] one-hot form of the two
- * scoring-gradient GEMMs, form[3] order-fixed (sorted) item-row sum.  For tools that label measurements (bench.py). */
-int tcar_step_form(const tcar_ctx_t* c, const tcar_batch_t* bt, int32_t* form /*host, 4 ints*/);
+ * scoring-gradient GEMMs, form[3] order-fixed (sorted) item-row sum, form[4] anchored softmax form (tcar_ce_anchor_fold: no rescale
+ * pass).  For tools that label measurements (bench.py). */
+int tcar_step_form(const tcar_ctx_t* c, const tcar_batch_t* bt, int32_t* form /*host, 5 ints*/);
 /* rank [B], topk [B,k], ce [B] (the logits buffer is consumed) */
 int tcar_eval_step(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, int k, void* stream);
 

@@ -22,10 +22,10 @@ NVAR = 22
 NSLOT = 32
 
 # every symbol include/tcar_hip.h declares
-ABI_VERSION = 28          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
+ABI_VERSION = 29          # == TCAR_ABI_VERSION of include/tcar_hip.h (struct mirrors below)
 
 SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_rows", "tcar_cand_time_fwd", "tcar_cand_time_bwd_indexed", "tcar_cand_time_ws_floats", "tcar_cand_time_bwd",
-           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_ce_shard_stats", "tcar_ce_rescale", "tcar_time_onehot", "tcar_time_scores", "tcar_time_scores_clip", "tcar_attout_finish_scores", "tcar_gemm_bf16_dx_onehot", "tcar_gemm_bf16_dx_onehot_tuned", "tcar_reduce_dact_onehot", "tcar_gemm_bf16_de_qz", "tcar_cand_time_bwd_onehot", "tcar_query_mlp", "tcar_query_mlp_bwd", "tcar_flag_fork_selftest", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
+           "tcar_gemm_f32", "tcar_gemm_f32_grouped", "tcar_gemm_x3_grouped", "tcar_gemm_bf16", "tcar_gemm_bf16_perm", "tcar_gemm_bf16_variant", "tcar_gemm_bf16_ce", "tcar_ce_finish", "tcar_ce_anchor_fold", "tcar_gemm_bf16_ce_anchor", "tcar_reduce_dact_onehot_scaled", "tcar_ce_shard_stats", "tcar_ce_rescale", "tcar_time_onehot", "tcar_time_scores", "tcar_time_scores_clip", "tcar_attout_finish_scores", "tcar_gemm_bf16_dx_onehot", "tcar_gemm_bf16_dx_onehot_tuned", "tcar_reduce_dact_onehot", "tcar_gemm_bf16_de_qz", "tcar_cand_time_bwd_onehot", "tcar_query_mlp", "tcar_query_mlp_bwd", "tcar_flag_fork_selftest", "tcar_split_bf16", "tcar_splitk_reduce", "tcar_gemm_splitk_effective", "tcar_attn_pool_fwd",
            "tcar_attn_pool_bwd", "tcar_attn_pool_bwd_q", "tcar_softmax_ce", "tcar_neg_term", "tcar_neg_fwd", "tcar_neg_scatter", "tcar_splitk_reduce_dact",
            "tcar_dact_colsum", "tcar_rank_topk", "tcar_eval_rows", "tcar_eval_diversity",
            "tcar_sqnorm", "tcar_clip_adam", "tcar_clip_adam_2d", "tcar_clip_adam_2d_bf16", "tcar_cand_time_fwd_bf16", "tcar_softmax_ce_bf16",
@@ -223,7 +223,8 @@ class Ctx(C.Structure):
                    ("tclip", C.c_void_p), ("dP", C.c_void_p), ("qz", C.c_void_p),
                    ("sig_dev", C.c_void_p), ("fork_host", C.c_void_p), ("sig_err_host", C.c_void_p), ("tune", C.c_void_p),
                    ("fold_scratch", C.c_void_p), ("fold_scratch_words", C.c_int32),
-                   ("small_det_ws", C.c_void_p), ("small_det_ws_floats", C.c_int64)])
+                   ("small_det_ws", C.c_void_p), ("small_det_ws_floats", C.c_int64),
+                   ("ce_anchor", C.c_void_p), ("ce_rowscale", C.c_void_p), ("aps16h", C.c_void_p), ("ce_form", C.c_void_p)])
 
 
 TUNING_FIELDS = ["bf16_tile", "bf16_ks", "wgrad_ks", "gather_big_rows", "mha_mfma", "sort_scatter", "det_small", "fused_ce", "onehot_time",
@@ -339,6 +340,10 @@ def load() -> C.CDLL:
     lib.tcar_gemm_bf16_de_qz.argtypes = [i32, i32, vp, i64, i64, vp, i64, i64, i32, vp, i64, vp, vp, vp, vp, i32, vp]
     lib.tcar_cand_time_bwd_onehot.argtypes = [P(Dims), i32, vp, vp, vp, vp, i64, vp, vp, P(Grads), vp]
     lib.tcar_ce_finish.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.tcar_ce_anchor_fold.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i64, vp]
+    lib.tcar_gemm_bf16_ce_anchor.argtypes = [i32, i32, i32, vp, vp, i64, i64, vp, vp, i64, i64, i32, vp, vp, vp, i64, vp, i64, i64, vp, i64,
+                                             vp, vp, i32, vp, vp, vp, i32, vp]
+    lib.tcar_reduce_dact_onehot_scaled.argtypes = [vp, i32, i32, i32, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, i32, vp]
     lib.tcar_ce_shard_stats.argtypes = [i32, i32, vp, vp, vp, i32, i32, vp, vp]
     lib.tcar_ce_rescale.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, i64, vp]
     lib.tcar_layernorm_fwd.argtypes = [i64, i32, vp, vp, vp, f32, vp, vp, vp]

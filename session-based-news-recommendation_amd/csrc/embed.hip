@@ -644,6 +644,9 @@ struct FinishArgs {
   float* out; long ld_out;
   __bf16* a_hi; __bf16* a_lo; int a_in32;                 // planes of attout (may be NULL)
   __bf16* ap_hi; __bf16* ap_lo; int ap_in32;              // packed [item | time] planes (may be NULL)
+  // anchor of the anchored softmax epilogue (score.hip: ce_anchor_fold_kernel; may be NULL): per row and 64-column block of the
+  // item | content columns, the partial sum of attout[b, :] . E[label[b], :] — the label's score without its time part, in fp32
+  const int32_t* label; const float* E; long ldE; float* anchor;
 };
 __device__ __forceinline__ void store_planes4(__bf16* hi, __bf16* lo, long o, float4 y) {
   typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_f;
@@ -719,6 +722,12 @@ __global__ __launch_bounds__(256) void attout_finish_kernel(const FinishArgs a) 
         store_planes4(a.ap_hi, a.ap_lo, kb32_off(row, col < ldh ? col : col - (ic - ldh), a.ap_in32), yv);
     }
     if (scores) st4(xl + r * ls + c * 4, yv);
+    if (a.anchor && !timeblk) {          // (workgroup-uniform) one partial per (row, column block): a fixed 16-lane tree
+      float dl = 0.f;
+      if (row < a.s.B) dl = dot4(yv, ld4(a.E + (long)clampi(a.label[row], 0, a.s.d.n_items - 1) * a.ldE + col));
+      dl = group_sum(dl, 16);
+      if (c == 0 && row < a.s.B) a.anchor[row * (ic >> 6) + (y - 5)] = dl;
+    }
   }
   if (!scores) return;
   __syncthreads();
@@ -1574,6 +1583,17 @@ extern "C" int tcar_attout_finish_scores(const tcar_dims_t* d, const float* cons
                                          int nd_pt, int64_t stride, const float* bias_o, const float* bias_ot, float* attout,
                                          int64_t ld_out, void* a_hi, void* a_lo, int64_t a_inner, void* ap_hi, void* ap_lo,
                                          int64_t ap_inner, void* p_hi, void* p_lo, int64_t p_inner, float* tclip, void* stream) {
+  return tcar_attout_finish_scores_a(d, time_tab, B, slabs, nd_ic, nd_pt, stride, bias_o, bias_ot, attout, ld_out, a_hi, a_lo, a_inner,
+                                     ap_hi, ap_lo, ap_inner, p_hi, p_lo, p_inner, tclip, nullptr, nullptr, 0, nullptr, stream);
+}
+// ... + the anchor partials of the anchored softmax epilogue: anchor [B, 2 ldh / 64] (NULL: none); E [n_items, ldE] fp32 candidate
+// rows (item | content columns first), label [B] 0-based
+int tcar_attout_finish_scores_a(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* slabs, int nd_ic, int nd_pt,
+                                int64_t stride, const float* bias_o, const float* bias_ot, float* attout, int64_t ld_out, void* a_hi,
+                                void* a_lo, int64_t a_inner, void* ap_hi, void* ap_lo, int64_t ap_inner, void* p_hi, void* p_lo,
+                                int64_t p_inner, float* tclip, const int32_t* label, const float* E, int64_t ldE, float* anchor,
+                                void* stream) {
+  if (anchor && (!label || !E || ldE < 2 * d->ldh || (ldE & 3) || !tcar_aligned16(E))) return TCAR_E_ARG;
   if (check_dims(d) || d->ldt != 64 || (d->ldh & 63) || !time_tab || B <= 0 || !slabs || nd_ic <= 0 || nd_pt <= 0 || !bias_o || !bias_ot ||
       !attout || (ld_out & 3) || !tcar_aligned16(slabs) || !tcar_aligned16(attout) || (stride & 3))
     return TCAR_E_ARG;
@@ -1588,6 +1608,7 @@ extern "C" int tcar_attout_finish_scores(const tcar_dims_t* d, const float* cons
   a.out = attout; a.ld_out = (long)ld_out;
   a.a_hi = (__bf16*)a_hi; a.a_lo = (__bf16*)a_lo; a.a_in32 = (int)(a_inner >> 5);
   a.ap_hi = (__bf16*)ap_hi; a.ap_lo = (__bf16*)ap_lo; a.ap_in32 = (int)(ap_inner >> 5);
+  a.label = label; a.E = E; a.ldE = (long)ldE; a.anchor = anchor;
   const long Bp = p_hi ? (((long)B + 127) & ~127L) : (((long)B + 15) & ~15L);      // the score planes' padding rows are written (zeros)
   const size_t lds = ((size_t)(61 + 16) * 68 + 64) * sizeof(float);
   TCAR_LAUNCH(attout_finish_kernel, dim3((unsigned)(Bp / 16), 5 + 2 * d->ldh / 64), dim3(256), lds, (hipStream_t)stream, a);

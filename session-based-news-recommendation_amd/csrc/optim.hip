@@ -420,6 +420,7 @@ __global__ __launch_bounds__(256) void clip_adam_all_kernel(const AdamAll p, con
 struct AdamEarly {
   AdamAll p;
   const int32_t* ids; long n_ids; uint32_t* bitmap; int n_rowblk;
+  const int32_t* ids2; long n_ids2;      // a second list, 0-BASED rows (the batch's labels: step.hip, anchored softmax form); may be empty
 };
 __device__ __forceinline__ void clip_adam_early_body(const AdamEarly& e, const SegArgs& a) {
   const AdamAll& p = e.p;
@@ -431,8 +432,8 @@ __device__ __forceinline__ void clip_adam_early_body(const AdamEarly& e, const S
   }
   const int lane = threadIdx.x & 63;
   const long i = (long)blockIdx.x * 4 + (threadIdx.x >> 6);          // one wave per listed id
-  if (i >= e.n_ids) return;
-  long r = (long)e.ids[i] - 1;                                        // ids are 1-based item ids (sampler.py:67)
+  if (i >= e.n_ids + e.n_ids2) return;
+  long r = i < e.n_ids ? (long)e.ids[i] - 1 : (long)e.ids2[i - e.n_ids];      // ids are 1-based item ids (sampler.py:67), ids2 0-based rows
   r = r < 0 ? 0 : (r >= p.rows ? p.rows - 1 : r);
   unsigned old = 0;
   if (lane == 0) old = atomicOr(e.bitmap + (r >> 5), 1u << (r & 31));
@@ -611,13 +612,25 @@ extern "C" int tcar_clip_adam_early(float* w, const float* g, float* m, float* v
                                     const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
                                     void* e16_hi, void* e16_lo, int64_t ld16, const int32_t* ids, int64_t n_ids,
                                     uint32_t* bitmap, void* stream) {
-  if (check_segs(segs) || !w || !g || !m || !v || !bitmap || n_ids < 0 || (n_ids > 0 && !ids)) return TCAR_E_ARG;
+  return tcar_clip_adam_early_2(w, g, m, v, segs, w2d, ldw, g2d, m2d, v2d, rows, cols, slot, sqn_dense, sqn_pieces, use_dense, clip, lr_t,
+                                b1, b2, eps, e16_hi, e16_lo, ld16, ids, n_ids, nullptr, 0, bitmap, stream);
+}
+// ... with a second list of 0-BASED rows that join the early part (internal: the labels of the batch, whose rows the anchored
+// softmax form reads in the forward pass, before the rest pass has ended)
+int tcar_clip_adam_early_2(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,
+                           const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot, const float* sqn_dense,
+                           const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
+                           void* e16_hi, void* e16_lo, int64_t ld16, const int32_t* ids, int64_t n_ids, const int32_t* ids2,
+                           int64_t n_ids2, uint32_t* bitmap, void* stream) {
+  if (check_segs(segs) || !w || !g || !m || !v || !bitmap || n_ids < 0 || (n_ids > 0 && !ids) || n_ids2 < 0 || (n_ids2 > 0 && !ids2))
+    return TCAR_E_ARG;
   AdamEarly e;
   const int rc = fill_adam_all(e.p, w, g, m, v, segs, w2d, ldw, g2d, m2d, v2d, rows, cols, slot, sqn_dense, sqn_pieces,
                                use_dense, clip, lr_t, b1, b2, eps, e16_hi, e16_lo, ld16);
   if (rc) return rc;
   e.ids = ids; e.n_ids = n_ids; e.bitmap = bitmap;
-  e.n_rowblk = (int)((n_ids + 3) / 4);
+  e.ids2 = ids2; e.n_ids2 = n_ids2;
+  e.n_rowblk = (int)((n_ids + n_ids2 + 3) / 4);
   SegArgs a;
   a.s = *segs;
   const int grid = e.n_rowblk + e.p.gx * segs->nseg;

@@ -277,6 +277,70 @@ __global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32,
   ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits, lab_off, lab_window, sig.cnt != nullptr);
   tcar_signal_done(sig);        // (the body is a function: its early returns end up here)
 }
+// ---- ANCHORED form (round 6): the plane holds exp(x - anchor[b]) with ONE reference per row (tcar_gemm_bf16_ce_o with
+// TcarOpt::anchor), so a row's softmax is plane / S_b with S_b = the sum of its group sums, and NO pass over the [B, N] plane
+// follows the logits GEMM: this launch (one wave per session row) folds the row's group sums in a fixed order — lse = anchor + log S,
+// ce = lse - x_label — and prepares the two consumers, which scale PER ROW:
+//   * the label's -1 goes INTO the plane as v = bf16(e_l - S_b).  Rounded like that it carries the one-hot — the LARGEST term of a
+//     row's gradient while the softmax is flat — with up to 2^-8 relative error (measured: 1.6e-3 instead of 1e-4 norm-wise on the
+//     time-side gradients against the fp64 oracle), so the residual d = (e_l - S_b) - v is kept in fp32;
+//   * dX is linear in the plane's rows: its slab reduce multiplies by scale2[b].x = 1 / S_b and adds scale2[b].y = d / S_b times the
+//     label's candidate row in fp32 (TcarRowFix) — softmax part scaled exactly, one-hot part exact;
+//   * dE contracts over b, so the scale rides on attout's rows: aps[b, :] = bf16((ap_hi + ap_lo)[b, :] / S') with S' = e_l - v, for which
+//     v / S' = e_l / S' - 1 EXACTLY — the one-hot part of dE (and of its (q, z) pairs, which are not linear) is exact, the rounding of
+//     v becomes a common factor S_b / S' = 1 +- 2^-8 on the row's softmax part.
+// 94 MB of plane traffic and ~23 us of the step's critical chain become 0.6 MB and one small launch.  The anchor is the label's
+// score up to rounding (embed.hip: attout_finish_kernel), hence S_b >= ~1 (no underflow for any logits), and a term overflows only
+// where a logit exceeds the label's by > 88 — a per-session loss > 88.
+__global__ __launch_bounds__(256) void ce_anchor_fold_kernel(int B, int N, int in32, int ngroups, const float* __restrict__ stats,
+                                                             const float* __restrict__ lab_logit, const int32_t* __restrict__ label,
+                                                             float* __restrict__ rowstat, float* __restrict__ ce,
+                                                             float* __restrict__ scale2, __bf16* __restrict__ plane,
+                                                             const __bf16* __restrict__ ap_hi, const __bf16* __restrict__ ap_lo,
+                                                             __bf16* __restrict__ aps, int ap_cols, int ap_in32) {
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const float2* st = reinterpret_cast<const float2*>(stats) + b * ngroups;
+  // per lane: groups lane, lane + 64, ... in order; then the shuffle tree (a fixed order: the same bits in every run)
+  constexpr int NG = 8;
+  float s = 0.f;
+  if (ngroups <= 64 * NG) {
+    float2 pr[NG];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int g = lane + 64 * j;
+      pr[j] = g < ngroups ? st[g] : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) s += pr[j].y;
+  } else {
+    for (int g = lane; g < ngroups; g += 64) s += st[g].y;
+  }
+  s = wave_sum(s);
+  const float anchor = st[0].x;
+  const int lab = clampi(label[b], 0, N - 1);
+  __bf16* q = plane + kb32_off(b, lab, in32);
+  const float el = (float)*q;                     // (every lane: the same address, the same bits)
+  const float t = el - s;
+  const __bf16 v = (__bf16)t;
+  const float inv = 1.0f / s, inv_e = 1.0f / (el - (float)v);
+  if (lane == 0) {
+    if (rowstat) { rowstat[2 * b] = anchor; rowstat[2 * b + 1] = inv; }
+    ce[b] = anchor + logf(s) - lab_logit[b];
+    scale2[2 * b] = inv;
+    scale2[2 * b + 1] = (t - (float)v) * inv;
+    *q = v;                                       // (v depends on the wave's one load of the entry: it has returned for every lane)
+  }
+  for (int c = lane * 4; c < ap_cols; c += 256) {
+    const long o = kb32_off(b, c, ap_in32);
+    const bf16x4_s h = *reinterpret_cast<const bf16x4_s*>(ap_hi + o), l = *reinterpret_cast<const bf16x4_s*>(ap_lo + o);
+    bf16x4_s y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = (__bf16)(inv_e * ((float)h[j] + (float)l[j]));
+    *reinterpret_cast<bf16x4_s*>(aps + o) = y;
+  }
+}
 // ce_combine + ce_rescale in ONE launch (round 5; TCAR_CE_FOLD): a workgroup owns 16 session rows x one slice of the plane's
 // column blocks.  It folds ITS rows' (max, sum) pairs itself — ngroups * 8 bytes per row out of L2, the same lane-strided loops and
 // shuffle trees as ce_combine_kernel, so lse / ce / the scale come out in the same bits — and then streams its slice: a wave
@@ -639,11 +703,20 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
                                                                  const float* __restrict__ y, long ldy, const float* __restrict__ tclip,
                                                                  float* __restrict__ out, long ldo, float* __restrict__ dP,
                                                                  float* __restrict__ bg0, float* __restrict__ bg1, TcarSignal sig,
-                                                                 const TcarWait wait_add) {
+                                                                 const TcarWait wait_add, const TcarRowFix fix) {
   __shared__ float4 sh[256];           // (bias column sums only: the atomic mode)
   const int tid = threadIdx.x, cg = tid & 15, rp = tid >> 4;
   const int nic = ic >> 6;
   const int r0 = blockIdx.y * 16, row = r0 + rp;
+  // anchored softmax form (ce_anchor_fold_kernel, TcarRowFix): the slabs hold (unscaled plane) [E | OH]; the row's 1 / S_b and the
+  // fp32 residual of its one-hot come in here
+  const bool fx = fix.scale2 != nullptr;
+  float rs = 1.f, rd = 0.f;
+  int flab = 0;
+  if (fx && row < M) {
+    rs = fix.scale2[2 * row]; rd = fix.scale2[2 * row + 1];
+    flab = clampi(fix.label[row], 0, fix.n_items - 1);
+  }
   float4 cs = zero4();
   int col;                                   // output column of this thread's float4
   if ((int)blockIdx.x < nic) {
@@ -660,6 +733,10 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
         for (int j = 0; j < 9; ++j) acc = add4(acc, t[j]);
       }
       for (; k < S; ++k) acc = add4(acc, ld4(sp + (long)k * M * lds_));
+      if (fx) {
+        const float4 e = ld4(fix.E + (long)flab * fix.ldE + col);
+        acc = make_float4(fmaf(rd, e.x, acc.x * rs), fmaf(rd, e.y, acc.y * rs), fmaf(rd, e.z, acc.z * rs), fmaf(rd, e.w, acc.w * rs));
+      }
     }
     // the negative term's part comes from the aux stream: behind its flag, waited for HERE (after the slab sum), or an event
     if (addend) tcar_wave_wait(wait_add);
@@ -695,6 +772,7 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
           for (int u = 0; u < 6; ++u) v[j] += t[u];
         }
         for (; q < S; ++q) v[j] += sp[(long)q * M * lds_];
+        if (fx) v[j] = fmaf(v[j], rs, (clampi(fix.mwdhm[(long)flab * 5 + k], 0, nk - 1) == c) ? rd : 0.f);
         if (sig.cnt) __hip_atomic_store(dP + (long)row * 160 + off + c, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else dP[(long)row * 160 + off + c] = v[j];
       }
@@ -1124,6 +1202,30 @@ extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const 
   return tcar_ce_finish_o(B, N, group_width, ngroups, stats, lab_logit, label, rowstat, ce, dl_hi, inner, stream, nullptr);
 }
 
+// anchored form of tcar_ce_finish (see ce_anchor_fold_kernel): B a multiple of 128 (no padding rows exist in the planes then);
+// ap_* / aps: the packed attout planes of the dE GEMM [B, ap_cols] with inner dimension ap_inner, KB32 layout
+int tcar_ce_anchor_fold_o(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
+                          float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner, const void* ap_hi, const void* ap_lo,
+                          void* aps_hi, int ap_cols, int64_t ap_inner, void* stream, TcarOpt* o) {
+  (void)o;
+  if (B <= 0) return TCAR_OK;
+  if ((B & 127) || N <= 0 || !stats || !lab_logit || !label || !ce || !scale2 || ((uintptr_t)scale2 & 7) || !dl_hi || (inner & 31) || inner < N || ngroups <= 0 ||
+      (group_width != 64 && group_width != 96) || (long)ngroups * group_width < N || (rowstat && ((uintptr_t)rowstat & 7)) || !ap_hi ||
+      !ap_lo || !aps_hi || ap_cols <= 0 || (ap_cols & 3) || (ap_inner & 31) || ap_inner < ap_cols || ((uintptr_t)stats & 7))
+    return TCAR_E_ARG;
+  TCAR_LAUNCH(ce_anchor_fold_kernel, dim3(B / 4), dim3(256), 0, (hipStream_t)stream, B, N, (int)(inner >> 5), ngroups, stats, lab_logit,
+              label, rowstat, ce, scale2, (__bf16*)dl_hi, (const __bf16*)ap_hi, (const __bf16*)ap_lo, (__bf16*)aps_hi, ap_cols,
+              (int)(ap_inner >> 5));
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+extern "C" int tcar_ce_anchor_fold(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit,
+                                   const int32_t* label, float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner,
+                                   const void* ap_hi, const void* ap_lo, void* aps_hi, int ap_cols, int64_t ap_inner, void* stream) {
+  return tcar_ce_anchor_fold_o(B, N, group_width, ngroups, stats, lab_logit, label, rowstat, ce, scale2, dl_hi, inner, ap_hi, ap_lo,
+                               aps_hi, ap_cols, ap_inner, stream, nullptr);
+}
+
 // second half of tcar_ce_finish on its own (catalog-sharded step: the row statistics come from the statistics exchange):
 // plane[b, n] = e[b, n] * exp(m_g - rowstat[b].x) * rowstat[b].y - [n == label[b] - lab_off]; lab_window != 0: a label outside
 // [lab_off, lab_off + N) belongs to another shard and nothing is subtracted
@@ -1248,9 +1350,21 @@ int tcar_reduce_dact_onehot_o(const float* slabs, int splitk, int M, int ic, int
 #endif
   TCAR_LAUNCH(reduce_dact_onehot_kernel, dim3(ic / 64 + 5, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, slabs, splitk, M, ic,
               (long)ld, addend, (long)ld_add, y, (long)ldy, tclip, out, (long)ldo, dP, bias_grad0, bias_grad1, tcar_sig(o),
-              o ? o->wait : TcarWait{});
+              o ? o->wait : TcarWait{}, (o && o->rowfix) ? *o->rowfix : TcarRowFix{});
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
+}
+// ... of the anchored softmax form: scale2 [M, 2] = (1 / S_m, residual) as tcar_ce_anchor_fold leaves them, label [M], E fp32
+// candidate rows [n_items, ldE], mwdhm [n_items, 5] (TcarRowFix); no bias column sums
+extern "C" int tcar_reduce_dact_onehot_scaled(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend,
+                                              int64_t ld_add, const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo,
+                                              float* dP, const float* scale2, const int32_t* label, const float* E, int64_t ldE,
+                                              const int32_t* mwdhm, int n_items, void* stream) {
+  if (!scale2 || !label || !E || !mwdhm || n_items <= 0 || ldE < ic || (ldE & 3) || !tcar_aligned16(E)) return TCAR_E_ARG;
+  const TcarRowFix fix{scale2, label, E, (long)ldE, mwdhm, n_items};
+  TcarOpt o;
+  o.rowfix = &fix;
+  return tcar_reduce_dact_onehot_o(slabs, splitk, M, ic, ld, addend, ld_add, y, ldy, tclip, out, ldo, dP, nullptr, nullptr, stream, &o);
 }
 extern "C" int tcar_reduce_dact_onehot(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
                                        const float* y, int64_t ldy, const float* tclip, float* out, int64_t ldo, float* dP,

@@ -16,7 +16,7 @@ const Switch kSwitches[] = {
     {"TCAR_BF16_TILE", &TcarTuning::bf16_tile, 0},          {"TCAR_BF16_KS", &TcarTuning::bf16_ks, 2},
     {"TCAR_WGRAD_KS", &TcarTuning::wgrad_ks, 1536},         {"TCAR_GATHER_BIG_ROWS", &TcarTuning::gather_big_rows, 16384},
     {"TCAR_MHA_MFMA", &TcarTuning::mha_mfma, 1},            {"TCAR_SORT_SCATTER", &TcarTuning::sort_scatter, 1},
-    {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},          {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 1},
+    {"TCAR_DET_SMALL", &TcarTuning::det_small, 1},          {"TCAR_FUSED_CE", &TcarTuning::fused_ce, 2},
     {"TCAR_ONEHOT_TIME", &TcarTuning::onehot_time, 2},      {"TCAR_FLAG_FORK", &TcarTuning::flag_fork, 4095},
     {"TCAR_CE_FOLD", &TcarTuning::ce_fold, 1024},           {"TCAR_PROJ_SPLIT_ROWS", &TcarTuning::proj_split_rows, 1024},
 };
@@ -317,6 +317,12 @@ bool onehot_bwd(const tcar_ctx_t* c, const tcar_batch_t* bt) {
   return onehot_fwd(c, bt->B) && tn(c).onehot_time >= 2 && c->tclip && c->dP && c->qz && c->d.ldt == 64 && c->et_perm && c->inv_off &&
          c->ct_ws && c->stream3 && c->ev3 && c->gw_rows && sorted_rows(c, bt) && tn(c).det_small != 0;
 }
+// anchored softmax form (score.hip: ce_anchor_fold_kernel): the one-hot step with the buffers of the form, full 128-row blocks
+// (the planes then have no padding rows for a rescale pass to zero) and at most eight 64-column anchor partials per row
+bool ce_anchored(const tcar_ctx_t* c, const tcar_batch_t* bt) {
+  return onehot_bwd(c, bt) && tn(c).fused_ce >= 2 && (bt->B & 127) == 0 && c->ce_anchor && c->ce_rowscale && c->aps16h && c->ce_form &&
+         c->d.ldh <= 256;
+}
 }  // namespace
 
 extern "C" int tcar_step_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, void* stream) {
@@ -331,7 +337,11 @@ namespace {
 // pending split update there
 // `so`: where the one-hot time scores of the logits GEMM go (forward_impl of a training step); when the output transforms run in
 // their split form the finishing launch computes them too and sets so->done — the caller then skips tcar_time_scores_clip
-struct ScoreOut { void* p_hi; void* p_lo; float* tclip; bool done; };
+struct ScoreOut {
+  void* p_hi; void* p_lo; float* tclip; bool done;
+  // anchored softmax form: the finishing launch also leaves the anchor partials (label rows of E: see forward_impl); anchor_done says so
+  const int32_t* label = nullptr; const float* E = nullptr; int64_t ldE = 0; float* anchor = nullptr; bool anchor_done = false;
+};
 template <class Hook>
 int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei, Hook hook,
                     ScoreOut* so = nullptr) {
@@ -440,11 +450,12 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     RET(small_gemm(c, 0, 2, p, stream));
     const float* tt[5];
     for (int k = 0; k < 5; ++k) tt[k] = W(c, TCAR_V_MONTH + k);
-    RET(tcar_attout_finish_scores(&c->d, tt, B, c->proj_slabs, na_ic, na_pt, astride, W(c, TCAR_V_O_B), W(c, TCAR_V_OT_B), c->attout,
-                                  g.ek, planes ? c->a16h : nullptr, planes ? c->a16l : nullptr, g.ek, planes ? c->ap16h : nullptr,
-                                  planes ? c->ap16l : nullptr, g.ldh + g.pt, so ? so->p_hi : nullptr, so ? so->p_lo : nullptr, 160,
-                                  so ? so->tclip : nullptr, stream));
-    if (so) so->done = true;
+    RET(tcar_attout_finish_scores_a(&c->d, tt, B, c->proj_slabs, na_ic, na_pt, astride, W(c, TCAR_V_O_B), W(c, TCAR_V_OT_B), c->attout,
+                                    g.ek, planes ? c->a16h : nullptr, planes ? c->a16l : nullptr, g.ek, planes ? c->ap16h : nullptr,
+                                    planes ? c->ap16l : nullptr, g.ldh + g.pt, so ? so->p_hi : nullptr, so ? so->p_lo : nullptr, 160,
+                                    so ? so->tclip : nullptr, so ? so->label : nullptr, so ? so->E : nullptr, so ? so->ldE : 0,
+                                    so ? so->anchor : nullptr, stream));
+    if (so) { so->done = true; so->anchor_done = so->anchor != nullptr; }
     return TCAR_OK;
   }
   {
@@ -519,6 +530,10 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   // a fused training step in the one-hot form reads the candidate-side time planes of E nowhere: their refresh is left to the
   // next entry point that does (evaluation, the op-level paths: the engine keeps refresh_time set until one of them ran)
   const bool oh_bwd = train_index && onehot_bwd(c, bt);
+  // anchored softmax form: the finishing launch of the session forward reads the LABEL rows of E (item | content columns) for the
+  // anchor — of a pending split update they join the early part, so that the rest pass (aux stream, beside the forward) never
+  // writes a row this step's forward reads: no race, the same bits in every run
+  const bool anchored = oh_bwd && ce_anchored(c, bt);
   // REST pass of a pending split update, on the aux stream (behind whatever the main stream has enqueued so far when it is
   // forked late); ev[1] = "aux stream ready for the logits GEMM"
   auto launch_rest = [&]() -> int {
@@ -542,10 +557,10 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
       // kernel, with the time refresh on the third stream: the 376-MB pass then runs beside the gather and the projections
       // as well and slows them by more than it gains — 0.626 vs 0.618 ms per step)
       const float* pieces = c->Gx + c->arena_n;
-      RET(tcar_clip_adam_early(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
-                               c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
-                               c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT,
-                               c->adam_bitmap, stream));
+      RET(tcar_clip_adam_early_2(c->W, c->Gx, c->M, c->V, &c->segs_all, c->E, g.ek, c->big, c->Mi, c->Vi, g.N, g.ldh,
+                                 c->slot_item, c->sqn_dense, pieces, c->use_dense, c->clip, rest_lr, c->b1, c->b2, c->eps,
+                                 c->scoring ? c->e16h : nullptr, c->scoring ? c->e16l : nullptr, g.ek, bt->seq, (int64_t)BT,
+                                 anchored ? bt->label : nullptr, anchored ? (int64_t)B : 0, c->adam_bitmap, stream));
       // (one-hot form: nothing is launched on the aux stream here — the rest pass is forked behind the projection launch, which is
       //  behind the early pass on this stream: no event on the main chain at the top of the step)
       if (!oh_bwd && (hipEventRecord((hipEvent_t)c->ev[0], s1) != hipSuccess || hipStreamWaitEvent(s2, (hipEvent_t)c->ev[0], 0) != hipSuccess))
@@ -581,6 +596,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   const bool ce_epi = c->scoring && train_index && fused_ce(c, B, &w);
   const bool onehot = ce_epi && onehot_fwd(c, B);
   ScoreOut so{c->p16h, c->p16l, oh_bwd ? c->tclip : nullptr, false};
+  if (anchored) { so.label = bt->label; so.E = c->E; so.ldE = g.ek; so.anchor = c->ce_anchor; }
   RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage, TcarOpt* o) -> int {
     if (rest_stage == 1 && stage == 0) o->sig = fork_arm(c, FK_PROJ);        // the projection launch carries the flag
     if (stage != rest_stage) return TCAR_OK;
@@ -619,6 +635,10 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     // split-bf16 path: the planes of attout were written by the output-transform GEMM's epilogue
     start_timer();
     if (ce_epi && s2) ol.sig = fork_arm(c, FK_LOGITS);       // backward_prologue releases the aux stream behind this launch
+    // the form the backward half of this step finds: anchored only when the finishing launch did leave the anchor partials
+    const bool anch = anchored && onehot && so.anchor_done;
+    if (c->ce_form) *c->ce_form = anch ? 1 : 0;
+    if (anch) { ol.anchor = c->ce_anchor; ol.anchor_n = g.ic >> 6; }
     if (ce_epi) {
       // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes
       // dlogits, plus per-group (max, sum) — no [B, N] fp32 logits; backward_impl finishes with tcar_ce_finish
@@ -761,9 +781,16 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   const int nsb = c->scoring_bwd ? c->scoring_bwd : c->scoring;
   // hi-only backward (bf16x3-mixed, bf16): the lo plane of dlogits is never read — and not written
   CeWs cw;
+  // anchored softmax form (decided by the forward half of this step): no pass over the plane — a fold launch leaves the row scales,
+  // the label's -1 inside the plane and the scaled attout plane of dE; dX is scaled in its slab reduce
+  const bool anch = ohb && c->ce_form && *c->ce_form == 1;
   if (ce_epilogue && fused_ce(c, B, &cw)) { // the forward pass of THIS step ran the softmax epilogue (same predicate)
     TcarOpt os = opt_of(c);
-    RET(tcar_ce_finish_o(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream, &os));
+    if (anch)
+      RET(tcar_ce_anchor_fold_o(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->ce_rowscale,
+                                c->dl16h, g.Npad, c->ap16h, c->ap16l, c->aps16h, g.ldh + g.pt, g.ldh + g.pt, stream, &os));
+    else
+      RET(tcar_ce_finish_o(B, g.N, c->ce_geo[0], c->ce_geo[1], cw.stats, cw.lab, bt->label, cw.rowstat, c->ce, c->dl16h, g.Npad, stream, &os));
   }
   else if (c->scoring) RET(tcar_softmax_ce_bf16_o(B, g.N, c->logits, g.Npad, bt->label, c->ce, c->dl16h, nsb == 1 ? nullptr : c->dl16l, stream));
   else RET(tcar_softmax_ce(B, g.N, c->logits, g.Npad, bt->label, c->ce, stream));
@@ -791,8 +818,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     if (ohb) {
       // item block only; the time block leaves as per-candidate (||gy||^2, x . gy) pairs in the order of the inverted index
       TcarOpt ob = opt_of(c);
-      RET(tcar_gemm_bf16_de_qz_o(g.N, (B + 31) & ~31, c->dl16h, g.Npad, (B + 127) & ~127, c->ap16h, g.ldh + g.pt, (B + 127) & ~127,
-                                 g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, de_tile(c, g.N), sB, &ob));
+      RET(tcar_gemm_bf16_de_qz_o(g.N, (B + 31) & ~31, c->dl16h, g.Npad, (B + 127) & ~127, anch ? c->aps16h : c->ap16h, g.ldh + g.pt,
+                                 (B + 127) & ~127, g.ldh, Gi, g.ldh, c->mwdhm, c->et_perm, c->tclip, c->qz, de_tile(c, g.N), sB, &ob));
     } else if (c->scoring) {
       // the time block goes out in the order of the inverted index (et_perm) so that its backward streams it
       TcarOpt ob = opt_of(c);
@@ -869,6 +896,8 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   if (ohb) {    // ... and the one-hot columns: dP = their slab sum, expanded to the time columns of dattout on the spot
     TcarOpt orr = opt_of(c);
     orr.sig = fork_arm(c, FK_REDUCE);          // (dP leaves write-through when the launch carries the flag)
+    const TcarRowFix fix{c->ce_rowscale, bt->label, c->E, (long)g.ek, c->mwdhm, g.N};
+    if (anch) orr.rowfix = &fix;
     RET(tcar_reduce_dact_onehot_o(c->slabs, S, B, g.ic, g.ic + 160, has_neg ? c->negpart : nullptr, g.ic, c->attout, g.ek, c->tclip,
                                   c->dattout, g.ek, c->dP, detc ? nullptr : G(c, TCAR_V_O_B), detc ? nullptr : G(c, TCAR_V_OT_B), stream,
                                   &orr));
@@ -1148,14 +1177,16 @@ extern "C" int tcar_step_update(const tcar_ctx_t* c, float lr_t, void* stream) {
 
 // Which form would a fused training step of `bt` take on this context?  The predicates the driver itself evaluates, for tools
 // that label measurements (bench.py's roofline entries): form[0] softmax epilogue in the logits GEMM, [1] one-hot time segment of
-// the logits GEMM, [2] one-hot form of the two gradient GEMMs, [3] sorted (order-fixed) item-row sum.  Launches nothing.
-extern "C" int tcar_step_form(const tcar_ctx_t* c, const tcar_batch_t* bt, int32_t* form /*host, 4 ints*/) {
+// the logits GEMM, [2] one-hot form of the two gradient GEMMs, [3] sorted (order-fixed) item-row sum, [4] anchored softmax form (no
+// rescale pass over the plane).  Launches nothing.
+extern "C" int tcar_step_form(const tcar_ctx_t* c, const tcar_batch_t* bt, int32_t* form /*host, 5 ints*/) {
   if (!form) return TCAR_E_ARG;
   RET(check_ctx(c, bt));
   form[0] = (c->scoring && fused_ce(c, bt->B, nullptr)) ? 1 : 0;
   form[1] = (form[0] && onehot_fwd(c, bt->B)) ? 1 : 0;
   form[2] = onehot_bwd(c, bt) ? 1 : 0;
   form[3] = sorted_rows(c, bt) ? 1 : 0;
+  form[4] = ce_anchored(c, bt) ? 1 : 0;
   return TCAR_OK;
 }
 

@@ -108,6 +108,13 @@ __device__ __forceinline__ float ld1_sc1(const float* p) { return __hip_atomic_l
 // sets `carried` when the kernel form it chose publishes the flag (flag-capable forms: the latency form of the forward gather,
 // the click-query MLP, small-GEMM launches WITHOUT bf16 plane outputs, the softmax-epilogue logits GEMM, sqnorm_seg, the
 // small-table norm fold); a launch that cannot carry it leaves `carried` false and the driver forks with an event.
+// Anchored softmax form, dX side (score.hip: ce_anchor_fold_kernel / reduce_dact_onehot_kernel).  The slabs hold the UNSCALED plane
+// times [E | OH]; scale2[m] = (1 / S_m, r_m): the slab sums (and dP) of row m are multiplied by 1 / S_m, and r_m — the part of the
+// one-hot's -1 that the bf16 label entry of the plane could not hold, already divided by S_m — comes back in fp32 as
+// r_m * [E[label[m], :] | onehot(publish time of label[m])].  E: fp32 candidate rows [n_items, ldE] (item | content columns first).
+struct TcarRowFix {
+  const float* scale2; const int32_t* label; const float* E; long ldE; const int32_t* mwdhm; int n_items;
+};
 struct TcarOpt {
   const tcar_tuning_t* tune = nullptr;
   TcarSignal sig{};
@@ -122,6 +129,13 @@ struct TcarOpt {
   // label window of the softmax-epilogue logits GEMM (catalog-sharded step): the column of row m's label is label[m] - lab_off,
   // and a label outside [0, N) is in another shard — no label score is written for it (lab_window = 0: labels are clamped)
   int lab_off = 0, lab_window = 0;
+  // ANCHORED softmax epilogue of the logits GEMM (round 6; step.hip: ce_anchored): the plane is exp(x - anchor[m]) with a per-row
+  // reference handed in (anchor[m] = sum of anchor_n partial sums at anchor + m * anchor_n, added in index order) instead of
+  // exp(x - group maximum): every group of a row then shares ONE scale, so the plane never needs the rescale pass — dX is scaled
+  // per row in its slab reduce (`rowscale`), dE contracts the plane with per-row scaled attout planes (tcar_ce_anchor_fold_o)
+  const float* anchor = nullptr;
+  int anchor_n = 0;
+  const TcarRowFix* rowfix = nullptr;      // one-hot slab reduce of the anchored form (below)
   // zeroed device words a launch may use for an order-fixed last-arrival fold (tcar_sqnorm_o: word 0 = arrival counter, kept zero
   // between launches; then one float per 32,768-float chunk): tcar_ctx_t.fold_scratch
   unsigned* scratch = nullptr;
@@ -138,6 +152,19 @@ inline TcarSignal tcar_sig(TcarOpt* o) {       // the flag a flag-capable launch
 // include/tcar_hip.h call them with the process snapshot and no flag
 int tcar_ce_finish_o(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                      float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream, TcarOpt* o);
+int tcar_ce_anchor_fold_o(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
+                          float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner, const void* ap_hi, const void* ap_lo,
+                          void* aps_hi, int ap_cols, int64_t ap_inner, void* stream, TcarOpt* o);
+int tcar_clip_adam_early_2(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,
+                           const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot, const float* sqn_dense,
+                           const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,
+                           void* e16_hi, void* e16_lo, int64_t ld16, const int32_t* ids, int64_t n_ids, const int32_t* ids2,
+                           int64_t n_ids2, uint32_t* bitmap, void* stream);
+int tcar_attout_finish_scores_a(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* slabs, int nd_ic, int nd_pt,
+                                int64_t stride, const float* bias_o, const float* bias_ot, float* attout, int64_t ld_out, void* a_hi,
+                                void* a_lo, int64_t a_inner, void* ap_hi, void* ap_lo, int64_t ap_inner, void* p_hi, void* p_lo,
+                                int64_t p_inner, float* tclip, const int32_t* label, const float* E, int64_t ldE, float* anchor,
+                                void* stream);
 int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, float* x_icp, float* x_pt,
                            float* x_act, float* click_t, void* stream, TcarOpt* o);
 int tcar_query_mlp_o(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b, const float* q2_w,

@@ -835,6 +835,18 @@ class TcarEngine:
                         if getattr(self, "_dP", None) is None or self._dP.numel() < self.work_B * 160:
                             self._dP = torch.zeros(self.work_B * 160, dtype=torch.float32, device=self.dev)
                         c.tclip, c.dP, c.qz = self._tclip.data_ptr(), self._dP.data_ptr(), self._qz.data_ptr()
+                        # anchored softmax form (tcar_hip.h: ce_anchor ...): anchor partials, row scales, the scaled attout plane of
+                        # dE, and the host int that carries the form from the forward to the backward half of a step
+                        if not os.environ.get("TCAR_NO_CE_ANCHOR"):
+                            Bp = _ru(self.work_B, 128)
+                            if getattr(self, "_ce_anchor", None) is None or self._ce_rowscale.numel() < 2 * Bp:
+                                self._ce_anchor = torch.zeros(Bp * 8, dtype=torch.float32, device=self.dev)
+                                self._ce_rowscale = torch.zeros(2 * Bp, dtype=torch.float32, device=self.dev)
+                                self._aps16h = torch.zeros(Bp, g.ldh + g.pt, dtype=torch.bfloat16, device=self.dev)
+                                self._ce_form = (C.c_int32 * 1)(0)
+                            c.ce_anchor, c.ce_rowscale, c.aps16h = (self._ce_anchor.data_ptr(), self._ce_rowscale.data_ptr(),
+                                                                    self._aps16h.data_ptr())
+                            c.ce_form = C.cast(self._ce_form, C.c_void_p)
         if self.overlap:
             if not hasattr(self, "_aux"):
                 self._aux = torch.cuda.Stream(self.dev)
@@ -937,12 +949,13 @@ class TcarEngine:
 
     def step_form(self, bt: Batch) -> Dict[str, bool]:
         """The form a fused training step of `bt` takes on this engine (tcar_step_form: the driver's own predicates) —
-        {"fused_ce", "onehot_fwd", "onehot_bwd", "sorted_rows"}.  Tools that label measurements ask this instead of re-deriving
-        it from the environment."""
+        {"fused_ce", "onehot_fwd", "onehot_bwd", "sorted_rows", "ce_anchored"}.  Tools that label measurements ask this instead of
+        re-deriving it from the environment."""
         self._ensure_work(bt.B, bt.T)
-        out = (C.c_int32 * 4)()
+        out = (C.c_int32 * 5)()
         check(self.lib.tcar_step_form(C.byref(self._ctx()), C.byref(bt), out), "tcar_step_form")
-        return {"fused_ce": bool(out[0]), "onehot_fwd": bool(out[1]), "onehot_bwd": bool(out[2]), "sorted_rows": bool(out[3])}
+        return {"fused_ce": bool(out[0]), "onehot_fwd": bool(out[1]), "onehot_bwd": bool(out[2]), "sorted_rows": bool(out[3]),
+                "ce_anchored": bool(out[4])}
 
     def _lr_t(self) -> float:
         return float(np.float32(self.lr) * np.sqrt(np.float32(1) - self.b2_pow) / (np.float32(1) - self.b1_pow))

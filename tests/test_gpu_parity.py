@@ -411,6 +411,36 @@ def test_globo_full_size_step_matches_oracle(scoring, T):
         assert rel_norm(p_e[k], p_o[k]) <= (3e-2 if mixed else 2e-3), ("param " + k, rel_norm(p_e[k], p_o[k]))
 
 
+@pytest.mark.parametrize("fused_ce", [2, 1])
+def test_fused_step_gradients_at_the_benched_size_match_oracle(fused_ce):
+    """The gradients the FUSED training step itself leaves (the driver bench.py times: softmax epilogue, one-hot gradient GEMMs,
+    order-fixed sums; `loss_and_grads` above takes the op-level path with materialised logits) against the fp64 oracle at the
+    benched size — all 23 variables + clip norms at the mixed-precision gate, and tighter where the form promises it: in the anchored
+    softmax form (2, default) the one-hot part of the softmax gradient is exact in dX and the plane is rounded once, so the
+    session-side time path (dP = dlogits OH is exact in its operands) agrees to 3e-4 norm-wise; the rescaled form (1) likewise."""
+    _need_gpu()
+    from oracle.tcar_oracle import TcarOracle
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, K, T = 46033, 250, 64, 512, 20, 2
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=1000 + T, emb_std=0.05, w_std=0.05)
+    ora = TcarOracle(params, content, mw)
+    o, g_o, sq_o = ora.loss_and_grads(batch)
+    g_o = {k: v.numpy() for k, v in g_o.items()}
+    eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+    eng.set_tuning(TCAR_FUSED_CE=fused_ce)
+    bt = eng.make_resident(batch)
+    form = eng.step_form(bt)
+    assert form["onehot_bwd"] and form["ce_anchored"] == (fused_ce == 2), form
+    loss = eng.train_step(None, bt=bt, defer_update=True)
+    torch.cuda.synchronize()
+    close(loss[:B].cpu().numpy(), o["loss"].detach().numpy(), name="loss")
+    g_e, sq_e = eng.export_grads(), eng.export_sqnorms()
+    check_grads(g_e, sq_e, g_o, sq_o, "bf16x3-mixed")
+    for k in ("cont_attention/input_linear_trans/w_3d", "cont_attention/cont_linear_trans/w_3d", "cont_attention/res_linear_trans/w_3d",
+              "attout_pt_trans/w1"):
+        assert rel_norm(g_e[k], g_o[k]) <= 3e-4, (k, rel_norm(g_e[k], g_o[k]))
+
+
 def test_dp_engine_single_rank_path_matches_oracle():
     """The data-parallel code path (gather backward emitting rows -> exchange schedule -> scatter kernel) with a
     world of one must reproduce the oracle exactly like the fused single-GPU path."""
@@ -527,6 +557,106 @@ def test_logits_gemm_softmax_epilogue(lib, M, N, K, nsplit, K2):
     assert (d[:M, N:] == 0).all() and (d[M:] == 0).all()                      # padding columns and the k-rows of dE
     rel = np.linalg.norm(d[:M, :N] - want) / np.linalg.norm(want)
     assert rel < 4e-3, rel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,K2", [(256, 1000, 64, 0), (128, 129, 96, 139), (512, 46033, 512, 139)])
+def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K, K2):
+    """Anchored form of the softmax epilogue (round 6): tcar_gemm_bf16_ce_anchor writes exp(x - a[b]) for a per-row reference handed in
+    as partial sums (here: the label's score +- 3, in 8 pieces), statistics (a[b], group sum); tcar_ce_anchor_fold then gives
+    ce = lse - x_label against fp64, rowscale = 1 / S, the label's entry as e - S, and the per-row scaled attout plane — and
+    plane * rowscale is softmax - onehot to the bf16 bound of ONE rounding (the rescaled form rounds twice)."""
+    rng = np.random.RandomState(M + N)
+    A = (rng.standard_normal((M, K)) * 0.7).astype(np.float32)
+    Bm = (rng.standard_normal((N, K)) * 0.6).astype(np.float32)
+    label = rng.randint(0, N, M).astype(np.int32)
+    label[0], label[-1] = 0, N - 1
+    x = A.astype(np.float64) @ Bm.astype(np.float64).T
+    ah, al, ai, ar = _planes(lib, A)
+    bh, bl, bi, br = _planes(lib, Bm)
+    seg2 = (K, None, None, None, 0)
+    if K2:
+        A2 = (rng.standard_normal((M, K2)) * 0.5).astype(np.float32)
+        B2 = (rng.uniform(size=(N, K2)) < 5.0 / K2).astype(np.float32)
+        x = x + A2.astype(np.float64) @ B2.astype(np.float64).T
+        a2h, a2l, a2i, _ = _planes(lib, A2)
+        b2h, b2l, b2i, _ = _planes(lib, B2)
+        seg2 = (K, ptr2(a2h), ptr2(a2l), ptr2(b2h), a2i)
+    xl = x[np.arange(M), label]
+    parts = rng.standard_normal((M, 8)).astype(np.float32)
+    parts[:, 0] += (xl + rng.uniform(-3, 3, M)).astype(np.float32) - parts.sum(1)
+    anchor = np.zeros(M, np.float32)
+    for j in range(8):
+        anchor = (anchor + parts[:, j]).astype(np.float32)          # the kernel's order
+    Np, Mp = (N + 127) // 128 * 128, (M + 127) // 128 * 128
+    assert Mp == M
+    plane = torch.full((Mp * Np,), float("nan"), dtype=torch.bfloat16, device="cuda")
+    nstat = M * ((N + 63) // 64 + 8) * 2
+    stats = torch.full((nstat,), float("nan"), device="cuda")
+    lab_d = torch.tensor(label).cuda()
+    lab_logit = torch.zeros(M, device="cuda")
+    parts_d = torch.tensor(parts).cuda()
+    gw, ng = C.c_int32(0), C.c_int32(0)
+    assert lib.tcar_gemm_bf16_ce_anchor(M, N, K + (160 if K2 else 0), ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, *seg2,
+                                        ptr2(plane), Np, Mp, ptr(stats), nstat, ptr2(lab_d), ptr(lab_logit), 3, C.byref(gw), C.byref(ng),
+                                        ptr(parts_d), 8, None) == 0
+    gw, ng = gw.value, ng.value
+    st = stats[:M * ng * 2].view(M, ng, 2).cpu().numpy()
+    assert (st[..., 0] == anchor[:, None]).all()
+    xp = np.full((M, ng * gw), -np.inf)
+    xp[:, :N] = x
+    want_e = np.exp(xp - anchor.astype(np.float64)[:, None])
+    assert np.allclose(st[..., 1], want_e.reshape(M, ng, gw).sum(2), rtol=3e-4, atol=1e-6)
+    assert np.allclose(lab_logit.cpu().numpy(), xl, rtol=1e-5, atol=1e-5 * np.abs(x).max())
+    idx = torch.tensor(_kb32_index(Mp, Np), device="cuda")
+    e = plane[idx].float().cpu().numpy()
+    # (bf16: 7 explicit mantissa bits — round-to-nearest is within 2^-8 relative; + the fp32 exponential's own last bits)
+    # ... + the split-bf16 logits' own error, 1e-4 at |x| ~ 40)
+    assert (np.abs(e[:, :N] - want_e[:, :N]) <= (2.0 ** -8 + 1e-3) * want_e[:, :N] + 1e-30).all() and (e[:, N:] == 0).all()
+    # ---- the fold
+    cols = 576
+    ap = (rng.standard_normal((M, cols)) * 0.5).astype(np.float32)
+    ph, pl, pi, _ = _planes(lib, ap)
+    aps = torch.full_like(ph, float("nan"))
+    rowstat, ce, rowscale = torch.zeros(2 * M, device="cuda"), torch.zeros(M, device="cuda"), torch.zeros(2 * M, device="cuda")
+    assert lib.tcar_ce_anchor_fold(M, N, gw, ng, ptr(stats), ptr(lab_logit), ptr2(lab_d), ptr(rowstat), ptr(ce), ptr(rowscale), ptr2(plane),
+                                   Np, ptr2(ph), ptr2(pl), ptr2(aps), cols, pi, None) == 0
+    m = x.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(x - m).sum(1))
+    close(ce.cpu().numpy(), lse - xl, name="ce", rtol=1e-4, atol_scale=1e-5)
+    S = st[..., 1].astype(np.float64).sum(1)
+    sc2 = rowscale.cpu().numpy().reshape(M, 2).astype(np.float64)
+    rs, rd = sc2[:, 0], sc2[:, 1]
+    assert np.allclose(rs, 1.0 / S, rtol=1e-5) and np.allclose(rowstat.cpu().numpy().reshape(M, 2), np.stack([anchor, 1.0 / S], 1), rtol=1e-5)
+    d = plane[idx].float().cpu().numpy()
+    keep = np.ones((M, N), bool)
+    keep[np.arange(M), label] = False
+    assert (d[:, :N][keep] == e[:, :N][keep]).all()                              # nothing but the label's entry moved
+    el, dl = e[np.arange(M), label].astype(np.float64), d[np.arange(M), label].astype(np.float64)
+    # dX side: label entry * (1 / S) + residual = e_l / S - 1 to fp32 — the one-hot part carries no bf16 rounding
+    assert np.abs(dl * rs + rd - (el * rs - 1.0)).max() <= 1e-6 and np.abs(rd).max() <= 1.01 * 2.0 ** -8
+    # dE side: the row scale 1 / S' = 1 / (e_l - v) makes v / S' = e_l / S' - 1 exact; S' within 2^-8 of S
+    s_e = el - dl
+    assert np.allclose(s_e, S, rtol=1.01 * 2.0 ** -8)
+    p = np.exp(x - lse[:, None])
+    want = p.copy()
+    want[np.arange(M), label] -= 1.0
+    got = d[:, :N] * rs[:, None]
+    got[np.arange(M), label] += rd
+    err = np.abs(got - want)
+    # ONE rounding per softmax element (+ the split-bf16 logits' own error inside the exponential, 1e-4 at |x| ~ 40)
+    bound = (2.0 ** -8 + 1e-3) * p + 1e-6 * (np.arange(N)[None, :] == label[:, None]) + 1e-30
+    w = np.unravel_index(np.argmax(err - bound), err.shape)
+    assert (err <= bound).all(), (w, int(label[w[0]]), float(got[w]), float(want[w]), float(e[w]), float(d[w]), float(rs[w[0]]), float(S[w[0]]))
+    assert np.linalg.norm(got - want) / np.linalg.norm(want) < 3e-3
+    rs = 1.0 / s_e                                                              # the scale of the attout plane of dE
+    pidx = torch.tensor(_kb32_index(Mp, pi), device="cuda")
+    sc = aps[pidx].float().cpu().numpy()[:, :cols]
+    want_sc = ap.astype(np.float64) * rs[:, None]
+    assert (np.abs(sc - want_sc) <= 1.01 * 2.0 ** -8 * np.abs(want_sc) + 1e-30).all()
+    # B that is no multiple of 128 is refused (the step keeps the rescaled form for such batches)
+    assert lib.tcar_ce_anchor_fold(M - 1, N, gw, ng, ptr(stats), ptr(lab_logit), ptr2(lab_d), ptr(rowstat), ptr(ce), ptr(rowscale), ptr2(plane),
+                                   Np, ptr2(ph), ptr2(pl), ptr2(aps), cols, pi, None) != 0
 
 
 @pytest.mark.parametrize("N,H,Ht,B", [(3000, 250, 64, 77), (46033, 250, 64, 512), (500, 30, 100, 5), (700, 100, 200, 33)])
@@ -847,13 +977,13 @@ def test_schedule_switches_agree_bitwise_with_the_default_schedule():
     different lengths — every loss, all variables, all Adam moments:
       * BITWISE for the switches that change WHERE or HOW a launch runs, not what it sums in which order: event forks instead of flag
         forks (TCAR_FLAG_FORK = 0, and the mask the multi-rank sharded engine takes), the cross-entropy finish as two launches
-        (TCAR_CE_FOLD = 0), the gradient GEMMs' LDS staging (TCAR_BF16_KS = 1 / 3 / 4: 32-deep stages, 64-deep everywhere, the dX ring),
+        (TCAR_CE_FOLD = 0: consulted only by the group-maximum form — test_ce_finish_as_one_launch_... compares it there), the gradient GEMMs' LDS staging (TCAR_BF16_KS = 1 / 3 / 4: 32-deep stages, 64-deep everywhere, the dX ring),
         the dE tile codes that keep the 192-row tile (TCAR_BF16_TILE = 1922 / 1923: double buffer / three-stage ring), the gather's
         throughput form from row 1 (TCAR_GATHER_BIG_ROWS = 1: the same clips and copies);
       * to 2e-4 of the loss scale for those that re-associate fp32 sums or take another arithmetic path: other workgroup tiles
         (TCAR_BF16_TILE = 256, 2562), the weight gradients' K chunk (TCAR_WGRAD_KS), the projections' split-K slabs on / off
-        (TCAR_PROJ_SPLIT_ROWS), float atomics instead of the order-fixed sums (TCAR_SORT_SCATTER = 0, TCAR_DET_SMALL = 0), materialised
-        fp32 logits (TCAR_FUSED_CE = 0), the materialised candidate-time columns (TCAR_ONEHOT_TIME = 1 / 0);
+        (TCAR_PROJ_SPLIT_ROWS), float atomics instead of the order-fixed sums (TCAR_SORT_SCATTER = 0, TCAR_DET_SMALL = 0), the softmax
+        epilogue with group maxima + the rescale pass instead of the anchored form (TCAR_FUSED_CE = 1), materialised fp32 logits (TCAR_FUSED_CE = 0), the materialised candidate-time columns (TCAR_ONEHOT_TIME = 1 / 0);
       * TCAR_MHA_MFMA (off the training step): tests/test_gpu_torch_ops.py runs the attention core in both forms."""
     _need_gpu()
     from tcar_amd.engine import TcarEngine
@@ -864,7 +994,7 @@ def test_schedule_switches_agree_bitwise_with_the_default_schedule():
                {"TCAR_BF16_KS": 1}, {"TCAR_BF16_KS": 3}, {"TCAR_BF16_KS": 4}, {"TCAR_BF16_TILE": 1922}, {"TCAR_BF16_TILE": 1923},
                {"TCAR_GATHER_BIG_ROWS": 1}]
     close_only = [{"TCAR_BF16_TILE": 256}, {"TCAR_BF16_TILE": 2562}, {"TCAR_WGRAD_KS": 512}, {"TCAR_PROJ_SPLIT_ROWS": 0},
-                  {"TCAR_PROJ_SPLIT_ROWS": 1 << 20}, {"TCAR_SORT_SCATTER": 0}, {"TCAR_DET_SMALL": 0}, {"TCAR_FUSED_CE": 0},
+                  {"TCAR_PROJ_SPLIT_ROWS": 1 << 20}, {"TCAR_SORT_SCATTER": 0}, {"TCAR_DET_SMALL": 0}, {"TCAR_FUSED_CE": 1}, {"TCAR_FUSED_CE": 0},
                   {"TCAR_ONEHOT_TIME": 1}, {"TCAR_ONEHOT_TIME": 0}]
     covered = set()
     for sw in bitwise + close_only:
@@ -891,14 +1021,79 @@ def test_schedule_switches_agree_bitwise_with_the_default_schedule():
                 assert np.array_equal(base[1][k], run[1][k]), (sw, k)
         else:
             assert np.isfinite(run[0]).all(), sw
-            assert np.abs(base[0] - run[0]).max() <= 2e-4 * np.abs(base[0]).max(), (sw, np.abs(base[0] - run[0]).max())
+            # (TCAR_FUSED_CE = 1 / 0 round the softmax gradient's bf16 plane twice / from fp32 logits where the anchored default rounds
+            #  once: bf16-level differences in the gradients, amplified by Adam — test_anchored_softmax_form_in_the_step)
+            tol = 5e-3 if "TCAR_FUSED_CE" in sw else 2e-4
+            assert np.abs(base[0] - run[0]).max() <= tol * np.abs(base[0]).max(), (sw, np.abs(base[0] - run[0]).max())
 
+
+
+def test_anchored_softmax_form_in_the_step():
+    """Round 6: the fused step at the benched size takes the ANCHORED softmax form (no rescale pass over the [B, N] plane).
+      * the form is on for full 128-row blocks and off for a 500-session tail batch and under TCAR_FUSED_CE = 1;
+      * the anchor the forward pass leaves is the label's score without its time part (|difference| small, S_b >= e^-|difference|);
+      * DEFERRED steps (label rows of E updated in the early part of the split update, beside which the forward reads them) and
+        IMMEDIATE steps give the same bits — losses, variables, Adam moments: the rest pass never writes a row the forward reads;
+      * the anchored form and the rescaled form agree to 2e-4 of the loss scale over 30 steps and in every variable to the Adam bound;
+      * a tail batch (B = 500) between full batches switches forms inside one run."""
+    _need_gpu()
+    from tcar_amd.engine import TcarEngine
+    N, H, Ht, B, K = 46033, 250, 64, 512, 20
+    params, content, mw, _ = _case(N, H, Ht, 8, 2, K, seed=37)
+    batches = [_case(N, H, Ht, B, T, K, seed=700 + T)[3] for T in (2, 1, 5)]
+    tail = _case(N, H, Ht, 500, 3, K, seed=777)[3]
+
+    def run(sw, defer, with_tail=False, steps=30):
+        eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
+        if sw:
+            eng.set_tuning(**sw)
+        res = [eng.make_resident(b) for b in batches]
+        rt = eng.make_resident(tail)
+        form = (eng.step_form(res[0])["ce_anchored"], eng.step_form(rt)["ce_anchored"])
+        losses = []
+        for i in range(steps):
+            bt = rt if (with_tail and i % 7 == 3) else res[i % len(res)]
+            losses.append(eng.train_step(None, bt=bt, defer_update=defer)[:500].clone())
+        eng.flush()
+        eng.check_forks()
+        extra = None
+        if not defer and not with_tail:
+            anc = eng._ce_anchor.view(-1, 8)[:B].sum(1).cpu().numpy()
+            lab = eng._ce_ws[2 * B:3 * B].cpu().numpy()
+            extra = (anc, lab, eng._ce_rowscale[:2 * B].view(B, 2)[:, 0].cpu().numpy())
+        out = (torch.stack(losses).cpu().numpy(), eng.export_state(), form, extra)
+        del eng, res, rt
+        torch.cuda.empty_cache()
+        return out
+
+    imm = run({}, False)
+    assert imm[2] == (True, False), imm[2]
+    anc, lab, rs = imm[3]
+    assert np.abs(anc - lab).max() < 6.0, float(np.abs(anc - lab).max())       # the time part of the label's score
+    assert (rs > 0).all() and (rs <= np.exp(np.abs(anc - lab)) * 1.001).all()     # S_b >= exp(x_label - anchor)
+    dfr = run({}, True)
+    assert (imm[0] == dfr[0]).all()
+    for k in imm[1]:
+        assert np.array_equal(imm[1][k], dfr[1][k]), k
+    old = run({"TCAR_FUSED_CE": 1}, True)
+    assert old[2] == (False, False)
+    # (the forward pass of step 0 is the same arithmetic up to the reference of the exponentials; from then on the two forms'
+    #  gradients differ by bf16 roundings — one per plane element against two —, which Adam amplifies like any rounding noise)
+    assert np.abs(old[0][0] - dfr[0][0]).max() <= 2e-6 * np.abs(dfr[0]).max(), np.abs(old[0][0] - dfr[0][0]).max()
+    assert np.abs(old[0] - dfr[0]).max() <= 5e-3 * np.abs(dfr[0]).max(), np.abs(old[0] - dfr[0]).max()
+    for k in dfr[1]:        # variables: inside the Adam bound (a weight moves at most ~lr per step; the two forms differ by roundings)
+        if k.startswith("var/"):
+            assert np.abs(dfr[1][k] - old[1][k]).max() <= 2 * 30 * 1e-3, k
+    mix_a, mix_b = run({}, True, with_tail=True), run({"TCAR_FUSED_CE": 1}, True, with_tail=True)
+    assert np.isfinite(mix_a[0]).all()
+    assert np.abs(mix_a[0] - mix_b[0]).max() <= 5e-3 * np.abs(mix_b[0]).max()
 
 
 def test_ce_finish_as_one_launch_agrees_bitwise_with_the_two_launches():
     """Round 5: tcar_ce_finish as ONE launch whose workgroups fold their own rows' (max, sum) pairs (TCAR_CE_FOLD = w > 0, default
     1024) against the combine launch + rescale launch (0), at three grid sizes — the same lane-strided sums and shuffle trees, so the
-    plane, the losses, every variable and every Adam moment after 40 deferred steps agree BIT FOR BIT."""
+    plane, the losses, every variable and every Adam moment after 40 deferred steps agree BIT FOR BIT.  (The group-maximum form,
+    TCAR_FUSED_CE = 1: the anchored form of round 6 has no pass over the plane to fold into.)"""
     _need_gpu()
     from tcar_amd.engine import TcarEngine
     N, H, Ht, B, K = 46033, 250, 64, 512, 20
@@ -907,8 +1102,7 @@ def test_ce_finish_as_one_launch_agrees_bitwise_with_the_two_launches():
 
     def run(sw):
         eng = TcarEngine(params, content, mw, scoring="bf16x3-mixed")
-        if sw:
-            eng.set_tuning(**sw)
+        eng.set_tuning(TCAR_FUSED_CE=1, **sw)
         res = [eng.make_resident(b) for b in batches]
         losses = [eng.train_step(None, bt=res[i % len(res)], defer_update=True).clone() for i in range(40)]
         eng.flush()

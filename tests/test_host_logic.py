@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s)
-    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 28
+    assert lib.tcar_abi_version() == _lib.ABI_VERSION == 29
     # the binary carries the digest of the sources it was built from; the loader refuses a stale one
     assert lib.tcar_build_id().decode() == _lib.source_build_id() == _lib.binary_build_id()
     assert lib.tcar_gemm_splitk_effective(46080, 16) == 16
@@ -38,7 +38,7 @@ def test_tuning_switch_defaults():
     lib = _lib.load()
     env = {k: v for k, v in os.environ.items() if k.startswith("TCAR_")}
     want = {"TCAR_BF16_TILE": 0, "TCAR_BF16_KS": 2, "TCAR_WGRAD_KS": 1536, "TCAR_GATHER_BIG_ROWS": 16384, "TCAR_MHA_MFMA": 1,
-            "TCAR_SORT_SCATTER": 1, "TCAR_DET_SMALL": 1, "TCAR_FUSED_CE": 1, "TCAR_ONEHOT_TIME": 2, "TCAR_FLAG_FORK": 4095,
+            "TCAR_SORT_SCATTER": 1, "TCAR_DET_SMALL": 1, "TCAR_FUSED_CE": 2, "TCAR_ONEHOT_TIME": 2, "TCAR_FLAG_FORK": 4095,
             "TCAR_CE_FOLD": 1024, "TCAR_PROJ_SPLIT_ROWS": 1024}
     assert len(want) == 12                               # at most twelve live switches
     header = open(os.path.join(ROOT, "include", "tcar_hip.h")).read()
