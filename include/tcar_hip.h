@@ -335,11 +335,14 @@ int tcar_time_scores_clip(const tcar_dims_t* d, const float* const time_tab[5], 
                           void* p_hi, void* p_lo, int64_t inner, float* tclip, void* stream);
 int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                    float* rowstat, float* ce, void* dl_hi, int64_t inner, void* stream);
-/* ANCHORED form of the softmax epilogue + finish (round 6).  When the logits GEMM is handed a per-row reference a[b] (the fused step:
- * the label's score up to rounding, from the forward pass's finishing launch) its plane is exp(x - a[b]) and every group's statistic
- * is (a[b], sum): all groups of a row share ONE scale, and the plane never needs the rescale pass.  tcar_ce_anchor_fold (one wave per
- * row; B a multiple of 128) folds the group sums in a fixed order: S_b, lse = a + log S_b, ce = lse - lab_logit; writes
- * rowstat[b] = (a, 1 / S_b) (may be NULL); puts the label's -1 into the plane as v = bf16(e_l - S_b); writes
+/* ANCHORED form of the softmax epilogue + finish (round 6).  When every logit of row b comes out of the GEMM as x - a[b] for a per-row
+ * reference a[b] — the fused step: the label's score up to rounding, subtracted INSIDE the contraction: the forward pass's finishing
+ * launch leaves minus its partial sums in eight spare columns (139 .. 146) of the time-score planes, the one-hot plane of
+ * tcar_time_onehot has ones there — tcar_gemm_bf16_ce_anchor writes the plane exp(accumulator) without group maxima, statistics
+ * (0, group sum) and lab_logit = the label's accumulator: all groups of a row share ONE scale, and the plane never needs the rescale
+ * pass.  tcar_ce_anchor_fold (one wave per row; B a multiple of 128) folds the group sums in a fixed order: S_b,
+ * ce = log S_b - lab_logit; writes
+ * rowstat[b] = (0, 1 / S_b) (may be NULL); puts the label's -1 into the plane as v = bf16(e_l - S_b); writes
  * scale2[b] = (1 / S_b, ((e_l - S_b) - v) / S_b) for the consumer that is linear in the plane's rows (the slab reduce of dX,
  * tcar_reduce_dact_onehot_scaled: softmax part scaled exactly, the one-hot's rounding residual added back in fp32); and writes
  * aps = bf16((ap_hi + ap_lo)[b, :] / S') with S' = e_l - v, the per-row scaled copy of the packed attout planes [B, ap_cols]
@@ -349,12 +352,13 @@ int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stat
 int tcar_ce_anchor_fold(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                         float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner, const void* ap_hi, const void* ap_lo,
                         void* aps_hi, int ap_cols, int64_t ap_inner, void* stream);
-/* tcar_gemm_bf16_ce with the anchored epilogue: anchor [M, anchor_n] partial sums of the row's reference (added in index order) */
+/* tcar_gemm_bf16_ce with the anchored epilogue: the caller has put the row references into the contraction (see above); plane =
+ * exp(accumulator), statistics (0, group sum), lab_logit = the label's accumulator */
 int tcar_gemm_bf16_ce_anchor(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
                              const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, int K1, const void* A2_hi,
                              const void* A2_lo, const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner, int64_t p_rows,
                              float* stats, int64_t stats_floats, const int32_t* label, float* lab_logit, int nsplit,
-                             int32_t* group_width, int32_t* ngroups, const float* anchor, int anchor_n, void* stream);
+                             int32_t* group_width, int32_t* ngroups, void* stream);
 /* tcar_reduce_dact_onehot for the anchored form: the slab sums (and dP) of row m times scale2[m].x, plus scale2[m].y times
  * [E[label[m], 0 .. ic) | onehot(mwdhm[label[m]])] (E: fp32 candidate rows [n_items, ldE]), in front of the addend; no bias column sums */
 int tcar_reduce_dact_onehot_scaled(const float* slabs, int splitk, int M, int ic, int64_t ld, const float* addend, int64_t ld_add,
@@ -813,11 +817,11 @@ typedef struct {
    * step keeps the row pieces in the tail of segsum_ws and one workgroup per table row */
   float* small_det_ws; int64_t small_det_ws_floats;
   /* optional buffers of the ANCHORED softmax form (fused training steps in the one-hot form with B a multiple of 128;
-   * TCAR_FUSED_CE = 2; tcar_ce_anchor_fold): ce_anchor [B, 2 ldh / 64] partial label scores written by the forward pass's
-   * finishing launch, ce_rowscale [B, 2] = (1 / S_b, one-hot residual), aps16h = the packed attout plane scaled per row, [ceil128(B), ldh + 5 ldt] bf16
-   * (KB32), ce_form = ONE host int that carries the form the forward half of a step chose to its backward half.  With them a
-   * step's plane of exponentials is never rescaled: 94 MB of traffic and one [B, N] pass less per step at the Globo shape. */
-  float* ce_anchor; float* ce_rowscale; void* aps16h; int32_t* ce_form /*host*/;
+   * TCAR_FUSED_CE = 2; tcar_ce_anchor_fold): ce_rowscale [B, 2] = (1 / S_b, one-hot residual), aps16h = the packed attout plane
+   * scaled per row, [ceil128(B), ldh + 5 ldt] bf16 (KB32), ce_form = ONE host int that carries the form the forward half of a step
+   * chose to its backward half.  With them a step's plane of exponentials is never rescaled: 94 MB of traffic and one [B, N] pass
+   * less per step at the Globo shape. */
+  float* ce_rowscale; void* aps16h; int32_t* ce_form /*host*/;
 } tcar_ctx_t;
 
 /* Probe before setting tcar_ctx_t.sig_dev: does a polling kernel on `side_stream` run beside a kernel enqueued BEHIND it on

@@ -224,7 +224,7 @@ class Ctx(C.Structure):
                    ("sig_dev", C.c_void_p), ("fork_host", C.c_void_p), ("sig_err_host", C.c_void_p), ("tune", C.c_void_p),
                    ("fold_scratch", C.c_void_p), ("fold_scratch_words", C.c_int32),
                    ("small_det_ws", C.c_void_p), ("small_det_ws_floats", C.c_int64),
-                   ("ce_anchor", C.c_void_p), ("ce_rowscale", C.c_void_p), ("aps16h", C.c_void_p), ("ce_form", C.c_void_p)])
+                   ("ce_rowscale", C.c_void_p), ("aps16h", C.c_void_p), ("ce_form", C.c_void_p)])
 
 
 TUNING_FIELDS = ["bf16_tile", "bf16_ks", "wgrad_ks", "gather_big_rows", "mha_mfma", "sort_scatter", "det_small", "fused_ce", "onehot_time",
@@ -342,7 +342,7 @@ def load() -> C.CDLL:
     lib.tcar_ce_finish.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.tcar_ce_anchor_fold.argtypes = [i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp, i32, i64, vp]
     lib.tcar_gemm_bf16_ce_anchor.argtypes = [i32, i32, i32, vp, vp, i64, i64, vp, vp, i64, i64, i32, vp, vp, vp, i64, vp, i64, i64, vp, i64,
-                                             vp, vp, i32, vp, vp, vp, i32, vp]
+                                             vp, vp, i32, vp, vp, vp]
     lib.tcar_reduce_dact_onehot_scaled.argtypes = [vp, i32, i32, i32, i64, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, i64, vp, i32, vp]
     lib.tcar_ce_shard_stats.argtypes = [i32, i32, vp, vp, vp, i32, i32, vp, vp]
     lib.tcar_ce_rescale.argtypes = [i32, i32, i32, i32, vp, vp, vp, i32, i32, vp, i64, vp]

@@ -553,6 +553,11 @@ __global__ __launch_bounds__(256) void time_onehot_kernel(int n_items, const int
     const int id = clampi(mwdhm[n * 5 + k], 0, time_vocab(k) - 1);
     oh[kb32_off(n, time_rowoff(k) + id, in32)] = (__bf16)1.0f;
   }
+  // columns 139 .. 146: ONES — the anchor columns of the anchored softmax form.  The time-score planes P hold minus the partial sums of
+  // a session's anchor there (attout_finish_kernel) and zeros otherwise (every other writer of P zeroes columns >= 139), so the logits
+  // GEMM's one-hot K segment — 160 columns of which 139 carry time rows — subtracts the anchor inside the contraction, for free
+#pragma unroll
+  for (int j = 0; j < TCAR_ANCHOR_COLS; ++j) oh[kb32_off(n, 139 + j, in32)] = (__bf16)1.0f;
 }
 struct ScoreArgs {
   tcar_dims_t d;
@@ -644,9 +649,10 @@ struct FinishArgs {
   float* out; long ld_out;
   __bf16* a_hi; __bf16* a_lo; int a_in32;                 // planes of attout (may be NULL)
   __bf16* ap_hi; __bf16* ap_lo; int ap_in32;              // packed [item | time] planes (may be NULL)
-  // anchor of the anchored softmax epilogue (score.hip: ce_anchor_fold_kernel; may be NULL): per row and 64-column block of the
-  // item | content columns, the partial sum of attout[b, :] . E[label[b], :] — the label's score without its time part, in fp32
-  const int32_t* label; const float* E; long ldE; float* anchor;
+  // anchor of the anchored softmax form (score.hip: ce_anchor_fold_kernel; label NULL: none): per row and 64-column block j of the
+  // item | content columns, the partial sum of attout[b, :] . E[label[b], :] — the label's score without its time part — leaves as
+  // P[b, 139 + j] = -partial (hi / lo), against the ones of the one-hot plane's anchor columns (time_onehot_kernel)
+  const int32_t* label; const float* E; long ldE;
 };
 __device__ __forceinline__ void store_planes4(__bf16* hi, __bf16* lo, long o, float4 y) {
   typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_f;
@@ -722,18 +728,25 @@ __global__ __launch_bounds__(256) void attout_finish_kernel(const FinishArgs a) 
         store_planes4(a.ap_hi, a.ap_lo, kb32_off(row, col < ldh ? col : col - (ic - ldh), a.ap_in32), yv);
     }
     if (scores) st4(xl + r * ls + c * 4, yv);
-    if (a.anchor && !timeblk) {          // (workgroup-uniform) one partial per (row, column block): a fixed 16-lane tree
+    if (a.label && !timeblk) {          // (workgroup-uniform) one partial per (row, column block): a fixed 16-lane tree
       float dl = 0.f;
       if (row < a.s.B) dl = dot4(yv, ld4(a.E + (long)clampi(a.label[row], 0, a.s.d.n_items - 1) * a.ldE + col));
-      dl = group_sum(dl, 16);
-      if (c == 0 && row < a.s.B) a.anchor[row * (ic >> 6) + (y - 5)] = dl;
+      dl = -group_sum(dl, 16);
+      if (c == 0) {                       // (padding rows of the 16-row block: zero, like every padding row of P)
+        const __bf16 h = (__bf16)dl;
+        const long o = kb32_off(row, 139 + (y - 5), a.s.in32);
+        a.s.ph[o] = h;
+        a.s.pl[o] = (__bf16)(dl - (float)h);
+      }
     }
   }
   if (!scores) return;
   __syncthreads();
   const int b = tid & 15, rg = tid >> 4;
   const float* x = xl + b * ls;
-  const int nz = y == 4 ? 160 - 139 : 0;         // the last table's workgroups also zero the padding columns
+  // the last table's workgroups also zero the padding columns — but for the anchor columns the item | content workgroups fill (above)
+  const int nanc = a.label ? (ic >> 6) : 0;
+  const int nz = y == 4 ? 160 - 139 : 0;
 #pragma unroll 2
   for (int r = rg; r < nk + nz; r += 16) {
     float v = 0.f;
@@ -747,6 +760,7 @@ __global__ __launch_bounds__(256) void attout_finish_kernel(const FinishArgs a) 
       }
       v = ((s4.x + s4.y) + (s4.z + s4.w)) * sc[r];
     }
+    if (r >= nk && r - nk < nanc) continue;       // an anchor column
     const __bf16 h = (__bf16)v;
     const long o = kb32_off(b0 + b, off + r, a.s.in32);
     a.s.ph[o] = h;
@@ -1584,16 +1598,16 @@ extern "C" int tcar_attout_finish_scores(const tcar_dims_t* d, const float* cons
                                          int64_t ld_out, void* a_hi, void* a_lo, int64_t a_inner, void* ap_hi, void* ap_lo,
                                          int64_t ap_inner, void* p_hi, void* p_lo, int64_t p_inner, float* tclip, void* stream) {
   return tcar_attout_finish_scores_a(d, time_tab, B, slabs, nd_ic, nd_pt, stride, bias_o, bias_ot, attout, ld_out, a_hi, a_lo, a_inner,
-                                     ap_hi, ap_lo, ap_inner, p_hi, p_lo, p_inner, tclip, nullptr, nullptr, 0, nullptr, stream);
+                                     ap_hi, ap_lo, ap_inner, p_hi, p_lo, p_inner, tclip, nullptr, nullptr, 0, stream);
 }
-// ... + the anchor partials of the anchored softmax epilogue: anchor [B, 2 ldh / 64] (NULL: none); E [n_items, ldE] fp32 candidate
+// ... + the anchor of the anchored softmax form (label != NULL; needs the score planes): P[b, 139 + j] = minus the j-th 64-column
+// partial of attout[b, :] . E[label[b], :] over the item | content columns (2 ldh / 64 <= 8 of them).  E [n_items, ldE] fp32 candidate
 // rows (item | content columns first), label [B] 0-based
 int tcar_attout_finish_scores_a(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* slabs, int nd_ic, int nd_pt,
                                 int64_t stride, const float* bias_o, const float* bias_ot, float* attout, int64_t ld_out, void* a_hi,
                                 void* a_lo, int64_t a_inner, void* ap_hi, void* ap_lo, int64_t ap_inner, void* p_hi, void* p_lo,
-                                int64_t p_inner, float* tclip, const int32_t* label, const float* E, int64_t ldE, float* anchor,
-                                void* stream) {
-  if (anchor && (!label || !E || ldE < 2 * d->ldh || (ldE & 3) || !tcar_aligned16(E))) return TCAR_E_ARG;
+                                int64_t p_inner, float* tclip, const int32_t* label, const float* E, int64_t ldE, void* stream) {
+  if (label && (!p_hi || !E || ldE < 2 * d->ldh || (ldE & 3) || !tcar_aligned16(E) || 2 * d->ldh / 64 > TCAR_ANCHOR_COLS)) return TCAR_E_ARG;
   if (check_dims(d) || d->ldt != 64 || (d->ldh & 63) || !time_tab || B <= 0 || !slabs || nd_ic <= 0 || nd_pt <= 0 || !bias_o || !bias_ot ||
       !attout || (ld_out & 3) || !tcar_aligned16(slabs) || !tcar_aligned16(attout) || (stride & 3))
     return TCAR_E_ARG;
@@ -1608,7 +1622,7 @@ int tcar_attout_finish_scores_a(const tcar_dims_t* d, const float* const time_ta
   a.out = attout; a.ld_out = (long)ld_out;
   a.a_hi = (__bf16*)a_hi; a.a_lo = (__bf16*)a_lo; a.a_in32 = (int)(a_inner >> 5);
   a.ap_hi = (__bf16*)ap_hi; a.ap_lo = (__bf16*)ap_lo; a.ap_in32 = (int)(ap_inner >> 5);
-  a.label = label; a.E = E; a.ldE = (long)ldE; a.anchor = anchor;
+  a.label = label; a.E = E; a.ldE = (long)ldE;
   const long Bp = p_hi ? (((long)B + 127) & ~127L) : (((long)B + 15) & ~15L);      // the score planes' padding rows are written (zeros)
   const size_t lds = ((size_t)(61 + 16) * 68 + 64) * sizeof(float);
   TCAR_LAUNCH(attout_finish_kernel, dim3((unsigned)(Bp / 16), 5 + 2 * d->ldh / 64), dim3(256), lds, (hipStream_t)stream, a);

@@ -59,7 +59,7 @@ struct BArgs {
   float* stats; int ngroups;   // [M, ngroups, 2]
   const int32_t* label; float* lab_logit;
   int lab_off, lab_window;     // TcarOpt: column of the label = label[m] - lab_off; window: outside [0, N) = not in this shard
-  const float* anchor; int anchor_n;     // TcarOpt: anchored epilogue — exp(x - anchor[m]) instead of exp(x - group maximum); NULL = maxima
+  int anchored;                // TcarOpt: anchored epilogue — the accumulators are x - anchor[m] already: exp(acc), no group maximum
   // dX of the one-hot form (layout 0, hi planes only): N tiles at or beyond column n_b2 (a multiple of the tile width) read their B
   // operand from the plane B2 (inner b2_in32 * 32, rows as B) at column n0 - n_b2 — the static one-hot matrix of
   // publish_time_MWDHM, so that those output columns are dP = dlogits OH instead of dlogits E_time.  0: unused.
@@ -410,10 +410,8 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
         const int row = m0 + wm * (32 * TMW) + u * 32 + li;
         const bool live = FAST || row < g.M;
         float mx = -INFINITY;
-        if (g.anchor) {      // anchored form (workgroup-uniform): the row's reference comes in, summed in index order
+        if (g.anchored) {      // anchored form (workgroup-uniform): the reference was subtracted inside the contraction
           mx = 0.f;
-          if (live)
-            for (int j = 0; j < g.anchor_n; ++j) mx += g.anchor[(long)row * g.anchor_n + j];
         } else {
 #pragma unroll
           for (int t = 0; t < TNW; ++t)
@@ -592,9 +590,7 @@ int launch_k(BArgs& g, int splitk, hipStream_t st, LaunchCall& lc) {
       g.sig = tcar_sig(lc.o);
       g.lab_off = lc.o ? lc.o->lab_off : 0;
       g.lab_window = lc.o ? lc.o->lab_window : 0;
-      g.anchor = lc.o ? lc.o->anchor : nullptr;
-      g.anchor_n = lc.o ? lc.o->anchor_n : 0;
-      if (g.anchor && g.anchor_n <= 0) return TCAR_E_ARG;
+      g.anchored = (lc.o && lc.o->anchored) ? 1 : 0;
       if (g.B2) {
         if constexpr (NSPLIT == 3 && KS == 1) {
           TCAR_SET_LDS_ONCE((gemm_bf16_kernel<MA, MB, NSPLIT, WMW, WNW, TMW, TNW, KS, 1, 1, VAR>), lds);
@@ -755,16 +751,15 @@ extern "C" int tcar_gemm_bf16_ce(int M, int N, int K, const void* A_hi, const vo
   return tcar_gemm_bf16_ce_o(M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, K1, A2_hi, A2_lo, B2_hi, inner2, p_hi,
                              p_inner, p_rows, stats, stats_floats, label, lab_logit, nsplit, group_width, ngroups, stream, nullptr);
 }
-// anchored form (TcarOpt::anchor): plane = exp(x - sum of the row's anchor_n partials), statistics (anchor, sum) per group
+// anchored form (TcarOpt::anchored): the caller has put the row references INTO the contraction (e.g. minus their partial sums in spare
+// columns of A2 against columns of ones in B2), so the plane is exp(accumulator), the statistics (0, group sum), lab_logit relative
 extern "C" int tcar_gemm_bf16_ce_anchor(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
                                         const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, int K1, const void* A2_hi,
                                         const void* A2_lo, const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner,
                                         int64_t p_rows, float* stats, int64_t stats_floats, const int32_t* label, float* lab_logit,
-                                        int nsplit, int32_t* group_width, int32_t* ngroups, const float* anchor, int anchor_n,
-                                        void* stream) {
-  if (!anchor || anchor_n <= 0) return TCAR_E_ARG;
+                                        int nsplit, int32_t* group_width, int32_t* ngroups, void* stream) {
   TcarOpt o;
-  o.anchor = anchor; o.anchor_n = anchor_n;
+  o.anchored = true;
   return tcar_gemm_bf16_ce_o(M, N, K, A_hi, A_lo, a_inner, a_rows, B_hi, B_lo, b_inner, b_rows, K1, A2_hi, A2_lo, B2_hi, inner2, p_hi,
                              p_inner, p_rows, stats, stats_floats, label, lab_logit, nsplit, group_width, ngroups, stream, &o);
 }

@@ -277,10 +277,12 @@ __global__ __launch_bounds__(256) void ce_rescale_kernel(int B, int N, int in32,
   ce_rescale_body<GW>(B, N, in32, ngroups, stats, rowstat, label, plane, nunits, lab_off, lab_window, sig.cnt != nullptr);
   tcar_signal_done(sig);        // (the body is a function: its early returns end up here)
 }
-// ---- ANCHORED form (round 6): the plane holds exp(x - anchor[b]) with ONE reference per row (tcar_gemm_bf16_ce_o with
-// TcarOpt::anchor), so a row's softmax is plane / S_b with S_b = the sum of its group sums, and NO pass over the [B, N] plane
-// follows the logits GEMM: this launch (one wave per session row) folds the row's group sums in a fixed order — lse = anchor + log S,
-// ce = lse - x_label — and prepares the two consumers, which scale PER ROW:
+// ---- ANCHORED form (round 6): the plane holds exp(x - anchor[b]) with ONE reference per row — subtracted INSIDE the logits GEMM's
+// contraction (anchor columns of its one-hot K segment: embed.hip; tcar_gemm_bf16_ce_o with TcarOpt::anchored), so that the GEMM's
+// epilogue neither computes group maxima nor loads anything —, a row's softmax is plane / S_b with S_b = the sum of its group sums, and
+// NO pass over the [B, N] plane follows the logits GEMM: this launch (one wave per session row) folds the row's group sums in a fixed
+// order — ce = log S_b - (x_label - anchor), the label's accumulator as the GEMM leaves it in lab_logit — and prepares the two
+// consumers, which scale PER ROW:
 //   * the label's -1 goes INTO the plane as v = bf16(e_l - S_b).  Rounded like that it carries the one-hot — the LARGEST term of a
 //     row's gradient while the softmax is flat — with up to 2^-8 relative error (measured: 1.6e-3 instead of 1e-4 norm-wise on the
 //     time-side gradients against the fp64 oracle), so the residual d = (e_l - S_b) - v is kept in fp32;
@@ -318,7 +320,6 @@ __global__ __launch_bounds__(256) void ce_anchor_fold_kernel(int B, int N, int i
     for (int g = lane; g < ngroups; g += 64) s += st[g].y;
   }
   s = wave_sum(s);
-  const float anchor = st[0].x;
   const int lab = clampi(label[b], 0, N - 1);
   __bf16* q = plane + kb32_off(b, lab, in32);
   const float el = (float)*q;                     // (every lane: the same address, the same bits)
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(256) void ce_anchor_fold_kernel(int B, int N, int i
   const __bf16 v = (__bf16)t;
   const float inv = 1.0f / s, inv_e = 1.0f / (el - (float)v);
   if (lane == 0) {
-    if (rowstat) { rowstat[2 * b] = anchor; rowstat[2 * b + 1] = inv; }
-    ce[b] = anchor + logf(s) - lab_logit[b];
+    if (rowstat) { rowstat[2 * b] = 0.f; rowstat[2 * b + 1] = inv; }         // (reference of the exponentials: the anchor = 0 here)
+    ce[b] = logf(s) - lab_logit[b];
     scale2[2 * b] = inv;
     scale2[2 * b + 1] = (t - (float)v) * inv;
     *q = v;                                       // (v depends on the wave's one load of the entry: it has returned for every lane)
@@ -713,9 +714,13 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
   const bool fx = fix.scale2 != nullptr;
   float rs = 1.f, rd = 0.f;
   int flab = 0;
+  float4 fe = zero4();       // the label's candidate row / publish-time index of this thread's columns: in flight beside the slab loads
+  int fk = -1;
   if (fx && row < M) {
     rs = fix.scale2[2 * row]; rd = fix.scale2[2 * row + 1];
     flab = clampi(fix.label[row], 0, fix.n_items - 1);
+    if ((int)blockIdx.x < nic) fe = ld4(fix.E + (long)flab * fix.ldE + blockIdx.x * 64 + cg * 4);
+    else fk = fix.mwdhm[(long)flab * 5 + (blockIdx.x - nic)];
   }
   float4 cs = zero4();
   int col;                                   // output column of this thread's float4
@@ -733,10 +738,7 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
         for (int j = 0; j < 9; ++j) acc = add4(acc, t[j]);
       }
       for (; k < S; ++k) acc = add4(acc, ld4(sp + (long)k * M * lds_));
-      if (fx) {
-        const float4 e = ld4(fix.E + (long)flab * fix.ldE + col);
-        acc = make_float4(fmaf(rd, e.x, acc.x * rs), fmaf(rd, e.y, acc.y * rs), fmaf(rd, e.z, acc.z * rs), fmaf(rd, e.w, acc.w * rs));
-      }
+      if (fx) acc = make_float4(fmaf(rd, fe.x, acc.x * rs), fmaf(rd, fe.y, acc.y * rs), fmaf(rd, fe.z, acc.z * rs), fmaf(rd, fe.w, acc.w * rs));
     }
     // the negative term's part comes from the aux stream: behind its flag, waited for HERE (after the slab sum), or an event
     if (addend) tcar_wave_wait(wait_add);
@@ -772,7 +774,7 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
           for (int u = 0; u < 6; ++u) v[j] += t[u];
         }
         for (; q < S; ++q) v[j] += sp[(long)q * M * lds_];
-        if (fx) v[j] = fmaf(v[j], rs, (clampi(fix.mwdhm[(long)flab * 5 + k], 0, nk - 1) == c) ? rd : 0.f);
+        if (fx) v[j] = fmaf(v[j], rs, (clampi(fk, 0, nk - 1) == c) ? rd : 0.f);
         if (sig.cnt) __hip_atomic_store(dP + (long)row * 160 + off + c, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else dP[(long)row * 160 + off + c] = v[j];
       }

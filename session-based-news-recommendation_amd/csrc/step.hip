@@ -318,10 +318,11 @@ bool onehot_bwd(const tcar_ctx_t* c, const tcar_batch_t* bt) {
          c->ct_ws && c->stream3 && c->ev3 && c->gw_rows && sorted_rows(c, bt) && tn(c).det_small != 0;
 }
 // anchored softmax form (score.hip: ce_anchor_fold_kernel): the one-hot step with the buffers of the form, full 128-row blocks
-// (the planes then have no padding rows for a rescale pass to zero) and at most eight 64-column anchor partials per row
+// (the planes then have no padding rows for a rescale pass to zero) and at most eight 64-column anchor partials per row (the anchor
+// columns of the one-hot K segment: embed.hip)
 bool ce_anchored(const tcar_ctx_t* c, const tcar_batch_t* bt) {
-  return onehot_bwd(c, bt) && tn(c).fused_ce >= 2 && (bt->B & 127) == 0 && c->ce_anchor && c->ce_rowscale && c->aps16h && c->ce_form &&
-         c->d.ldh <= 256;
+  return onehot_bwd(c, bt) && tn(c).fused_ce >= 2 && (bt->B & 127) == 0 && c->ce_rowscale && c->aps16h && c->ce_form &&
+         2 * c->d.ldh / 64 <= TCAR_ANCHOR_COLS;
 }
 }  // namespace
 
@@ -339,8 +340,9 @@ namespace {
 // their split form the finishing launch computes them too and sets so->done — the caller then skips tcar_time_scores_clip
 struct ScoreOut {
   void* p_hi; void* p_lo; float* tclip; bool done;
-  // anchored softmax form: the finishing launch also leaves the anchor partials (label rows of E: see forward_impl); anchor_done says so
-  const int32_t* label = nullptr; const float* E = nullptr; int64_t ldE = 0; float* anchor = nullptr; bool anchor_done = false;
+  // anchored softmax form: the finishing launch also leaves minus the anchor partials in the anchor columns of P (label rows of E: see
+  // forward_impl); anchor_done says so
+  const int32_t* label = nullptr; const float* E = nullptr; int64_t ldE = 0; bool anchor_done = false;
 };
 template <class Hook>
 int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, void* stream, bool planes, int ei, Hook hook,
@@ -453,9 +455,8 @@ int session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, const Geo& g, v
     RET(tcar_attout_finish_scores_a(&c->d, tt, B, c->proj_slabs, na_ic, na_pt, astride, W(c, TCAR_V_O_B), W(c, TCAR_V_OT_B), c->attout,
                                     g.ek, planes ? c->a16h : nullptr, planes ? c->a16l : nullptr, g.ek, planes ? c->ap16h : nullptr,
                                     planes ? c->ap16l : nullptr, g.ldh + g.pt, so ? so->p_hi : nullptr, so ? so->p_lo : nullptr, 160,
-                                    so ? so->tclip : nullptr, so ? so->label : nullptr, so ? so->E : nullptr, so ? so->ldE : 0,
-                                    so ? so->anchor : nullptr, stream));
-    if (so) { so->done = true; so->anchor_done = so->anchor != nullptr; }
+                                    so ? so->tclip : nullptr, so ? so->label : nullptr, so ? so->E : nullptr, so ? so->ldE : 0, stream));
+    if (so) { so->done = true; so->anchor_done = so->label != nullptr; }
     return TCAR_OK;
   }
   {
@@ -596,7 +597,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
   const bool ce_epi = c->scoring && train_index && fused_ce(c, B, &w);
   const bool onehot = ce_epi && onehot_fwd(c, B);
   ScoreOut so{c->p16h, c->p16l, oh_bwd ? c->tclip : nullptr, false};
-  if (anchored) { so.label = bt->label; so.E = c->E; so.ldE = g.ek; so.anchor = c->ce_anchor; }
+  if (anchored) { so.label = bt->label; so.E = c->E; so.ldE = g.ek; }
   RET(session_forward(c, bt, g, stream, c->scoring != 0, ei, [&](int stage, TcarOpt* o) -> int {
     if (rest_stage == 1 && stage == 0) o->sig = fork_arm(c, FK_PROJ);        // the projection launch carries the flag
     if (stage != rest_stage) return TCAR_OK;
@@ -638,7 +639,7 @@ int forward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, int refresh_time, 
     // the form the backward half of this step finds: anchored only when the finishing launch did leave the anchor partials
     const bool anch = anchored && onehot && so.anchor_done;
     if (c->ce_form) *c->ce_form = anch ? 1 : 0;
-    if (anch) { ol.anchor = c->ce_anchor; ol.anchor_n = g.ic >> 6; }
+    ol.anchored = anch;
     if (ce_epi) {
       // training step, hi-only backward: the GEMM's softmax epilogue writes exp(x - group max) as the bf16 plane that becomes
       // dlogits, plus per-group (max, sum) — no [B, N] fp32 logits; backward_impl finishes with tcar_ce_finish

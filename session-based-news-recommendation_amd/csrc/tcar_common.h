@@ -112,6 +112,7 @@ __device__ __forceinline__ float ld1_sc1(const float* p) { return __hip_atomic_l
 // times [E | OH]; scale2[m] = (1 / S_m, r_m): the slab sums (and dP) of row m are multiplied by 1 / S_m, and r_m — the part of the
 // one-hot's -1 that the bf16 label entry of the plane could not hold, already divided by S_m — comes back in fp32 as
 // r_m * [E[label[m], :] | onehot(publish time of label[m])].  E: fp32 candidate rows [n_items, ldE] (item | content columns first).
+constexpr int TCAR_ANCHOR_COLS = 8;      // columns 139 .. 146 of the one-hot K segment (embed.hip: time_onehot_kernel)
 struct TcarRowFix {
   const float* scale2; const int32_t* label; const float* E; long ldE; const int32_t* mwdhm; int n_items;
 };
@@ -129,12 +130,13 @@ struct TcarOpt {
   // label window of the softmax-epilogue logits GEMM (catalog-sharded step): the column of row m's label is label[m] - lab_off,
   // and a label outside [0, N) is in another shard — no label score is written for it (lab_window = 0: labels are clamped)
   int lab_off = 0, lab_window = 0;
-  // ANCHORED softmax epilogue of the logits GEMM (round 6; step.hip: ce_anchored): the plane is exp(x - anchor[m]) with a per-row
-  // reference handed in (anchor[m] = sum of anchor_n partial sums at anchor + m * anchor_n, added in index order) instead of
-  // exp(x - group maximum): every group of a row then shares ONE scale, so the plane never needs the rescale pass — dX is scaled
-  // per row in its slab reduce (`rowscale`), dE contracts the plane with per-row scaled attout planes (tcar_ce_anchor_fold_o)
-  const float* anchor = nullptr;
-  int anchor_n = 0;
+  // ANCHORED softmax epilogue of the logits GEMM (round 6; step.hip: ce_anchored): the accumulators already are x - anchor[m] — the
+  // anchor rides in the one-hot K segment (eight spare columns of the time-score planes hold minus its partial sums, the one-hot
+  // plane has ones there: embed.hip) — so the plane is exp(accumulator) with NO group maximum, the statistics are (0, group sum) and
+  // lab_logit is the label's accumulator (its score minus the anchor).  Every group of a row then shares ONE scale, the plane never
+  // needs the rescale pass: dX is scaled per row in its slab reduce (rowfix), dE contracts the plane with per-row scaled attout
+  // planes (tcar_ce_anchor_fold_o)
+  bool anchored = false;
   const TcarRowFix* rowfix = nullptr;      // one-hot slab reduce of the anchored form (below)
   // zeroed device words a launch may use for an order-fixed last-arrival fold (tcar_sqnorm_o: word 0 = arrival counter, kept zero
   // between launches; then one float per 32,768-float chunk): tcar_ctx_t.fold_scratch
@@ -163,8 +165,7 @@ int tcar_clip_adam_early_2(float* w, const float* g, float* m, float* v, const t
 int tcar_attout_finish_scores_a(const tcar_dims_t* d, const float* const time_tab[5], int B, const float* slabs, int nd_ic, int nd_pt,
                                 int64_t stride, const float* bias_o, const float* bias_ot, float* attout, int64_t ld_out, void* a_hi,
                                 void* a_lo, int64_t a_inner, void* ap_hi, void* ap_lo, int64_t ap_inner, void* p_hi, void* p_lo,
-                                int64_t p_inner, float* tclip, const int32_t* label, const float* E, int64_t ldE, float* anchor,
-                                void* stream);
+                                int64_t p_inner, float* tclip, const int32_t* label, const float* E, int64_t ldE, void* stream);
 int tcar_gather_clip_fwd_o(const tcar_dims_t* d, const tcar_tables_t* tab, const tcar_batch_t* bt, float* x_icp, float* x_pt,
                            float* x_act, float* click_t, void* stream, TcarOpt* o);
 int tcar_query_mlp_o(const tcar_dims_t* d, int B, const float* click_t, const float* q1_w, const float* q1_b, const float* q2_w,

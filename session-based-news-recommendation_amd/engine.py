@@ -835,17 +835,15 @@ class TcarEngine:
                         if getattr(self, "_dP", None) is None or self._dP.numel() < self.work_B * 160:
                             self._dP = torch.zeros(self.work_B * 160, dtype=torch.float32, device=self.dev)
                         c.tclip, c.dP, c.qz = self._tclip.data_ptr(), self._dP.data_ptr(), self._qz.data_ptr()
-                        # anchored softmax form (tcar_hip.h: ce_anchor ...): anchor partials, row scales, the scaled attout plane of
-                        # dE, and the host int that carries the form from the forward to the backward half of a step
+                        # anchored softmax form (tcar_hip.h: ce_rowscale ...): row scales, the scaled attout plane of dE, and the
+                        # host int that carries the form from the forward to the backward half of a step
                         if not os.environ.get("TCAR_NO_CE_ANCHOR"):
                             Bp = _ru(self.work_B, 128)
-                            if getattr(self, "_ce_anchor", None) is None or self._ce_rowscale.numel() < 2 * Bp:
-                                self._ce_anchor = torch.zeros(Bp * 8, dtype=torch.float32, device=self.dev)
+                            if getattr(self, "_ce_rowscale", None) is None or self._ce_rowscale.numel() < 2 * Bp:
                                 self._ce_rowscale = torch.zeros(2 * Bp, dtype=torch.float32, device=self.dev)
                                 self._aps16h = torch.zeros(Bp, g.ldh + g.pt, dtype=torch.bfloat16, device=self.dev)
                                 self._ce_form = (C.c_int32 * 1)(0)
-                            c.ce_anchor, c.ce_rowscale, c.aps16h = (self._ce_anchor.data_ptr(), self._ce_rowscale.data_ptr(),
-                                                                    self._aps16h.data_ptr())
+                            c.ce_rowscale, c.aps16h = self._ce_rowscale.data_ptr(), self._aps16h.data_ptr()
                             c.ce_form = C.cast(self._ce_form, C.c_void_p)
         if self.overlap:
             if not hasattr(self, "_aux"):

@@ -560,34 +560,38 @@ def test_logits_gemm_softmax_epilogue(lib, M, N, K, nsplit, K2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,N,K,K2", [(256, 1000, 64, 0), (128, 129, 96, 139), (512, 46033, 512, 139)])
-def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K, K2):
-    """Anchored form of the softmax epilogue (round 6): tcar_gemm_bf16_ce_anchor writes exp(x - a[b]) for a per-row reference handed in
-    as partial sums (here: the label's score +- 3, in 8 pieces), statistics (a[b], group sum); tcar_ce_anchor_fold then gives
-    ce = lse - x_label against fp64, rowscale = 1 / S, the label's entry as e - S, and the per-row scaled attout plane — and
-    plane * rowscale is softmax - onehot to the bf16 bound of ONE rounding (the rescaled form rounds twice)."""
+@pytest.mark.parametrize("M,N,K", [(256, 1000, 64), (128, 129, 96), (512, 46033, 512)])
+def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K):
+    """Anchored form of the softmax epilogue (round 6).  The row reference a[b] (here: the label's score +- 3) rides INSIDE the
+    contraction: the second K segment holds minus its eight partial sums in columns 139 .. 146 of A2 (hi / lo) against columns of ones
+    in B2 — as the step does with the time-score planes and the one-hot plane — so tcar_gemm_bf16_ce_anchor writes exp(x - a[b])
+    without group maxima, statistics (0, group sum) and the label's accumulator x_l - a; tcar_ce_anchor_fold then gives
+    ce = lse - x_label against fp64, scale2 = (1 / S, one-hot residual), the label's entry as bf16(e - S), and the per-row scaled
+    attout plane — and plane * scale (+ residual) is softmax - onehot to the bf16 bound of ONE rounding, the one-hot part to fp32."""
     rng = np.random.RandomState(M + N)
     A = (rng.standard_normal((M, K)) * 0.7).astype(np.float32)
     Bm = (rng.standard_normal((N, K)) * 0.6).astype(np.float32)
     label = rng.randint(0, N, M).astype(np.int32)
     label[0], label[-1] = 0, N - 1
-    x = A.astype(np.float64) @ Bm.astype(np.float64).T
-    ah, al, ai, ar = _planes(lib, A)
-    bh, bl, bi, br = _planes(lib, Bm)
-    seg2 = (K, None, None, None, 0)
-    if K2:
-        A2 = (rng.standard_normal((M, K2)) * 0.5).astype(np.float32)
-        B2 = (rng.uniform(size=(N, K2)) < 5.0 / K2).astype(np.float32)
-        x = x + A2.astype(np.float64) @ B2.astype(np.float64).T
-        a2h, a2l, a2i, _ = _planes(lib, A2)
-        b2h, b2l, b2i, _ = _planes(lib, B2)
-        seg2 = (K, ptr2(a2h), ptr2(a2l), ptr2(b2h), a2i)
+    A2 = np.zeros((M, 160), np.float32)
+    A2[:, :139] = rng.standard_normal((M, 139)) * 0.5
+    B2 = np.zeros((N, 160), np.float32)
+    B2[:, :139] = rng.uniform(size=(N, 139)) < 5.0 / 139
+    x = A.astype(np.float64) @ Bm.astype(np.float64).T + A2.astype(np.float64) @ B2.astype(np.float64).T
     xl = x[np.arange(M), label]
     parts = rng.standard_normal((M, 8)).astype(np.float32)
     parts[:, 0] += (xl + rng.uniform(-3, 3, M)).astype(np.float32) - parts.sum(1)
-    anchor = np.zeros(M, np.float32)
-    for j in range(8):
-        anchor = (anchor + parts[:, j]).astype(np.float32)          # the kernel's order
+    A2[:, 139:147] = -parts
+    B2[:, 139:147] = 1.0
+    ah, al, ai, ar = _planes(lib, A)
+    bh, bl, bi, br = _planes(lib, Bm)
+    a2h, a2l, a2i, _ = _planes(lib, A2)
+    b2h, b2l, b2i, _ = _planes(lib, B2)
+    assert a2i == b2i == 160 and float(b2l.float().abs().max()) == 0.0
+    # the reference the GEMM subtracts: the partials as their hi + lo planes hold them
+    pidx2 = torch.tensor(_kb32_index((M + 127) // 128 * 128, 160), device="cuda")
+    anchor = -(a2h[pidx2].double() + a2l[pidx2].double())[:M, 139:147].sum(1).cpu().numpy()
+    seg2 = (K, ptr2(a2h), ptr2(a2l), ptr2(b2h), a2i)
     Np, Mp = (N + 127) // 128 * 128, (M + 127) // 128 * 128
     assert Mp == M
     plane = torch.full((Mp * Np,), float("nan"), dtype=torch.bfloat16, device="cuda")
@@ -595,23 +599,22 @@ def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K, K2):
     stats = torch.full((nstat,), float("nan"), device="cuda")
     lab_d = torch.tensor(label).cuda()
     lab_logit = torch.zeros(M, device="cuda")
-    parts_d = torch.tensor(parts).cuda()
     gw, ng = C.c_int32(0), C.c_int32(0)
-    assert lib.tcar_gemm_bf16_ce_anchor(M, N, K + (160 if K2 else 0), ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, *seg2,
+    assert lib.tcar_gemm_bf16_ce_anchor(M, N, K + 160, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, *seg2,
                                         ptr2(plane), Np, Mp, ptr(stats), nstat, ptr2(lab_d), ptr(lab_logit), 3, C.byref(gw), C.byref(ng),
-                                        ptr(parts_d), 8, None) == 0
+                                        None) == 0
     gw, ng = gw.value, ng.value
     st = stats[:M * ng * 2].view(M, ng, 2).cpu().numpy()
-    assert (st[..., 0] == anchor[:, None]).all()
+    assert (st[..., 0] == 0).all()
     xp = np.full((M, ng * gw), -np.inf)
     xp[:, :N] = x
-    want_e = np.exp(xp - anchor.astype(np.float64)[:, None])
+    want_e = np.exp(xp - anchor[:, None])
     assert np.allclose(st[..., 1], want_e.reshape(M, ng, gw).sum(2), rtol=3e-4, atol=1e-6)
-    assert np.allclose(lab_logit.cpu().numpy(), xl, rtol=1e-5, atol=1e-5 * np.abs(x).max())
+    assert np.allclose(lab_logit.cpu().numpy(), xl - anchor, rtol=1e-5, atol=1e-5 * np.abs(x).max())
     idx = torch.tensor(_kb32_index(Mp, Np), device="cuda")
     e = plane[idx].float().cpu().numpy()
-    # (bf16: 7 explicit mantissa bits — round-to-nearest is within 2^-8 relative; + the fp32 exponential's own last bits)
-    # ... + the split-bf16 logits' own error, 1e-4 at |x| ~ 40)
+    # (bf16: 7 explicit mantissa bits — round-to-nearest is within 2^-8 relative; + the split-bf16 logits' own error inside the
+    #  exponential, 1e-4 at |x| ~ 40)
     assert (np.abs(e[:, :N] - want_e[:, :N]) <= (2.0 ** -8 + 1e-3) * want_e[:, :N] + 1e-30).all() and (e[:, N:] == 0).all()
     # ---- the fold
     cols = 576
@@ -627,7 +630,7 @@ def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K, K2):
     S = st[..., 1].astype(np.float64).sum(1)
     sc2 = rowscale.cpu().numpy().reshape(M, 2).astype(np.float64)
     rs, rd = sc2[:, 0], sc2[:, 1]
-    assert np.allclose(rs, 1.0 / S, rtol=1e-5) and np.allclose(rowstat.cpu().numpy().reshape(M, 2), np.stack([anchor, 1.0 / S], 1), rtol=1e-5)
+    assert np.allclose(rs, 1.0 / S, rtol=1e-5) and np.allclose(rowstat.cpu().numpy().reshape(M, 2), np.stack([0 * S, 1.0 / S], 1), rtol=1e-5)
     d = plane[idx].float().cpu().numpy()
     keep = np.ones((M, N), bool)
     keep[np.arange(M), label] = False
@@ -662,7 +665,8 @@ def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K, K2):
 @pytest.mark.parametrize("N,H,Ht,B", [(3000, 250, 64, 77), (46033, 250, 64, 512), (500, 30, 100, 5), (700, 100, 200, 33)])
 def test_time_onehot_plane_and_time_scores(lib, N, H, Ht, B):
     """tcar_time_onehot + tcar_time_scores (model_combine.py:86-92,135,138 — the candidate-side publish-time vectors' part of the
-    logits): OH is the exact one-hot plane of the five table rows of every item, P holds attout_t . clip(row) for every one of
+    logits): OH is the exact one-hot plane of the five table rows of every item (+ eight columns of ones, 139 .. 146, that the
+    anchored softmax form contracts with minus a session's anchor; P is zero there here), P holds attout_t . clip(row) for every one of
     the 139 rows, and (P OH^T)[b, n] equals sum_k attout_tk[b] . clip(table_k[mwdhm[n, k]]) in fp64 to the split-bf16 bound."""
     from tcar_amd._lib import Dims
     ldh, ldt = (H + 63) // 64 * 64, (Ht + 63) // 64 * 64
@@ -687,6 +691,7 @@ def test_time_onehot_plane_and_time_scores(lib, N, H, Ht, B):
     off = np.concatenate([[0], np.cumsum(sizes)])[:5]
     want_oh = np.zeros((Np, 160), np.float32)
     want_oh[np.arange(N)[:, None], off[None, :] + mw] = 1.0
+    want_oh[:N, 139:147] = 1.0           # the anchor columns of the anchored softmax form (P is zero there unless a step anchors)
     got_oh = oh[torch.tensor(_kb32_index(Np, 160), device="cuda")].float().cpu().numpy()
     assert (got_oh == want_oh).all()
     clipped = []
@@ -1058,8 +1063,9 @@ def test_anchored_softmax_form_in_the_step():
         eng.check_forks()
         extra = None
         if not defer and not with_tail:
-            anc = eng._ce_anchor.view(-1, 8)[:B].sum(1).cpu().numpy()
-            lab = eng._ce_ws[2 * B:3 * B].cpu().numpy()
+            pidx = torch.tensor(_kb32_index(512, 160), device="cuda")
+            anc = -(eng._p16h[pidx].double() + eng._p16l[pidx].double())[:B, 139:147].sum(1).cpu().numpy()
+            lab = eng._ce_ws[2 * B:3 * B].cpu().numpy() + anc          # (the GEMM leaves the label's accumulator: x_label - anchor)
             extra = (anc, lab, eng._ce_rowscale[:2 * B].view(B, 2)[:, 0].cpu().numpy())
         out = (torch.stack(losses).cpu().numpy(), eng.export_state(), form, extra)
         del eng, res, rt
