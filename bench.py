@@ -363,6 +363,8 @@ def main():
         from tcar_amd.engine import TcarEngine
         eng = TcarEngine(params, fold.content, fold.mwdhm, device=dev, scoring=args.scoring)
     resident = [eng.make_resident(b) for b in batches]
+    # the form the step driver itself takes for these batches (tcar_step_form), reported as `step_form`
+    step_form0 = eng.step_form(resident[0]) if (world == 1 and hasattr(eng, "step_form") and not os.environ.get("TCAR_FORCE_DP")) else {}
     mean_T = float(np.mean([b["seq"].shape[1] for b in batches]))
     if not os.environ.get("TCAR_NO_RESERVE"):
         # setup, not steps: size the activation workspace for the longest bucket once (a trainer does the same from its bucket
@@ -722,7 +724,10 @@ def main():
         opb_ = 4 if args.scoring == "f32" else (4 if args.scoring == "bf16x3" else 2)
         fl_step = B * (2.0 * N * (k_alg + k_alg + (H + 5 * Ht)) + 3.0e6 * (0.70 * mean_T + 1.02))
         by = {"logits (E planes + attout planes in, exp plane + statistics out)": 4 * (Npad_ * ic_ + B * ic_) + 2 * Npad_ * 160 + 4 * B * 160 + 2 * B * Npad_ + 8 * B * (Npad_ // 96),
-              "ce rescale (plane in place)": 4 * B * Npad_,
+              # (anchored softmax form, round 6: no pass over the plane — a fold launch reads the group sums and the packed attout
+              #  planes and writes the per-row scaled plane of dE)
+              ("ce fold (group sums in; row scales + scaled attout plane out)" if step_form0.get("ce_anchored") else "ce rescale (plane in place)"):
+                  (B * (8 * (Npad_ // 96) + 6 * (ldh_ + pt_)) if step_form0.get("ce_anchored") else 4 * B * Npad_),
               "dX (dlogits + E planes in, split-K slabs out and back in)": opb_ * (B * Npad_ + Npad_ * ic_) + 2 * Npad_ * 160 + 8 * eng_splitk * B * (ic_ + 160),
               "dE (dlogits + attout planes in, item block + (q, z) out)": opb_ * (B * Npad_ + B * (ldh_ + pt_)) + 4 * N * ldh_ + 40 * N,
               "clip + Adam over the item table (g, m, v, w in; m, v, w + bf16 planes out)": 32 * n_par,
@@ -747,7 +752,7 @@ def main():
                # what a user of main.py gets: the trainer loop over the whole fold, tail batches of every length bucket included
                # (details under end_to_end_sessions_per_s); `value` is the loop body over full batches of B sessions
                "trainer_loop_sessions_per_s": (e2e["value"] if e2e else None),
-               "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "step_form": step_form0,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": DTYPE_NOTE[args.scoring], "scoring": args.scoring, "data": "synthetic",
                "config": {"workload": "%s: N=%d items, %d-d content, B=%d/GPU, K=%d %s negatives, mean input length %.2f, "

@@ -24,6 +24,7 @@ bf = dict(dtype=torch.bfloat16, device="cuda")
 p = lambda t: C.c_void_p(t.data_ptr())
 e_h, e_l = torch.randn(Npad, EK, **bf), torch.randn(Npad, EK, **bf) * 0.004
 a_h, a_l = torch.randn(B, EK, **bf), torch.randn(B, EK, **bf) * 0.004
+a_s = (a_h.float() * 0.1).to(torch.bfloat16)
 d_h, d_l = torch.randn(B, Npad, **bf) * 0.01, torch.randn(B, Npad, **bf) * 1e-4
 ap_h, ap_l = torch.randn(B, 576, **bf), torch.randn(B, 576, **bf) * 0.004
 logits = torch.empty(B, Npad, device="cuda")
@@ -92,10 +93,11 @@ def run():
     if which == "fwdce":
         return lib.tcar_gemm_bf16_ce(B, N, EK, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, EK, None, None, None, 0, p(plane), Npad, B,
                                      p(stats), nstat, p(label), p(lab_logit), nsplit, C.byref(gw), C.byref(ng), None), 2.0 * B * N * 820
-    if which == "fwdce2":   # item | content columns + the 160-column one-hot segment of the publish-time rows
-        return lib.tcar_gemm_bf16_ce(B, N, 512 + 160, p(a_h), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, 512, p(p_h), p(p_l), p(oh), 160,
-                                     p(plane), Npad, B, p(stats), nstat, p(label), p(lab_logit), nsplit, C.byref(gw), C.byref(ng),
-                                     None), 2.0 * B * N * 820
+    if which == "fwdce2":   # item | content columns + the 160-column one-hot segment of the publish-time rows; the step's ANCHORED
+        # epilogue (round 6: exp(accumulator), no group maxima — attout scaled so that the synthetic logits stay inside exp's range)
+        return lib.tcar_gemm_bf16_ce_anchor(B, N, 512 + 160, p(a_s), p(a_l), EK, B, p(e_h), p(e_l), EK, Npad, 512, p(p_h), p(p_l), p(oh), 160,
+                                            p(plane), Npad, B, p(stats), nstat, p(label), p(lab_logit), nsplit, C.byref(gw), C.byref(ng),
+                                            None), 2.0 * B * N * 820
     if which == "dx":
         return lib.tcar_gemm_bf16(0, B, EK, Npad, p(d_h), p(d_l), Npad, B, p(e_h), p(e_l), EK, Npad, p(slabs), EK, None, 0, 0, nsplit, SK, None), 2.0 * B * N * 820
     return lib.tcar_gemm_bf16(2, N, 576, B, p(d_h), p(d_l), Npad, B, p(ap_h), p(ap_l), 576, B, p(gi), 256, p(det), 320, 256, nsplit, 1, None), 2.0 * B * N * 570
