@@ -881,7 +881,16 @@ typedef struct {
   int32_t head_K;
   int32_t* neg_all;
   float* coef_all;
+  /* optional buffers of the ANCHORED softmax form on the shard (world*cap a multiple of 128; TCAR_FUSED_CE = 2): aps16h = the packed
+   * attout plane scaled per row [ceil128(world*cap), ldh + 5 ldt] bf16 (KB32), scale2 [world*cap, 2] = (1 / S_b, one-hot residual).
+   * With them the shard's plane of exponentials is never rescaled: every shard subtracts the same per-session anchor inside its logits
+   * GEMM (tcar_shard_score), the statistics exchange adds plain sums, tcar_shard_backward scales per row. */
+  void* aps16h; float* scale2;
+  int32_t n_total;                   /* rows of the WHOLE catalog (the anchor reads E[label] of every session's label); 0: no anchored form */
 } tcar_shard_t;
+/* The form the shard pieces take for (c, s) — their own predicates, nothing is launched: form[0] the one-hot schedule with the softmax
+ * epilogue (no fp32 logits of the shard), form[1] the anchored softmax form (no rescale pass over the shard's plane). */
+int tcar_shard_form(const tcar_ctx_t* c, const tcar_shard_t* s, int32_t* form /*host, 2 ints*/);
 /* forward of the local sessions up to attout (+ the negative term's forward part when bt->K > 0) */
 int tcar_step_session_forward(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream);
 /* attout planes, logits = att_all E_shard^T, per-shard softmax statistics; refresh_time != 0 rebuilds the shard's time planes.

@@ -33,7 +33,7 @@ SYMBOLS = ["tcar_gather_clip_fwd", "tcar_gather_clip_bwd", "tcar_scatter_add_row
            "tcar_segsum_apply", "tcar_sqnorm_det", "tcar_softmax_stats", "tcar_softmax_combine", "tcar_softmax_combine_rowstat", "tcar_softmax_grad", "tcar_neg_scatter_range",
            "tcar_step_session_forward", "tcar_shard_score", "tcar_shard_backward", "tcar_shard_finish", "tcar_step_session_backward", "tcar_scatter_add_rows_packed", "tcar_shard_begin", "tcar_shard_join", "tcar_shard_step_local", "tcar_colsum_det", "tcar_fold_slabs", "tcar_gather_clip_bwd_sqnorm", "tcar_graph_probe", "tcar_attn_pool_bwd_det", "tcar_attn_pool_fwd_slabs", "tcar_attn_pool_bwd_slabs", "tcar_small_tables_bwd_det", "tcar_small_det_ws_floats", "tcar_shard_pack_head", "tcar_shard_unpack_head", "tcar_shard_pack_ids", "tcar_step_forward",
            "tcar_step_backward_local", "tcar_step_finish", "tcar_step_update", "tcar_train_step", "tcar_train_step_deferred", "tcar_eval_step",
-           "tcar_step_form", "tcar_step_dense_norms"]
+           "tcar_step_form", "tcar_shard_form", "tcar_step_dense_norms"]
 
 
 def _hipcc() -> str:
@@ -178,7 +178,7 @@ class Shard(C.Structure):
                  ("att_all", C.c_void_p), ("ld_att", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("lab_all", "logits", "stats", "lse", "ce", "a16h", "a16l", "ap16h", "ap16l",
                                              "dl16h", "dl16l", "slabs", "dx")]
-                + [("head_K", C.c_int32), ("neg_all", C.c_void_p), ("coef_all", C.c_void_p)])
+                + [("head_K", C.c_int32), ("neg_all", C.c_void_p), ("coef_all", C.c_void_p), ("aps16h", C.c_void_p), ("scale2", C.c_void_p), ("n_total", C.c_int32)])
 
 
 class Segments(C.Structure):
@@ -363,6 +363,7 @@ def load() -> C.CDLL:
     lib.tcar_train_step_deferred.argtypes = [P(Ctx), P(Batch), i32, i32, f32, vp]
     lib.tcar_eval_step.argtypes = [P(Ctx), P(Batch), i32, i32, vp]
     lib.tcar_step_form.argtypes = [P(Ctx), P(Batch), vp]
+    lib.tcar_shard_form.argtypes = [P(Ctx), P(Shard), vp]
     for s in SYMBOLS:
         getattr(lib, s).restype = C.c_int
     lib.tcar_segsum_ws_bytes.restype = C.c_int64

@@ -559,6 +559,31 @@ __global__ __launch_bounds__(256) void time_onehot_kernel(int n_items, const int
 #pragma unroll
   for (int j = 0; j < TCAR_ANCHOR_COLS; ++j) oh[kb32_off(n, 139 + j, in32)] = (__bf16)1.0f;
 }
+// anchor of the anchored softmax form where the finishing launch of the output transforms is not at hand (catalog-sharded step: the
+// shard scores the GATHERED attout rows of every rank): one wave per session, a = attout[b, 0 : 2 ldh) . E[label[b], 0 : 2 ldh) in a
+// fixed order — the same bits on every rank, whose copies of attout and of the fp32 table are identical —, P[b, 139] = -a (hi / lo);
+// the other anchor columns stay zero (tcar_time_scores_clip has just zeroed columns >= 139).  Padding sessions (label < 0): zero.
+__global__ __launch_bounds__(256) void anchor_scores_kernel(int ic, int B, const float* __restrict__ attout, long ld_att,
+                                                            const int32_t* __restrict__ label, const float* __restrict__ E, long ldE,
+                                                            long n_rows, __bf16* __restrict__ ph, __bf16* __restrict__ pl, int in32) {
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lab = label[b];
+  float a = 0.f;
+  if (lab >= 0) {
+    const float* x = attout + b * ld_att;
+    const float* e = E + (lab < n_rows ? (long)lab : n_rows - 1) * ldE;
+    for (int c = lane * 4; c < ic; c += 256) a += dot4(ld4(x + c), ld4(e + c));
+    a = -wave_sum(a);
+  }
+  if (lane == 0) {
+    const __bf16 h = (__bf16)a;
+    const long o = kb32_off(b, 139, in32);
+    ph[o] = h;
+    pl[o] = (__bf16)(a - (float)h);
+  }
+}
 struct ScoreArgs {
   tcar_dims_t d;
   const float* tab[5];
@@ -1626,6 +1651,18 @@ int tcar_attout_finish_scores_a(const tcar_dims_t* d, const float* const time_ta
   const long Bp = p_hi ? (((long)B + 127) & ~127L) : (((long)B + 15) & ~15L);      // the score planes' padding rows are written (zeros)
   const size_t lds = ((size_t)(61 + 16) * 68 + 64) * sizeof(float);
   TCAR_LAUNCH(attout_finish_kernel, dim3((unsigned)(Bp / 16), 5 + 2 * d->ldh / 64), dim3(256), lds, (hipStream_t)stream, a);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+int tcar_anchor_scores(int ldh, int B, const float* attout, int64_t ld_att, const int32_t* label, const float* E, int64_t ldE,
+                       int64_t n_rows, void* p_hi, void* p_lo, int64_t inner, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (ldh <= 0 || (ldh & 1) || !attout || (ld_att & 3) || ld_att < 2 * ldh || !label || !E || (ldE & 3) || ldE < 2 * ldh || n_rows <= 0 ||
+      !p_hi || !p_lo || (inner & 31) || inner < 160 || !tcar_aligned16(attout) || !tcar_aligned16(E))
+    return TCAR_E_ARG;
+  TCAR_LAUNCH(anchor_scores_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, 2 * ldh, B, attout, (long)ld_att,
+              label, E, (long)ldE, (long)n_rows, (__bf16*)p_hi, (__bf16*)p_lo, (int)(inner >> 5));
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

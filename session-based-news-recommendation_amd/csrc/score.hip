@@ -342,6 +342,45 @@ __global__ __launch_bounds__(256) void ce_anchor_fold_kernel(int B, int N, int i
     *reinterpret_cast<bf16x4_s*>(aps + o) = y;
   }
 }
+// ... for the catalog-sharded step: the row sums crossed the ranks (rowstat[b] = (lse, 1) from tcar_softmax_combine_rowstat; every
+// group reference is the anchor, i.e. 0 in the accumulators: S_b = exp(lse)), the label lives in ONE shard (window: label - lab_off
+// inside [0, N) or no label entry here: no patch, no residual, plain 1 / S_b on attout's row), and a padding session (label < 0,
+// lse = +inf) gets an exactly zero gradient row: scale 0 on both consumers
+__global__ __launch_bounds__(256) void ce_anchor_apply_kernel(int B, int N, int in32, const float* __restrict__ rowstat,
+                                                              const int32_t* __restrict__ label, int lab_off,
+                                                              float* __restrict__ scale2, __bf16* __restrict__ plane,
+                                                              const __bf16* __restrict__ ap_hi, const __bf16* __restrict__ ap_lo,
+                                                              __bf16* __restrict__ aps, int ap_cols, int ap_in32) {
+  const int lane = threadIdx.x & 63;
+  const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  const int lraw = label[b];
+  const int lab = lraw - lab_off;
+  float inv = 0.f, inv_e = 0.f, resid = 0.f;
+  if (lraw >= 0) {
+    const float s = expf(rowstat[2 * b]) / rowstat[2 * b + 1];
+    inv = 1.0f / s;
+    inv_e = inv;
+    if (lab >= 0 && lab < N) {
+      __bf16* q = plane + kb32_off(b, lab, in32);
+      const float el = (float)*q;
+      const float t = el - s;
+      const __bf16 v = (__bf16)t;
+      inv_e = 1.0f / (el - (float)v);
+      resid = (t - (float)v) * inv;
+      if (lane == 0) *q = v;
+    }
+  }
+  if (lane == 0) { scale2[2 * b] = inv; scale2[2 * b + 1] = resid; }
+  for (int c = lane * 4; c < ap_cols; c += 256) {
+    const long o = kb32_off(b, c, ap_in32);
+    const bf16x4_s h = *reinterpret_cast<const bf16x4_s*>(ap_hi + o), l = *reinterpret_cast<const bf16x4_s*>(ap_lo + o);
+    bf16x4_s y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = (__bf16)(inv_e * ((float)h[j] + (float)l[j]));
+    *reinterpret_cast<bf16x4_s*>(aps + o) = y;
+  }
+}
 // ce_combine + ce_rescale in ONE launch (round 5; TCAR_CE_FOLD): a workgroup owns 16 session rows x one slice of the plane's
 // column blocks.  It folds ITS rows' (max, sum) pairs itself — ngroups * 8 bytes per row out of L2, the same lane-strided loops and
 // shuffle trees as ce_combine_kernel, so lse / ce / the scale come out in the same bits — and then streams its slice: a wave
@@ -718,7 +757,7 @@ __global__ __launch_bounds__(256) void reduce_dact_onehot_kernel(const float* __
   int fk = -1;
   if (fx && row < M) {
     rs = fix.scale2[2 * row]; rd = fix.scale2[2 * row + 1];
-    flab = clampi(fix.label[row], 0, fix.n_items - 1);
+    flab = clampi(fix.label[row] - fix.lab_off, 0, fix.n_items - 1);
     if ((int)blockIdx.x < nic) fe = ld4(fix.E + (long)flab * fix.ldE + blockIdx.x * 64 + cg * 4);
     else fk = fix.mwdhm[(long)flab * 5 + (blockIdx.x - nic)];
   }
@@ -1226,6 +1265,18 @@ extern "C" int tcar_ce_anchor_fold(int B, int N, int group_width, int ngroups, c
                                    const void* ap_hi, const void* ap_lo, void* aps_hi, int ap_cols, int64_t ap_inner, void* stream) {
   return tcar_ce_anchor_fold_o(B, N, group_width, ngroups, stats, lab_logit, label, rowstat, ce, scale2, dl_hi, inner, ap_hi, ap_lo,
                                aps_hi, ap_cols, ap_inner, stream, nullptr);
+}
+
+int tcar_ce_anchor_apply_o(int B, int N, const float* rowstat, const int32_t* label, int lab_off, void* dl_hi, int64_t inner,
+                           const void* ap_hi, const void* ap_lo, void* aps_hi, int ap_cols, int64_t ap_inner, float* scale2, void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if ((B & 127) || N <= 0 || !rowstat || !label || !dl_hi || (inner & 31) || inner < N || !ap_hi || !ap_lo || !aps_hi || ap_cols <= 0 ||
+      (ap_cols & 3) || (ap_inner & 31) || ap_inner < ap_cols || !scale2 || ((uintptr_t)scale2 & 7))
+    return TCAR_E_ARG;
+  TCAR_LAUNCH(ce_anchor_apply_kernel, dim3(B / 4), dim3(256), 0, (hipStream_t)stream, B, N, (int)(inner >> 5), rowstat, label, lab_off,
+              scale2, (__bf16*)dl_hi, (const __bf16*)ap_hi, (const __bf16*)ap_lo, (__bf16*)aps_hi, ap_cols, (int)(ap_inner >> 5));
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
 }
 
 // second half of tcar_ce_finish on its own (catalog-sharded step: the row statistics come from the statistics exchange):

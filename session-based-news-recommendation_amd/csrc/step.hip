@@ -1301,6 +1301,11 @@ bool shard_onehot(const tcar_ctx_t* c, const tcar_shard_t* s, CeWs* w) {
   return c->scoring == 3 && c->d.ldt == 64 && fused_ce(&cc, s->world * s->cap, w) && c->ce_geo && c->oh16 && c->p16h && c->p16l &&
          c->tclip && c->dP && c->qz && c->inv_off && c->ct_ws && c->mwdhm && tn(c).onehot_time >= 2;
 }
+// anchored softmax form on the shard (score.hip: ce_anchor_apply_kernel): the shard's one-hot schedule, whole 128-row blocks of
+// exchanged sessions, the two buffers of the form in the shard descriptor
+bool shard_anchored(const tcar_ctx_t* c, const tcar_shard_t* s) {
+  return tn(c).fused_ce >= 2 && ((s->world * s->cap) & 127) == 0 && s->aps16h && s->scale2 && s->n_total >= s->n0 + s->n_loc;
+}
 int check_shard(const tcar_ctx_t* c, const tcar_shard_t* s) {
   if (!c || !s || !c->scoring || s->world <= 0 || s->cap <= 0 || s->n_loc <= 0 || s->n0 < 0) return TCAR_E_ARG;
   if (!s->att_all || !s->lab_all || !s->stats || !s->lse || !s->ce || !s->a16h || !s->a16l || !s->ap16h ||
@@ -1310,6 +1315,16 @@ int check_shard(const tcar_ctx_t* c, const tcar_shard_t* s) {
   return TCAR_OK;
 }
 }  // namespace
+
+// Which form do the shard pieces take for this context / descriptor (the predicates tcar_shard_score / _backward evaluate; launches
+// nothing): form[0] the one-hot schedule with the softmax epilogue, form[1] the anchored softmax form (no rescale pass)
+extern "C" int tcar_shard_form(const tcar_ctx_t* c, const tcar_shard_t* s, int32_t* form /*host, 2 ints*/) {
+  if (!form) return TCAR_E_ARG;
+  RET(check_shard(c, s));
+  form[0] = shard_onehot(c, s, nullptr) ? 1 : 0;
+  form[1] = (form[0] && shard_anchored(c, s)) ? 1 : 0;
+  return TCAR_OK;
+}
 
 extern "C" int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int refresh_time, void* stream) {
   RET(check_shard(c, s));
@@ -1343,6 +1358,15 @@ extern "C" int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int 
     TcarOpt ol = opt_of(c);
     ol.lab_off = s->n0;
     ol.lab_window = 1;
+    if (shard_anchored(c, s)) {
+      // anchored form: every shard computes the SAME anchor of every session — attout . E[label] over the item | content columns,
+      // from the gathered attout rows and its own copy of the whole fp32 table (identical on every rank after the row exchange) — and
+      // puts it into the anchor column of the time-score planes: the GEMM subtracts it, all shards' exponentials share one reference
+      // per row, and the statistics exchange adds plain sums.  `c` is the SHARD's context here (c->E = its first row) or the rank's
+      const float* e_all = c->E - ((int)g.N == nl ? (int64_t)s->n0 * g.ek : 0);
+      RET(tcar_anchor_scores(g.ldh, Bq, s->att_all, lda, s->lab_all, e_all, g.ek, s->n_total, c->p16h, c->p16l, 160, stream));
+      ol.anchored = true;
+    }
     int32_t gw = 0, ng = 0;
     RET(tcar_gemm_bf16_ce_o(Bq, nl, g.ic + 160, s->a16h, s->a16l, g.ek, Bq, c->e16h, c->e16l, g.ek, nlpad, g.ic, c->p16h, c->p16l,
                             c->oh16, 160, s->dl16h, nlpad, (Bq + 127) & ~127, w.stats, w.stats_floats, s->lab_all, w.lab, c->scoring,
@@ -1368,7 +1392,12 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
     // dE (aux stream) keeps its item block and leaves (||gy||^2, x . gy) pairs for the time block; dX contracts the shard against
     // [E_item | E_content | OH]; the slab reduce expands dP to the time columns WITHOUT tanh' (it follows the exchange)
     RET(tcar_softmax_combine_rowstat(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, w.rowstat, stream));
-    RET(tcar_ce_rescale(Bq, nl, c->ce_geo[0], c->ce_geo[1], w.stats, w.rowstat, s->lab_all, s->n0, 1, s->dl16h, nlpad, stream));
+    const bool anch = shard_anchored(c, s);
+    if (anch)      // no pass over the plane: row scales, the label's -1 where the label lives here, the scaled attout plane of dE
+      RET(tcar_ce_anchor_apply_o(Bq, nl, w.rowstat, s->lab_all, s->n0, s->dl16h, nlpad, s->ap16h, s->ap16l, s->aps16h, g.ldh + g.pt,
+                                 g.ldh + g.pt, s->scale2, stream));
+    else
+      RET(tcar_ce_rescale(Bq, nl, c->ce_geo[0], c->ce_geo[1], w.stats, w.rowstat, s->lab_all, s->n0, 1, s->dl16h, nlpad, stream));
     hipStream_t st = (hipStream_t)stream, s2 = aux_stream(c);
     // dE (aux stream) behind the rescale through an EVENT, dE launched first.  (backward_impl orders dE behind dX's START flag instead;
     // here that form — dX first, the poll, then dE — measured 14 us per step SLOWER on the one-rank shard, 0.548 against 0.534 ms in
@@ -1381,13 +1410,17 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
     const int forced = tn(c).bf16_tile;
     // (64-row tiles — 270 workgroups at the 8-rank shape — measured slower than 128-row ones there: 0.697 vs 0.653 ms per step)
     const int tile = (forced == 256 || forced == 128 || forced == 64) ? forced : (((nl + 191) / 192) * 3 < 200 ? 128 : 0);
-    RET(tcar_gemm_bf16_de_qz_o(nl, (Bq + 31) & ~31, s->dl16h, nlpad, Bp, s->ap16h, g.ldh + g.pt, Bp, g.ldh, c->big, g.ldh, c->mwdhm,
-                               c->et_perm, c->tclip, c->qz, tile, s2 ? (void*)s2 : stream, &ob));
+    RET(tcar_gemm_bf16_de_qz_o(nl, (Bq + 31) & ~31, s->dl16h, nlpad, Bp, anch ? s->aps16h : s->ap16h, g.ldh + g.pt, Bp, g.ldh, c->big, g.ldh,
+                               c->mwdhm, c->et_perm, c->tclip, c->qz, tile, s2 ? (void*)s2 : stream, &ob));
     RET(tcar_gemm_bf16_dx_onehot_o(Bq, g.ic, nlpad, s->dl16h, nlpad, Bq, c->e16h, g.ek, nlpad, c->oh16, 160, s->slabs, g.ic + 160,
                                    c->splitk, stream, &ox));
     const int S1 = tcar_gemm_splitk_effective(nlpad, c->splitk);
     TcarOpt orr = opt_of(c);
     if (s2) orr.sig = fork_arm(c, FK_REDUCE);          // (dP leaves write-through when the launch carries the flag)
+    // (anchored: E / mwdhm of the SHARD — the residual is non-zero only where the label lives here)
+    TcarRowFix fix{s->scale2, s->lab_all, c->E + ((int)g.N == nl ? 0 : (int64_t)s->n0 * g.ek), (long)g.ek, c->mwdhm, nl};
+    fix.lab_off = s->n0;
+    if (anch) orr.rowfix = &fix;
     RET(tcar_reduce_dact_onehot_o(s->slabs, S1, Bq, g.ic, g.ic + 160, nullptr, 0, nullptr, 0, c->tclip, s->dx, g.ek, c->dP, nullptr,
                                   nullptr, stream, &orr));
     // dP is complete: tcar_shard_finish lets the candidate-side table gradients (aux stream, behind dE) wait for this point — for

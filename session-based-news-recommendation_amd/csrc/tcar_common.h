@@ -113,8 +113,10 @@ __device__ __forceinline__ float ld1_sc1(const float* p) { return __hip_atomic_l
 // one-hot's -1 that the bf16 label entry of the plane could not hold, already divided by S_m — comes back in fp32 as
 // r_m * [E[label[m], :] | onehot(publish time of label[m])].  E: fp32 candidate rows [n_items, ldE] (item | content columns first).
 constexpr int TCAR_ANCHOR_COLS = 8;      // columns 139 .. 146 of the one-hot K segment (embed.hip: time_onehot_kernel)
+// lab_off: the label's row in E / mwdhm is label[m] - lab_off (catalog shard: E, mwdhm and n_items are the shard's; a label outside
+// [0, n_items) has r_m = 0 and is only clamped for the address)
 struct TcarRowFix {
-  const float* scale2; const int32_t* label; const float* E; long ldE; const int32_t* mwdhm; int n_items;
+  const float* scale2; const int32_t* label; const float* E; long ldE; const int32_t* mwdhm; int n_items; int lab_off = 0;
 };
 struct TcarOpt {
   const tcar_tuning_t* tune = nullptr;
@@ -157,6 +159,13 @@ int tcar_ce_finish_o(int B, int N, int group_width, int ngroups, const float* st
 int tcar_ce_anchor_fold_o(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                           float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner, const void* ap_hi, const void* ap_lo,
                           void* aps_hi, int ap_cols, int64_t ap_inner, void* stream, TcarOpt* o);
+// catalog-sharded step, anchored form: tcar_ce_anchor_fold's second half with the row sums from the statistics exchange (rowstat =
+// (lse, 1) of tcar_softmax_combine_rowstat, every group reference 0) and a label WINDOW; tcar_anchor_scores: P[b, 139] = -attout[b] .
+// E[label[b]] over the item | content columns (hi / lo), zero for padding sessions (label < 0)
+int tcar_ce_anchor_apply_o(int B, int N, const float* rowstat, const int32_t* label, int lab_off, void* dl_hi, int64_t inner,
+                           const void* ap_hi, const void* ap_lo, void* aps_hi, int ap_cols, int64_t ap_inner, float* scale2, void* stream);
+int tcar_anchor_scores(int ldh, int B, const float* attout, int64_t ld_att, const int32_t* label, const float* E, int64_t ldE,
+                       int64_t n_rows, void* p_hi, void* p_lo, int64_t inner, void* stream);
 int tcar_clip_adam_early_2(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,
                            const float* g2d, float* m2d, float* v2d, int64_t rows, int32_t cols, int32_t slot, const float* sqn_dense,
                            const float* sqn_pieces, const int32_t* use_dense, float clip, float lr_t, float b1, float b2, float eps,

@@ -426,6 +426,9 @@ class ShardedEngine(TcarEngine):
             self.s_dl16h, self.s_dl16l = torch.zeros(Bp, self.nlpad, **bf), torch.zeros(Bp, self.nlpad, **bf)
             self.s_slabs = torch.empty(self.splitk, Bq, g.ek, **f32)
             self.s_dx = torch.empty(Bq, g.ek, **f32)
+            # anchored softmax form on the shard (tcar_shard_t.aps16h / scale2): the per-row scaled attout plane of dE, the row scales
+            self.s_aps16h = torch.zeros(Bp, g.ldh + g.pt, **bf) if getattr(self, "onehot", False) and not os.environ.get("TCAR_NO_CE_ANCHOR") else None
+            self.s_scale2 = torch.zeros(2 * Bp, **f32) if self.s_aps16h is not None else None
             self.cap, self._kcap = cap, kc
 
     # two composite spans instead of the three GEMMs of the fused step: the C++ pieces between the exchanges
@@ -510,8 +513,17 @@ class ShardedEngine(TcarEngine):
                          ("dl16h", self.s_dl16h), ("dl16l", self.s_dl16l), ("slabs", self.s_slabs), ("dx", self.s_dx),
                          ("lab_all", self.s_lab), ("neg_all", self.s_neg), ("coef_all", self.s_coef)):
                 setattr(sh, n, t.data_ptr())
+            if getattr(self, "s_aps16h", None) is not None:
+                sh.aps16h, sh.scale2, sh.n_total = self.s_aps16h.data_ptr(), self.s_scale2.data_ptr(), self.geo.N
             self._sh, self._sh_key = sh, key
         return self._sh
+
+    def shard_form(self, cap: int) -> Dict[str, bool]:
+        """the form the C++ shard pieces take at a capacity of `cap` sessions per rank (tcar_shard_form: their own predicates)"""
+        self._ensure_score(cap, getattr(self, "_kcap", 0) or 0)
+        out = (C.c_int32 * 2)()
+        check(self.lib.tcar_shard_form(C.byref(self._shard_ctx()), C.byref(self._shard_desc(cap)), out), "tcar_shard_form")
+        return {"onehot": bool(out[0]), "ce_anchored": bool(out[1])}
 
     def _shard_ctx(self):
         """tcar_ctx_t whose candidate side is this rank's shard (tcar_step_update: arena + the owned item rows + planes)"""

@@ -134,7 +134,41 @@ def test_single_rank_sharded_split_update_matches_the_update_inside_the_step(sco
     b.world = 1
 
 
-def _worker(rank, world, port, ret, scoring="bf16x3"):
+def test_single_rank_sharded_anchored_form_matches_oracle():
+    """Round 6: the shard pieces take the ANCHORED softmax form when the exchanged session rows fill whole 128-row blocks (here 253
+    sessions at a capacity of 256: three padding sessions, whose gradient rows stay exactly zero).  Every shard computes the same
+    anchor from the gathered attout rows, the statistics exchange adds plain sums, no pass rescales the shard's plane: loss, all 23
+    gradients + clip norms against the fp64 oracle at the mixed-precision gate, two training steps, and agreement with the
+    group-maximum form (TCAR_FUSED_CE = 1) of the same engine class."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import tcar_amd  # noqa: F401
+    from oracle.tcar_oracle import TcarOracle
+    from tcar_amd.sharded import ShardedEngine
+    from test_gpu_parity import _case, check_grads, close, rel_norm
+    N, H, Ht, B, T, K = 3000, 250, 64, 253, 3, 7
+    params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=323)
+    ora = TcarOracle(params, content, mw, max_grad=2.0)
+    o, g_o, sq_o = ora.loss_and_grads(batch)
+    g_o = {k: v.numpy() for k, v in g_o.items()}
+    grads = {}
+    for f in (2, 1):
+        eng = ShardedEngine(params, content, mw, max_grad=2.0, scoring="bf16x3-mixed", world=1, rank=0)
+        eng.set_tuning(TCAR_FUSED_CE=f)
+        loss = eng.loss_and_grads(batch, cap=256)
+        assert eng.shard_form(256) == {"onehot": True, "ce_anchored": f == 2}
+        close(loss.cpu().numpy(), o["loss"].detach().numpy(), name="loss")
+        grads[f] = eng.export_grads()
+        check_grads(grads[f], eng.export_sqnorms(), g_o, sq_o, "bf16x3-mixed")
+        if f == 2:
+            for i in range(2):
+                close(eng.train_step(batch, cap=256).cpu().numpy(), ora.train_step(batch).numpy(), name="train loss", rtol=1e-2 if i else 1e-3)
+        del eng
+    for k in g_o:      # the two forms differ by bf16 roundings of the softmax gradient only
+        assert rel_norm(grads[2][k], grads[1][k]) <= 5e-3 or np.abs(g_o[k]).max() < 1e-9, (k, rel_norm(grads[2][k], grads[1][k]))
+
+
+def _worker(rank, world, port, ret, scoring="bf16x3", B=37):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -144,7 +178,7 @@ def _worker(rank, world, port, ret, scoring="bf16x3"):
         from tcar_amd.engine import TcarEngine
         from tcar_amd.sharded import ShardedEngine
         from test_gpu_parity import _case
-        N, H, Ht, B, T, K = 1000, 250, 64, 37, 4, 6          # 37 sessions: uneven shards (19 + 18)
+        N, H, Ht, T, K = 1000, 250, 64, 4, 6                  # B = 37 sessions: uneven shards (19 + 18); 256: two whole 128-row blocks
         params, content, mw, batch = _case(N, H, Ht, B, T, K, seed=5)
         _, _, _, tiny = _case(N, H, Ht, 1, 2, K, seed=6)      # a batch of ONE session: rank 1's shard is empty
         eng = ShardedEngine(params, content, mw, max_grad=2.0, group=dist.group.WORLD, scoring=scoring)
@@ -156,6 +190,8 @@ def _worker(rank, world, port, ret, scoring="bf16x3"):
             sub = {k: v[lo:hi] for k, v in full.items()} if hi > lo else None
             eng.train_step(sub, cap=cap, T=t, K=K)
         torch.cuda.synchronize()
+        if scoring == "bf16x3-mixed":       # (128 + 128 sessions: the anchored softmax form on both shards, rank 1's at catalog row 512)
+            assert eng.shard_form(shard_bounds(B, world, rank)[2]) == {"onehot": True, "ce_anchored": B % 128 == 0}
         got = eng.export_params()
         if rank == 0:
             ref = TcarEngine(params, content, mw, max_grad=2.0, scoring=scoring)
@@ -164,8 +200,11 @@ def _worker(rank, world, port, ret, scoring="bf16x3"):
             want = ref.export_params()
             for k in want:
                 d = np.abs(got[k] - want[k]).max()
-                # same kernels, different summation order (float atomics, reduction trees): Adam bound as in test_gpu_parity
-                assert d <= 1e-3 * np.abs(want[k]).max() + 0.25 * 1e-3 * 4, (k, d)
+                # same kernels, different summation order (float atomics, reduction trees): Adam bound as in test_gpu_parity.  (Anchored
+                # softmax form, B = 256: the shard's anchor is one wave's dot, the single engine's eight partial dots — the two planes
+                # of exponentials are rounded to bf16 relative to slightly different references: the mixed precision's noise bound)
+                travel = 2.0 if (scoring == "bf16x3-mixed" and B % 128 == 0) else 0.25
+                assert d <= 1e-3 * np.abs(want[k]).max() + travel * 1e-3 * 4, (k, d)
         flat = torch.cat([torch.tensor(v).reshape(-1) for v in got.values()])
         other = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(other, flat)
@@ -180,7 +219,7 @@ def _worker(rank, world, port, ret, scoring="bf16x3"):
         if rank == 0:
             want_st = ref.export_state()
             for k in ("m/item_emb", "v/item_emb", "m/attout_item_cont_trans/w1"):
-                assert np.abs(st[k] - want_st[k]).max() <= 2e-3 * np.abs(want_st[k]).max() + 1e-12, k
+                assert np.abs(st[k] - want_st[k]).max() <= (2e-2 if travel > 1 else 2e-3) * np.abs(want_st[k]).max() + 1e-12, k
         eng2 = ShardedEngine(params, content, mw, max_grad=2.0, group=dist.group.WORLD, scoring=scoring)
         eng2.load_state(st)
         assert eng2.step == eng.step and torch.equal(eng2.Mi, eng.Mi) and torch.equal(eng2.Vi, eng.Vi) and torch.equal(eng2.M, eng.M)
@@ -199,15 +238,15 @@ def _worker(rank, world, port, ret, scoring="bf16x3"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scoring", ["bf16x3", "bf16x3-mixed"])
-def test_two_ranks_sharded_match_single_engine(scoring):
+@pytest.mark.parametrize("scoring,B", [("bf16x3", 37), ("bf16x3-mixed", 37), ("bf16x3-mixed", 256)])
+def test_two_ranks_sharded_match_single_engine(scoring, B):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     world = 2
     mgr = mp.get_context("spawn").Manager()      # (a SPAWNED server: a fork of this process would inherit its GPU state)
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), ret, scoring), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), ret, scoring, B), nprocs=world, join=True)
     for r in range(world):
         assert ret.get(r) == "ok", ret.get(r)
 
