@@ -347,8 +347,9 @@ int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stat
  * tcar_reduce_dact_onehot_scaled: softmax part scaled exactly, the one-hot's rounding residual added back in fp32); and writes
  * aps = bf16((ap_hi + ap_lo)[b, :] / S') with S' = e_l - v, the per-row scaled copy of the packed attout planes [B, ap_cols]
  * (inner ap_inner) that the dE GEMM contracts the UNSCALED plane with — v / S' = e_l / S' - 1 exactly: the one-hot part of dE is
- * exact, the rounding of v becomes a common factor 1 +- 2^-8 on the row's softmax part.  S_b >= ~1 by construction of the anchor; a
- * term overflows only where a logit exceeds the label's score by more than 88 (a per-session loss > 88). */
+ * exact, the rounding of v becomes a common factor 1 +- 2^-8 on the row's softmax part.  S_b >= ~1 by construction of the anchor; the
+ * GEMM's exponent is clamped at 2^100: a logit more than 69 nats above its row's reference (a per-session loss > 69) saturates instead
+ * of overflowing — every quantity stays finite. */
 int tcar_ce_anchor_fold(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                         float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner, const void* ap_hi, const void* ap_lo,
                         void* aps_hi, int ap_cols, int64_t ap_inner, void* stream);

@@ -444,7 +444,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
             bf16x8 pk;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float pe = (FAST || n8 + j < g.N) ? __builtin_amdgcn_exp2f(fmaf(acc[u][t][8 * h + j], LOG2E, c)) : 0.f;
+              // (the exponent is CLAMPED at 2^100: a no-op with group maxima, where it is <= 0; in the anchored form a logit more
+              //  than 69 nats above its row's anchor — a per-session loss > 69 — saturates instead of overflowing, so the plane, the
+              //  sums and every gradient stay finite; such a row's largest probabilities are shared out evenly among the clamped)
+              const float pe = (FAST || n8 + j < g.N) ? __builtin_amdgcn_exp2f(fminf(fmaf(acc[u][t][8 * h + j], LOG2E, c), 100.f)) : 0.f;
               sum += pe;
               pk[j] = (__bf16)pe;
             }

@@ -657,6 +657,19 @@ def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K):
     sc = aps[pidx].float().cpu().numpy()[:, :cols]
     want_sc = ap.astype(np.float64) * rs[:, None]
     assert (np.abs(sc - want_sc) <= 1.01 * 2.0 ** -8 * np.abs(want_sc) + 1e-30).all()
+    # a logit far above its row's anchor SATURATES at 2^100 instead of overflowing: plane, sums and the fold stay finite
+    A2[3, 139] += 200.0                      # row 3: anchor 200 below its label's score
+    a2h, a2l, _, _ = _planes(lib, A2)
+    plane2 = torch.full_like(plane, float("nan"))
+    assert lib.tcar_gemm_bf16_ce_anchor(M, N, K + 160, ptr2(ah), ptr2(al), ai, ar, ptr2(bh), ptr2(bl), bi, br, K, ptr2(a2h), ptr2(a2l), ptr2(b2h),
+                                        a2i, ptr2(plane2), Np, Mp, ptr(stats), nstat, ptr2(lab_d), ptr(lab_logit), 3, C.byref(C.c_int32(0)),
+                                        C.byref(C.c_int32(0)), None) == 0
+    e2 = plane2[idx].float()
+    assert bool(torch.isfinite(e2).all()) and float(e2[3].max()) == 2.0 ** 100 and bool(torch.isfinite(stats[:M * ng * 2]).all())
+    assert (e2[:3].cpu().numpy() == e[:3]).all()                                 # (the other rows: the same bits as before)
+    assert lib.tcar_ce_anchor_fold(M, N, gw, ng, ptr(stats), ptr(lab_logit), ptr2(lab_d), ptr(rowstat), ptr(ce), ptr(rowscale), ptr2(plane2),
+                                   Np, ptr2(ph), ptr2(pl), ptr2(aps), cols, pi, None) == 0
+    assert bool(torch.isfinite(ce).all()) and bool(torch.isfinite(rowscale).all()) and bool(torch.isfinite(aps.float()[pidx][:, :cols]).all())
     # B that is no multiple of 128 is refused (the step keeps the rescaled form for such batches)
     assert lib.tcar_ce_anchor_fold(M - 1, N, gw, ng, ptr(stats), ptr(lab_logit), ptr2(lab_d), ptr(rowstat), ptr(ce), ptr(rowscale), ptr2(plane),
                                    Np, ptr2(ph), ptr2(pl), ptr2(aps), cols, pi, None) != 0
