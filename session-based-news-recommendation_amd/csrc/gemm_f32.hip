@@ -567,6 +567,10 @@ int launch_x3(GroupArgs& ga, hipStream_t st, TcarOpt* o) {
   }
   // (the ring of 2 for every launch of at most tcar_fixed::x3_oneshot stages per workgroup)
   if (max_stages <= tcar_fixed::x3_oneshot) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st, o);
+  // (diagnostic builds, tcar_fixed::x3_deep: a long-K launch that is at most one workgroup per CU walks HALF as many, 128-deep
+  //  stages — 96 KB of LDS per workgroup: only where no dE workgroup holds the CU's LDS, i.e. the step's tail)
+  if constexpr (tcar_fixed::x3_deep != 0)
+    if (wg <= 256) return launch_x3_v<LA, LB, 128, 1>(ga, wg, st, o);
   return launch_x3_v<LA, LB, 64, 1>(ga, wg, st, o);
 }
 

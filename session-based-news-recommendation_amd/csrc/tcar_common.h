@@ -60,6 +60,10 @@ constexpr int fork_delay = 7;      // us the aux prologue's flag fork holds its 
 #define TCAR_FIX_X3_ONESHOT 4      // (diagnostic builds override it: tools/micro/build_x3ring.sh)
 #endif
 constexpr int x3_oneshot = TCAR_FIX_X3_ONESHOT;      // small-GEMM launches of at most this many 64-deep stages per workgroup keep two stages in flight
+#ifndef TCAR_FIX_X3_DEEP
+#define TCAR_FIX_X3_DEEP 0         // (diagnostic builds: tools/micro/build_x3ring.sh deep)
+#endif
+constexpr int x3_deep = TCAR_FIX_X3_DEEP;            // 1: long-K small-GEMM launches of at most 256 workgroups take 128-deep stages
 constexpr int gather_wg = 2;       // 1024-thread workgroups per CU of the gather's throughput form (2 x 78 KB of LDS fit)
 }  // namespace tcar_fixed
 const TcarTuning& tcar_tuning();
