@@ -314,7 +314,7 @@ __device__ __forceinline__ unsigned x3_load(const float* __restrict__ P, long ld
   }
   return mask;
 }
-template <int LAY, int XK>
+template <int LAY, int XK, bool HI = false>
 __device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict__ lo, int tid, const v4f (&reg)[X3<XK>::NV],
                                          unsigned mask) {
 #pragma unroll
@@ -324,12 +324,12 @@ __device__ __forceinline__ void x3_store(char* __restrict__ hi, char* __restrict
     const float v[4] = {ok ? reg[i].x : 0.f, ok ? reg[i].y : 0.f, ok ? reg[i].z : 0.f, ok ? reg[i].w : 0.f};
     xbf16x4 h, l;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { h[j] = (__bf16)v[j]; l[j] = (__bf16)(v[j] - (float)h[j]); }
+    for (int j = 0; j < 4; ++j) { h[j] = (__bf16)v[j]; l[j] = HI ? (__bf16)0.f : (__bf16)(v[j] - (float)h[j]); }
     int off;
     if (LAY == 0) { const int row = f / (XK / 4), c4 = f % (XK / 4); off = row * X3<XK>::KC + c4 * 8; }
     else { const int krow = f >> 4, c4 = f & 15; off = krow * X3_MC + c4 * 8; }
     *reinterpret_cast<xbf16x4*>(hi + off) = h;
-    *reinterpret_cast<xbf16x4*>(lo + off) = l;
+    if (!HI) *reinterpret_cast<xbf16x4*>(lo + off) = l;
   }
 }
 // fragment of the 32-row block at `base`, k16 sub-step s of the XK-deep stage
@@ -351,7 +351,8 @@ __device__ __forceinline__ xbf16x8 x3_frag(const char* __restrict__ S, int base,
 // Register prefetch ring: the K loop of these launches is a latency chain (<= 1 workgroup per CU, a global-load round
 // trip of ~1-2 us per stage under load), so each thread keeps XD stages of both operands in flight in registers and the
 // (segment, k) stages of a K-concatenated problem form ONE flattened sequence — the ring runs across segment boundaries.
-template <int LA, int LB, int XK, int XD>
+// HI: plain bf16 operands (the hi planes only), ONE MFMA per product — the session-side backward GEMMs of the hi-only backward precision
+template <int LA, int LB, int XK, int XD, bool HI = false>
 __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
   constexpr int X3_PLANE = X3<XK>::PLANE, X3_NV = X3<XK>::NV;
   extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -421,8 +422,8 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
       const int s = base + d;
       __syncthreads();                                        // everyone is done reading the previous stage
       x3_wait<(XD - 1) * 2 * X3_NV, X3_NV>(ra[d], rb[d]);      // this slot has landed; XD - 1 younger stages stay in flight
-      x3_store<LA, XK>(smem, smem + X3_PLANE, tid, ra[d], ma[d]);
-      x3_store<LB, XK>(smem + 2 * X3_PLANE, smem + 3 * X3_PLANE, tid, rb[d], mb[d]);
+      x3_store<LA, XK, HI>(smem, smem + X3_PLANE, tid, ra[d], ma[d]);
+      x3_store<LB, XK, HI>(smem + 2 * X3_PLANE, smem + 3 * X3_PLANE, tid, rb[d], mb[d]);
       __syncthreads();
       load_stage(s + XD, ra[d], rb[d], ma[d], mb[d]);         // refill this ring slot: XD - 1 stages stay in flight
       const int sg = stage_seg(s);
@@ -431,10 +432,12 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GroupArgs ga) {
       const int nsub = s < total ? (min(XK, left + 15) >> 4) : 0;     // k16 sub-steps that hold data
 #pragma unroll 2
       for (int u = 0; u < nsub; ++u) {
-        const xbf16x8 ah = x3_frag<LA, XK>(smem, wm * 32, u, lane), al = x3_frag<LA, XK>(smem + X3_PLANE, wm * 32, u, lane);
-        const xbf16x8 bh = x3_frag<LB, XK>(smem + 2 * X3_PLANE, wn * 32, u, lane), bl = x3_frag<LB, XK>(smem + 3 * X3_PLANE, wn * 32, u, lane);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        const xbf16x8 ah = x3_frag<LA, XK>(smem, wm * 32, u, lane), bh = x3_frag<LB, XK>(smem + 2 * X3_PLANE, wn * 32, u, lane);
+        if constexpr (!HI) {
+          const xbf16x8 al = x3_frag<LA, XK>(smem + X3_PLANE, wm * 32, u, lane), bl = x3_frag<LB, XK>(smem + 3 * X3_PLANE, wn * 32, u, lane);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        }
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
       }
     }
@@ -525,7 +528,7 @@ int launch_layout(GroupArgs& ga, hipStream_t st) {
   return launch_variant<LA, LB, 64, 64>(ga, wg, st);
 }
 
-template <int LA, int LB, int XK, int XD>
+template <int LA, int LB, int XK, int XD, bool HI = false>
 int launch_x3_v(GroupArgs& ga, int wg, hipStream_t st, TcarOpt* o) {
   constexpr size_t lds = 4 * X3<XK>::PLANE;
   // A launch that carries a completion flag stores C write-through (agent-scope stores); its bf16 plane / pack outputs would
@@ -534,8 +537,8 @@ int launch_x3_v(GroupArgs& ga, int wg, hipStream_t st, TcarOpt* o) {
     for (int i = 0; i < ga.nprob; ++i)
       if (ga.p[i].plane_hi || ga.p[i].pack_hi) return TCAR_E_ARG;
   ga.sig = tcar_sig(o);
-  TCAR_SET_LDS_ONCE((gemm_x3_kernel<LA, LB, XK, XD>), lds);
-  TCAR_LAUNCH((gemm_x3_kernel<LA, LB, XK, XD>), dim3(wg), dim3(256), lds, st, ga);
+  TCAR_SET_LDS_ONCE((gemm_x3_kernel<LA, LB, XK, XD, HI>), lds);
+  TCAR_LAUNCH((gemm_x3_kernel<LA, LB, XK, XD, HI>), dim3(wg), dim3(256), lds, st, ga);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }
@@ -566,6 +569,9 @@ int launch_x3(GroupArgs& ga, hipStream_t st, TcarOpt* o) {
     max_stages = n > max_stages ? n : max_stages;
   }
   // (the ring of 2 for every launch of at most tcar_fixed::x3_oneshot stages per workgroup)
+  if constexpr (LA == LB)        // (the backward layouts 1 and 2: plain bf16 operands where the caller asks — TcarOpt::hi_only)
+    if (o && o->hi_only)
+      return max_stages <= tcar_fixed::x3_oneshot ? launch_x3_v<LA, LB, 64, 2, true>(ga, wg, st, o) : launch_x3_v<LA, LB, 64, 1, true>(ga, wg, st, o);
   if (max_stages <= tcar_fixed::x3_oneshot) return launch_x3_v<LA, LB, 64, 2>(ga, wg, st, o);
   // (diagnostic builds, tcar_fixed::x3_deep: a long-K launch that is at most one workgroup per CU walks HALF as many, 128-deep
   //  stages — 96 KB of LDS per workgroup: only where no dE workgroup holds the CU's LDS, i.e. the step's tail)

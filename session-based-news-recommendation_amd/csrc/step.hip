@@ -919,13 +919,17 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // chunk is its own set of workgroups writing its own slab, the pool backward folds them while it loads dpooled
   const int nd_ic = units(g.ic), nd_pt = units(g.pt);
   const int64_t dstride = (int64_t)B * g.ek;
+  // (diagnostic builds: the session-side backward GEMMs on plain bf16 operands under the hi-only backward precision)
+  const bool bwd_hi = tcar_fixed::bwd_small_hi != 0 && c->scoring_bwd == 1 && fuse_finish;
   const bool dsplit = detc && c->proj_slabs && c->proj_slab_floats >= (nd_ic > nd_pt ? nd_ic : nd_pt) * dstride;
   {
     tcar_gemm_desc_t p[2];
     float* dp = dsplit ? c->proj_slabs : c->dpooled;
     p[0] = prob1(B, g.ic, c->dattout, g.ek, W(c, TCAR_V_O_W), g.ic, g.ic, dp, g.ek, nullptr, 0, 0, dsplit ? nd_ic : 1);
     p[1] = prob1(B, g.pt, c->dattout + g.ic, g.ek, W(c, TCAR_V_OT_W), g.pt, g.pt, dp + g.ic, g.ek, nullptr, 0, 0, dsplit ? nd_pt : 1);
-    RET(small_gemm(c, 1, 2, p, stream));
+    TcarOpt odp = opt_of(c);
+    odp.hi_only = bwd_hi;
+    RET(small_gemm(c, 1, 2, p, stream, &odp));
   }
   // query MLP backward (modules.py:138-139).  Split-bf16 modes: tanh' + bias gradient of query_trans2 ride in the pool
   // backward, relu' + bias gradient of query_trans1 in the epilogue of the GEMM that produces dq1, and that GEMM shares ONE
@@ -954,6 +958,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
     p[2] = prob1(BT, g.ldt, c->dpre1, g.ldh, W(c, TCAR_V_M_WINT), g.ldh, g.ldh, c->dx_act, g.ldt);
     p[3] = prob1(BT, g.pt, c->dpre2, g.ldh, W(c, TCAR_V_S_WIN), g.ldh, g.ldh, c->dx_pt, g.pt, nullptr, 0, 1);
     TcarOpt oi = opt_of(c);
+    oi.hi_only = bwd_hi;
     if (s2 && fuse_finish && c->stream3 && c->ev3) oi.sig = fork_arm(c, FK_INGRAD);     // the third stream's fork below
     else fork_disarm(c, FK_INGRAD);
     RET(small_gemm(c, 1, 4, p, stream, &oi));
@@ -972,6 +977,7 @@ int backward_impl(const tcar_ctx_t* c, const tcar_batch_t* bt, void* stream, boo
   // backward, which only became ready when dE finished), else on the aux stream behind chain B.
   hipStream_t s3 = (s2 && fuse_finish && c->stream3 && c->ev3) ? (hipStream_t)c->stream3 : nullptr;
   TcarOpt ow = opt_of(c);
+  ow.hi_only = bwd_hi;
   if (s3) {
     sW = (void*)s3;      // ordered behind the main chain so far AND behind the aux stream's arena memset (ev[1])
     RET(fork_go(c, FK_INGRAD, st, s3, c->ev[0]));        // (flagged small-GEMM launches store write-through)

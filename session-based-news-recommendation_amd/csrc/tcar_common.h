@@ -60,6 +60,11 @@ constexpr int fork_delay = 7;      // us the aux prologue's flag fork holds its 
 #define TCAR_FIX_X3_ONESHOT 4      // (diagnostic builds override it: tools/micro/build_x3ring.sh)
 #endif
 constexpr int x3_oneshot = TCAR_FIX_X3_ONESHOT;      // small-GEMM launches of at most this many 64-deep stages per workgroup keep two stages in flight
+#ifndef TCAR_FIX_BWD_SMALL_HI
+#define TCAR_FIX_BWD_SMALL_HI 0    // (diagnostic builds: tools/micro/build_x3ring.sh bwdhi)
+#endif
+constexpr int bwd_small_hi = TCAR_FIX_BWD_SMALL_HI;  // 1: with the hi-only backward precision (scoring_bwd == 1) the session-side BACKWARD GEMMs
+                                                     // (dpooled, input gradients, weight gradients) contract plain bf16 operands too
 #ifndef TCAR_FIX_X3_DEEP
 #define TCAR_FIX_X3_DEEP 0         // (diagnostic builds: tools/micro/build_x3ring.sh deep)
 #endif
@@ -144,6 +149,7 @@ struct TcarOpt {
   // planes (tcar_ce_anchor_fold_o)
   bool anchored = false;
   const TcarRowFix* rowfix = nullptr;      // one-hot slab reduce of the anchored form (below)
+  bool hi_only = false;                    // small-GEMM launches (tcar_gemm_x3_grouped_o): plain bf16 operands, ONE MFMA per product
   // zeroed device words a launch may use for an order-fixed last-arrival fold (tcar_sqnorm_o: word 0 = arrival counter, kept zero
   // between launches; then one float per 32,768-float chunk): tcar_ctx_t.fold_scratch
   unsigned* scratch = nullptr;
