@@ -340,8 +340,9 @@ int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stat
  * launch leaves minus its partial sums in eight spare columns (139 .. 146) of the time-score planes, the one-hot plane of
  * tcar_time_onehot has ones there — tcar_gemm_bf16_ce_anchor writes the plane exp(accumulator) without group maxima, statistics
  * (0, group sum) and lab_logit = the label's accumulator: all groups of a row share ONE scale, and the plane never needs the rescale
- * pass.  tcar_ce_anchor_fold (one wave per row; B a multiple of 128) folds the group sums in a fixed order: S_b,
- * ce = log S_b - lab_logit; writes
+ * pass.  tcar_ce_anchor_fold (one wave per row; any B: the scaled attout rows [B, ceil32(B)) are zeroed) folds the group sums in a fixed order:
+ * S_b of the exponentials (ce = log S_b - lab_logit) and S_r of the plane's rounded entries (the gradient's scale: plane / S_r sums to one
+ * exactly — S_b below is S_r wherever a gradient is scaled); writes
  * rowstat[b] = (0, 1 / S_b) (may be NULL); puts the label's -1 into the plane as v = bf16(e_l - S_b); writes
  * scale2[b] = (1 / S_b, ((e_l - S_b) - v) / S_b) for the consumer that is linear in the plane's rows (the slab reduce of dX,
  * tcar_reduce_dact_onehot_scaled: softmax part scaled exactly, the one-hot's rounding residual added back in fp32); and writes
@@ -354,7 +355,7 @@ int tcar_ce_anchor_fold(int B, int N, int group_width, int ngroups, const float*
                         float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner, const void* ap_hi, const void* ap_lo,
                         void* aps_hi, int ap_cols, int64_t ap_inner, void* stream);
 /* tcar_gemm_bf16_ce with the anchored epilogue: the caller has put the row references into the contraction (see above); plane =
- * exp(accumulator), statistics (0, group sum), lab_logit = the label's accumulator */
+ * exp(accumulator), statistics (group sum of the plane's rounded entries, group sum of the exponentials), lab_logit = the label's accumulator */
 int tcar_gemm_bf16_ce_anchor(int M, int N, int K, const void* A_hi, const void* A_lo, int64_t a_inner, int64_t a_rows,
                              const void* B_hi, const void* B_lo, int64_t b_inner, int64_t b_rows, int K1, const void* A2_hi,
                              const void* A2_lo, const void* B2_hi, int64_t inner2, void* p_hi, int64_t p_inner, int64_t p_rows,
@@ -817,7 +818,7 @@ typedef struct {
    * (B * T >= 2,048) splits every table row's sources into chunks with a workgroup each (tcar_small_tables_bwd_det); without it the
    * step keeps the row pieces in the tail of segsum_ws and one workgroup per table row */
   float* small_det_ws; int64_t small_det_ws_floats;
-  /* optional buffers of the ANCHORED softmax form (fused training steps in the one-hot form with B a multiple of 128;
+  /* optional buffers of the ANCHORED softmax form (fused training steps in the one-hot form;
    * TCAR_FUSED_CE = 2; tcar_ce_anchor_fold): ce_rowscale [B, 2] = (1 / S_b, one-hot residual), aps16h = the packed attout plane
    * scaled per row, [ceil128(B), ldh + 5 ldt] bf16 (KB32), ce_form = ONE host int that carries the form the forward half of a step
    * chose to its backward half.  With them a step's plane of exponentials is never rescaled: 94 MB of traffic and one [B, N] pass
@@ -882,7 +883,7 @@ typedef struct {
   int32_t head_K;
   int32_t* neg_all;
   float* coef_all;
-  /* optional buffers of the ANCHORED softmax form on the shard (world*cap a multiple of 128; TCAR_FUSED_CE = 2): aps16h = the packed
+  /* optional buffers of the ANCHORED softmax form on the shard (TCAR_FUSED_CE = 2): aps16h = the packed
    * attout plane scaled per row [ceil128(world*cap), ldh + 5 ldt] bf16 (KB32), scale2 [world*cap, 2] = (1 / S_b, one-hot residual).
    * With them the shard's plane of exponentials is never rescaled: every shard subtracts the same per-session anchor inside its logits
    * GEMM (tcar_shard_score), the statistics exchange adds plain sums, tcar_shard_backward scales per row. */

@@ -59,7 +59,8 @@ struct BArgs {
   float* stats; int ngroups;   // [M, ngroups, 2]
   const int32_t* label; float* lab_logit;
   int lab_off, lab_window;     // TcarOpt: column of the label = label[m] - lab_off; window: outside [0, N) = not in this shard
-  int anchored;                // TcarOpt: anchored epilogue — the accumulators are x - anchor[m] already: exp(acc), no group maximum
+  int anchored;                // TcarOpt: anchored epilogue — the accumulators are x - anchor[m] already: exp(acc), no group maximum;
+                               // statistics (sum of the plane's ROUNDED entries, sum of the exponentials) per group
   // dX of the one-hot form (layout 0, hi planes only): N tiles at or beyond column n_b2 (a multiple of the tile width) read their B
   // operand from the plane B2 (inner b2_in32 * 32, rows as B) at column n0 - n_b2 — the static one-hot matrix of
   // publish_time_MWDHM, so that those output columns are dP = dlogits OH instead of dlogits E_time.  0: unused.
@@ -435,7 +436,12 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
           if (has_lab) g.lab_logit[row] = labv;
         }
         const float c = -mx * LOG2E;
-        float sum = 0.f;
+        // anchored form: TWO sums per group — of the exponentials (the loss: lse = anchor + log S) and of their bf16 ROUNDINGS as the
+        // plane holds them (the gradient: plane / S_r sums to one exactly, so that the label's e_l - S_r is the true -(sum of the others).
+        // With group maxima the dominant element is exp(0) = 1, exact in bf16; an anchored e_l = exp(x_l - a) is not, and near
+        // convergence (p_l -> 1) its 2^-9 rounding against an unrounded S was the whole of the label's gradient entry: two engines'
+        // runs of one overfit toy drifted 500x further apart than with group maxima until the sums were made consistent)
+        float sum = 0.f, sumr = 0.f;
 #pragma unroll
         for (int t = 0; t < TNW; ++t)
 #pragma unroll
@@ -450,11 +456,13 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
               const float pe = (FAST || n8 + j < g.N) ? __builtin_amdgcn_exp2f(fminf(fmaf(acc[u][t][8 * h + j], LOG2E, c), 100.f)) : 0.f;
               sum += pe;
               pk[j] = (__bf16)pe;
+              if (g.anchored) sumr += (float)pk[j];
             }
             if (VAR == 7 ? (sum == 12345.678f) : (live && (FAST || n8 < pcols)))
               *reinterpret_cast<bf16x8*>(g.p_hi + kb32_off(row, n8, g.p_in32)) = pk;
           }
         sum = xhalf(sum, [](float a, float b) { return a + b; });
+        if (g.anchored) mx = xhalf(sumr, [](float a, float b) { return a + b; });      // (the reference slot carries the rounded sum)
         if (live && lh == 0) *reinterpret_cast<float2*>(g.stats + ((long)row * g.ngroups + gidx) * 2) = make_float2(mx, sum);
         __builtin_amdgcn_sched_barrier(0);     // one session tile at a time: the accumulators leave no room for hoisted addresses
       }

@@ -302,11 +302,23 @@ __global__ __launch_bounds__(256) void ce_anchor_fold_kernel(int B, int N, int i
                                                              __bf16* __restrict__ aps, int ap_cols, int ap_in32) {
   const int lane = threadIdx.x & 63;
   const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
+  if (b >= B) {      // padding rows up to the next multiple of 32 are k-rows of dE: their attout rows are ZERO (the plane's own padding
+    //                  rows hold finite leftovers of earlier batches — the epilogue's exponent is clamped —, and finite times zero is zero)
+    if (b < ((B + 31) & ~31))
+      for (int c = lane * 4; c < ap_cols; c += 256) {
+        bf16x4_s z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = (__bf16)0.f;
+        *reinterpret_cast<bf16x4_s*>(aps + kb32_off(b, c, ap_in32)) = z;
+      }
+    return;
+  }
   const float2* st = reinterpret_cast<const float2*>(stats) + b * ngroups;
   // per lane: groups lane, lane + 64, ... in order; then the shuffle tree (a fixed order: the same bits in every run)
+  // (s: the sum of the plane's ROUNDED entries — the gradient's scale, consistent with what the GEMMs contract; st: the sum of the
+  //  exponentials themselves — the loss)
   constexpr int NG = 8;
-  float s = 0.f;
+  float s = 0.f, strue = 0.f;
   if (ngroups <= 64 * NG) {
     float2 pr[NG];
 #pragma unroll
@@ -315,11 +327,12 @@ __global__ __launch_bounds__(256) void ce_anchor_fold_kernel(int B, int N, int i
       pr[j] = g < ngroups ? st[g] : make_float2(0.f, 0.f);
     }
 #pragma unroll
-    for (int j = 0; j < NG; ++j) s += pr[j].y;
+    for (int j = 0; j < NG; ++j) { s += pr[j].x; strue += pr[j].y; }
   } else {
-    for (int g = lane; g < ngroups; g += 64) s += st[g].y;
+    for (int g = lane; g < ngroups; g += 64) { s += st[g].x; strue += st[g].y; }
   }
   s = wave_sum(s);
+  strue = wave_sum(strue);
   const int lab = clampi(label[b], 0, N - 1);
   __bf16* q = plane + kb32_off(b, lab, in32);
   const float el = (float)*q;                     // (every lane: the same address, the same bits)
@@ -327,8 +340,8 @@ __global__ __launch_bounds__(256) void ce_anchor_fold_kernel(int B, int N, int i
   const __bf16 v = (__bf16)t;
   const float inv = 1.0f / s, inv_e = 1.0f / (el - (float)v);
   if (lane == 0) {
-    if (rowstat) { rowstat[2 * b] = 0.f; rowstat[2 * b + 1] = inv; }         // (reference of the exponentials: the anchor = 0 here)
-    ce[b] = logf(s) - lab_logit[b];
+    if (rowstat) { rowstat[2 * b] = 0.f; rowstat[2 * b + 1] = 1.0f / strue; }         // (reference of the exponentials: the anchor = 0 here)
+    ce[b] = logf(strue) - lab_logit[b];
     scale2[2 * b] = inv;
     scale2[2 * b + 1] = (t - (float)v) * inv;
     *q = v;                                       // (v depends on the wave's one load of the entry: it has returned for every lane)
@@ -342,8 +355,8 @@ __global__ __launch_bounds__(256) void ce_anchor_fold_kernel(int B, int N, int i
     *reinterpret_cast<bf16x4_s*>(aps + o) = y;
   }
 }
-// ... for the catalog-sharded step: the row sums crossed the ranks (rowstat[b] = (lse, 1) from tcar_softmax_combine_rowstat; every
-// group reference is the anchor, i.e. 0 in the accumulators: S_b = exp(lse)), the label lives in ONE shard (window: label - lab_off
+// ... for the catalog-sharded step: the row sums crossed the ranks (rowstat[b].x = the sum over the shards of their planes' rounded
+// entries, from tcar_softmax_combine_anchored), the label lives in ONE shard (window: label - lab_off
 // inside [0, N) or no label entry here: no patch, no residual, plain 1 / S_b on attout's row), and a padding session (label < 0,
 // lse = +inf) gets an exactly zero gradient row: scale 0 on both consumers
 __global__ __launch_bounds__(256) void ce_anchor_apply_kernel(int B, int N, int in32, const float* __restrict__ rowstat,
@@ -353,12 +366,21 @@ __global__ __launch_bounds__(256) void ce_anchor_apply_kernel(int B, int N, int 
                                                               __bf16* __restrict__ aps, int ap_cols, int ap_in32) {
   const int lane = threadIdx.x & 63;
   const long b = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= B) return;
+  if (b >= B) {      // (padding k-rows of dE: zero attout rows, as in ce_anchor_fold_kernel)
+    if (b < ((B + 31) & ~31))
+      for (int c = lane * 4; c < ap_cols; c += 256) {
+        bf16x4_s z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z[j] = (__bf16)0.f;
+        *reinterpret_cast<bf16x4_s*>(aps + kb32_off(b, c, ap_in32)) = z;
+      }
+    return;
+  }
   const int lraw = label[b];
   const int lab = lraw - lab_off;
   float inv = 0.f, inv_e = 0.f, resid = 0.f;
   if (lraw >= 0) {
-    const float s = expf(rowstat[2 * b]) / rowstat[2 * b + 1];
+    const float s = rowstat[2 * b];               // (anchored convention: the sum over the shards of the planes' ROUNDED entries)
     inv = 1.0f / s;
     inv_e = inv;
     if (lab >= 0 && lab < N) {
@@ -530,11 +552,24 @@ __global__ __launch_bounds__(256) void ce_fold_rescale_kernel(int B, int N, int 
 // statistics all-gather (shard.hip: softmax_combine).  The label's score is 0 unless the label lies in [n0, n0 + n_loc).
 __global__ __launch_bounds__(256) void ce_shard_stats_kernel(int B, int ngroups, const float* __restrict__ stats,
                                                              const float* __restrict__ lab_logit, const int32_t* __restrict__ label,
-                                                             int n0, int n_loc, float* __restrict__ out3) {
+                                                             int n0, int n_loc, float* __restrict__ out3, int anchored) {
   const int lane = threadIdx.x & 63;
   const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (b >= B) return;
   const float2* st = reinterpret_cast<const float2*>(stats) + (long)b * ngroups;
+  if (anchored) {      // pairs (sum of the plane's rounded entries, sum of the exponentials), one reference per row: plain sums
+    float sr = 0.f, s2 = 0.f;
+    for (int g = lane; g < ngroups; g += 64) { const float2 v = st[g]; sr += v.x; s2 += v.y; }
+    sr = wave_sum(sr);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+      const int l = label[b] - n0;
+      out3[3L * b] = sr;
+      out3[3L * b + 1] = s2;
+      out3[3L * b + 2] = (l >= 0 && l < n_loc) ? lab_logit[b] : 0.f;
+    }
+    return;
+  }
   float m = -INFINITY;
   for (int g = lane; g < ngroups; g += 64) m = fmaxf(m, st[g].x);
   m = wave_max(m);
@@ -1243,18 +1278,18 @@ extern "C" int tcar_ce_finish(int B, int N, int group_width, int ngroups, const 
   return tcar_ce_finish_o(B, N, group_width, ngroups, stats, lab_logit, label, rowstat, ce, dl_hi, inner, stream, nullptr);
 }
 
-// anchored form of tcar_ce_finish (see ce_anchor_fold_kernel): B a multiple of 128 (no padding rows exist in the planes then);
-// ap_* / aps: the packed attout planes of the dE GEMM [B, ap_cols] with inner dimension ap_inner, KB32 layout
+// anchored form of tcar_ce_finish (see ce_anchor_fold_kernel); any B (planes of ceil128(B) rows; the fold zeroes the scaled attout rows
+// [B, ceil32(B)), the k-rows of dE beyond the batch); ap_* / aps: the packed attout planes of the dE GEMM [B, ap_cols] with inner dimension ap_inner, KB32 layout
 int tcar_ce_anchor_fold_o(int B, int N, int group_width, int ngroups, const float* stats, const float* lab_logit, const int32_t* label,
                           float* rowstat, float* ce, float* scale2, void* dl_hi, int64_t inner, const void* ap_hi, const void* ap_lo,
                           void* aps_hi, int ap_cols, int64_t ap_inner, void* stream, TcarOpt* o) {
   (void)o;
   if (B <= 0) return TCAR_OK;
-  if ((B & 127) || N <= 0 || !stats || !lab_logit || !label || !ce || !scale2 || ((uintptr_t)scale2 & 7) || !dl_hi || (inner & 31) || inner < N || ngroups <= 0 ||
+  if (N <= 0 || !stats || !lab_logit || !label || !ce || !scale2 || ((uintptr_t)scale2 & 7) || !dl_hi || (inner & 31) || inner < N || ngroups <= 0 ||
       (group_width != 64 && group_width != 96) || (long)ngroups * group_width < N || (rowstat && ((uintptr_t)rowstat & 7)) || !ap_hi ||
       !ap_lo || !aps_hi || ap_cols <= 0 || (ap_cols & 3) || (ap_inner & 31) || ap_inner < ap_cols || ((uintptr_t)stats & 7))
     return TCAR_E_ARG;
-  TCAR_LAUNCH(ce_anchor_fold_kernel, dim3(B / 4), dim3(256), 0, (hipStream_t)stream, B, N, (int)(inner >> 5), ngroups, stats, lab_logit,
+  TCAR_LAUNCH(ce_anchor_fold_kernel, dim3((((B + 31) & ~31) + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, N, (int)(inner >> 5), ngroups, stats, lab_logit,
               label, rowstat, ce, scale2, (__bf16*)dl_hi, (const __bf16*)ap_hi, (const __bf16*)ap_lo, (__bf16*)aps_hi, ap_cols,
               (int)(ap_inner >> 5));
   TCAR_CHECK_LAUNCH();
@@ -1270,10 +1305,10 @@ extern "C" int tcar_ce_anchor_fold(int B, int N, int group_width, int ngroups, c
 int tcar_ce_anchor_apply_o(int B, int N, const float* rowstat, const int32_t* label, int lab_off, void* dl_hi, int64_t inner,
                            const void* ap_hi, const void* ap_lo, void* aps_hi, int ap_cols, int64_t ap_inner, float* scale2, void* stream) {
   if (B <= 0) return TCAR_OK;
-  if ((B & 127) || N <= 0 || !rowstat || !label || !dl_hi || (inner & 31) || inner < N || !ap_hi || !ap_lo || !aps_hi || ap_cols <= 0 ||
+  if (N <= 0 || !rowstat || !label || !dl_hi || (inner & 31) || inner < N || !ap_hi || !ap_lo || !aps_hi || ap_cols <= 0 ||
       (ap_cols & 3) || (ap_inner & 31) || ap_inner < ap_cols || !scale2 || ((uintptr_t)scale2 & 7))
     return TCAR_E_ARG;
-  TCAR_LAUNCH(ce_anchor_apply_kernel, dim3(B / 4), dim3(256), 0, (hipStream_t)stream, B, N, (int)(inner >> 5), rowstat, label, lab_off,
+  TCAR_LAUNCH(ce_anchor_apply_kernel, dim3((((B + 31) & ~31) + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, N, (int)(inner >> 5), rowstat, label, lab_off,
               scale2, (__bf16*)dl_hi, (const __bf16*)ap_hi, (const __bf16*)ap_lo, (__bf16*)aps_hi, ap_cols, (int)(ap_inner >> 5));
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
@@ -1309,10 +1344,16 @@ extern "C" int tcar_ce_rescale(int B, int N, int group_width, int ngroups, const
 
 extern "C" int tcar_ce_shard_stats(int B, int ngroups, const float* stats, const float* lab_logit, const int32_t* label, int n0,
                                    int n_loc, float* out3, void* stream) {
+  return tcar_ce_shard_stats_a(B, ngroups, stats, lab_logit, label, n0, n_loc, out3, 0, stream);
+}
+// anchored != 0: the pairs of the anchored epilogue -> out3[b] = (sum of the plane's rounded entries, sum of the exponentials, label's
+// accumulator), to be combined by tcar_softmax_combine_anchored
+int tcar_ce_shard_stats_a(int B, int ngroups, const float* stats, const float* lab_logit, const int32_t* label, int n0, int n_loc,
+                          float* out3, int anchored, void* stream) {
   if (B <= 0) return TCAR_OK;
   if (ngroups <= 0 || !stats || !lab_logit || !label || !out3 || ((uintptr_t)stats & 7)) return TCAR_E_ARG;
   TCAR_LAUNCH(ce_shard_stats_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, B, ngroups, stats, lab_logit, label, n0,
-              n_loc, out3);
+              n_loc, out3, anchored);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;
 }

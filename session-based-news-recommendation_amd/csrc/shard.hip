@@ -125,6 +125,31 @@ __global__ __launch_bounds__(256) void softmax_combine_kernel(int W, int B, cons
   if (ce) ce[b] = l - lab;
 }
 
+// anchored form: stats_all [W, B, 3] = (sum of the plane's rounded entries, sum of the exponentials, label's accumulator) per shard,
+// every shard's exponentials relative to the SAME per-session anchor: plain sums in rank order.  lse (relative to the anchor) and ce
+// from the exponentials' sum; rowstat[b] = (rounded sum, 1 / true sum) for tcar_ce_anchor_apply_o
+__global__ __launch_bounds__(256) void softmax_combine_anchored_kernel(int W, int B, const float* __restrict__ stats_all,
+                                                                       const int32_t* __restrict__ label, float* __restrict__ lse,
+                                                                       float* __restrict__ ce, float* __restrict__ rowstat) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  if (label && label[b] < 0) {          // padding session: an exactly zero gradient row (the apply kernel tests the label itself)
+    lse[b] = INFINITY;
+    rowstat[2 * b] = INFINITY; rowstat[2 * b + 1] = 0.f;
+    if (ce) ce[b] = 0.f;
+    return;
+  }
+  float sr = 0.f, s = 0.f, lab = 0.f;
+  for (int w = 0; w < W; ++w) {
+    const float* t = stats_all + ((long)w * B + b) * 3;
+    sr += t[0]; s += t[1]; lab += t[2];
+  }
+  const float l = logf(s);
+  lse[b] = l;
+  rowstat[2 * b] = sr; rowstat[2 * b + 1] = 1.0f / s;
+  if (ce) ce[b] = l - lab;
+}
+
 __global__ __launch_bounds__(256) void softmax_grad_kernel(int B, int N, const float* __restrict__ logits, long ld,
                                                            const float* __restrict__ lse, const int32_t* __restrict__ label,
                                                            int n0, __bf16* __restrict__ dh, __bf16* __restrict__ dl) {
@@ -245,6 +270,16 @@ extern "C" int tcar_softmax_combine_rowstat(int W, int B, const float* stats_all
   if (B <= 0) return TCAR_OK;
   if (W <= 0 || !stats_all || !lse) return TCAR_E_ARG;
   TCAR_LAUNCH(softmax_combine_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, B, stats_all, label, lse, ce,
+              rowstat);
+  TCAR_CHECK_LAUNCH();
+  return TCAR_OK;
+}
+
+int tcar_softmax_combine_anchored(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce, float* rowstat,
+                                  void* stream) {
+  if (B <= 0) return TCAR_OK;
+  if (W <= 0 || !stats_all || !lse || !rowstat) return TCAR_E_ARG;
+  TCAR_LAUNCH(softmax_combine_anchored_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, B, stats_all, label, lse, ce,
               rowstat);
   TCAR_CHECK_LAUNCH();
   return TCAR_OK;

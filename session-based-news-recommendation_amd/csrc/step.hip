@@ -317,12 +317,10 @@ bool onehot_bwd(const tcar_ctx_t* c, const tcar_batch_t* bt) {
   return onehot_fwd(c, bt->B) && tn(c).onehot_time >= 2 && c->tclip && c->dP && c->qz && c->d.ldt == 64 && c->et_perm && c->inv_off &&
          c->ct_ws && c->stream3 && c->ev3 && c->gw_rows && sorted_rows(c, bt) && tn(c).det_small != 0;
 }
-// anchored softmax form (score.hip: ce_anchor_fold_kernel): the one-hot step with the buffers of the form, full 128-row blocks
-// (the planes then have no padding rows for a rescale pass to zero) and at most eight 64-column anchor partials per row (the anchor
-// columns of the one-hot K segment: embed.hip)
+// anchored softmax form (score.hip: ce_anchor_fold_kernel): the one-hot step with the buffers of the form and at most eight 64-column
+// anchor partials per row (the anchor columns of the one-hot K segment: embed.hip)
 bool ce_anchored(const tcar_ctx_t* c, const tcar_batch_t* bt) {
-  return onehot_bwd(c, bt) && tn(c).fused_ce >= 2 && (bt->B & 127) == 0 && c->ce_rowscale && c->aps16h && c->ce_form &&
-         2 * c->d.ldh / 64 <= TCAR_ANCHOR_COLS;
+  return onehot_bwd(c, bt) && tn(c).fused_ce >= 2 && c->ce_rowscale && c->aps16h && c->ce_form && 2 * c->d.ldh / 64 <= TCAR_ANCHOR_COLS;
 }
 }  // namespace
 
@@ -1307,10 +1305,10 @@ bool shard_onehot(const tcar_ctx_t* c, const tcar_shard_t* s, CeWs* w) {
   return c->scoring == 3 && c->d.ldt == 64 && fused_ce(&cc, s->world * s->cap, w) && c->ce_geo && c->oh16 && c->p16h && c->p16l &&
          c->tclip && c->dP && c->qz && c->inv_off && c->ct_ws && c->mwdhm && tn(c).onehot_time >= 2;
 }
-// anchored softmax form on the shard (score.hip: ce_anchor_apply_kernel): the shard's one-hot schedule, whole 128-row blocks of
-// exchanged sessions, the two buffers of the form in the shard descriptor
+// anchored softmax form on the shard (score.hip: ce_anchor_apply_kernel): the shard's one-hot schedule with the two buffers of the form
+// in the shard descriptor
 bool shard_anchored(const tcar_ctx_t* c, const tcar_shard_t* s) {
-  return tn(c).fused_ce >= 2 && ((s->world * s->cap) & 127) == 0 && s->aps16h && s->scale2 && s->n_total >= s->n0 + s->n_loc;
+  return tn(c).fused_ce >= 2 && s->aps16h && s->scale2 && s->n_total >= s->n0 + s->n_loc;
 }
 int check_shard(const tcar_ctx_t* c, const tcar_shard_t* s) {
   if (!c || !s || !c->scoring || s->world <= 0 || s->cap <= 0 || s->n_loc <= 0 || s->n0 < 0) return TCAR_E_ARG;
@@ -1378,7 +1376,7 @@ extern "C" int tcar_shard_score(const tcar_ctx_t* c, const tcar_shard_t* s, int 
                             c->oh16, 160, s->dl16h, nlpad, (Bq + 127) & ~127, w.stats, w.stats_floats, s->lab_all, w.lab, c->scoring,
                             &gw, &ng, stream, &ol));
     c->ce_geo[0] = gw; c->ce_geo[1] = ng;
-    return tcar_ce_shard_stats(Bq, ng, w.stats, w.lab, s->lab_all, s->n0, nl, s->stats, stream);
+    return tcar_ce_shard_stats_a(Bq, ng, w.stats, w.lab, s->lab_all, s->n0, nl, s->stats, ol.anchored ? 1 : 0, stream);
   }
   RET(tcar_gemm_bf16(1, Bq, nl, g.ek, s->a16h, s->a16l, g.ek, Bq, c->e16h, c->e16l, g.ek, nlpad, s->logits, nlpad, nullptr, 0, 0,
                      c->scoring, 1, stream));
@@ -1397,8 +1395,9 @@ extern "C" int tcar_shard_backward(const tcar_ctx_t* c, const tcar_shard_t* s, c
     // lse from the exchanged statistics, the exp plane rescaled in place to dlogits of the shard's columns; then the one-hot forms:
     // dE (aux stream) keeps its item block and leaves (||gy||^2, x . gy) pairs for the time block; dX contracts the shard against
     // [E_item | E_content | OH]; the slab reduce expands dP to the time columns WITHOUT tanh' (it follows the exchange)
-    RET(tcar_softmax_combine_rowstat(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, w.rowstat, stream));
     const bool anch = shard_anchored(c, s);
+    if (anch) RET(tcar_softmax_combine_anchored(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, w.rowstat, stream));
+    else RET(tcar_softmax_combine_rowstat(s->world, Bq, stats_all, s->lab_all, s->lse, s->ce, w.rowstat, stream));
     if (anch)      // no pass over the plane: row scales, the label's -1 where the label lives here, the scaled attout plane of dE
       RET(tcar_ce_anchor_apply_o(Bq, nl, w.rowstat, s->lab_all, s->n0, s->dl16h, nlpad, s->ap16h, s->ap16l, s->aps16h, g.ldh + g.pt,
                                  g.ldh + g.pt, s->scale2, stream));

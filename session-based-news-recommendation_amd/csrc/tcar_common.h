@@ -174,6 +174,10 @@ int tcar_ce_anchor_fold_o(int B, int N, int group_width, int ngroups, const floa
 // E[label[b]] over the item | content columns (hi / lo), zero for padding sessions (label < 0)
 int tcar_ce_anchor_apply_o(int B, int N, const float* rowstat, const int32_t* label, int lab_off, void* dl_hi, int64_t inner,
                            const void* ap_hi, const void* ap_lo, void* aps_hi, int ap_cols, int64_t ap_inner, float* scale2, void* stream);
+int tcar_ce_shard_stats_a(int B, int ngroups, const float* stats, const float* lab_logit, const int32_t* label, int n0, int n_loc,
+                          float* out3, int anchored, void* stream);
+int tcar_softmax_combine_anchored(int W, int B, const float* stats_all, const int32_t* label, float* lse, float* ce, float* rowstat,
+                                  void* stream);
 int tcar_anchor_scores(int ldh, int B, const float* attout, int64_t ld_att, const int32_t* label, const float* E, int64_t ldE,
                        int64_t n_rows, void* p_hi, void* p_lo, int64_t inner, void* stream);
 int tcar_clip_adam_early_2(float* w, const float* g, float* m, float* v, const tcar_segments_t* segs, float* w2d, int64_t ldw,

@@ -605,17 +605,20 @@ def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K):
                                         None) == 0
     gw, ng = gw.value, ng.value
     st = stats[:M * ng * 2].view(M, ng, 2).cpu().numpy()
-    assert (st[..., 0] == 0).all()
     xp = np.full((M, ng * gw), -np.inf)
     xp[:, :N] = x
     want_e = np.exp(xp - anchor[:, None])
-    assert np.allclose(st[..., 1], want_e.reshape(M, ng, gw).sum(2), rtol=3e-4, atol=1e-6)
+    assert np.allclose(st[..., 1], want_e.reshape(M, ng, gw).sum(2), rtol=3e-4, atol=1e-6)        # .y: the exponentials (the loss)
     assert np.allclose(lab_logit.cpu().numpy(), xl - anchor, rtol=1e-5, atol=1e-5 * np.abs(x).max())
     idx = torch.tensor(_kb32_index(Mp, Np), device="cuda")
     e = plane[idx].float().cpu().numpy()
     # (bf16: 7 explicit mantissa bits — round-to-nearest is within 2^-8 relative; + the split-bf16 logits' own error inside the
     #  exponential, 1e-4 at |x| ~ 40)
     assert (np.abs(e[:, :N] - want_e[:, :N]) <= (2.0 ** -8 + 1e-3) * want_e[:, :N] + 1e-30).all() and (e[:, N:] == 0).all()
+    # .x: the sum of the plane's entries AS ROUNDED (the gradient's scale: plane / S_r sums to one)
+    ep = np.zeros((M, ng * gw))
+    ep[:, :N] = e[:, :N]
+    assert np.allclose(st[..., 0], ep.reshape(M, ng, gw).sum(2), rtol=1e-5, atol=1e-30)
     # ---- the fold
     cols = 576
     ap = (rng.standard_normal((M, cols)) * 0.5).astype(np.float32)
@@ -627,10 +630,10 @@ def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K):
     m = x.max(1, keepdims=True)
     lse = m[:, 0] + np.log(np.exp(x - m).sum(1))
     close(ce.cpu().numpy(), lse - xl, name="ce", rtol=1e-4, atol_scale=1e-5)
-    S = st[..., 1].astype(np.float64).sum(1)
+    S, St = st[..., 0].astype(np.float64).sum(1), st[..., 1].astype(np.float64).sum(1)      # rounded / true
     sc2 = rowscale.cpu().numpy().reshape(M, 2).astype(np.float64)
     rs, rd = sc2[:, 0], sc2[:, 1]
-    assert np.allclose(rs, 1.0 / S, rtol=1e-5) and np.allclose(rowstat.cpu().numpy().reshape(M, 2), np.stack([0 * S, 1.0 / S], 1), rtol=1e-5)
+    assert np.allclose(rs, 1.0 / S, rtol=1e-5) and np.allclose(rowstat.cpu().numpy().reshape(M, 2), np.stack([0 * S, 1.0 / St], 1), rtol=1e-5)
     d = plane[idx].float().cpu().numpy()
     keep = np.ones((M, N), bool)
     keep[np.arange(M), label] = False
@@ -647,8 +650,12 @@ def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K):
     got = d[:, :N] * rs[:, None]
     got[np.arange(M), label] += rd
     err = np.abs(got - want)
-    # ONE rounding per softmax element (+ the split-bf16 logits' own error inside the exponential, 1e-4 at |x| ~ 40)
-    bound = (2.0 ** -8 + 1e-3) * p + 1e-6 * (np.arange(N)[None, :] == label[:, None]) + 1e-30
+    # the row's gradient sums to ZERO to fp32 (the scale is 1 / the sum of the plane's own entries, the one-hot exact): what keeps the
+    # label's entry right when p_label -> 1 (its e_l - S is then the small sum of the OTHER entries, not e_l's rounding error)
+    assert np.abs(got.sum(1)).max() <= 2e-6, float(np.abs(got.sum(1)).max())
+    # ONE rounding per softmax element (+ the split-bf16 logits' own error inside the exponential, 1e-4 at |x| ~ 40; + the rounded
+    # sum against the true one: up to 2^-8 where one element dominates)
+    bound = (2.0 ** -7 + 1e-3) * p + 1e-6 * (np.arange(N)[None, :] == label[:, None]) + 1e-30
     w = np.unravel_index(np.argmax(err - bound), err.shape)
     assert (err <= bound).all(), (w, int(label[w[0]]), float(got[w]), float(want[w]), float(e[w]), float(d[w]), float(rs[w[0]]), float(S[w[0]]))
     assert np.linalg.norm(got - want) / np.linalg.norm(want) < 3e-3
@@ -670,9 +677,12 @@ def test_logits_gemm_anchored_epilogue_and_fold(lib, M, N, K):
     assert lib.tcar_ce_anchor_fold(M, N, gw, ng, ptr(stats), ptr(lab_logit), ptr2(lab_d), ptr(rowstat), ptr(ce), ptr(rowscale), ptr2(plane2),
                                    Np, ptr2(ph), ptr2(pl), ptr2(aps), cols, pi, None) == 0
     assert bool(torch.isfinite(ce).all()) and bool(torch.isfinite(rowscale).all()) and bool(torch.isfinite(aps.float()[pidx][:, :cols]).all())
-    # B that is no multiple of 128 is refused (the step keeps the rescaled form for such batches)
-    assert lib.tcar_ce_anchor_fold(M - 1, N, gw, ng, ptr(stats), ptr(lab_logit), ptr2(lab_d), ptr(rowstat), ptr(ce), ptr(rowscale), ptr2(plane),
-                                   Np, ptr2(ph), ptr2(pl), ptr2(aps), cols, pi, None) != 0
+    # any B: the scaled attout rows [B, ceil32(B)) — k-rows of dE beyond the batch — are zeroed, rows beyond are left alone
+    before = aps[pidx].float().clone()
+    assert lib.tcar_ce_anchor_fold(M - 35, N, gw, ng, ptr(stats), ptr(lab_logit), ptr2(lab_d), ptr(rowstat), ptr(ce), ptr(rowscale), ptr2(plane2),
+                                   Np, ptr2(ph), ptr2(pl), ptr2(aps), cols, pi, None) == 0
+    after = aps[pidx].float()
+    assert float(after[M - 35:M - 32, :cols].abs().max()) == 0.0 and torch.equal(after[M - 32:], before[M - 32:])
 
 
 @pytest.mark.parametrize("N,H,Ht,B", [(3000, 250, 64, 77), (46033, 250, 64, 512), (500, 30, 100, 5), (700, 100, 200, 33)])
@@ -1048,12 +1058,12 @@ def test_schedule_switches_agree_bitwise_with_the_default_schedule():
 
 def test_anchored_softmax_form_in_the_step():
     """Round 6: the fused step at the benched size takes the ANCHORED softmax form (no rescale pass over the [B, N] plane).
-      * the form is on for full 128-row blocks and off for a 500-session tail batch and under TCAR_FUSED_CE = 1;
+      * the form is on for every batch (full ones and a 500-session tail batch) and off under TCAR_FUSED_CE = 1;
       * the anchor the forward pass leaves is the label's score without its time part (|difference| small, S_b >= e^-|difference|);
       * DEFERRED steps (label rows of E updated in the early part of the split update, beside which the forward reads them) and
         IMMEDIATE steps give the same bits — losses, variables, Adam moments: the rest pass never writes a row the forward reads;
       * the anchored form and the rescaled form agree to 2e-4 of the loss scale over 30 steps and in every variable to the Adam bound;
-      * a tail batch (B = 500) between full batches switches forms inside one run."""
+      * a tail batch (B = 500: padding rows in every plane) between full batches."""
     _need_gpu()
     from tcar_amd.engine import TcarEngine
     N, H, Ht, B, K = 46033, 250, 64, 512, 20
@@ -1086,7 +1096,7 @@ def test_anchored_softmax_form_in_the_step():
         return out
 
     imm = run({}, False)
-    assert imm[2] == (True, False), imm[2]
+    assert imm[2] == (True, True), imm[2]
     anc, lab, rs = imm[3]
     assert np.abs(anc - lab).max() < 6.0, float(np.abs(anc - lab).max())       # the time part of the label's score
     assert (rs > 0).all() and (rs <= np.exp(np.abs(anc - lab)) * 1.001).all()     # S_b >= exp(x_label - anchor)
