@@ -339,7 +339,7 @@ int tcar_ce_finish(int B, int N, int group_width, int ngroups, const float* stat
  * reference a[b] — the fused step: the label's score up to rounding, subtracted INSIDE the contraction: the forward pass's finishing
  * launch leaves minus its partial sums in eight spare columns (139 .. 146) of the time-score planes, the one-hot plane of
  * tcar_time_onehot has ones there — tcar_gemm_bf16_ce_anchor writes the plane exp(accumulator) without group maxima, statistics
- * (0, group sum) and lab_logit = the label's accumulator: all groups of a row share ONE scale, and the plane never needs the rescale
+ * (group sum of the plane's bf16-ROUNDED entries, group sum of the exponentials) and lab_logit = the label's accumulator: all groups of a row share ONE scale, and the plane never needs the rescale
  * pass.  tcar_ce_anchor_fold (one wave per row; any B: the scaled attout rows [B, ceil32(B)) are zeroed) folds the group sums in a fixed order:
  * S_b of the exponentials (ce = log S_b - lab_logit) and S_r of the plane's rounded entries (the gradient's scale: plane / S_r sums to one
  * exactly — S_b below is S_r wherever a gradient is scaled); writes
