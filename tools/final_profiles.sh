@@ -25,7 +25,7 @@ traces2() {
 case $1 in
   traces) traces1; traces2 ;;
   part1|part1_benches)
-    [ "$1" == part1 ] && $S tests
+    [ "$1" == part1 ] && $S tests smoke
     $S bench:default "bench:default_20_5:--steps 20 --warmup 5" "bench:resident_feed:--resident_feed --no_cpu_baseline --no_e2e"
     $S "bench:adressa:--config adressa" "bench:mind:--config mind"
     $S "bench:globo_bf16x3:--scoring bf16x3 --no_cpu_baseline --no_e2e" "bench:globo_bf16:--scoring bf16 --no_cpu_baseline --no_e2e" "bench:globo_f32:--scoring f32 --no_cpu_baseline --no_e2e"
