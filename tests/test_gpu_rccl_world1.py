@@ -83,7 +83,9 @@ for i in range(steps):
             assert d <= 1e-3 * np.abs(pr[k]).max() + 0.25 * 1e-3 * REF_STEPS, (k, float(d))
     if plain is not None:
         lp = plain.train_step(bt).clone()
-        worst_plain = max(worst_plain, float((l - lp).abs().max() / lp.abs().max()))
+        # (this toy overfits: its losses fall from 10 to 1e-4 — relative to the step's OWN largest loss the run-to-run noise of the
+        #  float atomics is O(0.1) there in either softmax form; the measure keeps a floor of 0.05 under the denominator)
+        worst_plain = max(worst_plain, float((l - lp).abs().max() / max(float(lp.abs().max()), 0.05)))
         if i < EARLY:
             worst_plain_early = worst_plain
         bit_equal_losses = bit_equal_losses and bool(torch.equal(l, lp))
