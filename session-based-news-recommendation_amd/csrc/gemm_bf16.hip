@@ -465,10 +465,7 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
               typedef unsigned u4_t __attribute__((ext_vector_type(4)));
               const u4_t w = __builtin_bit_cast(u4_t, pk);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                sumr += __uint_as_float(w[q] << 16);
-                sumr += __uint_as_float(w[q] & 0xffff0000u);
-              }
+              for (int q = 0; q < 4; ++q) sumr += __uint_as_float(w[q] << 16) + __uint_as_float(w[q] & 0xffff0000u);
             }
             if (VAR == 7 ? (sum == 12345.678f) : (live && (FAST || n8 < pcols)))
               *reinterpret_cast<bf16x8*>(g.p_hi + kb32_off(row, n8, g.p_in32)) = pk;
