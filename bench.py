@@ -15,7 +15,7 @@ sources and the example indices of every batch of the schedule; the device sampl
 stream while step i runs.  `--resident_feed` times the loop over pre-formed feeds instead (no sampler inside: reported as
 "device_step_sessions_per_s" in the default run).  Rank 0 prints ONE JSON line: whole-job sessions/sec plus
   "roofline"      the kernel with the largest total time among the three full-catalog GEMMs (logits = attout E^T,
-                  dX = dlogits E, dE = dlogits^T attout): algorithmic FLOPs per launch / mean HIP-event duration of that
+                  dX = dlogits E, dE = dlogits^T attout; the logits GEMM unless another exceeds it by > 10 %): algorithmic FLOPs per launch / mean HIP-event duration of that
                   launch, measured live in a second pass of the same K steps, on the stream the kernel is launched on (the C++
                   step driver records the events; the headline pass runs without them), against the dense bf16 MFMA peak (fp32 matrix peak for --scoring f32) of
                   /opt/skills/guides/MI355X_MICROARCH.md; "others" lists the other two the same way; "traffic" = HBM bytes
@@ -586,6 +586,12 @@ def main():
             kernels[tag] = {"launches": len(ms), "avg_ms": round(avg, 5), "tflops": round(ach, 2)}
         if ents:
             ents.sort(key=lambda e: -e["total_ms"])
+            # (the event-timed dE runs beside dX and a short run can put it a hair above the logits GEMM, which the kernel trace shows
+            #  as the longer launch: the forward GEMM stays the line's kernel unless another one exceeds it by more than 10 %)
+            fwd = [e for e in ents if e["tag"] == "score_fwd"]
+            if fwd and fwd[0]["total_ms"] >= 0.9 * ents[0]["total_ms"]:
+                ents.remove(fwd[0])
+                ents.insert(0, fwd[0])
             roof = dict(ents[0])
             roof["others"] = ents[1:]
         eng._ev = None
