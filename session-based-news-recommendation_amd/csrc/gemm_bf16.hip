@@ -464,8 +464,15 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
               //  erratum of docs/EXPERIMENTS.md, not pursued: plain shifts, masks and adds)
               typedef unsigned u4_t __attribute__((ext_vector_type(4)));
               const u4_t w = __builtin_bit_cast(u4_t, pk);
+#ifdef TCAR_DIAG_DOT2      // (diagnostic builds only — tools/micro/build_x3ring.sh dot2: the form that gave wrong sums in the step)
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) sumr = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w[q]), ones, sumr, false);
+#else
 #pragma unroll
               for (int q = 0; q < 4; ++q) sumr += __uint_as_float(w[q] << 16) + __uint_as_float(w[q] & 0xffff0000u);
+#endif
             }
             if (VAR == 7 ? (sum == 12345.678f) : (live && (FAST || n8 < pcols)))
               *reinterpret_cast<bf16x8*>(g.p_hi + kb32_off(row, n8, g.p_in32)) = pk;
