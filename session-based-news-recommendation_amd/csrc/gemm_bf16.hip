@@ -384,6 +384,10 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
     return;
   }
   if constexpr (EPI == 1) {
+#if defined(TCAR_DIAG_DOT2) && TCAR_DIAG_DOT2 >= 2      // (diagnostic: no wave of the workgroup issues an MFMA once any wave is in its epilogue)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_nop 7\n s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
+#endif
     // Softmax epilogue (model_combine.py:145 without materialised logits).  The accumulators of this form are TRANSPOSED
     // (compute() swaps the MFMA operands) and the B fragments are read with the row permutation of frag<., PERM>: a lane owns ONE
     // session (column lane & 31 of the tile = row m of the logits) and its 16 registers of catalog tile t are the 16 CONSECUTIVE
@@ -459,16 +463,24 @@ __global__ __launch_bounds__(64 * WMW * WNW, (EPI == 2 ? (WMW * WNW == 9 ? 5 : 4
             }
             {      // the eight ROUNDED values back out of the four packed dwords (the exponentials themselves are dead by now: converting
               //      inside the loop above kept them alive and spilled 80 registers)
-              // (v_dot2c_f32_bf16 against a pair of ones does it in four instructions and without a spill — and gave WRONG sums in
-              //  the step, beside the other waves' MFMAs: 9 % off in the item gradient of two parity cases; like the packed-FMA
-              //  erratum of docs/EXPERIMENTS.md, not pursued: plain shifts, masks and adds)
+              // (v_dot2c_f32_bf16 against a pair of ones: with the pairs BIT-CAST out of the packed dwords hipcc 7.2 feeds all four
+              //  instructions of a piece the same register — fast, spill-free and wrong (profiles/r06_dot2c_in_step.txt); with the
+              //  pairs taken from the vector's elements it is right, spills 76 registers and is 4 us slower.  Shifts, masks and adds.)
               typedef unsigned u4_t __attribute__((ext_vector_type(4)));
               const u4_t w = __builtin_bit_cast(u4_t, pk);
-#ifdef TCAR_DIAG_DOT2      // (diagnostic builds only — tools/micro/build_x3ring.sh dot2: the form that gave wrong sums in the step)
+#ifdef TCAR_DIAG_DOT2      // (diagnostic builds only — tools/micro/build_x3ring.sh dot2 | dot2b | dot2c)
               typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
               const bf16x2_t ones = {(__bf16)1.0f, (__bf16)1.0f};
+#if TCAR_DIAG_DOT2 >= 3    // pairs taken from the vector's ELEMENTS
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const bf16x2_t pr = {pk[2 * q], pk[2 * q + 1]};
+                sumr = __builtin_amdgcn_fdot2_f32_bf16(pr, ones, sumr, false);
+              }
+#else                      // pairs bit-cast out of the packed dwords: hipcc 7.2 feeds all four v_dot2c of a piece the SAME register
 #pragma unroll
               for (int q = 0; q < 4; ++q) sumr = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w[q]), ones, sumr, false);
+#endif
 #else
 #pragma unroll
               for (int q = 0; q < 4; ++q) sumr += __uint_as_float(w[q] << 16) + __uint_as_float(w[q] & 0xffff0000u);

@@ -11,7 +11,9 @@ F="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -fno-slp-vectorize"
 case "$1" in
   deep)  D=-DTCAR_FIX_X3_DEEP=1; SRC="gemm_f32" ;;
   bwdhi) D=-DTCAR_FIX_BWD_SMALL_HI=1; SRC="gemm_f32 step" ;;
-  dot2)  D=-DTCAR_DIAG_DOT2=1; SRC="gemm_bf16" ;;                  # the logits epilogue's rounded sum through v_dot2c_f32_bf16 (WRONG sums in the step)       # session-side backward GEMMs on plain bf16 operands (hi-only backward precision)
+  dot2)  D=-DTCAR_DIAG_DOT2=1; SRC="gemm_bf16" ;;
+  dot2b) D=-DTCAR_DIAG_DOT2=2; SRC="gemm_bf16" ;;
+  dot2c) D=-DTCAR_DIAG_DOT2=3; SRC="gemm_bf16" ;;                  # ... with the pairs taken from the vector's elements instead of a bit cast                  # ... behind a workgroup barrier: no wave's MFMAs beside another wave's epilogue                  # the logits epilogue's rounded sum through v_dot2c_f32_bf16 (WRONG sums in the step)       # session-side backward GEMMs on plain bf16 operands (hi-only backward precision)
   *)     D=-DTCAR_FIX_X3_ONESHOT=100; SRC="gemm_f32" ;;
 esac
 objs=$(ls $C/*.o)

@@ -1,9 +1,9 @@
-// v_dot2c_f32_bf16 beside MFMAs (round 6).  In the logits GEMM's epilogue `sum = dot2c(packed bf16 pair, (1, 1), sum)` gave the right sums
-// with the GEMM alone and WRONG ones in the step (docs/EXPERIMENTS.md, the gfx950 erratum).  This is the bare instruction, exact by
-// construction — eight pairs of small dyadic values per chain, every partial sum representable in fp32 whatever the rounding order —,
-// checked bit for bit against scalar adds, alone and beside a dense v_mfma_f32_32x32x16_bf16 loop on a second stream, in three
-// victim shapes: plain chains, chains with 200 accumulator registers alive (the epilogue's pressure), and the literal-constant form the
-// compiler emitted there (v_dot2c_f32_bf16_e32 v, 0x3f803f80, v).
+// v_dot2c_f32_bf16 beside MFMAs (round 6).  In the logits GEMM's epilogue `sum = dot2c(packed bf16 pair, (1, 1), sum)` gave wrong sums; this
+// is the bare instruction, exact by construction — eight pairs of small dyadic values per chain, every partial sum representable in
+// fp32 whatever the rounding order —, checked bit for bit against scalar adds, alone and beside a dense v_mfma_f32_32x32x16_bf16 loop
+// on a second stream, in three victim shapes: plain chains, chains with 200 accumulator registers alive (the epilogue's pressure), and the
+// literal-constant form the compiler emitted there (v_dot2c_f32_bf16_e32 v, 0x3f803f80, v).  Result: 0 wrong — the instruction is fine; the
+// kernel's wrong sums were a hipcc miscompile of the bit-cast operand (docs/EXPERIMENTS.md, profiles/r06_dot2c_in_step.txt).
 //   hipcc --offload-arch=gfx950 -O3 -o dot2c_mfma dot2c_mfma.hip ; ./dot2c_mfma [seconds per cell]
 #include <hip/hip_runtime.h>
 #include <cstdio>
